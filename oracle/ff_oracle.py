@@ -1,0 +1,380 @@
+"""CPU oracle: a NumPy restatement of the filter_functions hot path.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module, and only as the checker / the timed CPU baseline.  The product
+package ``filter_functions_amd`` never imports it and has no CPU fallback.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function
+here against fixtures generated from the upstream reference itself
+(``oracle/make_golden.py``, run in the build container against
+/root/reference) and against the reference's own golden vector
+(tests/test_precision.py:510-529 ``ref_infids``, atol 1e-12) and closed-form
+dynamical-decoupling filter functions (filter_functions/analytic.py:59-88).
+
+Every function cites the reference ``file:line`` (relative to /root/reference)
+whose arithmetic it follows.  The algorithm is deliberately the reference's own
+(per-segment loop, ``exp(ix)-1 = -2 sin^2(x/2) + i sin x``, Liouville-space
+contraction with the generated integral), so that it doubles as the same-box
+CPU baseline ("port") next to the GPU measurement.
+
+All arrays are C-contiguous float64 / complex128.
+"""
+from itertools import product
+
+import numpy as np
+
+__all__ = [
+    'paulis', 'basis_pauli', 'basis_ggm', 'basis_expand', 'ggm_expand', 'cexp', 'cexpm1',
+    'integrate', 'get_sample_frequencies', 'hamiltonian', 'diagonalize',
+    'first_order_integral', 'control_matrix_from_scratch', 'noise_operators_from_scratch',
+    'filter_function', 'liouville_representation', 'parse_spectrum', 'infidelity_from_filter_function',
+    'pauli_labels', 'equivalent_pauli_basis_elements', 'remap_pauli_basis_elements',
+    'control_matrix_from_atomic',
+]
+
+# --------------------------------------------------------------------------------------
+# Basis construction and indexing (bit-exact contract)
+# --------------------------------------------------------------------------------------
+
+#: Identity and Pauli matrices, filter_functions/util.py:109-118
+paulis = np.array([[[1, 0], [0, 1]],
+                   [[0, 1], [1, 0]],
+                   [[0, -1j], [1j, 0]],
+                   [[1, 0], [0, -1]]], dtype=complex)
+
+
+def pauli_labels(n):
+    """Labels in element order, filter_functions/basis.py:425-426."""
+    return [''.join(t) for t in product('IXYZ', repeat=n)]
+
+
+def basis_pauli(n):
+    """n-qubit Pauli basis, shape (4**n, 2**n, 2**n).
+
+    Element order is that of ``np.indices((4,)*n)``: last qubit fastest
+    (filter_functions/basis.py:393-426).  Normalised by sqrt(2**n).
+    """
+    d = 2**n
+    out = np.empty((4**n, d, d), dtype=complex)
+    for flat, combo in enumerate(product(range(4), repeat=n)):
+        elem = np.ones((1, 1), dtype=complex)
+        for c in combo:
+            elem = np.kron(elem, paulis[c])
+        out[flat] = elem
+    out /= np.sqrt(2**n)
+    return out
+
+
+def _ggm_offdiag_indices(d):
+    """Row-major enumeration of the strict upper triangle (j < k),
+    filter_functions/basis.py:460-467."""
+    j = [a for a in range(d - 1) for _ in range(d - 1 - a)]
+    k = [b for a in range(d - 1) for b in range(a + 1, d)]
+    return np.array(j, dtype=int), np.array(k, dtype=int)
+
+
+def basis_ggm(d):
+    """Generalised Gell-Mann basis, shape (d**2, d, d).
+
+    Order: identity/sqrt(d); n_sym symmetric; n_sym antisymmetric (-i at (j,k),
+    +i at (k,j)); d-1 diagonal (filter_functions/basis.py:428-489).
+    """
+    n_sym = d*(d - 1)//2
+    j, k = _ggm_offdiag_indices(d)
+    inv_sqrt2 = 1/np.sqrt(2)
+    lam = np.zeros((d*d, d, d), dtype=complex)
+    lam[0] = np.eye(d)/np.sqrt(d)
+    for s in range(n_sym):
+        lam[1 + s, j[s], k[s]] = inv_sqrt2
+        lam[1 + s, k[s], j[s]] = inv_sqrt2
+        lam[1 + n_sym + s, j[s], k[s]] = -1j*inv_sqrt2
+        lam[1 + n_sym + s, k[s], j[s]] = 1j*inv_sqrt2
+    for l in range(1, d):
+        elem = lam[2*n_sym + l]
+        for i in range(l):
+            elem[i, i] = 1
+        elem[l, l] = -l
+        # basis.py:484-486 divides the diagonal by sqrt(l (l+1))
+        elem[range(d), range(d)] /= np.sqrt(l*(l + 1))
+    return lam
+
+
+def basis_expand(M, basis, hermitian=False):
+    """c_j = tr(M C_j) for a normalised basis, filter_functions/basis.py:650-698."""
+    coeffs = np.tensordot(M, basis, axes=[(-2, -1), (-1, -2)])
+    return coeffs.real if hermitian else coeffs
+
+
+def ggm_expand(M, hermitian=False):
+    """Closed-form GGM expansion, filter_functions/basis.py:701-787."""
+    M = np.asarray(M)
+    d = M.shape[-1]
+    n_sym = d*(d - 1)//2
+    j, k = _ggm_offdiag_indices(d)
+    cast = (lambda a: a.real) if hermitian else (lambda a: a)
+    coeffs = np.zeros(M.shape[:-2] + (d*d,), dtype=float if hermitian else complex)
+    coeffs[..., 0] = cast(np.trace(M, axis1=-2, axis2=-1))/np.sqrt(d)
+    up = M[..., j, k]
+    lo = M[..., k, j]
+    coeffs[..., 1:1 + n_sym] = cast(up + lo)/np.sqrt(2)
+    coeffs[..., 1 + n_sym:1 + 2*n_sym] = cast(1j*(up - lo))/np.sqrt(2)
+    diag = np.diagonal(M, axis1=-2, axis2=-1)
+    l = np.arange(1, d)
+    coeffs[..., 1 + 2*n_sym:] = cast(np.cumsum(diag[..., :-1], axis=-1) - l*diag[..., 1:])
+    coeffs[..., 1 + 2*n_sym:] /= np.sqrt(l*(l + 1))
+    return coeffs
+
+
+def equivalent_pauli_basis_elements(idx, N):
+    """filter_functions/basis.py:790-800."""
+    idx = [idx] if isinstance(idx, int) else list(idx)
+    grids = np.ix_(*[range(4) if i in idx else [0] for i in range(N)])
+    return np.ravel_multi_index(grids, [4]*N).ravel()
+
+
+def remap_pauli_basis_elements(order, N):
+    """filter_functions/basis.py:803-815."""
+    tuples = np.indices((4,)*N).reshape(N, 4**N).T
+    return np.array([np.ravel_multi_index([tup[i] for i in order], (4,)*N) for tup in tuples])
+
+
+# --------------------------------------------------------------------------------------
+# Small numeric helpers
+# --------------------------------------------------------------------------------------
+
+def cexp(x):
+    """exp(ix) as cos + i sin, filter_functions/util.py:136-162."""
+    x = np.asarray(x, dtype=float)
+    out = np.empty(x.shape, dtype=complex)
+    out.real = np.cos(x)
+    out.imag = np.sin(x)
+    return out
+
+
+def cexpm1(x):
+    """exp(ix) - 1 = -2 sin^2(x/2) + i sin(x), filter_functions/util.py:165-182."""
+    x = np.asarray(x, dtype=float)
+    out = np.empty(x.shape, dtype=complex)
+    half = np.sin(x/2)
+    out.real = -2*np.square(half)
+    out.imag = np.sin(x)
+    return out
+
+
+def integrate(f, x):
+    """Trapezoid over the last axis, filter_functions/util.py:880-906:
+    sum((f[1:] + f[:-1]) * diff(x)) / 2."""
+    dx = np.diff(x)
+    ret = f[..., 1:] + f[..., :-1]
+    ret = ret*dx
+    return ret.sum(axis=-1)/2
+
+
+def get_sample_frequencies(tau, dt, n_samples=300, spacing='log', include_quasistatic=False,
+                           omega_min=None, omega_max=None):
+    """filter_functions/util.py:1054-1093."""
+    if omega_min is None:
+        omega_min = 2*np.pi*1e-2/tau
+    if omega_max is None:
+        omega_max = 2*np.pi*1e+1/np.min(dt)
+    if spacing == 'linear':
+        xspace = np.linspace
+    else:
+        xspace = np.geomspace
+    if include_quasistatic:
+        return np.insert(xspace(omega_min, omega_max, n_samples - 1), 0, 0)
+    return xspace(omega_min, omega_max, n_samples)
+
+
+# --------------------------------------------------------------------------------------
+# The hot path
+# --------------------------------------------------------------------------------------
+
+def hamiltonian(c_opers, c_coeffs):
+    """H_g = sum_i a_i(g) A_i, filter_functions/pulse_sequence.py:582."""
+    return np.einsum('ijk,il->ljk', c_opers, c_coeffs)
+
+
+def diagonalize(H, dt):
+    """Eigen-decomposition, segment propagators and cumulative propagators.
+
+    filter_functions/numeric.py:1886-1935: ``eigh`` (lower triangle, ascending),
+    P_g = V_g exp(-i D_g dt_g) V_g^dag (:1928), Q = [1, P_0, P_1 P_0, ...]
+    accumulated left-to-right in segment order (:1933, util.py:868-877).
+    """
+    H = np.asarray(H)
+    dt = np.asarray(dt, dtype=float)
+    G, d, _ = H.shape
+    eigvals, eigvecs = np.linalg.eigh(H)
+    phases = cexp(-dt[:, None]*eigvals)                       # (G, d)
+    P = (eigvecs*phases[:, None, :]) @ eigvecs.conj().transpose(0, 2, 1)
+    Q = np.empty((G + 1, d, d), dtype=complex)
+    Q[0] = np.identity(d)
+    for g in range(G):
+        Q[g + 1] = P[g] @ Q[g]
+    return eigvals, eigvecs, Q
+
+
+def first_order_integral(omega, eigvals_g, dt_g):
+    """I[o,m,n] = (exp(i x dt) - 1)/(i x), x = omega_o + D_m - D_n; dt where x == 0.
+
+    filter_functions/numeric.py:144-167 (argument (omega + dE)*dt, exact x != 0
+    mask) with util.cexpm1 (util.py:165-182).
+    """
+    dE = np.subtract.outer(eigvals_g, eigvals_g)              # dE[m,n] = D_m - D_n
+    x = np.add.outer(np.asarray(omega, dtype=float), dE)      # (W, d, d)
+    mask = x != 0
+    out = np.full(x.shape, dt_g, dtype=complex)
+    num = cexpm1(x[mask]*dt_g)
+    out[mask] = num/(1j*x[mask])
+    return out
+
+
+def _prologue(eigvals, eigvecs, propagators, n_opers, n_coeffs):
+    """Q_{g}^dag V_g (numeric.py:93-95, :818) and s_a(g) V_g^dag B_a V_g
+    (numeric.py:98-141, :819)."""
+    n_opers = np.asarray(n_opers)
+    n_coeffs = np.asarray(n_coeffs, dtype=float)
+    QdV = propagators[:-1].conj().transpose(0, 2, 1) @ eigvecs              # (G,d,d)
+    Vd = eigvecs.conj().transpose(0, 2, 1)
+    Bbar = Vd[None] @ (n_opers[:, None] @ eigvecs[None])                   # (A,G,d,d)
+    Bbar = Bbar*n_coeffs[:, :, None, None]
+    return QdV, Bbar
+
+
+def control_matrix_from_scratch(eigvals, eigvecs, propagators, omega, basis, n_opers, n_coeffs,
+                                dt, t=None, cache_intermediates=False):
+    """R[a,k,o] = sum_g e^{i w_o t_g} sum_mn Bbar^{(g)}_{a,mn} I^{(g)}_{o,mn} Cbar^{(g)}_{k,nm}.
+
+    filter_functions/numeric.py:707-881.  The einsum 'o,jmn,omn,knm->jko' (:843) is
+    restated as the (A N x d^2)(d^2 x W) product it is, segment by segment, with
+    the phase factor exp(i omega t_g) (:865) applied to the generated integral.
+    """
+    dt = np.asarray(dt, dtype=float)
+    omega = np.asarray(omega, dtype=float)
+    basis = np.asarray(basis)
+    if t is None:
+        t = np.concatenate(([0.0], dt.cumsum()))
+    G, d = eigvals.shape
+    A = len(n_opers)
+    N = len(basis)
+    W = len(omega)
+    QdV, Bbar = _prologue(eigvals, eigvecs, propagators, n_opers, n_coeffs)
+
+    R = np.zeros((A, N, W), dtype=complex)
+    if cache_intermediates:
+        basis_cache = np.empty((G, N, d, d), dtype=complex)
+        phase_cache = np.empty((G, W), dtype=complex)
+        int_cache = np.empty((G, W, d, d), dtype=complex)
+        step_cache = np.empty((G, A, N, W), dtype=complex)
+        cumulative_cache = np.zeros((max(G - 1, 0), A, N, W), dtype=complex)
+    for g in range(G):
+        if cache_intermediates and g > 0:
+            cumulative_cache[g - 1] = R
+        Cbar = QdV[g].conj().T @ basis @ QdV[g]                 # (N,d,d), numeric.py:863-864
+        phase = cexp(omega*t[g])                                # numeric.py:865
+        integral = first_order_integral(omega, eigvals[g], dt[g])   # (W,d,d)
+        # M[(a,k),(m,n)] = Bbar[a,m,n] * Cbar[k,n,m]
+        M = (Bbar[:, g, None, :, :]*Cbar.transpose(0, 2, 1)[None]).reshape(A*N, d*d)
+        step = (M @ (integral.reshape(W, d*d)*phase[:, None]).T).reshape(A, N, W)
+        R += step
+        if cache_intermediates:
+            basis_cache[g] = Cbar
+            phase_cache[g] = phase
+            int_cache[g] = integral
+            step_cache[g] = step
+    if cache_intermediates:
+        return R, dict(n_opers_transformed=Bbar, eigvecs_propagated=QdV,
+                       basis_transformed=basis_cache, phase_factors=phase_cache,
+                       first_order_integral=int_cache, control_matrix_step=step_cache,
+                       control_matrix_step_cumulative=cumulative_cache)
+    return R
+
+
+def noise_operators_from_scratch(eigvals, eigvecs, propagators, omega, n_opers, n_coeffs, dt,
+                                 t=None):
+    """Hilbert-space twin, result (W, A, d, d).
+
+    filter_functions/numeric.py:456-618:
+    B~_a(w) = sum_g e^{i w t_g} P_g^dag [Bbar_a^{(g)} o I^{(g)}(w)] P_g, P_g = V_g^dag Q_g
+    (:577 swaps the argument order of _propagate_eigenvectors).
+    """
+    dt = np.asarray(dt, dtype=float)
+    omega = np.asarray(omega, dtype=float)
+    if t is None:
+        t = np.concatenate(([0.0], dt.cumsum()))
+    G, d = eigvals.shape
+    A = len(n_opers)
+    W = len(omega)
+    _, Bbar = _prologue(eigvals, eigvecs, propagators, n_opers, n_coeffs)
+    P = eigvecs.conj().transpose(0, 2, 1) @ propagators[:-1]       # (G,d,d)
+    out = np.zeros((W, A, d, d), dtype=complex)
+    for g in range(G):
+        phase = cexp(omega*t[g])
+        integral = first_order_integral(omega, eigvals[g], dt[g])*phase[:, None, None]
+        X = Bbar[None, :, g]*integral[:, None]                     # (W,A,d,d)
+        out += P[g].conj().T @ X @ P[g]
+    return out
+
+
+def filter_function(R, which='fidelity'):
+    """F[a,b,o] = sum_k conj(R[a,k,o]) R[b,k,o]  (numeric.py:1461-1467)."""
+    if which == 'fidelity':
+        return np.einsum('ako,bko->abo', R.conj(), R)
+    return np.einsum('ako,blo->abklo', R.conj(), R)
+
+
+def liouville_representation(U, basis):
+    """L[i,j] = tr(U^dag C_i U C_j); real part if the basis is Hermitian.
+
+    filter_functions/superoperator.py:51-84 followed by Basis.expand
+    (basis.py:650-698).
+    """
+    U = np.asarray(U)
+    basis = np.asarray(basis)
+    conj_basis = np.einsum('...ba,ibc,...cd->...iad', U.conj(), basis, U)
+    L = np.tensordot(conj_basis, basis, axes=[(-2, -1), (-1, -2)])
+    herm = np.allclose(basis, basis.conj().transpose(0, 2, 1),
+                       atol=np.finfo(complex).eps*basis.shape[-1]**3, rtol=0)
+    return L.real if herm else L
+
+
+def parse_spectrum(spectrum, omega, idx):
+    """Broadcast/validate the spectrum, filter_functions/util.py:214-227."""
+    spectrum = np.asarray(spectrum)
+    shape = (len(idx),)*(spectrum.ndim - 1) + (len(omega),)
+    try:
+        spectrum = np.broadcast_to(spectrum, shape)
+    except ValueError as err:
+        raise ValueError(f'Spectrum should be of shape {shape}, not {spectrum.shape}.') from err
+    if spectrum.ndim == 3 and not np.allclose(spectrum, spectrum.conj().swapaxes(0, 1)):
+        raise ValueError('Cross-spectra given but not Hermitian along first two axes')
+    if spectrum.ndim > 3:
+        raise ValueError(f'Expected spectrum to have < 4 dimensions, not {spectrum.ndim}')
+    return spectrum
+
+
+def infidelity_from_filter_function(F, spectrum, omega, idx, d):
+    """(1/2 pi d) int S F dw, filter_functions/numeric.py:323-325, 351-352, 374, 2318-2320."""
+    omega = np.asarray(omega, dtype=float)
+    idx = np.asarray(idx)
+    spectrum = parse_spectrum(spectrum, omega, idx)
+    if spectrum.ndim in (1, 2):
+        integrand = F[idx, idx, :]*spectrum
+    else:
+        integrand = F[idx[:, None], idx, :]*spectrum
+    return integrate(integrand.real, omega)/(2*np.pi*d)
+
+
+def control_matrix_from_atomic(phases, R_atomic, Q_liouville, which='total'):
+    """R = sum_g e^{i w t_{g-1}} R^{(g)} Q^{(g-1)}  (numeric.py:621-704)."""
+    G = len(R_atomic)
+    steps = np.empty((G,) + R_atomic[0].shape, dtype=complex)
+    steps[0] = R_atomic[0]
+    for g in range(1, G):
+        # (A,N,W) -> contraction over the basis index with Q^{(g-1)} (N,N)
+        steps[g] = np.einsum('o,ako,kl->alo', phases[g - 1], R_atomic[g], Q_liouville[g - 1])
+    if which == 'correlations':
+        return steps
+    return steps.sum(axis=0)

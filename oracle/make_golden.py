@@ -1,0 +1,339 @@
+"""Generate the committed golden fixtures under tests/golden/ from the upstream reference.
+
+TEST INFRASTRUCTURE.  Runs ONLY in the build container, where the reference is
+mounted read-only at /root/reference; the reference never travels to the GPU
+box, the ``.npz`` files written here do (they are data: inputs and the
+reference's outputs on them).
+
+    PYTHONPATH=oracle/shim:/root/reference python oracle/make_golden.py
+
+The shim packages under oracle/shim stand in for ``opt_einsum`` and ``sparse``
+(absent from the image).  With them the reference's own suite
+passes here (97 passed / 5 qutip-skipped), including the 1e-12 golden
+``test_infidelity``.
+"""
+import hashlib
+import os
+import string
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'shim'))
+sys.path.insert(1, '/root/reference')
+
+import filter_functions as ff  # noqa: E402
+from filter_functions import analytic, numeric, util  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+# ---- workload generators (same recipes as the reference's tests/testutil.py:131-190, written
+# ---- against the public API; they only produce INPUT data) -----------------------------------
+def rand_herm_traceless(d, n, rng):
+    A = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+    A = (A + A.conj().transpose(0, 2, 1))/2
+    A = A.transpose()
+    A -= A.trace(axis1=0, axis2=1)/d
+    return A.transpose()
+
+
+def rand_pulse(d, n_dt, n_cops, n_nops, btype, rng):
+    c_opers = rand_herm_traceless(d, n_cops, rng)
+    n_opers = rand_herm_traceless(d, n_nops, rng)
+    c_coeffs = rng.standard_normal((n_cops, n_dt))
+    n_coeffs = rng.random((n_nops, n_dt))
+    letters = np.array(list(string.ascii_letters))
+    c_ids = rng.choice(letters, n_cops, replace=False)
+    n_ids = rng.choice(letters, n_nops, replace=False)
+    dt = 1 - rng.random(n_dt)
+    basis = ff.Basis.ggm(d) if btype == 'GGM' else ff.Basis.pauli(int(np.log2(d)))
+    return ff.PulseSequence(list(zip(c_opers, c_coeffs, c_ids)),
+                            list(zip(n_opers, n_coeffs, n_ids)), dt, basis)
+
+
+def pulse_inputs(pulse):
+    return dict(c_opers=pulse.c_opers, c_coeffs=pulse.c_coeffs,
+                c_oper_identifiers=pulse.c_oper_identifiers.astype('U8'),
+                n_opers=pulse.n_opers, n_coeffs=pulse.n_coeffs,
+                n_oper_identifiers=pulse.n_oper_identifiers.astype('U8'),
+                dt=pulse.dt, basis=np.asarray(pulse.basis), btype=np.array(pulse.basis.btype))
+
+
+def full_path_outputs(pulse, omega, spectra=True, intermediates=True, prefix=''):
+    """Everything the hot path produces for (pulse, omega), straight from the reference."""
+    out = {}
+    H = np.einsum('ijk,il->ljk', pulse.c_opers, pulse.c_coeffs)
+    D, V, Q = numeric.diagonalize(H, pulse.dt)
+    out['H'] = H
+    out['eigvals'], out['eigvecs'], out['propagators'] = D, V, Q
+    t = np.concatenate(([0], pulse.dt.cumsum()))
+    out['t'] = t
+    if intermediates:
+        R, inter = numeric.calculate_control_matrix_from_scratch(
+            D, V, Q, omega, pulse.basis, pulse.n_opers, pulse.n_coeffs, pulse.dt, t,
+            cache_intermediates=True)
+        # control_matrix_step_cumulative is cumsum(control_matrix_step)[:-1] (numeric.py:856-861);
+        # it is checked by reconstruction and not stored, to keep the fixtures small.
+        for key in ('n_opers_transformed', 'eigvecs_propagated', 'basis_transformed',
+                    'phase_factors', 'first_order_integral', 'control_matrix_step'):
+            out['inter_' + key] = inter[key]
+    else:
+        R = numeric.calculate_control_matrix_from_scratch(
+            D, V, Q, omega, pulse.basis, pulse.n_opers, pulse.n_coeffs, pulse.dt, t)
+    out['control_matrix'] = R
+    out['noise_operators'] = numeric.calculate_noise_operators_from_scratch(
+        D, V, Q, omega, pulse.n_opers, pulse.n_coeffs, pulse.dt, t)
+    out['filter_function'] = numeric.calculate_filter_function(R)
+    if len(pulse.basis)**2*len(pulse.n_opers)**2*len(omega)*16 < 1e6:
+        out['filter_function_gen'] = numeric.calculate_filter_function(R, 'generalized')
+    out['total_propagator_liouville'] = ff.liouville_representation(Q[-1], pulse.basis)
+    # getters on a fresh copy (exercises the caching front-end of the reference)
+    out['get_filter_function'] = pulse.get_filter_function(omega)
+    if spectra:
+        A = len(pulse.n_opers)
+        rng = np.random.default_rng(99)
+        w = np.abs(omega) + 1e-3
+        S1 = 1e-3/w
+        S2 = np.array([(a + 1)*1e-3/w**(0.5 + 0.1*a) for a in range(A)])
+        X = rng.standard_normal((A, A, len(omega))) + 1j*rng.standard_normal((A, A, len(omega)))
+        S3 = np.einsum('abo,cbo->aco', X, X.conj())*1e-3
+        out['S1'], out['S2'], out['S3'] = S1, S2, S3
+        for name, S in (('S1', S1), ('S2', S2), ('S3', S3)):
+            out['infidelity_' + name] = ff.infidelity(pulse, S, omega)
+        if A > 1:
+            ids = pulse.n_oper_identifiers[[A - 1, 0]]
+            out['subset_identifiers'] = ids.astype('U8')
+            out['infidelity_S1_subset'] = ff.infidelity(pulse, S1, omega, n_oper_identifiers=ids)
+            out['infidelity_S3_subset'] = ff.infidelity(pulse, S3[np.ix_([A - 1, 0], [A - 1, 0])],
+                                                        omega, n_oper_identifiers=ids)
+    return {prefix + k: v for k, v in out.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'{name}: {os.path.getsize(path)/1024:.1f} KiB, {len(arrays)} arrays')
+
+
+def main():
+    X, Y, Z = util.paulis[1:]
+
+    # 1. README Hadamard (config 1) --------------------------------------------------------
+    def hadamard():
+        return ff.PulseSequence([[X/2, [0, np.pi], 'X'], [Y/2, [np.pi/2, 0], 'Y']],
+                                [[Z/2, [1, 1], 'Z']], [1, 1])
+    p = hadamard()
+    omega = util.get_sample_frequencies(p, n_samples=200)
+    arrays = pulse_inputs(p)
+    arrays['omega'] = omega
+    arrays['omega_default'] = util.get_sample_frequencies(hadamard())
+    arrays.update(full_path_outputs(p, omega, spectra=False))
+    arrays['spectrum'] = 1e-2/omega
+    arrays['infidelity'] = ff.infidelity(p, 1e-2/omega, omega)
+    save('hadamard', **arrays)
+
+    # 2. the reference's own seeded golden vector (tests/test_precision.py:495-551) -------
+    rng = np.random.default_rng(seed=123456789)
+    arrays = {}
+    ref_infids = [
+        [2.1571674053883583, 2.1235628100639845],
+        [1.7951695420688032, 2.919850951578396],
+        [0.4327173760925169, 0.817672660809546],
+        [2.1571674053883583, 2.919850951578396],
+        [[1.7951695420688032, -1.1595479985471822], [-1.1595479985471822, 2.919850951578396]],
+        [0.8247284959004152, 2.495561429509174],
+        [0.854760904366362, 3.781670732974073],
+        [0.24181791977082442, 1.122626106375816],
+        [0.8247284959004152, 3.781670732974073],
+        [[0.854760904366362, -0.16574972846239408], [-0.16574972846239408, 3.781670732974073]],
+        [2.9464977186365267, 0.8622319594213088],
+        [2.8391133843027525, 0.678843575761492],
+        [0.813728718501677, 0.16950739577216872],
+        [2.9464977186365267, 0.678843575761492],
+        [[2.8391133843027525, 0.2725782717379744], [0.2725782717379744, 0.678843575761492]]]
+    count = 0
+    omega = np.geomspace(0.1, 10, 51)
+    arrays['omega'] = omega
+    for d in (2, 3, 4):
+        pulse = rand_pulse(d, 10, 2, 3, 'GGM', rng)
+        # the reference test relabels only the first two of the three noise operators
+        # (tests/test_precision.py:534), so ['B_0', 'B_2'] selects operator indices [0, 1]
+        pulse.n_oper_identifiers = np.array(['B_0', 'B_2'])
+        S0 = np.abs(rng.standard_normal())
+        for k, v in pulse_inputs(pulse).items():
+            arrays[f'd{d}_{k}'] = v
+        arrays[f'd{d}_idx'] = np.array([0, 1])
+        arrays[f'd{d}_S0'] = S0
+        w = np.abs(omega)
+        spectra = [S0*w**0, S0/w**0.7, S0*np.exp(-w), np.array([S0*w**0, S0/w**0.7]),
+                   np.array([[S0/w**0.7, S0/(1 + omega**2) + 1j*S0*omega],
+                             [S0/(1 + omega**2) - 1j*S0*omega, S0/w**0.7]])]
+        for s, S in enumerate(spectra):
+            got = ff.infidelity(pulse, S, omega, n_oper_identifiers=['B_0', 'B_2'])
+            assert np.allclose(got, ref_infids[count], atol=1e-12, rtol=0), (d, s)
+            arrays[f'd{d}_S{s}'] = S
+            arrays[f'd{d}_ref_infid{s}'] = np.array(ref_infids[count])
+            count += 1
+    save('test_infidelity', **arrays)
+
+    # 3./4. random pulses: small versions of configs 2 and 4, plus edge cases --------------
+    def two_sided(tau, dt, n):
+        w = np.geomspace(1e-2/tau, 1e2/dt.min(), n)
+        return np.concatenate([-w[::-1][:n//4], [0.0, 1e-10], w])
+
+    for name, (d, G, ncop, nnop, btype, seed, W) in {
+            'rand_d2_ggm': (2, 7, 2, 2, 'GGM', 1, 40),
+            'rand_d3_ggm': (3, 9, 3, 2, 'GGM', 2, 24),
+            'rand_d4_pauli': (4, 10, 3, 3, 'Pauli', 3, 32),
+            'rand_d4_ggm': (4, 10, 3, 3, 'GGM', 4, 32),
+            'rand_d5_ggm': (5, 6, 2, 4, 'GGM', 7, 16),
+            'rand_d8_pauli': (8, 12, 3, 4, 'Pauli', 5, 24),
+            'rand_d16_ggm': (16, 5, 4, 3, 'GGM', 6, 8),
+    }.items():
+        rng = np.random.default_rng(seed)
+        pulse = rand_pulse(d, G, ncop, nnop, btype, rng)
+        omega = two_sided(pulse.tau, pulse.dt, W)
+        arrays = pulse_inputs(pulse)
+        arrays['omega'] = omega
+        arrays.update(full_path_outputs(pulse, omega, intermediates=(d <= 4)))
+        save(name, **arrays)
+
+    # edge: a zero-Hamiltonian segment, exactly degenerate eigenvalues, single segment ------
+    rng = np.random.default_rng(11)
+    pulse = rand_pulse(4, 6, 2, 2, 'Pauli', rng)
+    pulse.c_coeffs[:, 2] = 0                       # identity gate segment (RB idle)
+    pulse.c_opers[0] = np.kron(Z, np.eye(2))/2     # doubly degenerate spectrum
+    pulse.c_coeffs[1, 4] = 0                       # segment 4 driven by c_opers[0] only
+    omega = two_sided(pulse.tau, pulse.dt, 32)
+    arrays = pulse_inputs(pulse)
+    arrays['omega'] = omega
+    arrays.update(full_path_outputs(pulse, omega))
+    save('edge_degenerate_d4', **arrays)
+
+    rng = np.random.default_rng(12)
+    pulse = rand_pulse(2, 1, 1, 1, 'GGM', rng)
+    omega = two_sided(pulse.tau, pulse.dt, 16)
+    arrays = pulse_inputs(pulse)
+    arrays['omega'] = omega
+    arrays.update(full_path_outputs(pulse, omega))
+    save('edge_single_segment_d2', **arrays)
+
+    # config 2 at reduced size but full recipe (seed 42, Pauli) – medium-size parity case ---
+    rng = np.random.default_rng(42)
+    pulse = rand_pulse(4, 64, 3, 3, 'Pauli', rng)
+    omega = np.geomspace(1e-2/pulse.tau, 1e2/pulse.dt.min(), 256)
+    arrays = pulse_inputs(pulse)
+    arrays['omega'] = omega
+    res = full_path_outputs(pulse, omega, intermediates=False)
+    res.pop('filter_function_gen', None)
+    arrays.update(res)
+    save('cfg2_small', **arrays)
+
+    # 5. dynamical decoupling: inputs + closed forms (analytic.py:59-88) -------------------
+    sys.path.insert(0, '/root/reference/tests')
+    import testutil  # noqa: E402  (reference test helper, used here only to build INPUT data)
+    arrays = {}
+    omega = np.logspace(0, 3, 100)
+    omega = np.concatenate([-omega[::-1], omega])
+    arrays['omega'] = omega
+    for dd, n in (('cpmg', 6), ('udd', 6), ('pdd', 6), ('cdd', 3), ('cpmg', 1)):
+        H_c, dt = testutil.generate_dd_hamiltonian(n, tau=np.pi, tau_pi=1e-9, dd_type=dd)
+        key = f'{dd}{n}'
+        arrays[key + '_c_coeffs'] = np.asarray(H_c[0][1], dtype=float)
+        arrays[key + '_dt'] = dt
+        fn = {'cpmg': analytic.CPMG, 'udd': analytic.UDD, 'pdd': analytic.PDD,
+              'cdd': analytic.CDD}[dd]
+        arrays[key + '_analytic'] = fn(omega*np.pi, n)
+        p = ff.PulseSequence(H_c, [[Z/2, np.ones_like(dt)]], dt)
+        arrays[key + '_F'] = p.get_filter_function(omega)[0, 0]
+    save('dynamical_decoupling', **arrays)
+
+    # 6. Liouville representation ----------------------------------------------------------
+    arrays = {}
+    rng = np.random.default_rng(21)
+    for d, basis, tag in ((2, ff.Basis.pauli(1), 'd2_pauli'), (3, ff.Basis.ggm(3), 'd3_ggm'),
+                          (4, ff.Basis.pauli(2), 'd4_pauli'), (4, ff.Basis.ggm(4), 'd4_ggm'),
+                          (8, ff.Basis.pauli(3), 'd8_pauli'), (16, ff.Basis.ggm(16), 'd16_ggm')):
+        U = testutil.rand_unit(d, 3 if d < 16 else 1, local_rng=rng)
+        arrays[tag + '_U'] = U
+        arrays[tag + '_basis'] = np.asarray(basis)
+        arrays[tag + '_L'] = ff.liouville_representation(U, basis)
+    # non-Hermitian basis -> complex result
+    nb = np.asarray(ff.Basis.ggm(3)).copy()
+    nb[1], nb[2] = (nb[1] + 1j*nb[4])/np.sqrt(2), (nb[1] - 1j*nb[4])/np.sqrt(2)
+    nb = ff.Basis(nb)
+    U = testutil.rand_unit(3, 2, local_rng=rng)
+    arrays['d3_nonherm_U'] = U
+    arrays['d3_nonherm_basis'] = np.asarray(nb)
+    arrays['d3_nonherm_L'] = ff.liouville_representation(U, nb)
+    save('liouville', **arrays)
+
+    # 7. bases: arrays + labels, bit-exact ------------------------------------------------
+    arrays = {}
+    for n in (1, 2, 3):
+        b = ff.Basis.pauli(n)
+        arrays[f'pauli{n}'] = np.asarray(b)
+        arrays[f'pauli{n}_labels'] = np.array(b.labels)
+    for d in range(2, 9):
+        b = ff.Basis.ggm(d)
+        arrays[f'ggm{d}'] = np.asarray(b)
+        arrays[f'ggm{d}_labels'] = np.array(b.labels)
+    # hashes of the value-normalised arrays (x + 0.0 maps -0.0 to +0.0: tensor products of
+    # Paulis produce signed zeros whose sign depends on the multiplication order only)
+    arrays['pauli4_sha256'] = np.array(hashlib.sha256(
+        np.ascontiguousarray(np.asarray(ff.Basis.pauli(4)) + 0.0).tobytes()).hexdigest())
+    arrays['ggm16_sha256'] = np.array(hashlib.sha256(
+        np.ascontiguousarray(np.asarray(ff.Basis.ggm(16)) + 0.0).tobytes()).hexdigest())
+    for N in (1, 2, 3, 4):
+        for q in range(N):
+            arrays[f'equiv_N{N}_q{q}'] = ff.basis.equivalent_pauli_basis_elements(q, N)
+        if N > 1:
+            arrays[f'equiv_N{N}_q01'] = ff.basis.equivalent_pauli_basis_elements([0, 1], N)
+            order = list(range(N))[::-1]
+            arrays[f'remap_N{N}_rev'] = ff.basis.remap_pauli_basis_elements(order, N)
+    arrays['remap_N3_120'] = ff.basis.remap_pauli_basis_elements([1, 2, 0], 3)
+    rng = np.random.default_rng(5)
+    M = rng.standard_normal((3, 5, 5)) + 1j*rng.standard_normal((3, 5, 5))
+    arrays['expand_M'] = M
+    arrays['expand_ggm5'] = ff.Basis.ggm(5).expand(M)
+    Mh = M + M.conj().transpose(0, 2, 1)
+    arrays['expand_ggm5_herm'] = ff.Basis.ggm(5).expand(Mh, hermitian=True)
+    M4 = rng.standard_normal((2, 4, 4)) + 1j*rng.standard_normal((2, 4, 4))
+    arrays['expand_M4'] = M4
+    arrays['expand_pauli2'] = ff.Basis.pauli(2).expand(M4)
+    save('basis', **arrays)
+
+    # 8. concatenation rule (NEXT-1) -------------------------------------------------------
+    rng = np.random.default_rng(31)
+    pulses = [rand_pulse(4, int(rng.integers(1, 6)), 2, 3, 'Pauli', rng) for _ in range(5)]
+    for q in pulses:
+        q.n_opers = pulses[0].n_opers
+        q.n_oper_identifiers = pulses[0].n_oper_identifiers
+    omega = np.geomspace(1e-2, 1e2, 33)
+    R_atomic = np.array([q.get_control_matrix(omega) for q in pulses])
+    phases = np.array([q.get_total_phases(omega) for q in pulses]).cumprod(axis=0)[:-1]
+    L = util.adot(np.array([q.total_propagator_liouville for q in pulses]))[:-1]
+    arrays = dict(omega=omega, R_atomic=R_atomic, phases=phases, propagators_liouville=L)
+    arrays['R_total'] = numeric.calculate_control_matrix_from_atomic(phases, R_atomic, L)
+    arrays['R_correlations'] = numeric.calculate_control_matrix_from_atomic(
+        phases, R_atomic, L, which='correlations')
+    total = ff.concatenate(pulses, calc_filter_function=True, omega=omega)
+    arrays['concat_control_matrix'] = total.get_control_matrix(omega)
+    for i, q in enumerate(pulses):
+        for k, v in pulse_inputs(q).items():
+            arrays[f'p{i}_{k}'] = v
+    save('from_atomic', **arrays)
+
+    # 9. util.integrate / sample frequencies ----------------------------------------------
+    rng = np.random.default_rng(41)
+    x = np.sort(rng.random(101))*10
+    f = rng.standard_normal((3, 101)) + 1j*rng.standard_normal((3, 101))
+    save('util', x=x, f=f, integral=util.integrate(f, x),
+         cexp_in=x*1e3, cexp_out=util.cexp(x*1e3), cexpm1_out=util.cexpm1(x*1e3 - 5e3))
+
+
+if __name__ == '__main__':
+    main()

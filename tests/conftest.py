@@ -1,0 +1,36 @@
+"""pytest configuration: markers, paths and fixture loading shared by all tests."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + '.npz')) as f:
+        return {k: f[k] for k in f.files}
+
+
+@pytest.fixture
+def golden():
+    return load_golden
+
+
+def rel_err(got, ref):
+    """max|got-ref| / max|ref| -- the tolerance contract of DESIGN.md (per tensor)."""
+    got = np.asarray(got)
+    ref = np.asarray(ref)
+    scale = np.max(np.abs(ref)) if ref.size else 1.0
+    if scale == 0:
+        scale = 1.0
+    return float(np.max(np.abs(got - ref))/scale) if ref.size else 0.0

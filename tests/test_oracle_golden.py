@@ -1,0 +1,198 @@
+"""Pin the CPU oracle (oracle/ff_oracle.py) against fixtures produced by the upstream reference.
+
+CPU-only.  Tolerances follow the reference's own pins: 1e-12 for the
+seeded infidelity vector (tests/test_precision.py:541), 1e-10 for the analytic DD filter
+functions (:75-182), ~1e-13 for einsum-order differences on O(1) data, bit-exact for bases.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+import ff_oracle as orc
+from conftest import load_golden, rel_err
+
+RAND = ['rand_d2_ggm', 'rand_d3_ggm', 'rand_d4_pauli', 'rand_d4_ggm', 'rand_d5_ggm',
+        'rand_d8_pauli', 'rand_d16_ggm', 'edge_degenerate_d4', 'edge_single_segment_d2',
+        'cfg2_small', 'hadamard']
+
+
+def test_basis_bit_exact():
+    g = load_golden('basis')
+    for n in (1, 2, 3):
+        assert np.array_equal(orc.basis_pauli(n), g[f'pauli{n}'])
+        assert orc.pauli_labels(n) == list(g[f'pauli{n}_labels'])
+    for d in range(2, 9):
+        assert np.array_equal(orc.basis_ggm(d), g[f'ggm{d}'])
+    sha = hashlib.sha256(np.ascontiguousarray(orc.basis_pauli(4) + 0.0).tobytes()).hexdigest()
+    assert sha == str(g['pauli4_sha256'])
+    sha = hashlib.sha256(np.ascontiguousarray(orc.basis_ggm(16) + 0.0).tobytes()).hexdigest()
+    assert sha == str(g['ggm16_sha256'])
+    # GGM(2) and Pauli(1) are the same array
+    assert np.array_equal(orc.basis_ggm(2), orc.basis_pauli(1))
+
+
+def test_basis_index_maps_bit_exact():
+    g = load_golden('basis')
+    for N in (1, 2, 3, 4):
+        for q in range(N):
+            assert np.array_equal(orc.equivalent_pauli_basis_elements(q, N), g[f'equiv_N{N}_q{q}'])
+        if N > 1:
+            assert np.array_equal(orc.equivalent_pauli_basis_elements([0, 1], N),
+                                  g[f'equiv_N{N}_q01'])
+            assert np.array_equal(orc.remap_pauli_basis_elements(list(range(N))[::-1], N),
+                                  g[f'remap_N{N}_rev'])
+    assert np.array_equal(orc.remap_pauli_basis_elements([1, 2, 0], 3), g['remap_N3_120'])
+
+
+def test_expand():
+    g = load_golden('basis')
+    assert rel_err(orc.ggm_expand(g['expand_M']), g['expand_ggm5']) < 1e-15
+    Mh = g['expand_M'] + g['expand_M'].conj().transpose(0, 2, 1)
+    assert rel_err(orc.ggm_expand(Mh, hermitian=True), g['expand_ggm5_herm']) < 1e-15
+    assert rel_err(orc.basis_expand(g['expand_M'], orc.basis_ggm(5)), g['expand_ggm5']) < 1e-15
+    assert rel_err(orc.basis_expand(g['expand_M4'], orc.basis_pauli(2)), g['expand_pauli2']) < 1e-15
+
+
+def test_util():
+    g = load_golden('util')
+    assert np.array_equal(orc.integrate(g['f'], g['x']), g['integral'])
+    assert np.array_equal(orc.cexp(g['cexp_in']), g['cexp_out'])
+    assert np.array_equal(orc.cexpm1(g['cexp_in'] - 5e3), g['cexpm1_out'])
+
+
+@pytest.mark.parametrize('name', RAND)
+def test_diagonalize(name):
+    g = load_golden(name)
+    H = orc.hamiltonian(g['c_opers'], g['c_coeffs'])
+    assert np.array_equal(H, g['H'])
+    D, V, Q = orc.diagonalize(H, g['dt'])
+    assert rel_err(D, g['eigvals']) < 1e-14
+    assert rel_err(Q, g['propagators']) < 1e-13
+    # eigenvectors are gauge dependent -> check by reconstruction (tests/testutil.py:41-57)
+    for g_, (v, d_) in enumerate(zip(V, D)):
+        assert np.allclose(v.conj().T @ H[g_] @ v, np.diag(d_), atol=1e-13)
+
+
+@pytest.mark.parametrize('name', RAND)
+def test_control_matrix_and_filter_function(name):
+    g = load_golden(name)
+    R = orc.control_matrix_from_scratch(g['eigvals'], g['eigvecs'], g['propagators'], g['omega'],
+                                        g['basis'], g['n_opers'], g['n_coeffs'], g['dt'], g['t'])
+    assert rel_err(R, g['control_matrix']) < 1e-13
+    F = orc.filter_function(R)
+    assert rel_err(F, g['filter_function']) < 1e-13
+    assert rel_err(F, g['get_filter_function']) < 1e-13
+    if 'filter_function_gen' in g:
+        assert rel_err(orc.filter_function(R, 'generalized'), g['filter_function_gen']) < 1e-13
+    # end to end from the Hamiltonian (own eigh gauge): R and F are gauge invariant
+    D, V, Q = orc.diagonalize(g['H'], g['dt'])
+    R2 = orc.control_matrix_from_scratch(D, V, Q, g['omega'], g['basis'], g['n_opers'],
+                                         g['n_coeffs'], g['dt'])
+    assert rel_err(R2, g['control_matrix']) < 1e-12
+
+
+@pytest.mark.parametrize('name', RAND)
+def test_noise_operators(name):
+    g = load_golden(name)
+    B = orc.noise_operators_from_scratch(g['eigvals'], g['eigvecs'], g['propagators'], g['omega'],
+                                         g['n_opers'], g['n_coeffs'], g['dt'], g['t'])
+    assert rel_err(B, g['noise_operators']) < 1e-13
+    # Hilbert-space vs Liouville-space consistency, tests/test_precision.py:313-353
+    R = orc.basis_expand(B, g['basis']).transpose(1, 2, 0)
+    assert rel_err(R, g['control_matrix']) < 1e-13
+
+
+@pytest.mark.parametrize('name', ['rand_d2_ggm', 'rand_d3_ggm', 'rand_d4_pauli', 'rand_d4_ggm',
+                                  'edge_degenerate_d4'])
+def test_intermediates(name):
+    g = load_golden(name)
+    R, inter = orc.control_matrix_from_scratch(
+        g['eigvals'], g['eigvecs'], g['propagators'], g['omega'], g['basis'], g['n_opers'],
+        g['n_coeffs'], g['dt'], g['t'], cache_intermediates=True)
+    for key in ('n_opers_transformed', 'eigvecs_propagated', 'basis_transformed',
+                'phase_factors', 'first_order_integral', 'control_matrix_step'):
+        assert rel_err(inter[key], g['inter_' + key]) < 1e-13, key
+    # tests/test_core.py:604-642
+    assert rel_err(inter['control_matrix_step'].sum(0), R) < 1e-13
+    cum = np.cumsum(g['inter_control_matrix_step'], axis=0)[:-1]
+    assert rel_err(inter['control_matrix_step_cumulative'], cum) < 1e-13
+
+
+@pytest.mark.parametrize('name', [n for n in RAND if n not in ('hadamard',)])
+def test_infidelity(name):
+    g = load_golden(name)
+    d = g['basis'].shape[-1]
+    A = len(g['n_opers'])
+    F = g['filter_function']
+    for key in ('S1', 'S2', 'S3'):
+        got = orc.infidelity_from_filter_function(F, g[key], g['omega'], np.arange(A), d)
+        assert rel_err(got, g['infidelity_' + key]) < 1e-13, key
+    if A > 1:
+        idx = np.array([A - 1, 0])
+        got = orc.infidelity_from_filter_function(F, g['S1'], g['omega'], idx, d)
+        assert rel_err(got, g['infidelity_S1_subset']) < 1e-13
+        got = orc.infidelity_from_filter_function(F, g['S3'][np.ix_(idx, idx)], g['omega'], idx, d)
+        assert rel_err(got, g['infidelity_S3_subset']) < 1e-13
+
+
+def test_reference_golden_infidelity_vector():
+    """The reference's own seeded golden vector, tests/test_precision.py:495-551, atol 1e-12."""
+    g = load_golden('test_infidelity')
+    omega = g['omega']
+    for d in (2, 3, 4):
+        H = orc.hamiltonian(g[f'd{d}_c_opers'], g[f'd{d}_c_coeffs'])
+        D, V, Q = orc.diagonalize(H, g[f'd{d}_dt'])
+        R = orc.control_matrix_from_scratch(D, V, Q, omega, orc.basis_ggm(d), g[f'd{d}_n_opers'],
+                                            g[f'd{d}_n_coeffs'], g[f'd{d}_dt'])
+        F = orc.filter_function(R)
+        for s in range(5):
+            got = orc.infidelity_from_filter_function(F, g[f'd{d}_S{s}'], omega, g[f'd{d}_idx'], d)
+            np.testing.assert_allclose(got, g[f'd{d}_ref_infid{s}'], atol=1e-12, rtol=0)
+
+
+def test_hadamard_readme():
+    g = load_golden('hadamard')
+    tau = g['dt'].sum()
+    assert np.array_equal(orc.get_sample_frequencies(tau, g['dt'], 200), g['omega'])
+    assert np.array_equal(orc.get_sample_frequencies(tau, g['dt']), g['omega_default'])
+    infid = orc.infidelity_from_filter_function(g['filter_function'], g['spectrum'], g['omega'],
+                                                np.arange(1), 2)
+    assert rel_err(infid, g['infidelity']) < 1e-13
+    assert abs(infid[0] - 0.0025) < 1e-4           # README.md:58-60
+
+
+@pytest.mark.parametrize('key,n', [('cpmg6', 6), ('udd6', 6), ('pdd6', 6), ('cdd3', 3),
+                                   ('cpmg1', 1)])
+def test_dynamical_decoupling_analytic(key, n):
+    """Closed forms of filter_functions/analytic.py:59-88, atol 1e-10 (test_precision.py:75-182)."""
+    g = load_golden('dynamical_decoupling')
+    omega = g['omega']
+    X, Z = orc.paulis[1], orc.paulis[3]
+    dt = g[key + '_dt']
+    H = orc.hamiltonian(np.array([X/2]), g[key + '_c_coeffs'][None])
+    D, V, Q = orc.diagonalize(H, dt)
+    R = orc.control_matrix_from_scratch(D, V, Q, omega, orc.basis_ggm(2), np.array([Z/2]),
+                                        np.ones((1, len(dt))), dt)
+    F = orc.filter_function(R)[0, 0]
+    # the reference's assertArrayAlmostEqual has rtol=1e-7 on top of atol (tests/testutil.py:65-79)
+    np.testing.assert_allclose((F*omega**2).real, g[key + '_analytic'], atol=1e-10, rtol=1e-7)
+    assert rel_err(F, g[key + '_F']) < 1e-12
+
+
+def test_liouville():
+    g = load_golden('liouville')
+    for tag in ('d2_pauli', 'd3_ggm', 'd4_pauli', 'd4_ggm', 'd8_pauli', 'd16_ggm', 'd3_nonherm'):
+        L = orc.liouville_representation(g[tag + '_U'], g[tag + '_basis'])
+        assert L.dtype == g[tag + '_L'].dtype
+        assert rel_err(L, g[tag + '_L']) < 1e-14, tag
+
+
+def test_from_atomic():
+    g = load_golden('from_atomic')
+    R = orc.control_matrix_from_atomic(g['phases'], g['R_atomic'], g['propagators_liouville'])
+    assert rel_err(R, g['R_total']) < 1e-13
+    assert rel_err(R, g['concat_control_matrix']) < 1e-13
+    Rc = orc.control_matrix_from_atomic(g['phases'], g['R_atomic'], g['propagators_liouville'],
+                                        which='correlations')
+    assert rel_err(Rc, g['R_correlations']) < 1e-13
