@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py -- filter-function elements/s on BASELINE.json config 2, 1..8 GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full pass of the hot path over one pulse, HBM-resident in and out: Hamiltonian ->
+eigendecomposition + expm + cumulative propagators -> control matrix -> filter function ->
+infidelity (ffk_pipeline_dev).  Workload (config 2): random 2-qubit pulse, d=4, 256 segments,
+3 noise operators, Pauli basis, 4096 omega per GPU, seed 42.  With N > 1 the
+frequency axis is sharded: every rank evaluates its own block of 4096 omega of a 4096*N grid
+(weak scaling), one RCCL all-gather reassembles F(omega) on every rank and the infidelity is
+integrated over the full grid.
+
+Rank 0 prints ONE JSON line.  value = elements/s over all ranks, element count
+E = n_seg * n_omega_total * n_nops * d^2 per step (BASELINE.json metric).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD datasheet); see DESIGN.md
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md
+
+
+def config2(seed=42, d=4, G=256, A=3, n_cops=3):
+    """rand_pulse_sequence recipe of the reference's tests/testutil.py:159-190."""
+    rng = np.random.default_rng(seed)
+
+    def herm_traceless(n):
+        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+        M = (M + M.conj().transpose(0, 2, 1))/2
+        return M - np.trace(M, axis1=1, axis2=2)[:, None, None]*np.eye(d)/d
+    c_opers, n_opers = herm_traceless(n_cops), herm_traceless(A)
+    c_coeffs = rng.standard_normal((n_cops, G))
+    n_coeffs = rng.random((A, G))
+    dt = 1 - rng.random(G)
+    return c_opers, c_coeffs, n_opers, n_coeffs, dt
+
+
+def cpu_baseline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum, budget_s=12.0):
+    """The oracle (NumPy restatement of the reference's algorithm) timed on this box's host cores:
+    full passes of the same workload until ~budget_s seconds have been spent."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import ff_oracle as orc
+    d = c_opers.shape[-1]
+    A, G, W = len(n_opers), len(dt), len(omega)
+
+    def one_pass():
+        H = orc.hamiltonian(c_opers, c_coeffs)
+        D, V, Q = orc.diagonalize(H, dt)
+        R = orc.control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+        F = orc.filter_function(R)
+        infid = orc.infidelity_from_filter_function(F, spectrum, omega, np.arange(A), d)
+        return R, F, infid
+    one_pass()                                   # warm-up (BLAS threads, page faults)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        result = one_pass()
+        n += 1
+        elapsed = time.perf_counter() - t0
+        if elapsed >= budget_s or n >= 50:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    value = n*G*W*A*d*d/elapsed
+    return dict(value=value, unit='elements/s', cores=int(threads), kind='port',
+                sample=f'{n} full passes of config 2 (d={d}, {G} segments, {A} noise ops, '
+                       f'{W} omega) in {elapsed:.1f} s, NumPy/OpenBLAS oracle, '
+                       f'os.cpu_count()={os.cpu_count()}'), result
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--omega-per-gpu', type=int, default=4096)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import filter_functions_amd as ff
+    from filter_functions_amd import _lib
+    from filter_functions_amd.device import DevicePipeline
+    from filter_functions_amd.parallel import gather_omega_shards, shard_bounds
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    lib = _lib.load()
+    _lib.check(lib.ffk_set_device(local_rank))
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+
+    d, G, A = 4, 256, 3
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = config2(d=d, G=G, A=A)
+    basis = ff.Basis.pauli(2)
+    W_total = args.omega_per_gpu*world
+    omega_full = np.geomspace(1e-2/dt.sum(), 1e2/dt.min(), W_total)
+    spectrum_full = 1e-3/omega_full
+    w0, w1 = shard_bounds(W_total, world, rank)
+    omega = omega_full[w0:w1]
+    # identifiers sort the operators exactly as PulseSequence does
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
+
+    pipe = DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, basis,
+                          omega, spectrum=spectrum_full[w0:w1], device=device)
+    if world > 1:
+        omega_full_dev = torch.from_numpy(omega_full).to(device)
+        S_full_dev = torch.from_numpy(spectrum_full.astype(complex)).to(device)
+        idx_dev = torch.arange(A, dtype=torch.int32, device=device)
+
+    stream = torch.cuda.current_stream(device).cuda_stream
+    n_ev = args.steps
+    ev = [[ctypes.c_void_p(), ctypes.c_void_p()] for _ in range(n_ev)]
+    for pair in ev:
+        for e in pair:
+            _lib.check(lib.ffk_event_create(ctypes.byref(e)))
+
+    def step(i=None):
+        if i is not None:
+            _lib.check(lib.ffk_set_accumulate_events(ev[i][0], ev[i][1]))
+        pipe.launch(stream=stream, with_infidelity=(world == 1))
+        if world > 1:
+            F_full = gather_omega_shards(pipe.filter_function, W_total)
+            return pipe.infidelity_from(F_full, omega_full_dev, S_full_dev, idx_dev, stream=stream)
+        return pipe.infid
+
+    for _ in range(args.warmup):
+        step()
+    _lib.check(lib.ffk_set_accumulate_events(None, None))
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        infid = step(i)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    _lib.check(lib.ffk_set_accumulate_events(None, None))
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+
+    # dominant kernel: ctrl_accumulate, timed by HIP events on its own stream inside the region
+    ms = ctypes.c_float()
+    acc_ms = []
+    for a, b in ev:
+        _lib.check(lib.ffk_event_elapsed_ms(a, b, ctypes.byref(ms)))
+        acc_ms.append(ms.value)
+    acc_ms = float(np.mean(acc_ms))
+    stats = _lib.stats()
+    for pair in ev:
+        for e in pair:
+            lib.ffk_event_destroy(e)
+
+    if rank == 0:
+        E_step = G*W_total*A*d*d
+        value = E_step*args.steps/elapsed
+        achieved = stats['accumulate_flops']/(acc_ms*1e-3)/1e12
+        out = {
+            'metric': 'filter-function elements/sec (n_seg*n_omega*n_nops*d^2) at d=4',
+            'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed/args.steps*1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': f'BASELINE config 2: random 2-qubit pulse d={d}, {G} segments, '
+                                   f'{A} noise ops, Pauli basis, {args.omega_per_gpu} omega per GPU '
+                                   f'({W_total} total), seed 42; one step = diagonalize + control '
+                                   'matrix + filter function + infidelity, HBM-resident',
+                       'sharding': 'omega blocks, RCCL all-gather of F' if world > 1 else 'none'},
+            'roofline': {
+                'kernel': 'ffk::ctrl_accumulate_kernel<4,4,4,2>', 'bound': 'mfma',
+                'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': None,
+                'avg_launch_ms': acc_ms, 'flops_per_launch': stats['accumulate_flops'],
+                'note': 'FP64 compute bound (vector = matrix peak 78.6 TFLOP/s on MI355X); '
+                        'flops = FMA-counted flops of the Hilbert-space algorithm actually run',
+            },
+            'roofline_hbm': {
+                'bound': 'hbm', 'achieved': stats['accumulate_bytes']/(acc_ms*1e-3)/1e9,
+                'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': stats['accumulate_bytes']/(acc_ms*1e-3)/1e9/HBM_PEAK_GBS,
+                'bytes_per_launch': stats['accumulate_bytes'],
+                'note': 'not the binding roof: algorithmic bytes of the accumulate kernel '
+                        '(partial sums out + operands in)',
+            },
+            'kernel_geometry': {k: stats[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z',
+                                                       'block', 'lds_bytes')},
+            'seg_omega_nop_per_s': G*W_total*A*args.steps/elapsed,
+            'device': _lib.device_info()[0],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, (R_ref, F_ref, infid_ref) = cpu_baseline(
+                pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, np.asarray(basis),
+                omega, spectrum_full)
+            out['cpu_baseline'] = base
+            F_gpu = pipe.filter_function.cpu().numpy()
+            R_gpu = pipe.control_matrix.cpu().numpy()
+            out['parity'] = {
+                'control_matrix_max_rel_err': float(np.abs(R_gpu - R_ref).max()/np.abs(R_ref).max()),
+                'filter_function_max_rel_err': float(np.abs(F_gpu - F_ref).max()/np.abs(F_ref).max()),
+                'infidelity_max_rel_err': float(np.abs(infid.cpu().numpy() - infid_ref).max()
+                                                / np.abs(infid_ref).max()),
+                'against': 'oracle (NumPy restatement of the reference), same inputs',
+            }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,25 @@
+"""filter_functions_amd -- the numeric hot path of qutech/filter_functions on AMD MI355X.
+
+A drop-in for ``PulseSequence.get_filter_function()`` and ``ff.infidelity()``::
+
+    import filter_functions_amd as ff
+
+    pulse = ff.PulseSequence(H_c, H_n, dt, basis=ff.Basis.pauli(2))
+    F = pulse.get_filter_function(omega)
+    infid = ff.infidelity(pulse, spectrum, omega)
+
+The arithmetic runs in hand-written HIP kernels for gfx950 behind a C ABI
+(``include/ffk.h``, ``filter_functions_amd/libffk.so``); this package is the Python host
+side: the reference's object model, argument checking, caching and exceptions.
+See DESIGN.md for the scope, INTEGRATION.md for the boundary.
+"""
+from . import basis, numeric, pulse_sequence, superoperator, util
+from .basis import Basis
+from .numeric import infidelity
+from .pulse_sequence import PulseSequence
+from .superoperator import liouville_representation
+
+__all__ = ['Basis', 'PulseSequence', 'basis', 'infidelity', 'liouville_representation', 'numeric',
+           'pulse_sequence', 'superoperator', 'util']
+
+__version__ = '0.1.0'

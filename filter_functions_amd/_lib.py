@@ -1,0 +1,170 @@
+"""ctypes binding of ``libffk.so`` (C ABI declared in ``include/ffk.h``).
+
+The product path has no CPU fallback: if the shared library is missing or a HIP
+call fails, the error is raised -- never papered over.  Importing this module
+only loads the library (no GPU is touched until the first call), so the
+package imports, and the exported symbols can be checked, on a machine without
+a GPU.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get('FFK_LIBRARY', os.path.join(_HERE, 'libffk.so'))
+
+FFK_OK = 0
+FFK_EINVAL = -1
+FFK_EHIP = -2
+FFK_ENOMEM = -3
+FFK_ENOCONV = -4
+
+WANT_NOISE_OPERATORS = 0x1
+FF_FIDELITY = 0
+FF_GENERALIZED = 1
+MAX_D = 16
+
+_dp = POINTER(c_double)
+_ip = POINTER(c_int32)
+
+
+class FFKError(RuntimeError):
+    """A HIP runtime failure inside libffk."""
+
+
+class ffk_stats(ctypes.Structure):
+    _fields_ = [('accumulate_flops', c_double), ('accumulate_bytes', c_double),
+                ('chunks', c_int), ('grid_x', c_int), ('grid_y', c_int), ('grid_z', c_int),
+                ('block', c_int), ('lds_bytes', c_int)]
+
+
+#: every symbol include/ffk.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    'ffk_last_error': (c_char_p, []),
+    'ffk_version': (c_int, []),
+    'ffk_device_count': (c_int, [POINTER(c_int)]),
+    'ffk_set_device': (c_int, [c_int]),
+    'ffk_get_device': (c_int, [POINTER(c_int)]),
+    'ffk_device_info': (c_int, [ctypes.c_char_p, c_int, POINTER(c_int), POINTER(c_size_t)]),
+    'ffk_malloc': (c_int, [POINTER(c_void_p), c_size_t]),
+    'ffk_free': (c_int, [c_void_p]),
+    'ffk_memset': (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    'ffk_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ffk_memcpy_d2h': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ffk_memcpy_d2d': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ffk_stream_create': (c_int, [POINTER(c_void_p)]),
+    'ffk_stream_destroy': (c_int, [c_void_p]),
+    'ffk_stream_synchronize': (c_int, [c_void_p]),
+    'ffk_device_synchronize': (c_int, []),
+    'ffk_event_create': (c_int, [POINTER(c_void_p)]),
+    'ffk_event_destroy': (c_int, [c_void_p]),
+    'ffk_event_record': (c_int, [c_void_p, c_void_p]),
+    'ffk_event_synchronize': (c_int, [c_void_p]),
+    'ffk_event_elapsed_ms': (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    'ffk_release_arena': (c_int, []),
+    'ffk_diagonalize': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'ffk_diagonalize_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'ffk_diagonalize_dev': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ffk_control_matrix': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                   c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_uint, c_void_p, c_void_p]),
+    'ffk_control_matrix_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'ffk_control_matrix_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                       c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                       c_int, c_uint, c_void_p, c_void_p, c_void_p, c_size_t,
+                                       c_void_p]),
+    'ffk_control_matrix_intermediates': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                 c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                                 c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p, c_void_p,
+                                                 c_void_p]),
+    'ffk_filter_function': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    'ffk_filter_function_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'ffk_infidelity': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                               c_int, c_void_p]),
+    'ffk_infidelity_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'ffk_infidelity_dev': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ffk_liouville': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    'ffk_liouville_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'ffk_liouville_dev': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
+    'ffk_pipeline_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'ffk_pipeline_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                 c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ffk_set_segment_chunks': (c_int, [c_int]),
+    'ffk_get_stats': (c_int, [POINTER(ffk_stats)]),
+    'ffk_set_accumulate_events': (c_int, [c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libffk.so (once) and declare the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f'{LIB_PATH} not found: build the HIP extension first '
+                "(python -c 'import __graft_entry__ as g; g.build()' or "
+                'make -C filter_functions_amd/csrc).  There is no CPU fallback.')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def check(status):
+    """Map a libffk status code to the exception class the reference would raise."""
+    if status == FFK_OK:
+        return
+    msg = load().ffk_last_error().decode(errors='replace')
+    if status == FFK_EINVAL:
+        raise ValueError(msg)
+    if status == FFK_ENOMEM:
+        raise MemoryError(msg)
+    if status == FFK_ENOCONV:
+        raise np.linalg.LinAlgError(msg)
+    raise FFKError(msg)
+
+
+def ptr(arr):
+    """void* of a C-contiguous ndarray (or None)."""
+    return None if arr is None else arr.ctypes.data_as(c_void_p)
+
+
+def as_c128(arr):
+    return np.ascontiguousarray(arr, dtype=np.complex128)
+
+
+def as_f64(arr):
+    return np.ascontiguousarray(arr, dtype=np.float64)
+
+
+def device_count():
+    n = c_int(0)
+    status = load().ffk_device_count(ctypes.byref(n))
+    return n.value if status == FFK_OK else 0
+
+
+def device_info():
+    name = ctypes.create_string_buffer(256)
+    cus = c_int(0)
+    mem = c_size_t(0)
+    check(load().ffk_device_info(name, 256, ctypes.byref(cus), ctypes.byref(mem)))
+    return name.value.decode(), cus.value, mem.value
+
+
+def stats():
+    out = ffk_stats()
+    check(load().ffk_get_stats(ctypes.byref(out)))
+    return {k: getattr(out, k) for k, _ in ffk_stats._fields_}

@@ -1,0 +1,706 @@
+// ffk_api.hip -- the extern "C" surface declared in include/ffk.h.
+//
+// *_dev entry points only slice the caller's workspace and enqueue kernels.  The host-pointer
+// entry points stage through a process-wide, grow-only device arena and synchronise before
+// returning, so that the NumPy-facing front-end has exactly the reference's call semantics
+// (borrowed inputs, freshly written outputs).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "ffk.h"
+#include "ffk_internal.h"
+
+using ffk::align_up;
+using ffk::cplx;
+
+namespace {
+
+thread_local std::string g_error;
+thread_local ffk_stats g_stats = {};
+int g_forced_chunks = 0;
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define FFK_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? FFK_ENOMEM : FFK_EHIP, "%s failed: %s", \
+                        #expr, hipGetErrorString(e_));                                     \
+    } while (0)
+
+#define FFK_REQUIRE(cond, ...) \
+    do {                       \
+        if (!(cond)) return fail(FFK_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+bool d_ok(int d) { return d >= 2 && d <= FFK_MAX_D; }
+
+// bump allocator over a caller- or arena-provided workspace
+struct Bump {
+    unsigned char* base;
+    size_t size, used = 0;
+    Bump(void* p, size_t n) : base(static_cast<unsigned char*>(p)), size(n) {}
+    template <typename T>
+    T* take(size_t count) {
+        const size_t bytes = align_up(count*sizeof(T));
+        if (used + bytes > size) return nullptr;
+        T* out = reinterpret_cast<T*>(base + used);
+        used += bytes;
+        return out;
+    }
+};
+
+// process-wide arena for the host-pointer flavour
+struct Arena {
+    std::mutex mu;
+    void* ptr = nullptr;
+    size_t size = 0;
+    int device = -1;
+} g_arena;
+
+int arena_reserve(size_t bytes, void** out) {
+    int dev = 0;
+    FFK_HIP(hipGetDevice(&dev));
+    if (g_arena.ptr && (g_arena.device != dev || g_arena.size < bytes)) {
+        FFK_HIP(hipDeviceSynchronize());
+        FFK_HIP(hipFree(g_arena.ptr));
+        g_arena.ptr = nullptr;
+        g_arena.size = 0;
+    }
+    if (!g_arena.ptr) {
+        const size_t want = align_up(bytes + bytes/4, size_t(1) << 20);
+        FFK_HIP(hipMalloc(&g_arena.ptr, want));
+        g_arena.size = want;
+        g_arena.device = dev;
+    }
+    *out = g_arena.ptr;
+    return FFK_OK;
+}
+
+// --- workspace layouts ------------------------------------------------------------------------
+size_t ctrl_ws_bytes(int W, int N, int A, int G, int d, int chunks) {
+    size_t b = 0;
+    b += align_up(sizeof(double)*G*ffk::seg_stride(d));                   // segtab
+    b += align_up(sizeof(cplx)*size_t(G)*d*d);                            // Tc
+    b += align_up(sizeof(cplx)*size_t(G)*A*d*d*d);                        // Wt
+    b += align_up(sizeof(cplx)*size_t(chunks)*A*d*d*W);                   // Ypart
+    b += align_up(sizeof(cplx)*size_t(A)*d*d*W);                          // Bt
+    (void)N;
+    return b;
+}
+
+int max_chunks_for(int W, int A, int G, int d) {
+    // upper bound of what accumulate_geometry may choose, for workspace sizing
+    const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);
+    return geo.chunks;
+}
+
+double accumulate_flops(int W, int A, int G, int d) {
+    // FMA-counted real flops of the accumulate kernel's algorithm (DESIGN.md "Roofline"):
+    //   contraction: 2 d^3 complex MACs per (g, w, a) = 16 d^3 flops
+    //   integral:    (d(d-1)+1) entries per (g, w), each ~ sincos(26) + reciprocal(9) + 14 misc
+    //                + complex phase multiply (6), counted as 55 flops; phase sincos 26
+    const double per_gw = 16.0*d*d*d*A + 55.0*(d*(d - 1) + 1) + 26.0;
+    return per_gw*double(G)*double(W);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ffk_last_error(void) { return g_error.c_str(); }
+int ffk_version(void) { return FFK_VERSION; }
+
+int ffk_device_count(int* count) {
+    FFK_REQUIRE(count, "count is NULL");
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(FFK_EHIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    return FFK_OK;
+}
+int ffk_set_device(int device) {
+    FFK_HIP(hipSetDevice(device));
+    return FFK_OK;
+}
+int ffk_get_device(int* device) {
+    FFK_REQUIRE(device, "device is NULL");
+    FFK_HIP(hipGetDevice(device));
+    return FFK_OK;
+}
+int ffk_device_info(char* name, int len, int* compute_units, size_t* global_mem_bytes) {
+    int dev = 0;
+    FFK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    FFK_HIP(hipGetDeviceProperties(&prop, dev));
+    if (name && len > 0) {
+        std::snprintf(name, len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (global_mem_bytes) *global_mem_bytes = prop.totalGlobalMem;
+    return FFK_OK;
+}
+
+int ffk_malloc(void** dptr, size_t bytes) {
+    FFK_REQUIRE(dptr, "dptr is NULL");
+    FFK_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return FFK_OK;
+}
+int ffk_free(void* dptr) {
+    FFK_HIP(hipFree(dptr));
+    return FFK_OK;
+}
+int ffk_memset(void* dptr, int value, size_t bytes, void* stream) {
+    FFK_HIP(hipMemsetAsync(dptr, value, bytes, static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+int ffk_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    FFK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+int ffk_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    FFK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+int ffk_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    FFK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+int ffk_stream_create(void** stream) {
+    FFK_REQUIRE(stream, "stream is NULL");
+    hipStream_t s;
+    FFK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return FFK_OK;
+}
+int ffk_stream_destroy(void* stream) {
+    FFK_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+int ffk_stream_synchronize(void* stream) {
+    FFK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+int ffk_device_synchronize(void) {
+    FFK_HIP(hipDeviceSynchronize());
+    return FFK_OK;
+}
+int ffk_event_create(void** event) {
+    FFK_REQUIRE(event, "event is NULL");
+    hipEvent_t e;
+    FFK_HIP(hipEventCreate(&e));
+    *event = e;
+    return FFK_OK;
+}
+int ffk_event_destroy(void* event) {
+    FFK_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return FFK_OK;
+}
+int ffk_event_record(void* event, void* stream) {
+    FFK_HIP(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+int ffk_event_synchronize(void* event) {
+    FFK_HIP(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+    return FFK_OK;
+}
+int ffk_event_elapsed_ms(void* start, void* stop, float* ms) {
+    FFK_REQUIRE(ms, "ms is NULL");
+    FFK_HIP(hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    return FFK_OK;
+}
+int ffk_release_arena(void) {
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    if (g_arena.ptr) {
+        FFK_HIP(hipDeviceSynchronize());
+        FFK_HIP(hipFree(g_arena.ptr));
+        g_arena.ptr = nullptr;
+        g_arena.size = 0;
+    }
+    return FFK_OK;
+}
+
+int ffk_set_segment_chunks(int chunks) {
+    FFK_REQUIRE(chunks >= 0, "chunks must be >= 0");
+    g_forced_chunks = chunks;
+    return FFK_OK;
+}
+int ffk_set_accumulate_events(void* start, void* stop) {
+    g_ev_start = static_cast<hipEvent_t>(start);
+    g_ev_stop = static_cast<hipEvent_t>(stop);
+    return FFK_OK;
+}
+int ffk_get_stats(ffk_stats* out) {
+    FFK_REQUIRE(out, "out is NULL");
+    *out = g_stats;
+    return FFK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// diagonalize
+// ---------------------------------------------------------------------------------------------
+size_t ffk_diagonalize_workspace_bytes(int G, int d) {
+    if (G < 1 || !d_ok(d)) return 0;
+    return align_up(sizeof(cplx)*size_t(G)*d*d) + ffk::scan_workspace_bytes(G, d) + align_up(sizeof(int));
+}
+
+int ffk_diagonalize_dev(const double* hamiltonian, const double* dt, int G, int d, double* eigvals,
+                        double* eigvecs, double* propagators, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(G >= 1, "need at least one segment, got G=%d", G);
+    FFK_REQUIRE(hamiltonian && dt && eigvals && eigvecs && propagators && workspace, "NULL argument");
+    FFK_REQUIRE(workspace_bytes >= ffk_diagonalize_workspace_bytes(G, d), "workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Bump ws(workspace, workspace_bytes);
+    cplx* seg_prop = ws.take<cplx>(size_t(G)*d*d);
+    void* scan_ws = ws.take<unsigned char>(ffk::scan_workspace_bytes(G, d));
+    int* status = ws.take<int>(1);
+    FFK_HIP(hipMemsetAsync(status, 0, sizeof(int), s));
+    FFK_HIP(ffk::launch_eigh_expm(reinterpret_cast<const cplx*>(hamiltonian), dt, G, d, eigvals,
+                                  reinterpret_cast<cplx*>(eigvecs), seg_prop, status, s));
+    FFK_HIP(ffk::launch_prefix_products(seg_prop, G, d, reinterpret_cast<cplx*>(propagators), scan_ws, s));
+    return FFK_OK;
+}
+
+int ffk_diagonalize(const double* hamiltonian, const double* dt, int G, int d, double* eigvals,
+                    double* eigvecs, double* propagators) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(G >= 1, "need at least one segment, got G=%d", G);
+    FFK_REQUIRE(hamiltonian && dt && eigvals && eigvecs && propagators, "NULL argument");
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nH = sizeof(cplx)*size_t(G)*d*d, nQ = sizeof(cplx)*size_t(G + 1)*d*d;
+    const size_t wsb = ffk_diagonalize_workspace_bytes(G, d);
+    const size_t total = 2*align_up(nH) + align_up(nQ) + 2*align_up(sizeof(double)*G*d) + wsb;
+    void* base;
+    if (int rc = arena_reserve(total, &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dH = a.take<double>(size_t(G)*d*d*2);
+    double* ddt = a.take<double>(G);
+    double* dD = a.take<double>(size_t(G)*d);
+    double* dV = a.take<double>(size_t(G)*d*d*2);
+    double* dQ = a.take<double>(size_t(G + 1)*d*d*2);
+    void* ws = a.take<unsigned char>(wsb);
+    FFK_REQUIRE(ws, "internal: arena too small");
+    FFK_HIP(hipMemcpyAsync(dH, hamiltonian, nH, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(ddt, dt, sizeof(double)*G, hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_diagonalize_dev(dH, ddt, G, d, dD, dV, dQ, ws, wsb, nullptr)) return rc;
+    int status = 0;
+    // status word is the last slice of the workspace
+    const int* dstatus = reinterpret_cast<const int*>(static_cast<unsigned char*>(ws) +
+                                                      align_up(nH) + ffk::scan_workspace_bytes(G, d));
+    FFK_HIP(hipMemcpyAsync(eigvals, dD, sizeof(double)*G*d, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipMemcpyAsync(eigvecs, dV, nH, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipMemcpyAsync(propagators, dQ, nQ, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipMemcpyAsync(&status, dstatus, sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    if (status != 0)
+        return fail(FFK_ENOCONV, "Jacobi eigensolver did not converge for %d segment(s)", status);
+    return FFK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// control matrix / noise operators
+// ---------------------------------------------------------------------------------------------
+size_t ffk_control_matrix_workspace_bytes(int W, int N, int A, int G, int d) {
+    if (W < 1 || N < 1 || A < 1 || G < 1 || !d_ok(d)) return 0;
+    return ctrl_ws_bytes(W, N, A, G, d, max_chunks_for(W, A, G, d));
+}
+
+int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const double* propagators,
+                           const double* omega, int W, const double* basis, int N,
+                           const double* n_opers, int A, const double* n_coeffs, const double* dt,
+                           const double* t, int G, int d, unsigned flags, double* control_matrix,
+                           double* noise_operators, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
+    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && n_opers && n_coeffs && dt && t && workspace,
+                "NULL argument");
+    FFK_REQUIRE(control_matrix || (flags & FFK_WANT_NOISE_OPERATORS), "no output requested");
+    FFK_REQUIRE(!control_matrix || basis, "basis is NULL");
+    FFK_REQUIRE(!(flags & FFK_WANT_NOISE_OPERATORS) || noise_operators, "noise_operators is NULL");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);
+    FFK_REQUIRE(workspace_bytes >= ctrl_ws_bytes(W, N, A, G, d, geo.chunks), "workspace too small");
+    Bump ws(workspace, workspace_bytes);
+    double* segtab = ws.take<double>(size_t(G)*ffk::seg_stride(d));
+    cplx* Tc = ws.take<cplx>(size_t(G)*d*d);
+    cplx* Wt = ws.take<cplx>(size_t(G)*A*d*d*d);
+    cplx* Ypart = ws.take<cplx>(size_t(geo.chunks)*A*d*d*W);
+    cplx* Bt = ws.take<cplx>(size_t(A)*d*d*W);
+    FFK_REQUIRE(Bt, "workspace too small");
+
+    FFK_HIP(ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
+                                 reinterpret_cast<const cplx*>(propagators),
+                                 reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G, d, A,
+                                 segtab, Tc, Wt, nullptr, nullptr, s));
+    if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_start, s));
+    FFK_HIP(ffk::launch_accumulate(omega, W, segtab, Wt, Tc, G, d, A, geo, Ypart, s));
+    if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_stop, s));
+    const size_t slab = size_t(A)*d*d*W;
+    const cplx* Bsum = Ypart;
+    if (geo.chunks > 1) {
+        FFK_HIP(ffk::launch_reduce_chunks(Ypart, geo.chunks, slab, Bt, s));
+        Bsum = Bt;
+    }
+    if (control_matrix)
+        FFK_HIP(ffk::launch_expand(Bsum, reinterpret_cast<const cplx*>(basis), A, N, d, W,
+                                   reinterpret_cast<cplx*>(control_matrix), s));
+    if (flags & FFK_WANT_NOISE_OPERATORS)
+        FFK_HIP(ffk::launch_transpose_noise_ops(Bsum, A, d, W, reinterpret_cast<cplx*>(noise_operators), s));
+
+    g_stats.accumulate_flops = accumulate_flops(W, A, G, d);
+    g_stats.accumulate_bytes = double(sizeof(cplx))*(double(geo.chunks)*slab) + 8.0*W +
+                               double(sizeof(cplx))*G*(double(A)*d*d*d + d*d);
+    g_stats.chunks = geo.chunks;
+    g_stats.grid_x = (W + 63)/64;
+    g_stats.grid_y = geo.task_groups;
+    g_stats.grid_z = geo.chunks;
+    g_stats.block = geo.nwaves*64;
+    g_stats.lds_bytes = geo.lds_bytes;
+    return FFK_OK;
+}
+
+int ffk_control_matrix(const double* eigvals, const double* eigvecs, const double* propagators,
+                       const double* omega, int W, const double* basis, int N,
+                       const double* n_opers, int A, const double* n_coeffs, const double* dt,
+                       const double* t, int G, int d, unsigned flags, double* control_matrix,
+                       double* noise_operators) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
+    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && n_opers && n_coeffs && dt && t,
+                "NULL argument");
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t dd = size_t(d)*d;
+    const size_t wsb = ffk_control_matrix_workspace_bytes(W, N, A, G, d);
+    const bool want_R = control_matrix != nullptr;
+    const bool want_B = (flags & FFK_WANT_NOISE_OPERATORS) != 0;
+    size_t total = wsb;
+    total += align_up(8*size_t(G)*d) + align_up(16*size_t(G)*dd) + align_up(16*size_t(G + 1)*dd);
+    total += align_up(8*size_t(W)) + align_up(16*size_t(N)*dd) + align_up(16*size_t(A)*dd);
+    total += align_up(8*size_t(A)*G) + align_up(8*size_t(G)) + align_up(8*size_t(G + 1));
+    if (want_R) total += align_up(16*size_t(A)*N*W);
+    if (want_B) total += align_up(16*size_t(A)*dd*W);
+    void* base;
+    if (int rc = arena_reserve(total, &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dD = a.take<double>(size_t(G)*d);
+    double* dV = a.take<double>(2*size_t(G)*dd);
+    double* dQ = a.take<double>(2*size_t(G + 1)*dd);
+    double* dom = a.take<double>(W);
+    double* dbasis = a.take<double>(2*size_t(N)*dd);
+    double* dnop = a.take<double>(2*size_t(A)*dd);
+    double* dnc = a.take<double>(size_t(A)*G);
+    double* ddt = a.take<double>(G);
+    double* dtt = a.take<double>(G + 1);
+    double* dR = want_R ? a.take<double>(2*size_t(A)*N*W) : nullptr;
+    double* dB = want_B ? a.take<double>(2*size_t(A)*dd*W) : nullptr;
+    void* ws = a.take<unsigned char>(wsb);
+    FFK_REQUIRE(ws, "internal: arena too small");
+    auto h2d = [](void* dst, const void* src, size_t n) {
+        return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, nullptr);
+    };
+    FFK_HIP(h2d(dD, eigvals, 8*size_t(G)*d));
+    FFK_HIP(h2d(dV, eigvecs, 16*size_t(G)*dd));
+    FFK_HIP(h2d(dQ, propagators, 16*size_t(G + 1)*dd));
+    FFK_HIP(h2d(dom, omega, 8*size_t(W)));
+    if (basis) FFK_HIP(h2d(dbasis, basis, 16*size_t(N)*dd));
+    FFK_HIP(h2d(dnop, n_opers, 16*size_t(A)*dd));
+    FFK_HIP(h2d(dnc, n_coeffs, 8*size_t(A)*G));
+    FFK_HIP(h2d(ddt, dt, 8*size_t(G)));
+    FFK_HIP(h2d(dtt, t, 8*size_t(G + 1)));
+    if (int rc = ffk_control_matrix_dev(dD, dV, dQ, dom, W, basis ? dbasis : nullptr, N, dnop, A, dnc,
+                                        ddt, dtt, G, d, flags, dR, dB, ws, wsb, nullptr))
+        return rc;
+    if (want_R)
+        FFK_HIP(hipMemcpyAsync(control_matrix, dR, 16*size_t(A)*N*W, hipMemcpyDeviceToHost, nullptr));
+    if (want_B)
+        FFK_HIP(hipMemcpyAsync(noise_operators, dB, 16*size_t(A)*dd*W, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvecs,
+                                     const double* propagators, const double* omega, int W,
+                                     const double* basis, int N, const double* n_opers, int A,
+                                     const double* n_coeffs, const double* dt, const double* t, int G,
+                                     int d, double* n_opers_transformed, double* eigvecs_propagated,
+                                     double* basis_transformed, double* phase_factors,
+                                     double* first_order_integral, double* control_matrix_step) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
+    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && basis && n_opers && n_coeffs && dt && t,
+                "NULL argument");
+    FFK_REQUIRE(size_t(G)*A <= 65535, "G*A = %zu too large for the materialising variant", size_t(G)*A);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t dd = size_t(d)*d;
+    // inputs + operands + every requested product, all resident at once (HBM is 288 GB)
+    size_t total = 0;
+    total += align_up(8*size_t(G)*d) + align_up(16*size_t(G)*dd) + align_up(16*size_t(G + 1)*dd);
+    total += align_up(8*size_t(W)) + align_up(16*size_t(N)*dd) + align_up(16*size_t(A)*dd);
+    total += align_up(8*size_t(A)*G) + align_up(8*size_t(G)) + align_up(8*size_t(G + 1));
+    total += align_up(8*size_t(G)*ffk::seg_stride(d)) + align_up(16*size_t(G)*dd) +
+             align_up(16*size_t(G)*A*dd*d);
+    total += align_up(16*size_t(A)*G*dd) + align_up(16*size_t(G)*dd);          // nt, ep
+    if (basis_transformed) total += align_up(16*size_t(G)*N*dd);
+    if (phase_factors) total += align_up(16*size_t(G)*W);
+    if (first_order_integral) total += align_up(16*size_t(G)*W*dd);
+    if (control_matrix_step) total += align_up(16*size_t(G)*A*dd*W) + align_up(16*size_t(G)*A*N*W);
+    void* base;
+    if (int rc = arena_reserve(total, &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dD = a.take<double>(size_t(G)*d);
+    cplx* dV = a.take<cplx>(size_t(G)*dd);
+    cplx* dQ = a.take<cplx>(size_t(G + 1)*dd);
+    double* dom = a.take<double>(W);
+    cplx* dbasis = a.take<cplx>(size_t(N)*dd);
+    cplx* dnop = a.take<cplx>(size_t(A)*dd);
+    double* dnc = a.take<double>(size_t(A)*G);
+    double* ddt = a.take<double>(G);
+    double* dtt = a.take<double>(G + 1);
+    double* segtab = a.take<double>(size_t(G)*ffk::seg_stride(d));
+    cplx* Tc = a.take<cplx>(size_t(G)*dd);
+    cplx* Wt = a.take<cplx>(size_t(G)*A*dd*d);
+    cplx* dnt = a.take<cplx>(size_t(A)*G*dd);
+    cplx* dep = a.take<cplx>(size_t(G)*dd);
+    cplx* dbt = basis_transformed ? a.take<cplx>(size_t(G)*N*dd) : nullptr;
+    cplx* dph = phase_factors ? a.take<cplx>(size_t(G)*W) : nullptr;
+    cplx* dint = first_order_integral ? a.take<cplx>(size_t(G)*W*dd) : nullptr;
+    cplx* Ypart = control_matrix_step ? a.take<cplx>(size_t(G)*A*dd*W) : nullptr;
+    cplx* dstep = control_matrix_step ? a.take<cplx>(size_t(G)*A*N*W) : nullptr;
+    FFK_REQUIRE(a.used <= g_arena.size, "internal: arena too small");
+    auto h2d = [](void* dst, const void* src, size_t n) {
+        return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, nullptr);
+    };
+    auto d2h = [](void* dst, const void* src, size_t n) {
+        return hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, nullptr);
+    };
+    FFK_HIP(h2d(dD, eigvals, 8*size_t(G)*d));
+    FFK_HIP(h2d(dV, eigvecs, 16*size_t(G)*dd));
+    FFK_HIP(h2d(dQ, propagators, 16*size_t(G + 1)*dd));
+    FFK_HIP(h2d(dom, omega, 8*size_t(W)));
+    FFK_HIP(h2d(dbasis, basis, 16*size_t(N)*dd));
+    FFK_HIP(h2d(dnop, n_opers, 16*size_t(A)*dd));
+    FFK_HIP(h2d(dnc, n_coeffs, 8*size_t(A)*G));
+    FFK_HIP(h2d(ddt, dt, 8*size_t(G)));
+    FFK_HIP(h2d(dtt, t, 8*size_t(G + 1)));
+    FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dnop, dnc, ddt, dtt, G, d, A, segtab, Tc, Wt, dnt, dep, nullptr));
+    if (dbt) FFK_HIP(ffk::launch_basis_transformed(Tc, dbasis, G, N, d, dbt, nullptr));
+    FFK_HIP(ffk::launch_phase_and_integral(dom, W, segtab, G, d, dph, dint, nullptr));
+    if (dstep) {
+        // one chunk per segment: Ypart[g] is that segment's Hilbert-space step, expanded in the basis
+        ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, G);
+        FFK_HIP(ffk::launch_accumulate(dom, W, segtab, Wt, Tc, G, d, A, geo, Ypart, nullptr));
+        FFK_HIP(ffk::launch_expand(Ypart, dbasis, G*A, N, d, W, dstep, nullptr));
+    }
+    if (n_opers_transformed) FFK_HIP(d2h(n_opers_transformed, dnt, 16*size_t(A)*G*dd));
+    if (eigvecs_propagated) FFK_HIP(d2h(eigvecs_propagated, dep, 16*size_t(G)*dd));
+    if (basis_transformed) FFK_HIP(d2h(basis_transformed, dbt, 16*size_t(G)*N*dd));
+    if (phase_factors) FFK_HIP(d2h(phase_factors, dph, 16*size_t(G)*W));
+    if (first_order_integral) FFK_HIP(d2h(first_order_integral, dint, 16*size_t(G)*W*dd));
+    if (control_matrix_step) FFK_HIP(d2h(control_matrix_step, dstep, 16*size_t(G)*A*N*W));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter function
+// ---------------------------------------------------------------------------------------------
+int ffk_filter_function_dev(const double* control_matrix, int A, int N, int W, int which,
+                            double* filter_function, void* stream) {
+    FFK_REQUIRE(control_matrix && filter_function, "NULL argument");
+    FFK_REQUIRE(A >= 1 && N >= 1 && W >= 1, "empty axis: A=%d N=%d W=%d", A, N, W);
+    FFK_REQUIRE(which == FFK_FF_FIDELITY || which == FFK_FF_GENERALIZED, "invalid which=%d", which);
+    FFK_HIP(ffk::launch_filter_function(reinterpret_cast<const cplx*>(control_matrix), A, N, W, which,
+                                        reinterpret_cast<cplx*>(filter_function),
+                                        static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+int ffk_filter_function(const double* control_matrix, int A, int N, int W, int which,
+                        double* filter_function) {
+    FFK_REQUIRE(control_matrix && filter_function, "NULL argument");
+    FFK_REQUIRE(A >= 1 && N >= 1 && W >= 1, "empty axis: A=%d N=%d W=%d", A, N, W);
+    FFK_REQUIRE(which == FFK_FF_FIDELITY || which == FFK_FF_GENERALIZED, "invalid which=%d", which);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nR = 16*size_t(A)*N*W;
+    const size_t nF = which == FFK_FF_FIDELITY ? 16*size_t(A)*A*W : 16*size_t(A)*A*N*N*W;
+    void* base;
+    if (int rc = arena_reserve(align_up(nR) + align_up(nF), &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dR = a.take<double>(nR/8);
+    double* dF = a.take<double>(nF/8);
+    FFK_HIP(hipMemcpyAsync(dR, control_matrix, nR, hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_filter_function_dev(dR, A, N, W, which, dF, nullptr)) return rc;
+    FFK_HIP(hipMemcpyAsync(filter_function, dF, nF, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// infidelity
+// ---------------------------------------------------------------------------------------------
+size_t ffk_infidelity_workspace_bytes(int W, int n_idx, int s_ndim) {
+    if (W < 1 || n_idx < 1 || s_ndim < 1 || s_ndim > 3) return 0;
+    return ffk::infidelity_workspace_bytes(W, n_idx, s_ndim);
+}
+
+int ffk_infidelity_dev(const double* filter_function, int A, int W, const double* spectrum,
+                       int s_ndim, const double* omega, const int32_t* idx, int n_idx, int d,
+                       double* infid, void* workspace, size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(filter_function && spectrum && omega && idx && infid && workspace, "NULL argument");
+    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
+    FFK_REQUIRE(A >= 1 && W >= 1 && n_idx >= 1 && d >= 1, "empty axis");
+    FFK_REQUIRE(workspace_bytes >= ffk_infidelity_workspace_bytes(W, n_idx, s_ndim), "workspace too small");
+    FFK_HIP(ffk::launch_infidelity(reinterpret_cast<const cplx*>(filter_function), A, W,
+                                   reinterpret_cast<const cplx*>(spectrum), s_ndim, omega, idx, n_idx,
+                                   d, infid, workspace, static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+int ffk_infidelity(const double* filter_function, int A, int W, const double* spectrum, int s_ndim,
+                   const double* omega, const int32_t* idx, int n_idx, int d, double* infid) {
+    FFK_REQUIRE(filter_function && spectrum && omega && idx && infid, "NULL argument");
+    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
+    FFK_REQUIRE(A >= 1 && W >= 1 && n_idx >= 1 && d >= 1, "empty axis");
+    for (int i = 0; i < n_idx; ++i)
+        FFK_REQUIRE(idx[i] >= 0 && idx[i] < A, "noise operator index %d out of range [0, %d)", idx[i], A);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nout = s_ndim == 3 ? size_t(n_idx)*n_idx : n_idx;
+    const size_t nS = 16*size_t(W)*(s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : size_t(n_idx)*n_idx));
+    const size_t nF = 16*size_t(A)*A*W;
+    const size_t wsb = ffk_infidelity_workspace_bytes(W, n_idx, s_ndim);
+    void* base;
+    if (int rc = arena_reserve(align_up(nF) + align_up(nS) + align_up(8*size_t(W)) + align_up(4*size_t(n_idx)) +
+                                   align_up(8*nout) + wsb, &base))
+        return rc;
+    Bump a(base, g_arena.size);
+    double* dF = a.take<double>(nF/8);
+    double* dS = a.take<double>(nS/8);
+    double* dom = a.take<double>(W);
+    int32_t* didx = a.take<int32_t>(n_idx);
+    double* dout = a.take<double>(nout);
+    void* ws = a.take<unsigned char>(wsb);
+    FFK_HIP(hipMemcpyAsync(dF, filter_function, nF, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dS, spectrum, nS, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dom, omega, 8*size_t(W), hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(didx, idx, 4*size_t(n_idx), hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_infidelity_dev(dF, A, W, dS, s_ndim, dom, didx, n_idx, d, dout, ws, wsb, nullptr))
+        return rc;
+    FFK_HIP(hipMemcpyAsync(infid, dout, 8*nout, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Liouville representation
+// ---------------------------------------------------------------------------------------------
+size_t ffk_liouville_workspace_bytes(int batch, int d, int N) {
+    if (batch < 1 || N < 1 || !d_ok(d)) return 0;
+    return ffk::liouville_workspace_bytes(batch, d, N);
+}
+
+int ffk_liouville_dev(const double* U, int batch, int d, const double* basis, int N,
+                      int hermitian_basis, double* liouville, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis: batch=%d N=%d", batch, N);
+    FFK_REQUIRE(U && basis && liouville && workspace, "NULL argument");
+    FFK_REQUIRE(workspace_bytes >= ffk_liouville_workspace_bytes(batch, d, N), "workspace too small");
+    FFK_HIP(ffk::launch_liouville(reinterpret_cast<const cplx*>(U), batch, d,
+                                  reinterpret_cast<const cplx*>(basis), N, hermitian_basis, liouville,
+                                  workspace, static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+int ffk_liouville(const double* U, int batch, int d, const double* basis, int N, int hermitian_basis,
+                  double* liouville) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis: batch=%d N=%d", batch, N);
+    FFK_REQUIRE(U && basis && liouville, "NULL argument");
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t dd = size_t(d)*d;
+    const size_t nU = 16*size_t(batch)*dd, nB = 16*size_t(N)*dd;
+    const size_t nL = (hermitian_basis ? 8 : 16)*size_t(batch)*N*N;
+    const size_t wsb = ffk_liouville_workspace_bytes(batch, d, N);
+    void* base;
+    if (int rc = arena_reserve(align_up(nU) + align_up(nB) + align_up(nL) + wsb, &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dU = a.take<double>(nU/8);
+    double* dB = a.take<double>(nB/8);
+    double* dL = a.take<double>(nL/8);
+    void* ws = a.take<unsigned char>(wsb);
+    FFK_HIP(hipMemcpyAsync(dU, U, nU, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dB, basis, nB, hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_liouville_dev(dU, batch, d, dB, N, hermitian_basis, dL, ws, wsb, nullptr)) return rc;
+    FFK_HIP(hipMemcpyAsync(liouville, dL, nL, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused device-resident pipeline
+// ---------------------------------------------------------------------------------------------
+size_t ffk_pipeline_workspace_bytes(int W, int N, int A, int G, int d, int n_idx, int s_ndim) {
+    if (W < 1 || N < 1 || A < 1 || G < 1 || !d_ok(d)) return 0;
+    size_t b = ffk_diagonalize_workspace_bytes(G, d) + ffk_control_matrix_workspace_bytes(W, N, A, G, d);
+    b += align_up(8*size_t(G)*d) + align_up(16*size_t(G)*d*d) + align_up(16*size_t(G + 1)*d*d);
+    b += align_up(16*size_t(A)*N*W) + align_up(16*size_t(A)*A*W);
+    if (n_idx > 0 && s_ndim >= 1 && s_ndim <= 3) b += ffk_infidelity_workspace_bytes(W, n_idx, s_ndim);
+    return b;
+}
+
+int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* t, int G, int d,
+                     const double* omega, int W, const double* basis, int N, const double* n_opers,
+                     int A, const double* n_coeffs, const double* spectrum, int s_ndim,
+                     const int32_t* idx, int n_idx, double* eigvals, double* eigvecs,
+                     double* propagators, double* control_matrix, double* filter_function,
+                     double* infid, void* workspace, size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
+    FFK_REQUIRE(hamiltonian && dt && t && omega && basis && n_opers && n_coeffs && workspace, "NULL argument");
+    const bool want_infid = spectrum != nullptr && infid != nullptr;
+    FFK_REQUIRE(!want_infid || (idx && n_idx >= 1 && s_ndim >= 1 && s_ndim <= 3), "bad spectrum arguments");
+    FFK_REQUIRE(workspace_bytes >= ffk_pipeline_workspace_bytes(W, N, A, G, d, want_infid ? n_idx : 0, s_ndim),
+                "workspace too small");
+    Bump ws(workspace, workspace_bytes);
+    const size_t dwsb = ffk_diagonalize_workspace_bytes(G, d);
+    const size_t cwsb = ffk_control_matrix_workspace_bytes(W, N, A, G, d);
+    void* dws = ws.take<unsigned char>(dwsb);
+    void* cws = ws.take<unsigned char>(cwsb);
+    double* D = eigvals ? eigvals : ws.take<double>(size_t(G)*d);
+    double* V = eigvecs ? eigvecs : ws.take<double>(2*size_t(G)*d*d);
+    double* Q = propagators ? propagators : ws.take<double>(2*size_t(G + 1)*d*d);
+    double* R = control_matrix ? control_matrix : ws.take<double>(2*size_t(A)*N*W);
+    double* F = filter_function ? filter_function : ws.take<double>(2*size_t(A)*A*W);
+    if (int rc = ffk_diagonalize_dev(hamiltonian, dt, G, d, D, V, Q, dws, dwsb, stream)) return rc;
+    if (int rc = ffk_control_matrix_dev(D, V, Q, omega, W, basis, N, n_opers, A, n_coeffs, dt, t, G, d, 0,
+                                        R, nullptr, cws, cwsb, stream))
+        return rc;
+    if (int rc = ffk_filter_function_dev(R, A, N, W, FFK_FF_FIDELITY, F, stream)) return rc;
+    if (want_infid) {
+        const size_t iwsb = ffk_infidelity_workspace_bytes(W, n_idx, s_ndim);
+        void* iws = ws.take<unsigned char>(iwsb);
+        FFK_REQUIRE(iws, "workspace too small");
+        if (int rc = ffk_infidelity_dev(F, A, W, spectrum, s_ndim, omega, idx, n_idx, d, infid, iws, iwsb, stream))
+            return rc;
+    }
+    return FFK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// ffk_internal.h -- launcher declarations shared between the kernel translation units and the
+// C-ABI layer (ffk_api.hip).  Everything here is device-pointer based and asynchronous on the
+// given stream; nothing allocates.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "ffk_math.h"
+
+namespace ffk {
+
+constexpr int kMaxD = 16;
+constexpr int kWave = 64;
+
+// Per-segment uniform table row: [0] = dt_g, [1] = t_g, [2 + m*d + n] = D_m - D_n, padded to a
+// multiple of 8 doubles so each row starts 64-byte aligned (scalar loads).
+__host__ __device__ constexpr int seg_stride(int d) { return ((2 + d*d + 7)/8)*8; }
+
+// Columns of the Hilbert-space accumulator kept per thread in ctrl_accumulate.
+__host__ __device__ constexpr int accum_jb(int d) {
+    return d <= 5 ? d : (d % 3 == 0 && d <= 9 ? 3 : (d % 2 == 0 ? 2 : 1));
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1)/a*a; }
+
+// ---- eigh.hip --------------------------------------------------------------------------------
+// eigvals (G,d), eigvecs (G,d,d), seg_prop (G,d,d) = V exp(-i D dt) V^dag; status: one int,
+// incremented for every matrix whose Jacobi iteration failed to converge.
+hipError_t launch_eigh_expm(const cplx* H, const double* dt, int G, int d, double* eigvals,
+                            cplx* eigvecs, cplx* seg_prop, int* status, hipStream_t stream);
+
+// ---- scan.hip --------------------------------------------------------------------------------
+size_t scan_workspace_bytes(int G, int d);
+// Q (G+1,d,d): Q[0] = 1, Q[g+1] = P[g] Q[g]
+hipError_t launch_prefix_products(const cplx* seg_prop, int G, int d, cplx* Q, void* ws,
+                                  hipStream_t stream);
+
+// ---- prep.hip --------------------------------------------------------------------------------
+// Fills the omega-independent operands of the accumulate kernel:
+//   segtab (G, seg_stride(d)); Tc (G,d,d) = conj(V^dag Q_g); Wt (G,A,d,d,d) with
+//   Wt[g,a,m,n,j] = s_a(g) (V^dag B_a V)[m,n] * (V^dag Q_g)[n,j].
+// Optional reference intermediates (may be NULL): n_opers_transformed (A,G,d,d),
+// eigvecs_propagated (G,d,d) = Q_g^dag V_g.
+hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cplx* propagators,
+                           const cplx* n_opers, const double* n_coeffs, const double* dt,
+                           const double* t, int G, int d, int A, double* segtab, cplx* Tc,
+                           cplx* Wt, cplx* n_opers_transformed, cplx* eigvecs_propagated,
+                           hipStream_t stream);
+// basis_transformed (G,N,d,d) = (Q^dag V)^dag C_k (Q^dag V)   (numeric.py:863-864)
+hipError_t launch_basis_transformed(const cplx* Tc, const cplx* basis, int G, int N, int d,
+                                    cplx* out, hipStream_t stream);
+// phase_factors (G,W) and first_order_integral (G,W,d,d)  (numeric.py:865-866)
+hipError_t launch_phase_and_integral(const double* omega, int W, const double* segtab, int G,
+                                     int d, cplx* phase_factors, cplx* integral,
+                                     hipStream_t stream);
+
+// ---- ctrl.hip --------------------------------------------------------------------------------
+struct AccumGeometry {
+    int chunks;       // segment chunks (grid.z)
+    int chunk_len;    // segments per chunk
+    int nwaves;       // waves per block
+    int task_groups;  // grid.y
+    int lds_bytes;
+    int nbuf;
+};
+AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks);
+// Ypart (chunks, A, d, d, W): partial Hilbert-space sums, omega fastest
+hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* Wt,
+                             const cplx* Tc, int G, int d, int A, const AccumGeometry& geo,
+                             cplx* Ypart, hipStream_t stream);
+
+// ---- post.hip --------------------------------------------------------------------------------
+// Bt (A,d,d,W) = sum over chunks of Ypart
+hipError_t launch_reduce_chunks(const cplx* Ypart, int chunks, size_t slab, cplx* Bt,
+                                hipStream_t stream);
+// R (A2,N,W) with R[a,k,w] = sum_ij Bt[a,i,j,w] C_k[j,i];  A2 = any leading batch
+hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d, int W, cplx* R,
+                         hipStream_t stream);
+// out (W,A,d,d) from Bt (A,d,d,W)
+hipError_t launch_transpose_noise_ops(const cplx* Bt, int A, int d, int W, cplx* out,
+                                      hipStream_t stream);
+hipError_t launch_filter_function(const cplx* R, int A, int N, int W, int which, cplx* F,
+                                  hipStream_t stream);
+size_t infidelity_workspace_bytes(int W, int n_idx, int s_ndim);
+hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_ndim,
+                             const double* omega, const int32_t* idx, int n_idx, int d,
+                             double* infid, void* ws, hipStream_t stream);
+
+// ---- liouville.hip ---------------------------------------------------------------------------
+size_t liouville_workspace_bytes(int batch, int d, int N);
+hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, int N,
+                            int hermitian, double* out, void* ws, hipStream_t stream);
+
+}  // namespace ffk

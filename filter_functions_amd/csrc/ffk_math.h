@@ -1,0 +1,140 @@
+// ffk_math.h -- scalar FP64 building blocks shared by every kernel of the filter-function path.
+//
+// All functions are __host__ __device__ so that tests/ can compile them for the host (a
+// test-only harness, tests/csrc/) and check them against NumPy without a GPU; the product
+// library only ever runs them on the device.
+//
+// Rounding contract (DESIGN.md "Numerics"): the reference evaluates sin/cos at the *rounded*
+// arguments fl(omega*t_g) (numeric.py:865) and fl(fl(omega + dE)*dt) (numeric.py:155-163).
+// For omega*t up to ~1e6 the rounding of the argument itself is worth ~1e-10 relative in the
+// result, so the kernels form exactly the same double-precision arguments and only the
+// sin/cos implementation (<= ~1 ulp) differs from NumPy's.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#define FFK_HD __host__ __device__ __forceinline__
+
+namespace ffk {
+
+struct cplx {
+    double re, im;
+};
+
+FFK_HD cplx cmul(cplx a, cplx b) {
+    return {fma(a.re, b.re, -(a.im*b.im)), fma(a.re, b.im, a.im*b.re)};
+}
+// acc += a*b
+FFK_HD void cmac(cplx& acc, cplx a, cplx b) {
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(-a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im);
+    acc.im = fma(a.im, b.re, acc.im);
+}
+// acc += conj(a)*b
+FFK_HD void cmac_conj(cplx& acc, cplx a, cplx b) {
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im);
+    acc.im = fma(-a.im, b.re, acc.im);
+}
+
+// ---------------------------------------------------------------------------------------
+// sincos for |x| < ~2^50: 3-term Cody-Waite reduction with FMA (pi/2 = P1 + P2 + P3 carries
+// ~160 bits, so the reduction error stays ~1e-16 absolute for every k that is an exact
+// double), then the classic minimax kernels on [-pi/4, pi/4] (13th/14th degree; the
+// coefficients are the widely published fdlibm k_sin/k_cos constants).  Max error observed
+// against NumPy on random arguments up to 1e8: 1 ulp (tests/test_math_host.py).
+// round-to-nearest and the quadrant come from the 1.5*2^52 "magic number" addition: the low
+// mantissa bits of t hold the integer k.  NaN/Inf give NaN.
+// ---------------------------------------------------------------------------------------
+FFK_HD void sincos_reduced(double r, double* s, double* c) {
+    const double z = r*r;
+    // sin
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    *s = fma(r*z, ps, r);
+    // cos
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5*z;
+    const double w = 1.0 - hz;
+    *c = w + (((1.0 - w) - hz) + z*z*pc);
+}
+
+FFK_HD unsigned low_word(double t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return static_cast<unsigned>(__double2loint(t));
+#else
+    unsigned long long bits;
+    __builtin_memcpy(&bits, &t, sizeof bits);
+    return static_cast<unsigned>(bits);
+#endif
+}
+
+FFK_HD void sincos_pi(double x, double* s, double* c) {
+    const double kMagic = 6755399441055744.0;                     // 1.5 * 2^52
+    const double t = fma(x, 6.36619772367581382433e-01, kMagic);  // x * 2/pi, rounded to integer
+    const unsigned q = low_word(t);
+    const double k = t - kMagic;
+    double r = fma(-k, 1.57079632679489655800e+00, x);            // pi/2 high
+    r = fma(-k, 6.12323399573676603587e-17, r);                   // pi/2 mid
+    r = fma(-k, -1.49738490485916983294e-33, r);                  // pi/2 low
+    double sr, cr;
+    sincos_reduced(r, &sr, &cr);
+    const double s0 = (q & 1u) ? cr : sr;
+    const double c0 = (q & 1u) ? sr : cr;
+    *s = (q & 2u) ? -s0 : s0;
+    *c = ((q + 1u) & 2u) ? -c0 : c0;
+}
+
+// Reciprocal to ~1 ulp.  Device: v_rcp_f64 seed + two Newton steps; host: plain division.
+FFK_HD double rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+#else
+    return 1.0/x;
+#endif
+}
+
+// First-order Magnus integral of one (m, n) entry, numeric.py:144-167 with util.cexpm1
+// (util.py:165-182):
+//     I = (exp(i x dt) - 1)/(i x),  x = omega + dE,  I = dt where x == 0 exactly.
+// exp(iy) - 1 = -2 sin^2(y/2) + i sin(y) and sin(y) = 2 sin(y/2) cos(y/2), so with
+// s = sin(y/2), c = cos(y/2):  I = (2 s / x) (c + i s).  Cancellation free like the
+// reference's form; one sincos instead of two sin.
+FFK_HD cplx first_order_integral(double omega, double dE, double dt) {
+    const double x = omega + dE;              // same rounding as np.add.outer(E, dE)
+    const double y = x*dt;                    // same rounding as int_buf.imag*dt
+    double s, c;
+    sincos_pi(0.5*y, &s, &c);
+    const double q = 2.0*s*rcp(x);
+    cplx out = {q*c, q*s};
+    if (x == 0.0) {
+        out.re = dt;
+        out.im = 0.0;
+    }
+    return out;
+}
+
+// exp(i x) as (cos, sin), util.py:136-162
+FFK_HD cplx cexp(double x) {
+    cplx out;
+    sincos_pi(x, &out.im, &out.re);
+    return out;
+}
+
+}  // namespace ffk

@@ -1,0 +1,156 @@
+// liouville.hip -- K5: superoperator.liouville_representation (superoperator.py:51-84 followed
+// by Basis.expand basis.py:650-698):  L[b,i,j] = tr(U_b^dag C_i U_b C_j).
+//
+// Two steps.  (1) conjugate the basis, CB[b,i] = U_b^dag C_i U_b, one wavefront per (b, i), and
+// scatter it as a REAL operand matrix.  (2) the contraction over the d^2 matrix entries is the
+// one genuine dense GEMM of the path (N x 2d^2 by 2d^2 x N per batch element); it runs on the
+// FP64 matrix cores, v_mfma_f64_16x16x4_f64, one 16 x 16 output tile per wavefront.
+//   Re L[i,j] = sum_ab  Re CB_i[a,b] Re C_j[b,a] - Im CB_i[a,b] Im C_j[b,a]
+//   Im L[i,j] = sum_ab  Im CB_i[a,b] Re C_j[b,a] + Re CB_i[a,b] Im C_j[b,a]
+// so with K = 2 d^2 and  Bop[kk][j] = (Re C_j[b,a] ; Im C_j[b,a]),
+//   AopRe[kk][i] = (Re CB_i[a,b] ; -Im CB_i[a,b]),  AopIm[kk][i] = (Im CB_i[a,b] ; Re CB_i[a,b]).
+// Operands are stored K-major so that the 16 lanes of an MFMA row group read 128 contiguous bytes.
+// The imaginary GEMM is skipped for Hermitian bases, where the reference returns the real part
+// only (basis.py:692 `cast`).
+#include "ffk_internal.h"
+
+namespace ffk {
+namespace {
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+// Bop[kk][j]: kk = b*d + a (Re), d*d + b*d + a (Im) of C_j[b][a]
+__global__ void build_bop_kernel(const cplx* __restrict__ basis, int N, int d, int Npad,
+                                 double* __restrict__ Bop) {
+    const int j = blockIdx.x*blockDim.x + threadIdx.x;
+    const int ab = blockIdx.y;  // a*d + b
+    if (j >= Npad) return;
+    const int a = ab / d, b = ab % d;
+    cplx v = {0.0, 0.0};
+    if (j < N) v = basis[(static_cast<size_t>(j)*d + b)*d + a];
+    Bop[static_cast<size_t>(ab)*Npad + j] = v.re;
+    Bop[static_cast<size_t>(d*d + ab)*Npad + j] = v.im;
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void conjugate_basis_kernel(const cplx* __restrict__ U,
+                                                             const cplx* __restrict__ basis, int N,
+                                                             int Npad, int want_imag,
+                                                             double* __restrict__ AopRe,
+                                                             double* __restrict__ AopIm) {
+    __shared__ cplx Us[D][D];
+    __shared__ cplx C[D][D];
+    __shared__ cplx CU[D][D];
+    const int i = blockIdx.x, bt = blockIdx.y, lane = threadIdx.x;
+    for (int e = lane; e < D*D; e += 64) {
+        Us[e / D][e % D] = U[static_cast<size_t>(bt)*D*D + e];
+        C[e / D][e % D] = basis[static_cast<size_t>(i)*D*D + e];
+    }
+    __syncthreads();
+    for (int e = lane; e < D*D; e += 64) {
+        const int r = e / D, c = e % D;
+        cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < D; ++k) cmac(acc, C[r][k], Us[k][c]);
+        CU[r][c] = acc;
+    }
+    __syncthreads();
+    const size_t K = (2*D*D + 3)/4*4;  // padded to the MFMA k-step; pad rows stay zero
+    double* are = AopRe + static_cast<size_t>(bt)*K*Npad;
+    double* aim = AopIm + static_cast<size_t>(bt)*K*Npad;
+    for (int e = lane; e < D*D; e += 64) {
+        const int a = e / D, b = e % D;  // CB[a][b] = sum_k conj(U[k][a]) CU[k][b]
+        cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < D; ++k) cmac_conj(acc, Us[k][a], CU[k][b]);
+        are[static_cast<size_t>(e)*Npad + i] = acc.re;
+        are[static_cast<size_t>(D*D + e)*Npad + i] = -acc.im;
+        if (want_imag) {
+            aim[static_cast<size_t>(e)*Npad + i] = acc.im;
+            aim[static_cast<size_t>(D*D + e)*Npad + i] = acc.re;
+        }
+    }
+}
+
+// One wavefront per 16x16 tile of L = Aop^T Bop.  v_mfma_f64_16x16x4_f64 operand maps
+// (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// D[row = (lane>>4) + 4 r][col = lane&15] for result register r = 0..3.
+__global__ __launch_bounds__(64) void liouville_gemm_kernel(const double* __restrict__ AopRe,
+                                                            const double* __restrict__ AopIm,
+                                                            const double* __restrict__ Bop, int N,
+                                                            int Npad, int K, int want_imag,
+                                                            double* __restrict__ out) {
+    const int lane = threadIdx.x;
+    const int ti = blockIdx.x, tj = blockIdx.y, bt = blockIdx.z;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const double* are = AopRe + static_cast<size_t>(bt)*K*Npad + ti*16 + l15;
+    const double* aim = AopIm + static_cast<size_t>(bt)*K*Npad + ti*16 + l15;
+    const double* bop = Bop + tj*16 + l15;
+    f64x4 cre = {0.0, 0.0, 0.0, 0.0}, cim = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const size_t row = static_cast<size_t>(k0 + lk)*Npad;
+        const double b = bop[row];
+        cre = __builtin_amdgcn_mfma_f64_16x16x4f64(are[row], b, cre, 0, 0, 0);
+        if (want_imag) cim = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[row], b, cim, 0, 0, 0);
+    }
+    const int col = tj*16 + l15;
+    if (col >= N) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rowi = ti*16 + lk + 4*r;
+        if (rowi >= N) continue;
+        const size_t o = (static_cast<size_t>(bt)*N + rowi)*N + col;
+        if (want_imag) {
+            out[2*o] = cre[r];
+            out[2*o + 1] = cim[r];
+        } else {
+            out[o] = cre[r];
+        }
+    }
+}
+
+}  // namespace
+
+size_t liouville_workspace_bytes(int batch, int d, int N) {
+    const size_t Npad = (static_cast<size_t>(N) + 15)/16*16;
+    const size_t K = (2*static_cast<size_t>(d)*d + 3)/4*4;
+    return align_up(K*Npad*sizeof(double)) + 2*align_up(static_cast<size_t>(batch)*K*Npad*sizeof(double));
+}
+
+hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, int N,
+                            int hermitian, double* out, void* ws, hipStream_t stream) {
+    const int Npad = (N + 15)/16*16;
+    const int K = (2*d*d + 3)/4*4;
+    const int want_imag = hermitian ? 0 : 1;
+    unsigned char* p = static_cast<unsigned char*>(ws);
+    double* Bop = reinterpret_cast<double*>(p);
+    p += align_up(static_cast<size_t>(K)*Npad*sizeof(double));
+    double* AopRe = reinterpret_cast<double*>(p);
+    p += align_up(static_cast<size_t>(batch)*K*Npad*sizeof(double));
+    double* AopIm = reinterpret_cast<double*>(p);
+    if (batch > 65535 || d*d > 65535) return hipErrorInvalidValue;
+
+    // zero everything once: padding rows (K) and columns (N -> Npad) must contribute nothing
+    hipError_t err = hipMemsetAsync(ws, 0, liouville_workspace_bytes(batch, d, N), stream);
+    if (err != hipSuccess) return err;
+    hipLaunchKernelGGL(build_bop_kernel, dim3((Npad + 63)/64, d*d), dim3(64), 0, stream, basis, N, d,
+                       Npad, Bop);
+    switch (d) {
+#define FFK_CASE(D)                                                                              \
+    case D:                                                                                      \
+        hipLaunchKernelGGL(conjugate_basis_kernel<D>, dim3(N, batch), dim3(64), 0, stream, U,    \
+                           basis, N, Npad, want_imag, AopRe, AopIm);                             \
+        break;
+        FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
+        FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
+        FFK_CASE(15) FFK_CASE(16)
+#undef FFK_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(liouville_gemm_kernel, dim3(Npad/16, Npad/16, batch), dim3(64), 0, stream,
+                       AopRe, AopIm, Bop, N, Npad, K, want_imag, out);
+    return hipGetLastError();
+}
+
+}  // namespace ffk

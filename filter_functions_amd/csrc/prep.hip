@@ -1,0 +1,200 @@
+// prep.hip -- omega-independent operands of the control-matrix accumulation, one wavefront per
+// segment, plus the two "cache_intermediates" side products that are cheap element-wise maps.
+//
+// Reference arithmetic restated here:
+//   T_g = V_g^dag Q_g                         (_propagate_eigenvectors, numeric.py:93-95, :577)
+//   Bbar_a^(g) = s_a(g) V_g^dag B_a V_g       (_transform_hamiltonian, numeric.py:98-141)
+//   dE^(g)[m,n] = D_m - D_n                   (np.subtract.outer, numeric.py:155)
+// and, new in this design, the folded operand
+//   Wt[g,a,m,n,j] = Bbar_a^(g)[m,n] * T_g[n,j]
+// which lets the hot loop form  Z = (Bbar o I') T  as one uniform-operand product.
+#include "ffk_internal.h"
+
+namespace ffk {
+namespace {
+
+template <int D>
+__global__ __launch_bounds__(64) void prologue_kernel(
+    const double* __restrict__ eigvals, const cplx* __restrict__ eigvecs,
+    const cplx* __restrict__ propagators, const cplx* __restrict__ n_opers,
+    const double* __restrict__ n_coeffs, const double* __restrict__ dt,
+    const double* __restrict__ t, int G, int A, double* __restrict__ segtab,
+    cplx* __restrict__ Tc, cplx* __restrict__ Wt, cplx* __restrict__ n_opers_transformed,
+    cplx* __restrict__ eigvecs_propagated) {
+    __shared__ cplx V[D][D];
+    __shared__ cplx Q[D][D];
+    __shared__ cplx T[D][D];
+    __shared__ cplx BV[D][D];
+    __shared__ cplx Bbar[D][D];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    constexpr int S = seg_stride(D);
+
+    for (int e = lane; e < D*D; e += 64) {
+        V[e / D][e % D] = eigvecs[static_cast<size_t>(g)*D*D + e];
+        Q[e / D][e % D] = propagators[static_cast<size_t>(g)*D*D + e];
+    }
+    double* st = segtab + static_cast<size_t>(g)*S;
+    if (lane == 0) {
+        st[0] = dt[g];
+        st[1] = t[g];
+    }
+    for (int e = lane; e < D*D; e += 64)
+        st[2 + e] = eigvals[static_cast<size_t>(g)*D + e / D] - eigvals[static_cast<size_t>(g)*D + e % D];
+    for (int e = 2 + D*D + lane; e < S; e += 64) st[e] = 0.0;
+    __syncthreads();
+
+    // T = V^dag Q
+    for (int e = lane; e < D*D; e += 64) {
+        const int m = e / D, j = e % D;
+        cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < D; ++k) cmac_conj(acc, V[k][m], Q[k][j]);
+        T[m][j] = acc;
+        Tc[static_cast<size_t>(g)*D*D + e] = {acc.re, -acc.im};
+        // eigvecs_propagated = Q^dag V = T^dag:  [i][j] = conj(T[j][i])
+        if (eigvecs_propagated)
+            eigvecs_propagated[static_cast<size_t>(g)*D*D + j*D + m] = {acc.re, -acc.im};
+    }
+    __syncthreads();
+
+    for (int a = 0; a < A; ++a) {
+        const cplx* B = n_opers + static_cast<size_t>(a)*D*D;
+        const double s = n_coeffs[static_cast<size_t>(a)*G + g];
+        // BV = B V
+        for (int e = lane; e < D*D; e += 64) {
+            const int i = e / D, n = e % D;
+            cplx acc = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < D; ++k) cmac(acc, B[i*D + k], V[k][n]);
+            BV[i][n] = acc;
+        }
+        __syncthreads();
+        // Bbar = s V^dag BV
+        for (int e = lane; e < D*D; e += 64) {
+            const int m = e / D, n = e % D;
+            cplx acc = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < D; ++k) cmac_conj(acc, V[k][m], BV[k][n]);
+            acc.re *= s;
+            acc.im *= s;
+            Bbar[m][n] = acc;
+            if (n_opers_transformed)
+                n_opers_transformed[(static_cast<size_t>(a)*G + g)*D*D + e] = acc;
+        }
+        __syncthreads();
+        // Wt[g,a,m,n,j] = Bbar[m,n] T[n,j]
+        cplx* Wg = Wt + (static_cast<size_t>(g)*A + a)*D*D*D;
+        for (int e = lane; e < D*D*D; e += 64) {
+            const int m = e/(D*D), n = (e / D) % D, j = e % D;
+            Wg[e] = cmul(Bbar[m][n], T[n][j]);
+        }
+        __syncthreads();
+    }
+}
+
+// out[g,k] = T_g C_k T_g^dag with T_g = conj(Tc[g])   (= (Q^dag V)^dag C_k (Q^dag V))
+template <int D>
+__global__ __launch_bounds__(64) void basis_transformed_kernel(const cplx* __restrict__ Tc,
+                                                               const cplx* __restrict__ basis,
+                                                               int N, cplx* __restrict__ out) {
+    __shared__ cplx T[D][D];
+    __shared__ cplx C[D][D];
+    __shared__ cplx TC[D][D];
+    const int k = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    for (int e = lane; e < D*D; e += 64) {
+        const cplx v = Tc[static_cast<size_t>(g)*D*D + e];
+        T[e / D][e % D] = {v.re, -v.im};
+        C[e / D][e % D] = basis[static_cast<size_t>(k)*D*D + e];
+    }
+    __syncthreads();
+    for (int e = lane; e < D*D; e += 64) {
+        const int i = e / D, j = e % D;
+        cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < D; ++a) cmac(acc, T[i][a], C[a][j]);
+        TC[i][j] = acc;
+    }
+    __syncthreads();
+    for (int e = lane; e < D*D; e += 64) {
+        const int i = e / D, j = e % D;
+        cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            const cplx tj = T[j][a];  // (T^dag)[a][j] = conj(T[j][a])
+            cmac_conj(acc, tj, TC[i][a]);
+        }
+        out[(static_cast<size_t>(g)*N + k)*D*D + e] = acc;
+    }
+}
+
+// phase_factors[g,w] = exp(i w t_g); integral[g,w,m,n] per numeric.py:144-167
+__global__ void phase_integral_kernel(const double* __restrict__ omega, int W,
+                                      const double* __restrict__ segtab, int d, int S,
+                                      cplx* __restrict__ phase_factors,
+                                      cplx* __restrict__ integral) {
+    const int g = blockIdx.y;
+    const int w = blockIdx.x*blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    const double* st = segtab + static_cast<size_t>(g)*S;
+    const double om = omega[w];
+    if (phase_factors) phase_factors[static_cast<size_t>(g)*W + w] = cexp(om*st[1]);
+    if (integral) {
+        cplx* out = integral + (static_cast<size_t>(g)*W + w)*d*d;
+        for (int e = 0; e < d*d; ++e) out[e] = first_order_integral(om, st[2 + e], st[0]);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cplx* propagators,
+                           const cplx* n_opers, const double* n_coeffs, const double* dt,
+                           const double* t, int G, int d, int A, double* segtab, cplx* Tc,
+                           cplx* Wt, cplx* n_opers_transformed, cplx* eigvecs_propagated,
+                           hipStream_t stream) {
+    switch (d) {
+#define FFK_CASE(D)                                                                             \
+    case D:                                                                                     \
+        hipLaunchKernelGGL(prologue_kernel<D>, dim3(G), dim3(64), 0, stream, eigvals, eigvecs,  \
+                           propagators, n_opers, n_coeffs, dt, t, G, A, segtab, Tc, Wt,         \
+                           n_opers_transformed, eigvecs_propagated);                            \
+        break;
+        FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
+        FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
+        FFK_CASE(15) FFK_CASE(16)
+#undef FFK_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_basis_transformed(const cplx* Tc, const cplx* basis, int G, int N, int d,
+                                    cplx* out, hipStream_t stream) {
+    switch (d) {
+#define FFK_CASE(D)                                                                            \
+    case D:                                                                                    \
+        hipLaunchKernelGGL(basis_transformed_kernel<D>, dim3(N, G), dim3(64), 0, stream, Tc,   \
+                           basis, N, out);                                                     \
+        break;
+        FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
+        FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
+        FFK_CASE(15) FFK_CASE(16)
+#undef FFK_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_phase_and_integral(const double* omega, int W, const double* segtab, int G,
+                                     int d, cplx* phase_factors, cplx* integral,
+                                     hipStream_t stream) {
+    if (!phase_factors && !integral) return hipSuccess;
+    const int block = 128;
+    hipLaunchKernelGGL(phase_integral_kernel, dim3((W + block - 1)/block, G), dim3(block), 0,
+                       stream, omega, W, segtab, d, seg_stride(d), phase_factors, integral);
+    return hipGetLastError();
+}
+
+}  // namespace ffk

@@ -1,0 +1,105 @@
+"""HBM-resident execution of the fused pipeline (``ffk_pipeline_dev``).
+
+``DevicePipeline`` uploads one pulse and one omega block once, owns the output and scratch
+buffers, and then launches the whole path -- diagonalise, control matrix, filter function,
+(optionally) infidelity -- asynchronously on a stream with no host transfers, allocations or
+synchronisation.  Device memory and streams come from PyTorch-ROCm (plumbing); the kernels are
+libffk's, addressed through raw device pointers.  Used by bench.py and by the multi-GPU driver.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+__all__ = ['DevicePipeline']
+
+
+class DevicePipeline:
+    """One pulse (c_opers/c_coeffs/n_opers/n_coeffs/dt/basis) on one omega block.
+
+    spectrum: optional, shape ([[n_idx,] n_idx,] W); idx: noise-operator indices (default all).
+    """
+
+    def __init__(self, c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum=None,
+                 idx=None, device=None):
+        import torch
+        self.torch = torch
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        c_opers = np.asarray(c_opers, dtype=complex)
+        H = np.einsum('ijk,il->ljk', c_opers, np.asarray(c_coeffs, dtype=float))
+        dt = np.asarray(dt, dtype=float)
+        t = np.concatenate(([0], dt.cumsum()))          # same expression as the reference
+        self.G, self.d = H.shape[0], H.shape[1]
+        self.A, self.N, self.W = len(n_opers), len(basis), len(omega)
+        up = self._upload
+        self.H, self.dt, self.t = up(H, complex), up(dt, float), up(t, float)
+        self.omega = up(omega, float)
+        self.basis = up(np.asarray(basis), complex)
+        self.n_opers, self.n_coeffs = up(n_opers, complex), up(n_coeffs, float)
+        self.s_ndim, self.n_idx = 0, 0
+        self.spectrum = self.idx = self.infid = None
+        if spectrum is not None:
+            self.set_spectrum(spectrum, idx)
+        kw = dict(device=self.device)
+        self.eigvals = torch.empty((self.G, self.d), dtype=torch.float64, **kw)
+        self.eigvecs = torch.empty((self.G, self.d, self.d), dtype=torch.complex128, **kw)
+        self.propagators = torch.empty((self.G + 1, self.d, self.d), dtype=torch.complex128, **kw)
+        self.control_matrix = torch.empty((self.A, self.N, self.W), dtype=torch.complex128, **kw)
+        self.filter_function = torch.empty((self.A, self.A, self.W), dtype=torch.complex128, **kw)
+        lib = _lib.load()
+        self.ws_bytes = lib.ffk_pipeline_workspace_bytes(self.W, self.N, self.A, self.G, self.d,
+                                                         max(self.n_idx, self.A), 3)
+        if self.ws_bytes == 0:
+            raise ValueError('unsupported problem shape')
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, **kw)
+
+    def _upload(self, arr, dtype):
+        return self.torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(self.device)
+
+    def set_spectrum(self, spectrum, idx=None):
+        from . import util
+        idx = np.arange(self.A) if idx is None else np.asarray(idx)
+        S = util.parse_spectrum(np.asanyarray(spectrum), np.empty(self.W), idx)
+        self.s_ndim, self.n_idx = S.ndim, len(idx)
+        self.spectrum = self._upload(S, complex)
+        self.idx = self._upload(idx, np.int32)
+        self.infid = self.torch.empty((self.n_idx, self.n_idx) if S.ndim == 3 else (self.n_idx,),
+                                      dtype=self.torch.float64, device=self.device)
+
+    @staticmethod
+    def _p(tensor):
+        return None if tensor is None else ctypes.c_void_p(tensor.data_ptr())
+
+    def launch(self, stream=None, with_infidelity=True):
+        """Enqueue one pass of the hot path on *stream* (default: torch's current stream)."""
+        s = self.torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        p = self._p
+        do_inf = with_infidelity and self.spectrum is not None
+        check(_lib.load().ffk_pipeline_dev(
+            p(self.H), p(self.dt), p(self.t), self.G, self.d, p(self.omega), self.W, p(self.basis),
+            self.N, p(self.n_opers), self.A, p(self.n_coeffs),
+            p(self.spectrum) if do_inf else None, self.s_ndim, p(self.idx) if do_inf else None,
+            self.n_idx, p(self.eigvals), p(self.eigvecs), p(self.propagators),
+            p(self.control_matrix), p(self.filter_function), p(self.infid) if do_inf else None,
+            p(self.workspace), self.ws_bytes, ctypes.c_void_p(s)))
+
+    def infidelity_from(self, filter_function, omega, spectrum, idx, stream=None):
+        """Device trapezoid on an arbitrary (gathered) F: tensors in, tensor out."""
+        torch = self.torch
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        A, W = filter_function.shape[0], filter_function.shape[-1]
+        n_idx = idx.numel()
+        s_ndim = spectrum.dim()
+        out = torch.empty((n_idx, n_idx) if s_ndim == 3 else (n_idx,), dtype=torch.float64,
+                          device=self.device)
+        lib = _lib.load()
+        need = lib.ffk_infidelity_workspace_bytes(W, n_idx, s_ndim)
+        if getattr(self, '_iws', None) is None or self._iws.numel() < need:
+            self._iws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        p = self._p
+        check(lib.ffk_infidelity_dev(p(filter_function), A, W, p(spectrum), s_ndim, p(omega),
+                                     p(idx), n_idx, self.d, p(out), p(self._iws), need,
+                                     ctypes.c_void_p(s)))
+        return out

@@ -1,0 +1,284 @@
+"""The numeric hot path, served by hand-written HIP kernels behind libffk's C ABI.
+
+Same free-function surface as ``filter_functions/numeric.py`` for the path:
+
+====================================================  ==============================
+this module                                           reference (file:line)
+====================================================  ==============================
+:func:`diagonalize`                                   numeric.py:1886-1935
+:func:`calculate_control_matrix_from_scratch`         numeric.py:707-881
+:func:`calculate_noise_operators_from_scratch`        numeric.py:456-618
+:func:`calculate_filter_function`                     numeric.py:1413-1467
+:func:`infidelity`                                    numeric.py:2062-2334
+====================================================  ==============================
+
+Inputs are borrowed NumPy arrays, outputs are fresh C-contiguous ``complex128`` /
+``float64`` arrays with the reference's shapes.  Every function raises if the HIP
+library or a GPU is missing -- there is no CPU fallback in the product.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib, util
+from ._lib import as_c128, as_f64, check, ptr
+
+__all__ = ['diagonalize', 'calculate_control_matrix_from_scratch',
+           'calculate_noise_operators_from_scratch', 'calculate_filter_function', 'infidelity',
+           'calculate_control_matrix_from_atomic']
+
+
+def _check_d(d):
+    if not 2 <= d <= _lib.MAX_D:
+        raise ValueError(f'Hilbert space dimension d={d} unsupported: need 2 <= d <= {_lib.MAX_D}.')
+
+
+def diagonalize(hamiltonian, dt):
+    r"""Diagonalise a piecewise-constant Hamiltonian (reference numeric.py:1886-1935).
+
+    Parameters
+    ----------
+    hamiltonian: array_like, shape (n_dt, d, d)
+        Only the lower triangle is read (``numpy.linalg.eigh`` default).
+    dt: array_like, shape (n_dt,)
+
+    Returns
+    -------
+    eigvals (n_dt, d) ascending; eigvecs (n_dt, d, d), eigenvectors in columns (defined up to
+    the usual phase / degenerate-subspace gauge); propagators (n_dt+1, d, d) with
+    ``propagators[0] = 1`` and ``propagators[g+1] = V_g exp(-i D_g dt_g) V_g^dag propagators[g]``.
+    """
+    H = as_c128(hamiltonian)
+    dt = as_f64(dt)
+    if H.ndim != 3 or H.shape[1] != H.shape[2]:
+        raise ValueError(f'Expected hamiltonian of shape (n_dt, d, d), not {H.shape}.')
+    G, d, _ = H.shape
+    _check_d(d)
+    if dt.shape != (G,):
+        raise ValueError(f'Expected dt of shape ({G},), not {dt.shape}.')
+    eigvals = np.empty((G, d), dtype=np.float64)
+    eigvecs = np.empty((G, d, d), dtype=np.complex128)
+    propagators = np.empty((G + 1, d, d), dtype=np.complex128)
+    check(_lib.load().ffk_diagonalize(ptr(H), ptr(dt), G, d, ptr(eigvals), ptr(eigvecs),
+                                      ptr(propagators)))
+    return eigvals, eigvecs, propagators
+
+
+def _prepare(eigvals, eigvecs, propagators, omega, n_opers, n_coeffs, dt, t):
+    eigvals = as_f64(eigvals)
+    eigvecs = as_c128(eigvecs)
+    propagators = as_c128(propagators)
+    omega = as_f64(omega)
+    n_opers = as_c128(n_opers)
+    n_coeffs = as_f64(n_coeffs)
+    dt = as_f64(dt)
+    if eigvals.ndim != 2:
+        raise ValueError(f'Expected eigvals of shape (n_dt, d), not {eigvals.shape}.')
+    G, d = eigvals.shape
+    _check_d(d)
+    if t is None:
+        # same expression as the reference (numeric.py:796-797) so that omega*t rounds identically
+        t = np.concatenate(([0], np.asarray(dt).cumsum()))
+    t = as_f64(t)
+    A = len(n_opers)
+    for name, arr, shape in (('eigvecs', eigvecs, (G, d, d)), ('propagators', propagators, (G + 1, d, d)),
+                             ('n_opers', n_opers, (A, d, d)), ('n_coeffs', n_coeffs, (A, G)),
+                             ('dt', dt, (G,)), ('t', t, (G + 1,))):
+        if arr.shape != shape:
+            raise ValueError(f'Expected {name} of shape {shape}, not {arr.shape}.')
+    if omega.ndim != 1:
+        raise ValueError(f'Expected omega to be one-dimensional, not {omega.shape}.')
+    return eigvals, eigvecs, propagators, omega, n_opers, n_coeffs, dt, t, G, d, A
+
+
+def calculate_control_matrix_from_scratch(eigvals, eigvecs, propagators, omega, basis, n_opers,
+                                          n_coeffs, dt, t=None, show_progressbar=False,
+                                          cache_intermediates=False, out=None):
+    r"""Control matrix :math:`\tilde{\mathcal B}_{\alpha k}(\omega)` of a pulse, from scratch
+    (reference numeric.py:707-881).
+
+    Returns ``control_matrix`` of shape (n_nops, n_basis, n_omega); with
+    ``cache_intermediates=True`` returns ``(control_matrix, intermediates)`` where
+    *intermediates* has the reference's keys (numeric.py:871-878).  ``out`` (if given) is
+    overwritten in place and returned.  ``show_progressbar`` is accepted and ignored: the
+    per-segment loop it decorated runs inside one kernel.
+    """
+    (eigvals, eigvecs, propagators, omega, n_opers, n_coeffs, dt, t,
+     G, d, A) = _prepare(eigvals, eigvecs, propagators, omega, n_opers, n_coeffs, dt, t)
+    basis_arr = as_c128(np.asarray(basis))
+    if basis_arr.ndim != 3 or basis_arr.shape[1:] != (d, d):
+        raise ValueError(f'Expected basis of shape (n_basis, {d}, {d}), not {basis_arr.shape}.')
+    N = len(basis_arr)
+    W = len(omega)
+    if out is None:
+        R = np.empty((A, N, W), dtype=np.complex128)
+    else:
+        if out.shape != (A, N, W) or out.dtype != np.complex128 or not out.flags.c_contiguous:
+            raise ValueError(f'out must be a C-contiguous complex128 array of shape {(A, N, W)}.')
+        R = out
+    lib = _lib.load()
+    if W == 0:
+        R[...] = 0
+    else:
+        check(lib.ffk_control_matrix(ptr(eigvals), ptr(eigvecs), ptr(propagators), ptr(omega), W,
+                                     ptr(basis_arr), N, ptr(n_opers), A, ptr(n_coeffs), ptr(dt),
+                                     ptr(t), G, d, 0, ptr(R), None))
+    if not cache_intermediates:
+        return R
+
+    inter = dict(
+        n_opers_transformed=np.empty((A, G, d, d), dtype=np.complex128),
+        eigvecs_propagated=np.empty((G, d, d), dtype=np.complex128),
+        basis_transformed=np.empty((G, N, d, d), dtype=np.complex128),
+        phase_factors=np.empty((G, W), dtype=np.complex128),
+        first_order_integral=np.empty((G, W, d, d), dtype=np.complex128),
+        control_matrix_step=np.empty((G, A, N, W), dtype=np.complex128),
+    )
+    if W > 0:
+        check(lib.ffk_control_matrix_intermediates(
+            ptr(eigvals), ptr(eigvecs), ptr(propagators), ptr(omega), W, ptr(basis_arr), N,
+            ptr(n_opers), A, ptr(n_coeffs), ptr(dt), ptr(t), G, d,
+            ptr(inter['n_opers_transformed']), ptr(inter['eigvecs_propagated']),
+            ptr(inter['basis_transformed']), ptr(inter['phase_factors']),
+            ptr(inter['first_order_integral']), ptr(inter['control_matrix_step'])))
+    # running sum over segments, g = 1 .. G-1 (numeric.py:856-861)
+    inter['control_matrix_step_cumulative'] = np.cumsum(inter['control_matrix_step'][:-1], axis=0)
+    return R, inter
+
+
+def calculate_noise_operators_from_scratch(eigvals, eigvecs, propagators, omega, n_opers,
+                                           n_coeffs, dt, t=None, show_progressbar=False,
+                                           cache_intermediates=False):
+    r"""Interaction-picture noise operators :math:`\tilde B_\alpha(\omega)`, shape
+    (n_omega, n_nops, d, d) (reference numeric.py:456-618)."""
+    (eigvals, eigvecs, propagators, omega, n_opers, n_coeffs, dt, t,
+     G, d, A) = _prepare(eigvals, eigvecs, propagators, omega, n_opers, n_coeffs, dt, t)
+    if cache_intermediates:
+        raise NotImplementedError('cache_intermediates is provided for the control matrix '
+                                  '(Liouville) variant only.')
+    W = len(omega)
+    B = np.empty((W, A, d, d), dtype=np.complex128)
+    if W > 0:
+        check(_lib.load().ffk_control_matrix(
+            ptr(eigvals), ptr(eigvecs), ptr(propagators), ptr(omega), W, None, 1, ptr(n_opers), A,
+            ptr(n_coeffs), ptr(dt), ptr(t), G, d, _lib.WANT_NOISE_OPERATORS, None, ptr(B)))
+    return B
+
+
+@util.parse_optional_parameters(which=('fidelity', 'generalized'))
+def calculate_filter_function(control_matrix, which='fidelity'):
+    r"""Filter function from the control matrix (reference numeric.py:1413-1467):
+    'fidelity' -> (n_nops, n_nops, n_omega), 'generalized' -> (n_nops, n_nops, d², d², n_omega)."""
+    R = as_c128(control_matrix)
+    if R.ndim != 3:
+        raise ValueError(f'Expected control_matrix of shape (n_nops, n_basis, n_omega), not {R.shape}.')
+    A, N, W = R.shape
+    shape = (A, A, W) if which == 'fidelity' else (A, A, N, N, W)
+    F = np.empty(shape, dtype=np.complex128)
+    if F.size:
+        check(_lib.load().ffk_filter_function(
+            ptr(R), A, N, W, _lib.FF_FIDELITY if which == 'fidelity' else _lib.FF_GENERALIZED, ptr(F)))
+    return F
+
+
+def _integrate_filter_function(filter_function, spectrum, omega, idx, d):
+    """(1 / 2 pi d) int dw Re(S F): the filter-function branch of ``_get_integrand``
+    (numeric.py:323-325, 351-352, 374) and ``util.integrate`` (util.py:903-906), on the device."""
+    omega = as_f64(omega)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    spectrum = util.parse_spectrum(spectrum, omega, idx)
+    F = as_c128(filter_function)
+    if F.ndim != 3 or F.shape[0] != F.shape[1] or F.shape[2] != len(omega):
+        raise ValueError(f'Expected filter_function of shape (n_nops, n_nops, {len(omega)}), '
+                         f'not {F.shape}.')
+    S = as_c128(spectrum)
+    n_idx = len(idx)
+    out = np.empty((n_idx, n_idx) if S.ndim == 3 else (n_idx,), dtype=np.float64)
+    if len(omega) < 2:
+        out[...] = 0.0
+        return out
+    check(_lib.load().ffk_infidelity(ptr(F), F.shape[0], len(omega), ptr(S), S.ndim, ptr(omega),
+                                     idx.ctypes.data_as(ctypes.c_void_p), n_idx, int(d), ptr(out)))
+    return out
+
+
+@util.parse_optional_parameters(which=('total', 'correlations'))
+def infidelity(pulse, spectrum, omega, n_oper_identifiers=None, which='total',
+               show_progressbar=False, cache_intermediates=False, return_smallness=False,
+               test_convergence=False):
+    r"""Leading-order entanglement infidelity
+    :math:`\frac{1}{2\pi d}\int d\omega\, S(\omega) F(\omega)` (reference numeric.py:2062-2334).
+
+    Same arguments, return shapes and exceptions as the reference: spectrum of shape
+    ([[n_nops,] n_nops,] n_omega); ``test_convergence`` expects a callable spectrum and a dict
+    for *omega*; ``return_smallness`` additionally returns :math:`\xi`.
+    """
+    idx = util.get_indices_from_identifiers(pulse.n_oper_identifiers, n_oper_identifiers)
+
+    if test_convergence:
+        if not callable(spectrum):
+            raise TypeError('Spectrum should be callable when test_convergence == True.')
+        try:
+            omega_IR = omega.get('omega_IR', 2*np.pi/pulse.tau*1e-2)
+        except AttributeError:
+            raise TypeError('omega should be dictionary with parameters '
+                            'when test_convergence == True.') from None
+        omega_UV = omega.get('omega_UV', 2*np.pi/pulse.tau*1e+2)
+        spacing = omega.get('spacing', 'linear')
+        n_min = omega.get('n_min', 100)
+        n_max = omega.get('n_max', 500)
+        n_points = omega.get('n_points', 10)
+        if spacing == 'linear':
+            xspace = np.linspace
+        elif spacing == 'log':
+            xspace = np.geomspace
+        else:
+            raise ValueError("spacing should be either 'linear' or 'log'.")
+        delta_n = (n_max - n_min)//(n_points - 1)
+        n_samples = np.arange(n_min, n_max + delta_n, delta_n)
+        convergence_infids = np.empty((len(n_samples), len(idx)))
+        for i, n in enumerate(n_samples):
+            freqs = xspace(omega_IR, omega_UV, n)
+            convergence_infids[i] = infidelity(pulse, spectrum(freqs), freqs,
+                                               n_oper_identifiers=n_oper_identifiers,
+                                               which='total', cache_intermediates=False)
+        return n_samples, convergence_infids
+
+    spectrum = np.asanyarray(spectrum)
+    if which == 'total':
+        if not pulse.basis.istraceless:
+            raise NotImplementedError(
+                'infidelity() for a basis that is not traceless needs the four-element trace '
+                'tensor (reference numeric.py:2295-2305), which is outside the accelerated path '
+                'in this release.')
+        filter_function = pulse.get_filter_function(omega, which='fidelity',
+                                                    show_progressbar=show_progressbar,
+                                                    cache_intermediates=cache_intermediates)
+        infid = _integrate_filter_function(filter_function, spectrum, omega, idx, pulse.d)
+    else:
+        if pulse.is_cached('omega') and not np.array_equal(pulse.omega, omega):
+            raise ValueError('Pulse correlation infidelities requested '
+                             'but omega not equal to cached frequencies.')
+        F_pc = pulse.get_pulse_correlation_filter_function()
+        # (n_pls, n_pls, n_nops, n_nops, n_omega): one device integral per pulse pair
+        n_pls = F_pc.shape[0]
+        first = _integrate_filter_function(F_pc[0, 0], spectrum, omega, idx, pulse.d)
+        infid = np.empty((n_pls, n_pls) + first.shape)
+        for g in range(n_pls):
+            for h in range(n_pls):
+                infid[g, h] = _integrate_filter_function(F_pc[g, h], spectrum, omega, idx, pulse.d)
+
+    if return_smallness:
+        if spectrum.ndim > 2:
+            raise NotImplementedError('Smallness parameter only implemented '
+                                      'for uncorrelated noise sources')
+        T1 = util.integrate(spectrum, omega)/(2*np.pi)
+        T2 = (pulse.dt*pulse.n_coeffs[idx]).sum(axis=-1)**2
+        T3 = util.abs2(pulse.n_opers[idx]).sum(axis=(1, 2))
+        return infid, np.sqrt((T1*T2*T3).sum())
+    return infid
+
+
+def calculate_control_matrix_from_atomic(*args, **kwargs):
+    raise NotImplementedError('The concatenation rule (reference numeric.py:621-704) is the next '
+                              'row of the scope table (SURVEY.md section 8f.1) and not built yet.')

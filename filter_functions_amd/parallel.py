@@ -1,0 +1,72 @@
+"""Frequency-axis sharding over the GPUs of one node.
+
+Every omega is independent in diagonalize -> control matrix -> filter function; only the
+trapezoid of the infidelity couples neighbours.  One process per GPU (``torch.distributed``,
+backend ``nccl`` = RCCL over xGMI): each rank evaluates a contiguous omega block with the HIP
+pipeline (the tiny omega-independent prologue is recomputed redundantly, cheaper than a
+broadcast), then a single all-gather reassembles F(omega) on every rank, after which the
+infidelity integral runs on the full grid exactly as in the single-GPU case (no halo, no
+all-reduce, bit-identical arithmetic).  torch is plumbing here: device memory, the process
+group and the collective; all arithmetic is libffk's.
+"""
+import numpy as np
+
+__all__ = ['shard_bounds', 'gather_omega_shards', 'sharded_filter_function']
+
+
+def shard_bounds(n_omega, world_size, rank):
+    """Contiguous block [w0, w1) of rank *rank*; block sizes differ by at most one."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f'rank {rank} outside world of size {world_size}')
+    base, extra = divmod(n_omega, world_size)
+    w0 = rank*base + min(rank, extra)
+    return w0, w0 + base + (1 if rank < extra else 0)
+
+
+def gather_omega_shards(local, n_omega, group=None):
+    """All-gather tensors whose LAST axis is this rank's omega block into the full
+    (..., n_omega) tensor, omega fastest, on every rank.
+
+    *local* is a torch tensor (cuda for nccl/RCCL, cpu for gloo) of shape (..., w1 - w0).
+    Uneven blocks are padded to the largest one for the collective and trimmed afterwards.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    lead = local.shape[:-1]
+    widths = [shard_bounds(n_omega, world, r)[1] - shard_bounds(n_omega, world, r)[0]
+              for r in range(world)]
+    wmax = max(widths)
+    send = local
+    if local.shape[-1] != wmax:
+        send = torch.zeros(lead + (wmax,), dtype=local.dtype, device=local.device)
+        send[..., :local.shape[-1]] = local
+    # complex dtypes travel as interleaved reals
+    flat = torch.view_as_real(send.contiguous()) if send.is_complex() else send.contiguous()
+    recv = torch.empty((world,) + flat.shape, dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(recv, flat, group=group)
+    if send.is_complex():
+        recv = torch.view_as_complex(recv)
+    # (world, ..., wmax) -> (..., world, wmax) -> (..., n_omega)
+    nd = recv.dim()
+    perm = tuple(range(1, nd - 1)) + (0, nd - 1)
+    stacked = recv.permute(perm)
+    if all(w == wmax for w in widths):
+        return stacked.reshape(lead + (world*wmax,)).contiguous()
+    parts = [stacked[..., r, :widths[r]] for r in range(world)]
+    return torch.cat(parts, dim=-1).contiguous()
+
+
+def sharded_filter_function(compute_shard, omega, group=None):
+    """Evaluate ``compute_shard(omega_block) -> tensor (..., len(omega_block))`` on this rank's
+    block of *omega* and return the gathered (..., len(omega)) result on every rank."""
+    import torch.distributed as dist
+
+    omega = np.asarray(omega)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    w0, w1 = shard_bounds(len(omega), world, rank)
+    local = compute_shard(omega[w0:w1])
+    return gather_omega_shards(local, len(omega), group=group)

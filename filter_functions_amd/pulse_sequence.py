@@ -1,0 +1,422 @@
+"""``PulseSequence``: the object model and memoising getters in front of the hot path.
+
+Mirrors the part of ``filter_functions/pulse_sequence.py`` that calls into the numeric
+kernels (constructor and input validation 272-310, ``from_arrays`` 312-359, caches and
+``is_cached`` 508-538, ``diagonalize`` 577-586, ``get_control_matrix`` / ``cache_control_matrix``
+588-677, ``get_filter_function`` / ``cache_filter_function`` 691-902, total phases 1056-1084,
+the cached-data properties 1086-1169 and ``cleanup`` 1188-1245) with the same three cache
+dictionaries and keys, the same invalidation rule (assigning a different ``omega`` drops all
+frequency-dependent data) and the same exceptions.  Values in the caches are host ndarrays,
+exactly as in the reference; the arithmetic behind them runs in libffk.
+"""
+import copy
+from itertools import chain, zip_longest
+from types import MappingProxyType
+
+import numpy as np
+
+from . import numeric, util
+from .basis import Basis
+from .superoperator import liouville_representation
+
+__all__ = ['PulseSequence']
+
+
+def _parse_hamiltonian(H, n_dt, H_str):
+    """Unpack ``[[oper, coeffs(, identifier)], ...]`` into arrays sorted by identifier
+    (reference pulse_sequence.py:1286-1337)."""
+    if not util.is_sequence_like(H):
+        raise TypeError(f'Expected {H_str} to be a sequence, not of type {type(H)}!')
+    if not all(util.is_sequence_like(item) for item in H):
+        raise TypeError(f'Expected {H_str} to be a sequence of sequences but found at least one '
+                        'item of H not a sequence!')
+    opers, *rest = zip_longest(*H, fillvalue=None)
+    coeffs = rest[0]
+    identifiers = list(rest[1]) if len(rest) > 1 else None
+    if not all(util.is_sequence_like(coeff) for coeff in coeffs):
+        raise TypeError(f'Expected coefficients in {H_str} to be a sequence')
+    prefix = 'A' if H_str == 'H_c' else 'B'
+    if identifiers is None:
+        identifiers = np.fromiter((f'{prefix}_{i}' for i in range(len(opers))), dtype='<U4')
+    else:
+        identifiers = [f'{prefix}_{i}' if ident is None else ident
+                       for i, ident in enumerate(identifiers)]
+        if len(set(identifiers)) != len(identifiers):
+            raise ValueError(f'{H_str} identifiers should be unique')
+    if not all(len(coeff) == n_dt for coeff in coeffs):
+        raise ValueError(f'Expected all coefficients in {H_str} to be of len(dt) = {n_dt}!')
+    order = np.argsort(identifiers)
+    opers = util.parse_operators(opers, H_str)
+    return opers[order], np.asarray(identifiers)[order], np.asarray(coeffs)[order]
+
+
+class PulseSequence:
+    r"""A piecewise-constant control pulse :math:`H_c(t)=\sum_i a_i(t)A_i` with noise
+    :math:`H_n(t)=\sum_\alpha s_\alpha(t) b_\alpha(t) B_\alpha` (reference
+    pulse_sequence.py:61-271).
+
+    Parameters
+    ----------
+    H_c, H_n: ``[[operator, coefficients(, identifier)], ...]`` with operators (d, d) and
+        coefficients of length ``len(dt)``.
+    dt: sequence of segment durations.
+    basis: :class:`~filter_functions_amd.basis.Basis`, optional (default ``Basis.ggm(d)``).
+    """
+    __array_interface__ = {'shape': (), 'typestr': '|O', 'version': 3}
+
+    def __new__(cls, *args, **kwargs):
+        new = super().__new__(cls)
+        new._data = dict()
+        new._frequency_data = dict()
+        new._intermediates = dict()
+        return new
+
+    def __init__(self, H_c, H_n, dt, basis=None):
+        if not util.is_sequence_like(dt):
+            raise TypeError(f'Expected a sequence of time steps, not {type(dt)}')
+        self.dt = np.asarray(dt)
+        if not np.isreal(self.dt).all():
+            raise ValueError('Times dt are not (all) real!')
+        if (self.dt < 0).any():
+            raise ValueError('Time steps are not (all) positive!')
+        self.c_opers, self.c_oper_identifiers, self.c_coeffs = _parse_hamiltonian(
+            H_c, len(self.dt), 'H_c')
+        self.n_opers, self.n_oper_identifiers, self.n_coeffs = _parse_hamiltonian(
+            H_n, len(self.dt), 'H_n')
+        if self.c_opers.shape[-2:] != self.n_opers.shape[-2:]:
+            raise ValueError('Control and noise Hamiltonian not same dimension!')
+        self.d = self.c_opers.shape[-1]
+        if basis is None:
+            self.basis = Basis.ggm(self.d)
+        else:
+            if not isinstance(basis, Basis):
+                raise ValueError("Expected basis to be an instance of the "
+                                 f"'filter_functions_amd.basis.Basis' class, not {type(basis)}!")
+            if basis.shape[1:] != (self.d, self.d):
+                raise ValueError("Expected basis elements to be of shape "
+                                 f"({self.d}, {self.d}), not {basis.shape[1:]}!")
+            self.basis = basis
+
+    @classmethod
+    def from_arrays(cls, c_opers, c_oper_identifiers, c_coeffs, n_opers, n_oper_identifiers,
+                    n_coeffs, dt, basis=None):
+        """Alternative constructor from already-parsed arrays (reference
+        pulse_sequence.py:312-359)."""
+        new = cls.__new__(cls)
+        new.c_opers = np.asanyarray(c_opers)
+        new.c_oper_identifiers = np.asanyarray(c_oper_identifiers)
+        new.c_coeffs = np.asanyarray(c_coeffs)
+        new.n_opers = np.asanyarray(n_opers)
+        new.n_oper_identifiers = np.asanyarray(n_oper_identifiers)
+        new.n_coeffs = np.asanyarray(n_coeffs)
+        new.dt = np.asanyarray(dt)
+        new.d = new.c_opers.shape[-1]
+        new.basis = np.asanyarray(basis).view(Basis) if basis is not None else Basis.ggm(new.d)
+        if not len(new.c_opers) == len(new.c_oper_identifiers) == len(new.c_coeffs):
+            raise ValueError('Control Hamiltonian not same length!')
+        if not len(new.n_opers) == len(new.n_oper_identifiers) == len(new.n_coeffs):
+            raise ValueError('Noise Hamiltonian not same length!')
+        if not len(set(new.c_opers.shape[1:] + new.n_opers.shape[1:])) == 1:
+            raise ValueError('Control and/or noise Hamiltonian not same, square dimension!')
+        if not new.dt.size == new.n_coeffs.shape[1] == new.c_coeffs.shape[1]:
+            raise ValueError('Time steps not same length!')
+        if not new.basis.d == new.d:
+            raise ValueError('Basis dimension not same as Hamiltonian dimension!')
+        return new
+
+    def __repr__(self):
+        return f'PulseSequence with total duration {self.tau}'
+
+    def __str__(self):
+        return f'{repr(self)}\n\tof dimension {self.d} and duration {self.duration}'
+
+    def __len__(self):
+        return len(self.dt)
+
+    def __getitem__(self, key):
+        """A slice of the pulse as a new PulseSequence (reference pulse_sequence.py:440-484)."""
+        new_dt = np.atleast_1d(self.dt[key])
+        if not new_dt.size:
+            raise IndexError('Cannot create empty PulseSequence')
+        new = self.__class__.from_arrays(
+            c_opers=self.c_opers, n_opers=self.n_opers,
+            c_oper_identifiers=self.c_oper_identifiers,
+            n_oper_identifiers=self.n_oper_identifiers,
+            c_coeffs=np.atleast_2d(self.c_coeffs.T[key]).T,
+            n_coeffs=np.atleast_2d(self.n_coeffs.T[key]).T,
+            dt=new_dt, basis=self.basis)
+        valid = isinstance(key, slice) and key.start in (None, 0) and key.step in (None, 1)
+        if valid and 'control_matrix_step_cumulative' in self._intermediates:
+            new.cache_control_matrix(
+                self.omega, self._intermediates['control_matrix_step_cumulative'][key.stop - 1])
+        return new
+
+    def __copy__(self):
+        copied = self.__class__.__new__(self.__class__)
+        copied.__dict__.update(self.__dict__)
+        copied._data = copy.copy(self._data)
+        copied._frequency_data = copy.copy(self._frequency_data)
+        copied._intermediates = copy.copy(self._intermediates)
+        return copied
+
+    def copy(self):
+        return self.__copy__()
+
+    def __matmul__(self, other):
+        if not isinstance(other, self.__class__):
+            raise TypeError(f'Incompatible type for concatenation: {type(other)}')
+        raise NotImplementedError('Concatenation is the next row of the scope table '
+                                  '(SURVEY.md section 8f.1) and not built yet.')
+
+    # ---- caches --------------------------------------------------------------------------
+    def is_cached(self, attr):
+        """True if *attr* is cached; accepts the reference's human-readable aliases
+        (pulse_sequence.py:508-538)."""
+        data_aliases = {
+            'eigenvalues': 'eigvals', 'eigenvectors': 'eigvecs', 'propagators': 'propagators',
+            'total propagator': 'total_propagator',
+            'total propagator liouville': 'total_propagator_liouville',
+        }
+        frequency_data_aliases = {
+            'frequencies': 'omega', 'total phases': 'total_phases',
+            'filter function': 'filter_function', 'fidelity filter function': 'filter_function',
+            'generalized filter function': 'filter_function_gen',
+            'pulse correlation filter function': 'filter_function_pc',
+            'fidelity pulse correlation filter function': 'filter_function_pc',
+            'generalized pulse correlation filter function': 'filter_function_pc_gen',
+            'second order filter function': 'filter_function_2',
+            'control matrix': 'control_matrix',
+            'pulse correlation control matrix': 'control_matrix_pc',
+        }
+        alias = attr.lower().replace('_', ' ')
+        if alias in data_aliases:
+            return data_aliases[alias] in self._data
+        if alias in frequency_data_aliases:
+            return frequency_data_aliases[alias] in self._frequency_data
+        return (attr in self._intermediates or attr in self._frequency_data
+                or attr in self._data)
+
+    @property
+    def data(self):
+        return MappingProxyType(self._data)
+
+    @property
+    def frequency_data(self):
+        return MappingProxyType(self._frequency_data)
+
+    @property
+    def intermediates(self):
+        return MappingProxyType(self._intermediates)
+
+    @property
+    def t(self):
+        """Absolute segment times [0, cumsum(dt)] (reference pulse_sequence.py:541-544)."""
+        return self._data.setdefault('t', np.concatenate(([0], self.dt.cumsum())))
+
+    @t.setter
+    def t(self, val):
+        self._data['t'] = val
+
+    @property
+    def tau(self):
+        return self._data.setdefault('tau', self.t[-1] if 't' in self._data else self.dt.sum())
+
+    @tau.setter
+    def tau(self, val):
+        self._data['tau'] = val
+
+    @property
+    def duration(self):
+        return self.tau
+
+    # ---- the hot path ----------------------------------------------------------------------
+    def diagonalize(self):
+        """Diagonalise the control Hamiltonian (reference pulse_sequence.py:577-586)."""
+        if not all(self.is_cached(attr) for attr in ('eigvals', 'eigvecs', 'propagators')):
+            hamiltonian = np.einsum('ijk,il->ljk', self.c_opers, self.c_coeffs)
+            self.eigvals, self.eigvecs, self.propagators = numeric.diagonalize(hamiltonian,
+                                                                               self.dt)
+        self.total_propagator = self.propagators[-1]
+
+    def get_control_matrix(self, omega, show_progressbar=False, cache_intermediates=False):
+        """Control matrix (n_nops, d**2, n_omega) for *omega*, memoised
+        (reference pulse_sequence.py:588-636)."""
+        self.omega = omega
+        if self.is_cached('control_matrix'):
+            return self._frequency_data['control_matrix']
+        if self.is_cached('control_matrix_pc'):
+            self._frequency_data['control_matrix'] = np.sum(
+                self._frequency_data['control_matrix_pc'], axis=0)
+            return self._frequency_data['control_matrix']
+        self.diagonalize()
+        control_matrix = numeric.calculate_control_matrix_from_scratch(
+            self.eigvals, self.eigvecs, self.propagators, self.omega, self.basis, self.n_opers,
+            self.n_coeffs, self.dt, self.t, show_progressbar=show_progressbar,
+            cache_intermediates=cache_intermediates)
+        if cache_intermediates:
+            control_matrix, intermediates = control_matrix
+            self._intermediates.update(intermediates)
+        self.cache_control_matrix(self.omega, control_matrix)
+        return self._frequency_data['control_matrix']
+
+    def cache_control_matrix(self, omega, control_matrix=None, show_progressbar=False,
+                             cache_intermediates=False):
+        """Cache the control matrix, total phases and total Liouville propagator
+        (reference pulse_sequence.py:638-677)."""
+        self.omega = omega
+        if control_matrix is None:
+            control_matrix = self.get_control_matrix(self.omega, show_progressbar,
+                                                     cache_intermediates)
+        if control_matrix.ndim == 4:
+            self._frequency_data['control_matrix_pc'] = control_matrix
+        else:
+            self._frequency_data['control_matrix'] = control_matrix
+        self.cache_total_phases(self.omega)
+        if not self.is_cached('total_propagator_liouville'):
+            self.total_propagator_liouville = liouville_representation(self.total_propagator,
+                                                                       self.basis)
+
+    def get_pulse_correlation_control_matrix(self):
+        if self.is_cached('control_matrix_pc'):
+            return self._frequency_data['control_matrix_pc']
+        raise util.CalculationError(
+            "Could not get the pulse correlation control matrix since it "
+            "was not computed during concatenation. Please run the "
+            "concatenation again with 'calc_pulse_correlation_FF' set to True.")
+
+    @util.parse_optional_parameters(which=('fidelity', 'generalized'), order=(1, 2))
+    def get_filter_function(self, omega, which='fidelity', order=1, show_progressbar=False,
+                            cache_intermediates=False, cache_second_order_cumulative=False):
+        """First-order filter function, memoised (reference pulse_sequence.py:691-805):
+        'fidelity' -> (n_nops, n_nops, n_omega); 'generalized' -> (n_nops, n_nops, d², d², n_omega)."""
+        if order != 1:
+            raise NotImplementedError('The second-order filter function is outside the '
+                                      'accelerated path (SURVEY.md section 2, row 14).')
+        self.omega = omega
+        key = 'filter_function' if which == 'fidelity' else 'filter_function_gen'
+        if key in self._frequency_data:
+            return self._frequency_data[key]
+        control_matrix = self.get_control_matrix(self.omega, show_progressbar,
+                                                 cache_intermediates)
+        self.cache_filter_function(self.omega, control_matrix=control_matrix, which=which,
+                                   order=order, show_progressbar=show_progressbar,
+                                   cache_intermediates=cache_intermediates)
+        return self._frequency_data[key]
+
+    @util.parse_optional_parameters(which=('fidelity', 'generalized'), order=(1, 2))
+    def cache_filter_function(self, omega, control_matrix=None, filter_function=None,
+                              which='fidelity', order=1, show_progressbar=False,
+                              cache_intermediates=False, cache_second_order_cumulative=False):
+        """Cache the filter function (reference pulse_sequence.py:807-902)."""
+        if order != 1:
+            raise NotImplementedError('The second-order filter function is outside the '
+                                      'accelerated path (SURVEY.md section 2, row 14).')
+        self.omega = omega
+        if filter_function is None:
+            if control_matrix is None:
+                control_matrix = self.get_control_matrix(self.omega, show_progressbar,
+                                                         cache_intermediates)
+            self.cache_control_matrix(self.omega, control_matrix)
+            if control_matrix.ndim == 4:
+                raise NotImplementedError('Pulse-correlation filter functions belong to the '
+                                          'concatenation path (SURVEY.md section 8f.4).')
+            filter_function = numeric.calculate_filter_function(control_matrix, which)
+        if which == 'fidelity':
+            self._frequency_data['filter_function'] = filter_function
+        else:
+            self._frequency_data['filter_function'] = filter_function.trace(axis1=2, axis2=3)
+            self._frequency_data['filter_function_gen'] = filter_function
+
+    @util.parse_optional_parameters(which=('fidelity', 'generalized'))
+    def get_pulse_correlation_filter_function(self, which='fidelity'):
+        key = 'filter_function_pc' if which == 'fidelity' else 'filter_function_pc_gen'
+        if key in self._frequency_data:
+            return self._frequency_data[key]
+        raise util.CalculationError(
+            "Could not get the pulse correlation filter function since it "
+            "was not computed during concatenation. Please run the "
+            "concatenation again with 'calc_pulse_correlation_FF' set to True.")
+
+    def get_total_phases(self, omega):
+        """exp(i omega tau), memoised (reference pulse_sequence.py:1056-1066)."""
+        self.omega = omega
+        if self.is_cached('total_phases'):
+            return self._frequency_data['total_phases']
+        self.cache_total_phases(self.omega, util.cexp(self.omega*self.tau))
+        return self._frequency_data['total_phases']
+
+    def cache_total_phases(self, omega, total_phases=None):
+        self.omega = omega
+        if total_phases is None:
+            total_phases = self.get_total_phases(self.omega)
+        self._frequency_data['total_phases'] = total_phases
+
+    # ---- cached-data properties ----------------------------------------------------------
+    def _cached(name):  # noqa: N805  (helper evaluated at class-creation time)
+        def getter(self):
+            if name not in self._data:
+                self.diagonalize()
+            return self._data[name]
+
+        def setter(self, value):
+            self._data[name] = value
+        return property(getter, setter)
+
+    eigvals = _cached('eigvals')
+    eigvecs = _cached('eigvecs')
+    propagators = _cached('propagators')
+    total_propagator = _cached('total_propagator')
+    del _cached
+
+    @property
+    def total_propagator_liouville(self):
+        if not self.is_cached('total_propagator_liouville'):
+            self._data['total_propagator_liouville'] = liouville_representation(
+                self.total_propagator, self.basis)
+        return self._data['total_propagator_liouville']
+
+    @total_propagator_liouville.setter
+    def total_propagator_liouville(self, value):
+        self._data['total_propagator_liouville'] = value
+
+    @property
+    def omega(self):
+        return self._frequency_data.get('omega', None)
+
+    @omega.setter
+    def omega(self, value):
+        """Cache the frequencies (a copy); a different grid drops every frequency-dependent
+        entry (reference pulse_sequence.py:1158-1169)."""
+        old = self._frequency_data.get('omega', None)
+        new = np.array(value, copy=True)
+        if not np.array_equal(old, new):
+            self.cleanup('frequency dependent')
+        self._frequency_data['omega'] = new
+
+    @property
+    def nbytes(self):
+        total = 0
+        for val in chain(self._data.values(), self._frequency_data.values(),
+                         self._intermediates.values()):
+            total += getattr(val, 'nbytes', 0)
+        return total
+
+    @util.parse_optional_parameters(method=('conservative', 'greedy', 'frequency dependent', 'all'))
+    def cleanup(self, method='conservative'):
+        """Drop cached by-products (reference pulse_sequence.py:1188-1245)."""
+        if method == 'all':
+            self._data.clear()
+            self._frequency_data.clear()
+            self._intermediates.clear()
+        elif method == 'frequency dependent':
+            self._frequency_data.clear()
+            self._intermediates.clear()
+        else:
+            for key in ('eigvals', 'eigvecs', 'propagators'):
+                self._data.pop(key, None)
+            if method == 'greedy':
+                self._intermediates.clear()
+                for key in ('total_propagator', 'total_propagator_liouville'):
+                    self._data.pop(key, None)
+                for key in ('total_phases', 'control_matrix', 'control_matrix_pc'):
+                    self._frequency_data.pop(key, None)

@@ -1,0 +1,210 @@
+/* ffk.h -- C ABI of libffk.so: the MI355X (gfx950) filter-function hot path.
+ *
+ * This is the drop-in boundary for the numeric hot path of qutech/filter_functions
+ * (reference v1.2.1).  The reference has no FFI of its own: the path sits behind Python
+ * free functions in filter_functions/numeric.py and superoperator.py.  Every entry point
+ * below replaces exactly one of those functions; the citation names the reference
+ * interface (file:line relative to the reference root) whose arguments, array layouts and
+ * results it reproduces.  INTEGRATION.md shows the ctypes stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - All arrays are C-contiguous.  "c128" is complex128 stored interleaved (re, im) as two
+ *     doubles, identical to NumPy's layout; such arrays are passed as `const double*` /
+ *     `double*` and have 2x the element count in doubles.
+ *   - Plain pointers and sizes only.  No torch / numpy types.
+ *   - Every function returns FFK_OK (0) or a negative FFK_E* code; ffk_last_error() returns
+ *     a thread-local message for the last failure.
+ *   - Two flavours per operation:
+ *       ffk_<op>      host pointers in/out; the library stages through its own device
+ *                     arena (H2D, kernels, D2H, synchronous).  This is what the NumPy-
+ *                     facing Python front-end calls.
+ *       ffk_<op>_dev  device pointers in/out, asynchronous on `stream` (a hipStream_t cast
+ *                     to void*, NULL = default stream); scratch memory is supplied by the
+ *                     caller (size from the matching *_workspace_bytes query).  No
+ *                     allocation, no synchronisation: safe to capture in a hipGraph.  This
+ *                     is what bench.py and the multi-GPU driver call with HBM-resident data.
+ *   - d (Hilbert-space dimension) must satisfy 2 <= d <= FFK_MAX_D.
+ *   - Thread-safety: calls on one device are serialised by the caller; the library keeps one
+ *     arena per process and device.
+ */
+#ifndef FFK_H
+#define FFK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFK_VERSION 100 /* 0.1.0 */
+#define FFK_MAX_D 16
+
+#define FFK_OK 0
+#define FFK_EINVAL -1   /* bad argument (shape, NULL, unsupported d) -> ValueError        */
+#define FFK_EHIP -2     /* a HIP runtime call failed -> RuntimeError                       */
+#define FFK_ENOMEM -3   /* device allocation failed / workspace too small -> MemoryError   */
+#define FFK_ENOCONV -4  /* Jacobi eigensolver did not converge -> numpy.linalg.LinAlgError */
+
+/* flags for ffk_control_matrix* */
+#define FFK_WANT_NOISE_OPERATORS 0x1 /* also return B~(w) laid out (W, A, d, d)           */
+
+/* which for ffk_filter_function* (numeric.py:1414 `which`) */
+#define FFK_FF_FIDELITY 0
+#define FFK_FF_GENERALIZED 1
+
+/* ---- library / device management ------------------------------------------------------ */
+const char* ffk_last_error(void);
+int ffk_version(void);
+int ffk_device_count(int* count);
+int ffk_set_device(int device);
+int ffk_get_device(int* device);
+/* name (<= len-1 chars), compute units, total global memory bytes of the current device */
+int ffk_device_info(char* name, int len, int* compute_units, size_t* global_mem_bytes);
+
+/* ---- device memory, streams, events (so a host language without a HIP binding can keep
+ *      data resident and time kernels on the stream they run on) --------------------------- */
+int ffk_malloc(void** dptr, size_t bytes);
+int ffk_free(void* dptr);
+int ffk_memset(void* dptr, int value, size_t bytes, void* stream);
+int ffk_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int ffk_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int ffk_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int ffk_stream_create(void** stream);
+int ffk_stream_destroy(void* stream);
+int ffk_stream_synchronize(void* stream);
+int ffk_device_synchronize(void);
+int ffk_event_create(void** event);
+int ffk_event_destroy(void* event);
+int ffk_event_record(void* event, void* stream);
+int ffk_event_synchronize(void* event);
+int ffk_event_elapsed_ms(void* start, void* stop, float* ms);
+/* release the library's cached device arena (host-pointer flavour) */
+int ffk_release_arena(void);
+
+/* ---- numeric.diagonalize (filter_functions/numeric.py:1886-1935; caller
+ *      pulse_sequence.py:577-586) ----------------------------------------------------------
+ * hamiltonian (G, d, d) c128 -- only the LOWER triangle is read (numpy.linalg.eigh default);
+ * dt (G,) f64.
+ * -> eigvals (G, d) f64 ascending; eigvecs (G, d, d) c128, columns are eigenvectors;
+ *    propagators (G+1, d, d) c128 with propagators[0] = 1 and
+ *    propagators[g+1] = V_g exp(-i D_g dt_g) V_g^dag propagators[g].                        */
+int ffk_diagonalize(const double* hamiltonian, const double* dt, int G, int d,
+                    double* eigvals, double* eigvecs, double* propagators);
+size_t ffk_diagonalize_workspace_bytes(int G, int d);
+int ffk_diagonalize_dev(const double* hamiltonian, const double* dt, int G, int d,
+                        double* eigvals, double* eigvecs, double* propagators,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- numeric.calculate_control_matrix_from_scratch (numeric.py:707-881; callers
+ *      pulse_sequence.py:625, 1843, 2595) and its Hilbert-space twin
+ *      numeric.calculate_noise_operators_from_scratch (numeric.py:456-618) -----------------
+ * eigvals (G, d) f64, eigvecs (G, d, d) c128, propagators (G+1, d, d) c128, omega (W,) f64,
+ * basis (N, d, d) c128, n_opers (A, d, d) c128, n_coeffs (A, G) f64, dt (G,) f64,
+ * t (G+1,) f64 (absolute segment times; t[0] is usually 0).
+ * -> control_matrix (A, N, W) c128, omega fastest (may be NULL if only the noise operators
+ *    are wanted); with FFK_WANT_NOISE_OPERATORS also noise_operators (W, A, d, d) c128,
+ *    omega slowest -- both exactly the reference's layouts.                                */
+int ffk_control_matrix(const double* eigvals, const double* eigvecs, const double* propagators,
+                       const double* omega, int W, const double* basis, int N,
+                       const double* n_opers, int A, const double* n_coeffs, const double* dt,
+                       const double* t, int G, int d, unsigned flags, double* control_matrix,
+                       double* noise_operators);
+size_t ffk_control_matrix_workspace_bytes(int W, int N, int A, int G, int d);
+int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs,
+                           const double* propagators, const double* omega, int W,
+                           const double* basis, int N, const double* n_opers, int A,
+                           const double* n_coeffs, const double* dt, const double* t, int G,
+                           int d, unsigned flags, double* control_matrix,
+                           double* noise_operators, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
+/* The `cache_intermediates=True` products of numeric.py:828-833, 871-878 (materialising,
+ * HBM-bound variant).  Any output pointer may be NULL to skip it.
+ *   n_opers_transformed (A, G, d, d), eigvecs_propagated (G, d, d), basis_transformed
+ *   (G, N, d, d), phase_factors (G, W), first_order_integral (G, W, d, d),
+ *   control_matrix_step (G, A, N, W); all c128.  (control_matrix_step_cumulative is the
+ *   running sum of control_matrix_step and is formed by the host wrapper.)                 */
+int ffk_control_matrix_intermediates(
+    const double* eigvals, const double* eigvecs, const double* propagators,
+    const double* omega, int W, const double* basis, int N, const double* n_opers, int A,
+    const double* n_coeffs, const double* dt, const double* t, int G, int d,
+    double* n_opers_transformed, double* eigvecs_propagated, double* basis_transformed,
+    double* phase_factors, double* first_order_integral, double* control_matrix_step);
+
+/* ---- numeric.calculate_filter_function (numeric.py:1413-1467) --------------------------
+ * control_matrix (A, N, W) c128 -> fidelity: (A, A, W) c128,
+ *                                  generalized: (A, A, N, N, W) c128.                       */
+int ffk_filter_function(const double* control_matrix, int A, int N, int W, int which,
+                        double* filter_function);
+int ffk_filter_function_dev(const double* control_matrix, int A, int N, int W, int which,
+                            double* filter_function, void* stream);
+
+/* ---- numeric.infidelity, filter-function branch (numeric.py:2307-2320 with _get_integrand
+ *      :323-325, :351-352, :374 and util.integrate util.py:880-906) ------------------------
+ * filter_function (A, A, W) c128; omega (W,) f64; idx (n_idx,) int32 noise-operator indices;
+ * spectrum c128 with s_ndim in {1, 2, 3}: (W,), (n_idx, W) or (n_idx, n_idx, W) (already
+ * validated / broadcast by the caller as util.parse_spectrum util.py:214-227 does).
+ * -> infid f64: (n_idx,) for s_ndim 1 or 2, (n_idx, n_idx) for s_ndim 3:
+ *    Re-part trapezoid of S*F over omega, divided by 2 pi d.                                 */
+int ffk_infidelity(const double* filter_function, int A, int W, const double* spectrum,
+                   int s_ndim, const double* omega, const int32_t* idx, int n_idx, int d,
+                   double* infid);
+size_t ffk_infidelity_workspace_bytes(int W, int n_idx, int s_ndim);
+int ffk_infidelity_dev(const double* filter_function, int A, int W, const double* spectrum,
+                       int s_ndim, const double* omega, const int32_t* idx, int n_idx, int d,
+                       double* infid, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- superoperator.liouville_representation (superoperator.py:51-84 + Basis.expand
+ *      basis.py:350-371, 650-698) --------------------------------------------------------
+ * U (batch, d, d) c128, basis (N, d, d) c128 -> liouville (batch, N, N):
+ * L_ij = tr(U^dag C_i U C_j), written as f64 (real part) if `hermitian_basis` != 0 (the
+ * reference casts to real iff basis.isherm), else c128.                                     */
+int ffk_liouville(const double* U, int batch, int d, const double* basis, int N,
+                  int hermitian_basis, double* liouville);
+size_t ffk_liouville_workspace_bytes(int batch, int d, int N);
+int ffk_liouville_dev(const double* U, int batch, int d, const double* basis, int N,
+                      int hermitian_basis, double* liouville, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ---- fused path: PulseSequence.get_filter_function + infidelity in one device-resident
+ *      pass (pulse_sequence.py:577-586, 588-636, 691-902 and numeric.py:2062-2334) ---------
+ * hamiltonian (G, d, d) c128 (lower triangle), dt (G,), omega (W,), basis (N, d, d),
+ * n_opers (A, d, d), n_coeffs (A, G); spectrum/idx/s_ndim as in ffk_infidelity (spectrum
+ * may be NULL: no infidelity).  Outputs (any may be NULL): eigvals, eigvecs, propagators,
+ * control_matrix (A, N, W), filter_function (A, A, W), infid.
+ * `t` is formed on the host by the caller (t = [0, cumsum(dt)]) exactly like the reference
+ * (pulse_sequence.py:534) so the phase arguments omega*t_g round identically.               */
+size_t ffk_pipeline_workspace_bytes(int W, int N, int A, int G, int d, int n_idx, int s_ndim);
+int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* t, int G, int d,
+                     const double* omega, int W, const double* basis, int N,
+                     const double* n_opers, int A, const double* n_coeffs,
+                     const double* spectrum, int s_ndim, const int32_t* idx, int n_idx,
+                     double* eigvals, double* eigvecs, double* propagators,
+                     double* control_matrix, double* filter_function, double* infid,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- tuning / introspection ------------------------------------------------------------ */
+/* Number of segment chunks the control-matrix kernel splits G into (0 = automatic).        */
+int ffk_set_segment_chunks(int chunks);
+/* Per-call statistics of the last ffk_control_matrix*_dev launch on this thread:
+ * algorithmic FP64 flops of the accumulate kernel, its grid/block geometry, chunks used.   */
+typedef struct ffk_stats {
+    double accumulate_flops;   /* FMA-counted real flops of ffk::ctrl_accumulate           */
+    double accumulate_bytes;   /* HBM bytes it must move (inputs + partial sums)            */
+    int chunks;                /* segment chunks                                            */
+    int grid_x, grid_y, grid_z, block;
+    int lds_bytes;
+} ffk_stats;
+int ffk_get_stats(ffk_stats* out);
+/* Profiling hook: when both are non-NULL hipEvent_t handles, the next ffk_control_matrix_dev /
+ * ffk_pipeline_dev calls on this thread record `start` immediately before and `stop`
+ * immediately after the accumulate kernel, on the stream it is launched on (so that a caller
+ * can time the dominant kernel inside its own timed region).  Pass NULLs to switch off.     */
+int ffk_set_accumulate_events(void* start, void* stop);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFK_H */

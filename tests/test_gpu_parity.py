@@ -1,0 +1,370 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against
+(i) golden fixtures generated from the upstream reference, (ii) the reference's own golden
+infidelity vector and analytic DD formulas, (iii) the CPU oracle on seeded inputs up to the full
+BASELINE config-2 size, (iv) size-independent properties.
+
+Tolerance contract (DESIGN.md "Numerics"): for a complex tensor T, max|T - T_ref| <=
+tol * max|T_ref| with tol = 1e-10 as the acceptance bar of BASELINE.json; the assertions below
+use the much tighter values the implementation actually reaches so that regressions show.
+"""
+import numpy as np
+import pytest
+
+import ff_oracle as orc
+import filter_functions_amd as ff
+from conftest import load_golden, rel_err
+from filter_functions_amd import _lib, numeric, util
+
+pytestmark = pytest.mark.gpu
+
+RAND = ['rand_d2_ggm', 'rand_d3_ggm', 'rand_d4_pauli', 'rand_d4_ggm', 'rand_d5_ggm',
+        'rand_d8_pauli', 'rand_d16_ggm', 'edge_degenerate_d4', 'edge_single_segment_d2',
+        'cfg2_small', 'hadamard']
+TOL = 1e-10          # acceptance bar (north_star)
+TIGHT = 2e-13        # what the kernels reach on O(1) data
+
+
+def pulse_from(g):
+    basis = ff.Basis(g['basis'], btype=str(g['btype']))
+    return ff.PulseSequence.from_arrays(g['c_opers'], g['c_oper_identifiers'], g['c_coeffs'],
+                                        g['n_opers'], g['n_oper_identifiers'], g['n_coeffs'],
+                                        g['dt'], basis)
+
+
+def test_native_library_is_the_one_running():
+    assert _lib.device_count() >= 1
+    name, cus, mem = _lib.device_info()
+    assert 'gfx950' in name, name
+    assert cus >= 200 and mem > 100e9
+
+
+@pytest.mark.parametrize('name', RAND)
+def test_diagonalize(name):
+    g = load_golden(name)
+    D, V, Q = numeric.diagonalize(g['H'], g['dt'])
+    assert D.shape == g['eigvals'].shape and V.shape == g['eigvecs'].shape
+    assert Q.shape == g['propagators'].shape
+    scale = max(1.0, np.abs(g['H']).max())
+    assert np.abs(D - g['eigvals']).max() < 1e-13*scale
+    assert rel_err(Q, g['propagators']) < 1e-12
+    assert np.array_equal(Q[0], np.eye(D.shape[1]))
+    assert np.all(np.diff(D, axis=1) >= 0)                      # ascending like eigh
+    for k in range(len(D)):                                     # tests/testutil.py:41-57
+        v = V[k]
+        assert np.abs(v.conj().T @ v - np.eye(len(v))).max() < 1e-13
+        assert np.abs(v.conj().T @ g['H'][k] @ v - np.diag(D[k])).max() < 2e-13*scale
+
+
+def test_diagonalize_reads_lower_triangle_only():
+    g = load_golden('rand_d4_pauli')
+    H = g['H'].copy()
+    H[:, 0, 3] = 123.0                                          # garbage in the upper triangle
+    H[:, 1, 1] += 5j                                            # and on the diagonal's imag part
+    D, V, Q = numeric.diagonalize(H, g['dt'])
+    assert np.abs(D - g['eigvals']).max() < 1e-13
+    assert rel_err(Q, g['propagators']) < 1e-12
+
+
+@pytest.mark.parametrize('name', RAND)
+def test_control_matrix_from_reference_eigensystem(name):
+    g = load_golden(name)
+    R = numeric.calculate_control_matrix_from_scratch(
+        g['eigvals'], g['eigvecs'], g['propagators'], g['omega'], g['basis'], g['n_opers'],
+        g['n_coeffs'], g['dt'], g['t'])
+    assert R.shape == g['control_matrix'].shape and R.dtype == np.complex128
+    assert R.flags.c_contiguous
+    assert rel_err(R, g['control_matrix']) < TIGHT
+    # t=None must give the same (reference numeric.py:796-797)
+    R2 = numeric.calculate_control_matrix_from_scratch(
+        g['eigvals'], g['eigvecs'], g['propagators'], g['omega'], g['basis'], g['n_opers'],
+        g['n_coeffs'], g['dt'])
+    assert np.array_equal(R, R2)
+    # out= is written in place
+    out = np.full_like(R, 7)
+    R3 = numeric.calculate_control_matrix_from_scratch(
+        g['eigvals'], g['eigvecs'], g['propagators'], g['omega'], g['basis'], g['n_opers'],
+        g['n_coeffs'], g['dt'], g['t'], out=out)
+    assert R3 is out and np.array_equal(out, R)
+
+
+@pytest.mark.parametrize('name', RAND)
+def test_noise_operators(name):
+    g = load_golden(name)
+    B = numeric.calculate_noise_operators_from_scratch(
+        g['eigvals'], g['eigvecs'], g['propagators'], g['omega'], g['n_opers'], g['n_coeffs'],
+        g['dt'], g['t'])
+    assert B.shape == g['noise_operators'].shape
+    assert rel_err(B, g['noise_operators']) < TIGHT
+    # Hilbert vs Liouville consistency, tests/test_precision.py:313-353
+    R = orc.basis_expand(B, g['basis']).transpose(1, 2, 0)
+    assert rel_err(R, g['control_matrix']) < TIGHT
+
+
+@pytest.mark.parametrize('name', RAND)
+def test_pulse_sequence_end_to_end(name):
+    """PulseSequence.get_filter_function / infidelity, own eigensolver (gauge-invariant outputs)."""
+    g = load_golden(name)
+    pulse = pulse_from(g)
+    omega = g['omega']
+    F = pulse.get_filter_function(omega)
+    assert rel_err(F, g['filter_function']) < 1e-12
+    assert rel_err(pulse.get_control_matrix(omega), g['control_matrix']) < 1e-12
+    assert np.abs(pulse.eigvals - g['eigvals']).max() < 1e-13*max(1, np.abs(g['H']).max())
+    assert rel_err(pulse.propagators, g['propagators']) < 1e-12
+    assert rel_err(pulse.total_propagator_liouville, g['total_propagator_liouville']) < 1e-12
+    # diagonal of F is real and non-negative (tests/test_core.py:750-760)
+    for a in range(F.shape[0]):
+        assert np.abs(F[a, a].imag).max() <= 1e-15*max(1, np.abs(F).max())
+        assert (F[a, a].real >= 0).all()
+    assert np.allclose(F, F.conj().swapaxes(0, 1), atol=0, rtol=1e-14)
+    # caching semantics: memoised by reference, list/array omega equivalent, re-query with a
+    # different grid recomputes (tests/test_core.py:644-683, :802)
+    assert pulse.get_filter_function(list(omega)) is F
+    assert pulse.is_cached('filter function') and pulse.is_cached('control matrix')
+    F2 = pulse.get_filter_function(omega + 1)
+    assert F2 is not F and not np.array_equal(F2, F)
+    if 'filter_function_gen' in g:
+        pulse = pulse_from(g)
+        Fg = pulse.get_filter_function(omega, which='generalized')
+        assert rel_err(Fg, g['filter_function_gen']) < 1e-12
+        assert rel_err(pulse.get_filter_function(omega), g['filter_function']) < 1e-12
+        assert rel_err(Fg.trace(axis1=2, axis2=3), g['filter_function']) < 1e-12
+    if 'infidelity_S1' in g:
+        pulse = pulse_from(g)
+        for key in ('S1', 'S2', 'S3'):
+            got = ff.infidelity(pulse, g[key], omega)
+            assert got.shape == g['infidelity_' + key].shape and got.dtype == np.float64
+            assert rel_err(got, g['infidelity_' + key]) < 1e-12, key
+        if 'subset_identifiers' in g:
+            ids = [str(s) for s in g['subset_identifiers']]
+            A = len(g['n_opers'])
+            sel = np.ix_([A - 1, 0], [A - 1, 0])
+            assert rel_err(ff.infidelity(pulse, g['S1'], omega, n_oper_identifiers=ids),
+                           g['infidelity_S1_subset']) < 1e-12
+            assert rel_err(ff.infidelity(pulse, g['S3'][sel], omega, n_oper_identifiers=ids),
+                           g['infidelity_S3_subset']) < 1e-12
+
+
+def test_reference_golden_infidelity_vector():
+    """tests/test_precision.py:495-551: seeded pulses, 15 literal results, atol 1e-12."""
+    g = load_golden('test_infidelity')
+    omega = g['omega']
+    for d in (2, 3, 4):
+        pulse = ff.PulseSequence.from_arrays(
+            g[f'd{d}_c_opers'], g[f'd{d}_c_oper_identifiers'], g[f'd{d}_c_coeffs'],
+            g[f'd{d}_n_opers'], np.array(['B_0', 'B_2', 'B_x']), g[f'd{d}_n_coeffs'],
+            g[f'd{d}_dt'], ff.Basis.ggm(d))
+        for s in range(5):
+            S = g[f'd{d}_S{s}']
+            got = ff.infidelity(pulse, S, omega, n_oper_identifiers=['B_0', 'B_2'])
+            np.testing.assert_allclose(got, g[f'd{d}_ref_infid{s}'], atol=1e-12, rtol=0)
+            if S.ndim == 3:
+                diag = ff.infidelity(pulse, S[range(2), range(2)], omega,
+                                     n_oper_identifiers=['B_0', 'B_2'])
+                np.testing.assert_allclose(np.diag(got), diag, rtol=1e-13)
+                assert np.array_equal(got, got.conj().T)
+
+
+def test_hadamard_readme_example():
+    g = load_golden('hadamard')
+    X, Y, Z = util.paulis[1:]
+    pulse = ff.PulseSequence([[X/2, [0, np.pi], 'X'], [Y/2, [np.pi/2, 0], 'Y']],
+                             [[Z/2, [1, 1], 'Z']], [1, 1])
+    omega = util.get_sample_frequencies(pulse, n_samples=200)
+    infid = ff.infidelity(pulse, 1e-2/omega, omega)
+    assert rel_err(infid, g['infidelity']) < 1e-12
+    assert abs(infid[0] - 0.0025) < 1e-4                       # README.md:58-60
+    assert rel_err(pulse.get_filter_function(omega), g['filter_function']) < 1e-12
+
+
+@pytest.mark.parametrize('key,n', [('cpmg6', 6), ('udd6', 6), ('pdd6', 6), ('cdd3', 3),
+                                   ('cpmg1', 1)])
+def test_dynamical_decoupling_analytic(key, n):
+    """Closed forms of filter_functions/analytic.py:59-88 (tests/test_precision.py:75-182):
+    pi-pulses of 1e-9 duration (|H| ~ 3e9), two-sided omega grid."""
+    g = load_golden('dynamical_decoupling')
+    omega = g['omega']
+    X, Z = util.paulis[1], util.paulis[3]
+    dt = g[key + '_dt']
+    pulse = ff.PulseSequence([[X/2, g[key + '_c_coeffs']]], [[Z/2, np.ones_like(dt)]], dt)
+    F = pulse.get_filter_function(omega)[0, 0]
+    np.testing.assert_allclose((F*omega**2).real, g[key + '_analytic'], atol=1e-10, rtol=1e-7)
+    assert rel_err(F, g[key + '_F']) < 1e-11
+
+
+def test_liouville_representation():
+    g = load_golden('liouville')
+    for tag in ('d2_pauli', 'd3_ggm', 'd4_pauli', 'd4_ggm', 'd8_pauli', 'd16_ggm', 'd3_nonherm'):
+        basis = ff.Basis(g[tag + '_basis'])
+        L = ff.liouville_representation(g[tag + '_U'], basis)
+        assert L.dtype == g[tag + '_L'].dtype and L.shape == g[tag + '_L'].shape
+        assert rel_err(L, g[tag + '_L']) < 1e-14, tag
+    # single unitary (no batch axis); orthogonality, tests/test_superoperator.py:35-74
+    U = g['d4_pauli_U'][0]
+    L = ff.liouville_representation(U, ff.Basis.pauli(2))
+    assert L.shape == (16, 16)
+    assert np.abs(L.T @ L - np.eye(16)).max() < 5*np.finfo(float).eps*16
+    # Pauli conjugation signs for d = 2: U = X maps (I,X,Y,Z) -> (I,X,-Y,-Z)
+    L = ff.liouville_representation(util.paulis[1], ff.Basis.pauli(1))
+    assert np.allclose(L, np.diag([1, 1, -1, -1]), atol=1e-15)
+
+
+@pytest.mark.parametrize('name', ['rand_d2_ggm', 'rand_d3_ggm', 'rand_d4_pauli', 'rand_d4_ggm',
+                                  'edge_degenerate_d4'])
+def test_intermediates(name):
+    """cache_intermediates=True products, tests/test_core.py:604-642."""
+    g = load_golden(name)
+    R, inter = numeric.calculate_control_matrix_from_scratch(
+        g['eigvals'], g['eigvecs'], g['propagators'], g['omega'], g['basis'], g['n_opers'],
+        g['n_coeffs'], g['dt'], g['t'], cache_intermediates=True)
+    assert rel_err(R, g['control_matrix']) < TIGHT
+    for key in ('n_opers_transformed', 'eigvecs_propagated', 'basis_transformed',
+                'phase_factors', 'first_order_integral', 'control_matrix_step'):
+        assert inter[key].shape == g['inter_' + key].shape, key
+        assert rel_err(inter[key], g['inter_' + key]) < TIGHT, key
+    assert rel_err(inter['control_matrix_step'].sum(0), R) < TIGHT
+    cum = np.cumsum(g['inter_control_matrix_step'], axis=0)[:-1]
+    assert rel_err(inter['control_matrix_step_cumulative'], cum) < TIGHT
+    # through the PulseSequence front-end: intermediates land in pulse.intermediates and a
+    # leading slice reuses the cumulative cache (pulse_sequence.py:462-473)
+    pulse = pulse_from(g)
+    pulse.get_control_matrix(g['omega'], cache_intermediates=True)
+    assert set(pulse.intermediates) >= {'control_matrix_step', 'phase_factors'}
+    if len(pulse) > 2:
+        head = pulse[:2]
+        assert head.is_cached('control_matrix')
+        fresh = pulse_from(g)[:2]
+        assert rel_err(head.get_control_matrix(g['omega']), fresh.get_control_matrix(g['omega'])) < 1e-12
+
+
+def test_segment_chunking_is_result_invariant():
+    """The split of the segment axis over blocks only re-associates the sum."""
+    g = load_golden('cfg2_small')
+    args = (g['eigvals'], g['eigvecs'], g['propagators'], g['omega'], g['basis'], g['n_opers'],
+            g['n_coeffs'], g['dt'], g['t'])
+    lib = _lib.load()
+    results = []
+    try:
+        for chunks in (1, 2, 7, 64, 0):
+            _lib.check(lib.ffk_set_segment_chunks(chunks))
+            results.append(numeric.calculate_control_matrix_from_scratch(*args))
+            if chunks:
+                assert _lib.stats()['chunks'] == min(chunks, 64) or chunks == 7
+    finally:
+        lib.ffk_set_segment_chunks(0)
+    for R in results:
+        assert rel_err(R, g['control_matrix']) < TIGHT
+    # and the run is deterministic: same geometry -> bit-identical
+    again = numeric.calculate_control_matrix_from_scratch(*args)
+    assert np.array_equal(again, results[-1])
+
+
+def test_ragged_and_tiny_shapes():
+    """W not a multiple of 64, W = 1, a single noise operator, one segment."""
+    g = load_golden('rand_d3_ggm')
+    for W in (1, 2, 63, 65):
+        omega = np.linspace(-3, 7, W)
+        R = numeric.calculate_control_matrix_from_scratch(
+            g['eigvals'], g['eigvecs'], g['propagators'], omega, g['basis'], g['n_opers'][:1],
+            g['n_coeffs'][:1], g['dt'], g['t'])
+        ref = orc.control_matrix_from_scratch(g['eigvals'], g['eigvecs'], g['propagators'], omega,
+                                              g['basis'], g['n_opers'][:1], g['n_coeffs'][:1],
+                                              g['dt'], g['t'])
+        assert R.shape == (1, 9, W) and rel_err(R, ref) < TIGHT
+    # incomplete basis (n_basis < d^2) is allowed by the reference (pulse_sequence.py:303-306)
+    R = numeric.calculate_control_matrix_from_scratch(
+        g['eigvals'], g['eigvecs'], g['propagators'], g['omega'], g['basis'][2:7], g['n_opers'],
+        g['n_coeffs'], g['dt'], g['t'])
+    assert rel_err(R, g['control_matrix'][:, 2:7]) < TIGHT
+
+
+def test_error_behaviour():
+    g = load_golden('rand_d2_ggm')
+    with pytest.raises(ValueError):
+        numeric.calculate_filter_function(g['control_matrix'], which='bogus')
+    with pytest.raises(ValueError):
+        numeric.diagonalize(np.zeros((3, 17, 17), complex), np.ones(3))         # d > 16
+    with pytest.raises(ValueError):
+        numeric.diagonalize(np.zeros((3, 2, 2), complex), np.ones(4))
+    pulse = pulse_from(g)
+    with pytest.raises(ValueError):
+        ff.infidelity(pulse, np.ones((5, len(g['omega']))), g['omega'])          # bad spectrum shape
+    with pytest.raises(ValueError):
+        ff.infidelity(pulse, g['S1'], g['omega'], n_oper_identifiers=['nope'])
+    with pytest.raises(ValueError):
+        ff.infidelity(pulse, g['S1'], g['omega'], which='bogus')
+    with pytest.raises(TypeError):
+        ff.infidelity(pulse, g['S1'], g['omega'], test_convergence=True)
+
+
+def test_convergence_and_smallness_wrappers():
+    g = load_golden('rand_d2_ggm')
+    pulse = pulse_from(g)
+    n, infids = ff.infidelity(pulse, lambda w: 1e-3/w, dict(n_min=20, n_max=60, n_points=3),
+                              test_convergence=True)
+    assert list(n) == [20, 40, 60] and infids.shape == (3, len(g['n_opers']))
+    w = np.linspace(*(2*np.pi/pulse.tau*np.array([1e-2, 1e2])), 60)
+    ref = orc.infidelity_from_filter_function(
+        orc.filter_function(orc.control_matrix_from_scratch(
+            g['eigvals'], g['eigvecs'], g['propagators'], w, g['basis'], g['n_opers'],
+            g['n_coeffs'], g['dt'], g['t'])), 1e-3/w, w, np.arange(len(g['n_opers'])), 2)
+    assert rel_err(infids[-1], ref) < 1e-12
+    omega = np.abs(g['omega']) + 0.1
+    infid, xi = ff.infidelity(pulse, 1e-3/omega, np.sort(omega), return_smallness=True)
+    assert infid.shape == (len(g['n_opers']),) and xi > 0
+
+
+# ---- BASELINE config 2 at full size: d=4, 256 segments, 3 noise ops, 4096 omega ---------------
+def config2_inputs(seed=42, d=4, G=256, A=3, W=4096, n_cops=3):
+    rng = np.random.default_rng(seed)
+
+    def herm_traceless(n):
+        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+        M = (M + M.conj().transpose(0, 2, 1))/2
+        return M - np.trace(M, axis1=1, axis2=2)[:, None, None]*np.eye(d)/d
+    c_opers, n_opers = herm_traceless(n_cops), herm_traceless(A)
+    c_coeffs = rng.standard_normal((n_cops, G))
+    n_coeffs = rng.random((A, G))
+    dt = 1 - rng.random(G)
+    omega = np.geomspace(1e-2/dt.sum(), 1e2/dt.min(), W)
+    return c_opers, c_coeffs, n_opers, n_coeffs, dt, omega
+
+
+def test_config2_full_size_against_oracle():
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs()
+    basis = ff.Basis.pauli(2)
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
+    F = pulse.get_filter_function(omega)
+    R = pulse.get_control_matrix(omega)
+    S = 1e-3/omega
+    infid = ff.infidelity(pulse, S, omega)
+    # oracle (the reference's algorithm in NumPy) on the same inputs
+    H = orc.hamiltonian(pulse.c_opers, pulse.c_coeffs)
+    D, V, Q = orc.diagonalize(H, dt)
+    R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), pulse.n_opers,
+                                            pulse.n_coeffs, dt)
+    F_ref = orc.filter_function(R_ref)
+    infid_ref = orc.infidelity_from_filter_function(F_ref, S, omega, np.arange(3), 4)
+    assert np.abs(pulse.eigvals - D).max() < 1e-13
+    assert rel_err(pulse.propagators, Q) < 1e-12
+    for a in range(3):                                       # per noise operator
+        assert rel_err(R[a], R_ref[a]) < 1e-11
+        assert rel_err(F[a], F_ref[a]) < 1e-11
+    # elementwise relative check where the data are not negligible
+    big = np.abs(R_ref) > 1e-6*np.abs(R_ref).max()
+    assert np.max(np.abs(R - R_ref)[big]/np.abs(R_ref)[big]) < TOL
+    assert rel_err(infid, infid_ref) < 1e-12
+    # size-independent properties
+    assert np.abs(R[:, 0]).max() < 1e-12*np.abs(R).max()      # identity column ~ 0 (traceless)
+    B = numeric.calculate_noise_operators_from_scratch(pulse.eigvals, pulse.eigvecs,
+                                                       pulse.propagators, omega, pulse.n_opers,
+                                                       pulse.n_coeffs, dt)
+    assert rel_err(orc.basis_expand(B, np.asarray(basis)).transpose(1, 2, 0), R) < 1e-13
+    # linearity in the noise sensitivities: R(2 s) = 2 R(s)
+    R2 = numeric.calculate_control_matrix_from_scratch(pulse.eigvals, pulse.eigvecs,
+                                                       pulse.propagators, omega, basis,
+                                                       pulse.n_opers, 2*pulse.n_coeffs, dt)
+    assert rel_err(R2, 2*R) < 1e-14
+    # basis independence of F (tests/test_basis.py:378-432)
+    pulse_ggm = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt)
+    assert rel_err(pulse_ggm.get_filter_function(omega), F) < 1e-12

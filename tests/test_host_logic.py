@@ -1,0 +1,190 @@
+"""CPU-only tests of the host-side mirror: basis construction (bit-exact against the reference's
+arrays), argument validation, cache bookkeeping that needs no kernel, host math harness."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import filter_functions_amd as ff
+from conftest import ROOT, load_golden, rel_err
+from filter_functions_amd import util
+from filter_functions_amd.basis import (Basis, equivalent_pauli_basis_elements, expand, ggm_expand,
+                                        remap_pauli_basis_elements)
+
+
+def test_basis_bit_exact_against_reference():
+    g = load_golden('basis')
+    for n in (1, 2, 3):
+        b = Basis.pauli(n)
+        assert np.array_equal(np.asarray(b), g[f'pauli{n}'])
+        assert b.labels == list(g[f'pauli{n}_labels'])
+        assert b.btype == 'Pauli' and b.d == 2**n
+    for d in range(2, 9):
+        b = Basis.ggm(d)
+        assert np.array_equal(np.asarray(b), g[f'ggm{d}'])
+        assert b.labels == list(g[f'ggm{d}_labels'])
+    sha = hashlib.sha256(np.ascontiguousarray(np.asarray(Basis.pauli(4)) + 0.0).tobytes()).hexdigest()
+    assert sha == str(g['pauli4_sha256'])
+    sha = hashlib.sha256(np.ascontiguousarray(np.asarray(Basis.ggm(16)) + 0.0).tobytes()).hexdigest()
+    assert sha == str(g['ggm16_sha256'])
+
+
+def test_basis_index_maps_bit_exact():
+    g = load_golden('basis')
+    for N in (1, 2, 3, 4):
+        for q in range(N):
+            assert np.array_equal(equivalent_pauli_basis_elements(q, N), g[f'equiv_N{N}_q{q}'])
+        if N > 1:
+            assert np.array_equal(equivalent_pauli_basis_elements([0, 1], N), g[f'equiv_N{N}_q01'])
+            assert np.array_equal(remap_pauli_basis_elements(list(range(N))[::-1], N),
+                                  g[f'remap_N{N}_rev'])
+    assert np.array_equal(remap_pauli_basis_elements([1, 2, 0], 3), g['remap_N3_120'])
+
+
+def test_basis_properties_and_expand():
+    g = load_golden('basis')
+    for b in (Basis.pauli(2), Basis.ggm(3), Basis.ggm(4)):
+        assert b.isherm and b.isnorm and b.isorthogonal and b.isorthonorm
+        assert b.istraceless and b.iscomplete
+        assert b == b and not (b != b)
+        assert b.H == b
+    assert rel_err(Basis.ggm(5).expand(g['expand_M']), g['expand_ggm5']) < 1e-15
+    Mh = g['expand_M'] + g['expand_M'].conj().transpose(0, 2, 1)
+    got = Basis.ggm(5).expand(Mh, hermitian=True)
+    assert got.dtype == np.float64 and rel_err(got, g['expand_ggm5_herm']) < 1e-15
+    assert rel_err(Basis.pauli(2).expand(g['expand_M4']), g['expand_pauli2']) < 1e-15
+    assert rel_err(expand(g['expand_M'], Basis.ggm(5)), ggm_expand(g['expand_M'])) < 1e-15
+    nonherm = Basis(np.array([[[0, 1], [0, 0]], [[0, 0], [1, 0]]]))
+    assert not nonherm.isherm and not nonherm.iscomplete and nonherm.btype == 'Custom'
+
+
+def test_util_against_reference_vectors():
+    g = load_golden('util')
+    assert np.array_equal(util.integrate(g['f'], g['x']), g['integral'])
+    assert np.array_equal(util.cexp(g['cexp_in']), g['cexp_out'])
+    assert np.array_equal(util.cexpm1(g['cexp_in'] - 5e3), g['cexpm1_out'])
+    h = load_golden('hadamard')
+    X, Y, Z = util.paulis[1:]
+    p = ff.PulseSequence([[X/2, [0, np.pi], 'X'], [Y/2, [np.pi/2, 0], 'Y']], [[Z/2, [1, 1], 'Z']],
+                         [1, 1])
+    assert np.array_equal(util.get_sample_frequencies(p, 200), h['omega'])
+    assert np.array_equal(util.get_sample_frequencies(p), h['omega_default'])
+    assert np.array_equal(np.asarray(p.basis), h['basis'])
+    assert np.array_equal(p.c_opers, h['c_opers']) and np.array_equal(p.c_coeffs, h['c_coeffs'])
+    assert list(p.c_oper_identifiers) == list(h['c_oper_identifiers'])
+
+
+def test_pulse_sequence_constructor_contract():
+    """Error types of the constructor, reference tests/test_core.py:42-221."""
+    X, Z = util.paulis[1], util.paulis[3]
+    with pytest.raises(TypeError):
+        ff.PulseSequence([[X, [1]]], [[Z, [1]]], 1.0)                  # dt not a sequence
+    with pytest.raises(ValueError):
+        ff.PulseSequence([[X, [1]]], [[Z, [1]]], [-1.0])               # negative dt
+    with pytest.raises(ValueError):
+        ff.PulseSequence([[X, [1]]], [[Z, [1]]], [1j])                 # complex dt
+    with pytest.raises(TypeError):
+        ff.PulseSequence(1, [[Z, [1]]], [1.0])
+    with pytest.raises(TypeError):
+        ff.PulseSequence([[X, 1]], [[Z, [1]]], [1.0])                  # coeffs not a sequence
+    with pytest.raises(ValueError):
+        ff.PulseSequence([[X, [1, 2]]], [[Z, [1]]], [1.0])             # wrong coeff length
+    with pytest.raises(ValueError):
+        ff.PulseSequence([[X, [1], 'a'], [Z, [1], 'a']], [[Z, [1]]], [1.0])   # duplicate ids
+    with pytest.raises(ValueError):
+        ff.PulseSequence([[X, [1]]], [[np.eye(3), [1]]], [1.0])        # dimension mismatch
+    with pytest.raises(ValueError):
+        ff.PulseSequence([[X, [1]]], [[Z, [1]]], [1.0], basis=np.eye(2))
+    with pytest.raises(ValueError):
+        ff.PulseSequence([[X, [1]]], [[Z, [1]]], [1.0], basis=Basis.pauli(2))
+    p = ff.PulseSequence([[X, [1, 2], 'b'], [Z, [3, 4], 'a']], [[Z, [1, 1]]], [1.0, 2.0])
+    assert list(p.c_oper_identifiers) == ['a', 'b']            # sorted by identifier
+    assert np.array_equal(p.c_coeffs, [[3, 4], [1, 2]])
+    assert list(p.n_oper_identifiers) == ['B_0']
+    assert p.d == 2 and p.basis.btype == 'GGM' and len(p) == 2
+    assert np.array_equal(p.t, [0, 1, 3]) and p.tau == 3 and p.duration == 3
+    q = p[:1]
+    assert len(q) == 1 and q.tau == 1
+    with pytest.raises(IndexError):
+        p[5:]
+    with pytest.raises(ValueError):
+        p.cleanup('nonsense')
+    with pytest.raises(ValueError):
+        p.get_filter_function([1.0], which='bogus')
+    with pytest.raises(util.CalculationError):
+        p.get_pulse_correlation_filter_function()
+    with pytest.raises(util.CalculationError):
+        p.get_pulse_correlation_control_matrix()
+    c = p.copy()
+    assert c._data is not p._data and c.dt is p.dt
+
+
+def test_cache_bookkeeping_without_kernels():
+    """omega setter / cleanup / is_cached semantics (reference pulse_sequence.py:1158-1245)."""
+    X, Z = util.paulis[1], util.paulis[3]
+    p = ff.PulseSequence([[X, [1]]], [[Z, [1]]], [1.0])
+    omega = [1.0, 2.0]
+    R = np.zeros((1, 4, 2), complex)
+    p._data['total_propagator'] = np.eye(2, dtype=complex)
+    p._data['total_propagator_liouville'] = np.eye(4)
+    p.cache_control_matrix(omega, R)
+    assert p.is_cached('control matrix') and p.is_cached('total_phases') and p.is_cached('omega')
+    assert p.get_control_matrix(np.array(omega)) is R            # list vs array omega: same cache
+    assert np.allclose(p.get_total_phases(omega), np.exp(1j*np.array(omega)))
+    F = np.ones((1, 1, 2), complex)
+    p.cache_filter_function(omega, filter_function=F)
+    assert p.get_filter_function(omega) is F
+    p.omega = [1.0, 3.0]                                          # different grid: wiped
+    assert not p.is_cached('control_matrix') and not p.is_cached('filter function')
+    assert p.is_cached('total propagator liouville')
+    p.cleanup('all')
+    assert not p.data and not p.frequency_data
+    assert p.nbytes == 0
+
+
+def test_spectrum_validation():
+    with pytest.raises(ValueError):
+        util.parse_spectrum(np.ones((3, 5)), np.arange(5), [0, 1])           # wrong n_idx
+    with pytest.raises(ValueError):
+        util.parse_spectrum(np.ones((2, 2, 5)) + 1j*np.arange(5), np.arange(5), [0, 1])
+    with pytest.raises(ValueError):
+        util.parse_spectrum(np.ones((2, 2, 2, 5)), np.arange(5), [0, 1])
+    assert util.parse_spectrum(np.ones(5), np.arange(5), [0, 1]).shape == (5,)
+    with pytest.raises(ValueError):
+        util.get_indices_from_identifiers(['a', 'b'], ['c'])
+    assert list(util.get_indices_from_identifiers(['a', 'b'], 'b')) == [1]
+
+
+def test_device_math_on_host():
+    """The __host__ __device__ numerics of csrc/ffk_math.h, compiled for the host by
+    tests/csrc (built by __graft_entry__.build()), against NumPy."""
+    path = os.path.join(ROOT, 'tests', 'csrc', 'libffk_math_host.so')
+    if not os.path.exists(path):
+        pytest.skip('host math harness not built')
+    lib = ctypes.CDLL(path)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rng = np.random.default_rng(0)
+    for scale in (1.0, 1e3, 1e6, 1e9):
+        x = (rng.random(200000)*2 - 1)*scale
+        s, c = np.empty_like(x), np.empty_like(x)
+        lib.ffk_host_sincos(ctypes.c_long(x.size), x.ctypes.data_as(dp), s.ctypes.data_as(dp),
+                            c.ctypes.data_as(dp))
+        assert np.max(np.abs(s - np.sin(x))/np.spacing(np.abs(np.sin(x)))) <= 2
+        assert np.max(np.abs(c - np.cos(x))/np.spacing(np.abs(np.cos(x)))) <= 2
+    # first-order integral incl. the exact-zero mask, omega = 0, 1e-10 and resonance
+    omega = np.concatenate([[0.0, 1e-10, -1e-10, 2.5, -2.5], rng.standard_normal(1000)*10])
+    dE = np.concatenate([[0.0, 0.0, 0.0, -2.5, 2.5], rng.standard_normal(1000)])
+    dt = 0.37
+    out = np.empty(2*omega.size)
+    lib.ffk_host_first_order_integral(ctypes.c_long(omega.size), omega.ctypes.data_as(dp),
+                                      dE.ctypes.data_as(dp), ctypes.c_double(dt),
+                                      out.ctypes.data_as(dp))
+    got = out[0::2] + 1j*out[1::2]
+    x = omega + dE
+    ref = np.full(x.shape, dt, dtype=complex)
+    m = x != 0
+    ref[m] = util.cexpm1(x[m]*dt)/(1j*x[m])
+    assert np.max(np.abs(got - ref)) < 5e-16
+    assert got[0] == dt and got[3] == dt and got[4] == dt
