@@ -108,6 +108,8 @@ def main():
     device = torch.device('cuda', local_rank)
     lib = _lib.load()
     _lib.check(lib.ffk_set_device(local_rank))
+    if os.environ.get('FFK_SEGMENT_CHUNKS'):            # tuning knob, 0/unset = automatic
+        _lib.check(lib.ffk_set_segment_chunks(int(os.environ['FFK_SEGMENT_CHUNKS'])))
     if world > 1:
         dist.init_process_group('nccl', device_id=device)
 

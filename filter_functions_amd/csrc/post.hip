@@ -66,20 +66,27 @@ __global__ __launch_bounds__(256) void transpose_kernel(const cplx* __restrict__
         if (c0 + c < cols && r0 + tx < rows) out[static_cast<size_t>(c0 + c)*rows + r0 + tx] = tile[tx][c];
 }
 
-// F[a,b,w] = sum_k conj(R[a,k,w]) R[b,k,w]      ('ako,bko->abo', numeric.py:1462)
+// F[a,b,w] = sum_k conj(R[a,k,w]) R[b,k,w]      ('ako,bko->abo', numeric.py:1462).
+// Only a <= b is summed; F[b,a] = conj(F[a,b]) is mirrored so that F is EXACTLY Hermitian in
+// (a,b) like NumPy's result (the reference asserts infidelity matrices equal their own
+// conjugate transpose bit for bit, tests/test_precision.py:549).
 __global__ void ff_fidelity_kernel(const cplx* __restrict__ R, int A, int N, int W,
                                    cplx* __restrict__ F) {
     const int w = blockIdx.x*blockDim.x + threadIdx.x;
     const int a = blockIdx.y / A, b = blockIdx.y % A;
-    if (w >= W) return;
+    if (w >= W || a > b) return;
     const cplx* ra = R + static_cast<size_t>(a)*N*W + w;
     const cplx* rb = R + static_cast<size_t>(b)*N*W + w;
     cplx acc = {0.0, 0.0};
     for (int k = 0; k < N; ++k) cmac_conj(acc, ra[static_cast<size_t>(k)*W], rb[static_cast<size_t>(k)*W]);
+    if (a == b) acc.im = 0.0;   // sum_k |R|^2: the imaginary parts cancel term by term
     F[(static_cast<size_t>(a)*A + b)*W + w] = acc;
+    if (a != b) F[(static_cast<size_t>(b)*A + a)*W + w] = {acc.re, -acc.im};
 }
 
-// F[a,b,k,l,w] = conj(R[a,k,w]) R[b,l,w]        ('ako,blo->abklo', numeric.py:1465)
+// F[a,b,k,l,w] = conj(R[a,k,w]) R[b,l,w]        ('ako,blo->abklo', numeric.py:1465).
+// Plain multiply / subtract (no FMA contraction across the two products) so that
+// F[b,a,l,k] == conj(F[a,b,k,l]) holds exactly, as it does for NumPy's complex multiply.
 __global__ void ff_generalized_kernel(const cplx* __restrict__ R, int A, int N, int W,
                                       cplx* __restrict__ F) {
     const int w = blockIdx.x*blockDim.x + threadIdx.x;
@@ -88,8 +95,13 @@ __global__ void ff_generalized_kernel(const cplx* __restrict__ R, int A, int N, 
     if (w >= W) return;
     const cplx x = R[(static_cast<size_t>(a)*N + k)*W + w];
     const cplx y = R[(static_cast<size_t>(b)*N + l)*W + w];
-    cplx v = {0.0, 0.0};
-    cmac_conj(v, x, y);
+    const double rr = x.re*y.re;
+    const double ii = x.im*y.im;
+    const double ri = x.re*y.im;
+    const double ir = x.im*y.re;
+    cplx v;
+    v.re = rr + ii;
+    v.im = ri - ir;
     F[((((static_cast<size_t>(a)*A + b)*N + k)*N + l))*W + w] = v;
 }
 
