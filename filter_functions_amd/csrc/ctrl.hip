@@ -7,9 +7,9 @@
 //     I^(g)_mn(w) = (e^{i (w + D_m - D_n) dt_g} - 1) / (i (w + D_m - D_n))
 // i.e. the interaction-picture noise operator B~_a(w) of numeric.py:516-537.  The control matrix
 // is its basis expansion R[a,k,w] = tr(Y_a(w) C_k), done once after the segment sum
-// (post.hip) instead of inside it: 2 d^3 complex MACs per (g, w, a) instead of the d^4 of the
-// reference's 'o,jmn,omn,knm->jko' contraction, with identical results (the reference pins the
-// two formulations against each other at 1e-14, tests/test_precision.py:313-353).
+// (post.hip) instead of inside it: d^2 + 2 d^3 complex MACs per (g, w, a) instead of the d^4 of
+// the reference's 'o,jmn,omn,knm->jko' contraction, with identical results (the reference pins
+// the two formulations against each other at 1e-14, tests/test_precision.py:313-353).
 //
 // Mapping:
 //   * grid.x tiles omega in 64s, one frequency per lane; grid.z splits the segment axis into
@@ -18,41 +18,62 @@
 //   * Phase A: the waves of a block share the generated integral: wave w computes entries
 //     w, w+nw, ... of e^{i w t_g} I^(g) (one sincos + one reciprocal each, the diagonal only
 //     once) and parks them in LDS, [entry][lane] so that reads/writes are 16-byte, conflict free.
-//   * Phase B: Z[m,:] = sum_n I'[m,n] Wt[m,n,:],  Y[i,:] += conj(T[m,i]) Z[m,:].  Every
-//     omega-independent operand (Wt, conj T, the segment table) is wave-uniform, so it is
-//     fetched by scalar loads and enters v_fma_f64 as the SGPR source; VGPRs hold only the
-//     accumulators and the current integral row.
+//     The same phase copies the segment's omega-independent operands (T_g and the block's
+//     Bbar_a^(g), (1 + n_a) d^2 complex numbers) from HBM/L2 into LDS.
+//   * Phase B, per row m:  X[m,:] = Bbar[m,:] o I'[m,:],  Z[m,:] = X[m,:] T,
+//     Y[i,:] += conj(T[m,i]) Z[m,:].  Operands come from LDS as broadcast ds_read_b128 (all
+//     lanes the same address): in-order LDS returns let the compiler keep many reads in flight
+//     behind counted lgkmcnt waits -- the first version fed the FMAs from scalar loads and spent
+//     60 % of its wave cycles in s_waitcnt lgkmcnt(0) (profiles/r01_b_*).
 //   * Double-buffered LDS: one barrier per segment.
+#include <algorithm>
+
 #include "ffk_internal.h"
 
 namespace ffk {
 namespace {
 
+constexpr int kWaveKernelMaxD = 4;
+bool g_force_block_kernel = false;   // tuning/testing: use the multi-wave LDS kernel for all d
+
 // MR = integral rows generated per LDS stage.  MR == D (one stage per segment, diagonal computed
 // once, optionally double-buffered) whenever the D*D*64 tile fits the 160 KiB LDS; MR < D splits
 // the rows over several single-buffered stages (D > 12).  MAXW = upper bound of waves per block
 // (launch bound: lets the register allocator use the VGPR budget the block size really leaves).
+// LDS per buffer: [MR*D][64] integral tile, then [(1 + NA)][D*D] operands (T_g, Bbar of the
+// block's noise operators), NA = accum_na(D, nwaves).
+#if defined(FFK_WPE)  /* tuning builds: pin the occupancy target of the register allocator */
+#define FFK_ACCUM_ATTR __attribute__((amdgpu_waves_per_eu(FFK_WPE, FFK_WPE)))
+#else
+#define FFK_ACCUM_ATTR
+#endif
+
 template <int D, int JB, int MR, int NBUF, int MAXW>
-__global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_kernel(const double* __restrict__ omega, int W,
-                                       const double* __restrict__ segtab,
-                                       const cplx* __restrict__ Wt, const cplx* __restrict__ Tc,
-                                       int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
+__global__ __launch_bounds__(MAXW*64) FFK_ACCUM_ATTR void ctrl_accumulate_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ segtab,
+    const cplx* __restrict__ ops, int G, int A, int chunk_len, int na_blk,
+    cplx* __restrict__ Ypart) {
     static_assert(MR == D || NBUF == 1, "row-blocked stages are single buffered");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    cplx* lds = reinterpret_cast<cplx*>(lds_raw);  // [NBUF][MR*D][64]
+    cplx* lds = reinterpret_cast<cplx*>(lds_raw);
     constexpr int S = seg_stride(D);
     constexpr int NJ = D / JB;
     constexpr int NSTAGE = (D + MR - 1)/MR;
     constexpr int NE = D*(D - 1) + 1;  // distinct integral entries (all diagonal ones coincide)
     constexpr int MUNROLL = D <= 8 ? D : 1;
+    constexpr int TILE = MR*D*64;      // cplx per integral tile
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
-    const int task = blockIdx.y*nwaves + wave;
+    const int task0 = blockIdx.y*nwaves;
+    const int task = task0 + wave;
     const bool active = task < A*NJ;
     const int alpha = active ? task / NJ : 0;
     const int jb = active ? task % NJ : 0;
+    const int alpha0 = task0 / NJ;                    // first noise operator of this block
+    const int n_alpha = min(na_blk, A - alpha0);      // operators staged by this block
+    const int buf_stride = TILE + (1 + na_blk)*D*D;   // cplx per LDS buffer
     const int iw = blockIdx.x*64 + lane;
     const double om = omega[iw < W ? iw : W - 1];
     const int g0 = blockIdx.z*chunk_len;
@@ -64,12 +85,21 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_kernel(const double* 
 #pragma unroll
         for (int j = 0; j < JB; ++j) Y[i][j] = {0.0, 0.0};
 
-    // Phase A: this wave's share of e^{i w t_g} I^(g)[rows of stage][:] -> LDS
+    // Phase A: this wave's share of e^{i w t_g} I^(g)[rows of stage][:] -> LDS, plus (stage 0)
+    // the segment's operands T_g, Bbar_{alpha0..}^(g) -> LDS.
     auto phase_a = [&](int g, int stage, int buf) {
         const double* st = segtab + static_cast<size_t>(g)*S;
+        cplx* tile = lds + static_cast<size_t>(buf)*buf_stride;
+        // operand copy: issue the global loads first, park them after the integral is done
+        const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*D*D;
+        const int n_ops = (1 + n_alpha)*D*D;
+        const int e0 = static_cast<int>(threadIdx.x);
+        cplx staged = {0.0, 0.0};
+        if (stage == 0 && e0 < n_ops)
+            staged = src_ops[e0 < D*D ? e0 : e0 + alpha0*D*D];
         const double dtg = st[0];
         const cplx ph = cexp(om*st[1]);
-        cplx* dst = lds + static_cast<size_t>(buf)*MR*D*64 + lane;
+        cplx* dst = tile + lane;
         if (MR == D) {
             for (int ce = wave; ce < NE; ce += nwaves) {
                 int slot = 0;  // the diagonal lives in slot 0
@@ -78,8 +108,12 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_kernel(const double* 
                     const int m = o/(D - 1), r = o % (D - 1);
                     slot = m*D + r + (r >= m ? 1 : 0);
                 }
+#if defined(FFK_ABLATE) && FFK_ABLATE == 1   /* diagnostic build: no integral generation */
+                dst[slot*64] = {om, dtg + ph.re};
+#else
                 const cplx I = first_order_integral(om, st[2 + slot], dtg);
                 dst[slot*64] = cmul(ph, I);
+#endif
             }
         } else {
             const int m0 = stage*MR;
@@ -89,31 +123,44 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_kernel(const double* 
                 dst[e*64] = cmul(ph, I);
             }
         }
+        if (stage == 0) {
+            cplx* dst_ops = tile + TILE;
+            if (e0 < n_ops) dst_ops[e0] = staged;
+            for (int e = e0 + static_cast<int>(blockDim.x); e < n_ops; e += blockDim.x)
+                dst_ops[e] = src_ops[e < D*D ? e : e + alpha0*D*D];
+        }
     };
 
-    // Phase B: Z[m,:] = sum_n I'[m,n] Wt[m,n,:];  Y[i,:] += conj(T[m,i]) Z[m,:]
+    // Phase B, rows of one stage
     auto phase_b = [&](int g, int stage, int buf) {
-        const cplx* Wg = Wt + (static_cast<size_t>(g)*A + alpha)*D*D*D + jb*JB;
-        const cplx* Tg = Tc + static_cast<size_t>(g)*D*D;
-        const cplx* src = lds + static_cast<size_t>(buf)*MR*D*64 + lane;
+        (void)g;
+        const cplx* tile = lds + static_cast<size_t>(buf)*buf_stride;
+        const cplx* src = tile + lane;
+        const cplx* opT = tile + TILE;                               // T[n][j]
+        const cplx* opB = opT + (1 + alpha - alpha0)*D*D;            // Bbar_alpha[m][n]
         const int m0 = stage*MR;
         const int m1 = min(D, m0 + MR);
 #pragma unroll MUNROLL
         for (int m = m0; m < m1; ++m) {
+            cplx X[D];
+#pragma unroll
+            for (int n = 0; n < D; ++n) {
+                const int slot = (MR == D) ? ((m == n) ? 0 : m*D + n) : (m - m0)*D + n;
+                X[n] = cmul(opB[m*D + n], src[slot*64]);
+            }
             cplx Z[JB];
 #pragma unroll
             for (int j = 0; j < JB; ++j) Z[j] = {0.0, 0.0};
 #pragma unroll
-            for (int n = 0; n < D; ++n) {
-                const int slot = (MR == D) ? ((m == n) ? 0 : m*D + n) : (m - m0)*D + n;
-                const cplx Iv = src[slot*64];
+            for (int n = 0; n < D; ++n)
 #pragma unroll
-                for (int j = 0; j < JB; ++j) cmac(Z[j], Wg[(m*D + n)*D + j], Iv);
+                for (int j = 0; j < JB; ++j) cmac(Z[j], opT[n*D + jb*JB + j], X[n]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const cplx t = opT[m*D + i];
+#pragma unroll
+                for (int j = 0; j < JB; ++j) cmac_conj(Y[i][j], t, Z[j]);
             }
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = 0; j < JB; ++j) cmac(Y[i][j], Tg[m*D + i], Z[j]);
         }
     };
 
@@ -123,7 +170,9 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_kernel(const double* 
         for (int g = g0; g < g1; ++g) {
             const int buf = (g - g0) & 1;
             if (g + 1 < g1) phase_a(g + 1, 0, buf ^ 1);
+#if !(defined(FFK_ABLATE) && FFK_ABLATE == 3)  /* diagnostic build 3: no contraction */
             if (active) phase_b(g, 0, buf);
+#endif
             __syncthreads();
         }
     } else {
@@ -146,55 +195,209 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_kernel(const double* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small-d variant (D <= 4): ONE wavefront per block, one frequency per lane, AT noise operators
+// per lane -- no barrier, no inter-wave sharing, perfect load balance.  v_fma_f64 issues back to
+// back from a single wave at >90 % of the FP64 rate (tools/fp64_latency.hip), so instead of many
+// thin waves the kernel runs one fat wave per SIMD (up to 512 VGPRs: the AT*D*D accumulators, all
+// D*D integral entries and the operands in flight stay in registers).  The wave keeps a private,
+// double-buffered copy of the segment's operands (T_g, Bbar_a^(g)) in LDS -- fetched one segment
+// ahead by a single coalesced global load -- and reads them back as broadcasts.
+// ---------------------------------------------------------------------------------------------
+template <int D, int AT>
+__global__ __launch_bounds__(64) void ctrl_accumulate_wave_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ segtab,
+    const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
+    constexpr int S = seg_stride(D);
+    constexpr int NOPS = (1 + AT)*D*D;
+    static_assert(NOPS <= 128, "operand block must fit two loads per lane");
+    __shared__ __attribute__((aligned(16))) cplx opbuf[2][NOPS];
+
+    const int lane = threadIdx.x;
+    const int iw = blockIdx.x*64 + lane;
+    const int alpha0 = blockIdx.y*AT;
+    const int na = min(AT, A - alpha0);
+    const int n_ops = (1 + na)*D*D;
+    const double om = omega[iw < W ? iw : W - 1];
+    const int g0 = blockIdx.z*chunk_len;
+    const int g1 = min(G, g0 + chunk_len);
+
+    cplx Y[AT][D][D];
+#pragma unroll
+    for (int a = 0; a < AT; ++a)
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) Y[a][i][j] = {0.0, 0.0};
+
+    auto src_index = [&](int e) { return e < D*D ? e : e + alpha0*D*D; };
+    if (g0 < g1) {
+        const cplx* src = ops + static_cast<size_t>(g0)*(1 + A)*D*D;
+        if (lane < n_ops) opbuf[0][lane] = src[src_index(lane)];
+        if (NOPS > 64 && lane + 64 < n_ops) opbuf[0][lane + 64] = src[src_index(lane + 64)];
+    }
+
+    for (int g = g0; g < g1; ++g) {
+        const int buf = (g - g0) & 1;
+        // operands of the next segment: issue the loads now, park them at the end of the body
+        cplx nxt0 = {0.0, 0.0}, nxt1 = {0.0, 0.0};
+        const bool more = g + 1 < g1;
+        if (more) {
+            const cplx* src = ops + static_cast<size_t>(g + 1)*(1 + A)*D*D;
+            if (lane < n_ops) nxt0 = src[src_index(lane)];
+            if (NOPS > 64 && lane + 64 < n_ops) nxt1 = src[src_index(lane + 64)];
+        }
+        const double* st = segtab + static_cast<size_t>(g)*S;
+        const double dtg = st[0];
+        const cplx ph = cexp(om*st[1]);
+
+        // e^{i w t_g} I^(g): the diagonal entries coincide (dE = 0)
+        cplx Ip[D][D];
+        Ip[0][0] = cmul(ph, first_order_integral(om, 0.0, dtg));
+#pragma unroll
+        for (int m = 0; m < D; ++m)
+#pragma unroll
+            for (int n = 0; n < D; ++n)
+                if (m != n) Ip[m][n] = cmul(ph, first_order_integral(om, st[2 + m*D + n], dtg));
+
+        const cplx* opT = opbuf[buf];
+#pragma unroll
+        for (int a = 0; a < AT; ++a) {
+            if (a < na) {
+                const cplx* opB = opbuf[buf] + (1 + a)*D*D;
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    cplx X[D];
+#pragma unroll
+                    for (int n = 0; n < D; ++n) X[n] = cmul(opB[m*D + n], m == n ? Ip[0][0] : Ip[m][n]);
+                    cplx Z[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Z[j] = {0.0, 0.0};
+#pragma unroll
+                    for (int n = 0; n < D; ++n)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) cmac(Z[j], opT[n*D + j], X[n]);
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        const cplx t = opT[m*D + i];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) cmac_conj(Y[a][i][j], t, Z[j]);
+                    }
+                }
+            }
+        }
+        if (more) {
+            if (lane < n_ops) opbuf[buf ^ 1][lane] = nxt0;
+            if (NOPS > 64 && lane + 64 < n_ops) opbuf[buf ^ 1][lane + 64] = nxt1;
+        }
+    }
+
+    if (iw < W) {
+#pragma unroll
+        for (int a = 0; a < AT; ++a) {
+            if (a < na) {
+                cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha0 + a)*D*D)*W + iw;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) out[static_cast<size_t>(i*D + j)*W] = Y[a][i][j];
+            }
+        }
+    }
+}
+
 __host__ __device__ constexpr int accum_mr(int d) { return d <= 12 ? d : 8; }
 
 template <typename K>
 hipError_t launch_kernel(K kern, const dim3& grid, const dim3& block, const AccumGeometry& geo,
                          hipStream_t stream, const double* omega, int W, const double* segtab,
-                         const cplx* Wt, const cplx* Tc, int G, int A, cplx* Ypart) {
+                         const cplx* ops, int G, int A, cplx* Ypart) {
     if (geo.lds_bytes > 48*1024) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              geo.lds_bytes);
         if (err != hipSuccess) return err;
     }
-    hipLaunchKernelGGL(kern, grid, block, geo.lds_bytes, stream, omega, W, segtab, Wt, Tc, G, A,
-                       geo.chunk_len, Ypart);
+    hipLaunchKernelGGL(kern, grid, block, geo.lds_bytes, stream, omega, W, segtab, ops, G, A,
+                       geo.chunk_len, geo.na_blk, Ypart);
     return hipGetLastError();
 }
 
 template <int D, int MAXW>
-hipError_t launch_dw(const double* omega, int W, const double* segtab, const cplx* Wt,
-                     const cplx* Tc, int G, int A, const AccumGeometry& geo, cplx* Ypart,
+hipError_t launch_dw(const double* omega, int W, const double* segtab, const cplx* ops,
+                     int G, int A, const AccumGeometry& geo, cplx* Ypart,
                      hipStream_t stream) {
     constexpr int JB = accum_jb(D);
     constexpr int MR = accum_mr(D);
     const dim3 grid((W + 63)/64, geo.task_groups, geo.chunks);
     const dim3 block(geo.nwaves*64);
-    if constexpr (MR == D && 2*D*D*64*sizeof(cplx) <= 158*1024) {
+    if constexpr (MR == D) {
         if (geo.nbuf == 2)
             return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 2, MAXW>, grid, block, geo,
-                                 stream, omega, W, segtab, Wt, Tc, G, A, Ypart);
+                                 stream, omega, W, segtab, ops, G, A, Ypart);
     }
     return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 1, MAXW>, grid, block, geo, stream,
-                         omega, W, segtab, Wt, Tc, G, A, Ypart);
+                         omega, W, segtab, ops, G, A, Ypart);
+}
+
+template <int D, int AT>
+hipError_t launch_wave(const double* omega, int W, const double* segtab, const cplx* ops, int G,
+                       int A, const AccumGeometry& geo, cplx* Ypart, hipStream_t stream) {
+    const dim3 grid((W + 63)/64, geo.task_groups, geo.chunks);
+    hipLaunchKernelGGL((ctrl_accumulate_wave_kernel<D, AT>), grid, dim3(64), 0, stream, omega, W,
+                       segtab, ops, G, A, geo.chunk_len, Ypart);
+    return hipGetLastError();
 }
 
 template <int D>
-hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx* Wt,
-                    const cplx* Tc, int G, int A, const AccumGeometry& geo, cplx* Ypart,
-                    hipStream_t stream) {
+hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx* ops, int G,
+                    int A, const AccumGeometry& geo, cplx* Ypart, hipStream_t stream) {
+    if constexpr (D <= kWaveKernelMaxD) {
+        if (geo.wave_kernel) {
+            switch (geo.na_blk) {
+                case 1:
+                    return launch_wave<D, 1>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
+                case 2:
+                    return launch_wave<D, 2>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
+                default:
+                    return launch_wave<D, 3>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
+            }
+        }
+    }
     if (geo.nwaves <= 4)
-        return launch_dw<D, 4>(omega, W, segtab, Wt, Tc, G, A, geo, Ypart, stream);
+        return launch_dw<D, 4>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
     if (geo.nwaves <= 8)
-        return launch_dw<D, 8>(omega, W, segtab, Wt, Tc, G, A, geo, Ypart, stream);
-    return launch_dw<D, 16>(omega, W, segtab, Wt, Tc, G, A, geo, Ypart, stream);
+        return launch_dw<D, 8>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
+    return launch_dw<D, 16>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
 }
 
 }  // namespace
 
+void set_force_block_kernel(bool on) { g_force_block_kernel = on; }
+
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks) {
     AccumGeometry geo;
+    geo.wave_kernel = d <= kWaveKernelMaxD && !g_force_block_kernel;
+    if (geo.wave_kernel) {
+        // one wave per block, up to 3 noise operators per lane; blocks per CU = 4 (1 wave/SIMD)
+        geo.na_blk = A <= 3 ? A : (A % 3 == 0 ? 3 : (A % 2 == 0 ? 2 : 3));
+        geo.nwaves = 1;
+        geo.task_groups = (A + geo.na_blk - 1)/geo.na_blk;
+        geo.nbuf = 2;
+        geo.lds_bytes = static_cast<int>(2*(1 + geo.na_blk)*d*d*sizeof(cplx));
+        const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups;
+        int chunks = forced_chunks;
+        if (chunks <= 0) {
+            const long slots = 1024;     // 256 CUs x 4 SIMDs, one fat wave each
+            chunks = static_cast<int>(std::max<long>(1, slots / tiles));
+            const int max_chunks = (G + 3)/4;
+            if (chunks > max_chunks) chunks = std::max(1, max_chunks);
+        }
+        chunks = std::max(1, std::min(chunks, G));
+        geo.chunk_len = (G + chunks - 1)/chunks;
+        geo.chunks = (G + geo.chunk_len - 1)/geo.chunk_len;
+        return geo;
+    }
     const int jb = accum_jb(d);
     const int ntasks = A*(d / jb);
     // waves per block: all tasks if they fit (<= 16 waves), otherwise the divisor-friendly
@@ -209,8 +412,10 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     }
     geo.nwaves = nw;
     geo.task_groups = (ntasks + nw - 1)/nw;
-    const size_t one = static_cast<size_t>(accum_mr(d))*d*64*sizeof(cplx);
-    geo.nbuf = (accum_mr(d) == d && 2*one <= 158*1024) ? 2 : 1;
+    const int nj = d / jb;
+    geo.na_blk = ntasks <= nw ? A : std::min(A, (nw - 1)/nj + 2);
+    const size_t one = (static_cast<size_t>(accum_mr(d))*d*64 + static_cast<size_t>(1 + geo.na_blk)*d*d)*sizeof(cplx);
+    geo.nbuf = (accum_mr(d) == d && 2*one <= 160*1024) ? 2 : 1;
     geo.lds_bytes = static_cast<int>(geo.nbuf*one);
     // segment chunks: aim for >= ~4 waves per SIMD over the chip (256 CUs x 4 SIMDs)
     const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups*nw;
@@ -229,13 +434,13 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     return geo;
 }
 
-hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* Wt,
-                             const cplx* Tc, int G, int d, int A, const AccumGeometry& geo,
-                             cplx* Ypart, hipStream_t stream) {
+hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
+                             int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
+                             hipStream_t stream) {
     switch (d) {
 #define FFK_CASE(D) \
     case D:         \
-        return launch_d<D>(omega, W, segtab, Wt, Tc, G, A, geo, Ypart, stream);
+        return launch_d<D>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
         FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
         FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
         FFK_CASE(15) FFK_CASE(16)

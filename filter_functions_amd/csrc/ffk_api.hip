@@ -95,7 +95,7 @@ size_t ctrl_ws_bytes(int W, int N, int A, int G, int d, int chunks) {
     size_t b = 0;
     b += align_up(sizeof(double)*G*ffk::seg_stride(d));                   // segtab
     b += align_up(sizeof(cplx)*size_t(G)*d*d);                            // Tc
-    b += align_up(sizeof(cplx)*size_t(G)*A*d*d*d);                        // Wt
+    b += align_up(sizeof(cplx)*size_t(G)*(1 + A)*d*d);                    // ops
     b += align_up(sizeof(cplx)*size_t(chunks)*A*d*d*W);                   // Ypart
     b += align_up(sizeof(cplx)*size_t(A)*d*d*W);                          // Bt
     (void)N;
@@ -110,10 +110,10 @@ int max_chunks_for(int W, int A, int G, int d) {
 
 double accumulate_flops(int W, int A, int G, int d) {
     // FMA-counted real flops of the accumulate kernel's algorithm (DESIGN.md "Roofline"):
-    //   contraction: 2 d^3 complex MACs per (g, w, a) = 16 d^3 flops
+    //   contraction: (2 d^3 MAC + d^2 mul) complex per (g, w, a) = 16 d^3 + 6 d^2 flops
     //   integral:    (d(d-1)+1) entries per (g, w), each ~ sincos(26) + reciprocal(9) + 14 misc
     //                + complex phase multiply (6), counted as 55 flops; phase sincos 26
-    const double per_gw = 16.0*d*d*d*A + 55.0*(d*(d - 1) + 1) + 26.0;
+    const double per_gw = (16.0*d*d*d + 6.0*d*d)*A + 55.0*(d*(d - 1) + 1) + 26.0;
     return per_gw*double(G)*double(W);
 }
 
@@ -340,7 +340,7 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     Bump ws(workspace, workspace_bytes);
     double* segtab = ws.take<double>(size_t(G)*ffk::seg_stride(d));
     cplx* Tc = ws.take<cplx>(size_t(G)*d*d);
-    cplx* Wt = ws.take<cplx>(size_t(G)*A*d*d*d);
+    cplx* ops = ws.take<cplx>(size_t(G)*(1 + A)*d*d);
     cplx* Ypart = ws.take<cplx>(size_t(geo.chunks)*A*d*d*W);
     cplx* Bt = ws.take<cplx>(size_t(A)*d*d*W);
     FFK_REQUIRE(Bt, "workspace too small");
@@ -348,9 +348,9 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     FFK_HIP(ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
                                  reinterpret_cast<const cplx*>(propagators),
                                  reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G, d, A,
-                                 segtab, Tc, Wt, nullptr, nullptr, s));
+                                 segtab, Tc, ops, nullptr, nullptr, s));
     if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_start, s));
-    FFK_HIP(ffk::launch_accumulate(omega, W, segtab, Wt, Tc, G, d, A, geo, Ypart, s));
+    FFK_HIP(ffk::launch_accumulate(omega, W, segtab, ops, G, d, A, geo, Ypart, s));
     if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_stop, s));
     const size_t slab = size_t(A)*d*d*W;
     const cplx* Bsum = Ypart;
@@ -366,7 +366,7 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
 
     g_stats.accumulate_flops = accumulate_flops(W, A, G, d);
     g_stats.accumulate_bytes = double(sizeof(cplx))*(double(geo.chunks)*slab) + 8.0*W +
-                               double(sizeof(cplx))*G*(double(A)*d*d*d + d*d);
+                               double(sizeof(cplx))*G*(double(1 + A)*d*d);
     g_stats.chunks = geo.chunks;
     g_stats.grid_x = (W + 63)/64;
     g_stats.grid_y = geo.task_groups;
@@ -455,7 +455,7 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
     total += align_up(8*size_t(W)) + align_up(16*size_t(N)*dd) + align_up(16*size_t(A)*dd);
     total += align_up(8*size_t(A)*G) + align_up(8*size_t(G)) + align_up(8*size_t(G + 1));
     total += align_up(8*size_t(G)*ffk::seg_stride(d)) + align_up(16*size_t(G)*dd) +
-             align_up(16*size_t(G)*A*dd*d);
+             align_up(16*size_t(G)*(1 + A)*dd);
     total += align_up(16*size_t(A)*G*dd) + align_up(16*size_t(G)*dd);          // nt, ep
     if (basis_transformed) total += align_up(16*size_t(G)*N*dd);
     if (phase_factors) total += align_up(16*size_t(G)*W);
@@ -475,7 +475,7 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
     double* dtt = a.take<double>(G + 1);
     double* segtab = a.take<double>(size_t(G)*ffk::seg_stride(d));
     cplx* Tc = a.take<cplx>(size_t(G)*dd);
-    cplx* Wt = a.take<cplx>(size_t(G)*A*dd*d);
+    cplx* ops = a.take<cplx>(size_t(G)*(1 + A)*dd);
     cplx* dnt = a.take<cplx>(size_t(A)*G*dd);
     cplx* dep = a.take<cplx>(size_t(G)*dd);
     cplx* dbt = basis_transformed ? a.take<cplx>(size_t(G)*N*dd) : nullptr;
@@ -499,13 +499,13 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
     FFK_HIP(h2d(dnc, n_coeffs, 8*size_t(A)*G));
     FFK_HIP(h2d(ddt, dt, 8*size_t(G)));
     FFK_HIP(h2d(dtt, t, 8*size_t(G + 1)));
-    FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dnop, dnc, ddt, dtt, G, d, A, segtab, Tc, Wt, dnt, dep, nullptr));
+    FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dnop, dnc, ddt, dtt, G, d, A, segtab, Tc, ops, dnt, dep, nullptr));
     if (dbt) FFK_HIP(ffk::launch_basis_transformed(Tc, dbasis, G, N, d, dbt, nullptr));
     FFK_HIP(ffk::launch_phase_and_integral(dom, W, segtab, G, d, dph, dint, nullptr));
     if (dstep) {
         // one chunk per segment: Ypart[g] is that segment's Hilbert-space step, expanded in the basis
         ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, G);
-        FFK_HIP(ffk::launch_accumulate(dom, W, segtab, Wt, Tc, G, d, A, geo, Ypart, nullptr));
+        FFK_HIP(ffk::launch_accumulate(dom, W, segtab, ops, G, d, A, geo, Ypart, nullptr));
         FFK_HIP(ffk::launch_expand(Ypart, dbasis, G*A, N, d, W, dstep, nullptr));
     }
     if (n_opers_transformed) FFK_HIP(d2h(n_opers_transformed, dnt, 16*size_t(A)*G*dd));

@@ -21,6 +21,9 @@ __host__ __device__ constexpr int seg_stride(int d) { return ((2 + d*d + 7)/8)*8
 
 // Columns of the Hilbert-space accumulator kept per thread in ctrl_accumulate.
 __host__ __device__ constexpr int accum_jb(int d) {
+#if defined(FFK_JB4)  /* tuning builds */
+    if (d == 4) return FFK_JB4;
+#endif
     return d <= 5 ? d : (d % 3 == 0 && d <= 9 ? 3 : (d % 2 == 0 ? 2 : 1));
 }
 
@@ -40,14 +43,14 @@ hipError_t launch_prefix_products(const cplx* seg_prop, int G, int d, cplx* Q, v
 
 // ---- prep.hip --------------------------------------------------------------------------------
 // Fills the omega-independent operands of the accumulate kernel:
-//   segtab (G, seg_stride(d)); Tc (G,d,d) = conj(V^dag Q_g); Wt (G,A,d,d,d) with
-//   Wt[g,a,m,n,j] = s_a(g) (V^dag B_a V)[m,n] * (V^dag Q_g)[n,j].
+//   segtab (G, seg_stride(d)); Tc (G,d,d) = conj(V^dag Q_g); ops (G, 1+A, d, d) with
+//   ops[g,0] = T_g = V_g^dag Q_g and ops[g,1+a] = Bbar_a^(g) = s_a(g) V_g^dag B_a V_g.
 // Optional reference intermediates (may be NULL): n_opers_transformed (A,G,d,d),
 // eigvecs_propagated (G,d,d) = Q_g^dag V_g.
 hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cplx* propagators,
                            const cplx* n_opers, const double* n_coeffs, const double* dt,
                            const double* t, int G, int d, int A, double* segtab, cplx* Tc,
-                           cplx* Wt, cplx* n_opers_transformed, cplx* eigvecs_propagated,
+                           cplx* ops, cplx* n_opers_transformed, cplx* eigvecs_propagated,
                            hipStream_t stream);
 // basis_transformed (G,N,d,d) = (Q^dag V)^dag C_k (Q^dag V)   (numeric.py:863-864)
 hipError_t launch_basis_transformed(const cplx* Tc, const cplx* basis, int G, int N, int d,
@@ -65,12 +68,15 @@ struct AccumGeometry {
     int task_groups;  // grid.y
     int lds_bytes;
     int nbuf;
+    int na_blk;       // noise operators whose Bbar one block stages in LDS
+    bool wave_kernel; // small-d one-wave-per-block variant
 };
+void set_force_block_kernel(bool on);
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks);
 // Ypart (chunks, A, d, d, W): partial Hilbert-space sums, omega fastest
-hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* Wt,
-                             const cplx* Tc, int G, int d, int A, const AccumGeometry& geo,
-                             cplx* Ypart, hipStream_t stream);
+hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
+                             int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
+                             hipStream_t stream);
 
 // ---- post.hip --------------------------------------------------------------------------------
 // Bt (A,d,d,W) = sum over chunks of Ypart

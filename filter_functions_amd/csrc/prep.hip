@@ -5,9 +5,8 @@
 //   T_g = V_g^dag Q_g                         (_propagate_eigenvectors, numeric.py:93-95, :577)
 //   Bbar_a^(g) = s_a(g) V_g^dag B_a V_g       (_transform_hamiltonian, numeric.py:98-141)
 //   dE^(g)[m,n] = D_m - D_n                   (np.subtract.outer, numeric.py:155)
-// and, new in this design, the folded operand
-//   Wt[g,a,m,n,j] = Bbar_a^(g)[m,n] * T_g[n,j]
-// which lets the hot loop form  Z = (Bbar o I') T  as one uniform-operand product.
+// packed per segment as ops[g] = (T_g, Bbar_0^(g), ..., Bbar_{A-1}^(g)), the block of operands the
+// accumulate kernel stages in LDS for segment g.
 #include "ffk_internal.h"
 
 namespace ffk {
@@ -19,13 +18,12 @@ __global__ __launch_bounds__(64) void prologue_kernel(
     const cplx* __restrict__ propagators, const cplx* __restrict__ n_opers,
     const double* __restrict__ n_coeffs, const double* __restrict__ dt,
     const double* __restrict__ t, int G, int A, double* __restrict__ segtab,
-    cplx* __restrict__ Tc, cplx* __restrict__ Wt, cplx* __restrict__ n_opers_transformed,
+    cplx* __restrict__ Tc, cplx* __restrict__ ops, cplx* __restrict__ n_opers_transformed,
     cplx* __restrict__ eigvecs_propagated) {
     __shared__ cplx V[D][D];
     __shared__ cplx Q[D][D];
     __shared__ cplx T[D][D];
     __shared__ cplx BV[D][D];
-    __shared__ cplx Bbar[D][D];
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     constexpr int S = seg_stride(D);
@@ -52,6 +50,7 @@ __global__ __launch_bounds__(64) void prologue_kernel(
         for (int k = 0; k < D; ++k) cmac_conj(acc, V[k][m], Q[k][j]);
         T[m][j] = acc;
         Tc[static_cast<size_t>(g)*D*D + e] = {acc.re, -acc.im};
+        ops[static_cast<size_t>(g)*(1 + A)*D*D + e] = acc;
         // eigvecs_propagated = Q^dag V = T^dag:  [i][j] = conj(T[j][i])
         if (eigvecs_propagated)
             eigvecs_propagated[static_cast<size_t>(g)*D*D + j*D + m] = {acc.re, -acc.im};
@@ -78,17 +77,11 @@ __global__ __launch_bounds__(64) void prologue_kernel(
             for (int k = 0; k < D; ++k) cmac_conj(acc, V[k][m], BV[k][n]);
             acc.re *= s;
             acc.im *= s;
-            Bbar[m][n] = acc;
+            ops[(static_cast<size_t>(g)*(1 + A) + 1 + a)*D*D + e] = acc;
             if (n_opers_transformed)
                 n_opers_transformed[(static_cast<size_t>(a)*G + g)*D*D + e] = acc;
         }
         __syncthreads();
-        // Wt[g,a,m,n,j] = Bbar[m,n] T[n,j]
-        cplx* Wg = Wt + (static_cast<size_t>(g)*A + a)*D*D*D;
-        for (int e = lane; e < D*D*D; e += 64) {
-            const int m = e/(D*D), n = (e / D) % D, j = e % D;
-            Wg[e] = cmul(Bbar[m][n], T[n][j]);
-        }
         __syncthreads();
     }
 }
@@ -150,13 +143,13 @@ __global__ void phase_integral_kernel(const double* __restrict__ omega, int W,
 hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cplx* propagators,
                            const cplx* n_opers, const double* n_coeffs, const double* dt,
                            const double* t, int G, int d, int A, double* segtab, cplx* Tc,
-                           cplx* Wt, cplx* n_opers_transformed, cplx* eigvecs_propagated,
+                           cplx* ops, cplx* n_opers_transformed, cplx* eigvecs_propagated,
                            hipStream_t stream) {
     switch (d) {
 #define FFK_CASE(D)                                                                             \
     case D:                                                                                     \
         hipLaunchKernelGGL(prologue_kernel<D>, dim3(G), dim3(64), 0, stream, eigvals, eigvecs,  \
-                           propagators, n_opers, n_coeffs, dt, t, G, A, segtab, Tc, Wt,         \
+                           propagators, n_opers, n_coeffs, dt, t, G, A, segtab, Tc, ops,        \
                            n_opers_transformed, eigvecs_propagated);                            \
         break;
         FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
