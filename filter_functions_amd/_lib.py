@@ -98,6 +98,7 @@ SIGNATURES = {
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
     'ffk_set_segment_chunks': (c_int, [c_int]),
+    'ffk_set_accumulate_variant': (c_int, [c_int]),
     'ffk_get_stats': (c_int, [POINTER(ffk_stats)]),
     'ffk_set_accumulate_events': (c_int, [c_void_p, c_void_p]),
 }

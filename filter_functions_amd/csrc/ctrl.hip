@@ -34,7 +34,7 @@ namespace ffk {
 namespace {
 
 constexpr int kWaveKernelMaxD = 4;
-bool g_force_block_kernel = false;   // tuning/testing: use the multi-wave LDS kernel for all d
+bool g_use_wave_kernel = false;   // tuning/testing: one-wave-per-block variant for d <= 4
 
 // MR = integral rows generated per LDS stage.  MR == D (one stage per segment, diagonal computed
 // once, optionally double-buffered) whenever the D*D*64 tile fits the 160 KiB LDS; MR < D splits
@@ -42,14 +42,19 @@ bool g_force_block_kernel = false;   // tuning/testing: use the multi-wave LDS k
 // (launch bound: lets the register allocator use the VGPR budget the block size really leaves).
 // LDS per buffer: [MR*D][64] integral tile, then [(1 + NA)][D*D] operands (T_g, Bbar of the
 // block's noise operators), NA = accum_na(D, nwaves).
-#if defined(FFK_WPE)  /* tuning builds: pin the occupancy target of the register allocator */
-#define FFK_ACCUM_ATTR __attribute__((amdgpu_waves_per_eu(FFK_WPE, FFK_WPE)))
+// Occupancy target handed to the register allocator (2nd __launch_bounds__ argument = minimum
+// waves per SIMD).  Measured on MI355X (profiles/r01_c_*): for the d = 4 kernel 3 waves/SIMD
+// (<= 168 VGPRs, LDS operands partly re-read instead of all kept in registers) beats both
+// 2 waves/SIMD (256 VGPRs, -17 %) and 4 waves/SIMD (128 VGPRs, spills, 8x slower).  Blocks are
+// therefore capped at 8 waves.  FFK_WPE overrides the target in tuning builds.
+#if defined(FFK_WPE)
+#define FFK_ACCUM_WPE(D) FFK_WPE
 #else
-#define FFK_ACCUM_ATTR
+#define FFK_ACCUM_WPE(D) ((D) <= 4 ? 3 : 2)
 #endif
 
 template <int D, int JB, int MR, int NBUF, int MAXW>
-__global__ __launch_bounds__(MAXW*64) FFK_ACCUM_ATTR void ctrl_accumulate_kernel(
+__global__ __launch_bounds__(MAXW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, int na_blk,
     cplx* __restrict__ Ypart) {
@@ -97,31 +102,46 @@ __global__ __launch_bounds__(MAXW*64) FFK_ACCUM_ATTR void ctrl_accumulate_kernel
         cplx staged = {0.0, 0.0};
         if (stage == 0 && e0 < n_ops)
             staged = src_ops[e0 < D*D ? e0 : e0 + alpha0*D*D];
+        // The per-entry table values (dE, sin b, cos b) are wave-uniform, but fetching them with
+        // scalar loads put two exposed s_waitcnt lgkmcnt(0) round trips in front of every entry
+        // (profiles/r01_c_*).  They are fetched as vector loads through a pointer the compiler can
+        // no longer prove uniform (every lane reads the same address: one L1 broadcast), issued
+        // one entry ahead, so vmcnt counting hides the latency behind the previous entry.
+        const double* stv = st;
+        asm volatile("" : "+v"(stv));
+        struct Tab { double dE, sb, cb; };
+        auto load_tab = [&](int e) -> Tab { return {stv[2 + e], stv[2 + D*D + e], stv[2 + 2*D*D + e]}; };
+        auto slot_of = [&](int ce) -> int {   // compact entry index -> m*D + n (0 = the diagonal)
+            if (ce == 0) return 0;
+            const int o = ce - 1;
+            const int m = o/(D - 1), r = o % (D - 1);
+            return m*D + r + (r >= m ? 1 : 0);
+        };
+        const int e_first = (MR == D) ? wave : wave;
+        const int e_count = (MR == D) ? NE : min(MR, D - stage*MR)*D;
+        const int e_base = (MR == D) ? 0 : stage*MR*D;
+        Tab cur = {0.0, 0.0, 1.0};
+        if (e_first < e_count) cur = load_tab((MR == D) ? slot_of(e_first) : e_base + e_first);
+
         const double dtg = st[0];
         const cplx ph = cexp(om*st[1]);
+        // half-angle of the diagonal entry, a = fl(w dt)/2: every off-diagonal entry follows
+        // from (sin a, cos a) and the segment's precomputed (sin b, cos b) by angle addition
+        // (dE = 0, sin b = 0, cos b = 1 on the diagonal and for exactly degenerate levels)
+        double sa, ca;
+        sincos_pi(0.5*(om*dtg), &sa, &ca);
         cplx* dst = tile + lane;
-        if (MR == D) {
-            for (int ce = wave; ce < NE; ce += nwaves) {
-                int slot = 0;  // the diagonal lives in slot 0
-                if (ce > 0) {
-                    const int o = ce - 1;
-                    const int m = o/(D - 1), r = o % (D - 1);
-                    slot = m*D + r + (r >= m ? 1 : 0);
-                }
+        for (int ce = e_first; ce < e_count; ce += nwaves) {
+            const int nxt = ce + nwaves;
+            Tab nx = cur;
+            if (nxt < e_count) nx = load_tab((MR == D) ? slot_of(nxt) : e_base + nxt);
+            const int slot = (MR == D) ? slot_of(ce) : ce;
 #if defined(FFK_ABLATE) && FFK_ABLATE == 1   /* diagnostic build: no integral generation */
-                dst[slot*64] = {om, dtg + ph.re};
+            dst[slot*64] = {om, dtg + ph.re + cur.dE};
 #else
-                const cplx I = first_order_integral(om, st[2 + slot], dtg);
-                dst[slot*64] = cmul(ph, I);
+            dst[slot*64] = cmul(ph, first_order_integral_aa(om, cur.dE, dtg, sa, ca, cur.sb, cur.cb));
 #endif
-            }
-        } else {
-            const int m0 = stage*MR;
-            const int rows = min(MR, D - m0);
-            for (int e = wave; e < rows*D; e += nwaves) {
-                const cplx I = first_order_integral(om, st[2 + m0*D + e], dtg);
-                dst[e*64] = cmul(ph, I);
-            }
+            cur = nx;
         }
         if (stage == 0) {
             cplx* dst_ops = tile + TILE;
@@ -169,6 +189,13 @@ __global__ __launch_bounds__(MAXW*64) FFK_ACCUM_ATTR void ctrl_accumulate_kernel
         __syncthreads();
         for (int g = g0; g < g1; ++g) {
             const int buf = (g - g0) & 1;
+#if defined(FFK_ABLATE) && (FFK_ABLATE == 4 || FFK_ABLATE == 5)  /* diagnostic: contraction only */
+            if (active) phase_b(g, 0, buf);
+#if FFK_ABLATE == 4
+            __syncthreads();
+#endif
+            continue;
+#endif
             if (g + 1 < g1) phase_a(g + 1, 0, buf ^ 1);
 #if !(defined(FFK_ABLATE) && FFK_ABLATE == 3)  /* diagnostic build 3: no contraction */
             if (active) phase_b(g, 0, buf);
@@ -251,14 +278,29 @@ __global__ __launch_bounds__(64) void ctrl_accumulate_wave_kernel(
         const double dtg = st[0];
         const cplx ph = cexp(om*st[1]);
 
-        // e^{i w t_g} I^(g): the diagonal entries coincide (dE = 0)
+        // e^{i w t_g} I^(g): the diagonal entries coincide (dE = 0); off-diagonal ones by angle
+        // addition from the diagonal's half-angle a = fl(w dt)/2
+        double sa, ca;
+        sincos_pi(0.5*(om*dtg), &sa, &ca);
         cplx Ip[D][D];
-        Ip[0][0] = cmul(ph, first_order_integral(om, 0.0, dtg));
+        {
+            const double q = 2.0*sa*rcp(om);
+            cplx I = {q*ca, q*sa};
+            if (om == 0.0) I = {dtg, 0.0};
+            Ip[0][0] = cmul(ph, I);
+        }
 #pragma unroll
         for (int m = 0; m < D; ++m)
 #pragma unroll
             for (int n = 0; n < D; ++n)
-                if (m != n) Ip[m][n] = cmul(ph, first_order_integral(om, st[2 + m*D + n], dtg));
+                if (m != n) {
+                    const int e = m*D + n;
+                    const double dE = st[2 + e];
+                    Ip[m][n] = dE == 0.0 ? Ip[0][0]
+                                         : cmul(ph, first_order_integral_aa(om, dE, dtg, sa, ca,
+                                                                            st[2 + D*D + e],
+                                                                            st[2 + 2*D*D + e]));
+                }
 
         const cplx* opT = opbuf[buf];
 #pragma unroll
@@ -366,18 +408,76 @@ hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx
     }
     if (geo.nwaves <= 4)
         return launch_dw<D, 4>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
-    if (geo.nwaves <= 8)
-        return launch_dw<D, 8>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
-    return launch_dw<D, 16>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
+    return launch_dw<D, 8>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
+}
+
+// resident blocks per CU of the kernel instantiation a geometry selects (occupancy API, cached)
+template <int D, int MAXW>
+int blocks_per_cu_dw(int nbuf, int block, int lds_bytes) {
+    constexpr int JB = accum_jb(D);
+    constexpr int MR = accum_mr(D);
+    int n = 0;
+    hipError_t err;
+    if constexpr (MR == D) {
+        if (nbuf == 2) {
+            auto kern = ctrl_accumulate_kernel<D, JB, MR, 2, MAXW>;
+            if (lds_bytes > 48*1024)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, block, lds_bytes);
+            return err == hipSuccess ? n : 0;
+        }
+    }
+    auto kern = ctrl_accumulate_kernel<D, JB, MR, 1, MAXW>;
+    if (lds_bytes > 48*1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, block, lds_bytes);
+    return err == hipSuccess ? n : 0;
+}
+
+int query_blocks_per_cu(int d, int nwaves, int nbuf, int lds_bytes) {
+    static int cache[kMaxD + 1][9][3] = {};
+    int& slot = cache[d][nwaves][nbuf];
+    if (slot > 0) return slot;
+    int n = 0;
+    switch (d) {
+#define FFK_CASE(D)                                                                     \
+    case D:                                                                             \
+        n = nwaves <= 4 ? blocks_per_cu_dw<D, 4>(nbuf, nwaves*64, lds_bytes)            \
+                        : blocks_per_cu_dw<D, 8>(nbuf, nwaves*64, lds_bytes);           \
+        break;
+        FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
+        FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
+        FFK_CASE(15) FFK_CASE(16)
+#undef FFK_CASE
+        default:
+            break;
+    }
+    if (n < 1) n = 1;
+    slot = n;
+    return n;
+}
+
+int device_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
 }
 
 }  // namespace
 
-void set_force_block_kernel(bool on) { g_force_block_kernel = on; }
+void set_use_wave_kernel(bool on) { g_use_wave_kernel = on; }
 
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks) {
     AccumGeometry geo;
-    geo.wave_kernel = d <= kWaveKernelMaxD && !g_force_block_kernel;
+    geo.wave_kernel = d <= kWaveKernelMaxD && g_use_wave_kernel;
     if (geo.wave_kernel) {
         // one wave per block, up to 3 noise operators per lane; blocks per CU = 4 (1 wave/SIMD)
         geo.na_blk = A <= 3 ? A : (A % 3 == 0 ? 3 : (A % 2 == 0 ? 2 : 3));
@@ -400,11 +500,11 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     }
     const int jb = accum_jb(d);
     const int ntasks = A*(d / jb);
-    // waves per block: all tasks if they fit (<= 16 waves), otherwise the divisor-friendly
-    // largest count <= 16 so that the generated integral is shared as widely as possible.
-    int nw = ntasks <= 16 ? ntasks : 16;
-    if (ntasks > 16) {
-        for (int c = 16; c >= 8; --c)
+    // waves per block: all tasks if they fit (<= 8 waves), otherwise the divisor-friendly
+    // largest count <= 8 so that the generated integral is shared as widely as possible.
+    int nw = ntasks <= 8 ? ntasks : 8;
+    if (ntasks > 8) {
+        for (int c = 8; c >= 5; --c)
             if (ntasks % c == 0) {
                 nw = c;
                 break;
@@ -417,15 +517,18 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     const size_t one = (static_cast<size_t>(accum_mr(d))*d*64 + static_cast<size_t>(1 + geo.na_blk)*d*d)*sizeof(cplx);
     geo.nbuf = (accum_mr(d) == d && 2*one <= 160*1024) ? 2 : 1;
     geo.lds_bytes = static_cast<int>(geo.nbuf*one);
-    // segment chunks: aim for >= ~4 waves per SIMD over the chip (256 CUs x 4 SIMDs)
-    const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups*nw;
+    // Segment chunks.  Every block runs its whole chunk, so the launch is fastest when the grid is
+    // a whole number of "rounds" of resident blocks (profiles/r01_a_chunk_sweep.txt: 16 chunks =
+    // 1024 blocks = exactly one round beat 22 chunks by 25 %): pick the chunk count that fills
+    // one round, or the largest that still gives every chunk >= 4 segments.
+    const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups;
     int chunks = forced_chunks;
     if (chunks <= 0) {
-        const long target = 4096;
-        chunks = static_cast<int>((target + tiles - 1)/tiles);
-        if (chunks < 1) chunks = 1;
-        const int max_chunks = (G + 3)/4;  // keep >= 4 segments per chunk
-        if (chunks > max_chunks) chunks = max_chunks < 1 ? 1 : max_chunks;
+        const long capacity = static_cast<long>(device_cu_count())*
+                              query_blocks_per_cu(d, nw, geo.nbuf, geo.lds_bytes);
+        chunks = static_cast<int>(std::max<long>(1, capacity / std::max<long>(1, tiles)));
+        const int max_chunks = std::max(1, (G + 3)/4);  // keep >= 4 segments per chunk
+        chunks = std::min(chunks, max_chunks);
     }
     if (chunks > G) chunks = G;
     if (chunks < 1) chunks = 1;

@@ -239,6 +239,11 @@ int ffk_set_segment_chunks(int chunks) {
     g_forced_chunks = chunks;
     return FFK_OK;
 }
+int ffk_set_accumulate_variant(int variant) {
+    FFK_REQUIRE(variant == 0 || variant == 1, "variant must be 0 or 1");
+    ffk::set_use_wave_kernel(variant == 1);
+    return FFK_OK;
+}
 int ffk_set_accumulate_events(void* start, void* stop) {
     g_ev_start = static_cast<hipEvent_t>(start);
     g_ev_stop = static_cast<hipEvent_t>(stop);

@@ -15,9 +15,11 @@ namespace ffk {
 constexpr int kMaxD = 16;
 constexpr int kWave = 64;
 
-// Per-segment uniform table row: [0] = dt_g, [1] = t_g, [2 + m*d + n] = D_m - D_n, padded to a
-// multiple of 8 doubles so each row starts 64-byte aligned (scalar loads).
-__host__ __device__ constexpr int seg_stride(int d) { return ((2 + d*d + 7)/8)*8; }
+// Per-segment uniform table row: [0] = dt_g, [1] = t_g, then three d x d blocks:
+// dE[m,n] = D_m - D_n, sin(b[m,n]) and cos(b[m,n]) with b = fl(dE*dt)/2 (the frequency-independent
+// half-angles of first_order_integral_aa); padded to a multiple of 8 doubles so each row starts
+// 64-byte aligned (scalar loads).
+__host__ __device__ constexpr int seg_stride(int d) { return ((2 + 3*d*d + 7)/8)*8; }
 
 // Columns of the Hilbert-space accumulator kept per thread in ctrl_accumulate.
 __host__ __device__ constexpr int accum_jb(int d) {
@@ -71,7 +73,7 @@ struct AccumGeometry {
     int na_blk;       // noise operators whose Bbar one block stages in LDS
     bool wave_kernel; // small-d one-wave-per-block variant
 };
-void set_force_block_kernel(bool on);
+void set_use_wave_kernel(bool on);
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks);
 // Ypart (chunks, A, d, d, W): partial Hilbert-space sums, omega fastest
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,

@@ -130,6 +130,32 @@ FFK_HD cplx first_order_integral(double omega, double dE, double dt) {
     return out;
 }
 
+// The same integral for an off-diagonal entry, given sin/cos of the two half-angles
+//     a = fl(omega*dt)/2     (per frequency: the diagonal entry's own argument) and
+//     b = fl(dE*dt)/2        (per segment and entry: frequency independent, precomputed),
+// through the addition theorems  sin(a+b) = sa cb + ca sb,  cos(a+b) = ca cb - sa sb:
+// 4 flops instead of a sincos.  x = fl(omega + dE) (for 1/x and the exact-zero test) is still
+// formed exactly like the reference; only the half-angle a+b differs from the reference's
+// fl(fl(omega+dE)*dt)/2 by a few ulp of (|omega|+|dE|) dt, worth ~1e-16*dt absolute in I.
+// Near a resonance (omega ~ -dE) the sum sa cb + ca sb cancels; below |h| < 2^-5 the direct
+// evaluation is used instead (a divergent but rare branch: the band is a few percent of a
+// logarithmic grid, for the half of the entries with dE < 0).
+FFK_HD cplx first_order_integral_aa(double omega, double dE, double dt, double sa, double ca,
+                                    double sb, double cb) {
+    const double x = omega + dE;
+    const double h = 0.5*(x*dt);
+    double s = fma(sa, cb, ca*sb);
+    double c = fma(ca, cb, -(sa*sb));
+    if (fabs(h) < 0.03125) sincos_pi(h, &s, &c);
+    const double q = 2.0*s*rcp(x);
+    cplx out = {q*c, q*s};
+    if (x == 0.0) {
+        out.re = dt;
+        out.im = 0.0;
+    }
+    return out;
+}
+
 // exp(i x) as (cos, sin), util.py:136-162
 FFK_HD cplx cexp(double x) {
     cplx out;

@@ -37,9 +37,15 @@ __global__ __launch_bounds__(64) void prologue_kernel(
         st[0] = dt[g];
         st[1] = t[g];
     }
-    for (int e = lane; e < D*D; e += 64)
-        st[2 + e] = eigvals[static_cast<size_t>(g)*D + e / D] - eigvals[static_cast<size_t>(g)*D + e % D];
-    for (int e = 2 + D*D + lane; e < S; e += 64) st[e] = 0.0;
+    for (int e = lane; e < D*D; e += 64) {
+        const double dE = eigvals[static_cast<size_t>(g)*D + e / D] - eigvals[static_cast<size_t>(g)*D + e % D];
+        double sb, cb;
+        sincos_pi(0.5*(dE*dt[g]), &sb, &cb);
+        st[2 + e] = dE;
+        st[2 + D*D + e] = sb;
+        st[2 + 2*D*D + e] = cb;
+    }
+    for (int e = 2 + 3*D*D + lane; e < S; e += 64) st[e] = 0.0;
     __syncthreads();
 
     // T = V^dag Q

@@ -47,7 +47,10 @@ def gather_omega_shards(local, n_omega, group=None):
     # complex dtypes travel as interleaved reals
     flat = torch.view_as_real(send.contiguous()) if send.is_complex() else send.contiguous()
     recv = torch.empty((world,) + flat.shape, dtype=flat.dtype, device=flat.device)
-    dist.all_gather_into_tensor(recv, flat, group=group)
+    if dist.get_backend(group) == 'gloo':       # gloo has no flat all-gather
+        dist.all_gather(list(recv.unbind(0)), flat, group=group)
+    else:                                       # nccl = RCCL: one collective into one buffer
+        dist.all_gather_into_tensor(recv, flat, group=group)
     if send.is_complex():
         recv = torch.view_as_complex(recv)
     # (world, ..., wmax) -> (..., world, wmax) -> (..., n_omega)

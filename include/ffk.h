@@ -188,6 +188,10 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Number of segment chunks the control-matrix kernel splits G into (0 = automatic).        */
 int ffk_set_segment_chunks(int chunks);
+/* Kernel variant of the control-matrix accumulation: 0 = default (multi-wave blocks sharing the
+ * generated integral through LDS), 1 = one-wave-per-block variant for d <= 4 (kept for tuning;
+ * measured slower on MI355X because its 48 accumulators per lane spill into AGPRs).           */
+int ffk_set_accumulate_variant(int variant);
 /* Per-call statistics of the last ffk_control_matrix*_dev launch on this thread:
  * algorithmic FP64 flops of the accumulate kernel, its grid/block geometry, chunks used.   */
 typedef struct ffk_stats {

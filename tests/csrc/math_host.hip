@@ -18,4 +18,16 @@ void ffk_host_first_order_integral(long n, const double* omega, const double* dE
     }
 }
 
+void ffk_host_first_order_integral_aa(long n, const double* omega, const double* dE, double dt,
+                                      double* out) {
+    for (long i = 0; i < n; ++i) {
+        double sa, ca, sb, cb;
+        ffk::sincos_pi(0.5*(omega[i]*dt), &sa, &ca);
+        ffk::sincos_pi(0.5*(dE[i]*dt), &sb, &cb);
+        ffk::cplx v = ffk::first_order_integral_aa(omega[i], dE[i], dt, sa, ca, sb, cb);
+        out[2*i] = v.re;
+        out[2*i + 1] = v.im;
+    }
+}
+
 }  // extern "C"

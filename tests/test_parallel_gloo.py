@@ -1,0 +1,81 @@
+"""CPU, world_size 2, gloo: the omega-sharding and all-gather logic of
+filter_functions_amd.parallel (partition, uneven blocks, complex payloads, layout), with the
+oracle standing in for the per-shard compute (the product's compute is the HIP pipeline; these
+tests only exercise the distribution logic, which is backend independent)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.multiprocessing as mp  # noqa: E402
+
+from conftest import ROOT  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_omega, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+
+    import ff_oracle as orc
+    from filter_functions_amd.parallel import (gather_omega_shards, shard_bounds,
+                                               sharded_filter_function)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'rand_d3_ggm.npz'))
+    omega = np.linspace(-2.0, 9.0, n_omega)
+
+    def compute_shard(omega_block):
+        R = orc.control_matrix_from_scratch(g['eigvals'], g['eigvecs'], g['propagators'],
+                                            omega_block, g['basis'], g['n_opers'], g['n_coeffs'],
+                                            g['dt'], g['t'])
+        return torch.from_numpy(orc.filter_function(R))
+
+    F = sharded_filter_function(compute_shard, omega).numpy()
+    # a real-valued payload with a different leading shape through the same collective
+    w0, w1 = shard_bounds(n_omega, world, rank)
+    local = torch.arange(w0, w1, dtype=torch.float64).repeat(2, 1)*(1.0)
+    idx = gather_omega_shards(local, n_omega).numpy()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), F=F, idx=idx)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_omega', [10, 13])       # even and uneven blocks
+def test_sharded_filter_function_matches_unsharded(tmp_path, n_omega):
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import ff_oracle as orc
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_omega, str(tmp_path)), nprocs=world, join=True)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'rand_d3_ggm.npz'))
+    omega = np.linspace(-2.0, 9.0, n_omega)
+    R = orc.control_matrix_from_scratch(g['eigvals'], g['eigvecs'], g['propagators'], omega,
+                                        g['basis'], g['n_opers'], g['n_coeffs'], g['dt'], g['t'])
+    F_ref = orc.filter_function(R)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f'rank{rank}.npz'))
+        assert got['F'].shape == F_ref.shape
+        assert np.array_equal(got['F'], F_ref)              # same arithmetic, only re-laid out
+        assert np.array_equal(got['idx'], np.tile(np.arange(n_omega, dtype=float), (2, 1)))
+
+
+def test_shard_bounds_partition():
+    from filter_functions_amd.parallel import shard_bounds
+    for n in (1, 7, 8, 4096, 65536 + 3):
+        for world in (1, 2, 3, 8):
+            bounds = [shard_bounds(n, world, r) for r in range(world)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == n
+            assert all(b[1] == c[0] for b, c in zip(bounds, bounds[1:]))
+            sizes = [b[1] - b[0] for b in bounds]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)

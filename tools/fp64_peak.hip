@@ -35,6 +35,48 @@ __global__ __launch_bounds__(256) void valu_kernel(double* out, double a, double
     out[blockIdx.x*blockDim.x + threadIdx.x] = s;
 }
 
+// three VGPR sources per FMA (acc += x*y with per-lane x, y): the operand pattern of a
+// contraction whose operands were broadcast from LDS into vector registers
+__global__ __launch_bounds__(256) void valu3_kernel(double* out, double a, double b) {
+    double acc[8], x[4], y[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = threadIdx.x*1e-9 + i;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = out[(threadIdx.x + 64*i) & 1023]*1e-30 + a;   // per-lane values -> VGPRs
+        y[i] = out[(threadIdx.x + 64*i + 7) & 1023]*1e-30 + b;
+    }
+    for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fma(x[i & 3], y[(i + (i >> 2)) & 3], acc[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fma(x[(i + 1) & 3], y[i & 3], acc[i]);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i];
+    out[blockIdx.x*blockDim.x + threadIdx.x] = s;
+}
+
+// two VGPR sources + one SGPR source (acc += s*y)
+__global__ __launch_bounds__(256) void valu2s_kernel(double* out, double a, double b) {
+    double acc[8], y[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = threadIdx.x*1e-9 + i;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = out[(threadIdx.x + 64*i + 7) & 1023]*1e-30 + b;
+    for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fma(a, y[i & 3], acc[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fma(b, y[(i + 1) & 3], acc[i]);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i];
+    out[blockIdx.x*blockDim.x + threadIdx.x] = s;
+}
+
 __global__ __launch_bounds__(256) void mfma16_kernel(double* out, double a, double b) {
     f64x4 acc[4];
 #pragma unroll
@@ -125,6 +167,8 @@ int main() {
     CHECK(hipMalloc(&out, sizeof(double)*prop.multiProcessorCount*8*512));
     // per thread and iteration: 16 FMA = 32 flop
     if (time_kernel("v_fma_f64 (VALU)", valu_kernel, 256, 32.0, out)) return 1;
+    if (time_kernel("v_fma_f64 3 VGPR sources", valu3_kernel, 256, 32.0, out)) return 1;
+    if (time_kernel("v_fma_f64 2 VGPR + 1 SGPR", valu2s_kernel, 256, 32.0, out)) return 1;
     // per wave and iteration: 4 MFMA x 16*16*4*2 flop = 8192 flop -> /64 lanes
     if (time_kernel("v_mfma_f64_16x16x4", mfma16_kernel, 256, 4*2048.0/64, out)) return 1;
     // 4x4x4 with 4 blocks: 4*4*4*4*2 = 512 flop per instruction

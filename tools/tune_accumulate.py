@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--A', type=int, default=3)
     ap.add_argument('--W', type=int, default=4096)
     ap.add_argument('--reps', type=int, default=30)
+    ap.add_argument('--variant', type=int, default=0, help='0 default block kernel, 1 one-wave kernel (d <= 4)')
     ap.add_argument('--chunks', type=int, nargs='*', default=[0, 4, 8, 11, 12, 16, 22, 32, 43, 64])
     args = ap.parse_args()
     d, G, A, W = args.d, args.G, args.A, args.W
@@ -41,6 +42,7 @@ def main():
     omega = np.geomspace(1e-2/dt.sum(), 1e2/dt.min(), W)
     basis = ff.Basis.pauli(int(np.log2(d))) if d in (2, 4, 8, 16) else ff.Basis.ggm(d)
     lib = _lib.load()
+    _lib.check(lib.ffk_set_accumulate_variant(args.variant))
     e0, e1, t0, t1 = (ctypes.c_void_p() for _ in range(4))
     for e in (e0, e1, t0, t1):
         _lib.check(lib.ffk_event_create(ctypes.byref(e)))
