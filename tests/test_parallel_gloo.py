@@ -64,7 +64,9 @@ def test_sharded_filter_function_matches_unsharded(tmp_path, n_omega):
     for rank in range(world):
         got = np.load(os.path.join(str(tmp_path), f'rank{rank}.npz'))
         assert got['F'].shape == F_ref.shape
-        assert np.array_equal(got['F'], F_ref)              # same arithmetic, only re-laid out
+        # the stand-in compute is BLAS-backed, whose blocking (hence rounding) depends on the block
+        # width; the layout/gather logic itself is exact (integer payload below)
+        assert np.abs(got['F'] - F_ref).max() <= 1e-13*np.abs(F_ref).max()
         assert np.array_equal(got['idx'], np.tile(np.arange(n_omega, dtype=float), (2, 1)))
 
 
