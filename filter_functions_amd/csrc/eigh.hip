@@ -17,27 +17,38 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Wave-private LDS state of one eigensolve
 template <int D>
-__global__ __launch_bounds__(64) void eigh_expm_kernel(const cplx* __restrict__ H,
-                                                       const double* __restrict__ dt, int G,
-                                                       double* __restrict__ eigvals,
-                                                       cplx* __restrict__ eigvecs,
-                                                       cplx* __restrict__ seg_prop,
-                                                       int* __restrict__ status) {
-    constexpr int DP = D + (D & 1);  // round-robin players (a bye when D is odd)
-    constexpr int NP = DP/2;         // rotations per step
-    constexpr int kMaxSweeps = 40;
-    __shared__ cplx A[D][D];
-    __shared__ cplx V[D][D];
-    __shared__ double rot_c[NP];
-    __shared__ cplx rot_w[NP];
-    __shared__ int rot_p[NP], rot_q[NP];
-    __shared__ double lam[D];
-    __shared__ cplx phase[D];
+struct EighState {
+    static constexpr int DP = D + (D & 1);  // round-robin players (a bye when D is odd)
+    static constexpr int NP = DP/2;         // rotations per step
+    cplx A[D][D];
+    cplx V[D][D];
+    cplx rot_w[NP];
+    double rot_c[NP];
+    int rot_p[NP], rot_q[NP];
+    cplx phase[D];
+};
 
-    const int g = blockIdx.x;
-    const int lane = threadIdx.x;
-    const cplx* Hg = H + static_cast<size_t>(g)*D*D;
+// Intra-wavefront hand-off through LDS: the LDS unit executes one wave's instructions in order,
+// so only the compiler needs telling that other lanes wrote memory.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One wavefront: eigendecomposition of Hg (lower triangle), eigenvalues/eigenvectors to global
+// memory in ascending order, segment propagator P = V exp(-i D dt) V^dag to `P` (LDS or global).
+// Returns false if the Jacobi iteration clearly failed to converge.
+template <int D>
+__device__ bool eigh_expm_wave(EighState<D>& st, const cplx* __restrict__ Hg, double dtg, int lane,
+                               double* __restrict__ eigvals_g, cplx* __restrict__ eigvecs_g,
+                               cplx* P) {
+    constexpr int DP = EighState<D>::DP;
+    constexpr int NP = EighState<D>::NP;
+    constexpr int kMaxSweeps = 40;
+    auto& A = st.A;
+    auto& V = st.V;
 
     for (int e = lane; e < D*D; e += 64) {
         const int i = e / D, j = e % D;
@@ -52,7 +63,7 @@ __global__ __launch_bounds__(64) void eigh_expm_kernel(const cplx* __restrict__ 
         A[i][j] = h;
         V[i][j] = {i == j ? 1.0 : 0.0, 0.0};
     }
-    __syncthreads();
+    wave_sync();
 
     const double tol2 = static_cast<double>(D*D)*4.930380657631324e-32;  // (D eps)^2
     bool converged = false;
@@ -93,61 +104,70 @@ __global__ __launch_bounds__(64) void eigh_expm_kernel(const cplx* __restrict__ 
                     const cplx apq = A[p][q];
                     const double mag2 = apq.re*apq.re + apq.im*apq.im;
                     if (mag2 > 0.0) {
-                        const double mag = sqrt(mag2);
-                        const double tau = (A[q][q].re - A[p][p].re)/(2.0*mag);
-                        const double sgn = tau >= 0.0 ? 1.0 : -1.0;
-                        const double tt = sgn/(fabs(tau) + sqrt(fma(tau, tau, 1.0)));
-                        c = 1.0/sqrt(fma(tt, tt, 1.0));
-                        const double s = tt*c;
-                        w = {s*apq.re/mag, s*apq.im/mag};
+                        // rotation angle without IEEE divisions / square roots (reciprocal and
+                        // reciprocal-square-root seeds + Newton): this scalar section is the
+                        // critical path of every Jacobi step
+                        const double rmag = rsqrt(mag2);                       // 1/|a_pq|
+                        const double tau = 0.5*(A[q][q].re - A[p][p].re)*rmag;
+                        if (fabs(tau) < 1e150) {
+                            const double h2 = fma(tau, tau, 1.0);
+                            const double h = h2*rsqrt(h2);                     // sqrt(1 + tau^2)
+                            const double tt = (tau >= 0.0 ? 1.0 : -1.0)*rcp(fabs(tau) + h);
+                            c = rsqrt(fma(tt, tt, 1.0));
+                            const double s = tt*c*rmag;
+                            w = {s*apq.re, s*apq.im};
+                        } else {
+                            valid = false;   // |a_pq| below 1e-150 of the diagonal gap: nothing to do
+                        }
                     } else {
                         valid = false;
                     }
                 }
-                rot_p[lane] = p;
-                rot_q[lane] = valid ? q : -1;
-                rot_c[lane] = c;
-                rot_w[lane] = w;
+                st.rot_p[lane] = p;
+                st.rot_q[lane] = valid ? q : -1;
+                st.rot_c[lane] = c;
+                st.rot_w[lane] = w;
             }
-            __syncthreads();
+            wave_sync();
             // column update of A and V:  (x_p, x_q) <- (c x_p - conj(w) x_q, w x_p + c x_q)
             for (int it = lane; it < NP*D*2; it += 64) {
                 const int pr = it/(2*D), r = it % (2*D);
-                const int q = rot_q[pr];
+                const int q = st.rot_q[pr];
                 if (q < 0) continue;
-                const int p = rot_p[pr];
-                const double c = rot_c[pr];
-                const cplx w = rot_w[pr];
+                const int p = st.rot_p[pr];
+                const double c = st.rot_c[pr];
+                const cplx w = st.rot_w[pr];
                 cplx(*M)[D] = (r >= D) ? V : A;
                 const int row = r % D;
                 const cplx xp = M[row][p], xq = M[row][q];
                 M[row][p] = {c*xp.re - (w.re*xq.re + w.im*xq.im), c*xp.im - (w.re*xq.im - w.im*xq.re)};
                 M[row][q] = {c*xq.re + (w.re*xp.re - w.im*xp.im), c*xq.im + (w.re*xp.im + w.im*xp.re)};
             }
-            __syncthreads();
+            wave_sync();
             // row update of A:  (x_p, x_q) <- (c x_p - w x_q, conj(w) x_p + c x_q)
             for (int it = lane; it < NP*D; it += 64) {
                 const int pr = it / D, col = it % D;
-                const int q = rot_q[pr];
+                const int q = st.rot_q[pr];
                 if (q < 0) continue;
-                const int p = rot_p[pr];
-                const double c = rot_c[pr];
-                const cplx w = rot_w[pr];
+                const int p = st.rot_p[pr];
+                const double c = st.rot_c[pr];
+                const cplx w = st.rot_w[pr];
                 const cplx xp = A[p][col], xq = A[q][col];
                 A[p][col] = {c*xp.re - (w.re*xq.re - w.im*xq.im), c*xp.im - (w.re*xq.im + w.im*xq.re)};
                 A[q][col] = {c*xq.re + (w.re*xp.re + w.im*xp.im), c*xq.im + (w.re*xp.im - w.im*xp.re)};
             }
-            __syncthreads();
-            if (lane < NP && rot_q[lane] >= 0) {
-                const int p = rot_p[lane], q = rot_q[lane];
+            wave_sync();
+            if (lane < NP && st.rot_q[lane] >= 0) {
+                const int p = st.rot_p[lane], q = st.rot_q[lane];
                 A[p][q] = {0.0, 0.0};
                 A[q][p] = {0.0, 0.0};
                 A[p][p].im = 0.0;
                 A[q][q].im = 0.0;
             }
-            __syncthreads();
+            wave_sync();
         }
     }
+    bool ok = true;
     if (!converged) {
         // accept a stall just above the threshold, flag a genuine failure
         double off = 0.0, tot = 0.0;
@@ -160,7 +180,7 @@ __global__ __launch_bounds__(64) void eigh_expm_kernel(const cplx* __restrict__ 
         }
         off = wave_sum(off);
         tot = wave_sum(tot);
-        if (!(off <= 1e-24*tot) && lane == 0) atomicAdd(status, 1);
+        ok = off <= 1e-24*tot;
     }
 
     // ascending order by rank (stable), write eigenvalues / eigenvectors
@@ -171,26 +191,41 @@ __global__ __launch_bounds__(64) void eigh_expm_kernel(const cplx* __restrict__ 
             const double lj = A[j][j].re;
             rank += (lj < li || (lj == li && j < lane)) ? 1 : 0;
         }
-        lam[rank] = li;
-        eigvals[static_cast<size_t>(g)*D + rank] = li;
-        rot_p[0] = 0;  // (keeps rot_p live; no effect)
-        // column `lane` of V goes to column `rank`
-        for (int row = 0; row < D; ++row)
-            eigvecs[(static_cast<size_t>(g)*D + row)*D + rank] = V[row][lane];
+        eigvals_g[rank] = li;
+        for (int row = 0; row < D; ++row) eigvecs_g[row*D + rank] = V[row][lane];
         // exp(-i lambda dt): argument rounded exactly like util.cexp(-dt*eigvals), numeric.py:1929
-        phase[lane] = cexp(-(dt[g]*li));
+        st.phase[lane] = cexp(-(dtg*li));
     }
-    __syncthreads();
+    wave_sync();
     // P = V diag(phase) V^dag  (column pairing is order independent)
     for (int e = lane; e < D*D; e += 64) {
         const int i = e / D, k = e % D;
         cplx acc = {0.0, 0.0};
         for (int j = 0; j < D; ++j) {
-            const cplx vp = cmul(V[i][j], phase[j]);
+            const cplx vp = cmul(V[i][j], st.phase[j]);
             cmac_conj(acc, V[k][j], vp);  // += conj(V[k][j]) * vp
         }
-        seg_prop[static_cast<size_t>(g)*D*D + e] = acc;
+        P[e] = acc;
     }
+    return ok;
+}
+
+// Stand-alone K1: one wavefront (= one block) per segment.
+template <int D>
+__global__ __launch_bounds__(64) void eigh_expm_kernel(const cplx* __restrict__ H,
+                                                       const double* __restrict__ dt, int G,
+                                                       double* __restrict__ eigvals,
+                                                       cplx* __restrict__ eigvecs,
+                                                       cplx* __restrict__ seg_prop,
+                                                       int* __restrict__ status) {
+    __shared__ EighState<D> st;
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const bool ok = eigh_expm_wave<D>(st, H + static_cast<size_t>(g)*D*D, dt[g], lane,
+                                      eigvals + static_cast<size_t>(g)*D,
+                                      eigvecs + static_cast<size_t>(g)*D*D,
+                                      seg_prop + static_cast<size_t>(g)*D*D);
+    if (lane == 0) status[g] = ok ? 0 : 1;
 }
 
 template <int D>

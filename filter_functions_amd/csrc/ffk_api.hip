@@ -7,8 +7,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "ffk.h"
 #include "ffk_internal.h"
@@ -47,6 +49,10 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 bool d_ok(int d) { return d >= 2 && d <= FFK_MAX_D; }
+
+// internal flag of ffk_control_matrix_dev: the workspace already holds segtab/Tc/ops (written by
+// the fused front end of ffk_pipeline_dev)
+constexpr unsigned FFK_INTERNAL_PROLOGUE_DONE = 0x80000000u;
 
 // bump allocator over a caller- or arena-provided workspace
 struct Bump {
@@ -258,10 +264,32 @@ int ffk_get_stats(ffk_stats* out) {
 // ---------------------------------------------------------------------------------------------
 // diagonalize
 // ---------------------------------------------------------------------------------------------
+// workspace layout: [status: G ints][seg_prop: G d^2][Qloc: (G+1) d^2][totals / scan scratch]
 size_t ffk_diagonalize_workspace_bytes(int G, int d) {
     if (G < 1 || !d_ok(d)) return 0;
-    return align_up(sizeof(cplx)*size_t(G)*d*d) + ffk::scan_workspace_bytes(G, d) + align_up(sizeof(int));
+    const size_t nch = (size_t(G) + ffk::front_chunk(d) - 1)/ffk::front_chunk(d);
+    return align_up(sizeof(int)*size_t(G)) + align_up(sizeof(cplx)*size_t(G)*d*d) +
+           align_up(sizeof(cplx)*size_t(G + 1)*d*d) +
+           std::max(ffk::scan_workspace_bytes(G, d), align_up(sizeof(cplx)*nch*d*d));
 }
+
+namespace {
+struct DiagWs {
+    int* status;
+    cplx* seg_prop;  // (G, d, d)
+    cplx* qloc;      // (G+1, d, d) chunk-local prefix products
+    void* small;     // scan scratch or chunk totals
+};
+DiagWs slice_diag_ws(void* workspace, size_t bytes, int G, int d) {
+    Bump ws(workspace, bytes);
+    DiagWs out;
+    out.status = ws.take<int>(G);
+    out.seg_prop = ws.take<cplx>(size_t(G)*d*d);
+    out.qloc = ws.take<cplx>(size_t(G + 1)*d*d);
+    out.small = ws.take<unsigned char>(1);
+    return out;
+}
+}  // namespace
 
 int ffk_diagonalize_dev(const double* hamiltonian, const double* dt, int G, int d, double* eigvals,
                         double* eigvecs, double* propagators, void* workspace,
@@ -271,14 +299,20 @@ int ffk_diagonalize_dev(const double* hamiltonian, const double* dt, int G, int 
     FFK_REQUIRE(hamiltonian && dt && eigvals && eigvecs && propagators && workspace, "NULL argument");
     FFK_REQUIRE(workspace_bytes >= ffk_diagonalize_workspace_bytes(G, d), "workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    Bump ws(workspace, workspace_bytes);
-    cplx* seg_prop = ws.take<cplx>(size_t(G)*d*d);
-    void* scan_ws = ws.take<unsigned char>(ffk::scan_workspace_bytes(G, d));
-    int* status = ws.take<int>(1);
-    FFK_HIP(hipMemsetAsync(status, 0, sizeof(int), s));
-    FFK_HIP(ffk::launch_eigh_expm(reinterpret_cast<const cplx*>(hamiltonian), dt, G, d, eigvals,
-                                  reinterpret_cast<cplx*>(eigvecs), seg_prop, status, s));
-    FFK_HIP(ffk::launch_prefix_products(seg_prop, G, d, reinterpret_cast<cplx*>(propagators), scan_ws, s));
+    const DiagWs w = slice_diag_ws(workspace, workspace_bytes, G, d);
+    const cplx* H = reinterpret_cast<const cplx*>(hamiltonian);
+    FFK_HIP(ffk::launch_eigh_expm(H, dt, G, d, eigvals, reinterpret_cast<cplx*>(eigvecs), w.seg_prop,
+                                  w.status, s));
+    if (ffk::use_fused_front(G, d)) {
+        cplx* totals = static_cast<cplx*>(w.small);
+        FFK_HIP(ffk::launch_scan_local(w.seg_prop, G, d, ffk::front_chunk(d), w.qloc, totals, s));
+        FFK_HIP(ffk::launch_apply_prologue(w.qloc, totals, G, d, reinterpret_cast<cplx*>(propagators),
+                                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                                           nullptr, nullptr, nullptr, s));
+    } else {
+        FFK_HIP(ffk::launch_prefix_products(w.seg_prop, G, d, reinterpret_cast<cplx*>(propagators),
+                                            w.small, s));
+    }
     return FFK_OK;
 }
 
@@ -304,15 +338,15 @@ int ffk_diagonalize(const double* hamiltonian, const double* dt, int G, int d, d
     FFK_HIP(hipMemcpyAsync(dH, hamiltonian, nH, hipMemcpyHostToDevice, nullptr));
     FFK_HIP(hipMemcpyAsync(ddt, dt, sizeof(double)*G, hipMemcpyHostToDevice, nullptr));
     if (int rc = ffk_diagonalize_dev(dH, ddt, G, d, dD, dV, dQ, ws, wsb, nullptr)) return rc;
-    int status = 0;
-    // status word is the last slice of the workspace
-    const int* dstatus = reinterpret_cast<const int*>(static_cast<unsigned char*>(ws) +
-                                                      align_up(nH) + ffk::scan_workspace_bytes(G, d));
+    std::vector<int> flags(G, 0);
+    const int* dstatus = slice_diag_ws(ws, wsb, G, d).status;
     FFK_HIP(hipMemcpyAsync(eigvals, dD, sizeof(double)*G*d, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipMemcpyAsync(eigvecs, dV, nH, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipMemcpyAsync(propagators, dQ, nQ, hipMemcpyDeviceToHost, nullptr));
-    FFK_HIP(hipMemcpyAsync(&status, dstatus, sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipMemcpyAsync(flags.data(), dstatus, sizeof(int)*G, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipStreamSynchronize(nullptr));
+    int status = 0;
+    for (int f : flags) status += f;
     if (status != 0)
         return fail(FFK_ENOCONV, "Jacobi eigensolver did not converge for %d segment(s)", status);
     return FFK_OK;
@@ -350,14 +384,16 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     cplx* Bt = ws.take<cplx>(size_t(A)*d*d*W);
     FFK_REQUIRE(Bt, "workspace too small");
 
-    FFK_HIP(ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
-                                 reinterpret_cast<const cplx*>(propagators),
-                                 reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G, d, A,
-                                 segtab, Tc, ops, nullptr, nullptr, s));
+    if (!(flags & FFK_INTERNAL_PROLOGUE_DONE))
+        FFK_HIP(ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
+                                     reinterpret_cast<const cplx*>(propagators),
+                                     reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G, d, A,
+                                     segtab, Tc, ops, nullptr, nullptr, s));
     if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_start, s));
     FFK_HIP(ffk::launch_accumulate(omega, W, segtab, ops, G, d, A, geo, Ypart, s));
     if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_stop, s));
     const size_t slab = size_t(A)*d*d*W;
+    const bool want_B = (flags & FFK_WANT_NOISE_OPERATORS) != 0;
     const cplx* Bsum = Ypart;
     if (geo.chunks > 1) {
         FFK_HIP(ffk::launch_reduce_chunks(Ypart, geo.chunks, slab, Bt, s));
@@ -366,7 +402,7 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     if (control_matrix)
         FFK_HIP(ffk::launch_expand(Bsum, reinterpret_cast<const cplx*>(basis), A, N, d, W,
                                    reinterpret_cast<cplx*>(control_matrix), s));
-    if (flags & FFK_WANT_NOISE_OPERATORS)
+    if (want_B)
         FFK_HIP(ffk::launch_transpose_noise_ops(Bsum, A, d, W, reinterpret_cast<cplx*>(noise_operators), s));
 
     g_stats.accumulate_flops = accumulate_flops(W, A, G, d);
@@ -693,9 +729,30 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
     double* Q = propagators ? propagators : ws.take<double>(2*size_t(G + 1)*d*d);
     double* R = control_matrix ? control_matrix : ws.take<double>(2*size_t(A)*N*W);
     double* F = filter_function ? filter_function : ws.take<double>(2*size_t(A)*A*W);
-    if (int rc = ffk_diagonalize_dev(hamiltonian, dt, G, d, D, V, Q, dws, dwsb, stream)) return rc;
-    if (int rc = ffk_control_matrix_dev(D, V, Q, omega, W, basis, N, n_opers, A, n_coeffs, dt, t, G, d, 0,
-                                        R, nullptr, cws, cwsb, stream))
+    unsigned cm_flags = 0;
+    if (ffk::use_fused_front(G, d)) {
+        // eigh, local scan, then scan fix-up + prologue writing straight into the control-matrix
+        // workspace (same slicing as ffk_control_matrix_dev)
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const DiagWs w = slice_diag_ws(dws, dwsb, G, d);
+        cplx* totals = static_cast<cplx*>(w.small);
+        FFK_HIP(ffk::launch_eigh_expm(reinterpret_cast<const cplx*>(hamiltonian), dt, G, d, D,
+                                      reinterpret_cast<cplx*>(V), w.seg_prop, w.status, s));
+        FFK_HIP(ffk::launch_scan_local(w.seg_prop, G, d, ffk::front_chunk(d), w.qloc, totals, s));
+        Bump cw(cws, cwsb);
+        double* segtab = cw.take<double>(size_t(G)*ffk::seg_stride(d));
+        cplx* Tc = cw.take<cplx>(size_t(G)*d*d);
+        cplx* ops = cw.take<cplx>(size_t(G)*(1 + A)*d*d);
+        FFK_HIP(ffk::launch_apply_prologue(w.qloc, totals, G, d, reinterpret_cast<cplx*>(Q), D,
+                                           reinterpret_cast<const cplx*>(V),
+                                           reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, A,
+                                           segtab, Tc, ops, s));
+        cm_flags = FFK_INTERNAL_PROLOGUE_DONE;
+    } else {
+        if (int rc = ffk_diagonalize_dev(hamiltonian, dt, G, d, D, V, Q, dws, dwsb, stream)) return rc;
+    }
+    if (int rc = ffk_control_matrix_dev(D, V, Q, omega, W, basis, N, n_opers, A, n_coeffs, dt, t, G, d,
+                                        cm_flags, R, nullptr, cws, cwsb, stream))
         return rc;
     if (int rc = ffk_filter_function_dev(R, A, N, W, FFK_FF_FIDELITY, F, stream)) return rc;
     if (want_infid) {

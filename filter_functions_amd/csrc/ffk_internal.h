@@ -32,13 +32,21 @@ __host__ __device__ constexpr int accum_jb(int d) {
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1)/a*a; }
 
 // ---- eigh.hip --------------------------------------------------------------------------------
-// eigvals (G,d), eigvecs (G,d,d), seg_prop (G,d,d) = V exp(-i D dt) V^dag; status: one int,
-// incremented for every matrix whose Jacobi iteration failed to converge.
+// eigvals (G,d), eigvecs (G,d,d), seg_prop (G,d,d) = V exp(-i D dt) V^dag; status (G) ints:
+// 1 for every segment whose Jacobi iteration failed to converge, else 0.
 hipError_t launch_eigh_expm(const cplx* H, const double* dt, int G, int d, double* eigvals,
                             cplx* eigvecs, cplx* seg_prop, int* status, hipStream_t stream);
+// Chunk length of the two-kernel scan used by the fused front end (scan_local + fix-up fused
+// with the prologue): both serial parts are ~sqrt(G) long at G = 256.
+__host__ __device__ constexpr int front_chunk(int d) { return d <= 8 ? 16 : 8; }
+// The fused front end is used while the serial part of its second kernel stays short.
+inline bool use_fused_front(int G, int d) { return (G + front_chunk(d) - 1)/front_chunk(d) <= 64; }
 
 // ---- scan.hip --------------------------------------------------------------------------------
 size_t scan_workspace_bytes(int G, int d);
+// chunk-local prefix products Qloc (G+1,d,d) (Qloc[0] = 1) and chunk totals (nchunks,d,d)
+hipError_t launch_scan_local(const cplx* seg_prop, int G, int d, int L, cplx* Qloc, cplx* totals,
+                             hipStream_t stream);
 // Q (G+1,d,d): Q[0] = 1, Q[g+1] = P[g] Q[g]
 hipError_t launch_prefix_products(const cplx* seg_prop, int G, int d, cplx* Q, void* ws,
                                   hipStream_t stream);
@@ -54,6 +62,13 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
                            const double* t, int G, int d, int A, double* segtab, cplx* Tc,
                            cplx* ops, cplx* n_opers_transformed, cplx* eigvecs_propagated,
                            hipStream_t stream);
+// Fused scan fix-up (+ prologue): every block rebuilds the exclusive chunk prefix E_c from
+// `totals`, writes Q[g+1] = Qloc[g+1] E_c (Q[0] = 1 by block 0) and, if segtab != NULL, runs the
+// prologue for its segment with Q[g] without a round trip through memory.
+hipError_t launch_apply_prologue(const cplx* Qloc, const cplx* totals, int G, int d, cplx* Q,
+                                 const double* eigvals, const cplx* eigvecs, const cplx* n_opers,
+                                 const double* n_coeffs, const double* dt, const double* t, int A,
+                                 double* segtab, cplx* Tc, cplx* ops, hipStream_t stream);
 // basis_transformed (G,N,d,d) = (Q^dag V)^dag C_k (Q^dag V)   (numeric.py:863-864)
 hipError_t launch_basis_transformed(const cplx* Tc, const cplx* basis, int G, int N, int d,
                                     cplx* out, hipStream_t stream);

@@ -110,6 +110,20 @@ FFK_HD double rcp(double x) {
 #endif
 }
 
+// 1/sqrt(x) to ~1 ulp for normal x > 0.  Device: v_rsq_f64 seed + two Newton steps.
+FFK_HD double rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x*y, y, 1.0);
+    y = fma(y, 0.5*e, y);
+    e = fma(-x*y, y, 1.0);
+    y = fma(y, 0.5*e, y);
+    return y;
+#else
+    return 1.0/sqrt(x);
+#endif
+}
+
 // First-order Magnus integral of one (m, n) entry, numeric.py:144-167 with util.cexpm1
 // (util.py:165-182):
 //     I = (exp(i x dt) - 1)/(i x),  x = omega + dE,  I = dt where x == 0 exactly.

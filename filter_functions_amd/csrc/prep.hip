@@ -12,26 +12,18 @@
 namespace ffk {
 namespace {
 
+// Prologue arithmetic for one segment by one wavefront; V (eigenvectors) and Q (propagator
+// before the segment) already sit in LDS.
 template <int D>
-__global__ __launch_bounds__(64) void prologue_kernel(
-    const double* __restrict__ eigvals, const cplx* __restrict__ eigvecs,
-    const cplx* __restrict__ propagators, const cplx* __restrict__ n_opers,
-    const double* __restrict__ n_coeffs, const double* __restrict__ dt,
-    const double* __restrict__ t, int G, int A, double* __restrict__ segtab,
-    cplx* __restrict__ Tc, cplx* __restrict__ ops, cplx* __restrict__ n_opers_transformed,
-    cplx* __restrict__ eigvecs_propagated) {
-    __shared__ cplx V[D][D];
-    __shared__ cplx Q[D][D];
-    __shared__ cplx T[D][D];
-    __shared__ cplx BV[D][D];
-    const int g = blockIdx.x;
-    const int lane = threadIdx.x;
+__device__ void prologue_segment(const cplx (*V)[D], const cplx (*Q)[D], cplx (*T)[D], cplx (*BV)[D],
+                                 int g, int lane, const double* __restrict__ eigvals,
+                                 const cplx* __restrict__ n_opers,
+                                 const double* __restrict__ n_coeffs,
+                                 const double* __restrict__ dt, const double* __restrict__ t, int G,
+                                 int A, double* __restrict__ segtab, cplx* __restrict__ Tc,
+                                 cplx* __restrict__ ops, cplx* __restrict__ n_opers_transformed,
+                                 cplx* __restrict__ eigvecs_propagated) {
     constexpr int S = seg_stride(D);
-
-    for (int e = lane; e < D*D; e += 64) {
-        V[e / D][e % D] = eigvecs[static_cast<size_t>(g)*D*D + e];
-        Q[e / D][e % D] = propagators[static_cast<size_t>(g)*D*D + e];
-    }
     double* st = segtab + static_cast<size_t>(g)*S;
     if (lane == 0) {
         st[0] = dt[g];
@@ -46,7 +38,6 @@ __global__ __launch_bounds__(64) void prologue_kernel(
         st[2 + 2*D*D + e] = cb;
     }
     for (int e = 2 + 3*D*D + lane; e < S; e += 64) st[e] = 0.0;
-    __syncthreads();
 
     // T = V^dag Q
     for (int e = lane; e < D*D; e += 64) {
@@ -88,8 +79,98 @@ __global__ __launch_bounds__(64) void prologue_kernel(
                 n_opers_transformed[(static_cast<size_t>(a)*G + g)*D*D + e] = acc;
         }
         __syncthreads();
-        __syncthreads();
     }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void prologue_kernel(
+    const double* __restrict__ eigvals, const cplx* __restrict__ eigvecs,
+    const cplx* __restrict__ propagators, const cplx* __restrict__ n_opers,
+    const double* __restrict__ n_coeffs, const double* __restrict__ dt,
+    const double* __restrict__ t, int G, int A, double* __restrict__ segtab,
+    cplx* __restrict__ Tc, cplx* __restrict__ ops, cplx* __restrict__ n_opers_transformed,
+    cplx* __restrict__ eigvecs_propagated) {
+    __shared__ cplx V[D][D];
+    __shared__ cplx Q[D][D];
+    __shared__ cplx T[D][D];
+    __shared__ cplx BV[D][D];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < D*D; e += 64) {
+        V[e / D][e % D] = eigvecs[static_cast<size_t>(g)*D*D + e];
+        Q[e / D][e % D] = propagators[static_cast<size_t>(g)*D*D + e];
+    }
+    __syncthreads();
+    prologue_segment<D>(V, Q, T, BV, g, lane, eigvals, n_opers, n_coeffs, dt, t, G, A, segtab, Tc,
+                        ops, n_opers_transformed, eigvecs_propagated);
+}
+
+// Fused scan fix-up + prologue, one wavefront per segment:
+//   E_c = T_{c-1} ... T_0 rebuilt serially from the chunk totals (<= 63 small products, done
+//   redundantly by every block instead of a third launch), Q[g+1] = Qloc[g+1] E_c written out,
+//   Q[g] = Qloc[g] E_c kept in LDS and fed straight into the prologue.
+template <int D>
+__global__ __launch_bounds__(64) void apply_prologue_kernel(
+    const cplx* __restrict__ Qloc, const cplx* __restrict__ totals, int G, int L,
+    cplx* __restrict__ Qout, const double* __restrict__ eigvals, const cplx* __restrict__ eigvecs,
+    const cplx* __restrict__ n_opers, const double* __restrict__ n_coeffs,
+    const double* __restrict__ dt, const double* __restrict__ t, int A,
+    double* __restrict__ segtab, cplx* __restrict__ Tc, cplx* __restrict__ ops) {
+    __shared__ cplx E[2][D][D];
+    __shared__ cplx M[D][D];
+    __shared__ cplx V[D][D];
+    __shared__ cplx Q[D][D];
+    __shared__ cplx T[D][D];
+    __shared__ cplx BV[D][D];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int c = g / L;
+    for (int e = lane; e < D*D; e += 64) E[0][e / D][e % D] = {(e / D == e % D) ? 1.0 : 0.0, 0.0};
+    int b = 0;
+    for (int k = 0; k < c; ++k) {
+        for (int e = lane; e < D*D; e += 64) M[e / D][e % D] = totals[static_cast<size_t>(k)*D*D + e];
+        __syncthreads();
+        for (int e = lane; e < D*D; e += 64) {
+            const int i = e / D, j = e % D;
+            cplx acc = {0.0, 0.0};
+#pragma unroll
+            for (int x = 0; x < D; ++x) cmac(acc, M[i][x], E[b][x][j]);
+            E[b ^ 1][i][j] = acc;
+        }
+        __syncthreads();
+        b ^= 1;
+    }
+    // Q[g] (into LDS) and Q[g+1] (to memory)
+    for (int e = lane; e < D*D; e += 64) M[e / D][e % D] = Qloc[static_cast<size_t>(g + 1)*D*D + e];
+    if (g == 0)
+        for (int e = lane; e < D*D; e += 64) Qout[e] = {(e / D == e % D) ? 1.0 : 0.0, 0.0};
+    __syncthreads();
+    for (int e = lane; e < D*D; e += 64) {
+        const int i = e / D, j = e % D;
+        cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int x = 0; x < D; ++x) cmac(acc, M[i][x], E[b][x][j]);
+        Qout[static_cast<size_t>(g + 1)*D*D + e] = acc;
+    }
+    if (segtab == nullptr) return;
+    __syncthreads();
+    if (g % L == 0) {
+        for (int e = lane; e < D*D; e += 64) Q[e / D][e % D] = E[b][e / D][e % D];
+    } else {
+        for (int e = lane; e < D*D; e += 64) M[e / D][e % D] = Qloc[static_cast<size_t>(g)*D*D + e];
+        __syncthreads();
+        for (int e = lane; e < D*D; e += 64) {
+            const int i = e / D, j = e % D;
+            cplx acc = {0.0, 0.0};
+#pragma unroll
+            for (int x = 0; x < D; ++x) cmac(acc, M[i][x], E[b][x][j]);
+            Q[i][j] = acc;
+        }
+    }
+    for (int e = lane; e < D*D; e += 64) V[e / D][e % D] = eigvecs[static_cast<size_t>(g)*D*D + e];
+    __syncthreads();
+    prologue_segment<D>(V, Q, T, BV, g, lane, eigvals, n_opers, n_coeffs, dt, t, G, A, segtab, Tc,
+                        ops, nullptr, nullptr);
 }
 
 // out[g,k] = T_g C_k T_g^dag with T_g = conj(Tc[g])   (= (Q^dag V)^dag C_k (Q^dag V))
@@ -157,6 +238,28 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
         hipLaunchKernelGGL(prologue_kernel<D>, dim3(G), dim3(64), 0, stream, eigvals, eigvecs,  \
                            propagators, n_opers, n_coeffs, dt, t, G, A, segtab, Tc, ops,        \
                            n_opers_transformed, eigvecs_propagated);                            \
+        break;
+        FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
+        FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
+        FFK_CASE(15) FFK_CASE(16)
+#undef FFK_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_apply_prologue(const cplx* Qloc, const cplx* totals, int G, int d, cplx* Q,
+                                 const double* eigvals, const cplx* eigvecs, const cplx* n_opers,
+                                 const double* n_coeffs, const double* dt, const double* t, int A,
+                                 double* segtab, cplx* Tc, cplx* ops, hipStream_t stream) {
+    const int L = front_chunk(d);
+    switch (d) {
+#define FFK_CASE(D)                                                                              \
+    case D:                                                                                      \
+        hipLaunchKernelGGL(apply_prologue_kernel<D>, dim3(G), dim3(64), 0, stream, Qloc, totals, \
+                           G, L, Q, eigvals, eigvecs, n_opers, n_coeffs, dt, t, A, segtab, Tc,   \
+                           ops);                                                                 \
         break;
         FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
         FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)

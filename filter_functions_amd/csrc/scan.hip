@@ -114,6 +114,27 @@ hipError_t launch_d(const cplx* P, int G, cplx* Q, void* ws, hipStream_t stream)
 
 }  // namespace
 
+// phase 1 only, with a caller-chosen chunk length (the fused fix-up + prologue kernel of
+// prep.hip does phases 2 and 3 itself)
+hipError_t launch_scan_local(const cplx* seg_prop, int G, int d, int L, cplx* Qloc, cplx* totals,
+                             hipStream_t stream) {
+    const int nchunks = (G + L - 1)/L;
+    switch (d) {
+#define FFK_CASE(D)                                                                              \
+    case D:                                                                                      \
+        hipLaunchKernelGGL(scan_local_kernel<D>, dim3(nchunks), dim3(64), 0, stream, seg_prop, G, \
+                           L, Qloc, totals);                                                     \
+        break;
+        FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
+        FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
+        FFK_CASE(15) FFK_CASE(16)
+#undef FFK_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 size_t scan_workspace_bytes(int G, int d) {
     const int L = chunk_length(G);
     const int nchunks = (G + L - 1)/L;
