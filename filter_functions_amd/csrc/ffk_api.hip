@@ -104,7 +104,7 @@ size_t ctrl_ws_bytes(int W, int N, int A, int G, int d, int chunks) {
     b += align_up(sizeof(cplx)*size_t(G)*(1 + A)*d*d);                    // ops
     b += align_up(sizeof(cplx)*size_t(chunks)*A*d*d*W);                   // Ypart
     b += align_up(sizeof(cplx)*size_t(A)*d*d*W);                          // Bt
-    (void)N;
+    b += ffk::expand_workspace_bytes(N, d);                               // compacted basis
     return b;
 }
 
@@ -382,7 +382,8 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     cplx* ops = ws.take<cplx>(size_t(G)*(1 + A)*d*d);
     cplx* Ypart = ws.take<cplx>(size_t(geo.chunks)*A*d*d*W);
     cplx* Bt = ws.take<cplx>(size_t(A)*d*d*W);
-    FFK_REQUIRE(Bt, "workspace too small");
+    void* ews = ws.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
+    FFK_REQUIRE(Bt && ews, "workspace too small");
 
     if (!(flags & FFK_INTERNAL_PROLOGUE_DONE))
         FFK_HIP(ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
@@ -401,7 +402,7 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     }
     if (control_matrix)
         FFK_HIP(ffk::launch_expand(Bsum, reinterpret_cast<const cplx*>(basis), A, N, d, W,
-                                   reinterpret_cast<cplx*>(control_matrix), s));
+                                   reinterpret_cast<cplx*>(control_matrix), ews, s));
     if (want_B)
         FFK_HIP(ffk::launch_transpose_noise_ops(Bsum, A, d, W, reinterpret_cast<cplx*>(noise_operators), s));
 
@@ -501,7 +502,8 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
     if (basis_transformed) total += align_up(16*size_t(G)*N*dd);
     if (phase_factors) total += align_up(16*size_t(G)*W);
     if (first_order_integral) total += align_up(16*size_t(G)*W*dd);
-    if (control_matrix_step) total += align_up(16*size_t(G)*A*dd*W) + align_up(16*size_t(G)*A*N*W);
+    if (control_matrix_step)
+        total += align_up(16*size_t(G)*A*dd*W) + align_up(16*size_t(G)*A*N*W) + ffk::expand_workspace_bytes(N, d);
     void* base;
     if (int rc = arena_reserve(total, &base)) return rc;
     Bump a(base, g_arena.size);
@@ -524,6 +526,7 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
     cplx* dint = first_order_integral ? a.take<cplx>(size_t(G)*W*dd) : nullptr;
     cplx* Ypart = control_matrix_step ? a.take<cplx>(size_t(G)*A*dd*W) : nullptr;
     cplx* dstep = control_matrix_step ? a.take<cplx>(size_t(G)*A*N*W) : nullptr;
+    void* dews = control_matrix_step ? a.take<unsigned char>(ffk::expand_workspace_bytes(N, d)) : nullptr;
     FFK_REQUIRE(a.used <= g_arena.size, "internal: arena too small");
     auto h2d = [](void* dst, const void* src, size_t n) {
         return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, nullptr);
@@ -547,7 +550,7 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
         // one chunk per segment: Ypart[g] is that segment's Hilbert-space step, expanded in the basis
         ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, G);
         FFK_HIP(ffk::launch_accumulate(dom, W, segtab, ops, G, d, A, geo, Ypart, nullptr));
-        FFK_HIP(ffk::launch_expand(Ypart, dbasis, G*A, N, d, W, dstep, nullptr));
+        FFK_HIP(ffk::launch_expand(Ypart, dbasis, G*A, N, d, W, dstep, dews, nullptr));
     }
     if (n_opers_transformed) FFK_HIP(d2h(n_opers_transformed, dnt, 16*size_t(A)*G*dd));
     if (eigvecs_propagated) FFK_HIP(d2h(eigvecs_propagated, dep, 16*size_t(G)*dd));

@@ -26,7 +26,15 @@ __host__ __device__ constexpr int accum_jb(int d) {
 #if defined(FFK_JB4)  /* tuning builds */
     if (d == 4) return FFK_JB4;
 #endif
-    return d <= 5 ? d : (d % 3 == 0 && d <= 9 ? 3 : (d % 2 == 0 ? 2 : 1));
+#if defined(FFK_JB8)
+    if (d == 8) return FFK_JB8;
+#endif
+#if defined(FFK_JB16)
+    if (d == 16) return FFK_JB16;
+#endif
+    // largest column block whose accumulators + row temporaries stay in registers (no scratch)
+    // at the 2-waves/SIMD budget: survey in profiles/r01_e_register_survey.txt
+    return d <= 5 ? d : (d == 6 ? 3 : ((d == 8 || d == 10) ? 2 : 1));
 }
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1)/a*a; }
@@ -100,8 +108,9 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
 hipError_t launch_reduce_chunks(const cplx* Ypart, int chunks, size_t slab, cplx* Bt,
                                 hipStream_t stream);
 // R (A2,N,W) with R[a,k,w] = sum_ij Bt[a,i,j,w] C_k[j,i];  A2 = any leading batch
+size_t expand_workspace_bytes(int N, int d);
 hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d, int W, cplx* R,
-                         hipStream_t stream);
+                         void* ws, hipStream_t stream);
 // out (W,A,d,d) from Bt (A,d,d,W)
 hipError_t launch_transpose_noise_ops(const cplx* Bt, int A, int d, int W, cplx* out,
                                       hipStream_t stream);
