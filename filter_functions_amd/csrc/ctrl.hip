@@ -38,7 +38,7 @@ bool g_use_wave_kernel = false;   // tuning/testing: one-wave-per-block variant 
 
 // MR = integral rows generated per LDS stage.  MR == D (one stage per segment, diagonal computed
 // once, optionally double-buffered) whenever the D*D*64 tile fits the 160 KiB LDS; MR < D splits
-// the rows over several single-buffered stages (D > 12).  MAXW = upper bound of waves per block
+// the rows over several single-buffered stages (D > 11).  MAXW = upper bound of waves per block
 // (launch bound: lets the register allocator use the VGPR budget the block size really leaves).
 // LDS per buffer: [MR*D][64] integral tile, then [(1 + NA)][D*D] operands (T_g, Bbar of the
 // block's noise operators), NA = accum_na(D, nwaves).
@@ -64,7 +64,6 @@ __global__ __launch_bounds__(MAXW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ker
     constexpr int S = seg_stride(D);
     constexpr int NJ = D / JB;
     constexpr int NSTAGE = (D + MR - 1)/MR;
-    constexpr int NE = D*(D - 1) + 1;  // distinct integral entries (all diagonal ones coincide)
     constexpr int MUNROLL = D <= 8 ? D : 1;
     constexpr int TILE = MR*D*64;      // cplx per integral tile
 
@@ -90,38 +89,56 @@ __global__ __launch_bounds__(MAXW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ker
 #pragma unroll
         for (int j = 0; j < JB; ++j) Y[i][j] = {0.0, 0.0};
 
+    // LDS: [NBUF x (integral tile | operands)] [2 x table row].  The table row of segment g is
+    // staged one segment ahead (slot (g - g0) & 1), so that nothing in phase A waits on global or
+    // scalar memory: an earlier version fetched (dE, sin b, cos b) per entry from memory and spent
+    // ~60 % of phase A in those round trips (profiles/r01_c_*).
+    double* tabs = reinterpret_cast<double*>(lds + static_cast<size_t>(NBUF)*buf_stride);
+    auto stage_table = [&](int g) {   // all threads: global -> LDS copy of one table row
+        if (g < g1) {
+            const cplx* src = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
+            cplx* dst = reinterpret_cast<cplx*>(tabs + ((g - g0) & 1)*S);
+            for (int e = static_cast<int>(threadIdx.x); e < S/2; e += blockDim.x) dst[e] = src[e];
+        }
+    };
+
     // Phase A: this wave's share of e^{i w t_g} I^(g)[rows of stage][:] -> LDS, plus (stage 0)
-    // the segment's operands T_g, Bbar_{alpha0..}^(g) -> LDS.
+    // the segment's operands T_g, Bbar_{alpha0..}^(g) and the NEXT segment's table row -> LDS.
+    cplx staged = {0.0, 0.0};   // this thread's share of the staging copy, in flight across phase B
     auto phase_a = [&](int g, int stage, int buf) {
-        const double* st = segtab + static_cast<size_t>(g)*S;
+        const double* st = tabs + ((g - g0) & 1)*S;          // LDS
         cplx* tile = lds + static_cast<size_t>(buf)*buf_stride;
-        // operand copy: issue the global loads first, park them after the integral is done
+        // staging copies: issue the global loads first, park them after the integral is done
         const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*D*D;
+        const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g + 1)*S);
         const int n_ops = (1 + n_alpha)*D*D;
+        const int n_tab = (g + 1 < g1) ? S/2 : 0;
         const int e0 = static_cast<int>(threadIdx.x);
-        cplx staged = {0.0, 0.0};
-        if (stage == 0 && e0 < n_ops)
-            staged = src_ops[e0 < D*D ? e0 : e0 + alpha0*D*D];
-        // The per-entry table values (dE, sin b, cos b) are wave-uniform, but fetching them with
-        // scalar loads put two exposed s_waitcnt lgkmcnt(0) round trips in front of every entry
-        // (profiles/r01_c_*).  They are fetched as vector loads through a pointer the compiler can
-        // no longer prove uniform (every lane reads the same address: one L1 broadcast), issued
-        // one entry ahead, so vmcnt counting hides the latency behind the previous entry.
-        const double* stv = st;
-        asm volatile("" : "+v"(stv));
+        if (stage == 0) {
+            if (e0 < n_ops)
+                staged = src_ops[e0 < D*D ? e0 : e0 + alpha0*D*D];
+            else if (e0 < n_ops + n_tab)
+                staged = src_tab[e0 - n_ops];
+        }
         struct Tab { double dE, sb, cb; };
-        auto load_tab = [&](int e) -> Tab { return {stv[2 + e], stv[2 + D*D + e], stv[2 + 2*D*D + e]}; };
-        auto slot_of = [&](int ce) -> int {   // compact entry index -> m*D + n (0 = the diagonal)
-            if (ce == 0) return 0;
-            const int o = ce - 1;
-            const int m = o/(D - 1), r = o % (D - 1);
-            return m*D + r + (r >= m ? 1 : 0);
+        auto load_tab = [&](int e) -> Tab {
+            const double* r = st + seg_rec(e);
+            return {r[0], r[1], r[2]};
         };
-        const int e_first = (MR == D) ? wave : wave;
-        const int e_count = (MR == D) ? NE : min(MR, D - stage*MR)*D;
+        const int e_count = (MR == D) ? D*D : min(MR, D - stage*MR)*D;
         const int e_base = (MR == D) ? 0 : stage*MR*D;
+        // single-stage tiles compute the diagonal once (slot 0) and skip the other diagonal slots
+        auto skip = [&](int e) -> bool { return MR == D && e != 0 && e / D == e % D; };
+        auto next_entry = [&](int e) -> int {
+            do {
+                e += nwaves;
+            } while (e < e_count && skip(e));
+            return e;
+        };
+        int ce = wave;
+        if (skip(ce)) ce = next_entry(ce);
         Tab cur = {0.0, 0.0, 1.0};
-        if (e_first < e_count) cur = load_tab((MR == D) ? slot_of(e_first) : e_base + e_first);
+        if (ce < e_count) cur = load_tab(e_base + ce);
 
         const double dtg = st[0];
         const cplx ph = cexp(om*st[1]);
@@ -131,23 +148,39 @@ __global__ __launch_bounds__(MAXW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ker
         double sa, ca;
         sincos_pi(0.5*(om*dtg), &sa, &ca);
         cplx* dst = tile + lane;
-        for (int ce = e_first; ce < e_count; ce += nwaves) {
-            const int nxt = ce + nwaves;
+        while (ce < e_count) {
+            const int nxt = next_entry(ce);
             Tab nx = cur;
-            if (nxt < e_count) nx = load_tab((MR == D) ? slot_of(nxt) : e_base + nxt);
-            const int slot = (MR == D) ? slot_of(ce) : ce;
+            if (nxt < e_count) nx = load_tab(e_base + nxt);
 #if defined(FFK_ABLATE) && FFK_ABLATE == 1   /* diagnostic build: no integral generation */
-            dst[slot*64] = {om, dtg + ph.re + cur.dE};
+            dst[ce*64] = {om, dtg + ph.re + cur.dE};
 #else
-            dst[slot*64] = cmul(ph, first_order_integral_aa(om, cur.dE, dtg, sa, ca, cur.sb, cur.cb));
+            dst[ce*64] = cmul(ph, first_order_integral_aa(om, cur.dE, dtg, sa, ca, cur.sb, cur.cb));
 #endif
             cur = nx;
+            ce = nxt;
         }
-        if (stage == 0) {
-            cplx* dst_ops = tile + TILE;
-            if (e0 < n_ops) dst_ops[e0] = staged;
-            for (int e = e0 + static_cast<int>(blockDim.x); e < n_ops; e += blockDim.x)
+    };
+    // second half of the staging copy: park the loaded values in LDS (after phase B, so that the
+    // global-load latency hides behind the contraction)
+    auto park = [&](int g, int buf) {
+        cplx* tile = lds + static_cast<size_t>(buf)*buf_stride;
+        const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*D*D;
+        const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g + 1)*S);
+        const int n_ops = (1 + n_alpha)*D*D;
+        const int n_tab = (g + 1 < g1) ? S/2 : 0;
+        const int e0 = static_cast<int>(threadIdx.x);
+        cplx* dst_ops = tile + TILE;
+        cplx* dst_tab = reinterpret_cast<cplx*>(tabs + ((g + 1 - g0) & 1)*S);
+        if (e0 < n_ops)
+            dst_ops[e0] = staged;
+        else if (e0 < n_ops + n_tab)
+            dst_tab[e0 - n_ops] = staged;
+        for (int e = e0 + static_cast<int>(blockDim.x); e < n_ops + n_tab; e += blockDim.x) {
+            if (e < n_ops)
                 dst_ops[e] = src_ops[e < D*D ? e : e + alpha0*D*D];
+            else
+                dst_tab[e - n_ops] = src_tab[e - n_ops];
         }
     };
 
@@ -184,8 +217,13 @@ __global__ __launch_bounds__(MAXW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ker
         }
     };
 
+    stage_table(g0);
+    __syncthreads();
     if (NBUF == 2) {
-        if (g0 < g1) phase_a(g0, 0, 0);
+        if (g0 < g1) {
+            phase_a(g0, 0, 0);
+            park(g0, 0);
+        }
         __syncthreads();
         for (int g = g0; g < g1; ++g) {
             const int buf = (g - g0) & 1;
@@ -200,12 +238,16 @@ __global__ __launch_bounds__(MAXW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ker
 #if !(defined(FFK_ABLATE) && FFK_ABLATE == 3)  /* diagnostic build 3: no contraction */
             if (active) phase_b(g, 0, buf);
 #endif
+            if (g + 1 < g1) park(g + 1, buf ^ 1);
+#if !(defined(FFK_ABLATE) && FFK_ABLATE == 6)  /* diagnostic build 6: no barrier (wrong results) */
             __syncthreads();
+#endif
         }
     } else {
         for (int g = g0; g < g1; ++g) {
             for (int stage = 0; stage < NSTAGE; ++stage) {
                 phase_a(g, stage, 0);
+                if (stage == 0) park(g, 0);
                 __syncthreads();
                 if (active) phase_b(g, stage, 0);
                 __syncthreads();
@@ -295,11 +337,11 @@ __global__ __launch_bounds__(64) void ctrl_accumulate_wave_kernel(
             for (int n = 0; n < D; ++n)
                 if (m != n) {
                     const int e = m*D + n;
-                    const double dE = st[2 + e];
+                    const double dE = st[seg_rec(e)];
                     Ip[m][n] = dE == 0.0 ? Ip[0][0]
                                          : cmul(ph, first_order_integral_aa(om, dE, dtg, sa, ca,
-                                                                            st[2 + D*D + e],
-                                                                            st[2 + 2*D*D + e]));
+                                                                            st[seg_rec(e) + 1],
+                                                                            st[seg_rec(e) + 2]));
                 }
 
         const cplx* opT = opbuf[buf];
@@ -348,7 +390,7 @@ __global__ __launch_bounds__(64) void ctrl_accumulate_wave_kernel(
     }
 }
 
-__host__ __device__ constexpr int accum_mr(int d) { return d <= 12 ? d : 8; }
+__host__ __device__ constexpr int accum_mr(int d) { return d <= 11 ? d : 8; }
 
 template <typename K>
 hipError_t launch_kernel(K kern, const dim3& grid, const dim3& block, const AccumGeometry& geo,
@@ -515,8 +557,9 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     const int nj = d / jb;
     geo.na_blk = ntasks <= nw ? A : std::min(A, (nw - 1)/nj + 2);
     const size_t one = (static_cast<size_t>(accum_mr(d))*d*64 + static_cast<size_t>(1 + geo.na_blk)*d*d)*sizeof(cplx);
-    geo.nbuf = (accum_mr(d) == d && 2*one <= 160*1024) ? 2 : 1;
-    geo.lds_bytes = static_cast<int>(geo.nbuf*one);
+    const size_t tabs = 2*static_cast<size_t>(seg_stride(d))*sizeof(double);
+    geo.nbuf = (accum_mr(d) == d && 2*one + tabs <= 160*1024) ? 2 : 1;
+    geo.lds_bytes = static_cast<int>(geo.nbuf*one + tabs);
     // Segment chunks.  Every block runs its whole chunk, so the launch is fastest when the grid is
     // a whole number of "rounds" of resident blocks (profiles/r01_a_chunk_sweep.txt: 16 chunks =
     // 1024 blocks = exactly one round beat 22 chunks by 25 %): pick the chunk count that fills

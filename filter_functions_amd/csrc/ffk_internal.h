@@ -15,11 +15,12 @@ namespace ffk {
 constexpr int kMaxD = 16;
 constexpr int kWave = 64;
 
-// Per-segment uniform table row: [0] = dt_g, [1] = t_g, then three d x d blocks:
-// dE[m,n] = D_m - D_n, sin(b[m,n]) and cos(b[m,n]) with b = fl(dE*dt)/2 (the frequency-independent
-// half-angles of first_order_integral_aa); padded to a multiple of 8 doubles so each row starts
-// 64-byte aligned (scalar loads).
-__host__ __device__ constexpr int seg_stride(int d) { return ((2 + 3*d*d + 7)/8)*8; }
+// Per-segment uniform table row (doubles): [0] = dt_g, [1] = t_g, [2..3] pad, then one 4-double
+// record per matrix entry e = m*d + n:  (dE = D_m - D_n, sin b, cos b, 0) with b = fl(dE*dt)/2,
+// the frequency-independent half-angle of first_order_integral_aa.  A record is one 32-byte LDS
+// read.  Rows are padded to a multiple of 8 doubles (64-byte aligned).
+__host__ __device__ constexpr int seg_stride(int d) { return ((4 + 4*d*d + 7)/8)*8; }
+__host__ __device__ constexpr int seg_rec(int e) { return 4 + 4*e; }
 
 // Columns of the Hilbert-space accumulator kept per thread in ctrl_accumulate.
 __host__ __device__ constexpr int accum_jb(int d) {

@@ -33,11 +33,13 @@ __device__ void prologue_segment(const cplx (*V)[D], const cplx (*Q)[D], cplx (*
         const double dE = eigvals[static_cast<size_t>(g)*D + e / D] - eigvals[static_cast<size_t>(g)*D + e % D];
         double sb, cb;
         sincos_pi(0.5*(dE*dt[g]), &sb, &cb);
-        st[2 + e] = dE;
-        st[2 + D*D + e] = sb;
-        st[2 + 2*D*D + e] = cb;
+        st[seg_rec(e)] = dE;
+        st[seg_rec(e) + 1] = sb;
+        st[seg_rec(e) + 2] = cb;
+        st[seg_rec(e) + 3] = 0.0;
     }
-    for (int e = 2 + 3*D*D + lane; e < S; e += 64) st[e] = 0.0;
+    if (lane < 2) st[2 + lane] = 0.0;
+    for (int e = 4 + 4*D*D + lane; e < S; e += 64) st[e] = 0.0;
 
     // T = V^dag Q
     for (int e = lane; e < D*D; e += 64) {
@@ -221,7 +223,7 @@ __global__ void phase_integral_kernel(const double* __restrict__ omega, int W,
     if (phase_factors) phase_factors[static_cast<size_t>(g)*W + w] = cexp(om*st[1]);
     if (integral) {
         cplx* out = integral + (static_cast<size_t>(g)*W + w)*d*d;
-        for (int e = 0; e < d*d; ++e) out[e] = first_order_integral(om, st[2 + e], st[0]);
+        for (int e = 0; e < d*d; ++e) out[e] = first_order_integral(om, st[seg_rec(e)], st[0]);
     }
 }
 
