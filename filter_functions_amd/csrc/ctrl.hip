@@ -27,6 +27,7 @@
 //     60 % of its wave cycles in s_waitcnt lgkmcnt(0) (profiles/r01_b_*).
 //   * Double-buffered LDS: one barrier per segment.
 #include <algorithm>
+#include <type_traits>
 
 #include "ffk_internal.h"
 
@@ -38,8 +39,10 @@ bool g_use_wave_kernel = false;   // tuning/testing: one-wave-per-block variant 
 
 // MR = integral rows generated per LDS stage.  MR == D (one stage per segment, diagonal computed
 // once, optionally double-buffered) whenever the D*D*64 tile fits the 160 KiB LDS; MR < D splits
-// the rows over several single-buffered stages (D > 11).  MAXW = upper bound of waves per block
-// (launch bound: lets the register allocator use the VGPR budget the block size really leaves).
+// the rows over several single-buffered stages (D > 11).  NW = waves per block, a template
+// parameter so that each wave's share of phase A is a compile-time list: straight-line code with
+// immediate LDS offsets and instruction-level parallelism across entries (the run-time
+// enumeration cost ~25 scalar instructions per entry and serialised the entries).
 // LDS per buffer: [MR*D][64] integral tile, then [(1 + NA)][D*D] operands (T_g, Bbar of the
 // block's noise operators), NA = accum_na(D, nwaves).
 // Occupancy target handed to the register allocator (2nd __launch_bounds__ argument = minimum
@@ -53,8 +56,33 @@ bool g_use_wave_kernel = false;   // tuning/testing: one-wave-per-block variant 
 #define FFK_ACCUM_WPE(D) ((D) <= 4 ? 3 : 2)
 #endif
 
-template <int D, int JB, int MR, int NBUF, int MAXW>
-__global__ __launch_bounds__(MAXW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kernel(
+// Compile-time list of the integral entries (slots m*D + n) that wave WV of an NW-wave block
+// generates: every NW-th slot, the diagonal (all diagonal entries coincide) only as slot 0.
+template <int D, int NW, int WV>
+struct EntryList {
+    static constexpr int build(int* out) {
+        int n = 0;
+        for (int e = WV; e < D*D; e += NW) {
+            if (e != 0 && e / D == e % D) continue;
+            if (out) out[n] = e;
+            ++n;
+        }
+        return n;
+    }
+    static constexpr int count = build(nullptr);
+    struct Slots {
+        int v[D*D];
+    };
+    static constexpr Slots make() {
+        Slots s{};
+        build(s.v);
+        return s;
+    }
+    static constexpr Slots slots = make();
+};
+
+template <int D, int JB, int MR, int NBUF, int NW>
+__global__ __launch_bounds__(NW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, int na_blk,
     cplx* __restrict__ Ypart) {
@@ -69,7 +97,7 @@ __global__ __launch_bounds__(MAXW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ker
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = blockDim.x >> 6;
+    constexpr int nwaves = NW;
     const int task0 = blockIdx.y*nwaves;
     const int task = task0 + wave;
     const bool active = task < A*NJ;
@@ -120,26 +148,6 @@ __global__ __launch_bounds__(MAXW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ker
             else if (e0 < n_ops + n_tab)
                 staged = src_tab[e0 - n_ops];
         }
-        struct Tab { double dE, sb, cb; };
-        auto load_tab = [&](int e) -> Tab {
-            const double* r = st + seg_rec(e);
-            return {r[0], r[1], r[2]};
-        };
-        const int e_count = (MR == D) ? D*D : min(MR, D - stage*MR)*D;
-        const int e_base = (MR == D) ? 0 : stage*MR*D;
-        // single-stage tiles compute the diagonal once (slot 0) and skip the other diagonal slots
-        auto skip = [&](int e) -> bool { return MR == D && e != 0 && e / D == e % D; };
-        auto next_entry = [&](int e) -> int {
-            do {
-                e += nwaves;
-            } while (e < e_count && skip(e));
-            return e;
-        };
-        int ce = wave;
-        if (skip(ce)) ce = next_entry(ce);
-        Tab cur = {0.0, 0.0, 1.0};
-        if (ce < e_count) cur = load_tab(e_base + ce);
-
         const double dtg = st[0];
         const cplx ph = cexp(om*st[1]);
         // half-angle of the diagonal entry, a = fl(w dt)/2: every off-diagonal entry follows
@@ -148,17 +156,35 @@ __global__ __launch_bounds__(MAXW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ker
         double sa, ca;
         sincos_pi(0.5*(om*dtg), &sa, &ca);
         cplx* dst = tile + lane;
-        while (ce < e_count) {
-            const int nxt = next_entry(ce);
-            Tab nx = cur;
-            if (nxt < e_count) nx = load_tab(e_base + nxt);
+        auto gen = [&](int slot, int e) {   // slot: LDS slot, e: matrix entry m*D + n
+            const double* r = st + seg_rec(e);
 #if defined(FFK_ABLATE) && FFK_ABLATE == 1   /* diagnostic build: no integral generation */
-            dst[ce*64] = {om, dtg + ph.re + cur.dE};
+            dst[slot*64] = {om, dtg + ph.re + r[0]};
 #else
-            dst[ce*64] = cmul(ph, first_order_integral_aa(om, cur.dE, dtg, sa, ca, cur.sb, cur.cb));
+            dst[slot*64] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
 #endif
-            cur = nx;
-            ce = nxt;
+        };
+        if constexpr (MR == D) {
+            // this wave's entries, fully unrolled per wave index
+            auto run = [&](auto tag) {
+                using EL = EntryList<D, NW, decltype(tag)::value>;
+#pragma unroll
+                for (int k = 0; k < EL::count; ++k) gen(EL::slots.v[k], EL::slots.v[k]);
+            };
+            switch (wave) {
+#define FFK_WCASE(I)                                         \
+    case I:                                                  \
+        if constexpr (NW > I) run(std::integral_constant<int, I>{}); \
+        break;
+                FFK_WCASE(0) FFK_WCASE(1) FFK_WCASE(2) FFK_WCASE(3) FFK_WCASE(4) FFK_WCASE(5)
+                FFK_WCASE(6) FFK_WCASE(7)
+#undef FFK_WCASE
+                default:
+                    break;
+            }
+        } else {
+            const int rows = min(MR, D - stage*MR);
+            for (int e = wave; e < rows*D; e += nwaves) gen(e, stage*MR*D + e);
         }
     };
     // second half of the staging copy: park the loaded values in LDS (after phase B, so that the
@@ -407,20 +433,20 @@ hipError_t launch_kernel(K kern, const dim3& grid, const dim3& block, const Accu
     return hipGetLastError();
 }
 
-template <int D, int MAXW>
+template <int D, int NW>
 hipError_t launch_dw(const double* omega, int W, const double* segtab, const cplx* ops,
                      int G, int A, const AccumGeometry& geo, cplx* Ypart,
                      hipStream_t stream) {
     constexpr int JB = accum_jb(D);
     constexpr int MR = accum_mr(D);
     const dim3 grid((W + 63)/64, geo.task_groups, geo.chunks);
-    const dim3 block(geo.nwaves*64);
+    const dim3 block(NW*64);
     if constexpr (MR == D) {
         if (geo.nbuf == 2)
-            return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 2, MAXW>, grid, block, geo,
+            return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 2, NW>, grid, block, geo,
                                  stream, omega, W, segtab, ops, G, A, Ypart);
     }
-    return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 1, MAXW>, grid, block, geo, stream,
+    return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 1, NW>, grid, block, geo, stream,
                          omega, W, segtab, ops, G, A, Ypart);
 }
 
@@ -448,34 +474,55 @@ hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx
             }
         }
     }
-    if (geo.nwaves <= 4)
-        return launch_dw<D, 4>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
-    return launch_dw<D, 8>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
+    switch (geo.nwaves) {
+#define FFK_NCASE(N) \
+    case N:          \
+        return launch_dw<D, N>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
+        FFK_NCASE(1) FFK_NCASE(2) FFK_NCASE(3) FFK_NCASE(4) FFK_NCASE(5) FFK_NCASE(6) FFK_NCASE(7)
+        FFK_NCASE(8)
+#undef FFK_NCASE
+        default:
+            return hipErrorInvalidValue;
+    }
 }
 
 // resident blocks per CU of the kernel instantiation a geometry selects (occupancy API, cached)
-template <int D, int MAXW>
-int blocks_per_cu_dw(int nbuf, int block, int lds_bytes) {
+template <int D, int NW>
+int blocks_per_cu_dw(int nbuf, int lds_bytes) {
     constexpr int JB = accum_jb(D);
     constexpr int MR = accum_mr(D);
     int n = 0;
     hipError_t err;
     if constexpr (MR == D) {
         if (nbuf == 2) {
-            auto kern = ctrl_accumulate_kernel<D, JB, MR, 2, MAXW>;
+            auto kern = ctrl_accumulate_kernel<D, JB, MR, 2, NW>;
             if (lds_bytes > 48*1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, block, lds_bytes);
+            err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, NW*64, lds_bytes);
             return err == hipSuccess ? n : 0;
         }
     }
-    auto kern = ctrl_accumulate_kernel<D, JB, MR, 1, MAXW>;
+    auto kern = ctrl_accumulate_kernel<D, JB, MR, 1, NW>;
     if (lds_bytes > 48*1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, block, lds_bytes);
+    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, NW*64, lds_bytes);
     return err == hipSuccess ? n : 0;
+}
+
+template <int D>
+int blocks_per_cu_d(int nwaves, int nbuf, int lds_bytes) {
+    switch (nwaves) {
+#define FFK_NCASE(N) \
+    case N:          \
+        return blocks_per_cu_dw<D, N>(nbuf, lds_bytes);
+        FFK_NCASE(1) FFK_NCASE(2) FFK_NCASE(3) FFK_NCASE(4) FFK_NCASE(5) FFK_NCASE(6) FFK_NCASE(7)
+        FFK_NCASE(8)
+#undef FFK_NCASE
+        default:
+            return 0;
+    }
 }
 
 int query_blocks_per_cu(int d, int nwaves, int nbuf, int lds_bytes) {
@@ -484,10 +531,9 @@ int query_blocks_per_cu(int d, int nwaves, int nbuf, int lds_bytes) {
     if (slot > 0) return slot;
     int n = 0;
     switch (d) {
-#define FFK_CASE(D)                                                                     \
-    case D:                                                                             \
-        n = nwaves <= 4 ? blocks_per_cu_dw<D, 4>(nbuf, nwaves*64, lds_bytes)            \
-                        : blocks_per_cu_dw<D, 8>(nbuf, nwaves*64, lds_bytes);           \
+#define FFK_CASE(D)                                      \
+    case D:                                              \
+        n = blocks_per_cu_d<D>(nwaves, nbuf, lds_bytes); \
         break;
         FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
         FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
