@@ -1,0 +1,135 @@
+// atomic.hip -- K6: the concatenation rule, numeric.calculate_control_matrix_from_atomic
+// (filter_functions/numeric.py:621-704):
+//     R[a,l,w] = R^(0)[a,l,w] + sum_{g>=1} phases[g-1,w] * sum_k R^(g)[a,k,w] L^(g-1)[k,l]
+// with R^(g) the control matrix of the g-th pulse, phases the cumulated total phase factors and
+// L the cumulated Liouville propagators (real for Hermitian bases, else complex).
+//
+// HBM-streaming: every atomic control-matrix element is read exactly once (16 B per
+// (g, a, k, w) + 16/(A N) B of phase), one lane per frequency so that all accesses are 16-byte
+// coalesced (1 KiB per wave instruction); the N x N propagator of the current pulse is wave
+// uniform (scalar loads).  grid = (omega tiles, noise operators, column tiles of LT basis
+// elements); the pulse axis can additionally be split into `gsplit` slabs whose partial sums
+// are combined in fixed order by a second pass when the omega axis alone cannot fill the chip.
+// which = 'correlations' writes every summand (G, A, N, W) instead of their sum.
+#include "ffk_internal.h"
+
+namespace ffk {
+namespace {
+
+template <int LT, bool LCPLX>
+__global__ __launch_bounds__(64) void from_atomic_kernel(const cplx* __restrict__ phases,
+                                                         const cplx* __restrict__ Ratomic,
+                                                         const double* __restrict__ L, int G, int A,
+                                                         int N, int W, int glen, int correlations,
+                                                         cplx* __restrict__ out) {
+    const int w = blockIdx.x*64 + threadIdx.x;
+    const int a = blockIdx.y;
+    const int nlt = (N + LT - 1)/LT;
+    const int l0 = (blockIdx.z % nlt)*LT;
+    const int slab = blockIdx.z / nlt;
+    const int g0 = slab*glen, g1 = min(G, g0 + glen);
+    if (w >= W) return;
+    const size_t pulse_stride = static_cast<size_t>(A)*N*W;
+    cplx acc[LT];
+#pragma unroll
+    for (int j = 0; j < LT; ++j) acc[j] = {0.0, 0.0};
+    for (int g = g0; g < g1; ++g) {
+        const cplx* Rg = Ratomic + g*pulse_stride + static_cast<size_t>(a)*N*W + w;
+        cplx step[LT];
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < LT; ++j) step[j] = (l0 + j < N) ? Rg[static_cast<size_t>(l0 + j)*W] : cplx{0.0, 0.0};
+        } else {
+#pragma unroll
+            for (int j = 0; j < LT; ++j) step[j] = {0.0, 0.0};
+            const cplx ph = phases[static_cast<size_t>(g - 1)*W + w];
+            const double* Lg = L + static_cast<size_t>(g - 1)*N*N*(LCPLX ? 2 : 1);
+            for (int k = 0; k < N; ++k) {
+                const cplx v = cmul(ph, Rg[static_cast<size_t>(k)*W]);
+#pragma unroll
+                for (int j = 0; j < LT; ++j) {
+                    if (l0 + j < N) {
+                        if (LCPLX) {
+                            const cplx q = {Lg[2*(k*N + l0 + j)], Lg[2*(k*N + l0 + j) + 1]};
+                            cmac(step[j], q, v);
+                        } else {
+                            const double q = Lg[k*N + l0 + j];
+                            step[j].re = fma(q, v.re, step[j].re);
+                            step[j].im = fma(q, v.im, step[j].im);
+                        }
+                    }
+                }
+            }
+        }
+        if (correlations) {
+            cplx* o = out + g*pulse_stride + static_cast<size_t>(a)*N*W + w;
+#pragma unroll
+            for (int j = 0; j < LT; ++j)
+                if (l0 + j < N) o[static_cast<size_t>(l0 + j)*W] = step[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < LT; ++j) {
+                acc[j].re += step[j].re;
+                acc[j].im += step[j].im;
+            }
+        }
+    }
+    if (!correlations) {
+        cplx* o = out + slab*pulse_stride + static_cast<size_t>(a)*N*W + w;
+#pragma unroll
+        for (int j = 0; j < LT; ++j)
+            if (l0 + j < N) o[static_cast<size_t>(l0 + j)*W] = acc[j];
+    }
+}
+
+template <bool LCPLX>
+hipError_t launch_c(const cplx* phases, const cplx* Ratomic, const double* L, int G, int A, int N,
+                    int W, int gsplit, int correlations, cplx* out, hipStream_t stream) {
+    const int glen = (G + gsplit - 1)/gsplit;
+    const unsigned tiles = (W + 63)/64;
+    if (N <= 4) {
+        hipLaunchKernelGGL((from_atomic_kernel<4, LCPLX>), dim3(tiles, A, gsplit), dim3(64), 0, stream,
+                           phases, Ratomic, L, G, A, N, W, glen, correlations, out);
+    } else if (N <= 16) {
+        hipLaunchKernelGGL((from_atomic_kernel<16, LCPLX>), dim3(tiles, A, gsplit), dim3(64), 0, stream,
+                           phases, Ratomic, L, G, A, N, W, glen, correlations, out);
+    } else {
+        const int nlt = (N + 15)/16;
+        hipLaunchKernelGGL((from_atomic_kernel<16, LCPLX>), dim3(tiles, A, gsplit*nlt), dim3(64), 0,
+                           stream, phases, Ratomic, L, G, A, N, W, glen, correlations, out);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// number of pulse-axis slabs used for which='total' (1 = single pass straight into the output)
+int from_atomic_gsplit(int G, int A, int N, int W) {
+    const long waves = static_cast<long>((W + 63)/64)*A*((N + 15)/16);
+    if (waves >= 2048 || G < 16) return 1;
+    long s = (2048 + waves - 1)/waves;
+    if (s > G/8) s = G/8;
+    return static_cast<int>(s < 1 ? 1 : s);
+}
+
+size_t from_atomic_workspace_bytes(int G, int A, int N, int W) {
+    const int s = from_atomic_gsplit(G, A, N, W);
+    return s > 1 ? align_up(sizeof(cplx)*static_cast<size_t>(s)*A*N*W) : 256;
+}
+
+hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const double* L,
+                              int l_is_complex, int G, int A, int N, int W, int correlations,
+                              cplx* out, void* ws, hipStream_t stream) {
+    if (A > 65535) return hipErrorInvalidValue;
+    const int gsplit = correlations ? 1 : from_atomic_gsplit(G, A, N, W);
+    cplx* target = (gsplit > 1) ? static_cast<cplx*>(ws) : out;
+    hipError_t err = l_is_complex
+                         ? launch_c<true>(phases, Ratomic, L, G, A, N, W, gsplit, correlations, target, stream)
+                         : launch_c<false>(phases, Ratomic, L, G, A, N, W, gsplit, correlations, target, stream);
+    if (err != hipSuccess) return err;
+    if (gsplit > 1)
+        return launch_reduce_chunks(target, gsplit, static_cast<size_t>(A)*N*W, out, stream);
+    return hipSuccess;
+}
+
+}  // namespace ffk

@@ -563,6 +563,67 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
 }
 
 // ---------------------------------------------------------------------------------------------
+// concatenation rule
+// ---------------------------------------------------------------------------------------------
+size_t ffk_control_matrix_from_atomic_workspace_bytes(int G, int A, int N, int W) {
+    if (G < 1 || A < 1 || N < 1 || W < 1) return 0;
+    return ffk::from_atomic_workspace_bytes(G, A, N, W);
+}
+
+int ffk_control_matrix_from_atomic_dev(const double* phases, const double* control_matrix_atomic,
+                                       const double* propagators_liouville, int l_is_complex,
+                                       int G, int A, int N, int W, int which, double* out,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(G >= 1 && A >= 1 && N >= 1 && W >= 1, "empty axis: G=%d A=%d N=%d W=%d", G, A, N, W);
+    FFK_REQUIRE(control_matrix_atomic && out && workspace, "NULL argument");
+    FFK_REQUIRE(G == 1 || (phases && propagators_liouville), "NULL argument");
+    FFK_REQUIRE(which == 0 || which == 1, "invalid which=%d", which);
+    FFK_REQUIRE(workspace_bytes >= ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W),
+                "workspace too small");
+    FFK_HIP(ffk::launch_from_atomic(reinterpret_cast<const cplx*>(phases),
+                                    reinterpret_cast<const cplx*>(control_matrix_atomic),
+                                    propagators_liouville, l_is_complex, G, A, N, W, which,
+                                    reinterpret_cast<cplx*>(out), workspace,
+                                    static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+int ffk_control_matrix_from_atomic(const double* phases, const double* control_matrix_atomic,
+                                   const double* propagators_liouville, int l_is_complex, int G,
+                                   int A, int N, int W, int which, double* out) {
+    FFK_REQUIRE(G >= 1 && A >= 1 && N >= 1 && W >= 1, "empty axis: G=%d A=%d N=%d W=%d", G, A, N, W);
+    FFK_REQUIRE(control_matrix_atomic && out, "NULL argument");
+    FFK_REQUIRE(G == 1 || (phases && propagators_liouville), "NULL argument");
+    FFK_REQUIRE(which == 0 || which == 1, "invalid which=%d", which);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nP = 16*size_t(G > 1 ? G - 1 : 1)*W, nR = 16*size_t(G)*A*N*W;
+    const size_t nL = (l_is_complex ? 16 : 8)*size_t(G > 1 ? G - 1 : 1)*N*N;
+    const size_t nO = which ? nR : 16*size_t(A)*N*W;
+    const size_t wsb = ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W);
+    void* base;
+    if (int rc = arena_reserve(align_up(nP) + align_up(nR) + align_up(nL) + align_up(nO) + wsb, &base))
+        return rc;
+    Bump a(base, g_arena.size);
+    double* dP = a.take<double>(nP/8);
+    double* dR = a.take<double>(nR/8);
+    double* dL = a.take<double>(nL/8);
+    double* dO = a.take<double>(nO/8);
+    void* ws = a.take<unsigned char>(wsb);
+    if (G > 1) {
+        FFK_HIP(hipMemcpyAsync(dP, phases, 16*size_t(G - 1)*W, hipMemcpyHostToDevice, nullptr));
+        FFK_HIP(hipMemcpyAsync(dL, propagators_liouville, (l_is_complex ? 16 : 8)*size_t(G - 1)*N*N,
+                               hipMemcpyHostToDevice, nullptr));
+    }
+    FFK_HIP(hipMemcpyAsync(dR, control_matrix_atomic, nR, hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_control_matrix_from_atomic_dev(dP, dR, dL, l_is_complex, G, A, N, W, which, dO, ws,
+                                                    wsb, nullptr))
+        return rc;
+    FFK_HIP(hipMemcpyAsync(out, dO, nO, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // filter function
 // ---------------------------------------------------------------------------------------------
 int ffk_filter_function_dev(const double* control_matrix, int A, int N, int W, int which,

@@ -122,6 +122,13 @@ hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_n
                              const double* omega, const int32_t* idx, int n_idx, int d,
                              double* infid, void* ws, hipStream_t stream);
 
+// ---- atomic.hip -----------------------------------------------------------------------------
+size_t from_atomic_workspace_bytes(int G, int A, int N, int W);
+// out: (A,N,W) for the sum, (G,A,N,W) for correlations != 0; L is (G-1,N,N) f64 or c128
+hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const double* L,
+                              int l_is_complex, int G, int A, int N, int W, int correlations,
+                              cplx* out, void* ws, hipStream_t stream);
+
 // ---- liouville.hip ---------------------------------------------------------------------------
 size_t liouville_workspace_bytes(int batch, int d, int N);
 hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, int N,

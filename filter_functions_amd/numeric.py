@@ -25,7 +25,7 @@ from ._lib import as_c128, as_f64, check, ptr
 
 __all__ = ['diagonalize', 'calculate_control_matrix_from_scratch',
            'calculate_noise_operators_from_scratch', 'calculate_filter_function', 'infidelity',
-           'calculate_control_matrix_from_atomic']
+           'calculate_control_matrix_from_atomic', 'calculate_pulse_correlation_filter_function']
 
 
 def _check_d(d):
@@ -279,6 +279,56 @@ def infidelity(pulse, spectrum, omega, n_oper_identifiers=None, which='total',
     return infid
 
 
-def calculate_control_matrix_from_atomic(*args, **kwargs):
-    raise NotImplementedError('The concatenation rule (reference numeric.py:621-704) is the next '
-                              'row of the scope table (SURVEY.md section 8f.1) and not built yet.')
+@util.parse_optional_parameters(which=('total', 'correlations'))
+def calculate_control_matrix_from_atomic(phases, control_matrix_atomic, propagators_liouville,
+                                         show_progressbar=False, which='total'):
+    r"""Control matrix of a concatenated sequence from those of its pulses
+    (reference numeric.py:621-704):
+
+    .. math:: \tilde{\mathcal B}(\omega) = \sum_g e^{i\omega t_{g-1}}
+              \tilde{\mathcal B}^{(g)}(\omega)\mathcal Q^{(g-1)}.
+
+    phases: (G-1, n_omega) cumulated phase factors; control_matrix_atomic: (G, n_nops, d², n_omega);
+    propagators_liouville: (G-1, d², d²) cumulated Liouville propagators.  Returns (n_nops, d²,
+    n_omega) for ``which='total'``, every summand (G, n_nops, d², n_omega) for 'correlations'.
+    """
+    R_atomic = as_c128(control_matrix_atomic)
+    if R_atomic.ndim != 4:
+        raise ValueError('Expected control_matrix_atomic of shape (G, n_nops, n_basis, n_omega), '
+                         f'not {R_atomic.shape}.')
+    G, A, N, W = R_atomic.shape
+    phases = as_c128(phases)
+    L = np.asarray(propagators_liouville)
+    l_is_complex = np.iscomplexobj(L)
+    L = as_c128(L) if l_is_complex else as_f64(L)
+    if G > 1:
+        if phases.shape[0] < G - 1 or phases.shape[1:] != (W,):
+            raise ValueError(f'Expected phases of shape ({G - 1}, {W}), not {phases.shape}.')
+        if L.shape[0] < G - 1 or L.shape[1:] != (N, N):
+            raise ValueError(f'Expected propagators_liouville of shape ({G - 1}, {N}, {N}), '
+                             f'not {L.shape}.')
+        phases = np.ascontiguousarray(phases[:G - 1])
+        L = np.ascontiguousarray(L[:G - 1])
+    out = np.empty((G, A, N, W) if which == 'correlations' else (A, N, W), dtype=np.complex128)
+    if out.size:
+        check(_lib.load().ffk_control_matrix_from_atomic(
+            ptr(phases) if G > 1 else None, ptr(R_atomic), ptr(L) if G > 1 else None,
+            int(l_is_complex), G, A, N, W, int(which == 'correlations'), ptr(out)))
+    return out
+
+
+@util.parse_optional_parameters(which=('fidelity', 'generalized'))
+def calculate_pulse_correlation_filter_function(control_matrix, which='fidelity'):
+    r"""Pulse-correlation filter function
+    :math:`F^{(gg')}_{\alpha\beta}(\omega)` from the pulse-resolved control matrix
+    (G, n_nops, d², n_omega) (reference numeric.py:1821-1883): (G, G, n_nops, n_nops, n_omega),
+    or (G, G, n_nops, n_nops, d², d², n_omega) for 'generalized'."""
+    R = as_c128(control_matrix)
+    if R.ndim != 4:
+        raise ValueError('Expected control_matrix.ndim == 4.')
+    G, A, N, W = R.shape
+    # 'gako,hbko->ghabo' is the fidelity filter function of the (G*A)-row control matrix
+    F = calculate_filter_function(R.reshape(G*A, N, W), which)
+    if which == 'fidelity':
+        return np.ascontiguousarray(F.reshape(G, A, G, A, W).transpose(0, 2, 1, 3, 4))
+    return np.ascontiguousarray(F.reshape(G, A, G, A, N, N, W).transpose(0, 2, 1, 3, 4, 5, 6))

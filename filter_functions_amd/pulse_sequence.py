@@ -19,7 +19,7 @@ from . import numeric, util
 from .basis import Basis
 from .superoperator import liouville_representation
 
-__all__ = ['PulseSequence']
+__all__ = ['PulseSequence', 'concatenate', 'concatenate_without_filter_function']
 
 
 def _parse_hamiltonian(H, n_dt, H_str):
@@ -165,8 +165,7 @@ class PulseSequence:
     def __matmul__(self, other):
         if not isinstance(other, self.__class__):
             raise TypeError(f'Incompatible type for concatenation: {type(other)}')
-        raise NotImplementedError('Concatenation is the next row of the scope table '
-                                  '(SURVEY.md section 8f.1) and not built yet.')
+        return concatenate((self, other))
 
     # ---- caches --------------------------------------------------------------------------
     def is_cached(self, attr):
@@ -318,9 +317,16 @@ class PulseSequence:
                                                          cache_intermediates)
             self.cache_control_matrix(self.omega, control_matrix)
             if control_matrix.ndim == 4:
-                raise NotImplementedError('Pulse-correlation filter functions belong to the '
-                                          'concatenation path (SURVEY.md section 8f.4).')
-            filter_function = numeric.calculate_filter_function(control_matrix, which)
+                # pulse-resolved control matrix: also cache the pulse correlation filter function
+                F_pc = numeric.calculate_pulse_correlation_filter_function(control_matrix, which)
+                if which == 'fidelity':
+                    self._frequency_data['filter_function_pc'] = F_pc
+                else:
+                    self._frequency_data['filter_function_pc'] = F_pc.trace(axis1=4, axis2=5)
+                    self._frequency_data['filter_function_pc_gen'] = F_pc
+                filter_function = F_pc.sum(axis=(0, 1))
+            else:
+                filter_function = numeric.calculate_filter_function(control_matrix, which)
         if which == 'fidelity':
             self._frequency_data['filter_function'] = filter_function
         else:
@@ -332,6 +338,11 @@ class PulseSequence:
         key = 'filter_function_pc' if which == 'fidelity' else 'filter_function_pc_gen'
         if key in self._frequency_data:
             return self._frequency_data[key]
+        if self.is_cached('control_matrix_pc'):
+            F_pc = numeric.calculate_pulse_correlation_filter_function(
+                self._frequency_data['control_matrix_pc'], which=which)
+            self._frequency_data[key] = F_pc
+            return F_pc
         raise util.CalculationError(
             "Could not get the pulse correlation filter function since it "
             "was not computed during concatenation. Please run the "
@@ -420,3 +431,182 @@ class PulseSequence:
                     self._data.pop(key, None)
                 for key in ('total_phases', 'control_matrix', 'control_matrix_pc'):
                     self._frequency_data.pop(key, None)
+
+
+# --------------------------------------------------------------------------------------------
+# Concatenation (reference pulse_sequence.py:1340-1483, 1599-1887).  Host-side bookkeeping on
+# identifiers and coefficient tables; the arithmetic -- atomic control matrices, Liouville
+# propagators, the concatenation rule and the filter functions -- runs in libffk.
+# --------------------------------------------------------------------------------------------
+def _all_bases_equal(pulses):
+    first = pulses[0].basis
+    return all(p.basis.shape == first.shape and np.array_equal(np.asarray(p.basis), np.asarray(first))
+               for p in pulses[1:])
+
+
+def _concatenate_hamiltonian(opers, identifiers, coeffs, kind):
+    """Merge the operator tables of several pulses (reference pulse_sequence.py:1340-1483).
+
+    Operators with identical matrices are one operator of the new pulse (they must then carry
+    the same identifier in every pulse, else ValueError); an identifier that names different
+    matrices in different pulses is disambiguated by appending the pulse position.  Returns the
+    operators sorted by their new identifiers, the identifiers, the (n_opers, sum n_dt)
+    coefficient table -- zero-filled for control terms a pulse lacks, filled with the common
+    constant for noise sensitivities (ValueError if it is not constant) -- and, per pulse, the
+    map old identifier -> new identifier.
+    """
+    n_segments = [np.shape(c)[1] for c in coeffs]
+    offsets = np.concatenate(([0], np.cumsum(n_segments)))
+    # one record per (pulse, operator)
+    records = [(p, i, np.ascontiguousarray(op).tobytes(), str(ident))
+               for p, (ops, ids) in enumerate(zip(opers, identifiers))
+               for i, (op, ident) in enumerate(zip(ops, ids))]
+    idents_of_matrix, matrices_of_ident = {}, {}
+    for _, _, key, ident in records:
+        idents_of_matrix.setdefault(key, set()).add(ident)
+        matrices_of_ident.setdefault(ident, set()).add(key)
+    if any(len(v) > 1 for v in idents_of_matrix.values()):
+        raise ValueError(f'Trying to concatenate pulses with equal {kind} operators but '
+                         f'different identifiers. Please choose unique {kind} identifiers!')
+    # new identifier of every distinct matrix
+    first_seen = {}
+    for p, i, key, ident in records:
+        first_seen.setdefault(key, (p, i, ident))
+    new_ident = {}
+    for key, (p, i, ident) in first_seen.items():
+        clash = len(matrices_of_ident[ident]) > 1
+        new_ident[key] = f'{ident}_{p}' if clash else ident
+    mapping = {p: {} for p in range(len(opers))}
+    for p, i, key, ident in records:
+        mapping[p][ident] = new_ident[key]
+    keys = sorted(first_seen, key=lambda k: new_ident[k])
+    concat_identifiers = np.array([new_ident[k] for k in keys])
+    concat_opers = np.array([np.asarray(opers[first_seen[k][0]][first_seen[k][1]]) for k in keys])
+    table = np.full((len(keys), int(offsets[-1])), np.nan)
+    row = {k: r for r, k in enumerate(keys)}
+    for p, i, key, _ in records:
+        table[row[key], offsets[p]:offsets[p + 1]] = np.asarray(coeffs[p])[i]
+    missing = np.isnan(table)
+    if kind == 'noise':
+        for r in np.nonzero(missing.any(axis=1))[0]:
+            known = table[r][~missing[r]]
+            if not (known == known[0]).all():
+                raise ValueError('Not all pulses have the same noise operators and '
+                                 'non-trivial noise sensitivities so I cannot infer them.')
+            table[r, missing[r]] = known[0]
+    else:
+        table[missing] = 0
+    return concat_opers, concat_identifiers, table, mapping
+
+
+def concatenate_without_filter_function(pulses, return_identifier_mappings=False):
+    """Concatenate pulses without touching any filter function
+    (reference pulse_sequence.py:1534-1665)."""
+    try:
+        pulses = tuple(pulses)
+    except TypeError:
+        raise TypeError(f'Expected pulses to be iterable, not {type(pulses)}') from None
+    if not all(isinstance(pulse, PulseSequence) for pulse in pulses):
+        raise TypeError('Can only concatenate PulseSequences!')
+    if len(set(pulse.d for pulse in pulses)) != 1:
+        raise ValueError('Trying to concatenate PulseSequence instances with different dimension!')
+    if not _all_bases_equal(pulses):
+        raise ValueError('Trying to concatenate PulseSequence instances with different bases!')
+    c_opers, c_ids, c_coeffs, c_map = _concatenate_hamiltonian(
+        [p.c_opers for p in pulses], [p.c_oper_identifiers for p in pulses],
+        [p.c_coeffs for p in pulses], kind='control')
+    n_opers, n_ids, n_coeffs, n_map = _concatenate_hamiltonian(
+        [p.n_opers for p in pulses], [p.n_oper_identifiers for p in pulses],
+        [p.n_coeffs for p in pulses], kind='noise')
+    dt = np.concatenate(tuple(pulse.dt for pulse in pulses))
+    newpulse = PulseSequence.from_arrays(c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt,
+                                         pulses[0].basis)
+    newpulse.tau = sum(pulse.tau for pulse in pulses)
+    if return_identifier_mappings:
+        return newpulse, c_map, n_map
+    return newpulse
+
+
+@util.parse_optional_parameters(which=('fidelity', 'generalized'))
+def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=None,
+                which='fidelity', omega=None, show_progressbar=False, calc_second_order_FF=False):
+    r"""Concatenate pulses and, where it pays, their filter functions by the concatenation rule
+    :math:`\tilde{\mathcal B}(\omega)=\sum_g e^{i\omega t_{g-1}}\tilde{\mathcal B}^{(g)}(\omega)
+    \mathcal Q^{(g-1)}` (reference pulse_sequence.py:1668-1887).
+
+    Same decision logic as the reference: the filter function is computed if
+    ``calc_filter_function`` is True, or left out if False, or -- by default -- computed only if
+    at least one pulse has a cached control matrix, all cached frequencies agree and at least
+    two pulses share a noise operator.  ``calc_pulse_correlation_FF`` keeps every summand and
+    caches the pulse correlation filter function.
+    """
+    if calc_second_order_FF:
+        raise NotImplementedError('The second-order filter function is outside the accelerated '
+                                  'path (SURVEY.md section 2, row 14).')
+    newpulse, _, n_map = concatenate_without_filter_function(pulses, return_identifier_mappings=True)
+    pulses = tuple(pulses)
+    if all(pls.is_cached('total_propagator') for pls in pulses):
+        newpulse.total_propagator = util.mdot([pls.total_propagator for pls in pulses][::-1])
+    if calc_pulse_correlation_FF:
+        calc_filter_function = True
+    if calc_filter_function is False:
+        return newpulse
+
+    # which noise operators of the new pulse does each pulse carry?
+    new_ids = list(newpulse.n_oper_identifiers)
+    present = np.zeros((len(pulses), len(new_ids)), dtype=bool)
+    for p in range(len(pulses)):
+        for ident in n_map[p].values():
+            present[p, new_ids.index(ident)] = True
+    shared_n_opers = bool((present.sum(axis=0) > 1).any())
+
+    if omega is None:
+        cached_R = [pls.is_cached('control_matrix') for pls in pulses]
+        cached_w = [pls.is_cached('omega') for pls in pulses]
+        candidates = [pls.omega for pls, c in zip(pulses, cached_R if any(cached_R) else cached_w) if c]
+        equal_omega = all(np.array_equal(candidates[0], w) for w in candidates[1:])
+        if not equal_omega or not candidates:
+            if calc_filter_function:
+                raise ValueError('Calculation of filter function forced but not all pulses '
+                                 'have the same frequencies cached and none were supplied!')
+            if calc_pulse_correlation_FF:
+                raise ValueError('Cannot compute the pulse correlation filter functions; do not '
+                                 'have the frequencies at which to evaluate.')
+            return newpulse
+        if calc_filter_function is None and (not shared_n_opers or not any(cached_R)):
+            return newpulse
+        omega = candidates[0]
+
+    if not shared_n_opers:
+        # nothing to reuse: plain from-scratch evaluation of the long sequence
+        newpulse.cache_filter_function(omega, which=which)
+        return newpulse
+
+    phases = np.array([pls.get_total_phases(omega) for pls in pulses[:-1]]).cumprod(axis=0)
+    propagators_liouville = util.adot(
+        np.array([pls.total_propagator_liouville for pls in pulses[:-1]]))
+    R_atomic = np.empty((len(pulses), len(newpulse.n_opers), len(newpulse.basis), len(omega)),
+                        dtype=complex)
+    seg = np.concatenate(([0], np.cumsum([len(pls.dt) for pls in pulses])))
+    for i, (pls, here) in enumerate(zip(pulses, present)):
+        # rows of the pulse's own control matrix, in the new pulse's (sorted) operator order
+        own_order = [list(pls.n_oper_identifiers).index(old)
+                     for new in np.asarray(new_ids)[here]
+                     for old, mapped in n_map[i].items() if mapped == new]
+        R_atomic[i, here] = pls.get_control_matrix(omega, show_progressbar)[own_order]
+        if not here.all():
+            # noise operators this pulse does not know: evaluate them on its control Hamiltonian
+            R_atomic[i, ~here] = numeric.calculate_control_matrix_from_scratch(
+                pls.eigvals, pls.eigvecs, pls.propagators, omega, pls.basis,
+                newpulse.n_opers[~here], newpulse.n_coeffs[~here, seg[i]:seg[i + 1]], pls.dt,
+                t=pls.t)
+    if not newpulse.is_cached('total_propagator'):
+        newpulse.total_propagator = util.mdot([pls.total_propagator for pls in pulses][::-1])
+    newpulse.cache_total_phases(omega)
+    newpulse.total_propagator_liouville = liouville_representation(newpulse.total_propagator,
+                                                                   newpulse.basis)
+    control_matrix = numeric.calculate_control_matrix_from_atomic(
+        phases, R_atomic, propagators_liouville,
+        which='correlations' if calc_pulse_correlation_FF else 'total')
+    newpulse.cache_filter_function(omega, control_matrix, which=which)
+    return newpulse

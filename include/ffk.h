@@ -133,6 +133,21 @@ int ffk_control_matrix_intermediates(
     double* n_opers_transformed, double* eigvecs_propagated, double* basis_transformed,
     double* phase_factors, double* first_order_integral, double* control_matrix_step);
 
+/* ---- numeric.calculate_control_matrix_from_atomic (numeric.py:621-704; caller
+ *      pulse_sequence.concatenate pulse_sequence.py:1858) -- the concatenation rule -----------
+ * phases (G-1, W) c128 cumulated total phase factors; control_matrix_atomic (G, A, N, W) c128;
+ * propagators_liouville (G-1, N, N), f64 if l_is_complex == 0 else c128.
+ * which 0 ('total'): out (A, N, W) = R^(0) + sum_g phases[g-1] R^(g) L^(g-1);
+ * which 1 ('correlations'): out (G, A, N, W), every summand.                                */
+int ffk_control_matrix_from_atomic(const double* phases, const double* control_matrix_atomic,
+                                   const double* propagators_liouville, int l_is_complex, int G,
+                                   int A, int N, int W, int which, double* out);
+size_t ffk_control_matrix_from_atomic_workspace_bytes(int G, int A, int N, int W);
+int ffk_control_matrix_from_atomic_dev(const double* phases, const double* control_matrix_atomic,
+                                       const double* propagators_liouville, int l_is_complex,
+                                       int G, int A, int N, int W, int which, double* out,
+                                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- numeric.calculate_filter_function (numeric.py:1413-1467) --------------------------
  * control_matrix (A, N, W) c128 -> fidelity: (A, A, W) c128,
  *                                  generalized: (A, A, N, N, W) c128.                       */

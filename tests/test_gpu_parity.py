@@ -368,3 +368,112 @@ def test_config2_full_size_against_oracle():
     # basis independence of F (tests/test_basis.py:378-432)
     pulse_ggm = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt)
     assert rel_err(pulse_ggm.get_filter_function(omega), F) < 1e-12
+
+
+# ---- NEXT-1: the concatenation rule --------------------------------------
+def atomic_pulses(g, n=5):
+    return [ff.PulseSequence.from_arrays(
+        g[f'p{i}_c_opers'], g[f'p{i}_c_oper_identifiers'], g[f'p{i}_c_coeffs'], g[f'p{i}_n_opers'],
+        g[f'p{i}_n_oper_identifiers'], g[f'p{i}_n_coeffs'], g[f'p{i}_dt'],
+        ff.Basis(g[f'p{i}_basis'], btype='Pauli')) for i in range(n)]
+
+
+def test_control_matrix_from_atomic():
+    """numeric.calculate_control_matrix_from_atomic against the reference's outputs."""
+    g = load_golden('from_atomic')
+    R = numeric.calculate_control_matrix_from_atomic(g['phases'], g['R_atomic'],
+                                                     g['propagators_liouville'])
+    assert R.shape == g['R_total'].shape and rel_err(R, g['R_total']) < TIGHT
+    Rc = numeric.calculate_control_matrix_from_atomic(g['phases'], g['R_atomic'],
+                                                      g['propagators_liouville'],
+                                                      which='correlations')
+    assert Rc.shape == g['R_correlations'].shape and rel_err(Rc, g['R_correlations']) < TIGHT
+    assert rel_err(Rc.sum(0), R) < TIGHT
+    # complex Liouville propagators (non-Hermitian basis) take the other kernel branch
+    Lc = g['propagators_liouville'].astype(complex)
+    assert rel_err(numeric.calculate_control_matrix_from_atomic(g['phases'], g['R_atomic'], Lc),
+                   g['R_total']) < TIGHT
+    # a single pulse is returned as is
+    R1 = numeric.calculate_control_matrix_from_atomic(g['phases'][:0], g['R_atomic'][:1],
+                                                      g['propagators_liouville'][:0])
+    assert np.array_equal(R1, g['R_atomic'][0])
+    with pytest.raises(ValueError):
+        numeric.calculate_control_matrix_from_atomic(g['phases'], g['R_atomic'],
+                                                     g['propagators_liouville'], which='bogus')
+    # long, thin case: the pulse axis is split into slabs (1000 single-segment gates, d = 2)
+    rng = np.random.default_rng(3)
+    G, A, N, W = 1000, 1, 4, 256
+    Ra = rng.standard_normal((G, A, N, W)) + 1j*rng.standard_normal((G, A, N, W))
+    ph = np.exp(1j*rng.standard_normal((G - 1, W)))
+    L = rng.standard_normal((G - 1, N, N))
+    got = numeric.calculate_control_matrix_from_atomic(ph, Ra, L)
+    ref = orc.control_matrix_from_atomic(ph, Ra, L)
+    assert rel_err(got, ref) < 1e-13
+
+
+def test_concatenate_matches_from_scratch_and_reference():
+    """tests/test_core.py:724-743: concatenation rule == from-scratch evaluation of the long pulse."""
+    g = load_golden('from_atomic')
+    omega = g['omega']
+    pulses = atomic_pulses(g)
+    total = ff.concatenate(pulses, calc_filter_function=True, omega=omega)
+    assert total.is_cached('control_matrix') and total.is_cached('filter_function')
+    R = total.get_control_matrix(omega)
+    assert rel_err(R, g['concat_control_matrix']) < 1e-12
+    scratch = ff.concatenate_without_filter_function(atomic_pulses(g))
+    assert rel_err(scratch.get_control_matrix(omega), R) < 1e-12
+    assert rel_err(scratch.get_filter_function(omega), total.get_filter_function(omega)) < 1e-12
+    assert np.allclose(total.total_propagator, scratch.total_propagator, atol=1e-13)
+    # operator @, default decision logic: FF concatenated only if cached with equal omega
+    a, b = atomic_pulses(g, 2)
+    assert not (a @ b).is_cached('filter_function')
+    a.cache_filter_function(omega)
+    b.cache_filter_function(omega)
+    ab = a @ b
+    assert ab.is_cached('filter_function')
+    ref = ff.concatenate_without_filter_function(atomic_pulses(g, 2)).get_filter_function(omega)
+    assert rel_err(ab.get_filter_function(omega), ref) < 1e-12
+    with pytest.raises(TypeError):
+        a @ 3
+    with pytest.raises(ValueError):
+        b2 = atomic_pulses(g, 2)[1]
+        b2.cache_filter_function(omega + 1)
+        ff.concatenate([a, b2], calc_filter_function=True)
+
+
+def test_pulse_correlation_filter_function():
+    g = load_golden('from_atomic')
+    omega = g['omega']
+    pulses = atomic_pulses(g, 3)
+    total = ff.concatenate(pulses, calc_pulse_correlation_FF=True, omega=omega)
+    F_pc = total.get_pulse_correlation_filter_function()
+    A = len(total.n_opers)
+    assert F_pc.shape == (3, 3, A, A, len(omega))
+    F = total.get_filter_function(omega)
+    assert rel_err(F_pc.sum(axis=(0, 1)), F) < 1e-12
+    ref = np.einsum('gako,hbko->ghabo', total.get_pulse_correlation_control_matrix().conj(),
+                    total.get_pulse_correlation_control_matrix())
+    assert rel_err(F_pc, ref) < 1e-13
+    S = 1e-3/omega
+    corr = ff.infidelity(total, S, omega, which='correlations')
+    assert corr.shape == (3, 3, A)
+    assert rel_err(corr.sum(axis=(0, 1)), ff.infidelity(total, S, omega)) < 1e-12
+
+
+def test_spin_echo_concatenation_is_cpmg():
+    """tests/test_sequencing.py:353-392: n concatenated spin echos == n-pulse CPMG (analytic)."""
+    X, Z = util.paulis[1], util.paulis[3]
+    n, tau, tau_pi = 6, np.pi, 1e-9
+    t_se = tau/n
+    dt = np.array([(t_se - tau_pi)/2, tau_pi, (t_se - tau_pi)/2])
+    se = ff.PulseSequence([[X/2, [0, np.pi/tau_pi, 0]]], [[Z/2, [1, 1, 1]]], dt)
+    omega = np.concatenate([-np.logspace(0, 3, 60)[::-1], np.logspace(0, 3, 60)])
+    se.cache_filter_function(omega)
+    cpmg = ff.concatenate([se]*n)
+    assert cpmg.is_cached('filter_function')
+    F = cpmg.get_filter_function(omega)[0, 0]
+    z = omega*tau
+    analytic = 8*np.sin(z/4/n)**4*np.sin(z/2)**2/np.cos(z/2/n)**2     # analytic.py CPMG, n even
+    np.testing.assert_allclose((F*omega**2).real, analytic, atol=1e-9, rtol=1e-7)
+    scratch = ff.concatenate_without_filter_function([se]*n).get_filter_function(omega)[0, 0]
+    assert rel_err(F, scratch) < 1e-10

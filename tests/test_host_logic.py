@@ -188,3 +188,47 @@ def test_device_math_on_host():
     ref[m] = util.cexpm1(x[m]*dt)/(1j*x[m])
     assert np.max(np.abs(got - ref)) < 5e-16
     assert got[0] == dt and got[3] == dt and got[4] == dt
+
+
+def test_concatenation_bookkeeping():
+    """Identifier / coefficient-table logic of concatenate_without_filter_function; expected values
+    are what the reference (pulse_sequence.py:1340-1483) produces on the same inputs."""
+    X, Y, Z = util.paulis[1:]
+    a = ff.PulseSequence([[X, [1., 2.], 'c']], [[Z, [1., 1.], 'n']], [1., 1.])
+    b = ff.PulseSequence([[Y, [3.], 'c']], [[Z, [1.], 'n']], [2.])
+    ab = ff.concatenate_without_filter_function([a, b])
+    assert list(ab.c_oper_identifiers) == ['c_0', 'c_1']        # same name, different operator
+    assert np.array_equal(ab.c_opers, [X, Y])
+    assert np.array_equal(ab.c_coeffs, [[1, 2, 0], [0, 0, 3]])  # control terms zero-filled
+    assert list(ab.n_oper_identifiers) == ['n'] and np.array_equal(ab.n_coeffs, [[1, 1, 1]])
+    assert np.array_equal(ab.dt, [1, 1, 2]) and ab.tau == 4 and len(ab) == 3
+    # a noise operator missing from one pulse inherits its (constant) sensitivity
+    c = ff.PulseSequence([[X, [1.], 'c']], [[Z, [2.], 'nz'], [X, [0.5], 'nx']], [1.])
+    d = ff.PulseSequence([[X, [3.], 'c']], [[Z, [2.], 'nz']], [2.])
+    cd, c_map, n_map = ff.concatenate_without_filter_function([c, d], return_identifier_mappings=True)
+    assert list(cd.n_oper_identifiers) == ['nx', 'nz']
+    assert np.array_equal(cd.n_coeffs, [[0.5, 0.5], [2, 2]])
+    assert n_map == {0: {'nx': 'nx', 'nz': 'nz'}, 1: {'nz': 'nz'}} and c_map[0] == {'c': 'c'}
+    # ... but not a time-dependent one
+    e = ff.PulseSequence([[X, [1., 1.], 'c']], [[Z, [2., 2.], 'nz'], [X, [0.5, 0.6], 'nx']], [1., 1.])
+    with pytest.raises(ValueError):
+        ff.concatenate_without_filter_function([e, d])
+    # equal operators under different names are refused
+    with pytest.raises(ValueError):
+        ff.concatenate_without_filter_function([a, ff.PulseSequence([[X, [1.], 'other']],
+                                                                    [[Z, [1.], 'n']], [1.])])
+    with pytest.raises(TypeError):
+        ff.concatenate_without_filter_function(5)
+    with pytest.raises(TypeError):
+        ff.concatenate_without_filter_function([a, 'b'])
+    with pytest.raises(ValueError):
+        ff.concatenate_without_filter_function([a, ff.PulseSequence([[np.eye(3), [1.]]],
+                                                                    [[np.eye(3), [1.]]], [1.])])
+    with pytest.raises(ValueError):
+        ff.concatenate_without_filter_function(
+            [a, ff.PulseSequence([[X, [1.]]], [[Z, [1.]]], [1.], basis=ff.Basis.pauli(1)[::-1])])
+    # no filter function work unless something is cached or asked for
+    assert not ff.concatenate([a, b]).is_cached('filter_function')
+    assert not ff.concatenate([a, b], calc_filter_function=False).is_cached('omega')
+    with pytest.raises(NotImplementedError):
+        ff.concatenate([a, b], calc_second_order_FF=True)
