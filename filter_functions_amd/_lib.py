@@ -87,6 +87,13 @@ SIGNATURES = {
     'ffk_control_matrix_from_atomic_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                    c_int, c_int, c_int, c_void_p, c_void_p,
                                                    c_size_t, c_void_p]),
+    'ffk_control_matrix_from_atomic_indexed': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                       c_int, c_int, c_int, c_int, c_int, c_int,
+                                                       c_void_p]),
+    'ffk_control_matrix_from_atomic_indexed_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p,
+                                                           c_int, c_int, c_int, c_int, c_int, c_int,
+                                                           c_int, c_void_p, c_void_p, c_size_t,
+                                                           c_void_p]),
     'ffk_filter_function': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ffk_filter_function_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ffk_infidelity': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,

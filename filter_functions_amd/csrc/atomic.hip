@@ -16,9 +16,16 @@
 namespace ffk {
 namespace {
 
-template <int LT, bool LCPLX>
+// INDEXED: sequences built from few distinct pulses (randomized benchmarking draws 1000 gates from
+// 24 Cliffords, examples/randomized_benchmarking.py:76-81): `Ratomic` and `phases` are then tables
+// over the T distinct pulses, `index[g]` names the pulse at position g, and the cumulated phase
+// factors (pulse_sequence.py:1824, a (G-1, W) cumprod on the host in the reference) become a
+// running product in registers.  The tables stay resident in L2 / Infinity Cache, so the kernel
+// is no longer bound by streaming G atomic control matrices from HBM.
+template <int LT, bool LCPLX, bool INDEXED>
 __global__ __launch_bounds__(64) void from_atomic_kernel(const cplx* __restrict__ phases,
                                                          const cplx* __restrict__ Ratomic,
+                                                         const int32_t* __restrict__ index,
                                                          const double* __restrict__ L, int G, int A,
                                                          int N, int W, int glen, int correlations,
                                                          cplx* __restrict__ out) {
@@ -33,8 +40,19 @@ __global__ __launch_bounds__(64) void from_atomic_kernel(const cplx* __restrict_
     cplx acc[LT];
 #pragma unroll
     for (int j = 0; j < LT; ++j) acc[j] = {0.0, 0.0};
+    // running product of the pulses' total phase factors (plain multiply/subtract like NumPy's
+    // complex cumprod); a slab that does not start at 0 first replays the product up to g0
+    cplx run = {1.0, 0.0};
+    auto advance = [&](int g) {   // run <- run * total_phase[pulse at position g]
+        const cplx tp = phases[static_cast<size_t>(index[g])*W + w];
+        const double rr = run.re*tp.re, ii = run.im*tp.im, ri = run.re*tp.im, ir = run.im*tp.re;
+        run.re = rr - ii;
+        run.im = ri + ir;
+    };
+    if (INDEXED)
+        for (int g = 0; g + 1 < g0; ++g) advance(g);
     for (int g = g0; g < g1; ++g) {
-        const cplx* Rg = Ratomic + g*pulse_stride + static_cast<size_t>(a)*N*W + w;
+        const cplx* Rg = Ratomic + (INDEXED ? index[g] : g)*pulse_stride + static_cast<size_t>(a)*N*W + w;
         cplx step[LT];
         if (g == 0) {
 #pragma unroll
@@ -42,7 +60,13 @@ __global__ __launch_bounds__(64) void from_atomic_kernel(const cplx* __restrict_
         } else {
 #pragma unroll
             for (int j = 0; j < LT; ++j) step[j] = {0.0, 0.0};
-            const cplx ph = phases[static_cast<size_t>(g - 1)*W + w];
+            cplx ph;
+            if (INDEXED) {
+                advance(g - 1);
+                ph = run;
+            } else {
+                ph = phases[static_cast<size_t>(g - 1)*W + w];
+            }
             const double* Lg = L + static_cast<size_t>(g - 1)*N*N*(LCPLX ? 2 : 1);
             for (int k = 0; k < N; ++k) {
                 const cplx v = cmul(ph, Rg[static_cast<size_t>(k)*W]);
@@ -82,21 +106,23 @@ __global__ __launch_bounds__(64) void from_atomic_kernel(const cplx* __restrict_
     }
 }
 
-template <bool LCPLX>
-hipError_t launch_c(const cplx* phases, const cplx* Ratomic, const double* L, int G, int A, int N,
-                    int W, int gsplit, int correlations, cplx* out, hipStream_t stream) {
+template <bool LCPLX, bool INDEXED>
+hipError_t launch_c(const cplx* phases, const cplx* Ratomic, const int32_t* index, const double* L,
+                    int G, int A, int N, int W, int gsplit, int correlations, cplx* out,
+                    hipStream_t stream) {
     const int glen = (G + gsplit - 1)/gsplit;
     const unsigned tiles = (W + 63)/64;
     if (N <= 4) {
-        hipLaunchKernelGGL((from_atomic_kernel<4, LCPLX>), dim3(tiles, A, gsplit), dim3(64), 0, stream,
-                           phases, Ratomic, L, G, A, N, W, glen, correlations, out);
+        hipLaunchKernelGGL((from_atomic_kernel<4, LCPLX, INDEXED>), dim3(tiles, A, gsplit), dim3(64),
+                           0, stream, phases, Ratomic, index, L, G, A, N, W, glen, correlations, out);
     } else if (N <= 16) {
-        hipLaunchKernelGGL((from_atomic_kernel<16, LCPLX>), dim3(tiles, A, gsplit), dim3(64), 0, stream,
-                           phases, Ratomic, L, G, A, N, W, glen, correlations, out);
+        hipLaunchKernelGGL((from_atomic_kernel<16, LCPLX, INDEXED>), dim3(tiles, A, gsplit), dim3(64),
+                           0, stream, phases, Ratomic, index, L, G, A, N, W, glen, correlations, out);
     } else {
         const int nlt = (N + 15)/16;
-        hipLaunchKernelGGL((from_atomic_kernel<16, LCPLX>), dim3(tiles, A, gsplit*nlt), dim3(64), 0,
-                           stream, phases, Ratomic, L, G, A, N, W, glen, correlations, out);
+        hipLaunchKernelGGL((from_atomic_kernel<16, LCPLX, INDEXED>), dim3(tiles, A, gsplit*nlt),
+                           dim3(64), 0, stream, phases, Ratomic, index, L, G, A, N, W, glen,
+                           correlations, out);
     }
     return hipGetLastError();
 }
@@ -117,15 +143,24 @@ size_t from_atomic_workspace_bytes(int G, int A, int N, int W) {
     return s > 1 ? align_up(sizeof(cplx)*static_cast<size_t>(s)*A*N*W) : 256;
 }
 
-hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const double* L,
-                              int l_is_complex, int G, int A, int N, int W, int correlations,
-                              cplx* out, void* ws, hipStream_t stream) {
+hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int32_t* index,
+                              const double* L, int l_is_complex, int G, int A, int N, int W,
+                              int correlations, cplx* out, void* ws, hipStream_t stream) {
     if (A > 65535) return hipErrorInvalidValue;
     const int gsplit = correlations ? 1 : from_atomic_gsplit(G, A, N, W);
     cplx* target = (gsplit > 1) ? static_cast<cplx*>(ws) : out;
-    hipError_t err = l_is_complex
-                         ? launch_c<true>(phases, Ratomic, L, G, A, N, W, gsplit, correlations, target, stream)
-                         : launch_c<false>(phases, Ratomic, L, G, A, N, W, gsplit, correlations, target, stream);
+    hipError_t err;
+    if (index) {
+        err = l_is_complex ? launch_c<true, true>(phases, Ratomic, index, L, G, A, N, W, gsplit,
+                                                  correlations, target, stream)
+                           : launch_c<false, true>(phases, Ratomic, index, L, G, A, N, W, gsplit,
+                                                   correlations, target, stream);
+    } else {
+        err = l_is_complex ? launch_c<true, false>(phases, Ratomic, index, L, G, A, N, W, gsplit,
+                                                   correlations, target, stream)
+                           : launch_c<false, false>(phases, Ratomic, index, L, G, A, N, W, gsplit,
+                                                    correlations, target, stream);
+    }
     if (err != hipSuccess) return err;
     if (gsplit > 1)
         return launch_reduce_chunks(target, gsplit, static_cast<size_t>(A)*N*W, out, stream);

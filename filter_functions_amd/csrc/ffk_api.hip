@@ -581,7 +581,7 @@ int ffk_control_matrix_from_atomic_dev(const double* phases, const double* contr
     FFK_REQUIRE(workspace_bytes >= ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W),
                 "workspace too small");
     FFK_HIP(ffk::launch_from_atomic(reinterpret_cast<const cplx*>(phases),
-                                    reinterpret_cast<const cplx*>(control_matrix_atomic),
+                                    reinterpret_cast<const cplx*>(control_matrix_atomic), nullptr,
                                     propagators_liouville, l_is_complex, G, A, N, W, which,
                                     reinterpret_cast<cplx*>(out), workspace,
                                     static_cast<hipStream_t>(stream)));
@@ -617,6 +617,69 @@ int ffk_control_matrix_from_atomic(const double* phases, const double* control_m
     FFK_HIP(hipMemcpyAsync(dR, control_matrix_atomic, nR, hipMemcpyHostToDevice, nullptr));
     if (int rc = ffk_control_matrix_from_atomic_dev(dP, dR, dL, l_is_complex, G, A, N, W, which, dO, ws,
                                                     wsb, nullptr))
+        return rc;
+    FFK_HIP(hipMemcpyAsync(out, dO, nO, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+int ffk_control_matrix_from_atomic_indexed_dev(const double* total_phases,
+                                               const double* control_matrix_table,
+                                               const int32_t* index,
+                                               const double* propagators_liouville,
+                                               int l_is_complex, int T, int G, int A, int N, int W,
+                                               int which, double* out, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(T >= 1 && G >= 1 && A >= 1 && N >= 1 && W >= 1, "empty axis");
+    FFK_REQUIRE(total_phases && control_matrix_table && index && out && workspace, "NULL argument");
+    FFK_REQUIRE(G == 1 || propagators_liouville, "NULL argument");
+    FFK_REQUIRE(which == 0 || which == 1, "invalid which=%d", which);
+    FFK_REQUIRE(workspace_bytes >= ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W),
+                "workspace too small");
+    FFK_HIP(ffk::launch_from_atomic(reinterpret_cast<const cplx*>(total_phases),
+                                    reinterpret_cast<const cplx*>(control_matrix_table), index,
+                                    propagators_liouville, l_is_complex, G, A, N, W, which,
+                                    reinterpret_cast<cplx*>(out), workspace,
+                                    static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+int ffk_control_matrix_from_atomic_indexed(const double* total_phases,
+                                           const double* control_matrix_table,
+                                           const int32_t* index,
+                                           const double* propagators_liouville, int l_is_complex,
+                                           int T, int G, int A, int N, int W, int which,
+                                           double* out) {
+    FFK_REQUIRE(T >= 1 && G >= 1 && A >= 1 && N >= 1 && W >= 1, "empty axis");
+    FFK_REQUIRE(total_phases && control_matrix_table && index && out, "NULL argument");
+    FFK_REQUIRE(G == 1 || propagators_liouville, "NULL argument");
+    FFK_REQUIRE(which == 0 || which == 1, "invalid which=%d", which);
+    for (int g = 0; g < G; ++g)
+        FFK_REQUIRE(index[g] >= 0 && index[g] < T, "index[%d] = %d outside [0, %d)", g, index[g], T);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nP = 16*size_t(T)*W, nR = 16*size_t(T)*A*N*W, nI = 4*size_t(G);
+    const size_t nL = (l_is_complex ? 16 : 8)*size_t(G > 1 ? G - 1 : 1)*N*N;
+    const size_t nO = which ? 16*size_t(G)*A*N*W : 16*size_t(A)*N*W;
+    const size_t wsb = ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W);
+    void* base;
+    if (int rc = arena_reserve(align_up(nP) + align_up(nR) + align_up(nI) + align_up(nL) + align_up(nO) + wsb,
+                               &base))
+        return rc;
+    Bump a(base, g_arena.size);
+    double* dP = a.take<double>(nP/8);
+    double* dR = a.take<double>(nR/8);
+    int32_t* dI = a.take<int32_t>(G);
+    double* dL = a.take<double>(nL/8);
+    double* dO = a.take<double>(nO/8);
+    void* ws = a.take<unsigned char>(wsb);
+    FFK_HIP(hipMemcpyAsync(dP, total_phases, nP, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dR, control_matrix_table, nR, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dI, index, nI, hipMemcpyHostToDevice, nullptr));
+    if (G > 1)
+        FFK_HIP(hipMemcpyAsync(dL, propagators_liouville, (l_is_complex ? 16 : 8)*size_t(G - 1)*N*N,
+                               hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_control_matrix_from_atomic_indexed_dev(dP, dR, dI, dL, l_is_complex, T, G, A, N, W,
+                                                            which, dO, ws, wsb, nullptr))
         return rc;
     FFK_HIP(hipMemcpyAsync(out, dO, nO, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipStreamSynchronize(nullptr));

@@ -124,10 +124,12 @@ hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_n
 
 // ---- atomic.hip -----------------------------------------------------------------------------
 size_t from_atomic_workspace_bytes(int G, int A, int N, int W);
-// out: (A,N,W) for the sum, (G,A,N,W) for correlations != 0; L is (G-1,N,N) f64 or c128
-hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const double* L,
-                              int l_is_complex, int G, int A, int N, int W, int correlations,
-                              cplx* out, void* ws, hipStream_t stream);
+// out: (A,N,W) for the sum, (G,A,N,W) for correlations != 0; L is (G-1,N,N) f64 or c128.
+// index == NULL: phases (G-1,W) cumulated, Ratomic (G,A,N,W).  index != NULL (G int32): phases
+// (T,W) total phase factors and Ratomic (T,A,N,W) tables over the distinct pulses.
+hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int32_t* index,
+                              const double* L, int l_is_complex, int G, int A, int N, int W,
+                              int correlations, cplx* out, void* ws, hipStream_t stream);
 
 // ---- liouville.hip ---------------------------------------------------------------------------
 size_t liouville_workspace_bytes(int batch, int d, int N);

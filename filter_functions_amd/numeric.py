@@ -25,7 +25,8 @@ from ._lib import as_c128, as_f64, check, ptr
 
 __all__ = ['diagonalize', 'calculate_control_matrix_from_scratch',
            'calculate_noise_operators_from_scratch', 'calculate_filter_function', 'infidelity',
-           'calculate_control_matrix_from_atomic', 'calculate_pulse_correlation_filter_function']
+           'calculate_control_matrix_from_atomic', 'calculate_control_matrix_from_atomic_indexed',
+           'calculate_pulse_correlation_filter_function']
 
 
 def _check_d(d):
@@ -314,6 +315,40 @@ def calculate_control_matrix_from_atomic(phases, control_matrix_atomic, propagat
         check(_lib.load().ffk_control_matrix_from_atomic(
             ptr(phases) if G > 1 else None, ptr(R_atomic), ptr(L) if G > 1 else None,
             int(l_is_complex), G, A, N, W, int(which == 'correlations'), ptr(out)))
+    return out
+
+
+@util.parse_optional_parameters(which=('total', 'correlations'))
+def calculate_control_matrix_from_atomic_indexed(total_phases, control_matrix_table, index,
+                                                 propagators_liouville, which='total'):
+    """The concatenation rule for a sequence drawn from few distinct pulses (no reference
+    counterpart as a free function; it is what ``concatenate`` does when the same PulseSequence
+    objects repeat, cf. examples/randomized_benchmarking.py:76-81).
+
+    total_phases: (T, n_omega) total phase factors of the T distinct pulses;
+    control_matrix_table: (T, n_nops, d², n_omega); index: (G,) position -> distinct pulse;
+    propagators_liouville: (G-1, d², d²) cumulated.  The cumulated phase factors are formed on
+    the device, the tables stay cache resident."""
+    tp = as_c128(total_phases)
+    table = as_c128(control_matrix_table)
+    index = np.ascontiguousarray(index, dtype=np.int32)
+    if table.ndim != 4 or tp.shape != (table.shape[0], table.shape[3]):
+        raise ValueError('Expected control_matrix_table (T, n_nops, n_basis, n_omega) and '
+                         f'total_phases (T, n_omega), not {table.shape} and {tp.shape}.')
+    T, A, N, W = table.shape
+    G = len(index)
+    if G < 1 or index.min() < 0 or index.max() >= T:
+        raise ValueError('index must be a non-empty sequence of values in [0, T).')
+    L = np.asarray(propagators_liouville)
+    l_is_complex = np.iscomplexobj(L)
+    L = as_c128(L) if l_is_complex else as_f64(L)
+    if G > 1 and (L.shape[0] < G - 1 or L.shape[1:] != (N, N)):
+        raise ValueError(f'Expected propagators_liouville of shape ({G - 1}, {N}, {N}), not {L.shape}.')
+    L = np.ascontiguousarray(L[:max(G - 1, 0)])
+    out = np.empty((G, A, N, W) if which == 'correlations' else (A, N, W), dtype=np.complex128)
+    check(_lib.load().ffk_control_matrix_from_atomic_indexed(
+        ptr(tp), ptr(table), index.ctypes.data_as(ctypes.c_void_p), ptr(L) if G > 1 else None,
+        int(l_is_complex), T, G, A, N, W, int(which == 'correlations'), ptr(out)))
     return out
 
 

@@ -582,31 +582,51 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
         newpulse.cache_filter_function(omega, which=which)
         return newpulse
 
-    phases = np.array([pls.get_total_phases(omega) for pls in pulses[:-1]]).cumprod(axis=0)
-    propagators_liouville = util.adot(
-        np.array([pls.total_propagator_liouville for pls in pulses[:-1]]))
-    R_atomic = np.empty((len(pulses), len(newpulse.n_opers), len(newpulse.basis), len(omega)),
-                        dtype=complex)
+    # distinct pulse objects (a randomized-benchmarking sequence draws 1000 gates from 24
+    # Cliffords): evaluate / fetch each control matrix once
+    position = {}
+    index = np.array([position.setdefault(id(pls), len(position)) for pls in pulses], dtype=np.int32)
+    distinct = [None]*len(position)
+    for pls, k in zip(pulses, index):
+        distinct[k] = pls
     seg = np.concatenate(([0], np.cumsum([len(pls.dt) for pls in pulses])))
-    for i, (pls, here) in enumerate(zip(pulses, present)):
-        # rows of the pulse's own control matrix, in the new pulse's (sorted) operator order
+
+    def atomic_control_matrix(i):
+        """Control matrix of the pulse at position i in the new pulse's operator order."""
+        pls, here = pulses[i], present[i]
+        R = np.empty((len(newpulse.n_opers), len(newpulse.basis), len(omega)), dtype=complex)
         own_order = [list(pls.n_oper_identifiers).index(old)
                      for new in np.asarray(new_ids)[here]
                      for old, mapped in n_map[i].items() if mapped == new]
-        R_atomic[i, here] = pls.get_control_matrix(omega, show_progressbar)[own_order]
+        R[here] = pls.get_control_matrix(omega, show_progressbar)[own_order]
         if not here.all():
             # noise operators this pulse does not know: evaluate them on its control Hamiltonian
-            R_atomic[i, ~here] = numeric.calculate_control_matrix_from_scratch(
+            R[~here] = numeric.calculate_control_matrix_from_scratch(
                 pls.eigvals, pls.eigvecs, pls.propagators, omega, pls.basis,
                 newpulse.n_opers[~here], newpulse.n_coeffs[~here, seg[i]:seg[i + 1]], pls.dt,
                 t=pls.t)
+        return R
+
+    propagators_liouville = util.adot(
+        np.array([pls.total_propagator_liouville for pls in pulses[:-1]]))
     if not newpulse.is_cached('total_propagator'):
         newpulse.total_propagator = util.mdot([pls.total_propagator for pls in pulses][::-1])
     newpulse.cache_total_phases(omega)
     newpulse.total_propagator_liouville = liouville_representation(newpulse.total_propagator,
                                                                    newpulse.basis)
-    control_matrix = numeric.calculate_control_matrix_from_atomic(
-        phases, R_atomic, propagators_liouville,
-        which='correlations' if calc_pulse_correlation_FF else 'total')
+    mode = 'correlations' if calc_pulse_correlation_FF else 'total'
+    # the indexed kernel assumes a repeated pulse contributes the same rows everywhere, which
+    # holds when every pulse carries every noise operator (else fall back to the plain rule)
+    if len(distinct) < len(pulses) and present.all():
+        first_position = [int(np.nonzero(index == k)[0][0]) for k in range(len(distinct))]
+        table = np.array([atomic_control_matrix(i) for i in first_position])
+        total_phases = np.array([pls.get_total_phases(omega) for pls in distinct])
+        control_matrix = numeric.calculate_control_matrix_from_atomic_indexed(
+            total_phases, table, index, propagators_liouville, which=mode)
+    else:
+        phases = np.array([pls.get_total_phases(omega) for pls in pulses[:-1]]).cumprod(axis=0)
+        R_atomic = np.array([atomic_control_matrix(i) for i in range(len(pulses))])
+        control_matrix = numeric.calculate_control_matrix_from_atomic(
+            phases, R_atomic, propagators_liouville, which=mode)
     newpulse.cache_filter_function(omega, control_matrix, which=which)
     return newpulse

@@ -148,6 +148,25 @@ int ffk_control_matrix_from_atomic_dev(const double* phases, const double* contr
                                        int G, int A, int N, int W, int which, double* out,
                                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same rule for sequences drawn from T distinct pulses (pulse_sequence.concatenate called with
+ * repeated PulseSequence objects, e.g. examples/randomized_benchmarking.py:76-81):
+ * total_phases (T, W) c128 = exp(i omega tau) of every distinct pulse, control_matrix_table
+ * (T, A, N, W) c128, index (G,) int32 = which distinct pulse sits at position g.  The cumulated
+ * phases of pulse_sequence.py:1824 are formed in the kernel.                                   */
+int ffk_control_matrix_from_atomic_indexed(const double* total_phases,
+                                           const double* control_matrix_table,
+                                           const int32_t* index,
+                                           const double* propagators_liouville, int l_is_complex,
+                                           int T, int G, int A, int N, int W, int which,
+                                           double* out);
+int ffk_control_matrix_from_atomic_indexed_dev(const double* total_phases,
+                                               const double* control_matrix_table,
+                                               const int32_t* index,
+                                               const double* propagators_liouville,
+                                               int l_is_complex, int T, int G, int A, int N, int W,
+                                               int which, double* out, void* workspace,
+                                               size_t workspace_bytes, void* stream);
+
 /* ---- numeric.calculate_filter_function (numeric.py:1413-1467) --------------------------
  * control_matrix (A, N, W) c128 -> fidelity: (A, A, W) c128,
  *                                  generalized: (A, A, N, N, W) c128.                       */

@@ -477,3 +477,38 @@ def test_spin_echo_concatenation_is_cpmg():
     np.testing.assert_allclose((F*omega**2).real, analytic, atol=1e-9, rtol=1e-7)
     scratch = ff.concatenate_without_filter_function([se]*n).get_filter_function(omega)[0, 0]
     assert rel_err(F, scratch) < 1e-10
+
+
+def test_randomized_benchmarking_sequence_via_table():
+    """BASELINE config 3 in miniature (examples/randomized_benchmarking.py:95-151): a sequence
+    drawn from a few distinct gates takes the gather-from-table kernel; it must agree with the
+    plain concatenation rule on the materialised arrays and with the from-scratch evaluation."""
+    X, Y = util.paulis[1], util.paulis[2]
+    T = 20.0
+    omega = 2*np.pi*np.geomspace(1e-2/(7*151*T), 1e2/T, 300)
+    X2 = ff.PulseSequence([[X/2, [np.pi/2/T], 'X']], [[X/2, [1], 'X']], [T])
+    Y2 = ff.PulseSequence([[Y/2, [np.pi/2/T], 'Y']], [[X/2, [1], 'X']], [T])
+    for p in (X2, Y2):
+        p.cache_control_matrix(omega)
+    gates = [X2, Y2, X2 @ X2, Y2 @ X2, X2 @ Y2 @ Y2 @ Y2]
+    assert all(gate.is_cached('control_matrix') for gate in gates)
+    rng = np.random.default_rng(0)
+    draw = rng.integers(0, len(gates), 120)
+    seq = [gates[k] for k in draw]
+    total = ff.concatenate(seq)                                   # repeated objects -> table path
+    R = total.get_control_matrix(omega)
+    # plain rule on the materialised (G, A, N, W) array
+    phases = np.array([p.get_total_phases(omega) for p in seq[:-1]]).cumprod(axis=0)
+    L = util.adot(np.array([p.total_propagator_liouville for p in seq[:-1]]))
+    R_atomic = np.array([p.get_control_matrix(omega) for p in seq])
+    R_plain = numeric.calculate_control_matrix_from_atomic(phases, R_atomic, L)
+    assert rel_err(R, R_plain) < 1e-13
+    assert rel_err(R, orc.control_matrix_from_atomic(phases, R_atomic, L)) < 1e-13
+    scratch = ff.concatenate_without_filter_function(seq)
+    assert len(scratch) == sum(len(p) for p in seq)
+    assert rel_err(scratch.get_filter_function(omega), total.get_filter_function(omega)) < 1e-10
+    # 'correlations' through the table path as well
+    short = [gates[k] for k in draw[:7]]
+    pc = ff.concatenate(short, calc_pulse_correlation_FF=True)
+    assert rel_err(pc.get_pulse_correlation_control_matrix().sum(0),
+                   ff.concatenate(short).get_control_matrix(omega)) < 1e-13
