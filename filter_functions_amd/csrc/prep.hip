@@ -124,23 +124,32 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
     __shared__ cplx Q[D][D];
     __shared__ cplx T[D][D];
     __shared__ cplx BV[D][D];
+    constexpr int kBatch = 16;
+    __shared__ cplx tot[kBatch][D][D];
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     const int c = g / L;
     for (int e = lane; e < D*D; e += 64) E[0][e / D][e % D] = {(e / D == e % D) ? 1.0 : 0.0, 0.0};
     int b = 0;
-    for (int k = 0; k < c; ++k) {
-        for (int e = lane; e < D*D; e += 64) M[e / D][e % D] = totals[static_cast<size_t>(k)*D*D + e];
+    // exclusive prefix of the chunk totals; the totals are staged in batches of independent loads
+    // (one dependent global load per step cost ~0.5 us each)
+    for (int kb = 0; kb < c; kb += kBatch) {
+        const int nb = min(kBatch, c - kb);
         __syncthreads();
-        for (int e = lane; e < D*D; e += 64) {
-            const int i = e / D, j = e % D;
-            cplx acc = {0.0, 0.0};
+        for (int e = lane; e < nb*D*D; e += 64)
+            (&tot[0][0][0])[e] = totals[static_cast<size_t>(kb)*D*D + e];
+        __syncthreads();
+        for (int k = 0; k < nb; ++k) {
+            for (int e = lane; e < D*D; e += 64) {
+                const int i = e / D, j = e % D;
+                cplx acc = {0.0, 0.0};
 #pragma unroll
-            for (int x = 0; x < D; ++x) cmac(acc, M[i][x], E[b][x][j]);
-            E[b ^ 1][i][j] = acc;
+                for (int x = 0; x < D; ++x) cmac(acc, tot[k][i][x], E[b][x][j]);
+                E[b ^ 1][i][j] = acc;
+            }
+            __syncthreads();
+            b ^= 1;
         }
-        __syncthreads();
-        b ^= 1;
     }
     // Q[g] (into LDS) and Q[g+1] (to memory)
     for (int e = lane; e < D*D; e += 64) M[e / D][e % D] = Qloc[static_cast<size_t>(g + 1)*D*D + e];

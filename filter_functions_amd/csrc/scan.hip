@@ -31,12 +31,17 @@ __device__ __forceinline__ void matmul_lds(const cplx (*a)[D], const cplx (*b)[D
     }
 }
 
+// Chunk-local prefix products.  All segment propagators of the chunk are fetched into LDS by one
+// batch of independent loads first: with one global load per step, the serial chain paid an
+// exposed memory round trip (~0.5 us) per segment.
+constexpr int kScanBatch = 16;   // propagators staged per batch
+
 template <int D>
 __global__ __launch_bounds__(64) void scan_local_kernel(const cplx* __restrict__ P, int G, int L,
                                                         cplx* __restrict__ Q,
                                                         cplx* __restrict__ totals) {
     __shared__ cplx cur[2][D][D];
-    __shared__ cplx pg[D][D];
+    __shared__ cplx pg[kScanBatch][D][D];
     const int lane = threadIdx.x;
     const int c = blockIdx.x;
     const int g0 = c*L, g1 = min(G, g0 + L);
@@ -44,14 +49,19 @@ __global__ __launch_bounds__(64) void scan_local_kernel(const cplx* __restrict__
     if (c == 0)
         for (int e = lane; e < D*D; e += 64) Q[e] = {(e / D == e % D) ? 1.0 : 0.0, 0.0};
     int b = 0;
-    for (int g = g0; g < g1; ++g) {
-        for (int e = lane; e < D*D; e += 64) pg[e / D][e % D] = P[static_cast<size_t>(g)*D*D + e];
+    for (int gb = g0; gb < g1; gb += kScanBatch) {
+        const int nb = min(kScanBatch, g1 - gb);
         __syncthreads();
-        matmul_lds<D>(pg, cur[b], cur[b ^ 1], lane);
+        for (int e = lane; e < nb*D*D; e += 64)
+            (&pg[0][0][0])[e] = P[static_cast<size_t>(gb)*D*D + e];
         __syncthreads();
-        b ^= 1;
-        for (int e = lane; e < D*D; e += 64)
-            Q[static_cast<size_t>(g + 1)*D*D + e] = cur[b][e / D][e % D];
+        for (int s2 = 0; s2 < nb; ++s2) {
+            matmul_lds<D>(pg[s2], cur[b], cur[b ^ 1], lane);
+            __syncthreads();
+            b ^= 1;
+            for (int e = lane; e < D*D; e += 64)
+                Q[static_cast<size_t>(gb + s2 + 1)*D*D + e] = cur[b][e / D][e % D];
+        }
     }
     for (int e = lane; e < D*D; e += 64)
         totals[static_cast<size_t>(c)*D*D + e] = cur[b][e / D][e % D];

@@ -9,6 +9,8 @@ infidelity integral runs on the full grid exactly as in the single-GPU case (no 
 all-reduce, bit-identical arithmetic).  torch is plumbing here: device memory, the process
 group and the collective; all arithmetic is libffk's.
 """
+import os
+
 import numpy as np
 
 __all__ = ['shard_bounds', 'gather_omega_shards', 'sharded_filter_function']
@@ -34,8 +36,8 @@ def gather_omega_shards(local, n_omega, group=None):
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    if world == 1:
-        return local
+    if world == 1 and not os.environ.get('FFK_FORCE_COLLECTIVE'):   # test hook: run the
+        return local                                                 # collective on one rank too
     lead = local.shape[:-1]
     widths = [shard_bounds(n_omega, world, r)[1] - shard_bounds(n_omega, world, r)[0]
               for r in range(world)]
