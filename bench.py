@@ -127,28 +127,65 @@ def main():
     # identifiers sort the operators exactly as PulseSequence does
     pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
 
-    pipe = DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, basis,
-                          omega, spectrum=spectrum_full[w0:w1], device=device)
+    def make_pipe():
+        return DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, basis,
+                              omega, spectrum=spectrum_full[w0:w1], device=device)
+    # With sharding, the all-gather + infidelity of step i run on a second stream while step i+1
+    # computes (the steps are independent passes): two sets of buffers, ping-pong.
+    pipes = [make_pipe(), make_pipe()] if use_dist else [make_pipe()]
+    pipe = pipes[0]
     if use_dist:
         omega_full_dev = torch.from_numpy(omega_full).to(device)
         S_full_dev = torch.from_numpy(spectrum_full.astype(complex)).to(device)
         idx_dev = torch.arange(A, dtype=torch.int32, device=device)
+        comm_stream = torch.cuda.Stream(device=device)
+        free_events = [None, None]
+        # all-gather buffers (world, A, A, W_shard) and results, allocated once
+        gathered = [torch.empty((world, A, A, w1 - w0), dtype=torch.complex128, device=device)
+                    for _ in range(2)]
+        infid_out = [torch.empty(A, dtype=torch.float64, device=device) for _ in range(2)]
+        equal_shards = all(shard_bounds(W_total, world, r)[1] - shard_bounds(W_total, world, r)[0]
+                           == w1 - w0 for r in range(world))
 
-    stream = torch.cuda.current_stream(device).cuda_stream
+    compute_stream = torch.cuda.current_stream(device)
+    stream = compute_stream.cuda_stream
     n_ev = args.steps
     ev = [[ctypes.c_void_p(), ctypes.c_void_p()] for _ in range(n_ev)]
     for pair in ev:
         for e in pair:
             _lib.check(lib.ffk_event_create(ctypes.byref(e)))
+    counter = [0]
 
     def step(i=None):
         if i is not None:
             _lib.check(lib.ffk_set_accumulate_events(ev[i][0], ev[i][1]))
-        pipe.launch(stream=stream, with_infidelity=not use_dist)
-        if use_dist:
-            F_full = gather_omega_shards(pipe.filter_function, W_total)
-            return pipe.infidelity_from(F_full, omega_full_dev, S_full_dev, idx_dev, stream=stream)
-        return pipe.infid
+        if not use_dist:
+            pipe.launch(stream=stream, with_infidelity=True)
+            return pipe.infid
+        k = counter[0] % 2
+        counter[0] += 1
+        p = pipes[k]
+        if free_events[k] is not None:
+            compute_stream.wait_event(free_events[k])       # its F was consumed by the gather
+        p.launch(stream=stream, with_infidelity=False)
+        ready = torch.cuda.Event()
+        ready.record(compute_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready)
+            if equal_shards:
+                # one collective into a preallocated buffer; the integral reads the shards in place
+                dist.all_gather_into_tensor(torch.view_as_real(gathered[k]),
+                                            torch.view_as_real(p.filter_function))
+                out = p.infidelity_from_shards(gathered[k], omega_full_dev, S_full_dev, idx_dev,
+                                               infid_out[k], stream=comm_stream.cuda_stream)
+            else:
+                F_full = gather_omega_shards(p.filter_function, W_total)
+                out = p.infidelity_from(F_full, omega_full_dev, S_full_dev, idx_dev,
+                                        stream=comm_stream.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(comm_stream)
+            free_events[k] = done
+        return out
 
     for _ in range(args.warmup):
         step()

@@ -101,6 +101,8 @@ SIGNATURES = {
     'ffk_infidelity_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'ffk_infidelity_dev': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                                    c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ffk_infidelity_sharded_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                           c_void_p, c_int, c_int, c_void_p, c_void_p]),
     'ffk_liouville': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'ffk_liouville_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'ffk_liouville_dev': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,

@@ -737,7 +737,20 @@ int ffk_infidelity_dev(const double* filter_function, int A, int W, const double
     FFK_REQUIRE(workspace_bytes >= ffk_infidelity_workspace_bytes(W, n_idx, s_ndim), "workspace too small");
     FFK_HIP(ffk::launch_infidelity(reinterpret_cast<const cplx*>(filter_function), A, W,
                                    reinterpret_cast<const cplx*>(spectrum), s_ndim, omega, idx, n_idx,
-                                   d, infid, workspace, static_cast<hipStream_t>(stream)));
+                                   d, 0, infid, workspace, static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+int ffk_infidelity_sharded_dev(const double* filter_function_shards, int n_shards, int shard_width,
+                               int A, const double* spectrum, int s_ndim, const double* omega,
+                               const int32_t* idx, int n_idx, int d, double* infid, void* stream) {
+    FFK_REQUIRE(filter_function_shards && spectrum && omega && idx && infid, "NULL argument");
+    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
+    FFK_REQUIRE(n_shards >= 1 && shard_width >= 1 && A >= 1 && n_idx >= 1 && d >= 1, "empty axis");
+    FFK_HIP(ffk::launch_infidelity(reinterpret_cast<const cplx*>(filter_function_shards), A,
+                                   n_shards*shard_width, reinterpret_cast<const cplx*>(spectrum),
+                                   s_ndim, omega, idx, n_idx, d, shard_width, infid, nullptr,
+                                   static_cast<hipStream_t>(stream)));
     return FFK_OK;
 }
 

@@ -120,7 +120,7 @@ hipError_t launch_filter_function(const cplx* R, int A, int N, int W, int which,
 size_t infidelity_workspace_bytes(int W, int n_idx, int s_ndim);
 hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_ndim,
                              const double* omega, const int32_t* idx, int n_idx, int d,
-                             double* infid, void* ws, hipStream_t stream);
+                             int shard_width, double* infid, void* ws, hipStream_t stream);
 
 // ---- atomic.hip -----------------------------------------------------------------------------
 size_t from_atomic_workspace_bytes(int G, int A, int N, int W);

@@ -136,11 +136,14 @@ __global__ void ff_generalized_kernel(const cplx* __restrict__ R, int A, int N, 
 // (f[w+1] + f[w]) (omega[w+1] - omega[w])   (util.integrate, util.py:903-906, before the /2).
 // One block per output element p: the whole omega axis is reduced by 1024 threads in fixed order
 // (thread t sums intervals t, t+1024, ...; then a tree over the block): deterministic, one launch.
+// shard_width > 0: F is the raw all-gather buffer (n_shards, A, A, shard_width) of omega blocks
+// (one block per rank) instead of (A, A, W): global frequency w lives in shard w / shard_width.
 __global__ __launch_bounds__(1024) void infid_kernel(const cplx* __restrict__ F, int A, int W,
                                                      const cplx* __restrict__ S, int s_ndim,
                                                      const double* __restrict__ omega,
                                                      const int32_t* __restrict__ idx, int n_idx,
-                                                     int d, double* __restrict__ infid) {
+                                                     int d, int shard_width,
+                                                     double* __restrict__ infid) {
     __shared__ double red[1024];
     const int p = blockIdx.x;  // output element
     int ia, ib;
@@ -153,10 +156,16 @@ __global__ __launch_bounds__(1024) void infid_kernel(const cplx* __restrict__ F,
         ia = ib = idx[p];
         Sp = S + (s_ndim == 2 ? static_cast<size_t>(p)*W : 0);
     }
-    const cplx* Fp = F + (static_cast<size_t>(ia)*A + ib)*W;
+    auto Fat = [&](int w) -> cplx {
+        if (shard_width > 0) {
+            const int r = w / shard_width, wl = w - r*shard_width;
+            return F[((static_cast<size_t>(r)*A + ia)*A + ib)*shard_width + wl];
+        }
+        return F[(static_cast<size_t>(ia)*A + ib)*W + w];
+    };
     double acc = 0.0;
     for (int w = threadIdx.x; w < W - 1; w += 1024) {
-        const cplx f0 = Fp[w], f1 = Fp[w + 1], s0 = Sp[w], s1 = Sp[w + 1];
+        const cplx f0 = Fat(w), f1 = Fat(w + 1), s0 = Sp[w], s1 = Sp[w + 1];
         const double i0 = f0.re*s0.re - f0.im*s0.im;
         const double i1 = f1.re*s1.re - f1.im*s1.im;
         acc += (i1 + i0)*(omega[w + 1] - omega[w]);
@@ -240,11 +249,11 @@ size_t infidelity_workspace_bytes(int W, int n_idx, int s_ndim) {
 
 hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_ndim,
                              const double* omega, const int32_t* idx, int n_idx, int d,
-                             double* infid, void* ws, hipStream_t stream) {
+                             int shard_width, double* infid, void* ws, hipStream_t stream) {
     (void)ws;
     const int nout = s_ndim == 3 ? n_idx*n_idx : n_idx;
     hipLaunchKernelGGL(infid_kernel, dim3(nout), dim3(1024), 0, stream, F, A, W, S, s_ndim, omega,
-                       idx, n_idx, d, infid);
+                       idx, n_idx, d, shard_width, infid);
     return hipGetLastError();
 }
 

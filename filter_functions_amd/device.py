@@ -85,6 +85,16 @@ class DevicePipeline:
             p(self.control_matrix), p(self.filter_function), p(self.infid) if do_inf else None,
             p(self.workspace), self.ws_bytes, ctypes.c_void_p(s)))
 
+    def infidelity_from_shards(self, shards, omega, spectrum, idx, out, stream=None):
+        """Device trapezoid straight on an all-gather buffer (n_shards, A, A, shard_width);
+        *out* is a preallocated float64 tensor.  No allocation, no re-layout."""
+        s = self.torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        p = self._p
+        check(_lib.load().ffk_infidelity_sharded_dev(
+            p(shards), shards.shape[0], shards.shape[-1], shards.shape[1], p(spectrum),
+            spectrum.dim(), p(omega), p(idx), idx.numel(), self.d, p(out), ctypes.c_void_p(s)))
+        return out
+
     def infidelity_from(self, filter_function, omega, spectrum, idx, stream=None):
         """Device trapezoid on an arbitrary (gathered) F: tensors in, tensor out."""
         torch = self.torch

@@ -190,6 +190,13 @@ int ffk_infidelity_dev(const double* filter_function, int A, int W, const double
                        int s_ndim, const double* omega, const int32_t* idx, int n_idx, int d,
                        double* infid, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same integral on the raw buffer of an all-gather over omega blocks: filter_function_shards
+ * (n_shards, A, A, shard_width) c128, block r holding frequencies [r, r+1) * shard_width of the
+ * global grid omega (n_shards * shard_width,).  Saves the re-layout pass on the multi-GPU path. */
+int ffk_infidelity_sharded_dev(const double* filter_function_shards, int n_shards, int shard_width,
+                               int A, const double* spectrum, int s_ndim, const double* omega,
+                               const int32_t* idx, int n_idx, int d, double* infid, void* stream);
+
 /* ---- superoperator.liouville_representation (superoperator.py:51-84 + Basis.expand
  *      basis.py:350-371, 650-698) --------------------------------------------------------
  * U (batch, d, d) c128, basis (N, d, d) c128 -> liouville (batch, N, N):

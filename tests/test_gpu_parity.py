@@ -512,3 +512,36 @@ def test_randomized_benchmarking_sequence_via_table():
     pc = ff.concatenate(short, calc_pulse_correlation_FF=True)
     assert rel_err(pc.get_pulse_correlation_control_matrix().sum(0),
                    ff.concatenate(short).get_control_matrix(omega)) < 1e-13
+
+
+def test_logical_omega_shards_on_one_gpu():
+    """the N-way omega sharding executed as N logical shards on one
+    device equals the unsharded pass -- F blocks bit-identical, and the integral taken straight
+    on the all-gather layout (n_shards, A, A, W/n) equals the one on (A, A, W)."""
+    torch = pytest.importorskip('torch')
+    from filter_functions_amd.device import DevicePipeline
+    from filter_functions_amd.parallel import shard_bounds
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs(G=32, W=1024)
+    basis = ff.Basis.pauli(2)
+    S = 1e-3/omega
+    full = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum=S)
+    full.launch()
+    torch.cuda.synchronize()
+    F_full = full.filter_function.cpu().numpy()
+    infid_full = full.infid.cpu().numpy()
+    n = 4
+    shards = torch.empty((n, 3, 3, 1024//n), dtype=torch.complex128, device='cuda')
+    for r in range(n):
+        w0, w1 = shard_bounds(1024, n, r)
+        part = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega[w0:w1])
+        part.launch()
+        shards[r] = part.filter_function
+        assert np.array_equal(part.filter_function.cpu().numpy(), F_full[:, :, w0:w1])
+    dev = lambda a, ty: torch.from_numpy(np.ascontiguousarray(a, dtype=ty)).cuda()
+    out = torch.empty(3, dtype=torch.float64, device='cuda')
+    full.infidelity_from_shards(shards, dev(omega, float), dev(S, complex),
+                                torch.arange(3, dtype=torch.int32, device='cuda'), out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), infid_full)
+    ref = orc.infidelity_from_filter_function(F_full, S, omega, np.arange(3), 4)
+    assert rel_err(infid_full, ref) < 1e-13
