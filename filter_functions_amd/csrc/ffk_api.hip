@@ -396,13 +396,20 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     const size_t slab = size_t(A)*d*d*W;
     const bool want_B = (flags & FFK_WANT_NOISE_OPERATORS) != 0;
     const cplx* Bsum = Ypart;
+    bool compacted = false;
     if (geo.chunks > 1) {
-        FFK_HIP(ffk::launch_reduce_chunks(Ypart, geo.chunks, slab, Bt, s));
+        if (control_matrix) {
+            FFK_HIP(ffk::launch_reduce_and_compact(Ypart, geo.chunks, slab, Bt,
+                                                   reinterpret_cast<const cplx*>(basis), N, d, ews, s));
+            compacted = true;
+        } else {
+            FFK_HIP(ffk::launch_reduce_chunks(Ypart, geo.chunks, slab, Bt, s));
+        }
         Bsum = Bt;
     }
     if (control_matrix)
         FFK_HIP(ffk::launch_expand(Bsum, reinterpret_cast<const cplx*>(basis), A, N, d, W,
-                                   reinterpret_cast<cplx*>(control_matrix), ews, s));
+                                   reinterpret_cast<cplx*>(control_matrix), ews, compacted, s));
     if (want_B)
         FFK_HIP(ffk::launch_transpose_noise_ops(Bsum, A, d, W, reinterpret_cast<cplx*>(noise_operators), s));
 
@@ -550,7 +557,7 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
         // one chunk per segment: Ypart[g] is that segment's Hilbert-space step, expanded in the basis
         ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, G);
         FFK_HIP(ffk::launch_accumulate(dom, W, segtab, ops, G, d, A, geo, Ypart, nullptr));
-        FFK_HIP(ffk::launch_expand(Ypart, dbasis, G*A, N, d, W, dstep, dews, nullptr));
+        FFK_HIP(ffk::launch_expand(Ypart, dbasis, G*A, N, d, W, dstep, dews, false, nullptr));
     }
     if (n_opers_transformed) FFK_HIP(d2h(n_opers_transformed, dnt, 16*size_t(A)*G*dd));
     if (eigvecs_propagated) FFK_HIP(d2h(eigvecs_propagated, dep, 16*size_t(G)*dd));

@@ -110,8 +110,12 @@ hipError_t launch_reduce_chunks(const cplx* Ypart, int chunks, size_t slab, cplx
                                 hipStream_t stream);
 // R (A2,N,W) with R[a,k,w] = sum_ij Bt[a,i,j,w] C_k[j,i];  A2 = any leading batch
 size_t expand_workspace_bytes(int N, int d);
+// `compacted`: the basis lists in ws were already produced by launch_reduce_and_compact
 hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d, int W, cplx* R,
-                         void* ws, hipStream_t stream);
+                         void* ws, bool compacted, hipStream_t stream);
+// reduce_chunks + basis compaction in one launch
+hipError_t launch_reduce_and_compact(const cplx* Ypart, int chunks, size_t slab, cplx* Bt,
+                                     const cplx* basis, int N, int d, void* ws, hipStream_t stream);
 // out (W,A,d,d) from Bt (A,d,d,W)
 hipError_t launch_transpose_noise_ops(const cplx* Bt, int A, int d, int W, cplx* out,
                                       hipStream_t stream);

@@ -27,11 +27,10 @@ __global__ void reduce_chunks_kernel(const cplx* __restrict__ Ypart, int chunks,
 // the expansion only touches the non-zeros: d^3 instead of d^4 work per (a, w) for Pauli bases,
 // ~d^2 for GGM -- the same saving the reference gets from its closed-form ggm_expand
 // (basis.py:701-787), without special-casing the basis type.  Dense bases cost what they did.
-__global__ __launch_bounds__(64) void basis_compact_kernel(const cplx* __restrict__ basis, int d,
-                                                           int* __restrict__ nnz,
-                                                           int* __restrict__ rows,
-                                                           cplx* __restrict__ vals) {
-    const int k = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void basis_compact_one(const cplx* __restrict__ basis, int d, int k,
+                                                  int lane, int* __restrict__ nnz,
+                                                  int* __restrict__ rows,
+                                                  cplx* __restrict__ vals) {
     const int dd = d*d;
     const cplx* C = basis + static_cast<size_t>(k)*dd;
     int count = 0;
@@ -49,6 +48,39 @@ __global__ __launch_bounds__(64) void basis_compact_kernel(const cplx* __restric
         count += __popcll(mask);
     }
     if (lane == 0) nnz[k] = count;
+}
+
+__global__ __launch_bounds__(64) void basis_compact_kernel(const cplx* __restrict__ basis, int d,
+                                                           int* __restrict__ nnz,
+                                                           int* __restrict__ rows,
+                                                           cplx* __restrict__ vals) {
+    basis_compact_one(basis, d, blockIdx.x, threadIdx.x, nnz, rows, vals);
+}
+
+// Chunk reduction and basis compaction in ONE launch (they are independent and both precede the
+// expansion; every launch saved is ~4-5 us of the config-2 step): blocks [0, nred) reduce,
+// blocks [nred, nred + N) compact basis element k = blockIdx.x - nred with their first wavefront.
+__global__ __launch_bounds__(256) void reduce_compact_kernel(const cplx* __restrict__ Ypart,
+                                                             int chunks, size_t slab,
+                                                             cplx* __restrict__ Bt, int nred,
+                                                             const cplx* __restrict__ basis, int d,
+                                                             int* __restrict__ nnz,
+                                                             int* __restrict__ rows,
+                                                             cplx* __restrict__ vals) {
+    if (static_cast<int>(blockIdx.x) >= nred) {
+        if (threadIdx.x < 64)
+            basis_compact_one(basis, d, static_cast<int>(blockIdx.x) - nred, threadIdx.x, nnz, rows, vals);
+        return;
+    }
+    const size_t e = static_cast<size_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+    if (e >= slab) return;
+    cplx acc = Ypart[e];
+    for (int c = 1; c < chunks; ++c) {
+        const cplx v = Ypart[static_cast<size_t>(c)*slab + e];
+        acc.re += v.re;
+        acc.im += v.im;
+    }
+    Bt[e] = acc;
 }
 
 // one lane per omega; blockIdx.y = a; blockIdx.z = basis element group of KT
@@ -194,17 +226,45 @@ size_t expand_workspace_bytes(int N, int d) {
     return align_up(sizeof(int)*N) + align_up(sizeof(int)*N*dd) + align_up(sizeof(cplx)*N*dd);
 }
 
-hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d, int W, cplx* R,
-                         void* ws, hipStream_t stream) {
-    if (A2 > 65535) return hipErrorInvalidValue;
+namespace {
+struct CompactWs {
+    int* nnz;
+    int* rows;
+    cplx* vals;
+};
+CompactWs slice_compact_ws(void* ws, int N, int d) {
     const size_t dd = static_cast<size_t>(d)*d;
     unsigned char* p = static_cast<unsigned char*>(ws);
-    int* nnz = reinterpret_cast<int*>(p);
+    CompactWs out;
+    out.nnz = reinterpret_cast<int*>(p);
     p += align_up(sizeof(int)*N);
-    int* rows = reinterpret_cast<int*>(p);
+    out.rows = reinterpret_cast<int*>(p);
     p += align_up(sizeof(int)*N*dd);
-    cplx* vals = reinterpret_cast<cplx*>(p);
-    hipLaunchKernelGGL(basis_compact_kernel, dim3(N), dim3(64), 0, stream, basis, d, nnz, rows, vals);
+    out.vals = reinterpret_cast<cplx*>(p);
+    return out;
+}
+}  // namespace
+
+hipError_t launch_reduce_and_compact(const cplx* Ypart, int chunks, size_t slab, cplx* Bt,
+                                     const cplx* basis, int N, int d, void* ws, hipStream_t stream) {
+    const CompactWs c = slice_compact_ws(ws, N, d);
+    const int block = 256;
+    const int nred = static_cast<int>((slab + block - 1)/block);
+    hipLaunchKernelGGL(reduce_compact_kernel, dim3(nred + N), dim3(block), 0, stream, Ypart, chunks,
+                       slab, Bt, nred, basis, d, c.nnz, c.rows, c.vals);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d, int W, cplx* R,
+                         void* ws, bool compacted, hipStream_t stream) {
+    if (A2 > 65535) return hipErrorInvalidValue;
+    const size_t dd = static_cast<size_t>(d)*d;
+    const CompactWs cw = slice_compact_ws(ws, N, d);
+    int* nnz = cw.nnz;
+    int* rows = cw.rows;
+    cplx* vals = cw.vals;
+    if (!compacted)
+        hipLaunchKernelGGL(basis_compact_kernel, dim3(N), dim3(64), 0, stream, basis, d, nnz, rows, vals);
     // few basis elements per thread when the grid would otherwise be small
     const long blocks1 = static_cast<long>((W + 63)/64)*A2;
     if (blocks1*N <= 16384 || N <= 16) {
