@@ -35,6 +35,11 @@ namespace ffk {
 namespace {
 
 constexpr int kWaveKernelMaxD = 4;
+// in-block segment split (template GS of the block kernel): instantiated for small d only
+constexpr int kGsplit = 4;
+constexpr int kGsplitMaxD = 4;
+constexpr int kGsplitMaxNW = 4;
+bool g_use_gsplit = true;
 bool g_use_wave_kernel = false;   // tuning/testing: one-wave-per-block variant for d <= 4
 
 // MR = integral rows generated per LDS stage.  MR == D (one stage per segment, diagonal computed
@@ -81,14 +86,18 @@ struct EntryList {
     static constexpr Slots slots = make();
 };
 
-template <int D, int JB, int MR, int NBUF, int NW>
-__global__ __launch_bounds__(NW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kernel(
+// GS > 1: the block additionally splits ITS segment chunk over GS groups of NW waves ("sub-chunks",
+// each with its own LDS tiles, advancing in lock step) and adds their accumulators up through LDS
+// before writing: GS x fewer partial sums in HBM (16 chunks x 3.1 MB at config 2 cost ~9 us of
+// write tail here and as much again in the reduction kernel) at unchanged parallelism.
+template <int D, int JB, int MR, int NBUF, int NW, int GS>
+__global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, int na_blk,
     cplx* __restrict__ Ypart) {
     static_assert(MR == D || NBUF == 1, "row-blocked stages are single buffered");
+    static_assert(GS == 1 || (MR == D && NBUF == 2), "sub-chunks need the double-buffered layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    cplx* lds = reinterpret_cast<cplx*>(lds_raw);
     constexpr int S = seg_stride(D);
     constexpr int NJ = D / JB;
     constexpr int NSTAGE = (D + MR - 1)/MR;
@@ -96,8 +105,12 @@ __global__ __launch_bounds__(NW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kerne
     constexpr int TILE = MR*D*64;      // cplx per integral tile
 
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = GS == 1 ? 0 : wave_all / NW;      // sub-chunk of this wave
+    const int wave = GS == 1 ? wave_all : wave_all % NW;
+    const int tid = static_cast<int>(threadIdx.x) - sub*NW*64;   // thread index within the sub-chunk
     constexpr int nwaves = NW;
+    constexpr int nthreads = NW*64;
     const int task0 = blockIdx.y*nwaves;
     const int task = task0 + wave;
     const bool active = task < A*NJ;
@@ -106,10 +119,13 @@ __global__ __launch_bounds__(NW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kerne
     const int alpha0 = task0 / NJ;                    // first noise operator of this block
     const int n_alpha = min(na_blk, A - alpha0);      // operators staged by this block
     const int buf_stride = TILE + (1 + na_blk)*D*D;   // cplx per LDS buffer
+    const int sub_stride = NBUF*buf_stride + S;       // cplx per sub-chunk region (2 table rows = S cplx)
+    cplx* lds = reinterpret_cast<cplx*>(lds_raw) + static_cast<size_t>(sub)*sub_stride;
     const int iw = blockIdx.x*64 + lane;
     const double om = omega[iw < W ? iw : W - 1];
-    const int g0 = blockIdx.z*chunk_len;
-    const int g1 = min(G, g0 + chunk_len);
+    const int sub_len = (chunk_len + GS - 1)/GS;      // lock-step trip count of the block
+    const int g0 = blockIdx.z*chunk_len + sub*sub_len;
+    const int g1 = min(min(G, static_cast<int>(blockIdx.z + 1)*chunk_len), g0 + sub_len);
 
     cplx Y[D][JB];
 #pragma unroll
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(NW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kerne
         if (g < g1) {
             const cplx* src = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
             cplx* dst = reinterpret_cast<cplx*>(tabs + ((g - g0) & 1)*S);
-            for (int e = static_cast<int>(threadIdx.x); e < S/2; e += blockDim.x) dst[e] = src[e];
+            for (int e = tid; e < S/2; e += nthreads) dst[e] = src[e];
         }
     };
 
@@ -141,7 +157,7 @@ __global__ __launch_bounds__(NW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kerne
         const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g + 1)*S);
         const int n_ops = (1 + n_alpha)*D*D;
         const int n_tab = (g + 1 < g1) ? S/2 : 0;
-        const int e0 = static_cast<int>(threadIdx.x);
+        const int e0 = tid;
         if (stage == 0) {
             if (e0 < n_ops)
                 staged = src_ops[e0 < D*D ? e0 : e0 + alpha0*D*D];
@@ -195,14 +211,14 @@ __global__ __launch_bounds__(NW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kerne
         const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g + 1)*S);
         const int n_ops = (1 + n_alpha)*D*D;
         const int n_tab = (g + 1 < g1) ? S/2 : 0;
-        const int e0 = static_cast<int>(threadIdx.x);
+        const int e0 = tid;
         cplx* dst_ops = tile + TILE;
         cplx* dst_tab = reinterpret_cast<cplx*>(tabs + ((g + 1 - g0) & 1)*S);
         if (e0 < n_ops)
             dst_ops[e0] = staged;
         else if (e0 < n_ops + n_tab)
             dst_tab[e0 - n_ops] = staged;
-        for (int e = e0 + static_cast<int>(blockDim.x); e < n_ops + n_tab; e += blockDim.x) {
+        for (int e = e0 + nthreads; e < n_ops + n_tab; e += nthreads) {
             if (e < n_ops)
                 dst_ops[e] = src_ops[e < D*D ? e : e + alpha0*D*D];
             else
@@ -251,20 +267,26 @@ __global__ __launch_bounds__(NW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kerne
             park(g0, 0);
         }
         __syncthreads();
-        for (int g = g0; g < g1; ++g) {
-            const int buf = (g - g0) & 1;
+        // every wave of the block runs sub_len iterations (barriers must match); a sub-chunk that
+        // is shorter (last chunk) idles through the tail
+        const int trip = GS == 1 ? g1 - g0 : sub_len;
+        for (int it = 0; it < trip; ++it) {
+            const int g = g0 + it;
+            const int buf = it & 1;
 #if defined(FFK_ABLATE) && (FFK_ABLATE == 4 || FFK_ABLATE == 5)  /* diagnostic: contraction only */
-            if (active) phase_b(g, 0, buf);
+            if (active && g < g1) phase_b(g, 0, buf);
 #if FFK_ABLATE == 4
             __syncthreads();
 #endif
             continue;
 #endif
-            if (g + 1 < g1) phase_a(g + 1, 0, buf ^ 1);
+            if (g < g1) {
+                if (g + 1 < g1) phase_a(g + 1, 0, buf ^ 1);
 #if !(defined(FFK_ABLATE) && FFK_ABLATE == 3)  /* diagnostic build 3: no contraction */
-            if (active) phase_b(g, 0, buf);
+                if (active) phase_b(g, 0, buf);
 #endif
-            if (g + 1 < g1) park(g + 1, buf ^ 1);
+                if (g + 1 < g1) park(g + 1, buf ^ 1);
+            }
 #if !(defined(FFK_ABLATE) && FFK_ABLATE == 6)  /* diagnostic build 6: no barrier (wrong results) */
             __syncthreads();
 #endif
@@ -279,6 +301,36 @@ __global__ __launch_bounds__(NW*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_kerne
                 __syncthreads();
             }
         }
+    }
+
+    if constexpr (GS > 1) {
+        // tree reduction of the sub-chunks' accumulators through LDS (all tiles are dead now)
+        cplx* red = reinterpret_cast<cplx*>(lds_raw);
+        constexpr int YSZ = D*JB*64;   // cplx per wave
+#pragma unroll
+        for (int stride = GS/2; stride >= 1; stride >>= 1) {
+            if (sub >= stride && sub < 2*stride) {
+                cplx* dst = red + static_cast<size_t>((sub - stride)*NW + wave)*YSZ + lane;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) dst[(i*JB + j)*64] = Y[i][j];
+            }
+            __syncthreads();
+            if (sub < stride) {
+                const cplx* src = red + static_cast<size_t>(sub*NW + wave)*YSZ + lane;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < JB; ++j) {
+                        const cplx v = src[(i*JB + j)*64];
+                        Y[i][j].re += v.re;
+                        Y[i][j].im += v.im;
+                    }
+            }
+            __syncthreads();
+        }
+        if (sub != 0) return;
     }
 
     if (active && iw < W) {
@@ -440,13 +492,18 @@ hipError_t launch_dw(const double* omega, int W, const double* segtab, const cpl
     constexpr int JB = accum_jb(D);
     constexpr int MR = accum_mr(D);
     const dim3 grid((W + 63)/64, geo.task_groups, geo.chunks);
-    const dim3 block(NW*64);
+    const dim3 block(NW*geo.gsplit*64);
     if constexpr (MR == D) {
+        if constexpr (D <= kGsplitMaxD && NW <= kGsplitMaxNW) {
+            if (geo.nbuf == 2 && geo.gsplit == kGsplit)
+                return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 2, NW, kGsplit>, grid, block,
+                                     geo, stream, omega, W, segtab, ops, G, A, Ypart);
+        }
         if (geo.nbuf == 2)
-            return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 2, NW>, grid, block, geo,
+            return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 2, NW, 1>, grid, block, geo,
                                  stream, omega, W, segtab, ops, G, A, Ypart);
     }
-    return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 1, NW>, grid, block, geo, stream,
+    return launch_kernel(ctrl_accumulate_kernel<D, JB, MR, 1, NW, 1>, grid, block, geo, stream,
                          omega, W, segtab, ops, G, A, Ypart);
 }
 
@@ -495,7 +552,7 @@ int blocks_per_cu_dw(int nbuf, int lds_bytes) {
     hipError_t err;
     if constexpr (MR == D) {
         if (nbuf == 2) {
-            auto kern = ctrl_accumulate_kernel<D, JB, MR, 2, NW>;
+            auto kern = ctrl_accumulate_kernel<D, JB, MR, 2, NW, 1>;
             if (lds_bytes > 48*1024)
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -503,7 +560,7 @@ int blocks_per_cu_dw(int nbuf, int lds_bytes) {
             return err == hipSuccess ? n : 0;
         }
     }
-    auto kern = ctrl_accumulate_kernel<D, JB, MR, 1, NW>;
+    auto kern = ctrl_accumulate_kernel<D, JB, MR, 1, NW, 1>;
     if (lds_bytes > 48*1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -562,9 +619,11 @@ int device_cu_count() {
 }  // namespace
 
 void set_use_wave_kernel(bool on) { g_use_wave_kernel = on; }
+void set_use_gsplit(bool on) { g_use_gsplit = on; }
 
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks) {
     AccumGeometry geo;
+    geo.gsplit = 1;
     geo.wave_kernel = d <= kWaveKernelMaxD && g_use_wave_kernel;
     if (geo.wave_kernel) {
         // one wave per block, up to 3 noise operators per lane; blocks per CU = 4 (1 wave/SIMD)
@@ -606,6 +665,7 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     const size_t tabs = 2*static_cast<size_t>(seg_stride(d))*sizeof(double);
     geo.nbuf = (accum_mr(d) == d && 2*one + tabs <= 160*1024) ? 2 : 1;
     geo.lds_bytes = static_cast<int>(geo.nbuf*one + tabs);
+    geo.gsplit = 1;
     // Segment chunks.  Every block runs its whole chunk, so the launch is fastest when the grid is
     // a whole number of "rounds" of resident blocks (profiles/r01_a_chunk_sweep.txt: 16 chunks =
     // 1024 blocks = exactly one round beat 22 chunks by 25 %): pick the chunk count that fills
@@ -618,6 +678,15 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         chunks = static_cast<int>(std::max<long>(1, capacity / std::max<long>(1, tiles)));
         const int max_chunks = std::max(1, (G + 3)/4);  // keep >= 4 segments per chunk
         chunks = std::min(chunks, max_chunks);
+        // fold a factor kGsplit of the split into the block (same number of waves in flight,
+        // kGsplit x fewer partial sums) when the block stays within 16 waves and the LDS
+        if (g_use_gsplit && d <= kGsplitMaxD && nw <= kGsplitMaxNW && geo.nbuf == 2 &&
+            chunks >= kGsplit && chunks % kGsplit == 0 &&
+            static_cast<size_t>(kGsplit)*geo.lds_bytes <= 160*1024) {
+            geo.gsplit = kGsplit;
+            geo.lds_bytes *= kGsplit;
+            chunks /= kGsplit;
+        }
     }
     if (chunks > G) chunks = G;
     if (chunks < 1) chunks = 1;

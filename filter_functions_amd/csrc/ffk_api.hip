@@ -246,8 +246,9 @@ int ffk_set_segment_chunks(int chunks) {
     return FFK_OK;
 }
 int ffk_set_accumulate_variant(int variant) {
-    FFK_REQUIRE(variant == 0 || variant == 1, "variant must be 0 or 1");
+    FFK_REQUIRE(variant >= 0 && variant <= 2, "variant must be 0, 1 or 2");
     ffk::set_use_wave_kernel(variant == 1);
+    ffk::set_use_gsplit(variant != 2);
     return FFK_OK;
 }
 int ffk_set_accumulate_events(void* start, void* stop) {
@@ -420,7 +421,7 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     g_stats.grid_x = (W + 63)/64;
     g_stats.grid_y = geo.task_groups;
     g_stats.grid_z = geo.chunks;
-    g_stats.block = geo.nwaves*64;
+    g_stats.block = geo.nwaves*geo.gsplit*64;
     g_stats.lds_bytes = geo.lds_bytes;
     return FFK_OK;
 }

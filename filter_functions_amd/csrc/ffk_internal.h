@@ -96,8 +96,10 @@ struct AccumGeometry {
     int nbuf;
     int na_blk;       // noise operators whose Bbar one block stages in LDS
     bool wave_kernel; // small-d one-wave-per-block variant
+    int gsplit;       // sub-chunks per block (in-block segment split), 1 = none
 };
 void set_use_wave_kernel(bool on);
+void set_use_gsplit(bool on);
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks);
 // Ypart (chunks, A, d, d, W): partial Hilbert-space sums, omega fastest
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,

@@ -26,7 +26,7 @@ def main():
     ap.add_argument('--A', type=int, default=3)
     ap.add_argument('--W', type=int, default=4096)
     ap.add_argument('--reps', type=int, default=30)
-    ap.add_argument('--variant', type=int, default=0, help='0 default block kernel, 1 one-wave kernel (d <= 4)')
+    ap.add_argument('--variant', type=int, default=0, help='0 default, 1 one-wave kernel (d <= 4), 2 no in-block segment split')
     ap.add_argument('--chunks', type=int, nargs='*', default=[0, 4, 8, 11, 12, 16, 22, 32, 43, 64])
     args = ap.parse_args()
     d, G, A, W = args.d, args.G, args.A, args.W
