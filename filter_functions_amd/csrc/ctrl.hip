@@ -61,6 +61,13 @@ bool g_use_wave_kernel = false;   // tuning/testing: one-wave-per-block variant 
 #define FFK_ACCUM_WPE(D) ((D) <= 4 ? 3 : 2)
 #endif
 
+// every supported dimension; a tuning build may restrict the instantiations (-DFFK_ONLY_D=4)
+#ifdef FFK_ONLY_D
+#define FFK_ALL_D(X) X(FFK_ONLY_D)
+#else
+#define FFK_ALL_D(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#endif
+
 // Compile-time list of the integral entries (slots m*D + n) that wave WV of an NW-wave block
 // generates: every NW-th slot, the diagonal (all diagonal entries coincide) only as slot 0.
 template <int D, int NW, int WV>
@@ -592,9 +599,7 @@ int query_blocks_per_cu(int d, int nwaves, int nbuf, int lds_bytes) {
     case D:                                              \
         n = blocks_per_cu_d<D>(nwaves, nbuf, lds_bytes); \
         break;
-        FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
-        FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
-        FFK_CASE(15) FFK_CASE(16)
+        FFK_ALL_D(FFK_CASE)
 #undef FFK_CASE
         default:
             break;
@@ -702,9 +707,7 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
 #define FFK_CASE(D) \
     case D:         \
         return launch_d<D>(omega, W, segtab, ops, G, A, geo, Ypart, stream);
-        FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
-        FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
-        FFK_CASE(15) FFK_CASE(16)
+        FFK_ALL_D(FFK_CASE)
 #undef FFK_CASE
         default:
             return hipErrorInvalidValue;

@@ -70,6 +70,21 @@ FFK_HD void sincos_reduced(double r, double* s, double* c) {
     *c = w + (((1.0 - w) - hz) + z*z*pc);
 }
 
+// the same kernels cut to the terms that matter for |r| < 2^-5 (z < 2^-10: the dropped terms are
+// below 2^-60 relative)
+FFK_HD void sincos_small(double r, double* s, double* c) {
+    const double z = r*r;
+    double ps = fma(z, 2.75573137070700676789e-06, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    *s = fma(r*z, ps, r);
+    double pc = fma(z, 2.48015872894767294178e-05, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5*z;
+    const double w = 1.0 - hz;
+    *c = w + (((1.0 - w) - hz) + z*z*pc);
+}
+
 FFK_HD unsigned low_word(double t) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return static_cast<unsigned>(__double2loint(t));
@@ -160,7 +175,7 @@ FFK_HD cplx first_order_integral_aa(double omega, double dE, double dt, double s
     const double h = 0.5*(x*dt);
     double s = fma(sa, cb, ca*sb);
     double c = fma(ca, cb, -(sa*sb));
-    if (fabs(h) < 0.03125) sincos_pi(h, &s, &c);
+    if (fabs(h) < 0.03125) sincos_small(h, &s, &c);   // no range reduction needed here
     const double q = 2.0*s*rcp(x);
     cplx out = {q*c, q*s};
     if (x == 0.0) {

@@ -188,6 +188,29 @@ def test_device_math_on_host():
     ref[m] = util.cexpm1(x[m]*dt)/(1j*x[m])
     assert np.max(np.abs(got - ref)) < 5e-16
     assert got[0] == dt and got[3] == dt and got[4] == dt
+    # angle-addition form used by the accumulate kernel, including the near-resonance band where
+    # it switches to the direct small-angle evaluation (|h| < 2^-5) and the band's edge
+    om2 = np.concatenate([omega, 10.0**rng.uniform(-2, 3, 4000)])
+    gap = np.concatenate([[0.01, 0.03125/0.185, 0.0313/0.185, 1e-3, 1e-6, 1e-9, -1e-4],
+                          rng.standard_normal(2000)*0.2])
+    dE2 = np.concatenate([dE, -om2[dE.size:dE.size + gap.size] + gap,
+                          rng.standard_normal(om2.size - dE.size - gap.size)*3])
+    out2 = np.empty(2*om2.size)
+    lib.ffk_host_first_order_integral_aa(ctypes.c_long(om2.size), om2.ctypes.data_as(dp),
+                                         dE2.ctypes.data_as(dp), ctypes.c_double(dt),
+                                         out2.ctypes.data_as(dp))
+    got2 = out2[0::2] + 1j*out2[1::2]
+    x2 = om2 + dE2
+    ref2 = np.full(x2.shape, dt, dtype=complex)
+    m2 = x2 != 0
+    ref2[m2] = util.cexpm1(x2[m2]*dt)/(1j*x2[m2])
+    # the half-angle a + b differs from the reference's fl(fl(w + dE) dt)/2 by a few ulp of
+    # (|w| + |dE|) dt; inside the band the evaluation is direct (relative error of a few ulp)
+    eps = np.finfo(float).eps
+    tol = 64*eps*np.abs(ref2) + 8*eps*(np.abs(om2) + np.abs(dE2))*dt*dt
+    assert np.all(np.abs(got2 - ref2) <= tol)
+    band = np.abs(0.5*x2*dt) < 0.03
+    assert band.sum() > 1000 and np.all(np.abs(got2 - ref2)[band] <= 8*eps*np.abs(ref2[band]))
 
 
 def test_concatenation_bookkeeping():
