@@ -125,8 +125,15 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
     const int jb = active ? task % NJ : 0;
     const int alpha0 = task0 / NJ;                    // first noise operator of this block
     const int n_alpha = min(na_blk, A - alpha0);      // operators staged by this block
+    // SHARE: the per-segment trigonometry every entry needs -- e^{i w t_g} and sin/cos of
+    // a = fl(w dt_g)/2 -- is computed ONCE per sub-chunk (by two designated waves, one segment
+    // ahead of the integral generation, handed over through LDS) instead of by every wave: two
+    // range-reduced sincos less on the critical path of each wave and segment.
+    constexpr bool SHARE = (MR == D && NBUF == 2);
+    constexpr int NTAB = SHARE ? 3 : 2;               // table rows resident in LDS
+    constexpr int TRIG = SHARE ? 2*2*64 : 0;          // cplx: [2 slots][phase | (sin a, cos a)][lane]
     const int buf_stride = TILE + (1 + na_blk)*D*D;   // cplx per LDS buffer
-    const int sub_stride = NBUF*buf_stride + S;       // cplx per sub-chunk region (2 table rows = S cplx)
+    const int sub_stride = NBUF*buf_stride + NTAB*S/2 + TRIG;   // cplx per sub-chunk region
     cplx* lds = reinterpret_cast<cplx*>(lds_raw) + static_cast<size_t>(sub)*sub_stride;
     const int iw = blockIdx.x*64 + lane;
     const double om = omega[iw < W ? iw : W - 1];
@@ -140,30 +147,51 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
 #pragma unroll
         for (int j = 0; j < JB; ++j) Y[i][j] = {0.0, 0.0};
 
-    // LDS: [NBUF x (integral tile | operands)] [2 x table row].  The table row of segment g is
-    // staged one segment ahead (slot (g - g0) & 1), so that nothing in phase A waits on global or
-    // scalar memory: an earlier version fetched (dE, sin b, cos b) per entry from memory and spent
-    // ~60 % of phase A in those round trips (profiles/r01_c_*).
+    // LDS: [NBUF x (integral tile | operands)] [NTAB x table row] [shared trigonometry].  Table
+    // rows are staged ahead of their use (slot = segment offset mod NTAB), so that nothing in
+    // phase A waits on global or scalar memory: an earlier version fetched (dE, sin b, cos b) per
+    // entry from memory and spent ~60 % of phase A in those round trips (profiles/r01_c_*).
     double* tabs = reinterpret_cast<double*>(lds + static_cast<size_t>(NBUF)*buf_stride);
-    auto stage_table = [&](int g) {   // all threads: global -> LDS copy of one table row
+    cplx* trig = reinterpret_cast<cplx*>(tabs + NTAB*S);
+    constexpr int AHEAD = NTAB - 1;    // rows are fetched this many segments ahead
+    auto stage_table = [&](int g, int slot) {   // all threads: global -> LDS copy of one table row
         if (g < g1) {
             const cplx* src = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
-            cplx* dst = reinterpret_cast<cplx*>(tabs + ((g - g0) & 1)*S);
+            cplx* dst = reinterpret_cast<cplx*>(tabs + slot*S);
             for (int e = tid; e < S/2; e += nthreads) dst[e] = src[e];
+        }
+    };
+    // designated waves: trigonometry of the segment whose table row sits in `row_slot`
+    constexpr int WAVE_P = NW - 1;
+    constexpr int WAVE_S = NW >= 2 ? NW - 2 : 0;
+    auto share_trig = [&](int row_slot, int trig_slot) {
+        const double* st = tabs + row_slot*S;
+        // (constants pinned to the point of use: hoisted out of the segment loop they would
+        // occupy ~34 VGPRs across the contraction)
+        if (wave == WAVE_P) {
+            cplx ph;
+            sincos_pi<true>(om*st[1], &ph.im, &ph.re);
+            trig[trig_slot*128 + lane] = ph;
+        }
+        if (wave == WAVE_S) {
+            double sa, ca;
+            sincos_pi<true>(0.5*(om*st[0]), &sa, &ca);
+            trig[trig_slot*128 + 64 + lane] = {sa, ca};
         }
     };
 
     // Phase A: this wave's share of e^{i w t_g} I^(g)[rows of stage][:] -> LDS, plus (stage 0)
-    // the segment's operands T_g, Bbar_{alpha0..}^(g) and the NEXT segment's table row -> LDS.
+    // the segment's operands T_g, Bbar_{alpha0..}^(g) and the table row of segment g + AHEAD -> LDS.
     cplx staged = {0.0, 0.0};   // this thread's share of the staging copy, in flight across phase B
-    auto phase_a = [&](int g, int stage, int buf) {
-        const double* st = tabs + ((g - g0) & 1)*S;          // LDS
+    auto phase_a = [&](int g, int stage, int buf, int row_slot, int trig_slot) {
+        const double* st = tabs + row_slot*S;                // LDS
         cplx* tile = lds + static_cast<size_t>(buf)*buf_stride;
         // staging copies: issue the global loads first, park them after the integral is done
         const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*D*D;
-        const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g + 1)*S);
+        const cplx* src_tab =
+            reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g + AHEAD)*S);
         const int n_ops = (1 + n_alpha)*D*D;
-        const int n_tab = (g + 1 < g1) ? S/2 : 0;
+        const int n_tab = (g + AHEAD < g1) ? S/2 : 0;
         const int e0 = tid;
         if (stage == 0) {
             if (e0 < n_ops)
@@ -172,12 +200,21 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
                 staged = src_tab[e0 - n_ops];
         }
         const double dtg = st[0];
-        const cplx ph = cexp(om*st[1]);
-        // half-angle of the diagonal entry, a = fl(w dt)/2: every off-diagonal entry follows
-        // from (sin a, cos a) and the segment's precomputed (sin b, cos b) by angle addition
-        // (dE = 0, sin b = 0, cos b = 1 on the diagonal and for exactly degenerate levels)
+        // e^{i w t_g}, and the half-angle of the diagonal entry, a = fl(w dt)/2: every
+        // off-diagonal entry follows from (sin a, cos a) and the segment's precomputed
+        // (sin b, cos b) by angle addition (dE = 0, sin b = 0, cos b = 1 on the diagonal and for
+        // exactly degenerate levels)
+        cplx ph;
         double sa, ca;
-        sincos_pi(0.5*(om*dtg), &sa, &ca);
+        if constexpr (SHARE) {
+            ph = trig[trig_slot*128 + lane];
+            const cplx sc = trig[trig_slot*128 + 64 + lane];
+            sa = sc.re;
+            ca = sc.im;
+        } else {
+            ph = cexp(om*st[1]);
+            sincos_pi(0.5*(om*dtg), &sa, &ca);
+        }
         cplx* dst = tile + lane;
         auto gen = [&](int slot, int e) {   // slot: LDS slot, e: matrix entry m*D + n
             const double* r = st + seg_rec(e);
@@ -211,16 +248,17 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
         }
     };
     // second half of the staging copy: park the loaded values in LDS (after phase B, so that the
-    // global-load latency hides behind the contraction)
-    auto park = [&](int g, int buf) {
+    // global-load latency hides behind the contraction); `next_slot` receives row g + AHEAD
+    auto park = [&](int g, int buf, int next_slot) {
         cplx* tile = lds + static_cast<size_t>(buf)*buf_stride;
         const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*D*D;
-        const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g + 1)*S);
+        const cplx* src_tab =
+            reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g + AHEAD)*S);
         const int n_ops = (1 + n_alpha)*D*D;
-        const int n_tab = (g + 1 < g1) ? S/2 : 0;
+        const int n_tab = (g + AHEAD < g1) ? S/2 : 0;
         const int e0 = tid;
         cplx* dst_ops = tile + TILE;
-        cplx* dst_tab = reinterpret_cast<cplx*>(tabs + ((g + 1 - g0) & 1)*S);
+        cplx* dst_tab = reinterpret_cast<cplx*>(tabs + next_slot*S);
         if (e0 < n_ops)
             dst_ops[e0] = staged;
         else if (e0 < n_ops + n_tab)
@@ -266,20 +304,32 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
         }
     };
 
-    stage_table(g0);
-    __syncthreads();
-    if (NBUF == 2) {
+    if constexpr (SHARE) {
+        // Software pipeline over the segments g = g0 + it of the sub-chunk; in iteration it:
+        //   table row g+3 and operands g+1 : global -> registers (parked in LDS at the end),
+        //   trigonometry of g+2            : designated waves -> LDS,
+        //   integrals of g+1               : all waves -> LDS tile (buf ^ 1),
+        //   contraction of g               : from LDS tile (buf).
+        // Row slots rotate mod 3, trigonometry slots and tiles mod 2; one barrier per segment.
+        stage_table(g0, 0);
+        stage_table(g0 + 1, 1);
+        __syncthreads();
+        if (g0 < g1) share_trig(0, 0);
+        __syncthreads();
         if (g0 < g1) {
-            phase_a(g0, 0, 0);
-            park(g0, 0);
+            phase_a(g0, 0, 0, 0, 0);
+            if (g0 + 1 < g1) share_trig(1, 1);
+            park(g0, 0, 2);
         }
         __syncthreads();
         // every wave of the block runs sub_len iterations (barriers must match); a sub-chunk that
         // is shorter (last chunk) idles through the tail
         const int trip = GS == 1 ? g1 - g0 : sub_len;
+        int r0 = 0;   // it mod 3
         for (int it = 0; it < trip; ++it) {
             const int g = g0 + it;
             const int buf = it & 1;
+            const int r1 = r0 == 2 ? 0 : r0 + 1, r2 = r1 == 2 ? 0 : r1 + 1;
 #if defined(FFK_ABLATE) && (FFK_ABLATE == 4 || FFK_ABLATE == 5)  /* diagnostic: contraction only */
             if (active && g < g1) phase_b(g, 0, buf);
 #if FFK_ABLATE == 4
@@ -288,21 +338,28 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
             continue;
 #endif
             if (g < g1) {
-                if (g + 1 < g1) phase_a(g + 1, 0, buf ^ 1);
+                if (g + 1 < g1) {
+                    phase_a(g + 1, 0, buf ^ 1, r1, buf ^ 1);
+                    if (g + 2 < g1) share_trig(r2, buf);
+                }
 #if !(defined(FFK_ABLATE) && FFK_ABLATE == 3)  /* diagnostic build 3: no contraction */
                 if (active) phase_b(g, 0, buf);
 #endif
-                if (g + 1 < g1) park(g + 1, buf ^ 1);
+                if (g + 1 < g1) park(g + 1, buf ^ 1, r0);
             }
 #if !(defined(FFK_ABLATE) && FFK_ABLATE == 6)  /* diagnostic build 6: no barrier (wrong results) */
             __syncthreads();
 #endif
+            r0 = r1;
         }
     } else {
+        stage_table(g0, 0);
+        __syncthreads();
         for (int g = g0; g < g1; ++g) {
+            const int slot = (g - g0) & 1;
             for (int stage = 0; stage < NSTAGE; ++stage) {
-                phase_a(g, stage, 0);
-                if (stage == 0) park(g, 0);
+                phase_a(g, stage, 0, slot, 0);
+                if (stage == 0) park(g, 0, slot ^ 1);
                 __syncthreads();
                 if (active) phase_b(g, stage, 0);
                 __syncthreads();
@@ -667,9 +724,11 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     const int nj = d / jb;
     geo.na_blk = ntasks <= nw ? A : std::min(A, (nw - 1)/nj + 2);
     const size_t one = (static_cast<size_t>(accum_mr(d))*d*64 + static_cast<size_t>(1 + geo.na_blk)*d*d)*sizeof(cplx);
-    const size_t tabs = 2*static_cast<size_t>(seg_stride(d))*sizeof(double);
-    geo.nbuf = (accum_mr(d) == d && 2*one + tabs <= 160*1024) ? 2 : 1;
-    geo.lds_bytes = static_cast<int>(geo.nbuf*one + tabs);
+    // table rows + (double-buffered kernels) the shared trigonometry, see the kernel's LDS layout
+    const size_t row = static_cast<size_t>(seg_stride(d))*sizeof(double);
+    const size_t tabs2 = 3*row + 2*2*64*sizeof(cplx);
+    geo.nbuf = (accum_mr(d) == d && 2*one + tabs2 <= 160*1024) ? 2 : 1;
+    geo.lds_bytes = static_cast<int>(geo.nbuf == 2 ? 2*one + tabs2 : one + 2*row);
     geo.gsplit = 1;
     // Segment chunks.  Every block runs its whole chunk, so the launch is fastest when the grid is
     // a whole number of "rounds" of resident blocks (profiles/r01_a_chunk_sweep.txt: 16 chunks =

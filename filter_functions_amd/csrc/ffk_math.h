@@ -50,21 +50,39 @@ FFK_HD void cmac_conj(cplx& acc, cplx a, cplx b) {
 // round-to-nearest and the quadrant come from the 1.5*2^52 "magic number" addition: the low
 // mantissa bits of t hold the integer k.  NaN/Inf give NaN.
 // ---------------------------------------------------------------------------------------
+// FFK_PIN(c): the constant is materialised (two v_mov_b32) where it is used.  Inside a loop the
+// compiler otherwise hoists every polynomial coefficient into a register that stays live across
+// the whole loop body; the accumulate kernel (ctrl.hip) cannot afford those ~34 VGPRs across its
+// contraction phase.
+template <unsigned long long BITS>
+FFK_HD double pinned_bits() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned lo, hi;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lo) : "n"(static_cast<unsigned>(BITS & 0xffffffffull)));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(hi) : "n"(static_cast<unsigned>(BITS >> 32)));
+    return __hiloint2double(static_cast<int>(hi), static_cast<int>(lo));
+#else
+    return __builtin_bit_cast(double, BITS);
+#endif
+}
+#define FFK_PIN(c) (PIN ? pinned_bits<__builtin_bit_cast(unsigned long long, static_cast<double>(c))>() : (c))
+
+template <bool PIN = false>
 FFK_HD void sincos_reduced(double r, double* s, double* c) {
     const double z = r*r;
     // sin
-    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = fma(z, ps, 2.75573137070700676789e-06);
-    ps = fma(z, ps, -1.98412698298579493134e-04);
-    ps = fma(z, ps, 8.33333333332248946124e-03);
-    ps = fma(z, ps, -1.66666666666666324348e-01);
+    double ps = fma(z, FFK_PIN(1.58969099521155010221e-10), FFK_PIN(-2.50507602534068634195e-08));
+    ps = fma(z, ps, FFK_PIN(2.75573137070700676789e-06));
+    ps = fma(z, ps, FFK_PIN(-1.98412698298579493134e-04));
+    ps = fma(z, ps, FFK_PIN(8.33333333332248946124e-03));
+    ps = fma(z, ps, FFK_PIN(-1.66666666666666324348e-01));
     *s = fma(r*z, ps, r);
     // cos
-    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = fma(z, pc, -2.75573143513906633035e-07);
-    pc = fma(z, pc, 2.48015872894767294178e-05);
-    pc = fma(z, pc, -1.38888888888741095749e-03);
-    pc = fma(z, pc, 4.16666666666666019037e-02);
+    double pc = fma(z, FFK_PIN(-1.13596475577881948265e-11), FFK_PIN(2.08757232129817482790e-09));
+    pc = fma(z, pc, FFK_PIN(-2.75573143513906633035e-07));
+    pc = fma(z, pc, FFK_PIN(2.48015872894767294178e-05));
+    pc = fma(z, pc, FFK_PIN(-1.38888888888741095749e-03));
+    pc = fma(z, pc, FFK_PIN(4.16666666666666019037e-02));
     const double hz = 0.5*z;
     const double w = 1.0 - hz;
     *c = w + (((1.0 - w) - hz) + z*z*pc);
@@ -72,14 +90,15 @@ FFK_HD void sincos_reduced(double r, double* s, double* c) {
 
 // the same kernels cut to the terms that matter for |r| < 2^-5 (z < 2^-10: the dropped terms are
 // below 2^-60 relative)
+template <bool PIN = false>
 FFK_HD void sincos_small(double r, double* s, double* c) {
     const double z = r*r;
-    double ps = fma(z, 2.75573137070700676789e-06, -1.98412698298579493134e-04);
-    ps = fma(z, ps, 8.33333333332248946124e-03);
-    ps = fma(z, ps, -1.66666666666666324348e-01);
+    double ps = fma(z, FFK_PIN(2.75573137070700676789e-06), FFK_PIN(-1.98412698298579493134e-04));
+    ps = fma(z, ps, FFK_PIN(8.33333333332248946124e-03));
+    ps = fma(z, ps, FFK_PIN(-1.66666666666666324348e-01));
     *s = fma(r*z, ps, r);
-    double pc = fma(z, 2.48015872894767294178e-05, -1.38888888888741095749e-03);
-    pc = fma(z, pc, 4.16666666666666019037e-02);
+    double pc = fma(z, FFK_PIN(2.48015872894767294178e-05), FFK_PIN(-1.38888888888741095749e-03));
+    pc = fma(z, pc, FFK_PIN(4.16666666666666019037e-02));
     const double hz = 0.5*z;
     const double w = 1.0 - hz;
     *c = w + (((1.0 - w) - hz) + z*z*pc);
@@ -95,21 +114,24 @@ FFK_HD unsigned low_word(double t) {
 #endif
 }
 
+template <bool PIN = false>
 FFK_HD void sincos_pi(double x, double* s, double* c) {
-    const double kMagic = 6755399441055744.0;                     // 1.5 * 2^52
-    const double t = fma(x, 6.36619772367581382433e-01, kMagic);  // x * 2/pi, rounded to integer
+    const double kMagic = FFK_PIN(6755399441055744.0);                     // 1.5 * 2^52
+    const double t = fma(x, FFK_PIN(6.36619772367581382433e-01), kMagic);  // x * 2/pi, rounded to integer
     const unsigned q = low_word(t);
     const double k = t - kMagic;
-    double r = fma(-k, 1.57079632679489655800e+00, x);            // pi/2 high
-    r = fma(-k, 6.12323399573676603587e-17, r);                   // pi/2 mid
-    r = fma(-k, -1.49738490485916983294e-33, r);                  // pi/2 low
+    double r = fma(-k, FFK_PIN(1.57079632679489655800e+00), x);            // pi/2 high
+    r = fma(-k, FFK_PIN(6.12323399573676603587e-17), r);                   // pi/2 mid
+    r = fma(-k, FFK_PIN(-1.49738490485916983294e-33), r);                  // pi/2 low
     double sr, cr;
-    sincos_reduced(r, &sr, &cr);
+    sincos_reduced<PIN>(r, &sr, &cr);
     const double s0 = (q & 1u) ? cr : sr;
     const double c0 = (q & 1u) ? sr : cr;
     *s = (q & 2u) ? -s0 : s0;
     *c = ((q + 1u) & 2u) ? -c0 : c0;
 }
+
+#undef FFK_PIN
 
 // Reciprocal to ~1 ulp.  Device: v_rcp_f64 seed + two Newton steps; host: plain division.
 FFK_HD double rcp(double x) {
@@ -175,7 +197,7 @@ FFK_HD cplx first_order_integral_aa(double omega, double dE, double dt, double s
     const double h = 0.5*(x*dt);
     double s = fma(sa, cb, ca*sb);
     double c = fma(ca, cb, -(sa*sb));
-    if (fabs(h) < 0.03125) sincos_small(h, &s, &c);   // no range reduction needed here
+    if (fabs(h) < 0.03125) sincos_small<true>(h, &s, &c);   // no range reduction needed here
     const double q = 2.0*s*rcp(x);
     cplx out = {q*c, q*s};
     if (x == 0.0) {
