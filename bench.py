@@ -225,6 +225,19 @@ def main():
         E_step = G*W_total*A*d*d
         value = E_step*args.steps/elapsed
         achieved = stats['accumulate_flops']/(acc_ms*1e-3)/1e12
+        # HBM traffic of the same kernel: PMC counters cannot be read from inside this process,
+        # so the figure is the committed rocprofv3 --pmc measurement of this very command
+        # (profiles/k3_hbm_traffic.json; per launch, 2*FETCH_SIZE + WRITE_SIZE as the MI355X guide
+        # prescribes for gfx950); null when the launch geometry differs from the profiled one
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                                   'k3_hbm_traffic.json')) as fh:
+                prof = json.load(fh)
+            if prof['geometry'] == [stats[k] for k in ('grid_x', 'grid_y', 'grid_z', 'block')]:
+                traffic, traffic_src = prof['traffic_bytes'], prof['source']
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             'metric': 'filter-function elements/sec (n_seg*n_omega*n_nops*d^2) at d=4',
             'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps,
@@ -237,9 +250,9 @@ def main():
                                    'matrix + filter function + infidelity, HBM-resident',
                        'sharding': 'omega blocks, RCCL all-gather of F' if use_dist else 'none'},
             'roofline': {
-                'kernel': 'ffk::ctrl_accumulate_kernel<4,4,4,2>', 'bound': 'mfma',
+                'kernel': 'ffk::ctrl_accumulate_kernel<4,4,4,2,3,4>', 'bound': 'mfma',
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': None,
+                'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'avg_launch_ms': acc_ms, 'flops_per_launch': stats['accumulate_flops'],
                 'note': 'FP64 compute bound (vector = matrix peak 78.6 TFLOP/s on MI355X); '
                         'flops = FMA-counted flops of the Hilbert-space algorithm actually run',
