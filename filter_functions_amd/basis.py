@@ -85,7 +85,7 @@ class Basis(np.ndarray):
 
     def _invalidate_cached_properties(self):
         for attr in ('isherm', 'isnorm', 'isorthogonal', 'isorthonorm', 'istraceless',
-                     'iscomplete'):
+                     'iscomplete', 'four_element_traces'):
             self.__dict__.pop(attr, None)
 
     @cached_property
@@ -129,6 +129,20 @@ class Basis(np.ndarray):
     def iscomplete(self):
         flat = self.view(np.ndarray).reshape(len(self), -1)
         return bool(np.linalg.matrix_rank(flat) == self.d**2)
+
+    @cached_property
+    def four_element_traces(self):
+        """``T_ijkl = tr(C_i C_j C_k C_l)`` (reference basis.py:330-348) as a dense array.  The
+        device code never forms this ``N**4`` tensor (see ``numeric.calculate_cumulant_function``);
+        the property exists for user code and is limited to small bases."""
+        arr = self.view(np.ndarray)
+        if arr.ndim != 3:
+            raise ValueError('four_element_traces needs a basis of shape (N, d, d).')
+        if 16*float(len(arr))**4 > 2**31:
+            raise MemoryError(f'four_element_traces of {len(arr)} elements would need '
+                              f'{16*float(len(arr))**4/2**30:.0f} GiB as a dense array.')
+        pair = np.einsum('iab,jbc->ijac', arr, arr)
+        return np.einsum('ijac,klca->ijkl', pair, pair)
 
     @property
     def H(self):

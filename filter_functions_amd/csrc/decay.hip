@@ -1,0 +1,361 @@
+// decay.hip -- K7: decay amplitudes and cumulant function.
+//
+// Decay amplitudes, numeric.calculate_decay_amplitudes (filter_functions/numeric.py:1194-1337)
+// with the 'generalized' integrand of _get_integrand (:310-374) and util.integrate (util.py:880-906):
+//     Gamma[g,h,a,b,k,l] = int dw/2pi  Re( R*[g,a,k,w] S_ab(w) R[h,b,l,w] ).
+// The reference materialises the (A, d^2, d^2, W) integrand and integrates it; here the integral
+// IS a matrix product over the frequency axis.  Viewing a complex row R[a,k,:] as 2W interleaved
+// reals, Re(x* y) summed over w is the plain dot product of the two real rows, so
+//     Gamma_ab = Lreal (d^2 x 2W)  .  ((w S_ab/2pi) o R_b)real^T (2W x d^2),
+// w = trapezoid weights: a real FP64 GEMM with K = 2W on v_mfma_f64_16x16x4_f64.  Each lane
+// fetches 4 consecutive frequencies (64 contiguous bytes) of its row; the k index of an MFMA is
+// free to permute as long as both operands agree, so no transposition or LDS staging is needed.
+// The frequency axis is split over blocks (split-K) and reduced in fixed order.
+//
+// Cumulant function, numeric.calculate_cumulant_function (:957-1191, first order):
+//     K_ij = -1/2 sum_kl Gamma_kl (T_klji - T_kjli - T_kilj + T_kijl),  T = 4-element traces,
+// evaluated without the N^4 trace tensor: with D_k = sum_l Gamma_kl C_l the cumulant
+// superoperator is  K(X) = -1/2 sum_k (C_k D_k X - C_k X D_k - D_k X C_k + X D_k C_k)  and
+// K_ij = tr(C_i K(C_j)): four small complex GEMMs (O(d^6)) per noise-operator pair.
+#include "ffk_internal.h"
+
+namespace ffk {
+namespace {
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+// scale[row][w] = trapezoid weight(w) * S_row(w) / (2 pi)
+__global__ __launch_bounds__(256) void spectral_weights_kernel(const cplx* __restrict__ S, int rows,
+                                                               int W,
+                                                               const double* __restrict__ omega,
+                                                               cplx* __restrict__ scale) {
+    const int w = blockIdx.x*256 + threadIdx.x;
+    if (w >= W) return;
+    const double lo = w > 0 ? omega[w] - omega[w - 1] : 0.0;
+    const double hi = w < W - 1 ? omega[w + 1] - omega[w] : 0.0;
+    const double wgt = 0.5*(lo + hi)/(2.0*3.141592653589793);
+    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+        const cplx s = S[static_cast<size_t>(r)*W + w];
+        scale[static_cast<size_t>(r)*W + w] = {s.re*wgt, s.im*wgt};
+    }
+}
+
+// One wavefront: a (16 TM) x (16 TN) tile of one Gamma[g,h,a,b] over the block's frequency range.
+// MFMA operand maps: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// D[row = (lane>>4) + 4 r][col = lane&15] (cdna_hip_programming.md section 3).
+template <int TM, int TN>
+__global__ __launch_bounds__(64) void decay_gemm_kernel(
+    const cplx* __restrict__ R, int Gp, int A, int N, int W, const cplx* __restrict__ scale,
+    int s_ndim, const int32_t* __restrict__ idx, int n_idx, int kchunk, int tiles_m, int tiles_n,
+    double* __restrict__ out, size_t split_stride) {
+    const int lane = threadIdx.x;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int tiles = tiles_m*tiles_n;
+    const int tile = blockIdx.x % tiles;
+    int z = blockIdx.x / tiles;
+    const int ti = tile / tiles_n, tj = tile % tiles_n;
+    const int nb = s_ndim == 3 ? n_idx : 1;
+    const int ib0 = z % nb;
+    z /= nb;
+    const int ia = z % n_idx;
+    z /= n_idx;
+    const int h = z % Gp, g = z / Gp;
+    const int ib = s_ndim == 3 ? ib0 : ia;
+    const int srow = s_ndim == 1 ? 0 : (s_ndim == 2 ? ia : ia*n_idx + ib);
+    const cplx* sp = scale + static_cast<size_t>(srow)*W;
+    const cplx* Lp[TM];
+    const cplx* Rp[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int row = min(N - 1, (ti*TM + tm)*16 + l15);
+        Lp[tm] = R + ((static_cast<size_t>(g)*A + idx[ia])*N + row)*W;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int row = min(N - 1, (tj*TN + tn)*16 + l15);
+        Rp[tn] = R + ((static_cast<size_t>(h)*A + idx[ib])*N + row)*W;
+    }
+    f64x4 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = {0.0, 0.0, 0.0, 0.0};
+
+    const int wbeg = blockIdx.y*kchunk;
+    const int wend = min(W, wbeg + kchunk);
+    for (int w0 = wbeg; w0 < wend; w0 += 16) {
+        cplx a[TM][4], b[TN][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int w = w0 + 4*lk + c;
+            const bool ok = w < wend;
+            const int wc = ok ? w : wend - 1;
+            cplx s = sp[wc];
+            if (!ok) s = {0.0, 0.0};
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) a[tm][c] = Lp[tm][wc];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) b[tn][c] = cmul(s, Rp[tn][wc]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm][c].re, b[tn][c].re,
+                                                                       acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm][c].im, b[tn][c].im,
+                                                                       acc[tm][tn], 0, 0, 0);
+                }
+    }
+    double* o = out + static_cast<size_t>(blockIdx.y)*split_stride +
+                static_cast<size_t>(blockIdx.x / tiles)*N*N;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = (tj*TN + tn)*16 + l15;
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = (ti*TM + tm)*16 + lk + 4*r;
+                if (row < N) o[static_cast<size_t>(row)*N + col] = acc[tm][tn][r];
+            }
+        }
+}
+
+// out[i] = sum_s part[s][i], fixed order
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const double* __restrict__ part,
+                                                            int nsplit, size_t n,
+                                                            double* __restrict__ out) {
+    const size_t i = static_cast<size_t>(blockIdx.x)*256 + threadIdx.x;
+    if (i >= n) return;
+    double acc = part[i];
+    for (int s = 1; s < nsplit; ++s) acc += part[static_cast<size_t>(s)*n + i];
+    out[i] = acc;
+}
+
+struct DecayPlan {
+    int tm, tn, tiles_m, tiles_n, ksplit, kchunk;
+    size_t batch;
+};
+
+DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
+    DecayPlan p;
+    const int t = N <= 16 ? 1 : 2;
+    p.tm = p.tn = t;
+    p.tiles_m = p.tiles_n = (N + 16*t - 1)/(16*t);
+    p.batch = static_cast<size_t>(Gp)*Gp*n_idx*(s_ndim == 3 ? n_idx : 1);
+    const size_t waves = p.batch*p.tiles_m*p.tiles_n;
+    // enough wavefronts for 256 CUs x 8, at least 64 frequencies per split
+    size_t want = (4096 + waves - 1)/waves;
+    const size_t max_split = static_cast<size_t>((W + 63)/64);
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    p.kchunk = static_cast<int>(((W + want - 1)/want + 15)/16*16);
+    p.ksplit = (W + p.kchunk - 1)/p.kchunk;
+    return p;
+}
+
+// ---- cumulant function ------------------------------------------------------------------------
+// Generic strided GEMM for the small products: C[b][m][n] = sum_k A[b][m][k] B[b][k][n]
+// (element strides; complex operands unless a_real; real part only if c_real).
+struct GemmDesc {
+    int M, N, K;
+    long sAm, sAk, sAb;
+    long sBk, sBn, sBb;
+    long sCm, sCn, sCb;
+    int a_real, c_real;
+};
+
+__global__ __launch_bounds__(256) void gemm_small_kernel(const double* __restrict__ A,
+                                                         const double* __restrict__ B,
+                                                         double* __restrict__ C, GemmDesc g) {
+    __shared__ cplx As[16][17];
+    __shared__ cplx Bs[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m = blockIdx.y*16 + ty, n = blockIdx.x*16 + tx;
+    const long b = blockIdx.z;
+    const double* Ab = A + (g.a_real ? 1 : 2)*b*g.sAb;
+    const cplx* Bb = reinterpret_cast<const cplx*>(B) + b*g.sBb;
+    cplx acc = {0.0, 0.0};
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        // A tile: rows m (ty), columns k0 + tx;  B tile: rows k0 + ty, columns n (tx)
+        cplx av = {0.0, 0.0}, bv = {0.0, 0.0};
+        if (m < g.M && k0 + tx < g.K) {
+            const long o = m*g.sAm + (k0 + tx)*g.sAk;
+            if (g.a_real)
+                av = {Ab[o], 0.0};
+            else
+                av = reinterpret_cast<const cplx*>(Ab)[o];
+        }
+        if (k0 + ty < g.K && n < g.N) bv = Bb[(k0 + ty)*g.sBk + n*g.sBn];
+        As[ty][tx] = av;
+        Bs[ty][tx] = bv;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cmac(acc, As[ty][k], Bs[k][tx]);
+        __syncthreads();
+    }
+    if (m < g.M && n < g.N) {
+        const long o = b*g.sCb + m*g.sCm + n*g.sCn;
+        if (g.c_real)
+            C[o] = acc.re;
+        else
+            reinterpret_cast<cplx*>(C)[o] = acc;
+    }
+}
+
+hipError_t launch_gemm_small(const void* A, const void* B, void* C, const GemmDesc& g, int batch,
+                             hipStream_t stream) {
+    const dim3 grid((g.N + 15)/16, (g.M + 15)/16, batch);
+    hipLaunchKernelGGL(gemm_small_kernel, grid, dim3(256), 0, stream,
+                       static_cast<const double*>(A), static_cast<const double*>(B),
+                       static_cast<double*>(C), g);
+    return hipGetLastError();
+}
+
+// M4[a,b,c,e] = sum_k C_k[a,b] D_k[c,e]  ->  superoperator, rows ordered (q', p'):
+//   S4[(q',p'),(p,q)] = -1/2 ( d_{q'q} G1[p',p] + d_{p'p} G2[q,q'] - M4[p',p,q,q'] - M4[q,q',p',p] ),
+//   G1[p',p] = sum_x M4[p',x,x,p] (= sum_k C_k D_k),  G2[q,q'] = sum_x M4[x,q',q,x] (= sum_k D_k C_k)
+__global__ __launch_bounds__(256) void cumulant_superop_kernel(const cplx* __restrict__ M4, int d,
+                                                               long batch_stride,
+                                                               cplx* __restrict__ S4) {
+    const int d2 = d*d;
+    const int e = blockIdx.x*256 + threadIdx.x;
+    if (e >= d2*d2) return;
+    const cplx* M = M4 + static_cast<size_t>(blockIdx.y)*batch_stride;
+    const int col = e % d2, rowi = e / d2;
+    const int qp = rowi / d, pp = rowi % d;   // q', p'
+    const int p = col / d, q = col % d;
+    auto at = [&](int a, int b, int c, int f) { return M[((a*d + b)*d + c)*d + f]; };
+    cplx v = at(pp, p, q, qp);
+    const cplx v2 = at(q, qp, pp, p);
+    v.re += v2.re;
+    v.im += v2.im;
+    v.re = -v.re;
+    v.im = -v.im;
+    if (qp == q)
+        for (int x = 0; x < d; ++x) {
+            const cplx t = at(pp, x, x, p);
+            v.re += t.re;
+            v.im += t.im;
+        }
+    if (pp == p)
+        for (int x = 0; x < d; ++x) {
+            const cplx t = at(x, qp, q, x);
+            v.re += t.re;
+            v.im += t.im;
+        }
+    S4[static_cast<size_t>(blockIdx.y)*batch_stride + e] = {-0.5*v.re, -0.5*v.im};
+}
+
+// Single qubit, Pauli/GGM basis: the simplified expression of numeric.py:1119-1141
+//   K_ij = Gamma_ij (i != j, i, j >= 1);  K_ii = -sum_{k >= 1, k != i} Gamma_kk;  K_0j = K_i0 = 0.
+__global__ __launch_bounds__(64) void cumulant_single_qubit_kernel(const double* __restrict__ G,
+                                                                   size_t batch,
+                                                                   double* __restrict__ K) {
+    const size_t t = static_cast<size_t>(blockIdx.x)*64 + threadIdx.x;
+    if (t >= batch*16) return;
+    const size_t b = t / 16;
+    const int i = (t % 16) / 4, j = t % 4;
+    const double* g = G + b*16;
+    double v = 0.0;
+    if (i >= 1 && j >= 1) {
+        if (i != j) {
+            v = g[i*4 + j];
+        } else {
+            for (int k = 1; k < 4; ++k)
+                if (k != i) v -= g[k*4 + k];
+        }
+    }
+    K[t] = v;
+}
+
+}  // namespace
+
+size_t decay_amplitudes_workspace_bytes(int Gp, int N, int W, int n_idx, int s_ndim) {
+    const DecayPlan p = decay_plan(Gp, N, W, n_idx, s_ndim);
+    const size_t rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : static_cast<size_t>(n_idx)*n_idx);
+    size_t bytes = align_up(rows*W*sizeof(cplx));
+    if (p.ksplit > 1) bytes += align_up(static_cast<size_t>(p.ksplit)*p.batch*N*N*sizeof(double));
+    return bytes;
+}
+
+hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, const cplx* S,
+                                   int s_ndim, const double* omega, const int32_t* idx, int n_idx,
+                                   double* gamma, void* ws, hipStream_t stream) {
+    const DecayPlan p = decay_plan(Gp, N, W, n_idx, s_ndim);
+    const int rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : n_idx*n_idx);
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    cplx* scale = reinterpret_cast<cplx*>(base);
+    double* part = reinterpret_cast<double*>(base + align_up(static_cast<size_t>(rows)*W*sizeof(cplx)));
+    hipLaunchKernelGGL(spectral_weights_kernel, dim3((W + 255)/256, min(rows, 1024)), dim3(256), 0,
+                       stream, S, rows, W, omega, scale);
+    const size_t n = p.batch*N*N;
+    const size_t blocks = p.batch*p.tiles_m*p.tiles_n;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    double* dst = p.ksplit > 1 ? part : gamma;
+    const dim3 grid(static_cast<unsigned>(blocks), p.ksplit);
+    if (p.tm == 1)
+        hipLaunchKernelGGL((decay_gemm_kernel<1, 1>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n);
+    else
+        hipLaunchKernelGGL((decay_gemm_kernel<2, 2>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n);
+    if (p.ksplit > 1)
+        hipLaunchKernelGGL(reduce_splits_kernel, dim3(static_cast<unsigned>((n + 255)/256)),
+                           dim3(256), 0, stream, part, p.ksplit, n, gamma);
+    return hipGetLastError();
+}
+
+size_t cumulant_workspace_bytes(size_t batch, int N, int d) {
+    const size_t d2 = static_cast<size_t>(d)*d;
+    // D (N x d^2), M4 (d^2 x d^2), S4 (d^2 x d^2), U (d^2 x N) per batch element
+    return batch*(2*align_up(N*d2*sizeof(cplx)) + 2*align_up(d2*d2*sizeof(cplx)));
+}
+
+hipError_t launch_cumulant_function(const double* gamma, size_t batch, int N, int d,
+                                    const cplx* basis, int single_qubit, double* K, void* ws,
+                                    hipStream_t stream) {
+    if (single_qubit) {
+        if (d != 2 || N != 4) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(cumulant_single_qubit_kernel,
+                           dim3(static_cast<unsigned>((batch*16 + 63)/64)), dim3(64), 0, stream,
+                           gamma, batch, K);
+        return hipGetLastError();
+    }
+    if (batch > 65535) return hipErrorInvalidValue;
+    const int nb = static_cast<int>(batch);
+    const long d2 = static_cast<long>(d)*d;
+    unsigned char* p = static_cast<unsigned char*>(ws);
+    cplx* D = reinterpret_cast<cplx*>(p);
+    p += batch*align_up(N*d2*sizeof(cplx));
+    cplx* M4 = reinterpret_cast<cplx*>(p);
+    p += batch*align_up(d2*d2*sizeof(cplx));
+    cplx* S4 = reinterpret_cast<cplx*>(p);
+    p += batch*align_up(d2*d2*sizeof(cplx));
+    cplx* U = reinterpret_cast<cplx*>(p);
+    const long sD = static_cast<long>(align_up(N*d2*sizeof(cplx))/sizeof(cplx));
+    const long sM = static_cast<long>(align_up(d2*d2*sizeof(cplx))/sizeof(cplx));
+    hipError_t err;
+    // 1. D_k = sum_l Gamma_kl C_l
+    GemmDesc g1{N, static_cast<int>(d2), N, N, 1, static_cast<long>(N)*N, d2, 1, 0, d2, 1, sD, 1, 0};
+    if ((err = launch_gemm_small(gamma, basis, D, g1, nb, stream)) != hipSuccess) return err;
+    // 2. M4[(a,b),(c,e)] = sum_k C_k[a,b] D_k[c,e]
+    GemmDesc g2{static_cast<int>(d2), static_cast<int>(d2), N, 1, d2, 0, d2, 1, sD, d2, 1, sM, 0, 0};
+    if ((err = launch_gemm_small(basis, D, M4, g2, nb, stream)) != hipSuccess) return err;
+    // 3. superoperator
+    hipLaunchKernelGGL(cumulant_superop_kernel, dim3(static_cast<unsigned>((d2*d2 + 255)/256), nb),
+                       dim3(256), 0, stream, M4, d, sM, S4);
+    // 4. U[(q',p'), j] = sum_(p,q) S4[(q',p'),(p,q)] C_j[p,q]
+    GemmDesc g4{static_cast<int>(d2), N, static_cast<int>(d2), d2, 1, sM, 1, d2, 0, N, 1, sD, 0, 0};
+    if ((err = launch_gemm_small(S4, basis, U, g4, nb, stream)) != hipSuccess) return err;
+    // 5. K_ij = Re sum_(q',p') C_i[q',p'] U[(q',p'), j]
+    GemmDesc g5{N, N, static_cast<int>(d2), d2, 1, 0, N, 1, sD, N, 1, static_cast<long>(N)*N, 0, 1};
+    if ((err = launch_gemm_small(basis, U, K, g5, nb, stream)) != hipSuccess) return err;
+    return hipGetLastError();
+}
+
+}  // namespace ffk

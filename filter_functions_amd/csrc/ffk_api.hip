@@ -797,6 +797,116 @@ int ffk_infidelity(const double* filter_function, int A, int W, const double* sp
 }
 
 // ---------------------------------------------------------------------------------------------
+// Decay amplitudes, cumulant function
+// ---------------------------------------------------------------------------------------------
+size_t ffk_decay_amplitudes_workspace_bytes(int n_pulses, int N, int W, int n_idx, int s_ndim) {
+    if (n_pulses < 1 || N < 1 || W < 1 || n_idx < 1 || s_ndim < 1 || s_ndim > 3) return 0;
+    return ffk::decay_amplitudes_workspace_bytes(n_pulses, N, W, n_idx, s_ndim);
+}
+
+int ffk_decay_amplitudes_dev(const double* control_matrix, int n_pulses, int A, int N, int W,
+                             const double* spectrum, int s_ndim, const double* omega,
+                             const int32_t* idx, int n_idx, double* decay_amplitudes,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(control_matrix && spectrum && omega && idx && decay_amplitudes && workspace,
+                "NULL argument");
+    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
+    FFK_REQUIRE(n_pulses >= 1 && A >= 1 && N >= 1 && W >= 1 && n_idx >= 1, "empty axis");
+    FFK_REQUIRE(workspace_bytes >= ffk_decay_amplitudes_workspace_bytes(n_pulses, N, W, n_idx, s_ndim),
+                "workspace too small");
+    FFK_HIP(ffk::launch_decay_amplitudes(reinterpret_cast<const cplx*>(control_matrix), n_pulses, A,
+                                         N, W, reinterpret_cast<const cplx*>(spectrum), s_ndim,
+                                         omega, idx, n_idx, decay_amplitudes, workspace,
+                                         static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+int ffk_decay_amplitudes(const double* control_matrix, int n_pulses, int A, int N, int W,
+                         const double* spectrum, int s_ndim, const double* omega,
+                         const int32_t* idx, int n_idx, double* decay_amplitudes) {
+    FFK_REQUIRE(control_matrix && spectrum && omega && idx && decay_amplitudes, "NULL argument");
+    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
+    FFK_REQUIRE(n_pulses >= 1 && A >= 1 && N >= 1 && W >= 1 && n_idx >= 1, "empty axis");
+    for (int i = 0; i < n_idx; ++i)
+        FFK_REQUIRE(idx[i] >= 0 && idx[i] < A, "noise operator index %d out of range [0, %d)", idx[i], A);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nR = 16*size_t(n_pulses)*A*N*W;
+    const size_t nS = 16*size_t(W)*(s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : size_t(n_idx)*n_idx));
+    const size_t nout = size_t(n_pulses)*n_pulses*n_idx*(s_ndim == 3 ? n_idx : 1)*N*N;
+    const size_t wsb = ffk_decay_amplitudes_workspace_bytes(n_pulses, N, W, n_idx, s_ndim);
+    void* base;
+    if (int rc = arena_reserve(align_up(nR) + align_up(nS) + align_up(8*size_t(W)) +
+                                   align_up(4*size_t(n_idx)) + align_up(8*nout) + wsb, &base))
+        return rc;
+    Bump a(base, g_arena.size);
+    double* dR = a.take<double>(nR/8);
+    double* dS = a.take<double>(nS/8);
+    double* dom = a.take<double>(W);
+    int32_t* didx = a.take<int32_t>(n_idx);
+    double* dout = a.take<double>(nout);
+    void* ws = a.take<unsigned char>(wsb);
+    FFK_HIP(hipMemcpyAsync(dR, control_matrix, nR, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dS, spectrum, nS, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dom, omega, 8*size_t(W), hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(didx, idx, 4*size_t(n_idx), hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_decay_amplitudes_dev(dR, n_pulses, A, N, W, dS, s_ndim, dom, didx, n_idx, dout,
+                                          ws, wsb, nullptr))
+        return rc;
+    FFK_HIP(hipMemcpyAsync(decay_amplitudes, dout, 8*nout, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+size_t ffk_cumulant_function_workspace_bytes(int batch, int N, int d) {
+    if (batch < 1 || N < 1 || !d_ok(d)) return 0;
+    return ffk::cumulant_workspace_bytes(batch, N, d);
+}
+
+int ffk_cumulant_function_dev(const double* decay_amplitudes, int batch, int N, int d,
+                              const double* basis, int single_qubit, double* cumulant_function,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(decay_amplitudes && basis && cumulant_function, "NULL argument");
+    FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis");
+    FFK_REQUIRE(d_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D);
+    FFK_REQUIRE(!single_qubit || (d == 2 && N == 4), "single-qubit expression needs d = 2, N = 4");
+    if (!single_qubit) {
+        FFK_REQUIRE(batch <= 65535, "batch %d too large", batch);
+        FFK_REQUIRE(workspace && workspace_bytes >= ffk_cumulant_function_workspace_bytes(batch, N, d),
+                    "workspace too small");
+    }
+    FFK_HIP(ffk::launch_cumulant_function(decay_amplitudes, batch, N, d,
+                                          reinterpret_cast<const cplx*>(basis), single_qubit,
+                                          cumulant_function, workspace,
+                                          static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+int ffk_cumulant_function(const double* decay_amplitudes, int batch, int N, int d,
+                          const double* basis, int single_qubit, double* cumulant_function) {
+    FFK_REQUIRE(decay_amplitudes && basis && cumulant_function, "NULL argument");
+    FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis");
+    FFK_REQUIRE(d_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nG = 8*size_t(batch)*N*N;
+    const size_t nB = 16*size_t(N)*d*d;
+    const size_t wsb = single_qubit ? 0 : ffk_cumulant_function_workspace_bytes(batch, N, d);
+    void* base;
+    if (int rc = arena_reserve(2*align_up(nG) + align_up(nB) + wsb + 256, &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dG = a.take<double>(nG/8);
+    double* dK = a.take<double>(nG/8);
+    double* dB = a.take<double>(nB/8);
+    void* ws = a.take<unsigned char>(wsb + 16);
+    FFK_HIP(hipMemcpyAsync(dG, decay_amplitudes, nG, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dB, basis, nB, hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_cumulant_function_dev(dG, batch, N, d, dB, single_qubit, dK, ws, wsb, nullptr))
+        return rc;
+    FFK_HIP(hipMemcpyAsync(cumulant_function, dK, nG, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Liouville representation
 // ---------------------------------------------------------------------------------------------
 size_t ffk_liouville_workspace_bytes(int batch, int d, int N) {

@@ -10,6 +10,9 @@ this module                                           reference (file:line)
 :func:`calculate_noise_operators_from_scratch`        numeric.py:456-618
 :func:`calculate_filter_function`                     numeric.py:1413-1467
 :func:`infidelity`                                    numeric.py:2062-2334
+:func:`calculate_decay_amplitudes`                    numeric.py:1194-1337
+:func:`calculate_cumulant_function`                   numeric.py:957-1191 (first order)
+:func:`error_transfer_matrix`                         numeric.py:1938-2059
 ====================================================  ==============================
 
 Inputs are borrowed NumPy arrays, outputs are fresh C-contiguous ``complex128`` /
@@ -26,7 +29,8 @@ from ._lib import as_c128, as_f64, check, ptr
 __all__ = ['diagonalize', 'calculate_control_matrix_from_scratch',
            'calculate_noise_operators_from_scratch', 'calculate_filter_function', 'infidelity',
            'calculate_control_matrix_from_atomic', 'calculate_control_matrix_from_atomic_indexed',
-           'calculate_pulse_correlation_filter_function']
+           'calculate_pulse_correlation_filter_function', 'calculate_decay_amplitudes',
+           'calculate_cumulant_function', 'error_transfer_matrix']
 
 
 def _check_d(d):
@@ -367,3 +371,126 @@ def calculate_pulse_correlation_filter_function(control_matrix, which='fidelity'
     if which == 'fidelity':
         return np.ascontiguousarray(F.reshape(G, A, G, A, W).transpose(0, 2, 1, 3, 4))
     return np.ascontiguousarray(F.reshape(G, A, G, A, N, N, W).transpose(0, 2, 1, 3, 4, 5, 6))
+
+
+@util.parse_optional_parameters(which=('total', 'correlations'))
+def calculate_decay_amplitudes(pulse, spectrum, omega, n_oper_identifiers=None, which='total',
+                               show_progressbar=False, cache_intermediates=False,
+                               memory_parsimonious=False):
+    r"""Decay amplitudes :math:`\Gamma_{\alpha\beta,kl} = \int\frac{d\omega}{2\pi}
+    \tilde{\mathcal{B}}^\ast_{\alpha k}(\omega) S_{\alpha\beta}(\omega)
+    \tilde{\mathcal{B}}_{\beta l}(\omega)` (reference numeric.py:1194-1337).
+
+    Returns an array of shape ``([[G, G,] n_nops,] n_nops, d**2, d**2)`` exactly like the
+    reference.  The reference builds the ``(n_nops, d**2, d**2, n_omega)`` integrand and integrates
+    it (or loops over ``k`` if *memory_parsimonious*); here the integral is one FP64 matrix
+    product over the frequency axis on the matrix cores, so *memory_parsimonious* changes nothing.
+    """
+    idx = util.get_indices_from_identifiers(pulse.n_oper_identifiers, n_oper_identifiers)
+    if which == 'total':
+        control_matrix = pulse.get_control_matrix(omega, show_progressbar, cache_intermediates)
+    else:
+        if pulse.is_cached('omega') and not np.array_equal(pulse.omega, omega):
+            raise ValueError('Pulse correlation decay amplitudes requested but omega not '
+                             'equal to cached frequencies.')
+        control_matrix = pulse.get_pulse_correlation_control_matrix()
+    return _decay_amplitudes(control_matrix, spectrum, omega, idx, which)
+
+
+def _decay_amplitudes(control_matrix, spectrum, omega, idx, which):
+    omega = as_f64(omega)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    S = as_c128(util.parse_spectrum(spectrum, omega, idx))
+    R = as_c128(control_matrix)
+    if R.ndim != (3 if which == 'total' else 4) or R.shape[-1] != len(omega):
+        raise ValueError(f'control matrix of shape {R.shape} does not match which={which!r} and '
+                         f'{len(omega)} frequencies.')
+    n_pls = 1 if which == 'total' else R.shape[0]
+    A, N, W = R.shape[-3:]
+    n_idx = len(idx)
+    shape = (n_idx, n_idx, N, N) if S.ndim == 3 else (n_idx, N, N)
+    if which == 'correlations':
+        shape = (n_pls, n_pls) + shape
+    out = np.empty(shape, dtype=np.float64)
+    check(_lib.load().ffk_decay_amplitudes(ptr(R), n_pls, A, N, W, ptr(S), S.ndim, ptr(omega),
+                                           idx.ctypes.data_as(ctypes.c_void_p), n_idx, ptr(out)))
+    return out
+
+
+@util.parse_optional_parameters(which=('total', 'correlations'))
+def calculate_cumulant_function(pulse, spectrum=None, omega=None, n_oper_identifiers=None,
+                                which='total', second_order=False, decay_amplitudes=None,
+                                frequency_shifts=None, show_progressbar=False,
+                                memory_parsimonious=False, cache_intermediates=None):
+    r"""Cumulant function :math:`\mathcal{K}(\tau)`, first order in the Magnus expansion
+    (reference numeric.py:957-1191):
+
+    .. math:: K_{\alpha\beta,ij} = -\frac{1}{2}\sum_{kl}\Gamma_{\alpha\beta,kl}
+              \left(T_{klji} - T_{kjli} - T_{kilj} + T_{kijl}\right).
+
+    Same arguments, shapes and errors as the reference.  The contraction with the four-element
+    trace tensor is evaluated on the device without forming the tensor.  ``second_order=True``
+    (frequency shifts) is not part of the accelerated path.
+    """
+    if spectrum is None and omega is None:
+        if decay_amplitudes is None or (frequency_shifts is None and second_order):
+            raise ValueError('Require either spectrum and frequencies or precomputed '
+                             'decay amplitudes (frequency shifts)')
+    if which == 'correlations' and second_order:
+        raise ValueError('Cannot compute correlation cumulant function for second order terms')
+    if second_order:
+        raise NotImplementedError('Frequency shifts (second-order Magnus terms, reference '
+                                  'numeric.py:1340-1410) are outside the accelerated path.')
+    if cache_intermediates is None:
+        cache_intermediates = second_order
+    if decay_amplitudes is None:
+        decay_amplitudes = calculate_decay_amplitudes(pulse, spectrum, omega, n_oper_identifiers,
+                                                      which, show_progressbar,
+                                                      cache_intermediates, memory_parsimonious)
+    return _cumulant_function(decay_amplitudes, pulse.basis)
+
+
+def _cumulant_function(decay_amplitudes, basis):
+    N, d = basis.shape[:2]
+    _check_d(d)
+    G = as_f64(decay_amplitudes)
+    if G.ndim < 2 or G.shape[-2:] != (N, N):
+        raise ValueError(f'Expected decay amplitudes of shape (..., {N}, {N}), not {G.shape}.')
+    single_qubit = int(d == 2 and basis.btype in ('Pauli', 'GGM'))
+    flat = G.reshape(-1, N, N)
+    out = np.empty_like(flat)
+    C = as_c128(np.asarray(basis))
+    step = 16384
+    for lo in range(0, len(flat), step):
+        part = np.ascontiguousarray(flat[lo:lo + step])
+        res = np.empty_like(part)
+        check(_lib.load().ffk_cumulant_function(ptr(part), len(part), N, d, ptr(C), single_qubit,
+                                                ptr(res)))
+        out[lo:lo + step] = res
+    return out.reshape(G.shape)
+
+
+def error_transfer_matrix(pulse=None, spectrum=None, omega=None, n_oper_identifiers=None,
+                          second_order=False, cumulant_function=None, show_progressbar=False,
+                          memory_parsimonious=False, cache_intermediates=False):
+    r"""Error transfer matrix :math:`\langle\tilde{\mathcal{U}}\rangle = \exp\mathcal{K}`
+    (reference numeric.py:1938-2059): the cumulant function summed over the noise operators,
+    exponentiated (one ``d**2 x d**2`` real matrix; ``scipy.linalg.expm`` on the host like the
+    reference)."""
+    from scipy import linalg as sla
+
+    if cumulant_function is None:
+        if pulse is None or spectrum is None or omega is None:
+            raise ValueError('Require either precomputed cumulant function '
+                             'or pulse, spectrum, and omega as arguments.')
+        cumulant_function = calculate_cumulant_function(pulse, spectrum, omega, n_oper_identifiers,
+                                                        'total', second_order,
+                                                        show_progressbar=show_progressbar,
+                                                        memory_parsimonious=memory_parsimonious,
+                                                        cache_intermediates=cache_intermediates)
+    try:
+        return sla.expm(cumulant_function.sum(axis=tuple(range(cumulant_function.ndim - 2))))
+    except AttributeError as aerr:
+        raise TypeError(f'cumulant_function invalid type: {type(cumulant_function)}') from aerr
+    except ValueError as verr:
+        raise ValueError(f'cumulant_function invalid shape: {cumulant_function.shape}') from verr

@@ -197,6 +197,36 @@ int ffk_infidelity_sharded_dev(const double* filter_function_shards, int n_shard
                                int A, const double* spectrum, int s_ndim, const double* omega,
                                const int32_t* idx, int n_idx, int d, double* infid, void* stream);
 
+/* ---- numeric.calculate_decay_amplitudes (numeric.py:1194-1337; integrand _get_integrand
+ *      :310-374 'generalized' with the control matrix; util.integrate util.py:880-906) -------
+ * control_matrix (n_pulses, A, N, W) c128: n_pulses = 1 is the total control matrix
+ * (which='total'), n_pulses = G the pulse-correlation control matrix (which='correlations').
+ * spectrum / s_ndim / idx / n_idx as in ffk_infidelity.
+ * -> decay_amplitudes f64: (n_pulses, n_pulses, n_idx, N, N) for s_ndim 1 or 2,
+ *    (n_pulses, n_pulses, n_idx, n_idx, N, N) for s_ndim 3:
+ *    Gamma[g,h,a,b,k,l] = int dw/2pi Re(R*[g,a,k,w] S_ab(w) R[h,b,l,w])  (trapezoid).          */
+size_t ffk_decay_amplitudes_workspace_bytes(int n_pulses, int N, int W, int n_idx, int s_ndim);
+int ffk_decay_amplitudes_dev(const double* control_matrix, int n_pulses, int A, int N, int W,
+                             const double* spectrum, int s_ndim, const double* omega,
+                             const int32_t* idx, int n_idx, double* decay_amplitudes,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int ffk_decay_amplitudes(const double* control_matrix, int n_pulses, int A, int N, int W,
+                         const double* spectrum, int s_ndim, const double* omega,
+                         const int32_t* idx, int n_idx, double* decay_amplitudes);
+
+/* ---- numeric.calculate_cumulant_function, first order (numeric.py:957-1191) ----------------
+ * decay_amplitudes (batch, N, N) f64 (any leading axes flattened into batch), basis (N, d, d)
+ * c128 -> cumulant_function (batch, N, N) f64,
+ *    K_ij = -1/2 sum_kl Gamma_kl (T_klji - T_kjli - T_kilj + T_kijl),  T = Basis.four_element_traces
+ * (basis.py:330-348), evaluated without forming T.  single_qubit != 0 selects the simplified
+ * expression the reference uses for d = 2 with a Pauli or GGM basis (:1119-1141).             */
+size_t ffk_cumulant_function_workspace_bytes(int batch, int N, int d);
+int ffk_cumulant_function_dev(const double* decay_amplitudes, int batch, int N, int d,
+                              const double* basis, int single_qubit, double* cumulant_function,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int ffk_cumulant_function(const double* decay_amplitudes, int batch, int N, int d,
+                          const double* basis, int single_qubit, double* cumulant_function);
+
 /* ---- superoperator.liouville_representation (superoperator.py:51-84 + Basis.expand
  *      basis.py:350-371, 650-698) --------------------------------------------------------
  * U (batch, d, d) c128, basis (N, d, d) c128 -> liouville (batch, N, N):

@@ -378,3 +378,81 @@ def control_matrix_from_atomic(phases, R_atomic, Q_liouville, which='total'):
     if which == 'correlations':
         return steps
     return steps.sum(axis=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Decay amplitudes -> cumulant function -> error transfer matrix
+# ---------------------------------------------------------------------------------------------
+def decay_amplitudes(control_matrix, spectrum, omega, idx, which='total'):
+    """Gamma_{ab,kl} = int dw/2pi Re[R*_{ak} S_{ab} R_{bl}], filter_functions/numeric.py:1194-1337
+    with the integrand of _get_integrand (:310-374, 'generalized', control matrix given).
+    control_matrix: (A, N, W) for which='total', (G, A, N, W) for 'correlations'."""
+    omega = np.asarray(omega, dtype=float)
+    idx = np.asarray(idx)
+    R = np.asarray(control_matrix)
+    S = parse_spectrum(spectrum, omega, idx)
+    left, right = R.conj()[..., idx, :, :], R[..., idx, :, :]
+    if S.ndim in (1, 2):
+        sub = 'g...ko,...o,h...lo->gh...klo' if which == 'correlations' else '...ko,...o,...lo->...klo'
+    else:
+        sub = 'gako,abo,hblo->ghabklo' if which == 'correlations' else 'ako,abo,blo->abklo'
+    integrand = np.einsum(sub, left, S, right).real
+    return integrate(integrand, omega)/(2*np.pi)
+
+
+def four_element_traces(basis):
+    """T_ijkl = tr(C_i C_j C_k C_l), filter_functions/basis.py:330-348 (dense; small d only)."""
+    C = np.asarray(basis)
+    P = np.einsum('iab,jbc->ijac', C, C)
+    return np.einsum('ijac,klca->ijkl', P, P)
+
+
+def cumulant_function_dense(Gamma, basis, single_qubit=False):
+    """K_{ij} = -1/2 sum_kl Gamma_kl (T_klji - T_kjli - T_kilj + T_kijl),
+    filter_functions/numeric.py:1119-1165, 1190 (first order only).  single_qubit: the simplified
+    expression the reference takes for d = 2 Pauli/GGM bases (:1119-1141)."""
+    Gamma = np.asarray(Gamma)
+    N = Gamma.shape[-1]
+    if single_qubit:
+        K = np.zeros(Gamma.shape, Gamma.dtype)
+        mask = np.zeros((N, N), dtype=bool)
+        mask[1:, 1:] = ~np.eye(N - 1, dtype=bool)
+        K[..., mask] = Gamma[..., mask]
+        for i in range(1, N):
+            others = [j for j in range(1, N) if j != i]
+            K[..., i, i] = -Gamma[..., others, others].sum(axis=-1)
+        return K
+    T = four_element_traces(basis)
+    K = -(np.einsum('...kl,klji->...ij', Gamma, T).real
+          - np.einsum('...kl,kjli->...ij', Gamma, T).real
+          - np.einsum('...kl,kilj->...ij', Gamma, T).real
+          + np.einsum('...kl,kijl->...ij', Gamma, T).real)
+    return K*0.5
+
+
+def cumulant_function(Gamma, basis):
+    """The same contraction without the N^4 trace tensor: with D_k = sum_l Gamma_kl C_l
+    the cumulant superoperator is
+        K(X) = -1/2 sum_k (C_k D_k X - C_k X D_k - D_k X C_k + X D_k C_k),
+    and K_ij = tr(C_i K(C_j)).  O(d^6) instead of O(d^8); what the device path implements."""
+    C = np.asarray(basis)
+    N, d = C.shape[:2]
+    Cf = C.reshape(N, d*d)
+    D = np.asarray(Gamma) @ Cf                                   # (..., N, d^2)
+    M4 = (Cf.T @ D).reshape(D.shape[:-2] + (d, d, d, d))         # [a,b,c,e] = sum_k C_k[a,b] D_k[c,e]
+    G1 = np.einsum('...apbq,pb->...aq', M4, np.eye(d))           # sum_k C_k D_k
+    G2 = np.einsum('...pqab,bp->...aq', M4, np.eye(d))           # sum_k D_k C_k
+    eye = np.eye(d)
+    S4 = (np.einsum('...ap,bq->...abpq', G1, eye)                # [p',q',p,q]: G1 X
+          + np.einsum('ap,...qb->...abpq', eye, G2)              # X G2
+          - np.einsum('...apqb->...abpq', M4)                    # C_k X D_k
+          - np.einsum('...qbap->...abpq', M4))                   # D_k X C_k
+    S4 = -0.5*S4
+    return np.einsum('iba,...abpq,jpq->...ij', C, S4, C).real
+
+
+def error_transfer_matrix(K):
+    """exp(sum over all but the last two axes of K), filter_functions/numeric.py:2049-2053."""
+    from scipy.linalg import expm
+    K = np.asarray(K)
+    return expm(K.sum(axis=tuple(range(K.ndim - 2))))

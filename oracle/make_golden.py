@@ -118,7 +118,83 @@ def save(name, **arrays):
     print(f'{name}: {os.path.getsize(path)/1024:.1f} KiB, {len(arrays)} arrays')
 
 
+
+def make_etm():
+    """10. decay amplitudes -> cumulant function -> error transfer matrix (NEXT-2), the cases of
+    the reference's tests/test_precision.py:631-727: single qubit (simplified formula, incl. a
+    noise operator with finite trace), Pauli d=4, GGM d=3 and d=6; white/1-D, per-operator and
+    complex cross-correlated spectra; pulse correlations of a concatenated sequence."""
+    rng = np.random.default_rng(51)
+    arrays = {}
+    cases = [('q1', 2, 5, 3, 2, 'Pauli', False), ('q1id', 2, 3, 3, 2, 'Pauli', True),
+             ('p4', 4, 4, 4, 2, 'Pauli', False), ('g3', 3, 3, 4, 2, 'GGM', False),
+             ('g6', 6, 2, 4, 2, 'GGM', False)]
+    for name, d, n_dt, n_cops, n_nops, btype, finite_trace in cases:
+        pulse = rand_pulse(d, n_dt, n_cops, n_nops, btype, rng)
+        if finite_trace:
+            pulse.n_opers[0] = np.eye(d)/np.sqrt(d)
+        omega = util.get_sample_frequencies(pulse, n_samples=51)
+        spec3 = np.tile(1e-8/abs(omega)**2, (n_nops, n_nops, 1)).astype(complex)
+        for i in range(n_nops):
+            for j in range(i + 1, n_nops):
+                spec3[i, j] += 1j*1e-10*omega
+                spec3[j, i] -= 1j*1e-10*omega
+        spectra = [1e-8/omega**2,
+                   np.outer(1e-7*(np.arange(n_nops) + 1), 400/(omega**2 + 400)), spec3]
+        for k, v in pulse_inputs(pulse).items():
+            arrays[f'{name}_{k}'] = v
+        arrays[f'{name}_omega'] = omega
+        arrays[f'{name}_control_matrix'] = pulse.get_control_matrix(omega)
+        for i, S in enumerate(spectra, 1):
+            arrays[f'{name}_S{i}'] = S
+            G = numeric.calculate_decay_amplitudes(pulse, S, omega)
+            K = numeric.calculate_cumulant_function(pulse, S, omega)
+            U = numeric.error_transfer_matrix(pulse, S, omega)
+            Up = numeric.error_transfer_matrix(pulse, S, omega, memory_parsimonious=True)
+            assert np.allclose(U, Up, rtol=1e-12, atol=1e-15)
+            arrays[f'{name}_decay_amplitudes_S{i}'] = G
+            arrays[f'{name}_cumulant_function_S{i}'] = K
+            arrays[f'{name}_error_transfer_matrix_S{i}'] = U
+            if not finite_trace:
+                arrays[f'{name}_infidelity_S{i}'] = numeric.infidelity(pulse, S, omega)
+        # a subset of the noise operators
+        ident = pulse.n_oper_identifiers[1:]
+        arrays[f'{name}_decay_amplitudes_S1_sub'] = numeric.calculate_decay_amplitudes(
+            pulse, spectra[0], omega, n_oper_identifiers=ident)
+        arrays[f'{name}_sub_idx'] = util.get_indices_from_identifiers(
+            pulse.n_oper_identifiers, ident)
+    # pulse correlations of a concatenated sequence (Pauli d=4)
+    pulses = [rand_pulse(4, int(rng.integers(1, 4)), 2, 2, 'Pauli', rng) for _ in range(3)]
+    for q in pulses:
+        q.n_opers = pulses[0].n_opers
+        q.n_oper_identifiers = pulses[0].n_oper_identifiers
+    omega = np.geomspace(1e-2, 1e2, 41)
+    for q in pulses:
+        q.cache_filter_function(omega)
+    total = ff.concatenate(pulses, calc_pulse_correlation_FF=True, omega=omega)
+    S = np.outer(1e-7*(np.arange(2) + 1), 400/(omega**2 + 400))
+    arrays['pc_omega'] = omega
+    arrays['pc_S2'] = S
+    arrays['pc_control_matrix'] = total.get_pulse_correlation_control_matrix()
+    arrays['pc_basis'] = np.asarray(total.basis)
+    arrays['pc_decay_amplitudes'] = numeric.calculate_decay_amplitudes(total, S, omega,
+                                                                       which='correlations')
+    arrays['pc_cumulant_function'] = numeric.calculate_cumulant_function(total, S, omega,
+                                                                         which='correlations')
+    arrays['pc_cumulant_function_total'] = numeric.calculate_cumulant_function(total, S, omega)
+    for i, q in enumerate(pulses):
+        for k, v in pulse_inputs(q).items():
+            arrays[f'pc_p{i}_{k}'] = v
+    # four-element traces of the small bases (dense)
+    arrays['traces_pauli1'] = np.asarray(ff.Basis.pauli(1).four_element_traces.todense())
+    arrays['traces_ggm3'] = np.asarray(ff.Basis.ggm(3).four_element_traces.todense())
+    save('etm', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'etm':   # only the newest fixture
+        make_etm()
+        return
     X, Y, Z = util.paulis[1:]
 
     # 1. README Hadamard (config 1) --------------------------------------------------------
@@ -333,6 +409,8 @@ def main():
     f = rng.standard_normal((3, 101)) + 1j*rng.standard_normal((3, 101))
     save('util', x=x, f=f, integral=util.integrate(f, x),
          cexp_in=x*1e3, cexp_out=util.cexp(x*1e3), cexpm1_out=util.cexpm1(x*1e3 - 5e3))
+
+    make_etm()
 
 
 if __name__ == '__main__':

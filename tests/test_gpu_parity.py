@@ -545,3 +545,129 @@ def test_logical_omega_shards_on_one_gpu():
     assert np.array_equal(out.cpu().numpy(), infid_full)
     ref = orc.infidelity_from_filter_function(F_full, S, omega, np.arange(3), 4)
     assert rel_err(infid_full, ref) < 1e-13
+
+
+# ---- decay amplitudes -> cumulant function -> error transfer matrix --------------
+def etm_pulse(g, name):
+    basis = ff.Basis(g[f'{name}_basis'], btype=str(g[f'{name}_btype']))
+    return ff.PulseSequence.from_arrays(
+        g[f'{name}_c_opers'], g[f'{name}_c_oper_identifiers'], g[f'{name}_c_coeffs'],
+        g[f'{name}_n_opers'], g[f'{name}_n_oper_identifiers'], g[f'{name}_n_coeffs'],
+        g[f'{name}_dt'], basis)
+
+
+@pytest.mark.parametrize('name', ['q1', 'q1id', 'p4', 'g3', 'g6'])
+def test_error_transfer_matrix_against_reference(name):
+    """Gamma, K and exp(K) through the PulseSequence API against the reference's outputs
+    (cases of the reference's tests/test_precision.py:631-727)."""
+    g = load_golden('etm')
+    pulse = etm_pulse(g, name)
+    omega = g[f'{name}_omega']
+    assert rel_err(pulse.get_control_matrix(omega), g[f'{name}_control_matrix']) < TOL
+    for i in (1, 2, 3):
+        S = g[f'{name}_S{i}']
+        gamma = numeric.calculate_decay_amplitudes(pulse, S, omega)
+        ref = g[f'{name}_decay_amplitudes_S{i}']
+        assert gamma.shape == ref.shape and gamma.dtype == np.float64
+        assert rel_err(gamma, ref) < TOL
+        K = numeric.calculate_cumulant_function(pulse, S, omega)
+        assert rel_err(K, g[f'{name}_cumulant_function_S{i}']) < TOL
+        # precomputed decay amplitudes: the contraction alone, tight
+        K2 = numeric.calculate_cumulant_function(pulse, decay_amplitudes=ref)
+        assert rel_err(K2, g[f'{name}_cumulant_function_S{i}']) < 1e-13
+        U = ff.error_transfer_matrix(pulse, S, omega)
+        U_ref = g[f'{name}_error_transfer_matrix_S{i}']
+        assert np.abs(U - U_ref).max() < TOL*np.abs(U_ref - np.eye(len(U_ref))).max() + 1e-15
+        assert np.allclose(ff.error_transfer_matrix(cumulant_function=K), U, rtol=0, atol=1e-15)
+        assert np.allclose(ff.error_transfer_matrix(pulse, S, omega, memory_parsimonious=True), U)
+        if f'{name}_infidelity_S{i}' in g:
+            # entanglement infidelity from the cumulant function, reference test :671-676
+            d = pulse.d
+            assert np.allclose(-np.einsum('...ii', K)/d**2, g[f'{name}_infidelity_S{i}'],
+                               rtol=1e-9, atol=1e-18)
+    sub = numeric.calculate_decay_amplitudes(pulse, g[f'{name}_S1'], omega,
+                                             n_oper_identifiers=pulse.n_oper_identifiers[1:])
+    assert rel_err(sub, g[f'{name}_decay_amplitudes_S1_sub']) < TOL
+
+
+def test_pulse_correlation_decay_amplitudes_and_cumulant():
+    g = load_golden('etm')
+    omega = g['pc_omega']
+    pulses = [ff.PulseSequence.from_arrays(
+        g[f'pc_p{i}_c_opers'], g[f'pc_p{i}_c_oper_identifiers'], g[f'pc_p{i}_c_coeffs'],
+        g[f'pc_p{i}_n_opers'], g[f'pc_p{i}_n_oper_identifiers'], g[f'pc_p{i}_n_coeffs'],
+        g[f'pc_p{i}_dt'], ff.Basis(g[f'pc_p{i}_basis'], btype='Pauli')) for i in range(3)]
+    for q in pulses:
+        q.cache_filter_function(omega)
+    total = ff.concatenate(pulses, calc_pulse_correlation_FF=True, omega=omega)
+    assert rel_err(total.get_pulse_correlation_control_matrix(), g['pc_control_matrix']) < TOL
+    gamma = numeric.calculate_decay_amplitudes(total, g['pc_S2'], omega, which='correlations')
+    assert gamma.shape == g['pc_decay_amplitudes'].shape
+    assert rel_err(gamma, g['pc_decay_amplitudes']) < TOL
+    K = numeric.calculate_cumulant_function(total, g['pc_S2'], omega, which='correlations')
+    assert rel_err(K, g['pc_cumulant_function']) < TOL
+    assert rel_err(K.sum(axis=(0, 1)), g['pc_cumulant_function_total']) < TOL
+    with pytest.raises(ValueError):
+        numeric.calculate_decay_amplitudes(total, g['pc_S2'], omega[:-1], which='correlations')
+
+
+@pytest.mark.parametrize('A,N,W,s_ndim', [(3, 16, 4096, 2), (2, 25, 1000, 3), (2, 36, 777, 1),
+                                           (1, 49, 130, 2), (2, 64, 2048, 3), (1, 4, 1, 1),
+                                           (2, 9, 2, 2), (1, 256, 515, 1)])
+def test_decay_amplitudes_gemm_against_oracle(A, N, W, s_ndim):
+    """The frequency-axis GEMM on random control matrices: tile edges (N not a multiple of 16/32),
+    frequency tails (W not a multiple of 16), split-K, all spectrum kinds, W = 1 and 2."""
+    rng = np.random.default_rng(N*W)
+    R = rng.standard_normal((A, N, W)) + 1j*rng.standard_normal((A, N, W))
+    omega = np.sort(rng.random(W))*50 + 1e-3
+    if s_ndim == 1:
+        S = 1/(1 + omega**2)
+    elif s_ndim == 2:
+        S = rng.random((A, W))
+    else:
+        S = rng.standard_normal((A, A, W)) + 1j*rng.standard_normal((A, A, W))
+        S = S + S.conj().swapaxes(0, 1)
+    idx = np.arange(A)
+    got = numeric._decay_amplitudes(R, S, omega, idx, 'total')
+    ref = orc.decay_amplitudes(R, S, omega, idx)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1e-12*max(np.abs(ref).max(), 1e-300)
+
+
+@pytest.mark.parametrize('d,btype', [(3, 'GGM'), (4, 'Pauli'), (5, 'GGM'), (8, 'Pauli'), (16, 'GGM')])
+def test_cumulant_function_against_trace_free_oracle(d, btype):
+    """The device contraction against the oracle's trace-free formulation (itself pinned against
+    the reference's four-element-trace contraction for d <= 6), up to d = 16 where the N^4 trace
+    tensor would need 68 GB."""
+    rng = np.random.default_rng(d)
+    basis = ff.Basis.ggm(d) if btype == 'GGM' else ff.Basis.pauli(int(np.log2(d)))
+    N = d*d
+    gamma = rng.standard_normal((2, 3, N, N))
+    got = numeric._cumulant_function(gamma, basis)
+    ref = orc.cumulant_function(gamma, np.asarray(basis))
+    assert rel_err(got, ref) < 1e-12
+    if d <= 5:
+        assert rel_err(got, orc.cumulant_function_dense(gamma, np.asarray(basis))) < 1e-12
+
+
+def test_cumulant_and_etm_error_behaviour():
+    g = load_golden('etm')
+    pulse = etm_pulse(g, 'p4')
+    omega = g['p4_omega']
+    with pytest.raises(ValueError):
+        numeric.calculate_cumulant_function(pulse)
+    with pytest.raises(ValueError):
+        numeric.calculate_cumulant_function(pulse, g['p4_S1'], omega, which='correlations',
+                                            second_order=True)
+    with pytest.raises(NotImplementedError):
+        numeric.calculate_cumulant_function(pulse, g['p4_S1'], omega, second_order=True)
+    with pytest.raises(ValueError):
+        ff.error_transfer_matrix(pulse)
+    with pytest.raises(TypeError):
+        ff.error_transfer_matrix(cumulant_function=[[1.0]])
+    with pytest.raises(ValueError):
+        ff.error_transfer_matrix(cumulant_function=np.ones((3, 2)))
+    with pytest.raises(ValueError):
+        numeric.calculate_decay_amplitudes(pulse, np.ones((3, 5)), omega)
+    with pytest.raises(ValueError):
+        numeric.calculate_cumulant_function(pulse, decay_amplitudes=np.ones((3, 3)))

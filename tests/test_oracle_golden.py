@@ -196,3 +196,43 @@ def test_from_atomic():
     Rc = orc.control_matrix_from_atomic(g['phases'], g['R_atomic'], g['propagators_liouville'],
                                         which='correlations')
     assert rel_err(Rc, g['R_correlations']) < 1e-13
+
+
+ETM_CASES = [('q1', True), ('q1id', True), ('p4', False), ('g3', False), ('g6', False)]
+
+
+@pytest.mark.parametrize('name,single_qubit', ETM_CASES)
+def test_decay_amplitudes_cumulant_and_error_transfer_matrix(name, single_qubit):
+    """Oracle vs the reference's calculate_decay_amplitudes / calculate_cumulant_function /
+    error_transfer_matrix outputs (cases of the reference's tests/test_precision.py:631-727)."""
+    g = load_golden('etm')
+    basis, R, omega = g[f'{name}_basis'], g[f'{name}_control_matrix'], g[f'{name}_omega']
+    idx = np.arange(R.shape[0])
+    for i in (1, 2, 3):
+        S = g[f'{name}_S{i}']
+        gamma = orc.decay_amplitudes(R, S, omega, idx)
+        assert rel_err(gamma, g[f'{name}_decay_amplitudes_S{i}']) < 1e-14
+        K_ref = g[f'{name}_cumulant_function_S{i}']
+        assert rel_err(orc.cumulant_function_dense(gamma, basis, single_qubit), K_ref) < 1e-14
+        if not (single_qubit and i == 3):
+            # the trace-free formulation (what the device implements) is the general expression;
+            # the reference's single-qubit shortcut differs from it for cross-correlated spectra
+            # before the sum over operator pairs
+            assert rel_err(orc.cumulant_function(gamma, basis), K_ref) < 1e-14
+        K_sum = orc.cumulant_function(gamma, basis).sum(axis=tuple(range(gamma.ndim - 2)))
+        assert np.abs(K_sum - K_ref.sum(axis=tuple(range(gamma.ndim - 2)))).max() < 1e-20
+        U = orc.error_transfer_matrix(orc.cumulant_function_dense(gamma, basis, single_qubit))
+        assert np.abs(U - g[f'{name}_error_transfer_matrix_S{i}']).max() < 1e-15
+    sub = orc.decay_amplitudes(R, g[f'{name}_S1'], omega, g[f'{name}_sub_idx'])
+    assert rel_err(sub, g[f'{name}_decay_amplitudes_S1_sub']) < 1e-14
+
+
+def test_pulse_correlation_decay_amplitudes():
+    g = load_golden('etm')
+    gamma = orc.decay_amplitudes(g['pc_control_matrix'], g['pc_S2'], g['pc_omega'], np.arange(2),
+                                 which='correlations')
+    assert rel_err(gamma, g['pc_decay_amplitudes']) < 1e-14
+    K = orc.cumulant_function(gamma, g['pc_basis'])
+    assert rel_err(K, g['pc_cumulant_function']) < 1e-14
+    assert rel_err(K.sum(axis=(0, 1)), g['pc_cumulant_function_total']) < 1e-12
+    assert rel_err(orc.four_element_traces(g['g3_basis']), g['traces_ggm3']) < 1e-15
