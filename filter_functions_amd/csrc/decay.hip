@@ -97,17 +97,23 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) b[tn][c] = cmul(s, Rp[tn][wc]);
         }
+        // real parts of all tiles, then imaginary parts: consecutive MFMAs never share an
+        // accumulator (a dependent v_mfma_f64_16x16x4 waits out the 16 passes of its predecessor)
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 4; ++c) {
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
+                for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm][c].re, b[tn][c].re,
                                                                        acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
                     acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm][c].im, b[tn][c].im,
                                                                        acc[tm][tn], 0, 0, 0);
-                }
+        }
     }
     double* o = out + static_cast<size_t>(blockIdx.y)*split_stride +
                 static_cast<size_t>(blockIdx.x / tiles)*N*N;
@@ -143,7 +149,7 @@ struct DecayPlan {
 
 DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
     DecayPlan p;
-    const int t = N <= 16 ? 1 : 2;
+    const int t = N <= 16 ? 1 : (N < 128 ? 2 : 4);
     p.tm = p.tn = t;
     p.tiles_m = p.tiles_n = (N + 16*t - 1)/(16*t);
     p.batch = static_cast<size_t>(Gp)*Gp*n_idx*(s_ndim == 3 ? n_idx : 1);
@@ -301,8 +307,11 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
     if (p.tm == 1)
         hipLaunchKernelGGL((decay_gemm_kernel<1, 1>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
                            scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n);
-    else
+    else if (p.tm == 2)
         hipLaunchKernelGGL((decay_gemm_kernel<2, 2>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n);
+    else
+        hipLaunchKernelGGL((decay_gemm_kernel<4, 4>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
                            scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n);
     if (p.ksplit > 1)
         hipLaunchKernelGGL(reduce_splits_kernel, dim3(static_cast<unsigned>((n + 255)/256)),
