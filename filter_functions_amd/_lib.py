@@ -107,6 +107,9 @@ SIGNATURES = {
     'ffk_decay_amplitudes_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                          c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t,
                                          c_void_p]),
+    'ffk_decay_amplitudes_shard_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                               c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                               c_void_p, c_void_p, c_size_t, c_void_p]),
     'ffk_decay_amplitudes': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                      c_void_p, c_void_p, c_int, c_void_p]),
     'ffk_cumulant_function_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

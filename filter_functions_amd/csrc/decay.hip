@@ -24,15 +24,18 @@ namespace {
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
-// scale[row][w] = trapezoid weight(w) * S_row(w) / (2 pi)
+// scale[row][w] = trapezoid weight(w_offset + w) * S_row(w) / (2 pi); the weights are those of the
+// GLOBAL grid omega (Wg,), of which this call integrates the block [w_offset, w_offset + W)
 __global__ __launch_bounds__(256) void spectral_weights_kernel(const cplx* __restrict__ S, int rows,
                                                                int W,
                                                                const double* __restrict__ omega,
+                                                               int Wg, int w_offset,
                                                                cplx* __restrict__ scale) {
     const int w = blockIdx.x*256 + threadIdx.x;
     if (w >= W) return;
-    const double lo = w > 0 ? omega[w] - omega[w - 1] : 0.0;
-    const double hi = w < W - 1 ? omega[w + 1] - omega[w] : 0.0;
+    const int gw = w_offset + w;
+    const double lo = gw > 0 ? omega[gw] - omega[gw - 1] : 0.0;
+    const double hi = gw < Wg - 1 ? omega[gw + 1] - omega[gw] : 0.0;
     const double wgt = 0.5*(lo + hi)/(2.0*3.141592653589793);
     for (int r = blockIdx.y; r < rows; r += gridDim.y) {
         const cplx s = S[static_cast<size_t>(r)*W + w];
@@ -290,15 +293,16 @@ size_t decay_amplitudes_workspace_bytes(int Gp, int N, int W, int n_idx, int s_n
 }
 
 hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, const cplx* S,
-                                   int s_ndim, const double* omega, const int32_t* idx, int n_idx,
-                                   double* gamma, void* ws, hipStream_t stream) {
+                                   int s_ndim, const double* omega, int Wg, int w_offset,
+                                   const int32_t* idx, int n_idx, double* gamma, void* ws,
+                                   hipStream_t stream) {
     const DecayPlan p = decay_plan(Gp, N, W, n_idx, s_ndim);
     const int rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : n_idx*n_idx);
     unsigned char* base = static_cast<unsigned char*>(ws);
     cplx* scale = reinterpret_cast<cplx*>(base);
     double* part = reinterpret_cast<double*>(base + align_up(static_cast<size_t>(rows)*W*sizeof(cplx)));
     hipLaunchKernelGGL(spectral_weights_kernel, dim3((W + 255)/256, min(rows, 1024)), dim3(256), 0,
-                       stream, S, rows, W, omega, scale);
+                       stream, S, rows, W, omega, Wg, w_offset, scale);
     const size_t n = p.batch*N*N;
     const size_t blocks = p.batch*p.tiles_m*p.tiles_n;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;

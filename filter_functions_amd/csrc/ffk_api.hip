@@ -804,21 +804,33 @@ size_t ffk_decay_amplitudes_workspace_bytes(int n_pulses, int N, int W, int n_id
     return ffk::decay_amplitudes_workspace_bytes(n_pulses, N, W, n_idx, s_ndim);
 }
 
+int ffk_decay_amplitudes_shard_dev(const double* control_matrix, int n_pulses, int A, int N,
+                                   int W_block, const double* spectrum, int s_ndim,
+                                   const double* omega, int W, int w_offset, const int32_t* idx,
+                                   int n_idx, double* decay_amplitudes, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(control_matrix && spectrum && omega && idx && decay_amplitudes && workspace,
+                "NULL argument");
+    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
+    FFK_REQUIRE(n_pulses >= 1 && A >= 1 && N >= 1 && W_block >= 1 && n_idx >= 1, "empty axis");
+    FFK_REQUIRE(w_offset >= 0 && w_offset + W_block <= W, "frequency block [%d, %d) outside [0, %d)",
+                w_offset, w_offset + W_block, W);
+    FFK_REQUIRE(workspace_bytes >= ffk_decay_amplitudes_workspace_bytes(n_pulses, N, W_block, n_idx, s_ndim),
+                "workspace too small");
+    FFK_HIP(ffk::launch_decay_amplitudes(reinterpret_cast<const cplx*>(control_matrix), n_pulses, A,
+                                         N, W_block, reinterpret_cast<const cplx*>(spectrum), s_ndim,
+                                         omega, W, w_offset, idx, n_idx, decay_amplitudes, workspace,
+                                         static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
 int ffk_decay_amplitudes_dev(const double* control_matrix, int n_pulses, int A, int N, int W,
                              const double* spectrum, int s_ndim, const double* omega,
                              const int32_t* idx, int n_idx, double* decay_amplitudes,
                              void* workspace, size_t workspace_bytes, void* stream) {
-    FFK_REQUIRE(control_matrix && spectrum && omega && idx && decay_amplitudes && workspace,
-                "NULL argument");
-    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
-    FFK_REQUIRE(n_pulses >= 1 && A >= 1 && N >= 1 && W >= 1 && n_idx >= 1, "empty axis");
-    FFK_REQUIRE(workspace_bytes >= ffk_decay_amplitudes_workspace_bytes(n_pulses, N, W, n_idx, s_ndim),
-                "workspace too small");
-    FFK_HIP(ffk::launch_decay_amplitudes(reinterpret_cast<const cplx*>(control_matrix), n_pulses, A,
-                                         N, W, reinterpret_cast<const cplx*>(spectrum), s_ndim,
-                                         omega, idx, n_idx, decay_amplitudes, workspace,
-                                         static_cast<hipStream_t>(stream)));
-    return FFK_OK;
+    return ffk_decay_amplitudes_shard_dev(control_matrix, n_pulses, A, N, W, spectrum, s_ndim, omega,
+                                          W, 0, idx, n_idx, decay_amplitudes, workspace,
+                                          workspace_bytes, stream);
 }
 
 int ffk_decay_amplitudes(const double* control_matrix, int n_pulses, int A, int N, int W,

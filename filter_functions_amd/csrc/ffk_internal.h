@@ -139,11 +139,13 @@ hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int
 
 // ---- decay.hip -------------------------------------------------------------------------------
 // Gamma (Gp,Gp,n_idx[,n_idx],N,N) f64 from R (Gp,A,N,W) c128 (Gp = 1: the total control matrix),
-// S c128 (W,), (n_idx,W) or (n_idx,n_idx,W)
+// S c128 (W,), (n_idx,W) or (n_idx,n_idx,W); omega (Wg,) is the global grid of which R and S hold
+// the block [w_offset, w_offset + W)
 size_t decay_amplitudes_workspace_bytes(int Gp, int N, int W, int n_idx, int s_ndim);
 hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, const cplx* S,
-                                   int s_ndim, const double* omega, const int32_t* idx, int n_idx,
-                                   double* gamma, void* ws, hipStream_t stream);
+                                   int s_ndim, const double* omega, int Wg, int w_offset,
+                                   const int32_t* idx, int n_idx, double* gamma, void* ws,
+                                   hipStream_t stream);
 // K (batch,N,N) f64 from Gamma (batch,N,N) f64 and the basis (N,d,d)
 size_t cumulant_workspace_bytes(size_t batch, int N, int d);
 hipError_t launch_cumulant_function(const double* gamma, size_t batch, int N, int d,

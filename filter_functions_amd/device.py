@@ -113,3 +113,44 @@ class DevicePipeline:
                                      p(idx), n_idx, self.d, p(out), p(self._iws), need,
                                      ctypes.c_void_p(s)))
         return out
+
+    def decay_amplitudes(self, omega_global=None, w_offset=0, stream=None):
+        """Decay amplitudes of the noise operators selected by ``set_spectrum`` from the device
+        control matrix of the last ``launch`` (``ffk_decay_amplitudes_shard_dev``): tensor
+        ``(n_idx[, n_idx], N, N)``.  With *omega_global* (device tensor, the full grid) and
+        *w_offset*, this block's contribution to the integral over the full grid (multi-GPU)."""
+        torch = self.torch
+        if self.spectrum is None:
+            raise ValueError('set_spectrum() first')
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        omega = self.omega if omega_global is None else omega_global
+        shape = (self.n_idx, self.n_idx, self.N, self.N) if self.s_ndim == 3 else \
+            (self.n_idx, self.N, self.N)
+        out = torch.empty(shape, dtype=torch.float64, device=self.device)
+        lib = _lib.load()
+        need = lib.ffk_decay_amplitudes_workspace_bytes(1, self.N, self.W, self.n_idx, self.s_ndim)
+        if getattr(self, '_dws', None) is None or self._dws.numel() < need:
+            self._dws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+        p = self._p
+        check(lib.ffk_decay_amplitudes_shard_dev(
+            p(self.control_matrix), 1, self.A, self.N, self.W, p(self.spectrum), self.s_ndim,
+            p(omega), omega.numel(), int(w_offset), p(self.idx), self.n_idx, p(out), p(self._dws),
+            need, ctypes.c_void_p(s)))
+        return out
+
+    def cumulant_function(self, decay_amplitudes, single_qubit=False, stream=None):
+        """First-order cumulant function of device decay amplitudes ``(..., N, N)``."""
+        torch = self.torch
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        gamma = decay_amplitudes.contiguous()
+        batch = gamma.numel()//(self.N*self.N)
+        out = torch.empty_like(gamma)
+        lib = _lib.load()
+        need = 0 if single_qubit else lib.ffk_cumulant_function_workspace_bytes(batch, self.N, self.d)
+        if getattr(self, '_cws', None) is None or self._cws.numel() < need:
+            self._cws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+        p = self._p
+        check(lib.ffk_cumulant_function_dev(p(gamma), batch, self.N, self.d, p(self.basis),
+                                            int(single_qubit), p(out), p(self._cws), need,
+                                            ctypes.c_void_p(s)))
+        return out

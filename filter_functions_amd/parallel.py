@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-__all__ = ['shard_bounds', 'gather_omega_shards', 'sharded_filter_function']
+__all__ = ['shard_bounds', 'gather_omega_shards', 'sharded_filter_function', 'sum_omega_shards']
 
 
 def shard_bounds(n_omega, world_size, rank):
@@ -75,3 +75,27 @@ def sharded_filter_function(compute_shard, omega, group=None):
     w0, w1 = shard_bounds(len(omega), world, rank)
     local = compute_shard(omega[w0:w1])
     return gather_omega_shards(local, len(omega), group=group)
+
+
+def sum_omega_shards(local, group=None):
+    """Sum per-rank contributions to an integral over omega (decay amplitudes: each rank
+    integrates its block with the global trapezoid weights, ``ffk_decay_amplitudes_shard_dev``)
+    on every rank.  The partial results are all-gathered and added in rank order, so the sum is
+    bit-reproducible and identical on all ranks (a ring all-reduce adds in a rank-dependent
+    order); the payload is tiny (n_nops * d^4 doubles)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if world == 1 and not os.environ.get('FFK_FORCE_COLLECTIVE'):
+        return local
+    flat = local.contiguous()
+    recv = torch.empty((world,) + flat.shape, dtype=flat.dtype, device=flat.device)
+    if dist.get_backend(group) == 'gloo':
+        dist.all_gather(list(recv.unbind(0)), flat, group=group)
+    else:
+        dist.all_gather_into_tensor(recv, flat, group=group)
+    total = recv[0].clone()
+    for r in range(1, world):
+        total += recv[r]
+    return total

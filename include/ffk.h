@@ -213,6 +213,16 @@ int ffk_decay_amplitudes_dev(const double* control_matrix, int n_pulses, int A, 
 int ffk_decay_amplitudes(const double* control_matrix, int n_pulses, int A, int N, int W,
                          const double* spectrum, int s_ndim, const double* omega,
                          const int32_t* idx, int n_idx, double* decay_amplitudes);
+/* The contribution of one frequency block to the same integral (multi-GPU path):
+ * control_matrix (n_pulses, A, N, W_block) and spectrum ([[n_idx,] n_idx,] W_block) hold the
+ * frequencies [w_offset, w_offset + W_block) of the global grid omega (W,); the trapezoid
+ * weights are those of the global grid, so the blocks' results add up to ffk_decay_amplitudes
+ * of the whole grid.                                                                           */
+int ffk_decay_amplitudes_shard_dev(const double* control_matrix, int n_pulses, int A, int N,
+                                   int W_block, const double* spectrum, int s_ndim,
+                                   const double* omega, int W, int w_offset, const int32_t* idx,
+                                   int n_idx, double* decay_amplitudes, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* ---- numeric.calculate_cumulant_function, first order (numeric.py:957-1191) ----------------
  * decay_amplitudes (batch, N, N) f64 (any leading axes flattened into batch), basis (N, d, d)

@@ -400,6 +400,24 @@ def decay_amplitudes(control_matrix, spectrum, omega, idx, which='total'):
     return integrate(integrand, omega)/(2*np.pi)
 
 
+def decay_amplitudes_shard(control_matrix_block, spectrum_block, omega, w_offset, idx):
+    """Contribution of the frequency block [w_offset, w_offset + Wb) to decay_amplitudes(...,
+    which='total') over the global grid omega: the trapezoid written as a weighted sum,
+    sum_i w_i f_i with w_i = (omega_{i+1} - omega_{i-1})/2 (one-sided at the ends)."""
+    omega = np.asarray(omega, dtype=float)
+    R = np.asarray(control_matrix_block)[np.asarray(idx)]
+    Wb = R.shape[-1]
+    wgt = np.zeros(len(omega))
+    wgt[:-1] += 0.5*np.diff(omega)
+    wgt[1:] += 0.5*np.diff(omega)
+    S = parse_spectrum(spectrum_block, np.empty(Wb), np.asarray(idx))*wgt[w_offset:w_offset + Wb]
+    if S.ndim in (1, 2):
+        integrand = np.einsum('...ko,...o,...lo->...kl', R.conj(), S, R)
+    else:
+        integrand = np.einsum('ako,abo,blo->abkl', R.conj(), S, R)
+    return integrand.real/(2*np.pi)
+
+
 def four_element_traces(basis):
     """T_ijkl = tr(C_i C_j C_k C_l), filter_functions/basis.py:330-348 (dense; small d only)."""
     C = np.asarray(basis)

@@ -671,3 +671,31 @@ def test_cumulant_and_etm_error_behaviour():
         numeric.calculate_decay_amplitudes(pulse, np.ones((3, 5)), omega)
     with pytest.raises(ValueError):
         numeric.calculate_cumulant_function(pulse, decay_amplitudes=np.ones((3, 3)))
+
+
+def test_decay_amplitudes_from_logical_omega_shards():
+    """Device-resident path of the multi-GPU error-transfer-matrix run on one GPU: two frequency
+    blocks, each integrated with the global trapezoid weights, add up to the unsharded result."""
+    import torch
+    from filter_functions_amd.device import DevicePipeline
+    from filter_functions_amd.parallel import shard_bounds
+    g = load_golden('etm')
+    name = 'g6'
+    omega, S = g[f'{name}_omega'], g[f'{name}_S3']
+    args = (g[f'{name}_c_opers'], g[f'{name}_c_coeffs'], g[f'{name}_n_opers'],
+            g[f'{name}_n_coeffs'], g[f'{name}_dt'], g[f'{name}_basis'])
+    omega_dev = torch.from_numpy(omega).cuda()
+    total = None
+    for rank in range(2):
+        w0, w1 = shard_bounds(len(omega), 2, rank)
+        pipe = DevicePipeline(*args, omega[w0:w1], spectrum=S[..., w0:w1])
+        pipe.launch(with_infidelity=False)
+        part = pipe.decay_amplitudes(omega_global=omega_dev, w_offset=w0)
+        total = part if total is None else total + part
+    ref = g[f'{name}_decay_amplitudes_S3']
+    assert rel_err(total.cpu().numpy(), ref) < TOL
+    K = pipe.cumulant_function(total).cpu().numpy()
+    assert rel_err(K, g[f'{name}_cumulant_function_S3']) < TOL
+    whole = DevicePipeline(*args, omega, spectrum=S)
+    whole.launch(with_infidelity=False)
+    assert rel_err(whole.decay_amplitudes().cpu().numpy(), ref) < TOL

@@ -46,7 +46,15 @@ def _worker(rank, world, port, n_omega, out_dir):
     w0, w1 = shard_bounds(n_omega, world, rank)
     local = torch.arange(w0, w1, dtype=torch.float64).repeat(2, 1)*(1.0)
     idx = gather_omega_shards(local, n_omega).numpy()
-    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), F=F, idx=idx)
+    # decay amplitudes: per-rank partial integrals with the global trapezoid weights, summed in
+    # rank order on every rank (sum_omega_shards)
+    from filter_functions_amd.parallel import sum_omega_shards
+    e = np.load(os.path.join(ROOT, 'tests', 'golden', 'etm.npz'))
+    R, S, om = e['g3_control_matrix'], e['g3_S2'], e['g3_omega']
+    b0, b1 = shard_bounds(len(om), world, rank)
+    part = orc.decay_amplitudes_shard(R[..., b0:b1], S[..., b0:b1], om, b0, np.arange(len(R)))
+    gamma = sum_omega_shards(torch.from_numpy(part)).numpy()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), F=F, idx=idx, gamma=gamma)
     dist.destroy_process_group()
 
 
@@ -68,6 +76,11 @@ def test_sharded_filter_function_matches_unsharded(tmp_path, n_omega):
         # width; the layout/gather logic itself is exact (integer payload below)
         assert np.abs(got['F'] - F_ref).max() <= 1e-13*np.abs(F_ref).max()
         assert np.array_equal(got['idx'], np.tile(np.arange(n_omega, dtype=float), (2, 1)))
+    e = np.load(os.path.join(ROOT, 'tests', 'golden', 'etm.npz'))
+    gammas = [np.load(os.path.join(str(tmp_path), f'rank{r}.npz'))['gamma'] for r in range(world)]
+    assert np.array_equal(gammas[0], gammas[1])            # rank-order sum: identical everywhere
+    ref = e['g3_decay_amplitudes_S2']
+    assert np.abs(gammas[0] - ref).max() <= 1e-13*np.abs(ref).max()
 
 
 def test_shard_bounds_partition():
