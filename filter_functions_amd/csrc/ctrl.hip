@@ -27,6 +27,7 @@
 //     60 % of its wave cycles in s_waitcnt lgkmcnt(0) (profiles/r01_b_*).
 //   * Double-buffered LDS: one barrier per segment.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "ffk_internal.h"
@@ -709,15 +710,27 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     }
     const int jb = accum_jb(d);
     const int ntasks = A*(d / jb);
-    // waves per block: all tasks if they fit (<= 8 waves), otherwise the divisor-friendly
-    // largest count <= 8 so that the generated integral is shared as widely as possible.
+    // waves per block: all tasks if they fit (<= 8 waves); otherwise the count in 5..8 that
+    // minimises (task groups) x (per-wave share of the integral generation + one task's
+    // contraction), in VALU instructions per segment: every task group regenerates the integral,
+    // and wider blocks also raise the occupancy (measured at d = 8, A = 9: 8 waves x 5 groups
+    // 11.3 ms, 6 x 6 12.8 ms, 4 x 9 17.4 ms).
     int nw = ntasks <= 8 ? ntasks : 8;
     if (ntasks > 8) {
-        for (int c = 8; c >= 5; --c)
-            if (ntasks % c == 0) {
+        const double gen = 35.0*(d*(d - 1) + 1);
+        const double contr = 4.0*d*d*(2*jb + 1);
+        double best = 0.0;
+        for (int c = 8; c >= 5; --c) {
+            const double cost = ((ntasks + c - 1)/c)*(gen/c + contr);
+            if (c == 8 || cost < best) {
+                best = cost;
                 nw = c;
-                break;
             }
+        }
+    }
+    if (const char* env = std::getenv("FFK_TUNE_NWAVES")) {   // tuning only
+        const int v = std::atoi(env);
+        if (v >= 1 && v <= 8) nw = std::min(v, ntasks);
     }
     geo.nwaves = nw;
     geo.task_groups = (ntasks + nw - 1)/nw;
@@ -732,16 +745,25 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     geo.gsplit = 1;
     // Segment chunks.  Every block runs its whole chunk, so the launch is fastest when the grid is
     // a whole number of "rounds" of resident blocks (profiles/r01_a_chunk_sweep.txt: 16 chunks =
-    // 1024 blocks = exactly one round beat 22 chunks by 25 %): pick the chunk count that fills
-    // one round, or the largest that still gives every chunk >= 4 segments.
+    // 1024 blocks = exactly one round beat 22 chunks by 25 %).  Model: rounds x (segments per
+    // chunk + ~2 segments' worth of prologue/epilogue), minimised over the chunk count with every
+    // chunk keeping >= 4 segments.
     const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups;
     int chunks = forced_chunks;
     if (chunks <= 0) {
         const long capacity = static_cast<long>(device_cu_count())*
                               query_blocks_per_cu(d, nw, geo.nbuf, geo.lds_bytes);
-        chunks = static_cast<int>(std::max<long>(1, capacity / std::max<long>(1, tiles)));
-        const int max_chunks = std::max(1, (G + 3)/4);  // keep >= 4 segments per chunk
-        chunks = std::min(chunks, max_chunks);
+        const int max_chunks = std::max(1, std::min((G + 3)/4, 256));  // keep >= 4 segments per chunk
+        double best = 0.0;
+        chunks = 1;
+        for (int c = 1; c <= max_chunks; ++c) {
+            const long rounds = (tiles*c + capacity - 1)/capacity;
+            const double cost = static_cast<double>(rounds)*((G + c - 1)/c + 2);
+            if (c == 1 || cost < best*0.999) {
+                best = cost;
+                chunks = c;
+            }
+        }
         // fold a factor kGsplit of the split into the block (same number of waves in flight,
         // kGsplit x fewer partial sums) when the block stays within 16 waves and the LDS
         if (g_use_gsplit && d <= kGsplitMaxD && nw <= kGsplitMaxNW && geo.nbuf == 2 &&
