@@ -76,6 +76,10 @@ SIGNATURES = {
                                        c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                        c_int, c_uint, c_void_p, c_void_p, c_void_p, c_size_t,
                                        c_void_p]),
+    'ffk_noise_operators_intermediates': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                  c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p]),
     'ffk_control_matrix_intermediates': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                                  c_void_p, c_int, c_void_p, c_int, c_void_p,
                                                  c_void_p, c_void_p, c_int, c_int, c_void_p,

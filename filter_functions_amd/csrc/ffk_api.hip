@@ -485,17 +485,19 @@ int ffk_control_matrix(const double* eigvals, const double* eigvecs, const doubl
     return FFK_OK;
 }
 
-int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvecs,
-                                     const double* propagators, const double* omega, int W,
-                                     const double* basis, int N, const double* n_opers, int A,
-                                     const double* n_coeffs, const double* dt, const double* t, int G,
-                                     int d, double* n_opers_transformed, double* eigvecs_propagated,
-                                     double* basis_transformed, double* phase_factors,
-                                     double* first_order_integral, double* control_matrix_step) {
+static int intermediates_impl(const double* eigvals, const double* eigvecs,
+                              const double* propagators, const double* omega, int W,
+                              const double* basis, int N, const double* n_opers, int A,
+                              const double* n_coeffs, const double* dt, const double* t, int G,
+                              int d, double* n_opers_transformed, double* eigvecs_propagated,
+                              double* basis_transformed, double* phase_factors,
+                              double* first_order_integral, double* control_matrix_step,
+                              double* noise_operators_step) {
     FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
-    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && basis && n_opers && n_coeffs && dt && t,
+    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && n_opers && n_coeffs && dt && t,
                 "NULL argument");
+    FFK_REQUIRE(basis || !(basis_transformed || control_matrix_step), "basis is NULL");
     FFK_REQUIRE(size_t(G)*A <= 65535, "G*A = %zu too large for the materialising variant", size_t(G)*A);
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t dd = size_t(d)*d;
@@ -510,8 +512,10 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
     if (basis_transformed) total += align_up(16*size_t(G)*N*dd);
     if (phase_factors) total += align_up(16*size_t(G)*W);
     if (first_order_integral) total += align_up(16*size_t(G)*W*dd);
+    if (control_matrix_step || noise_operators_step) total += align_up(16*size_t(G)*A*dd*W);
     if (control_matrix_step)
-        total += align_up(16*size_t(G)*A*dd*W) + align_up(16*size_t(G)*A*N*W) + ffk::expand_workspace_bytes(N, d);
+        total += align_up(16*size_t(G)*A*N*W) + ffk::expand_workspace_bytes(N, d);
+    if (noise_operators_step) total += align_up(16*size_t(G)*W*A*dd);
     void* base;
     if (int rc = arena_reserve(total, &base)) return rc;
     Bump a(base, g_arena.size);
@@ -532,7 +536,8 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
     cplx* dbt = basis_transformed ? a.take<cplx>(size_t(G)*N*dd) : nullptr;
     cplx* dph = phase_factors ? a.take<cplx>(size_t(G)*W) : nullptr;
     cplx* dint = first_order_integral ? a.take<cplx>(size_t(G)*W*dd) : nullptr;
-    cplx* Ypart = control_matrix_step ? a.take<cplx>(size_t(G)*A*dd*W) : nullptr;
+    cplx* Ypart = (control_matrix_step || noise_operators_step) ? a.take<cplx>(size_t(G)*A*dd*W) : nullptr;
+    cplx* dnstep = noise_operators_step ? a.take<cplx>(size_t(G)*W*A*dd) : nullptr;
     cplx* dstep = control_matrix_step ? a.take<cplx>(size_t(G)*A*N*W) : nullptr;
     void* dews = control_matrix_step ? a.take<unsigned char>(ffk::expand_workspace_bytes(N, d)) : nullptr;
     FFK_REQUIRE(a.used <= g_arena.size, "internal: arena too small");
@@ -546,7 +551,7 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
     FFK_HIP(h2d(dV, eigvecs, 16*size_t(G)*dd));
     FFK_HIP(h2d(dQ, propagators, 16*size_t(G + 1)*dd));
     FFK_HIP(h2d(dom, omega, 8*size_t(W)));
-    FFK_HIP(h2d(dbasis, basis, 16*size_t(N)*dd));
+    if (basis) FFK_HIP(h2d(dbasis, basis, 16*size_t(N)*dd));
     FFK_HIP(h2d(dnop, n_opers, 16*size_t(A)*dd));
     FFK_HIP(h2d(dnc, n_coeffs, 8*size_t(A)*G));
     FFK_HIP(h2d(ddt, dt, 8*size_t(G)));
@@ -554,20 +559,50 @@ int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvec
     FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dnop, dnc, ddt, dtt, G, d, A, segtab, Tc, ops, dnt, dep, nullptr));
     if (dbt) FFK_HIP(ffk::launch_basis_transformed(Tc, dbasis, G, N, d, dbt, nullptr));
     FFK_HIP(ffk::launch_phase_and_integral(dom, W, segtab, G, d, dph, dint, nullptr));
-    if (dstep) {
-        // one chunk per segment: Ypart[g] is that segment's Hilbert-space step, expanded in the basis
+    if (Ypart) {
+        // one chunk per segment: Ypart[g] is that segment's Hilbert-space step
         ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, G);
         FFK_HIP(ffk::launch_accumulate(dom, W, segtab, ops, G, d, A, geo, Ypart, nullptr));
-        FFK_HIP(ffk::launch_expand(Ypart, dbasis, G*A, N, d, W, dstep, dews, false, nullptr));
     }
+    if (dstep)    // ... expanded in the basis
+        FFK_HIP(ffk::launch_expand(Ypart, dbasis, G*A, N, d, W, dstep, dews, false, nullptr));
+    if (dnstep)   // ... or re-laid out as (W, A, d, d) per segment
+        for (int g = 0; g < G; ++g)
+            FFK_HIP(ffk::launch_transpose_noise_ops(Ypart + size_t(g)*A*dd*W, A, d, W,
+                                                    dnstep + size_t(g)*W*A*dd, nullptr));
     if (n_opers_transformed) FFK_HIP(d2h(n_opers_transformed, dnt, 16*size_t(A)*G*dd));
     if (eigvecs_propagated) FFK_HIP(d2h(eigvecs_propagated, dep, 16*size_t(G)*dd));
     if (basis_transformed) FFK_HIP(d2h(basis_transformed, dbt, 16*size_t(G)*N*dd));
     if (phase_factors) FFK_HIP(d2h(phase_factors, dph, 16*size_t(G)*W));
     if (first_order_integral) FFK_HIP(d2h(first_order_integral, dint, 16*size_t(G)*W*dd));
     if (control_matrix_step) FFK_HIP(d2h(control_matrix_step, dstep, 16*size_t(G)*A*N*W));
+    if (noise_operators_step) FFK_HIP(d2h(noise_operators_step, dnstep, 16*size_t(G)*W*A*dd));
     FFK_HIP(hipStreamSynchronize(nullptr));
     return FFK_OK;
+}
+
+int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvecs,
+                                     const double* propagators, const double* omega, int W,
+                                     const double* basis, int N, const double* n_opers, int A,
+                                     const double* n_coeffs, const double* dt, const double* t, int G,
+                                     int d, double* n_opers_transformed, double* eigvecs_propagated,
+                                     double* basis_transformed, double* phase_factors,
+                                     double* first_order_integral, double* control_matrix_step) {
+    FFK_REQUIRE(basis, "NULL argument");
+    return intermediates_impl(eigvals, eigvecs, propagators, omega, W, basis, N, n_opers, A, n_coeffs,
+                              dt, t, G, d, n_opers_transformed, eigvecs_propagated, basis_transformed,
+                              phase_factors, first_order_integral, control_matrix_step, nullptr);
+}
+
+int ffk_noise_operators_intermediates(const double* eigvals, const double* eigvecs,
+                                      const double* propagators, const double* omega, int W,
+                                      const double* n_opers, int A, const double* n_coeffs,
+                                      const double* dt, const double* t, int G, int d,
+                                      double* n_opers_transformed, double* phase_factors,
+                                      double* first_order_integral, double* noise_operators_step) {
+    return intermediates_impl(eigvals, eigvecs, propagators, omega, W, nullptr, 1, n_opers, A,
+                              n_coeffs, dt, t, G, d, n_opers_transformed, nullptr, nullptr,
+                              phase_factors, first_order_integral, nullptr, noise_operators_step);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -158,16 +158,26 @@ def calculate_noise_operators_from_scratch(eigvals, eigvecs, propagators, omega,
     (n_omega, n_nops, d, d) (reference numeric.py:456-618)."""
     (eigvals, eigvecs, propagators, omega, n_opers, n_coeffs, dt, t,
      G, d, A) = _prepare(eigvals, eigvecs, propagators, omega, n_opers, n_coeffs, dt, t)
-    if cache_intermediates:
-        raise NotImplementedError('cache_intermediates is provided for the control matrix '
-                                  '(Liouville) variant only.')
     W = len(omega)
     B = np.empty((W, A, d, d), dtype=np.complex128)
     if W > 0:
         check(_lib.load().ffk_control_matrix(
             ptr(eigvals), ptr(eigvecs), ptr(propagators), ptr(omega), W, None, 1, ptr(n_opers), A,
             ptr(n_coeffs), ptr(dt), ptr(t), G, d, _lib.WANT_NOISE_OPERATORS, None, ptr(B)))
-    return B
+    if not cache_intermediates:
+        return B
+    # the reference's step caches (numeric.py:586-615), materialised by a second pass
+    inter = dict(n_opers_transformed=np.empty((A, G, d, d), dtype=np.complex128),
+                 first_order_integral=np.empty((G, W, d, d), dtype=np.complex128),
+                 phase_factors=np.empty((G, W), dtype=np.complex128),
+                 noise_operators_step=np.empty((G, W, A, d, d), dtype=np.complex128))
+    if W > 0:
+        check(_lib.load().ffk_noise_operators_intermediates(
+            ptr(eigvals), ptr(eigvecs), ptr(propagators), ptr(omega), W, ptr(n_opers), A,
+            ptr(n_coeffs), ptr(dt), ptr(t), G, d, ptr(inter['n_opers_transformed']),
+            ptr(inter['phase_factors']), ptr(inter['first_order_integral']),
+            ptr(inter['noise_operators_step'])))
+    return B, inter
 
 
 @util.parse_optional_parameters(which=('fidelity', 'generalized'))

@@ -132,6 +132,15 @@ int ffk_control_matrix_intermediates(
     const double* n_coeffs, const double* dt, const double* t, int G, int d,
     double* n_opers_transformed, double* eigvecs_propagated, double* basis_transformed,
     double* phase_factors, double* first_order_integral, double* control_matrix_step);
+/* The cache_intermediates products of calculate_noise_operators_from_scratch
+ * (numeric.py:586-615): n_opers_transformed (A, G, d, d), phase_factors (G, W),
+ * first_order_integral (G, W, d, d), noise_operators_step (G, W, A, d, d) c128 (any may be NULL). */
+int ffk_noise_operators_intermediates(const double* eigvals, const double* eigvecs,
+                                      const double* propagators, const double* omega, int W,
+                                      const double* n_opers, int A, const double* n_coeffs,
+                                      const double* dt, const double* t, int G, int d,
+                                      double* n_opers_transformed, double* phase_factors,
+                                      double* first_order_integral, double* noise_operators_step);
 
 /* ---- numeric.calculate_control_matrix_from_atomic (numeric.py:621-704; caller
  *      pulse_sequence.concatenate pulse_sequence.py:1858) -- the concatenation rule -----------

@@ -293,7 +293,7 @@ def control_matrix_from_scratch(eigvals, eigvecs, propagators, omega, basis, n_o
 
 
 def noise_operators_from_scratch(eigvals, eigvecs, propagators, omega, n_opers, n_coeffs, dt,
-                                 t=None):
+                                 t=None, cache_intermediates=False):
     """Hilbert-space twin, result (W, A, d, d).
 
     filter_functions/numeric.py:456-618:
@@ -310,11 +310,17 @@ def noise_operators_from_scratch(eigvals, eigvecs, propagators, omega, n_opers, 
     _, Bbar = _prologue(eigvals, eigvecs, propagators, n_opers, n_coeffs)
     P = eigvecs.conj().transpose(0, 2, 1) @ propagators[:-1]       # (G,d,d)
     out = np.zeros((W, A, d, d), dtype=complex)
+    steps = np.empty((G, W, A, d, d), dtype=complex) if cache_intermediates else None
     for g in range(G):
         phase = cexp(omega*t[g])
         integral = first_order_integral(omega, eigvals[g], dt[g])*phase[:, None, None]
         X = Bbar[None, :, g]*integral[:, None]                     # (W,A,d,d)
-        out += P[g].conj().T @ X @ P[g]
+        step = P[g].conj().T @ X @ P[g]
+        if cache_intermediates:
+            steps[g] = step                                         # 'noise_operators_step', :611-615
+        out += step
+    if cache_intermediates:
+        return out, dict(noise_operators_step=steps)
     return out
 
 

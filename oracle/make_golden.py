@@ -191,9 +191,28 @@ def make_etm():
     save('etm', **arrays)
 
 
+def make_noise_operator_steps():
+    """11. cache_intermediates products of calculate_noise_operators_from_scratch
+    (numeric.py:586-615) on a small GGM d=3 pulse."""
+    rng = np.random.default_rng(61)
+    pulse = rand_pulse(3, 4, 2, 2, 'GGM', rng)
+    omega = np.concatenate(([0.0, 1e-10], np.geomspace(1e-2, 30, 7), [-0.7]))
+    pulse.diagonalize()
+    B, inter = numeric.calculate_noise_operators_from_scratch(
+        pulse.eigvals, pulse.eigvecs, pulse.propagators, omega, pulse.n_opers, pulse.n_coeffs,
+        pulse.dt, pulse.t, cache_intermediates=True)
+    arrays = dict(pulse_inputs(pulse), omega=omega, eigvals=pulse.eigvals, eigvecs=pulse.eigvecs,
+                  propagators=pulse.propagators, t=pulse.t, noise_operators=B)
+    arrays.update({f'inter_{k}': v for k, v in inter.items()})
+    save('noise_operator_steps', **arrays)
+
+
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == 'etm':   # only the newest fixture
+    if len(sys.argv) > 1 and sys.argv[1] == 'etm':   # only the newest fixtures
         make_etm()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'nops':
+        make_noise_operator_steps()
         return
     X, Y, Z = util.paulis[1:]
 
@@ -411,6 +430,7 @@ def main():
          cexp_in=x*1e3, cexp_out=util.cexp(x*1e3), cexpm1_out=util.cexpm1(x*1e3 - 5e3))
 
     make_etm()
+    make_noise_operator_steps()
 
 
 if __name__ == '__main__':

@@ -699,3 +699,21 @@ def test_decay_amplitudes_from_logical_omega_shards():
     whole = DevicePipeline(*args, omega, spectrum=S)
     whole.launch(with_infidelity=False)
     assert rel_err(whole.decay_amplitudes().cpu().numpy(), ref) < TOL
+
+
+def test_noise_operator_step_cache():
+    """cache_intermediates products of calculate_noise_operators_from_scratch
+    (reference numeric.py:586-615)."""
+    g = load_golden('noise_operator_steps')
+    B, inter = numeric.calculate_noise_operators_from_scratch(
+        g['eigvals'], g['eigvecs'], g['propagators'], g['omega'], g['n_opers'], g['n_coeffs'],
+        g['dt'], g['t'], cache_intermediates=True)
+    assert rel_err(B, g['noise_operators']) < TOL
+    assert sorted(inter) == ['first_order_integral', 'n_opers_transformed', 'noise_operators_step',
+                             'phase_factors']
+    for key in ('first_order_integral', 'phase_factors', 'noise_operators_step'):
+        assert inter[key].shape == g[f'inter_{key}'].shape
+        assert rel_err(inter[key], g[f'inter_{key}']) < TOL
+    # the eigenvectors are inputs here, so the transformed operators are comparable directly
+    assert rel_err(inter['n_opers_transformed'], g['inter_n_opers_transformed']) < TOL
+    assert rel_err(inter['noise_operators_step'].sum(axis=0), B) < 1e-13

@@ -236,3 +236,12 @@ def test_pulse_correlation_decay_amplitudes():
     assert rel_err(K, g['pc_cumulant_function']) < 1e-14
     assert rel_err(K.sum(axis=(0, 1)), g['pc_cumulant_function_total']) < 1e-12
     assert rel_err(orc.four_element_traces(g['g3_basis']), g['traces_ggm3']) < 1e-15
+
+
+def test_noise_operator_step_cache():
+    g = load_golden('noise_operator_steps')
+    B, inter = orc.noise_operators_from_scratch(g['eigvals'], g['eigvecs'], g['propagators'],
+                                                g['omega'], g['n_opers'], g['n_coeffs'], g['dt'],
+                                                g['t'], cache_intermediates=True)
+    assert rel_err(B, g['noise_operators']) < 1e-13
+    assert rel_err(inter['noise_operators_step'], g['inter_noise_operators_step']) < 1e-13
