@@ -56,7 +56,7 @@ class DevicePipeline:
         self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, **kw)
 
     def _upload(self, arr, dtype):
-        return self.torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(self.device)
+        return self.torch.from_numpy(np.require(arr, dtype=dtype, requirements=['C', 'W'])).to(self.device)
 
     def set_spectrum(self, spectrum, idx=None):
         from . import util
