@@ -42,6 +42,7 @@ constexpr int kGsplitMaxD = 4;
 constexpr int kGsplitMaxNW = 4;
 bool g_use_gsplit = true;
 bool g_use_wave_kernel = false;   // tuning/testing: one-wave-per-block variant for d <= 4
+int g_mfma_policy = 0;            // 0: matrix-core kernel for d >= 12, 1: never, 2: also d = 8
 
 // MR = integral rows generated per LDS stage.  MR == D (one stage per segment, diagonal computed
 // once, optionally double-buffered) whenever the D*D*64 tile fits the 160 KiB LDS; MR < D splits
@@ -683,10 +684,41 @@ int device_cu_count() {
 
 void set_use_wave_kernel(bool on) { g_use_wave_kernel = on; }
 void set_use_gsplit(bool on) { g_use_gsplit = on; }
+void set_mfma_policy(int policy) { g_mfma_policy = policy; }
 
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks) {
     AccumGeometry geo;
     geo.gsplit = 1;
+    geo.mfma = mfma_accumulate_supported(d) && g_mfma_policy != 1 && (d >= 12 || g_mfma_policy == 2);
+    if (geo.mfma) {
+        // one wavefront per noise operator, 16 frequencies per block, one block per CU
+        geo.wave_kernel = false;
+        geo.nwaves = mfma_accumulate_waves();
+        geo.task_groups = (A + geo.nwaves - 1)/geo.nwaves;
+        geo.na_blk = geo.nwaves;
+        geo.nbuf = 1;
+        geo.lds_bytes = mfma_accumulate_lds_bytes(d);
+        const long tiles = static_cast<long>((W + 15)/16)*geo.task_groups;
+        int chunks = forced_chunks;
+        if (chunks <= 0) {
+            const long capacity = device_cu_count();
+            const int max_chunks = std::max(1, std::min((G + 3)/4, 256));
+            double best = 0.0;
+            chunks = 1;
+            for (int c = 1; c <= max_chunks; ++c) {
+                const long rounds = (tiles*c + capacity - 1)/capacity;
+                const double cost = static_cast<double>(rounds)*((G + c - 1)/c + 1);
+                if (c == 1 || cost < best*0.999) {
+                    best = cost;
+                    chunks = c;
+                }
+            }
+        }
+        chunks = std::max(1, std::min(chunks, G));
+        geo.chunk_len = (G + chunks - 1)/chunks;
+        geo.chunks = (G + geo.chunk_len - 1)/geo.chunk_len;
+        return geo;
+    }
     geo.wave_kernel = d <= kWaveKernelMaxD && g_use_wave_kernel;
     if (geo.wave_kernel) {
         // one wave per block, up to 3 noise operators per lane; blocks per CU = 4 (1 wave/SIMD)
@@ -784,6 +816,9 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
                              hipStream_t stream) {
+    if (geo.mfma)
+        return launch_accumulate_mfma(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len,
+                                      Ypart, stream);
     switch (d) {
 #define FFK_CASE(D) \
     case D:         \

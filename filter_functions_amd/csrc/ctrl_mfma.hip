@@ -1,0 +1,259 @@
+// ctrl_mfma.hip -- K3m: the control-matrix accumulation for large Hilbert spaces (d = 8, 12, 16) on
+// the FP64 matrix cores.  Same mathematics, inputs and output layout as ctrl.hip:
+//     Y_a(w) = sum_g T_g^dag [ Bbar_a^(g) o E^(g)(w) ] T_g ,   E = e^{i w t_g} I^(g)(w),
+// but the two d x d products per (segment, frequency, noise operator) run as v_mfma_f64_16x16x4
+// with the FREQUENCY as the column index of the tile:
+//     step 1, per row m:   Z_m[j, w]  = sum_n  T[n, j]        X_m[n, w],   X_m[n, w] = Bbar[m, n] E[m, n](w)
+//     step 2, per column j: Y[i, j, w] += sum_m conj(T[m, i]) Z_m[j, w].
+// A operands (16 x 4: i = lane & 15, k = lane >> 4) are the frequency-independent T; B operands
+// (4 x 16: k = lane >> 4, col = lane & 15) are the per-frequency X / Z; a tile covers 16
+// frequencies.  Step 1 leaves Z_m[j = q + 4r, w_c] in lane (c, q), step 2 wants
+// Z_{m = 4 mg + q}[j, w_c] there: a 4 x 4 transpose across the four 16-lane rows of the wavefront,
+// done with v_permlane16_swap / v_permlane32_swap (gfx950) -- no LDS round trip.
+// One wavefront owns one noise operator: its d x d x 16 complex accumulators are 128 f64 per lane
+// (the reason the VALU kernel can only afford 1-2 columns of Y per wave at d = 16, regenerating
+// the integral for every column block).  The 4 waves of a block share the generated E tile
+// (d^2 entries x 16 frequencies, 64 KiB at d = 16) through LDS.
+#include <algorithm>
+
+#include "ffk_internal.h"
+
+namespace ffk {
+namespace {
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+constexpr int kMW = 4;   // wavefronts (= noise operators) per block, one per SIMD
+
+// 2 x 2 transposes between two registers and the 16-lane rows (bit 0 / bit 1 of the row index)
+__device__ __forceinline__ void swap_rows16(double& a, double& b) {
+    unsigned alo = static_cast<unsigned>(__double2loint(a)), ahi = static_cast<unsigned>(__double2hiint(a));
+    unsigned blo = static_cast<unsigned>(__double2loint(b)), bhi = static_cast<unsigned>(__double2hiint(b));
+    auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0]));
+    b = __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
+}
+__device__ __forceinline__ void swap_rows32(double& a, double& b) {
+    unsigned alo = static_cast<unsigned>(__double2loint(a)), ahi = static_cast<unsigned>(__double2hiint(a));
+    unsigned blo = static_cast<unsigned>(__double2loint(b)), bhi = static_cast<unsigned>(__double2hiint(b));
+    auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0]));
+    b = __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
+}
+// v[k] in row q  <-  v[q] in row k   (rows = lane >> 4)
+__device__ __forceinline__ void transpose_rows(double (&v)[4]) {
+    swap_rows16(v[0], v[1]);
+    swap_rows16(v[2], v[3]);
+    swap_rows32(v[0], v[2]);
+    swap_rows32(v[1], v[3]);
+}
+
+template <int D>
+struct MfmaLayout {
+    static constexpr int S = seg_stride(D);
+    static constexpr int DD = D*D;
+    static constexpr int kTile = DD*16;                   // cplx: E[m*D + n][16 frequencies]
+    static constexpr int kOps = (1 + kMW)*DD;             // cplx per operand buffer
+    static constexpr int kStageElems = kOps + S/2;        // cplx staged per segment
+    static constexpr int kStagePerThread = (kStageElems + kMW*64 - 1)/(kMW*64);
+    static constexpr size_t lds_bytes = (static_cast<size_t>(kTile) + 2*kOps)*sizeof(cplx) +
+                                        2*static_cast<size_t>(S)*sizeof(double);
+};
+
+template <int D>
+__global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ segtab,
+    const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
+    static_assert(D % 4 == 0 && D >= 8 && D <= 16, "d must be 8, 12 or 16");
+    using L = MfmaLayout<D>;
+    constexpr int S = L::S, DD = L::DD, NS = D/4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    cplx* tile = reinterpret_cast<cplx*>(lds_raw);
+    cplx* opsb = tile + L::kTile;
+    double* rows = reinterpret_cast<double*>(opsb + 2*L::kOps);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int iw = blockIdx.x*16 + c;
+    const double om = omega[iw < W ? iw : W - 1];
+    const int alpha0 = blockIdx.y*kMW;
+    const int alpha = alpha0 + wave;
+    const bool active = alpha < A;
+    const int n_alpha = min(kMW, A - alpha0);
+    const int n_ops = (1 + n_alpha)*DD;
+    const int g0 = blockIdx.z*chunk_len;
+    const int g1 = min(G, g0 + chunk_len);
+
+    f64x4 Yr[D], Yi[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        Yr[j] = {0.0, 0.0, 0.0, 0.0};
+        Yi[j] = {0.0, 0.0, 0.0, 0.0};
+    }
+
+    // staging copy of segment g: operands (T_g, Bbar of this block's operators) -> opsb[buf],
+    // table row -> rows[slot]; loads issued before the contraction, parked after it
+    cplx staged[L::kStagePerThread];
+    auto issue_stage = [&](int g) {
+        const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*DD;
+        const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
+#pragma unroll
+        for (int k = 0; k < L::kStagePerThread; ++k) {
+            const int e = tid + k*kMW*64;
+            if (e < n_ops)
+                staged[k] = src_ops[e < DD ? e : e + alpha0*DD];
+            else if (e < n_ops + S/2)
+                staged[k] = src_tab[e - n_ops];
+        }
+    };
+    auto park = [&](int buf) {
+        cplx* dst_ops = opsb + buf*L::kOps;
+        cplx* dst_tab = reinterpret_cast<cplx*>(rows + buf*S);
+#pragma unroll
+        for (int k = 0; k < L::kStagePerThread; ++k) {
+            const int e = tid + k*kMW*64;
+            if (e < n_ops)
+                dst_ops[e] = staged[k];
+            else if (e < n_ops + S/2)
+                dst_tab[e - n_ops] = staged[k];
+        }
+    };
+
+    // generation: thread (wave, q, c) -> entries (wave*4 + q) + 16 s of frequency c
+    auto generate = [&](int slot) {
+        const double* st = rows + slot*S;
+        const double dtg = st[0];
+        cplx ph;
+        sincos_pi<true>(om*st[1], &ph.im, &ph.re);
+        double sa, ca;
+        sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
+        const int eg = wave*4 + q;
+#pragma unroll 4
+        for (int s = 0; s < DD/16; ++s) {
+            const int e = eg + 16*s;
+            const double* r = st + seg_rec(e);
+            tile[e*16 + c] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+        }
+    };
+
+    auto contract = [&](int buf) {
+        const cplx* opT = opsb + buf*L::kOps;
+        const cplx* opB = opT + (1 + wave)*DD;
+        // A operand of both steps: T[4 s + q][c]  (rows beyond d contribute zeros)
+        double tr[NS], ti[NS], nti[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            cplx t = {0.0, 0.0};
+            if (c < D) t = opT[(4*s + q)*D + c];
+            tr[s] = t.re;
+            ti[s] = t.im;
+            nti[s] = -t.im;
+        }
+#pragma unroll
+        for (int mg = 0; mg < NS; ++mg) {
+            f64x4 Zr[4], Zi[4];
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                const int m = 4*mg + mm;
+                Zr[mm] = {0.0, 0.0, 0.0, 0.0};
+                Zi[mm] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int n = 4*s + q;
+                    const cplx x = cmul(opB[m*D + n], tile[(m*D + n)*16 + c]);
+                    Zr[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[s], x.re, Zr[mm], 0, 0, 0);
+                    Zi[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[s], x.im, Zi[mm], 0, 0, 0);
+                    Zr[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(nti[s], x.im, Zr[mm], 0, 0, 0);
+                    Zi[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[s], x.re, Zi[mm], 0, 0, 0);
+                }
+            }
+            // lane (c, q) holds Z_{4 mg + mm}[j = q + 4 r]; step 2 needs Z_{4 mg + q}[j = qo + 4 r]
+#pragma unroll
+            for (int r = 0; r < (D + 3)/4; ++r) {
+                double zr[4] = {Zr[0][r], Zr[1][r], Zr[2][r], Zr[3][r]};
+                double zi[4] = {Zi[0][r], Zi[1][r], Zi[2][r], Zi[3][r]};
+                transpose_rows(zr);
+                transpose_rows(zi);
+#pragma unroll
+                for (int qo = 0; qo < 4; ++qo) {
+                    const int j = qo + 4*r;
+                    if (j >= D) continue;
+                    // Y[i, j] += conj(T[m, i]) Z_m[j]
+                    Yr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[mg], zr[qo], Yr[j], 0, 0, 0);
+                    Yi[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[mg], zi[qo], Yi[j], 0, 0, 0);
+                    Yr[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[mg], zi[qo], Yr[j], 0, 0, 0);
+                    Yi[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(nti[mg], zr[qo], Yi[j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // prologue: segment g0's operands and table row straight into buffer 0
+    if (g0 < g1) {
+        issue_stage(g0);
+        park(0);
+    }
+    for (int g = g0; g < g1; ++g) {
+        const int buf = (g - g0) & 1;
+        __syncthreads();                 // tile free, staged data of segment g visible
+        generate(buf);
+        __syncthreads();
+        if (g + 1 < g1) issue_stage(g + 1);
+        if (active) contract(buf);
+        if (g + 1 < g1) park(buf ^ 1);
+    }
+
+    if (active && iw < W) {
+        cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W + iw;
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = q + 4*r;
+                if (i < D) out[static_cast<size_t>(i*D + j)*W] = {Yr[j][r], Yi[j][r]};
+            }
+    }
+}
+
+template <int D>
+hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
+                    int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
+    auto kern = ctrl_accumulate_mfma_kernel<D>;
+    const int lds = static_cast<int>(MfmaLayout<D>::lds_bytes);
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) return err;
+    const dim3 grid((W + 15)/16, (A + kMW - 1)/kMW, chunks);
+    hipLaunchKernelGGL(kern, grid, dim3(kMW*64), lds, stream, omega, W, segtab, ops, G, A, chunk_len,
+                       Ypart);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool mfma_accumulate_supported(int d) { return d == 8 || d == 12 || d == 16; }
+int mfma_accumulate_waves() { return kMW; }
+int mfma_accumulate_lds_bytes(int d) {
+    switch (d) {
+        case 8: return static_cast<int>(MfmaLayout<8>::lds_bytes);
+        case 12: return static_cast<int>(MfmaLayout<12>::lds_bytes);
+        case 16: return static_cast<int>(MfmaLayout<16>::lds_bytes);
+        default: return 0;
+    }
+}
+
+hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segtab, const cplx* ops,
+                                  int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
+                                  hipStream_t stream) {
+    switch (d) {
+        case 8: return launch_d<8>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
+        case 12: return launch_d<12>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
+        case 16: return launch_d<16>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ffk

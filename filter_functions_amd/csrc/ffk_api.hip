@@ -246,9 +246,10 @@ int ffk_set_segment_chunks(int chunks) {
     return FFK_OK;
 }
 int ffk_set_accumulate_variant(int variant) {
-    FFK_REQUIRE(variant >= 0 && variant <= 2, "variant must be 0, 1 or 2");
+    FFK_REQUIRE(variant >= 0 && variant <= 4, "variant must be 0..4");
     ffk::set_use_wave_kernel(variant == 1);
     ffk::set_use_gsplit(variant != 2);
+    ffk::set_mfma_policy(variant == 3 ? 1 : (variant == 4 ? 2 : 0));
     return FFK_OK;
 }
 int ffk_set_accumulate_events(void* start, void* stop) {
@@ -418,7 +419,7 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     g_stats.accumulate_bytes = double(sizeof(cplx))*(double(geo.chunks)*slab) + 8.0*W +
                                double(sizeof(cplx))*G*(double(1 + A)*d*d);
     g_stats.chunks = geo.chunks;
-    g_stats.grid_x = (W + 63)/64;
+    g_stats.grid_x = geo.mfma ? (W + 15)/16 : (W + 63)/64;
     g_stats.grid_y = geo.task_groups;
     g_stats.grid_z = geo.chunks;
     g_stats.block = geo.nwaves*geo.gsplit*64;

@@ -97,14 +97,24 @@ struct AccumGeometry {
     int na_blk;       // noise operators whose Bbar one block stages in LDS
     bool wave_kernel; // small-d one-wave-per-block variant
     int gsplit;       // sub-chunks per block (in-block segment split), 1 = none
+    bool mfma;        // large-d matrix-core kernel (ctrl_mfma.hip): 16 frequencies per block
 };
 void set_use_wave_kernel(bool on);
 void set_use_gsplit(bool on);
+void set_mfma_policy(int policy);   // 0 default (d >= 12), 1 never, 2 wherever supported (d = 8 too)
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks);
 // Ypart (chunks, A, d, d, W): partial Hilbert-space sums, omega fastest
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
                              hipStream_t stream);
+
+// ---- ctrl_mfma.hip ---------------------------------------------------------------------------
+bool mfma_accumulate_supported(int d);
+int mfma_accumulate_waves();
+int mfma_accumulate_lds_bytes(int d);
+hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segtab, const cplx* ops,
+                                  int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
+                                  hipStream_t stream);
 
 // ---- post.hip --------------------------------------------------------------------------------
 // Bt (A,d,d,W) = sum over chunks of Ypart

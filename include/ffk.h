@@ -281,7 +281,8 @@ int ffk_set_segment_chunks(int chunks);
 /* Kernel variant of the control-matrix accumulation: 0 = default (multi-wave blocks sharing the
  * generated integral through LDS), 1 = one-wave-per-block variant for d <= 4 (kept for tuning;
  * measured slower on MI355X because its 48 accumulators per lane spill into AGPRs),
- * 2 = default kernel without the in-block segment split (tuning).                            */
+ * 2 = default kernel without the in-block segment split (tuning), 3 = never use the matrix-core
+ * kernel (d >= 12 use it by default), 4 = use the matrix-core kernel wherever it exists (d = 8 too). */
 int ffk_set_accumulate_variant(int variant);
 /* Per-call statistics of the last ffk_control_matrix*_dev launch on this thread:
  * algorithmic FP64 flops of the accumulate kernel, its grid/block geometry, chunks used.   */

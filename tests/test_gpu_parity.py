@@ -717,3 +717,44 @@ def test_noise_operator_step_cache():
     # the eigenvectors are inputs here, so the transformed operators are comparable directly
     assert rel_err(inter['n_opers_transformed'], g['inter_n_opers_transformed']) < TOL
     assert rel_err(inter['noise_operators_step'].sum(axis=0), B) < 1e-13
+
+
+@pytest.mark.parametrize('d,G,A,W', [(8, 7, 3, 100), (12, 5, 5, 33), (16, 6, 2, 16), (16, 3, 9, 50),
+                                      (8, 20, 1, 257)])
+def test_matrix_core_accumulate_kernel_matches_vector_kernel(d, G, A, W):
+    """ctrl_mfma.hip (v_mfma_f64_16x16x4, frequency = tile column) against ctrl.hip on the same
+    inputs: ragged frequency tiles (W not a multiple of 16), operator counts that do not fill a
+    block, d = 12 (partial tiles), several segment chunks."""
+    rng = np.random.default_rng(d*1000 + W)
+    basis = ff.Basis.ggm(d)
+    c_opers = rng.standard_normal((3, d, d)) + 1j*rng.standard_normal((3, d, d))
+    c_opers = c_opers + c_opers.conj().transpose(0, 2, 1)
+    n_opers = rng.standard_normal((A, d, d)) + 1j*rng.standard_normal((A, d, d))
+    n_opers = n_opers + n_opers.conj().transpose(0, 2, 1)
+    H = np.einsum('ijk,il->ljk', c_opers, rng.standard_normal((3, G)))
+    dt = 0.5 + rng.random(G)
+    n_coeffs = rng.random((A, G)) + 0.5
+    omega = np.concatenate(([0.0], np.geomspace(1e-3, 50, W - 1)))
+    D, V, Q = numeric.diagonalize(H, dt)
+    lib = _lib.load()
+    try:
+        _lib.check(lib.ffk_set_accumulate_variant(3))
+        R_vec = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers,
+                                                              n_coeffs, dt)
+        _lib.check(lib.ffk_set_accumulate_variant(4))
+        R_mat = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers,
+                                                              n_coeffs, dt)
+        assert _lib.stats()['block'] == 256
+        for chunks in (2, 3):
+            _lib.check(lib.ffk_set_segment_chunks(chunks))
+            R_c = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers,
+                                                                n_coeffs, dt)
+            assert rel_err(R_c, R_mat) < 1e-13
+    finally:
+        _lib.check(lib.ffk_set_segment_chunks(0))
+        _lib.check(lib.ffk_set_accumulate_variant(0))
+    assert rel_err(R_mat, R_vec) < 1e-12
+    t = np.concatenate(([0], dt.cumsum()))
+    R_orc = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), n_opers, n_coeffs,
+                                            dt, t)
+    assert rel_err(R_mat, R_orc) < TOL
