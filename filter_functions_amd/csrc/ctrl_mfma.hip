@@ -157,17 +157,32 @@ __global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
             f64x4 Zr[4], Zi[4];
 #pragma unroll
             for (int mm = 0; mm < 4; ++mm) {
-                const int m = 4*mg + mm;
                 Zr[mm] = {0.0, 0.0, 0.0, 0.0};
                 Zi[mm] = {0.0, 0.0, 0.0, 0.0};
+            }
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const int n = 4*s + q;
-                    const cplx x = cmul(opB[m*D + n], tile[(m*D + n)*16 + c]);
-                    Zr[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[s], x.re, Zr[mm], 0, 0, 0);
-                    Zi[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[s], x.im, Zi[mm], 0, 0, 0);
-                    Zr[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(nti[s], x.im, Zr[mm], 0, 0, 0);
-                    Zi[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[s], x.re, Zi[mm], 0, 0, 0);
+            for (int s = 0; s < NS; ++s) {
+                const int n = 4*s + q;
+                cplx x[4];
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) {
+                    const int m = 4*mg + mm;
+#if defined(FFK_M_ABLATE) && FFK_M_ABLATE == 4      /* diagnostic: no LDS operands */
+                    x[mm] = {om + m, om - n};
+#else
+                    x[mm] = cmul(opB[m*D + n], tile[(m*D + n)*16 + c]);
+#endif
+                }
+                // eight independent accumulators between two uses of the same one
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) {
+                    Zr[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[s], x[mm].re, Zr[mm], 0, 0, 0);
+                    Zi[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[s], x[mm].im, Zi[mm], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) {
+                    Zr[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(nti[s], x[mm].im, Zr[mm], 0, 0, 0);
+                    Zi[mm] = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[s], x[mm].re, Zi[mm], 0, 0, 0);
                 }
             }
             // lane (c, q) holds Z_{4 mg + mm}[j = q + 4 r]; step 2 needs Z_{4 mg + q}[j = qo + 4 r]
@@ -175,8 +190,10 @@ __global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
             for (int r = 0; r < (D + 3)/4; ++r) {
                 double zr[4] = {Zr[0][r], Zr[1][r], Zr[2][r], Zr[3][r]};
                 double zi[4] = {Zi[0][r], Zi[1][r], Zi[2][r], Zi[3][r]};
+#if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 3)   /* diagnostic: no transposes (wrong results) */
                 transpose_rows(zr);
                 transpose_rows(zi);
+#endif
 #pragma unroll
                 for (int qo = 0; qo < 4; ++qo) {
                     const int j = qo + 4*r;
@@ -199,10 +216,14 @@ __global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
     for (int g = g0; g < g1; ++g) {
         const int buf = (g - g0) & 1;
         __syncthreads();                 // tile free, staged data of segment g visible
+#if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 1)   /* diagnostic build 1: no generation */
         generate(buf);
+#endif
         __syncthreads();
         if (g + 1 < g1) issue_stage(g + 1);
+#if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 2)   /* diagnostic build 2: no contraction */
         if (active) contract(buf);
+#endif
         if (g + 1 < g1) park(buf ^ 1);
     }
 
