@@ -758,3 +758,18 @@ def test_matrix_core_accumulate_kernel_matches_vector_kernel(d, G, A, W):
     R_orc = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), n_opers, n_coeffs,
                                             dt, t)
     assert rel_err(R_mat, R_orc) < TOL
+
+
+@pytest.mark.parametrize('A,N,W', [(5, 9, 100), (7, 16, 257), (13, 4, 64), (18, 25, 130)])
+def test_filter_function_many_noise_operators(A, N, W):
+    """Blocked F kernel (A > 4): against the oracle, exactly Hermitian in the operator indices,
+    bit-identical to the pairwise kernel's summation order (checked through a 4-operator slice)."""
+    rng = np.random.default_rng(A*W)
+    R = rng.standard_normal((A, N, W)) + 1j*rng.standard_normal((A, N, W))
+    F = numeric.calculate_filter_function(R)
+    assert F.shape == (A, A, W)
+    assert rel_err(F, orc.filter_function(R)) < 1e-14
+    assert np.array_equal(F, F.conj().transpose(1, 0, 2))
+    assert np.all(F[np.arange(A), np.arange(A)].imag == 0)
+    sub = numeric.calculate_filter_function(R[:4])            # pairwise kernel
+    assert np.array_equal(sub, F[:4, :4])
