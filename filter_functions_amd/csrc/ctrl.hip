@@ -693,15 +693,17 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     if (geo.mfma) {
         // one wavefront per noise operator, 16 frequencies per block, one block per CU
         geo.wave_kernel = false;
-        geo.nwaves = mfma_accumulate_waves();
+        geo.nwaves = mfma_accumulate_waves(d, A);
         geo.task_groups = (A + geo.nwaves - 1)/geo.nwaves;
         geo.na_blk = geo.nwaves;
         geo.nbuf = 1;
-        geo.lds_bytes = mfma_accumulate_lds_bytes(d);
+        geo.lds_bytes = mfma_accumulate_lds_bytes(d, geo.nwaves);
         const long tiles = static_cast<long>((W + 15)/16)*geo.task_groups;
         int chunks = forced_chunks;
         if (chunks <= 0) {
-            const long capacity = device_cu_count();
+            // resident blocks: one per CU for the 512-register kernel; for d = 8 two waves per SIMD
+            const long per_cu = d == 8 ? std::max(1, 8/geo.nwaves) : 1;
+            const long capacity = device_cu_count()*per_cu;
             const int max_chunks = std::max(1, std::min((G + 3)/4, 256));
             double best = 0.0;
             chunks = 1;
@@ -818,7 +820,7 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
                              hipStream_t stream) {
     if (geo.mfma)
         return launch_accumulate_mfma(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len,
-                                      Ypart, stream);
+                                      geo.nwaves, Ypart, stream);
     switch (d) {
 #define FFK_CASE(D) \
     case D:         \

@@ -239,6 +239,211 @@ __global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// d = 8: the same scheme on v_mfma_f64_4x4x4_4b (4 blocks of 4x4x4 per instruction), which has no
+// 16-row tile to leave half empty.  Layout (tools/mfma4_layout_probe.hip): with c = lane & 15,
+// q = lane >> 4 and block b = c >> 2,  A[i = c & 3][k = q] (per block),  B[k = q][col = c],
+// D[i = q][col = c]: again 16 frequencies as columns, 4 rows per instruction, A replicated over the
+// blocks.  Accumulators are one f64 per lane and (row group, column): 2 d^2/4 registers, so the
+// kernel runs at 2-3 waves per SIMD with NW wavefronts (= noise operators) per block.
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(512) void ctrl_accumulate_mfma4_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ segtab,
+    const cplx* __restrict__ ops, int G, int A, int chunk_len, int nw, cplx* __restrict__ Ypart) {
+    static_assert(D % 4 == 0 && D >= 4 && D <= 16, "d must be a multiple of 4");
+    constexpr int S = seg_stride(D), DD = D*D, NS = D/4;
+    constexpr int kMaxStage = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int kops = (1 + nw)*DD;
+    cplx* tile = reinterpret_cast<cplx*>(lds_raw);
+    cplx* opsb = tile + DD*16;
+    double* rows = reinterpret_cast<double*>(opsb + 2*kops);
+
+    const int tid = threadIdx.x;
+    const int nthreads = nw*64;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4, c4 = c & 3;
+    const int iw = blockIdx.x*16 + c;
+    const double om = omega[iw < W ? iw : W - 1];
+    const int alpha0 = blockIdx.y*nw;
+    const int alpha = alpha0 + wave;
+    const bool active = alpha < A;
+    const int n_alpha = min(nw, A - alpha0);
+    const int n_ops = (1 + n_alpha)*DD;
+    const int g0 = blockIdx.z*chunk_len;
+    const int g1 = min(G, g0 + chunk_len);
+
+    double Yr[NS][D], Yi[NS][D];
+#pragma unroll
+    for (int ig = 0; ig < NS; ++ig)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            Yr[ig][j] = 0.0;
+            Yi[ig][j] = 0.0;
+        }
+
+    cplx staged[kMaxStage];
+    auto issue_stage = [&](int g) {
+        const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*DD;
+        const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
+#pragma unroll
+        for (int k = 0; k < kMaxStage; ++k) {
+            const int e = tid + k*nthreads;
+            if (e < n_ops)
+                staged[k] = src_ops[e < DD ? e : e + alpha0*DD];
+            else if (e < n_ops + S/2)
+                staged[k] = src_tab[e - n_ops];
+        }
+    };
+    auto park = [&](int buf) {
+        cplx* dst_ops = opsb + buf*kops;
+        cplx* dst_tab = reinterpret_cast<cplx*>(rows + buf*S);
+#pragma unroll
+        for (int k = 0; k < kMaxStage; ++k) {
+            const int e = tid + k*nthreads;
+            if (e < n_ops)
+                dst_ops[e] = staged[k];
+            else if (e < n_ops + S/2)
+                dst_tab[e - n_ops] = staged[k];
+        }
+    };
+    auto generate = [&](int slot) {
+        const double* st = rows + slot*S;
+        const double dtg = st[0];
+        cplx ph;
+        sincos_pi<true>(om*st[1], &ph.im, &ph.re);
+        double sa, ca;
+        sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
+        for (int e = wave*4 + q; e < DD; e += 4*nw) {
+            const double* r = st + seg_rec(e);
+            tile[e*16 + c] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+        }
+    };
+    auto contract = [&](int buf) {
+        const cplx* opT = opsb + buf*kops;
+        const cplx* opB = opT + (1 + wave)*DD;
+        // A operands of both steps: T[4 s + q][4 jg + (c & 3)]
+        double tr[NS][NS], ti[NS][NS], nti[NS][NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int jg = 0; jg < NS; ++jg) {
+                const cplx t = opT[(4*s + q)*D + 4*jg + c4];
+                tr[s][jg] = t.re;
+                ti[s][jg] = t.im;
+                nti[s][jg] = -t.im;
+            }
+#pragma unroll
+        for (int mg = 0; mg < NS; ++mg) {
+            double zr[NS][4], zi[NS][4];   // [jg][mm]
+#pragma unroll
+            for (int jg = 0; jg < NS; ++jg)
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) {
+                    zr[jg][mm] = 0.0;
+                    zi[jg][mm] = 0.0;
+                }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int n = 4*s + q;
+                cplx x[4];
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) {
+                    const int m = 4*mg + mm;
+                    x[mm] = cmul(opB[m*D + n], tile[(m*D + n)*16 + c]);
+                }
+                // Z_m[j = 4 jg + q] += T[n, j] X_m[n]   (accumulators vary fastest)
+#pragma unroll
+                for (int jg = 0; jg < NS; ++jg)
+#pragma unroll
+                    for (int mm = 0; mm < 4; ++mm) {
+                        zr[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(tr[s][jg], x[mm].re, zr[jg][mm], 0, 0, 0);
+                        zi[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(tr[s][jg], x[mm].im, zi[jg][mm], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int jg = 0; jg < NS; ++jg)
+#pragma unroll
+                    for (int mm = 0; mm < 4; ++mm) {
+                        zr[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(nti[s][jg], x[mm].im, zr[jg][mm], 0, 0, 0);
+                        zi[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(ti[s][jg], x[mm].re, zi[jg][mm], 0, 0, 0);
+                    }
+            }
+            // lane (c, q) holds Z_{4 mg + mm}[4 jg + q]; step 2 needs Z_{4 mg + q}[4 jg + qo]
+#pragma unroll
+            for (int jg = 0; jg < NS; ++jg) {
+                transpose_rows(zr[jg]);
+                transpose_rows(zi[jg]);
+            }
+            // Y[i = 4 ig + q, j] += conj(T[m, i]) Z_m[j],  m = 4 mg + q
+#pragma unroll
+            for (int jg = 0; jg < NS; ++jg)
+#pragma unroll
+                for (int qo = 0; qo < 4; ++qo) {
+                    const int j = 4*jg + qo;
+#pragma unroll
+                    for (int ig = 0; ig < NS; ++ig) {
+                        Yr[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(tr[mg][ig], zr[jg][qo], Yr[ig][j], 0, 0, 0);
+                        Yi[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(tr[mg][ig], zi[jg][qo], Yi[ig][j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int ig = 0; ig < NS; ++ig) {
+                        Yr[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(ti[mg][ig], zi[jg][qo], Yr[ig][j], 0, 0, 0);
+                        Yi[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(nti[mg][ig], zr[jg][qo], Yi[ig][j], 0, 0, 0);
+                    }
+                }
+        }
+    };
+
+    if (g0 < g1) {
+        issue_stage(g0);
+        park(0);
+    }
+    for (int g = g0; g < g1; ++g) {
+        const int buf = (g - g0) & 1;
+        __syncthreads();
+        generate(buf);
+        __syncthreads();
+        if (g + 1 < g1) issue_stage(g + 1);
+        if (active) contract(buf);
+        if (g + 1 < g1) park(buf ^ 1);
+    }
+
+    if (active && iw < W) {
+        cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W + iw;
+#pragma unroll
+        for (int ig = 0; ig < NS; ++ig)
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                out[static_cast<size_t>((4*ig + q)*D + j)*W] = {Yr[ig][j], Yi[ig][j]};
+    }
+}
+
+template <int D>
+size_t mfma4_lds_bytes(int nw) {
+    return (static_cast<size_t>(D*D)*16 + 2*static_cast<size_t>(1 + nw)*D*D)*sizeof(cplx) +
+           2*static_cast<size_t>(seg_stride(D))*sizeof(double);
+}
+
+template <int D>
+hipError_t launch_d4(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
+                     int chunks, int chunk_len, int nw, cplx* Ypart, hipStream_t stream) {
+    auto kern = ctrl_accumulate_mfma4_kernel<D>;
+    const int lds = static_cast<int>(mfma4_lds_bytes<D>(nw));
+    // staging: (1 + nw) d^2 + row/2 elements over nw*64 threads must fit kMaxStage = 4 per thread
+    if ((1 + nw)*D*D + seg_stride(D)/2 > 4*nw*64) return hipErrorInvalidValue;
+    if (lds > 48*1024) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (err != hipSuccess) return err;
+    }
+    const dim3 grid((W + 15)/16, (A + nw - 1)/nw, chunks);
+    hipLaunchKernelGGL(kern, grid, dim3(nw*64), lds, stream, omega, W, segtab, ops, G, A, chunk_len,
+                       nw, Ypart);
+    return hipGetLastError();
+}
+
 template <int D>
 hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                     int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
@@ -256,10 +461,24 @@ hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx
 }  // namespace
 
 bool mfma_accumulate_supported(int d) { return d == 8 || d == 12 || d == 16; }
-int mfma_accumulate_waves() { return kMW; }
-int mfma_accumulate_lds_bytes(int d) {
+// waves (= noise operators) per block: 4 for the 16x16x4 kernel; for the 4x4x4 kernel (d = 8) the
+// count in 3..8 with the fewest idle wave slots (ties: the larger, which shares the generated
+// integral more widely)
+int mfma_accumulate_waves(int d, int A) {
+    if (d != 8) return kMW;
+    int best = 8, best_idle = 1 << 30;
+    for (int nw = 8; nw >= 3; --nw) {
+        const int idle = (A + nw - 1)/nw*nw - A;
+        if (idle < best_idle) {
+            best_idle = idle;
+            best = nw;
+        }
+    }
+    return std::min(best, std::max(A, 3));
+}
+int mfma_accumulate_lds_bytes(int d, int nw) {
     switch (d) {
-        case 8: return static_cast<int>(MfmaLayout<8>::lds_bytes);
+        case 8: return static_cast<int>(mfma4_lds_bytes<8>(nw));
         case 12: return static_cast<int>(MfmaLayout<12>::lds_bytes);
         case 16: return static_cast<int>(MfmaLayout<16>::lds_bytes);
         default: return 0;
@@ -267,10 +486,10 @@ int mfma_accumulate_lds_bytes(int d) {
 }
 
 hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segtab, const cplx* ops,
-                                  int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
-                                  hipStream_t stream) {
+                                  int G, int d, int A, int chunks, int chunk_len, int nw,
+                                  cplx* Ypart, hipStream_t stream) {
     switch (d) {
-        case 8: return launch_d<8>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
+        case 8: return launch_d4<8>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);
         case 12: return launch_d<12>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
         case 16: return launch_d<16>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
         default: return hipErrorInvalidValue;
