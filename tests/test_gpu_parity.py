@@ -754,6 +754,13 @@ def test_matrix_core_accumulate_kernel_matches_vector_kernel(d, G, A, W):
         _lib.check(lib.ffk_set_segment_chunks(0))
         _lib.check(lib.ffk_set_accumulate_variant(0))
     assert rel_err(R_mat, R_vec) < 1e-12
+    if d >= 12 and W <= 50:
+        # step cache through the matrix-core kernel (one segment per block)
+        R_i, inter = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers,
+                                                                   n_coeffs, dt,
+                                                                   cache_intermediates=True)
+        assert rel_err(inter['control_matrix_step'].sum(axis=0), R_mat) < 1e-12
+        assert rel_err(R_i, R_mat) < 1e-13
     t = np.concatenate(([0], dt.cumsum()))
     R_orc = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), n_opers, n_coeffs,
                                             dt, t)
