@@ -409,6 +409,15 @@ def test_control_matrix_from_atomic():
     got = numeric.calculate_control_matrix_from_atomic(ph, Ra, L)
     ref = orc.control_matrix_from_atomic(ph, Ra, L)
     assert rel_err(got, ref) < 1e-13
+    # larger bases (d = 8 and 16: N = 64, 256), ragged omega
+    for G, A, N, W in ((4, 2, 64, 70), (3, 1, 256, 33)):
+        Ra = rng.standard_normal((G, A, N, W)) + 1j*rng.standard_normal((G, A, N, W))
+        ph = np.exp(1j*rng.standard_normal((G - 1, W)))
+        L = rng.standard_normal((G - 1, N, N))
+        got = numeric.calculate_control_matrix_from_atomic(ph, Ra, L)
+        assert rel_err(got, orc.control_matrix_from_atomic(ph, Ra, L)) < 1e-13
+        gotc = numeric.calculate_control_matrix_from_atomic(ph, Ra, L, which='correlations')
+        assert rel_err(gotc, orc.control_matrix_from_atomic(ph, Ra, L, 'correlations')) < 1e-13
 
 
 def test_concatenate_matches_from_scratch_and_reference():
