@@ -100,6 +100,10 @@ SIGNATURES = {
                                                            c_void_p]),
     'ffk_filter_function': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ffk_filter_function_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'ffk_filter_function_weighted': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double,
+                                             c_void_p]),
+    'ffk_filter_function_weighted_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double,
+                                                 c_void_p, c_void_p]),
     'ffk_infidelity': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                c_int, c_void_p]),
     'ffk_infidelity_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

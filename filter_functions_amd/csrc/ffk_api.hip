@@ -744,6 +744,38 @@ int ffk_filter_function_dev(const double* control_matrix, int A, int N, int W, i
     return FFK_OK;
 }
 
+int ffk_filter_function_weighted_dev(const double* control_matrix, int A, int N, int W,
+                                     const double* weights, double scale, double* filter_function,
+                                     void* stream) {
+    FFK_REQUIRE(control_matrix && weights && filter_function, "NULL argument");
+    FFK_REQUIRE(A >= 1 && N >= 1 && W >= 1, "empty axis: A=%d N=%d W=%d", A, N, W);
+    FFK_HIP(ffk::launch_filter_function_weighted(reinterpret_cast<const cplx*>(control_matrix), A, N, W,
+                                                 reinterpret_cast<const cplx*>(weights), scale,
+                                                 reinterpret_cast<cplx*>(filter_function),
+                                                 static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+int ffk_filter_function_weighted(const double* control_matrix, int A, int N, int W,
+                                 const double* weights, double scale, double* filter_function) {
+    FFK_REQUIRE(control_matrix && weights && filter_function, "NULL argument");
+    FFK_REQUIRE(A >= 1 && N >= 1 && W >= 1, "empty axis: A=%d N=%d W=%d", A, N, W);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nR = 16*size_t(A)*N*W, nM = 16*size_t(N)*N, nF = 16*size_t(A)*A*W;
+    void* base;
+    if (int rc = arena_reserve(align_up(nR) + align_up(nM) + align_up(nF), &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dR = a.take<double>(nR/8);
+    double* dM = a.take<double>(nM/8);
+    double* dF = a.take<double>(nF/8);
+    FFK_HIP(hipMemcpyAsync(dR, control_matrix, nR, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dM, weights, nM, hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_filter_function_weighted_dev(dR, A, N, W, dM, scale, dF, nullptr)) return rc;
+    FFK_HIP(hipMemcpyAsync(filter_function, dF, nF, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
 int ffk_filter_function(const double* control_matrix, int A, int N, int W, int which,
                         double* filter_function) {
     FFK_REQUIRE(control_matrix && filter_function, "NULL argument");

@@ -133,6 +133,8 @@ hipError_t launch_transpose_noise_ops(const cplx* Bt, int A, int d, int W, cplx*
                                       hipStream_t stream);
 hipError_t launch_filter_function(const cplx* R, int A, int N, int W, int which, cplx* F,
                                   hipStream_t stream);
+hipError_t launch_filter_function_weighted(const cplx* R, int A, int N, int W, const cplx* M,
+                                           double scale, cplx* F, hipStream_t stream);
 size_t infidelity_workspace_bytes(int W, int n_idx, int s_ndim);
 hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_ndim,
                              const double* omega, const int32_t* idx, int n_idx, int d,

@@ -186,6 +186,25 @@ __global__ __launch_bounds__(128) void ff_fidelity_blocked_kernel(const cplx* __
         }
 }
 
+// F[a,b,w] = scale * sum_kl conj(R[a,k,w]) M[k,l] R[b,l,w]   ('ako,blo,kl->abo', the filter
+// function of a basis that is not traceless, numeric.py:2295-2305; M from the four-element traces)
+__global__ __launch_bounds__(128) void ff_weighted_kernel(const cplx* __restrict__ R, int A, int N,
+                                                          int W, const cplx* __restrict__ M,
+                                                          double scale, cplx* __restrict__ F) {
+    const int w = blockIdx.x*blockDim.x + threadIdx.x;
+    const int a = blockIdx.y / A, b = blockIdx.y % A;
+    if (w >= W) return;
+    const cplx* ra = R + static_cast<size_t>(a)*N*W + w;
+    const cplx* rb = R + static_cast<size_t>(b)*N*W + w;
+    cplx acc = {0.0, 0.0};
+    for (int k = 0; k < N; ++k) {
+        cplx u = {0.0, 0.0};                       // sum_l M[k,l] R[b,l,w]
+        for (int l = 0; l < N; ++l) cmac(u, M[k*N + l], rb[static_cast<size_t>(l)*W]);
+        cmac_conj(acc, ra[static_cast<size_t>(k)*W], u);
+    }
+    F[(static_cast<size_t>(a)*A + b)*W + w] = {scale*acc.re, scale*acc.im};
+}
+
 // F[a,b,k,l,w] = conj(R[a,k,w]) R[b,l,w]        ('ako,blo->abklo', numeric.py:1465).
 // Plain multiply / subtract (no FMA contraction across the two products) so that
 // F[b,a,l,k] == conj(F[a,b,k,l]) holds exactly, as it does for NumPy's complex multiply.
@@ -346,6 +365,15 @@ hipError_t launch_filter_function(const cplx* R, int A, int N, int W, int which,
         hipLaunchKernelGGL(ff_generalized_kernel, dim3((W + block - 1)/block, N*N, A*A), dim3(block),
                            0, stream, R, A, N, W, F);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_function_weighted(const cplx* R, int A, int N, int W, const cplx* M,
+                                           double scale, cplx* F, hipStream_t stream) {
+    const int block = 128;
+    if (A*A > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ff_weighted_kernel, dim3((W + block - 1)/block, A*A), dim3(block), 0, stream,
+                       R, A, N, W, M, scale, F);
     return hipGetLastError();
 }
 

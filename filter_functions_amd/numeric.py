@@ -262,13 +262,22 @@ def infidelity(pulse, spectrum, omega, n_oper_identifiers=None, which='total',
     spectrum = np.asanyarray(spectrum)
     if which == 'total':
         if not pulse.basis.istraceless:
-            raise NotImplementedError(
-                'infidelity() for a basis that is not traceless needs the four-element trace '
-                'tensor (reference numeric.py:2295-2305), which is outside the accelerated path '
-                'in this release.')
-        filter_function = pulse.get_filter_function(omega, which='fidelity',
-                                                    show_progressbar=show_progressbar,
-                                                    cache_intermediates=cache_intermediates)
+            # Fidelity is not simply the sum over the diagonal of the decay amplitudes: the trace
+            # tensor enters (reference numeric.py:2295-2305).  Its two partial traces are formed
+            # here without the N^4 tensor, the contraction with the control matrix runs on device.
+            C = np.asarray(pulse.basis)
+            P = np.einsum('mab,mbc->ac', C, C)                       # sum_m C_m C_m
+            Q = np.einsum('mab,lbc,mcd->lad', C, C, C)               # sum_m C_m C_l C_m
+            weights = as_c128(np.einsum('kab,lbc,ca->kl', C, C, P) - np.einsum('kab,lba->kl', C, Q))
+            R = as_c128(pulse.get_control_matrix(omega, show_progressbar, cache_intermediates))
+            A, N, W = R.shape
+            filter_function = np.empty((A, A, W), dtype=np.complex128)
+            check(_lib.load().ffk_filter_function_weighted(ptr(R), A, N, W, ptr(weights),
+                                                           1.0/pulse.d, ptr(filter_function)))
+        else:
+            filter_function = pulse.get_filter_function(omega, which='fidelity',
+                                                        show_progressbar=show_progressbar,
+                                                        cache_intermediates=cache_intermediates)
         infid = _integrate_filter_function(filter_function, spectrum, omega, idx, pulse.d)
     else:
         if pulse.is_cached('omega') and not np.array_equal(pulse.omega, omega):

@@ -184,6 +184,15 @@ int ffk_filter_function(const double* control_matrix, int A, int N, int W, int w
 int ffk_filter_function_dev(const double* control_matrix, int A, int N, int W, int which,
                             double* filter_function, void* stream);
 
+/* The filter function of a basis that is not traceless (numeric.py:2295-2305):
+ * F[a,b,w] = scale * sum_kl conj(R[a,k,w]) M[k,l] R[b,l,w], weights M (N, N) c128 built by the
+ * caller from the four-element traces of the basis, scale = 1/d.                               */
+int ffk_filter_function_weighted(const double* control_matrix, int A, int N, int W,
+                                 const double* weights, double scale, double* filter_function);
+int ffk_filter_function_weighted_dev(const double* control_matrix, int A, int N, int W,
+                                     const double* weights, double scale, double* filter_function,
+                                     void* stream);
+
 /* ---- numeric.infidelity, filter-function branch (numeric.py:2307-2320 with _get_integrand
  *      :323-325, :351-352, :374 and util.integrate util.py:880-906) ------------------------
  * filter_function (A, A, W) c128; omega (W,) f64; idx (n_idx,) int32 noise-operator indices;

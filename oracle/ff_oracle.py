@@ -373,6 +373,16 @@ def infidelity_from_filter_function(F, spectrum, omega, idx, d):
     return integrate(integrand.real, omega)/(2*np.pi*d)
 
 
+def infidelity_nontraceless(control_matrix, basis, spectrum, omega, idx, d):
+    """infidelity() for a basis that is not traceless, filter_functions/numeric.py:2295-2305:
+    F_ab = sum_kl R*_ak R_bl (sum_m T_klmm - sum_m T_kmlm)/d, then the usual integral."""
+    T = four_element_traces(basis)
+    traces_diag = np.einsum('klmm->kl', T) - np.einsum('kmlm->kl', T)
+    R = np.asarray(control_matrix)
+    F = np.einsum('ako,blo,kl->abo', R.conj(), R, traces_diag)/d
+    return infidelity_from_filter_function(F, spectrum, omega, idx, d)
+
+
 def control_matrix_from_atomic(phases, R_atomic, Q_liouville, which='total'):
     """R = sum_g e^{i w t_{g-1}} R^{(g)} Q^{(g-1)}  (numeric.py:621-704)."""
     G = len(R_atomic)

@@ -207,7 +207,40 @@ def make_noise_operator_steps():
     save('noise_operator_steps', **arrays)
 
 
+def make_nontraceless():
+    """12. infidelity() with a basis that is not traceless (numeric.py:2295-2305): matrix units on
+    the diagonal instead of the identity and the diagonal GGM elements."""
+    rng = np.random.default_rng(71)
+    arrays = {}
+    for name, d in (('d2', 2), ('d3', 3)):
+        ggm = np.asarray(ff.Basis.ggm(d))
+        n_off = d*(d - 1)
+        units = np.zeros((d, d, d), dtype=complex)
+        units[np.arange(d), np.arange(d), np.arange(d)] = 1
+        basis = ff.Basis(np.concatenate([units, ggm[1:1 + n_off]]))
+        assert not basis.istraceless and basis.isorthonorm
+        proto = rand_pulse(d, 4, 2, 2, 'GGM', rng)
+        pulse = ff.PulseSequence(list(zip(proto.c_opers, proto.c_coeffs, proto.c_oper_identifiers)),
+                                 list(zip(proto.n_opers, proto.n_coeffs, proto.n_oper_identifiers)),
+                                 proto.dt, basis)
+        omega = np.geomspace(1e-2, 1e2, 40)
+        S3 = np.tile(1e-3/omega, (2, 2, 1)).astype(complex)
+        S3[0, 1] += 1j*1e-4*omega
+        S3[1, 0] -= 1j*1e-4*omega
+        for k, v in pulse_inputs(pulse).items():
+            arrays[f'{name}_{k}'] = v
+        arrays[f'{name}_omega'] = omega
+        arrays[f'{name}_control_matrix'] = pulse.get_control_matrix(omega)
+        for i, S in enumerate((1e-3/omega, np.outer([1e-3, 2e-3], 1/omega), S3), 1):
+            arrays[f'{name}_S{i}'] = S
+            arrays[f'{name}_infidelity_S{i}'] = numeric.infidelity(pulse, S, omega)
+    save('nontraceless', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'nontraceless':
+        make_nontraceless()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'etm':   # only the newest fixtures
         make_etm()
         return
@@ -431,6 +464,7 @@ def main():
 
     make_etm()
     make_noise_operator_steps()
+    make_nontraceless()
 
 
 if __name__ == '__main__':

@@ -789,3 +789,21 @@ def test_filter_function_many_noise_operators(A, N, W):
     assert np.all(F[np.arange(A), np.arange(A)].imag == 0)
     sub = numeric.calculate_filter_function(R[:4])            # pairwise kernel
     assert np.array_equal(sub, F[:4, :4])
+
+
+@pytest.mark.parametrize('name', ['d2', 'd3'])
+def test_infidelity_nontraceless_basis(name):
+    """infidelity() with a basis that is not traceless (reference numeric.py:2295-2305)."""
+    g = load_golden('nontraceless')
+    basis = ff.Basis(g[f'{name}_basis'])
+    assert not basis.istraceless and basis.btype == 'Custom'
+    pulse = ff.PulseSequence.from_arrays(
+        g[f'{name}_c_opers'], g[f'{name}_c_oper_identifiers'], g[f'{name}_c_coeffs'],
+        g[f'{name}_n_opers'], g[f'{name}_n_oper_identifiers'], g[f'{name}_n_coeffs'],
+        g[f'{name}_dt'], basis)
+    omega = g[f'{name}_omega']
+    assert rel_err(pulse.get_control_matrix(omega), g[f'{name}_control_matrix']) < TOL
+    for i in (1, 2, 3):
+        infid = ff.infidelity(pulse, g[f'{name}_S{i}'], omega)
+        assert infid.shape == g[f'{name}_infidelity_S{i}'].shape
+        assert rel_err(infid, g[f'{name}_infidelity_S{i}']) < TOL

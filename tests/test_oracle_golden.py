@@ -245,3 +245,14 @@ def test_noise_operator_step_cache():
                                                 g['t'], cache_intermediates=True)
     assert rel_err(B, g['noise_operators']) < 1e-13
     assert rel_err(inter['noise_operators_step'], g['inter_noise_operators_step']) < 1e-13
+
+
+@pytest.mark.parametrize('name', ['d2', 'd3'])
+def test_infidelity_nontraceless_basis(name):
+    g = load_golden('nontraceless')
+    R = g[f'{name}_control_matrix']
+    d = g[f'{name}_basis'].shape[-1]
+    for i in (1, 2, 3):
+        got = orc.infidelity_nontraceless(R, g[f'{name}_basis'], g[f'{name}_S{i}'],
+                                          g[f'{name}_omega'], np.arange(len(R)), d)
+        assert rel_err(got, g[f'{name}_infidelity_S{i}']) < 1e-13
