@@ -111,6 +111,8 @@ SIGNATURES = {
                                    c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ffk_infidelity_sharded_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                            c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    'ffk_noise_operators_from_atomic': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                c_int, c_void_p]),
     'ffk_decay_amplitudes_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'ffk_decay_amplitudes_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                          c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t,

@@ -167,4 +167,67 @@ hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int
     return hipSuccess;
 }
 
+
+// ---- Hilbert-space twin: calculate_noise_operators_from_atomic (numeric.py:377-453) ------------
+//   B(w, a) = B^(0)(w, a) + sum_{g >= 1} phases[g-1, w] P_{g-1}^dag B^(g)(w, a) P_{g-1}
+// One wavefront per (w, a): the d x d operator, the propagator and the half product live in LDS.
+namespace {
+__global__ __launch_bounds__(64) void noise_ops_from_atomic_kernel(
+    const cplx* __restrict__ phases, const cplx* __restrict__ atomic, const cplx* __restrict__ props,
+    int G, int W, int A, int d, cplx* __restrict__ out) {
+    __shared__ cplx Bg[kMaxD*kMaxD], P[kMaxD*kMaxD], T[kMaxD*kMaxD];
+    const int lane = threadIdx.x;
+    const int w = blockIdx.x / A, a = blockIdx.x % A;
+    const int dd = d*d;
+    constexpr int kPer = (kMaxD*kMaxD + 63)/64;
+    cplx acc[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int e = lane + 64*k;
+        acc[k] = e < dd ? atomic[(static_cast<size_t>(w)*A + a)*dd + e] : cplx{0.0, 0.0};
+    }
+    for (int g = 1; g < G; ++g) {
+        const cplx ph = phases[static_cast<size_t>(g - 1)*W + w];
+        const cplx* src = atomic + ((static_cast<size_t>(g)*W + w)*A + a)*dd;
+        __syncthreads();
+        for (int e = lane; e < dd; e += 64) {
+            Bg[e] = src[e];
+            P[e] = props[static_cast<size_t>(g - 1)*dd + e];
+        }
+        __syncthreads();
+        for (int e = lane; e < dd; e += 64) {     // T = B P
+            const int i = e / d, j = e % d;
+            cplx t = {0.0, 0.0};
+            for (int k = 0; k < d; ++k) cmac(t, Bg[i*d + k], P[k*d + j]);
+            T[e] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {          // acc += ph P^dag T
+            const int e = lane + 64*k;
+            if (e < dd) {
+                const int i = e / d, j = e % d;
+                cplx t = {0.0, 0.0};
+                for (int m = 0; m < d; ++m) cmac_conj(t, P[m*d + i], T[m*d + j]);
+                cmac(acc[k], ph, t);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int e = lane + 64*k;
+        if (e < dd) out[(static_cast<size_t>(w)*A + a)*dd + e] = acc[k];
+    }
+}
+}  // namespace
+
+hipError_t launch_noise_ops_from_atomic(const cplx* phases, const cplx* atomic, const cplx* props,
+                                        int G, int W, int A, int d, cplx* out, hipStream_t stream) {
+    const size_t blocks = static_cast<size_t>(W)*A;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(noise_ops_from_atomic_kernel, dim3(static_cast<unsigned>(blocks)), dim3(64), 0,
+                       stream, phases, atomic, props, G, W, A, d, out);
+    return hipGetLastError();
+}
+
 }  // namespace ffk

@@ -730,6 +730,36 @@ int ffk_control_matrix_from_atomic_indexed(const double* total_phases,
     return FFK_OK;
 }
 
+int ffk_noise_operators_from_atomic(const double* phases, const double* noise_operators_atomic,
+                                    const double* propagators, int G, int W, int A, int d,
+                                    double* noise_operators) {
+    FFK_REQUIRE(noise_operators_atomic && noise_operators, "NULL argument");
+    FFK_REQUIRE(G == 1 || (phases && propagators), "NULL argument");
+    FFK_REQUIRE(G >= 1 && W >= 1 && A >= 1, "empty axis: G=%d W=%d A=%d", G, W, A);
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t dd = size_t(d)*d;
+    const size_t nph = 16*size_t(G > 1 ? G - 1 : 1)*W, nat = 16*size_t(G)*W*A*dd;
+    const size_t npr = 16*size_t(G > 1 ? G - 1 : 1)*dd, nout = 16*size_t(W)*A*dd;
+    void* base;
+    if (int rc = arena_reserve(align_up(nph) + align_up(nat) + align_up(npr) + align_up(nout), &base))
+        return rc;
+    Bump a(base, g_arena.size);
+    cplx* dph = a.take<cplx>(nph/16);
+    cplx* dat = a.take<cplx>(nat/16);
+    cplx* dpr = a.take<cplx>(npr/16);
+    cplx* dout = a.take<cplx>(nout/16);
+    if (G > 1) {
+        FFK_HIP(hipMemcpyAsync(dph, phases, 16*size_t(G - 1)*W, hipMemcpyHostToDevice, nullptr));
+        FFK_HIP(hipMemcpyAsync(dpr, propagators, 16*size_t(G - 1)*dd, hipMemcpyHostToDevice, nullptr));
+    }
+    FFK_HIP(hipMemcpyAsync(dat, noise_operators_atomic, nat, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(ffk::launch_noise_ops_from_atomic(dph, dat, dpr, G, W, A, d, dout, nullptr));
+    FFK_HIP(hipMemcpyAsync(noise_operators, dout, nout, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // filter function
 // ---------------------------------------------------------------------------------------------

@@ -164,6 +164,10 @@ hipError_t launch_cumulant_function(const double* gamma, size_t batch, int N, in
                                     const cplx* basis, int single_qubit, double* K, void* ws,
                                     hipStream_t stream);
 
+// B (W,A,d,d) = B^(0) + sum_g phases[g-1] P_{g-1}^dag B^(g) P_{g-1}; atomic (G,W,A,d,d), props (G-1,d,d)
+hipError_t launch_noise_ops_from_atomic(const cplx* phases, const cplx* atomic, const cplx* props,
+                                        int G, int W, int A, int d, cplx* out, hipStream_t stream);
+
 // ---- liouville.hip ---------------------------------------------------------------------------
 size_t liouville_workspace_bytes(int batch, int d, int N);
 hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, int N,

@@ -29,6 +29,7 @@ from ._lib import as_c128, as_f64, check, ptr
 __all__ = ['diagonalize', 'calculate_control_matrix_from_scratch',
            'calculate_noise_operators_from_scratch', 'calculate_filter_function', 'infidelity',
            'calculate_control_matrix_from_atomic', 'calculate_control_matrix_from_atomic_indexed',
+           'calculate_noise_operators_from_atomic',
            'calculate_pulse_correlation_filter_function', 'calculate_decay_amplitudes',
            'calculate_cumulant_function', 'error_transfer_matrix']
 
@@ -338,6 +339,33 @@ def calculate_control_matrix_from_atomic(phases, control_matrix_atomic, propagat
         check(_lib.load().ffk_control_matrix_from_atomic(
             ptr(phases) if G > 1 else None, ptr(R_atomic), ptr(L) if G > 1 else None,
             int(l_is_complex), G, A, N, W, int(which == 'correlations'), ptr(out)))
+    return out
+
+
+def calculate_noise_operators_from_atomic(phases, noise_operators_atomic, propagators,
+                                          show_progressbar=False):
+    r"""Interaction-picture noise operators of a sequence from those of its atomic pulses, the
+    Hilbert-space twin of :func:`calculate_control_matrix_from_atomic` (reference
+    numeric.py:377-453): :math:`\tilde B(\omega) = \sum_g e^{i\omega t_{g-1}}
+    Q_{g-1}^\dagger \tilde B^{(g)}(\omega) Q_{g-1}`.
+
+    phases (G-1, n_omega) (extra rows are ignored like in the reference), noise_operators_atomic
+    (G, n_omega, n_nops, d, d), propagators (G-1, d, d) -> (n_omega, n_nops, d, d)."""
+    Ba = as_c128(noise_operators_atomic)
+    if Ba.ndim != 5 or Ba.shape[-1] != Ba.shape[-2]:
+        raise ValueError(f'Expected noise_operators_atomic of shape (G, n_omega, n_nops, d, d), '
+                         f'not {Ba.shape}.')
+    G, W, A, d = Ba.shape[:4]
+    _check_d(d)
+    ph = as_c128(np.asarray(phases)[:max(G - 1, 0)])
+    props = as_c128(np.asarray(propagators)[:max(G - 1, 0)])
+    if G > 1 and (ph.shape != (G - 1, W) or props.shape != (G - 1, d, d)):
+        raise ValueError(f'phases {np.shape(phases)} / propagators {np.shape(propagators)} do not '
+                         f'match {G} atomic pulses, {W} frequencies and d = {d}.')
+    out = np.empty((W, A, d, d), dtype=np.complex128)
+    check(_lib.load().ffk_noise_operators_from_atomic(ptr(ph) if G > 1 else None, ptr(Ba),
+                                                      ptr(props) if G > 1 else None, G, W, A, d,
+                                                      ptr(out)))
     return out
 
 

@@ -215,6 +215,13 @@ int ffk_infidelity_sharded_dev(const double* filter_function_shards, int n_shard
                                int A, const double* spectrum, int s_ndim, const double* omega,
                                const int32_t* idx, int n_idx, int d, double* infid, void* stream);
 
+/* ---- numeric.calculate_noise_operators_from_atomic (numeric.py:377-453) -------------------
+ * phases (G-1, W) c128, noise_operators_atomic (G, W, A, d, d) c128, propagators (G-1, d, d) c128
+ * -> noise_operators (W, A, d, d):  B = B^(0) + sum_{g>=1} phases[g-1] P_{g-1}^dag B^(g) P_{g-1}. */
+int ffk_noise_operators_from_atomic(const double* phases, const double* noise_operators_atomic,
+                                    const double* propagators, int G, int W, int A, int d,
+                                    double* noise_operators);
+
 /* ---- numeric.calculate_decay_amplitudes (numeric.py:1194-1337; integrand _get_integrand
  *      :310-374 'generalized' with the control matrix; util.integrate util.py:880-906) -------
  * control_matrix (n_pulses, A, N, W) c128: n_pulses = 1 is the total control matrix

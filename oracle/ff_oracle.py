@@ -373,6 +373,17 @@ def infidelity_from_filter_function(F, spectrum, omega, idx, d):
     return integrate(integrand.real, omega)/(2*np.pi*d)
 
 
+def noise_operators_from_atomic(phases, B_atomic, propagators):
+    """B = B^(0) + sum_g phases[g-1] P_{g-1}^dag B^(g) P_{g-1}, filter_functions/numeric.py:377-453
+    (_transform_by_unitary :126-141 is U^dag X U)."""
+    B_atomic = np.asarray(B_atomic)
+    out = B_atomic[0].copy()
+    for g in range(1, len(B_atomic)):
+        P = np.asarray(propagators[g - 1])
+        out += P.conj().T @ (B_atomic[g]*np.asarray(phases[g - 1])[:, None, None, None]) @ P
+    return out
+
+
 def infidelity_nontraceless(control_matrix, basis, spectrum, omega, idx, d):
     """infidelity() for a basis that is not traceless, filter_functions/numeric.py:2295-2305:
     F_ab = sum_kl R*_ak R_bl (sum_m T_klmm - sum_m T_kmlm)/d, then the usual integral."""

@@ -237,7 +237,36 @@ def make_nontraceless():
     save('nontraceless', **arrays)
 
 
+def make_noise_operators_from_atomic():
+    """13. calculate_noise_operators_from_atomic (numeric.py:377-453), inputs as in the reference's
+    tests/test_precision.py:313-353 (total phases / total propagators of each pulse)."""
+    rng = np.random.default_rng(81)
+    arrays = {}
+    for name, d, G in (('d2', 2, 5), ('d3', 3, 4), ('d5', 5, 3)):
+        pulses = [rand_pulse(d, int(rng.integers(1, 6)), 2, 3, 'GGM', rng) for _ in range(G)]
+        for q in pulses:
+            q.n_opers = pulses[0].n_opers
+            q.n_oper_identifiers = pulses[0].n_oper_identifiers
+        omega = np.concatenate(([0.0], rng.random(16)*5))
+        for q in pulses:
+            q.diagonalize()
+        B_atomic = np.array([numeric.calculate_noise_operators_from_scratch(
+            q.eigvals, q.eigvecs, q.propagators, omega, q.n_opers, q.n_coeffs, q.dt, q.t)
+            for q in pulses])
+        phases = np.array([q.get_total_phases(omega) for q in pulses])
+        props = np.array([q.total_propagator for q in pulses])
+        arrays[f'{name}_omega'] = omega
+        arrays[f'{name}_B_atomic'] = B_atomic
+        arrays[f'{name}_phases'] = phases
+        arrays[f'{name}_propagators'] = props
+        arrays[f'{name}_B'] = numeric.calculate_noise_operators_from_atomic(phases, B_atomic, props)
+    save('noise_operators_from_atomic', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'nopsatomic':
+        make_noise_operators_from_atomic()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'nontraceless':
         make_nontraceless()
         return
@@ -465,6 +494,7 @@ def main():
     make_etm()
     make_noise_operator_steps()
     make_nontraceless()
+    make_noise_operators_from_atomic()
 
 
 if __name__ == '__main__':

@@ -807,3 +807,28 @@ def test_infidelity_nontraceless_basis(name):
         infid = ff.infidelity(pulse, g[f'{name}_S{i}'], omega)
         assert infid.shape == g[f'{name}_infidelity_S{i}'].shape
         assert rel_err(infid, g[f'{name}_infidelity_S{i}']) < TOL
+
+
+@pytest.mark.parametrize('name', ['d2', 'd3', 'd5'])
+def test_noise_operators_from_atomic(name):
+    """numeric.calculate_noise_operators_from_atomic against the reference's output; the phases
+    array carries one row more than needed, like in the reference's own test."""
+    g = load_golden('noise_operators_from_atomic')
+    B = numeric.calculate_noise_operators_from_atomic(g[f'{name}_phases'], g[f'{name}_B_atomic'],
+                                                      g[f'{name}_propagators'])
+    assert B.shape == g[f'{name}_B'].shape and rel_err(B, g[f'{name}_B']) < TIGHT
+    one = numeric.calculate_noise_operators_from_atomic(g[f'{name}_phases'][:0],
+                                                        g[f'{name}_B_atomic'][:1],
+                                                        g[f'{name}_propagators'][:0])
+    assert np.array_equal(one, g[f'{name}_B_atomic'][0])
+    with pytest.raises(ValueError):
+        numeric.calculate_noise_operators_from_atomic(g[f'{name}_phases'][:1],
+                                                      g[f'{name}_B_atomic'],
+                                                      g[f'{name}_propagators'])
+    # d = 16: one operator per wavefront with 4 elements per lane
+    rng = np.random.default_rng(0)
+    Ba = rng.standard_normal((3, 5, 2, 16, 16)) + 1j*rng.standard_normal((3, 5, 2, 16, 16))
+    ph = np.exp(1j*rng.standard_normal((2, 5)))
+    P = np.linalg.qr(rng.standard_normal((2, 16, 16)) + 1j*rng.standard_normal((2, 16, 16)))[0]
+    got = numeric.calculate_noise_operators_from_atomic(ph, Ba, P)
+    assert rel_err(got, orc.noise_operators_from_atomic(ph, Ba, P)) < 1e-13

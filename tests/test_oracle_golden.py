@@ -256,3 +256,11 @@ def test_infidelity_nontraceless_basis(name):
         got = orc.infidelity_nontraceless(R, g[f'{name}_basis'], g[f'{name}_S{i}'],
                                           g[f'{name}_omega'], np.arange(len(R)), d)
         assert rel_err(got, g[f'{name}_infidelity_S{i}']) < 1e-13
+
+
+@pytest.mark.parametrize('name', ['d2', 'd3', 'd5'])
+def test_noise_operators_from_atomic(name):
+    g = load_golden('noise_operators_from_atomic')
+    got = orc.noise_operators_from_atomic(g[f'{name}_phases'], g[f'{name}_B_atomic'],
+                                          g[f'{name}_propagators'])
+    assert rel_err(got, g[f'{name}_B']) < 1e-14
