@@ -167,6 +167,46 @@ class PulseSequence:
             raise TypeError(f'Incompatible type for concatenation: {type(other)}')
         return concatenate((self, other))
 
+    def __imatmul__(self, other):
+        raise NotImplementedError
+
+    def __eq__(self, other):
+        """Two sequences are equal if dt, operators, identifiers, coefficients and basis agree,
+        after merging consecutive segments with identical control (reference
+        pulse_sequence.py:363-440)."""
+        if not isinstance(other, self.__class__):
+            return NotImplemented
+        atol = np.finfo(complex).eps*self.basis.shape[0]
+        mine, theirs = _merge_constant_segments(self), _merge_constant_segments(other)
+        if len(mine[2]) != len(theirs[2]) or not np.allclose(mine[2], theirs[2], 1e-10, atol):
+            return False
+        for opers, idents, k in (('c_opers', 'c_oper_identifiers', 0),
+                                 ('n_opers', 'n_oper_identifiers', 1)):
+            ia = np.argsort(getattr(self, idents))
+            ib = np.argsort(getattr(other, idents))
+            if len(ia) != len(ib):
+                return False
+            if not np.array_equal(getattr(self, opers)[ia], getattr(other, opers)[ib]):
+                return False
+            if not np.array_equal(getattr(self, idents)[ia], getattr(other, idents)[ib]):
+                return False
+            if not np.array_equal(mine[k][ia], theirs[k][ib]):
+                return False
+        return bool(self.basis == other.basis)
+
+    __hash__ = None
+
+    def propagator_at_arb_t(self, t):
+        """Cumulative propagator Q(t) at arbitrary times: the segment propagator up to the
+        enclosing step times the partial evolution within it (reference
+        pulse_sequence.py:1247-1267).  Small host-side matrices, not on the accelerated path."""
+        self.diagonalize()
+        t = np.asarray(t, dtype=float)
+        idx = np.clip(np.searchsorted(self.t, t) - 1, 0, len(self.dt) - 1)
+        V = self.eigvecs[idx]
+        phase = util.cexp((self.t[idx] - t)[:, None]*self.eigvals[idx])
+        return (V*phase[:, None, :]) @ V.conj().swapaxes(-1, -2) @ self.propagators[idx]
+
     # ---- caches --------------------------------------------------------------------------
     def is_cached(self, attr):
         """True if *attr* is cached; accepts the reference's human-readable aliases
@@ -438,6 +478,19 @@ class PulseSequence:
 # identifiers and coefficient tables; the arithmetic -- atomic control matrices, Liouville
 # propagators, the concatenation rule and the filter functions -- runs in libffk.
 # --------------------------------------------------------------------------------------------
+def _merge_constant_segments(pulse):
+    """(c_coeffs, n_coeffs, dt) with runs of segments whose control amplitudes do not change
+    merged into one (their durations added), so that equality does not depend on how a constant
+    stretch was split (reference pulse_sequence.py:1270-1285)."""
+    same = (np.diff(pulse.c_coeffs) == 0).all(axis=0).nonzero()[0]
+    if same.size == 0:
+        return pulse.c_coeffs, pulse.n_coeffs, pulse.dt
+    dt = np.delete(pulse.dt, same)
+    for old, new in zip(same, same - np.arange(len(same))):
+        dt[new] += pulse.dt[old]
+    return np.delete(pulse.c_coeffs, same, axis=1), np.delete(pulse.n_coeffs, same, axis=1), dt
+
+
 def _all_bases_equal(pulses):
     first = pulses[0].basis
     return all(p.basis.shape == first.shape and np.array_equal(np.asarray(p.basis), np.asarray(first))

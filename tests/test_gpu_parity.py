@@ -832,3 +832,17 @@ def test_noise_operators_from_atomic(name):
     P = np.linalg.qr(rng.standard_normal((2, 16, 16)) + 1j*rng.standard_normal((2, 16, 16)))[0]
     got = numeric.calculate_noise_operators_from_atomic(ph, Ba, P)
     assert rel_err(got, orc.noise_operators_from_atomic(ph, Ba, P)) < 1e-13
+
+
+def test_propagator_at_arbitrary_times():
+    g = load_golden('rand_d3_ggm')
+    pulse = pulse_from(g)
+    Q = pulse.propagator_at_arb_t(pulse.t)
+    assert rel_err(Q, pulse.propagators) < 1e-13
+    # inside a segment: Q(t) = exp(-i H_l (t - t_l)) Q_l, checked through the group property
+    t_mid = pulse.t[:-1] + 0.3*pulse.dt
+    Qm = pulse.propagator_at_arb_t(t_mid)
+    H = np.einsum('ijk,il->ljk', pulse.c_opers, pulse.c_coeffs)
+    w, V = np.linalg.eigh(H)
+    step = (V*np.exp(-1j*w*0.3*pulse.dt[:, None])[:, None, :]) @ V.conj().transpose(0, 2, 1)
+    assert rel_err(Qm, step @ pulse.propagators[:-1]) < 1e-12

@@ -255,3 +255,20 @@ def test_concatenation_bookkeeping():
     assert not ff.concatenate([a, b], calc_filter_function=False).is_cached('omega')
     with pytest.raises(NotImplementedError):
         ff.concatenate([a, b], calc_second_order_FF=True)
+
+
+def test_pulse_sequence_equality():
+    """__eq__ merges constant stretches before comparing (reference pulse_sequence.py:363-440)."""
+    X, Y, Z = util.paulis[1:]
+
+    def make(dt, cx, ident='X'):
+        return ff.PulseSequence([[X, cx, ident], [Y, [0.5]*len(dt), 'Y']],
+                                [[Z, [1.0]*len(dt), 'Z']], dt)
+    a, b, c = make([1., 1., 2.], [1., 1., 3.]), make([2., 2.], [1., 3.]), make([2., 2.], [1., 4.])
+    assert a == b and a == a and not (a == c) and a != c
+    assert not (a == make([2., 2.1], [1., 3.])) and not (a == make([2., 2.], [1., 3.], 'Xx'))
+    assert (a == 5) is False
+    with pytest.raises(NotImplementedError):
+        a @= b
+    with pytest.raises(TypeError):
+        hash(a)
