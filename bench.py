@@ -197,6 +197,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         infid = step(i)
+    t_issue = time.perf_counter() - t0          # host time to enqueue all steps
     torch.cuda.synchronize(device)
     if use_dist:
         dist.barrier()
@@ -268,6 +269,7 @@ def main():
             'kernel_geometry': {k: stats[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z',
                                                        'block', 'lds_bytes')},
             'seg_omega_nop_per_s': G*W_total*A*args.steps/elapsed,
+            'host_enqueue_ms_per_step': t_issue/args.steps*1e3,
             'device': _lib.device_info()[0],
         }
         if world == 1 and not args.no_cpu_baseline:
