@@ -403,10 +403,14 @@ __global__ __launch_bounds__(512) void ctrl_accumulate_mfma4_kernel(
     for (int g = g0; g < g1; ++g) {
         const int buf = (g - g0) & 1;
         __syncthreads();
+#if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 1)
         generate(buf);
+#endif
         __syncthreads();
         if (g + 1 < g1) issue_stage(g + 1);
+#if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 2)
         if (active) contract(buf);
+#endif
         if (g + 1 < g1) park(buf ^ 1);
     }
 
