@@ -263,7 +263,40 @@ def make_noise_operators_from_atomic():
     save('noise_operators_from_atomic', **arrays)
 
 
+def make_cnot():
+    """14. The reference's singlet-triplet CNOT test (tests/test_precision.py:274-311): exchange-
+    coupled 4-spin pulse restricted to the 6-dimensional S_z = 0 subspace, 250 steps, partial
+    (15-element) Pauli basis of the computational subspace; infidelities compared with the Monte
+    Carlo numbers shipped in the reference's examples/data/CNOT.mat (within 10 %)."""
+    sys.path.insert(0, '/root/reference/tests')
+    import testutil   # the reference's own workload definition (reads examples/data/CNOT.mat)
+    c_opers = np.array(testutil.subspace_opers)
+    c_coeffs, n_coeffs = np.array(testutil.c_coeffs), np.array(testutil.n_coeffs)
+    dt = testutil.dt
+    basis = ff.Basis([np.pad(b, 1, 'constant') for b in ff.Basis.pauli(2)[1:]], btype='Pauli')
+    identifiers = ['eps_12', 'eps_23', 'eps_34', 'b_12', 'b_23', 'b_34']
+    cnot = ff.PulseSequence(list(zip(c_opers, c_coeffs, identifiers)),
+                            list(zip(c_opers, n_coeffs, identifiers)), dt, basis=basis)
+    cnot.d = 4
+    omega = np.geomspace(1/cnot.tau, 1e2, 250)
+    arrays = dict(c_opers=c_opers, c_coeffs=c_coeffs, n_coeffs=n_coeffs, dt=dt,
+                  basis=np.asarray(basis), identifiers=np.array(identifiers), omega=omega,
+                  amplitudes=np.asarray(testutil.A), alphas=np.array([0.0, 0.7]),
+                  infid_monte_carlo=np.asarray(testutil.cnot_infid_fast))
+    for i, (Aamp, alpha) in enumerate(zip(testutil.A, (0.0, 0.7))):
+        S = Aamp/omega**alpha
+        infid, xi = ff.infidelity(cnot, S, omega, identifiers[:3], return_smallness=True)
+        arrays[f'S{i}'] = S
+        arrays[f'infid{i}'] = infid
+        arrays[f'xi{i}'] = xi
+    arrays['filter_function'] = cnot.get_filter_function(omega)
+    save('cnot', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'cnot':
+        make_cnot()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'nopsatomic':
         make_noise_operators_from_atomic()
         return
@@ -495,6 +528,7 @@ def main():
     make_noise_operator_steps()
     make_nontraceless()
     make_noise_operators_from_atomic()
+    make_cnot()
 
 
 if __name__ == '__main__':

@@ -846,3 +846,25 @@ def test_propagator_at_arbitrary_times():
     w, V = np.linalg.eigh(H)
     step = (V*np.exp(-1j*w*0.3*pulse.dt[:, None])[:, None, :]) @ V.conj().transpose(0, 2, 1)
     assert rel_err(Qm, step @ pulse.propagators[:-1]) < 1e-12
+
+
+def test_singlet_triplet_cnot_against_monte_carlo():
+    """The reference's CNOT test (tests/test_precision.py:274-311): d = 6 subspace of four
+    exchange-coupled spins, 250 steps, a partial 15-element Pauli basis of the computational
+    subspace, dimension overridden to 4; infidelities within 10 % of the Monte Carlo results and
+    equal to the reference's own numbers."""
+    g = load_golden('cnot')
+    ident = [str(s) for s in g['identifiers']]
+    basis = ff.Basis(g['basis'], btype='Pauli')
+    assert basis.shape == (15, 6, 6) and not basis.iscomplete
+    cnot = ff.PulseSequence(list(zip(g['c_opers'], g['c_coeffs'], ident)),
+                            list(zip(g['c_opers'], g['n_coeffs'], ident)), g['dt'], basis=basis)
+    cnot.d = 4
+    omega = g['omega']
+    assert rel_err(cnot.get_filter_function(omega), g['filter_function']) < TOL
+    for i in (0, 1):
+        infid, xi = ff.infidelity(cnot, g[f'S{i}'], omega, ident[:3], return_smallness=True)
+        assert rel_err(infid, g[f'infid{i}']) < TOL
+        assert abs(xi - g[f'xi{i}']) <= 1e-12*abs(g[f'xi{i}'])
+        assert abs(1 - infid.sum()/g['infid_monte_carlo'][i]) <= 0.10
+        assert infid.sum() <= xi**2/4

@@ -264,3 +264,19 @@ def test_noise_operators_from_atomic(name):
     got = orc.noise_operators_from_atomic(g[f'{name}_phases'], g[f'{name}_B_atomic'],
                                           g[f'{name}_propagators'])
     assert rel_err(got, g[f'{name}_B']) < 1e-14
+
+
+def test_cnot_fixture_against_oracle():
+    """The reference's singlet-triplet CNOT workload (partial basis, d = 6, 250 steps)."""
+    g = load_golden('cnot')
+    H = orc.hamiltonian(g['c_opers'], g['c_coeffs'])
+    D, V, Q = orc.diagonalize(H, g['dt'])
+    order = np.argsort(g['identifiers'])          # PulseSequence stores operators sorted by name
+    R = orc.control_matrix_from_scratch(D, V, Q, g['omega'], g['basis'], g['c_opers'][order],
+                                        g['n_coeffs'][order], g['dt'])
+    F = orc.filter_function(R)
+    assert rel_err(F, g['filter_function']) < 1e-12
+    idx = np.array([list(g['identifiers'][order]).index(s) for s in g['identifiers'][:3]])
+    for i in (0, 1):
+        infid = orc.infidelity_from_filter_function(F, g[f'S{i}'], g['omega'], idx, 4)
+        assert rel_err(infid, g[f'infid{i}']) < 1e-12
