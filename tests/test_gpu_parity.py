@@ -868,3 +868,37 @@ def test_singlet_triplet_cnot_against_monte_carlo():
         assert abs(xi - g[f'xi{i}']) <= 1e-12*abs(g[f'xi{i}'])
         assert abs(1 - infid.sum()/g['infid_monte_carlo'][i]) <= 0.10
         assert infid.sum() <= xi**2/4
+
+
+def test_filter_function_is_basis_independent():
+    """Reference tests/test_basis.py:378-432: the fidelity filter function does not depend on the
+    (complete, orthonormal) operator basis; the identity column of the control matrix vanishes
+    iff the noise operators are traceless."""
+    rng = np.random.default_rng(11)
+    d, G, A = 4, 6, 2
+    def herm(n, traceless=True):
+        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+        M = M + M.conj().transpose(0, 2, 1)
+        if traceless:
+            M -= np.trace(M, axis1=1, axis2=2)[:, None, None]*np.eye(d)/d
+        return M
+    c_opers, c_coeffs = herm(2), rng.standard_normal((2, G))
+    n_coeffs, dt = rng.random((A, G)) + 0.5, rng.random(G) + 0.5
+    omega = np.geomspace(1e-2, 1e2, 77)
+    # a third basis: a random orthogonal rotation of the GGM elements (complete, not traceless)
+    ggm = np.asarray(ff.Basis.ggm(d))
+    Qr = np.linalg.qr(rng.standard_normal((d*d, d*d)))[0]
+    rotated = ff.Basis(np.einsum('kl,lij->kij', Qr, ggm))
+    for traceless in (True, False):
+        n_opers = herm(A, traceless)
+        results = []
+        for basis in (ff.Basis.pauli(2), ff.Basis.ggm(d), rotated):
+            pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)),
+                                     dt, basis)
+            R = pulse.get_control_matrix(omega)
+            results.append(pulse.get_filter_function(omega))
+            if basis is not rotated:
+                zero = np.abs(R[:, 0]).max() < 1e-13*np.abs(R).max()
+                assert zero == traceless
+        assert rel_err(results[1], results[0]) < 1e-12
+        assert rel_err(results[2], results[0]) < 1e-12
