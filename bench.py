@@ -256,7 +256,9 @@ def main():
                 'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'avg_launch_ms': acc_ms, 'flops_per_launch': stats['accumulate_flops'],
                 'note': 'FP64 compute bound (vector = matrix peak 78.6 TFLOP/s on MI355X); '
-                        'flops = FMA-counted flops of the Hilbert-space algorithm actually run',
+                        'flops = FMA-counted flops of the Hilbert-space algorithm actually run; '
+                        'a pure v_fma_f64 stream on pseudo-random operands sustains 55 TFLOP/s on '
+                        'this part (tools/fp64_data_probe.hip, profiles/r01_k_*)',
             },
             'roofline_hbm': {
                 'bound': 'hbm', 'achieved': stats['accumulate_bytes']/(acc_ms*1e-3)/1e9,
