@@ -902,3 +902,47 @@ def test_filter_function_is_basis_independent():
                 assert zero == traceless
         assert rel_err(results[1], results[0]) < 1e-12
         assert rel_err(results[2], results[0]) < 1e-12
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_randomised_shapes_against_oracle(seed):
+    """Sweep of random problem shapes (every Hilbert-space dimension 2..16, few to many segments,
+    1-5 noise operators, ragged frequency counts incl. W = 1) through the PulseSequence API against
+    the oracle: control matrix, filter function, infidelity, noise operators."""
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(4):
+        d = int(rng.integers(2, 17))
+        G = int(rng.integers(1, 24))
+        A = int(rng.integers(1, 6))
+        W = int(rng.choice([1, 2, 17, 63, 64, 65, 130]))
+        n_cops = int(rng.integers(1, 4))
+        def herm(n):
+            M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+            return M + M.conj().transpose(0, 2, 1)
+        c_opers, n_opers = herm(n_cops), herm(A)
+        c_coeffs = rng.standard_normal((n_cops, G))
+        n_coeffs = rng.random((A, G)) + 0.1
+        dt = rng.random(G) + 0.2
+        omega = np.sort(rng.random(W))*20 - 2.0
+        basis = ff.Basis.ggm(d)
+        pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
+        R = pulse.get_control_matrix(omega)
+        F = pulse.get_filter_function(omega)
+        H = orc.hamiltonian(pulse.c_opers, pulse.c_coeffs)
+        D, V, Q = orc.diagonalize(H, dt)
+        R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), pulse.n_opers,
+                                                pulse.n_coeffs, dt)
+        tag = f'd={d} G={G} A={A} W={W}'
+        assert rel_err(R, R_ref) < TOL, tag
+        assert rel_err(F, orc.filter_function(R_ref)) < TOL, tag
+        B = numeric.calculate_noise_operators_from_scratch(pulse.eigvals, pulse.eigvecs,
+                                                           pulse.propagators, omega, pulse.n_opers,
+                                                           pulse.n_coeffs, dt, pulse.t)
+        B_ref = orc.noise_operators_from_scratch(D, V, Q, omega, pulse.n_opers, pulse.n_coeffs, dt)
+        assert rel_err(B, B_ref) < TOL, tag
+        if W > 1:
+            S = 1/(1 + omega**2)
+            infid = ff.infidelity(pulse, S, omega)
+            ref = orc.infidelity_from_filter_function(orc.filter_function(R_ref), S, omega,
+                                                      np.arange(A), d)
+            assert np.abs(infid - ref).max() <= TOL*np.abs(ref).max(), tag
