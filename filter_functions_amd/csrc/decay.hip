@@ -50,7 +50,7 @@ template <int TM, int TN>
 __global__ __launch_bounds__(64) void decay_gemm_kernel(
     const cplx* __restrict__ R, int Gp, int A, int N, int W, const cplx* __restrict__ scale,
     int s_ndim, const int32_t* __restrict__ idx, int n_idx, int kchunk, int tiles_m, int tiles_n,
-    double* __restrict__ out, size_t split_stride) {
+    double* __restrict__ out, size_t split_stride, int mirror_in_store) {
     const int lane = threadIdx.x;
     const int l15 = lane & 15, lk = lane >> 4;
     const int tiles = tiles_m*tiles_n;
@@ -64,6 +64,10 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
     z /= n_idx;
     const int h = z % Gp, g = z / Gp;
     const int ib = s_ndim == 3 ? ib0 : ia;
+    // Gamma_aa of one pulse with itself is symmetric in (k, l) (real weights): only the tiles on
+    // and above the diagonal are computed, the rest mirrored at the store
+    const bool symmetric = s_ndim != 3 && g == h;
+    if (symmetric && ti > tj) return;
     const int srow = s_ndim == 1 ? 0 : (s_ndim == 2 ? ia : ia*n_idx + ib);
     const cplx* sp = scale + static_cast<size_t>(srow)*W;
     const cplx* Lp[TM];
@@ -129,19 +133,33 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = (ti*TM + tm)*16 + lk + 4*r;
-                if (row < N) o[static_cast<size_t>(row)*N + col] = acc[tm][tn][r];
+                if (row < N) {
+                    o[static_cast<size_t>(row)*N + col] = acc[tm][tn][r];
+                    if (mirror_in_store && symmetric && ti < tj)
+                        o[static_cast<size_t>(col)*N + row] = acc[tm][tn][r];
+                }
             }
         }
 }
 
-// out[i] = sum_s part[s][i], fixed order
+// out[i] = sum_s part[s][i], fixed order.  tile > 0: batches of a pulse with itself (g == h in the
+// batch index (g*Gp + h)*n_idx + a) are symmetric matrices of which only the tiles (of `tile`
+// rows/columns) on or above the diagonal were computed; the rest is read transposed.
 __global__ __launch_bounds__(256) void reduce_splits_kernel(const double* __restrict__ part,
-                                                            int nsplit, size_t n,
+                                                            int nsplit, size_t n, int N, int tile,
+                                                            int Gp, int n_idx,
                                                             double* __restrict__ out) {
     const size_t i = static_cast<size_t>(blockIdx.x)*256 + threadIdx.x;
     if (i >= n) return;
-    double acc = part[i];
-    for (int s = 1; s < nsplit; ++s) acc += part[static_cast<size_t>(s)*n + i];
+    size_t src = i;
+    if (tile > 0) {
+        const size_t b = i / (static_cast<size_t>(N)*N);
+        const int row = static_cast<int>((i / N) % N), col = static_cast<int>(i % N);
+        const size_t gh = b / n_idx;
+        if (gh / Gp == gh % Gp && row / tile > col / tile) src = (b*N + col)*N + row;
+    }
+    double acc = part[src];
+    for (int s = 1; s < nsplit; ++s) acc += part[static_cast<size_t>(s)*n + src];
     out[i] = acc;
 }
 
@@ -307,19 +325,21 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
     const size_t blocks = p.batch*p.tiles_m*p.tiles_n;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     double* dst = p.ksplit > 1 ? part : gamma;
+    const int mirror = p.ksplit > 1 ? 0 : 1;    // with split-K the reduction fills the lower tiles
     const dim3 grid(static_cast<unsigned>(blocks), p.ksplit);
     if (p.tm == 1)
         hipLaunchKernelGGL((decay_gemm_kernel<1, 1>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n);
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror);
     else if (p.tm == 2)
         hipLaunchKernelGGL((decay_gemm_kernel<2, 2>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n);
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror);
     else
         hipLaunchKernelGGL((decay_gemm_kernel<4, 4>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n);
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror);
     if (p.ksplit > 1)
         hipLaunchKernelGGL(reduce_splits_kernel, dim3(static_cast<unsigned>((n + 255)/256)),
-                           dim3(256), 0, stream, part, p.ksplit, n, gamma);
+                           dim3(256), 0, stream, part, p.ksplit, n, N,
+                           s_ndim != 3 ? 16*p.tm : 0, Gp, n_idx, gamma);
     return hipGetLastError();
 }
 
