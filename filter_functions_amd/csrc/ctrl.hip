@@ -694,15 +694,16 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         // one wavefront per noise operator, 16 frequencies per block, one block per CU
         geo.wave_kernel = false;
         geo.nwaves = mfma_accumulate_waves(d, A);
-        geo.task_groups = (A + geo.nwaves - 1)/geo.nwaves;
-        geo.na_blk = geo.nwaves;
+        const int ops_per_block = mfma_accumulate_ops_per_block(d, A);
+        geo.task_groups = (A + ops_per_block - 1)/ops_per_block;
+        geo.na_blk = ops_per_block;
         geo.nbuf = 1;
         geo.lds_bytes = mfma_accumulate_lds_bytes(d, geo.nwaves);
         const long tiles = static_cast<long>((W + 15)/16)*geo.task_groups;
         int chunks = forced_chunks;
         if (chunks <= 0) {
             // resident blocks: one per CU for the 512-register kernel; for d = 8 two waves per SIMD
-            const long per_cu = d == 8 ? std::max(1, 8/geo.nwaves) : 1;
+            const long per_cu = std::max(1, 8/geo.nwaves);
             const long capacity = device_cu_count()*per_cu;
             const int max_chunks = std::max(1, std::min((G + 3)/4, 256));
             double best = 0.0;

@@ -15,6 +15,7 @@
 // the integral for every column block).  The 4 waves of a block share the generated E tile
 // (d^2 entries x 16 frequencies, 64 KiB at d = 16) through LDS.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ffk_internal.h"
 
@@ -247,15 +248,22 @@ __global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
 // blocks.  Accumulators are one f64 per lane and (row group, column): 2 d^2/4 registers, so the
 // kernel runs at 2-3 waves per SIMD with NW wavefronts (= noise operators) per block.
 // ---------------------------------------------------------------------------------------------
-template <int D>
+// JH > 1: the columns j of Y are split over JH wavefronts per noise operator (each computes Z only
+// for its own row groups -- the 4-row instruction has no tile to leave half empty), which halves
+// the accumulators per wave: d = 16 fits 256 registers, i.e. two wavefronts per SIMD.
+// `nw` counts wavefronts; a block serves nw / JH noise operators.
+template <int D, int JH>
 __global__ __launch_bounds__(512) void ctrl_accumulate_mfma4_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, int nw, cplx* __restrict__ Ypart) {
     static_assert(D % 4 == 0 && D >= 4 && D <= 16, "d must be a multiple of 4");
+    static_assert((D/4) % JH == 0, "row groups must split evenly");
     constexpr int S = seg_stride(D), DD = D*D, NS = D/4;
-    constexpr int kMaxStage = 4;
+    constexpr int NJG = NS/JH;        // row groups (of 4 columns of Y) owned by this wave
+    constexpr int kMaxStage = D == 16 ? 4 : 8;   // staged elements per thread (see launch_d4)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int kops = (1 + nw)*DD;
+    const int na = nw/JH;             // noise operators per block
+    const int kops = (1 + na)*DD;
     cplx* tile = reinterpret_cast<cplx*>(lds_raw);
     cplx* opsb = tile + DD*16;
     double* rows = reinterpret_cast<double*>(opsb + 2*kops);
@@ -267,19 +275,20 @@ __global__ __launch_bounds__(512) void ctrl_accumulate_mfma4_kernel(
     const int c = lane & 15, q = lane >> 4, c4 = c & 3;
     const int iw = blockIdx.x*16 + c;
     const double om = omega[iw < W ? iw : W - 1];
-    const int alpha0 = blockIdx.y*nw;
-    const int alpha = alpha0 + wave;
+    const int alpha0 = blockIdx.y*na;
+    const int alpha_l = wave / JH, jh = wave % JH;
+    const int alpha = alpha0 + alpha_l;
     const bool active = alpha < A;
-    const int n_alpha = min(nw, A - alpha0);
+    const int n_alpha = min(na, A - alpha0);
     const int n_ops = (1 + n_alpha)*DD;
     const int g0 = blockIdx.z*chunk_len;
     const int g1 = min(G, g0 + chunk_len);
 
-    double Yr[NS][D], Yi[NS][D];
+    double Yr[NS][4*NJG], Yi[NS][4*NJG];   // [row group ig][own column]
 #pragma unroll
     for (int ig = 0; ig < NS; ++ig)
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
+        for (int j = 0; j < 4*NJG; ++j) {
             Yr[ig][j] = 0.0;
             Yi[ig][j] = 0.0;
         }
@@ -321,31 +330,21 @@ __global__ __launch_bounds__(512) void ctrl_accumulate_mfma4_kernel(
             tile[e*16 + c] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
         }
     };
+    // v_mfma_f64: the last builtin argument carries the NEG bits of the operands (bit 0 = A)
     auto contract = [&](int buf) {
         const cplx* opT = opsb + buf*kops;
-        const cplx* opB = opT + (1 + wave)*DD;
-        // A operands of both steps: T[4 s + q][4 jg + (c & 3)]
-        double tr[NS][NS], ti[NS][NS], nti[NS][NS];
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int jg = 0; jg < NS; ++jg) {
-                const cplx t = opT[(4*s + q)*D + 4*jg + c4];
-                tr[s][jg] = t.re;
-                ti[s][jg] = t.im;
-                nti[s][jg] = -t.im;
-            }
-#pragma unroll
+        const cplx* opB = opT + (1 + alpha_l)*DD;
+#pragma unroll 1
         for (int mg = 0; mg < NS; ++mg) {
-            double zr[NS][4], zi[NS][4];   // [jg][mm]
+            double zr[NJG][4], zi[NJG][4];   // [own row group][mm]
 #pragma unroll
-            for (int jg = 0; jg < NS; ++jg)
+            for (int jg = 0; jg < NJG; ++jg)
 #pragma unroll
                 for (int mm = 0; mm < 4; ++mm) {
                     zr[jg][mm] = 0.0;
                     zi[jg][mm] = 0.0;
                 }
-#pragma unroll
+#pragma unroll 1
             for (int s = 0; s < NS; ++s) {
                 const int n = 4*s + q;
                 cplx x[4];
@@ -354,43 +353,50 @@ __global__ __launch_bounds__(512) void ctrl_accumulate_mfma4_kernel(
                     const int m = 4*mg + mm;
                     x[mm] = cmul(opB[m*D + n], tile[(m*D + n)*16 + c]);
                 }
+                // A operand of step 1: T[4 s + q][4 jg + (c & 3)] for the own row groups
+                cplx tj[NJG];
+#pragma unroll
+                for (int jg = 0; jg < NJG; ++jg) tj[jg] = opT[n*D + 4*(jh*NJG + jg) + c4];
                 // Z_m[j = 4 jg + q] += T[n, j] X_m[n]   (accumulators vary fastest)
 #pragma unroll
-                for (int jg = 0; jg < NS; ++jg)
+                for (int jg = 0; jg < NJG; ++jg)
 #pragma unroll
                     for (int mm = 0; mm < 4; ++mm) {
-                        zr[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(tr[s][jg], x[mm].re, zr[jg][mm], 0, 0, 0);
-                        zi[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(tr[s][jg], x[mm].im, zi[jg][mm], 0, 0, 0);
+                        zr[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(tj[jg].re, x[mm].re, zr[jg][mm], 0, 0, 0);
+                        zi[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(tj[jg].re, x[mm].im, zi[jg][mm], 0, 0, 0);
                     }
 #pragma unroll
-                for (int jg = 0; jg < NS; ++jg)
+                for (int jg = 0; jg < NJG; ++jg)
 #pragma unroll
                     for (int mm = 0; mm < 4; ++mm) {
-                        zr[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(nti[s][jg], x[mm].im, zr[jg][mm], 0, 0, 0);
-                        zi[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(ti[s][jg], x[mm].re, zi[jg][mm], 0, 0, 0);
+                        zr[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(tj[jg].im, x[mm].im, zr[jg][mm], 0, 0, 1);
+                        zi[jg][mm] = __builtin_amdgcn_mfma_f64_4x4x4f64(tj[jg].im, x[mm].re, zi[jg][mm], 0, 0, 0);
                     }
             }
             // lane (c, q) holds Z_{4 mg + mm}[4 jg + q]; step 2 needs Z_{4 mg + q}[4 jg + qo]
 #pragma unroll
-            for (int jg = 0; jg < NS; ++jg) {
+            for (int jg = 0; jg < NJG; ++jg) {
                 transpose_rows(zr[jg]);
                 transpose_rows(zi[jg]);
             }
-            // Y[i = 4 ig + q, j] += conj(T[m, i]) Z_m[j],  m = 4 mg + q
+            // Y[i = 4 ig + q, j] += conj(T[m, i]) Z_m[j],  m = 4 mg + q;  A operand T[m][4 ig + (c & 3)]
+            cplx ti_[NS];
 #pragma unroll
-            for (int jg = 0; jg < NS; ++jg)
+            for (int ig = 0; ig < NS; ++ig) ti_[ig] = opT[(4*mg + q)*D + 4*ig + c4];
+#pragma unroll
+            for (int jg = 0; jg < NJG; ++jg)
 #pragma unroll
                 for (int qo = 0; qo < 4; ++qo) {
-                    const int j = 4*jg + qo;
+                    const int j = 4*jg + qo;          // own column index
 #pragma unroll
                     for (int ig = 0; ig < NS; ++ig) {
-                        Yr[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(tr[mg][ig], zr[jg][qo], Yr[ig][j], 0, 0, 0);
-                        Yi[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(tr[mg][ig], zi[jg][qo], Yi[ig][j], 0, 0, 0);
+                        Yr[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(ti_[ig].re, zr[jg][qo], Yr[ig][j], 0, 0, 0);
+                        Yi[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(ti_[ig].re, zi[jg][qo], Yi[ig][j], 0, 0, 0);
                     }
 #pragma unroll
                     for (int ig = 0; ig < NS; ++ig) {
-                        Yr[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(ti[mg][ig], zi[jg][qo], Yr[ig][j], 0, 0, 0);
-                        Yi[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(nti[mg][ig], zr[jg][qo], Yi[ig][j], 0, 0, 0);
+                        Yr[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(ti_[ig].im, zi[jg][qo], Yr[ig][j], 0, 0, 0);
+                        Yi[ig][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(ti_[ig].im, zr[jg][qo], Yi[ig][j], 0, 0, 1);
                     }
                 }
         }
@@ -419,30 +425,32 @@ __global__ __launch_bounds__(512) void ctrl_accumulate_mfma4_kernel(
 #pragma unroll
         for (int ig = 0; ig < NS; ++ig)
 #pragma unroll
-            for (int j = 0; j < D; ++j)
-                out[static_cast<size_t>((4*ig + q)*D + j)*W] = {Yr[ig][j], Yi[ig][j]};
+            for (int j = 0; j < 4*NJG; ++j)
+                out[static_cast<size_t>((4*ig + q)*D + 4*jh*NJG + j)*W] = {Yr[ig][j], Yi[ig][j]};
     }
 }
 
-template <int D>
+template <int D, int JH>
 size_t mfma4_lds_bytes(int nw) {
-    return (static_cast<size_t>(D*D)*16 + 2*static_cast<size_t>(1 + nw)*D*D)*sizeof(cplx) +
+    return (static_cast<size_t>(D*D)*16 + 2*static_cast<size_t>(1 + nw/JH)*D*D)*sizeof(cplx) +
            2*static_cast<size_t>(seg_stride(D))*sizeof(double);
 }
 
-template <int D>
+template <int D, int JH>
 hipError_t launch_d4(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                      int chunks, int chunk_len, int nw, cplx* Ypart, hipStream_t stream) {
-    auto kern = ctrl_accumulate_mfma4_kernel<D>;
-    const int lds = static_cast<int>(mfma4_lds_bytes<D>(nw));
-    // staging: (1 + nw) d^2 + row/2 elements over nw*64 threads must fit kMaxStage = 4 per thread
-    if ((1 + nw)*D*D + seg_stride(D)/2 > 4*nw*64) return hipErrorInvalidValue;
+    auto kern = ctrl_accumulate_mfma4_kernel<D, JH>;
+    const int lds = static_cast<int>(mfma4_lds_bytes<D, JH>(nw));
+    // staging: (1 + na) d^2 + row/2 elements over nw*64 threads must fit kMaxStage per thread
+    constexpr int kMaxStage = D == 16 ? 4 : 8;
+    if (nw % JH != 0 || (1 + nw/JH)*D*D + seg_stride(D)/2 > kMaxStage*nw*64) return hipErrorInvalidValue;
     if (lds > 48*1024) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (err != hipSuccess) return err;
     }
-    const dim3 grid((W + 15)/16, (A + nw - 1)/nw, chunks);
+    const int na = nw/JH;
+    const dim3 grid((W + 15)/16, (A + na - 1)/na, chunks);
     hipLaunchKernelGGL(kern, grid, dim3(nw*64), lds, stream, omega, W, segtab, ops, G, A, chunk_len,
                        nw, Ypart);
     return hipGetLastError();
@@ -464,27 +472,65 @@ hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx
 
 }  // namespace
 
+// Kernel choice per dimension: 0 = the 16x16x4 kernel (one wavefront per operator), JH >= 1 = the
+// 4x4x4 kernel with the columns of Y split over JH wavefronts per operator.  Measured (MI355X):
+//   d = 16 (13 segments, 18 operators, 16384 omega): 16x16x4 6.7 ms, JH = 2 5.4 ms, JH = 4 6.5 ms
+//   d = 12 (64 segments, 6 operators, 8192 omega):   16x16x4 3.4 ms, JH = 1 2.4 ms, JH = 3 3.3 ms
+// -- two wavefronts per SIMD beat the wider tile.  FFK_TUNE_MFMA_JH overrides (tuning).
+static int mfma_column_split(int d) {
+    static const int env = [] {
+        const char* e = std::getenv("FFK_TUNE_MFMA_JH");
+        return e ? std::atoi(e) : -1;
+    }();
+    const int def = d == 16 ? 2 : 1;
+    if (env < 0) return def;
+    const bool ok = (d == 16 && (env == 0 || env == 2 || env == 4)) ||
+                    (d == 12 && (env == 0 || env == 1 || env == 3)) ||
+                    (d == 8 && (env == 1 || env == 2));
+    return ok ? env : def;
+}
+
 bool mfma_accumulate_supported(int d) { return d == 8 || d == 12 || d == 16; }
 // waves (= noise operators) per block: 4 for the 16x16x4 kernel; for the 4x4x4 kernel (d = 8) the
 // count in 3..8 with the fewest idle wave slots (ties: the larger, which shares the generated
 // integral more widely)
-int mfma_accumulate_waves(int d, int A) {
-    if (d != 8) return kMW;
-    int best = 8, best_idle = 1 << 30;
-    for (int nw = 8; nw >= 3; --nw) {
-        const int idle = (A + nw - 1)/nw*nw - A;
-        if (idle < best_idle) {
-            best_idle = idle;
-            best = nw;
+int mfma_accumulate_ops_per_block(int d, int A) {
+    const int jh = mfma_column_split(d);
+    if (jh == 0) return kMW;
+    if (d == 8 && jh == 1) {
+        // the count in 3..8 with the fewest idle wave slots (ties: the larger, which shares the
+        // generated integral more widely)
+        int best = 8, best_idle = 1 << 30;
+        for (int nw = 8; nw >= 3; --nw) {
+            const int idle = (A + nw - 1)/nw*nw - A;
+            if (idle < best_idle) {
+                best_idle = idle;
+                best = nw;
+            }
         }
+        return std::min(best, std::max(A, 3));
     }
-    return std::min(best, std::max(A, 3));
+    return std::max(1, 8/jh);         // eight wavefronts per block
+}
+int mfma_accumulate_waves(int d, int A) {
+    const int jh = mfma_column_split(d);
+    return mfma_accumulate_ops_per_block(d, A)*(jh == 0 ? 1 : jh);
 }
 int mfma_accumulate_lds_bytes(int d, int nw) {
+    const int jh = mfma_column_split(d);
     switch (d) {
-        case 8: return static_cast<int>(mfma4_lds_bytes<8>(nw));
-        case 12: return static_cast<int>(MfmaLayout<12>::lds_bytes);
-        case 16: return static_cast<int>(MfmaLayout<16>::lds_bytes);
+        case 8:
+            if (jh == 2) return static_cast<int>(mfma4_lds_bytes<8, 2>(nw));
+            return static_cast<int>(mfma4_lds_bytes<8, 1>(nw));
+        case 12:
+            if (jh == 1) return static_cast<int>(mfma4_lds_bytes<12, 1>(nw));
+            if (jh == 3) return static_cast<int>(mfma4_lds_bytes<12, 3>(nw));
+            return static_cast<int>(MfmaLayout<12>::lds_bytes);
+        case 16:
+            if (jh == 1) return static_cast<int>(mfma4_lds_bytes<16, 1>(nw));
+            if (jh == 2) return static_cast<int>(mfma4_lds_bytes<16, 2>(nw));
+            if (jh == 4) return static_cast<int>(mfma4_lds_bytes<16, 4>(nw));
+            return static_cast<int>(MfmaLayout<16>::lds_bytes);
         default: return 0;
     }
 }
@@ -492,8 +538,13 @@ int mfma_accumulate_lds_bytes(int d, int nw) {
 hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segtab, const cplx* ops,
                                   int G, int d, int A, int chunks, int chunk_len, int nw,
                                   cplx* Ypart, hipStream_t stream) {
+    const int jh = mfma_column_split(d);
+#define FFK_M4(D, JH) \
+    if (d == D && jh == JH) \
+        return launch_d4<D, JH>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);
+    FFK_M4(8, 1) FFK_M4(8, 2) FFK_M4(12, 1) FFK_M4(12, 3) FFK_M4(16, 1) FFK_M4(16, 2) FFK_M4(16, 4)
+#undef FFK_M4
     switch (d) {
-        case 8: return launch_d4<8>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);
         case 12: return launch_d<12>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
         case 16: return launch_d<16>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
         default: return hipErrorInvalidValue;

@@ -111,6 +111,7 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
 // ---- ctrl_mfma.hip ---------------------------------------------------------------------------
 bool mfma_accumulate_supported(int d);
 int mfma_accumulate_waves(int d, int A);
+int mfma_accumulate_ops_per_block(int d, int A);
 int mfma_accumulate_lds_bytes(int d, int nw);
 hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segtab, const cplx* ops,
                                   int G, int d, int A, int chunks, int chunk_len, int nw,
