@@ -703,7 +703,7 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         int chunks = forced_chunks;
         if (chunks <= 0) {
             // resident blocks: one per CU for the 512-register kernel; for d = 8 two waves per SIMD
-            const long per_cu = std::max(1, 8/geo.nwaves);
+            const long per_cu = std::max(1, (geo.nwaves > 8 ? 12 : 8)/geo.nwaves);
             const long capacity = device_cu_count()*per_cu;
             const int max_chunks = std::max(1, std::min((G + 3)/4, 256));
             double best = 0.0;

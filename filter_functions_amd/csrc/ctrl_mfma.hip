@@ -252,8 +252,8 @@ __global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
 // for its own row groups -- the 4-row instruction has no tile to leave half empty), which halves
 // the accumulators per wave: d = 16 fits 256 registers, i.e. two wavefronts per SIMD.
 // `nw` counts wavefronts; a block serves nw / JH noise operators.
-template <int D, int JH>
-__global__ __launch_bounds__(512) void ctrl_accumulate_mfma4_kernel(
+template <int D, int JH, int MAXW = 8>
+__global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, int nw, cplx* __restrict__ Ypart) {
     static_assert(D % 4 == 0 && D >= 4 && D <= 16, "d must be a multiple of 4");
@@ -436,10 +436,11 @@ size_t mfma4_lds_bytes(int nw) {
            2*static_cast<size_t>(seg_stride(D))*sizeof(double);
 }
 
-template <int D, int JH>
+template <int D, int JH, int MAXW = 8>
 hipError_t launch_d4(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                      int chunks, int chunk_len, int nw, cplx* Ypart, hipStream_t stream) {
-    auto kern = ctrl_accumulate_mfma4_kernel<D, JH>;
+    auto kern = ctrl_accumulate_mfma4_kernel<D, JH, MAXW>;
+    if (nw > MAXW) return hipErrorInvalidValue;
     const int lds = static_cast<int>(mfma4_lds_bytes<D, JH>(nw));
     // staging: (1 + na) d^2 + row/2 elements over nw*64 threads must fit kMaxStage per thread
     constexpr int kMaxStage = D == 16 ? 4 : 8;
@@ -510,6 +511,7 @@ int mfma_accumulate_ops_per_block(int d, int A) {
         }
         return std::min(best, std::max(A, 3));
     }
+    if (d == 16 && jh == 4) return 3;  // twelve wavefronts per block (tuning variant)
     return std::max(1, 8/jh);         // eight wavefronts per block
 }
 int mfma_accumulate_waves(int d, int A) {
@@ -542,8 +544,10 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
 #define FFK_M4(D, JH) \
     if (d == D && jh == JH) \
         return launch_d4<D, JH>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);
-    FFK_M4(8, 1) FFK_M4(8, 2) FFK_M4(12, 1) FFK_M4(12, 3) FFK_M4(16, 1) FFK_M4(16, 2) FFK_M4(16, 4)
+    FFK_M4(8, 1) FFK_M4(8, 2) FFK_M4(12, 1) FFK_M4(12, 3) FFK_M4(16, 1) FFK_M4(16, 2)
 #undef FFK_M4
+    if (d == 16 && jh == 4)
+        return launch_d4<16, 4, 12>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);
     switch (d) {
         case 12: return launch_d<12>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
         case 16: return launch_d<16>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
