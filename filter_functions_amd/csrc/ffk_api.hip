@@ -53,6 +53,12 @@ bool d_ok(int d) { return d >= 2 && d <= FFK_MAX_D; }
 // internal flag of ffk_control_matrix_dev: the workspace already holds segtab/Tc/ops (written by
 // the fused front end of ffk_pipeline_dev)
 constexpr unsigned FFK_INTERNAL_PROLOGUE_DONE = 0x80000000u;
+// ... and the compacted basis lists in the expansion workspace (same launch)
+constexpr unsigned FFK_INTERNAL_COMPACT_DONE = 0x40000000u;
+// set by ffk_pipeline_dev around its call of ffk_control_matrix_dev: where the fidelity filter
+// function should go if the expansion launch can produce it too, and whether it did
+thread_local cplx* g_fuse_F = nullptr;
+thread_local bool g_fuse_F_done = false;
 
 // bump allocator over a caller- or arena-provided workspace
 struct Bump {
@@ -398,9 +404,19 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     const size_t slab = size_t(A)*d*d*W;
     const bool want_B = (flags & FFK_WANT_NOISE_OPERATORS) != 0;
     const cplx* Bsum = Ypart;
-    bool compacted = false;
+    bool compacted = (flags & FFK_INTERNAL_COMPACT_DONE) != 0;
+    if (compacted && control_matrix && !want_B && g_fuse_F && ffk::expand_ff_supported(A, N)) {
+        // only R and F are wanted and the basis lists are ready: chunk sum, expansion and F in one
+        FFK_HIP(ffk::launch_expand_ff(Ypart, geo.chunks, slab, A, N, d, W,
+                                      reinterpret_cast<cplx*>(control_matrix), g_fuse_F, ews, s));
+        g_fuse_F_done = true;
+    } else if (compacted && control_matrix && !want_B && geo.chunks > 1) {
+        // only R is wanted and the basis lists are ready: expand straight from the chunk partials
+        FFK_HIP(ffk::launch_expand_chunks(Ypart, geo.chunks, slab, A, N, d, W,
+                                          reinterpret_cast<cplx*>(control_matrix), ews, s));
+    } else {
     if (geo.chunks > 1) {
-        if (control_matrix) {
+        if (control_matrix && !compacted) {
             FFK_HIP(ffk::launch_reduce_and_compact(Ypart, geo.chunks, slab, Bt,
                                                    reinterpret_cast<const cplx*>(basis), N, d, ews, s));
             compacted = true;
@@ -414,6 +430,7 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
                                    reinterpret_cast<cplx*>(control_matrix), ews, compacted, s));
     if (want_B)
         FFK_HIP(ffk::launch_transpose_noise_ops(Bsum, A, d, W, reinterpret_cast<cplx*>(noise_operators), s));
+    }
 
     g_stats.accumulate_flops = accumulate_flops(W, A, G, d);
     g_stats.accumulate_bytes = double(sizeof(cplx))*(double(geo.chunks)*slab) + 8.0*W +
@@ -1107,22 +1124,32 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
         FFK_HIP(ffk::launch_eigh_expm(reinterpret_cast<const cplx*>(hamiltonian), dt, G, d, D,
                                       reinterpret_cast<cplx*>(V), w.seg_prop, w.status, s));
         FFK_HIP(ffk::launch_scan_local(w.seg_prop, G, d, ffk::front_chunk(d), w.qloc, totals, s));
+        // same slicing as ffk_control_matrix_dev; the launch also compacts the basis (extra blocks)
+        const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);
         Bump cw(cws, cwsb);
         double* segtab = cw.take<double>(size_t(G)*ffk::seg_stride(d));
         cplx* Tc = cw.take<cplx>(size_t(G)*d*d);
         cplx* ops = cw.take<cplx>(size_t(G)*(1 + A)*d*d);
-        FFK_HIP(ffk::launch_apply_prologue(w.qloc, totals, G, d, reinterpret_cast<cplx*>(Q), D,
-                                           reinterpret_cast<const cplx*>(V),
-                                           reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, A,
-                                           segtab, Tc, ops, s));
-        cm_flags = FFK_INTERNAL_PROLOGUE_DONE;
+        cw.take<cplx>(size_t(geo.chunks)*A*d*d*W);     // Ypart
+        cw.take<cplx>(size_t(A)*d*d*W);                // Bt
+        void* ews = cw.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
+        FFK_REQUIRE(ews, "workspace too small");
+        FFK_HIP(ffk::launch_apply_prologue_compact(
+            w.qloc, totals, G, d, reinterpret_cast<cplx*>(Q), D, reinterpret_cast<const cplx*>(V),
+            reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, A, segtab, Tc, ops,
+            reinterpret_cast<const cplx*>(basis), N, ews, s));
+        cm_flags = FFK_INTERNAL_PROLOGUE_DONE | FFK_INTERNAL_COMPACT_DONE;
     } else {
         if (int rc = ffk_diagonalize_dev(hamiltonian, dt, G, d, D, V, Q, dws, dwsb, stream)) return rc;
     }
-    if (int rc = ffk_control_matrix_dev(D, V, Q, omega, W, basis, N, n_opers, A, n_coeffs, dt, t, G, d,
-                                        cm_flags, R, nullptr, cws, cwsb, stream))
-        return rc;
-    if (int rc = ffk_filter_function_dev(R, A, N, W, FFK_FF_FIDELITY, F, stream)) return rc;
+    g_fuse_F = reinterpret_cast<cplx*>(F);
+    g_fuse_F_done = false;
+    const int rc_cm = ffk_control_matrix_dev(D, V, Q, omega, W, basis, N, n_opers, A, n_coeffs, dt, t,
+                                             G, d, cm_flags, R, nullptr, cws, cwsb, stream);
+    g_fuse_F = nullptr;
+    if (rc_cm) return rc_cm;
+    if (!g_fuse_F_done)
+        if (int rc = ffk_filter_function_dev(R, A, N, W, FFK_FF_FIDELITY, F, stream)) return rc;
     if (want_infid) {
         const size_t iwsb = ffk_infidelity_workspace_bytes(W, n_idx, s_ndim);
         void* iws = ws.take<unsigned char>(iwsb);

@@ -78,6 +78,14 @@ hipError_t launch_apply_prologue(const cplx* Qloc, const cplx* totals, int G, in
                                  const double* eigvals, const cplx* eigvecs, const cplx* n_opers,
                                  const double* n_coeffs, const double* dt, const double* t, int A,
                                  double* segtab, cplx* Tc, cplx* ops, hipStream_t stream);
+// The same launch with N extra blocks that compact the basis into the expansion workspace `ews`
+// (what launch_expand_chunks needs) -- no separate launch for it.
+hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, int G, int d, cplx* Q,
+                                         const double* eigvals, const cplx* eigvecs,
+                                         const cplx* n_opers, const double* n_coeffs,
+                                         const double* dt, const double* t, int A, double* segtab,
+                                         cplx* Tc, cplx* ops, const cplx* basis, int N, void* ews,
+                                         hipStream_t stream);
 // basis_transformed (G,N,d,d) = (Q^dag V)^dag C_k (Q^dag V)   (numeric.py:863-864)
 hipError_t launch_basis_transformed(const cplx* Tc, const cplx* basis, int G, int N, int d,
                                     cplx* out, hipStream_t stream);
@@ -123,6 +131,14 @@ hipError_t launch_reduce_chunks(const cplx* Ypart, int chunks, size_t slab, cplx
                                 hipStream_t stream);
 // R (A2,N,W) with R[a,k,w] = sum_ij Bt[a,i,j,w] C_k[j,i];  A2 = any leading batch
 size_t expand_workspace_bytes(int N, int d);
+void expand_workspace_slices(void* ws, int N, int d, int** nnz, int** rows, cplx** vals);
+// R from the chunk partials directly (basis lists already compacted in ws)
+hipError_t launch_expand_chunks(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d,
+                                int W, cplx* R, void* ws, hipStream_t stream);
+// ... and the fidelity filter function F (A,A,W) in the same launch (small A*N)
+bool expand_ff_supported(int A, int N);
+hipError_t launch_expand_ff(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d, int W,
+                            cplx* R, cplx* F, void* ws, hipStream_t stream);
 // `compacted`: the basis lists in ws were already produced by launch_reduce_and_compact
 hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d, int W, cplx* R,
                          void* ws, bool compacted, hipStream_t stream);
@@ -173,5 +189,34 @@ hipError_t launch_noise_ops_from_atomic(const cplx* phases, const cplx* atomic, 
 size_t liouville_workspace_bytes(int batch, int d, int N);
 hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, int N,
                             int hermitian, double* out, void* ws, hipStream_t stream);
+
+
+#if defined(__HIPCC__)
+// One wavefront compacts basis element k into (count, entry index e = i*d + j, value C_k[j][i])
+// lists: the expansion R[a,k,w] = sum_ij Y[a,i,j,w] C_k[j,i] then only touches the non-zeros
+// (d per element for Pauli bases, <= 2 for the off-diagonal GGM elements).
+__device__ __forceinline__ void basis_compact_one(const cplx* __restrict__ basis, int d, int k,
+                                                  int lane, int* __restrict__ nnz,
+                                                  int* __restrict__ rows,
+                                                  cplx* __restrict__ vals) {
+    const int dd = d*d;
+    const cplx* C = basis + static_cast<size_t>(k)*dd;
+    int count = 0;
+    for (int base = 0; base < dd; base += 64) {
+        const int e = base + lane;            // e = i*d + j  (row index into Bt)
+        cplx v = {0.0, 0.0};
+        if (e < dd) v = C[(e % d)*d + e / d];  // C_k[j][i]
+        const bool nz = v.re != 0.0 || v.im != 0.0;
+        const unsigned long long mask = __ballot(nz);
+        if (nz) {
+            const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
+            rows[static_cast<size_t>(k)*dd + pos] = e;
+            vals[static_cast<size_t>(k)*dd + pos] = v;
+        }
+        count += __popcll(mask);
+    }
+    if (lane == 0) nnz[k] = count;
+}
+#endif
 
 }  // namespace ffk

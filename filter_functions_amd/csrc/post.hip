@@ -1,6 +1,8 @@
 // post.hip -- everything downstream of the segment sum: chunk reduction, basis expansion
 // R = tr(B~ C_k), filter function F = R^dag R and the trapezoid integrals of the infidelity.
 // All of these are single-pass, HBM-streaming kernels with omega as the fastest (lane) axis.
+#include <algorithm>
+
 #include "ffk_internal.h"
 
 namespace ffk {
@@ -27,29 +29,6 @@ __global__ void reduce_chunks_kernel(const cplx* __restrict__ Ypart, int chunks,
 // the expansion only touches the non-zeros: d^3 instead of d^4 work per (a, w) for Pauli bases,
 // ~d^2 for GGM -- the same saving the reference gets from its closed-form ggm_expand
 // (basis.py:701-787), without special-casing the basis type.  Dense bases cost what they did.
-__device__ __forceinline__ void basis_compact_one(const cplx* __restrict__ basis, int d, int k,
-                                                  int lane, int* __restrict__ nnz,
-                                                  int* __restrict__ rows,
-                                                  cplx* __restrict__ vals) {
-    const int dd = d*d;
-    const cplx* C = basis + static_cast<size_t>(k)*dd;
-    int count = 0;
-    for (int base = 0; base < dd; base += 64) {
-        const int e = base + lane;            // e = i*d + j  (row index into Bt)
-        cplx v = {0.0, 0.0};
-        if (e < dd) v = C[(e % d)*d + e / d];  // C_k[j][i]
-        const bool nz = v.re != 0.0 || v.im != 0.0;
-        const unsigned long long mask = __ballot(nz);
-        if (nz) {
-            const int pos = count + __popcll(mask & ((1ull << lane) - 1ull));
-            rows[static_cast<size_t>(k)*dd + pos] = e;
-            vals[static_cast<size_t>(k)*dd + pos] = v;
-        }
-        count += __popcll(mask);
-    }
-    if (lane == 0) nnz[k] = count;
-}
-
 __global__ __launch_bounds__(64) void basis_compact_kernel(const cplx* __restrict__ basis, int d,
                                                            int* __restrict__ nnz,
                                                            int* __restrict__ rows,
@@ -315,6 +294,145 @@ hipError_t launch_reduce_and_compact(const cplx* Ypart, int chunks, size_t slab,
     const int nred = static_cast<int>((slab + block - 1)/block);
     hipLaunchKernelGGL(reduce_compact_kernel, dim3(nred + N), dim3(block), 0, stream, Ypart, chunks,
                        slab, Bt, nred, basis, d, c.nnz, c.rows, c.vals);
+    return hipGetLastError();
+}
+
+void expand_workspace_slices(void* ws, int N, int d, int** nnz, int** rows, cplx** vals) {
+    const CompactWs cw = slice_compact_ws(ws, N, d);
+    *nnz = cw.nnz;
+    *rows = cw.rows;
+    *vals = cw.vals;
+}
+
+// Expansion straight from the segment-chunk partials: R[a,k,w] = sum_nz C_k[j,i] (sum_z
+// Ypart[z,a,i,j,w]) with the chunk sum taken on the fly in chunk order (the same value
+// reduce_chunks produces), so that the reduction launch and the round trip of the summed Y through
+// HBM disappear when only the control matrix is wanted.  Each entry of Y is summed once per basis
+// element that touches it (d times for a Pauli basis): more L2 reads, one launch less.
+__global__ __launch_bounds__(64) void expand_chunks_kernel(const cplx* __restrict__ Ypart, int chunks,
+                                                           size_t slab, const int* __restrict__ nnz,
+                                                           const int* __restrict__ rows,
+                                                           const cplx* __restrict__ vals, int N,
+                                                           int dd, int W, cplx* __restrict__ R) {
+    const int w = blockIdx.x*64 + threadIdx.x;
+    const int a = blockIdx.y, k = blockIdx.z;
+    if (w >= W) return;
+    const cplx* b = Ypart + static_cast<size_t>(a)*dd*W + w;
+    const int n = nnz[k];
+    const int* rk = rows + static_cast<size_t>(k)*dd;
+    const cplx* vk = vals + static_cast<size_t>(k)*dd;
+    auto summed = [&](int e) {
+        cplx acc = b[static_cast<size_t>(e)*W];
+        for (int z = 1; z < chunks; ++z) {
+            const cplx v = b[z*slab + static_cast<size_t>(e)*W];
+            acc.re += v.re;
+            acc.im += v.im;
+        }
+        return acc;
+    };
+    cplx acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+    int q = 0;
+    for (; q + 1 < n; q += 2) {
+        cmac(acc0, vk[q], summed(rk[q]));
+        cmac(acc1, vk[q + 1], summed(rk[q + 1]));
+    }
+    if (q < n) cmac(acc0, vk[q], summed(rk[q]));
+    R[(static_cast<size_t>(a)*N + k)*W + w] = {acc0.re + acc1.re, acc0.im + acc1.im};
+}
+
+// The same expansion followed, in the same launch, by the fidelity filter function of the block's
+// 16 frequencies: F[a,b,w] = sum_k conj(R[a,k,w]) R[b,k,w] (a <= b, mirrored; the summation order
+// of ff_fidelity_kernel).  Block = 16 frequencies x `kt` basis-element lanes; R passes through LDS.
+__global__ __launch_bounds__(1024) void expand_ff_kernel(const cplx* __restrict__ Ypart, int chunks,
+                                                         size_t slab, const int* __restrict__ nnz,
+                                                         const int* __restrict__ rows,
+                                                         const cplx* __restrict__ vals, int N, int dd,
+                                                         int W, int A, int kt, cplx* __restrict__ R,
+                                                         cplx* __restrict__ F) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    cplx* rl = reinterpret_cast<cplx*>(lds_raw);       // [A][N][16]
+    // thread = (frequency wl, basis-element lane kl, noise operator lane al)
+    const int wl = threadIdx.x & 15;
+    const int kl = (threadIdx.x >> 4) % kt, al = (threadIdx.x >> 4) / kt;
+    const int at = (blockDim.x >> 4) / kt;
+    const int w = blockIdx.x*16 + wl;
+    const int wc = w < W ? w : W - 1;
+    for (int a = al; a < A; a += at) {
+        const cplx* b = Ypart + static_cast<size_t>(a)*dd*W + wc;
+        for (int k = kl; k < N; k += kt) {
+            const int n = nnz[k];
+            const int* rk = rows + static_cast<size_t>(k)*dd;
+            const cplx* vk = vals + static_cast<size_t>(k)*dd;
+            auto summed = [&](int e) {
+                cplx acc = b[static_cast<size_t>(e)*W];
+                for (int z = 1; z < chunks; ++z) {
+                    const cplx v = b[z*slab + static_cast<size_t>(e)*W];
+                    acc.re += v.re;
+                    acc.im += v.im;
+                }
+                return acc;
+            };
+            cplx acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+            int q = 0;
+            for (; q + 1 < n; q += 2) {
+                cmac(acc0, vk[q], summed(rk[q]));
+                cmac(acc1, vk[q + 1], summed(rk[q + 1]));
+            }
+            if (q < n) cmac(acc0, vk[q], summed(rk[q]));
+            const cplx r = {acc0.re + acc1.re, acc0.im + acc1.im};
+            rl[(static_cast<size_t>(a)*N + k)*16 + wl] = r;
+            if (w < W) R[(static_cast<size_t>(a)*N + k)*W + w] = r;
+        }
+    }
+    __syncthreads();
+    if (w >= W) return;
+    const int npairs = A*(A + 1)/2;
+    const int lanes = blockDim.x >> 4;
+    for (int p = threadIdx.x >> 4; p < npairs; p += lanes) {
+        int a = 0, rem = p;                  // p -> (a, b), a <= b, row-major over the upper triangle
+        while (rem >= A - a) {
+            rem -= A - a;
+            ++a;
+        }
+        const int b = a + rem;
+        const cplx* ra = rl + static_cast<size_t>(a)*N*16 + wl;
+        const cplx* rb = rl + static_cast<size_t>(b)*N*16 + wl;
+        cplx acc = {0.0, 0.0};
+        for (int k = 0; k < N; ++k) cmac_conj(acc, ra[k*16], rb[k*16]);
+        if (a == b) acc.im = 0.0;
+        F[(static_cast<size_t>(a)*A + b)*W + w] = acc;
+        if (a != b) F[(static_cast<size_t>(b)*A + a)*W + w] = {acc.re, -acc.im};
+    }
+}
+
+bool expand_ff_supported(int A, int N) {
+    return static_cast<size_t>(A)*N*16*sizeof(cplx) <= 64*1024;
+}
+
+hipError_t launch_expand_ff(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d, int W,
+                            cplx* R, cplx* F, void* ws, hipStream_t stream) {
+    if (!expand_ff_supported(A, N)) return hipErrorInvalidValue;
+    const CompactWs cw = slice_compact_ws(ws, N, d);
+    const int kt = N >= 16 ? 16 : (N >= 8 ? 8 : 4);
+    const int at = std::max(1, std::min(A, 64/kt));          // block = 16 x kt x at <= 1024 threads
+    const size_t lds = static_cast<size_t>(A)*N*16*sizeof(cplx);
+    if (lds > 48*1024) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(expand_ff_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds));
+        if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(expand_ff_kernel, dim3((W + 15)/16), dim3(16*kt*at), lds, stream, Ypart,
+                       chunks, slab, cw.nnz, cw.rows, cw.vals, N, d*d, W, A, kt, R, F);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_chunks(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d,
+                                int W, cplx* R, void* ws, hipStream_t stream) {
+    if (A > 65535 || N > 65535) return hipErrorInvalidValue;
+    const CompactWs cw = slice_compact_ws(ws, N, d);
+    hipLaunchKernelGGL(expand_chunks_kernel, dim3((W + 63)/64, A, N), dim3(64), 0, stream, Ypart,
+                       chunks, slab, cw.nnz, cw.rows, cw.vals, N, d*d, W, R);
     return hipGetLastError();
 }
 

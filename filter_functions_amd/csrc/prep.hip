@@ -117,7 +117,14 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
     cplx* __restrict__ Qout, const double* __restrict__ eigvals, const cplx* __restrict__ eigvecs,
     const cplx* __restrict__ n_opers, const double* __restrict__ n_coeffs,
     const double* __restrict__ dt, const double* __restrict__ t, int A,
-    double* __restrict__ segtab, cplx* __restrict__ Tc, cplx* __restrict__ ops) {
+    double* __restrict__ segtab, cplx* __restrict__ Tc, cplx* __restrict__ ops,
+    const cplx* __restrict__ basis, int* __restrict__ nnz, int* __restrict__ rows,
+    cplx* __restrict__ vals) {
+    // extra blocks (launch_apply_prologue_compact): basis compaction
+    if (static_cast<int>(blockIdx.x) >= G) {
+        basis_compact_one(basis, D, static_cast<int>(blockIdx.x) - G, threadIdx.x, nnz, rows, vals);
+        return;
+    }
     __shared__ cplx E[2][D][D];
     __shared__ cplx M[D][D];
     __shared__ cplx V[D][D];
@@ -260,17 +267,27 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
     return hipGetLastError();
 }
 
-hipError_t launch_apply_prologue(const cplx* Qloc, const cplx* totals, int G, int d, cplx* Q,
-                                 const double* eigvals, const cplx* eigvecs, const cplx* n_opers,
-                                 const double* n_coeffs, const double* dt, const double* t, int A,
-                                 double* segtab, cplx* Tc, cplx* ops, hipStream_t stream) {
+hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, int G, int d, cplx* Q,
+                                         const double* eigvals, const cplx* eigvecs,
+                                         const cplx* n_opers, const double* n_coeffs,
+                                         const double* dt, const double* t, int A, double* segtab,
+                                         cplx* Tc, cplx* ops, const cplx* basis, int N, void* ews,
+                                         hipStream_t stream) {
     const int L = front_chunk(d);
+    int* nnz = nullptr;
+    int* rows = nullptr;
+    cplx* vals = nullptr;
+    int extra = 0;
+    if (basis) {
+        expand_workspace_slices(ews, N, d, &nnz, &rows, &vals);
+        extra = N;
+    }
     switch (d) {
 #define FFK_CASE(D)                                                                              \
     case D:                                                                                      \
-        hipLaunchKernelGGL(apply_prologue_kernel<D>, dim3(G), dim3(64), 0, stream, Qloc, totals, \
-                           G, L, Q, eigvals, eigvecs, n_opers, n_coeffs, dt, t, A, segtab, Tc,   \
-                           ops);                                                                 \
+        hipLaunchKernelGGL(apply_prologue_kernel<D>, dim3(G + extra), dim3(64), 0, stream, Qloc, \
+                           totals, G, L, Q, eigvals, eigvecs, n_opers, n_coeffs, dt, t, A,       \
+                           segtab, Tc, ops, basis, nnz, rows, vals);                             \
         break;
         FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
         FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
@@ -280,6 +297,14 @@ hipError_t launch_apply_prologue(const cplx* Qloc, const cplx* totals, int G, in
             return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+hipError_t launch_apply_prologue(const cplx* Qloc, const cplx* totals, int G, int d, cplx* Q,
+                                 const double* eigvals, const cplx* eigvecs, const cplx* n_opers,
+                                 const double* n_coeffs, const double* dt, const double* t, int A,
+                                 double* segtab, cplx* Tc, cplx* ops, hipStream_t stream) {
+    return launch_apply_prologue_compact(Qloc, totals, G, d, Q, eigvals, eigvecs, n_opers, n_coeffs,
+                                         dt, t, A, segtab, Tc, ops, nullptr, 0, nullptr, stream);
 }
 
 hipError_t launch_basis_transformed(const cplx* Tc, const cplx* basis, int G, int N, int d,
