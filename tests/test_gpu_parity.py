@@ -946,3 +946,42 @@ def test_randomised_shapes_against_oracle(seed):
             ref = orc.infidelity_from_filter_function(orc.filter_function(R_ref), S, omega,
                                                       np.arange(A), d)
             assert np.abs(infid - ref).max() <= TOL*np.abs(ref).max(), tag
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_device_pipeline_random_shapes(seed):
+    """The fused device pipeline (ffk_pipeline_dev: compaction inside the prologue launch, chunk sum
+    + expansion + F in one launch where A d^2 <= 256, separate kernels otherwise) over random
+    shapes against the oracle."""
+    import torch
+    from filter_functions_amd.device import DevicePipeline
+    rng = np.random.default_rng(500 + seed)
+    for _ in range(3):
+        d = int(rng.choice([2, 3, 4, 5, 6, 8, 12, 16]))
+        G = int(rng.integers(1, 40))
+        A = int(rng.integers(1, 6))
+        W = int(rng.choice([2, 16, 63, 200, 1000]))
+        def herm(n):
+            M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+            return M + M.conj().transpose(0, 2, 1)
+        c_opers, n_opers = herm(2), herm(A)
+        c_coeffs, n_coeffs = rng.standard_normal((2, G)), rng.random((A, G)) + 0.1
+        dt = rng.random(G) + 0.2
+        omega = np.sort(rng.random(W))*30 + 1e-3
+        basis = ff.Basis.ggm(d) if rng.random() < 0.5 or d not in (2, 4, 8, 16) else \
+            ff.Basis.pauli(int(np.log2(d)))
+        S = rng.random((A, W)) + 0.1
+        pipe = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum=S)
+        pipe.launch()
+        torch.cuda.synchronize()
+        H = orc.hamiltonian(c_opers, c_coeffs)
+        D, V, Q = orc.diagonalize(H, dt)
+        R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), n_opers, n_coeffs, dt)
+        F_ref = orc.filter_function(R_ref)
+        tag = f'd={d} G={G} A={A} W={W} {basis.btype}'
+        assert rel_err(pipe.control_matrix.cpu().numpy(), R_ref) < TOL, tag
+        F = pipe.filter_function.cpu().numpy()
+        assert rel_err(F, F_ref) < TOL, tag
+        assert np.array_equal(F, F.conj().transpose(1, 0, 2)), tag
+        ref = orc.infidelity_from_filter_function(F_ref, S, omega, np.arange(A), d)
+        assert np.abs(pipe.infid.cpu().numpy() - ref).max() <= TOL*np.abs(ref).max(), tag
