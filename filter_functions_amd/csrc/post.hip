@@ -427,9 +427,68 @@ hipError_t launch_expand_ff(const cplx* Ypart, int chunks, size_t slab, int A, i
     return hipGetLastError();
 }
 
+// Large d: one block per (noise operator, 16 frequencies) stages Y[a,:,:,w-tile] in LDS once
+// (summing the segment chunks on the way) and expands it for every basis element from there.  Y is
+// read from HBM exactly once whatever the sparsity of the basis (a Pauli element of d = 16 has 16
+// non-zeros: the per-element kernel re-read Y 16 times through L2, 2.7 ms at config-5 size).
+__global__ __launch_bounds__(256) void expand_lds_kernel(const cplx* __restrict__ Ypart, int chunks,
+                                                         size_t slab, const int* __restrict__ nnz,
+                                                         const int* __restrict__ rows,
+                                                         const cplx* __restrict__ vals, int N, int dd,
+                                                         int W, cplx* __restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    cplx* yl = reinterpret_cast<cplx*>(lds_raw);       // [dd][16]
+    const int wl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int a = blockIdx.y;
+    const int w = blockIdx.x*16 + wl;
+    const int wc = w < W ? w : W - 1;
+    const cplx* b = Ypart + static_cast<size_t>(a)*dd*W + wc;
+    for (int e = kl; e < dd; e += 16) {
+        cplx acc = b[static_cast<size_t>(e)*W];
+        for (int z = 1; z < chunks; ++z) {
+            const cplx v = b[z*slab + static_cast<size_t>(e)*W];
+            acc.re += v.re;
+            acc.im += v.im;
+        }
+        yl[e*16 + wl] = acc;
+    }
+    __syncthreads();
+    if (w >= W) return;
+    for (int k = kl; k < N; k += 16) {
+        const int n = nnz[k];
+        const int* rk = rows + static_cast<size_t>(k)*dd;
+        const cplx* vk = vals + static_cast<size_t>(k)*dd;
+        cplx acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+        int q = 0;
+        for (; q + 1 < n; q += 2) {
+            cmac(acc0, vk[q], yl[rk[q]*16 + wl]);
+            cmac(acc1, vk[q + 1], yl[rk[q + 1]*16 + wl]);
+        }
+        if (q < n) cmac(acc0, vk[q], yl[rk[q]*16 + wl]);
+        R[(static_cast<size_t>(a)*N + k)*W + w] = {acc0.re + acc1.re, acc0.im + acc1.im};
+    }
+}
+
+hipError_t launch_expand_lds(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d, int W,
+                             cplx* R, void* ws, hipStream_t stream) {
+    if (A > 65535) return hipErrorInvalidValue;
+    const CompactWs cw = slice_compact_ws(ws, N, d);
+    const size_t lds = static_cast<size_t>(d)*d*16*sizeof(cplx);
+    if (lds > 48*1024) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(expand_lds_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds));
+        if (err != hipSuccess) return err;
+    }
+    hipLaunchKernelGGL(expand_lds_kernel, dim3((W + 15)/16, A), dim3(256), lds, stream, Ypart, chunks,
+                       slab, cw.nnz, cw.rows, cw.vals, N, d*d, W, R);
+    return hipGetLastError();
+}
+
 hipError_t launch_expand_chunks(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d,
                                 int W, cplx* R, void* ws, hipStream_t stream) {
     if (A > 65535 || N > 65535) return hipErrorInvalidValue;
+    if (d >= 8) return launch_expand_lds(Ypart, chunks, slab, A, N, d, W, R, ws, stream);
     const CompactWs cw = slice_compact_ws(ws, N, d);
     hipLaunchKernelGGL(expand_chunks_kernel, dim3((W + 63)/64, A, N), dim3(64), 0, stream, Ypart,
                        chunks, slab, cw.nnz, cw.rows, cw.vals, N, d*d, W, R);
@@ -446,6 +505,10 @@ hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d
     cplx* vals = cw.vals;
     if (!compacted)
         hipLaunchKernelGGL(basis_compact_kernel, dim3(N), dim3(64), 0, stream, basis, d, nnz, rows, vals);
+    if (d >= 8) {
+        hipError_t err = launch_expand_lds(Bt, 1, 0, A2, N, d, W, R, ws, stream);
+        return err;
+    }
     // few basis elements per thread when the grid would otherwise be small
     const long blocks1 = static_cast<long>((W + 63)/64)*A2;
     if (blocks1*N <= 16384 || N <= 16) {
