@@ -17,6 +17,9 @@
 // evaluated without the N^4 trace tensor: with D_k = sum_l Gamma_kl C_l the cumulant
 // superoperator is  K(X) = -1/2 sum_k (C_k D_k X - C_k X D_k - D_k X C_k + X D_k C_k)  and
 // K_ij = tr(C_i K(C_j)): four small complex GEMMs (O(d^6)) per noise-operator pair.
+#include <cmath>
+#include <utility>
+
 #include "ffk_internal.h"
 
 namespace ffk {
@@ -388,6 +391,63 @@ hipError_t launch_cumulant_function(const double* gamma, size_t batch, int N, in
     // 5. K_ij = Re sum_(q',p') C_i[q',p'] U[(q',p'), j]
     GemmDesc g5{N, N, static_cast<int>(d2), d2, 1, 0, N, 1, sD, N, 1, static_cast<long>(N)*N, 0, 1};
     if ((err = launch_gemm_small(basis, U, K, g5, nb, stream)) != hipSuccess) return err;
+    return hipGetLastError();
+}
+
+
+// ---- matrix exponential of a real N x N matrix (error_transfer_matrix, numeric.py:2049-2053) ----
+// C = alpha A B + (add_identity ? 1 : 0), real FP64, row-major, one 16x16 tile per wavefront on
+// v_mfma_f64_16x16x4 (operand maps as in decay_gemm_kernel); edges are zero-padded by the loads.
+namespace {
+__global__ __launch_bounds__(64) void dgemm_eye_kernel(const double* __restrict__ A,
+                                                       const double* __restrict__ B, int N,
+                                                       double alpha, int add_identity,
+                                                       double* __restrict__ C) {
+    const int lane = threadIdx.x;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    const int row = ti*16 + l15, col = tj*16 + l15;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < N; k0 += 4) {
+        const int k = k0 + lk;
+        const double a = (row < N && k < N) ? A[static_cast<size_t>(row)*N + k] : 0.0;
+        const double b = (k < N && col < N) ? B[static_cast<size_t>(k)*N + col] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    if (col >= N) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = ti*16 + lk + 4*r;
+        if (i < N) C[static_cast<size_t>(i)*N + col] = alpha*acc[r] + ((add_identity && i == col) ? 1.0 : 0.0);
+    }
+}
+}  // namespace
+
+// out = exp(A) by scaling and squaring: B = A / 2^s with |B|_1 <= 1/2, Taylor polynomial of degree
+// 18 in Horner form (remainder < 2^-19/19! ~ 1e-23), then s squarings.  A, out, and two N x N
+// scratch matrices are device pointers; `squarings` = s is chosen by the caller from the norm.
+hipError_t launch_expm_real(const double* A, int N, int squarings, double* out, double* t0, double* t1,
+                            hipStream_t stream) {
+    const dim3 grid((N + 15)/16, (N + 15)/16);
+    const double scale = std::ldexp(1.0, -squarings);
+    constexpr int kDegree = 18;
+    // T = 1 + B/kDegree;  T <- 1 + (B T)/m for m = kDegree-1 .. 1
+    double* cur = t0;
+    double* nxt = t1;
+    // first step: B * 1 / kDegree + 1  ==  (A * I) needs no product: use alpha on A itself via A*A? no:
+    // start from T = 1 (identity built by a product with alpha = 0)
+    hipLaunchKernelGGL(dgemm_eye_kernel, grid, dim3(64), 0, stream, A, A, N, 0.0, 1, cur);
+    for (int m = kDegree; m >= 1; --m) {
+        hipLaunchKernelGGL(dgemm_eye_kernel, grid, dim3(64), 0, stream, A, cur, N, scale/m, 1, nxt);
+        std::swap(cur, nxt);
+    }
+    for (int q = 0; q < squarings; ++q) {
+        hipLaunchKernelGGL(dgemm_eye_kernel, grid, dim3(64), 0, stream, cur, cur, N, 1.0, 0, nxt);
+        std::swap(cur, nxt);
+    }
+    hipError_t err = hipMemcpyAsync(out, cur, sizeof(double)*static_cast<size_t>(N)*N,
+                                    hipMemcpyDeviceToDevice, stream);
+    if (err != hipSuccess) return err;
     return hipGetLastError();
 }
 

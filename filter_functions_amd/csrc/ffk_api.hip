@@ -1033,6 +1033,41 @@ int ffk_cumulant_function(const double* decay_amplitudes, int batch, int N, int 
     return FFK_OK;
 }
 
+int ffk_expm_real(const double* matrix, int N, double* result) {
+    FFK_REQUIRE(matrix && result, "NULL argument");
+    FFK_REQUIRE(N >= 1 && N <= 4096, "matrix dimension %d outside [1, 4096]", N);
+    // scaling from the 1-norm (host: the matrix is N^2 <= 65536 doubles on this path)
+    double norm = 0.0;
+    for (int j = 0; j < N; ++j) {
+        double col = 0.0;
+        for (int i = 0; i < N; ++i) {
+            const double v = matrix[size_t(i)*N + j];
+            FFK_REQUIRE(v == v && v - v == 0.0, "matrix contains NaN or Inf");
+            col += v < 0 ? -v : v;
+        }
+        norm = col > norm ? col : norm;
+    }
+    int squarings = 0;
+    while (norm > 0.5 && squarings < 64) {
+        norm *= 0.5;
+        ++squarings;
+    }
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nb = 8*size_t(N)*N;
+    void* base;
+    if (int rc = arena_reserve(4*align_up(nb), &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dA = a.take<double>(nb/8);
+    double* dO = a.take<double>(nb/8);
+    double* t0 = a.take<double>(nb/8);
+    double* t1 = a.take<double>(nb/8);
+    FFK_HIP(hipMemcpyAsync(dA, matrix, nb, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(ffk::launch_expm_real(dA, N, squarings, dO, t0, t1, nullptr));
+    FFK_HIP(hipMemcpyAsync(result, dO, nb, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Liouville representation
 // ---------------------------------------------------------------------------------------------

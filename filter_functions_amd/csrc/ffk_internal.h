@@ -185,6 +185,10 @@ hipError_t launch_cumulant_function(const double* gamma, size_t batch, int N, in
 hipError_t launch_noise_ops_from_atomic(const cplx* phases, const cplx* atomic, const cplx* props,
                                         int G, int W, int A, int d, cplx* out, hipStream_t stream);
 
+// exp of a real N x N matrix (device pointers; t0, t1: N*N scratch each); see decay.hip
+hipError_t launch_expm_real(const double* A, int N, int squarings, double* out, double* t0, double* t1,
+                            hipStream_t stream);
+
 // ---- liouville.hip ---------------------------------------------------------------------------
 size_t liouville_workspace_bytes(int batch, int d, int N);
 hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, int N,

@@ -536,7 +536,14 @@ def error_transfer_matrix(pulse=None, spectrum=None, omega=None, n_oper_identifi
                                                         memory_parsimonious=memory_parsimonious,
                                                         cache_intermediates=cache_intermediates)
     try:
-        return sla.expm(cumulant_function.sum(axis=tuple(range(cumulant_function.ndim - 2))))
+        K = cumulant_function.sum(axis=tuple(range(cumulant_function.ndim - 2)))
+        if (np.ndim(K) != 2 or K.shape[0] != K.shape[1] or np.iscomplexobj(K) or K.shape[0] < 32
+                or not np.isfinite(K).all()):
+            return sla.expm(K)       # tiny or unusual input: SciPy, exactly like the reference
+        K = as_f64(K)
+        out = np.empty_like(K)
+        check(_lib.load().ffk_expm_real(ptr(K), K.shape[0], ptr(out)))
+        return out
     except AttributeError as aerr:
         raise TypeError(f'cumulant_function invalid type: {type(cumulant_function)}') from aerr
     except ValueError as verr:

@@ -262,6 +262,12 @@ int ffk_cumulant_function_dev(const double* decay_amplitudes, int batch, int N, 
 int ffk_cumulant_function(const double* decay_amplitudes, int batch, int N, int d,
                           const double* basis, int single_qubit, double* cumulant_function);
 
+/* ---- exp of the summed cumulant function (numeric.error_transfer_matrix, numeric.py:2049-2053;
+ *      the reference calls scipy.linalg.expm) ---------------------------------------------------
+ * matrix (N, N) f64 row-major -> result (N, N) = exp(matrix): scaling and squaring with a Taylor
+ * polynomial of degree 18, every product on v_mfma_f64_16x16x4.                                */
+int ffk_expm_real(const double* matrix, int N, double* result);
+
 /* ---- superoperator.liouville_representation (superoperator.py:51-84 + Basis.expand
  *      basis.py:350-371, 650-698) --------------------------------------------------------
  * U (batch, d, d) c128, basis (N, d, d) c128 -> liouville (batch, N, N):

@@ -985,3 +985,22 @@ def test_device_pipeline_random_shapes(seed):
         assert np.array_equal(F, F.conj().transpose(1, 0, 2)), tag
         ref = orc.infidelity_from_filter_function(F_ref, S, omega, np.arange(A), d)
         assert np.abs(pipe.infid.cpu().numpy() - ref).max() <= TOL*np.abs(ref).max(), tag
+
+
+@pytest.mark.parametrize('N,scale', [(36, 1e-4), (64, 0.3), (100, 5.0), (256, 1e-3), (256, 40.0), (33, 0.0)])
+def test_matrix_exponential_against_scipy(N, scale):
+    """ffk_expm_real (scaling and squaring, Taylor degree 18, MFMA products) against
+    scipy.linalg.expm, which the reference's error_transfer_matrix calls (numeric.py:2051)."""
+    import ctypes
+    from scipy.linalg import expm
+    rng = np.random.default_rng(N)
+    K = rng.standard_normal((N, N))*scale/np.sqrt(N)
+    K = K - 0.5*np.abs(K).sum(axis=0).max()*np.eye(N)*(scale > 1)      # decaying, like a cumulant
+    out = np.empty_like(K)
+    _lib.check(_lib.load().ffk_expm_real(K.ctypes.data_as(ctypes.c_void_p), N,
+                                         out.ctypes.data_as(ctypes.c_void_p)))
+    ref = expm(K)
+    assert np.abs(out - ref).max() <= 1e-12*max(np.abs(ref).max(), 1.0)
+    # the public function takes the same route for N >= 32
+    U = ff.error_transfer_matrix(cumulant_function=K[None])
+    assert np.array_equal(U, out)
