@@ -13,7 +13,8 @@ import os
 
 import numpy as np
 
-__all__ = ['shard_bounds', 'gather_omega_shards', 'sharded_filter_function', 'sum_omega_shards']
+__all__ = ['shard_bounds', 'gather_omega_shards', 'sharded_filter_function', 'sum_omega_shards',
+           'sharded_error_transfer_matrix']
 
 
 def shard_bounds(n_omega, world_size, rank):
@@ -99,3 +100,24 @@ def sum_omega_shards(local, group=None):
     for r in range(1, world):
         total += recv[r]
     return total
+
+
+def sharded_error_transfer_matrix(pipe, omega_global, w_offset, single_qubit=False, group=None):
+    """Error transfer matrix of a pulse whose frequency axis is sharded over the ranks (BASELINE
+    config 5): *pipe* is this rank's ``DevicePipeline`` over its omega block (already launched),
+    *omega_global* the full grid as a device tensor, *w_offset* the block's first index.
+
+    Each rank integrates its block of the decay amplitudes with the global trapezoid weights
+    (``ffk_decay_amplitudes_shard_dev``), the (n_nops, d^2, d^2) partial results are summed in rank
+    order on every rank (:func:`sum_omega_shards`: one small all-gather, bit-reproducible), and
+    the cumulant contraction and the matrix exponential -- omega independent, tiny -- run
+    redundantly on every rank.  Returns ``(decay_amplitudes, cumulant_function, U)``; the first
+    two are device tensors, ``U`` a NumPy array.
+    """
+    from . import numeric
+    gamma = sum_omega_shards(pipe.decay_amplitudes(omega_global=omega_global, w_offset=w_offset),
+                             group=group)
+    K = pipe.cumulant_function(gamma, single_qubit=single_qubit)
+    U = numeric.error_transfer_matrix(
+        cumulant_function=K.sum(dim=tuple(range(K.dim() - 2))).cpu().numpy()[None])
+    return gamma, K, U

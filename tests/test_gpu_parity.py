@@ -1004,3 +1004,32 @@ def test_matrix_exponential_against_scipy(N, scale):
     # the public function takes the same route for N >= 32
     U = ff.error_transfer_matrix(cumulant_function=K[None])
     assert np.array_equal(U, out)
+
+
+def test_sharded_error_transfer_matrix_single_rank():
+    """parallel.sharded_error_transfer_matrix on a one-rank gloo group (the collective path with
+    world size 1 is the identity): same result as the host API."""
+    import torch
+    import torch.distributed as dist
+    from filter_functions_amd.device import DevicePipeline
+    from filter_functions_amd.parallel import sharded_error_transfer_matrix
+    g = load_golden('etm')
+    name = 'g6'
+    omega, S = g[f'{name}_omega'], g[f'{name}_S2']
+    pipe = DevicePipeline(g[f'{name}_c_opers'], g[f'{name}_c_coeffs'], g[f'{name}_n_opers'],
+                          g[f'{name}_n_coeffs'], g[f'{name}_dt'], g[f'{name}_basis'], omega,
+                          spectrum=S)
+    pipe.launch(with_infidelity=False)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1)
+        created = True
+    try:
+        gamma, K, U = sharded_error_transfer_matrix(pipe, torch.from_numpy(omega).cuda(), 0)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert rel_err(gamma.cpu().numpy(), g[f'{name}_decay_amplitudes_S2']) < TOL
+    assert rel_err(K.cpu().numpy(), g[f'{name}_cumulant_function_S2']) < TOL
+    U_ref = g[f'{name}_error_transfer_matrix_S2']
+    assert np.abs(U - U_ref).max() < TOL*np.abs(U_ref - np.eye(len(U_ref))).max() + 1e-15
