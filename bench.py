@@ -82,6 +82,53 @@ def cpu_baseline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectru
                        f'os.cpu_count()={os.cpu_count()}'), result
 
 
+def measure_hbm_traffic(omega_per_gpu):
+    """HBM traffic of the accumulate kernel, per launch, from the PMC counters: two short child runs
+    of this script under ``rocprofv3 --pmc`` (FETCH_SIZE and WRITE_SIZE in separate passes, as the
+    MI355X guide prescribes; FETCH_SIZE counts half the bytes of wide streaming reads on gfx950,
+    hence the factor 2).  Returns (bytes, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(prof):
+        return None, 'rocprofv3 not found'
+    script = os.path.abspath(__file__)
+    means = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        out_dir = tempfile.mkdtemp(prefix='ffk_pmc_', dir='/tmp')
+        try:
+            env = dict(os.environ, TMPDIR='/tmp')
+            for key in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+                env.pop(key, None)
+            cmd = [prof, '--pmc', counter, '--output-format', 'csv', '-d', out_dir, '--',
+                   sys.executable, script, '--steps', '8', '--warmup', '2', '--no-cpu-baseline',
+                   '--no-pmc', '--omega-per-gpu', str(omega_per_gpu)]
+            res = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.DEVNULL, timeout=240)
+            if res.returncode != 0:
+                return None, f'rocprofv3 --pmc {counter} exited with {res.returncode}'
+            values = []
+            for f in glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if 'ctrl_accumulate' in row['Kernel_Name'] and row['Counter_Name'] == counter:
+                            values.append(float(row['Counter_Value']))
+            if not values:
+                return None, f'no {counter} samples for the accumulate kernel'
+            means[counter] = sum(values)/len(values)
+        except (OSError, subprocess.SubprocessError) as err:
+            return None, f'rocprofv3 --pmc {counter} failed: {err}'
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    traffic = (2.0*means['FETCH_SIZE'] + means['WRITE_SIZE'])*1024.0
+    return traffic, ('live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this script, '
+                     f"per launch: FETCH_SIZE {means['FETCH_SIZE']:.0f} KiB (x2), "
+                     f"WRITE_SIZE {means['WRITE_SIZE']:.0f} KiB")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -89,6 +136,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--omega-per-gpu', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-pmc', action='store_true',
+                    help='skip the rocprofv3 --pmc child runs that measure the HBM traffic')
     args = ap.parse_args()
 
     import torch
@@ -226,19 +275,25 @@ def main():
         E_step = G*W_total*A*d*d
         value = E_step*args.steps/elapsed
         achieved = stats['accumulate_flops']/(acc_ms*1e-3)/1e12
-        # HBM traffic of the same kernel: PMC counters cannot be read from inside this process,
-        # so the figure is the committed rocprofv3 --pmc measurement of this very command
-        # (profiles/k3_hbm_traffic.json; per launch, 2*FETCH_SIZE + WRITE_SIZE as the MI355X guide
-        # prescribes for gfx950); null when the launch geometry differs from the profiled one
+        # HBM traffic of the same kernel, per launch: measured live by two short child runs of this
+        # script under rocprofv3 --pmc (2*FETCH_SIZE + WRITE_SIZE as the MI355X guide prescribes for
+        # gfx950); if the profiler is unavailable, the committed measurement of the same command
+        # (profiles/k3_hbm_traffic.json) when the launch geometry matches, else null
         traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                                   'k3_hbm_traffic.json')) as fh:
-                prof = json.load(fh)
-            if prof['geometry'] == [stats[k] for k in ('grid_x', 'grid_y', 'grid_z', 'block')]:
-                traffic, traffic_src = prof['traffic_bytes'], prof['source']
-        except (OSError, KeyError, ValueError):
-            pass
+        if world == 1 and not args.no_pmc:
+            traffic, traffic_src = measure_hbm_traffic(args.omega_per_gpu)
+            if traffic is None:
+                traffic_src = f'PMC run failed ({traffic_src}); '
+        if traffic is None:
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                                       'k3_hbm_traffic.json')) as fh:
+                    prof = json.load(fh)
+                if prof['geometry'] == [stats[k] for k in ('grid_x', 'grid_y', 'grid_z', 'block')]:
+                    traffic = prof['traffic_bytes']
+                    traffic_src = (traffic_src or '') + 'committed: ' + prof['source']
+            except (OSError, KeyError, ValueError):
+                pass
         out = {
             'metric': 'filter-function elements/sec (n_seg*n_omega*n_nops*d^2) at d=4',
             'value': value, 'unit': 'elements/s', 'n_gpus': world, 'steps': args.steps,
