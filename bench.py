@@ -107,7 +107,7 @@ def measure_hbm_traffic(omega_per_gpu):
                    sys.executable, script, '--steps', '8', '--warmup', '2', '--no-cpu-baseline',
                    '--no-pmc', '--omega-per-gpu', str(omega_per_gpu)]
             res = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL,
-                                 stderr=subprocess.DEVNULL, timeout=240)
+                                 stderr=subprocess.DEVNULL, timeout=90)
             if res.returncode != 0:
                 return None, f'rocprofv3 --pmc {counter} exited with {res.returncode}'
             values = []
