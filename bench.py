@@ -95,6 +95,9 @@ def measure_hbm_traffic(omega_per_gpu):
     prof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
     if not os.path.exists(prof):
         return None, 'rocprofv3 not found'
+    if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or \
+            'rocprof' in os.environ.get('LD_PRELOAD', ''):
+        return None, 'already running under a profiler'
     script = os.path.abspath(__file__)
     means = {}
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
