@@ -493,8 +493,16 @@ def _merge_constant_segments(pulse):
 
 def _all_bases_equal(pulses):
     first = pulses[0].basis
-    return all(p.basis.shape == first.shape and np.array_equal(np.asarray(p.basis), np.asarray(first))
-               for p in pulses[1:])
+    # the same Basis object (or one already compared) needs no element-wise comparison: a long
+    # sequence is typically built from a handful of distinct pulse objects
+    seen = {id(first)}
+    for p in pulses[1:]:
+        if id(p.basis) in seen:
+            continue
+        if p.basis.shape != first.shape or not np.array_equal(np.asarray(p.basis), np.asarray(first)):
+            return False
+        seen.add(id(p.basis))
+    return True
 
 
 def _concatenate_hamiltonian(opers, identifiers, coeffs, kind):
@@ -511,9 +519,15 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind):
     n_segments = [np.shape(c)[1] for c in coeffs]
     offsets = np.concatenate(([0], np.cumsum(n_segments)))
     # one record per (pulse, operator)
-    records = [(p, i, np.ascontiguousarray(op).tobytes(), str(ident))
+    keys = {}                  # operator tables of repeated pulse objects are hashed once
+    def table_keys(ops):
+        cached = keys.get(id(ops))
+        if cached is None:
+            cached = keys[id(ops)] = [np.ascontiguousarray(op).tobytes() for op in ops]
+        return cached
+    records = [(p, i, key, str(ident))
                for p, (ops, ids) in enumerate(zip(opers, identifiers))
-               for i, (op, ident) in enumerate(zip(ops, ids))]
+               for i, (key, ident) in enumerate(zip(table_keys(ops), ids))]
     idents_of_matrix, matrices_of_ident = {}, {}
     for _, _, key, ident in records:
         idents_of_matrix.setdefault(key, set()).add(ident)
@@ -617,7 +631,8 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
         cached_R = [pls.is_cached('control_matrix') for pls in pulses]
         cached_w = [pls.is_cached('omega') for pls in pulses]
         candidates = [pls.omega for pls, c in zip(pulses, cached_R if any(cached_R) else cached_w) if c]
-        equal_omega = all(np.array_equal(candidates[0], w) for w in candidates[1:])
+        distinct = {id(w): w for w in candidates}           # repeated pulse objects share arrays
+        equal_omega = all(np.array_equal(candidates[0], w) for w in distinct.values())
         if not equal_omega or not candidates:
             if calc_filter_function:
                 raise ValueError('Calculation of filter function forced but not all pulses '
