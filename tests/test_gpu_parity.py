@@ -1033,3 +1033,54 @@ def test_sharded_error_transfer_matrix_single_rank():
     assert rel_err(K.cpu().numpy(), g[f'{name}_cumulant_function_S2']) < TOL
     U_ref = g[f'{name}_error_transfer_matrix_S2']
     assert np.abs(U - U_ref).max() < TOL*np.abs(U_ref - np.eye(len(U_ref))).max() + 1e-15
+
+
+def test_cache_cleanup_semantics():
+    """cleanup() modes, nbytes and the caches filled by concatenate, as the reference's
+    tests/test_core.py:386-455 walks through them."""
+    X, Y = util.paulis[1], util.paulis[2]
+    A = ff.PulseSequence([[X, [1]]], [[Y, [2]]], [3])
+    A.diagonalize()
+    for _ in range(3):
+        A.cleanup('conservative')
+        assert A.eigvals is not None and A.eigvecs is not None and A.propagators is not None
+    A.cleanup('all')
+    a = A.nbytes
+    A.diagonalize()
+    b = A.nbytes
+    A.cache_control_matrix([1])
+    c = A.nbytes
+    A.cleanup('frequency dependent')
+    A.cache_control_matrix([1], cache_intermediates=True)
+    d = A.nbytes
+    assert a != b and b != c and c != d
+    A.cleanup('all')
+    omega = util.get_sample_frequencies(A)
+    C = ff.concatenate((A, A), calc_pulse_correlation_FF=True, which='generalized', omega=omega)
+    C.diagonalize()
+    attrs = ['eigvals', 'eigvecs', 'propagators']
+    assert all(C.is_cached(x) for x in attrs)
+    C.cleanup()
+    assert not any(C.is_cached(x) for x in attrs)
+    C.diagonalize()
+    C.cache_control_matrix(A.omega)
+    attrs += ['control_matrix', 'total_phases', 'total_propagator', 'total_propagator_liouville']
+    assert all(C.is_cached(x) for x in attrs)
+    C.cleanup('greedy')
+    assert not any(C.is_cached(x) for x in attrs)
+    C.cache_filter_function(A.omega, which='generalized')
+    assert all(C.is_cached(x) for x in attrs + ['omega', 'filter_function_gen',
+                                                 'filter_function_pc_gen'])
+    C = ff.concatenate((A, A), calc_pulse_correlation_FF=True, which='fidelity', omega=A.omega)
+    C.diagonalize()
+    C.cache_filter_function(A.omega, which='fidelity')
+    attrs += ['omega', 'filter_function', 'filter_function_pc']
+    assert all(C.is_cached(x) for x in attrs)
+    C.cleanup('all')
+    assert not any(C.is_cached(x) for x in attrs + ['filter_function_gen', 'filter_function_pc_gen'])
+    C.cache_filter_function(A.omega, which='fidelity')
+    C.cleanup('frequency dependent')
+    freq = {'omega', 'control_matrix', 'filter_function', 'filter_function_gen',
+            'filter_function_pc', 'filter_function_pc_gen', 'total_phases'}
+    assert not any(C.is_cached(x) for x in freq)
+    assert all(C.is_cached(x) for x in set(attrs) - freq)

@@ -272,3 +272,65 @@ def test_pulse_sequence_equality():
         a @= b
     with pytest.raises(TypeError):
         hash(a)
+
+
+def test_from_arrays_contract():
+    """PulseSequence.from_arrays: success and the ValueErrors the reference's
+    tests/test_core.py:1124-1222 expect."""
+    rng = np.random.default_rng(5)
+    c_opers = rng.standard_normal((3, 4, 4)) + 1j*rng.standard_normal((3, 4, 4))
+    c_ids = np.array(['c1', 'c2', 'c3'])
+    c_coeffs = rng.random((3, 100))
+    n_opers = rng.standard_normal((2, 4, 4)) + 1j*rng.standard_normal((2, 4, 4))
+    n_ids = np.array(['n1', 'n2'])
+    n_coeffs = rng.random((2, 100))
+    dt = np.linspace(0, 10, 100)
+    p = ff.PulseSequence.from_arrays(c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt)
+    assert np.array_equal(p.c_opers, c_opers) and np.array_equal(p.c_oper_identifiers, c_ids)
+    assert np.array_equal(p.c_coeffs, c_coeffs) and np.array_equal(p.n_opers, n_opers)
+    assert np.array_equal(p.n_oper_identifiers, n_ids) and np.array_equal(p.n_coeffs, n_coeffs)
+    assert np.array_equal(p.dt, dt)
+    bad = [
+        (c_opers[:, :, :3], c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt),       # not square
+        (c_opers, c_ids, c_coeffs, n_opers[:, :, :3], n_ids, n_coeffs, dt),
+        (c_opers, c_ids[:-1], c_coeffs, n_opers, n_ids, n_coeffs, dt),            # lengths
+        (c_opers, c_ids, c_coeffs, n_opers, n_ids[:-1], n_coeffs, dt),
+        (c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt[:-1]),            # time steps
+    ]
+    for args in bad:
+        with pytest.raises(ValueError):
+            ff.PulseSequence.from_arrays(*args)
+    with pytest.raises(ValueError):
+        ff.PulseSequence.from_arrays(c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt,
+                                     basis=ff.Basis.ggm(5))
+
+
+def test_is_cached_aliases():
+    """is_cached accepts the human-readable aliases in any case and with underscores (reference
+    tests/test_core.py:349-385, pulse_sequence.py:508-538)."""
+    X, Z = util.paulis[1], util.paulis[3]
+    A = ff.PulseSequence([[X, [1]]], [[Z, [2]]], [3])
+    aliases = {'eigenvalues': 'eigvals', 'eigenvectors': 'eigvecs', 'propagators': 'propagators',
+               'total propagator': 'total_propagator',
+               'total propagator liouville': 'total_propagator_liouville'}
+    frequency_aliases = {
+        'frequencies': 'omega', 'total phases': 'total_phases', 'filter function': 'filter_function',
+        'fidelity filter function': 'filter_function',
+        'generalized filter function': 'filter_function_gen',
+        'pulse correlation filter function': 'filter_function_pc',
+        'fidelity pulse correlation filter function': 'filter_function_pc',
+        'generalized pulse correlation filter function': 'filter_function_pc_gen',
+        'control matrix': 'control_matrix', 'pulse correlation control matrix': 'control_matrix_pc'}
+    for present in (True, False):
+        for alias, attr in {**aliases, **frequency_aliases}.items():
+            store = A._data if alias in aliases else A._frequency_data
+            if present:
+                store[attr] = 'foo'
+            else:
+                store.pop(attr, None)
+            for name in (alias, alias.upper(), alias.replace(' ', '_')):
+                assert A.is_cached(name) is present
+    pulse = ff.PulseSequence([[X, [1, 2, 3]]], [[Z, [1, 1, 1]]], [0.5, 1.0, 1.5])
+    assert 't' not in pulse.data and 'tau' not in pulse.data
+    assert np.array_equal(pulse.t, [0, *pulse.dt.cumsum()])
+    assert pulse.tau == pulse.t[-1] and pulse.duration == pulse.tau
