@@ -1084,3 +1084,43 @@ def test_cache_cleanup_semantics():
             'filter_function_pc', 'filter_function_pc_gen', 'total_phases'}
     assert not any(C.is_cached(x) for x in freq)
     assert all(C.is_cached(x) for x in set(attrs) - freq)
+
+
+@pytest.mark.parametrize('d,n_dt', [(2, 40), (5, 25), (7, 12)])
+def test_filter_function_scratch_vs_atomic_and_getters(d, n_dt):
+    """The reference's tests/test_core.py:685-782: the control matrix from scratch equals the
+    one assembled from single-segment pulses by the concatenation rule (atol 1e-13), autocorrelation
+    filter functions are real, F_fidelity is the trace of F_generalized, also after the cached
+    frequencies change."""
+    rng = np.random.default_rng(d*n_dt)
+    def herm(n):
+        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+        M = M + M.conj().transpose(0, 2, 1)
+        return M - np.trace(M, axis1=1, axis2=2)[:, None, None]*np.eye(d)/d
+    c_opers, n_opers = herm(4), herm(6)
+    c_coeffs, n_coeffs = rng.standard_normal((4, n_dt)), rng.random((6, n_dt))
+    dt = 1 - rng.random(n_dt)
+    total = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt)
+    omega = util.get_sample_frequencies(total, n_samples=100)
+    R = total.get_control_matrix(omega, show_progressbar=True)
+    assert all(total.is_cached(x) for x in ('total_phases', 'total_propagator',
+                                            'total_propagator_liouville'))
+    pulses = [ff.PulseSequence(list(zip(total.c_opers, total.c_coeffs[:, i:i + 1])),
+                               list(zip(total.n_opers, total.n_coeffs[:, i:i + 1])), dt[i:i + 1])
+              for i in range(n_dt)]
+    phases = np.exp(1j*total.t[1:, None]*omega)
+    L = ff.liouville_representation(total.propagators[1:], total.basis)
+    R_g = np.array([p.get_control_matrix(omega) for p in pulses])
+    R_atomic = numeric.calculate_control_matrix_from_atomic(phases, R_g, L)
+    D, V, _ = numeric.diagonalize(np.einsum('il,ijk->ljk', total.c_coeffs, total.c_opers), dt)
+    R_scratch = numeric.calculate_control_matrix_from_scratch(
+        eigvals=D, eigvecs=V, propagators=total.propagators, omega=omega, basis=total.basis,
+        n_opers=total.n_opers, n_coeffs=total.n_coeffs, dt=dt)
+    assert np.allclose(R, R_scratch, rtol=1e-7, atol=1e-13)
+    assert np.allclose(R_scratch, R_atomic, rtol=1e-7, atol=1e-13)
+    F = total.get_filter_function(omega)
+    assert np.isreal(F[np.eye(6, dtype=bool)]).all()
+    for shift in (0, 0, 1):
+        Fg = total.get_filter_function(omega + shift, which='generalized')
+        Ff = total.get_filter_function(omega + shift, which='fidelity')
+        assert np.allclose(Ff, Fg.trace(axis1=2, axis2=3), rtol=1e-7, atol=1e-13)
