@@ -309,7 +309,7 @@ def main():
                                    'matrix + filter function + infidelity, HBM-resident',
                        'sharding': 'omega blocks, RCCL all-gather of F' if use_dist else 'none'},
             'roofline': {
-                'kernel': 'ffk::ctrl_accumulate_kernel<4,4,4,2,3,4>', 'bound': 'mfma',
+                'kernel': 'ffk::ctrl_accumulate_pc_kernel<4,3>', 'bound': 'mfma',
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
                 'avg_launch_ms': acc_ms, 'flops_per_launch': stats['accumulate_flops'],

@@ -689,7 +689,46 @@ void set_mfma_policy(int policy) { g_mfma_policy = policy; }
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks) {
     AccumGeometry geo;
     geo.gsplit = 1;
+    geo.pc = false;
     geo.mfma = mfma_accumulate_supported(d) && g_mfma_policy != 1 && (d >= 12 || g_mfma_policy == 2);
+    // d = 4: the producer/consumer kernel (ctrl_pc.hip) is the default -- 3.4 % faster than the
+    // symmetric kernel below at config 2 (101 vs 104.5 us on the same box) and free of register
+    // spills; FFK_TUNE_PC=0 or the tuning variants 1/2 select the symmetric kernel
+    static const bool use_pc = [] {
+        const char* e = std::getenv("FFK_TUNE_PC");
+        return e == nullptr || e[0] != '0';
+    }();
+    if (use_pc && g_use_gsplit && !g_use_wave_kernel && pc_accumulate_supported(d, A) && !geo.mfma) {
+        // producer/consumer kernel: 3 sub-chunks x (1 producer + nc consumers) per block
+        const int nc = pc_accumulate_ops_per_block(A);
+        geo.pc = true;
+        geo.wave_kernel = false;
+        geo.nwaves = (nc + 1)*pc_accumulate_subchunks();
+        geo.task_groups = (A + nc - 1)/nc;
+        geo.na_blk = nc;
+        geo.nbuf = 2;
+        geo.lds_bytes = pc_accumulate_lds_bytes(d, nc);
+        const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups;
+        int chunks = forced_chunks;
+        if (chunks <= 0) {
+            const long capacity = device_cu_count();
+            const int max_chunks = std::max(1, std::min((G + 11)/12, 256));
+            double best = 0.0;
+            chunks = 1;
+            for (int c = 1; c <= max_chunks; ++c) {
+                const long rounds = (tiles*c + capacity - 1)/capacity;
+                const double cost = static_cast<double>(rounds)*((G + 3*c - 1)/(3*c) + 2);
+                if (c == 1 || cost < best*0.999) {
+                    best = cost;
+                    chunks = c;
+                }
+            }
+        }
+        chunks = std::max(1, std::min(chunks, G));
+        geo.chunk_len = (G + chunks - 1)/chunks;
+        geo.chunks = (G + geo.chunk_len - 1)/geo.chunk_len;
+        return geo;
+    }
     if (geo.mfma) {
         // one wavefront per noise operator, 16 frequencies per block, one block per CU
         geo.wave_kernel = false;
@@ -819,6 +858,9 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
                              hipStream_t stream) {
+    if (geo.pc)
+        return launch_accumulate_pc(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
+                                    geo.chunk_len, Ypart, stream);
     if (geo.mfma)
         return launch_accumulate_mfma(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len,
                                       geo.nwaves, Ypart, stream);

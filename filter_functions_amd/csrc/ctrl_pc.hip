@@ -1,0 +1,254 @@
+// ctrl_pc.hip -- K3p: the control-matrix accumulation for small d with SPECIALISED wavefronts.
+// Same mathematics, inputs, output layout and per-lane arithmetic as ctrl.hip (one frequency per
+// lane, 64 per wave; Y_a(w) = sum_g T_g^dag [Bbar_a o E_g(w)] T_g), different division of labour:
+// every sub-chunk of a block consists of ONE producer wavefront, which generates the whole integral
+// tile e^{i w t_g} I^(g)(w) of the next segment (and moves the segment's operands and table rows
+// from global memory into LDS), and NC consumer wavefronts, one per noise operator, which do
+// nothing but the two d x d products on the tile of the current segment.  In ctrl.hip every wave
+// alternates between the two phases and all waves of a block are in the same phase at the same
+// time; the latency-bound generation and the FMA-bound contraction never overlap there
+// (profiles/r01_c_*: generation alone 43 us, contraction alone 80 us, together 111 us).  Here they
+// run side by side on every SIMD.  Producers sit on different SIMDs (sub-chunk s -> wave s of its
+// group), so each SIMD hosts one producer and two consumers, or three consumers: with 13 entries
+// the producer's ~555 instructions per segment match a consumer's 576.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "ffk_internal.h"
+
+namespace ffk {
+namespace {
+
+constexpr int kPcSub = 3;   // sub-chunks per block: 3 x (1 + 3) = 12 waves = 3 per SIMD
+
+template <int D>
+struct PcEntries {          // every entry once, the (coinciding) diagonal entries as slot 0
+    static constexpr int build(int* out) {
+        int n = 0;
+        for (int e = 0; e < D*D; ++e) {
+            if (e != 0 && e / D == e % D) continue;
+            if (out) out[n] = e;
+            ++n;
+        }
+        return n;
+    }
+    static constexpr int count = build(nullptr);
+    struct Slots {
+        int v[D*D];
+    };
+    static constexpr Slots make() {
+        Slots s{};
+        build(s.v);
+        return s;
+    }
+    static constexpr Slots slots = make();
+};
+
+template <int D, int NC>
+__global__ __launch_bounds__((NC + 1)*kPcSub*64, 3) void ctrl_accumulate_pc_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ segtab,
+    const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
+    constexpr int GS = kPcSub, NWS = NC + 1;
+    constexpr int S = seg_stride(D), DD = D*D;
+    constexpr int TILE = DD*64;                       // cplx per integral tile
+    constexpr int BUF = TILE + (1 + NC)*DD;           // cplx per buffer: tile | T_g, Bbar_0..
+    constexpr int SUB = 2*BUF + S;                    // cplx per sub-chunk: 2 buffers | 2 table rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = wave_all / NWS, wl = wave_all % NWS;
+    const int pw = sub % NWS;                         // producer's position inside the group
+    const bool producer = wl == pw;
+    const int cidx = wl < pw ? wl : wl - 1;           // consumer index 0..NC-1
+    const int alpha0 = blockIdx.y*NC;
+    const int alpha = alpha0 + cidx;
+    const bool active = !producer && alpha < A;
+    const int n_alpha = min(NC, A - alpha0);
+    cplx* lds = reinterpret_cast<cplx*>(lds_raw) + static_cast<size_t>(sub)*SUB;
+    double* rows = reinterpret_cast<double*>(lds + 2*BUF);
+    const int iw = blockIdx.x*64 + lane;
+    const double om = omega[iw < W ? iw : W - 1];
+    const int sub_len = (chunk_len + GS - 1)/GS;
+    const int g0 = blockIdx.z*chunk_len + sub*sub_len;
+    const int g1 = min(min(G, static_cast<int>(blockIdx.z + 1)*chunk_len), g0 + sub_len);
+
+    if (producer) {
+        // ---- producer: operands + table rows -> LDS, integral tile of the next segment ----------
+        const int n_ops = (1 + n_alpha)*DD;           // <= 64: one element per lane
+        auto load_ops = [&](int g) -> cplx {
+            const cplx* src = ops + static_cast<size_t>(g)*(1 + A)*DD;
+            return lane < n_ops ? src[lane < DD ? lane : lane + alpha0*DD] : cplx{0.0, 0.0};
+        };
+        auto load_row = [&](int g) -> cplx {
+            const cplx* src = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
+            return lane < S/2 ? src[lane] : cplx{0.0, 0.0};
+        };
+        auto generate = [&](int buf, int slot) {
+            const double* st = rows + slot*S;
+            cplx* tile = lds + static_cast<size_t>(buf)*BUF + lane;
+            const double dtg = st[0];
+            cplx ph;
+            sincos_pi<true>(om*st[1], &ph.im, &ph.re);
+            double sa, ca;
+            sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
+#pragma unroll
+            for (int k = 0; k < PcEntries<D>::count; ++k) {
+                constexpr auto& sl = PcEntries<D>::slots;
+                const int e = sl.v[k];
+                const double* r = st + seg_rec(e);
+                tile[e*64] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+            }
+        };
+        static_assert((1 + NC)*DD <= 64 && S/2 <= 64, "one staging element per lane");
+        // prologue: rows g0, g0+1 and operands g0 straight in, tile g0
+        if (g0 < g1) {
+            const cplx r0 = load_row(g0), o0 = load_ops(g0);
+            const cplx r1 = g0 + 1 < g1 ? load_row(g0 + 1) : cplx{0.0, 0.0};
+            if (lane < S/2) {
+                reinterpret_cast<cplx*>(rows)[lane] = r0;
+                reinterpret_cast<cplx*>(rows + S)[lane] = r1;
+            }
+            if (lane < n_ops) lds[TILE + lane] = o0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            generate(0, 0);
+        }
+        __syncthreads();
+        for (int it = 0; it < sub_len; ++it) {
+            const int g = g0 + it;
+            const int nb = (it + 1) & 1;
+            if (g + 1 < g1) {
+                // operands of g+1 and the table row of g+2: loads now, LDS stores after the tile
+                const cplx o = load_ops(g + 1);
+                const cplx r = g + 2 < g1 ? load_row(g + 2) : cplx{0.0, 0.0};
+                generate(nb, nb);                     // row g+1 lives in slot (it+1) & 1
+                if (lane < n_ops) lds[static_cast<size_t>(nb)*BUF + TILE + lane] = o;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();      // row g+1 fully read before it is replaced
+                if (lane < S/2) reinterpret_cast<cplx*>(rows + (it & 1)*S)[lane] = r;
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- consumers: Y += T^dag [Bbar o E] T on the tile of the current segment -------------
+        cplx Y[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) Y[i][j] = {0.0, 0.0};
+        __syncthreads();
+        for (int it = 0; it < sub_len; ++it) {
+            const int g = g0 + it;
+            if (active && g < g1) {
+                const cplx* tile = lds + static_cast<size_t>(it & 1)*BUF;
+                const cplx* src = tile + lane;
+                const cplx* opT = tile + TILE;                       // T[n][j]
+                const cplx* opB = opT + (1 + cidx)*DD;               // Bbar_alpha[m][n]
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    cplx X[D];
+#pragma unroll
+                    for (int n = 0; n < D; ++n) {
+                        const int slot = (m == n) ? 0 : m*D + n;
+                        X[n] = cmul(opB[m*D + n], src[slot*64]);
+                    }
+                    cplx Z[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Z[j] = {0.0, 0.0};
+#pragma unroll
+                    for (int n = 0; n < D; ++n)
+#pragma unroll
+                        for (int j = 0; j < D; ++j) cmac(Z[j], opT[n*D + j], X[n]);
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        const cplx t = opT[m*D + i];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) cmac_conj(Y[i][j], t, Z[j]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // sub-chunks > 0 hand their accumulators to sub-chunk 0 through LDS (tiles are dead now)
+        cplx* red = reinterpret_cast<cplx*>(lds_raw);
+        constexpr int YSZ = DD*64;
+#pragma unroll
+        for (int s = 1; s < GS; ++s) {
+            if (sub == s) {
+                cplx* dst = red + static_cast<size_t>(cidx)*YSZ + lane;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) dst[(i*D + j)*64] = Y[i][j];
+            }
+            __syncthreads();
+            if (sub == 0) {
+                const cplx* srcy = red + static_cast<size_t>(cidx)*YSZ + lane;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const cplx v = srcy[(i*D + j)*64];
+                        Y[i][j].re += v.re;
+                        Y[i][j].im += v.im;
+                    }
+            }
+            __syncthreads();
+        }
+        if (sub == 0 && active && iw < W) {
+            cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W + iw;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) out[static_cast<size_t>(i*D + j)*W] = Y[i][j];
+        }
+        return;
+    }
+    // producers keep the consumers' epilogue barriers company
+#pragma unroll
+    for (int s = 1; s < GS; ++s) {
+        __syncthreads();
+        __syncthreads();
+    }
+}
+
+template <int D, int NC>
+hipError_t launch_pc(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
+                     int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
+    constexpr int S = seg_stride(D), DD = D*D;
+    const int lds = static_cast<int>(kPcSub*(2*(DD*64 + (1 + NC)*DD) + S)*sizeof(cplx));
+    auto kern = ctrl_accumulate_pc_kernel<D, NC>;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) return err;
+    const dim3 grid((W + 63)/64, (A + NC - 1)/NC, chunks);
+    hipLaunchKernelGGL(kern, grid, dim3((NC + 1)*kPcSub*64), lds, stream, omega, W, segtab, ops, G, A,
+                       chunk_len, Ypart);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool pc_accumulate_supported(int d, int A) { return d == 4 && A >= 1; }
+int pc_accumulate_ops_per_block(int A) { return A >= 3 ? 3 : A; }
+int pc_accumulate_subchunks() { return kPcSub; }
+int pc_accumulate_lds_bytes(int d, int nc) {
+    const int S = seg_stride(d), dd = d*d;
+    return static_cast<int>(kPcSub*(2*(dd*64 + (1 + nc)*dd) + S)*sizeof(cplx));
+}
+
+hipError_t launch_accumulate_pc(const double* omega, int W, const double* segtab, const cplx* ops,
+                                int G, int d, int A, int nc, int chunks, int chunk_len, cplx* Ypart,
+                                hipStream_t stream) {
+    if (d != 4) return hipErrorInvalidValue;
+    switch (nc) {
+        case 1: return launch_pc<4, 1>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
+        case 2: return launch_pc<4, 2>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
+        case 3: return launch_pc<4, 3>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ffk

@@ -106,6 +106,7 @@ struct AccumGeometry {
     bool wave_kernel; // small-d one-wave-per-block variant
     int gsplit;       // sub-chunks per block (in-block segment split), 1 = none
     bool mfma;        // large-d matrix-core kernel (ctrl_mfma.hip): 16 frequencies per block
+    bool pc;          // producer/consumer kernel (ctrl_pc.hip), d = 4
 };
 void set_use_wave_kernel(bool on);
 void set_use_gsplit(bool on);
@@ -124,6 +125,15 @@ int mfma_accumulate_lds_bytes(int d, int nw);
 hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segtab, const cplx* ops,
                                   int G, int d, int A, int chunks, int chunk_len, int nw,
                                   cplx* Ypart, hipStream_t stream);
+
+// ---- ctrl_pc.hip -----------------------------------------------------------------------------
+bool pc_accumulate_supported(int d, int A);
+int pc_accumulate_ops_per_block(int A);
+int pc_accumulate_subchunks();
+int pc_accumulate_lds_bytes(int d, int nc);
+hipError_t launch_accumulate_pc(const double* omega, int W, const double* segtab, const cplx* ops,
+                                int G, int d, int A, int nc, int chunks, int chunk_len, cplx* Ypart,
+                                hipStream_t stream);
 
 // ---- post.hip --------------------------------------------------------------------------------
 // Bt (A,d,d,W) = sum over chunks of Ypart
