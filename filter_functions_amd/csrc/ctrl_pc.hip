@@ -123,7 +123,9 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, 3) void ctrl_accumulate_pc_kern
                 // operands of g+1 and the table row of g+2: loads now, LDS stores after the tile
                 const cplx o = load_ops(g + 1);
                 const cplx r = g + 2 < g1 ? load_row(g + 2) : cplx{0.0, 0.0};
+#if !(defined(FFK_PC_ABLATE) && FFK_PC_ABLATE == 1)   /* diagnostic: no generation */
                 generate(nb, nb);                     // row g+1 lives in slot (it+1) & 1
+#endif
                 if (lane < n_ops) lds[static_cast<size_t>(nb)*BUF + TILE + lane] = o;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();      // row g+1 fully read before it is replaced
@@ -141,7 +143,11 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, 3) void ctrl_accumulate_pc_kern
         __syncthreads();
         for (int it = 0; it < sub_len; ++it) {
             const int g = g0 + it;
+#if defined(FFK_PC_ABLATE) && FFK_PC_ABLATE == 2      /* diagnostic: no contraction */
+            if (false) {
+#else
             if (active && g < g1) {
+#endif
                 const cplx* tile = lds + static_cast<size_t>(it & 1)*BUF;
                 const cplx* src = tile + lane;
                 const cplx* opT = tile + TILE;                       // T[n][j]
