@@ -712,12 +712,13 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         int chunks = forced_chunks;
         if (chunks <= 0) {
             const long capacity = device_cu_count();
-            const int max_chunks = std::max(1, std::min((G + 11)/12, 256));
+            const int ns = pc_accumulate_subchunks();
+            const int max_chunks = std::max(1, std::min((G + 4*ns - 1)/(4*ns), 256));
             double best = 0.0;
             chunks = 1;
             for (int c = 1; c <= max_chunks; ++c) {
                 const long rounds = (tiles*c + capacity - 1)/capacity;
-                const double cost = static_cast<double>(rounds)*((G + 3*c - 1)/(3*c) + 2);
+                const double cost = static_cast<double>(rounds)*((G + ns*c - 1)/(ns*c) + 2);
                 if (c == 1 || cost < best*0.999) {
                     best = cost;
                     chunks = c;

@@ -9,8 +9,16 @@
 // time; the latency-bound generation and the FMA-bound contraction never overlap there
 // (profiles/r01_c_*: generation alone 43 us, contraction alone 80 us, together 111 us).  Here they
 // run side by side on every SIMD.  Producers sit on different SIMDs (sub-chunk s -> wave s of its
-// group), so each SIMD hosts one producer and two consumers, or three consumers: with 13 entries
-// the producer's ~555 instructions per segment match a consumer's 576.
+// group): with four sub-chunks of one producer and three consumers every SIMD hosts exactly one
+// producer and three consumers, and with 13 entries the producer's ~555 instructions per segment
+// match a consumer's 576.
+// The consumers take T_g through SCALAR loads (wave-uniform addresses, issued one segment ahead at
+// the end of the previous one): 32 doubles in SGPRs feed v_fma_f64 directly instead of occupying
+// 64 VGPRs, which brings the kernel to 104 VGPRs, i.e. four wavefronts per SIMD.  (The first
+// version of ctrl.hip fed ALL operands from scalar loads issued right before their use and spent
+// 60 % of its time waiting for them; here the loads have a whole barrier interval to land.)
+// Measured at config 2 on one box: symmetric kernel 108.4 us, 3 sub-chunks with T_g from LDS
+// 104.5 us (166 VGPRs), 3 sub-chunks scalar T_g 106.9 us, 4 sub-chunks scalar T_g 100.8 us.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -20,7 +28,11 @@
 namespace ffk {
 namespace {
 
-constexpr int kPcSub = 3;   // sub-chunks per block: 3 x (1 + 3) = 12 waves = 3 per SIMD
+#if defined(FFK_PC_SUB)       /* tuning builds */
+constexpr int kPcSub = FFK_PC_SUB;
+#else
+constexpr int kPcSub = 4;   // sub-chunks per block: 4 x (1 + 3) = 16 waves = 4 per SIMD
+#endif
 
 template <int D>
 struct PcEntries {          // every entry once, the (coinciding) diagonal entries as slot 0
@@ -46,7 +58,7 @@ struct PcEntries {          // every entry once, the (coinciding) diagonal entri
 };
 
 template <int D, int NC>
-__global__ __launch_bounds__((NC + 1)*kPcSub*64, 3) void ctrl_accumulate_pc_kernel(
+__global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
     constexpr int GS = kPcSub, NWS = NC + 1;
@@ -140,6 +152,19 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, 3) void ctrl_accumulate_pc_kern
         for (int i = 0; i < D; ++i)
 #pragma unroll
             for (int j = 0; j < D; ++j) Y[i][j] = {0.0, 0.0};
+#if !defined(FFK_PC_T_FROM_LDS)
+        // T_g through scalar loads (wave-uniform addresses -> SGPRs feeding v_fma_f64 directly):
+        // 64 VGPRs less per consumer; the loads for segment g+1 are issued at the end of segment g
+        cplx Ts[D][D];
+        auto load_T = [&](int g) {
+            const cplx* tg = ops + static_cast<size_t>(g)*(1 + A)*DD;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) Ts[i][j] = tg[i*D + j];
+        };
+        if (g0 < g1) load_T(g0);
+#endif
         __syncthreads();
         for (int it = 0; it < sub_len; ++it) {
             const int g = g0 + it;
@@ -166,15 +191,28 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, 3) void ctrl_accumulate_pc_kern
 #pragma unroll
                     for (int n = 0; n < D; ++n)
 #pragma unroll
-                        for (int j = 0; j < D; ++j) cmac(Z[j], opT[n*D + j], X[n]);
+                        for (int j = 0; j < D; ++j) {
+#if !defined(FFK_PC_T_FROM_LDS)
+                            cmac(Z[j], Ts[n][j], X[n]);
+#else
+                            cmac(Z[j], opT[n*D + j], X[n]);
+#endif
+                        }
 #pragma unroll
                     for (int i = 0; i < D; ++i) {
+#if !defined(FFK_PC_T_FROM_LDS)
+                        const cplx t = Ts[m][i];
+#else
                         const cplx t = opT[m*D + i];
+#endif
 #pragma unroll
                         for (int j = 0; j < D; ++j) cmac_conj(Y[i][j], t, Z[j]);
                     }
                 }
             }
+#if !defined(FFK_PC_T_FROM_LDS)
+            if (g + 1 < g1) load_T(g + 1);
+#endif
             __syncthreads();
         }
         // sub-chunks > 0 hand their accumulators to sub-chunk 0 through LDS (tiles are dead now)
