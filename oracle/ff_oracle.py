@@ -501,3 +501,119 @@ def error_transfer_matrix(K):
     from scipy.linalg import expm
     K = np.asarray(K)
     return expm(K.sum(axis=tuple(range(K.ndim - 2))))
+
+
+# ---------------------------------------------------------------------------------------------
+# Second order: nested Magnus integral -> second-order filter function -> frequency shifts
+# (SURVEY 8f.3 consumer of the step caches)
+# ---------------------------------------------------------------------------------------------
+def _frac(x, dt):
+    """(e^{i x dt} - 1)/x, and its limit i dt where x == 0 exactly
+    (filter_functions/numeric.py:229-235 via util.cexpm1)."""
+    x = np.asarray(x, dtype=float)
+    out = np.full(x.shape, 1j*dt, dtype=complex)
+    nz = x != 0
+    out[nz] = cexpm1(x[nz]*dt)/x[nz]
+    return out
+
+
+def second_order_integral(omega, eigvals_g, dt_g):
+    """I[o,i,j,m,n], the nested time integral of the second-order Magnus term over one segment,
+    filter_functions/numeric.py:170-256:
+
+        b = w + W_mn != 0:             (f(W_ij - w) - f(W_ij + W_mn)) / b,  f(x) = (e^{i x dt}-1)/x
+        b == 0, a = W_ij - w != 0:     (f(a) - i dt e^{i a dt}) / a
+        b == 0, a == 0:                dt^2/2
+
+    with W_mn = D_m - D_n.  The reference evaluates the b == 0 rows only for w == 0 exactly
+    (:241-255; for w != 0 its masked ufuncs leave the buffer untouched there); this restatement
+    applies the documented formula (:186-194) to every b == 0 entry, which coincides at w == 0."""
+    E = np.asarray(omega, dtype=float)
+    dE = np.subtract.outer(eigvals_g, eigvals_g)
+    a = np.add.outer(-E, dE)                                    # (W,d,d)  W_ij - w
+    b = np.add.outer(E, dE)                                     # (W,d,d)  w + W_mn
+    c = np.add.outer(dE, dE)                                    # (d,d,d,d)
+    f1 = _frac(a, dt_g)
+    f2 = _frac(c, dt_g)
+    W, d = len(E), len(eigvals_g)
+    bb = np.broadcast_to(b[:, None, None], (W, d, d, d, d))
+    aa = np.broadcast_to(a[:, :, :, None, None], (W, d, d, d, d))
+    f1b = np.broadcast_to(f1[:, :, :, None, None], (W, d, d, d, d))
+    out = np.empty((W, d, d, d, d), dtype=complex)
+    gen = bb != 0
+    out[gen] = ((f1b - f2[None])[gen])/bb[gen]
+    lim = ~gen & (aa != 0)
+    out[lim] = (f1b[lim] - 1j*dt_g*cexp(aa[lim]*dt_g))/aa[lim]
+    out[~gen & (aa == 0)] = dt_g**2/2
+    return out
+
+
+def second_order_filter_function(eigvals, eigvecs, propagators, omega, basis, n_opers, n_coeffs,
+                                 dt):
+    """F2[a,b,k,l,o] = sum_g [ conj(G^(g)_{ak}) sum_{g'<g} G^(g')_{bl}
+                               + sum_ijmn N^(g)_{ak,ij} I^(g)_{o,ijmn} N^(g)_{bl,mn} ],
+    N^(g)_{ak,ij} = Bbar^(g)_{a,ij} Cbar^(g)_{k,ji}, G^(g) the control-matrix step;
+    filter_functions/numeric.py:1470-1699 (from scratch, no caches)."""
+    dt = np.asarray(dt, dtype=float)
+    omega = np.asarray(omega, dtype=float)
+    basis = np.asarray(basis)
+    G, d = eigvals.shape
+    A, N, W = len(n_opers), len(basis), len(omega)
+    t = np.concatenate(([0.0], dt.cumsum()))
+    QdV, Bbar = _prologue(eigvals, eigvecs, propagators, n_opers, n_coeffs)
+    F2 = np.zeros((A, A, N, N, W), dtype=complex)
+    cumulative = np.zeros((A, N, W), dtype=complex)
+    for g in range(G):
+        Cbar = QdV[g].conj().T @ basis @ QdV[g]                              # numeric.py:1644
+        NB = (Bbar[:, g, None, :, :]*Cbar.transpose(0, 2, 1)[None]).reshape(A*N, d*d)  # :1632
+        I1 = first_order_integral(omega, eigvals[g], dt[g]).reshape(W, d*d)
+        step = (NB @ (I1*cexp(omega*t[g])[:, None]).T).reshape(A, N, W)      # numeric.py:1649
+        I2 = second_order_integral(omega, eigvals[g], dt[g]).reshape(W, d*d, d*d)
+        inc = np.einsum('pi,oim,qm->pqo', NB, I2, NB).reshape(A, N, A, N, W)  # numeric.py:1625
+        F2 += inc.transpose(0, 2, 1, 3, 4)
+        if g > 0:
+            F2 += step.conj()[:, None, :, None]*cumulative[None, :, None]    # numeric.py:1679
+        cumulative += step
+    return F2
+
+
+def frequency_shifts(F2, spectrum, omega, idx):
+    """Delta_{ab,kl} = int dw/2pi Re[S_ab F2_{ab,kl}], filter_functions/numeric.py:1340-1410 with
+    the 'generalized' filter-function branch of _get_integrand (:318-329, :351-354)."""
+    omega = np.asarray(omega, dtype=float)
+    idx = np.asarray(idx)
+    S = parse_spectrum(spectrum, omega, idx)
+    if S.ndim in (1, 2):
+        integrand = F2[idx, idx]*(S[:, None, None, :] if S.ndim == 2 else S)
+    else:
+        integrand = F2[idx[:, None], idx]*S[:, :, None, None, :]
+    return integrate(integrand.real, omega)/(2*np.pi)
+
+
+def cumulant_second_order_dense(Delta, basis, single_qubit=False):
+    """The frequency-shift contribution to K: -1/2 sum_kl Delta_kl (T_klji - T_lkji - T_klij +
+    T_lkij), filter_functions/numeric.py:1166-1190; single qubit: -(Delta - Delta^T) on the
+    traceless block (:1139-1141)."""
+    Delta = np.asarray(Delta)
+    if single_qubit:
+        K = np.zeros(Delta.shape, Delta.dtype)
+        K[..., 1:, 1:] = -Delta[..., 1:, 1:] + Delta[..., 1:, 1:].swapaxes(-1, -2)
+        return K
+    T = four_element_traces(basis)
+    K = -(np.einsum('...kl,klji->...ij', Delta, T).real
+          - np.einsum('...kl,lkji->...ij', Delta, T).real
+          - np.einsum('...kl,klij->...ij', Delta, T).real
+          + np.einsum('...kl,lkij->...ij', Delta, T).real)
+    return K*0.5
+
+
+def cumulant_second_order(Delta, basis):
+    """The same without the trace tensor: with X = sum_kl (Delta_kl - Delta_lk) C_k C_l the
+    contribution is K_ij = -1/2 Re tr(C_i [X, C_j]), a commutator with the effective Hamiltonian
+    of the frequency shifts.  What the device path implements."""
+    C = np.asarray(basis)
+    Delta = np.asarray(Delta)
+    Asym = Delta - Delta.swapaxes(-1, -2)
+    X = np.einsum('...kl,kab,lbc->...ac', Asym, C, C)
+    comm = np.einsum('...ab,jbc->...jac', X, C) - np.einsum('jab,...bc->...jac', C, X)
+    return -0.5*np.einsum('iba,...jab->...ij', C, comm).real

@@ -293,7 +293,60 @@ def make_cnot():
     save('cnot', **arrays)
 
 
+def make_second_order():
+    """15. second-order filter function, frequency shifts and the second-order cumulant function
+    / error transfer matrix (reference numeric.py:170-256, 1340-1410, 1470-1699, 1166-1190), the
+    cases of tests/test_core.py:784-800, 1005-1066 and tests/test_precision.py:218-270, 631-727 in
+    small: Pauli d=2, GGM d=3, Pauli d=4 (one with an idle segment, i.e. fully degenerate
+    eigenvalues); grids with negative, zero and positive frequencies."""
+    rng = np.random.default_rng(77)
+    arrays = {}
+    cases = [('q1', 2, 4, 2, 2, 'Pauli', False), ('g3', 3, 3, 3, 2, 'GGM', False),
+             ('p4', 4, 3, 3, 2, 'Pauli', False), ('p4idle', 4, 3, 2, 2, 'Pauli', True)]
+    for name, d, n_dt, n_cops, n_nops, btype, idle in cases:
+        pulse = rand_pulse(d, n_dt, n_cops, n_nops, btype, rng)
+        if idle:
+            pulse.c_coeffs[:, 1] = 0.0
+        omega = np.sort(np.concatenate([[-7.5, -0.3, 0.0], np.geomspace(2e-2, 40.0, 10)]))
+        n = n_nops
+        spec3 = np.tile(1e-3/(1 + omega**2), (n, n, 1)).astype(complex)
+        for i in range(n):
+            for j in range(i + 1, n):
+                spec3[i, j] += 1j*1e-4*omega/(1 + omega**2)
+                spec3[j, i] -= 1j*1e-4*omega/(1 + omega**2)
+        spectra = [1e-3/(1 + omega**2), np.outer(np.arange(n) + 1.0, 1e-3/(4 + omega**2)), spec3]
+        for k, v in pulse_inputs(pulse).items():
+            arrays[f'{name}_{k}'] = v
+        arrays[f'{name}_omega'] = omega
+        pulse.diagonalize()
+        arrays[f'{name}_eigvals'] = pulse.eigvals
+        arrays[f'{name}_eigvecs'] = pulse.eigvecs
+        arrays[f'{name}_propagators'] = pulse.propagators
+        arrays[f'{name}_filter_function_2'] = pulse.get_filter_function(omega, order=2)
+        for i, S in enumerate(spectra, 1):
+            arrays[f'{name}_S{i}'] = S
+            arrays[f'{name}_frequency_shifts_S{i}'] = numeric.calculate_frequency_shifts(
+                pulse, S, omega)
+            arrays[f'{name}_cumulant_function_2_S{i}'] = numeric.calculate_cumulant_function(
+                pulse, S, omega, second_order=True)
+            arrays[f'{name}_error_transfer_matrix_2_S{i}'] = numeric.error_transfer_matrix(
+                pulse, S, omega, second_order=True)
+        # the nested integral of one segment, all branches (w = 0 row included)
+        G = 1 if idle else 0
+        bufs = ((np.empty((d, d, d, d)), np.empty((len(omega), d, d)), np.empty((len(omega), d, d))),
+                (np.empty((len(omega), d, d), dtype=complex), np.empty((d, d, d, d), dtype=complex)),
+                np.empty((4, len(omega), d, d, d, d), dtype=bool))
+        int_buf = np.zeros((len(omega), d, d, d, d), dtype=complex)
+        arrays[f'{name}_second_order_integral'] = numeric._second_order_integral(
+            omega, pulse.eigvals[G], pulse.dt[G], int_buf, bufs[1], bufs[0], bufs[2]).copy()
+        arrays[f'{name}_second_order_integral_segment'] = G
+    save('second_order', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'second_order':
+        make_second_order()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'cnot':
         make_cnot()
         return

@@ -280,3 +280,37 @@ def test_cnot_fixture_against_oracle():
     for i in (0, 1):
         infid = orc.infidelity_from_filter_function(F, g[f'S{i}'], g['omega'], idx, 4)
         assert rel_err(infid, g[f'infid{i}']) < 1e-12
+
+
+SECOND_ORDER_CASES = [('q1', True), ('g3', False), ('p4', False), ('p4idle', False)]
+
+
+@pytest.mark.parametrize('name,single_qubit', SECOND_ORDER_CASES)
+def test_second_order_filter_function_and_frequency_shifts(name, single_qubit):
+    """Oracle vs the reference's second-order chain (numeric.py:170-256, 1340-1410, 1470-1699,
+    1166-1190): nested integral incl. the w == 0 limits, F2, Delta for 1-D/2-D/3-D spectra, the
+    second-order cumulant function and error transfer matrix."""
+    g = load_golden('second_order')
+    omega, basis = g[f'{name}_omega'], g[f'{name}_basis']
+    D, V, Q = g[f'{name}_eigvals'], g[f'{name}_eigvecs'], g[f'{name}_propagators']
+    seg = int(g[f'{name}_second_order_integral_segment'])
+    I2 = orc.second_order_integral(omega, D[seg], g[f'{name}_dt'][seg])
+    assert rel_err(I2, g[f'{name}_second_order_integral']) < 1e-13
+    F2 = orc.second_order_filter_function(D, V, Q, omega, basis, g[f'{name}_n_opers'],
+                                          g[f'{name}_n_coeffs'], g[f'{name}_dt'])
+    assert rel_err(F2, g[f'{name}_filter_function_2']) < 1e-13
+    A = F2.shape[0]
+    R = orc.control_matrix_from_scratch(D, V, Q, omega, basis, g[f'{name}_n_opers'],
+                                        g[f'{name}_n_coeffs'], g[f'{name}_dt'])
+    for i in (1, 2, 3):
+        S = g[f'{name}_S{i}']
+        delta = orc.frequency_shifts(F2, S, omega, np.arange(A))
+        assert rel_err(delta, g[f'{name}_frequency_shifts_S{i}']) < 1e-13
+        gamma = orc.decay_amplitudes(R, S, omega, np.arange(A))
+        K1 = orc.cumulant_function_dense(gamma, basis, single_qubit)
+        K_ref = g[f'{name}_cumulant_function_2_S{i}']
+        K2 = orc.cumulant_second_order_dense(delta, basis, single_qubit)
+        assert rel_err(K1 + K2, K_ref) < 1e-13
+        assert np.abs(orc.cumulant_second_order(delta, basis) - K2).max() < 1e-17
+        U = orc.error_transfer_matrix(K1 + K2)
+        assert np.abs(U - g[f'{name}_error_transfer_matrix_2_S{i}']).max() < 1e-14
