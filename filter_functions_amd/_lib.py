@@ -126,6 +126,13 @@ SIGNATURES = {
     'ffk_cumulant_function_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                           c_void_p, c_size_t, c_void_p]),
     'ffk_cumulant_function': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    'ffk_second_order_filter_function': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                 c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                                 c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'ffk_frequency_shifts': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
+                                     c_void_p, c_int, c_void_p]),
+    'ffk_cumulant_function_second_order': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p,
+                                                   c_void_p]),
     'ffk_expm_real': (c_int, [c_void_p, c_int, c_void_p]),
     'ffk_liouville': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'ffk_liouville_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

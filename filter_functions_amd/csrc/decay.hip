@@ -305,6 +305,13 @@ __global__ __launch_bounds__(64) void cumulant_single_qubit_kernel(const double*
 
 }  // namespace
 
+hipError_t launch_spectral_weights(const cplx* S, int rows, int W, const double* omega, int Wg,
+                                   int w_offset, cplx* scale, hipStream_t stream) {
+    hipLaunchKernelGGL(spectral_weights_kernel, dim3((W + 255)/256, min(rows, 1024)), dim3(256), 0,
+                       stream, S, rows, W, omega, Wg, w_offset, scale);
+    return hipGetLastError();
+}
+
 size_t decay_amplitudes_workspace_bytes(int Gp, int N, int W, int n_idx, int s_ndim) {
     const DecayPlan p = decay_plan(Gp, N, W, n_idx, s_ndim);
     const size_t rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : static_cast<size_t>(n_idx)*n_idx);

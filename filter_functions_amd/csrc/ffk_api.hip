@@ -1033,6 +1033,136 @@ int ffk_cumulant_function(const double* decay_amplitudes, int batch, int N, int 
     return FFK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// second order: filter function, frequency shifts, cumulant-function contribution
+// ---------------------------------------------------------------------------------------------
+int ffk_second_order_filter_function(const double* eigvals, const double* eigvecs,
+                                     const double* propagators, const double* omega, int W,
+                                     const double* basis, int N, const double* n_opers, int A,
+                                     const double* n_coeffs, const double* dt, const double* t, int G,
+                                     int d, double* filter_function_2) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
+    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && basis && n_opers && n_coeffs && dt && t &&
+                    filter_function_2, "NULL argument");
+    FFK_REQUIRE(size_t(A)*N <= 65535, "A*N = %zu too large", size_t(A)*N);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t dd = size_t(d)*d;
+    const size_t nF = size_t(A)*A*N*N*W;
+    const size_t wsb = ffk::second_order_workspace_bytes(G, A, N, d);
+    size_t total = 0;
+    total += align_up(8*size_t(G)*d) + align_up(16*size_t(G)*dd) + align_up(16*size_t(G + 1)*dd);
+    total += align_up(8*size_t(W)) + align_up(16*size_t(N)*dd) + align_up(16*size_t(A)*dd);
+    total += align_up(8*size_t(A)*G) + align_up(8*size_t(G)) + align_up(8*size_t(G + 1));
+    total += align_up(8*size_t(G)*ffk::seg_stride(d)) + align_up(16*size_t(G)*dd) +
+             align_up(16*size_t(G)*(1 + A)*dd);
+    total += align_up(16*size_t(A)*G*dd) + align_up(16*size_t(G)*dd) + align_up(16*size_t(G)*N*dd);
+    total += wsb + align_up(16*nF);
+    void* base;
+    if (int rc = arena_reserve(total, &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dD = a.take<double>(size_t(G)*d);
+    cplx* dV = a.take<cplx>(size_t(G)*dd);
+    cplx* dQ = a.take<cplx>(size_t(G + 1)*dd);
+    double* dom = a.take<double>(W);
+    cplx* dbasis = a.take<cplx>(size_t(N)*dd);
+    cplx* dnop = a.take<cplx>(size_t(A)*dd);
+    double* dnc = a.take<double>(size_t(A)*G);
+    double* ddt = a.take<double>(G);
+    double* dtt = a.take<double>(G + 1);
+    double* segtab = a.take<double>(size_t(G)*ffk::seg_stride(d));
+    cplx* Tc = a.take<cplx>(size_t(G)*dd);
+    cplx* ops = a.take<cplx>(size_t(G)*(1 + A)*dd);
+    cplx* dnt = a.take<cplx>(size_t(A)*G*dd);
+    cplx* dep = a.take<cplx>(size_t(G)*dd);
+    cplx* dbt = a.take<cplx>(size_t(G)*N*dd);
+    void* ws = a.take<unsigned char>(wsb);
+    cplx* dF = a.take<cplx>(nF);
+    FFK_REQUIRE(dF && a.used <= g_arena.size, "internal: arena too small");
+    auto h2d = [](void* dst, const void* src, size_t n) {
+        return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, nullptr);
+    };
+    FFK_HIP(h2d(dD, eigvals, 8*size_t(G)*d));
+    FFK_HIP(h2d(dV, eigvecs, 16*size_t(G)*dd));
+    FFK_HIP(h2d(dQ, propagators, 16*size_t(G + 1)*dd));
+    FFK_HIP(h2d(dom, omega, 8*size_t(W)));
+    FFK_HIP(h2d(dbasis, basis, 16*size_t(N)*dd));
+    FFK_HIP(h2d(dnop, n_opers, 16*size_t(A)*dd));
+    FFK_HIP(h2d(dnc, n_coeffs, 8*size_t(A)*G));
+    FFK_HIP(h2d(ddt, dt, 8*size_t(G)));
+    FFK_HIP(h2d(dtt, t, 8*size_t(G + 1)));
+    FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dnop, dnc, ddt, dtt, G, d, A, segtab, Tc, ops, dnt, dep, nullptr));
+    FFK_HIP(ffk::launch_basis_transformed(Tc, dbasis, G, N, d, dbt, nullptr));
+    FFK_HIP(ffk::launch_second_order_filter_function(dom, W, dD, ddt, dtt, dnt, dbt, G, d, A, N, dF, ws,
+                                                     nullptr));
+    FFK_HIP(hipMemcpyAsync(filter_function_2, dF, 16*nF, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+int ffk_frequency_shifts(const double* filter_function_2, int A, int N, int W, const double* spectrum,
+                         int s_ndim, const double* omega, const int32_t* idx, int n_idx,
+                         double* frequency_shifts) {
+    FFK_REQUIRE(filter_function_2 && spectrum && omega && idx && frequency_shifts, "NULL argument");
+    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
+    FFK_REQUIRE(A >= 1 && N >= 1 && W >= 1 && n_idx >= 1, "empty axis");
+    for (int i = 0; i < n_idx; ++i)
+        FFK_REQUIRE(idx[i] >= 0 && idx[i] < A, "noise operator index %d out of range [0, %d)", idx[i], A);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nF = 16*size_t(A)*A*N*N*W;
+    const int rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : n_idx*n_idx);
+    const size_t nS = 16*size_t(W)*rows;
+    const size_t nout = size_t(n_idx)*(s_ndim == 3 ? n_idx : 1)*N*N;
+    void* base;
+    if (int rc = arena_reserve(align_up(nF) + 2*align_up(nS) + align_up(8*size_t(W)) +
+                                   align_up(4*size_t(n_idx)) + align_up(8*nout), &base))
+        return rc;
+    Bump a(base, g_arena.size);
+    cplx* dF = a.take<cplx>(nF/16);
+    cplx* dS = a.take<cplx>(nS/16);
+    cplx* dscale = a.take<cplx>(nS/16);
+    double* dom = a.take<double>(W);
+    int32_t* didx = a.take<int32_t>(n_idx);
+    double* dout = a.take<double>(nout);
+    FFK_REQUIRE(dout, "internal: arena too small");
+    FFK_HIP(hipMemcpyAsync(dF, filter_function_2, nF, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dS, spectrum, nS, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dom, omega, 8*size_t(W), hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(didx, idx, 4*size_t(n_idx), hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(ffk::launch_spectral_weights(dS, rows, W, dom, W, 0, dscale, nullptr));
+    FFK_HIP(ffk::launch_frequency_shifts(dF, A, N, W, dscale, s_ndim, didx, n_idx, dout, nullptr));
+    FFK_HIP(hipMemcpyAsync(frequency_shifts, dout, 8*nout, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+int ffk_cumulant_function_second_order(const double* frequency_shifts, int batch, int N, int d,
+                                       const double* basis, double* cumulant_function) {
+    FFK_REQUIRE(frequency_shifts && basis && cumulant_function, "NULL argument");
+    FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis");
+    FFK_REQUIRE(d_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nG = 8*size_t(batch)*N*N;
+    const size_t nB = 16*size_t(N)*d*d;
+    const size_t wsb = ffk::cumulant_second_order_workspace_bytes(batch, N, d);
+    void* base;
+    if (int rc = arena_reserve(2*align_up(nG) + align_up(nB) + align_up(wsb), &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dD = a.take<double>(nG/8);
+    double* dK = a.take<double>(nG/8);
+    double* dB = a.take<double>(nB/8);
+    void* ws = a.take<unsigned char>(wsb);
+    FFK_REQUIRE(ws, "internal: arena too small");
+    FFK_HIP(hipMemcpyAsync(dD, frequency_shifts, nG, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dK, cumulant_function, nG, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dB, basis, nB, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(ffk::launch_cumulant_second_order(dD, batch, N, d, reinterpret_cast<const cplx*>(dB), dK, ws,
+                                              nullptr));
+    FFK_HIP(hipMemcpyAsync(cumulant_function, dK, nG, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
 int ffk_expm_real(const double* matrix, int N, double* result) {
     FFK_REQUIRE(matrix && result, "NULL argument");
     FFK_REQUIRE(N >= 1 && N <= 4096, "matrix dimension %d outside [1, 4096]", N);

@@ -191,6 +191,26 @@ hipError_t launch_cumulant_function(const double* gamma, size_t batch, int N, in
                                     const cplx* basis, int single_qubit, double* K, void* ws,
                                     hipStream_t stream);
 
+// scale (rows,W) = trapezoid weight(w_offset + w) S[row,w] / 2 pi over the global grid omega (Wg,)
+hipError_t launch_spectral_weights(const cplx* S, int rows, int W, const double* omega, int Wg,
+                                   int w_offset, cplx* scale, hipStream_t stream);
+
+// ---- second.hip ------------------------------------------------------------------------------
+// F2 (A,A,N,N,W) from nt = n_opers_transformed (A,G,d,d) and bt = basis_transformed (G,N,d,d)
+size_t second_order_workspace_bytes(int G, int A, int N, int d);
+hipError_t launch_second_order_filter_function(const double* omega, int W, const double* eigvals,
+                                               const double* dt, const double* t, const cplx* nt,
+                                               const cplx* bt, int G, int d, int A, int N, cplx* F2,
+                                               void* ws, hipStream_t stream);
+// Delta (n_idx[,n_idx],N,N) = sum_w Re(F2[idx,idx] scale); scale from launch_spectral_weights
+hipError_t launch_frequency_shifts(const cplx* F2, int A, int N, int W, const cplx* scale,
+                                   int s_ndim, const int32_t* idx, int n_idx, double* out,
+                                   hipStream_t stream);
+// K (batch,N,N) += second-order contribution of Delta (batch,N,N)
+size_t cumulant_second_order_workspace_bytes(size_t batch, int N, int d);
+hipError_t launch_cumulant_second_order(const double* delta, size_t batch, int N, int d,
+                                        const cplx* basis, double* K, void* ws, hipStream_t stream);
+
 // B (W,A,d,d) = B^(0) + sum_g phases[g-1] P_{g-1}^dag B^(g) P_{g-1}; atomic (G,W,A,d,d), props (G-1,d,d)
 hipError_t launch_noise_ops_from_atomic(const cplx* phases, const cplx* atomic, const cplx* props,
                                         int G, int W, int A, int d, cplx* out, hipStream_t stream);

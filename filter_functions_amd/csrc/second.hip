@@ -1,0 +1,428 @@
+// second.hip -- K8: second-order filter function (the consumer of the step caches).
+//
+// numeric.calculate_second_order_filter_function_from_scratch (filter_functions/numeric.py:1470-1699)
+// with the nested Magnus integral _second_order_integral (:170-256):
+//
+//   F2[a,b,k,l,w] = sum_g [ conj(G^(g)_{ak}(w)) sum_{g'<g} G^(g')_{bl}(w)                 "complete"
+//                           + sum_{ij,mn} NB^(g)_{ak,ij} I^(g)_{ij,mn}(w) NB^(g)_{bl,mn} ]  "incomplete"
+//   NB^(g)_{ak,ij} = Bbar^(g)_{a,ij} Cbar^(g)_{k,ji}        (:1632),
+//   G^(g)_{ak}(w)  = e^{i w t_g} sum_ij NB^(g)_{ak,ij} I1^(g)_{ij}(w)   (the control-matrix step, :1649).
+//
+// The reference materialises I (W d^4 entries per segment) and contracts it twice.  Here the
+// general branch of the integral is used in its factored form
+//   I_{ij,mn} = (f(W_ij - w) - f(W_ij + W_mn)) / (w + W_mn),   f(x) = (e^{i x dt} - 1)/x,
+// so that  X_{ak,mn} := sum_ij NB_{ak,ij} I_{ij,mn} = u_mn (P_ak - M_{ak,mn})  with
+//   u_mn = 1/(w + W_mn)               one reciprocal per (g, w, mn),
+//   P_ak = sum_ij NB_{ak,ij} f(W_ij - w)        A N d^2 MACs per (g, w),
+//   M_{ak,mn} = sum_ij NB_{ak,ij} f(W_ij + W_mn)   frequency independent (so_prepare_kernel),
+// and only the second contraction, F2_{ak,bl} += sum_mn X_{ak,mn} NB_{bl,mn}, is O((A N)^2 d^2) per
+// (g, w): 8 (A N)^2 d^2 flops instead of 8 A N d^4 + 8 (A N)^2 d^2.  Entries with w + W_mn == 0
+// exactly take the limit formulas (:186-194, :241-255) through X_{ak,mn} = sum_ij NB_{ak,ij} Isp_ij.
+//
+// One block: a (16 RT) x (16 RT) tile of the (A N) x (A N) output for WT frequencies; the segment
+// loop runs inside the block, accumulators stay in registers, operands are staged through LDS in
+// [mn][row] layout (the row index is the fast one: a wave reads 16 distinct NB rows and broadcasts
+// its 4 X rows).
+#include "ffk_internal.h"
+
+namespace ffk {
+namespace {
+
+// (e^{i x dt} - 1)/x = (2 s / x)(-s + i c), s = sin(x dt/2), c = cos(x dt/2); i dt at x == 0
+// (util.cexpm1, util.py:165-182, divided as in numeric.py:229-235)
+__device__ __forceinline__ cplx frac(double x, double dt) {
+    double s, c;
+    sincos_pi(0.5*(x*dt), &s, &c);
+    const double q = 2.0*s*rcp(x);
+    cplx out = {-q*s, q*c};
+    if (x == 0.0) out = {0.0, dt};
+    return out;
+}
+
+// One block per (segment g, row r = a N + k):
+//   NB[g][r][e = i d + j] = Bbar[a,g,i,j] Cbar[g,k,j,i]
+//   M[g][r][f = m d + n]  = sum_e NB[g][r][e] f(dE_e + dE_f)
+__global__ __launch_bounds__(64) void so_prepare_kernel(const cplx* __restrict__ nt,
+                                                        const cplx* __restrict__ bt,
+                                                        const double* __restrict__ eigvals,
+                                                        const double* __restrict__ dt, int G, int A,
+                                                        int N, int d, cplx* __restrict__ NB,
+                                                        cplx* __restrict__ M) {
+    extern __shared__ unsigned char smem[];
+    const int d2 = d*d;
+    cplx* row = reinterpret_cast<cplx*>(smem);                 // [d2]
+    double* dE = reinterpret_cast<double*>(row + d2);          // [d2]
+    const int g = blockIdx.x, r = blockIdx.y;
+    const int a = r / N, k = r % N;
+    const cplx* B = nt + (static_cast<size_t>(a)*G + g)*d2;
+    const cplx* C = bt + (static_cast<size_t>(g)*N + k)*d2;
+    cplx* NBr = NB + (static_cast<size_t>(g)*A*N + r)*d2;
+    for (int e = threadIdx.x; e < d2; e += 64) {
+        const int i = e / d, j = e % d;
+        const cplx v = cmul(B[e], C[j*d + i]);
+        row[e] = v;
+        NBr[e] = v;
+        dE[e] = eigvals[static_cast<size_t>(g)*d + i] - eigvals[static_cast<size_t>(g)*d + j];
+    }
+    __syncthreads();
+    const double dtg = dt[g];
+    cplx* Mr = M + (static_cast<size_t>(g)*A*N + r)*d2;
+    for (int f = threadIdx.x; f < d2; f += 64) {
+        cplx acc = {0.0, 0.0};
+        const double df = dE[f];
+        for (int e = 0; e < d2; ++e) cmac(acc, row[e], frac(dE[e] + df, dtg));
+        Mr[f] = acc;
+    }
+}
+
+template <int RT, int WT>
+__global__ __launch_bounds__(256) void so_accumulate_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ eigvals,
+    const double* __restrict__ dt, const double* __restrict__ t, const cplx* __restrict__ NB,
+    const cplx* __restrict__ M, int G, int d, int A, int N, int mc, cplx* __restrict__ F2) {
+    constexpr int T = 16*RT, Tp = T + 1;
+    const int d2 = d*d, AN = A*N;
+    extern __shared__ unsigned char smem[];
+    cplx* Xs = reinterpret_cast<cplx*>(smem);   // [WT][mc][Tp]
+    cplx* NBs = Xs + WT*mc*Tp;                  // [mc][Tp]
+    cplx* frc1 = NBs + mc*Tp;                   // [WT][d2]   f(W_ij - w)
+    cplx* I1 = frc1 + WT*d2;                    // [WT][d2]   e^{i w t_g} I1_ij(w)
+    cplx* Isp = I1 + WT*d2;                     // [WT][d2]   limit integrals (w + W_mn == 0)
+    cplx* P = Isp + WT*d2;                      // [WT][T]
+    cplx* Xsp = P + WT*T;                       // [WT][T]
+    cplx* GsA = Xsp + WT*T;                     // [WT][T]
+    cplx* GsB = GsA + WT*T;                     // [WT][T]
+    cplx* Gcum = GsB + WT*T;                    // [WT][T]
+    double* u = reinterpret_cast<double*>(Gcum + WT*T);   // [WT][d2]   1/(w + W_mn), 0 if special
+    int* spec = reinterpret_cast<int*>(u + WT*d2);        // [WT][d2]
+
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int w0 = blockIdx.x*WT;
+    const int rowA0 = blockIdx.y*T, rowB0 = blockIdx.z*T;
+
+    cplx acc[WT][RT][RT];
+#pragma unroll
+    for (int wi = 0; wi < WT; ++wi)
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < RT; ++j) acc[wi][i][j] = {0.0, 0.0};
+    for (int q = tid; q < WT*T; q += 256) Gcum[q] = {0.0, 0.0};
+
+    for (int g = 0; g < G; ++g) {
+        const double dtg = dt[g], tg = t[g];
+        const double* D = eigvals + static_cast<size_t>(g)*d;
+        // (1) the frequency-dependent scalars of this segment
+        int special = 0;
+        for (int q = tid; q < WT*d2; q += 256) {
+            const int wi = q / d2, e = q % d2;
+            const double dE = D[e / d] - D[e % d];
+            const double w = omega[min(w0 + wi, W - 1)];
+            const double a = -w + dE;              // np.add.outer(-E, dE), numeric.py:208
+            const double b = w + dE;               // np.add.outer(E, dE),  numeric.py:207
+            const cplx fa = frac(a, dtg);
+            const cplx fb = frac(b, dtg);
+            frc1[q] = fa;
+            I1[q] = cmul(cexp(w*tg), cplx{fb.im, -fb.re});     // first-order integral = -i f(b)
+            const bool sp = b == 0.0;
+            special |= sp;
+            spec[q] = sp;
+            u[q] = sp ? 0.0 : 1.0/b;
+            cplx lim = {0.5*dtg*dtg, 0.0};
+            if (a != 0.0) {
+                const cplx ph = cexp(a*dtg);
+                const double ra = 1.0/a;
+                lim = {(fa.re + dtg*ph.im)*ra, (fa.im - dtg*ph.re)*ra};   // (f(a) - i dt e^{i a dt})/a
+            }
+            Isp[q] = lim;
+        }
+        const int any_special = __syncthreads_or(special);
+        // (2) per-row contractions with the d^2 scalars: P, Xsp, G^(g) for the A rows; G^(g) for the
+        // B rows
+        if (tid < WT*2*T) {
+            const int wi = tid / (2*T), side = (tid / T) & 1, r = tid % T;
+            const int rowi = (side ? rowB0 : rowA0) + r;
+            cplx p = {0.0, 0.0}, gs = {0.0, 0.0}, xs = {0.0, 0.0};
+            if (rowi < AN) {
+                const cplx* nb = NB + (static_cast<size_t>(g)*AN + rowi)*d2;
+                const cplx* f1 = frc1 + wi*d2;
+                const cplx* i1 = I1 + wi*d2;
+                const cplx* is = Isp + wi*d2;
+                for (int e = 0; e < d2; ++e) {
+                    const cplx v = nb[e];
+                    cmac(gs, v, i1[e]);
+                    if (!side) {
+                        cmac(p, v, f1[e]);
+                        if (any_special) cmac(xs, v, is[e]);
+                    }
+                }
+            }
+            if (side) {
+                GsB[wi*T + r] = gs;
+            } else {
+                GsA[wi*T + r] = gs;
+                P[wi*T + r] = p;
+                Xsp[wi*T + r] = xs;
+            }
+        }
+        __syncthreads();
+        // (3) complete intervals: conj(G^(g)_A) x cumulative G_B up to g-1   (numeric.py:1679)
+        if (g > 0) {
+#pragma unroll
+            for (int wi = 0; wi < WT; ++wi) {
+                cplx gb[RT];
+#pragma unroll
+                for (int j = 0; j < RT; ++j) gb[j] = Gcum[wi*T + tx*RT + j];
+#pragma unroll
+                for (int i = 0; i < RT; ++i) {
+                    const cplx ga = GsA[wi*T + ty*RT + i];
+                    const cplx gac = {ga.re, -ga.im};
+#pragma unroll
+                    for (int j = 0; j < RT; ++j) cmac(acc[wi][i][j], gac, gb[j]);
+                }
+            }
+        }
+        // (4) incomplete interval, mn in chunks of mc
+        for (int f0 = 0; f0 < d2; f0 += mc) {
+            const int mcur = min(mc, d2 - f0);
+            for (int q = tid; q < mcur*T; q += 256) {
+                const int fl = q % mcur, r = q / mcur;
+                const int f = f0 + fl;
+                const int rb = rowB0 + r, ra = rowA0 + r;
+                cplx nbv = {0.0, 0.0};
+                if (rb < AN) nbv = NB[(static_cast<size_t>(g)*AN + rb)*d2 + f];
+                NBs[fl*Tp + r] = nbv;
+                cplx mv = {0.0, 0.0};
+                if (ra < AN) mv = M[(static_cast<size_t>(g)*AN + ra)*d2 + f];
+#pragma unroll
+                for (int wi = 0; wi < WT; ++wi) {
+                    const cplx pv = P[wi*T + r];
+                    const double uv = u[wi*d2 + f];
+                    cplx x = {uv*(pv.re - mv.re), uv*(pv.im - mv.im)};
+                    if (spec[wi*d2 + f]) x = Xsp[wi*T + r];
+                    if (ra >= AN) x = {0.0, 0.0};
+                    Xs[(wi*mc + fl)*Tp + r] = x;
+                }
+            }
+            __syncthreads();
+            if (f0 == 0 && tid < WT*T) {          // every wave is past (3): advance the cumulative sum
+                Gcum[tid].re += GsB[tid].re;
+                Gcum[tid].im += GsB[tid].im;
+            }
+            for (int fl = 0; fl < mcur; ++fl) {
+                cplx nb[RT];
+#pragma unroll
+                for (int j = 0; j < RT; ++j) nb[j] = NBs[fl*Tp + tx*RT + j];
+#pragma unroll
+                for (int wi = 0; wi < WT; ++wi) {
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) {
+                        const cplx x = Xs[(wi*mc + fl)*Tp + ty*RT + i];
+#pragma unroll
+                        for (int j = 0; j < RT; ++j) cmac(acc[wi][i][j], x, nb[j]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // F2[a,b,k,l,w]: row r_A = a N + k, r_B = b N + l
+#pragma unroll
+    for (int wi = 0; wi < WT; ++wi) {
+        const int w = w0 + wi;
+        if (w >= W) continue;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int ra = rowA0 + ty*RT + i;
+            if (ra >= AN) continue;
+            const int a = ra / N, k = ra % N;
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+                const int rb = rowB0 + tx*RT + j;
+                if (rb >= AN) continue;
+                const int b = rb / N, l = rb % N;
+                F2[(((static_cast<size_t>(a)*A + b)*N + k)*N + l)*W + w] = acc[wi][i][j];
+            }
+        }
+    }
+}
+
+size_t so_lds_bytes(int rt, int wt, int mc, int d2) {
+    const size_t T = 16*rt, Tp = T + 1;
+    return sizeof(cplx)*((wt + 1)*mc*Tp + 3*size_t(wt)*d2 + 5*size_t(wt)*T) +
+           size_t(wt)*d2*(sizeof(double) + sizeof(int));
+}
+
+template <int RT, int WT>
+hipError_t launch_so(const double* omega, int W, const double* eigvals, const double* dt,
+                     const double* t, const cplx* NB, const cplx* M, int G, int d, int A, int N,
+                     int mc, cplx* F2, hipStream_t stream) {
+    const int AN = A*N, T = 16*RT;
+    const int tiles = (AN + T - 1)/T;
+    const size_t lds = so_lds_bytes(RT, WT, mc, d*d);
+    auto kern = so_accumulate_kernel<RT, WT>;
+    if (lds > 48*1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    const dim3 grid((W + WT - 1)/WT, tiles, tiles);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, omega, W, eigvals, dt, t, NB, M, G, d, A,
+                       N, mc, F2);
+    return hipGetLastError();
+}
+
+// Delta[row] = sum_w Re( F2[pair(row), kl(row), w] * scale[srow, w] ), one block per output row
+__global__ __launch_bounds__(256) void frequency_shifts_kernel(const cplx* __restrict__ F2, int A,
+                                                               int N, int W,
+                                                               const cplx* __restrict__ scale,
+                                                               int s_ndim,
+                                                               const int32_t* __restrict__ idx,
+                                                               int n_idx, double* __restrict__ out) {
+    const size_t NN = static_cast<size_t>(N)*N;
+    const size_t row = blockIdx.x;
+    const size_t pair = row / NN, kl = row % NN;
+    int a, b, srow;
+    if (s_ndim == 3) {
+        a = idx[pair / n_idx];
+        b = idx[pair % n_idx];
+        srow = static_cast<int>(pair);
+    } else {
+        a = b = idx[pair];
+        srow = s_ndim == 2 ? static_cast<int>(pair) : 0;
+    }
+    const cplx* f = F2 + ((static_cast<size_t>(a)*A + b)*NN + kl)*W;
+    const cplx* s = scale + static_cast<size_t>(srow)*W;
+    double sum = 0.0;
+    for (int w = threadIdx.x; w < W; w += 256) sum += f[w].re*s[w].re - f[w].im*s[w].im;
+    __shared__ double red[256];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[row] = red[0];
+}
+
+// K[b][i][j] += -1/2 Re tr(C_i [X_b, C_j]),  X_b = sum_kl (Delta_kl - Delta_lk) C_k C_l
+// (numeric.py:1166-1190 without the four-element trace tensor).  One block per batch element; the
+// sizes are those of one error transfer matrix (N^2 outputs).
+__global__ __launch_bounds__(256) void cumulant_second_order_kernel(const double* __restrict__ delta,
+                                                                    int N, int d,
+                                                                    const cplx* __restrict__ basis,
+                                                                    cplx* __restrict__ ws,
+                                                                    double* __restrict__ K) {
+    const int d2 = d*d;
+    const size_t b = blockIdx.x;
+    const double* Dl = delta + b*N*N;
+    cplx* Dk = ws + b*(static_cast<size_t>(N)*d2 + d2 + static_cast<size_t>(N)*d2);   // [N][d2]
+    cplx* X = Dk + static_cast<size_t>(N)*d2;                                          // [d2]
+    cplx* Y = X + d2;                                                                  // [N][d2]
+    // D_k = sum_l (Delta_kl - Delta_lk) C_l
+    for (int q = threadIdx.x; q < N*d2; q += 256) {
+        const int k = q / d2, e = q % d2;
+        cplx acc = {0.0, 0.0};
+        for (int l = 0; l < N; ++l) {
+            const double c = Dl[k*N + l] - Dl[l*N + k];
+            const cplx v = basis[static_cast<size_t>(l)*d2 + e];
+            acc.re = fma(c, v.re, acc.re);
+            acc.im = fma(c, v.im, acc.im);
+        }
+        Dk[q] = acc;
+    }
+    __syncthreads();
+    // X = sum_k C_k D_k
+    for (int e = threadIdx.x; e < d2; e += 256) {
+        const int i = e / d, j = e % d;
+        cplx acc = {0.0, 0.0};
+        for (int k = 0; k < N; ++k)
+            for (int x = 0; x < d; ++x)
+                cmac(acc, basis[static_cast<size_t>(k)*d2 + i*d + x], Dk[k*d2 + x*d + j]);
+        X[e] = acc;
+    }
+    __syncthreads();
+    // Y_j = [X, C_j]
+    for (int q = threadIdx.x; q < N*d2; q += 256) {
+        const int jj = q / d2, e = q % d2, i = e / d, j = e % d;
+        const cplx* C = basis + static_cast<size_t>(jj)*d2;
+        cplx acc = {0.0, 0.0};
+        for (int x = 0; x < d; ++x) {
+            cmac(acc, X[i*d + x], C[x*d + j]);
+            const cplx c = C[i*d + x], xv = X[x*d + j];
+            acc.re -= c.re*xv.re - c.im*xv.im;
+            acc.im -= c.re*xv.im + c.im*xv.re;
+        }
+        Y[q] = acc;
+    }
+    __syncthreads();
+    // K_ij += -1/2 Re tr(C_i Y_j)
+    for (int q = threadIdx.x; q < N*N; q += 256) {
+        const int i = q / N, j = q % N;
+        const cplx* C = basis + static_cast<size_t>(i)*d2;
+        const cplx* Yj = Y + static_cast<size_t>(j)*d2;
+        double acc = 0.0;
+        for (int p = 0; p < d; ++p)
+            for (int x = 0; x < d; ++x) {
+                const cplx c = C[p*d + x], y = Yj[x*d + p];
+                acc += c.re*y.re - c.im*y.im;
+            }
+        K[b*N*N + q] += -0.5*acc;
+    }
+}
+
+}  // namespace
+
+size_t second_order_workspace_bytes(int G, int A, int N, int d) {
+    return 2*align_up(sizeof(cplx)*size_t(G)*A*N*d*d);
+}
+
+hipError_t launch_second_order_filter_function(const double* omega, int W, const double* eigvals,
+                                               const double* dt, const double* t, const cplx* nt,
+                                               const cplx* bt, int G, int d, int A, int N, cplx* F2,
+                                               void* ws, hipStream_t stream) {
+    const int d2 = d*d, AN = A*N;
+    if (AN > 65535) return hipErrorInvalidValue;
+    cplx* NB = static_cast<cplx*>(ws);
+    cplx* M = reinterpret_cast<cplx*>(static_cast<unsigned char*>(ws) +
+                                      align_up(sizeof(cplx)*size_t(G)*AN*d2));
+    hipLaunchKernelGGL(so_prepare_kernel, dim3(G, AN), dim3(64), d2*(sizeof(cplx) + sizeof(double)),
+                       stream, nt, bt, eigvals, dt, G, A, N, d, NB, M);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    const int rt = min(4, (AN + 15)/16);
+    const int wt = W >= 512 ? 2 : 1;
+    const int mc = min(d2, 16);
+#define FFK_SO_CASE(R, Wt)                                                                       \
+    if (rt == R && wt == Wt)                                                                     \
+        return launch_so<R, Wt>(omega, W, eigvals, dt, t, NB, M, G, d, A, N, mc, F2, stream);
+    FFK_SO_CASE(1, 1) FFK_SO_CASE(2, 1) FFK_SO_CASE(3, 1) FFK_SO_CASE(4, 1)
+    FFK_SO_CASE(1, 2) FFK_SO_CASE(2, 2) FFK_SO_CASE(3, 2) FFK_SO_CASE(4, 2)
+#undef FFK_SO_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_frequency_shifts(const cplx* F2, int A, int N, int W, const cplx* scale,
+                                   int s_ndim, const int32_t* idx, int n_idx, double* out,
+                                   hipStream_t stream) {
+    const size_t rows = (s_ndim == 3 ? size_t(n_idx)*n_idx : size_t(n_idx))*N*N;
+    if (rows > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(frequency_shifts_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0,
+                       stream, F2, A, N, W, scale, s_ndim, idx, n_idx, out);
+    return hipGetLastError();
+}
+
+size_t cumulant_second_order_workspace_bytes(size_t batch, int N, int d) {
+    return batch*sizeof(cplx)*(2*size_t(N)*d*d + size_t(d)*d);
+}
+
+hipError_t launch_cumulant_second_order(const double* delta, size_t batch, int N, int d,
+                                        const cplx* basis, double* K, void* ws, hipStream_t stream) {
+    if (batch > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cumulant_second_order_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), 0,
+                       stream, delta, N, d, basis, static_cast<cplx*>(ws), K);
+    return hipGetLastError();
+}
+
+}  // namespace ffk

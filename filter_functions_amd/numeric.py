@@ -11,7 +11,9 @@ this module                                           reference (file:line)
 :func:`calculate_filter_function`                     numeric.py:1413-1467
 :func:`infidelity`                                    numeric.py:2062-2334
 :func:`calculate_decay_amplitudes`                    numeric.py:1194-1337
-:func:`calculate_cumulant_function`                   numeric.py:957-1191 (first order)
+:func:`calculate_cumulant_function`                   numeric.py:957-1191
+:func:`calculate_second_order_filter_function_from_scratch`  numeric.py:1470-1699 (:170-256)
+:func:`calculate_frequency_shifts`                    numeric.py:1340-1410
 :func:`error_transfer_matrix`                         numeric.py:1938-2059
 ====================================================  ==============================
 
@@ -20,6 +22,7 @@ Inputs are borrowed NumPy arrays, outputs are fresh C-contiguous ``complex128`` 
 library or a GPU is missing -- there is no CPU fallback in the product.
 """
 import ctypes
+from warnings import warn
 
 import numpy as np
 
@@ -31,7 +34,8 @@ __all__ = ['diagonalize', 'calculate_control_matrix_from_scratch',
            'calculate_control_matrix_from_atomic', 'calculate_control_matrix_from_atomic_indexed',
            'calculate_noise_operators_from_atomic',
            'calculate_pulse_correlation_filter_function', 'calculate_decay_amplitudes',
-           'calculate_cumulant_function', 'error_transfer_matrix']
+           'calculate_cumulant_function', 'error_transfer_matrix',
+           'calculate_second_order_filter_function_from_scratch', 'calculate_frequency_shifts']
 
 
 def _check_d(d):
@@ -476,8 +480,9 @@ def calculate_cumulant_function(pulse, spectrum=None, omega=None, n_oper_identif
               \left(T_{klji} - T_{kjli} - T_{kilj} + T_{kijl}\right).
 
     Same arguments, shapes and errors as the reference.  The contraction with the four-element
-    trace tensor is evaluated on the device without forming the tensor.  ``second_order=True``
-    (frequency shifts) is not part of the accelerated path.
+    trace tensor is evaluated on the device without forming the tensor.  ``second_order=True`` adds
+    the frequency-shift terms (reference numeric.py:1139-1141, 1166-1190), evaluated as the
+    commutator with the effective Hamiltonian :math:`\sum_{kl}(\Delta_{kl}-\Delta_{lk})C_kC_l`.
     """
     if spectrum is None and omega is None:
         if decay_amplitudes is None or (frequency_shifts is None and second_order):
@@ -485,19 +490,89 @@ def calculate_cumulant_function(pulse, spectrum=None, omega=None, n_oper_identif
                              'decay amplitudes (frequency shifts)')
     if which == 'correlations' and second_order:
         raise ValueError('Cannot compute correlation cumulant function for second order terms')
-    if second_order:
-        raise NotImplementedError('Frequency shifts (second-order Magnus terms, reference '
-                                  'numeric.py:1340-1410) are outside the accelerated path.')
     if cache_intermediates is None:
         cache_intermediates = second_order
     if decay_amplitudes is None:
         decay_amplitudes = calculate_decay_amplitudes(pulse, spectrum, omega, n_oper_identifiers,
                                                       which, show_progressbar,
                                                       cache_intermediates, memory_parsimonious)
-    return _cumulant_function(decay_amplitudes, pulse.basis)
+    if second_order:
+        if frequency_shifts is None:
+            if memory_parsimonious:
+                warn('Memory parsimonious calculation not implemented for frequency shifts.')
+            frequency_shifts = calculate_frequency_shifts(pulse, spectrum, omega,
+                                                          n_oper_identifiers, show_progressbar)
+        if np.shape(frequency_shifts) != np.shape(decay_amplitudes):
+            raise ValueError('Frequency shifts not same shape as decay amplitudes')
+    return _cumulant_function(decay_amplitudes, pulse.basis,
+                              frequency_shifts if second_order else None)
 
 
-def _cumulant_function(decay_amplitudes, basis):
+def calculate_frequency_shifts(pulse, spectrum, omega, n_oper_identifiers=None,
+                               show_progressbar=False):
+    r"""Frequency shifts :math:`\Delta_{\alpha\beta,kl} = \int\frac{d\omega}{2\pi}
+    S_{\alpha\beta}(\omega) F^{(2)}_{\alpha\beta,kl}(\omega)` (reference numeric.py:1340-1410):
+    shape ``([n_nops,] n_nops, d**2, d**2)``.  The second-order filter function comes from (and is
+    cached on) *pulse*; the integral is one reduction kernel over the frequency axis."""
+    idx = util.get_indices_from_identifiers(pulse.n_oper_identifiers, n_oper_identifiers)
+    F2 = pulse.get_filter_function(omega, order=2, show_progressbar=show_progressbar)
+    return _frequency_shifts(F2, spectrum, omega, idx)
+
+
+def _frequency_shifts(filter_function_2, spectrum, omega, idx):
+    omega = as_f64(omega)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    S = as_c128(util.parse_spectrum(spectrum, omega, idx))
+    F2 = as_c128(filter_function_2)
+    if F2.ndim != 5 or F2.shape[0] != F2.shape[1] or F2.shape[2] != F2.shape[3] \
+            or F2.shape[-1] != len(omega):
+        raise ValueError(f'Expected a second-order filter function of shape (n_nops, n_nops, d**2, '
+                         f'd**2, {len(omega)}), not {F2.shape}.')
+    A, N, W = F2.shape[0], F2.shape[2], F2.shape[4]
+    n_idx = len(idx)
+    out = np.empty((n_idx, n_idx, N, N) if S.ndim == 3 else (n_idx, N, N), dtype=np.float64)
+    check(_lib.load().ffk_frequency_shifts(ptr(F2), A, N, W, ptr(S), S.ndim, ptr(omega),
+                                           idx.ctypes.data_as(ctypes.c_void_p), n_idx, ptr(out)))
+    return out
+
+
+def calculate_second_order_filter_function_from_scratch(eigvals, eigvecs, propagators, omega, basis,
+                                                        n_opers, n_coeffs, dt, intermediates=None,
+                                                        show_progressbar=False,
+                                                        cache_intermediates=False,
+                                                        cache_cumulative=False):
+    r"""Second-order filter function :math:`F^{(2)}_{\alpha\beta,kl}(\omega)`, shape
+    ``(n_nops, n_nops, d**2, d**2, n_omega)`` (reference numeric.py:1470-1699, nested integral
+    :170-256), one device pass: the segment loop, the control-matrix steps and their cumulative sums
+    live inside the kernel, so the step caches the reference recycles (*intermediates*) are not
+    needed and are ignored.  The reference's own caches of this function (``second_order_integral``
+    with ``n_dt*n_omega*d**4`` entries, ``filter_function_2_step_cumulative``) are not materialised;
+    with *cache_intermediates* the (unchanged) dict is returned alongside for signature parity."""
+    D = as_f64(eigvals)
+    V = as_c128(eigvecs)
+    Q = as_c128(propagators)
+    omega = as_f64(omega)
+    C = as_c128(np.asarray(basis))
+    B = as_c128(n_opers)
+    s = as_f64(n_coeffs)
+    dt = as_f64(dt)
+    G, d = D.shape
+    _check_d(d)
+    if cache_cumulative:
+        raise NotImplementedError('cache_cumulative: the per-segment cumulative second-order filter '
+                                  'function is not materialised by the device path.')
+    A, N, W = len(B), len(C), len(omega)
+    t = np.concatenate(([0.0], dt.cumsum()))
+    out = np.empty((A, A, N, N, W), dtype=np.complex128)
+    check(_lib.load().ffk_second_order_filter_function(
+        ptr(D), ptr(V), ptr(Q), ptr(omega), W, ptr(C), N, ptr(B), A, ptr(s), ptr(dt), ptr(t), G, d,
+        ptr(out)))
+    if cache_intermediates:
+        return out, (intermediates if intermediates is not None else dict())
+    return out
+
+
+def _cumulant_function(decay_amplitudes, basis, frequency_shifts=None):
     N, d = basis.shape[:2]
     _check_d(d)
     G = as_f64(decay_amplitudes)
@@ -513,6 +588,10 @@ def _cumulant_function(decay_amplitudes, basis):
         res = np.empty_like(part)
         check(_lib.load().ffk_cumulant_function(ptr(part), len(part), N, d, ptr(C), single_qubit,
                                                 ptr(res)))
+        if frequency_shifts is not None:
+            delta = np.ascontiguousarray(as_f64(frequency_shifts).reshape(-1, N, N)[lo:lo + step])
+            check(_lib.load().ffk_cumulant_function_second_order(ptr(delta), len(delta), N, d,
+                                                                 ptr(C), ptr(res)))
         out[lo:lo + step] = res
     return out.reshape(G.shape)
 

@@ -326,20 +326,24 @@ class PulseSequence:
     @util.parse_optional_parameters(which=('fidelity', 'generalized'), order=(1, 2))
     def get_filter_function(self, omega, which='fidelity', order=1, show_progressbar=False,
                             cache_intermediates=False, cache_second_order_cumulative=False):
-        """First-order filter function, memoised (reference pulse_sequence.py:691-805):
-        'fidelity' -> (n_nops, n_nops, n_omega); 'generalized' -> (n_nops, n_nops, d², d², n_omega)."""
-        if order != 1:
-            raise NotImplementedError('The second-order filter function is outside the '
-                                      'accelerated path (SURVEY.md section 2, row 14).')
+        """Filter function, memoised (reference pulse_sequence.py:691-805).  order=1: 'fidelity' ->
+        (n_nops, n_nops, n_omega), 'generalized' -> (n_nops, n_nops, d², d², n_omega); order=2: the
+        second-order filter function (n_nops, n_nops, d², d², n_omega), *which* ignored."""
         self.omega = omega
-        key = 'filter_function' if which == 'fidelity' else 'filter_function_gen'
+        if order == 1:
+            key = 'filter_function' if which == 'fidelity' else 'filter_function_gen'
+        else:
+            key = 'filter_function_2'
         if key in self._frequency_data:
             return self._frequency_data[key]
-        control_matrix = self.get_control_matrix(self.omega, show_progressbar,
-                                                 cache_intermediates)
+        control_matrix = None
+        if order == 1:
+            control_matrix = self.get_control_matrix(self.omega, show_progressbar,
+                                                     cache_intermediates)
         self.cache_filter_function(self.omega, control_matrix=control_matrix, which=which,
                                    order=order, show_progressbar=show_progressbar,
-                                   cache_intermediates=cache_intermediates)
+                                   cache_intermediates=cache_intermediates,
+                                   cache_second_order_cumulative=cache_second_order_cumulative)
         return self._frequency_data[key]
 
     @util.parse_optional_parameters(which=('fidelity', 'generalized'), order=(1, 2))
@@ -347,10 +351,18 @@ class PulseSequence:
                               which='fidelity', order=1, show_progressbar=False,
                               cache_intermediates=False, cache_second_order_cumulative=False):
         """Cache the filter function (reference pulse_sequence.py:807-902)."""
-        if order != 1:
-            raise NotImplementedError('The second-order filter function is outside the '
-                                      'accelerated path (SURVEY.md section 2, row 14).')
         self.omega = omega
+        if order == 2:
+            if filter_function is None:
+                filter_function = numeric.calculate_second_order_filter_function_from_scratch(
+                    self.eigvals, self.eigvecs, self.propagators, self.omega, self.basis,
+                    self.n_opers, self.n_coeffs, self.dt, self._intermediates, show_progressbar,
+                    cache_intermediates, cache_second_order_cumulative)
+                if cache_intermediates:
+                    filter_function, intermediates = filter_function
+                    self._intermediates.update(intermediates)
+            self._frequency_data['filter_function_2'] = filter_function
+            return
         if filter_function is None:
             if control_matrix is None:
                 control_matrix = self.get_control_matrix(self.omega, show_progressbar,

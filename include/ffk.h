@@ -262,6 +262,28 @@ int ffk_cumulant_function_dev(const double* decay_amplitudes, int batch, int N, 
 int ffk_cumulant_function(const double* decay_amplitudes, int batch, int N, int d,
                           const double* basis, int single_qubit, double* cumulant_function);
 
+/* ---- second order: numeric.calculate_second_order_filter_function_from_scratch
+ *      (numeric.py:1470-1699, nested integral :170-256), numeric.calculate_frequency_shifts
+ *      (:1340-1410) and the frequency-shift terms of calculate_cumulant_function (:1139-1141,
+ *      :1166-1190) ---------------------------------------------------------------------------
+ * Inputs as ffk_control_matrix.  filter_function_2 (A, A, N, N, W) c128, omega fastest.        */
+int ffk_second_order_filter_function(const double* eigvals, const double* eigvecs,
+                                     const double* propagators, const double* omega, int W,
+                                     const double* basis, int N, const double* n_opers, int A,
+                                     const double* n_coeffs, const double* dt, const double* t, int G,
+                                     int d, double* filter_function_2);
+/* Delta = int dw/2pi Re(S F2): spectrum/s_ndim/idx as in ffk_decay_amplitudes; frequency_shifts
+ * (n_idx, N, N) f64 for s_ndim 1, 2 and (n_idx, n_idx, N, N) for s_ndim 3.                      */
+int ffk_frequency_shifts(const double* filter_function_2, int A, int N, int W, const double* spectrum,
+                         int s_ndim, const double* omega, const int32_t* idx, int n_idx,
+                         double* frequency_shifts);
+/* cumulant_function (batch, N, N) f64, IN/OUT: the first-order result of ffk_cumulant_function, to
+ * which -1/2 sum_kl Delta_kl (T_klji - T_lkji - T_klij + T_lkij) is added, evaluated as the
+ * commutator -1/2 Re tr(C_i [X, C_j]), X = sum_kl (Delta_kl - Delta_lk) C_k C_l (which is also the
+ * reference's single-qubit expression -(Delta - Delta^T) on the traceless block).              */
+int ffk_cumulant_function_second_order(const double* frequency_shifts, int batch, int N, int d,
+                                       const double* basis, double* cumulant_function);
+
 /* ---- exp of the summed cumulant function (numeric.error_transfer_matrix, numeric.py:2049-2053;
  *      the reference calls scipy.linalg.expm) ---------------------------------------------------
  * matrix (N, N) f64 row-major -> result (N, N) = exp(matrix): scaling and squaring with a Taylor

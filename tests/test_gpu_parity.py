@@ -1124,3 +1124,149 @@ def test_filter_function_scratch_vs_atomic_and_getters(d, n_dt):
         Fg = total.get_filter_function(omega + shift, which='generalized')
         Ff = total.get_filter_function(omega + shift, which='fidelity')
         assert np.allclose(Ff, Fg.trace(axis1=2, axis2=3), rtol=1e-7, atol=1e-13)
+
+
+# ---- second order: F2 -> frequency shifts -> cumulant function / error transfer matrix ----------
+@pytest.mark.parametrize('name', ['q1', 'g3', 'p4', 'p4idle'])
+def test_second_order_chain_against_reference(name):
+    """Second-order filter function (incl. negative and zero frequencies, an idle segment with fully
+    degenerate eigenvalues), frequency shifts for 1-D/2-D/3-D spectra, second-order cumulant
+    function and error transfer matrix against the reference's outputs (cases of the reference's
+    tests/test_core.py:784-800, 1005-1066, tests/test_precision.py:631-727)."""
+    g = load_golden('second_order')
+    pulse = etm_pulse(g, name)
+    omega = g[f'{name}_omega']
+    F2 = pulse.get_filter_function(omega, order=2)
+    ref = g[f'{name}_filter_function_2']
+    assert F2.shape == ref.shape and F2.dtype == np.complex128 and F2.flags.c_contiguous
+    assert rel_err(F2, ref) < TOL
+    assert pulse.get_filter_function(omega, order=2) is F2           # memoised by reference
+    assert pulse.is_cached('filter_function_2')
+    # from the reference's own eigensystem, through the free function: tight
+    F2_free = numeric.calculate_second_order_filter_function_from_scratch(
+        g[f'{name}_eigvals'], g[f'{name}_eigvecs'], g[f'{name}_propagators'], omega, pulse.basis,
+        pulse.n_opers, pulse.n_coeffs, pulse.dt)
+    assert rel_err(F2_free, ref) < 1e-12
+    for i in (1, 2, 3):
+        S = g[f'{name}_S{i}']
+        delta = numeric.calculate_frequency_shifts(pulse, S, omega)
+        d_ref = g[f'{name}_frequency_shifts_S{i}']
+        assert delta.shape == d_ref.shape and delta.dtype == np.float64
+        assert rel_err(delta, d_ref) < TOL
+        K = numeric.calculate_cumulant_function(pulse, S, omega, second_order=True)
+        K_ref = g[f'{name}_cumulant_function_2_S{i}']
+        assert rel_err(K, K_ref) < TOL
+        gamma = numeric.calculate_decay_amplitudes(pulse, S, omega)
+        K_pre = numeric.calculate_cumulant_function(pulse, decay_amplitudes=gamma,
+                                                    frequency_shifts=d_ref, second_order=True)
+        assert rel_err(K_pre, K_ref) < TOL
+        U = ff.error_transfer_matrix(pulse, S, omega, second_order=True)
+        U_ref = g[f'{name}_error_transfer_matrix_2_S{i}']
+        assert np.abs(U - U_ref).max() < TOL*np.abs(U_ref - np.eye(len(U_ref))).max() + 1e-15
+    sub = numeric.calculate_frequency_shifts(pulse, g[f'{name}_S1'], omega,
+                                             n_oper_identifiers=pulse.n_oper_identifiers[1:])
+    assert rel_err(sub, g[f'{name}_frequency_shifts_S1'][1:]) < TOL
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_second_order_filter_function_random_shapes(seed):
+    """Random shapes against the oracle: output tiles of every register-tile size (A N from 4 to
+    > 64, i.e. several tiles per axis), odd frequency counts on both sides of the two-frequencies-
+    per-block switch, grids containing w = 0 and negative frequencies."""
+    rng = np.random.default_rng(7000 + seed)
+    shapes = [(2, 1, 5, 601), (2, 3, 3, 37), (3, 2, 4, 64), (4, 3, 6, 33), (5, 3, 2, 9),
+              (3, 5, 3, 513), (6, 2, 2, 5), (4, 1, 7, 1)]
+    for d, A, G, W in shapes[seed % 2::2] if seed < 4 else shapes[seed - 4::3]:
+        def herm(n):
+            M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+            return M + M.conj().transpose(0, 2, 1)
+        n_cops = int(rng.integers(1, 3))
+        c_opers, n_opers = herm(n_cops), herm(A)
+        c_coeffs = rng.standard_normal((n_cops, G))
+        n_coeffs = rng.random((A, G)) + 0.1
+        dt = rng.random(G) + 0.2
+        omega = np.sort(rng.random(W))*12 - 3.0
+        if W > 2:
+            omega[W//3] = 0.0
+        pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt,
+                                 ff.Basis.ggm(d))
+        F2 = pulse.get_filter_function(omega, order=2)
+        H = orc.hamiltonian(pulse.c_opers, pulse.c_coeffs)
+        D, V, Q = orc.diagonalize(H, dt)
+        ref = orc.second_order_filter_function(D, V, Q, omega, np.asarray(pulse.basis),
+                                               pulse.n_opers, pulse.n_coeffs, dt)
+        tag = f'd={d} A={A} G={G} W={W}'
+        assert rel_err(F2, ref) < TOL, tag
+        if W > 1:
+            S = np.tile(1/(1 + omega**2), (A, A, 1)).astype(complex)
+            delta = numeric.calculate_frequency_shifts(pulse, S, omega)
+            assert rel_err(delta, orc.frequency_shifts(ref, S, omega, np.arange(A))) < TOL, tag
+            K1 = numeric.calculate_cumulant_function(pulse, S, omega)
+            K2 = numeric.calculate_cumulant_function(pulse, S, omega, second_order=True)
+            contrib = K2 - K1
+            assert np.abs(contrib - orc.cumulant_second_order(delta, np.asarray(pulse.basis))).max() \
+                < 1e-12*max(np.abs(delta).max(), 1e-300), tag
+            # the frequency-shift terms generate a rotation: antisymmetric (reference
+            # tests/test_core.py:1057-1063)
+            assert np.abs(contrib + contrib.swapaxes(-1, -2)).max() < 1e-14*np.abs(delta).max(), tag
+
+
+def test_second_order_free_induction_decay_closed_form():
+    """Reference tests/test_precision.py:218-270: an idle qubit under white and quasistatic noise.
+    F2 of the single segment is known in closed form, splitting the segment changes nothing, and
+    the frequency shift is sigma^2 tau/2 (white) resp. sigma^2 tau^2/2 (quasistatic)."""
+    rng = np.random.default_rng(11)
+    for ix in (1, 2, 3):
+        tau = float(rng.random()) + 0.1
+        sigma = float(rng.random()) + 0.1
+        X = util.paulis[1]/np.sqrt(2)
+        B = util.paulis[ix]/np.sqrt(2)
+        piecewise = ff.PulseSequence([[X, np.zeros(21)]], [[B, np.ones(21)]], [tau/21]*21)
+        single = ff.PulseSequence([[X, np.zeros(1)]], [[B, np.ones(1)]], [tau])
+        omega = util.get_sample_frequencies(piecewise, 501, include_quasistatic=False)
+        omega = np.concatenate([-omega[::-1], [0], omega])
+        spect = np.full_like(omega, sigma**2)
+        d_pw = numeric.calculate_frequency_shifts(piecewise, spect, omega)
+        d_1 = numeric.calculate_frequency_shifts(single, spect, omega)
+        F2 = single.get_filter_function(omega, order=2)
+        mask = np.zeros_like(d_1, dtype=bool)
+        mask[0, ix, ix] = True
+        assert np.abs(d_1 - d_pw).max() < 1e-12
+        assert np.allclose(d_1[mask], sigma**2*tau/2, rtol=1e-3)
+        assert np.abs(d_1[~mask]).max() < 1e-12
+        w = omega[502:]
+        closed = (util.cexpm1(-w*tau)/(1j*w) + tau)/(1j*w)
+        assert rel_err(F2[0, 0, ix, ix, 502:], closed) < TOL
+        assert rel_err(F2[0, 0, ix, ix, 501], tau**2/2) < 1e-14
+        assert np.abs(util.integrate(F2.imag, omega)).max() < 1e-12
+        # quasistatic limit: only the w == 0 entry carries weight
+        omega = np.array([-1e-15, 0, 1e-15])/tau
+        spect = 2*np.pi*sigma**2*np.array([0, 1/omega[-1], 0])
+        d_pw = numeric.calculate_frequency_shifts(piecewise, spect, omega)
+        d_1 = numeric.calculate_frequency_shifts(single, spect, omega)
+        assert np.abs(d_1 - d_pw).max() < 1e-12
+        assert np.allclose(d_1[mask], sigma**2*tau**2/2, rtol=1e-10)
+        assert np.abs(d_1[~mask]).max() < 1e-12
+
+
+def test_second_order_error_behaviour():
+    """Argument errors of the reference (tests/test_core.py:1019-1046)."""
+    g = load_golden('second_order')
+    pulse = etm_pulse(g, 'q1')
+    omega, S = g['q1_omega'], g['q1_S1']
+    gamma = numeric.calculate_decay_amplitudes(pulse, S, omega)
+    with pytest.raises(ValueError):
+        numeric.calculate_cumulant_function(pulse, None, None, frequency_shifts=None,
+                                            second_order=True)
+    with pytest.raises(ValueError):
+        numeric.calculate_cumulant_function(pulse, S, omega, second_order=True, which='correlations')
+    with pytest.raises(ValueError):
+        numeric.calculate_cumulant_function(pulse, S, omega, second_order=True,
+                                            decay_amplitudes=gamma[1:])
+    with pytest.warns(UserWarning):
+        numeric.calculate_cumulant_function(pulse, S, omega, second_order=True,
+                                            memory_parsimonious=True)
+    with pytest.raises(ValueError):
+        pulse.get_filter_function(omega, order=3)
+    with pytest.raises(ValueError):
+        numeric.calculate_frequency_shifts(pulse, S[:-1], omega)
