@@ -128,15 +128,22 @@ __global__ __launch_bounds__(256) void so_accumulate_kernel(
             special |= sp;
             spec[q] = sp;
             u[q] = sp ? 0.0 : 1.0/b;
-            cplx lim = {0.5*dtg*dtg, 0.0};
-            if (a != 0.0) {
-                const cplx ph = cexp(a*dtg);
-                const double ra = 1.0/a;
-                lim = {(fa.re + dtg*ph.im)*ra, (fa.im - dtg*ph.re)*ra};   // (f(a) - i dt e^{i a dt})/a
-            }
-            Isp[q] = lim;
         }
         const int any_special = __syncthreads_or(special);
+        if (any_special) {      // rare: the limit integrals of the entries with w + W_mn == 0
+            for (int q = tid; q < WT*d2; q += 256) {
+                const int wi = q / d2, e = q % d2;
+                const double a = -omega[min(w0 + wi, W - 1)] + (D[e / d] - D[e % d]);
+                cplx lim = {0.5*dtg*dtg, 0.0};
+                if (a != 0.0) {
+                    const cplx fa = frc1[q], ph = cexp(a*dtg);
+                    const double ra = 1.0/a;
+                    lim = {(fa.re + dtg*ph.im)*ra, (fa.im - dtg*ph.re)*ra};   // (f(a) - i dt e^{i a dt})/a
+                }
+                Isp[q] = lim;
+            }
+            __syncthreads();
+        }
         // (2) per-row contractions with the d^2 scalars: P, Xsp, G^(g) for the A rows; G^(g) for the
         // B rows
         if (tid < WT*2*T) {

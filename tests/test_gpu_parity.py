@@ -1270,3 +1270,30 @@ def test_second_order_error_behaviour():
         pulse.get_filter_function(omega, order=3)
     with pytest.raises(ValueError):
         numeric.calculate_frequency_shifts(pulse, S[:-1], omega)
+
+
+def test_second_order_config2_size_against_oracle_subsample():
+    """BASELINE config-2 shape (d=4, 256 segments, 3 noise operators, 4096 frequencies; F2 is 151 MB).
+    Every frequency is independent, so the oracle on a 16-frequency subsample pins the full-size
+    run; the frequency shifts are compared through the oracle's integration of the device F2 and
+    through the antisymmetry of their cumulant contribution."""
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs()
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt,
+                             ff.Basis.pauli(2))
+    basis = np.asarray(pulse.basis)
+    F2 = pulse.get_filter_function(omega, order=2)
+    assert F2.shape == (3, 3, 16, 16, 4096)
+    sel = np.linspace(0, len(omega) - 1, 16).astype(int)
+    H = orc.hamiltonian(pulse.c_opers, pulse.c_coeffs)
+    D, V, Q = orc.diagonalize(H, dt)
+    ref = orc.second_order_filter_function(D, V, Q, omega[sel], basis, pulse.n_opers,
+                                           pulse.n_coeffs, dt)
+    assert rel_err(F2[..., sel], ref) < TOL
+    S = 1e-3/omega
+    delta = numeric.calculate_frequency_shifts(pulse, S, omega)
+    assert rel_err(delta, orc.frequency_shifts(F2, S, omega, np.arange(3))) < 1e-12
+    K1 = numeric.calculate_cumulant_function(pulse, S, omega)
+    K2 = numeric.calculate_cumulant_function(pulse, S, omega, second_order=True)
+    contrib = K2 - K1
+    assert np.abs(contrib).max() > 0
+    assert np.abs(contrib + contrib.swapaxes(-1, -2)).max() < 1e-13*np.abs(delta).max()
