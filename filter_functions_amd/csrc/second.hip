@@ -23,6 +23,8 @@
 // loop runs inside the block, accumulators stay in registers, operands are staged through LDS in
 // [mn][row] layout (the row index is the fast one: a wave reads 16 distinct NB rows and broadcasts
 // its 4 X rows).
+#include <cstdlib>
+
 #include "ffk_internal.h"
 
 namespace ffk {
@@ -254,6 +256,246 @@ __global__ __launch_bounds__(256) void so_accumulate_kernel(
     }
 }
 
+// ---- the same pass on the matrix cores -----------------------------------------------------------
+// One wavefront owns a (16 MT) x (16 NT) complex tile of the (A N) x (A N) output of ONE frequency
+// as MT NT 2 accumulator tiles of v_mfma_f64_16x16x4 (operand maps: A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15], D[row = (lane>>4) + 4 r][col = lane&15]).  Per segment the second
+// contraction is the complex product X (16 MT x d^2) . NB^T (d^2 x 16 NT): four real MFMA chains
+// over ceil(d^2/4) k-steps, with the X operand formed in registers, X = u (P - M), directly in the
+// A-operand layout.  The complete-interval term conj(G_A) x Gcum_B is a rank-one update: two more
+// MFMAs per tile whose k = 0, 1 slots carry (re, im) and k = 2, 3 are zero.  The four wavefronts of
+// a block take four consecutive frequencies and share the LDS copy of the segment's NB and M rows.
+// (Splitting the tile over wavefronts instead -- 16-row strips, 48 accumulator registers, more
+// wavefronts per SIMD -- was measured 2x slower: the per-segment scalar work does not shrink with
+// the tile.)
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256, 2) void so_mfma_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ eigvals,
+    const double* __restrict__ dt, const double* __restrict__ t, const cplx* __restrict__ NB,
+    const cplx* __restrict__ M, int G, int d, int A, int N, cplx* __restrict__ F2) {
+    constexpr int RA = 16*MT, RB = 16*NT;
+    const int d2 = d*d, d2s = d2 + 1, AN = A*N, KS = (d2 + 3)/4;
+    extern __shared__ unsigned char smem[];
+    cplx* NBa = reinterpret_cast<cplx*>(smem);      // [RA][d2s]
+    cplx* Ma = NBa + RA*d2s;                        // [RA][d2s]
+    cplx* NBb = Ma + RA*d2s;                        // [RB][d2s]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int per_wave = 4*d2 + 3*RA + 2*RB;
+    cplx* frc1 = NBb + RB*d2s + wave*per_wave;      // [d2]
+    cplx* I1 = frc1 + d2;                           // [d2]
+    cplx* Isp = I1 + d2;                            // [d2]
+    cplx* P = Isp + d2;                             // [RA]
+    cplx* Xsp = P + RA;                             // [RA]
+    cplx* GsA = Xsp + RA;                           // [RA]
+    cplx* GsB = GsA + RA;                           // [RB]
+    cplx* Gcum = GsB + RB;                          // [RB]
+    double* us = reinterpret_cast<double*>(Gcum + RB);   // [d2]  1/(w + W_mn); 0 where that is singular
+    int* spec = reinterpret_cast<int*>(us + d2);         // [d2]  ... and the flag for it
+
+    const int w = blockIdx.x*4 + wave;
+    const double om = omega[min(w, W - 1)];
+    const int rowA0 = blockIdx.y*RA, rowB0 = blockIdx.z*RB;
+    // on a diagonal tile the B rows are the A rows: G_B = G_A
+    const bool diag = rowA0 == rowB0 && RA == RB;
+
+    f64x4 cre[MT][NT], cim[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            cre[mt][nt] = {0.0, 0.0, 0.0, 0.0};
+            cim[mt][nt] = {0.0, 0.0, 0.0, 0.0};
+        }
+    for (int q = lane; q < RB; q += 64) Gcum[q] = {0.0, 0.0};
+
+    for (int g = 0; g < G; ++g) {
+        const double dtg = dt[g], tg = t[g];
+        const double* D = eigvals + static_cast<size_t>(g)*d;
+        __syncthreads();                            // the previous segment's operands are consumed
+        for (int q = tid; q < RA*d2; q += 256) {
+            const int r = q / d2, e = q % d2;
+            cplx nb = {0.0, 0.0}, m = {0.0, 0.0};
+            if (rowA0 + r < AN) {
+                const size_t o = (static_cast<size_t>(g)*AN + rowA0 + r)*d2 + e;
+                nb = NB[o];
+                m = M[o];
+            }
+            NBa[r*d2s + e] = nb;
+            Ma[r*d2s + e] = m;
+        }
+        for (int q = tid; q < RB*d2; q += 256) {
+            const int r = q / d2, e = q % d2;
+            cplx nb = {0.0, 0.0};
+            if (rowB0 + r < AN) nb = NB[(static_cast<size_t>(g)*AN + rowB0 + r)*d2 + e];
+            NBb[r*d2s + e] = nb;
+        }
+        // (1) this wavefront's frequency-dependent scalars
+        bool special = false;
+        for (int e = lane; e < d2; e += 64) {
+            const double dE = D[e / d] - D[e % d];
+            const double a = -om + dE, b = om + dE;
+            const cplx fa = frac(a, dtg), fb = frac(b, dtg);
+            frc1[e] = fa;
+            I1[e] = cmul(cexp(om*tg), cplx{fb.im, -fb.re});      // e^{i w t_g} (-i f(b))
+            const bool sp = b == 0.0;
+            special |= sp;
+            spec[e] = sp;
+            us[e] = sp ? 0.0 : rcp(b);
+        }
+        const bool any_special = __ballot(special) != 0ull;
+        if (any_special) {      // rare: the limit integrals of the entries with w + W_mn == 0
+            for (int e = lane; e < d2; e += 64) {
+                const double a = -om + (D[e / d] - D[e % d]);
+                cplx lim = {0.5*dtg*dtg, 0.0};
+                if (a != 0.0) {
+                    const cplx fa = frac(a, dtg), ph = cexp(a*dtg);
+                    const double ra = 1.0/a;
+                    lim = {(fa.re + dtg*ph.im)*ra, (fa.im - dtg*ph.re)*ra};
+                }
+                Isp[e] = lim;
+            }
+        }
+        __syncthreads();
+        // (2) row contractions with the d^2 scalars
+        for (int job = lane; job < (diag ? RA : RA + RB); job += 64) {
+            const bool side = job >= RA;
+            const int r = side ? job - RA : job;
+            const cplx* nb = (side ? NBb : NBa) + r*d2s;
+            cplx p = {0.0, 0.0}, gs = {0.0, 0.0}, xs = {0.0, 0.0};
+            for (int e = 0; e < d2; ++e) {
+                const cplx v = nb[e];
+                cmac(gs, v, I1[e]);
+                if (!side) {
+                    cmac(p, v, frc1[e]);
+                    if (any_special) cmac(xs, v, Isp[e]);
+                }
+            }
+            if (side) {
+                GsB[r] = gs;
+            } else {
+                GsA[r] = gs;
+                if (diag) GsB[r] = gs;
+                P[r] = p;
+                Xsp[r] = xs;
+            }
+        }
+        wave_sync();
+        // (3) complete intervals: conj(G_A) x Gcum_B as a rank-one MFMA update
+        if (g > 0) {
+            double b1[NT], b2[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const cplx gc = Gcum[nt*16 + li];
+                b1[nt] = lk == 0 ? gc.re : (lk == 1 ? gc.im : 0.0);
+                b2[nt] = lk == 0 ? gc.im : (lk == 1 ? gc.re : 0.0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const cplx ga = GsA[mt*16 + li];
+                const double a1 = lk == 0 ? ga.re : (lk == 1 ? ga.im : 0.0);
+                const double a2 = lk == 0 ? ga.re : (lk == 1 ? -ga.im : 0.0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[nt], cre[mt][nt], 0, 0, 0);
+                    cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2[nt], cim[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        wave_sync();
+        for (int q = lane; q < RB; q += 64) {
+            Gcum[q].re += GsB[q].re;
+            Gcum[q].im += GsB[q].im;
+        }
+        // (4) incomplete interval: X . NB^T over the k-steps
+        cplx p[MT], xsp[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            p[mt] = P[mt*16 + li];
+            xsp[mt] = Xsp[mt*16 + li];
+        }
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ++ks) {
+            const int mn = ks*4 + lk;
+            const bool valid = mn < d2;
+            const int e = valid ? mn : 0;
+            const bool sp = valid && spec[e];
+            const double u = valid ? us[e] : 0.0;
+            double bre[NT], bim[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const cplx v = NBb[(nt*16 + li)*d2s + e];
+                bre[nt] = valid ? v.re : 0.0;
+                bim[nt] = valid ? v.im : 0.0;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const cplx m = Ma[(mt*16 + li)*d2s + e];
+                double xre = u*(p[mt].re - m.re), xim = u*(p[mt].im - m.im);
+                if (sp) {
+                    xre = xsp[mt].re;
+                    xim = xsp[mt].im;
+                }
+                const double nxim = -xim;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xre, bre[nt], cre[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xre, bim[nt], cim[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cre[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(nxim, bim[nt], cre[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    cim[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(xim, bre[nt], cim[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    if (w >= W) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ra = rowA0 + mt*16 + lk + 4*r, rb = rowB0 + nt*16 + li;
+                if (ra >= AN || rb >= AN) continue;
+                const int a = ra / N, k = ra % N, b = rb / N, l = rb % N;
+                F2[(((static_cast<size_t>(a)*A + b)*N + k)*N + l)*W + w] = {cre[mt][nt][r], cim[mt][nt][r]};
+            }
+}
+
+size_t so_mfma_lds_bytes(int mt, int nt, int d2) {
+    const size_t ra = 16*mt, rb = 16*nt;
+    return sizeof(cplx)*((2*ra + rb)*(d2 + 1) + 4*(4*size_t(d2) + 3*ra + 2*rb));
+}
+
+template <int MT, int NT>
+hipError_t launch_so_mfma(const double* omega, int W, const double* eigvals, const double* dt,
+                          const double* t, const cplx* NB, const cplx* M, int G, int d, int A, int N,
+                          cplx* F2, hipStream_t stream) {
+    const int AN = A*N;
+    const size_t lds = so_mfma_lds_bytes(MT, NT, d*d);
+    auto kern = so_mfma_kernel<MT, NT>;
+    if (lds > 48*1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    const dim3 grid((W + 3)/4, (AN + 16*MT - 1)/(16*MT), (AN + 16*NT - 1)/(16*NT));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, omega, W, eigvals, dt, t, NB, M, G, d, A,
+                       N, F2);
+    return hipGetLastError();
+}
+
 size_t so_lds_bytes(int rt, int wt, int mc, int d2) {
     const size_t T = 16*rt, Tp = T + 1;
     return sizeof(cplx)*((wt + 1)*mc*Tp + 3*size_t(wt)*d2 + 5*size_t(wt)*T) +
@@ -398,6 +640,19 @@ hipError_t launch_second_order_filter_function(const double* omega, int W, const
                        stream, nt, bt, eigvals, dt, G, A, N, d, NB, M);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return err;
+    // matrix-core kernel: the largest square wave tile (<= 48 x 48) whose operands fit in LDS twice
+    // per CU; FFK_TUNE_SO_MFMA=0 forces the vector kernel (cross-check in tests/)
+    bool use_mfma = true;
+    if (const char* e = getenv("FFK_TUNE_SO_MFMA")) use_mfma = atoi(e) != 0;
+    if (use_mfma) {
+        const int tiles16 = (AN + 15)/16;
+        for (int mt = min(3, tiles16); mt >= 1; --mt) {
+            if (so_mfma_lds_bytes(mt, mt, d2) > 78*1024) continue;
+            if (mt == 3) return launch_so_mfma<3, 3>(omega, W, eigvals, dt, t, NB, M, G, d, A, N, F2, stream);
+            if (mt == 2) return launch_so_mfma<2, 2>(omega, W, eigvals, dt, t, NB, M, G, d, A, N, F2, stream);
+            return launch_so_mfma<1, 1>(omega, W, eigvals, dt, t, NB, M, G, d, A, N, F2, stream);
+        }
+    }
     const int rt = min(4, (AN + 15)/16);
     const int wt = W >= 512 ? 2 : 1;
     const int mc = min(d2, 16);

@@ -1175,7 +1175,7 @@ def test_second_order_filter_function_random_shapes(seed):
     per-block switch, grids containing w = 0 and negative frequencies."""
     rng = np.random.default_rng(7000 + seed)
     shapes = [(2, 1, 5, 601), (2, 3, 3, 37), (3, 2, 4, 64), (4, 3, 6, 33), (5, 3, 2, 9),
-              (3, 5, 3, 513), (6, 2, 2, 5), (4, 1, 7, 1)]
+              (3, 5, 3, 513), (6, 2, 2, 5), (4, 1, 7, 1), (9, 1, 2, 3), (8, 2, 2, 6)]
     for d, A, G, W in shapes[seed % 2::2] if seed < 4 else shapes[seed - 4::3]:
         def herm(n):
             M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
@@ -1209,6 +1209,31 @@ def test_second_order_filter_function_random_shapes(seed):
             # the frequency-shift terms generate a rotation: antisymmetric (reference
             # tests/test_core.py:1057-1063)
             assert np.abs(contrib + contrib.swapaxes(-1, -2)).max() < 1e-14*np.abs(delta).max(), tag
+
+
+def test_second_order_matrix_core_kernel_matches_vector_kernel(monkeypatch):
+    """The MFMA kernel (default where its operands fit in LDS) against the register-tiled vector
+    kernel on the same inputs; both are compared with the oracle elsewhere."""
+    rng = np.random.default_rng(99)
+    for d, A, G, W in [(4, 3, 9, 130), (2, 1, 4, 7), (3, 4, 5, 33), (5, 2, 3, 18), (8, 1, 2, 9)]:
+        def herm(n):
+            M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+            return M + M.conj().transpose(0, 2, 1)
+        c_opers, n_opers = herm(2), herm(A)
+        dt = rng.random(G) + 0.2
+        omega = np.sort(rng.random(W))*12 - 3.0
+        omega[W//2] = 0.0
+        pulse = ff.PulseSequence(list(zip(c_opers, rng.standard_normal((2, G)))),
+                                 list(zip(n_opers, rng.random((A, G)) + 0.1)), dt, ff.Basis.ggm(d))
+        pulse.diagonalize()
+        args = (pulse.eigvals, pulse.eigvecs, pulse.propagators, omega, pulse.basis, pulse.n_opers,
+                pulse.n_coeffs, pulse.dt)
+        monkeypatch.setenv('FFK_TUNE_SO_MFMA', '1')
+        F_mfma = numeric.calculate_second_order_filter_function_from_scratch(*args)
+        monkeypatch.setenv('FFK_TUNE_SO_MFMA', '0')
+        F_vec = numeric.calculate_second_order_filter_function_from_scratch(*args)
+        monkeypatch.delenv('FFK_TUNE_SO_MFMA')
+        assert rel_err(F_mfma, F_vec) < 1e-12, f'd={d} A={A} G={G} W={W}'
 
 
 def test_second_order_free_induction_decay_closed_form():
