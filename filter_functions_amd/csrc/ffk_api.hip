@@ -1036,16 +1036,30 @@ int ffk_cumulant_function(const double* decay_amplitudes, int batch, int N, int 
 // ---------------------------------------------------------------------------------------------
 // second order: filter function, frequency shifts, cumulant-function contribution
 // ---------------------------------------------------------------------------------------------
-int ffk_second_order_filter_function(const double* eigvals, const double* eigvecs,
-                                     const double* propagators, const double* omega, int W,
-                                     const double* basis, int N, const double* n_opers, int A,
-                                     const double* n_coeffs, const double* dt, const double* t, int G,
-                                     int d, double* filter_function_2) {
+static int second_order_impl(const double* eigvals, const double* eigvecs,
+                             const double* propagators, const double* omega, int W,
+                             const double* basis, int N, const double* n_opers, int A,
+                             const double* n_coeffs, const double* dt, const double* t, int G, int d,
+                             double* filter_function_2, const double* spectrum, int s_ndim,
+                             const int32_t* idx, int n_idx, double* frequency_shifts) {
     FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
-    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && basis && n_opers && n_coeffs && dt && t &&
-                    filter_function_2, "NULL argument");
+    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && basis && n_opers && n_coeffs && dt && t,
+                "NULL argument");
+    FFK_REQUIRE(filter_function_2 || frequency_shifts, "no output requested");
     FFK_REQUIRE(size_t(A)*N <= 65535, "A*N = %zu too large", size_t(A)*N);
+    size_t nS = 0, nout = 0;
+    int srows = 0;
+    if (frequency_shifts) {
+        FFK_REQUIRE(spectrum && idx, "NULL argument");
+        FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
+        FFK_REQUIRE(n_idx >= 1, "empty axis");
+        for (int i = 0; i < n_idx; ++i)
+            FFK_REQUIRE(idx[i] >= 0 && idx[i] < A, "noise operator index %d out of range [0, %d)", idx[i], A);
+        srows = s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : n_idx*n_idx);
+        nS = 16*size_t(W)*srows;
+        nout = size_t(n_idx)*(s_ndim == 3 ? n_idx : 1)*N*N;
+    }
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t dd = size_t(d)*d;
     const size_t nF = size_t(A)*A*N*N*W;
@@ -1058,6 +1072,7 @@ int ffk_second_order_filter_function(const double* eigvals, const double* eigvec
              align_up(16*size_t(G)*(1 + A)*dd);
     total += align_up(16*size_t(A)*G*dd) + align_up(16*size_t(G)*dd) + align_up(16*size_t(G)*N*dd);
     total += wsb + align_up(16*nF);
+    total += 2*align_up(nS) + align_up(4*size_t(n_idx > 0 ? n_idx : 1)) + align_up(8*nout);
     void* base;
     if (int rc = arena_reserve(total, &base)) return rc;
     Bump a(base, g_arena.size);
@@ -1078,7 +1093,12 @@ int ffk_second_order_filter_function(const double* eigvals, const double* eigvec
     cplx* dbt = a.take<cplx>(size_t(G)*N*dd);
     void* ws = a.take<unsigned char>(wsb);
     cplx* dF = a.take<cplx>(nF);
-    FFK_REQUIRE(dF && a.used <= g_arena.size, "internal: arena too small");
+    cplx* dS = frequency_shifts ? a.take<cplx>(nS/16) : nullptr;
+    cplx* dscale = frequency_shifts ? a.take<cplx>(nS/16) : nullptr;
+    int32_t* didx = frequency_shifts ? a.take<int32_t>(n_idx) : nullptr;
+    double* dout = frequency_shifts ? a.take<double>(nout) : nullptr;
+    FFK_REQUIRE(dF && (!frequency_shifts || dout) && a.used <= g_arena.size,
+                "internal: arena too small");
     auto h2d = [](void* dst, const void* src, size_t n) {
         return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, nullptr);
     };
@@ -1095,9 +1115,38 @@ int ffk_second_order_filter_function(const double* eigvals, const double* eigvec
     FFK_HIP(ffk::launch_basis_transformed(Tc, dbasis, G, N, d, dbt, nullptr));
     FFK_HIP(ffk::launch_second_order_filter_function(dom, W, dD, ddt, dtt, dnt, dbt, G, d, A, N, dF, ws,
                                                      nullptr));
-    FFK_HIP(hipMemcpyAsync(filter_function_2, dF, 16*nF, hipMemcpyDeviceToHost, nullptr));
+    if (frequency_shifts) {
+        FFK_HIP(h2d(dS, spectrum, nS));
+        FFK_HIP(h2d(didx, idx, 4*size_t(n_idx)));
+        FFK_HIP(ffk::launch_spectral_weights(dS, srows, W, dom, W, 0, dscale, nullptr));
+        FFK_HIP(ffk::launch_frequency_shifts(dF, A, N, W, dscale, s_ndim, didx, n_idx, dout, nullptr));
+        FFK_HIP(hipMemcpyAsync(frequency_shifts, dout, 8*nout, hipMemcpyDeviceToHost, nullptr));
+    }
+    if (filter_function_2)
+        FFK_HIP(hipMemcpyAsync(filter_function_2, dF, 16*nF, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipStreamSynchronize(nullptr));
     return FFK_OK;
+}
+
+int ffk_second_order_filter_function(const double* eigvals, const double* eigvecs,
+                                     const double* propagators, const double* omega, int W,
+                                     const double* basis, int N, const double* n_opers, int A,
+                                     const double* n_coeffs, const double* dt, const double* t, int G,
+                                     int d, double* filter_function_2) {
+    FFK_REQUIRE(filter_function_2, "NULL argument");
+    return second_order_impl(eigvals, eigvecs, propagators, omega, W, basis, N, n_opers, A, n_coeffs, dt,
+                             t, G, d, filter_function_2, nullptr, 0, nullptr, 0, nullptr);
+}
+
+int ffk_frequency_shifts_from_scratch(const double* eigvals, const double* eigvecs,
+                                      const double* propagators, const double* omega, int W,
+                                      const double* basis, int N, const double* n_opers, int A,
+                                      const double* n_coeffs, const double* dt, const double* t, int G,
+                                      int d, const double* spectrum, int s_ndim, const int32_t* idx,
+                                      int n_idx, double* filter_function_2, double* frequency_shifts) {
+    FFK_REQUIRE(frequency_shifts, "NULL argument");
+    return second_order_impl(eigvals, eigvecs, propagators, omega, W, basis, N, n_opers, A, n_coeffs, dt,
+                             t, G, d, filter_function_2, spectrum, s_ndim, idx, n_idx, frequency_shifts);
 }
 
 int ffk_frequency_shifts(const double* filter_function_2, int A, int N, int W, const double* spectrum,

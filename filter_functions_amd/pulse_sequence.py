@@ -620,8 +620,10 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     caches the pulse correlation filter function.
     """
     if calc_second_order_FF:
-        raise NotImplementedError('The second-order filter function is outside the accelerated '
-                                  'path (SURVEY.md section 2, row 14).')
+        raise NotImplementedError('Concatenating second-order filter functions (reference '
+                                  'numeric.py:1702-1818) needs the d^4-sized per-segment integral '
+                                  'caches, which the device path does not materialise; compute '
+                                  'get_filter_function(omega, order=2) on the concatenated pulse.')
     newpulse, _, n_map = concatenate_without_filter_function(pulses, return_identifier_mappings=True)
     pulses = tuple(pulses)
     if all(pls.is_cached('total_propagator') for pls in pulses):

@@ -277,6 +277,14 @@ int ffk_second_order_filter_function(const double* eigvals, const double* eigvec
 int ffk_frequency_shifts(const double* filter_function_2, int A, int N, int W, const double* spectrum,
                          int s_ndim, const double* omega, const int32_t* idx, int n_idx,
                          double* frequency_shifts);
+/* Both in one device-resident pass (F2 never crosses PCIe unless filter_function_2 != NULL, in
+ * which case it is returned as well, for the caller's cache).                                   */
+int ffk_frequency_shifts_from_scratch(const double* eigvals, const double* eigvecs,
+                                      const double* propagators, const double* omega, int W,
+                                      const double* basis, int N, const double* n_opers, int A,
+                                      const double* n_coeffs, const double* dt, const double* t, int G,
+                                      int d, const double* spectrum, int s_ndim, const int32_t* idx,
+                                      int n_idx, double* filter_function_2, double* frequency_shifts);
 /* cumulant_function (batch, N, N) f64, IN/OUT: the first-order result of ffk_cumulant_function, to
  * which -1/2 sum_kl Delta_kl (T_klji - T_lkji - T_klij + T_lkij) is added, evaluated as the
  * commutator -1/2 Re tr(C_i [X, C_j]), X = sum_kl (Delta_kl - Delta_lk) C_k C_l (which is also the

@@ -668,8 +668,11 @@ def test_cumulant_and_etm_error_behaviour():
     with pytest.raises(ValueError):
         numeric.calculate_cumulant_function(pulse, g['p4_S1'], omega, which='correlations',
                                             second_order=True)
+    with pytest.raises(ValueError):       # precomputed decay amplitudes of another shape
+        numeric.calculate_cumulant_function(pulse, g['p4_S1'], omega, second_order=True,
+                                            decay_amplitudes=np.ones((1, 16, 16)))
     with pytest.raises(NotImplementedError):
-        numeric.calculate_cumulant_function(pulse, g['p4_S1'], omega, second_order=True)
+        ff.concatenate([pulse, pulse], calc_second_order_FF=True)
     with pytest.raises(ValueError):
         ff.error_transfer_matrix(pulse)
     with pytest.raises(TypeError):
@@ -1166,6 +1169,16 @@ def test_second_order_chain_against_reference(name):
     sub = numeric.calculate_frequency_shifts(pulse, g[f'{name}_S1'], omega,
                                              n_oper_identifiers=pulse.n_oper_identifiers[1:])
     assert rel_err(sub, g[f'{name}_frequency_shifts_S1'][1:]) < TOL
+    # a pulse without a cached F2 takes the fused device pass, which also fills the cache
+    fresh = etm_pulse(g, name)
+    for i in (3, 1):
+        delta = numeric.calculate_frequency_shifts(fresh, g[f'{name}_S{i}'], omega)
+        assert rel_err(delta, g[f'{name}_frequency_shifts_S{i}']) < TOL
+        assert fresh.is_cached('filter_function_2')
+        assert rel_err(fresh.get_filter_function(omega, order=2), ref) < TOL
+    sub = numeric.calculate_frequency_shifts(etm_pulse(g, name), g[f'{name}_S2'][1:], omega,
+                                             n_oper_identifiers=pulse.n_oper_identifiers[1:])
+    assert rel_err(sub, g[f'{name}_frequency_shifts_S2'][1:]) < TOL
 
 
 @pytest.mark.parametrize('seed', range(6))
