@@ -137,6 +137,18 @@ SIGNATURES = {
                                      c_void_p, c_int, c_void_p]),
     'ffk_cumulant_function_second_order': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p,
                                                    c_void_p]),
+    'ffk_second_order_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'ffk_second_order_filter_function_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                     c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                                     c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                                     c_void_p, c_size_t, c_void_p]),
+    'ffk_frequency_shifts_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'ffk_frequency_shifts_shard_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int,
+                                               c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                               c_void_p, c_size_t, c_void_p]),
+    'ffk_cumulant_function_second_order_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'ffk_cumulant_function_second_order_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p,
+                                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     'ffk_expm_real': (c_int, [c_void_p, c_int, c_void_p]),
     'ffk_liouville': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'ffk_liouville_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

@@ -1212,6 +1212,98 @@ int ffk_cumulant_function_second_order(const double* frequency_shifts, int batch
     return FFK_OK;
 }
 
+size_t ffk_second_order_workspace_bytes(int W, int N, int A, int G, int d) {
+    if (W < 1 || N < 1 || A < 1 || G < 1 || !d_ok(d)) return 0;
+    const size_t dd = size_t(d)*d;
+    size_t b = 0;
+    b += align_up(8*size_t(G)*ffk::seg_stride(d)) + align_up(16*size_t(G)*dd);        // segtab, Tc
+    b += align_up(16*size_t(G)*(1 + A)*dd);                                           // ops
+    b += align_up(16*size_t(A)*G*dd) + align_up(16*size_t(G)*dd);                     // nt, ep
+    b += align_up(16*size_t(G)*N*dd);                                                 // bt
+    b += ffk::second_order_workspace_bytes(G, A, N, d);                               // NB, M
+    return b;
+}
+
+int ffk_second_order_filter_function_dev(const double* eigvals, const double* eigvecs,
+                                         const double* propagators, const double* omega, int W,
+                                         const double* basis, int N, const double* n_opers, int A,
+                                         const double* n_coeffs, const double* dt, const double* t,
+                                         int G, int d, double* filter_function_2, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
+    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && basis && n_opers && n_coeffs && dt && t &&
+                    filter_function_2 && workspace, "NULL argument");
+    FFK_REQUIRE(size_t(A)*N <= 65535, "A*N = %zu too large", size_t(A)*N);
+    FFK_REQUIRE(workspace_bytes >= ffk_second_order_workspace_bytes(W, N, A, G, d), "workspace too small");
+    const size_t dd = size_t(d)*d;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Bump a(workspace, workspace_bytes);
+    double* segtab = a.take<double>(size_t(G)*ffk::seg_stride(d));
+    cplx* Tc = a.take<cplx>(size_t(G)*dd);
+    cplx* ops = a.take<cplx>(size_t(G)*(1 + A)*dd);
+    cplx* dnt = a.take<cplx>(size_t(A)*G*dd);
+    cplx* dep = a.take<cplx>(size_t(G)*dd);
+    cplx* dbt = a.take<cplx>(size_t(G)*N*dd);
+    void* ws = a.take<unsigned char>(ffk::second_order_workspace_bytes(G, A, N, d));
+    FFK_REQUIRE(ws, "internal: workspace too small");
+    FFK_HIP(ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
+                                 reinterpret_cast<const cplx*>(propagators),
+                                 reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G, d, A, segtab,
+                                 Tc, ops, dnt, dep, st));
+    FFK_HIP(ffk::launch_basis_transformed(Tc, reinterpret_cast<const cplx*>(basis), G, N, d, dbt, st));
+    FFK_HIP(ffk::launch_second_order_filter_function(omega, W, eigvals, dt, t, dnt, dbt, G, d, A, N,
+                                                     reinterpret_cast<cplx*>(filter_function_2), ws, st));
+    return FFK_OK;
+}
+
+size_t ffk_frequency_shifts_workspace_bytes(int W, int n_idx, int s_ndim) {
+    if (W < 1 || n_idx < 1 || s_ndim < 1 || s_ndim > 3) return 0;
+    return align_up(16*size_t(W)*(s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : size_t(n_idx)*n_idx)));
+}
+
+int ffk_frequency_shifts_shard_dev(const double* filter_function_2, int A, int N, int W_block,
+                                   const double* spectrum, int s_ndim, const double* omega, int W,
+                                   int w_offset, const int32_t* idx, int n_idx,
+                                   double* frequency_shifts, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    FFK_REQUIRE(filter_function_2 && spectrum && omega && idx && frequency_shifts && workspace,
+                "NULL argument");
+    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
+    FFK_REQUIRE(A >= 1 && N >= 1 && W_block >= 1 && n_idx >= 1, "empty axis");
+    FFK_REQUIRE(w_offset >= 0 && w_offset + W_block <= W, "frequency block [%d, %d) outside [0, %d)",
+                w_offset, w_offset + W_block, W);
+    FFK_REQUIRE(workspace_bytes >= ffk_frequency_shifts_workspace_bytes(W_block, n_idx, s_ndim),
+                "workspace too small");
+    const int rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : n_idx*n_idx);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    cplx* scale = static_cast<cplx*>(workspace);
+    FFK_HIP(ffk::launch_spectral_weights(reinterpret_cast<const cplx*>(spectrum), rows, W_block, omega, W,
+                                         w_offset, scale, st));
+    FFK_HIP(ffk::launch_frequency_shifts(reinterpret_cast<const cplx*>(filter_function_2), A, N, W_block,
+                                         scale, s_ndim, idx, n_idx, frequency_shifts, st));
+    return FFK_OK;
+}
+
+size_t ffk_cumulant_function_second_order_workspace_bytes(int batch, int N, int d) {
+    if (batch < 1 || N < 1 || !d_ok(d)) return 0;
+    return align_up(ffk::cumulant_second_order_workspace_bytes(batch, N, d));
+}
+
+int ffk_cumulant_function_second_order_dev(const double* frequency_shifts, int batch, int N, int d,
+                                           const double* basis, double* cumulant_function,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(frequency_shifts && basis && cumulant_function && workspace, "NULL argument");
+    FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis");
+    FFK_REQUIRE(d_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D);
+    FFK_REQUIRE(workspace_bytes >= ffk_cumulant_function_second_order_workspace_bytes(batch, N, d),
+                "workspace too small");
+    FFK_HIP(ffk::launch_cumulant_second_order(frequency_shifts, batch, N, d,
+                                              reinterpret_cast<const cplx*>(basis), cumulant_function,
+                                              workspace, static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
 int ffk_expm_real(const double* matrix, int N, double* result) {
     FFK_REQUIRE(matrix && result, "NULL argument");
     FFK_REQUIRE(N >= 1 && N <= 4096, "matrix dimension %d outside [1, 4096]", N);

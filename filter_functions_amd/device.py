@@ -154,3 +154,64 @@ class DevicePipeline:
                                             int(single_qubit), p(out), p(self._cws), need,
                                             ctypes.c_void_p(s)))
         return out
+
+    def second_order_filter_function(self, stream=None):
+        """Second-order filter function ``(A, A, N, N, W)`` of the pulse on this omega block, from
+        the eigensystem of the last ``launch`` (``ffk_second_order_filter_function_dev``); stays in
+        HBM."""
+        torch = self.torch
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        lib = _lib.load()
+        need = lib.ffk_second_order_workspace_bytes(self.W, self.N, self.A, self.G, self.d)
+        if getattr(self, '_sows', None) is None or self._sows.numel() < need:
+            self._sows = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+        if getattr(self, 'filter_function_2', None) is None:
+            self.filter_function_2 = torch.empty((self.A, self.A, self.N, self.N, self.W),
+                                                 dtype=torch.complex128, device=self.device)
+        p = self._p
+        check(lib.ffk_second_order_filter_function_dev(
+            p(self.eigvals), p(self.eigvecs), p(self.propagators), p(self.omega), self.W,
+            p(self.basis), self.N, p(self.n_opers), self.A, p(self.n_coeffs), p(self.dt), p(self.t),
+            self.G, self.d, p(self.filter_function_2), p(self._sows), need, ctypes.c_void_p(s)))
+        return self.filter_function_2
+
+    def frequency_shifts(self, omega_global=None, w_offset=0, stream=None):
+        """Frequency shifts ``(n_idx[, n_idx], N, N)`` from the device second-order filter function
+        (computed on demand); with *omega_global* / *w_offset* this block's contribution to the
+        integral over the full grid (multi-GPU), like :meth:`decay_amplitudes`."""
+        torch = self.torch
+        if self.spectrum is None:
+            raise ValueError('set_spectrum() first')
+        if getattr(self, 'filter_function_2', None) is None:
+            self.second_order_filter_function(stream)
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        omega = self.omega if omega_global is None else omega_global
+        shape = (self.n_idx, self.n_idx, self.N, self.N) if self.s_ndim == 3 else \
+            (self.n_idx, self.N, self.N)
+        out = torch.empty(shape, dtype=torch.float64, device=self.device)
+        lib = _lib.load()
+        need = lib.ffk_frequency_shifts_workspace_bytes(self.W, self.n_idx, self.s_ndim)
+        if getattr(self, '_fsws', None) is None or self._fsws.numel() < need:
+            self._fsws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+        p = self._p
+        check(lib.ffk_frequency_shifts_shard_dev(
+            p(self.filter_function_2), self.A, self.N, self.W, p(self.spectrum), self.s_ndim,
+            p(omega), omega.numel(), int(w_offset), p(self.idx), self.n_idx, p(out), p(self._fsws),
+            need, ctypes.c_void_p(s)))
+        return out
+
+    def add_second_order_cumulant(self, cumulant_function, frequency_shifts, stream=None):
+        """Adds the frequency-shift terms to a device cumulant function in place and returns it."""
+        torch = self.torch
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        delta = frequency_shifts.contiguous()
+        batch = delta.numel()//(self.N*self.N)
+        lib = _lib.load()
+        need = lib.ffk_cumulant_function_second_order_workspace_bytes(batch, self.N, self.d)
+        if getattr(self, '_c2ws', None) is None or self._c2ws.numel() < need:
+            self._c2ws = torch.empty(max(need, 16), dtype=torch.uint8, device=self.device)
+        p = self._p
+        check(lib.ffk_cumulant_function_second_order_dev(p(delta), batch, self.N, self.d,
+                                                         p(self.basis), p(cumulant_function),
+                                                         p(self._c2ws), need, ctypes.c_void_p(s)))
+        return cumulant_function

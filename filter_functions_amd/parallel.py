@@ -102,7 +102,8 @@ def sum_omega_shards(local, group=None):
     return total
 
 
-def sharded_error_transfer_matrix(pipe, omega_global, w_offset, single_qubit=False, group=None):
+def sharded_error_transfer_matrix(pipe, omega_global, w_offset, single_qubit=False, group=None,
+                                  second_order=False):
     """Error transfer matrix of a pulse whose frequency axis is sharded over the ranks (BASELINE
     config 5): *pipe* is this rank's ``DevicePipeline`` over its omega block (already launched),
     *omega_global* the full grid as a device tensor, *w_offset* the block's first index.
@@ -111,13 +112,20 @@ def sharded_error_transfer_matrix(pipe, omega_global, w_offset, single_qubit=Fal
     (``ffk_decay_amplitudes_shard_dev``), the (n_nops, d^2, d^2) partial results are summed in rank
     order on every rank (:func:`sum_omega_shards`: one small all-gather, bit-reproducible), and
     the cumulant contraction and the matrix exponential -- omega independent, tiny -- run
-    redundantly on every rank.  Returns ``(decay_amplitudes, cumulant_function, U)``; the first
-    two are device tensors, ``U`` a NumPy array.
+    redundantly on every rank.  With *second_order* the frequency shifts are treated the same way
+    (every frequency of the second-order filter function is independent, so each rank computes its
+    block of it; ``ffk_frequency_shifts_shard_dev``; one more small all-gather) and their
+    commutator terms are added to the cumulant function.  Returns ``(decay_amplitudes,
+    cumulant_function, U)``; the first two are device tensors, ``U`` a NumPy array.
     """
     from . import numeric
     gamma = sum_omega_shards(pipe.decay_amplitudes(omega_global=omega_global, w_offset=w_offset),
                              group=group)
     K = pipe.cumulant_function(gamma, single_qubit=single_qubit)
+    if second_order:
+        delta = sum_omega_shards(pipe.frequency_shifts(omega_global=omega_global, w_offset=w_offset),
+                                 group=group)
+        K = pipe.add_second_order_cumulant(K, delta)
     U = numeric.error_transfer_matrix(
         cumulant_function=K.sum(dim=tuple(range(K.dim() - 2))).cpu().numpy()[None])
     return gamma, K, U

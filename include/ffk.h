@@ -292,6 +292,28 @@ int ffk_frequency_shifts_from_scratch(const double* eigvals, const double* eigve
 int ffk_cumulant_function_second_order(const double* frequency_shifts, int batch, int N, int d,
                                        const double* basis, double* cumulant_function);
 
+/* Device-resident flavours (device pointers, caller-provided workspace, asynchronous on `stream`);
+ * ffk_frequency_shifts_shard_dev integrates the frequency block [w_offset, w_offset + W_block) of
+ * the global grid omega (W,) with the global trapezoid weights (multi-GPU: the per-rank results
+ * add up to the unsharded integral).                                                            */
+size_t ffk_second_order_workspace_bytes(int W, int N, int A, int G, int d);
+int ffk_second_order_filter_function_dev(const double* eigvals, const double* eigvecs,
+                                         const double* propagators, const double* omega, int W,
+                                         const double* basis, int N, const double* n_opers, int A,
+                                         const double* n_coeffs, const double* dt, const double* t,
+                                         int G, int d, double* filter_function_2, void* workspace,
+                                         size_t workspace_bytes, void* stream);
+size_t ffk_frequency_shifts_workspace_bytes(int W, int n_idx, int s_ndim);
+int ffk_frequency_shifts_shard_dev(const double* filter_function_2, int A, int N, int W_block,
+                                   const double* spectrum, int s_ndim, const double* omega, int W,
+                                   int w_offset, const int32_t* idx, int n_idx,
+                                   double* frequency_shifts, void* workspace, size_t workspace_bytes,
+                                   void* stream);
+size_t ffk_cumulant_function_second_order_workspace_bytes(int batch, int N, int d);
+int ffk_cumulant_function_second_order_dev(const double* frequency_shifts, int batch, int N, int d,
+                                           const double* basis, double* cumulant_function,
+                                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- exp of the summed cumulant function (numeric.error_transfer_matrix, numeric.py:2049-2053;
  *      the reference calls scipy.linalg.expm) ---------------------------------------------------
  * matrix (N, N) f64 row-major -> result (N, N) = exp(matrix): scaling and squaring with a Taylor

@@ -590,6 +590,23 @@ def frequency_shifts(F2, spectrum, omega, idx):
     return integrate(integrand.real, omega)/(2*np.pi)
 
 
+def frequency_shifts_shard(F2_block, spectrum_block, omega, w_offset, idx):
+    """Contribution of the frequency block [w_offset, w_offset + Wb) to frequency_shifts over the
+    global grid omega (trapezoid as a weighted sum, like decay_amplitudes_shard)."""
+    omega = np.asarray(omega, dtype=float)
+    idx = np.asarray(idx)
+    Wb = F2_block.shape[-1]
+    wgt = np.zeros(len(omega))
+    wgt[:-1] += 0.5*np.diff(omega)
+    wgt[1:] += 0.5*np.diff(omega)
+    S = parse_spectrum(spectrum_block, np.empty(Wb), idx)*wgt[w_offset:w_offset + Wb]
+    if S.ndim in (1, 2):
+        integrand = F2_block[idx, idx]*(S[:, None, None, :] if S.ndim == 2 else S)
+    else:
+        integrand = F2_block[idx[:, None], idx]*S[:, :, None, None, :]
+    return integrand.real.sum(axis=-1)/(2*np.pi)
+
+
 def cumulant_second_order_dense(Delta, basis, single_qubit=False):
     """The frequency-shift contribution to K: -1/2 sum_kl Delta_kl (T_klji - T_lkji - T_klij +
     T_lkij), filter_functions/numeric.py:1166-1190; single qubit: -(Delta - Delta^T) on the

@@ -1335,3 +1335,49 @@ def test_second_order_config2_size_against_oracle_subsample():
     contrib = K2 - K1
     assert np.abs(contrib).max() > 0
     assert np.abs(contrib + contrib.swapaxes(-1, -2)).max() < 1e-13*np.abs(delta).max()
+
+
+@pytest.mark.parametrize('name', ['q1', 'p4', 'p4idle'])
+def test_device_resident_second_order_with_logical_omega_shards(name):
+    """The multi-GPU second-order path on one GPU: F2 and the frequency shifts stay in HBM
+    (DevicePipeline, ``*_dev`` entries); two frequency blocks integrated with the global trapezoid
+    weights add up to the reference's frequency shifts, and the sharded error transfer matrix with
+    second_order=True reproduces the reference's."""
+    import torch
+    import torch.distributed as dist
+    from filter_functions_amd.device import DevicePipeline
+    from filter_functions_amd.parallel import shard_bounds, sharded_error_transfer_matrix
+    g = load_golden('second_order')
+    omega = g[f'{name}_omega']
+    om_dev = torch.from_numpy(omega).cuda()
+    for i in (1, 2, 3):
+        S = g[f'{name}_S{i}']
+        total = None
+        for rank in range(2):
+            w0, w1 = shard_bounds(len(omega), 2, rank)
+            pipe = DevicePipeline(g[f'{name}_c_opers'], g[f'{name}_c_coeffs'], g[f'{name}_n_opers'],
+                                  g[f'{name}_n_coeffs'], g[f'{name}_dt'], g[f'{name}_basis'],
+                                  omega[w0:w1], spectrum=S[..., w0:w1])
+            pipe.launch(with_infidelity=False)
+            F2 = pipe.second_order_filter_function()
+            assert rel_err(F2.cpu().numpy(), g[f'{name}_filter_function_2'][..., w0:w1]) < TOL
+            part = pipe.frequency_shifts(omega_global=om_dev, w_offset=w0)
+            total = part if total is None else total + part
+        assert rel_err(total.cpu().numpy(), g[f'{name}_frequency_shifts_S{i}']) < TOL
+    S = g[f'{name}_S2']
+    pipe = DevicePipeline(g[f'{name}_c_opers'], g[f'{name}_c_coeffs'], g[f'{name}_n_opers'],
+                          g[f'{name}_n_coeffs'], g[f'{name}_dt'], g[f'{name}_basis'], omega, spectrum=S)
+    pipe.launch(with_infidelity=False)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29534', rank=0, world_size=1)
+        created = True
+    try:
+        gamma, K, U = sharded_error_transfer_matrix(pipe, om_dev, 0, single_qubit=(name == 'q1'),
+                                                    second_order=True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert rel_err(K.cpu().numpy(), g[f'{name}_cumulant_function_2_S2']) < TOL
+    U_ref = g[f'{name}_error_transfer_matrix_2_S2']
+    assert np.abs(U - U_ref).max() < TOL*np.abs(U_ref - np.eye(len(U_ref))).max() + 1e-15

@@ -54,7 +54,17 @@ def _worker(rank, world, port, n_omega, out_dir):
     b0, b1 = shard_bounds(len(om), world, rank)
     part = orc.decay_amplitudes_shard(R[..., b0:b1], S[..., b0:b1], om, b0, np.arange(len(R)))
     gamma = sum_omega_shards(torch.from_numpy(part)).numpy()
-    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), F=F, idx=idx, gamma=gamma)
+    # frequency shifts: every frequency of the second-order filter function is independent, each
+    # rank computes its block of it and integrates with the global weights
+    so = np.load(os.path.join(ROOT, 'tests', 'golden', 'second_order.npz'))
+    om2, S2 = so['g3_omega'], so['g3_S3']
+    c0, c1 = shard_bounds(len(om2), world, rank)
+    F2_block = orc.second_order_filter_function(so['g3_eigvals'], so['g3_eigvecs'],
+                                                so['g3_propagators'], om2[c0:c1], so['g3_basis'],
+                                                so['g3_n_opers'], so['g3_n_coeffs'], so['g3_dt'])
+    part = orc.frequency_shifts_shard(F2_block, S2[..., c0:c1], om2, c0, np.arange(len(S2)))
+    delta = sum_omega_shards(torch.from_numpy(part)).numpy()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), F=F, idx=idx, gamma=gamma, delta=delta)
     dist.destroy_process_group()
 
 
@@ -81,6 +91,10 @@ def test_sharded_filter_function_matches_unsharded(tmp_path, n_omega):
     assert np.array_equal(gammas[0], gammas[1])            # rank-order sum: identical everywhere
     ref = e['g3_decay_amplitudes_S2']
     assert np.abs(gammas[0] - ref).max() <= 1e-13*np.abs(ref).max()
+    deltas = [np.load(os.path.join(str(tmp_path), f'rank{r}.npz'))['delta'] for r in range(world)]
+    assert np.array_equal(deltas[0], deltas[1])
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'second_order.npz'))['g3_frequency_shifts_S3']
+    assert np.abs(deltas[0] - ref).max() <= 1e-13*np.abs(ref).max()
 
 
 def test_shard_bounds_partition():
