@@ -129,6 +129,8 @@ SIGNATURES = {
     'ffk_second_order_filter_function': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                                  c_void_p, c_int, c_void_p, c_int, c_void_p,
                                                  c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    'ffk_second_order_filter_function_from_atomic': (c_int, [c_void_p, c_void_p, c_void_p, c_int,
+                                                             c_int, c_int, c_int, c_void_p]),
     'ffk_frequency_shifts_from_scratch': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                                   c_void_p, c_int, c_void_p, c_int, c_void_p,
                                                   c_void_p, c_void_p, c_int, c_int, c_void_p,

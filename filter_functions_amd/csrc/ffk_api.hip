@@ -1149,6 +1149,39 @@ int ffk_frequency_shifts_from_scratch(const double* eigvals, const double* eigve
                              t, G, d, filter_function_2, spectrum, s_ndim, idx, n_idx, frequency_shifts);
 }
 
+int ffk_second_order_filter_function_from_atomic(const double* filter_function_atomic,
+                                                 const double* control_matrix_step,
+                                                 const double* propagators_liouville, int G, int A,
+                                                 int N, int W, double* filter_function_2) {
+    FFK_REQUIRE(filter_function_atomic && control_matrix_step && filter_function_2, "NULL argument");
+    FFK_REQUIRE(G >= 1 && A >= 1 && N >= 1 && W >= 1, "empty axis: G=%d A=%d N=%d W=%d", G, A, N, W);
+    FFK_REQUIRE(G == 1 || propagators_liouville, "NULL argument");
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nF = 16*size_t(A)*A*N*N*W, nR = 16*size_t(G)*A*N*W;
+    const size_t nL = 8*size_t(G > 1 ? G - 1 : 1)*N*N;
+    const size_t wsb = ffk::second_order_from_atomic_workspace_bytes(G, A, N, W);
+    void* base;
+    if (int rc = arena_reserve(align_up(size_t(G)*nF) + align_up(nR) + align_up(nL) + wsb +
+                                   align_up(nF), &base))
+        return rc;
+    Bump a(base, g_arena.size);
+    cplx* dFa = a.take<cplx>(size_t(G)*nF/16);
+    cplx* dR = a.take<cplx>(nR/16);
+    double* dL = a.take<double>(nL/8);
+    void* ws = a.take<unsigned char>(wsb);
+    cplx* dout = a.take<cplx>(nF/16);
+    FFK_REQUIRE(dout, "internal: arena too small");
+    FFK_HIP(hipMemcpyAsync(dFa, filter_function_atomic, size_t(G)*nF, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dR, control_matrix_step, nR, hipMemcpyHostToDevice, nullptr));
+    if (G > 1)
+        FFK_HIP(hipMemcpyAsync(dL, propagators_liouville, 8*size_t(G - 1)*N*N, hipMemcpyHostToDevice,
+                               nullptr));
+    FFK_HIP(ffk::launch_second_order_from_atomic(dFa, dR, dL, G, A, N, W, dout, ws, nullptr));
+    FFK_HIP(hipMemcpyAsync(filter_function_2, dout, nF, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
 int ffk_frequency_shifts(const double* filter_function_2, int A, int N, int W, const double* spectrum,
                          int s_ndim, const double* omega, const int32_t* idx, int n_idx,
                          double* frequency_shifts) {

@@ -202,6 +202,12 @@ hipError_t launch_second_order_filter_function(const double* omega, int W, const
                                                const double* dt, const double* t, const cplx* nt,
                                                const cplx* bt, int G, int d, int A, int N, cplx* F2,
                                                void* ws, hipStream_t stream);
+// concatenation rule: F2_atomic (G,A,A,N,N,W), step (G,A,N,W) = summands of the sequence's control
+// matrix, L (G-1,N,N) f64 = Liouville matrices of the cumulative propagators -> out (A,A,N,N,W)
+size_t second_order_from_atomic_workspace_bytes(int G, int A, int N, int W);
+hipError_t launch_second_order_from_atomic(const cplx* F2_atomic, const cplx* step, const double* L,
+                                           int G, int A, int N, int W, cplx* out, void* ws,
+                                           hipStream_t stream);
 // Delta (n_idx[,n_idx],N,N) = sum_w Re(F2[idx,idx] scale); scale from launch_spectral_weights
 hipError_t launch_frequency_shifts(const cplx* F2, int A, int N, int W, const cplx* scale,
                                    int s_ndim, const int32_t* idx, int n_idx, double* out,

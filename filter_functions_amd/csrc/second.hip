@@ -621,7 +621,106 @@ __global__ __launch_bounds__(256) void cumulant_second_order_kernel(const double
     }
 }
 
+// ---- concatenation rule of the second-order filter function --------------------------------------
+// numeric.calculate_second_order_filter_function_from_atomic (numeric.py:1702-1818).  Both the
+// complete and the incomplete steps of a pulse are bilinear in the basis elements, so pulse g's own
+// F2^(g) enters the sequence's through the Liouville matrix of the preceding propagator on both
+// basis indices (the absolute-time phases of the nested integral cancel), and what is left is the
+// rank-one term between pulse g's summand of the control matrix and the sum of the earlier ones:
+//   F2[ab,kl] = sum_g ( sum_pq L^(g-1)[p,k] F2^(g)[ab,pq] L^(g-1)[q,l]
+//                       + conj(G^(g)[a,k]) sum_{g'<g} G^(g')[b,l] ),       L^(-1) = 1.
+// (The reference re-evaluates the incomplete steps from its W d^4 integral caches instead; the
+// rotated form needs only each pulse's F2.)  One lane per frequency, one (a, b, k, 16 values of l)
+// per thread; the Liouville entries are wave-uniform (scalar loads).
+__global__ __launch_bounds__(64) void so_cumulative_kernel(const cplx* __restrict__ step, int G,
+                                                           size_t slab, cplx* __restrict__ cum) {
+    const size_t e = static_cast<size_t>(blockIdx.x)*64 + threadIdx.x;
+    if (e >= slab) return;
+    cplx acc = {0.0, 0.0};
+    for (int g = 0; g < G; ++g) {
+        const cplx v = step[g*slab + e];
+        acc.re += v.re;
+        acc.im += v.im;
+        cum[g*slab + e] = acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void so_concat_kernel(const cplx* __restrict__ F2a,
+                                                       const cplx* __restrict__ step,
+                                                       const cplx* __restrict__ cum,
+                                                       const double* __restrict__ L, int G, int A,
+                                                       int N, int W, cplx* __restrict__ out) {
+    const int w = blockIdx.x*64 + threadIdx.x;
+    const int a = blockIdx.y / A, b = blockIdx.y % A;
+    const int ltiles = (N + 15)/16;
+    const int k = blockIdx.z / ltiles, l0 = (blockIdx.z % ltiles)*16;
+    if (w >= W) return;
+    const size_t NN = static_cast<size_t>(N)*N;
+    cplx acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = {0.0, 0.0};
+    for (int g = 0; g < G; ++g) {
+        const cplx* F = F2a + ((static_cast<size_t>(g)*A*A + blockIdx.y)*NN)*W + w;
+        if (g == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (l0 + i < N) {
+                    const cplx v = F[(static_cast<size_t>(k)*N + l0 + i)*W];
+                    acc[i].re += v.re;
+                    acc[i].im += v.im;
+                }
+            continue;
+        }
+        const double* Lg = L + static_cast<size_t>(g - 1)*NN;
+        for (int q = 0; q < N; ++q) {
+            cplx t = {0.0, 0.0};
+            for (int p = 0; p < N; ++p) {
+                const double lp = Lg[p*N + k];
+                const cplx v = F[(static_cast<size_t>(p)*N + q)*W];
+                t.re = fma(lp, v.re, t.re);
+                t.im = fma(lp, v.im, t.im);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double lq = l0 + i < N ? Lg[q*N + l0 + i] : 0.0;
+                acc[i].re = fma(t.re, lq, acc[i].re);
+                acc[i].im = fma(t.im, lq, acc[i].im);
+            }
+        }
+        const cplx ga = step[((static_cast<size_t>(g)*A + a)*N + k)*W + w];
+        const cplx gc = {ga.re, -ga.im};
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (l0 + i < N)
+                cmac(acc[i], gc, cum[((static_cast<size_t>(g - 1)*A + b)*N + l0 + i)*W + w]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (l0 + i < N)
+            out[((static_cast<size_t>(blockIdx.y)*N + k)*N + l0 + i)*W + w] = acc[i];
+}
+
 }  // namespace
+
+size_t second_order_from_atomic_workspace_bytes(int G, int A, int N, int W) {
+    return align_up(sizeof(cplx)*size_t(G)*A*N*W);
+}
+
+hipError_t launch_second_order_from_atomic(const cplx* F2_atomic, const cplx* step, const double* L,
+                                           int G, int A, int N, int W, cplx* out, void* ws,
+                                           hipStream_t stream) {
+    const size_t slab = static_cast<size_t>(A)*N*W;
+    const int ltiles = (N + 15)/16;
+    if (static_cast<size_t>(N)*ltiles > 65535 || static_cast<size_t>(A)*A > 65535 ||
+        (slab + 63)/64 > 0x7fffffffull)
+        return hipErrorInvalidValue;
+    cplx* cum = static_cast<cplx*>(ws);
+    hipLaunchKernelGGL(so_cumulative_kernel, dim3(static_cast<unsigned>((slab + 63)/64)), dim3(64), 0,
+                       stream, step, G, slab, cum);
+    hipLaunchKernelGGL(so_concat_kernel, dim3((W + 63)/64, A*A, N*ltiles), dim3(64), 0, stream,
+                       F2_atomic, step, cum, L, G, A, N, W, out);
+    return hipGetLastError();
+}
 
 size_t second_order_workspace_bytes(int G, int A, int N, int d) {
     return 2*align_up(sizeof(cplx)*size_t(G)*A*N*d*d);

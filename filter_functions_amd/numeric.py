@@ -13,6 +13,7 @@ this module                                           reference (file:line)
 :func:`calculate_decay_amplitudes`                    numeric.py:1194-1337
 :func:`calculate_cumulant_function`                   numeric.py:957-1191
 :func:`calculate_second_order_filter_function_from_scratch`  numeric.py:1470-1699 (:170-256)
+:func:`calculate_second_order_filter_function_from_atomic`   numeric.py:1702-1818
 :func:`calculate_frequency_shifts`                    numeric.py:1340-1410
 :func:`error_transfer_matrix`                         numeric.py:1938-2059
 ====================================================  ==============================
@@ -35,7 +36,8 @@ __all__ = ['diagonalize', 'calculate_control_matrix_from_scratch',
            'calculate_noise_operators_from_atomic',
            'calculate_pulse_correlation_filter_function', 'calculate_decay_amplitudes',
            'calculate_cumulant_function', 'error_transfer_matrix',
-           'calculate_second_order_filter_function_from_scratch', 'calculate_frequency_shifts']
+           'calculate_second_order_filter_function_from_scratch',
+           'calculate_second_order_filter_function_from_atomic', 'calculate_frequency_shifts']
 
 
 def _check_d(d):
@@ -590,6 +592,45 @@ def calculate_second_order_filter_function_from_scratch(eigvals, eigvecs, propag
         ptr(out)))
     if cache_intermediates:
         return out, (intermediates if intermediates is not None else dict())
+    return out
+
+
+def calculate_second_order_filter_function_from_atomic(filter_function_atomic,
+                                                       control_matrix_atomic_step,
+                                                       propagators_liouville):
+    r"""Second-order filter function of a sequence of pulses from those of the pulses (reference
+    numeric.py:1702-1818), in the rotated form of the concatenation rule
+
+    .. math:: F^{(2)}_{\alpha\beta,kl} = \sum_g\Big[\sum_{pq}\mathcal Q^{(g-1)}_{pk}
+              F^{(2,g)}_{\alpha\beta,pq}\mathcal Q^{(g-1)}_{ql} + \mathcal G^{(g)\ast}_{\alpha k}
+              \sum_{g'<g}\mathcal G^{(g')}_{\beta l}\Big],
+
+    which needs only each pulse's own second-order filter function (the reference re-evaluates the
+    incomplete steps from its ``second_order_integral`` caches instead; same result).
+
+    filter_function_atomic: (G, n_nops, n_nops, d**2, d**2, n_omega); control_matrix_atomic_step:
+    (G, n_nops, d**2, n_omega), the summands of the sequence's control matrix
+    (``calculate_control_matrix_from_atomic(..., which='correlations')``); propagators_liouville:
+    (G-1, d**2, d**2), real (Hermitian basis)."""
+    Fa = as_c128(filter_function_atomic)
+    Rs = as_c128(control_matrix_atomic_step)
+    if Fa.ndim != 6 or Rs.ndim != 4 or Fa.shape[0] != Rs.shape[0]:
+        raise ValueError(f'Expected filter_function_atomic (G, A, A, N, N, W) and '
+                         f'control_matrix_atomic_step (G, A, N, W), not {Fa.shape} and {Rs.shape}.')
+    G, A, N, W = Rs.shape
+    if Fa.shape[1:] != (A, A, N, N, W):
+        raise ValueError(f'Expected filter_function_atomic of shape {(G, A, A, N, N, W)}, '
+                         f'not {Fa.shape}.')
+    if np.iscomplexobj(propagators_liouville):
+        raise NotImplementedError('second-order concatenation needs a Hermitian basis (real '
+                                  'Liouville representation)')
+    L = as_f64(propagators_liouville)
+    if G > 1 and (L.ndim != 3 or L.shape[0] < G - 1 or L.shape[1:] != (N, N)):
+        raise ValueError(f'Expected propagators_liouville of shape ({G - 1}, {N}, {N}), not {L.shape}.')
+    L = np.ascontiguousarray(L[:max(G - 1, 0)])
+    out = np.empty((A, A, N, N, W), dtype=np.complex128)
+    check(_lib.load().ffk_second_order_filter_function_from_atomic(
+        ptr(Fa), ptr(Rs), ptr(L) if G > 1 else None, G, A, N, W, ptr(out)))
     return out
 
 

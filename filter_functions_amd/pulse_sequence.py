@@ -12,6 +12,7 @@ exactly as in the reference; the arithmetic behind them runs in libffk.
 import copy
 from itertools import chain, zip_longest
 from types import MappingProxyType
+from warnings import warn
 
 import numpy as np
 
@@ -619,16 +620,11 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     two pulses share a noise operator.  ``calc_pulse_correlation_FF`` keeps every summand and
     caches the pulse correlation filter function.
     """
-    if calc_second_order_FF:
-        raise NotImplementedError('Concatenating second-order filter functions (reference '
-                                  'numeric.py:1702-1818) needs the d^4-sized per-segment integral '
-                                  'caches, which the device path does not materialise; compute '
-                                  'get_filter_function(omega, order=2) on the concatenated pulse.')
     newpulse, _, n_map = concatenate_without_filter_function(pulses, return_identifier_mappings=True)
     pulses = tuple(pulses)
     if all(pls.is_cached('total_propagator') for pls in pulses):
         newpulse.total_propagator = util.mdot([pls.total_propagator for pls in pulses][::-1])
-    if calc_pulse_correlation_FF:
+    if calc_pulse_correlation_FF or calc_second_order_FF is True:
         calc_filter_function = True
     if calc_filter_function is False:
         return newpulse
@@ -640,6 +636,10 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
         for ident in n_map[p].values():
             present[p, new_ids.index(ident)] = True
     shared_n_opers = bool((present.sum(axis=0) > 1).any())
+    if calc_second_order_FF and not present.all():
+        warn('Second order FF requested but not all pulses have the same n_opers. '
+             'Not implemented.', UserWarning)
+        calc_second_order_FF = False
 
     if omega is None:
         cached_R = [pls.is_cached('control_matrix') for pls in pulses]
@@ -662,6 +662,8 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     if not shared_n_opers:
         # nothing to reuse: plain from-scratch evaluation of the long sequence
         newpulse.cache_filter_function(omega, which=which)
+        if calc_second_order_FF:
+            newpulse.cache_filter_function(omega, order=2)
         return newpulse
 
     # distinct pulse objects (a randomized-benchmarking sequence draws 1000 gates from 24
@@ -696,7 +698,7 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     newpulse.cache_total_phases(omega)
     newpulse.total_propagator_liouville = liouville_representation(newpulse.total_propagator,
                                                                    newpulse.basis)
-    mode = 'correlations' if calc_pulse_correlation_FF else 'total'
+    mode = 'correlations' if calc_pulse_correlation_FF or calc_second_order_FF else 'total'
     # the indexed kernel assumes a repeated pulse contributes the same rows everywhere, which
     # holds when every pulse carries every noise operator (else fall back to the plain rule)
     if len(distinct) < len(pulses) and present.all():
@@ -710,5 +712,24 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
         R_atomic = np.array([atomic_control_matrix(i) for i in range(len(pulses))])
         control_matrix = numeric.calculate_control_matrix_from_atomic(
             phases, R_atomic, propagators_liouville, which=mode)
+    if calc_second_order_FF:
+        # each pulse's own second-order filter function (cached or computed now), in the new
+        # pulse's noise-operator order; control_matrix holds the summands of the sequence's
+        def atomic_second_order(i):
+            pls = pulses[i]
+            order = [list(pls.n_oper_identifiers).index(old) for new in new_ids
+                     for old, mapped in n_map[i].items() if mapped == new]
+            F2 = pls.get_filter_function(omega, order=2, show_progressbar=show_progressbar)
+            return F2[np.ix_(order, order)]
+        cache = {}
+        for i, k in enumerate(index):
+            if k not in cache:
+                cache[k] = atomic_second_order(i)
+        F2_atomic = np.array([cache[k] for k in index])
+        filter_function_2 = numeric.calculate_second_order_filter_function_from_atomic(
+            F2_atomic, control_matrix, propagators_liouville)
+        newpulse.cache_filter_function(omega, filter_function=filter_function_2, order=2)
+        if not calc_pulse_correlation_FF:
+            control_matrix = control_matrix.sum(axis=0)
     newpulse.cache_filter_function(omega, control_matrix, which=which)
     return newpulse

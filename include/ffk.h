@@ -272,6 +272,15 @@ int ffk_second_order_filter_function(const double* eigvals, const double* eigvec
                                      const double* basis, int N, const double* n_opers, int A,
                                      const double* n_coeffs, const double* dt, const double* t, int G,
                                      int d, double* filter_function_2);
+/* numeric.calculate_second_order_filter_function_from_atomic (numeric.py:1702-1818), the
+ * concatenation rule: filter_function_atomic (G, A, A, N, N, W) c128 = each pulse's own F2,
+ * control_matrix_step (G, A, N, W) c128 = the summands of the sequence's control matrix
+ * (ffk_control_matrix_from_atomic with correlations != 0), propagators_liouville (G-1, N, N) f64
+ * (Hermitian basis) -> filter_function_2 (A, A, N, N, W).                                       */
+int ffk_second_order_filter_function_from_atomic(const double* filter_function_atomic,
+                                                 const double* control_matrix_step,
+                                                 const double* propagators_liouville, int G, int A,
+                                                 int N, int W, double* filter_function_2);
 /* Delta = int dw/2pi Re(S F2): spectrum/s_ndim/idx as in ffk_decay_amplitudes; frequency_shifts
  * (n_idx, N, N) f64 for s_ndim 1, 2 and (n_idx, n_idx, N, N) for s_ndim 3.                      */
 int ffk_frequency_shifts(const double* filter_function_2, int A, int N, int W, const double* spectrum,

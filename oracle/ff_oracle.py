@@ -577,6 +577,27 @@ def second_order_filter_function(eigvals, eigvecs, propagators, omega, basis, n_
     return F2
 
 
+def second_order_from_atomic(F2_atomic, control_matrix_step, propagators_liouville):
+    """Concatenation rule of the second-order filter function,
+    filter_functions/numeric.py:1702-1818, in its rotated form: the complete steps of pulse g are
+    rotated by the Liouville matrix of the preceding propagator on both basis indices (:1809-1812,
+    'pk,abpqo,ql->abklo'); the incomplete steps, which the reference re-evaluates with the
+    propagated eigenvectors (:1787-1790, :1815-1817), are bilinear in the basis elements and hence
+    rotate the same way; and the rank-one term couples pulse g's summand of the control matrix
+    with the cumulative earlier ones (:1804-1806).
+    F2_atomic (G,A,A,N,N,W); control_matrix_step (G,A,N,W); propagators_liouville (G-1,N,N)."""
+    F2_atomic = np.asarray(F2_atomic)
+    Rs = np.asarray(control_matrix_step)
+    out = F2_atomic[0].copy()
+    cum = Rs[0].copy()
+    for g in range(1, len(Rs)):
+        L = np.asarray(propagators_liouville[g - 1])
+        out += np.einsum('pk,abpqo,ql->abklo', L, F2_atomic[g], L)
+        out += Rs[g].conj()[:, None, :, None]*cum[None, :, None]
+        cum += Rs[g]
+    return out
+
+
 def frequency_shifts(F2, spectrum, omega, idx):
     """Delta_{ab,kl} = int dw/2pi Re[S_ab F2_{ab,kl}], filter_functions/numeric.py:1340-1410 with
     the 'generalized' filter-function branch of _get_integrand (:318-329, :351-354)."""

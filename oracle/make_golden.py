@@ -343,7 +343,48 @@ def make_second_order():
     save('second_order', **arrays)
 
 
+def make_second_order_concat():
+    """16. concatenation of second-order filter functions (reference pulse_sequence.py:1863-1881,
+    numeric.py:1702-1818; cases of tests/test_sequencing.py:471-505): three pulses sharing their
+    noise operators, Pauli d=2 and d=4, GGM d=3; each pulse's own F2, the reference's concatenated
+    F2, the pulse-resolved control matrix and the Liouville propagators."""
+    from filter_functions import superoperator
+    rng = np.random.default_rng(88)
+    arrays = {}
+    for name, d, btype in [('q1', 2, 'Pauli'), ('g3', 3, 'GGM'), ('p4', 4, 'Pauli')]:
+        pulses = [rand_pulse(d, int(rng.integers(1, 4)), 2, 2, btype, rng) for _ in range(3)]
+        for q in pulses[1:]:
+            q.n_opers = pulses[0].n_opers
+            q.n_oper_identifiers = pulses[0].n_oper_identifiers
+        omega = np.sort(np.concatenate([[-2.0, 0.0], np.geomspace(1e-2, 20, 9)]))
+        for q in pulses:
+            q.cache_filter_function(omega, order=1, cache_intermediates=True)
+            q.cache_filter_function(omega, order=2, cache_intermediates=True)
+        total = ff.concatenate(pulses, calc_second_order_FF=True, calc_pulse_correlation_FF=True)
+        only2 = ff.concatenate(pulses, calc_second_order_FF=True)
+        assert np.allclose(only2.get_filter_function(omega, order=2),
+                           total.get_filter_function(omega, order=2), rtol=1e-13, atol=1e-15)
+        arrays[f'{name}_omega'] = omega
+        arrays[f'{name}_filter_function_2'] = total.get_filter_function(omega, order=2)
+        arrays[f'{name}_filter_function'] = total.get_filter_function(omega)
+        arrays[f'{name}_control_matrix_pc'] = total.get_pulse_correlation_control_matrix()
+        Qc = [np.eye(d)]
+        for q in pulses[:-1]:
+            Qc.append(q.total_propagator @ Qc[-1])
+        arrays[f'{name}_propagators_liouville'] = np.array(
+            [superoperator.liouville_representation(Q, pulses[0].basis) for Q in Qc[1:]])
+        arrays[f'{name}_filter_function_2_atomic'] = np.array(
+            [q.get_filter_function(omega, order=2) for q in pulses])
+        for i, q in enumerate(pulses):
+            for k, v in pulse_inputs(q).items():
+                arrays[f'{name}_p{i}_{k}'] = v
+    save('second_order_concat', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'second_order_concat':
+        make_second_order_concat()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'second_order':
         make_second_order()
         return

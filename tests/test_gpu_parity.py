@@ -671,8 +671,6 @@ def test_cumulant_and_etm_error_behaviour():
     with pytest.raises(ValueError):       # precomputed decay amplitudes of another shape
         numeric.calculate_cumulant_function(pulse, g['p4_S1'], omega, second_order=True,
                                             decay_amplitudes=np.ones((1, 16, 16)))
-    with pytest.raises(NotImplementedError):
-        ff.concatenate([pulse, pulse], calc_second_order_FF=True)
     with pytest.raises(ValueError):
         ff.error_transfer_matrix(pulse)
     with pytest.raises(TypeError):
@@ -1381,3 +1379,60 @@ def test_device_resident_second_order_with_logical_omega_shards(name):
     assert rel_err(K.cpu().numpy(), g[f'{name}_cumulant_function_2_S2']) < TOL
     U_ref = g[f'{name}_error_transfer_matrix_2_S2']
     assert np.abs(U - U_ref).max() < TOL*np.abs(U_ref - np.eye(len(U_ref))).max() + 1e-15
+
+
+@pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
+def test_second_order_concatenation(name):
+    """concatenate(calc_second_order_FF=True) against the reference's result and against the
+    from-scratch second-order filter function of the long sequence (reference
+    tests/test_sequencing.py:471-505); the free function against the oracle's rule."""
+    g = load_golden('second_order_concat')
+    omega = g[f'{name}_omega']
+
+    def pulses():
+        out = []
+        for i in range(3):
+            basis = ff.Basis(g[f'{name}_p{i}_basis'], btype=str(g[f'{name}_p{i}_btype']))
+            out.append(ff.PulseSequence.from_arrays(
+                g[f'{name}_p{i}_c_opers'], g[f'{name}_p{i}_c_oper_identifiers'],
+                g[f'{name}_p{i}_c_coeffs'], g[f'{name}_p{i}_n_opers'],
+                g[f'{name}_p{i}_n_oper_identifiers'], g[f'{name}_p{i}_n_coeffs'],
+                g[f'{name}_p{i}_dt'], basis))
+        return out
+    ref = g[f'{name}_filter_function_2']
+    F2 = numeric.calculate_second_order_filter_function_from_atomic(
+        g[f'{name}_filter_function_2_atomic'], g[f'{name}_control_matrix_pc'],
+        g[f'{name}_propagators_liouville'])
+    assert rel_err(F2, ref) < 1e-12
+    seq = pulses()
+    total = ff.concatenate(seq, calc_second_order_FF=True, omega=omega)
+    assert total.is_cached('filter_function_2') and total.is_cached('filter_function')
+    assert not total.is_cached('control_matrix_pc')
+    assert rel_err(total.get_filter_function(omega, order=2), ref) < TOL
+    assert rel_err(total.get_filter_function(omega), g[f'{name}_filter_function']) < TOL
+    # every pulse now holds its own F2 (computed on the way)
+    assert all(p.is_cached('filter_function_2') for p in seq)
+    both = ff.concatenate(pulses(), calc_second_order_FF=True, calc_pulse_correlation_FF=True,
+                          omega=omega)
+    assert rel_err(both.get_filter_function(omega, order=2), ref) < TOL
+    assert rel_err(both.get_pulse_correlation_control_matrix(), g[f'{name}_control_matrix_pc']) < TOL
+    # from scratch on the long sequence
+    long = ff.concatenate_without_filter_function(pulses())
+    assert rel_err(long.get_filter_function(omega, order=2), ref) < TOL
+    # a repeated pulse object: its F2 is computed once and reused
+    p0, p1 = pulses()[:2]
+    rep = ff.concatenate([p0, p1, p0], calc_second_order_FF=True, omega=omega)
+    plain = ff.concatenate_without_filter_function([p0, p1, p0])
+    assert rel_err(rep.get_filter_function(omega, order=2),
+                   plain.get_filter_function(omega, order=2)) < TOL
+    # differing noise operators: warning, first order only (reference pulse_sequence.py:1773-1776)
+    rng = np.random.default_rng(3)
+    d = p0.d
+    M = rng.standard_normal((4, d, d)) + 1j*rng.standard_normal((4, d, d))
+    M = M + M.conj().transpose(0, 2, 1)
+    one = ff.PulseSequence([[M[0], [0.3, -0.2]]], [[M[1], [1.0, 1.0], 'n_a']], [1.0, 0.5], p0.basis)
+    other = ff.PulseSequence([[M[0], [0.7]]], [[M[2], [1.0], 'n_b']], [0.8], p0.basis)
+    p0 = one
+    with pytest.warns(UserWarning):
+        mixed = ff.concatenate([p0, other], calc_second_order_FF=True, omega=omega)
+    assert not mixed.is_cached('filter_function_2')

@@ -253,7 +253,7 @@ def test_concatenation_bookkeeping():
     # no filter function work unless something is cached or asked for
     assert not ff.concatenate([a, b]).is_cached('filter_function')
     assert not ff.concatenate([a, b], calc_filter_function=False).is_cached('omega')
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):          # forces the filter function, but no frequencies known
         ff.concatenate([a, b], calc_second_order_FF=True)
 
 

@@ -314,3 +314,13 @@ def test_second_order_filter_function_and_frequency_shifts(name, single_qubit):
         assert np.abs(orc.cumulant_second_order(delta, basis) - K2).max() < 1e-17
         U = orc.error_transfer_matrix(K1 + K2)
         assert np.abs(U - g[f'{name}_error_transfer_matrix_2_S{i}']).max() < 1e-14
+
+
+@pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
+def test_second_order_concatenation_rule(name):
+    """Oracle (rotated form of the rule) vs the reference's concatenate(calc_second_order_FF=True)."""
+    g = load_golden('second_order_concat')
+    F2 = orc.second_order_from_atomic(g[f'{name}_filter_function_2_atomic'],
+                                      g[f'{name}_control_matrix_pc'],
+                                      g[f'{name}_propagators_liouville'])
+    assert rel_err(F2, g[f'{name}_filter_function_2']) < 1e-13
