@@ -655,3 +655,104 @@ def cumulant_second_order(Delta, basis):
     X = np.einsum('...kl,kab,lbc->...ac', Asym, C, C)
     comm = np.einsum('...ab,jbc->...jac', X, C) - np.einsum('jab,...bc->...jac', C, X)
     return -0.5*np.einsum('iba,...jab->...ij', C, comm).real
+
+
+# ---------------------------------------------------------------------------------------------
+# Gradient of the filter function / infidelity with respect to the control amplitudes
+# (filter_functions/gradient.py; consumer of the step caches)
+# ---------------------------------------------------------------------------------------------
+def _nested_exponential_integral(x, I1, dt):
+    """int_0^dt tau e^{i x tau} dtau = (dt e^{i x dt} - I1(x))/(i x), dt^2/2 at x == 0: the
+    Omega_pq == 0 case of the derivative integral, filter_functions/gradient.py:84-94."""
+    out = np.full(np.shape(x), dt**2/2, dtype=complex)
+    nz = x != 0
+    out[nz] = (dt*cexp(x[nz]*dt) - I1[nz])/(1j*x[nz])
+    return out
+
+
+def filter_function_derivative(eigvals, eigvecs, propagators, omega, basis, n_opers, n_coeffs,
+                               c_opers, dt, n_coeffs_deriv=None):
+    """dF_a(w)/du_h(t_s), shape (n_nops, n_dt, n_ctrl, n_omega): what
+    PulseSequence.get_filter_function_derivative returns (filter_functions/pulse_sequence.py:977-1054
+    = gradient.calculate_filter_function_derivative(:526-556) of
+    gradient.calculate_derivative_of_control_matrix_from_scratch(:384-523)).
+
+    The reference builds the derivative of the control matrix, (n_ctrl, W, G, A, d^2), from
+      (I)  the derivative of segment s's own contribution (_control_matrix_at_timestep_derivative,
+           :200-381, with the nested integral _derivative_integral :69-108), and
+      (II) the derivative of every later Liouville propagator (_liouville_derivative :111-197,
+           contracted over all pairs of segments at :520),
+    and contracts it with conj(R).  Restated here in Hilbert space, with Y_a(w) the interaction
+    picture noise operator (R_ak = tr(Y_a C_k)):
+      (I)  2 Re tr(Y_a^dag Y'),  Y' = -i e^{i w t_s} T^dag G^T T,  T = V_s^dag Q_s, and
+           G_xy = sum_n Bbar_yn Abar_nx J(w; W_yn, W_nx) - sum_q Abar_yq Bbar_qx J(w; W_qx, W_yq),
+           J(w; a, b) = int_0^dt dtau e^{i(w+a)tau} int_0^tau dtau' e^{i b tau'};
+      (II) a later propagator changes by Q_g -> Q_g E with the SAME generator
+           E = -i T^dag (Abar o I1(0)) T for every g > s, so that the sum over later segments
+           collapses to -2 Re tr(E [Y_a^dag, Ycum_{s,a}]) with Ycum the steps up to and including s
+           (the part proportional to the total Y_a drops out of the real part);
+      and the explicit dependence of the noise sensitivities, (n'_ah / n_a) 2 Re tr(Y_a^dag Ystep_s)
+      (:376-379)."""
+    dt = np.asarray(dt, dtype=float)
+    omega = np.asarray(omega, dtype=float)
+    G, d = eigvals.shape
+    A, H, W = len(n_opers), len(c_opers), len(omega)
+    t = np.concatenate(([0.0], dt.cumsum()))
+    QdV, Bbar = _prologue(eigvals, eigvecs, propagators, n_opers, n_coeffs)
+    _, Abar = _prologue(eigvals, eigvecs, propagators, c_opers, np.ones((H, G)))
+    n_coeffs = np.asarray(n_coeffs, dtype=float)
+    # Hilbert-space steps Ystep[g,a,w] = e^{i w t_g} T^dag (Bbar o I1) T
+    Ystep = np.empty((G, A, W, d, d), dtype=complex)
+    I1_all = np.empty((G, W, d, d), dtype=complex)
+    for g in range(G):
+        T = QdV[g].conj().T
+        I1_all[g] = first_order_integral(omega, eigvals[g], dt[g])
+        inner = Bbar[:, g, None]*I1_all[g][None]*cexp(omega*t[g])[None, :, None, None]
+        Ystep[g] = T.conj().T @ inner @ T
+    Ycum = Ystep.cumsum(axis=0)
+    Ytot = Ycum[-1]
+    Ytot_dag = Ytot.conj().swapaxes(-1, -2)
+    out = np.empty((A, G, H, W))
+    for s in range(G):
+        T = QdV[s].conj().T
+        dE = np.subtract.outer(eigvals[s], eigvals[s])
+        I0 = first_order_integral(np.zeros(1), eigvals[s], dt[s])[0]
+        I1 = I1_all[s]                                        # (W,d,d): I1(w + W_mn)
+        x = omega[:, None, None] + dE[None]
+        Jd = _nested_exponential_integral(x, I1, dt[s])       # b == 0 case at a = W_mn
+        # J1[w,m,n,q] = J(w; W_mn, W_nq),  J2[w,p,q,n] = J(w; W_qn, W_pq)
+        J1 = np.empty((W, d, d, d), dtype=complex)
+        J2 = np.empty((W, d, d, d), dtype=complex)
+        for m in range(d):
+            for n in range(d):
+                for q in range(d):
+                    J1[:, m, n, q] = Jd[:, m, n] if dE[n, q] == 0 else \
+                        (I1[:, m, q] - I1[:, m, n])/(1j*dE[n, q])
+        for p in range(d):
+            for q in range(d):
+                for n in range(d):
+                    J2[:, p, q, n] = Jd[:, q, n] if dE[p, q] == 0 else \
+                        (I1[:, p, n] - I1[:, q, n])/(1j*dE[p, q])
+        phase = cexp(omega*t[s])
+        Wa = T[None, None] @ Ytot_dag @ T.conj().T[None, None]                    # (A,W,d,d)
+        comm = Ytot_dag @ Ycum[s] - Ycum[s] @ Ytot_dag                           # (A,W,d,d)
+        for h in range(H):
+            E = -1j*(T.conj().T @ (Abar[h, s]*I0) @ T)
+            second = -2*np.einsum('xy,awyx->aw', E, comm).real
+            for a in range(A):
+                Yq = np.einsum('mn,nq,wmnq->wqm', Bbar[a, s], Abar[h, s], J1)
+                Zn = np.einsum('pq,qn,wpqn->wnp', Abar[h, s], Bbar[a, s], J2)
+                first = 2*(-1j*phase*np.einsum('wxy,wxy->w', Wa[a], Yq - Zn)).real
+                out[a, s, h] = first + second[a]
+                if n_coeffs_deriv is not None:
+                    ratio = np.asarray(n_coeffs_deriv)[a, h, s]/n_coeffs[a, s]
+                    out[a, s, h] += ratio*2*np.einsum('wyx,wxy->w', Ytot_dag[a], Ystep[s, a]).real
+    return out
+
+
+def infidelity_derivative(dF, spectrum, omega, d):
+    """int dw/(2 pi d) S dF, filter_functions/gradient.py:667-676."""
+    omega = np.asarray(omega, dtype=float)
+    S = parse_spectrum(spectrum, omega, np.arange(dF.shape[0]))
+    integrand = np.einsum('...o,...tho->...tho', S, dF)
+    return integrate(integrand, omega)/(2*np.pi*d)

@@ -381,7 +381,52 @@ def make_second_order_concat():
     save('second_order_concat', **arrays)
 
 
+def make_gradient():
+    """17. filter-function and infidelity derivatives with respect to the control amplitudes
+    (reference gradient.py, PulseSequence.get_filter_function_derivative; cases of
+    tests/test_gradient.py:70-176 in small): Pauli d=2, GGM d=3, Pauli d=4 (one with an idle
+    segment); with and without n_coeffs_deriv; subsets of control and noise operators."""
+    from filter_functions import gradient
+    rng = np.random.default_rng(99)
+    arrays = {}
+    cases = [('q1', 2, 4, 2, 2, 'Pauli', False), ('g3', 3, 3, 3, 2, 'GGM', False),
+             ('p4', 4, 5, 2, 3, 'Pauli', False), ('p4idle', 4, 3, 2, 2, 'Pauli', True)]
+    for name, d, n_dt, n_cops, n_nops, btype, idle in cases:
+        pulse = rand_pulse(d, n_dt, n_cops, n_nops, btype, rng)
+        if idle:
+            pulse.c_coeffs[:, 1] = 0.0
+        omega = np.sort(np.concatenate([[-4.0, 0.0], np.geomspace(2e-2, 40.0, 10)]))
+        spectra = [1e-3/(1 + omega**2),
+                   np.outer(np.arange(n_nops) + 1.0, 1e-3/(4 + omega**2))]
+        ncd = rng.standard_normal((n_nops, n_cops, n_dt))
+        for k, v in pulse_inputs(pulse).items():
+            arrays[f'{name}_{k}'] = v
+        arrays[f'{name}_omega'] = omega
+        arrays[f'{name}_n_coeffs_deriv'] = ncd
+        arrays[f'{name}_filter_function_derivative'] = pulse.get_filter_function_derivative(omega)
+        arrays[f'{name}_filter_function_derivative_ncd'] = pulse.get_filter_function_derivative(
+            omega, n_coeffs_deriv=ncd)
+        for i, S in enumerate(spectra, 1):
+            arrays[f'{name}_S{i}'] = S
+            arrays[f'{name}_infidelity_derivative_S{i}'] = gradient.infidelity_derivative(
+                pulse, S, omega)
+            arrays[f'{name}_infidelity_derivative_ncd_S{i}'] = gradient.infidelity_derivative(
+                pulse, S, omega, n_coeffs_deriv=ncd)
+        c_sub, n_sub = pulse.c_oper_identifiers[1:], pulse.n_oper_identifiers[:1]
+        arrays[f'{name}_filter_function_derivative_sub'] = pulse.get_filter_function_derivative(
+            omega, control_identifiers=c_sub, n_oper_identifiers=n_sub)
+        arrays[f'{name}_sub_c_idx'] = util.get_indices_from_identifiers(pulse.c_oper_identifiers, c_sub)
+        arrays[f'{name}_sub_n_idx'] = util.get_indices_from_identifiers(pulse.n_oper_identifiers, n_sub)
+        arrays[f'{name}_eigvals'] = pulse.eigvals
+        arrays[f'{name}_eigvecs'] = pulse.eigvecs
+        arrays[f'{name}_propagators'] = pulse.propagators
+    save('gradient', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'gradient':
+        make_gradient()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'second_order_concat':
         make_second_order_concat()
         return

@@ -324,3 +324,30 @@ def test_second_order_concatenation_rule(name):
                                       g[f'{name}_control_matrix_pc'],
                                       g[f'{name}_propagators_liouville'])
     assert rel_err(F2, g[f'{name}_filter_function_2']) < 1e-13
+
+
+@pytest.mark.parametrize('name', ['q1', 'g3', 'p4', 'p4idle'])
+def test_filter_function_and_infidelity_derivative(name):
+    """Oracle (Hilbert-space form with one generator per (control, segment)) vs the reference's
+    get_filter_function_derivative / gradient.infidelity_derivative."""
+    g = load_golden('gradient')
+    omega, basis = g[f'{name}_omega'], g[f'{name}_basis']
+    args = (g[f'{name}_eigvals'], g[f'{name}_eigvecs'], g[f'{name}_propagators'], omega, basis)
+    dF = orc.filter_function_derivative(*args, g[f'{name}_n_opers'], g[f'{name}_n_coeffs'],
+                                        g[f'{name}_c_opers'], g[f'{name}_dt'])
+    assert rel_err(dF, g[f'{name}_filter_function_derivative']) < 1e-12
+    dFn = orc.filter_function_derivative(*args, g[f'{name}_n_opers'], g[f'{name}_n_coeffs'],
+                                         g[f'{name}_c_opers'], g[f'{name}_dt'],
+                                         g[f'{name}_n_coeffs_deriv'])
+    assert rel_err(dFn, g[f'{name}_filter_function_derivative_ncd']) < 1e-12
+    d = basis.shape[-1]
+    for i in (1, 2):
+        S = g[f'{name}_S{i}']
+        assert rel_err(orc.infidelity_derivative(dF, S, omega, d),
+                       g[f'{name}_infidelity_derivative_S{i}']) < 1e-12
+        assert rel_err(orc.infidelity_derivative(dFn, S, omega, d),
+                       g[f'{name}_infidelity_derivative_ncd_S{i}']) < 1e-12
+    ci, ni = g[f'{name}_sub_c_idx'], g[f'{name}_sub_n_idx']
+    sub = orc.filter_function_derivative(*args, g[f'{name}_n_opers'][ni], g[f'{name}_n_coeffs'][ni],
+                                         g[f'{name}_c_opers'][ci], g[f'{name}_dt'])
+    assert rel_err(sub, g[f'{name}_filter_function_derivative_sub']) < 1e-12
