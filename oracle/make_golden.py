@@ -384,17 +384,17 @@ def make_second_order_concat():
 def make_gradient():
     """17. filter-function and infidelity derivatives with respect to the control amplitudes
     (reference gradient.py, PulseSequence.get_filter_function_derivative; cases of
-    tests/test_gradient.py:70-176 in small): Pauli d=2, GGM d=3, Pauli d=4 (one with an idle
-    segment); with and without n_coeffs_deriv; subsets of control and noise operators."""
+    tests/test_gradient.py:70-176 in small): Pauli d=2, GGM d=3, Pauli d=4; with and without
+    n_coeffs_deriv; subsets of control and noise operators.  (No idle segment: the reference divides
+    by the eigenvalue differences without a mask, gradient.py:176, and returns NaN for degenerate
+    spectra.)"""
     from filter_functions import gradient
     rng = np.random.default_rng(99)
     arrays = {}
     cases = [('q1', 2, 4, 2, 2, 'Pauli', False), ('g3', 3, 3, 3, 2, 'GGM', False),
-             ('p4', 4, 5, 2, 3, 'Pauli', False), ('p4idle', 4, 3, 2, 2, 'Pauli', True)]
+             ('p4', 4, 5, 2, 3, 'Pauli', False)]
     for name, d, n_dt, n_cops, n_nops, btype, idle in cases:
         pulse = rand_pulse(d, n_dt, n_cops, n_nops, btype, rng)
-        if idle:
-            pulse.c_coeffs[:, 1] = 0.0
         omega = np.sort(np.concatenate([[-4.0, 0.0], np.geomspace(2e-2, 40.0, 10)]))
         spectra = [1e-3/(1 + omega**2),
                    np.outer(np.arange(n_nops) + 1.0, 1e-3/(4 + omega**2))]

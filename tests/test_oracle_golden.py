@@ -326,7 +326,7 @@ def test_second_order_concatenation_rule(name):
     assert rel_err(F2, g[f'{name}_filter_function_2']) < 1e-13
 
 
-@pytest.mark.parametrize('name', ['q1', 'g3', 'p4', 'p4idle'])
+@pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
 def test_filter_function_and_infidelity_derivative(name):
     """Oracle (Hilbert-space form with one generator per (control, segment)) vs the reference's
     get_filter_function_derivative / gradient.infidelity_derivative."""
