@@ -13,14 +13,14 @@ The arithmetic runs in hand-written HIP kernels for gfx950 behind a C ABI
 side: the reference's object model, argument checking, caching and exceptions.
 See DESIGN.md for the scope, INTEGRATION.md for the boundary.
 """
-from . import basis, numeric, pulse_sequence, superoperator, util
+from . import basis, gradient, numeric, pulse_sequence, superoperator, util
 from .basis import Basis
 from .numeric import error_transfer_matrix, infidelity
 from .pulse_sequence import PulseSequence, concatenate, concatenate_without_filter_function
 from .superoperator import liouville_representation
 
 __all__ = ['Basis', 'PulseSequence', 'basis', 'concatenate', 'concatenate_without_filter_function',
-           'error_transfer_matrix', 'infidelity', 'liouville_representation', 'numeric',
+           'error_transfer_matrix', 'gradient', 'infidelity', 'liouville_representation', 'numeric',
            'pulse_sequence', 'superoperator', 'util']
 
 __version__ = '0.1.0'

@@ -1337,6 +1337,111 @@ int ffk_cumulant_function_second_order_dev(const double* frequency_shifts, int b
     return FFK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// gradient: derivative of the filter function / infidelity w.r.t. the control amplitudes
+// ---------------------------------------------------------------------------------------------
+int ffk_filter_function_derivative(const double* eigvals, const double* eigvecs,
+                                   const double* propagators, const double* omega, int W,
+                                   const double* n_opers, int A, const double* n_coeffs,
+                                   const double* c_opers, int H, const double* n_coeffs_ratio,
+                                   const double* dt, const double* t, int G, int d,
+                                   const double* spectrum, int s_ndim,
+                                   double* filter_function_derivative,
+                                   double* infidelity_derivative) {
+    FFK_REQUIRE(d >= 2 && d <= 8, "the gradient kernels support 2 <= d <= 8, not d=%d", d);
+    FFK_REQUIRE(W >= 1 && A >= 1 && H >= 1 && G >= 1, "empty axis: W=%d A=%d H=%d G=%d", W, A, H, G);
+    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && n_opers && n_coeffs && c_opers && dt && t,
+                "NULL argument");
+    FFK_REQUIRE(filter_function_derivative || infidelity_derivative, "no output requested");
+    FFK_REQUIRE(!infidelity_derivative || (spectrum && (s_ndim == 1 || s_ndim == 2)),
+                "infidelity derivative needs a spectrum of shape (W,) or (A, W)");
+    FFK_REQUIRE(size_t(G)*A <= 65535, "G*A = %zu too large", size_t(G)*A);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t dd = size_t(d)*d;
+    const size_t nY = size_t(G)*A*dd*W, nF = size_t(A)*G*H*W;
+    const int srows = s_ndim == 2 ? A : 1;
+    const size_t nS = infidelity_derivative ? 16*size_t(W)*srows : 0;
+    const int HA = H > A ? H : A;
+    size_t total = 0;
+    total += align_up(8*size_t(G)*d) + align_up(16*size_t(G)*dd) + align_up(16*size_t(G + 1)*dd);
+    total += align_up(8*size_t(W)) + align_up(16*size_t(A)*dd) + align_up(16*size_t(H)*dd);
+    total += align_up(8*size_t(A)*G) + align_up(8*size_t(H)*G) + align_up(8*size_t(G)) + align_up(8*size_t(G + 1));
+    total += align_up(8*size_t(A)*H*G);
+    total += 2*(align_up(8*size_t(G)*ffk::seg_stride(d)) + align_up(16*size_t(G)*dd) +
+                align_up(16*size_t(G)*(1 + HA)*dd));
+    total += align_up(16*size_t(A)*G*dd) + align_up(16*size_t(H)*G*dd) + 2*align_up(16*size_t(G)*dd);
+    total += align_up(16*size_t(H)*G*dd);                                       // E
+    total += align_up(16*nY) + align_up(8*nF) + 2*align_up(nS) + align_up(8*size_t(A)*G*H);
+    void* base;
+    if (int rc = arena_reserve(total, &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dD = a.take<double>(size_t(G)*d);
+    cplx* dV = a.take<cplx>(size_t(G)*dd);
+    cplx* dQ = a.take<cplx>(size_t(G + 1)*dd);
+    double* dom = a.take<double>(W);
+    cplx* dnop = a.take<cplx>(size_t(A)*dd);
+    cplx* dcop = a.take<cplx>(size_t(H)*dd);
+    double* dnc = a.take<double>(size_t(A)*G);
+    double* dones = a.take<double>(size_t(H)*G);
+    double* ddt = a.take<double>(G);
+    double* dtt = a.take<double>(G + 1);
+    double* dratio = a.take<double>(size_t(A)*H*G);
+    double* segtab = a.take<double>(size_t(G)*ffk::seg_stride(d));
+    cplx* Tc = a.take<cplx>(size_t(G)*dd);
+    cplx* ops = a.take<cplx>(size_t(G)*(1 + HA)*dd);
+    double* segtab2 = a.take<double>(size_t(G)*ffk::seg_stride(d));
+    cplx* Tc2 = a.take<cplx>(size_t(G)*dd);
+    cplx* ops2 = a.take<cplx>(size_t(G)*(1 + HA)*dd);
+    cplx* dnt = a.take<cplx>(size_t(A)*G*dd);
+    cplx* dabar = a.take<cplx>(size_t(H)*G*dd);
+    cplx* dep = a.take<cplx>(size_t(G)*dd);
+    cplx* dep2 = a.take<cplx>(size_t(G)*dd);
+    cplx* dE = a.take<cplx>(size_t(H)*G*dd);
+    cplx* Y = a.take<cplx>(nY);
+    double* dF = a.take<double>(nF);
+    cplx* dS = nS ? a.take<cplx>(nS/16) : nullptr;
+    cplx* dscale = nS ? a.take<cplx>(nS/16) : nullptr;
+    double* dI = a.take<double>(size_t(A)*G*H);
+    FFK_REQUIRE(dI && a.used <= g_arena.size, "internal: arena too small");
+    auto h2d = [](void* dst, const void* src, size_t n) {
+        return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, nullptr);
+    };
+    std::vector<double> ones(size_t(H)*G, 1.0);
+    FFK_HIP(h2d(dD, eigvals, 8*size_t(G)*d));
+    FFK_HIP(h2d(dV, eigvecs, 16*size_t(G)*dd));
+    FFK_HIP(h2d(dQ, propagators, 16*size_t(G + 1)*dd));
+    FFK_HIP(h2d(dom, omega, 8*size_t(W)));
+    FFK_HIP(h2d(dnop, n_opers, 16*size_t(A)*dd));
+    FFK_HIP(h2d(dcop, c_opers, 16*size_t(H)*dd));
+    FFK_HIP(h2d(dnc, n_coeffs, 8*size_t(A)*G));
+    FFK_HIP(h2d(dones, ones.data(), 8*size_t(H)*G));
+    FFK_HIP(h2d(ddt, dt, 8*size_t(G)));
+    FFK_HIP(h2d(dtt, t, 8*size_t(G + 1)));
+    if (n_coeffs_ratio) FFK_HIP(h2d(dratio, n_coeffs_ratio, 8*size_t(A)*H*G));
+    // Bbar, T (noise operators) and Abar (control operators, unit coefficients)
+    FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dnop, dnc, ddt, dtt, G, d, A, segtab, Tc, ops, dnt, dep, nullptr));
+    FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dcop, dones, ddt, dtt, G, d, H, segtab2, Tc2, ops2, dabar, dep2,
+                                 nullptr));
+    // Hilbert-space steps of the interaction-picture noise operators, one chunk per segment, then
+    // their running sums
+    ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, G);
+    FFK_HIP(ffk::launch_accumulate(dom, W, segtab, ops, G, d, A, geo, Y, nullptr));
+    FFK_HIP(ffk::launch_segment_prefix_sum(Y, G, size_t(A)*dd*W, nullptr));
+    FFK_HIP(ffk::launch_filter_function_derivative(dom, W, dD, ddt, dtt, ops, dabar, Y,
+                                                   n_coeffs_ratio ? dratio : nullptr, G, d, A, H, dE, dF,
+                                                   nullptr));
+    if (infidelity_derivative) {
+        FFK_HIP(h2d(dS, spectrum, nS));
+        FFK_HIP(ffk::launch_spectral_weights(dS, srows, W, dom, W, 0, dscale, nullptr));
+        FFK_HIP(ffk::launch_infidelity_derivative(dF, A, G, H, W, dscale, s_ndim, d, dI, nullptr));
+        FFK_HIP(hipMemcpyAsync(infidelity_derivative, dI, 8*size_t(A)*G*H, hipMemcpyDeviceToHost, nullptr));
+    }
+    if (filter_function_derivative)
+        FFK_HIP(hipMemcpyAsync(filter_function_derivative, dF, 8*nF, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
 int ffk_expm_real(const double* matrix, int N, double* result) {
     FFK_REQUIRE(matrix && result, "NULL argument");
     FFK_REQUIRE(N >= 1 && N <= 4096, "matrix dimension %d outside [1, 4096]", N);

@@ -217,6 +217,21 @@ size_t cumulant_second_order_workspace_bytes(size_t batch, int N, int d);
 hipError_t launch_cumulant_second_order(const double* delta, size_t batch, int N, int d,
                                         const cplx* basis, double* K, void* ws, hipStream_t stream);
 
+// in-place inclusive prefix sum over the G leading slabs of Y (G, slab)
+hipError_t launch_segment_prefix_sum(cplx* Y, int G, size_t slab, hipStream_t stream);
+
+// ---- grad.hip --------------------------------------------------------------------------------
+// dF (A,G,H,W) f64 from ops (G,1+A,d,d) [T_s, Bbar], abar (H,G,d,d) = V^dag A_h V, Ycum (G,A,d,d,W)
+// = prefix sums of the Hilbert-space steps, ratio (A,H,G) = n'_ahs/n_as or NULL; E (H,G,d,d) scratch
+hipError_t launch_filter_function_derivative(const double* omega, int W, const double* eigvals,
+                                             const double* dt, const double* t, const cplx* ops,
+                                             const cplx* abar, const cplx* Ycum, const double* ratio,
+                                             int G, int d, int A, int H, cplx* E, double* out,
+                                             hipStream_t stream);
+// out (A,G,H) = sum_w dF Re(scale)/d, scale from launch_spectral_weights with rows = 1 or A
+hipError_t launch_infidelity_derivative(const double* dF, int A, int G, int H, int W, const cplx* scale,
+                                        int s_ndim, int d, double* out, hipStream_t stream);
+
 // B (W,A,d,d) = B^(0) + sum_g phases[g-1] P_{g-1}^dag B^(g) P_{g-1}; atomic (G,W,A,d,d), props (G-1,d,d)
 hipError_t launch_noise_ops_from_atomic(const cplx* phases, const cplx* atomic, const cplx* props,
                                         int G, int W, int A, int d, cplx* out, hipStream_t stream);

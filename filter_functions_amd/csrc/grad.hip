@@ -1,0 +1,290 @@
+// grad.hip -- K9: derivative of the filter function with respect to the control amplitudes
+// (filter_functions/gradient.py; PulseSequence.get_filter_function_derivative,
+// pulse_sequence.py:977-1054).
+//
+// The reference builds the derivative of the control matrix, (n_ctrl, W, G, A, d^2), from (I) the
+// derivative of segment s's own contribution (_control_matrix_at_timestep_derivative, :200-381, with
+// the nested integral _derivative_integral, :69-108) and (II) the derivative of every later Liouville
+// propagator (_liouville_derivative, :111-197, contracted over all pairs of segments at :520 -- an
+// O(G^2) tensor), and contracts it with conj(R) (calculate_filter_function_derivative, :526-556).
+//
+// Here everything stays in Hilbert space.  With Y_a(w) the interaction-picture noise operator
+// (R_ak = tr(Y_a C_k), what the accumulate kernel sums), T = V_s^dag Q_s and bars denoting the
+// eigenbasis of segment s:
+//   (I)  2 Re tr(Y_a^dag Y'),  Y' = -i e^{i w t_s} T^dag G^T T,
+//        G_xy = sum_n Bbar_yn Abar_nx J(w; W_yn, W_nx) - sum_q Abar_yq Bbar_qx J(w; W_qx, W_yq),
+//        J(w; a, b) = int_0^dt dtau e^{i (w+a) tau} int_0^tau dtau' e^{i b tau'}
+//                   = (I1(w+a+b) - I1(w+a)) / (i b)            (b != 0)
+//                   = (dt e^{i (w+a) dt} - I1(w+a)) / (i (w+a))  (b == 0; dt^2/2 if w+a == 0 too),
+//        so only the d^2 first-order integrals I1(w + W_mn) of the segment are needed
+//        (W_yn + W_nx = W_yx): the same d^2 sincos per (segment, frequency) as the control matrix;
+//   (II) a later propagator changes by Q_g -> Q_g E with the SAME anti-Hermitian generator
+//        E_hs = -i T^dag (Abar_h o I1(0)) T for every g > s, so the sum over later segments collapses
+//        to -2 Re tr(E_hs [Y_a^dag, Ycum_sa]) with Ycum the steps up to and including s (the part
+//        proportional to the total Y_a drops out of the real part): O(G) instead of O(G^2);
+//   and the explicit dependence of the noise sensitivities, (n'_ahs / n_as) 2 Re tr(Y_a^dag Ystep_sa)
+//   (:376-379).
+// Pass 1 (existing kernels) leaves the per-segment steps of Y in HBM; a prefix sum turns them into
+// Ycum; this kernel: one lane per frequency, one block row per segment, everything that does not
+// depend on the frequency broadcast from LDS.
+#include "ffk_internal.h"
+
+namespace ffk {
+namespace {
+
+// E[h][s] = -i T^dag (Abar_h o I1(0)) T, one block per (s, h)
+__global__ __launch_bounds__(64) void grad_generator_kernel(const cplx* __restrict__ ops, int ops_stride,
+                                                            const cplx* __restrict__ abar,
+                                                            const double* __restrict__ eigvals,
+                                                            const double* __restrict__ dt, int G,
+                                                            int d, cplx* __restrict__ E) {
+    extern __shared__ unsigned char smem[];
+    const int d2 = d*d;
+    cplx* X = reinterpret_cast<cplx*>(smem);          // Abar o I1(0)
+    cplx* Ts = X + d2;
+    const int s = blockIdx.x, h = blockIdx.y;
+    const cplx* T = ops + static_cast<size_t>(s)*ops_stride;
+    const cplx* Ab = abar + (static_cast<size_t>(h)*G + s)*d2;
+    const double dts = dt[s];
+    for (int e = threadIdx.x; e < d2; e += 64) {
+        const int m = e / d, n = e % d;
+        const double dE = eigvals[static_cast<size_t>(s)*d + m] - eigvals[static_cast<size_t>(s)*d + n];
+        X[e] = cmul(Ab[e], first_order_integral(0.0, dE, dts));
+        Ts[e] = T[e];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < d2; e += 64) {
+        const int x = e / d, y = e % d;
+        cplx acc = {0.0, 0.0};
+        for (int m = 0; m < d; ++m) {
+            cplx row = {0.0, 0.0};
+            for (int n = 0; n < d; ++n) cmac(row, X[m*d + n], Ts[n*d + y]);
+            cmac_conj(acc, Ts[m*d + x], row);
+        }
+        E[(static_cast<size_t>(h)*G + s)*d2 + e] = {acc.im, -acc.re};      // -i acc
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void grad_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ eigvals,
+    const double* __restrict__ dt, const double* __restrict__ t, const cplx* __restrict__ ops,
+    const cplx* __restrict__ abar, const cplx* __restrict__ E, const cplx* __restrict__ Ycum,
+    const double* __restrict__ ratio, int G, int A, int H, double* __restrict__ out) {
+    constexpr int D2 = D*D;
+    constexpr int U = D <= 4 ? D : 1;          // unroll (register arrays) only where they fit
+    constexpr int U2 = D <= 4 ? D*D : 1;
+    extern __shared__ unsigned char smem[];
+    double* dE = reinterpret_cast<double*>(smem);          // [D2]  W_mn
+    double* inv = dE + D2;                                 // [D2]  1/W_mn, 0 where W_mn == 0
+    cplx* Ts = reinterpret_cast<cplx*>(inv + D2);          // [D2]
+    cplx* Bs = Ts + D2;                                    // [A][D2]
+    cplx* As = Bs + A*D2;                                  // [H][D2]
+    cplx* Es = As + H*D2;                                  // [H][D2]
+    const int s = blockIdx.y;
+    const int w = blockIdx.x*64 + threadIdx.x;
+    for (int e = threadIdx.x; e < D2; e += 64) {
+        const double v = eigvals[static_cast<size_t>(s)*D + e / D] - eigvals[static_cast<size_t>(s)*D + e % D];
+        dE[e] = v;
+        inv[e] = v == 0.0 ? 0.0 : 1.0/v;
+        Ts[e] = ops[static_cast<size_t>(s)*(1 + A)*D2 + e];
+    }
+    for (int e = threadIdx.x; e < A*D2; e += 64) Bs[e] = ops[(static_cast<size_t>(s)*(1 + A) + 1)*D2 + e];
+    for (int e = threadIdx.x; e < H*D2; e += 64) {
+        const int h = e / D2, r = e % D2;
+        As[e] = abar[(static_cast<size_t>(h)*G + s)*D2 + r];
+        Es[e] = E[(static_cast<size_t>(h)*G + s)*D2 + r];
+    }
+    __syncthreads();
+    if (w >= W) return;
+    const double om = omega[w], dts = dt[s];
+    const cplx ph = cexp(om*t[s]);
+    // I1[m][n] = I1(w + W_mn); Jd[m][n] = int_0^dt tau e^{i (w + W_mn) tau} dtau
+    cplx I1[D2], Jd[D2];
+#pragma unroll U2
+    for (int e = 0; e < D2; ++e) {
+        const double x = om + dE[e];
+        const cplx i1 = first_order_integral(om, dE[e], dts);
+        I1[e] = i1;
+        // e^{i x dt} = 1 + i x I1
+        const cplx ex = {1.0 - x*i1.im, x*i1.re};
+        cplx jd = {0.5*dts*dts, 0.0};
+        if (x != 0.0) {
+            const double rx = 1.0/x;
+            // (dt ex - I1)/(i x) = -i (dt ex - I1)/x
+            jd = {(dts*ex.im - i1.im)*rx, -(dts*ex.re - i1.re)*rx};
+        }
+        Jd[e] = jd;
+    }
+    const size_t slab = static_cast<size_t>(A)*D2*W;       // one segment of Ycum
+    for (int a = 0; a < A; ++a) {
+        const cplx* Ytot = Ycum + static_cast<size_t>(G - 1)*slab + static_cast<size_t>(a)*D2*W + w;
+        const cplx* Yc = Ycum + static_cast<size_t>(s)*slab + static_cast<size_t>(a)*D2*W + w;
+        cplx Yd[D2], Yq[D2];                               // Ytot^dag, Ycum_s
+#pragma unroll U
+        for (int x = 0; x < D; ++x)
+#pragma unroll U
+            for (int y = 0; y < D; ++y) {
+                const cplx v = Ytot[static_cast<size_t>(y*D + x)*W];
+                Yd[x*D + y] = {v.re, -v.im};
+                Yq[x*D + y] = Yc[static_cast<size_t>(x*D + y)*W];
+            }
+        // Wa = T Yd T^dag,  comm = Yd Ycum - Ycum Yd
+        cplx Wa[D2], comm[D2];
+        {
+            cplx tmp[D2];
+#pragma unroll U
+            for (int x = 0; x < D; ++x)
+#pragma unroll U
+                for (int y = 0; y < D; ++y) {
+                    cplx acc = {0.0, 0.0}, c = {0.0, 0.0};
+#pragma unroll U
+                    for (int k = 0; k < D; ++k) {
+                        const cplx ty = Ts[y*D + k];
+                        cmac(acc, Yd[x*D + k], cplx{ty.re, -ty.im});       // (Yd T^dag)[x][y]
+                        cmac(c, Yd[x*D + k], Yq[k*D + y]);
+                        const cplx p = cmul(Yq[x*D + k], Yd[k*D + y]);
+                        c.re -= p.re;
+                        c.im -= p.im;
+                    }
+                    tmp[x*D + y] = acc;
+                    comm[x*D + y] = c;
+                }
+#pragma unroll U
+            for (int x = 0; x < D; ++x)
+#pragma unroll U
+                for (int y = 0; y < D; ++y) {
+                    cplx acc = {0.0, 0.0};
+#pragma unroll U
+                    for (int k = 0; k < D; ++k) cmac(acc, Ts[x*D + k], tmp[k*D + y]);
+                    Wa[x*D + y] = acc;
+                }
+        }
+        // explicit sensitivity term: 2 Re tr(Yd Ystep), Ystep = Ycum_s - Ycum_{s-1}
+        double tr_step = 0.0;
+        if (ratio) {
+            const cplx* Yp = Yc - slab;
+#pragma unroll U
+            for (int x = 0; x < D; ++x)
+#pragma unroll U
+                for (int y = 0; y < D; ++y) {
+                    cplx st = Yq[y*D + x];
+                    if (s > 0) {
+                        const cplx pv = Yp[static_cast<size_t>(y*D + x)*W];
+                        st.re -= pv.re;
+                        st.im -= pv.im;
+                    }
+                    tr_step += Yd[x*D + y].re*st.re - Yd[x*D + y].im*st.im;
+                }
+            tr_step *= 2.0;
+        }
+        const cplx* Bb = Bs + a*D2;
+        for (int h = 0; h < H; ++h) {
+            const cplx* Ab = As + h*D2;
+            const cplx* Eh = Es + h*D2;
+            double second = 0.0;
+            cplx first = {0.0, 0.0};
+#pragma unroll U
+            for (int x = 0; x < D; ++x)
+#pragma unroll U
+                for (int y = 0; y < D; ++y) {
+                    const cplx c = comm[y*D + x], e = Eh[x*D + y];
+                    second += e.re*c.re - e.im*c.im;
+                    // G_xy
+                    cplx g = {0.0, 0.0};
+                    const cplx iyx = I1[y*D + x];
+#pragma unroll U
+                    for (int n = 0; n < D; ++n) {
+                        // + Bbar_yn Abar_nx J(w; W_yn, W_nx)
+                        const double r1 = inv[n*D + x];
+                        cplx j1 = Jd[y*D + n];
+                        if (r1 != 0.0) {
+                            const cplx df = {iyx.re - I1[y*D + n].re, iyx.im - I1[y*D + n].im};
+                            j1 = {df.im*r1, -df.re*r1};                     // df/(i W_nx)
+                        }
+                        cmac(g, cmul(Bb[y*D + n], Ab[n*D + x]), j1);
+                        // - Abar_yn Bbar_nx J(w; W_nx, W_yn)
+                        const double r2 = inv[y*D + n];
+                        cplx j2 = Jd[n*D + x];
+                        if (r2 != 0.0) {
+                            const cplx df = {iyx.re - I1[n*D + x].re, iyx.im - I1[n*D + x].im};
+                            j2 = {df.im*r2, -df.re*r2};
+                        }
+                        const cplx ab = cmul(Ab[y*D + n], Bb[n*D + x]);
+                        cmac(g, cplx{-ab.re, -ab.im}, j2);
+                    }
+                    cmac(first, Wa[x*D + y], g);
+                }
+            // 2 Re(-i ph first) = 2 Im(ph first)
+            const cplx pf = cmul(ph, first);
+            double val = 2.0*pf.im - 2.0*second;
+            if (ratio) val += ratio[(static_cast<size_t>(a)*H + h)*G + s]*tr_step;
+            out[((static_cast<size_t>(a)*G + s)*H + h)*W + w] = val;
+        }
+    }
+}
+
+// out[row] = sum_w dF[row, w] * Re(scale[srow(row), w]) / d, rows = (a, s, h)
+__global__ __launch_bounds__(256) void grad_integrate_kernel(const double* __restrict__ dF, int GH,
+                                                             int W, const cplx* __restrict__ scale,
+                                                             int s_ndim, double inv_d,
+                                                             double* __restrict__ out) {
+    const size_t row = blockIdx.x;
+    const cplx* sc = scale + (s_ndim == 2 ? (row / GH)*static_cast<size_t>(W) : 0);
+    const double* f = dF + row*W;
+    double sum = 0.0;
+    for (int w = threadIdx.x; w < W; w += 256) sum += f[w]*sc[w].re;
+    __shared__ double red[256];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[row] = red[0]*inv_d;
+}
+
+template <int D>
+hipError_t launch_grad(const double* omega, int W, const double* eigvals, const double* dt,
+                       const double* t, const cplx* ops, const cplx* abar, const cplx* E,
+                       const cplx* Ycum, const double* ratio, int G, int A, int H, double* out,
+                       hipStream_t stream) {
+    const size_t lds = 2*D*D*sizeof(double) + size_t(1 + A + 2*H)*D*D*sizeof(cplx);
+    if (lds > 64*1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((grad_kernel<D>), dim3((W + 63)/64, G), dim3(64), lds, stream, omega, W, eigvals,
+                       dt, t, ops, abar, E, Ycum, ratio, G, A, H, out);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_filter_function_derivative(const double* omega, int W, const double* eigvals,
+                                             const double* dt, const double* t, const cplx* ops,
+                                             const cplx* abar, const cplx* Ycum, const double* ratio,
+                                             int G, int d, int A, int H, cplx* E, double* out,
+                                             hipStream_t stream) {
+    if (d < 2 || d > 8 || G > 65535 || H > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(grad_generator_kernel, dim3(G, H), dim3(64), 2*d*d*sizeof(cplx), stream, ops,
+                       (1 + A)*d*d, abar, eigvals, dt, G, d, E);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    switch (d) {
+#define FFK_GRAD_CASE(D) \
+    case D: return launch_grad<D>(omega, W, eigvals, dt, t, ops, abar, E, Ycum, ratio, G, A, H, out, stream);
+        FFK_GRAD_CASE(2) FFK_GRAD_CASE(3) FFK_GRAD_CASE(4) FFK_GRAD_CASE(5)
+        FFK_GRAD_CASE(6) FFK_GRAD_CASE(7) FFK_GRAD_CASE(8)
+#undef FFK_GRAD_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_infidelity_derivative(const double* dF, int A, int G, int H, int W, const cplx* scale,
+                                        int s_ndim, int d, double* out, hipStream_t stream) {
+    const size_t rows = static_cast<size_t>(A)*G*H;
+    if (rows > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(grad_integrate_kernel, dim3(static_cast<unsigned>(rows)), dim3(256), 0, stream,
+                       dF, G*H, W, scale, s_ndim, 1.0/d, out);
+    return hipGetLastError();
+}
+
+}  // namespace ffk

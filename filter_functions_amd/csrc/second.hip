@@ -632,8 +632,8 @@ __global__ __launch_bounds__(256) void cumulant_second_order_kernel(const double
 // (The reference re-evaluates the incomplete steps from its W d^4 integral caches instead; the
 // rotated form needs only each pulse's F2.)  One lane per frequency, one (a, b, k, 16 values of l)
 // per thread; the Liouville entries are wave-uniform (scalar loads).
-__global__ __launch_bounds__(64) void so_cumulative_kernel(const cplx* __restrict__ step, int G,
-                                                           size_t slab, cplx* __restrict__ cum) {
+__global__ __launch_bounds__(64) void so_cumulative_kernel(const cplx* step, int G, size_t slab,
+                                                           cplx* cum) {      // cum may alias step
     const size_t e = static_cast<size_t>(blockIdx.x)*64 + threadIdx.x;
     if (e >= slab) return;
     cplx acc = {0.0, 0.0};
@@ -701,6 +701,13 @@ __global__ __launch_bounds__(64) void so_concat_kernel(const cplx* __restrict__ 
 }
 
 }  // namespace
+
+hipError_t launch_segment_prefix_sum(cplx* Y, int G, size_t slab, hipStream_t stream) {
+    if ((slab + 63)/64 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(so_cumulative_kernel, dim3(static_cast<unsigned>((slab + 63)/64)), dim3(64), 0,
+                       stream, Y, G, slab, Y);
+    return hipGetLastError();
+}
 
 size_t second_order_from_atomic_workspace_bytes(int G, int A, int N, int W) {
     return align_up(sizeof(cplx)*size_t(G)*A*N*W);

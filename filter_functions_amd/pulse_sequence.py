@@ -386,6 +386,15 @@ class PulseSequence:
             self._frequency_data['filter_function'] = filter_function.trace(axis1=2, axis2=3)
             self._frequency_data['filter_function_gen'] = filter_function
 
+    def get_filter_function_derivative(self, omega, control_identifiers=None,
+                                       n_oper_identifiers=None, n_coeffs_deriv=None):
+        """Derivative of the filter function by the control amplitudes, shape (n_nops, n_dt,
+        n_ctrl, n_omega) (reference pulse_sequence.py:977-1054); see
+        :func:`filter_functions_amd.gradient.filter_function_derivative`."""
+        from . import gradient
+        return gradient.filter_function_derivative(self, omega, control_identifiers,
+                                                   n_oper_identifiers, n_coeffs_deriv)
+
     @util.parse_optional_parameters(which=('fidelity', 'generalized'))
     def get_pulse_correlation_filter_function(self, which='fidelity'):
         key = 'filter_function_pc' if which == 'fidelity' else 'filter_function_pc_gen'

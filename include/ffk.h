@@ -323,6 +323,25 @@ int ffk_cumulant_function_second_order_dev(const double* frequency_shifts, int b
                                            const double* basis, double* cumulant_function,
                                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- gradient (filter_functions/gradient.py; PulseSequence.get_filter_function_derivative,
+ *      pulse_sequence.py:977-1054; gradient.infidelity_derivative, gradient.py:559-676) ----------
+ * Derivative of the fidelity filter function of each noise operator with respect to the amplitude
+ * of control operator h during segment s: filter_function_derivative (A, G, H, W) f64 (the
+ * reference's (n_nops, n_dt, n_ctrl, n_omega)); infidelity_derivative (A, G, H) f64 =
+ * int dw/(2 pi d) S_a(w) dF_a/du_h(t_s) for a spectrum (W,) or (A, W) c128 (s_ndim 1, 2).  Either
+ * output may be NULL.  c_opers (H, d, d) c128: the control operators to differentiate by (the
+ * eigensystem is that of the full control Hamiltonian); n_coeffs_ratio (A, H, G) f64 or NULL:
+ * (d n_coeffs[a, s] / d u_h(t_s)) / n_coeffs[a, s], the explicit dependence of the noise
+ * sensitivities on the controls (gradient.py:376-379).  Supports 2 <= d <= 8.                  */
+int ffk_filter_function_derivative(const double* eigvals, const double* eigvecs,
+                                   const double* propagators, const double* omega, int W,
+                                   const double* n_opers, int A, const double* n_coeffs,
+                                   const double* c_opers, int H, const double* n_coeffs_ratio,
+                                   const double* dt, const double* t, int G, int d,
+                                   const double* spectrum, int s_ndim,
+                                   double* filter_function_derivative,
+                                   double* infidelity_derivative);
+
 /* ---- exp of the summed cumulant function (numeric.error_transfer_matrix, numeric.py:2049-2053;
  *      the reference calls scipy.linalg.expm) ---------------------------------------------------
  * matrix (N, N) f64 row-major -> result (N, N) = exp(matrix): scaling and squaring with a Taylor

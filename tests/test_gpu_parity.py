@@ -13,7 +13,7 @@ import pytest
 import ff_oracle as orc
 import filter_functions_amd as ff
 from conftest import load_golden, rel_err
-from filter_functions_amd import _lib, numeric, util
+from filter_functions_amd import _lib, gradient, numeric, util
 
 pytestmark = pytest.mark.gpu
 
@@ -1436,3 +1436,95 @@ def test_second_order_concatenation(name):
     with pytest.warns(UserWarning):
         mixed = ff.concatenate([p0, other], calc_second_order_FF=True, omega=omega)
     assert not mixed.is_cached('filter_function_2')
+
+
+# ---- gradient: derivative of the filter function / infidelity by the control amplitudes ----------
+@pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
+def test_filter_function_and_infidelity_derivative_against_reference(name):
+    """get_filter_function_derivative / gradient.infidelity_derivative against the reference's
+    outputs (gradient.py; cases of the reference's tests/test_gradient.py:70-176): all controls and
+    noise operators, subsets selected by identifiers, with and without n_coeffs_deriv."""
+    g = load_golden('gradient')
+    pulse = etm_pulse(g, name)
+    omega = g[f'{name}_omega']
+    dF = pulse.get_filter_function_derivative(omega)
+    ref = g[f'{name}_filter_function_derivative']
+    assert dF.shape == ref.shape and dF.dtype == np.float64
+    assert rel_err(dF, ref) < TOL
+    ncd = g[f'{name}_n_coeffs_deriv']
+    assert rel_err(pulse.get_filter_function_derivative(omega, n_coeffs_deriv=ncd),
+                   g[f'{name}_filter_function_derivative_ncd']) < TOL
+    for i in (1, 2):
+        S = g[f'{name}_S{i}']
+        assert rel_err(gradient.infidelity_derivative(pulse, S, omega),
+                       g[f'{name}_infidelity_derivative_S{i}']) < TOL
+        assert rel_err(gradient.infidelity_derivative(pulse, S, omega, n_coeffs_deriv=ncd),
+                       g[f'{name}_infidelity_derivative_ncd_S{i}']) < TOL
+    c_sub = pulse.c_oper_identifiers[g[f'{name}_sub_c_idx']]
+    n_sub = pulse.n_oper_identifiers[g[f'{name}_sub_n_idx']]
+    sub = pulse.get_filter_function_derivative(omega, control_identifiers=c_sub,
+                                               n_oper_identifiers=n_sub)
+    assert rel_err(sub, g[f'{name}_filter_function_derivative_sub']) < TOL
+    with pytest.raises(ValueError):
+        pulse.get_filter_function_derivative(omega, n_coeffs_deriv=ncd[:, :1])
+
+
+@pytest.mark.parametrize('seed', range(4))
+def test_gradient_random_shapes_against_oracle_and_finite_differences(seed):
+    """Random shapes (d = 2..8, idle segments with degenerate spectra, w = 0 and negative
+    frequencies) against the oracle; and the analytic infidelity gradient against central finite
+    differences of the device infidelity (reference tests/test_gradient.py:158-176)."""
+    rng = np.random.default_rng(4200 + seed)
+    for _ in range(3):
+        d = int(rng.integers(2, 9))
+        G = int(rng.integers(1, 7))
+        A, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        W = int(rng.choice([1, 9, 64, 70]))
+
+        def herm(n):
+            M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+            return M + M.conj().transpose(0, 2, 1)
+        c_opers, n_opers = herm(H), herm(A)
+        c_coeffs = rng.standard_normal((H, G))
+        if G > 2:
+            c_coeffs[:, 1] = 0.0                                   # idle segment
+        n_coeffs = rng.random((A, G)) + 0.1
+        dt = rng.random(G) + 0.2
+        omega = np.sort(rng.random(W))*10 - 2.0
+        if W > 2:
+            omega[W//2] = 0.0
+        pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt,
+                                 ff.Basis.ggm(d))
+        dF = pulse.get_filter_function_derivative(omega)
+        Hm = orc.hamiltonian(pulse.c_opers, pulse.c_coeffs)
+        D, V, Q = orc.diagonalize(Hm, dt)
+        ref = orc.filter_function_derivative(D, V, Q, omega, np.asarray(pulse.basis), pulse.n_opers,
+                                             pulse.n_coeffs, pulse.c_opers, dt)
+        tag = f'd={d} G={G} A={A} H={H} W={W}'
+        assert rel_err(dF, ref) < TOL, tag
+    # finite differences of the infidelity
+    d, G = 3, 4
+    c_opers, n_opers = herm(2)[:, :d, :d], herm(2)[:, :d, :d]
+    c_opers = (c_opers + c_opers.conj().transpose(0, 2, 1))/2
+    n_opers = (n_opers + n_opers.conj().transpose(0, 2, 1))/2
+    c_coeffs = rng.standard_normal((2, G))
+    n_coeffs = rng.random((2, G)) + 0.5
+    dt = rng.random(G) + 0.3
+    omega = np.geomspace(1e-2, 30, 200)
+    S = 1e-2/omega
+
+    def infid(cc):
+        p = ff.PulseSequence(list(zip(c_opers, cc)), list(zip(n_opers, n_coeffs)), dt, ff.Basis.ggm(d))
+        return ff.infidelity(p, S, omega)
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt,
+                             ff.Basis.ggm(d))
+    grad = gradient.infidelity_derivative(pulse, S, omega)            # (A, G, H)
+    eps = 1e-6
+    order = np.argsort(np.argsort(pulse.c_oper_identifiers))
+    for s in range(G):
+        for h in range(2):
+            cp, cm = c_coeffs.copy(), c_coeffs.copy()
+            cp[h, s] += eps
+            cm[h, s] -= eps
+            fd = (infid(cp) - infid(cm))/(2*eps)
+            assert np.allclose(grad[:, s, order[h]], fd, rtol=1e-5, atol=1e-9), (s, h)
