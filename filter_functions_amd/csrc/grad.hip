@@ -72,8 +72,12 @@ __global__ __launch_bounds__(64) void grad_kernel(
     const cplx* __restrict__ abar, const cplx* __restrict__ E, const cplx* __restrict__ Ycum,
     const double* __restrict__ ratio, int G, int A, int H, double* __restrict__ out) {
     constexpr int D2 = D*D;
-    constexpr int U = D <= 4 ? D : 1;          // unroll (register arrays) only where they fit
-    constexpr int U2 = D <= 4 ? D*D : 1;
+#if defined(FFK_GRAD_UNROLL_MAX)
+    constexpr int kUnrollMax = FFK_GRAD_UNROLL_MAX;
+#else
+    constexpr int kUnrollMax = 4;
+#endif
+    constexpr int U = D <= kUnrollMax ? D : 1;  // unroll (register arrays) only where they fit
     extern __shared__ unsigned char smem[];
     double* dE = reinterpret_cast<double*>(smem);          // [D2]  W_mn
     double* inv = dE + D2;                                 // [D2]  1/W_mn, 0 where W_mn == 0
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(64) void grad_kernel(
     cplx* Bs = Ts + D2;                                    // [A][D2]
     cplx* As = Bs + A*D2;                                  // [H][D2]
     cplx* Es = As + H*D2;                                  // [H][D2]
+    double* sec = reinterpret_cast<double*>(Es + H*D2);    // [H][64]  per-lane Re tr(E_h comm)
     const int s = blockIdx.y;
     const int w = blockIdx.x*64 + threadIdx.x;
     for (int e = threadIdx.x; e < D2; e += 64) {
@@ -99,56 +104,89 @@ __global__ __launch_bounds__(64) void grad_kernel(
     if (w >= W) return;
     const double om = omega[w], dts = dt[s];
     const cplx ph = cexp(om*t[s]);
-    // I1[m][n] = I1(w + W_mn); Jd[m][n] = int_0^dt tau e^{i (w + W_mn) tau} dtau
-    cplx I1[D2], Jd[D2];
-#pragma unroll U2
-    for (int e = 0; e < D2; ++e) {
+    // I1[m][n] = I1(w + W_mn) and, further down, Wa: per-lane columns in LDS for D <= 4 (dynamic
+    // indexing without scratch), thread-local arrays (scratch) above
+    constexpr bool kLds = D <= 4;
+    cplx I1loc[kLds ? 1 : D2], Waloc[kLds ? 1 : D2];
+    cplx* I1 = kLds ? reinterpret_cast<cplx*>(sec + H*64) + threadIdx.x : I1loc;
+    cplx* Wa = kLds ? reinterpret_cast<cplx*>(sec + H*64) + D2*64 + threadIdx.x : Waloc;
+    constexpr int LS = kLds ? 64 : 1;           // element stride of the two arrays
+#pragma unroll 1
+    for (int e = 0; e < D2; ++e) I1[e*LS] = first_order_integral(om, dE[e], dts);
+    // int_0^dt tau e^{i x tau} dtau, x = w + W_e, from I1(x): the b == 0 branch of J
+    auto nested = [&](cplx i1, int e) {
         const double x = om + dE[e];
-        const cplx i1 = first_order_integral(om, dE[e], dts);
-        I1[e] = i1;
-        // e^{i x dt} = 1 + i x I1
-        const cplx ex = {1.0 - x*i1.im, x*i1.re};
+        const cplx ex = {1.0 - x*i1.im, x*i1.re};                  // e^{i x dt} = 1 + i x I1
         cplx jd = {0.5*dts*dts, 0.0};
         if (x != 0.0) {
             const double rx = 1.0/x;
-            // (dt ex - I1)/(i x) = -i (dt ex - I1)/x
-            jd = {(dts*ex.im - i1.im)*rx, -(dts*ex.re - i1.re)*rx};
+            jd = {(dts*ex.im - i1.im)*rx, -(dts*ex.re - i1.re)*rx};   // (dt ex - I1)/(i x)
         }
-        Jd[e] = jd;
-    }
+        return jd;
+    };
     const size_t slab = static_cast<size_t>(A)*D2*W;       // one segment of Ycum
     for (int a = 0; a < A; ++a) {
         const cplx* Ytot = Ycum + static_cast<size_t>(G - 1)*slab + static_cast<size_t>(a)*D2*W + w;
         const cplx* Yc = Ycum + static_cast<size_t>(s)*slab + static_cast<size_t>(a)*D2*W + w;
-        cplx Yd[D2], Yq[D2];                               // Ytot^dag, Ycum_s
-#pragma unroll U
-        for (int x = 0; x < D; ++x)
-#pragma unroll U
-            for (int y = 0; y < D; ++y) {
-                const cplx v = Ytot[static_cast<size_t>(y*D + x)*W];
-                Yd[x*D + y] = {v.re, -v.im};
-                Yq[x*D + y] = Yc[static_cast<size_t>(x*D + y)*W];
-            }
-        // Wa = T Yd T^dag,  comm = Yd Ycum - Ycum Yd
-        cplx Wa[D2], comm[D2];
+        double tr_step = 0.0;
         {
-            cplx tmp[D2];
+            cplx Yd[D2], Yq[D2];                           // Ytot^dag, Ycum_s
 #pragma unroll U
             for (int x = 0; x < D; ++x)
 #pragma unroll U
                 for (int y = 0; y < D; ++y) {
-                    cplx acc = {0.0, 0.0}, c = {0.0, 0.0};
+                    const cplx v = Ytot[static_cast<size_t>(y*D + x)*W];
+                    Yd[x*D + y] = {v.re, -v.im};
+                    Yq[x*D + y] = Yc[static_cast<size_t>(x*D + y)*W];
+                }
+            // (II): sec[h] = Re tr(E_h [Yd, Ycum])
+            for (int h = 0; h < H; ++h) sec[h*64 + threadIdx.x] = 0.0;
+#pragma unroll U
+            for (int x = 0; x < D; ++x)
+#pragma unroll U
+                for (int y = 0; y < D; ++y) {
+                    cplx c = {0.0, 0.0};                   // comm[y][x]
+#pragma unroll U
+                    for (int k = 0; k < D; ++k) {
+                        cmac(c, Yd[y*D + k], Yq[k*D + x]);
+                        const cplx p = cmul(Yq[y*D + k], Yd[k*D + x]);
+                        c.re -= p.re;
+                        c.im -= p.im;
+                    }
+                    for (int h = 0; h < H; ++h) {
+                        const cplx e = Es[h*D2 + x*D + y];
+                        sec[h*64 + threadIdx.x] += e.re*c.re - e.im*c.im;
+                    }
+                }
+            // explicit sensitivity term: 2 Re tr(Yd Ystep), Ystep = Ycum_s - Ycum_{s-1}
+            if (ratio) {
+                const cplx* Yp = Yc - slab;
+#pragma unroll U
+                for (int x = 0; x < D; ++x)
+#pragma unroll U
+                    for (int y = 0; y < D; ++y) {
+                        cplx st = Yq[y*D + x];
+                        if (s > 0) {
+                            const cplx pv = Yp[static_cast<size_t>(y*D + x)*W];
+                            st.re -= pv.re;
+                            st.im -= pv.im;
+                        }
+                        tr_step += Yd[x*D + y].re*st.re - Yd[x*D + y].im*st.im;
+                    }
+                tr_step *= 2.0;
+            }
+            // Wa = T Yd T^dag (Yq's registers are free from here on)
+#pragma unroll U
+            for (int x = 0; x < D; ++x)
+#pragma unroll U
+                for (int y = 0; y < D; ++y) {
+                    cplx acc = {0.0, 0.0};
 #pragma unroll U
                     for (int k = 0; k < D; ++k) {
                         const cplx ty = Ts[y*D + k];
                         cmac(acc, Yd[x*D + k], cplx{ty.re, -ty.im});       // (Yd T^dag)[x][y]
-                        cmac(c, Yd[x*D + k], Yq[k*D + y]);
-                        const cplx p = cmul(Yq[x*D + k], Yd[k*D + y]);
-                        c.re -= p.re;
-                        c.im -= p.im;
                     }
-                    tmp[x*D + y] = acc;
-                    comm[x*D + y] = c;
+                    Yq[x*D + y] = acc;
                 }
 #pragma unroll U
             for (int x = 0; x < D; ++x)
@@ -156,68 +194,52 @@ __global__ __launch_bounds__(64) void grad_kernel(
                 for (int y = 0; y < D; ++y) {
                     cplx acc = {0.0, 0.0};
 #pragma unroll U
-                    for (int k = 0; k < D; ++k) cmac(acc, Ts[x*D + k], tmp[k*D + y]);
-                    Wa[x*D + y] = acc;
+                    for (int k = 0; k < D; ++k) cmac(acc, Ts[x*D + k], Yq[k*D + y]);
+                    Wa[(x*D + y)*LS] = acc;
                 }
-        }
-        // explicit sensitivity term: 2 Re tr(Yd Ystep), Ystep = Ycum_s - Ycum_{s-1}
-        double tr_step = 0.0;
-        if (ratio) {
-            const cplx* Yp = Yc - slab;
-#pragma unroll U
-            for (int x = 0; x < D; ++x)
-#pragma unroll U
-                for (int y = 0; y < D; ++y) {
-                    cplx st = Yq[y*D + x];
-                    if (s > 0) {
-                        const cplx pv = Yp[static_cast<size_t>(y*D + x)*W];
-                        st.re -= pv.re;
-                        st.im -= pv.im;
-                    }
-                    tr_step += Yd[x*D + y].re*st.re - Yd[x*D + y].im*st.im;
-                }
-            tr_step *= 2.0;
         }
         const cplx* Bb = Bs + a*D2;
         for (int h = 0; h < H; ++h) {
             const cplx* Ab = As + h*D2;
-            const cplx* Eh = Es + h*D2;
-            double second = 0.0;
             cplx first = {0.0, 0.0};
-#pragma unroll U
+#pragma unroll 1
             for (int x = 0; x < D; ++x)
-#pragma unroll U
+#pragma unroll 1
                 for (int y = 0; y < D; ++y) {
-                    const cplx c = comm[y*D + x], e = Eh[x*D + y];
-                    second += e.re*c.re - e.im*c.im;
                     // G_xy
                     cplx g = {0.0, 0.0};
-                    const cplx iyx = I1[y*D + x];
+                    const cplx iyx = I1[(y*D + x)*LS];
 #pragma unroll U
                     for (int n = 0; n < D; ++n) {
                         // + Bbar_yn Abar_nx J(w; W_yn, W_nx)
                         const double r1 = inv[n*D + x];
-                        cplx j1 = Jd[y*D + n];
+                        const cplx iyn = I1[(y*D + n)*LS];
+                        cplx j1;
                         if (r1 != 0.0) {
-                            const cplx df = {iyx.re - I1[y*D + n].re, iyx.im - I1[y*D + n].im};
+                            const cplx df = {iyx.re - iyn.re, iyx.im - iyn.im};
                             j1 = {df.im*r1, -df.re*r1};                     // df/(i W_nx)
+                        } else {
+                            j1 = nested(iyn, y*D + n);
                         }
                         cmac(g, cmul(Bb[y*D + n], Ab[n*D + x]), j1);
                         // - Abar_yn Bbar_nx J(w; W_nx, W_yn)
                         const double r2 = inv[y*D + n];
-                        cplx j2 = Jd[n*D + x];
+                        const cplx inx = I1[(n*D + x)*LS];
+                        cplx j2;
                         if (r2 != 0.0) {
-                            const cplx df = {iyx.re - I1[n*D + x].re, iyx.im - I1[n*D + x].im};
+                            const cplx df = {iyx.re - inx.re, iyx.im - inx.im};
                             j2 = {df.im*r2, -df.re*r2};
+                        } else {
+                            j2 = nested(inx, n*D + x);
                         }
                         const cplx ab = cmul(Ab[y*D + n], Bb[n*D + x]);
                         cmac(g, cplx{-ab.re, -ab.im}, j2);
                     }
-                    cmac(first, Wa[x*D + y], g);
+                    cmac(first, Wa[(x*D + y)*LS], g);
                 }
             // 2 Re(-i ph first) = 2 Im(ph first)
             const cplx pf = cmul(ph, first);
-            double val = 2.0*pf.im - 2.0*second;
+            double val = 2.0*pf.im - 2.0*sec[h*64 + threadIdx.x];
             if (ratio) val += ratio[(static_cast<size_t>(a)*H + h)*G + s]*tr_step;
             out[((static_cast<size_t>(a)*G + s)*H + h)*W + w] = val;
         }
@@ -249,7 +271,8 @@ hipError_t launch_grad(const double* omega, int W, const double* eigvals, const 
                        const double* t, const cplx* ops, const cplx* abar, const cplx* E,
                        const cplx* Ycum, const double* ratio, int G, int A, int H, double* out,
                        hipStream_t stream) {
-    const size_t lds = 2*D*D*sizeof(double) + size_t(1 + A + 2*H)*D*D*sizeof(cplx);
+    const size_t lds = 2*D*D*sizeof(double) + size_t(1 + A + 2*H)*D*D*sizeof(cplx) +
+                       size_t(H)*64*sizeof(double) + (D <= 4 ? 2*size_t(D*D)*64*sizeof(cplx) : 0);
     if (lds > 64*1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL((grad_kernel<D>), dim3((W + 63)/64, G), dim3(64), lds, stream, omega, W, eigvals,
                        dt, t, ops, abar, E, Ycum, ratio, G, A, H, out);

@@ -53,7 +53,8 @@ def _derivative(pulse, omega, control_identifiers, n_oper_identifiers, n_coeffs_
     ratio = None
     if n_coeffs_deriv is not None:
         ratio = as_f64(np.asarray(n_coeffs_deriv, dtype=float)/s[:, None, :])
-    dF = np.empty((A, G, H, W), dtype=np.float64)
+    # the filter-function derivative crosses PCIe only if it is what was asked for
+    dF = np.empty((A, G, H, W), dtype=np.float64) if spectrum is None else None
     dI = None
     S = None
     if spectrum is not None:
@@ -71,8 +72,8 @@ def _derivative(pulse, omega, control_identifiers, n_oper_identifiers, n_coeffs_
     check(_lib.load().ffk_filter_function_derivative(
         ptr(D), ptr(V), ptr(Q), ptr(omega), W, ptr(B), A, ptr(s), ptr(C), H,
         ptr(ratio) if ratio is not None else None, ptr(dt), ptr(t), G, d,
-        ptr(S) if S is not None else None, S.ndim if S is not None else 0, ptr(dF),
-        ptr(dI) if dI is not None else None))
+        ptr(S) if S is not None else None, S.ndim if S is not None else 0,
+        ptr(dF) if dF is not None else None, ptr(dI) if dI is not None else None))
     return dF, dI
 
 
