@@ -16,10 +16,12 @@ See DESIGN.md for the scope, INTEGRATION.md for the boundary.
 from . import basis, gradient, numeric, pulse_sequence, superoperator, util
 from .basis import Basis
 from .numeric import error_transfer_matrix, infidelity
-from .pulse_sequence import PulseSequence, concatenate, concatenate_without_filter_function
+from .pulse_sequence import (PulseSequence, concatenate, concatenate_periodic,
+                             concatenate_without_filter_function)
 from .superoperator import liouville_representation
 
-__all__ = ['Basis', 'PulseSequence', 'basis', 'concatenate', 'concatenate_without_filter_function',
+__all__ = ['Basis', 'PulseSequence', 'basis', 'concatenate', 'concatenate_periodic',
+           'concatenate_without_filter_function',
            'error_transfer_matrix', 'gradient', 'infidelity', 'liouville_representation', 'numeric',
            'pulse_sequence', 'superoperator', 'util']
 

@@ -742,3 +742,39 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
             control_matrix = control_matrix.sum(axis=0)
     newpulse.cache_filter_function(omega, control_matrix, which=which)
     return newpulse
+
+
+def concatenate_periodic(pulse, repeats, check_invertible=True):
+    r"""Concatenate *repeats* periods of *pulse* (reference pulse_sequence.py:1890-1973).  If the
+    pulse has a cached control matrix, the new pulse's filter function is computed too.
+
+    The reference sums the geometric series :math:`\tilde{\mathcal B}^{(1)}\sum_g(e^{i\omega T}
+    \mathcal Q^{(1)})^g` in closed form with one matrix inverse per frequency (and falls back to
+    the plain sum where the inverse fails, *check_invertible*); here the sum itself runs on the
+    device through the gather-from-table concatenation kernel (one control-matrix table, *repeats*
+    positions), which needs no inverse and no fallback -- *check_invertible* is accepted and
+    ignored."""
+    if not isinstance(pulse, PulseSequence):
+        raise TypeError('Can only concatenate PulseSequences!')
+    repeats = int(repeats)
+    newpulse = PulseSequence.from_arrays(
+        c_opers=pulse.c_opers, c_oper_identifiers=pulse.c_oper_identifiers,
+        c_coeffs=np.tile(pulse.c_coeffs, (1, repeats)),
+        n_opers=pulse.n_opers, n_oper_identifiers=pulse.n_oper_identifiers,
+        n_coeffs=np.tile(pulse.n_coeffs, (1, repeats)),
+        dt=np.tile(pulse.dt, repeats), basis=pulse.basis)
+    newpulse.tau = repeats*pulse.tau
+    if not pulse.is_cached('control_matrix'):
+        return newpulse
+    omega = pulse.omega
+    newpulse.total_propagator = np.linalg.matrix_power(pulse.total_propagator, repeats)
+    newpulse.cache_total_phases(omega)
+    # cumulative Liouville propagators L, L^2, ..., L^(repeats-1)
+    L = np.asarray(pulse.total_propagator_liouville)
+    propagators_liouville = util.adot(np.broadcast_to(L, (max(repeats - 1, 0),) + L.shape)) \
+        if repeats > 1 else np.empty((0,) + L.shape, dtype=L.dtype)
+    control_matrix = numeric.calculate_control_matrix_from_atomic_indexed(
+        pulse.get_total_phases(omega)[None], pulse.get_control_matrix(omega)[None],
+        np.zeros(repeats, dtype=np.int32), propagators_liouville)
+    newpulse.cache_filter_function(omega, control_matrix)
+    return newpulse

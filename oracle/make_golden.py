@@ -423,7 +423,31 @@ def make_gradient():
     save('gradient', **arrays)
 
 
+def make_periodic():
+    """18. concatenate_periodic (reference pulse_sequence.py:1890-1973 with
+    numeric.calculate_control_matrix_periodic): a short pulse repeated 1, 2 and 9 times; cases of
+    tests/test_sequencing.py (periodic) in small."""
+    rng = np.random.default_rng(111)
+    arrays = {}
+    for name, d, btype in [('q1', 2, 'Pauli'), ('g3', 3, 'GGM'), ('p4', 4, 'Pauli')]:
+        pulse = rand_pulse(d, 3, 2, 2, btype, rng)
+        omega = np.sort(np.concatenate([[-1.5, 0.0], np.geomspace(1e-2, 30, 12)]))
+        pulse.cache_filter_function(omega)
+        for k, v in pulse_inputs(pulse).items():
+            arrays[f'{name}_{k}'] = v
+        arrays[f'{name}_omega'] = omega
+        for reps in (1, 2, 9):
+            per = ff.concatenate_periodic(pulse, reps)
+            arrays[f'{name}_control_matrix_x{reps}'] = per.get_control_matrix(omega)
+            arrays[f'{name}_filter_function_x{reps}'] = per.get_filter_function(omega)
+            arrays[f'{name}_total_propagator_x{reps}'] = per.total_propagator
+    save('periodic', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'periodic':
+        make_periodic()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'gradient':
         make_gradient()
         return

@@ -1528,3 +1528,24 @@ def test_gradient_random_shapes_against_oracle_and_finite_differences(seed):
             cm[h, s] -= eps
             fd = (infid(cp) - infid(cm))/(2*eps)
             assert np.allclose(grad[:, s, order[h]], fd, rtol=1e-5, atol=1e-9), (s, h)
+
+
+@pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
+def test_concatenate_periodic(name):
+    """concatenate_periodic against the reference's closed-form result (pulse_sequence.py:1890-1973)
+    and against the from-scratch control matrix of the tiled pulse."""
+    g = load_golden('periodic')
+    omega = g[f'{name}_omega']
+    pulse = etm_pulse(g, name)
+    assert not ff.concatenate_periodic(pulse, 3).is_cached('control_matrix')     # nothing cached yet
+    pulse.cache_filter_function(omega)
+    for reps in (1, 2, 9):
+        per = ff.concatenate_periodic(pulse, reps)
+        assert len(per) == reps*len(pulse) and np.isclose(per.tau, reps*pulse.tau)
+        assert rel_err(per.get_control_matrix(omega), g[f'{name}_control_matrix_x{reps}']) < TOL
+        assert rel_err(per.get_filter_function(omega), g[f'{name}_filter_function_x{reps}']) < TOL
+        assert rel_err(per.total_propagator, g[f'{name}_total_propagator_x{reps}']) < TOL
+        scratch = ff.concatenate_without_filter_function([pulse]*reps)
+        assert rel_err(per.get_control_matrix(omega), scratch.get_control_matrix(omega)) < TOL
+    with pytest.raises(TypeError):
+        ff.concatenate_periodic('pulse', 2)
