@@ -155,6 +155,13 @@ SIGNATURES = {
                                                c_void_p, c_int, c_void_p, c_void_p, c_int,
                                                c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                c_void_p, c_int, c_void_p, c_void_p]),
+    'ffk_filter_function_derivative_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'ffk_filter_function_derivative_shard_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                                         c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                                         c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                         c_void_p, c_int, c_void_p, c_int, c_int,
+                                                         c_void_p, c_void_p, c_void_p, c_size_t,
+                                                         c_void_p]),
     'ffk_expm_real': (c_int, [c_void_p, c_int, c_void_p]),
     'ffk_liouville': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'ffk_liouville_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

@@ -1382,7 +1382,6 @@ int ffk_filter_function_derivative(const double* eigvals, const double* eigvecs,
     cplx* dnop = a.take<cplx>(size_t(A)*dd);
     cplx* dcop = a.take<cplx>(size_t(H)*dd);
     double* dnc = a.take<double>(size_t(A)*G);
-    double* dones = a.take<double>(size_t(H)*G);
     double* ddt = a.take<double>(G);
     double* dtt = a.take<double>(G + 1);
     double* dratio = a.take<double>(size_t(A)*H*G);
@@ -1406,7 +1405,6 @@ int ffk_filter_function_derivative(const double* eigvals, const double* eigvecs,
     auto h2d = [](void* dst, const void* src, size_t n) {
         return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, nullptr);
     };
-    std::vector<double> ones(size_t(H)*G, 1.0);
     FFK_HIP(h2d(dD, eigvals, 8*size_t(G)*d));
     FFK_HIP(h2d(dV, eigvecs, 16*size_t(G)*dd));
     FFK_HIP(h2d(dQ, propagators, 16*size_t(G + 1)*dd));
@@ -1414,14 +1412,13 @@ int ffk_filter_function_derivative(const double* eigvals, const double* eigvecs,
     FFK_HIP(h2d(dnop, n_opers, 16*size_t(A)*dd));
     FFK_HIP(h2d(dcop, c_opers, 16*size_t(H)*dd));
     FFK_HIP(h2d(dnc, n_coeffs, 8*size_t(A)*G));
-    FFK_HIP(h2d(dones, ones.data(), 8*size_t(H)*G));
     FFK_HIP(h2d(ddt, dt, 8*size_t(G)));
     FFK_HIP(h2d(dtt, t, 8*size_t(G + 1)));
     if (n_coeffs_ratio) FFK_HIP(h2d(dratio, n_coeffs_ratio, 8*size_t(A)*H*G));
     // Bbar, T (noise operators) and Abar (control operators, unit coefficients)
     FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dnop, dnc, ddt, dtt, G, d, A, segtab, Tc, ops, dnt, dep, nullptr));
-    FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dcop, dones, ddt, dtt, G, d, H, segtab2, Tc2, ops2, dabar, dep2,
-                                 nullptr));
+    FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dcop, nullptr, ddt, dtt, G, d, H, segtab2, Tc2, ops2, dabar,
+                                 dep2, nullptr));
     // Hilbert-space steps of the interaction-picture noise operators, one chunk per segment, then
     // their running sums
     ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, G);
@@ -1439,6 +1436,81 @@ int ffk_filter_function_derivative(const double* eigvals, const double* eigvecs,
     if (filter_function_derivative)
         FFK_HIP(hipMemcpyAsync(filter_function_derivative, dF, 8*nF, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+size_t ffk_filter_function_derivative_workspace_bytes(int W, int A, int H, int G, int d) {
+    if (W < 1 || A < 1 || H < 1 || G < 1 || d < 2 || d > 8) return 0;
+    const size_t dd = size_t(d)*d;
+    const int HA = H > A ? H : A;
+    size_t b = 0;
+    b += 2*(align_up(8*size_t(G)*ffk::seg_stride(d)) + align_up(16*size_t(G)*dd) +
+            align_up(16*size_t(G)*(1 + HA)*dd));                                   // segtab, Tc, ops (x2)
+    b += align_up(16*size_t(A)*G*dd) + align_up(16*size_t(H)*G*dd) + 2*align_up(16*size_t(G)*dd);
+    b += align_up(16*size_t(H)*G*dd);                                              // E
+    b += align_up(16*size_t(G)*A*dd*W);                                            // Y steps / Ycum
+    b += align_up(16*size_t(W)*A);                                                 // spectral weights
+    return b;
+}
+
+int ffk_filter_function_derivative_shard_dev(const double* eigvals, const double* eigvecs,
+                                             const double* propagators, const double* omega_block,
+                                             int W_block, const double* n_opers, int A,
+                                             const double* n_coeffs, const double* c_opers, int H,
+                                             const double* n_coeffs_ratio, const double* dt,
+                                             const double* t, int G, int d, const double* spectrum,
+                                             int s_ndim, const double* omega, int W, int w_offset,
+                                             double* filter_function_derivative,
+                                             double* infidelity_derivative, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(d >= 2 && d <= 8, "the gradient kernels support 2 <= d <= 8, not d=%d", d);
+    FFK_REQUIRE(W_block >= 1 && A >= 1 && H >= 1 && G >= 1, "empty axis");
+    FFK_REQUIRE(eigvals && eigvecs && propagators && omega_block && n_opers && n_coeffs && c_opers && dt &&
+                    t && filter_function_derivative && workspace, "NULL argument");
+    FFK_REQUIRE(!infidelity_derivative || (spectrum && omega && (s_ndim == 1 || s_ndim == 2)),
+                "infidelity derivative needs a spectrum of shape (W,) or (A, W) and the global grid");
+    FFK_REQUIRE(!infidelity_derivative || (w_offset >= 0 && w_offset + W_block <= W),
+                "frequency block [%d, %d) outside [0, %d)", w_offset, w_offset + W_block, W);
+    FFK_REQUIRE(size_t(G)*A <= 65535, "G*A = %zu too large", size_t(G)*A);
+    FFK_REQUIRE(workspace_bytes >= ffk_filter_function_derivative_workspace_bytes(W_block, A, H, G, d),
+                "workspace too small");
+    const size_t dd = size_t(d)*d;
+    const int HA = H > A ? H : A;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Bump a(workspace, workspace_bytes);
+    double* segtab = a.take<double>(size_t(G)*ffk::seg_stride(d));
+    cplx* Tc = a.take<cplx>(size_t(G)*dd);
+    cplx* ops = a.take<cplx>(size_t(G)*(1 + HA)*dd);
+    double* segtab2 = a.take<double>(size_t(G)*ffk::seg_stride(d));
+    cplx* Tc2 = a.take<cplx>(size_t(G)*dd);
+    cplx* ops2 = a.take<cplx>(size_t(G)*(1 + HA)*dd);
+    cplx* dnt = a.take<cplx>(size_t(A)*G*dd);
+    cplx* dabar = a.take<cplx>(size_t(H)*G*dd);
+    cplx* dep = a.take<cplx>(size_t(G)*dd);
+    cplx* dep2 = a.take<cplx>(size_t(G)*dd);
+    cplx* dE = a.take<cplx>(size_t(H)*G*dd);
+    cplx* Y = a.take<cplx>(size_t(G)*A*dd*W_block);
+    cplx* dscale = a.take<cplx>(size_t(W_block)*A);
+    FFK_REQUIRE(dscale, "internal: workspace too small");
+    const cplx* V = reinterpret_cast<const cplx*>(eigvecs);
+    const cplx* Q = reinterpret_cast<const cplx*>(propagators);
+    FFK_HIP(ffk::launch_prologue(eigvals, V, Q, reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G,
+                                 d, A, segtab, Tc, ops, dnt, dep, st));
+    FFK_HIP(ffk::launch_prologue(eigvals, V, Q, reinterpret_cast<const cplx*>(c_opers), nullptr, dt, t, G,
+                                 d, H, segtab2, Tc2, ops2, dabar, dep2, st));
+    ffk::AccumGeometry geo = ffk::accumulate_geometry(W_block, A, G, d, G);
+    FFK_HIP(ffk::launch_accumulate(omega_block, W_block, segtab, ops, G, d, A, geo, Y, st));
+    FFK_HIP(ffk::launch_segment_prefix_sum(Y, G, size_t(A)*dd*W_block, st));
+    FFK_HIP(ffk::launch_filter_function_derivative(omega_block, W_block, eigvals, dt, t, ops, dabar, Y,
+                                                   n_coeffs_ratio, G, d, A, H, dE,
+                                                   filter_function_derivative, st));
+    if (infidelity_derivative) {
+        const int srows = s_ndim == 2 ? A : 1;
+        FFK_HIP(ffk::launch_spectral_weights(reinterpret_cast<const cplx*>(spectrum), srows, W_block, omega,
+                                             W, w_offset, dscale, st));
+        FFK_HIP(ffk::launch_infidelity_derivative(filter_function_derivative, A, G, H, W_block, dscale,
+                                                  s_ndim, d, infidelity_derivative, st));
+    }
     return FFK_OK;
 }
 

@@ -58,7 +58,7 @@ __device__ void prologue_segment(const cplx (*V)[D], const cplx (*Q)[D], cplx (*
 
     for (int a = 0; a < A; ++a) {
         const cplx* B = n_opers + static_cast<size_t>(a)*D*D;
-        const double s = n_coeffs[static_cast<size_t>(a)*G + g];
+        const double s = n_coeffs ? n_coeffs[static_cast<size_t>(a)*G + g] : 1.0;   // NULL: unit
         // BV = B V
         for (int e = lane; e < D*D; e += 64) {
             const int i = e / D, n = e % D;

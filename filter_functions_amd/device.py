@@ -38,6 +38,7 @@ class DevicePipeline:
         self.omega = up(omega, float)
         self.basis = up(np.asarray(basis), complex)
         self.n_opers, self.n_coeffs = up(n_opers, complex), up(n_coeffs, float)
+        self.c_opers = up(c_opers, complex)
         self.s_ndim, self.n_idx = 0, 0
         self.spectrum = self.idx = self.infid = None
         if spectrum is not None:
@@ -215,3 +216,40 @@ class DevicePipeline:
                                                          p(self.basis), p(cumulant_function),
                                                          p(self._c2ws), need, ctypes.c_void_p(s)))
         return cumulant_function
+
+    def infidelity_gradient(self, omega_global=None, w_offset=0, n_coeffs_deriv=None, stream=None):
+        """Derivative of the infidelity by the amplitude of every control operator in every
+        segment, tensor ``(n_nops, n_dt, n_ctrl)`` (``ffk_filter_function_derivative_shard_dev``),
+        from the eigensystem of the last ``launch`` and the spectrum of ``set_spectrum`` (shape
+        (W,) or (n_nops, W), all noise operators).  With *omega_global* / *w_offset* this block's
+        contribution to the integral over the full grid (multi-GPU: sum the per-rank results, e.g.
+        with ``parallel.sum_omega_shards``).  The filter-function derivative itself stays in
+        ``self.filter_function_derivative`` (n_nops, n_dt, n_ctrl, W)."""
+        torch = self.torch
+        if self.spectrum is None or self.s_ndim > 2 or self.n_idx != self.A:
+            raise ValueError('set_spectrum() with a spectrum of shape (W,) or (n_nops, W) first')
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        H = self.c_opers.shape[0]
+        omega = self.omega if omega_global is None else omega_global
+        lib = _lib.load()
+        need = lib.ffk_filter_function_derivative_workspace_bytes(self.W, self.A, H, self.G, self.d)
+        if need == 0:
+            raise ValueError('the gradient kernels support 2 <= d <= 8')
+        if getattr(self, '_gws', None) is None or self._gws.numel() < need:
+            self._gws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if getattr(self, 'filter_function_derivative', None) is None:
+            self.filter_function_derivative = torch.empty((self.A, self.G, H, self.W),
+                                                          dtype=torch.float64, device=self.device)
+        ratio = None
+        if n_coeffs_deriv is not None:
+            ratio = (torch.as_tensor(np.asarray(n_coeffs_deriv, dtype=float), device=self.device)
+                     / self.n_coeffs[:, None, :]).contiguous()
+        out = torch.empty((self.A, self.G, H), dtype=torch.float64, device=self.device)
+        p = self._p
+        check(lib.ffk_filter_function_derivative_shard_dev(
+            p(self.eigvals), p(self.eigvecs), p(self.propagators), p(self.omega), self.W,
+            p(self.n_opers), self.A, p(self.n_coeffs), p(self.c_opers), H, p(ratio), p(self.dt),
+            p(self.t), self.G, self.d, p(self.spectrum), self.s_ndim, p(omega), omega.numel(),
+            int(w_offset), p(self.filter_function_derivative), p(out), p(self._gws), need,
+            ctypes.c_void_p(s)))
+        return out

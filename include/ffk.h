@@ -342,6 +342,23 @@ int ffk_filter_function_derivative(const double* eigvals, const double* eigvecs,
                                    double* filter_function_derivative,
                                    double* infidelity_derivative);
 
+/* Device-resident flavour on one block [w_offset, w_offset + W_block) of the global grid omega (W,):
+ * omega_block (W_block,) are the block's frequencies, spectrum (W_block,) or (A, W_block) its part of
+ * the spectrum; the trapezoid weights are those of the global grid, so the per-rank
+ * infidelity_derivative results add up to the unsharded one (multi-GPU).
+ * filter_function_derivative (A, G, H, W_block) is required (device scratch if not wanted).       */
+size_t ffk_filter_function_derivative_workspace_bytes(int W, int A, int H, int G, int d);
+int ffk_filter_function_derivative_shard_dev(const double* eigvals, const double* eigvecs,
+                                             const double* propagators, const double* omega_block,
+                                             int W_block, const double* n_opers, int A,
+                                             const double* n_coeffs, const double* c_opers, int H,
+                                             const double* n_coeffs_ratio, const double* dt,
+                                             const double* t, int G, int d, const double* spectrum,
+                                             int s_ndim, const double* omega, int W, int w_offset,
+                                             double* filter_function_derivative,
+                                             double* infidelity_derivative, void* workspace,
+                                             size_t workspace_bytes, void* stream);
+
 /* ---- exp of the summed cumulant function (numeric.error_transfer_matrix, numeric.py:2049-2053;
  *      the reference calls scipy.linalg.expm) ---------------------------------------------------
  * matrix (N, N) f64 row-major -> result (N, N) = exp(matrix): scaling and squaring with a Taylor

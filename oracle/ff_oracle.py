@@ -756,3 +756,16 @@ def infidelity_derivative(dF, spectrum, omega, d):
     S = parse_spectrum(spectrum, omega, np.arange(dF.shape[0]))
     integrand = np.einsum('...o,...tho->...tho', S, dF)
     return integrate(integrand, omega)/(2*np.pi*d)
+
+
+def infidelity_derivative_shard(dF_block, spectrum_block, omega, w_offset, d):
+    """Contribution of the frequency block [w_offset, w_offset + Wb) to infidelity_derivative over
+    the global grid omega (trapezoid as a weighted sum, like decay_amplitudes_shard)."""
+    omega = np.asarray(omega, dtype=float)
+    Wb = dF_block.shape[-1]
+    wgt = np.zeros(len(omega))
+    wgt[:-1] += 0.5*np.diff(omega)
+    wgt[1:] += 0.5*np.diff(omega)
+    S = parse_spectrum(spectrum_block, np.empty(Wb), np.arange(dF_block.shape[0]))
+    S = S*wgt[w_offset:w_offset + Wb]
+    return np.einsum('...o,...tho->...th', S, dF_block)/(2*np.pi*d)

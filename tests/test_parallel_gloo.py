@@ -64,7 +64,18 @@ def _worker(rank, world, port, n_omega, out_dir):
                                                 so['g3_n_opers'], so['g3_n_coeffs'], so['g3_dt'])
     part = orc.frequency_shifts_shard(F2_block, S2[..., c0:c1], om2, c0, np.arange(len(S2)))
     delta = sum_omega_shards(torch.from_numpy(part)).numpy()
-    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), F=F, idx=idx, gamma=gamma, delta=delta)
+    # infidelity gradient: each rank differentiates on its frequency block, global weights
+    gr = np.load(os.path.join(ROOT, 'tests', 'golden', 'gradient.npz'))
+    om3, S3 = gr['g3_omega'], gr['g3_S2']
+    e0, e1 = shard_bounds(len(om3), world, rank)
+    dF_block = orc.filter_function_derivative(gr['g3_eigvals'], gr['g3_eigvecs'],
+                                              gr['g3_propagators'], om3[e0:e1], gr['g3_basis'],
+                                              gr['g3_n_opers'], gr['g3_n_coeffs'], gr['g3_c_opers'],
+                                              gr['g3_dt'])
+    part = orc.infidelity_derivative_shard(dF_block, S3[..., e0:e1], om3, e0, 3)
+    grad = sum_omega_shards(torch.from_numpy(part)).numpy()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), F=F, idx=idx, gamma=gamma, delta=delta,
+             grad=grad)
     dist.destroy_process_group()
 
 
@@ -95,6 +106,10 @@ def test_sharded_filter_function_matches_unsharded(tmp_path, n_omega):
     assert np.array_equal(deltas[0], deltas[1])
     ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'second_order.npz'))['g3_frequency_shifts_S3']
     assert np.abs(deltas[0] - ref).max() <= 1e-13*np.abs(ref).max()
+    grads = [np.load(os.path.join(str(tmp_path), f'rank{r}.npz'))['grad'] for r in range(world)]
+    assert np.array_equal(grads[0], grads[1])
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'gradient.npz'))['g3_infidelity_derivative_S2']
+    assert np.abs(grads[0] - ref).max() <= 1e-12*np.abs(ref).max()
 
 
 def test_shard_bounds_partition():
