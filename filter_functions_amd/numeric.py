@@ -33,7 +33,7 @@ from ._lib import as_c128, as_f64, check, ptr
 __all__ = ['diagonalize', 'calculate_control_matrix_from_scratch',
            'calculate_noise_operators_from_scratch', 'calculate_filter_function', 'infidelity',
            'calculate_control_matrix_from_atomic', 'calculate_control_matrix_from_atomic_indexed',
-           'calculate_noise_operators_from_atomic',
+           'calculate_noise_operators_from_atomic', 'calculate_control_matrix_periodic',
            'calculate_pulse_correlation_filter_function', 'calculate_decay_amplitudes',
            'calculate_cumulant_function', 'error_transfer_matrix',
            'calculate_second_order_filter_function_from_scratch',
@@ -407,6 +407,25 @@ def calculate_control_matrix_from_atomic_indexed(total_phases, control_matrix_ta
         ptr(tp), ptr(table), index.ctypes.data_as(ctypes.c_void_p), ptr(L) if G > 1 else None,
         int(l_is_complex), T, G, A, N, W, int(which == 'correlations'), ptr(out)))
     return out
+
+
+def calculate_control_matrix_periodic(phases, control_matrix, total_propagator_liouville, repeats,
+                                      check_invertible=True):
+    r"""Control matrix of *repeats* periods of a pulse from the control matrix (n_nops, d**2,
+    n_omega), total phase factors (n_omega,) and Liouville total propagator (d**2, d**2) of one
+    period (reference numeric.py ``calculate_control_matrix_periodic``): :math:`\tilde{\mathcal
+    B}^{(1)}\sum_{g<G}(e^{i\omega T}\mathcal Q^{(1)})^g`.  The series is summed on the device by the
+    gather-from-table concatenation kernel; no per-frequency inverse, so *check_invertible* has
+    nothing to check."""
+    L = np.asarray(total_propagator_liouville)
+    repeats = int(repeats)
+    if repeats < 1:
+        raise ValueError('repeats must be a positive integer')
+    cumulative = util.adot(np.broadcast_to(L, (repeats - 1,) + L.shape)) if repeats > 1 \
+        else np.empty((0,) + L.shape, dtype=L.dtype)
+    return calculate_control_matrix_from_atomic_indexed(
+        np.asarray(phases)[None], np.asarray(control_matrix)[None],
+        np.zeros(repeats, dtype=np.int32), cumulative)
 
 
 @util.parse_optional_parameters(which=('fidelity', 'generalized'))

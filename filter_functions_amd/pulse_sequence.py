@@ -769,12 +769,8 @@ def concatenate_periodic(pulse, repeats, check_invertible=True):
     omega = pulse.omega
     newpulse.total_propagator = np.linalg.matrix_power(pulse.total_propagator, repeats)
     newpulse.cache_total_phases(omega)
-    # cumulative Liouville propagators L, L^2, ..., L^(repeats-1)
-    L = np.asarray(pulse.total_propagator_liouville)
-    propagators_liouville = util.adot(np.broadcast_to(L, (max(repeats - 1, 0),) + L.shape)) \
-        if repeats > 1 else np.empty((0,) + L.shape, dtype=L.dtype)
-    control_matrix = numeric.calculate_control_matrix_from_atomic_indexed(
-        pulse.get_total_phases(omega)[None], pulse.get_control_matrix(omega)[None],
-        np.zeros(repeats, dtype=np.int32), propagators_liouville)
+    control_matrix = numeric.calculate_control_matrix_periodic(
+        pulse.get_total_phases(omega), pulse.get_control_matrix(omega),
+        pulse.total_propagator_liouville, repeats, check_invertible)
     newpulse.cache_filter_function(omega, control_matrix)
     return newpulse
