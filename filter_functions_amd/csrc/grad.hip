@@ -29,6 +29,11 @@
 // depend on the frequency broadcast from LDS.
 #include "ffk_internal.h"
 
+#ifndef FFK_GRAD_LDS_MAX_D
+#define FFK_GRAD_LDS_MAX_D 4      // per-lane I1 / W_a columns in LDS up to this dimension (above: scratch
+                                  // arrays win, the LDS footprint costs more occupancy than it saves)
+#endif
+
 namespace ffk {
 namespace {
 
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(64) void grad_kernel(
     const cplx ph = cexp(om*t[s]);
     // I1[m][n] = I1(w + W_mn) and, further down, Wa: per-lane columns in LDS for D <= 4 (dynamic
     // indexing without scratch), thread-local arrays (scratch) above
-    constexpr bool kLds = D <= 4;
+    constexpr bool kLds = D <= FFK_GRAD_LDS_MAX_D;
     cplx I1loc[kLds ? 1 : D2], Waloc[kLds ? 1 : D2];
     cplx* I1 = kLds ? reinterpret_cast<cplx*>(sec + H*64) + threadIdx.x : I1loc;
     cplx* Wa = kLds ? reinterpret_cast<cplx*>(sec + H*64) + D2*64 + threadIdx.x : Waloc;
@@ -272,8 +277,15 @@ hipError_t launch_grad(const double* omega, int W, const double* eigvals, const 
                        const cplx* Ycum, const double* ratio, int G, int A, int H, double* out,
                        hipStream_t stream) {
     const size_t lds = 2*D*D*sizeof(double) + size_t(1 + A + 2*H)*D*D*sizeof(cplx) +
-                       size_t(H)*64*sizeof(double) + (D <= 4 ? 2*size_t(D*D)*64*sizeof(cplx) : 0);
-    if (lds > 64*1024) return hipErrorInvalidValue;
+                       size_t(H)*64*sizeof(double) +
+                       (D <= FFK_GRAD_LDS_MAX_D ? 2*size_t(D*D)*64*sizeof(cplx) : 0);
+    if (lds > 160*1024) return hipErrorInvalidValue;
+    if (lds > 48*1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(grad_kernel<D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((grad_kernel<D>), dim3((W + 63)/64, G), dim3(64), lds, stream, omega, W, eigvals,
                        dt, t, ops, abar, E, Ycum, ratio, G, A, H, out);
     return hipGetLastError();
