@@ -444,7 +444,40 @@ def make_periodic():
     save('periodic', **arrays)
 
 
+def make_superoperator():
+    """19. Choi matrix and (conditional) complete positivity of Liouville-space superoperators
+    (reference superoperator.py:87-266; cases of tests/test_superoperator.py:76-170 in small):
+    unitary channels, a cumulant function (a generator: cCP but not CP) and its exponential, and
+    the transposition map (not CP)."""
+    from filter_functions import superoperator
+    rng = np.random.default_rng(5)
+    arrays = {}
+    for name, basis in [('pauli1', ff.Basis.pauli(1)), ('ggm3', ff.Basis.ggm(3)),
+                        ('pauli2', ff.Basis.pauli(2))]:
+        d = basis.d
+        A = rng.standard_normal((3, d, d)) + 1j*rng.standard_normal((3, d, d))
+        U = np.linalg.qr(A)[0]
+        U_sup = superoperator.liouville_representation(U, basis)
+        pulse = rand_pulse(d, 3, 2, 2, 'Pauli' if name.startswith('pauli') else 'GGM', rng)
+        omega = util.get_sample_frequencies(pulse, n_samples=40)
+        K = numeric.calculate_cumulant_function(pulse, 1e-2/omega, omega).sum(axis=0)
+        from scipy.linalg import expm
+        T = np.einsum('iab,jab->ij', np.asarray(basis), np.asarray(basis)).real   # transposition
+        stack = np.concatenate([U_sup, K[None], expm(K)[None], T[None]])
+        arrays[f'{name}_basis'] = np.asarray(basis)
+        arrays[f'{name}_superoperators'] = stack
+        arrays[f'{name}_choi'] = superoperator.liouville_to_choi(stack, basis)
+        CP, (D, V) = superoperator.liouville_is_CP(stack, basis, True)
+        cCP, (D2, V2) = superoperator.liouville_is_cCP(stack, basis, True)
+        arrays[f'{name}_CP'], arrays[f'{name}_CP_eigvals'] = CP, D
+        arrays[f'{name}_cCP'], arrays[f'{name}_cCP_eigvals'] = cCP, D2
+    save('superoperator', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'superoperator':
+        make_superoperator()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'periodic':
         make_periodic()
         return

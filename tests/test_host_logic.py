@@ -334,3 +334,29 @@ def test_is_cached_aliases():
     assert 't' not in pulse.data and 'tau' not in pulse.data
     assert np.array_equal(pulse.t, [0, *pulse.dt.cumsum()])
     assert pulse.tau == pulse.t[-1] and pulse.duration == pulse.tau
+
+
+@pytest.mark.parametrize('name', ['pauli1', 'ggm3', 'pauli2'])
+def test_choi_matrix_and_complete_positivity(name):
+    """liouville_to_choi / liouville_is_CP / liouville_is_cCP against the reference's outputs
+    (superoperator.py:87-266): unitary channels (CP), a cumulant function (cCP, not CP), its
+    exponential (CP) and the transposition map (not CP)."""
+    from conftest import load_golden, rel_err
+    from filter_functions_amd import superoperator
+    g = load_golden('superoperator')
+    btype = 'Pauli' if name.startswith('pauli') else 'GGM'
+    basis = ff.Basis(g[f'{name}_basis'], btype=btype)
+    S = g[f'{name}_superoperators']
+    assert rel_err(superoperator.liouville_to_choi(S, basis), g[f'{name}_choi']) < 1e-14
+    CP, (D, V) = superoperator.liouville_is_CP(S, basis, True)
+    assert np.array_equal(CP, g[f'{name}_CP'])
+    assert np.abs(D - g[f'{name}_CP_eigvals']).max() < 1e-12
+    assert np.array_equal(superoperator.liouville_is_CP(S, basis), CP)
+    cCP, (D2, _) = superoperator.liouville_is_cCP(S, basis, True)
+    assert np.array_equal(cCP, g[f'{name}_cCP'])
+    assert np.abs(D2 - g[f'{name}_cCP_eigvals']).max() < 1e-12
+    # the physics: unitaries and exp(K) are CP, K itself only conditionally, transposition neither
+    assert CP[:3].all() and not CP[3] and CP[4] and not CP[5]
+    assert cCP[3]
+    # single matrix in, scalar bool out
+    assert bool(superoperator.liouville_is_CP(S[0], basis)) is True
