@@ -17,12 +17,12 @@ from . import basis, gradient, numeric, pulse_sequence, superoperator, util
 from .basis import Basis
 from .numeric import error_transfer_matrix, infidelity
 from .pulse_sequence import (PulseSequence, concatenate, concatenate_periodic,
-                             concatenate_without_filter_function)
+                             concatenate_without_filter_function, extend, remap)
 from .superoperator import liouville_representation
 
 __all__ = ['Basis', 'PulseSequence', 'basis', 'concatenate', 'concatenate_periodic',
            'concatenate_without_filter_function',
-           'error_transfer_matrix', 'gradient', 'infidelity', 'liouville_representation', 'numeric',
-           'pulse_sequence', 'superoperator', 'util']
+           'error_transfer_matrix', 'extend', 'gradient', 'infidelity', 'liouville_representation', 'numeric',
+           'pulse_sequence', 'remap', 'superoperator', 'util']
 
 __version__ = '0.1.0'

@@ -774,3 +774,272 @@ def concatenate_periodic(pulse, repeats, check_invertible=True):
         pulse.total_propagator_liouville, repeats, check_invertible)
     newpulse.cache_filter_function(omega, control_matrix)
     return newpulse
+
+
+# ---- qubit registers: remap and extend (reference pulse_sequence.py:1976-2625) ------------------
+def _map_identifiers(identifiers, mapping):
+    """New identifiers and the permutation that sorts them (identity if no mapping)."""
+    if mapping is None:
+        return np.asarray(identifiers), np.arange(len(identifiers))
+    mapped = np.array([mapping[identifier] for identifier in identifiers])
+    return mapped, np.argsort(mapped)
+
+
+def _default_extend_mapping(identifiers, mapping, qubits):
+    """Default identifier mapping of extend(): the qubit indices appended, 'X' -> 'X_0', 'XY_12'."""
+    if mapping is not None:
+        return mapping
+    suffix = ''.join(str(q) for q in qubits) if np.ndim(qubits) else str(qubits)
+    return {identifier: f'{identifier}_{suffix}' for identifier in identifiers}
+
+
+def remap(pulse, order, d_per_qubit=2, oper_identifier_mapping=None):
+    """Permute the qubits of *pulse*'s register: the factor at position ``j`` of every tensor
+    product becomes the one at ``order[j]`` (reference pulse_sequence.py:1976-2120).  Cached
+    attributes are carried over: the diagonalisation by permuting tensor factors; the filter
+    function as is; the control matrix and Liouville propagator -- for a Pauli basis, whose elements
+    are tensor products -- by permuting basis elements."""
+    from .basis import remap_pauli_basis_elements
+    N = int(round(np.log(pulse.d)/np.log(d_per_qubit)))
+    dims = [[d_per_qubit]*N]*2
+    c_opers = util.tensor_transpose(pulse.c_opers, order, dims)
+    n_opers = util.tensor_transpose(pulse.n_opers, order, dims)
+    c_ids, c_sort = _map_identifiers(pulse.c_oper_identifiers, oper_identifier_mapping)
+    n_ids, n_sort = _map_identifiers(pulse.n_oper_identifiers, oper_identifier_mapping)
+    remapped = PulseSequence.from_arrays(
+        c_opers=c_opers[c_sort], c_oper_identifiers=c_ids[c_sort], c_coeffs=pulse.c_coeffs[c_sort],
+        n_opers=n_opers[n_sort], n_oper_identifiers=n_ids[n_sort], n_coeffs=pulse.n_coeffs[n_sort],
+        dt=pulse.dt, basis=pulse.basis)
+    for attr in ('t', 'tau'):
+        if attr in pulse._data:
+            setattr(remapped, attr, getattr(pulse, attr))
+    if pulse.is_cached('eigvals'):
+        remapped.eigvals = util.tensor_transpose(pulse.eigvals, order, dims[:1], rank=1)
+    for attr in ('eigvecs', 'propagators', 'total_propagator'):
+        if pulse.is_cached(attr):
+            setattr(remapped, attr, util.tensor_transpose(getattr(pulse, attr), order, dims))
+    if not pulse.is_cached('omega'):
+        return remapped
+    omega = pulse.omega
+    if pulse.is_cached('total_phases'):
+        remapped.cache_total_phases(omega, pulse.get_total_phases(omega))
+    if pulse.is_cached('filter_function'):
+        remapped.cache_filter_function(
+            omega, filter_function=pulse.get_filter_function(omega)[np.ix_(n_sort, n_sort)])
+    if pulse.is_cached('total_propagator_liouville') or pulse.is_cached('control_matrix'):
+        if pulse.basis.btype != 'Pauli':
+            warn('pulse does not have a separable basis which is needed to retain cached control '
+                 'matrices.')
+            return remapped
+        perm = remap_pauli_basis_elements(order, N)
+        if pulse.is_cached('total_propagator_liouville'):
+            L = np.empty_like(pulse.total_propagator_liouville)
+            L[np.ix_(perm, perm)] = pulse.total_propagator_liouville
+            remapped.total_propagator_liouville = L
+        if pulse.is_cached('control_matrix'):
+            R_old = pulse.get_control_matrix(omega)
+            R = np.empty_like(R_old)
+            R[np.ix_(np.argsort(n_sort), perm)] = R_old
+            remapped.cache_control_matrix(omega, R)
+    return remapped
+
+
+def extend(pulse_to_qubit_mapping, N=None, d_per_qubit=2, additional_noise_Hamiltonian=None,
+           cache_diagonalization=None, cache_filter_function=None, omega=None,
+           show_progressbar=False):
+    r"""Map pulses defined on one or few qubits onto a register of *N* qubits (reference
+    pulse_sequence.py:2123-2625).
+
+    pulse_to_qubit_mapping: sequence of ``(pulse, qubit)`` or ``(pulse, qubit, identifier_mapping)``
+    with *qubit* an int or a tuple of ints (a multi-qubit pulse; its register is permuted first if
+    the tuple is not ascending).  Operators are padded with identities on all other qubits and get
+    the qubit indices appended to their identifiers unless a mapping is given.
+    additional_noise_Hamiltonian: noise operators on the whole register (e.g. crosstalk).
+
+    For Pauli bases -- whose elements are tensor products -- cached data survive: the
+    diagonalisation as products of the embedded factors, control matrices and filter functions
+    by placing each pulse's rows at the equivalent basis elements of the register's Pauli basis
+    (scaled by the dimension of the padding); rows of the additional noise operators are computed
+    from scratch on the device."""
+    from .basis import equivalent_pauli_basis_elements
+    multi, single = [], []           # (pulse, qubits, id_mapping)
+    taken = []
+    for entry in pulse_to_qubit_mapping:
+        pulse, qubit = entry[0], entry[1]
+        id_mapping = entry[2] if len(entry) > 2 else None
+        if not isinstance(pulse, PulseSequence):
+            raise TypeError('Can only extend PulseSequences!')
+        if np.ndim(qubit):
+            qubit = tuple(int(q) for q in qubit)
+            taken.extend(qubit)
+            ascending = tuple(sorted(qubit))
+            if qubit != ascending:
+                try:
+                    pulse = remap(pulse, np.argsort(qubit), d_per_qubit)
+                except ValueError as err:
+                    raise ValueError(f'Could not remap {pulse!r} mapped to qubits {qubit}. Do the '
+                                     'dimensions match?') from err
+            multi.append((pulse, list(ascending), id_mapping))
+        else:
+            taken.append(int(qubit))
+            single.append((pulse, int(qubit), id_mapping))
+    if not all(pulse.d == d_per_qubit for pulse, _, _ in single):
+        raise ValueError(f'Not all single-qubit pulses have dimension d_per_qubit = {d_per_qubit}.')
+    if not all(pulse.d == d_per_qubit**len(qubits) for pulse, qubits, _ in multi):
+        raise ValueError('Not all multi-qubit pulses have correct dimension!')
+    entries = multi + single
+    pulses = [entry[0] for entry in entries]
+    if not util.all_array_equal(pulse.dt for pulse in pulses):
+        raise ValueError('All pulses should be defined on the same time steps')
+    if len(set(taken)) != len(taken):
+        raise ValueError('Qubit clash: multiple pulses mapped to same qubit!')
+    if N is None:
+        N = max(taken) + 1
+    elif max(taken) + 1 > N:
+        raise ValueError('Number of qubits N smaller than highest qubit index + 1 = '
+                         f'{max(taken) + 1}')
+    if len(entries) == 1:
+        if multi and N == len(multi[0][1]):
+            warn('Single multi-qubit pulse given and mapped to its original qubits. Returning the '
+                 'same.')
+            return multi[0][0]
+        if single and N == 1:
+            warn('Single single-qubit pulse given and mapped to its original qubit. Returning the '
+                 'same.')
+            return single[0][0]
+
+    if cache_filter_function is not False:
+        all_cached = all(pulse.is_cached('control_matrix') for pulse in pulses)
+        equal_omega = all(pulse.is_cached('omega') for pulse in pulses) and \
+            util.all_array_equal(pulse.omega for pulse in pulses)
+        if cache_filter_function is None:
+            cache_filter_function = all_cached and equal_omega
+            if cache_filter_function:
+                omega = pulses[0].omega
+        elif omega is None:
+            if not equal_omega:
+                raise ValueError('Filter function should be cached but omega was not provided and '
+                                 'could not be inferred.')
+            omega = pulses[0].omega
+    if cache_diagonalization is None:
+        if cache_filter_function and additional_noise_Hamiltonian is not None:
+            cache_diagonalization = True
+        else:
+            cache_diagonalization = all(pulse.is_cached(attr) for pulse in pulses
+                                        for attr in ('eigvals', 'eigvecs', 'propagators'))
+    elif not cache_diagonalization and additional_noise_Hamiltonian is not None:
+        raise ValueError('Additional noise Hamiltonian given and cache_diagonalization set to '
+                         'False but required.')
+
+    def register_qubits(qubits):
+        return list(qubits) if np.ndim(qubits) else [qubits]
+
+    d = d_per_qubit**N
+    n_dt = len(pulses[0].dt)
+    c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs = [], [], [], [], [], []
+    for pulse, qubits, id_mapping in entries:
+        where = register_qubits(qubits)
+        c_map = _default_extend_mapping(pulse.c_oper_identifiers, id_mapping, qubits)
+        n_map = _default_extend_mapping(pulse.n_oper_identifiers, id_mapping, qubits)
+        c_ids.extend(_map_identifiers(pulse.c_oper_identifiers, c_map)[0])
+        n_ids.extend(_map_identifiers(pulse.n_oper_identifiers, n_map)[0])
+        c_opers.extend(util.embed_in_register(pulse.c_opers, where, N, d_per_qubit))
+        n_opers.extend(util.embed_in_register(pulse.n_opers, where, N, d_per_qubit))
+        c_coeffs.extend(pulse.c_coeffs)
+        n_coeffs.extend(pulse.n_coeffs)
+    n_pulse_nops = len(n_ids)
+    if additional_noise_Hamiltonian is not None:
+        add_opers, add_ids, add_coeffs = _parse_hamiltonian(additional_noise_Hamiltonian, n_dt,
+                                                            'H_n')
+        if add_opers.shape[1:] != (d, d):
+            raise ValueError(f'Expected additional noise operators to have dimensions {(d, d)}, '
+                             f'not {add_opers.shape[1:]}.')
+        duplicates = set(n_ids).intersection(add_ids)
+        if duplicates:
+            raise ValueError(f'Found duplicate noise operator identifiers: {duplicates}')
+        n_opers.extend(add_opers)
+        n_coeffs.extend(add_coeffs)
+        n_ids.extend(add_ids)
+
+    btypes = {pulse.basis.btype for pulse in pulses}
+    if len(btypes) != 1:
+        warn('Not all pulses had the same basis type. Cannot retain cached control matrices.')
+        basis = Basis.ggm(d)
+    elif btypes == {'Pauli'}:
+        basis = Basis.pauli(N)
+    elif btypes == {'GGM'}:
+        warn('Original pulses had GGM basis which is not separable into a tensor product. Cannot '
+             'retain cached control matrices.')
+        basis = Basis.ggm(d)
+    else:
+        warn('Original pulses had custom basis which I cannot extend.')
+        basis = Basis.ggm(d)
+
+    c_sort, n_sort = np.argsort(c_ids), np.argsort(n_ids)
+    newpulse = PulseSequence.from_arrays(
+        c_opers=np.asarray(c_opers)[c_sort], c_oper_identifiers=np.asarray(c_ids)[c_sort],
+        c_coeffs=np.asarray(c_coeffs)[c_sort],
+        n_opers=np.asarray(n_opers)[n_sort], n_oper_identifiers=np.asarray(n_ids)[n_sort],
+        n_coeffs=np.asarray(n_coeffs)[n_sort], dt=pulses[0].dt, basis=basis)
+    for attr in ('t', 'tau'):
+        if attr in pulses[0]._data:
+            setattr(newpulse, attr, getattr(pulses[0], attr))
+    if newpulse.basis.btype != 'Pauli':
+        if cache_diagonalization:
+            newpulse.diagonalize()
+        if cache_filter_function:
+            newpulse.cache_filter_function(omega)
+        return newpulse
+
+    def embedded_product(attr):
+        """Product over the pulses of their embedded attribute: the factors act on disjoint qubits,
+        so this is the tensor product in register order."""
+        out = None
+        for pulse, qubits, _ in entries:
+            factor = util.embed_in_register(getattr(pulse, attr), register_qubits(qubits), N,
+                                            d_per_qubit)
+            out = factor if out is None else out @ factor
+        return out
+
+    if cache_diagonalization:
+        eigvals = np.zeros((n_dt, d))
+        for pulse, qubits, _ in entries:
+            eigvals += util.embed_in_register(pulse.eigvals, register_qubits(qubits), N, d_per_qubit,
+                                              rank=1)
+        newpulse.eigvals = eigvals
+        newpulse.eigvecs = embedded_product('eigvecs')
+        newpulse.propagators = embedded_product('propagators')
+        newpulse.total_propagator = newpulse.propagators[-1]
+    elif all(pulse.is_cached('total_propagator') for pulse in pulses):
+        newpulse.total_propagator = embedded_product('total_propagator')
+
+    if cache_filter_function:
+        newpulse.omega = omega
+        W = len(newpulse.omega)
+        control_matrix = np.zeros((len(n_ids), d**2, W), dtype=complex)
+        filter_function = np.zeros((len(n_ids), len(n_ids), W), dtype=complex)
+        row = 0
+        for pulse, qubits, _ in entries:
+            where = register_qubits(qubits)
+            rows = slice(row, row + len(pulse.n_opers))
+            row += len(pulse.n_opers)
+            scale = d_per_qubit**(N - len(where))
+            control_matrix[rows, equivalent_pauli_basis_elements(where, N)] = \
+                pulse.get_control_matrix(omega, show_progressbar)*np.sqrt(scale)
+            filter_function[rows, rows] = pulse.get_filter_function(
+                omega, show_progressbar=show_progressbar)*scale
+        if additional_noise_Hamiltonian is not None:
+            add_idx = util.get_indices_from_identifiers(newpulse.n_oper_identifiers,
+                                                        n_ids[n_pulse_nops:])
+            control_matrix[n_pulse_nops:] = numeric.calculate_control_matrix_from_scratch(
+                newpulse.eigvals, newpulse.eigvecs, newpulse.propagators, omega, newpulse.basis,
+                newpulse.n_opers[add_idx], newpulse.n_coeffs[add_idx], newpulse.dt, t=newpulse.t)
+            filter_function[n_pulse_nops:, n_pulse_nops:] = numeric.calculate_filter_function(
+                control_matrix[n_pulse_nops:])
+        newpulse.cache_total_phases(omega)
+        newpulse.total_propagator_liouville = liouville_representation(newpulse.total_propagator,
+                                                                       newpulse.basis)
+        newpulse.cache_control_matrix(omega, control_matrix[n_sort])
+        newpulse.cache_filter_function(omega,
+                                       filter_function=filter_function[np.ix_(n_sort, n_sort)])
+    return newpulse

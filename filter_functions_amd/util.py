@@ -11,7 +11,8 @@ from itertools import accumulate
 
 import numpy as np
 
-__all__ = ['paulis', 'abs2', 'cexp', 'cexpm1', 'get_indices_from_identifiers', 'parse_spectrum',
+__all__ = ['tensor_transpose', 'embed_in_register', 'all_array_equal', 'remove_float_errors',
+           'oper_equiv', 'paulis', 'abs2', 'cexp', 'cexpm1', 'get_indices_from_identifiers', 'parse_spectrum',
            'parse_operators', 'parse_optional_parameters', 'is_sequence_like', 'integrate',
            'get_sample_frequencies', 'mdot', 'adot', 'tensor', 'CalculationError',
            'progressbar_range']
@@ -168,9 +169,101 @@ def adot(arr, axis=0):
     return np.array(list(accumulate(arr, lambda acc, new: new @ acc))).swapaxes(0, axis)
 
 
-def tensor(*args):
-    """Kronecker product of matrices (the rank-2 case of reference util.py:360-457)."""
-    return functools.reduce(np.kron, args)
+def tensor(*args, rank=2):
+    """Tensor product of stacks of matrices (rank=2) or vectors (rank=1) with broadcasting over
+    the leading axes (the two cases of reference util.py:360-457 that the package uses)."""
+    if rank not in (1, 2):
+        raise ValueError('rank must be 1 or 2')
+
+    def pair(a, b):
+        a, b = np.asarray(a), np.asarray(b)
+        if rank == 2:
+            out = np.einsum('...ij,...kl->...ikjl', a, b)
+            return out.reshape(out.shape[:-4] + (a.shape[-2]*b.shape[-2], a.shape[-1]*b.shape[-1]))
+        out = np.einsum('...i,...k->...ik', a, b)
+        return out.reshape(out.shape[:-2] + (a.shape[-1]*b.shape[-1],))
+    return functools.reduce(pair, args)
+
+
+def tensor_transpose(arr, order, arr_dims, rank=2):
+    """Re-order the factors of a tensor product: for ``arr == tensor(A, B, C)`` and
+    ``order == (1, 2, 0)`` the result is ``tensor(B, C, A)`` (reference util.py:783-860).
+    arr_dims: for each of the last *rank* axes the dimensions of the factors along it."""
+    arr = np.asarray(arr)
+    if len(arr_dims) != rank or len({len(dims) for dims in arr_dims}) != 1:
+        raise ValueError(f'arr_dims should be {rank} lists of equal length')
+    n = len(arr_dims[0])
+    lead = arr.shape[:arr.ndim - rank]
+    try:
+        split = arr.reshape(lead + tuple(dim for dims in arr_dims for dim in dims))
+    except ValueError as err:
+        raise ValueError('arr_dims not compatible with arr.shape[-rank:] = '
+                         f'{arr.shape[-rank:]}') from err
+    try:
+        order = [int(o) for o in order]
+    except (TypeError, ValueError) as err:
+        raise TypeError("Could not transpose the order. Are all elements of 'order' integers?") \
+            from err
+    if sorted(order) != list(range(n)):
+        raise ValueError("Could not transpose the order. Are all elements of 'order' unique and "
+                         "match the array?")
+    axes = list(range(len(lead))) + [len(lead) + r*n + o for r in range(rank) for o in order]
+    return split.transpose(axes).reshape(arr.shape)
+
+
+def embed_in_register(arr, qubits, n_qubits, d_per_qubit=2, rank=2):
+    """The stack of operators (rank=2) or diagonals (rank=1) *arr*, defined on the qubits
+    *qubits* (ascending) of a register of *n_qubits*, on the whole register: identity (ones) on
+    all other qubits, tensor factors in register order.  (What the reference assembles step by step
+    with util.tensor_insert / tensor_merge, util.py:466-780.)"""
+    qubits = [int(q) for q in qubits]
+    rest = [q for q in range(n_qubits) if q not in qubits]
+    arr = np.asarray(arr)
+    if rest:
+        filler = np.eye(d_per_qubit**len(rest)) if rank == 2 else np.ones(d_per_qubit**len(rest))
+        arr = tensor(arr, filler, rank=rank)
+    current = qubits + rest
+    order = [current.index(q) for q in range(n_qubits)]
+    return tensor_transpose(arr, order, [[d_per_qubit]*n_qubits]*rank, rank=rank)
+
+
+def all_array_equal(it):
+    """Are all arrays produced by the iterable equal (reference util.py:1103-1109)?"""
+    arrays = list(it)
+    return all(np.array_equal(arrays[0], a) for a in arrays[1:]) if arrays else True
+
+
+def remove_float_errors(arr, eps_scale=None):
+    """Set entries whose magnitude is below eps_scale*eps to zero, separately for real and
+    imaginary parts (reference util.py:909-938)."""
+    eps_scale = 1 if eps_scale is None else eps_scale
+    atol = np.finfo(np.float64).eps*eps_scale
+    arr = np.array(arr, copy=True)
+    if np.iscomplexobj(arr):
+        arr.real[np.abs(arr.real) <= atol] = 0
+        arr.imag[np.abs(arr.imag) <= atol] = 0
+    else:
+        arr[np.abs(arr) <= atol] = 0
+    return arr
+
+
+def oper_equiv(psi, phi, eps=None, normalized=False):
+    """Are two operators (or states) equal up to a global phase?  Returns (bool, phase) with
+    ``psi == exp(-1j*phase)*phi`` -- the convention of reference util.py:941-1010."""
+    psi, phi = np.atleast_2d(np.asarray(psi), np.asarray(phi))
+    if eps is None:
+        eps = max(np.finfo(psi.dtype).eps if np.issubdtype(psi.dtype, np.inexact) else 0,
+                  np.finfo(phi.dtype).eps if np.issubdtype(phi.dtype, np.inexact) else 0,
+                  np.finfo(float).eps)*np.prod(psi.shape)*phi.shape[-1]*2
+        if not normalized:
+            eps *= (np.prod(psi.shape[-2:])*phi.shape[-1]*2)**2
+    try:
+        inner = np.einsum('...ij,...ij', psi.conj(), phi)
+    except ValueError as err:
+        raise ValueError('psi and phi have incompatible dimensions!') from err
+    norm = 1 if normalized else np.sqrt(np.einsum('...ij,...ij', psi.conj(), psi).real
+                                        * np.einsum('...ij,...ij', phi.conj(), phi).real)
+    return abs(norm - abs(inner)) <= eps, np.angle(inner)
 
 
 def progressbar_range(*args, show_progressbar=False, **kwargs):

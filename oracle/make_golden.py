@@ -474,7 +474,56 @@ def make_superoperator():
     save('superoperator', **arrays)
 
 
+def make_register():
+    """20. remap and extend (reference pulse_sequence.py:1976-2625; cases of
+    tests/test_sequencing.py extend/remap tests in small): Hamiltonian bookkeeping, embedded
+    diagonalisation and retained control matrices / filter functions for Pauli bases, incl. a
+    permuted two-qubit pulse, identifier mappings and an additional noise Hamiltonian."""
+    rng = np.random.default_rng(21)
+    arrays = {}
+    p1 = rand_pulse(2, 3, 2, 2, 'Pauli', rng)
+    p1b = rand_pulse(2, 3, 2, 1, 'Pauli', rng)
+    p2 = rand_pulse(4, 3, 2, 2, 'Pauli', rng)
+    p3 = rand_pulse(8, 3, 2, 2, 'Pauli', rng)
+    p1b.dt = p1.dt
+    p2.dt = p1.dt
+    omega = np.sort(np.concatenate([[-1.0, 0.0], np.geomspace(1e-2, 30, 10)]))
+    for name, q in [('p1', p1), ('p1b', p1b), ('p2', p2), ('p3', p3)]:
+        for k, v in pulse_inputs(q).items():
+            arrays[f'{name}_{k}'] = v
+        q.cache_filter_function(omega)
+    arrays['omega'] = omega
+
+    def outputs(prefix, pulse):
+        arrays[f'{prefix}_c_opers'] = pulse.c_opers
+        arrays[f'{prefix}_n_opers'] = pulse.n_opers
+        arrays[f'{prefix}_c_coeffs'] = pulse.c_coeffs
+        arrays[f'{prefix}_n_coeffs'] = pulse.n_coeffs
+        arrays[f'{prefix}_c_oper_identifiers'] = pulse.c_oper_identifiers.astype('U16')
+        arrays[f'{prefix}_n_oper_identifiers'] = pulse.n_oper_identifiers.astype('U16')
+        arrays[f'{prefix}_control_matrix'] = pulse.get_control_matrix(omega)
+        arrays[f'{prefix}_filter_function'] = pulse.get_filter_function(omega)
+        arrays[f'{prefix}_eigvals'] = pulse.eigvals
+        arrays[f'{prefix}_propagators'] = pulse.propagators
+        arrays[f'{prefix}_total_propagator_liouville'] = pulse.total_propagator_liouville
+
+    outputs('remap_p2_10', ff.remap(p2, (1, 0)))
+    outputs('remap_p3_201', ff.remap(p3, (2, 0, 1)))
+    mapping = {i: i + '_x' for i in list(p2.c_oper_identifiers) + list(p2.n_oper_identifiers)}
+    outputs('remap_p2_10_mapped', ff.remap(p2, (1, 0), oper_identifier_mapping=mapping))
+    arrays['mapping_keys'] = np.array(list(mapping.keys()), dtype='U16')
+    outputs('extend_singles', ff.extend([(p1, 0), (p1b, 2)], N=3))
+    outputs('extend_multi', ff.extend([(p2, (2, 0)), (p1, 1)], N=4))
+    ZZ = util.tensor(util.paulis[3], np.eye(2), util.paulis[3])
+    outputs('extend_additional', ff.extend([(p1, 0), (p1b, 2)], N=3,
+                                           additional_noise_Hamiltonian=[[ZZ, np.ones(3), 'ZZ']]))
+    save('register', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'register':
+        make_register()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'superoperator':
         make_superoperator()
         return

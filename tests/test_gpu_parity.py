@@ -1583,3 +1583,72 @@ def test_device_resident_infidelity_gradient_with_logical_omega_shards(name):
                 total_ncd = part if total_ncd is None else total_ncd + part
             assert rel_err(total.cpu().numpy(), g[f'{name}_infidelity_derivative_S{i}']) < TOL
             assert rel_err(total_ncd.cpu().numpy(), g[f'{name}_infidelity_derivative_ncd_S{i}']) < TOL
+
+
+# ---- qubit registers: remap and extend -------------------------------------------------------------
+def _register_pulses():
+    g = load_golden('register')
+    out = {}
+    for name in ('p1', 'p1b', 'p2', 'p3'):
+        out[name] = ff.PulseSequence.from_arrays(
+            g[f'{name}_c_opers'], g[f'{name}_c_oper_identifiers'], g[f'{name}_c_coeffs'],
+            g[f'{name}_n_opers'], g[f'{name}_n_oper_identifiers'], g[f'{name}_n_coeffs'],
+            g[f'{name}_dt'], ff.Basis(g[f'{name}_basis'], btype='Pauli'))
+        out[name].cache_filter_function(g['omega'])
+    return g, out
+
+
+def _check_register(g, prefix, pulse, tol=TOL):
+    omega = g['omega']
+    assert list(pulse.c_oper_identifiers) == list(g[f'{prefix}_c_oper_identifiers'])
+    assert list(pulse.n_oper_identifiers) == list(g[f'{prefix}_n_oper_identifiers'])
+    for attr in ('c_opers', 'n_opers', 'c_coeffs', 'n_coeffs'):
+        assert rel_err(getattr(pulse, attr), g[f'{prefix}_{attr}']) < 1e-14, attr
+    assert pulse.is_cached('control_matrix') and pulse.is_cached('filter_function')
+    assert rel_err(pulse.get_control_matrix(omega), g[f'{prefix}_control_matrix']) < tol
+    assert rel_err(pulse.get_filter_function(omega), g[f'{prefix}_filter_function']) < tol
+    assert rel_err(pulse.total_propagator_liouville, g[f'{prefix}_total_propagator_liouville']) < tol
+    # ... and the retained data are what a from-scratch evaluation of the new pulse gives
+    fresh = ff.PulseSequence.from_arrays(pulse.c_opers, pulse.c_oper_identifiers, pulse.c_coeffs,
+                                         pulse.n_opers, pulse.n_oper_identifiers, pulse.n_coeffs,
+                                         pulse.dt, pulse.basis)
+    assert rel_err(pulse.get_filter_function(omega), fresh.get_filter_function(omega)) < tol
+
+
+def test_remap_retains_cached_filter_functions():
+    """remap (reference pulse_sequence.py:1976-2120): permuted tensor factors, identifier mapping,
+    cached diagonalisation, control matrix and Liouville propagator through the Pauli basis
+    permutation -- against the reference's outputs and a from-scratch evaluation."""
+    g, p = _register_pulses()
+    _check_register(g, 'remap_p2_10', ff.remap(p['p2'], (1, 0)))
+    _check_register(g, 'remap_p3_201', ff.remap(p['p3'], (2, 0, 1)))
+    mapping = {str(k): str(k) + '_x' for k in g['mapping_keys']}
+    _check_register(g, 'remap_p2_10_mapped', ff.remap(p['p2'], (1, 0),
+                                                      oper_identifier_mapping=mapping))
+    twice = ff.remap(ff.remap(p['p3'], (2, 0, 1)), (1, 2, 0))
+    assert rel_err(twice.get_control_matrix(g['omega']), p['p3'].get_control_matrix(g['omega'])) < TOL
+    with pytest.raises(ValueError):
+        ff.remap(p['p2'], (0, 0))
+
+
+def test_extend_retains_cached_filter_functions():
+    """extend (reference pulse_sequence.py:2123-2625): single- and multi-qubit pulses on a larger
+    register, a permuted two-qubit pulse, an additional noise Hamiltonian on the whole register."""
+    g, p = _register_pulses()
+    _check_register(g, 'extend_singles', ff.extend([(p['p1'], 0), (p['p1b'], 2)], N=3))
+    ext = ff.extend([(p['p2'], (2, 0)), (p['p1'], 1)], N=4)
+    _check_register(g, 'extend_multi', ext)
+    assert ext.d == 16 and ext.basis.btype == 'Pauli'
+    assert rel_err(ext.eigvals, g['extend_multi_eigvals']) < TOL
+    ZZ = util.tensor(util.paulis[3], np.eye(2), util.paulis[3])
+    _check_register(g, 'extend_additional',
+                    ff.extend([(p['p1'], 0), (p['p1b'], 2)], N=3,
+                              additional_noise_Hamiltonian=[[ZZ, np.ones(3), 'ZZ']]))
+    with pytest.raises(ValueError):
+        ff.extend([(p['p1'], 0), (p['p1b'], 0)])                  # qubit clash
+    with pytest.raises(ValueError):
+        ff.extend([(p['p1'], 0), (p['p1b'], 2)], N=2)             # register too small
+    with pytest.raises(ValueError):
+        ff.extend([(p['p2'], 0)])                                 # dimension mismatch
+    with pytest.warns(UserWarning):
+        assert ff.extend([(p['p1'], 0)], N=1) is p['p1']

@@ -360,3 +360,45 @@ def test_choi_matrix_and_complete_positivity(name):
     assert cCP[3]
     # single matrix in, scalar bool out
     assert bool(superoperator.liouville_is_CP(S[0], basis)) is True
+
+
+def test_remap_and_extend_bookkeeping():
+    """Hamiltonian / identifier bookkeeping of remap and extend against the reference's outputs
+    (pulse_sequence.py:1976-2625); no frequencies cached, so nothing touches the device."""
+    from conftest import load_golden, rel_err
+    g = load_golden('register')
+    p = {}
+    for name in ('p1', 'p1b', 'p2', 'p3'):
+        p[name] = ff.PulseSequence.from_arrays(
+            g[f'{name}_c_opers'], g[f'{name}_c_oper_identifiers'], g[f'{name}_c_coeffs'],
+            g[f'{name}_n_opers'], g[f'{name}_n_oper_identifiers'], g[f'{name}_n_coeffs'],
+            g[f'{name}_dt'], ff.Basis(g[f'{name}_basis'], btype='Pauli'))
+    ZZ = ff.util.tensor(ff.util.paulis[3], np.eye(2), ff.util.paulis[3])
+    cases = {
+        'remap_p2_10': ff.remap(p['p2'], (1, 0)),
+        'remap_p3_201': ff.remap(p['p3'], (2, 0, 1)),
+        'extend_singles': ff.extend([(p['p1'], 0), (p['p1b'], 2)], N=3),
+        'extend_multi': ff.extend([(p['p2'], (2, 0)), (p['p1'], 1)], N=4),
+        'extend_additional': ff.extend([(p['p1'], 0), (p['p1b'], 2)], N=3,
+                                       additional_noise_Hamiltonian=[[ZZ, np.ones(3), 'ZZ']]),
+    }
+    for prefix, pulse in cases.items():
+        assert list(pulse.c_oper_identifiers) == list(g[f'{prefix}_c_oper_identifiers'])
+        assert list(pulse.n_oper_identifiers) == list(g[f'{prefix}_n_oper_identifiers'])
+        for attr in ('c_opers', 'n_opers', 'c_coeffs', 'n_coeffs'):
+            assert rel_err(getattr(pulse, attr), g[f'{prefix}_{attr}']) < 1e-14, (prefix, attr)
+        assert not pulse.is_cached('control_matrix')
+    assert cases['extend_multi'].basis.btype == 'Pauli' and cases['extend_multi'].d == 16
+    # tensor utilities
+    X, Y, Z = ff.util.paulis[1:]
+    t = ff.util.tensor(X, Y, Z)
+    assert np.array_equal(ff.util.tensor_transpose(t, [1, 2, 0], [[2, 2, 2]]*2), ff.util.tensor(Y, Z, X))
+    assert np.array_equal(ff.util.embed_in_register(ff.util.tensor(X, Z), [0, 2], 3),
+                          ff.util.tensor(X, np.eye(2), Z))
+    assert np.array_equal(ff.util.embed_in_register(np.array([1., 2.]), [1], 2, rank=1),
+                          [1., 2., 1., 2.])
+    ok, phase = ff.util.oper_equiv(X, np.exp(0.25j)*X)
+    assert ok and np.isclose(phase, 0.25)
+    assert ff.util.all_array_equal([np.arange(3)]*3) and not ff.util.all_array_equal([[1], [2]])
+    with pytest.raises(ValueError):
+        ff.util.tensor_transpose(t, [0, 0, 1], [[2, 2, 2]]*2)
