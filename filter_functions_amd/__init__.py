@@ -13,14 +13,14 @@ The arithmetic runs in hand-written HIP kernels for gfx950 behind a C ABI
 side: the reference's object model, argument checking, caching and exceptions.
 See DESIGN.md for the scope, INTEGRATION.md for the boundary.
 """
-from . import basis, gradient, numeric, pulse_sequence, superoperator, util
+from . import analytic, basis, gradient, numeric, pulse_sequence, superoperator, util
 from .basis import Basis
 from .numeric import error_transfer_matrix, infidelity
 from .pulse_sequence import (PulseSequence, concatenate, concatenate_periodic,
                              concatenate_without_filter_function, extend, remap)
 from .superoperator import liouville_representation
 
-__all__ = ['Basis', 'PulseSequence', 'basis', 'concatenate', 'concatenate_periodic',
+__all__ = ['analytic', 'Basis', 'PulseSequence', 'basis', 'concatenate', 'concatenate_periodic',
            'concatenate_without_filter_function',
            'error_transfer_matrix', 'extend', 'gradient', 'infidelity', 'liouville_representation', 'numeric',
            'pulse_sequence', 'remap', 'superoperator', 'util']

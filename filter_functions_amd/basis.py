@@ -10,6 +10,8 @@ Host-side NumPy on arrays of at most a few hundred KB; no kernel involved.
 from functools import cached_property
 from itertools import product
 
+from warnings import warn
+
 import numpy as np
 
 from . import util
@@ -209,9 +211,60 @@ class Basis(np.ndarray):
         return cls(lam, btype='GGM', labels=[rf'$\Lambda_{{{i}}}$' for i in range(d*d)])
 
     @classmethod
-    def from_partial(cls, *args, **kwargs):
-        raise NotImplementedError('Basis.from_partial is outside the accelerated path '
-                                  '(SURVEY.md section 2, row 17).')
+    def from_partial(cls, partial_basis_array, traceless=None, btype=None, labels=None):
+        """Complete a set of orthogonal operators to a full orthonormal basis of the d x d matrices
+        (reference basis.py:492-620): the given elements come first (after the identity if the
+        basis is traceless), the remainder spans their orthogonal complement.  The complement is
+        found in the coefficient space of the generalised Gell-Mann basis, so Hermitian input gives
+        a Hermitian basis; its choice is not unique (an orthonormal null-space basis)."""
+        from scipy.linalg import null_space
+        given = normalize(cls(partial_basis_array))
+        if labels is None and len(getattr(partial_basis_array, 'labels', ())) == len(given):
+            labels = partial_basis_array.labels
+        if not given.isherm:
+            warn("(Some) elems not hermitian! The resulting basis also won't be.")
+        if not given.isorthogonal:
+            raise ValueError('The basis elements are not orthogonal!')
+        if traceless is None:
+            traceless = given.istraceless
+        elif traceless and not given.istraceless:
+            raise ValueError('The basis elements are not traceless (up to an identity element) '
+                             'but a traceless basis was requested!')
+        d = given.d
+        if labels is not None and len(labels) not in (len(given), d*d):
+            raise ValueError(f'Got {len(labels)} labels but expected {len(given)} or {d*d}')
+        frame = cls.ggm(d).view(np.ndarray)
+        # coordinates of the given elements in the Gell-Mann frame, tr(Lambda_j C_i)
+        coords = np.einsum('jab,iba->ij', frame, given.view(np.ndarray))
+        if given.isherm:
+            coords = coords.real
+        coords = _tidy(coords.astype(complex), d*d).real if given.isherm else _tidy(coords, d*d)
+        if traceless:
+            # the identity direction is fixed as the first element; complete the rest
+            frame_rest, coords = frame[1:], coords[:, 1:]
+        else:
+            frame_rest = frame
+        coords = coords[np.any(coords != 0, axis=1)]
+        if coords.size:
+            coords = np.concatenate((coords, null_space(coords).conj().T))
+            elems = np.einsum('ij,jab->iab', coords, frame_rest)
+        else:
+            elems = frame_rest
+        if traceless:
+            elems = np.concatenate((frame[:1], elems))
+        out = cls(elems, btype=btype or 'From partial')
+        out.tidyup()
+        if labels is not None and len(labels) == len(given):
+            labels = list(labels)
+            if traceless:
+                is_id = [np.allclose(frame[0], e, rtol=0, atol=given._atol)
+                         for e in given.view(np.ndarray)]
+                if any(is_id):
+                    labels.insert(0, labels.pop(is_id.index(True)))
+            labels.extend(f'$C_{{{i}}}$' for i in range(len(labels), len(out)))
+        if labels is not None:
+            out.labels = list(labels)
+        return out
 
 
 def _norm(b):

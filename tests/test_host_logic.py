@@ -402,3 +402,33 @@ def test_remap_and_extend_bookkeeping():
     assert ff.util.all_array_equal([np.arange(3)]*3) and not ff.util.all_array_equal([[1], [2]])
     with pytest.raises(ValueError):
         ff.util.tensor_transpose(t, [0, 0, 1], [[2, 2, 2]]*2)
+
+
+def test_basis_from_partial_and_analytic_formulas():
+    """Basis.from_partial (reference basis.py:492-620): given elements first (after the identity
+    for traceless bases), orthonormal Hermitian completion; the closed-form DD filter functions
+    (reference analytic.py:59-88) at a few known values."""
+    X, Y, Z = ff.util.paulis[1:]
+    b = ff.Basis.from_partial([X, Y], labels=['X', 'Y'])
+    assert b.shape == (4, 2, 2) and b.isorthonorm and b.isherm and b.istraceless and b.iscomplete
+    assert np.allclose(b[0], np.eye(2)/np.sqrt(2)) and np.allclose(b[1], X/np.sqrt(2))
+    assert np.allclose(b[2], Y/np.sqrt(2)) and np.allclose(np.abs(b[3]), np.abs(Z)/np.sqrt(2))
+    assert b.btype == 'From partial' and list(b.labels)[:2] == ['X', 'Y'] and len(b.labels) == 4
+    ggm = ff.Basis.ggm(4)
+    b4 = ff.Basis.from_partial(ggm[[3, 7, 9]])
+    assert b4.shape == (16, 4, 4) and b4.isorthonorm and b4.iscomplete and b4.istraceless
+    assert np.allclose(np.asarray(b4)[1:4], np.asarray(ggm)[[3, 7, 9]])
+    nt = ff.Basis.from_partial([np.diag([1.0, 0.0, 0.0])])          # not traceless
+    assert nt.shape == (9, 3, 3) and nt.isorthonorm and not nt.istraceless
+    with pytest.raises(ValueError):
+        ff.Basis.from_partial([X, X + Y])                            # not orthogonal
+    with pytest.raises(ValueError):
+        ff.Basis.from_partial([np.diag([1.0, 0.0])], traceless=True)
+    with pytest.raises(ValueError):
+        ff.Basis.from_partial([X, Y], labels=['only one'])
+    z = np.array([np.pi, 2*np.pi])
+    assert np.allclose(ff.analytic.FID(z), [2, 0]) and np.allclose(ff.analytic.SE(z), [2, 8])
+    assert np.allclose(ff.analytic.CPMG(z, 1), ff.analytic.SE(z))
+    assert np.allclose(ff.analytic.UDD(z, 1), ff.analytic.SE(z))
+    assert np.allclose(ff.analytic.CDD(z, 1), ff.analytic.PDD(z, 1))
+    assert np.isscalar(float(ff.analytic.UDD(1.3, 4)))
