@@ -11,7 +11,8 @@ from itertools import accumulate
 
 import numpy as np
 
-__all__ = ['tensor_transpose', 'embed_in_register', 'all_array_equal', 'remove_float_errors',
+__all__ = ['tensor_transpose', 'tensor_insert', 'tensor_merge', 'hash_array_along_axis',
+           'progressbar', 'embed_in_register', 'all_array_equal', 'remove_float_errors',
            'oper_equiv', 'paulis', 'abs2', 'cexp', 'cexpm1', 'get_indices_from_identifiers', 'parse_spectrum',
            'parse_operators', 'parse_optional_parameters', 'is_sequence_like', 'integrate',
            'get_sample_frequencies', 'mdot', 'adot', 'tensor', 'CalculationError',
@@ -169,20 +170,108 @@ def adot(arr, axis=0):
     return np.array(list(accumulate(arr, lambda acc, new: new @ acc))).swapaxes(0, axis)
 
 
-def tensor(*args, rank=2):
-    """Tensor product of stacks of matrices (rank=2) or vectors (rank=1) with broadcasting over
-    the leading axes (the two cases of reference util.py:360-457 that the package uses)."""
-    if rank not in (1, 2):
-        raise ValueError('rank must be 1 or 2')
+def tensor(*args, rank=2, optimize=False):
+    """Tensor product over the last *rank* axes of the arguments (Kronecker product of vectors
+    for rank=1, of matrices for rank=2, ...), broadcasting over the leading axes (reference
+    util.py:360-463).  *optimize* is accepted for signature compatibility; the product is formed
+    by broadcasting, there is no contraction order to optimise."""
+    if not args:
+        raise ValueError('Require nonzero number of args!')
 
     def pair(a, b):
         a, b = np.asarray(a), np.asarray(b)
-        if rank == 2:
-            out = np.einsum('...ij,...kl->...ikjl', a, b)
-            return out.reshape(out.shape[:-4] + (a.shape[-2]*b.shape[-2], a.shape[-1]*b.shape[-1]))
-        out = np.einsum('...i,...k->...ik', a, b)
-        return out.reshape(out.shape[:-2] + (a.shape[-1]*b.shape[-1],))
+        if a.ndim < rank or b.ndim < rank:
+            raise ValueError(f'Incompatible shapes {a.shape} and {b.shape} for tensor product '
+                             f'of rank {rank}.')
+        da, db = a.shape[a.ndim - rank:], b.shape[b.ndim - rank:]
+        # factor axes interleaved: a's at even positions, b's at odd ones
+        a = a.reshape(a.shape[:a.ndim - rank] + tuple(x for n in da for x in (n, 1)))
+        b = b.reshape(b.shape[:b.ndim - rank] + tuple(x for n in db for x in (1, n)))
+        try:
+            out = a*b
+        except ValueError as err:
+            raise ValueError(f'Incompatible shapes {a.shape} and {b.shape} for tensor product '
+                             f'of rank {rank}.') from err
+        return out.reshape(out.shape[:out.ndim - 2*rank] + tuple(x*y for x, y in zip(da, db)))
     return functools.reduce(pair, args)
+
+
+def _check_dims(name, dims, rank):
+    if not len(dims) == rank:
+        raise ValueError(f'{name}_dims should be of length rank = {rank}, not {len(dims)}')
+    if len({len(axis) for axis in dims}) != 1:
+        raise ValueError(f'Require all lists in {name}_dims to be of same length!')
+
+
+def _chain_after_insertion(n_arr, pos, n_ins, sort_wrapped):
+    """Positions in the product chain ``[arr factors..., ins factors...]`` in the order they take
+    after ins factor j has been inserted before arr factor ``pos[j]`` (negative positions count
+    from the end).  Insertions happen in ascending order of position, each shifting the later
+    ones by one -- the rule of numpy.insert.  The reference orders them by the wrapped position
+    in tensor_insert (util.py:617-623) but by the position as given in tensor_merge (:748); the
+    two differ for mixed signs, and both are reproduced."""
+    wrapped = []
+    for p in pos:
+        if not -n_arr <= p <= n_arr:
+            raise IndexError(f'Invalid position {p} specified. Must be between -{n_arr} and '
+                             f'{n_arr}.')
+        wrapped.append(p + n_arr if p < 0 else p)
+    keys = wrapped if sort_wrapped else pos
+    chain = list(range(n_arr))
+    for shift, j in enumerate(sorted(range(n_ins), key=lambda j: (keys[j], j))):
+        chain.insert(wrapped[j] + shift, n_arr + j)
+    return chain
+
+
+def tensor_merge(arr, ins, pos, arr_dims, ins_dims, rank=2, optimize=False, _sort_wrapped=False):
+    """Merge the product chain *ins* into the product chain *arr*: constituent j of *ins* goes
+    before the constituent ``pos[j]`` of *arr* (reference util.py:640-780), e.g.
+    ``tensor_merge(tensor(X, Y, Z), tensor(I, I), pos=[1, 2], ...) == tensor(X, I, Y, I, Z)``.
+    arr_dims / ins_dims: per tensor axis the dimensions of the constituents.
+
+    Formed as the plain product ``arr (x) ins`` followed by one re-ordering of the factors
+    (:func:`tensor_transpose`), instead of the reference's einsum over split axes."""
+    _check_dims('arr', arr_dims, rank)
+    _check_dims('ins', ins_dims, rank)
+    n_arr, n_ins = len(arr_dims[0]), len(ins_dims[0])
+    pos = [int(p) for p in pos]
+    if len(pos) != n_ins:
+        raise ValueError('Expected one position per constituent of ins, i.e. '
+                         f'{n_ins}, not {len(pos)}')
+    arr, ins = np.asarray(arr), np.asarray(ins)
+    for name, a, dims in (('arr', arr, arr_dims), ('ins', ins, ins_dims)):
+        if tuple(int(np.prod(axis)) for axis in dims) != a.shape[a.ndim - rank:]:
+            raise ValueError(f'{name}_dims {dims} do not match the shape {a.shape} of {name}.')
+    order = _chain_after_insertion(n_arr, pos, n_ins, _sort_wrapped)
+    dims = [list(a) + list(i) for a, i in zip(arr_dims, ins_dims)]
+    return tensor_transpose(tensor(arr, ins, rank=rank), order, dims, rank=rank)
+
+
+def tensor_insert(arr, *args, pos, arr_dims, rank=2, optimize=False):
+    """Insert *args* into the product chain *arr* (reference util.py:466-637): with an integer
+    *pos* all of them, in a row, before constituent *pos*; with a sequence, ``args[j]`` before the
+    constituent ``pos[j]`` of the original chain -- the rule of :func:`numpy.insert`."""
+    if len(args) == 0:
+        raise ValueError('Require nonzero number of args!')
+    if np.issubdtype(type(pos), np.integer):
+        args = (tensor(*args, rank=rank),)
+        pos = (int(pos),)
+    elif len(pos) != len(args):
+        raise ValueError('Expected pos to be either an int or a sequence of the same length '
+                         f'as the number of args, not length {len(pos)}')
+    _check_dims('arr', arr_dims, rank)
+    args = [np.asarray(a) for a in args]
+    for k, a in enumerate(args):
+        if a.ndim < rank:
+            raise ValueError(f'Could not insert arg {k} with shape {a.shape} into the array '
+                             f'with shape {np.shape(arr)} at position {pos[k]}.')
+    ins_dims = [[a.shape[a.ndim - rank + axis] for a in args] for axis in range(rank)]
+    try:
+        return tensor_merge(arr, tensor(*args, rank=rank), pos, arr_dims, ins_dims, rank=rank,
+                            _sort_wrapped=True)
+    except ValueError as err:
+        raise ValueError(f'Could not insert args with shapes {[a.shape for a in args]} into the '
+                         f'array with shape {np.shape(arr)} at positions {list(pos)}.') from err
 
 
 def tensor_transpose(arr, order, arr_dims, rank=2):
@@ -264,6 +353,22 @@ def oper_equiv(psi, phi, eps=None, normalized=False):
     norm = 1 if normalized else np.sqrt(np.einsum('...ij,...ij', psi.conj(), psi).real
                                         * np.einsum('...ij,...ij', phi.conj(), phi).real)
     return abs(norm - abs(inner)) <= eps, np.angle(inner)
+
+
+def hash_array_along_axis(arr, axis=0):
+    """Hashes of the slices of *arr* along *axis*; -0.0 and 0.0 hash alike (reference
+    util.py:1096-1100)."""
+    return [hash((a + 0.0).tobytes()) for a in np.swapaxes(np.asarray(arr), 0, axis)]
+
+
+def progressbar(iterable, *args, **kwargs):
+    """tqdm progress bar around *iterable* where tqdm is installed, the bare iterable otherwise
+    (reference util.py:1112-1121)."""
+    try:
+        from tqdm import tqdm
+    except ImportError:
+        return iterable
+    return tqdm(iterable, *args, **kwargs)
 
 
 def progressbar_range(*args, show_progressbar=False, **kwargs):

@@ -432,3 +432,74 @@ def test_basis_from_partial_and_analytic_formulas():
     assert np.allclose(ff.analytic.UDD(z, 1), ff.analytic.SE(z))
     assert np.allclose(ff.analytic.CDD(z, 1), ff.analytic.PDD(z, 1))
     assert np.isscalar(float(ff.analytic.UDD(1.3, 4)))
+
+
+def test_tensor_product_chains():
+    """util.tensor / tensor_insert / tensor_merge / tensor_transpose on product chains with known
+    constituents (after the reference's tests/test_util.py tensor tests and the doctest examples of
+    util.py:521-556, :695-726); the chain orders for mixed-sign merge positions are the
+    reference's own (generated by running it, see the literal table)."""
+    rng = np.random.default_rng(11)
+    t = util.tensor
+    I, X, Y, Z = util.paulis
+    assert np.array_equal(t(X, Z), np.kron(X, Z))
+    dims = [[2, 2], [2, 2]]
+    arr = t(X, I)
+    assert np.array_equal(util.tensor_insert(arr, Y, Z, arr_dims=dims, pos=0), t(Y, Z, X, I))
+    assert np.array_equal(util.tensor_insert(arr, Y, Z, arr_dims=dims, pos=1), t(X, Y, Z, I))
+    assert np.array_equal(util.tensor_insert(arr, Y, Z, arr_dims=dims, pos=2), t(X, I, Y, Z))
+    assert np.array_equal(util.tensor_insert(arr, Y, Z, arr_dims=dims, pos=-1), t(X, Y, Z, I))
+    A, B, C = rng.standard_normal((2, 3, 1, 2)), rng.standard_normal((2, 2, 2, 2)), \
+        rng.standard_normal((3, 2, 1))
+    r = util.tensor_insert(t(A, C, rank=3), B, pos=1, rank=3, arr_dims=[[3, 3], [1, 2], [2, 1]])
+    assert r.shape == (2, 18, 4, 4) and np.allclose(r, t(A, B, C, rank=3))
+    # random chains of random rank with broadcast leading axes: numpy.insert rule
+    for _ in range(60):
+        rank = int(rng.integers(1, 4))
+        n_arr, n_ins = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        arrs = [rng.standard_normal(tuple(rng.integers(1, 4, size=rank))) for _ in range(n_arr)]
+        inss = [rng.standard_normal(tuple(rng.integers(1, 4, size=rank))) for _ in range(n_ins)]
+        arrs[0] = rng.standard_normal((2,) + arrs[0].shape)
+        arr_dims = [[a.shape[a.ndim - rank + ax] for a in arrs] for ax in range(rank)]
+        ins_dims = [[a.shape[a.ndim - rank + ax] for a in inss] for ax in range(rank)]
+        pos = sorted(int(p) for p in rng.integers(0, n_arr + 1, size=n_ins))
+        chain = list(range(n_arr))
+        for shift, (p, j) in enumerate(zip(pos, range(n_ins))):
+            chain.insert(p + shift, n_arr + j)
+        expected = t(*[(arrs + inss)[k] for k in chain], rank=rank)
+        arr, ins = t(*arrs, rank=rank), t(*inss, rank=rank)
+        got = util.tensor_merge(arr, ins, pos=pos, arr_dims=arr_dims, ins_dims=ins_dims, rank=rank)
+        assert got.shape == expected.shape and np.allclose(got, expected)
+        got = util.tensor_insert(arr, *inss, pos=pos, arr_dims=arr_dims, rank=rank)
+        assert got.shape == expected.shape and np.allclose(got, expected)
+        # and back: moving the inserted factors to the end restores arr (x) ins
+        all_dims = [[(a + i)[k] for k in chain] for a, i in zip(arr_dims, ins_dims)]
+        back = util.tensor_transpose(got, np.argsort(chain), all_dims, rank=rank)
+        assert np.allclose(back, t(arr, ins, rank=rank))
+    # chain orders of the reference for (n_arr, pos): constituents 0..n_arr-1 are arr's
+    reference_chains = [(2, [0, -1], [0, 2, 3, 1]), (2, [1, -1, -2], [4, 0, 3, 2, 1]),
+                        (3, [-1, 0, 1], [0, 4, 1, 5, 3, 2]), (3, [2, -1], [0, 1, 4, 3, 2]),
+                        (3, [0, 3, -1], [0, 3, 1, 5, 2, 4]), (2, [2, 0], [3, 0, 1, 2]),
+                        (3, [1, 1], [0, 3, 4, 1, 2])]
+    for n_arr, pos, chain in reference_chains:
+        parts = [np.array([1.0, 2.0 + k]) for k in range(n_arr + len(pos))]
+        got = util.tensor_merge(t(*parts[:n_arr], rank=1), t(*parts[n_arr:], rank=1), pos=pos,
+                                arr_dims=[[2]*n_arr], ins_dims=[[2]*len(pos)], rank=1)
+        assert np.array_equal(got, t(*[parts[k] for k in chain], rank=1)), (n_arr, pos)
+    # error behaviour (reference util.py:564-577, :610-612, :750-753)
+    with pytest.raises(ValueError):
+        util.tensor_insert(t(X, I), pos=0, arr_dims=dims)
+    with pytest.raises(ValueError):
+        util.tensor_insert(t(X, I), Y, Z, pos=(0,), arr_dims=dims)
+    with pytest.raises(IndexError):
+        util.tensor_insert(t(X, I), Y, pos=(3,), arr_dims=dims)
+    with pytest.raises(IndexError):
+        util.tensor_merge(t(X, I), t(Y, Z), pos=(0, -3), arr_dims=dims, ins_dims=dims)
+    with pytest.raises(ValueError):
+        util.tensor_merge(t(X, I), t(Y, Z), pos=(0, 1), arr_dims=[[2, 2]], ins_dims=dims)
+    with pytest.raises(ValueError):
+        util.tensor_merge(t(X, I), t(Y, Z), pos=(0, 1), arr_dims=[[2, 3], [2, 2]], ins_dims=dims)
+    # hashes: one per slice, signed zeros alike (reference util.py:1096-1100)
+    h = util.hash_array_along_axis(np.array([[0.0, 1.0], [-0.0, 1.0], [0.0, 2.0]]))
+    assert h[0] == h[1] != h[2]
+    assert list(util.progressbar(range(3), disable=True)) == [0, 1, 2]
