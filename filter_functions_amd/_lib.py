@@ -155,6 +155,12 @@ SIGNATURES = {
                                                c_void_p, c_int, c_void_p, c_void_p, c_int,
                                                c_void_p, c_void_p, c_void_p, c_int, c_int,
                                                c_void_p, c_int, c_void_p, c_void_p]),
+    'ffk_control_matrix_derivative': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                              c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                              c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                              c_int, c_int, c_void_p]),
+    'ffk_filter_function_derivative_from_control_matrix': (c_int, [c_void_p, c_void_p, c_int, c_int,
+                                                                   c_int, c_int, c_int, c_void_p]),
     'ffk_filter_function_derivative_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'ffk_filter_function_derivative_shard_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                                          c_void_p, c_int, c_void_p, c_void_p, c_int,
@@ -181,6 +187,27 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64 (torch/lib).  Two HSA runtimes in
+    one process do not both see the GPU: if libffk pulled in /opt/rocm's copy first, a later
+    ``torch.cuda`` initialisation (device.py, parallel.py) fails with "No HIP GPUs are available".
+    Both copies carry the same SONAME, so loading torch's copy first -- without importing torch --
+    makes libffk and torch share one runtime whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load libffk.so (once) and declare the prototypes.  Raises if it is missing."""
     global _lib
@@ -190,6 +217,7 @@ def load():
                 f'{LIB_PATH} not found: build the HIP extension first '
                 "(python -c 'import __graft_entry__ as g; g.build()' or "
                 'make -C filter_functions_amd/csrc).  There is no CPU fallback.')
+        _share_hip_runtime_with_torch()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -1439,6 +1439,113 @@ int ffk_filter_function_derivative(const double* eigvals, const double* eigvecs,
     return FFK_OK;
 }
 
+int ffk_control_matrix_derivative(const double* eigvals, const double* eigvecs, const double* propagators,
+                                  const double* omega, int W, const double* basis, int N,
+                                  const double* n_opers, int A, const double* n_coeffs,
+                                  const double* c_opers, int H, const double* n_coeffs_ratio,
+                                  const double* dt, const double* t, int G, int d,
+                                  double* control_matrix_derivative) {
+    FFK_REQUIRE(d >= 2 && d <= 8, "the gradient kernels support 2 <= d <= 8, not d=%d", d);
+    FFK_REQUIRE(W >= 1 && A >= 1 && H >= 1 && G >= 1 && N >= 1, "empty axis: W=%d A=%d H=%d G=%d N=%d", W,
+                A, H, G, N);
+    FFK_REQUIRE(eigvals && eigvecs && propagators && omega && basis && n_opers && n_coeffs && c_opers && dt &&
+                    t && control_matrix_derivative, "NULL argument");
+    FFK_REQUIRE(size_t(G)*A <= 65535, "G*A = %zu too large", size_t(G)*A);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t dd = size_t(d)*d;
+    const size_t nY = size_t(G)*A*dd*W, nR = size_t(H)*W*G*A*N;
+    const int HA = H > A ? H : A;
+    size_t total = 0;
+    total += align_up(8*size_t(G)*d) + align_up(16*size_t(G)*dd) + align_up(16*size_t(G + 1)*dd);
+    total += align_up(8*size_t(W)) + align_up(16*size_t(A)*dd) + align_up(16*size_t(H)*dd);
+    total += align_up(16*size_t(N)*dd);
+    total += align_up(8*size_t(A)*G) + align_up(8*size_t(G)) + align_up(8*size_t(G + 1));
+    total += align_up(8*size_t(A)*H*G);
+    total += 2*(align_up(8*size_t(G)*ffk::seg_stride(d)) + align_up(16*size_t(G)*dd) +
+                align_up(16*size_t(G)*(1 + HA)*dd));
+    total += align_up(16*size_t(A)*G*dd) + align_up(16*size_t(H)*G*dd) + 2*align_up(16*size_t(G)*dd);
+    total += align_up(16*size_t(H)*G*dd);
+    total += align_up(16*nY) + align_up(16*nR);
+    void* base;
+    if (int rc = arena_reserve(total, &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dD = a.take<double>(size_t(G)*d);
+    cplx* dV = a.take<cplx>(size_t(G)*dd);
+    cplx* dQ = a.take<cplx>(size_t(G + 1)*dd);
+    double* dom = a.take<double>(W);
+    cplx* dnop = a.take<cplx>(size_t(A)*dd);
+    cplx* dcop = a.take<cplx>(size_t(H)*dd);
+    cplx* dbasis = a.take<cplx>(size_t(N)*dd);
+    double* dnc = a.take<double>(size_t(A)*G);
+    double* ddt = a.take<double>(G);
+    double* dtt = a.take<double>(G + 1);
+    double* dratio = a.take<double>(size_t(A)*H*G);
+    double* segtab = a.take<double>(size_t(G)*ffk::seg_stride(d));
+    cplx* Tc = a.take<cplx>(size_t(G)*dd);
+    cplx* ops = a.take<cplx>(size_t(G)*(1 + HA)*dd);
+    double* segtab2 = a.take<double>(size_t(G)*ffk::seg_stride(d));
+    cplx* Tc2 = a.take<cplx>(size_t(G)*dd);
+    cplx* ops2 = a.take<cplx>(size_t(G)*(1 + HA)*dd);
+    cplx* dnt = a.take<cplx>(size_t(A)*G*dd);
+    cplx* dabar = a.take<cplx>(size_t(H)*G*dd);
+    cplx* dep = a.take<cplx>(size_t(G)*dd);
+    cplx* dep2 = a.take<cplx>(size_t(G)*dd);
+    cplx* dE = a.take<cplx>(size_t(H)*G*dd);
+    cplx* Y = a.take<cplx>(nY);
+    cplx* dR = a.take<cplx>(nR);
+    FFK_REQUIRE(dR && a.used <= g_arena.size, "internal: arena too small");
+    auto h2d = [](void* dst, const void* src, size_t n) {
+        return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, nullptr);
+    };
+    FFK_HIP(h2d(dD, eigvals, 8*size_t(G)*d));
+    FFK_HIP(h2d(dV, eigvecs, 16*size_t(G)*dd));
+    FFK_HIP(h2d(dQ, propagators, 16*size_t(G + 1)*dd));
+    FFK_HIP(h2d(dom, omega, 8*size_t(W)));
+    FFK_HIP(h2d(dnop, n_opers, 16*size_t(A)*dd));
+    FFK_HIP(h2d(dcop, c_opers, 16*size_t(H)*dd));
+    FFK_HIP(h2d(dbasis, basis, 16*size_t(N)*dd));
+    FFK_HIP(h2d(dnc, n_coeffs, 8*size_t(A)*G));
+    FFK_HIP(h2d(ddt, dt, 8*size_t(G)));
+    FFK_HIP(h2d(dtt, t, 8*size_t(G + 1)));
+    if (n_coeffs_ratio) FFK_HIP(h2d(dratio, n_coeffs_ratio, 8*size_t(A)*H*G));
+    FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dnop, dnc, ddt, dtt, G, d, A, segtab, Tc, ops, dnt, dep, nullptr));
+    FFK_HIP(ffk::launch_prologue(dD, dV, dQ, dcop, nullptr, ddt, dtt, G, d, H, segtab2, Tc2, ops2, dabar,
+                                 dep2, nullptr));
+    ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, G);
+    FFK_HIP(ffk::launch_accumulate(dom, W, segtab, ops, G, d, A, geo, Y, nullptr));
+    FFK_HIP(ffk::launch_segment_prefix_sum(Y, G, size_t(A)*dd*W, nullptr));
+    FFK_HIP(ffk::launch_control_matrix_derivative(dom, W, dD, ddt, dtt, ops, dabar, Y,
+                                                  n_coeffs_ratio ? dratio : nullptr, dbasis, N, G, d, A, H,
+                                                  dE, dR, nullptr));
+    FFK_HIP(hipMemcpyAsync(control_matrix_derivative, dR, 16*nR, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+int ffk_filter_function_derivative_from_control_matrix(const double* control_matrix,
+                                                       const double* control_matrix_derivative, int A,
+                                                       int N, int W, int G, int H,
+                                                       double* filter_function_derivative) {
+    FFK_REQUIRE(control_matrix && control_matrix_derivative && filter_function_derivative, "NULL argument");
+    FFK_REQUIRE(A >= 1 && N >= 1 && W >= 1 && G >= 1 && H >= 1, "empty axis: A=%d N=%d W=%d G=%d H=%d", A, N,
+                W, G, H);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nR = size_t(A)*N*W, nD = size_t(H)*W*G*A*N, nF = size_t(A)*G*H*W;
+    void* base;
+    if (int rc = arena_reserve(align_up(16*nR) + align_up(16*nD) + align_up(8*nF), &base)) return rc;
+    Bump a(base, g_arena.size);
+    cplx* dR = a.take<cplx>(nR);
+    cplx* dD = a.take<cplx>(nD);
+    double* dF = a.take<double>(nF);
+    FFK_REQUIRE(dF && a.used <= g_arena.size, "internal: arena too small");
+    FFK_HIP(hipMemcpyAsync(dR, control_matrix, 16*nR, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dD, control_matrix_derivative, 16*nD, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(ffk::launch_filter_function_derivative_from_control_matrix(dR, dD, A, N, W, G, H, dF, nullptr));
+    FFK_HIP(hipMemcpyAsync(filter_function_derivative, dF, 8*nF, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
 size_t ffk_filter_function_derivative_workspace_bytes(int W, int A, int H, int G, int d) {
     if (W < 1 || A < 1 || H < 1 || G < 1 || d < 2 || d > 8) return 0;
     const size_t dd = size_t(d)*d;

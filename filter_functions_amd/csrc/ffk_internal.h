@@ -228,6 +228,16 @@ hipError_t launch_filter_function_derivative(const double* omega, int W, const d
                                              const cplx* abar, const cplx* Ycum, const double* ratio,
                                              int G, int d, int A, int H, cplx* E, double* out,
                                              hipStream_t stream);
+// dR (H,W,G,A,N) c128 = d R_ak / d u_h(t_s), same operands plus the basis (N,d,d)
+hipError_t launch_control_matrix_derivative(const double* omega, int W, const double* eigvals,
+                                            const double* dt, const double* t, const cplx* ops,
+                                            const cplx* abar, const cplx* Ycum, const double* ratio,
+                                            const cplx* basis, int N, int G, int d, int A, int H, cplx* E,
+                                            cplx* out, hipStream_t stream);
+// dF (A,G,H,W) = 2 Re sum_k conj(R[a,k,w]) dR[h,w,s,a,k]
+hipError_t launch_filter_function_derivative_from_control_matrix(const cplx* R, const cplx* dR, int A,
+                                                                 int N, int W, int G, int H, double* out,
+                                                                 hipStream_t stream);
 // out (A,G,H) = sum_w dF Re(scale)/d, scale from launch_spectral_weights with rows = 1 or A
 hipError_t launch_infidelity_derivative(const double* dF, int A, int G, int H, int W, const cplx* scale,
                                         int s_ndim, int d, double* out, hipStream_t stream);

@@ -251,6 +251,181 @@ __global__ __launch_bounds__(64) void grad_kernel(
     }
 }
 
+// The derivative of the control matrix itself (gradient.calculate_derivative_of_control_matrix_from_scratch,
+// gradient.py:384-523), out (H, W, G, A, N) = tr(dY C_k) with
+//   dY_a/du_h(t_s) = Y' + [Ytot_a - Ycum_{s,a}, E_hs] + ratio_ahs Ystep_{s,a}
+// (same Y', E, Ycum as above; here the part proportional to Ytot does not drop out).  One lane per
+// frequency, one block row per segment; the tensor is written for callers that want it -- the
+// filter-function / infidelity gradients above never form it.
+template <int D>
+__global__ __launch_bounds__(64) void grad_ctrlmat_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ eigvals,
+    const double* __restrict__ dt, const double* __restrict__ t, const cplx* __restrict__ ops,
+    const cplx* __restrict__ abar, const cplx* __restrict__ E, const cplx* __restrict__ Ycum,
+    const double* __restrict__ ratio, const cplx* __restrict__ basis, int N, int G, int A, int H,
+    cplx* __restrict__ out) {
+    constexpr int D2 = D*D;
+    constexpr int U = D <= 4 ? D : 1;
+    extern __shared__ unsigned char smem[];
+    double* dE = reinterpret_cast<double*>(smem);          // [D2]  W_mn
+    double* inv = dE + D2;                                 // [D2]  1/W_mn, 0 where W_mn == 0
+    cplx* Ts = reinterpret_cast<cplx*>(inv + D2);          // [D2]
+    cplx* Bs = Ts + D2;                                    // [A][D2]
+    cplx* As = Bs + A*D2;                                  // [H][D2]
+    cplx* Es = As + H*D2;                                  // [H][D2]
+    cplx* Cb = Es + H*D2;                                  // [N][D2]
+    const int s = blockIdx.y;
+    const int w = blockIdx.x*64 + threadIdx.x;
+    for (int e = threadIdx.x; e < D2; e += 64) {
+        const double v = eigvals[static_cast<size_t>(s)*D + e / D] - eigvals[static_cast<size_t>(s)*D + e % D];
+        dE[e] = v;
+        inv[e] = v == 0.0 ? 0.0 : 1.0/v;
+        Ts[e] = ops[static_cast<size_t>(s)*(1 + A)*D2 + e];
+    }
+    for (int e = threadIdx.x; e < A*D2; e += 64) Bs[e] = ops[(static_cast<size_t>(s)*(1 + A) + 1)*D2 + e];
+    for (int e = threadIdx.x; e < H*D2; e += 64) {
+        const int h = e / D2, r = e % D2;
+        As[e] = abar[(static_cast<size_t>(h)*G + s)*D2 + r];
+        Es[e] = E[(static_cast<size_t>(h)*G + s)*D2 + r];
+    }
+    for (int e = threadIdx.x; e < N*D2; e += 64) Cb[e] = basis[e];
+    __syncthreads();
+    if (w >= W) return;
+    const double om = omega[w], dts = dt[s];
+    const cplx ph = cexp(om*t[s]);
+    cplx I1[D2];
+#pragma unroll U
+    for (int e = 0; e < D2; ++e) I1[e] = first_order_integral(om, dE[e], dts);
+    auto nested = [&](cplx i1, int e) {                    // int_0^dt tau e^{i x tau} dtau from I1(x)
+        const double x = om + dE[e];
+        const cplx ex = {1.0 - x*i1.im, x*i1.re};
+        cplx jd = {0.5*dts*dts, 0.0};
+        if (x != 0.0) {
+            const double rx = 1.0/x;
+            jd = {(dts*ex.im - i1.im)*rx, -(dts*ex.re - i1.re)*rx};
+        }
+        return jd;
+    };
+    const size_t slab = static_cast<size_t>(A)*D2*W;
+    for (int a = 0; a < A; ++a) {
+        const cplx* Ytot = Ycum + static_cast<size_t>(G - 1)*slab + static_cast<size_t>(a)*D2*W + w;
+        const cplx* Yc = Ycum + static_cast<size_t>(s)*slab + static_cast<size_t>(a)*D2*W + w;
+        cplx Yr[D2], Ys[D2];                               // Ytot - Ycum_s, Ystep_s
+#pragma unroll U
+        for (int e = 0; e < D2; ++e) {
+            const cplx tot = Ytot[static_cast<size_t>(e)*W], c = Yc[static_cast<size_t>(e)*W];
+            cplx p = {0.0, 0.0};
+            if (s > 0) p = (Yc - slab)[static_cast<size_t>(e)*W];
+            Yr[e] = {tot.re - c.re, tot.im - c.im};
+            Ys[e] = {c.re - p.re, c.im - p.im};
+        }
+        const cplx* Bb = Bs + a*D2;
+        for (int h = 0; h < H; ++h) {
+            const cplx* Ab = As + h*D2;
+            const cplx* Eh = Es + h*D2;
+            cplx Gm[D2];
+#pragma unroll U
+            for (int x = 0; x < D; ++x)
+#pragma unroll U
+                for (int y = 0; y < D; ++y) {
+                    cplx g = {0.0, 0.0};
+                    const cplx iyx = I1[y*D + x];
+#pragma unroll U
+                    for (int n = 0; n < D; ++n) {
+                        const double r1 = inv[n*D + x];
+                        const cplx iyn = I1[y*D + n];
+                        cplx j1;
+                        if (r1 != 0.0) {
+                            const cplx df = {iyx.re - iyn.re, iyx.im - iyn.im};
+                            j1 = {df.im*r1, -df.re*r1};
+                        } else {
+                            j1 = nested(iyn, y*D + n);
+                        }
+                        cmac(g, cmul(Bb[y*D + n], Ab[n*D + x]), j1);
+                        const double r2 = inv[y*D + n];
+                        const cplx inx = I1[n*D + x];
+                        cplx j2;
+                        if (r2 != 0.0) {
+                            const cplx df = {iyx.re - inx.re, iyx.im - inx.im};
+                            j2 = {df.im*r2, -df.re*r2};
+                        } else {
+                            j2 = nested(inx, n*D + x);
+                        }
+                        const cplx ab = cmul(Ab[y*D + n], Bb[n*D + x]);
+                        cmac(g, cplx{-ab.re, -ab.im}, j2);
+                    }
+                    Gm[x*D + y] = g;
+                }
+            // M = G^T T, then dY = -i ph T^dag M
+            cplx M[D2];
+#pragma unroll U
+            for (int x = 0; x < D; ++x)
+#pragma unroll U
+                for (int j = 0; j < D; ++j) {
+                    cplx acc = {0.0, 0.0};
+#pragma unroll U
+                    for (int y = 0; y < D; ++y) cmac(acc, Gm[y*D + x], Ts[y*D + j]);
+                    M[x*D + j] = acc;
+                }
+            const double r = ratio ? ratio[(static_cast<size_t>(a)*H + h)*G + s] : 0.0;
+            cplx dY[D2];
+#pragma unroll U
+            for (int i = 0; i < D; ++i)
+#pragma unroll U
+                for (int j = 0; j < D; ++j) {
+                    cplx acc = {0.0, 0.0};
+#pragma unroll U
+                    for (int x = 0; x < D; ++x) cmac_conj(acc, Ts[x*D + i], M[x*D + j]);
+                    const cplx pv = cmul(ph, acc);
+                    cplx v = {pv.im, -pv.re};                               // -i ph acc
+                    // + [Yr, E]_ij
+#pragma unroll U
+                    for (int k = 0; k < D; ++k) {
+                        cmac(v, Yr[i*D + k], Eh[k*D + j]);
+                        const cplx q = cmul(Eh[i*D + k], Yr[k*D + j]);
+                        v.re -= q.re;
+                        v.im -= q.im;
+                    }
+                    v.re += r*Ys[i*D + j].re;
+                    v.im += r*Ys[i*D + j].im;
+                    dY[i*D + j] = v;
+                }
+            cplx* dst = out + (((static_cast<size_t>(h)*W + w)*G + s)*A + a)*N;
+            for (int k = 0; k < N; ++k) {
+                const cplx* C = Cb + k*D2;
+                cplx acc = {0.0, 0.0};
+#pragma unroll U
+                for (int i = 0; i < D; ++i)
+#pragma unroll U
+                    for (int j = 0; j < D; ++j) cmac(acc, dY[i*D + j], C[j*D + i]);
+                dst[k] = acc;
+            }
+        }
+    }
+}
+
+// out (A,G,H,W) = 2 Re sum_k conj(R[a,k,w]) dR[h,w,s,a,k]  (gradient.py:526-556)
+__global__ __launch_bounds__(256) void ctrlmat_deriv_contract_kernel(const cplx* __restrict__ R,
+                                                                     const cplx* __restrict__ dR, int A,
+                                                                     int N, int W, int G, int H,
+                                                                     double* __restrict__ out) {
+    const size_t idx = static_cast<size_t>(blockIdx.x)*256 + threadIdx.x;
+    const size_t total = static_cast<size_t>(A)*G*H*W;
+    if (idx >= total) return;
+    const int w = static_cast<int>(idx % W);
+    const int h = static_cast<int>((idx / W) % H);
+    const int s = static_cast<int>((idx / W / H) % G);
+    const int a = static_cast<int>(idx / W / H / G);
+    const cplx* d = dR + (((static_cast<size_t>(h)*W + w)*G + s)*A + a)*N;
+    const cplx* r = R + static_cast<size_t>(a)*N*W + w;
+    double sum = 0.0;
+    for (int k = 0; k < N; ++k) {
+        const cplx rv = r[static_cast<size_t>(k)*W];
+        sum += rv.re*d[k].re + rv.im*d[k].im;
+    }
+    out[idx] = 2.0*sum;
+}
+
 // out[row] = sum_w dF[row, w] * Re(scale[srow(row), w]) / d, rows = (a, s, h)
 __global__ __launch_bounds__(256) void grad_integrate_kernel(const double* __restrict__ dF, int GH,
                                                              int W, const cplx* __restrict__ scale,
@@ -311,6 +486,49 @@ hipError_t launch_filter_function_derivative(const double* omega, int W, const d
 #undef FFK_GRAD_CASE
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_control_matrix_derivative(const double* omega, int W, const double* eigvals,
+                                            const double* dt, const double* t, const cplx* ops,
+                                            const cplx* abar, const cplx* Ycum, const double* ratio,
+                                            const cplx* basis, int N, int G, int d, int A, int H, cplx* E,
+                                            cplx* out, hipStream_t stream) {
+    if (d < 2 || d > 8 || G > 65535 || H > 65535 || N < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(grad_generator_kernel, dim3(G, H), dim3(64), 2*d*d*sizeof(cplx), stream, ops,
+                       (1 + A)*d*d, abar, eigvals, dt, G, d, E);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return err;
+    const size_t lds = 2*size_t(d)*d*sizeof(double) + size_t(1 + A + 2*H + N)*d*d*sizeof(cplx);
+    if (lds > 160*1024) return hipErrorInvalidValue;
+    const dim3 grid((W + 63)/64, G);
+    switch (d) {
+#define FFK_GRADC_CASE(D)                                                                                 \
+    case D: {                                                                                             \
+        if (lds > 48*1024) {                                                                              \
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(grad_ctrlmat_kernel<D>),              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+            if (err != hipSuccess) return err;                                                            \
+        }                                                                                                 \
+        hipLaunchKernelGGL((grad_ctrlmat_kernel<D>), grid, dim3(64), lds, stream, omega, W, eigvals, dt, t, \
+                           ops, abar, E, Ycum, ratio, basis, N, G, A, H, out);                            \
+        return hipGetLastError();                                                                         \
+    }
+        FFK_GRADC_CASE(2) FFK_GRADC_CASE(3) FFK_GRADC_CASE(4) FFK_GRADC_CASE(5)
+        FFK_GRADC_CASE(6) FFK_GRADC_CASE(7) FFK_GRADC_CASE(8)
+#undef FFK_GRADC_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_filter_function_derivative_from_control_matrix(const cplx* R, const cplx* dR, int A,
+                                                                 int N, int W, int G, int H, double* out,
+                                                                 hipStream_t stream) {
+    const size_t total = static_cast<size_t>(A)*G*H*W;
+    const size_t blocks = (total + 255)/256;
+    if (blocks == 0 || blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ctrlmat_deriv_contract_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                       stream, R, dR, A, N, W, G, H, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_infidelity_derivative(const double* dF, int A, int G, int H, int W, const cplx* scale,

@@ -342,6 +342,25 @@ int ffk_filter_function_derivative(const double* eigvals, const double* eigvecs,
                                    double* filter_function_derivative,
                                    double* infidelity_derivative);
 
+/* The two tensor-level gradient functions of the reference.
+ * ffk_control_matrix_derivative: gradient.calculate_derivative_of_control_matrix_from_scratch
+ * (gradient.py:384-523): control_matrix_derivative (H, W, G, A, N) c128 = d R_ak(w) / d u_h(t_s)
+ * [the reference's (n_ctrl, n_omega, n_dt, n_nops, d**2)]; basis (N, d, d) c128; the other arguments
+ * as for ffk_filter_function_derivative.  2 <= d <= 8.
+ * ffk_filter_function_derivative_from_control_matrix: gradient.calculate_filter_function_derivative
+ * (gradient.py:526-556): (A, G, H, W) f64 = 2 Re sum_k conj(R[a,k,w]) dR[h,w,s,a,k] from
+ * control_matrix (A, N, W) c128 and control_matrix_derivative (H, W, G, A, N) c128.              */
+int ffk_control_matrix_derivative(const double* eigvals, const double* eigvecs, const double* propagators,
+                                  const double* omega, int W, const double* basis, int N,
+                                  const double* n_opers, int A, const double* n_coeffs,
+                                  const double* c_opers, int H, const double* n_coeffs_ratio,
+                                  const double* dt, const double* t, int G, int d,
+                                  double* control_matrix_derivative);
+int ffk_filter_function_derivative_from_control_matrix(const double* control_matrix,
+                                                       const double* control_matrix_derivative, int A,
+                                                       int N, int W, int G, int H,
+                                                       double* filter_function_derivative);
+
 /* Device-resident flavour on one block [w_offset, w_offset + W_block) of the global grid omega (W,):
  * omega_block (W_block,) are the block's frequencies, spectrum (W_block,) or (A, W_block) its part of
  * the spectrum; the trapezoid weights are those of the global grid, so the per-rank

@@ -750,6 +750,70 @@ def filter_function_derivative(eigvals, eigvecs, propagators, omega, basis, n_op
     return out
 
 
+def control_matrix_derivative(eigvals, eigvecs, propagators, omega, basis, n_opers, n_coeffs,
+                              c_opers, dt, n_coeffs_deriv=None):
+    """d R_ak(w) / d u_h(t_s), shape (n_ctrl, n_omega, n_dt, n_nops, n_basis): what
+    gradient.calculate_derivative_of_control_matrix_from_scratch returns
+    (filter_functions/gradient.py:384-523).  Hilbert-space restatement with the quantities of
+    filter_function_derivative above: R_ak = tr(Y_a C_k) and
+        dY_a/du_h(t_s) = Y' + [Ytot_a - Ycum_{s,a}, E_hs] + (n'_ahs / n_as) Ystep_{s,a},
+    Y' = -i e^{i w t_s} T^dag G^T T (segment s's own contribution, :200-381), the commutator with
+    the anti-Hermitian generator E_hs the change of all later propagators (Q_g -> Q_g E for g > s;
+    _liouville_derivative :111-197 and the pairwise contraction :520), the last term :376-379."""
+    dt = np.asarray(dt, dtype=float)
+    omega = np.asarray(omega, dtype=float)
+    basis = np.asarray(basis)
+    G, d = eigvals.shape
+    A, H, W = len(n_opers), len(c_opers), len(omega)
+    t = np.concatenate(([0.0], dt.cumsum()))
+    QdV, Bbar = _prologue(eigvals, eigvecs, propagators, n_opers, n_coeffs)
+    _, Abar = _prologue(eigvals, eigvecs, propagators, c_opers, np.ones((H, G)))
+    n_coeffs = np.asarray(n_coeffs, dtype=float)
+    Ystep = np.empty((G, A, W, d, d), dtype=complex)
+    I1_all = np.empty((G, W, d, d), dtype=complex)
+    for g in range(G):
+        T = QdV[g].conj().T
+        I1_all[g] = first_order_integral(omega, eigvals[g], dt[g])
+        inner = Bbar[:, g, None]*I1_all[g][None]*cexp(omega*t[g])[None, :, None, None]
+        Ystep[g] = T.conj().T @ inner @ T
+    Ycum = Ystep.cumsum(axis=0)
+    out = np.empty((H, W, G, A, len(basis)), dtype=complex)
+    for s in range(G):
+        T = QdV[s].conj().T
+        dE = np.subtract.outer(eigvals[s], eigvals[s])
+        I0 = first_order_integral(np.zeros(1), eigvals[s], dt[s])[0]
+        I1 = I1_all[s]
+        Jd = _nested_exponential_integral(omega[:, None, None] + dE[None], I1, dt[s])
+        J1 = np.empty((W, d, d, d), dtype=complex)
+        J2 = np.empty((W, d, d, d), dtype=complex)
+        for m in range(d):
+            for n in range(d):
+                for q in range(d):
+                    J1[:, m, n, q] = Jd[:, m, n] if dE[n, q] == 0 else \
+                        (I1[:, m, q] - I1[:, m, n])/(1j*dE[n, q])
+                    J2[:, m, n, q] = Jd[:, n, q] if dE[m, n] == 0 else \
+                        (I1[:, m, q] - I1[:, n, q])/(1j*dE[m, n])
+        phase = cexp(omega*t[s])
+        rest = Ycum[-1] - Ycum[s]                                               # (A,W,d,d)
+        for h in range(H):
+            E = -1j*(T.conj().T @ (Abar[h, s]*I0) @ T)
+            later = rest @ E - E @ rest
+            for a in range(A):
+                Gm = (np.einsum('mn,nq,wmnq->wqm', Bbar[a, s], Abar[h, s], J1)
+                      - np.einsum('pq,qn,wpqn->wnp', Abar[h, s], Bbar[a, s], J2))
+                dY = -1j*phase[:, None, None]*(T.conj().T @ Gm.swapaxes(-1, -2) @ T) + later[a]
+                if n_coeffs_deriv is not None:
+                    dY = dY + np.asarray(n_coeffs_deriv)[a, h, s]/n_coeffs[a, s]*Ystep[s, a]
+                out[h, :, s, a] = np.einsum('wij,kji->wk', dY, basis)
+    return out
+
+
+def filter_function_derivative_from_control_matrix(ctrlmat, ctrlmat_deriv):
+    """2 Re sum_k conj(R_ak) dR_ak: (A, N, W), (H, W, G, A, N) -> (A, G, H, W)
+    (gradient.calculate_filter_function_derivative, filter_functions/gradient.py:526-556)."""
+    return 2*np.einsum('ako,hotak->atho', np.conj(ctrlmat), ctrlmat_deriv).real
+
+
 def infidelity_derivative(dF, spectrum, omega, d):
     """int dw/(2 pi d) S dF, filter_functions/gradient.py:667-676."""
     omega = np.asarray(omega, dtype=float)

@@ -520,7 +520,44 @@ def make_register():
     save('register', **arrays)
 
 
+def make_gradient_ctrlmat():
+    """18. the two tensor-level gradient functions (reference gradient.py:384-556):
+    calculate_derivative_of_control_matrix_from_scratch, shape (n_ctrl, n_omega, n_dt, n_nops, d^2),
+    with and without n_coeffs_deriv, and calculate_filter_function_derivative of it.  Pauli d=2,
+    GGM d=3, Pauli d=4, GGM d=5; frequencies incl. 0 and a negative one."""
+    from filter_functions import gradient
+    rng = np.random.default_rng(1234)
+    arrays = {}
+    for name, d, n_dt, n_cops, n_nops, btype in [('q1', 2, 4, 2, 2, 'Pauli'), ('g3', 3, 3, 3, 2, 'GGM'),
+                                                 ('p4', 4, 5, 2, 3, 'Pauli'), ('g5', 5, 3, 2, 2, 'GGM')]:
+        pulse = rand_pulse(d, n_dt, n_cops, n_nops, btype, rng)
+        omega = np.sort(np.concatenate([[-3.0, 0.0], np.geomspace(3e-2, 30.0, 9)]))
+        ncd = rng.standard_normal((n_nops, n_cops, n_dt))
+        pulse.diagonalize()
+        t = np.concatenate(([0.0], pulse.dt.cumsum()))
+        for k, v in pulse_inputs(pulse).items():
+            arrays[f'{name}_{k}'] = v
+        arrays[f'{name}_omega'] = omega
+        arrays[f'{name}_n_coeffs_deriv'] = ncd
+        arrays[f'{name}_eigvals'] = pulse.eigvals
+        arrays[f'{name}_eigvecs'] = pulse.eigvecs
+        arrays[f'{name}_propagators'] = pulse.propagators
+        R = pulse.get_control_matrix(omega)
+        arrays[f'{name}_control_matrix'] = R
+        for tag, nd in (('', None), ('_ncd', ncd)):
+            dR = gradient.calculate_derivative_of_control_matrix_from_scratch(
+                omega, pulse.propagators, pulse.eigvals, pulse.eigvecs, pulse.basis, t, pulse.dt,
+                pulse.n_opers, pulse.n_coeffs, pulse.c_opers, nd)
+            arrays[f'{name}_control_matrix_derivative{tag}'] = dR
+            arrays[f'{name}_filter_function_derivative{tag}'] = \
+                gradient.calculate_filter_function_derivative(R, dR)
+    save('gradient_ctrlmat', **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'gradient_ctrlmat':
+        make_gradient_ctrlmat()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'register':
         make_register()
         return

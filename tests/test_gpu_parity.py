@@ -1530,6 +1530,102 @@ def test_gradient_random_shapes_against_oracle_and_finite_differences(seed):
             assert np.allclose(grad[:, s, order[h]], fd, rtol=1e-5, atol=1e-9), (s, h)
 
 
+@pytest.mark.parametrize('name', ['q1', 'g3', 'p4', 'g5'])
+def test_control_matrix_derivative_against_reference(name):
+    """gradient.calculate_derivative_of_control_matrix_from_scratch and
+    calculate_filter_function_derivative against the reference's outputs (gradient.py:384-556),
+    with and without n_coeffs_deriv; consistency with get_filter_function_derivative."""
+    g = load_golden('gradient_ctrlmat')
+    omega, dt = g[f'{name}_omega'], g[f'{name}_dt']
+    t = np.concatenate(([0.0], dt.cumsum()))
+    args = (omega, g[f'{name}_propagators'], g[f'{name}_eigvals'], g[f'{name}_eigvecs'],
+            g[f'{name}_basis'], t, dt, g[f'{name}_n_opers'], g[f'{name}_n_coeffs'],
+            g[f'{name}_c_opers'])
+    R = g[f'{name}_control_matrix']
+    for tag, ncd in (('', None), ('_ncd', g[f'{name}_n_coeffs_deriv'])):
+        dR = gradient.calculate_derivative_of_control_matrix_from_scratch(*args, ncd)
+        ref = g[f'{name}_control_matrix_derivative{tag}']
+        assert dR.shape == ref.shape and dR.dtype == np.complex128
+        assert rel_err(dR, ref) < TOL
+        dF = gradient.calculate_filter_function_derivative(R, dR)
+        assert dF.dtype == np.float64
+        assert rel_err(dF, g[f'{name}_filter_function_derivative{tag}']) < TOL
+        assert rel_err(gradient.calculate_filter_function_derivative(R, ref),
+                       g[f'{name}_filter_function_derivative{tag}']) < TOL
+    pulse = etm_pulse(g, name)
+    assert rel_err(pulse.get_filter_function_derivative(omega),
+                   g[f'{name}_filter_function_derivative']) < TOL
+    with pytest.raises(ValueError):
+        gradient.calculate_derivative_of_control_matrix_from_scratch(
+            *args, g[f'{name}_n_coeffs_deriv'][:, :1])
+    with pytest.raises(ValueError):
+        gradient.calculate_filter_function_derivative(R[:, :-1], ref)
+
+
+@pytest.mark.parametrize('seed', range(3))
+def test_control_matrix_derivative_random_shapes_against_oracle(seed):
+    """Random shapes (d = 2..8, an idle segment, w = 0 and negative frequencies, W not a multiple
+    of the wavefront) against the oracle, and a finite-difference check of the control matrix."""
+    rng = np.random.default_rng(5200 + seed)
+    for _ in range(3):
+        d = int(rng.integers(2, 9))
+        G = int(rng.integers(1, 6))
+        A, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        W = int(rng.choice([1, 9, 64, 70]))
+
+        def herm(n):
+            M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+            return M + M.conj().transpose(0, 2, 1)
+        c_opers, n_opers = herm(H), herm(A)
+        c_coeffs = rng.standard_normal((H, G))
+        if G > 2:
+            c_coeffs[:, 1] = 0.0
+        n_coeffs = rng.random((A, G)) + 0.1
+        dt = rng.random(G) + 0.2
+        omega = np.sort(rng.random(W))*10 - 2.0
+        if W > 2:
+            omega[W//2] = 0.0
+        basis = np.asarray(ff.Basis.ggm(d))
+        Hm = orc.hamiltonian(c_opers, c_coeffs)
+        D, V, Q = orc.diagonalize(Hm, dt)
+        ncd = rng.standard_normal((A, H, G)) if rng.random() < 0.5 else None
+        t = np.concatenate(([0.0], dt.cumsum()))
+        dR = gradient.calculate_derivative_of_control_matrix_from_scratch(
+            omega, Q, D, V, basis, t, dt, n_opers, n_coeffs, c_opers, ncd)
+        ref = orc.control_matrix_derivative(D, V, Q, omega, basis, n_opers, n_coeffs, c_opers, dt,
+                                            ncd)
+        tag = f'd={d} G={G} A={A} H={H} W={W}'
+        assert rel_err(dR, ref) < TOL, tag
+        R = orc.control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+        assert rel_err(gradient.calculate_filter_function_derivative(R, dR),
+                       orc.filter_function_derivative_from_control_matrix(R, ref)) < TOL, tag
+    # central finite differences of the device control matrix
+    d, G, H, A = 3, 3, 2, 2
+    c_opers, n_opers = herm(H)[:, :d, :d], herm(A)[:, :d, :d]
+    c_opers = (c_opers + c_opers.conj().transpose(0, 2, 1))/2
+    n_opers = (n_opers + n_opers.conj().transpose(0, 2, 1))/2
+    c_coeffs, n_coeffs = rng.standard_normal((H, G)), rng.random((A, G)) + 0.5
+    dt = rng.random(G) + 0.3
+    omega = np.linspace(-2, 8, 11)
+    basis = ff.Basis.ggm(d)
+
+    def ctrlmat(cc):
+        Dm, Vm, Qm = numeric.diagonalize(np.einsum('hij,hg->gij', c_opers, cc), dt)
+        return numeric.calculate_control_matrix_from_scratch(Dm, Vm, Qm, omega, basis, n_opers,
+                                                             n_coeffs, dt), (Dm, Vm, Qm)
+    _, (D, V, Q) = ctrlmat(c_coeffs)
+    dR = gradient.calculate_derivative_of_control_matrix_from_scratch(
+        omega, Q, D, V, basis, None, dt, n_opers, n_coeffs, c_opers)
+    eps = 1e-6
+    for s in range(G):
+        for h in range(H):
+            cp, cm = c_coeffs.copy(), c_coeffs.copy()
+            cp[h, s] += eps
+            cm[h, s] -= eps
+            fd = (ctrlmat(cp)[0] - ctrlmat(cm)[0])/(2*eps)           # (A, N, W)
+            assert np.allclose(dR[h, :, s].transpose(1, 2, 0), fd, rtol=1e-5, atol=1e-8), (s, h)
+
+
 @pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
 def test_concatenate_periodic(name):
     """concatenate_periodic against the reference's closed-form result (pulse_sequence.py:1890-1973)
@@ -1652,3 +1748,22 @@ def test_extend_retains_cached_filter_functions():
         ff.extend([(p['p2'], 0)])                                 # dimension mismatch
     with pytest.warns(UserWarning):
         assert ff.extend([(p['p1'], 0)], N=1) is p['p1']
+
+
+def test_libffk_before_torch_shares_one_hip_runtime():
+    """libffk used first, torch.cuda initialised afterwards, in a fresh interpreter: both must see
+    the GPU (one HIP/HSA runtime in the process, _lib._share_hip_runtime_with_torch)."""
+    import subprocess
+    import sys
+    code = ('import numpy as np, filter_functions_amd as ff\n'
+            'from filter_functions_amd import _lib\n'
+            'assert _lib.device_count() >= 1\n'
+            'D, V, Q = ff.numeric.diagonalize(np.array([np.diag([1.0, -1.0]).astype(complex)]), '
+            'np.array([0.5]))\n'
+            'import torch\n'
+            'x = torch.ones(4, device="cuda")\n'
+            'assert float(x.sum()) == 4.0\n'
+            'print("shared", D.ravel())\n')
+    res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0 and 'shared' in res.stdout, res.stderr[-2000:]

@@ -351,3 +351,20 @@ def test_filter_function_and_infidelity_derivative(name):
     sub = orc.filter_function_derivative(*args, g[f'{name}_n_opers'][ni], g[f'{name}_n_coeffs'][ni],
                                          g[f'{name}_c_opers'][ci], g[f'{name}_dt'])
     assert rel_err(sub, g[f'{name}_filter_function_derivative_sub']) < 1e-12
+
+
+@pytest.mark.parametrize('name', ['q1', 'g3', 'p4', 'g5'])
+def test_control_matrix_derivative(name):
+    """Oracle (Hilbert-space derivative of the interaction-picture noise operators, expanded in the
+    basis) vs the reference's gradient.calculate_derivative_of_control_matrix_from_scratch and
+    calculate_filter_function_derivative (gradient.py:384-556)."""
+    g = load_golden('gradient_ctrlmat')
+    args = (g[f'{name}_eigvals'], g[f'{name}_eigvecs'], g[f'{name}_propagators'], g[f'{name}_omega'],
+            g[f'{name}_basis'], g[f'{name}_n_opers'], g[f'{name}_n_coeffs'], g[f'{name}_c_opers'],
+            g[f'{name}_dt'])
+    for tag, ncd in (('', None), ('_ncd', g[f'{name}_n_coeffs_deriv'])):
+        dR = orc.control_matrix_derivative(*args, ncd)
+        ref = g[f'{name}_control_matrix_derivative{tag}']
+        assert dR.shape == ref.shape and rel_err(dR, ref) < 1e-13
+        dF = orc.filter_function_derivative_from_control_matrix(g[f'{name}_control_matrix'], ref)
+        assert rel_err(dF, g[f'{name}_filter_function_derivative{tag}']) < 1e-13
