@@ -12,7 +12,7 @@ import pytest
 
 import ff_oracle as orc
 import filter_functions_amd as ff
-from conftest import load_golden, rel_err
+from conftest import ROOT, load_golden, rel_err
 from filter_functions_amd import _lib, gradient, numeric, util
 
 pytestmark = pytest.mark.gpu
