@@ -3,7 +3,7 @@ concatenation (examples/randomized_benchmarking.py:95-151, naive gates, d=2, 1 n
 8192 omega).  Times ff.concatenate(...) on the GPU (whole call, host bookkeeping included) and
 the CPU oracle's concatenation rule on the same atomic control matrices.
 
-    python tools/bench_concatenate.py [--gates 1000] [--omega 8192]
+    python tests/tools/bench_concatenate.py [--gates 1000] [--omega 8192]
 """
 import argparse
 import os
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 

@@ -2,7 +2,7 @@
 operators, GGM basis, 16384 omega -- the full error-transfer-matrix path
 (control matrix -> decay amplitudes -> cumulant function -> exp), device resident.
 
-    python tools/bench_config5.py [--W 16384] [--cpu-sample 128]
+    python tests/tools/bench_config5.py [--W 16384] [--cpu-sample 128]
 
 The pulse is synthetic (seeded random amplitudes on single-qubit X/Y/Z and nearest-neighbour
 ZZ / XX terms); the CPU leg runs the NumPy oracle on a bounded sample of the frequencies.
@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 

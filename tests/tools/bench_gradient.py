@@ -1,12 +1,12 @@
 """Time the infidelity gradient at the BASELINE config-2 shape (d=4, 256 segments, 3 noise operators,
-3 control operators, 4096 frequencies).  Usage: python tools/bench_gradient.py [W] [reps]"""
+3 control operators, 4096 frequencies).  Usage: python tests/tools/bench_gradient.py [W] [reps]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import ff_oracle as orc  # noqa: E402

@@ -1,13 +1,13 @@
 """Time the second-order filter function at the BASELINE config-2 shape (d=4, 256 segments, 3 noise
 operators, 4096 frequencies: F2 is (3,3,16,16,4096) c128 = 151 MB) and check a frequency subsample
-against the oracle.  Usage: python tools/bench_second_order.py [W] [reps]"""
+against the oracle.  Usage: python tests/tools/bench_second_order.py [W] [reps]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import ff_oracle as orc  # noqa: E402

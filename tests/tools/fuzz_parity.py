@@ -1,12 +1,12 @@
 """Randomised parity sweep against the oracle (not part of the test suite: run on the GPU box when
-kernels change).  Usage: python tools/fuzz_parity.py [n_cases] [seed]"""
+kernels change).  Usage: python tests/tools/fuzz_parity.py [n_cases] [seed]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import ff_oracle as orc  # noqa: E402
