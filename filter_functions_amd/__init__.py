@@ -15,6 +15,7 @@ See DESIGN.md for the scope, INTEGRATION.md for the boundary.
 """
 from . import analytic, basis, gradient, numeric, pulse_sequence, superoperator, util
 from .basis import Basis
+from .gradient import infidelity_derivative
 from .numeric import error_transfer_matrix, infidelity
 from .pulse_sequence import (PulseSequence, concatenate, concatenate_periodic,
                              concatenate_without_filter_function, extend, remap)
@@ -22,7 +23,8 @@ from .superoperator import liouville_representation
 
 __all__ = ['analytic', 'Basis', 'PulseSequence', 'basis', 'concatenate', 'concatenate_periodic',
            'concatenate_without_filter_function',
-           'error_transfer_matrix', 'extend', 'gradient', 'infidelity', 'liouville_representation', 'numeric',
+           'error_transfer_matrix', 'extend', 'gradient', 'infidelity', 'infidelity_derivative',
+           'liouville_representation', 'numeric',
            'pulse_sequence', 'remap', 'superoperator', 'util']
 
 __version__ = '0.1.0'

@@ -503,3 +503,67 @@ def test_tensor_product_chains():
     h = util.hash_array_along_axis(np.array([[0.0, 1.0], [-0.0, 1.0], [0.0, 2.0]]))
     assert h[0] == h[1] != h[2]
     assert list(util.progressbar(range(3), disable=True)) == [0, 1, 2]
+
+
+# public names of the reference's modules (v1.2.1; functions, classes, methods and properties)
+REFERENCE_API = {'analytic': ['CDD', 'CPMG', 'FID', 'PDD', 'SE', 'UDD'],
+ 'basis': ['Basis', 'Basis.H', 'Basis.T', 'Basis.expand', 'Basis.four_element_traces',
+           'Basis.from_partial', 'Basis.ggm', 'Basis.iscomplete', 'Basis.isherm', 'Basis.isnorm',
+           'Basis.isorthogonal', 'Basis.isorthonorm', 'Basis.istraceless', 'Basis.normalize',
+           'Basis.pauli', 'Basis.sparse', 'Basis.tidyup', 'equivalent_pauli_basis_elements',
+           'expand', 'ggm_expand', 'normalize', 'remap_pauli_basis_elements'],
+ 'gradient': ['calculate_derivative_of_control_matrix_from_scratch',
+              'calculate_filter_function_derivative', 'infidelity_derivative'],
+ 'numeric': ['calculate_control_matrix_from_atomic', 'calculate_control_matrix_from_scratch',
+             'calculate_control_matrix_periodic', 'calculate_cumulant_function',
+             'calculate_decay_amplitudes', 'calculate_filter_function',
+             'calculate_frequency_shifts', 'calculate_noise_operators_from_atomic',
+             'calculate_noise_operators_from_scratch',
+             'calculate_pulse_correlation_filter_function',
+             'calculate_second_order_filter_function_from_atomic',
+             'calculate_second_order_filter_function_from_scratch', 'diagonalize',
+             'error_transfer_matrix', 'infidelity'],
+ 'pulse_sequence': ['PulseSequence', 'PulseSequence.cache_control_matrix',
+                    'PulseSequence.cache_filter_function', 'PulseSequence.cache_total_phases',
+                    'PulseSequence.cleanup', 'PulseSequence.data', 'PulseSequence.diagonalize',
+                    'PulseSequence.duration', 'PulseSequence.eigvals', 'PulseSequence.eigvecs',
+                    'PulseSequence.frequency_data', 'PulseSequence.from_arrays',
+                    'PulseSequence.get_control_matrix', 'PulseSequence.get_filter_function',
+                    'PulseSequence.get_filter_function_derivative',
+                    'PulseSequence.get_pulse_correlation_control_matrix',
+                    'PulseSequence.get_pulse_correlation_filter_function',
+                    'PulseSequence.get_total_phases', 'PulseSequence.intermediates',
+                    'PulseSequence.is_cached', 'PulseSequence.nbytes', 'PulseSequence.omega',
+                    'PulseSequence.propagator_at_arb_t', 'PulseSequence.propagators',
+                    'PulseSequence.t', 'PulseSequence.tau', 'PulseSequence.total_propagator',
+                    'PulseSequence.total_propagator_liouville', 'concatenate',
+                    'concatenate_periodic', 'concatenate_without_filter_function', 'extend',
+                    'remap'],
+ 'superoperator': ['liouville_is_CP', 'liouville_is_cCP', 'liouville_representation',
+                   'liouville_to_choi'],
+ 'util': ['CalculationError', 'abs2', 'adot', 'all_array_equal', 'cexp', 'cexpm1', 'dot_HS',
+          'get_indices_from_identifiers', 'get_sample_frequencies', 'hash_array_along_axis',
+          'integrate', 'is_sequence_like', 'mdot', 'oper_equiv', 'parse_operators',
+          'parse_optional_parameters', 'parse_spectrum', 'progressbar', 'progressbar_range',
+          'remove_float_errors', 'tensor', 'tensor_insert', 'tensor_merge', 'tensor_transpose']}
+NOT_BUILT = {'basis': {'Basis.sparse'}}       # needs the `sparse` package
+
+
+def test_public_api_surface_covers_the_reference():
+    """Every public function, class, method and property of the reference's modules (plotting aside,
+    SURVEY section 2) exists here under the same name; package-level exports likewise."""
+    import importlib
+    for mod, names in REFERENCE_API.items():
+        m = importlib.import_module(f'filter_functions_amd.{mod}')
+        for name in names:
+            if name in NOT_BUILT.get(mod, ()):
+                continue
+            obj = m
+            for part in name.split('.'):
+                assert hasattr(obj, part), f'{mod}.{name} missing'
+                obj = getattr(obj, part)
+    for name in ['Basis', 'PulseSequence', 'analytic', 'basis', 'concatenate', 'concatenate_periodic',
+                 'error_transfer_matrix', 'extend', 'infidelity', 'liouville_representation',
+                 'numeric', 'gradient', 'pulse_sequence', 'remap', 'util', 'superoperator',
+                 'infidelity_derivative']:
+        assert name in ff.__all__ and hasattr(ff, name), name
