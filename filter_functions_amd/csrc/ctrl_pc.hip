@@ -28,6 +28,9 @@
 namespace ffk {
 namespace {
 
+#ifndef FFK_PC_PRIO_PRODUCER   /* 0..3; tuning builds override */
+#define FFK_PC_PRIO_PRODUCER 1
+#endif
 #if defined(FFK_PC_SUB)       /* tuning builds */
 constexpr int kPcSub = FFK_PC_SUB;
 #else
@@ -88,6 +91,12 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
 
     if (producer) {
         // ---- producer: operands + table rows -> LDS, integral tile of the next segment ----------
+        // Static issue priority: the producer's work is a chain of dependent operations (argument
+        // reduction -> polynomial -> reciprocal -> entries); at equal priority it competes with three
+        // consumers' independent FMAs for every issue slot, finishes last and all 16 waves wait for it
+        // at the barrier.  One s_setprio before the loop, no per-segment flips: accumulate 92.0 ->
+        // 86.2 us at config 2 (priority 3: the same; consumers at priority 1 instead: 94.6 us).
+        __builtin_amdgcn_s_setprio(FFK_PC_PRIO_PRODUCER);
         const int n_ops = (1 + n_alpha)*DD;           // <= 64: one element per lane
         auto load_ops = [&](int g) -> cplx {
             const cplx* src = ops + static_cast<size_t>(g)*(1 + A)*DD;
@@ -147,6 +156,9 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
         }
     } else {
         // ---- consumers: Y += T^dag [Bbar o E] T on the tile of the current segment -------------
+#if defined(FFK_PC_PRIO_CONSUMER)     /* tuning builds */
+        __builtin_amdgcn_s_setprio(FFK_PC_PRIO_CONSUMER);
+#endif
         cplx Y[D][D];
 #pragma unroll
         for (int i = 0; i < D; ++i)
