@@ -139,6 +139,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--omega-per-gpu', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--pipeline-depth', type=int, default=8,
+                    help='N > 1: buffer sets in flight (the all-gather of step i may complete while '
+                         'steps i+1 .. i+depth-1 compute)')
     ap.add_argument('--no-pmc', action='store_true',
                     help='skip the rocprofv3 --pmc child runs that measure the HBM traffic')
     args = ap.parse_args()
@@ -182,24 +185,37 @@ def main():
     def make_pipe():
         return DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, basis,
                               omega, spectrum=spectrum_full[w0:w1], device=device)
-    # With sharding, the all-gather + infidelity of step i run on a second stream while step i+1
-    # computes (the steps are independent passes): two sets of buffers, ping-pong.
-    pipes = [make_pipe(), make_pipe()] if use_dist else [make_pipe()]
+    # With sharding, the all-gather + infidelity of step i run on a second stream while the next
+    # steps compute (the steps are independent passes): `depth` sets of buffers, round robin.  The
+    # accumulate kernel holds every CU's LDS, so a collective kernel that becomes ready while it
+    # runs only starts when its blocks retire; with two buffer sets the next-but-one step then waits
+    # for it (0.163 ms/step on one rank), with more the collective falls into the window of the
+    # small kernels between two accumulate launches.
+    depth = max(2, args.pipeline_depth + (args.pipeline_depth & 1))      # even
+    pipes = [make_pipe() for _ in range(depth)] if use_dist else [make_pipe()]
     pipe = pipes[0]
     if use_dist:
         omega_full_dev = torch.from_numpy(omega_full).to(device)
         S_full_dev = torch.from_numpy(spectrum_full.astype(complex)).to(device)
         idx_dev = torch.arange(A, dtype=torch.int32, device=device)
         comm_stream = torch.cuda.Stream(device=device)
-        free_events = [None, None]
+        free_events = [None]*depth
         # all-gather buffers (world, A, A, W_shard) and results, allocated once
         gathered = [torch.empty((world, A, A, w1 - w0), dtype=torch.complex128, device=device)
-                    for _ in range(2)]
-        infid_out = [torch.empty(A, dtype=torch.float64, device=device) for _ in range(2)]
+                    for _ in range(depth)]
+        infid_out = [torch.empty(A, dtype=torch.float64, device=device) for _ in range(depth)]
         equal_shards = all(shard_bounds(W_total, world, r)[1] - shard_bounds(W_total, world, r)[0]
                            == w1 - w0 for r in range(world))
 
-    compute_stream = torch.cuda.current_stream(device)
+    if use_dist and not os.environ.get('FFK_BENCH_DEFAULT_STREAM'):
+        # Two explicitly created streams: HIP spreads created streams over the hardware queues,
+        # whereas torch's default stream and one side stream shared a queue on this system (every
+        # kernel of the trace on one queue, in submission order: nothing overlapped).
+        compute_stream = torch.cuda.Stream(device=device)
+        comm_stream = torch.cuda.Stream(device=device)
+        torch.cuda.synchronize(device)
+    else:
+        compute_stream = torch.cuda.current_stream(device)
     stream = compute_stream.cuda_stream
     n_ev = args.steps
     ev = [[ctypes.c_void_p(), ctypes.c_void_p()] for _ in range(n_ev)]
@@ -214,11 +230,17 @@ def main():
         if not use_dist:
             pipe.launch(stream=stream, with_infidelity=True)
             return pipe.infid
-        k = counter[0] % 2
+        k = counter[0] % depth
         counter[0] += 1
         p = pipes[k]
-        if free_events[k] is not None:
-            compute_stream.wait_event(free_events[k])       # its F was consumed by the gather
+        # Buffer set k was last read by the gather of step c - depth.  The comm stream is in order,
+        # so it is enough that the compute stream waits, every depth/2 steps, for the comm work of
+        # depth/2 steps ago: for every step j of the following half-window, gather(j - depth) is
+        # older than that.  (A wait per step costs ~4 us of barrier-packet handling each.)
+        c = counter[0] - 1
+        half = depth//2
+        if c >= half and c % half == 0:
+            compute_stream.wait_event(free_events[(c - half) % depth])
         p.launch(stream=stream, with_infidelity=False)
         ready = torch.cuda.Event()
         ready.record(compute_stream)
