@@ -28,6 +28,9 @@
 namespace ffk {
 namespace {
 
+#ifndef FFK_PC_WFOLD            /* 1: consumers contract with Bbar_mn T_nj from LDS (no Bbar o E pass) */
+#define FFK_PC_WFOLD 0
+#endif
 #ifndef FFK_PC_PRIO_PRODUCER   /* 0..3; tuning builds override */
 #define FFK_PC_PRIO_PRODUCER 1
 #endif
@@ -67,7 +70,12 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
     constexpr int GS = kPcSub, NWS = NC + 1;
     constexpr int S = seg_stride(D), DD = D*D;
     constexpr int TILE = DD*64;                       // cplx per integral tile
-    constexpr int BUF = TILE + (1 + NC)*DD;           // cplx per buffer: tile | T_g, Bbar_0..
+#if FFK_PC_WFOLD
+    constexpr int OPS = DD + NC*D*DD;                 // T_g | W_a[m][n][j] = Bbar_a[m][n] T_g[n][j]
+#else
+    constexpr int OPS = (1 + NC)*DD;                  // T_g | Bbar_0 ..
+#endif
+    constexpr int BUF = TILE + OPS;                   // cplx per buffer: tile | operands
     constexpr int SUB = 2*BUF + S;                    // cplx per sub-chunk: 2 buffers | 2 table rows
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
@@ -102,6 +110,24 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
             const cplx* src = ops + static_cast<size_t>(g)*(1 + A)*DD;
             return lane < n_ops ? src[lane < DD ? lane : lane + alpha0*DD] : cplx{0.0, 0.0};
         };
+        // operands of one segment into LDS; lane l holds element l of [T | Bbar_0 | Bbar_1 ..]
+        auto store_ops = [&](cplx* dst, cplx o) {
+#if FFK_PC_WFOLD
+            // W_a[m][n][j] = Bbar_a[m][n] T[n][j], (m, n, j) = this lane's index: the factors come
+            // from the lanes that loaded them
+            if (lane < DD) dst[lane] = o;
+            const int src_t = lane % DD;                          // T[n][j]
+            const cplx tv = {__shfl(o.re, src_t, 64), __shfl(o.im, src_t, 64)};
+#pragma unroll
+            for (int a = 0; a < NC; ++a) {
+                const int src_b = DD + a*DD + lane / D;           // Bbar_a[m][n]
+                const cplx bv = {__shfl(o.re, src_b, 64), __shfl(o.im, src_b, 64)};
+                dst[DD + a*D*DD + lane] = cmul(bv, tv);
+            }
+#else
+            if (lane < n_ops) dst[lane] = o;
+#endif
+        };
         auto load_row = [&](int g) -> cplx {
             const cplx* src = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
             return lane < S/2 ? src[lane] : cplx{0.0, 0.0};
@@ -123,6 +149,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
             }
         };
         static_assert((1 + NC)*DD <= 64 && S/2 <= 64, "one staging element per lane");
+        static_assert(!FFK_PC_WFOLD || D*DD == 64, "W_a has one element per lane");
         // prologue: rows g0, g0+1 and operands g0 straight in, tile g0
         if (g0 < g1) {
             const cplx r0 = load_row(g0), o0 = load_ops(g0);
@@ -131,7 +158,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
                 reinterpret_cast<cplx*>(rows)[lane] = r0;
                 reinterpret_cast<cplx*>(rows + S)[lane] = r1;
             }
-            if (lane < n_ops) lds[TILE + lane] = o0;
+            store_ops(lds + TILE, o0);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             generate(0, 0);
@@ -147,7 +174,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
 #if !(defined(FFK_PC_ABLATE) && FFK_PC_ABLATE == 1)   /* diagnostic: no generation */
                 generate(nb, nb);                     // row g+1 lives in slot (it+1) & 1
 #endif
-                if (lane < n_ops) lds[static_cast<size_t>(nb)*BUF + TILE + lane] = o;
+                store_ops(lds + static_cast<size_t>(nb)*BUF + TILE, o);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();      // row g+1 fully read before it is replaced
                 if (lane < S/2) reinterpret_cast<cplx*>(rows + (it & 1)*S)[lane] = r;
@@ -188,18 +215,32 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
                 const cplx* tile = lds + static_cast<size_t>(it & 1)*BUF;
                 const cplx* src = tile + lane;
                 const cplx* opT = tile + TILE;                       // T[n][j]
+#if FFK_PC_WFOLD
+                const cplx* opW = opT + DD + cidx*D*DD;              // Bbar_alpha[m][n] T[n][j]
+#else
                 const cplx* opB = opT + (1 + cidx)*DD;               // Bbar_alpha[m][n]
+#endif
 #pragma unroll
                 for (int m = 0; m < D; ++m) {
+                    cplx Z[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) Z[j] = {0.0, 0.0};
+#if FFK_PC_WFOLD
+                    // Z_j = sum_n E_mn (Bbar_mn T_nj): no separate Bbar o E pass
+#pragma unroll
+                    for (int n = 0; n < D; ++n) {
+                        const int slot = (m == n) ? 0 : m*D + n;
+                        const cplx e = src[slot*64];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) cmac(Z[j], opW[(m*D + n)*D + j], e);
+                    }
+#else
                     cplx X[D];
 #pragma unroll
                     for (int n = 0; n < D; ++n) {
                         const int slot = (m == n) ? 0 : m*D + n;
                         X[n] = cmul(opB[m*D + n], src[slot*64]);
                     }
-                    cplx Z[D];
-#pragma unroll
-                    for (int j = 0; j < D; ++j) Z[j] = {0.0, 0.0};
 #pragma unroll
                     for (int n = 0; n < D; ++n)
 #pragma unroll
@@ -210,6 +251,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
                             cmac(Z[j], opT[n*D + j], X[n]);
 #endif
                         }
+#endif
 #pragma unroll
                     for (int i = 0; i < D; ++i) {
 #if !defined(FFK_PC_T_FROM_LDS)
@@ -274,7 +316,7 @@ template <int D, int NC>
 hipError_t launch_pc(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                      int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
     constexpr int S = seg_stride(D), DD = D*D;
-    const int lds = static_cast<int>(kPcSub*(2*(DD*64 + (1 + NC)*DD) + S)*sizeof(cplx));
+    const int lds = pc_accumulate_lds_bytes(D, NC);
     auto kern = ctrl_accumulate_pc_kernel<D, NC>;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -292,7 +334,8 @@ int pc_accumulate_ops_per_block(int A) { return A >= 3 ? 3 : A; }
 int pc_accumulate_subchunks() { return kPcSub; }
 int pc_accumulate_lds_bytes(int d, int nc) {
     const int S = seg_stride(d), dd = d*d;
-    return static_cast<int>(kPcSub*(2*(dd*64 + (1 + nc)*dd) + S)*sizeof(cplx));
+    const int ops = FFK_PC_WFOLD ? dd + nc*d*dd : (1 + nc)*dd;
+    return static_cast<int>(kPcSub*(2*(dd*64 + ops) + S)*sizeof(cplx));
 }
 
 hipError_t launch_accumulate_pc(const double* omega, int W, const double* segtab, const cplx* ops,
