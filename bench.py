@@ -143,7 +143,7 @@ def main():
                     help='N > 1: buffer sets in flight (the all-gather of step i may complete while '
                          'steps i+1 .. i+depth-1 compute)')
     ap.add_argument('--event-stride', type=int, default=8,
-                    help='time the accumulate kernel with HIP events on every n-th step')
+                    help='time the accumulate kernel with HIP events on the last steps/n steps')
     ap.add_argument('--no-pmc', action='store_true',
                     help='skip the rocprofv3 --pmc child runs that measure the HBM traffic')
     args = ap.parse_args()
@@ -219,12 +219,16 @@ def main():
     else:
         compute_stream = torch.cuda.current_stream(device)
     stream = compute_stream.cuda_stream
-    # HIP events around the accumulate kernel on every `stride`-th step of the timed region: each
-    # timed event record costs ~5.5 us of barrier-packet handling on this stack (kernel trace: the only
-    # two gaps of a step were the ones around the instrumented launch), so instrumenting every step
-    # would tax the measured throughput by 8 %.
+    # HIP events around the accumulate kernel on the last steps/`stride` steps of the timed region
+    # (at least 25): each timed event record costs several us of barrier-packet handling on this
+    # stack (kernel trace: the only two gaps of a step were the ones around the instrumented
+    # launch), so instrumenting every step taxed the measured throughput by 3-4 %.  A contiguous
+    # block, not every n-th step: an isolated event pair in an otherwise gap-free stream reads
+    # ~3.5 us longer than the kernel (91.2 against rocprofv3's 87.6 us), back-to-back pairs ~1 us;
+    # and the last steps, not the first: right after the barrier the queue is still shallow and the
+    # clocks are ramping (first 25 steps: 96-97 us).
     stride = max(1, args.event_stride)
-    n_ev = (args.steps + stride - 1)//stride
+    n_ev = min(args.steps, max(25, (args.steps + stride - 1)//stride))
     ev = [[ctypes.c_void_p(), ctypes.c_void_p()] for _ in range(n_ev)]
     for pair in ev:
         for e in pair:
@@ -233,10 +237,9 @@ def main():
 
     def step(i=None):
         if i is not None:
-            if i % stride == 0:
-                _lib.check(lib.ffk_set_accumulate_events(ev[i//stride][0], ev[i//stride][1]))
-            elif i % stride == 1:
-                _lib.check(lib.ffk_set_accumulate_events(None, None))
+            j = i - (args.steps - n_ev)
+            if j >= 0:
+                _lib.check(lib.ffk_set_accumulate_events(ev[j][0], ev[j][1]))
         if not use_dist:
             pipe.launch(stream=stream, with_infidelity=True)
             return pipe.infid
