@@ -37,6 +37,26 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Complex Jacobi rotation annihilating a_pq:  (x_p, x_q) <- (c x_p - conj(w) x_q, w x_p + c x_q) on
+// columns, with alpha = (a_qq - a_pp)/2, r = sqrt(alpha^2 + |a_pq|^2):
+//     cos 2t = |alpha|/r,  c = sqrt((1 + cos 2t)/2),  |w| = sin t = (|a_pq|/r)/(2c)   (|t| <= pi/4),
+//     w = sign(alpha) a_pq/(2 r c).
+// Two reciprocal square roots in the dependent chain, no division, no square root (this scalar
+// section is the critical path of every Jacobi step; the tan-based form needed four).  c^2 lies in
+// [1/2, 1]: no cancellation.  Returns false where there is nothing to rotate.
+__device__ __forceinline__ bool jacobi_rotation(cplx apq, double alpha, double* c, cplx* w) {
+    const double mag2 = apq.re*apq.re + apq.im*apq.im;
+    const double r2 = fma(alpha, alpha, mag2);
+    if (!(mag2 > 0.0) || !(r2 < 1e300) || r2 < 2.3e-308) return false;
+    const double ri = rsqrt(r2);
+    const double c2 = fma(0.5*fabs(alpha), ri, 0.5);
+    const double ci = rsqrt(c2);
+    const double k = (alpha >= 0.0 ? 0.5 : -0.5)*ri*ci;
+    *c = c2*ci;
+    *w = {k*apq.re, k*apq.im};
+    return true;
+}
+
 // One wavefront: eigendecomposition of Hg (lower triangle), eigenvalues/eigenvectors to global
 // memory in ascending order, segment propagator P = V exp(-i D dt) V^dag to `P` (LDS or global).
 // Returns false if the Jacobi iteration clearly failed to converge.
@@ -47,6 +67,7 @@ __device__ bool eigh_expm_wave(EighState<D>& st, const cplx* __restrict__ Hg, do
     constexpr int DP = EighState<D>::DP;
     constexpr int NP = EighState<D>::NP;
     constexpr int kMaxSweeps = 40;
+    constexpr bool kRegisterRotations = NP*2*D <= 64;    // D <= 8
     auto& A = st.A;
     auto& V = st.V;
 
@@ -83,6 +104,64 @@ __device__ bool eigh_expm_wave(EighState<D>& st, const cplx* __restrict__ Hg, do
             break;
         }
         for (int step = 0; step < DP - 1; ++step) {
+            if constexpr (kRegisterRotations) {
+                // One lane per (rotation, matrix, row): every lane derives its rotation's angle
+                // itself (no hand-off through LDS) and keeps it in registers for the column update
+                // (A and V) and the row update (A; lanes of the A half, their row index as the
+                // column).  Two dependent LDS round trips per step instead of four.
+                const int pr = lane/(2*D), r = lane % (2*D);
+                int p, q;
+                if (pr == 0) {
+                    p = DP - 1;
+                    q = step;
+                } else {
+                    p = (step + pr) % (DP - 1);
+                    q = (step + (DP - 1) - pr) % (DP - 1);
+                }
+                if (p > q) {
+                    const int tmp = p;
+                    p = q;
+                    q = tmp;
+                }
+                bool valid = lane < NP*2*D && q < D;
+                double c = 1.0;
+                cplx w = {0.0, 0.0};
+                cplx(*M)[D] = (r >= D) ? V : A;
+                const int row = r % D;
+                cplx xp = {0.0, 0.0}, xq = {0.0, 0.0};
+                if (valid) {
+                    const cplx apq = A[p][q];
+                    const double alpha = 0.5*(A[q][q].re - A[p][p].re);
+                    xp = M[row][p];
+                    xq = M[row][q];
+                    valid = jacobi_rotation(apq, alpha, &c, &w);
+                }
+                if (valid) {
+                    M[row][p] = {c*xp.re - (w.re*xq.re + w.im*xq.im), c*xp.im - (w.re*xq.im - w.im*xq.re)};
+                    M[row][q] = {c*xq.re + (w.re*xp.re - w.im*xp.im), c*xq.im + (w.re*xp.im + w.im*xp.re)};
+                }
+                wave_sync();
+                if (valid && r < D) {
+                    const int col = r;
+                    xp = A[p][col];
+                    xq = A[q][col];
+                    cplx np = {c*xp.re - (w.re*xq.re - w.im*xq.im), c*xp.im - (w.re*xq.im + w.im*xq.re)};
+                    cplx nq = {c*xq.re + (w.re*xp.re + w.im*xp.im), c*xq.im + (w.re*xp.im - w.im*xp.re)};
+                    // the annihilated pair is exactly zero, the diagonal exactly real
+                    if (col == q) {
+                        np = {0.0, 0.0};
+                        nq.im = 0.0;
+                    }
+                    if (col == p) {
+                        nq = {0.0, 0.0};
+                        np.im = 0.0;
+                    }
+                    A[p][col] = np;
+                    A[q][col] = nq;
+                }
+                wave_sync();
+                continue;
+            }
             if (lane < NP) {
                 int p, q;
                 if (lane == 0) {
@@ -100,29 +179,7 @@ __device__ bool eigh_expm_wave(EighState<D>& st, const cplx* __restrict__ Hg, do
                 double c = 1.0;
                 cplx w = {0.0, 0.0};
                 bool valid = q < D;
-                if (valid) {
-                    const cplx apq = A[p][q];
-                    const double mag2 = apq.re*apq.re + apq.im*apq.im;
-                    if (mag2 > 0.0) {
-                        // rotation angle without IEEE divisions / square roots (reciprocal and
-                        // reciprocal-square-root seeds + Newton): this scalar section is the
-                        // critical path of every Jacobi step
-                        const double rmag = rsqrt(mag2);                       // 1/|a_pq|
-                        const double tau = 0.5*(A[q][q].re - A[p][p].re)*rmag;
-                        if (fabs(tau) < 1e150) {
-                            const double h2 = fma(tau, tau, 1.0);
-                            const double h = h2*rsqrt(h2);                     // sqrt(1 + tau^2)
-                            const double tt = (tau >= 0.0 ? 1.0 : -1.0)*rcp(fabs(tau) + h);
-                            c = rsqrt(fma(tt, tt, 1.0));
-                            const double s = tt*c*rmag;
-                            w = {s*apq.re, s*apq.im};
-                        } else {
-                            valid = false;   // |a_pq| below 1e-150 of the diagonal gap: nothing to do
-                        }
-                    } else {
-                        valid = false;
-                    }
-                }
+                if (valid) valid = jacobi_rotation(A[p][q], 0.5*(A[q][q].re - A[p][p].re), &c, &w);
                 st.rot_p[lane] = p;
                 st.rot_q[lane] = valid ? q : -1;
                 st.rot_c[lane] = c;
