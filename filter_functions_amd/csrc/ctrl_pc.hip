@@ -315,7 +315,6 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
 template <int D, int NC>
 hipError_t launch_pc(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                      int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
-    constexpr int S = seg_stride(D), DD = D*D;
     const int lds = pc_accumulate_lds_bytes(D, NC);
     auto kern = ctrl_accumulate_pc_kernel<D, NC>;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -132,12 +132,51 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
     __shared__ cplx T[D][D];
     __shared__ cplx BV[D][D];
     constexpr int kBatch = 16;
-    __shared__ cplx tot[kBatch][D][D];
+    constexpr bool kTree = D <= 8;                 // a whole matrix fits one pass of the 64 lanes
+    constexpr int kTot = kTree ? 64 : kBatch;      // use_fused_front: at most 64 chunks
+    __shared__ cplx tot[kTot][D][D];
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     const int c = g / L;
     for (int e = lane; e < D*D; e += 64) E[0][e / D][e % D] = {(e / D == e % D) ? 1.0 : 0.0, 0.0};
     int b = 0;
+    if constexpr (kTree) {
+        // exclusive prefix E_c = T_{c-1} ... T_0 of the chunk totals as an ordered pairwise tree
+        // (newer factor on the left), several products per pass: ceil(log2 c) dependent levels
+        // instead of c - 1 dependent products.  In place: pass j writes slot j after reading slots
+        // 2j and 2j+1, which no later pass of the level reads.
+        constexpr int DD = D*D, PER = 64/DD;
+        for (int e = lane; e < c*DD; e += 64) (&tot[0][0][0])[e] = totals[e];
+        __syncthreads();
+        int n = c;
+        while (n > 1) {
+            const int pairs = n >> 1;
+            for (int j0 = 0; j0 < pairs; j0 += PER) {
+                const int jj = j0 + lane/DD, e = lane % DD, i = e / D, k = e % D;
+                const bool act = lane < PER*DD && jj < pairs;
+                cplx acc = {0.0, 0.0};
+                if (act) {
+#pragma unroll
+                    for (int x = 0; x < D; ++x) cmac(acc, tot[2*jj + 1][i][x], tot[2*jj][x][k]);
+                }
+                __syncthreads();
+                if (act) tot[jj][i][k] = acc;
+                __syncthreads();
+            }
+            if (n & 1) {                            // the newest factor moves up unpaired
+                cplx carry = {0.0, 0.0};
+                if (lane < DD) carry = (&tot[n - 1][0][0])[lane];
+                __syncthreads();
+                if (lane < DD) (&tot[pairs][0][0])[lane] = carry;
+                __syncthreads();
+            }
+            n = pairs + (n & 1);
+        }
+        if (c > 0) {
+            for (int e = lane; e < DD; e += 64) E[0][e / D][e % D] = tot[0][e / D][e % D];
+            __syncthreads();
+        }
+    } else {
     // exclusive prefix of the chunk totals; the totals are staged in batches of independent loads
     // (one dependent global load per step cost ~0.5 us each)
     for (int kb = 0; kb < c; kb += kBatch) {
@@ -157,6 +196,7 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
             __syncthreads();
             b ^= 1;
         }
+    }
     }
     // Q[g] (into LDS) and Q[g+1] (to memory)
     for (int e = lane; e < D*D; e += 64) M[e / D][e % D] = Qloc[static_cast<size_t>(g + 1)*D*D + e];
