@@ -48,6 +48,62 @@ __global__ __launch_bounds__(64) void scan_local_kernel(const cplx* __restrict__
     for (int e = lane; e < D*D; e += 64) cur[0][e / D][e % D] = {(e / D == e % D) ? 1.0 : 0.0, 0.0};
     if (c == 0)
         for (int e = lane; e < D*D; e += 64) Q[e] = {(e / D == e % D) ? 1.0 : 0.0, 0.0};
+    if constexpr (D <= 4) {
+        // Four matrices fit one pass of the 64 lanes: the 16 segments of the chunk as four groups of
+        // four -- group-local prefixes side by side (3 dependent products), the exclusive prefixes
+        // of the four group totals (2), one independent fix-up per segment (1): 6 dependent
+        // products instead of 16.  Segments beyond the end count as identity.
+        constexpr int DD = D*D, NG = 4, GL = kScanBatch/NG;
+        if (L == kScanBatch) {
+            __shared__ cplx lp[NG][GL][D][D];
+            __shared__ cplx xg[NG][D][D];
+            for (int e = lane; e < kScanBatch*DD; e += 64) {
+                const int sg = e / DD, ent = e % DD;
+                cplx v = {(ent / D == ent % D) ? 1.0 : 0.0, 0.0};
+                if (g0 + sg < g1) v = P[static_cast<size_t>(g0 + sg)*DD + ent];
+                (&pg[0][0][0])[e] = v;
+            }
+            __syncthreads();
+            const int k = (lane / DD) % NG, e = lane % DD, i = e / D, j = e % D;
+            const bool act = lane < NG*DD;
+            if (act) lp[k][0][i][j] = pg[k*GL][i][j];
+            __syncthreads();
+            for (int sg = 1; sg < GL; ++sg) {
+                cplx acc = {0.0, 0.0};
+                if (act) {
+#pragma unroll
+                    for (int x = 0; x < D; ++x) cmac(acc, pg[k*GL + sg][i][x], lp[k][sg - 1][x][j]);
+                    lp[k][sg][i][j] = acc;
+                }
+                __syncthreads();
+            }
+            if (lane < DD) {
+                xg[0][i][j] = {(i == j) ? 1.0 : 0.0, 0.0};
+                xg[1][i][j] = lp[0][GL - 1][i][j];
+            }
+            __syncthreads();
+            for (int k2 = 2; k2 < NG; ++k2) {
+                if (lane < DD) {
+                    cplx acc = {0.0, 0.0};
+#pragma unroll
+                    for (int x = 0; x < D; ++x) cmac(acc, lp[k2 - 1][GL - 1][i][x], xg[k2 - 1][x][j]);
+                    xg[k2][i][j] = acc;
+                }
+                __syncthreads();
+            }
+            for (int sg = 0; sg < GL; ++sg) {
+                const int g = g0 + k*GL + sg;
+                if (act && g < g1) {
+                    cplx acc = {0.0, 0.0};
+#pragma unroll
+                    for (int x = 0; x < D; ++x) cmac(acc, lp[k][sg][i][x], xg[k][x][j]);
+                    Q[static_cast<size_t>(g + 1)*DD + e] = acc;
+                    if (g == g1 - 1) totals[static_cast<size_t>(c)*DD + e] = acc;
+                }
+            }
+            return;
+        }
+    }
     int b = 0;
     for (int gb = g0; gb < g1; gb += kScanBatch) {
         const int nb = min(kScanBatch, g1 - gb);
