@@ -351,27 +351,33 @@ __global__ __launch_bounds__(1024) void expand_ff_kernel(const cplx* __restrict_
                                                          cplx* __restrict__ F) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     cplx* rl = reinterpret_cast<cplx*>(lds_raw);       // [A][N][16]
+    cplx* ys = rl + static_cast<size_t>(A)*N*16;        // [A][dd][16]: chunk partials summed
     // thread = (frequency wl, basis-element lane kl, noise operator lane al)
     const int wl = threadIdx.x & 15;
     const int kl = (threadIdx.x >> 4) % kt, al = (threadIdx.x >> 4) / kt;
     const int at = (blockDim.x >> 4) / kt;
     const int w = blockIdx.x*16 + wl;
     const int wc = w < W ? w : W - 1;
+    // every partial sum is read from memory once (in chunk order) and expanded from LDS: a matrix
+    // element takes part in several basis elements (four for the Pauli basis of d = 4)
+    for (int idx = threadIdx.x >> 4; idx < A*dd; idx += blockDim.x >> 4) {
+        const cplx* b = Ypart + static_cast<size_t>(idx)*W + wc;
+        cplx acc = b[0];
+        for (int z = 1; z < chunks; ++z) {
+            const cplx v = b[z*slab];
+            acc.re += v.re;
+            acc.im += v.im;
+        }
+        ys[static_cast<size_t>(idx)*16 + wl] = acc;
+    }
+    __syncthreads();
     for (int a = al; a < A; a += at) {
-        const cplx* b = Ypart + static_cast<size_t>(a)*dd*W + wc;
+        const cplx* ya = ys + static_cast<size_t>(a)*dd*16 + wl;
         for (int k = kl; k < N; k += kt) {
             const int n = nnz[k];
             const int* rk = rows + static_cast<size_t>(k)*dd;
             const cplx* vk = vals + static_cast<size_t>(k)*dd;
-            auto summed = [&](int e) {
-                cplx acc = b[static_cast<size_t>(e)*W];
-                for (int z = 1; z < chunks; ++z) {
-                    const cplx v = b[z*slab + static_cast<size_t>(e)*W];
-                    acc.re += v.re;
-                    acc.im += v.im;
-                }
-                return acc;
-            };
+            auto summed = [&](int e) { return ya[e*16]; };
             cplx acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
             int q = 0;
             for (; q + 1 < n; q += 2) {
@@ -406,7 +412,8 @@ __global__ __launch_bounds__(1024) void expand_ff_kernel(const cplx* __restrict_
 }
 
 bool expand_ff_supported(int A, int N) {
-    return static_cast<size_t>(A)*N*16*sizeof(cplx) <= 64*1024;
+    // R tile [A][N][16] + summed partials [A][d^2][16], d^2 <= N for a complete basis; N bounds both
+    return static_cast<size_t>(A)*2*N*16*sizeof(cplx) <= 64*1024;
 }
 
 hipError_t launch_expand_ff(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d, int W,
@@ -415,7 +422,8 @@ hipError_t launch_expand_ff(const cplx* Ypart, int chunks, size_t slab, int A, i
     const CompactWs cw = slice_compact_ws(ws, N, d);
     const int kt = N >= 16 ? 16 : (N >= 8 ? 8 : 4);
     const int at = std::max(1, std::min(A, 64/kt));          // block = 16 x kt x at <= 1024 threads
-    const size_t lds = static_cast<size_t>(A)*N*16*sizeof(cplx);
+    const size_t lds = static_cast<size_t>(A)*(N + d*d)*16*sizeof(cplx);
+    if (lds > 160*1024) return hipErrorInvalidValue;
     if (lds > 48*1024) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(expand_ff_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
