@@ -135,8 +135,11 @@ def measure_hbm_traffic(omega_per_gpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    # Defaults long enough to measure sustained throughput: after an idle period the accumulate
+    # kernel runs 95 us and settles at 81.6 us only ~300 steps (35 ms) later, as the clocks ramp
+    # (profiles/r01_q_clock_ramp.txt); 2500 steps are 0.3 s of GPU time.
+    ap.add_argument('--steps', type=int, default=2000)
+    ap.add_argument('--warmup', type=int, default=500)
     ap.add_argument('--omega-per-gpu', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pipeline-depth', type=int, default=8,

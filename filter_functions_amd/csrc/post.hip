@@ -413,7 +413,7 @@ __global__ __launch_bounds__(1024) void expand_ff_kernel(const cplx* __restrict_
 
 bool expand_ff_supported(int A, int N) {
     // R tile [A][N][16] + summed partials [A][d^2][16], d^2 <= N for a complete basis; N bounds both
-    return static_cast<size_t>(A)*2*N*16*sizeof(cplx) <= 64*1024;
+    return static_cast<size_t>(A)*2*N*16*sizeof(cplx) <= 128*1024;
 }
 
 hipError_t launch_expand_ff(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d, int W,
