@@ -1769,3 +1769,28 @@ def test_libffk_before_torch_shares_one_hip_runtime():
     res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True,
                          timeout=300)
     assert res.returncode == 0 and 'shared' in res.stdout, res.stderr[-2000:]
+
+
+def test_many_noise_operators_fused_expansion():
+    """Many noise operators at small d: the fused chunk-sum + expansion + F kernel with an LDS
+    footprint above 48 and above 64 KiB (A*d^2 up to 256), against the oracle."""
+    rng = np.random.default_rng(3)
+    for d, A, G, W in [(4, 12, 40, 300), (4, 16, 33, 100), (2, 40, 20, 77), (4, 9, 64, 130)]:
+        def herm(n):
+            M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+            return (M + M.conj().transpose(0, 2, 1))/2
+        c_opers, n_opers = herm(2), herm(A)
+        c_coeffs, n_coeffs = rng.standard_normal((2, G)), rng.random((A, G))
+        dt = 1 - rng.random(G)*0.5
+        omega = np.geomspace(1e-2, 50, W)
+        ids = [f'n{i:02d}' for i in range(A)]
+        pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs, ids)),
+                                 dt, ff.Basis.pauli(int(np.log2(d))))
+        F = pulse.get_filter_function(omega)
+        R = pulse.get_control_matrix(omega)
+        D, V, Q = orc.diagonalize(orc.hamiltonian(pulse.c_opers, pulse.c_coeffs), dt)
+        R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(pulse.basis),
+                                                pulse.n_opers, pulse.n_coeffs, dt)
+        tag = f'd={d} A={A} G={G} W={W}'
+        assert rel_err(R, R_ref) < TOL, tag
+        assert rel_err(F, orc.filter_function(R_ref)) < TOL, tag
