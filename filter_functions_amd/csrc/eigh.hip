@@ -88,20 +88,26 @@ __device__ bool eigh_expm_wave(EighState<D>& st, const cplx* __restrict__ Hg, do
 
     const double tol2 = static_cast<double>(D*D)*4.930380657631324e-32;  // (D eps)^2
     bool converged = false;
+    // A dense matrix needs at least four sweeps to reach (D eps)^2: the convergence test (an LDS
+    // pass and two wave reductions) starts after the third; on an already diagonal matrix the
+    // untested sweeps are no-ops (nothing to rotate).
+    constexpr int kFirstTest = D >= 3 ? 3 : 1;
     for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
-        double off = 0.0, tot = 0.0;
-        for (int e = lane; e < D*D; e += 64) {
-            const int i = e / D, j = e % D;
-            const cplx a = A[i][j];
-            const double m2 = a.re*a.re + a.im*a.im;
-            tot += m2;
-            if (i != j) off += m2;
-        }
-        off = wave_sum(off);
-        tot = wave_sum(tot);
-        if (off <= tol2*tot) {
-            converged = true;
-            break;
+        if (sweep >= kFirstTest) {
+            double off = 0.0, tot = 0.0;
+            for (int e = lane; e < D*D; e += 64) {
+                const int i = e / D, j = e % D;
+                const cplx a = A[i][j];
+                const double m2 = a.re*a.re + a.im*a.im;
+                tot += m2;
+                if (i != j) off += m2;
+            }
+            off = wave_sum(off);
+            tot = wave_sum(tot);
+            if (off <= tol2*tot) {
+                converged = true;
+                break;
+            }
         }
         for (int step = 0; step < DP - 1; ++step) {
             if constexpr (kRegisterRotations) {
