@@ -439,7 +439,8 @@ def decay_amplitudes_shard(control_matrix_block, spectrum_block, omega, w_offset
     wgt[1:] += 0.5*np.diff(omega)
     S = parse_spectrum(spectrum_block, np.empty(Wb), np.asarray(idx))*wgt[w_offset:w_offset + Wb]
     if S.ndim in (1, 2):
-        integrand = np.einsum('...ko,...o,...lo->...kl', R.conj(), S, R)
+        # sum_o conj(R_ko) S_o R_lo as one matrix product per operator (full-size grids)
+        integrand = (R.conj()*S[..., None, :]) @ R.swapaxes(-1, -2)
     else:
         integrand = np.einsum('ako,abo,blo->abkl', R.conj(), S, R)
     return integrand.real/(2*np.pi)

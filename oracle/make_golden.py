@@ -554,7 +554,79 @@ def make_gradient_ctrlmat():
     save('gradient_ctrlmat', **arrays)
 
 
+def make_baseline_configs():
+    """BASELINE configs 3, 4 and 5 pinned by the reference on sub-grids of their frequency axes
+    (every frequency is independent, so a sub-grid pins the full-size run's values at those
+    frequencies).  Inputs come from workloads.py (the same builders the tests and bench.py use);
+    the fixtures hold the reference's outputs only, plus the assembled QFT pulse's arrays."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import workloads as wl
+
+    # config 5: the 4-qubit QFT of examples/qft.py:42-136 (13 segments, d=16, 18 noise operators)
+    qft = wl.qft_pulse(ff)
+    U = wl.bit_reversal() @ qft.total_propagator
+    assert util.oper_equiv(U, wl.qft_matrix(), eps=1e-13)[0]
+    W_full = wl.CONFIG5['W']
+    omega_full = np.logspace(-2, 2, W_full)
+    sub = np.linspace(0, W_full - 1, 64).astype(int)
+    omega = omega_full[sub]
+    arrays = {k: v for k, v in pulse_inputs(qft).items() if k != 'basis'}
+    arrays['basis_sha256'] = np.array(hashlib.sha256(
+        np.ascontiguousarray(np.asarray(qft.basis)).tobytes()).hexdigest())
+    arrays['omega_index'] = sub
+    arrays['omega'] = omega
+    arrays['total_propagator'] = qft.total_propagator
+    R = qft.get_control_matrix(omega)
+    rows = np.array([0, 5, 11, 17])
+    arrays['rows'] = rows
+    arrays['control_matrix_rows'] = R[rows]
+    arrays['filter_function'] = qft.get_filter_function(omega)
+    A = len(qft.n_opers)
+    S2 = np.outer(1e-6*(np.arange(A) + 1), 1/omega)
+    arrays['S2'] = S2
+    arrays['infidelity_S2'] = ff.infidelity(qft, S2, omega)
+    ids = qft.n_oper_identifiers[[6, 12]]
+    arrays['decay_identifiers'] = ids.astype('U8')
+    arrays['decay_amplitudes_S2_sub'] = numeric.calculate_decay_amplitudes(
+        qft, S2[[6, 12]], omega, n_oper_identifiers=ids)
+    save('qft', **arrays)
+
+    # config 4: random 3-qubit pulse, seed 43, full 512 segments on 12 of the 65536 frequencies
+    cfg = wl.CONFIG4
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
+    omega_full = wl.random_pulse_omega(dt, cfg['W'])
+    sub = np.linspace(0, cfg['W'] - 1, 12).astype(int)
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt,
+                             ff.Basis.pauli(3))
+    omega = omega_full[sub]
+    R = pulse.get_control_matrix(omega)
+    save('cfg4_subgrid', omega_index=sub, omega=omega, control_matrix=R,
+         filter_function=pulse.get_filter_function(omega),
+         infidelity=ff.infidelity(pulse, 1e-3/omega, omega),
+         eigvals=pulse.eigvals, total_propagator=pulse.total_propagator)
+
+    # config 3: the 1000-gate randomized-benchmarking sequence on 24 of the 8192 frequencies
+    cfg = wl.CONFIG3
+    omega_full = wl.rb_omega(cfg['W'], cfg['T'])
+    sub = np.linspace(0, cfg['W'] - 1, 24).astype(int)
+    omega = omega_full[sub]
+    _, cliffords = wl.rb_cliffords(ff, omega, cfg['T'])
+    draw = wl.rb_draw(cfg['n_gates'], cfg['seed'])
+    total = ff.concatenate([cliffords[k] for k in draw])
+    assert total.is_cached('control_matrix')
+    S = wl.rb_spectrum(omega)
+    save('cfg3_subgrid', omega_index=sub, omega=omega, draw=draw,
+         control_matrix=total.get_control_matrix(omega),
+         filter_function=total.get_filter_function(omega),
+         infidelity=ff.infidelity(total, S, omega),
+         total_propagator=total.total_propagator,
+         clifford_control_matrices=np.array([c.get_control_matrix(omega) for c in cliffords]))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'configs':
+        make_baseline_configs()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'gradient_ctrlmat':
         make_gradient_ctrlmat()
         return
@@ -811,6 +883,7 @@ def main():
     make_nontraceless()
     make_noise_operators_from_atomic()
     make_cnot()
+    make_baseline_configs()
 
 
 if __name__ == '__main__':

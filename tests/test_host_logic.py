@@ -567,3 +567,20 @@ def test_public_api_surface_covers_the_reference():
                  'numeric', 'gradient', 'pulse_sequence', 'remap', 'util', 'superoperator',
                  'infidelity_derivative']:
         assert name in ff.__all__ and hasattr(ff, name), name
+
+
+def test_qft_pulse_assembly_matches_reference_bit_exact():
+    """BASELINE config 5: the 4-qubit QFT of examples/qft.py:42-136 assembled by this package's
+    concatenation bookkeeping (identifier sort, zero-filled control amplitudes, noise
+    sensitivities filled in from the other pulses, pulse_sequence.py:1340-1483) carries exactly
+    the arrays the reference assembles."""
+    import workloads as wl
+    g = load_golden('qft')
+    qft = wl.qft_pulse(ff)
+    assert len(qft) == 13 and qft.d == 16
+    for key in ('c_opers', 'c_coeffs', 'n_opers', 'n_coeffs', 'dt'):
+        assert np.array_equal(getattr(qft, key), g[key]), key
+    assert list(qft.c_oper_identifiers) == list(g['c_oper_identifiers'])
+    assert list(qft.n_oper_identifiers) == list(g['n_oper_identifiers'])
+    assert qft.basis.btype == str(g['btype']) == 'GGM'
+    assert qft.tau == 13.0

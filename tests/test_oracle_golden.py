@@ -368,3 +368,80 @@ def test_control_matrix_derivative(name):
         assert dR.shape == ref.shape and rel_err(dR, ref) < 1e-13
         dF = orc.filter_function_derivative_from_control_matrix(g[f'{name}_control_matrix'], ref)
         assert rel_err(dF, g[f'{name}_filter_function_derivative{tag}']) < 1e-13
+
+
+# ---- BASELINE configs 3, 4, 5 on sub-grids of their frequency axes (reference outputs) ----------
+def test_config5_qft_fixture_against_oracle():
+    """examples/qft.py:42-136: the oracle on the assembled QFT pulse's arrays reproduces the
+    reference's control matrix rows, filter function, infidelities and decay amplitudes."""
+    g = load_golden('qft')
+    basis = orc.basis_ggm(16)
+    assert hashlib.sha256(np.ascontiguousarray(basis).tobytes()).hexdigest() == str(g['basis_sha256'])
+    H = orc.hamiltonian(g['c_opers'], g['c_coeffs'])
+    D, V, Q = orc.diagonalize(H, g['dt'])
+    assert rel_err(Q[-1], g['total_propagator']) < 1e-13
+    omega = g['omega']
+    R = orc.control_matrix_from_scratch(D, V, Q, omega, basis, g['n_opers'], g['n_coeffs'], g['dt'])
+    assert rel_err(R[g['rows']], g['control_matrix_rows']) < 1e-13
+    F = orc.filter_function(R)
+    assert rel_err(F, g['filter_function']) < 1e-13
+    A = len(g['n_opers'])
+    infid = orc.infidelity_from_filter_function(F, g['S2'], omega, np.arange(A), 16)
+    assert rel_err(infid, g['infidelity_S2']) < 1e-13
+    idx = np.array([list(g['n_oper_identifiers']).index(i) for i in g['decay_identifiers']])
+    gamma = orc.decay_amplitudes(R, g['S2'][idx], omega, idx)
+    assert rel_err(gamma, g['decay_amplitudes_S2_sub']) < 1e-13
+
+
+def test_config4_subgrid_fixture_against_oracle():
+    import workloads as wl
+    g = load_golden('cfg4_subgrid')
+    cfg = wl.CONFIG4
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
+    omega = wl.random_pulse_omega(dt, cfg['W'])[g['omega_index']]
+    assert np.array_equal(omega, g['omega'])
+    D, V, Q = orc.diagonalize(orc.hamiltonian(c_opers, c_coeffs), dt)
+    assert np.abs(D - g['eigvals']).max() < 1e-12
+    assert rel_err(Q[-1], g['total_propagator']) < 1e-11
+    R = orc.control_matrix_from_scratch(D, V, Q, omega, orc.basis_pauli(3), n_opers, n_coeffs, dt)
+    assert rel_err(R, g['control_matrix']) < 1e-12
+    F = orc.filter_function(R)
+    assert rel_err(F, g['filter_function']) < 1e-12
+    infid = orc.infidelity_from_filter_function(F, 1e-3/omega, omega, np.arange(cfg['A']), cfg['d'])
+    assert rel_err(infid, g['infidelity']) < 1e-12
+
+
+def test_config3_subgrid_fixture_against_oracle():
+    """The 1000-gate sequence by the concatenation rule on the reference's own Clifford control
+    matrices (examples/randomized_benchmarking.py:95-151, numeric.py:621-704)."""
+    import workloads as wl
+    g = load_golden('cfg3_subgrid')
+    cfg = wl.CONFIG3
+    omega = g['omega']
+    assert np.array_equal(wl.rb_omega(cfg['W'], cfg['T'])[g['omega_index']], omega)
+    draw = g['draw']
+    assert np.array_equal(draw, wl.rb_draw(cfg['n_gates'], cfg['seed']))
+    table = g['clifford_control_matrices']                       # (24, 1, 4, W)
+    # per-Clifford propagators and durations from the words
+    X, Y = np.array([[0, 1], [1, 0]], complex), np.array([[0, -1j], [1j, 0]])
+    atom = {'x': (np.eye(2) - 1j*X)/np.sqrt(2), 'y': (np.eye(2) - 1j*Y)/np.sqrt(2)}
+    basis = orc.basis_pauli(1)
+    U, tau = [], []
+    for word in wl.CLIFFORD_WORDS:
+        M = np.eye(2, dtype=complex)
+        for letter in word:
+            M = atom[letter] @ M
+        U.append(M)
+        tau.append(cfg['T']*len(word))
+    L = np.array([orc.liouville_representation(u, basis) for u in U])
+    phase_step = np.array([orc.cexp(omega*t) for t in tau])
+    Qs, ph = [np.eye(4)], [np.ones(len(omega), complex)]
+    for k in draw[:-1]:
+        Qs.append(L[k] @ Qs[-1])
+        ph.append(ph[-1]*phase_step[k])
+    R = orc.control_matrix_from_atomic(np.array(ph[1:]), table[draw], np.array(Qs[1:]))
+    assert rel_err(R, g['control_matrix']) < 1e-11
+    F = orc.filter_function(R)
+    assert rel_err(F, g['filter_function']) < 1e-11
+    infid = orc.infidelity_from_filter_function(F, wl.rb_spectrum(omega), omega, np.arange(1), 2)
+    assert rel_err(infid, g['infidelity']) < 1e-11
