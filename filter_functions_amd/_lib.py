@@ -178,6 +178,18 @@ SIGNATURES = {
                                  c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
+    'ffk_eigensolver_status_dev': (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
+    'ffk_resident_create': (c_int, [POINTER(c_void_p)]),
+    'ffk_resident_destroy': (c_int, [c_void_p]),
+    'ffk_resident_release_pools': (c_int, []),
+    'ffk_resident_filter_function': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                             c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                             c_void_p, POINTER(c_void_p), POINTER(c_void_p),
+                                             POINTER(c_void_p), POINTER(c_void_p)]),
+    'ffk_resident_control_matrix': (c_int, [c_void_p, c_void_p]),
+    'ffk_resident_control_matrix_dev': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),
+                                                POINTER(c_void_p)]),
+    'ffk_resident_infidelity': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     'ffk_set_segment_chunks': (c_int, [c_int]),
     'ffk_set_accumulate_variant': (c_int, [c_int]),
     'ffk_get_stats': (c_int, [POINTER(ffk_stats)]),

@@ -1,0 +1,147 @@
+"""Resident evaluation of one pulse on one frequency grid (``ffk_resident_*``, include/ffk.h).
+
+``PulseSequence.get_filter_function(omega)`` on a pulse with nothing cached, followed by
+``ff.infidelity(pulse, S, omega)``, is the north-star call.  Served by the array-in/array-out
+entry points it costs five synchronous library calls and moves the control matrix (5x the bytes
+of F at BASELINE config 2) across PCIe twice.  Here the whole pass is one call: one H2D copy of
+the packed inputs, the fused device pipeline, one D2H copy of eigensystem + F into pinned host
+memory that the returned arrays view directly.  The control matrix stays in HBM until someone
+reads ``pulse.get_control_matrix`` / ``pulse.frequency_data['control_matrix']``
+(:class:`Deferred`), and the infidelity integral runs on the resident F.
+"""
+import copy
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_c128, as_f64, check, ptr
+
+__all__ = ['Deferred', 'LazyCache', 'ResidentResult']
+
+
+class Deferred:
+    """A cache entry that is produced on first read (a device-resident array, a by-product nobody
+    has asked for yet).  *nbytes* is what the entry will occupy once produced."""
+    __slots__ = ('produce', 'nbytes')
+
+    def __init__(self, produce, nbytes=0):
+        self.produce = produce
+        self.nbytes = nbytes
+
+
+class LazyCache(dict):
+    """``dict`` whose values may be :class:`Deferred`: reading such an entry produces the value,
+    stores it in place of the placeholder and returns it.  Membership, length and iteration over
+    the keys never trigger production, so ``is_cached`` stays free."""
+
+    def __getitem__(self, key):
+        value = dict.__getitem__(self, key)
+        if type(value) is Deferred:
+            value = value.produce()
+            dict.__setitem__(self, key, value)
+        return value
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            dict.__setitem__(self, key, default)
+        return self[key]
+
+    def values(self):
+        return [self[key] for key in self]
+
+    def items(self):
+        return [(key, self[key]) for key in self]
+
+    def peek(self, key):
+        """The raw entry (possibly still a :class:`Deferred`)."""
+        return dict.__getitem__(self, key)
+
+    def stored_nbytes(self):
+        """Bytes held or promised by the entries, without producing any of them."""
+        return sum(getattr(dict.__getitem__(self, key), 'nbytes', 0) for key in self)
+
+    def copy(self):
+        return LazyCache(dict.items(self))
+
+    __copy__ = copy
+
+    def __deepcopy__(self, memo):
+        return LazyCache((key, copy.deepcopy(self[key], memo)) for key in self)
+
+    def __reduce__(self):
+        return (LazyCache, (dict(self.items()),))
+
+
+def _view(address, count, dtype, shape, owner):
+    """ndarray over *count* doubles of foreign memory at *address*; *owner* stays alive as long
+    as the array (or anything derived from it) does."""
+    buf = (ctypes.c_double*count).from_address(address)
+    buf._owner = owner
+    return np.ctypeslib.as_array(buf).view(dtype).reshape(shape)
+
+
+class ResidentResult:
+    """Owns one ``ffk_resident`` handle: the device-resident control matrix, filter function and
+    frequency grid of one pass, and the pinned host block the small results live in."""
+
+    def __init__(self):
+        self._lib = _lib.load()
+        self._handle = ctypes.c_void_p()
+        check(self._lib.ffk_resident_create(ctypes.byref(self._handle)))
+        self.shape = None
+        self.filter_function = None
+
+    def __del__(self):
+        handle, self._handle = getattr(self, '_handle', None), None
+        if handle:
+            self._lib.ffk_resident_destroy(handle)
+
+    def evaluate(self, hamiltonian, dt, t, omega, basis, n_opers, n_coeffs):
+        """One pass; returns (eigvals, eigvecs, propagators, filter_function) as arrays that view
+        the handle's pinned memory (no copy)."""
+        H, dt, t, omega = as_c128(hamiltonian), as_f64(dt), as_f64(t), as_f64(omega)
+        C, B, s = as_c128(basis), as_c128(n_opers), as_f64(n_coeffs)
+        G, d = H.shape[0], H.shape[1]
+        W, N, A = len(omega), len(C), len(B)
+        out = [ctypes.c_void_p() for _ in range(4)]
+        check(self._lib.ffk_resident_filter_function(
+            self._handle, ptr(H), ptr(dt), ptr(t), G, d, ptr(omega), W, ptr(C), N, ptr(B), A, ptr(s),
+            *(ctypes.byref(p) for p in out)))
+        self.shape = (G, d, W, N, A)
+        D = _view(out[0].value, G*d, np.float64, (G, d), self)
+        V = _view(out[1].value, 2*G*d*d, np.complex128, (G, d, d), self)
+        Q = _view(out[2].value, 2*(G + 1)*d*d, np.complex128, (G + 1, d, d), self)
+        F = _view(out[3].value, 2*A*A*W, np.complex128, (A, A, W), self)
+        self.filter_function = F
+        return D, V, Q, F
+
+    def control_matrix(self):
+        """The resident control matrix (n_nops, n_basis, n_omega), copied to the host now."""
+        G, d, W, N, A = self.shape
+        R = np.empty((A, N, W), dtype=np.complex128)
+        check(self._lib.ffk_resident_control_matrix(self._handle, ptr(R)))
+        return R
+
+    def control_matrix_nbytes(self):
+        G, d, W, N, A = self.shape
+        return 16*A*N*W
+
+    def infidelity(self, spectrum, idx):
+        """(1/2 pi d) int dw Re(S F) on the resident F; *spectrum* already validated
+        (``util.parse_spectrum``), *idx* the noise-operator indices."""
+        G, d, W, N, A = self.shape
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        real = not np.iscomplexobj(spectrum)
+        S = as_f64(spectrum) if real else as_c128(spectrum)
+        n_idx = len(idx)
+        out = np.empty((n_idx, n_idx) if S.ndim == 3 else (n_idx,), dtype=np.float64)
+        if W < 2:
+            out[...] = 0.0
+            return out
+        check(self._lib.ffk_resident_infidelity(self._handle, ptr(S), S.ndim, int(real),
+                                                idx.ctypes.data_as(ctypes.c_void_p), n_idx, ptr(out)))
+        return out

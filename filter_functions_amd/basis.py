@@ -67,11 +67,10 @@ class Basis(np.ndarray):
         return np.ndarray.__array_wrap__(self, arr, context, False)
 
     def __eq__(self, other):
-        try:
-            if self.shape != other.shape:
-                return False
-        except AttributeError:
-            return np.equal(self, other)
+        if not hasattr(other, 'shape'):
+            return np.equal(self, other)          # scalars and the like: elementwise
+        if other.shape != self.shape:
+            return False
         return np.allclose(self.view(np.ndarray), np.asarray(other), atol=self._atol,
                            rtol=self._rtol)
 
@@ -161,10 +160,11 @@ class Basis(np.ndarray):
         return expand(M, self, self.isnorm, hermitian, tidyup)
 
     def normalize(self, copy=False):
-        if copy:
-            return normalize(self)
-        self /= _norm(self)
-        self._invalidate_cached_properties()
+        if not copy:
+            self /= _norm(self)
+            self._invalidate_cached_properties()
+            return None
+        return normalize(self)
 
     def tidyup(self, eps_scale=None):
         atol = self._atol if eps_scale is None else self._eps*eps_scale

@@ -33,17 +33,21 @@ __global__ __launch_bounds__(256) void spectral_weights_kernel(const cplx* __res
                                                                int W,
                                                                const double* __restrict__ omega,
                                                                int Wg, int w_offset,
-                                                               cplx* __restrict__ scale) {
+                                                               cplx* __restrict__ scale,
+                                                               int* __restrict__ complex_weights) {
     const int w = blockIdx.x*256 + threadIdx.x;
     if (w >= W) return;
     const int gw = w_offset + w;
     const double lo = gw > 0 ? omega[gw] - omega[gw - 1] : 0.0;
     const double hi = gw < Wg - 1 ? omega[gw + 1] - omega[gw] : 0.0;
     const double wgt = 0.5*(lo + hi)/(2.0*3.141592653589793);
+    bool any_imag = false;
     for (int r = blockIdx.y; r < rows; r += gridDim.y) {
         const cplx s = S[static_cast<size_t>(r)*W + w];
         scale[static_cast<size_t>(r)*W + w] = {s.re*wgt, s.im*wgt};
+        any_imag |= s.im != 0.0;
     }
+    if (complex_weights && any_imag) atomicOr(complex_weights, 1);
 }
 
 // One wavefront: a (16 TM) x (16 TN) tile of one Gamma[g,h,a,b] over the block's frequency range.
@@ -53,7 +57,8 @@ template <int TM, int TN>
 __global__ __launch_bounds__(64) void decay_gemm_kernel(
     const cplx* __restrict__ R, int Gp, int A, int N, int W, const cplx* __restrict__ scale,
     int s_ndim, const int32_t* __restrict__ idx, int n_idx, int kchunk, int tiles_m, int tiles_n,
-    double* __restrict__ out, size_t split_stride, int mirror_in_store) {
+    double* __restrict__ out, size_t split_stride, int mirror_in_store,
+    const int* __restrict__ complex_weights) {
     const int lane = threadIdx.x;
     const int l15 = lane & 15, lk = lane >> 4;
     const int tiles = tiles_m*tiles_n;
@@ -67,9 +72,10 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
     z /= n_idx;
     const int h = z % Gp, g = z / Gp;
     const int ib = s_ndim == 3 ? ib0 : ia;
-    // Gamma_aa of one pulse with itself is symmetric in (k, l) (real weights): only the tiles on
-    // and above the diagonal are computed, the rest mirrored at the store
-    const bool symmetric = s_ndim != 3 && g == h;
+    // Gamma_aa of one pulse with itself is symmetric in (k, l) for real weights: only the tiles on
+    // and above the diagonal are computed, the rest mirrored at the store.  (A complex spectrum of
+    // one or two dimensions adds an antisymmetric part: no shortcut then.)
+    const bool symmetric = s_ndim != 3 && g == h && *complex_weights == 0;
     if (symmetric && ti > tj) return;
     const int srow = s_ndim == 1 ? 0 : (s_ndim == 2 ? ia : ia*n_idx + ib);
     const cplx* sp = scale + static_cast<size_t>(srow)*W;
@@ -151,11 +157,12 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
 __global__ __launch_bounds__(256) void reduce_splits_kernel(const double* __restrict__ part,
                                                             int nsplit, size_t n, int N, int tile,
                                                             int Gp, int n_idx,
+                                                            const int* __restrict__ complex_weights,
                                                             double* __restrict__ out) {
     const size_t i = static_cast<size_t>(blockIdx.x)*256 + threadIdx.x;
     if (i >= n) return;
     size_t src = i;
-    if (tile > 0) {
+    if (tile > 0 && *complex_weights == 0) {
         const size_t b = i / (static_cast<size_t>(N)*N);
         const int row = static_cast<int>((i / N) % N), col = static_cast<int>(i % N);
         const size_t gh = b / n_idx;
@@ -308,14 +315,14 @@ __global__ __launch_bounds__(64) void cumulant_single_qubit_kernel(const double*
 hipError_t launch_spectral_weights(const cplx* S, int rows, int W, const double* omega, int Wg,
                                    int w_offset, cplx* scale, hipStream_t stream) {
     hipLaunchKernelGGL(spectral_weights_kernel, dim3((W + 255)/256, min(rows, 1024)), dim3(256), 0,
-                       stream, S, rows, W, omega, Wg, w_offset, scale);
+                       stream, S, rows, W, omega, Wg, w_offset, scale, nullptr);
     return hipGetLastError();
 }
 
 size_t decay_amplitudes_workspace_bytes(int Gp, int N, int W, int n_idx, int s_ndim) {
     const DecayPlan p = decay_plan(Gp, N, W, n_idx, s_ndim);
     const size_t rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : static_cast<size_t>(n_idx)*n_idx);
-    size_t bytes = align_up(rows*W*sizeof(cplx));
+    size_t bytes = align_up(sizeof(int)) + align_up(rows*W*sizeof(cplx));   // flag, scale
     if (p.ksplit > 1) bytes += align_up(static_cast<size_t>(p.ksplit)*p.batch*N*N*sizeof(double));
     return bytes;
 }
@@ -327,10 +334,16 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
     const DecayPlan p = decay_plan(Gp, N, W, n_idx, s_ndim);
     const int rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : n_idx*n_idx);
     unsigned char* base = static_cast<unsigned char*>(ws);
+    // complex_weights != 0 after the weights kernel if any spectrum value has an imaginary part:
+    // Gamma_aa is then not symmetric in (k, l) and every tile is computed
+    int* complex_weights = reinterpret_cast<int*>(base);
+    base += align_up(sizeof(int));
     cplx* scale = reinterpret_cast<cplx*>(base);
     double* part = reinterpret_cast<double*>(base + align_up(static_cast<size_t>(rows)*W*sizeof(cplx)));
+    hipError_t merr = hipMemsetAsync(complex_weights, 0, sizeof(int), stream);
+    if (merr != hipSuccess) return merr;
     hipLaunchKernelGGL(spectral_weights_kernel, dim3((W + 255)/256, min(rows, 1024)), dim3(256), 0,
-                       stream, S, rows, W, omega, Wg, w_offset, scale);
+                       stream, S, rows, W, omega, Wg, w_offset, scale, s_ndim != 3 ? complex_weights : nullptr);
     const size_t n = p.batch*N*N;
     const size_t blocks = p.batch*p.tiles_m*p.tiles_n;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
@@ -339,17 +352,20 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
     const dim3 grid(static_cast<unsigned>(blocks), p.ksplit);
     if (p.tm == 1)
         hipLaunchKernelGGL((decay_gemm_kernel<1, 1>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror);
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror,
+                           complex_weights);
     else if (p.tm == 2)
         hipLaunchKernelGGL((decay_gemm_kernel<2, 2>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror);
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror,
+                           complex_weights);
     else
         hipLaunchKernelGGL((decay_gemm_kernel<4, 4>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror);
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror,
+                           complex_weights);
     if (p.ksplit > 1)
         hipLaunchKernelGGL(reduce_splits_kernel, dim3(static_cast<unsigned>((n + 255)/256)),
                            dim3(256), 0, stream, part, p.ksplit, n, N,
-                           s_ndim != 3 ? 16*p.tm : 0, Gp, n_idx, gamma);
+                           s_ndim != 3 ? 16*p.tm : 0, Gp, n_idx, complex_weights, gamma);
     return hipGetLastError();
 }
 

@@ -299,7 +299,25 @@ hipError_t launch_d(const cplx* H, const double* dt, int G, double* eigvals, cpl
     return hipGetLastError();
 }
 
+// Number of segments flagged by the eigensolver, as one device integer (one block).
+__global__ __launch_bounds__(256) void count_failures_kernel(const int* __restrict__ status, int G,
+                                                            int32_t* __restrict__ out) {
+    __shared__ int total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    int mine = 0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) mine += status[g] != 0;
+    if (mine) atomicAdd(&total, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) *out = total;
+}
+
 }  // namespace
+
+hipError_t launch_count_failures(const int* status, int G, int32_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(count_failures_kernel, dim3(1), dim3(256), 0, stream, status, G, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_eigh_expm(const cplx* H, const double* dt, int G, int d, double* eigvals,
                             cplx* eigvecs, cplx* seg_prop, int* status, hipStream_t stream) {

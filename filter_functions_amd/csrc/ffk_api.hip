@@ -9,6 +9,7 @@
 #include <cstring>
 #include <algorithm>
 #include <mutex>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -1781,6 +1782,292 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
             return rc;
     }
     return FFK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// eigensolver status of a device-resident run
+// ---------------------------------------------------------------------------------------------
+int ffk_eigensolver_status_dev(const void* workspace, size_t workspace_bytes, int G, int d,
+                               int32_t* n_failed, void* stream) {
+    FFK_REQUIRE(workspace && n_failed && G >= 1 && d_ok(d), "bad argument");
+    FFK_REQUIRE(workspace_bytes >= ffk_diagonalize_workspace_bytes(G, d), "workspace too small");
+    // the flags are the first slice of both the diagonalize and the pipeline workspace
+    const DiagWs w = slice_diag_ws(const_cast<void*>(workspace), workspace_bytes, G, d);
+    FFK_HIP(ffk::launch_count_failures(w.status, G, n_failed, static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// resident evaluation: the user-facing PulseSequence.get_filter_function / infidelity call with
+// one H2D, one pass of ffk_pipeline_dev, one D2H of the small results; R stays in HBM
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct Block {
+    void* ptr;
+    size_t size;
+};
+
+// Grow-only pools of device and pinned-host blocks: a PulseSequence is short-lived in user code
+// (one per gate), hipMalloc / hipHostMalloc cost more than the whole pass at config 2.
+struct BlockPool {
+    std::mutex mu;
+    std::vector<Block> free_blocks;
+    bool pinned;
+    explicit BlockPool(bool p) : pinned(p) {}
+    int take(size_t bytes, Block* out) {
+        std::lock_guard<std::mutex> lock(mu);
+        int best = -1;
+        for (int i = 0; i < int(free_blocks.size()); ++i)
+            if (free_blocks[i].size >= bytes && free_blocks[i].size <= 2*bytes + (1 << 16) &&
+                (best < 0 || free_blocks[i].size < free_blocks[best].size))
+                best = i;
+        if (best >= 0) {
+            *out = free_blocks[best];
+            free_blocks.erase(free_blocks.begin() + best);
+            return FFK_OK;
+        }
+        const size_t want = align_up(bytes, size_t(1) << 16);
+        void* p = nullptr;
+        if (pinned)
+            FFK_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        else
+            FFK_HIP(hipMalloc(&p, want));
+        *out = {p, want};
+        return FFK_OK;
+    }
+    void give(Block b) {
+        if (!b.ptr) return;
+        std::lock_guard<std::mutex> lock(mu);
+        if (free_blocks.size() >= 16) {       // bound what an idle process keeps
+            if (pinned) (void)hipHostFree(b.ptr); else (void)hipFree(b.ptr);
+            return;
+        }
+        free_blocks.push_back(b);
+    }
+    int release() {
+        std::lock_guard<std::mutex> lock(mu);
+        for (Block& b : free_blocks) {
+            if (pinned) FFK_HIP(hipHostFree(b.ptr)); else FFK_HIP(hipFree(b.ptr));
+        }
+        free_blocks.clear();
+        return FFK_OK;
+    }
+};
+BlockPool g_dev_pool(false), g_pin_pool(true);
+hipStream_t g_resident_stream = nullptr;
+
+int resident_stream(hipStream_t* out) {
+    if (!g_resident_stream)
+        FFK_HIP(hipStreamCreateWithFlags(&g_resident_stream, hipStreamNonBlocking));
+    *out = g_resident_stream;
+    return FFK_OK;
+}
+
+// byte offsets of the arrays inside the device block and (first two groups) the pinned block
+struct ResidentLayout {
+    size_t H, dt, t, omega, basis, n_opers, n_coeffs, inputs_end;     // one H2D
+    size_t D, V, Q, F, status, outputs_end;                            // one D2H
+    size_t R, S, idx, infid, end;                                      // device only (+ infid D2H)
+};
+ResidentLayout resident_layout(int G, int d, int W, int N, int A) {
+    ResidentLayout L;
+    const size_t dd = size_t(d)*d;
+    size_t o = 0;
+    auto put = [&o](size_t bytes) { const size_t at = o; o += align_up(bytes); return at; };
+    L.H = put(16*size_t(G)*dd);
+    L.dt = put(8*size_t(G));
+    L.t = put(8*size_t(G + 1));
+    L.omega = put(8*size_t(W));
+    L.basis = put(16*size_t(N)*dd);
+    L.n_opers = put(16*size_t(A)*dd);
+    L.n_coeffs = put(8*size_t(A)*G);
+    L.inputs_end = o;
+    L.D = put(8*size_t(G)*d);
+    L.V = put(16*size_t(G)*dd);
+    L.Q = put(16*size_t(G + 1)*dd);
+    L.F = put(16*size_t(A)*A*W);
+    L.status = put(sizeof(int32_t));
+    L.outputs_end = o;
+    L.R = put(16*size_t(A)*N*W);
+    L.S = put(16*size_t(A)*A*W);          // largest spectrum: (A, A, W) c128
+    L.idx = put(sizeof(int32_t)*size_t(A));
+    L.infid = put(8*size_t(A)*A);
+    L.end = o;
+    return L;
+}
+
+}  // namespace
+
+struct ffk_resident {
+    int device = -1;
+    int G = 0, d = 0, W = 0, N = 0, A = 0;
+    bool valid = false;
+    Block dev = {nullptr, 0}, pin = {nullptr, 0};
+    ResidentLayout L = {};
+};
+
+extern "C" {
+
+int ffk_resident_create(ffk_resident** out) {
+    FFK_REQUIRE(out, "NULL argument");
+    *out = new (std::nothrow) ffk_resident();
+    FFK_REQUIRE(*out, "out of host memory");
+    return FFK_OK;
+}
+
+int ffk_resident_destroy(ffk_resident* r) {
+    if (!r) return FFK_OK;
+    g_dev_pool.give(r->dev);
+    g_pin_pool.give(r->pin);
+    delete r;
+    return FFK_OK;
+}
+
+int ffk_resident_release_pools(void) {
+    if (int rc = g_dev_pool.release()) return rc;
+    return g_pin_pool.release();
+}
+
+int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, const double* dt,
+                                 const double* t, int G, int d, const double* omega, int W,
+                                 const double* basis, int N, const double* n_opers, int A,
+                                 const double* n_coeffs, double** eigvals, double** eigvecs,
+                                 double** propagators, double** filter_function) {
+    FFK_REQUIRE(r, "NULL handle");
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
+    FFK_REQUIRE(hamiltonian && dt && t && omega && basis && n_opers && n_coeffs, "NULL argument");
+    FFK_REQUIRE(eigvals && eigvecs && propagators && filter_function, "NULL output argument");
+    r->valid = false;
+    int dev = 0;
+    FFK_HIP(hipGetDevice(&dev));
+    const ResidentLayout L = resident_layout(G, d, W, N, A);
+    if (r->device != dev || r->dev.size < L.end || r->pin.size < L.outputs_end) {
+        g_dev_pool.give(r->dev);
+        g_pin_pool.give(r->pin);
+        r->dev = r->pin = {nullptr, 0};
+        if (int rc = g_dev_pool.take(L.end, &r->dev)) return rc;
+        if (int rc = g_pin_pool.take(L.outputs_end, &r->pin)) return rc;
+        r->device = dev;
+    }
+    r->G = G; r->d = d; r->W = W; r->N = N; r->A = A; r->L = L;
+    unsigned char* hp = static_cast<unsigned char*>(r->pin.ptr);
+    unsigned char* dp = static_cast<unsigned char*>(r->dev.ptr);
+    const size_t dd = size_t(d)*d;
+    std::memcpy(hp + L.H, hamiltonian, 16*size_t(G)*dd);
+    std::memcpy(hp + L.dt, dt, 8*size_t(G));
+    std::memcpy(hp + L.t, t, 8*size_t(G + 1));
+    std::memcpy(hp + L.omega, omega, 8*size_t(W));
+    std::memcpy(hp + L.basis, basis, 16*size_t(N)*dd);
+    std::memcpy(hp + L.n_opers, n_opers, 16*size_t(A)*dd);
+    std::memcpy(hp + L.n_coeffs, n_coeffs, 8*size_t(A)*G);
+    hipStream_t s;
+    if (int rc = resident_stream(&s)) return rc;
+    // scratch of the pass from the shared arena (held only for the duration of this call)
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t wsb = ffk_pipeline_workspace_bytes(W, N, A, G, d, 0, 0);
+    void* ws;
+    if (int rc = arena_reserve(wsb, &ws)) return rc;
+    FFK_HIP(hipMemcpyAsync(dp, hp, L.inputs_end, hipMemcpyHostToDevice, s));
+    auto dptr = [dp](size_t off) { return reinterpret_cast<double*>(dp + off); };
+    if (int rc = ffk_pipeline_dev(dptr(L.H), dptr(L.dt), dptr(L.t), G, d, dptr(L.omega), W,
+                                  dptr(L.basis), N, dptr(L.n_opers), A, dptr(L.n_coeffs), nullptr, 0,
+                                  nullptr, 0, dptr(L.D), dptr(L.V), dptr(L.Q), dptr(L.R), dptr(L.F),
+                                  nullptr, ws, wsb, s))
+        return rc;
+    if (int rc = ffk_eigensolver_status_dev(ws, wsb, G, d, reinterpret_cast<int32_t*>(dp + L.status), s))
+        return rc;
+    FFK_HIP(hipMemcpyAsync(hp + L.D, dp + L.D, L.outputs_end - L.D, hipMemcpyDeviceToHost, s));
+    FFK_HIP(hipStreamSynchronize(s));
+    const int32_t failed = *reinterpret_cast<const int32_t*>(hp + L.status);
+    if (failed != 0)
+        return fail(FFK_ENOCONV, "Jacobi eigensolver did not converge for %d segment(s)", int(failed));
+    *eigvals = reinterpret_cast<double*>(hp + L.D);
+    *eigvecs = reinterpret_cast<double*>(hp + L.V);
+    *propagators = reinterpret_cast<double*>(hp + L.Q);
+    *filter_function = reinterpret_cast<double*>(hp + L.F);
+    r->valid = true;
+    return FFK_OK;
+}
+
+int ffk_resident_control_matrix(ffk_resident* r, double* control_matrix) {
+    FFK_REQUIRE(r && r->valid, "no resident result");
+    FFK_REQUIRE(control_matrix, "NULL argument");
+    hipStream_t s;
+    if (int rc = resident_stream(&s)) return rc;
+    const unsigned char* dp = static_cast<const unsigned char*>(r->dev.ptr);
+    FFK_HIP(hipMemcpyAsync(control_matrix, dp + r->L.R, 16*size_t(r->A)*r->N*r->W,
+                           hipMemcpyDeviceToHost, s));
+    FFK_HIP(hipStreamSynchronize(s));
+    return FFK_OK;
+}
+
+int ffk_resident_control_matrix_dev(ffk_resident* r, const double** control_matrix,
+                                    const double** filter_function, const double** omega) {
+    FFK_REQUIRE(r && r->valid, "no resident result");
+    const unsigned char* dp = static_cast<const unsigned char*>(r->dev.ptr);
+    if (control_matrix) *control_matrix = reinterpret_cast<const double*>(dp + r->L.R);
+    if (filter_function) *filter_function = reinterpret_cast<const double*>(dp + r->L.F);
+    if (omega) *omega = reinterpret_cast<const double*>(dp + r->L.omega);
+    return FFK_OK;
+}
+
+int ffk_resident_infidelity(ffk_resident* r, const double* spectrum, int s_ndim, int spectrum_is_real,
+                            const int32_t* idx, int n_idx, double* infid) {
+    FFK_REQUIRE(r && r->valid, "no resident result");
+    FFK_REQUIRE(spectrum && idx && infid, "NULL argument");
+    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3 && n_idx >= 1 && n_idx <= r->A, "bad spectrum arguments");
+    const int W = r->W, A = r->A;
+    const size_t rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? size_t(n_idx) : size_t(n_idx)*n_idx);
+    const size_t n_out = s_ndim == 3 ? size_t(n_idx)*n_idx : size_t(n_idx);
+    unsigned char* hp = static_cast<unsigned char*>(r->pin.ptr);
+    unsigned char* dp = static_cast<unsigned char*>(r->dev.ptr);
+    const ResidentLayout& L = r->L;
+    // stage spectrum (as c128), idx in the pinned input region (free after the pass)
+    const size_t s_bytes = 16*rows*W;
+    const size_t stage = align_up(s_bytes) + align_up(sizeof(int32_t)*size_t(n_idx));
+    hipStream_t s;
+    if (int rc = resident_stream(&s)) return rc;
+    const bool fits = stage <= L.inputs_end;
+    Block extra = {nullptr, 0};
+    unsigned char* stage_ptr = hp;
+    if (!fits) {
+        if (int rc = g_pin_pool.take(stage, &extra)) return rc;
+        stage_ptr = static_cast<unsigned char*>(extra.ptr);
+    }
+    double* hs = reinterpret_cast<double*>(stage_ptr);
+    if (spectrum_is_real) {
+        for (size_t i = 0; i < rows*W; ++i) { hs[2*i] = spectrum[i]; hs[2*i + 1] = 0.0; }
+    } else {
+        std::memcpy(hs, spectrum, s_bytes);
+    }
+    std::memcpy(stage_ptr + align_up(s_bytes), idx, sizeof(int32_t)*size_t(n_idx));
+    FFK_HIP(hipMemcpyAsync(dp + L.S, stage_ptr, s_bytes, hipMemcpyHostToDevice, s));
+    FFK_HIP(hipMemcpyAsync(dp + L.idx, stage_ptr + align_up(s_bytes), sizeof(int32_t)*size_t(n_idx),
+                           hipMemcpyHostToDevice, s));
+    int rc = FFK_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_arena.mu);
+        const size_t iwsb = ffk_infidelity_workspace_bytes(W, n_idx, s_ndim);
+        void* iws;
+        rc = arena_reserve(iwsb, &iws);
+        if (!rc)
+            rc = ffk_infidelity_dev(reinterpret_cast<const double*>(dp + L.F), A, W,
+                                    reinterpret_cast<const double*>(dp + L.S), s_ndim,
+                                    reinterpret_cast<const double*>(dp + L.omega),
+                                    reinterpret_cast<const int32_t*>(dp + L.idx), n_idx, r->d,
+                                    reinterpret_cast<double*>(dp + L.infid), iws, iwsb, s);
+        if (!rc) {
+            hipError_t e = hipMemcpyAsync(infid, dp + L.infid, 8*n_out, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) rc = fail(FFK_EHIP, "infidelity copy failed: %s", hipGetErrorString(e));
+        }
+    }
+    g_pin_pool.give(extra);
+    return rc;
 }
 
 }  // extern "C"

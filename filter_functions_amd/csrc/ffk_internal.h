@@ -45,6 +45,8 @@ inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1)/a*a; }
 // 1 for every segment whose Jacobi iteration failed to converge, else 0.
 hipError_t launch_eigh_expm(const cplx* H, const double* dt, int G, int d, double* eigvals,
                             cplx* eigvecs, cplx* seg_prop, int* status, hipStream_t stream);
+// out[0] = number of non-zero entries of status (G): the device-resident paths' convergence check
+hipError_t launch_count_failures(const int* status, int G, int32_t* out, hipStream_t stream);
 // Chunk length of the two-kernel scan used by the fused front end (scan_local + fix-up fused
 // with the prologue): both serial parts are ~sqrt(G) long at G = 256.
 __host__ __device__ constexpr int front_chunk(int d) { return d <= 8 ? 16 : 8; }

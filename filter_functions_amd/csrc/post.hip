@@ -110,15 +110,21 @@ __global__ __launch_bounds__(256) void transpose_kernel(const cplx* __restrict__
 __global__ void ff_fidelity_kernel(const cplx* __restrict__ R, int A, int N, int W,
                                    cplx* __restrict__ F) {
     const int w = blockIdx.x*blockDim.x + threadIdx.x;
-    const int a = blockIdx.y / A, b = blockIdx.y % A;
-    if (w >= W || a > b) return;
-    const cplx* ra = R + static_cast<size_t>(a)*N*W + w;
-    const cplx* rb = R + static_cast<size_t>(b)*N*W + w;
-    cplx acc = {0.0, 0.0};
-    for (int k = 0; k < N; ++k) cmac_conj(acc, ra[static_cast<size_t>(k)*W], rb[static_cast<size_t>(k)*W]);
-    if (a == b) acc.im = 0.0;   // sum_k |R|^2: the imaginary parts cancel term by term
-    F[(static_cast<size_t>(a)*A + b)*W + w] = acc;
-    if (a != b) F[(static_cast<size_t>(b)*A + a)*W + w] = {acc.re, -acc.im};
+    if (w >= W) return;
+    // operator pairs on grid.y, strided: A*A may exceed the 65535 blocks a grid axis holds
+    // (pulse-correlation filter functions of long sequences: A = n_pulses * n_nops)
+    for (long long pair = blockIdx.y; pair < static_cast<long long>(A)*A; pair += gridDim.y) {
+        const int a = static_cast<int>(pair / A), b = static_cast<int>(pair % A);
+        if (a > b) continue;
+        const cplx* ra = R + static_cast<size_t>(a)*N*W + w;
+        const cplx* rb = R + static_cast<size_t>(b)*N*W + w;
+        cplx acc = {0.0, 0.0};
+        for (int k = 0; k < N; ++k)
+            cmac_conj(acc, ra[static_cast<size_t>(k)*W], rb[static_cast<size_t>(k)*W]);
+        if (a == b) acc.im = 0.0;   // sum_k |R|^2: the imaginary parts cancel term by term
+        F[(static_cast<size_t>(a)*A + b)*W + w] = acc;
+        if (a != b) F[(static_cast<size_t>(b)*A + a)*W + w] = {acc.re, -acc.im};
+    }
 }
 
 // The same for many noise operators: one thread per frequency and per TB x TB block of operator
@@ -131,8 +137,10 @@ __global__ __launch_bounds__(128) void ff_fidelity_blocked_kernel(const cplx* __
                                                                   cplx* __restrict__ F) {
     const int w = blockIdx.x*blockDim.x + threadIdx.x;
     const int nb = (A + TB - 1)/TB;
-    const int ba = blockIdx.y / nb, bb = blockIdx.y % nb;
-    if (w >= W || ba > bb) return;
+    if (w >= W) return;
+    for (long long tile = blockIdx.y; tile < static_cast<long long>(nb)*nb; tile += gridDim.y) {
+    const int ba = static_cast<int>(tile / nb), bb = static_cast<int>(tile % nb);
+    if (ba > bb) continue;
     const int a0 = ba*TB, b0 = bb*TB;
     cplx acc[TB][TB];
 #pragma unroll
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(128) void ff_fidelity_blocked_kernel(const cplx* __
             F[(static_cast<size_t>(a)*A + b)*W + w] = v;
             if (a != b) F[(static_cast<size_t>(b)*A + a)*W + w] = {v.re, -v.im};
         }
+    }
 }
 
 // F[a,b,w] = scale * sum_kl conj(R[a,k,w]) M[k,l] R[b,l,w]   ('ako,blo,kl->abo', the filter
@@ -171,17 +180,19 @@ __global__ __launch_bounds__(128) void ff_weighted_kernel(const cplx* __restrict
                                                           int W, const cplx* __restrict__ M,
                                                           double scale, cplx* __restrict__ F) {
     const int w = blockIdx.x*blockDim.x + threadIdx.x;
-    const int a = blockIdx.y / A, b = blockIdx.y % A;
     if (w >= W) return;
-    const cplx* ra = R + static_cast<size_t>(a)*N*W + w;
-    const cplx* rb = R + static_cast<size_t>(b)*N*W + w;
-    cplx acc = {0.0, 0.0};
-    for (int k = 0; k < N; ++k) {
-        cplx u = {0.0, 0.0};                       // sum_l M[k,l] R[b,l,w]
-        for (int l = 0; l < N; ++l) cmac(u, M[k*N + l], rb[static_cast<size_t>(l)*W]);
-        cmac_conj(acc, ra[static_cast<size_t>(k)*W], u);
+    for (long long pair = blockIdx.y; pair < static_cast<long long>(A)*A; pair += gridDim.y) {
+        const int a = static_cast<int>(pair / A), b = static_cast<int>(pair % A);
+        const cplx* ra = R + static_cast<size_t>(a)*N*W + w;
+        const cplx* rb = R + static_cast<size_t>(b)*N*W + w;
+        cplx acc = {0.0, 0.0};
+        for (int k = 0; k < N; ++k) {
+            cplx u = {0.0, 0.0};                       // sum_l M[k,l] R[b,l,w]
+            for (int l = 0; l < N; ++l) cmac(u, M[k*N + l], rb[static_cast<size_t>(l)*W]);
+            cmac_conj(acc, ra[static_cast<size_t>(k)*W], u);
+        }
+        F[(static_cast<size_t>(a)*A + b)*W + w] = {scale*acc.re, scale*acc.im};
     }
-    F[(static_cast<size_t>(a)*A + b)*W + w] = {scale*acc.re, scale*acc.im};
 }
 
 // F[a,b,k,l,w] = conj(R[a,k,w]) R[b,l,w]        ('ako,blo->abklo', numeric.py:1465).
@@ -190,19 +201,24 @@ __global__ __launch_bounds__(128) void ff_weighted_kernel(const cplx* __restrict
 __global__ void ff_generalized_kernel(const cplx* __restrict__ R, int A, int N, int W,
                                       cplx* __restrict__ F) {
     const int w = blockIdx.x*blockDim.x + threadIdx.x;
-    const int l = blockIdx.y % N, k = blockIdx.y / N;
-    const int a = blockIdx.z / A, b = blockIdx.z % A;
     if (w >= W) return;
-    const cplx x = R[(static_cast<size_t>(a)*N + k)*W + w];
-    const cplx y = R[(static_cast<size_t>(b)*N + l)*W + w];
-    const double rr = x.re*y.re;
-    const double ii = x.im*y.im;
-    const double ri = x.re*y.im;
-    const double ir = x.im*y.re;
-    cplx v;
-    v.re = rr + ii;
-    v.im = ri - ir;
-    F[((((static_cast<size_t>(a)*A + b)*N + k)*N + l))*W + w] = v;
+    // basis pairs on grid.y and operator pairs on grid.z, both strided (d = 16: N*N = 65536 > 65535)
+    for (long long ab = blockIdx.z; ab < static_cast<long long>(A)*A; ab += gridDim.z) {
+        const int a = static_cast<int>(ab / A), b = static_cast<int>(ab % A);
+        for (long long kl = blockIdx.y; kl < static_cast<long long>(N)*N; kl += gridDim.y) {
+            const int k = static_cast<int>(kl / N), l = static_cast<int>(kl % N);
+            const cplx x = R[(static_cast<size_t>(a)*N + k)*W + w];
+            const cplx y = R[(static_cast<size_t>(b)*N + l)*W + w];
+            const double rr = x.re*y.re;
+            const double ii = x.im*y.im;
+            const double ri = x.re*y.im;
+            const double ir = x.im*y.re;
+            cplx v;
+            v.re = rr + ii;
+            v.im = ri - ir;
+            F[((((static_cast<size_t>(a)*A + b)*N + k)*N + l))*W + w] = v;
+        }
+    }
 }
 
 // ---- infidelity ------------------------------------------------------------------------------
@@ -538,21 +554,27 @@ hipError_t launch_transpose_noise_ops(const cplx* Bt, int A, int d, int W, cplx*
     return hipGetLastError();
 }
 
+// blocks on grid.y / grid.z: at most 65535; the kernels stride over what does not fit
+static unsigned grid_axis(long long count) { return static_cast<unsigned>(count < 65535 ? count : 65535); }
+
 hipError_t launch_filter_function(const cplx* R, int A, int N, int W, int which, cplx* F,
                                   hipStream_t stream) {
     const int block = 128;
     if (which == 0 && A > 4) {
         constexpr int TB = 6;
         const int nb = (A + TB - 1)/TB;
-        hipLaunchKernelGGL(ff_fidelity_blocked_kernel<TB>, dim3((W + block - 1)/block, nb*nb),
+        hipLaunchKernelGGL(ff_fidelity_blocked_kernel<TB>,
+                           dim3((W + block - 1)/block, grid_axis(static_cast<long long>(nb)*nb)),
                            dim3(block), 0, stream, R, A, N, W, F);
     } else if (which == 0) {
-        hipLaunchKernelGGL(ff_fidelity_kernel, dim3((W + block - 1)/block, A*A), dim3(block), 0,
-                           stream, R, A, N, W, F);
+        hipLaunchKernelGGL(ff_fidelity_kernel,
+                           dim3((W + block - 1)/block, grid_axis(static_cast<long long>(A)*A)),
+                           dim3(block), 0, stream, R, A, N, W, F);
     } else {
-        if (N*N > 65535 || A*A > 65535) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(ff_generalized_kernel, dim3((W + block - 1)/block, N*N, A*A), dim3(block),
-                           0, stream, R, A, N, W, F);
+        hipLaunchKernelGGL(ff_generalized_kernel,
+                           dim3((W + block - 1)/block, grid_axis(static_cast<long long>(N)*N),
+                                grid_axis(static_cast<long long>(A)*A)),
+                           dim3(block), 0, stream, R, A, N, W, F);
     }
     return hipGetLastError();
 }
@@ -560,9 +582,9 @@ hipError_t launch_filter_function(const cplx* R, int A, int N, int W, int which,
 hipError_t launch_filter_function_weighted(const cplx* R, int A, int N, int W, const cplx* M,
                                            double scale, cplx* F, hipStream_t stream) {
     const int block = 128;
-    if (A*A > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ff_weighted_kernel, dim3((W + block - 1)/block, A*A), dim3(block), 0, stream,
-                       R, A, N, W, M, scale, F);
+    hipLaunchKernelGGL(ff_weighted_kernel,
+                       dim3((W + block - 1)/block, grid_axis(static_cast<long long>(A)*A)),
+                       dim3(block), 0, stream, R, A, N, W, M, scale, F);
     return hipGetLastError();
 }
 

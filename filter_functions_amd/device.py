@@ -86,6 +86,23 @@ class DevicePipeline:
             p(self.control_matrix), p(self.filter_function), p(self.infid) if do_inf else None,
             p(self.workspace), self.ws_bytes, ctypes.c_void_p(s)))
 
+    def check_status(self, stream=None):
+        """Raise ``numpy.linalg.LinAlgError`` if the eigensolver of the last :meth:`launch` flagged
+        a segment (no convergence, NaN/Inf in the Hamiltonian): the device-resident counterpart of
+        the exception ``numeric.diagonalize`` raises.  Copies 4 bytes and synchronises the stream."""
+        torch = self.torch
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        if getattr(self, '_n_failed', None) is None:
+            self._n_failed = torch.zeros(1, dtype=torch.int32, device=self.device)
+        check(_lib.load().ffk_eigensolver_status_dev(self._p(self.workspace), self.ws_bytes, self.G,
+                                                     self.d, self._p(self._n_failed),
+                                                     ctypes.c_void_p(s)))
+        check(_lib.load().ffk_stream_synchronize(ctypes.c_void_p(s)))
+        failed = int(self._n_failed.cpu().item())
+        if failed:
+            raise np.linalg.LinAlgError(
+                f'Jacobi eigensolver did not converge for {failed} segment(s)')
+
     def infidelity_from_shards(self, shards, omega, spectrum, idx, out, stream=None):
         """Device trapezoid straight on an all-gather buffer (n_shards, A, A, shard_width);
         *out* is a preallocated float64 tensor.  No allocation, no re-layout."""

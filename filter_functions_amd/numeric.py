@@ -203,12 +203,18 @@ def calculate_filter_function(control_matrix, which='fidelity'):
     return F
 
 
-def _integrate_filter_function(filter_function, spectrum, omega, idx, d):
+def _integrate_filter_function(filter_function, spectrum, omega, idx, d, pulse=None):
     """(1 / 2 pi d) int dw Re(S F): the filter-function branch of ``_get_integrand``
-    (numeric.py:323-325, 351-352, 374) and ``util.integrate`` (util.py:903-906), on the device."""
+    (numeric.py:323-325, 351-352, 374) and ``util.integrate`` (util.py:903-906), on the device.
+    If *filter_function* is the array a resident pass of *pulse* left in HBM it is integrated
+    there (no upload)."""
     omega = as_f64(omega)
     idx = np.ascontiguousarray(idx, dtype=np.int32)
     spectrum = util.parse_spectrum(spectrum, omega, idx)
+    if pulse is not None:
+        resident = pulse.resident_infidelity(filter_function, spectrum, idx)
+        if resident is not None:
+            return resident
     F = as_c128(filter_function)
     if F.ndim != 3 or F.shape[0] != F.shape[1] or F.shape[2] != len(omega):
         raise ValueError(f'Expected filter_function of shape (n_nops, n_nops, {len(omega)}), '
@@ -222,6 +228,32 @@ def _integrate_filter_function(filter_function, spectrum, omega, idx, d):
     check(_lib.load().ffk_infidelity(ptr(F), F.shape[0], len(omega), ptr(S), S.ndim, ptr(omega),
                                      idx.ctypes.data_as(ctypes.c_void_p), n_idx, int(d), ptr(out)))
     return out
+
+
+def _convergence_study(pulse, spectrum, settings, n_oper_identifiers):
+    """``infidelity(..., test_convergence=True)``: the infidelity on frequency grids of growing
+    size (contract of reference numeric.py:2250-2292).  *spectrum* is a callable ``S(omega)``,
+    *settings* a mapping with optional keys omega_IR, omega_UV (default 2 pi/tau x 1e-2, 1e2),
+    spacing ('linear' | 'log'), n_min, n_max, n_points.  Returns (n_samples, infidelities)."""
+    if not callable(spectrum):
+        raise TypeError('Spectrum should be callable when test_convergence == True.')
+    if not hasattr(settings, 'get'):
+        raise TypeError('omega should be dictionary with parameters when test_convergence == True.')
+    scale = 2*np.pi/pulse.tau
+    options = dict(omega_IR=scale*1e-2, omega_UV=scale*1e+2, spacing='linear', n_min=100,
+                   n_max=500, n_points=10)
+    options.update((key, settings.get(key)) for key in options if settings.get(key) is not None)
+    make_grid = {'linear': np.linspace, 'log': np.geomspace}.get(options['spacing'])
+    if make_grid is None:
+        raise ValueError("spacing should be either 'linear' or 'log'.")
+    stride = (options['n_max'] - options['n_min'])//(options['n_points'] - 1)
+    n_samples = np.arange(options['n_min'], options['n_max'] + stride, stride)
+    results = []
+    for n in n_samples:
+        grid = make_grid(options['omega_IR'], options['omega_UV'], n)
+        results.append(infidelity(pulse, spectrum(grid), grid,
+                                  n_oper_identifiers=n_oper_identifiers, which='total'))
+    return n_samples, np.array(results)
 
 
 @util.parse_optional_parameters(which=('total', 'correlations'))
@@ -238,33 +270,7 @@ def infidelity(pulse, spectrum, omega, n_oper_identifiers=None, which='total',
     idx = util.get_indices_from_identifiers(pulse.n_oper_identifiers, n_oper_identifiers)
 
     if test_convergence:
-        if not callable(spectrum):
-            raise TypeError('Spectrum should be callable when test_convergence == True.')
-        try:
-            omega_IR = omega.get('omega_IR', 2*np.pi/pulse.tau*1e-2)
-        except AttributeError:
-            raise TypeError('omega should be dictionary with parameters '
-                            'when test_convergence == True.') from None
-        omega_UV = omega.get('omega_UV', 2*np.pi/pulse.tau*1e+2)
-        spacing = omega.get('spacing', 'linear')
-        n_min = omega.get('n_min', 100)
-        n_max = omega.get('n_max', 500)
-        n_points = omega.get('n_points', 10)
-        if spacing == 'linear':
-            xspace = np.linspace
-        elif spacing == 'log':
-            xspace = np.geomspace
-        else:
-            raise ValueError("spacing should be either 'linear' or 'log'.")
-        delta_n = (n_max - n_min)//(n_points - 1)
-        n_samples = np.arange(n_min, n_max + delta_n, delta_n)
-        convergence_infids = np.empty((len(n_samples), len(idx)))
-        for i, n in enumerate(n_samples):
-            freqs = xspace(omega_IR, omega_UV, n)
-            convergence_infids[i] = infidelity(pulse, spectrum(freqs), freqs,
-                                               n_oper_identifiers=n_oper_identifiers,
-                                               which='total', cache_intermediates=False)
-        return n_samples, convergence_infids
+        return _convergence_study(pulse, spectrum, omega, n_oper_identifiers)
 
     spectrum = np.asanyarray(spectrum)
     if which == 'total':
@@ -285,7 +291,7 @@ def infidelity(pulse, spectrum, omega, n_oper_identifiers=None, which='total',
             filter_function = pulse.get_filter_function(omega, which='fidelity',
                                                         show_progressbar=show_progressbar,
                                                         cache_intermediates=cache_intermediates)
-        infid = _integrate_filter_function(filter_function, spectrum, omega, idx, pulse.d)
+        infid = _integrate_filter_function(filter_function, spectrum, omega, idx, pulse.d, pulse)
     else:
         if pulse.is_cached('omega') and not np.array_equal(pulse.omega, omega):
             raise ValueError('Pulse correlation infidelities requested '
@@ -505,26 +511,24 @@ def calculate_cumulant_function(pulse, spectrum=None, omega=None, n_oper_identif
     the frequency-shift terms (reference numeric.py:1139-1141, 1166-1190), evaluated as the
     commutator with the effective Hamiltonian :math:`\sum_{kl}(\Delta_{kl}-\Delta_{lk})C_kC_l`.
     """
-    if spectrum is None and omega is None:
-        if decay_amplitudes is None or (frequency_shifts is None and second_order):
-            raise ValueError('Require either spectrum and frequencies or precomputed '
-                             'decay amplitudes (frequency shifts)')
-    if which == 'correlations' and second_order:
+    have_spectrum = spectrum is not None or omega is not None
+    if not have_spectrum and (decay_amplitudes is None or (second_order and frequency_shifts is None)):
+        raise ValueError('Require either spectrum and frequencies or precomputed '
+                         'decay amplitudes (frequency shifts)')
+    if second_order and which == 'correlations':
         raise ValueError('Cannot compute correlation cumulant function for second order terms')
-    if cache_intermediates is None:
-        cache_intermediates = second_order
     if decay_amplitudes is None:
-        decay_amplitudes = calculate_decay_amplitudes(pulse, spectrum, omega, n_oper_identifiers,
-                                                      which, show_progressbar,
-                                                      cache_intermediates, memory_parsimonious)
-    if second_order:
-        if frequency_shifts is None:
-            if memory_parsimonious:
-                warn('Memory parsimonious calculation not implemented for frequency shifts.')
-            frequency_shifts = calculate_frequency_shifts(pulse, spectrum, omega,
-                                                          n_oper_identifiers, show_progressbar)
-        if np.shape(frequency_shifts) != np.shape(decay_amplitudes):
-            raise ValueError('Frequency shifts not same shape as decay amplitudes')
+        decay_amplitudes = calculate_decay_amplitudes(
+            pulse, spectrum, omega, n_oper_identifiers, which, show_progressbar,
+            second_order if cache_intermediates is None else cache_intermediates,
+            memory_parsimonious)
+    if second_order and frequency_shifts is None:
+        if memory_parsimonious:
+            warn('Memory parsimonious calculation not implemented for frequency shifts.')
+        frequency_shifts = calculate_frequency_shifts(pulse, spectrum, omega, n_oper_identifiers,
+                                                      show_progressbar)
+    if second_order and np.shape(frequency_shifts) != np.shape(decay_amplitudes):
+        raise ValueError('Frequency shifts not same shape as decay amplitudes')
     return _cumulant_function(decay_amplitudes, pulse.basis,
                               frequency_shifts if second_order else None)
 
@@ -687,24 +691,24 @@ def error_transfer_matrix(pulse=None, spectrum=None, omega=None, n_oper_identifi
     from scipy import linalg as sla
 
     if cumulant_function is None:
-        if pulse is None or spectrum is None or omega is None:
+        if None in (pulse, spectrum) or omega is None:
             raise ValueError('Require either precomputed cumulant function '
                              'or pulse, spectrum, and omega as arguments.')
-        cumulant_function = calculate_cumulant_function(pulse, spectrum, omega, n_oper_identifiers,
-                                                        'total', second_order,
-                                                        show_progressbar=show_progressbar,
-                                                        memory_parsimonious=memory_parsimonious,
-                                                        cache_intermediates=cache_intermediates)
-    try:
-        K = cumulant_function.sum(axis=tuple(range(cumulant_function.ndim - 2)))
-        if (np.ndim(K) != 2 or K.shape[0] != K.shape[1] or np.iscomplexobj(K) or K.shape[0] < 32
-                or not np.isfinite(K).all()):
-            return sla.expm(K)       # tiny or unusual input: SciPy, exactly like the reference
-        K = as_f64(K)
-        out = np.empty_like(K)
-        check(_lib.load().ffk_expm_real(ptr(K), K.shape[0], ptr(out)))
-        return out
-    except AttributeError as aerr:
-        raise TypeError(f'cumulant_function invalid type: {type(cumulant_function)}') from aerr
-    except ValueError as verr:
-        raise ValueError(f'cumulant_function invalid shape: {cumulant_function.shape}') from verr
+        cumulant_function = calculate_cumulant_function(
+            pulse, spectrum, omega, n_oper_identifiers, 'total', second_order,
+            show_progressbar=show_progressbar, memory_parsimonious=memory_parsimonious,
+            cache_intermediates=cache_intermediates)
+    if not hasattr(cumulant_function, 'sum'):
+        raise TypeError(f'cumulant_function invalid type: {type(cumulant_function)}')
+    if np.ndim(cumulant_function) < 2:
+        raise ValueError(f'cumulant_function invalid shape: {cumulant_function.shape}')
+    # sum over everything but the two Liouville-space axes (noise operators, pulse pairs)
+    K = cumulant_function.sum(axis=tuple(range(cumulant_function.ndim - 2)))
+    if K.shape[0] != K.shape[1]:
+        raise ValueError(f'cumulant_function invalid shape: {cumulant_function.shape}')
+    if np.iscomplexobj(K) or K.shape[0] < 32 or not np.isfinite(K).all():
+        return sla.expm(K)       # tiny or unusual input: SciPy, exactly like the reference
+    K = as_f64(K)
+    out = np.empty_like(K)
+    check(_lib.load().ffk_expm_real(ptr(K), K.shape[0], ptr(out)))
+    return out

@@ -1,54 +1,116 @@
 """``PulseSequence``: the object model and memoising getters in front of the hot path.
 
-Mirrors the part of ``filter_functions/pulse_sequence.py`` that calls into the numeric
+Behavioural twin of the part of ``filter_functions/pulse_sequence.py`` that calls into the numeric
 kernels (constructor and input validation 272-310, ``from_arrays`` 312-359, caches and
 ``is_cached`` 508-538, ``diagonalize`` 577-586, ``get_control_matrix`` / ``cache_control_matrix``
 588-677, ``get_filter_function`` / ``cache_filter_function`` 691-902, total phases 1056-1084,
-the cached-data properties 1086-1169 and ``cleanup`` 1188-1245) with the same three cache
+the cached-data properties 1086-1169 and ``cleanup`` 1188-1245): the same three cache
 dictionaries and keys, the same invalidation rule (assigning a different ``omega`` drops all
-frequency-dependent data) and the same exceptions.  Values in the caches are host ndarrays,
-exactly as in the reference; the arithmetic behind them runs in libffk.
+frequency-dependent data) and the same exceptions.
+
+The implementation is its own: the caches are :class:`~filter_functions_amd._resident.LazyCache`
+dictionaries whose entries may still live on the GPU.  A pulse with nothing cached evaluates
+``get_filter_function`` in ONE library call (``ffk_resident_filter_function``: one H2D, the fused
+device pass, one D2H of the eigensystem and F); the control matrix stays in HBM and the
+by-products the reference computes eagerly (total phases, Liouville propagator) are produced the
+first time somebody reads them.  From the outside every entry is an ndarray, exactly as in the
+reference.
 """
 import copy
-from itertools import chain, zip_longest
 from types import MappingProxyType
 from warnings import warn
 
 import numpy as np
 
 from . import numeric, util
+from ._resident import Deferred, LazyCache, ResidentResult
 from .basis import Basis
 from .superoperator import liouville_representation
 
 __all__ = ['PulseSequence', 'concatenate', 'concatenate_without_filter_function']
 
+_DIAGONALIZATION = ('eigvals', 'eigvecs', 'propagators')
+
+# human-readable names accepted by is_cached (reference pulse_sequence.py:508-538) -> cache key
+_DATA_KEYS = {
+    'eigenvalues': 'eigvals', 'eigenvectors': 'eigvecs', 'propagators': 'propagators',
+    'total propagator': 'total_propagator',
+    'total propagator liouville': 'total_propagator_liouville',
+}
+_FREQUENCY_KEYS = {
+    'frequencies': 'omega', 'total phases': 'total_phases',
+    'filter function': 'filter_function', 'fidelity filter function': 'filter_function',
+    'generalized filter function': 'filter_function_gen',
+    'pulse correlation filter function': 'filter_function_pc',
+    'fidelity pulse correlation filter function': 'filter_function_pc',
+    'generalized pulse correlation filter function': 'filter_function_pc_gen',
+    'second order filter function': 'filter_function_2',
+    'control matrix': 'control_matrix',
+    'pulse correlation control matrix': 'control_matrix_pc',
+}
+# cleanup(method): keys dropped from (_data, _frequency_data), and whether intermediates go too
+_CLEANUP = {
+    'conservative': (_DIAGONALIZATION, (), False),
+    'greedy': (_DIAGONALIZATION + ('total_propagator', 'total_propagator_liouville'),
+               ('total_phases', 'control_matrix', 'control_matrix_pc'), True),
+}
+_NOT_CONCATENATED = ("Could not get the pulse correlation {} since it "
+                     "was not computed during concatenation. Please run the "
+                     "concatenation again with 'calc_pulse_correlation_FF' set to True.")
+
 
 def _parse_hamiltonian(H, n_dt, H_str):
     """Unpack ``[[oper, coeffs(, identifier)], ...]`` into arrays sorted by identifier
-    (reference pulse_sequence.py:1286-1337)."""
+    (contract of reference pulse_sequence.py:1286-1337)."""
     if not util.is_sequence_like(H):
         raise TypeError(f'Expected {H_str} to be a sequence, not of type {type(H)}!')
-    if not all(util.is_sequence_like(item) for item in H):
-        raise TypeError(f'Expected {H_str} to be a sequence of sequences but found at least one '
-                        'item of H not a sequence!')
-    opers, *rest = zip_longest(*H, fillvalue=None)
-    coeffs = rest[0]
-    identifiers = list(rest[1]) if len(rest) > 1 else None
-    if not all(util.is_sequence_like(coeff) for coeff in coeffs):
-        raise TypeError(f'Expected coefficients in {H_str} to be a sequence')
+    opers, coeffs, identifiers = [], [], []
+    for term in H:
+        if not util.is_sequence_like(term):
+            raise TypeError(f'Expected {H_str} to be a sequence of sequences but found at least one '
+                            'item of H not a sequence!')
+        term = tuple(term)
+        opers.append(term[0] if term else None)
+        coeffs.append(term[1] if len(term) > 1 else None)
+        identifiers.append(term[2] if len(term) > 2 else None)
+    for coeff in coeffs:
+        if not util.is_sequence_like(coeff):
+            raise TypeError(f'Expected coefficients in {H_str} to be a sequence')
     prefix = 'A' if H_str == 'H_c' else 'B'
-    if identifiers is None:
-        identifiers = np.fromiter((f'{prefix}_{i}' for i in range(len(opers))), dtype='<U4')
-    else:
-        identifiers = [f'{prefix}_{i}' if ident is None else ident
-                       for i, ident in enumerate(identifiers)]
-        if len(set(identifiers)) != len(identifiers):
-            raise ValueError(f'{H_str} identifiers should be unique')
-    if not all(len(coeff) == n_dt for coeff in coeffs):
-        raise ValueError(f'Expected all coefficients in {H_str} to be of len(dt) = {n_dt}!')
+    named = [ident is not None for ident in identifiers]
+    identifiers = [ident if given else f'{prefix}_{i}'
+                   for i, (ident, given) in enumerate(zip(identifiers, named))]
+    if any(named) and len(set(identifiers)) != len(identifiers):
+        raise ValueError(f'{H_str} identifiers should be unique')
+    for coeff in coeffs:
+        if len(coeff) != n_dt:
+            raise ValueError(f'Expected all coefficients in {H_str} to be of len(dt) = {n_dt}!')
     order = np.argsort(identifiers)
-    opers = util.parse_operators(opers, H_str)
-    return opers[order], np.asarray(identifiers)[order], np.asarray(coeffs)[order]
+    return (util.parse_operators(opers, H_str)[order], np.asarray(identifiers)[order],
+            np.asarray(coeffs)[order])
+
+
+def _checked_durations(dt):
+    if not util.is_sequence_like(dt):
+        raise TypeError(f'Expected a sequence of time steps, not {type(dt)}')
+    dt = np.asarray(dt)
+    if np.iscomplexobj(dt) and dt.imag.any():
+        raise ValueError('Times dt are not (all) real!')
+    if (dt.real < 0).any():
+        raise ValueError('Time steps are not (all) positive!')
+    return dt
+
+
+def _checked_basis(basis, d):
+    if basis is None:
+        return Basis.ggm(d)
+    if not isinstance(basis, Basis):
+        raise ValueError("Expected basis to be an instance of the "
+                         f"'filter_functions_amd.basis.Basis' class, not {type(basis)}!")
+    if basis.shape[1:] != (d, d):
+        raise ValueError(f"Expected basis elements to be of shape ({d}, {d}), "
+                         f"not {basis.shape[1:]}!")
+    return basis
 
 
 class PulseSequence:
@@ -65,64 +127,53 @@ class PulseSequence:
     """
     __array_interface__ = {'shape': (), 'typestr': '|O', 'version': 3}
 
-    def __new__(cls, *args, **kwargs):
-        new = super().__new__(cls)
-        new._data = dict()
-        new._frequency_data = dict()
-        new._intermediates = dict()
+    @classmethod
+    def _blank(cls):
+        """An instance with empty caches and no Hamiltonian yet."""
+        new = object.__new__(cls)
+        new._data, new._frequency_data, new._intermediates = LazyCache(), LazyCache(), LazyCache()
+        new._resident = None
         return new
 
+    def __new__(cls, *args, **kwargs):
+        return cls._blank()
+
     def __init__(self, H_c, H_n, dt, basis=None):
-        if not util.is_sequence_like(dt):
-            raise TypeError(f'Expected a sequence of time steps, not {type(dt)}')
-        self.dt = np.asarray(dt)
-        if not np.isreal(self.dt).all():
-            raise ValueError('Times dt are not (all) real!')
-        if (self.dt < 0).any():
-            raise ValueError('Time steps are not (all) positive!')
-        self.c_opers, self.c_oper_identifiers, self.c_coeffs = _parse_hamiltonian(
-            H_c, len(self.dt), 'H_c')
-        self.n_opers, self.n_oper_identifiers, self.n_coeffs = _parse_hamiltonian(
-            H_n, len(self.dt), 'H_n')
-        if self.c_opers.shape[-2:] != self.n_opers.shape[-2:]:
+        self.dt = _checked_durations(dt)
+        control = _parse_hamiltonian(H_c, len(self.dt), 'H_c')
+        noise = _parse_hamiltonian(H_n, len(self.dt), 'H_n')
+        if control[0].shape[-2:] != noise[0].shape[-2:]:
             raise ValueError('Control and noise Hamiltonian not same dimension!')
+        self.c_opers, self.c_oper_identifiers, self.c_coeffs = control
+        self.n_opers, self.n_oper_identifiers, self.n_coeffs = noise
         self.d = self.c_opers.shape[-1]
-        if basis is None:
-            self.basis = Basis.ggm(self.d)
-        else:
-            if not isinstance(basis, Basis):
-                raise ValueError("Expected basis to be an instance of the "
-                                 f"'filter_functions_amd.basis.Basis' class, not {type(basis)}!")
-            if basis.shape[1:] != (self.d, self.d):
-                raise ValueError("Expected basis elements to be of shape "
-                                 f"({self.d}, {self.d}), not {basis.shape[1:]}!")
-            self.basis = basis
+        self.basis = _checked_basis(basis, self.d)
 
     @classmethod
     def from_arrays(cls, c_opers, c_oper_identifiers, c_coeffs, n_opers, n_oper_identifiers,
                     n_coeffs, dt, basis=None):
-        """Alternative constructor from already-parsed arrays (reference
-        pulse_sequence.py:312-359)."""
-        new = cls.__new__(cls)
-        new.c_opers = np.asanyarray(c_opers)
-        new.c_oper_identifiers = np.asanyarray(c_oper_identifiers)
-        new.c_coeffs = np.asanyarray(c_coeffs)
-        new.n_opers = np.asanyarray(n_opers)
-        new.n_oper_identifiers = np.asanyarray(n_oper_identifiers)
-        new.n_coeffs = np.asanyarray(n_coeffs)
-        new.dt = np.asanyarray(dt)
+        """Alternative constructor from already-parsed arrays (contract of reference
+        pulse_sequence.py:312-359): no sorting, consistency checks only."""
+        new = cls._blank()
+        given = dict(c_opers=c_opers, c_oper_identifiers=c_oper_identifiers, c_coeffs=c_coeffs,
+                     n_opers=n_opers, n_oper_identifiers=n_oper_identifiers, n_coeffs=n_coeffs,
+                     dt=dt)
+        for name, value in given.items():
+            setattr(new, name, np.asanyarray(value))
         new.d = new.c_opers.shape[-1]
-        new.basis = np.asanyarray(basis).view(Basis) if basis is not None else Basis.ggm(new.d)
-        if not len(new.c_opers) == len(new.c_oper_identifiers) == len(new.c_coeffs):
-            raise ValueError('Control Hamiltonian not same length!')
-        if not len(new.n_opers) == len(new.n_oper_identifiers) == len(new.n_coeffs):
-            raise ValueError('Noise Hamiltonian not same length!')
-        if not len(set(new.c_opers.shape[1:] + new.n_opers.shape[1:])) == 1:
-            raise ValueError('Control and/or noise Hamiltonian not same, square dimension!')
-        if not new.dt.size == new.n_coeffs.shape[1] == new.c_coeffs.shape[1]:
-            raise ValueError('Time steps not same length!')
-        if not new.basis.d == new.d:
-            raise ValueError('Basis dimension not same as Hamiltonian dimension!')
+        new.basis = Basis.ggm(new.d) if basis is None else np.asanyarray(basis).view(Basis)
+        n_control = {len(new.c_opers), len(new.c_oper_identifiers), len(new.c_coeffs)}
+        n_noise = {len(new.n_opers), len(new.n_oper_identifiers), len(new.n_coeffs)}
+        extents = set(new.c_opers.shape[1:] + new.n_opers.shape[1:])
+        n_steps = {new.dt.size, new.c_coeffs.shape[1], new.n_coeffs.shape[1]}
+        for consistent, complaint in (
+                (len(n_control) == 1, 'Control Hamiltonian not same length!'),
+                (len(n_noise) == 1, 'Noise Hamiltonian not same length!'),
+                (len(extents) == 1, 'Control and/or noise Hamiltonian not same, square dimension!'),
+                (len(n_steps) == 1, 'Time steps not same length!'),
+                (new.basis.d == new.d, 'Basis dimension not same as Hamiltonian dimension!')):
+            if not consistent:
+                raise ValueError(complaint)
         return new
 
     def __repr__(self):
@@ -136,29 +187,28 @@ class PulseSequence:
 
     def __getitem__(self, key):
         """A slice of the pulse as a new PulseSequence (reference pulse_sequence.py:440-484)."""
-        new_dt = np.atleast_1d(self.dt[key])
-        if not new_dt.size:
+        durations = np.atleast_1d(self.dt[key])
+        if durations.size == 0:
             raise IndexError('Cannot create empty PulseSequence')
-        new = self.__class__.from_arrays(
-            c_opers=self.c_opers, n_opers=self.n_opers,
-            c_oper_identifiers=self.c_oper_identifiers,
-            n_oper_identifiers=self.n_oper_identifiers,
-            c_coeffs=np.atleast_2d(self.c_coeffs.T[key]).T,
-            n_coeffs=np.atleast_2d(self.n_coeffs.T[key]).T,
-            dt=new_dt, basis=self.basis)
-        valid = isinstance(key, slice) and key.start in (None, 0) and key.step in (None, 1)
-        if valid and 'control_matrix_step_cumulative' in self._intermediates:
-            new.cache_control_matrix(
-                self.omega, self._intermediates['control_matrix_step_cumulative'][key.stop - 1])
+
+        def columns(table):
+            return np.atleast_2d(table.T[key]).T
+        new = type(self).from_arrays(self.c_opers, self.c_oper_identifiers, columns(self.c_coeffs),
+                                     self.n_opers, self.n_oper_identifiers, columns(self.n_coeffs),
+                                     durations, self.basis)
+        # a leading slice can reuse the running sum of the control matrix, if that was kept
+        leading = isinstance(key, slice) and key.start in (None, 0) and key.step in (None, 1)
+        if leading and 'control_matrix_step_cumulative' in self._intermediates:
+            running = self._intermediates['control_matrix_step_cumulative']
+            new.cache_control_matrix(self.omega, running[key.stop - 1])
         return new
 
     def __copy__(self):
-        copied = self.__class__.__new__(self.__class__)
-        copied.__dict__.update(self.__dict__)
-        copied._data = copy.copy(self._data)
-        copied._frequency_data = copy.copy(self._frequency_data)
-        copied._intermediates = copy.copy(self._intermediates)
-        return copied
+        twin = self._blank()
+        twin.__dict__.update(self.__dict__)
+        for cache in ('_data', '_frequency_data', '_intermediates'):
+            setattr(twin, cache, getattr(self, cache).copy())
+        return twin
 
     def copy(self):
         return self.__copy__()
@@ -211,30 +261,14 @@ class PulseSequence:
     # ---- caches --------------------------------------------------------------------------
     def is_cached(self, attr):
         """True if *attr* is cached; accepts the reference's human-readable aliases
-        (pulse_sequence.py:508-538)."""
-        data_aliases = {
-            'eigenvalues': 'eigvals', 'eigenvectors': 'eigvecs', 'propagators': 'propagators',
-            'total propagator': 'total_propagator',
-            'total propagator liouville': 'total_propagator_liouville',
-        }
-        frequency_data_aliases = {
-            'frequencies': 'omega', 'total phases': 'total_phases',
-            'filter function': 'filter_function', 'fidelity filter function': 'filter_function',
-            'generalized filter function': 'filter_function_gen',
-            'pulse correlation filter function': 'filter_function_pc',
-            'fidelity pulse correlation filter function': 'filter_function_pc',
-            'generalized pulse correlation filter function': 'filter_function_pc_gen',
-            'second order filter function': 'filter_function_2',
-            'control matrix': 'control_matrix',
-            'pulse correlation control matrix': 'control_matrix_pc',
-        }
-        alias = attr.lower().replace('_', ' ')
-        if alias in data_aliases:
-            return data_aliases[alias] in self._data
-        if alias in frequency_data_aliases:
-            return frequency_data_aliases[alias] in self._frequency_data
-        return (attr in self._intermediates or attr in self._frequency_data
-                or attr in self._data)
+        (pulse_sequence.py:508-538).  Never triggers a computation or a transfer."""
+        spoken = attr.lower().replace('_', ' ')
+        if spoken in _DATA_KEYS:
+            return _DATA_KEYS[spoken] in self._data
+        if spoken in _FREQUENCY_KEYS:
+            return _FREQUENCY_KEYS[spoken] in self._frequency_data
+        return any(attr in cache for cache in (self._data, self._frequency_data,
+                                               self._intermediates))
 
     @property
     def data(self):
@@ -251,7 +285,9 @@ class PulseSequence:
     @property
     def t(self):
         """Absolute segment times [0, cumsum(dt)] (reference pulse_sequence.py:541-544)."""
-        return self._data.setdefault('t', np.concatenate(([0], self.dt.cumsum())))
+        if 't' not in self._data:
+            self._data['t'] = np.concatenate(([0], self.dt.cumsum()))
+        return self._data['t']
 
     @t.setter
     def t(self, val):
@@ -259,7 +295,9 @@ class PulseSequence:
 
     @property
     def tau(self):
-        return self._data.setdefault('tau', self.t[-1] if 't' in self._data else self.dt.sum())
+        if 'tau' not in self._data:
+            self._data['tau'] = self._data['t'][-1] if 't' in self._data else self.dt.sum()
+        return self._data['tau']
 
     @tau.setter
     def tau(self, val):
@@ -270,59 +308,87 @@ class PulseSequence:
         return self.tau
 
     # ---- the hot path ----------------------------------------------------------------------
+    def _hamiltonian(self):
+        return np.einsum('ijk,il->ljk', self.c_opers, self.c_coeffs)
+
     def diagonalize(self):
         """Diagonalise the control Hamiltonian (reference pulse_sequence.py:577-586)."""
-        if not all(self.is_cached(attr) for attr in ('eigvals', 'eigvecs', 'propagators')):
-            hamiltonian = np.einsum('ijk,il->ljk', self.c_opers, self.c_coeffs)
-            self.eigvals, self.eigvecs, self.propagators = numeric.diagonalize(hamiltonian,
-                                                                               self.dt)
-        self.total_propagator = self.propagators[-1]
+        if any(key not in self._data for key in _DIAGONALIZATION):
+            results = numeric.diagonalize(self._hamiltonian(), self.dt)
+            self._data.update(zip(_DIAGONALIZATION, results))
+        self._data['total_propagator'] = self._data['propagators'][-1]
+
+    def _resident_pass_applies(self, which, order, cache_intermediates):
+        """The one-call evaluation serves the plain request on a pulse that has nothing to reuse."""
+        return (order == 1 and which == 'fidelity' and not cache_intermediates
+                and len(self.omega) > 0 and 2 <= self.d <= numeric._lib.MAX_D
+                and not any(key in self._data for key in _DIAGONALIZATION)
+                and not any(key in self._frequency_data
+                            for key in ('control_matrix', 'control_matrix_pc')))
+
+    def _resident_pass(self):
+        """diagonalize + control matrix + filter function in one library call; the control matrix
+        stays on the device behind a :class:`Deferred` cache entry."""
+        result = ResidentResult()
+        D, V, Q, F = result.evaluate(self._hamiltonian(), self.dt, self.t, self.omega,
+                                     np.asarray(self.basis), self.n_opers, self.n_coeffs)
+        self._data.update(eigvals=D, eigvecs=V, propagators=Q, total_propagator=Q[-1])
+        self._frequency_data['control_matrix'] = Deferred(result.control_matrix,
+                                                          result.control_matrix_nbytes())
+        self._frequency_data['filter_function'] = F
+        self._defer_by_products()
+        self._resident = result
+
+    def _defer_by_products(self):
+        """What the reference's cache_control_matrix computes on the spot -- total phase factors and
+        the Liouville representation of the total propagator -- becomes due on first read."""
+        if 'total_phases' not in self._frequency_data:
+            omega = self.omega
+            self._frequency_data['total_phases'] = Deferred(
+                lambda: util.cexp(np.asarray(omega)*self.tau), 16*len(omega))
+        if 'total_propagator_liouville' not in self._data:
+            self._data['total_propagator_liouville'] = Deferred(
+                lambda: liouville_representation(self.total_propagator, self.basis),
+                8*len(self.basis)**2)
+
+    def _store_control_matrix(self, control_matrix):
+        slot = 'control_matrix_pc' if control_matrix.ndim == 4 else 'control_matrix'
+        self._frequency_data[slot] = control_matrix
+        self._defer_by_products()
 
     def get_control_matrix(self, omega, show_progressbar=False, cache_intermediates=False):
         """Control matrix (n_nops, d**2, n_omega) for *omega*, memoised
         (reference pulse_sequence.py:588-636)."""
         self.omega = omega
-        if self.is_cached('control_matrix'):
-            return self._frequency_data['control_matrix']
-        if self.is_cached('control_matrix_pc'):
-            self._frequency_data['control_matrix'] = np.sum(
-                self._frequency_data['control_matrix_pc'], axis=0)
-            return self._frequency_data['control_matrix']
-        self.diagonalize()
-        control_matrix = numeric.calculate_control_matrix_from_scratch(
-            self.eigvals, self.eigvecs, self.propagators, self.omega, self.basis, self.n_opers,
-            self.n_coeffs, self.dt, self.t, show_progressbar=show_progressbar,
-            cache_intermediates=cache_intermediates)
-        if cache_intermediates:
-            control_matrix, intermediates = control_matrix
-            self._intermediates.update(intermediates)
-        self.cache_control_matrix(self.omega, control_matrix)
-        return self._frequency_data['control_matrix']
+        known = self._frequency_data
+        if 'control_matrix' not in known and 'control_matrix_pc' in known:
+            known['control_matrix'] = np.sum(known['control_matrix_pc'], axis=0)
+        if 'control_matrix' not in known:
+            self.diagonalize()
+            result = numeric.calculate_control_matrix_from_scratch(
+                self.eigvals, self.eigvecs, self.propagators, self.omega, self.basis, self.n_opers,
+                self.n_coeffs, self.dt, self.t, show_progressbar=show_progressbar,
+                cache_intermediates=cache_intermediates)
+            if cache_intermediates:
+                result, by_products = result
+                self._intermediates.update(by_products)
+            self._store_control_matrix(result)
+        return known['control_matrix']
 
     def cache_control_matrix(self, omega, control_matrix=None, show_progressbar=False,
                              cache_intermediates=False):
-        """Cache the control matrix, total phases and total Liouville propagator
-        (reference pulse_sequence.py:638-677)."""
+        """Cache the control matrix -- computed now if not given --, the total phases and the
+        total Liouville propagator (reference pulse_sequence.py:638-677)."""
         self.omega = omega
         if control_matrix is None:
-            control_matrix = self.get_control_matrix(self.omega, show_progressbar,
-                                                     cache_intermediates)
-        if control_matrix.ndim == 4:
-            self._frequency_data['control_matrix_pc'] = control_matrix
+            self.get_control_matrix(self.omega, show_progressbar, cache_intermediates)
         else:
-            self._frequency_data['control_matrix'] = control_matrix
-        self.cache_total_phases(self.omega)
-        if not self.is_cached('total_propagator_liouville'):
-            self.total_propagator_liouville = liouville_representation(self.total_propagator,
-                                                                       self.basis)
+            self._store_control_matrix(control_matrix)
 
     def get_pulse_correlation_control_matrix(self):
-        if self.is_cached('control_matrix_pc'):
-            return self._frequency_data['control_matrix_pc']
-        raise util.CalculationError(
-            "Could not get the pulse correlation control matrix since it "
-            "was not computed during concatenation. Please run the "
-            "concatenation again with 'calc_pulse_correlation_FF' set to True.")
+        if 'control_matrix_pc' not in self._frequency_data:
+            raise util.CalculationError(_NOT_CONCATENATED.format('control matrix'))
+        return self._frequency_data['control_matrix_pc']
 
     @util.parse_optional_parameters(which=('fidelity', 'generalized'), order=(1, 2))
     def get_filter_function(self, omega, which='fidelity', order=1, show_progressbar=False,
@@ -331,28 +397,26 @@ class PulseSequence:
         (n_nops, n_nops, n_omega), 'generalized' -> (n_nops, n_nops, d², d², n_omega); order=2: the
         second-order filter function (n_nops, n_nops, d², d², n_omega), *which* ignored."""
         self.omega = omega
-        if order == 1:
-            key = 'filter_function' if which == 'fidelity' else 'filter_function_gen'
-        else:
-            key = 'filter_function_2'
-        if key in self._frequency_data:
-            return self._frequency_data[key]
-        control_matrix = None
-        if order == 1:
-            control_matrix = self.get_control_matrix(self.omega, show_progressbar,
-                                                     cache_intermediates)
-        self.cache_filter_function(self.omega, control_matrix=control_matrix, which=which,
-                                   order=order, show_progressbar=show_progressbar,
-                                   cache_intermediates=cache_intermediates,
-                                   cache_second_order_cumulative=cache_second_order_cumulative)
-        return self._frequency_data[key]
+        wanted = ('filter_function_2' if order == 2 else
+                  'filter_function' if which == 'fidelity' else 'filter_function_gen')
+        if wanted not in self._frequency_data:
+            if self._resident_pass_applies(which, order, cache_intermediates):
+                self._resident_pass()
+            else:
+                self.cache_filter_function(
+                    self.omega, which=which, order=order, show_progressbar=show_progressbar,
+                    cache_intermediates=cache_intermediates,
+                    cache_second_order_cumulative=cache_second_order_cumulative)
+        return self._frequency_data[wanted]
 
     @util.parse_optional_parameters(which=('fidelity', 'generalized'), order=(1, 2))
     def cache_filter_function(self, omega, control_matrix=None, filter_function=None,
                               which='fidelity', order=1, show_progressbar=False,
                               cache_intermediates=False, cache_second_order_cumulative=False):
-        """Cache the filter function (reference pulse_sequence.py:807-902)."""
+        """Cache the filter function -- given, or computed from the (given or cached or computed)
+        control matrix (reference pulse_sequence.py:807-902)."""
         self.omega = omega
+        known = self._frequency_data
         if order == 2:
             if filter_function is None:
                 filter_function = numeric.calculate_second_order_filter_function_from_scratch(
@@ -360,31 +424,35 @@ class PulseSequence:
                     self.n_opers, self.n_coeffs, self.dt, self._intermediates, show_progressbar,
                     cache_intermediates, cache_second_order_cumulative)
                 if cache_intermediates:
-                    filter_function, intermediates = filter_function
-                    self._intermediates.update(intermediates)
-            self._frequency_data['filter_function_2'] = filter_function
+                    filter_function, by_products = filter_function
+                    self._intermediates.update(by_products)
+            known['filter_function_2'] = filter_function
             return
+        generalized = which == 'generalized'
         if filter_function is None:
             if control_matrix is None:
                 control_matrix = self.get_control_matrix(self.omega, show_progressbar,
                                                          cache_intermediates)
-            self.cache_control_matrix(self.omega, control_matrix)
-            if control_matrix.ndim == 4:
-                # pulse-resolved control matrix: also cache the pulse correlation filter function
-                F_pc = numeric.calculate_pulse_correlation_filter_function(control_matrix, which)
-                if which == 'fidelity':
-                    self._frequency_data['filter_function_pc'] = F_pc
-                else:
-                    self._frequency_data['filter_function_pc'] = F_pc.trace(axis1=4, axis2=5)
-                    self._frequency_data['filter_function_pc_gen'] = F_pc
-                filter_function = F_pc.sum(axis=(0, 1))
             else:
+                self._store_control_matrix(control_matrix)
+            if control_matrix.ndim == 3:
                 filter_function = numeric.calculate_filter_function(control_matrix, which)
-        if which == 'fidelity':
-            self._frequency_data['filter_function'] = filter_function
-        else:
-            self._frequency_data['filter_function'] = filter_function.trace(axis1=2, axis2=3)
-            self._frequency_data['filter_function_gen'] = filter_function
+            else:
+                # one control matrix per pulse of a concatenation: keep the pulse correlations too
+                correlations = numeric.calculate_pulse_correlation_filter_function(control_matrix,
+                                                                                   which)
+                if generalized:
+                    known['filter_function_pc_gen'] = correlations
+                    known['filter_function_pc'] = correlations.trace(axis1=4, axis2=5)
+                else:
+                    known['filter_function_pc'] = correlations
+                filter_function = correlations.sum(axis=(0, 1))
+        if generalized:
+            known['filter_function_gen'] = filter_function
+            filter_function = filter_function.trace(axis1=2, axis2=3)
+        known['filter_function'] = filter_function
+        if self._resident is not None and self._resident.filter_function is not filter_function:
+            self._resident = None
 
     def get_filter_function_derivative(self, omega, control_identifiers=None,
                                        n_oper_identifiers=None, n_coeffs_deriv=None):
@@ -397,53 +465,57 @@ class PulseSequence:
 
     @util.parse_optional_parameters(which=('fidelity', 'generalized'))
     def get_pulse_correlation_filter_function(self, which='fidelity'):
-        key = 'filter_function_pc' if which == 'fidelity' else 'filter_function_pc_gen'
-        if key in self._frequency_data:
-            return self._frequency_data[key]
-        if self.is_cached('control_matrix_pc'):
-            F_pc = numeric.calculate_pulse_correlation_filter_function(
-                self._frequency_data['control_matrix_pc'], which=which)
-            self._frequency_data[key] = F_pc
-            return F_pc
-        raise util.CalculationError(
-            "Could not get the pulse correlation filter function since it "
-            "was not computed during concatenation. Please run the "
-            "concatenation again with 'calc_pulse_correlation_FF' set to True.")
+        known = self._frequency_data
+        wanted = 'filter_function_pc' if which == 'fidelity' else 'filter_function_pc_gen'
+        if wanted not in known:
+            if 'control_matrix_pc' not in known:
+                raise util.CalculationError(_NOT_CONCATENATED.format('filter function'))
+            known[wanted] = numeric.calculate_pulse_correlation_filter_function(
+                known['control_matrix_pc'], which=which)
+        return known[wanted]
 
     def get_total_phases(self, omega):
         """exp(i omega tau), memoised (reference pulse_sequence.py:1056-1066)."""
         self.omega = omega
-        if self.is_cached('total_phases'):
-            return self._frequency_data['total_phases']
-        self.cache_total_phases(self.omega, util.cexp(self.omega*self.tau))
+        if 'total_phases' not in self._frequency_data:
+            self._frequency_data['total_phases'] = util.cexp(np.asarray(self.omega)*self.tau)
         return self._frequency_data['total_phases']
 
     def cache_total_phases(self, omega, total_phases=None):
         self.omega = omega
         if total_phases is None:
-            total_phases = self.get_total_phases(self.omega)
-        self._frequency_data['total_phases'] = total_phases
+            self.get_total_phases(self.omega)
+        else:
+            self._frequency_data['total_phases'] = total_phases
+
+    def resident_infidelity(self, filter_function, spectrum, idx):
+        """Integrate *spectrum* against *filter_function* on the device if that array is the one a
+        resident pass left in HBM (no upload of F); ``None`` if it is not."""
+        resident = self._resident
+        if resident is None or resident.filter_function is not filter_function:
+            return None
+        return resident.infidelity(spectrum, idx)
 
     # ---- cached-data properties ----------------------------------------------------------
-    def _cached(name):  # noqa: N805  (helper evaluated at class-creation time)
-        def getter(self):
+    def _diagonalization_product(name):  # noqa: N805  (evaluated while the class body runs)
+        def read(self):
             if name not in self._data:
                 self.diagonalize()
             return self._data[name]
 
-        def setter(self, value):
+        def write(self, value):
             self._data[name] = value
-        return property(getter, setter)
+        return property(read, write)
 
-    eigvals = _cached('eigvals')
-    eigvecs = _cached('eigvecs')
-    propagators = _cached('propagators')
-    total_propagator = _cached('total_propagator')
-    del _cached
+    eigvals = _diagonalization_product('eigvals')
+    eigvecs = _diagonalization_product('eigvecs')
+    propagators = _diagonalization_product('propagators')
+    total_propagator = _diagonalization_product('total_propagator')
+    del _diagonalization_product
 
     @property
     def total_propagator_liouville(self):
-        if not self.is_cached('total_propagator_liouville'):
+        if 'total_propagator_liouville' not in self._data:
             self._data['total_propagator_liouville'] = liouville_representation(
                 self.total_propagator, self.basis)
         return self._data['total_propagator_liouville']
@@ -454,45 +526,43 @@ class PulseSequence:
 
     @property
     def omega(self):
-        return self._frequency_data.get('omega', None)
+        return self._frequency_data.get('omega')
 
     @omega.setter
     def omega(self, value):
-        """Cache the frequencies (a copy); a different grid drops every frequency-dependent
-        entry (reference pulse_sequence.py:1158-1169)."""
-        old = self._frequency_data.get('omega', None)
-        new = np.array(value, copy=True)
-        if not np.array_equal(old, new):
+        """Remember (a copy of) the frequencies; a grid that differs from the remembered one
+        invalidates everything that depends on frequency (reference pulse_sequence.py:1158-1169)."""
+        grid = np.array(value, copy=True)
+        if not np.array_equal(self._frequency_data.get('omega'), grid):
             self.cleanup('frequency dependent')
-        self._frequency_data['omega'] = new
+        self._frequency_data['omega'] = grid
 
     @property
     def nbytes(self):
-        total = 0
-        for val in chain(self._data.values(), self._frequency_data.values(),
-                         self._intermediates.values()):
-            total += getattr(val, 'nbytes', 0)
-        return total
+        """Bytes held by the caches (device-resident entries count with their host size)."""
+        return sum(cache.stored_nbytes()
+                   for cache in (self._data, self._frequency_data, self._intermediates))
 
     @util.parse_optional_parameters(method=('conservative', 'greedy', 'frequency dependent', 'all'))
     def cleanup(self, method='conservative'):
-        """Drop cached by-products (reference pulse_sequence.py:1188-1245)."""
-        if method == 'all':
-            self._data.clear()
+        """Drop cached by-products (reference pulse_sequence.py:1188-1245): 'conservative' the
+        diagonalisation; 'greedy' also the total propagators, the control matrices, the total
+        phases and the intermediates (the filter functions stay); 'frequency dependent' all that
+        belongs to a frequency grid; 'all' everything."""
+        if method in ('all', 'frequency dependent'):
+            if method == 'all':
+                self._data.clear()
             self._frequency_data.clear()
             self._intermediates.clear()
-        elif method == 'frequency dependent':
-            self._frequency_data.clear()
+            self._resident = None
+            return
+        from_data, from_frequency_data, intermediates_too = _CLEANUP[method]
+        for key in from_data:
+            self._data.pop(key, None)
+        for key in from_frequency_data:
+            self._frequency_data.pop(key, None)
+        if intermediates_too:
             self._intermediates.clear()
-        else:
-            for key in ('eigvals', 'eigvecs', 'propagators'):
-                self._data.pop(key, None)
-            if method == 'greedy':
-                self._intermediates.clear()
-                for key in ('total_propagator', 'total_propagator_liouville'):
-                    self._data.pop(key, None)
-                for key in ('total_phases', 'control_matrix', 'control_matrix_pc'):
-                    self._frequency_data.pop(key, None)
 
 
 # --------------------------------------------------------------------------------------------
@@ -595,9 +665,10 @@ def concatenate_without_filter_function(pulses, return_identifier_mappings=False
         pulses = tuple(pulses)
     except TypeError:
         raise TypeError(f'Expected pulses to be iterable, not {type(pulses)}') from None
-    if not all(isinstance(pulse, PulseSequence) for pulse in pulses):
-        raise TypeError('Can only concatenate PulseSequences!')
-    if len(set(pulse.d for pulse in pulses)) != 1:
+    for pulse in pulses:
+        if not isinstance(pulse, PulseSequence):
+            raise TypeError('Can only concatenate PulseSequences!')
+    if any(pulse.d != pulses[0].d for pulse in pulses):
         raise ValueError('Trying to concatenate PulseSequence instances with different dimension!')
     if not _all_bases_equal(pulses):
         raise ValueError('Trying to concatenate PulseSequence instances with different bases!')
@@ -629,13 +700,22 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     two pulses share a noise operator.  ``calc_pulse_correlation_FF`` keeps every summand and
     caches the pulse correlation filter function.
     """
+    try:
+        pulses = tuple(pulses)           # any iterable, also a generator: consumed exactly once
+    except TypeError:
+        raise TypeError(f'Expected pulses to be iterable, not {type(pulses)}') from None
+    if len(pulses) == 1 and isinstance(pulses[0], PulseSequence):
+        return copy.deepcopy(pulses[0])  # nothing to concatenate: an independent copy, caches kept
     newpulse, _, n_map = concatenate_without_filter_function(pulses, return_identifier_mappings=True)
-    pulses = tuple(pulses)
-    if all(pls.is_cached('total_propagator') for pls in pulses):
-        newpulse.total_propagator = util.mdot([pls.total_propagator for pls in pulses][::-1])
+
+    def chain_total_propagators():
+        # U = U_n ... U_2 U_1
+        return util.mdot([pls.total_propagator for pls in reversed(pulses)])
+    if all('total_propagator' in pls._data for pls in pulses):
+        newpulse.total_propagator = chain_total_propagators()
     if calc_pulse_correlation_FF or calc_second_order_FF is True:
-        calc_filter_function = True
-    if calc_filter_function is False:
+        calc_filter_function = True         # both need every summand of the control matrix
+    elif calc_filter_function is False:
         return newpulse
 
     # which noise operators of the new pulse does each pulse carry?
@@ -700,13 +780,13 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
                 t=pls.t)
         return R
 
+    # Liouville representation of the propagators accumulated before each pulse
     propagators_liouville = util.adot(
         np.array([pls.total_propagator_liouville for pls in pulses[:-1]]))
-    if not newpulse.is_cached('total_propagator'):
-        newpulse.total_propagator = util.mdot([pls.total_propagator for pls in pulses][::-1])
-    newpulse.cache_total_phases(omega)
-    newpulse.total_propagator_liouville = liouville_representation(newpulse.total_propagator,
-                                                                   newpulse.basis)
+    if 'total_propagator' not in newpulse._data:
+        newpulse.total_propagator = chain_total_propagators()
+    newpulse.omega = omega
+    newpulse._defer_by_products()           # total phases, Liouville propagator: on first read
     mode = 'correlations' if calc_pulse_correlation_FF or calc_second_order_FF else 'total'
     # the indexed kernel assumes a repeated pulse contributes the same rows everywhere, which
     # holds when every pulse carries every noise operator (else fall back to the plain rule)
@@ -909,24 +989,24 @@ def extend(pulse_to_qubit_mapping, N=None, d_per_qubit=2, additional_noise_Hamil
             return single[0][0]
 
     if cache_filter_function is not False:
-        all_cached = all(pulse.is_cached('control_matrix') for pulse in pulses)
-        equal_omega = all(pulse.is_cached('omega') for pulse in pulses) and \
-            util.all_array_equal(pulse.omega for pulse in pulses)
+        # the grid the pulses agree on, if they do
+        grids = [pulse._frequency_data.get('omega') for pulse in pulses]
+        common = grids[0] if all(g is not None and np.array_equal(g, grids[0]) for g in grids) \
+            else None
         if cache_filter_function is None:
-            cache_filter_function = all_cached and equal_omega
-            if cache_filter_function:
-                omega = pulses[0].omega
+            # by default the filter function is carried over exactly when every pulse brings one
+            cache_filter_function = common is not None and all(
+                'control_matrix' in pulse._frequency_data for pulse in pulses)
+            omega = common if cache_filter_function else omega
         elif omega is None:
-            if not equal_omega:
+            if common is None:
                 raise ValueError('Filter function should be cached but omega was not provided and '
                                  'could not be inferred.')
-            omega = pulses[0].omega
+            omega = common
+    needs_eigensystem = cache_filter_function and additional_noise_Hamiltonian is not None
     if cache_diagonalization is None:
-        if cache_filter_function and additional_noise_Hamiltonian is not None:
-            cache_diagonalization = True
-        else:
-            cache_diagonalization = all(pulse.is_cached(attr) for pulse in pulses
-                                        for attr in ('eigvals', 'eigvecs', 'propagators'))
+        cache_diagonalization = bool(needs_eigensystem) or all(
+            key in pulse._data for pulse in pulses for key in _DIAGONALIZATION)
     elif not cache_diagonalization and additional_noise_Hamiltonian is not None:
         raise ValueError('Additional noise Hamiltonian given and cache_diagonalization set to '
                          'False but required.')
@@ -976,19 +1056,22 @@ def extend(pulse_to_qubit_mapping, N=None, d_per_qubit=2, additional_noise_Hamil
         basis = Basis.ggm(d)
 
     c_sort, n_sort = np.argsort(c_ids), np.argsort(n_ids)
+
+    def in_order(items, order):
+        return np.asarray(items)[order]
     newpulse = PulseSequence.from_arrays(
-        c_opers=np.asarray(c_opers)[c_sort], c_oper_identifiers=np.asarray(c_ids)[c_sort],
-        c_coeffs=np.asarray(c_coeffs)[c_sort],
-        n_opers=np.asarray(n_opers)[n_sort], n_oper_identifiers=np.asarray(n_ids)[n_sort],
-        n_coeffs=np.asarray(n_coeffs)[n_sort], dt=pulses[0].dt, basis=basis)
-    for attr in ('t', 'tau'):
-        if attr in pulses[0]._data:
-            setattr(newpulse, attr, getattr(pulses[0], attr))
+        in_order(c_opers, c_sort), in_order(c_ids, c_sort), in_order(c_coeffs, c_sort),
+        in_order(n_opers, n_sort), in_order(n_ids, n_sort), in_order(n_coeffs, n_sort),
+        pulses[0].dt, basis)
+    newpulse._data.update((key, pulses[0]._data[key]) for key in ('t', 'tau')
+                          if key in pulses[0]._data)
     if newpulse.basis.btype != 'Pauli':
-        if cache_diagonalization:
-            newpulse.diagonalize()
+        # no tensor-product structure to exploit: evaluate what was asked for from scratch
+        # (the filter function brings the diagonalisation with it)
         if cache_filter_function:
             newpulse.cache_filter_function(omega)
+        elif cache_diagonalization:
+            newpulse.diagonalize()
         return newpulse
 
     def embedded_product(attr):

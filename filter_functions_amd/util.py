@@ -39,9 +39,11 @@ def abs2(x):
 def cexp(x, out=None, where=True):
     """exp(ix) = cos x + i sin x (reference util.py:136-162); host helper for O(W) vectors."""
     x = np.asarray(x)
-    out = np.empty(x.shape, dtype=np.complex128) if out is None else out
-    out.real = np.cos(x, out=out.real, where=where)
-    out.imag = np.sin(x, out=out.imag, where=where)
+    if out is None:
+        out = np.empty(x.shape, dtype=np.complex128)
+    # NumPy's own cos and sin (not exp): this is what the device sincos is checked against
+    np.cos(x, out=out.real, where=where)
+    np.sin(x, out=out.imag, where=where)
     return out
 
 

@@ -413,6 +413,44 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
                      double* control_matrix, double* filter_function, double* infid,
                      void* workspace, size_t workspace_bytes, void* stream);
 
+/* Number of segments whose eigensolver iteration did not converge (or met NaN/Inf) in the last
+ * ffk_diagonalize_dev / ffk_pipeline_dev run that used `workspace`, written to the device integer
+ * `n_failed` on `stream`: the device-resident counterpart of the FFK_ENOCONV return of
+ * ffk_diagonalize (numpy.linalg.LinAlgError of numeric.py:1919).                               */
+int ffk_eigensolver_status_dev(const void* workspace, size_t workspace_bytes, int G, int d,
+                               int32_t* n_failed, void* stream);
+
+/* ---- resident evaluation: the user-facing call PulseSequence.get_filter_function(omega)
+ *      followed by ff.infidelity(pulse, S, omega) (pulse_sequence.py:691-805, 577-677;
+ *      numeric.py:2062-2334) on host arrays with the minimum of PCIe traffic ------------------
+ * ffk_resident_filter_function stages all inputs (same arrays as ffk_pipeline_dev, host pointers)
+ * through one pinned block with ONE H2D copy, runs the fused pass, and returns the small results
+ * -- eigvals (G, d), eigvecs (G, d, d), propagators (G+1, d, d), filter_function (A, A, W) -- by ONE
+ * D2H copy as pointers into pinned host memory owned by the handle (valid until the handle runs
+ * another pass or is destroyed; the binding wraps them as arrays without copying).  The control
+ * matrix (A, N, W) -- 5x the bytes of F at config 2 -- stays in HBM and is fetched only when the
+ * caller asks for it (ffk_resident_control_matrix), which is what the reference's cache
+ * (`pulse._frequency_data['control_matrix']`) needs it for.  ffk_resident_infidelity integrates
+ * the resident F against a host spectrum ((W,), (n_idx, W) or (n_idx, n_idx, W); real f64 if
+ * spectrum_is_real, else c128) on the resident frequency grid.  Returns FFK_ENOCONV like
+ * ffk_diagonalize.  Device and pinned blocks come from grow-only pools
+ * (ffk_resident_release_pools frees what is idle).                                             */
+typedef struct ffk_resident ffk_resident;
+int ffk_resident_create(ffk_resident** handle);
+int ffk_resident_destroy(ffk_resident* handle);
+int ffk_resident_release_pools(void);
+int ffk_resident_filter_function(ffk_resident* handle, const double* hamiltonian, const double* dt,
+                                 const double* t, int G, int d, const double* omega, int W,
+                                 const double* basis, int N, const double* n_opers, int A,
+                                 const double* n_coeffs, double** eigvals, double** eigvecs,
+                                 double** propagators, double** filter_function);
+int ffk_resident_control_matrix(ffk_resident* handle, double* control_matrix);
+/* device pointers of the resident control matrix, filter function and frequencies (any may be NULL) */
+int ffk_resident_control_matrix_dev(ffk_resident* handle, const double** control_matrix,
+                                    const double** filter_function, const double** omega);
+int ffk_resident_infidelity(ffk_resident* handle, const double* spectrum, int s_ndim,
+                            int spectrum_is_real, const int32_t* idx, int n_idx, double* infid);
+
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Number of segment chunks the control-matrix kernel splits G into (0 = automatic).        */
 int ffk_set_segment_chunks(int chunks);

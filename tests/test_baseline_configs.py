@@ -5,8 +5,8 @@ of the frequency axis (fixtures `tests/golden/{cfg3_subgrid,cfg4_subgrid,qft}.np
 oracle/make_golden.py from the imported reference; every frequency is independent, so the
 full-size run must reproduce them at those frequencies), (ii) against the CPU oracle on another
 subsample / on the integrals over the full grid, (iii) through size-independent properties
-(exact Hermiticity of F, vanishing identity column, sharded == unsharded bit for bit, trace
-preservation of the error transfer matrix).  Inputs come from workloads.py.
+(exact Hermiticity of F, vanishing identity column, sharded == unsharded, trace preservation
+of the error transfer matrix).  Inputs come from workloads.py.
 """
 import numpy as np
 import pytest
@@ -115,7 +115,8 @@ def test_config5_full_size_error_transfer_matrix():
         w0, w1 = shard_bounds(W, 8, rank)
         part = DevicePipeline(*args, omega[w0:w1], spectrum=S[:, w0:w1])
         part.launch(with_infidelity=False)
-        assert torch.equal(part.filter_function, pipe.filter_function[:, :, w0:w1])
+        # (the number of segment chunks depends on the block width: same values, re-associated sum)
+        assert rel_err(part.filter_function.cpu().numpy(), F[:, :, w0:w1]) < 1e-13
         contribution = part.decay_amplitudes(omega_global=omega_dev, w_offset=w0)
         total = contribution if total is None else total + contribution
     assert rel_err(total.cpu().numpy(), gamma_ref) < 1e-12
@@ -171,15 +172,17 @@ def test_config4_full_grid_sharded_and_unsharded():
     assert rel_err(F[:, :, sub], orc.filter_function(R_ref)) < TOL
     infid_ref = orc.infidelity_from_filter_function(F, S, omega, np.arange(A), d)
     assert rel_err(infid.cpu().numpy(), infid_ref) < 1e-12
-    # (iii) properties, and the unsharded pass over the whole grid: bit-identical
+    # (iii) properties, and the unsharded pass over the whole grid
     assert _hermitian_in_operators(F)
     assert np.abs(R[:, 0]).max() < 1e-12*np.abs(R).max()
     whole = DevicePipeline(*args, omega, spectrum=S)
     whole.launch()
     torch.cuda.synchronize()
-    assert np.array_equal(whole.filter_function.cpu().numpy(), F)
-    assert np.array_equal(whole.control_matrix.cpu().numpy(), R)
-    assert np.array_equal(whole.infid.cpu().numpy(), infid.cpu().numpy())
+    # (the number of segment chunks depends on the block width: same values, re-associated sum)
+    assert rel_err(whole.filter_function.cpu().numpy(), F) < 1e-13
+    assert rel_err(whole.control_matrix.cpu().numpy(), R) < 1e-13
+    assert rel_err(whole.infid.cpu().numpy(), infid.cpu().numpy()) < 1e-13
+    assert _hermitian_in_operators(whole.filter_function.cpu().numpy())
     # the user-facing call on one rank's shard
     w0, w1 = shard_bounds(W, n, 3)
     assert rel_err(pulse.get_filter_function(omega[w0:w1]), F[:, :, w0:w1]) < 1e-13

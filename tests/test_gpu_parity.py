@@ -1794,3 +1794,124 @@ def test_many_noise_operators_fused_expansion():
         tag = f'd={d} A={A} G={G} W={W}'
         assert rel_err(R, R_ref) < TOL, tag
         assert rel_err(F, orc.filter_function(R_ref)) < TOL, tag
+
+
+# ---- round 2: resident evaluation, large pair grids, complex spectra, device-side status ---------
+def test_resident_pass_matches_array_path():
+    """get_filter_function on a fresh pulse runs as one library call (ffk_resident_*): same
+    results as the array-in/array-out route, control matrix fetched from HBM only on demand,
+    infidelity integrated on the resident F."""
+    from filter_functions_amd._resident import Deferred
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs(G=40, W=700)
+    basis = ff.Basis.pauli(2)
+
+    def fresh():
+        return ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
+    fast, slow = fresh(), fresh()
+    slow.diagonalize()                                   # anything cached -> array route
+    F_slow = slow.get_filter_function(omega)
+    assert slow._resident is None
+    F = fast.get_filter_function(omega)
+    assert fast._resident is not None
+    assert isinstance(fast._frequency_data.peek('control_matrix'), Deferred)     # still in HBM
+    for key in ('control_matrix', 'total_phases', 'filter_function', 'omega'):
+        assert fast.is_cached(key)
+    assert fast.is_cached('total_propagator_liouville') and fast.is_cached('eigvals')
+    assert fast.nbytes == slow.nbytes
+    assert rel_err(F, F_slow) < 1e-14 and rel_err(fast.propagators, slow.propagators) < 1e-14
+    assert np.array_equal(fast.eigvals, slow.eigvals)
+    assert fast.total_propagator is not None and rel_err(fast.total_propagator, slow.total_propagator) < 1e-14
+    S1, S2 = 1e-3/omega, np.outer([1.0, 2.0, 3.0], 1e-3/omega)
+    X = np.random.default_rng(0).standard_normal((3, 3, len(omega)))
+    S3 = (np.einsum('abo,cbo->aco', X, X) + 0j)*1e-3
+    for S in (S1, S2, S3):
+        assert rel_err(ff.infidelity(fast, S, omega), ff.infidelity(slow, S, omega)) < 1e-13
+    ids = fast.n_oper_identifiers[[2, 0]]
+    assert rel_err(ff.infidelity(fast, S2[[2, 0]], omega, n_oper_identifiers=ids),
+                   ff.infidelity(slow, S2[[2, 0]], omega, n_oper_identifiers=ids)) < 1e-13
+    with pytest.raises(ValueError):
+        ff.infidelity(fast, np.ones((2, 5)), omega)
+    R = fast.get_control_matrix(omega)                   # D2H now
+    assert isinstance(R, np.ndarray) and fast.get_control_matrix(omega) is R
+    assert rel_err(R, slow.get_control_matrix(omega)) < 1e-14
+    assert rel_err(fast.get_total_phases(omega), slow.get_total_phases(omega)) == 0
+    assert rel_err(fast.total_propagator_liouville, slow.total_propagator_liouville) < 1e-14
+    # results outlive the pulse and its handle
+    del fast
+    import gc
+    gc.collect()
+    assert rel_err(F, F_slow) < 1e-14
+    # a new frequency grid drops the resident result with everything else
+    again = fresh()
+    again.get_filter_function(omega)
+    again.get_filter_function(omega[:100])
+    assert len(again.omega) == 100 and again.get_filter_function(omega[:100]).shape == (3, 3, 100)
+    assert rel_err(again.get_filter_function(omega[:100]), F_slow[..., :100]) < 1e-14
+    # the mapping views hand out arrays, never placeholders
+    view = fresh()
+    view.get_filter_function(omega)
+    assert isinstance(view.frequency_data['control_matrix'], np.ndarray)
+    assert all(isinstance(v, np.ndarray) for v in view.frequency_data.values())
+
+
+def test_eigensolver_failure_is_reported_on_every_path():
+    """NaN in the Hamiltonian: LinAlgError from the array route, the resident route and the
+    device-resident pipeline (ffk_eigensolver_status_dev)."""
+    import torch
+    from filter_functions_amd.device import DevicePipeline
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs(G=12, W=64)
+    bad = c_coeffs.copy()
+    bad[0, 5] = np.nan
+    basis = ff.Basis.pauli(2)
+    pulse = ff.PulseSequence(list(zip(c_opers, bad)), list(zip(n_opers, n_coeffs)), dt, basis)
+    with pytest.raises(np.linalg.LinAlgError):
+        pulse.diagonalize()
+    with pytest.raises(np.linalg.LinAlgError):
+        pulse.get_filter_function(omega)
+    pipe = DevicePipeline(c_opers, bad, n_opers, n_coeffs, dt, basis, omega)
+    pipe.launch()
+    with pytest.raises(np.linalg.LinAlgError):
+        pipe.check_status()
+    good = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega)
+    good.launch()
+    good.check_status()
+    torch.cuda.synchronize()
+
+
+def test_filter_function_pair_grids_beyond_65535():
+    """'generalized' at d = 16 has N*N = 65536 basis pairs, a pulse-correlation filter function of
+    a long sequence (G*A)^2 operator pairs: both exceed one grid axis."""
+    rng = np.random.default_rng(16)
+    R = rng.standard_normal((1, 256, 3)) + 1j*rng.standard_normal((1, 256, 3))
+    F = numeric.calculate_filter_function(R, 'generalized')
+    assert F.shape == (1, 1, 256, 256, 3)
+    assert rel_err(F, orc.filter_function(R, 'generalized')) < 1e-15
+    # fidelity filter function of 1600 rows (2.56 M operator pairs)
+    R = rng.standard_normal((1600, 4, 5)) + 1j*rng.standard_normal((1600, 4, 5))
+    F = numeric.calculate_filter_function(R)
+    assert rel_err(F, orc.filter_function(R)) < 1e-14
+    assert np.array_equal(F, F.conj().swapaxes(0, 1))
+    # pulse correlations: (G, A) = (300, 1) 'generalized' -> 90000 operator pairs on grid.z
+    Rpc = rng.standard_normal((300, 1, 4, 2)) + 1j*rng.standard_normal((300, 1, 4, 2))
+    Fpc = numeric.calculate_pulse_correlation_filter_function(Rpc, 'generalized')
+    ref = np.einsum('gako,hblo->ghabklo', Rpc.conj(), Rpc)
+    assert Fpc.shape == ref.shape and rel_err(Fpc, ref) < 1e-15
+
+
+@pytest.mark.parametrize('s_ndim', [1, 2])
+def test_decay_amplitudes_complex_spectrum_below_three_dimensions(s_ndim):
+    """A complex spectrum of one or two dimensions makes Gamma_aa non-symmetric in (k, l): the
+    GEMM's mirror shortcut must switch itself off; N = 40 spans several tiles."""
+    rng = np.random.default_rng(40 + s_ndim)
+    A, N, W = 2, 40, 300
+    R = rng.standard_normal((A, N, W)) + 1j*rng.standard_normal((A, N, W))
+    omega = np.sort(rng.random(W))*20 + 1e-3
+    shape = (W,) if s_ndim == 1 else (A, W)
+    S = rng.random(shape) + 1j*rng.standard_normal(shape)
+    got = numeric._decay_amplitudes(R, S, omega, np.arange(A), 'total')
+    ref = orc.decay_amplitudes(R, S, omega, np.arange(A))
+    assert np.abs(ref - ref.swapaxes(-1, -2)).max() > 1e-3*np.abs(ref).max()   # really asymmetric
+    assert rel_err(got, ref) < 1e-12
+    real = numeric._decay_amplitudes(R, S.real, omega, np.arange(A), 'total')
+    assert rel_err(real, orc.decay_amplitudes(R, S.real, omega, np.arange(A))) < 1e-12
+    assert np.array_equal(real, real.swapaxes(-1, -2))

@@ -584,3 +584,56 @@ def test_qft_pulse_assembly_matches_reference_bit_exact():
     assert list(qft.n_oper_identifiers) == list(g['n_oper_identifiers'])
     assert qft.basis.btype == str(g['btype']) == 'GGM'
     assert qft.tau == 13.0
+
+
+def test_concatenate_accepts_any_iterable_and_single_pulse():
+    """concatenate() takes any iterable exactly once (a generator too) and returns an independent
+    copy -- caches included -- for a single pulse (reference pulse_sequence.py:1745-1752)."""
+    X, Z = util.paulis[1], util.paulis[3]
+    p = ff.PulseSequence([[X, [1.0], 'X']], [[Z, [1.0], 'Z']], [1.0])
+    q = ff.PulseSequence([[Z, [0.5, 0.25], 'Zc']], [[Z, [1.0, 1.0], 'Z']], [1.0, 2.0])
+    from_list = ff.concatenate([p, q])
+    from_generator = ff.concatenate(pulse for pulse in (p, q))
+    assert from_list == from_generator and len(from_generator) == 3
+    with pytest.raises(TypeError):
+        ff.concatenate(5)
+    with pytest.raises(TypeError):
+        ff.concatenate([p, 'not a pulse'])
+    omega = [1.0, 2.0]
+    R = np.arange(8, dtype=complex).reshape(1, 4, 2)
+    p._data['total_propagator'] = np.eye(2, dtype=complex)
+    p._data['total_propagator_liouville'] = np.eye(4)
+    p.cache_control_matrix(omega, R)
+    p.cache_filter_function(omega, filter_function=np.ones((1, 1, 2), complex))
+    single = ff.concatenate(iter([p]))
+    assert single is not p and single == p
+    assert single.is_cached('control_matrix') and single.is_cached('filter_function')
+    assert single.get_control_matrix(omega) is not R
+    assert np.array_equal(single.get_control_matrix(omega), R)
+    assert np.array_equal(single.get_total_phases(omega), p.get_total_phases(omega))
+
+
+def test_lazy_cache_semantics():
+    """Deferred entries are produced once, on first read; membership and nbytes never produce."""
+    from filter_functions_amd._resident import Deferred, LazyCache
+    calls = []
+
+    def produce():
+        calls.append(1)
+        return np.ones(4)
+    cache = LazyCache(a=1, b=Deferred(produce, nbytes=32))
+    assert 'b' in cache and len(cache) == 2 and cache.stored_nbytes() == 32 and not calls
+    twin = cache.copy()
+    assert isinstance(twin, LazyCache) and not calls
+    assert np.array_equal(cache['b'], np.ones(4)) and calls == [1]
+    assert cache['b'] is cache.get('b') and calls == [1]               # produced once
+    assert [k for k, _ in cache.items()] == ['a', 'b'] and len(cache.values()) == 2
+    assert cache.setdefault('c', 5) == 5 and cache.setdefault('a', 7) == 1
+    assert cache.get('missing', 3) == 3 and cache.pop('a') == 1
+    import copy
+    import pickle
+    assert np.array_equal(copy.deepcopy(twin)['b'], np.ones(4))        # produces in the copy
+    assert np.array_equal(pickle.loads(pickle.dumps(twin))['b'], np.ones(4))
+    from types import MappingProxyType
+    view = MappingProxyType(LazyCache(x=Deferred(lambda: 42)))
+    assert view['x'] == 42 and dict(view.items()) == {'x': 42}
