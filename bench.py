@@ -6,14 +6,23 @@
 
 A "step" is one full pass of the hot path over one pulse, HBM-resident in and out: Hamiltonian ->
 eigendecomposition + expm + cumulative propagators -> control matrix -> filter function ->
-infidelity (ffk_pipeline_dev).  Workload (config 2): random 2-qubit pulse, d=4, 256 segments,
-3 noise operators, Pauli basis, 4096 omega per GPU, seed 42.  With N > 1 the
-frequency axis is sharded: every rank evaluates its own block of 4096 omega of a 4096*N grid
-(weak scaling), one RCCL all-gather reassembles F(omega) on every rank and the infidelity is
+infidelity (ffk_pipeline_dev).  Headline workload (config 2): random 2-qubit pulse, d=4, 256
+segments, 3 noise operators, Pauli basis, 4096 omega per GPU, seed 42.  With
+N > 1 the frequency axis is sharded: every rank evaluates its own block of 4096 omega of a 4096*N
+grid (weak scaling), one RCCL all-gather reassembles F(omega) on every rank and the infidelity is
 integrated over the full grid.
 
+Before the W warm-up steps an UNTIMED, disclosed clock pre-warm runs the same step until the
+accumulate kernel's HIP-event time is stable (`prewarm` object of the JSON line): after an idle
+period the part needs ~300 steps (35 ms) to reach its sustained clocks (profiles/r01_q_*), which a
+`--steps 20 --warmup 5` run never gets to on its own.
+
 Rank 0 prints ONE JSON line.  value = elements/s over all ranks, element count
-E = n_seg * n_omega_total * n_nops * d^2 per step (BASELINE.json metric).
+E = n_seg * n_omega_total * n_nops * d^2 per step (BASELINE.json metric).  Besides the contract
+keys the line carries `roofline` (+ `frac_step`), `cpu_baseline`, `api_call_ms` (the user-facing
+PulseSequence.get_filter_function + ff.infidelity call on host arrays) and `configs`: BASELINE
+configs 3, 4 (one rank's shard; with N > 1 the whole 65536-omega grid strong-scaled over the ranks)
+and 5, each timed in-process after the headline.
 """
 import argparse
 import ctypes
@@ -27,28 +36,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import workloads as wl  # noqa: E402
+
 FP64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD datasheet); see DESIGN.md
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md
 
 
-def config2(seed=42, d=4, G=256, A=3, n_cops=3):
-    """rand_pulse_sequence recipe of the reference's tests/testutil.py:159-190."""
-    rng = np.random.default_rng(seed)
-
-    def herm_traceless(n):
-        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
-        M = (M + M.conj().transpose(0, 2, 1))/2
-        return M - np.trace(M, axis1=1, axis2=2)[:, None, None]*np.eye(d)/d
-    c_opers, n_opers = herm_traceless(n_cops), herm_traceless(A)
-    c_coeffs = rng.standard_normal((n_cops, G))
-    n_coeffs = rng.random((A, G))
-    dt = 1 - rng.random(G)
-    return c_opers, c_coeffs, n_opers, n_coeffs, dt
-
-
-def cpu_baseline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum, budget_s=12.0):
-    """The oracle (NumPy restatement of the reference's algorithm) timed on this box's host cores:
-    full passes of the same workload until ~budget_s seconds have been spent."""
+# ---- CPU baseline ---------------------------------------------------------------------------------
+def cpu_baseline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum, budget_s=14.0):
+    """The oracle (NumPy restatement of the reference's algorithm) timed on this box's host cores on
+    full passes of the headline workload.  The BLAS thread count is chosen first: one pass per
+    candidate, the fastest one is then timed for the rest of the budget."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import ff_oracle as orc
     d = c_opers.shape[-1]
@@ -61,27 +59,46 @@ def cpu_baseline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectru
         F = orc.filter_function(R)
         infid = orc.infidelity_from_filter_function(F, spectrum, omega, np.arange(A), d)
         return R, F, infid
-    one_pass()                                   # warm-up (BLAS threads, page faults)
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        threadpool_limits = None
+    n_cpu = os.cpu_count() or 1
+    result = one_pass()                          # warm-up (page faults, BLAS thread pool)
+    survey = {}
+    best = None
+    if threadpool_limits is not None:
+        for threads in [t for t in (1, 4, 8, 16, 32, 64) if t <= n_cpu]:
+            with threadpool_limits(limits=threads):
+                t0 = time.perf_counter()
+                one_pass()
+                survey[threads] = time.perf_counter() - t0
+        best = min(survey, key=survey.get)
     t0 = time.perf_counter()
     n = 0
-    while True:
-        result = one_pass()
-        n += 1
-        elapsed = time.perf_counter() - t0
-        if elapsed >= budget_s or n >= 50:
-            break
+    ctx = threadpool_limits(limits=best) if best else None
+    if ctx is not None:
+        ctx.__enter__()
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+        while True:
+            result = one_pass()
+            n += 1
+            elapsed = time.perf_counter() - t0
+            if elapsed >= budget_s - sum(survey.values()) or n >= 50:
+                break
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
     value = n*G*W*A*d*d/elapsed
-    return dict(value=value, unit='elements/s', cores=int(threads), kind='port',
-                sample=f'{n} full passes of config 2 (d={d}, {G} segments, {A} noise ops, '
-                       f'{W} omega) in {elapsed:.1f} s, NumPy/OpenBLAS oracle, '
-                       f'os.cpu_count()={os.cpu_count()}'), result
+    return dict(value=value, unit='elements/s', cores=int(best or n_cpu), kind='port',
+                sample=f'{n} full passes of config 2 (d={d}, {G} segments, {A} noise ops, {W} omega) '
+                       f'in {elapsed:.1f} s, NumPy/OpenBLAS oracle with {best or n_cpu} BLAS threads '
+                       f'(fastest of one pass each at '
+                       f'{ {k: round(v, 2) for k, v in survey.items()} } s; '
+                       f'os.cpu_count()={n_cpu})'), result
 
 
+# ---- HBM traffic of the dominant kernel from the PMC counters ---------------------------------------
 def measure_hbm_traffic(omega_per_gpu):
     """HBM traffic of the accumulate kernel, per launch, from the PMC counters: two short child runs
     of this script under ``rocprofv3 --pmc`` (FETCH_SIZE and WRITE_SIZE in separate passes, as the
@@ -107,8 +124,8 @@ def measure_hbm_traffic(omega_per_gpu):
             for key in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
                 env.pop(key, None)
             cmd = [prof, '--pmc', counter, '--output-format', 'csv', '-d', out_dir, '--',
-                   sys.executable, script, '--steps', '8', '--warmup', '2', '--no-cpu-baseline',
-                   '--no-pmc', '--omega-per-gpu', str(omega_per_gpu)]
+                   sys.executable, script, '--steps', '8', '--warmup', '2', '--child',
+                   '--omega-per-gpu', str(omega_per_gpu)]
             res = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL,
                                  stderr=subprocess.DEVNULL, timeout=90)
             if res.returncode != 0:
@@ -132,24 +149,234 @@ def measure_hbm_traffic(omega_per_gpu):
                      f"WRITE_SIZE {means['WRITE_SIZE']:.0f} KiB")
 
 
+class AccumulateTimer:
+    """HIP events around the accumulate kernel, recorded by libffk on the stream the kernel is
+    launched on (ffk_set_accumulate_events)."""
+
+    def __init__(self, lib, _lib, n):
+        self.lib, self._lib = lib, _lib
+        self.pairs = [[ctypes.c_void_p(), ctypes.c_void_p()] for _ in range(n)]
+        for pair in self.pairs:
+            for e in pair:
+                _lib.check(lib.ffk_event_create(ctypes.byref(e)))
+
+    def arm(self, j):
+        self._lib.check(self.lib.ffk_set_accumulate_events(self.pairs[j][0], self.pairs[j][1]))
+
+    def disarm(self):
+        self._lib.check(self.lib.ffk_set_accumulate_events(None, None))
+
+    def read_ms(self, upto=None):
+        ms = ctypes.c_float()
+        out = []
+        for a, b in self.pairs[:upto]:
+            self._lib.check(self.lib.ffk_event_elapsed_ms(a, b, ctypes.byref(ms)))
+            out.append(ms.value)
+        return out
+
+    def close(self):
+        for pair in self.pairs:
+            for e in pair:
+                self.lib.ffk_event_destroy(e)
+
+
+def prewarm_clocks(step, sync, timer, max_s, adaptive, batch=100):
+    """Untimed: run `step` in batches until the accumulate kernel's HIP-event time (last step of a
+    batch) changes by less than 1 % between batches twice in a row and at least 0.1 s have
+    passed, or `max_s` seconds are over.  Not adaptive (N > 1: every rank must issue the same
+    collectives): a fixed 3 batches."""
+    t0 = time.perf_counter()
+    trace, steps, stable = [], 0, 0
+    while True:
+        for i in range(batch):
+            if i == batch - 1:
+                timer.arm(0)
+            step()
+        timer.disarm()
+        sync()
+        steps += batch
+        trace.append(timer.read_ms(1)[0])
+        elapsed = time.perf_counter() - t0
+        if not adaptive:
+            if steps >= 3*batch:
+                break
+            continue
+        if len(trace) > 1 and abs(trace[-1] - trace[-2]) <= 0.01*trace[-1]:
+            stable += 1
+        else:
+            stable = 0
+        if (stable >= 2 and elapsed >= 0.1) or elapsed >= max_s:
+            break
+    return dict(steps=steps, seconds=time.perf_counter() - t0,
+                accumulate_ms_first_batch=trace[0], accumulate_ms_last_batch=trace[-1],
+                rule=('adaptive: batches of 100 steps until the accumulate kernel time is stable '
+                      f'within 1 % twice in a row (>= 0.1 s) or {max_s} s' if adaptive
+                      else 'fixed 300 steps (N > 1: ranks must issue identical collectives)'))
+
+
+# ---- the other BASELINE configurations, timed in-process after the headline -----------------------
+def time_pipeline(pipe, torch, lib, _lib, stream, reps, extra=None):
+    """ms per pass of `pipe.launch` (+ `extra()` per pass), and of its accumulate kernel."""
+    def run():
+        pipe.launch(stream=stream)
+        if extra is not None:
+            extra()
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    timer = AccumulateTimer(lib, _lib, 1)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        if i == reps - 1:
+            timer.arm(0)
+        run()
+    timer.disarm()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0)/reps*1e3
+    kernel_ms = timer.read_ms()[0]
+    timer.close()
+    return ms, kernel_ms
+
+
+def bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream, rank=0, world=1):
+    """d = 8, 512 segments, 9 noise operators: one rank's block of the 65536-omega grid."""
+    from filter_functions_amd.parallel import shard_bounds
+    cfg = wl.CONFIG4
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
+    omega_full = wl.random_pulse_omega(dt, cfg['W'])
+    n = max(world, cfg['n_shards']) if world == 1 else world
+    w0, w1 = shard_bounds(cfg['W'], n, rank if world > 1 else 0)
+    omega = omega_full[w0:w1]
+    basis = ff.Basis.pauli(3)
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
+    pipe = DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, basis,
+                          omega, spectrum=1e-3/omega, device=device)
+    ms, kernel_ms = time_pipeline(pipe, torch, lib, _lib, stream, reps=6)
+    st = _lib.stats()
+    E = cfg['G']*len(omega)*cfg['A']*cfg['d']**2
+    return pipe, dict(
+        config=4, workload=f"d=8, 512 segments, 9 noise ops, Pauli basis, seed 43: omega block "
+                           f"[{w0}, {w1}) of the 65536-omega grid ({n} shards), diagonalize -> "
+                           'infidelity, HBM-resident',
+        ms=ms, elements_per_s=E/(ms*1e-3), dominant_kernel='ffk::ctrl_accumulate (d = 8)',
+        kernel_ms=kernel_ms, executed_flops=st['accumulate_flops'],
+        tflops=st['accumulate_flops']/(kernel_ms*1e-3)/1e12,
+        frac=st['accumulate_flops']/(kernel_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+        geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')})
+
+
+def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, stream):
+    """examples/qft.py: d = 16, 13 segments, 18 noise operators, 16384 omega: control matrix ->
+    decay amplitudes -> cumulant function -> error transfer matrix."""
+    W = wl.CONFIG5['W']
+    omega = np.logspace(-2, 2, W)
+    qft = wl.qft_pulse(ff)
+    A = len(qft.n_opers)
+    S = np.outer(1e-6*(np.arange(A) + 1), 1/omega)
+    pipe = DevicePipeline(qft.c_opers, qft.c_coeffs, qft.n_opers, qft.n_coeffs, qft.dt, qft.basis,
+                          omega, spectrum=S, device=device)
+    result = {}
+
+    def etm():
+        gamma = pipe.decay_amplitudes(stream=stream)
+        K = pipe.cumulant_function(gamma, stream=stream)
+        result['U'] = ff.error_transfer_matrix(cumulant_function=K.sum(dim=0).cpu().numpy()[None])
+    ms, kernel_ms = time_pipeline(pipe, torch, lib, _lib, stream, reps=5, extra=etm)
+    st = _lib.stats()
+    E = len(qft.dt)*W*A*qft.d**2
+    U = result['U']
+    return dict(
+        config=5, workload='examples/qft.py 4-qubit QFT: d=16, 13 segments, 18 noise ops, GGM basis, '
+                           '16384 omega; control matrix + F + infidelity -> decay amplitudes -> '
+                           'cumulant function -> exp (error transfer matrix returned to the host)',
+        ms=ms, elements_per_s=E/(ms*1e-3), dominant_kernel='ffk::ctrl_accumulate_mfma4 (d = 16)',
+        kernel_ms=kernel_ms, executed_flops=st['accumulate_flops'],
+        tflops=st['accumulate_flops']/(kernel_ms*1e-3)/1e12,
+        frac=st['accumulate_flops']/(kernel_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+        entanglement_infidelity=float(1 - np.trace(U)/qft.d**2),
+        geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')})
+
+
+def bench_config3(ff):
+    """examples/randomized_benchmarking.py: 1000 Clifford gates drawn from 24, 8192 omega, filter
+    function by the concatenation rule (whole Python call, host arrays in and out)."""
+    from filter_functions_amd import numeric, util
+    cfg = wl.CONFIG3
+    omega = wl.rb_omega(cfg['W'], cfg['T'])
+    _, cliffords = wl.rb_cliffords(ff, omega, cfg['T'])
+    draw = wl.rb_draw(cfg['n_gates'], cfg['seed'])
+    seq = [cliffords[k] for k in draw]
+    times = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        total = ff.concatenate(seq)
+        total.get_filter_function(omega)
+        times.append(time.perf_counter() - t0)
+    table = np.array([c.get_control_matrix(omega) for c in cliffords])
+    phases = np.array([c.get_total_phases(omega) for c in cliffords])
+    L = util.adot(np.array([p.total_propagator_liouville for p in seq[:-1]]))
+    rule = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        numeric.calculate_control_matrix_from_atomic_indexed(phases, table, draw.astype(np.int32), L)
+        rule.append(time.perf_counter() - t0)
+    E = cfg['n_gates']*cfg['W']*1*4
+    # HBM model of the rule: the 24 control-matrix tables stay cache resident, R is written once
+    return dict(
+        config=3, workload='1000-gate randomized-benchmarking sequence (24 Cliffords from X/2, Y/2), '
+                           'd=2, 1 noise op, 8192 omega, ff.concatenate + get_filter_function on host '
+                           'arrays',
+        ms=min(times)*1e3, elements_per_s=E/min(times),
+        dominant_kernel='ffk::from_atomic_kernel (gather-from-table concatenation rule)',
+        rule_call_ms=min(rule)*1e3,
+        note='ms = whole Python call incl. host bookkeeping over 1000 pulse objects; rule_call_ms = '
+             'the indexed concatenation rule alone (tables H2D + kernel + R D2H)')
+
+
+def bench_api_call(ff, c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum, reps=30):
+    """perf_counter around the user-facing call on host arrays: a fresh PulseSequence each time
+    (nothing cached), pulse.get_filter_function(omega) then ff.infidelity(pulse, S, omega)."""
+    H_c, H_n = list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs))
+    t_ff, t_inf = [], []
+    for i in range(reps + 3):
+        pulse = ff.PulseSequence(H_c, H_n, dt, basis)
+        t0 = time.perf_counter()
+        pulse.get_filter_function(omega)
+        t1 = time.perf_counter()
+        infid = ff.infidelity(pulse, spectrum, omega)
+        t2 = time.perf_counter()
+        if i >= 3:
+            t_ff.append(t1 - t0)
+            t_inf.append(t2 - t1)
+    total = np.array(t_ff) + np.array(t_inf)
+    return dict(api_call_ms=float(np.median(total)*1e3), api_call_ms_min=float(total.min()*1e3),
+                get_filter_function_ms=float(np.median(t_ff)*1e3),
+                infidelity_ms=float(np.median(t_inf)*1e3)), infid
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # Defaults long enough to measure sustained throughput: after an idle period the accumulate
-    # kernel runs 95 us and settles at 81.6 us only ~300 steps (35 ms) later, as the clocks ramp
-    # (profiles/r01_q_clock_ramp.txt); 2500 steps are 0.3 s of GPU time.
     ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--omega-per-gpu', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--pipeline-depth', type=int, default=8,
                     help='N > 1: buffer sets in flight (the all-gather of step i may complete while '
                          'steps i+1 .. i+depth-1 compute)')
-    ap.add_argument('--event-stride', type=int, default=8,
-                    help='time the accumulate kernel with HIP events on the last steps/n steps')
+    ap.add_argument('--event-steps', type=int, default=0,
+                    help='time the accumulate kernel with HIP events on the last n timed steps '
+                         '(default: max(5, steps/8))')
     ap.add_argument('--no-pmc', action='store_true',
                     help='skip the rocprofv3 --pmc child runs that measure the HBM traffic')
+    ap.add_argument('--no-configs', action='store_true', help='headline only (no configs 3-5)')
+    ap.add_argument('--no-prewarm', action='store_true')
+    ap.add_argument('--prewarm-max-s', type=float, default=1.0)
+    ap.add_argument('--child', action='store_true',
+                    help='profiler child run: headline loop only, no baseline / PMC / configs')
     args = ap.parse_args()
+    if args.child:
+        args.no_cpu_baseline = args.no_pmc = args.no_configs = True
 
     import torch
     import torch.distributed as dist
@@ -176,11 +403,12 @@ def main():
     if use_dist:
         dist.init_process_group('nccl', device_id=device)
 
-    d, G, A = 4, 256, 3
-    c_opers, c_coeffs, n_opers, n_coeffs, dt = config2(d=d, G=G, A=A)
+    cfg = wl.CONFIG2
+    d, G, A = cfg['d'], cfg['G'], cfg['A']
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
     basis = ff.Basis.pauli(2)
     W_total = args.omega_per_gpu*world
-    omega_full = np.geomspace(1e-2/dt.sum(), 1e2/dt.min(), W_total)
+    omega_full = wl.random_pulse_omega(dt, W_total)
     spectrum_full = 1e-3/omega_full
     w0, w1 = shard_bounds(W_total, world, rank)
     omega = omega_full[w0:w1]
@@ -200,86 +428,44 @@ def main():
     pipes = [make_pipe() for _ in range(depth)] if use_dist else [make_pipe()]
     pipe = pipes[0]
     if use_dist:
-        omega_full_dev = torch.from_numpy(omega_full).to(device)
-        S_full_dev = torch.from_numpy(spectrum_full.astype(complex)).to(device)
-        idx_dev = torch.arange(A, dtype=torch.int32, device=device)
-        comm_stream = torch.cuda.Stream(device=device)
-        free_events = [None]*depth
-        # all-gather buffers (world, A, A, W_shard) and results, allocated once
-        gathered = [torch.empty((world, A, A, w1 - w0), dtype=torch.complex128, device=device)
-                    for _ in range(depth)]
-        infid_out = [torch.empty(A, dtype=torch.float64, device=device) for _ in range(depth)]
-        equal_shards = all(shard_bounds(W_total, world, r)[1] - shard_bounds(W_total, world, r)[0]
-                           == w1 - w0 for r in range(world))
-
-    if use_dist and not os.environ.get('FFK_BENCH_DEFAULT_STREAM'):
+        from filter_functions_amd.parallel import ShardedStepRing
         # Two explicitly created streams: HIP spreads created streams over the hardware queues,
         # whereas torch's default stream and one side stream shared a queue on this system (every
         # kernel of the trace on one queue, in submission order: nothing overlapped).
         compute_stream = torch.cuda.Stream(device=device)
         comm_stream = torch.cuda.Stream(device=device)
         torch.cuda.synchronize(device)
+        ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_stream,
+                               comm_stream, world, rank)
     else:
         compute_stream = torch.cuda.current_stream(device)
     stream = compute_stream.cuda_stream
-    # HIP events around the accumulate kernel on the last steps/`stride` steps of the timed region
-    # (at least 25): each timed event record costs several us of barrier-packet handling on this
-    # stack (kernel trace: the only two gaps of a step were the ones around the instrumented
-    # launch), so instrumenting every step taxed the measured throughput by 3-4 %.  A contiguous
-    # block, not every n-th step: an isolated event pair in an otherwise gap-free stream reads
-    # ~3.5 us longer than the kernel (91.2 against rocprofv3's 87.6 us), back-to-back pairs ~1 us;
-    # and the last steps, not the first: right after the barrier the queue is still shallow and the
-    # clocks are ramping (first 25 steps: 96-97 us).
-    stride = max(1, args.event_stride)
-    n_ev = min(args.steps, max(25, (args.steps + stride - 1)//stride))
-    ev = [[ctypes.c_void_p(), ctypes.c_void_p()] for _ in range(n_ev)]
-    for pair in ev:
-        for e in pair:
-            _lib.check(lib.ffk_event_create(ctypes.byref(e)))
-    counter = [0]
+    # HIP events around the accumulate kernel on the LAST n_ev steps of the timed region: each
+    # timed event record costs several us of barrier-packet handling on this stack, so only a
+    # contiguous tail is instrumented (an isolated pair in a gap-free stream reads ~3.5 us long,
+    # back-to-back pairs ~1 us), and the tail rather than the head because right after the
+    # barrier the queue is still shallow.
+    n_ev = args.event_steps or max(5, args.steps//8)
+    n_ev = max(1, min(args.steps, n_ev))
+    timer = AccumulateTimer(lib, _lib, n_ev)
 
     def step(i=None):
-        if i is not None:
-            j = i - (args.steps - n_ev)
-            if j >= 0:
-                _lib.check(lib.ffk_set_accumulate_events(ev[j][0], ev[j][1]))
+        if i is not None and i >= args.steps - n_ev:
+            timer.arm(i - (args.steps - n_ev))
         if not use_dist:
             pipe.launch(stream=stream, with_infidelity=True)
             return pipe.infid
-        k = counter[0] % depth
-        counter[0] += 1
-        p = pipes[k]
-        # Buffer set k was last read by the gather of step c - depth.  The comm stream is in order,
-        # so it is enough that the compute stream waits, every depth/2 steps, for the comm work of
-        # depth/2 steps ago: for every step j of the following half-window, gather(j - depth) is
-        # older than that.  (A wait per step costs ~4 us of barrier-packet handling each.)
-        c = counter[0] - 1
-        half = depth//2
-        if c >= half and c % half == 0:
-            compute_stream.wait_event(free_events[(c - half) % depth])
-        p.launch(stream=stream, with_infidelity=False)
-        ready = torch.cuda.Event()
-        ready.record(compute_stream)
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ready)
-            if equal_shards:
-                # one collective into a preallocated buffer; the integral reads the shards in place
-                dist.all_gather_into_tensor(torch.view_as_real(gathered[k]),
-                                            torch.view_as_real(p.filter_function))
-                out = p.infidelity_from_shards(gathered[k], omega_full_dev, S_full_dev, idx_dev,
-                                               infid_out[k], stream=comm_stream.cuda_stream)
-            else:
-                F_full = gather_omega_shards(p.filter_function, W_total)
-                out = p.infidelity_from(F_full, omega_full_dev, S_full_dev, idx_dev,
-                                        stream=comm_stream.cuda_stream)
-            done = torch.cuda.Event()
-            done.record(comm_stream)
-            free_events[k] = done
-        return out
+        return ring.step()
 
+    def sync():
+        torch.cuda.synchronize(device)
+
+    prewarm = None
+    if not args.no_prewarm:
+        prewarm = prewarm_clocks(step, sync, timer, args.prewarm_max_s, adaptive=not use_dist)
     for _ in range(args.warmup):
         step()
-    _lib.check(lib.ffk_set_accumulate_events(None, None))
+    timer.disarm()
     torch.cuda.synchronize(device)
     if use_dist:
         dist.barrier()
@@ -293,29 +479,36 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
-    _lib.check(lib.ffk_set_accumulate_events(None, None))
+    timer.disarm()
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
+    pipe.check_status()                          # eigensolver flags of the device-resident run
 
     # dominant kernel: ctrl_accumulate, timed by HIP events on its own stream inside the region
-    ms = ctypes.c_float()
-    acc_ms = []
-    for a, b in ev:
-        _lib.check(lib.ffk_event_elapsed_ms(a, b, ctypes.byref(ms)))
-        acc_ms.append(ms.value)
-    acc_ms = float(np.mean(acc_ms))
+    acc_ms = float(np.mean(timer.read_ms()))
     stats = _lib.stats()
-    for pair in ev:
-        for e in pair:
-            lib.ffk_event_destroy(e)
+    timer.close()
+
+    # the other BASELINE configurations (every rank takes part in the strong-scaled config 4)
+    configs = []
+    if not args.no_configs:
+        if use_dist:
+            configs.append(bench_config4_strong(ff, torch, dist, lib, _lib, DevicePipeline, device,
+                                                compute_stream, comm_stream, world, rank,
+                                                args.pipeline_depth))
+        elif rank == 0:
+            configs.append(bench_config3(ff))
+            configs.append(bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream)[1])
+            configs.append(bench_config5(ff, torch, lib, _lib, DevicePipeline, device, stream))
 
     if rank == 0:
         E_step = G*W_total*A*d*d
         value = E_step*args.steps/elapsed
         achieved = stats['accumulate_flops']/(acc_ms*1e-3)/1e12
+        step_tflops = stats['accumulate_flops']*args.steps/elapsed/1e12
         # HBM traffic of the same kernel, per launch: measured live by two short child runs of this
         # script under rocprofv3 --pmc (2*FETCH_SIZE + WRITE_SIZE as the MI355X guide prescribes for
         # gfx950); if the profiler is unavailable, the committed measurement of the same command
@@ -327,8 +520,7 @@ def main():
                 traffic_src = f'PMC run failed ({traffic_src}); '
         if traffic is None:
             try:
-                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                                       'k3_hbm_traffic.json')) as fh:
+                with open(os.path.join(ROOT, 'profiles', 'k3_hbm_traffic.json')) as fh:
                     prof = json.load(fh)
                 if prof['geometry'] == [stats[k] for k in ('grid_x', 'grid_y', 'grid_z', 'block')]:
                     traffic = prof['traffic_bytes']
@@ -346,16 +538,20 @@ def main():
                                    f'({W_total} total), seed 42; one step = diagonalize + control '
                                    'matrix + filter function + infidelity, HBM-resident',
                        'sharding': 'omega blocks, RCCL all-gather of F' if use_dist else 'none'},
+            'prewarm': prewarm,
             'roofline': {
-                'kernel': 'ffk::ctrl_accumulate_pc_kernel<4,3>', 'bound': 'mfma',
+                'kernel': 'ffk::ctrl_accumulate_pc_kernel<4,3>', 'bound': 'fp64_valu',
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved/FP64_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_src,
+                'frac': achieved/FP64_PEAK_TFLOPS, 'frac_step': step_tflops/FP64_PEAK_TFLOPS,
+                'traffic': traffic, 'traffic_source': traffic_src,
                 'avg_launch_ms': acc_ms, 'launches_timed': n_ev,
                 'flops_per_launch': stats['accumulate_flops'],
-                'note': 'FP64 compute bound (vector = matrix peak 78.6 TFLOP/s on MI355X); '
-                        'flops = FMA-counted flops of the Hilbert-space algorithm actually run; '
-                        'a pure v_fma_f64 stream on pseudo-random operands sustains 55 TFLOP/s on '
-                        'this part (tools/fp64_data_probe.hip, profiles/r01_k_*)',
+                'note': 'FP64 vector-FMA issue bound (the kernel issues v_fma_f64 only; vector = '
+                        'matrix FP64 peak 78.6 TFLOP/s on MI355X); flops = FMA-counted flops of the '
+                        'Hilbert-space algorithm actually run; frac = dominant kernel, frac_step = '
+                        'the same flops over the whole step time; a pure v_fma_f64 stream on '
+                        'pseudo-random operands sustains 55 TFLOP/s on this part '
+                        '(tools/fp64_data_probe.hip, profiles/r01_k_*)',
             },
             'roofline_hbm': {
                 'bound': 'hbm', 'achieved': stats['accumulate_bytes']/(acc_ms*1e-3)/1e9,
@@ -371,6 +567,12 @@ def main():
             'host_enqueue_ms_per_step': t_issue/args.steps*1e3,
             'device': _lib.device_info()[0],
         }
+        if configs:
+            out['configs'] = configs
+        if world == 1 and not args.child:
+            api, infid_api = bench_api_call(ff, c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega,
+                                            spectrum_full)
+            out.update(api)
         if world == 1 and not args.no_cpu_baseline:
             base, (R_ref, F_ref, infid_ref) = cpu_baseline(
                 pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, np.asarray(basis),
@@ -383,11 +585,53 @@ def main():
                 'filter_function_max_rel_err': float(np.abs(F_gpu - F_ref).max()/np.abs(F_ref).max()),
                 'infidelity_max_rel_err': float(np.abs(infid.cpu().numpy() - infid_ref).max()
                                                 / np.abs(infid_ref).max()),
+                'api_infidelity_max_rel_err': float(np.abs(infid_api - infid_ref).max()
+                                                    / np.abs(infid_ref).max()),
                 'against': 'oracle (NumPy restatement of the reference), same inputs',
             }
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def bench_config4_strong(ff, torch, dist, lib, _lib, DevicePipeline, device, compute_stream,
+                         comm_stream, world, rank, depth):
+    """Config 4 as BASELINE states it: the 65536-omega grid split over the ranks (strong scaling),
+    RCCL all-gather of F (9 x 9 x 65536/N c128 per rank), infidelity over the full grid."""
+    from filter_functions_amd.parallel import ShardedStepRing, shard_bounds
+    cfg = wl.CONFIG4
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
+    W = cfg['W']
+    omega_full = wl.random_pulse_omega(dt, W)
+    S_full = 1e-3/omega_full
+    w0, w1 = shard_bounds(W, world, rank)
+    basis = ff.Basis.pauli(3)
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
+    depth = 2
+    pipes = [DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, basis,
+                            omega_full[w0:w1], spectrum=S_full[w0:w1], device=device)
+             for _ in range(depth)]
+    ring = ShardedStepRing(pipes, W, omega_full, S_full, compute_stream, comm_stream, world, rank)
+    reps = 6
+    for _ in range(2):
+        ring.step()
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ring.step()
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    torch.cuda.synchronize(device)
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item())/reps*1e3
+    E = cfg['G']*W*cfg['A']*cfg['d']**2
+    return dict(config=4, scaling='strong', n_gpus=world,
+                workload=f'd=8, 512 segments, 9 noise ops, 65536 omega split over {world} ranks '
+                         f'({w1 - w0} per rank), RCCL all-gather of F, infidelity over the full grid',
+                ms=ms, elements_per_s=E/(ms*1e-3))
 
 
 if __name__ == '__main__':

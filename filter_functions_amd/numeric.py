@@ -691,7 +691,7 @@ def error_transfer_matrix(pulse=None, spectrum=None, omega=None, n_oper_identifi
     from scipy import linalg as sla
 
     if cumulant_function is None:
-        if None in (pulse, spectrum) or omega is None:
+        if any(arg is None for arg in (pulse, spectrum, omega)):
             raise ValueError('Require either precomputed cumulant function '
                              'or pulse, spectrum, and omega as arguments.')
         cumulant_function = calculate_cumulant_function(

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 __all__ = ['shard_bounds', 'gather_omega_shards', 'sharded_filter_function', 'sum_omega_shards',
-           'sharded_error_transfer_matrix']
+           'sharded_error_transfer_matrix', 'ShardedStepRing']
 
 
 def shard_bounds(n_omega, world_size, rank):
@@ -129,3 +129,106 @@ def sharded_error_transfer_matrix(pipe, omega_global, w_offset, single_qubit=Fal
     U = numeric.error_transfer_matrix(
         cumulant_function=K.sum(dim=tuple(range(K.dim() - 2))).cpu().numpy()[None])
     return gamma, K, U
+
+
+class _CudaStreams:
+    """Stream plumbing of :class:`ShardedStepRing` on PyTorch-ROCm streams and events."""
+
+    def __init__(self, compute, comm):
+        import torch
+        self.torch, self.compute, self.comm = torch, compute, comm
+
+    def record(self, stream):
+        event = self.torch.cuda.Event()
+        event.record(stream)
+        return event
+
+    def wait(self, stream, event):
+        stream.wait_event(event)
+
+    def on(self, stream):
+        return self.torch.cuda.stream(stream)
+
+    def handle(self, stream):
+        return stream.cuda_stream
+
+
+class ShardedStepRing:
+    """The frequency-sharded step of ``bench.py --gpus N`` and of any driver that evaluates many
+    independent pulses: rank r computes F on its omega block, one all-gather reassembles F(omega)
+    on every rank, the infidelity is integrated over the full grid.
+
+    The collective and the integral of step i run on a communication stream while the following
+    steps compute: *pipes* is a ring of ``depth`` buffer sets (one ``DevicePipeline`` each, same
+    pulse and omega block) used round robin.  Buffer set k is read by the gather of step c and
+    written again by step c + depth; the communication stream is in order, so it is enough that
+    the compute stream waits -- every depth/2 steps, a wait costs ~4 us of barrier-packet handling
+    -- for the communication work of depth/2 steps ago: for every step j of the following
+    half-window, gather(j - depth) is older than that.
+
+    *streams* abstracts record/wait/handle (default: PyTorch-ROCm streams); the CPU/gloo tests
+    inject a recording fake to check exactly this ordering logic.
+    """
+
+    def __init__(self, pipes, n_omega, omega_full, spectrum_full, compute_stream, comm_stream,
+                 world, rank, group=None, streams=None):
+        import torch
+        self.torch = torch
+        self.pipes = list(pipes)
+        self.depth = len(self.pipes)
+        if self.depth < 2 or self.depth % 2:
+            raise ValueError('the ring needs an even number (>= 2) of buffer sets')
+        self.world, self.rank, self.group, self.n_omega = world, rank, group, n_omega
+        self.compute_stream, self.comm_stream = compute_stream, comm_stream
+        self.streams = streams if streams is not None else _CudaStreams(compute_stream, comm_stream)
+        first = self.pipes[0]
+        device, A = first.filter_function.device, first.A
+        w0, w1 = shard_bounds(n_omega, world, rank)
+        self.width = w1 - w0
+        self.equal_shards = all(
+            shard_bounds(n_omega, world, r)[1] - shard_bounds(n_omega, world, r)[0] == self.width
+            for r in range(world))
+        self.omega_full = torch.as_tensor(np.ascontiguousarray(omega_full, dtype=float)).to(device)
+        self.spectrum_full = torch.as_tensor(
+            np.ascontiguousarray(spectrum_full, dtype=complex)).to(device)
+        self.idx = torch.arange(A, dtype=torch.int32, device=device)
+        n_out = (A, A) if self.spectrum_full.dim() == 3 else (A,)
+        self.gathered = [torch.empty((world, A, A, self.width), dtype=torch.complex128, device=device)
+                         for _ in range(self.depth)]
+        self.infid = [torch.empty(n_out, dtype=torch.float64, device=device)
+                      for _ in range(self.depth)]
+        self.free_events = [None]*self.depth
+        self.count = 0
+
+    def step(self):
+        """Enqueue one sharded step; returns the tensor that will hold its infidelities (valid
+        once the communication stream has passed the step)."""
+        import torch.distributed as dist
+        st = self.streams
+        c = self.count
+        self.count += 1
+        k = c % self.depth
+        pipe = self.pipes[k]
+        half = self.depth//2
+        if c >= half and c % half == 0:
+            st.wait(self.compute_stream, self.free_events[(c - half) % self.depth])
+        pipe.launch(stream=st.handle(self.compute_stream), with_infidelity=False)
+        ready = st.record(self.compute_stream)
+        with st.on(self.comm_stream):
+            st.wait(self.comm_stream, ready)
+            if self.equal_shards:
+                # one collective into a preallocated buffer; the integral reads the shards in place
+                send, recv = pipe.filter_function, self.gathered[k]
+                if dist.get_backend(self.group) == 'gloo':         # gloo has no flat all-gather
+                    dist.all_gather(list(recv.unbind(0)), send, group=self.group)
+                else:
+                    dist.all_gather_into_tensor(self.torch.view_as_real(recv),
+                                                self.torch.view_as_real(send), group=self.group)
+                out = pipe.infidelity_from_shards(recv, self.omega_full, self.spectrum_full, self.idx,
+                                                  self.infid[k], stream=st.handle(self.comm_stream))
+            else:
+                full = gather_omega_shards(pipe.filter_function, self.n_omega, group=self.group)
+                out = pipe.infidelity_from(full, self.omega_full, self.spectrum_full, self.idx,
+                                           stream=st.handle(self.comm_stream))
+            self.free_events[k] = st.record(self.comm_stream)
+        return out

@@ -123,3 +123,124 @@ def test_shard_bounds_partition():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_bounds(10, 2, 2)
+
+
+# ---- the buffer ring of the sharded step (bench.py --gpus N) on CPU / gloo --------------------------
+class _RecordingStreams:
+    """Stands in for the two HIP streams: work executes at issue time (CPU), while the object logs
+    what each stream has waited for, so that the buffer-reuse rule of ShardedStepRing can be
+    checked: before step c overwrites buffer set c % depth, the compute stream must have waited
+    for the communication work of step c - depth."""
+
+    def __init__(self, depth):
+        self.depth = depth
+        self.position = {'compute': 0, 'comm': 0}      # ops recorded so far per stream
+        self.waited = {'compute': {}, 'comm': {}}      # stream -> {other stream: position}
+        self.done_position = []                         # comm position after gather + integral of step i
+        self.launches = 0
+        self.waits_on_compute = 0
+
+    def record(self, stream):
+        self.position[stream] += 1
+        if stream == 'comm':
+            self.done_position.append(self.position[stream])
+        return (stream, self.position[stream])
+
+    def wait(self, stream, event):
+        other, pos = event
+        self.waited[stream][other] = max(self.waited[stream].get(other, 0), pos)
+        if stream == 'compute':
+            self.waits_on_compute += 1
+
+    def on(self, stream):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def handle(self, stream):
+        return stream
+
+    def check_launch(self):
+        c = self.launches
+        self.launches += 1
+        if c >= self.depth:
+            assert self.waited['compute'].get('comm', 0) >= self.done_position[c - self.depth], \
+                f'step {c} reuses buffer set {c % self.depth} before the gather of step {c - self.depth}'
+
+
+class _FakePipe:
+    """DevicePipeline stand-in on CPU tensors: F[a, b, w] = (1 + a + 2 b + i a b) omega_w (step + 1)."""
+
+    def __init__(self, omega_block, A, d, streams, step_counter):
+        self.A, self.d = A, d
+        self.omega_block = torch.from_numpy(omega_block)
+        self.filter_function = torch.zeros((A, A, len(omega_block)), dtype=torch.complex128)
+        self.streams, self.step_counter = streams, step_counter
+
+    @staticmethod
+    def model(omega, A, step):
+        a = torch.arange(A, dtype=torch.float64)
+        coeff = (1 + a[:, None] + 2*a[None, :]) + 1j*(a[:, None]*a[None, :])
+        return coeff[:, :, None]*omega[None, None, :]*(step + 1)
+
+    def launch(self, stream, with_infidelity):
+        assert stream == 'compute' and not with_infidelity
+        self.streams.check_launch()
+        self.filter_function.copy_(self.model(self.omega_block, self.A, self.step_counter[0]))
+        self.step_counter[0] += 1
+
+    @staticmethod
+    def integrate(F, omega, S, d):
+        f = (F.diagonal(dim1=0, dim2=1).T*S).real            # (A, W)
+        return torch.trapezoid(f, omega, dim=-1)/(2*np.pi*d)
+
+    def infidelity_from_shards(self, shards, omega, S, idx, out, stream):
+        assert stream == 'comm'
+        world, A, _, width = shards.shape
+        F = shards.permute(1, 2, 0, 3).reshape(A, A, world*width)
+        out.copy_(self.integrate(F, omega, S, self.d))
+        return out
+
+    def infidelity_from(self, F_full, omega, S, idx, stream):
+        assert stream == 'comm'
+        return self.integrate(F_full, omega, S, self.d)
+
+
+def _ring_worker(rank, world, port, n_omega, depth, n_steps, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+
+    from filter_functions_amd.parallel import ShardedStepRing, shard_bounds
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    A, d = 3, 4
+    omega = np.geomspace(0.1, 50.0, n_omega)
+    S = 1e-3/omega
+    w0, w1 = shard_bounds(n_omega, world, rank)
+    streams = _RecordingStreams(depth)
+    counter = [0]
+    pipes = [_FakePipe(omega[w0:w1], A, d, streams, counter) for _ in range(depth)]
+    ring = ShardedStepRing(pipes, n_omega, omega, S, 'compute', 'comm', world, rank, streams=streams)
+    results = [ring.step().clone().numpy() for _ in range(n_steps)]
+    np.savez(os.path.join(out_dir, f'ring{rank}.npz'), results=np.array(results),
+             waits=streams.waits_on_compute)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_omega,depth', [(12, 4), (13, 4), (16, 2), (40, 8)])
+def test_sharded_step_ring(tmp_path, n_omega, depth):
+    """World size 2: every step's infidelities equal the unsharded integral, for equal and unequal
+    omega blocks, over more steps than buffer sets; buffer sets are never reused before the
+    communication work that reads them, and the compute stream waits only twice per ring."""
+    world, n_steps = 2, 3*depth + 1
+    mp.spawn(_ring_worker, args=(world, _free_port(), n_omega, depth, n_steps, str(tmp_path)),
+             nprocs=world, join=True)
+    omega = torch.from_numpy(np.geomspace(0.1, 50.0, n_omega))
+    S = 1e-3/omega
+    ref = np.array([_FakePipe.integrate(_FakePipe.model(omega, 3, step), omega, S, 4).numpy()
+                    for step in range(n_steps)])
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f'ring{rank}.npz'))
+        assert got['results'].shape == ref.shape
+        assert np.abs(got['results'] - ref).max() <= 1e-14*np.abs(ref).max()
+        assert int(got['waits']) == (n_steps - 1)//(depth//2)
