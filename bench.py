@@ -182,7 +182,7 @@ class AccumulateTimer:
 
 def prewarm_clocks(step, sync, timer, max_s, adaptive, batch=100):
     """Untimed: run `step` in batches until the accumulate kernel's HIP-event time (last step of a
-    batch) changes by less than 1 % between batches twice in a row and at least 0.1 s have
+    batch) changes by less than 1 % between batches twice in a row and at least 0.3 s have
     passed, or `max_s` seconds are over.  Not adaptive (N > 1: every rank must issue the same
     collectives): a fixed 3 batches."""
     t0 = time.perf_counter()
@@ -205,12 +205,12 @@ def prewarm_clocks(step, sync, timer, max_s, adaptive, batch=100):
             stable += 1
         else:
             stable = 0
-        if (stable >= 2 and elapsed >= 0.1) or elapsed >= max_s:
+        if (stable >= 2 and elapsed >= 0.3) or elapsed >= max_s:
             break
     return dict(steps=steps, seconds=time.perf_counter() - t0,
                 accumulate_ms_first_batch=trace[0], accumulate_ms_last_batch=trace[-1],
                 rule=('adaptive: batches of 100 steps until the accumulate kernel time is stable '
-                      f'within 1 % twice in a row (>= 0.1 s) or {max_s} s' if adaptive
+                      f'within 1 % twice in a row and 0.3 s have passed or {max_s} s' if adaptive
                       else 'fixed 300 steps (N > 1: ranks must issue identical collectives)'))
 
 

@@ -189,7 +189,8 @@ SIGNATURES = {
     'ffk_resident_control_matrix': (c_int, [c_void_p, c_void_p]),
     'ffk_resident_control_matrix_dev': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),
                                                 POINTER(c_void_p)]),
-    'ffk_resident_infidelity': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    'ffk_resident_infidelity': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                        c_void_p]),
     'ffk_set_segment_chunks': (c_int, [c_int]),
     'ffk_set_accumulate_variant': (c_int, [c_int]),
     'ffk_get_stats': (c_int, [POINTER(ffk_stats)]),

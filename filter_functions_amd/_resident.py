@@ -130,10 +130,11 @@ class ResidentResult:
         G, d, W, N, A = self.shape
         return 16*A*N*W
 
-    def infidelity(self, spectrum, idx):
+    def infidelity(self, spectrum, idx, d):
         """(1/2 pi d) int dw Re(S F) on the resident F; *spectrum* already validated
-        (``util.parse_spectrum``), *idx* the noise-operator indices."""
-        G, d, W, N, A = self.shape
+        (``util.parse_spectrum``), *idx* the noise-operator indices, *d* the pulse's (possibly
+        user-overridden) dimension."""
+        G, _, W, N, A = self.shape
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         real = not np.iscomplexobj(spectrum)
         S = as_f64(spectrum) if real else as_c128(spectrum)
@@ -143,5 +144,6 @@ class ResidentResult:
             out[...] = 0.0
             return out
         check(self._lib.ffk_resident_infidelity(self._handle, ptr(S), S.ndim, int(real),
-                                                idx.ctypes.data_as(ctypes.c_void_p), n_idx, ptr(out)))
+                                                idx.ctypes.data_as(ctypes.c_void_p), n_idx, int(d),
+                                                ptr(out)))
         return out

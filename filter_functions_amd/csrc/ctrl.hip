@@ -63,6 +63,16 @@ int g_mfma_policy = 0;            // 0: matrix-core kernel for d >= 12, 1: never
 #define FFK_ACCUM_WPE(D) ((D) <= 4 ? 3 : 2)
 #endif
 
+#ifndef FFK_PHASE_SKEW          /* 1: opposite phase order on the two halves of a block's waves: */
+#define FFK_PHASE_SKEW 0        /* measured SLOWER at d = 8 (9.5 -> 12.3 ms), profiles/r02_d8_*    */
+#endif
+#ifndef FFK_TCOL_SGPR           /* 1: the wave's columns of T_g through scalar loads (d >= 6):     */
+#define FFK_TCOL_SGPR 0         /* in this template the allocator answers with 752 spilled VGPRs;  */
+#endif                          /* the idea lives in ctrl_pcw.hip, written around it               */
+#ifndef FFK_SKEW_PRIO           /* issue priority of a wave while it generates (skewed build) */
+#define FFK_SKEW_PRIO 1
+#endif
+
 // every supported dimension; a tuning build may restrict the instantiations (-DFFK_ONLY_D=4)
 #ifdef FFK_ONLY_D
 #define FFK_ALL_D(X) X(FFK_ONLY_D)
@@ -185,7 +195,10 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
     // Phase A: this wave's share of e^{i w t_g} I^(g)[rows of stage][:] -> LDS, plus (stage 0)
     // the segment's operands T_g, Bbar_{alpha0..}^(g) and the table row of segment g + AHEAD -> LDS.
     cplx staged = {0.0, 0.0};   // this thread's share of the staging copy, in flight across phase B
-    auto phase_a = [&](int g, int stage, int buf, int row_slot, int trig_slot) {
+    // fetch: issue the staging loads; generate: compute this wave's integral entries (the two
+    // halves can be called apart, so that the loads are in flight across whatever runs between)
+    auto phase_a = [&](int g, int stage, int buf, int row_slot, int trig_slot, bool fetch = true,
+                       bool generate = true) {
         const double* st = tabs + row_slot*S;                // LDS
         cplx* tile = lds + static_cast<size_t>(buf)*buf_stride;
         // staging copies: issue the global loads first, park them after the integral is done
@@ -195,12 +208,13 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
         const int n_ops = (1 + n_alpha)*D*D;
         const int n_tab = (g + AHEAD < g1) ? S/2 : 0;
         const int e0 = tid;
-        if (stage == 0) {
+        if (stage == 0 && fetch) {
             if (e0 < n_ops)
                 staged = src_ops[e0 < D*D ? e0 : e0 + alpha0*D*D];
             else if (e0 < n_ops + n_tab)
                 staged = src_tab[e0 - n_ops];
         }
+        if (!generate) return;
         const double dtg = st[0];
         // e^{i w t_g}, and the half-angle of the diagonal entry, a = fl(w dt)/2: every
         // off-diagonal entry follows from (sin a, cos a) and the segment's precomputed
@@ -273,6 +287,24 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
         }
     };
 
+    // The wave's JB columns of T_g (the operand of Z = X T, the same for every row m of a segment)
+    // through SCALAR loads: D*JB wave-uniform complex numbers in SGPRs feed v_fma_f64 directly
+    // instead of D*JB broadcast ds_read_b128 per row.  At d = 8 (JB = 2) the LDS array is otherwise
+    // as busy as the FP64 pipe: 40 ds_read_b128 (4 LDS cycles each, 8 waves per CU) against 160
+    // v_fma_f64 (4 cycles each, 2 waves per SIMD) per row -- 1280 cycles both; with the columns in
+    // SGPRs 24 reads remain.  Loaded for segment g + 1 at the end of segment g (ctrl_pc.hip scheme).
+    constexpr bool TCOL = FFK_TCOL_SGPR && SHARE && D >= 6 && D*JB <= 16;
+    cplx Tcol[TCOL ? D : 1][TCOL ? JB : 1];
+    auto load_tcol = [&](int g) {
+        if constexpr (TCOL) {
+            const cplx* tg = ops + static_cast<size_t>(g)*(1 + A)*D*D + jb*JB;
+#pragma unroll
+            for (int n = 0; n < D; ++n)
+#pragma unroll
+                for (int j = 0; j < JB; ++j) Tcol[n][j] = tg[n*D + j];
+        }
+    };
+
     // Phase B, rows of one stage
     auto phase_b = [&](int g, int stage, int buf) {
         (void)g;
@@ -296,7 +328,12 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
 #pragma unroll
             for (int n = 0; n < D; ++n)
 #pragma unroll
-                for (int j = 0; j < JB; ++j) cmac(Z[j], opT[n*D + jb*JB + j], X[n]);
+                for (int j = 0; j < JB; ++j) {
+                    if constexpr (TCOL)
+                        cmac(Z[j], Tcol[n][j], X[n]);
+                    else
+                        cmac(Z[j], opT[n*D + jb*JB + j], X[n]);
+                }
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 const cplx t = opT[m*D + i];
@@ -326,7 +363,12 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
         __syncthreads();
         // every wave of the block runs sub_len iterations (barriers must match); a sub-chunk that
         // is shorter (last chunk) idles through the tail
+        if (active && g0 < g1) load_tcol(g0);
         const int trip = GS == 1 ? g1 - g0 : sub_len;
+#if FFK_PHASE_SKEW
+        // waves w and w + 4 of a block share a SIMD
+        const bool contract_first = NW*GS > 4 && ((wave_all >> 2) & 1) != 0;
+#endif
         int r0 = 0;   // it mod 3
         for (int it = 0; it < trip; ++it) {
             const int g = g0 + it;
@@ -340,6 +382,34 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
             continue;
 #endif
             if (g < g1) {
+#if FFK_PHASE_SKEW
+                // Half of the waves generate first and contract afterwards, the other half the
+                // other way round: the latency-bound generation of one wave then overlaps the
+                // FMA-bound contraction of its SIMD neighbour instead of all waves of the block
+                // sitting in the same phase at the same time.  (Generation writes tile buf ^ 1,
+                // contraction reads tile buf: any order is valid within the barrier interval.)
+                // One copy of each phase in the instruction stream; the two half-steps run them in
+                // the order of this wave's parity.  The generating wave runs at raised issue priority:
+                // its dependent chains (argument reduction -> polynomial -> reciprocal) otherwise lose
+                // every arbitration against the neighbour's independent FMAs (cf. ctrl_pc.hip).
+                if (g + 1 < g1) phase_a(g + 1, 0, buf ^ 1, r1, buf ^ 1, true, false);
+#pragma nounroll
+                for (int half = 0; half < 2; ++half) {
+                    if ((half == 0) != contract_first) {
+                        if (g + 1 < g1) {
+                            __builtin_amdgcn_s_setprio(FFK_SKEW_PRIO);
+                            phase_a(g + 1, 0, buf ^ 1, r1, buf ^ 1, false, true);
+                            if (g + 2 < g1) share_trig(r2, buf);
+                            __builtin_amdgcn_s_setprio(0);
+                        }
+                    } else {
+#if !(defined(FFK_ABLATE) && FFK_ABLATE == 3)
+                        if (active) phase_b(g, 0, buf);
+#endif
+                    }
+                }
+                if (g + 1 < g1) park(g + 1, buf ^ 1, r0);
+#else
                 if (g + 1 < g1) {
                     phase_a(g + 1, 0, buf ^ 1, r1, buf ^ 1);
                     if (g + 2 < g1) share_trig(r2, buf);
@@ -347,7 +417,9 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
 #if !(defined(FFK_ABLATE) && FFK_ABLATE == 3)  /* diagnostic build 3: no contraction */
                 if (active) phase_b(g, 0, buf);
 #endif
+                if (active && g + 1 < g1) load_tcol(g + 1);
                 if (g + 1 < g1) park(g + 1, buf ^ 1, r0);
+#endif
             }
 #if !(defined(FFK_ABLATE) && FFK_ABLATE == 6)  /* diagnostic build 6: no barrier (wrong results) */
             __syncthreads();
@@ -690,6 +762,7 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     AccumGeometry geo;
     geo.gsplit = 1;
     geo.pc = false;
+    geo.pcw = false;
     geo.mfma = mfma_accumulate_supported(d) && g_mfma_policy != 1 && (d >= 12 || g_mfma_policy == 2);
     // d = 4: the producer/consumer kernel (ctrl_pc.hip) is the default -- 3.4 % faster than the
     // symmetric kernel below at config 2 (101 vs 104.5 us on the same box) and free of register
@@ -719,6 +792,42 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
             for (int c = 1; c <= max_chunks; ++c) {
                 const long rounds = (tiles*c + capacity - 1)/capacity;
                 const double cost = static_cast<double>(rounds)*((G + ns*c - 1)/(ns*c) + 2);
+                if (c == 1 || cost < best*0.999) {
+                    best = cost;
+                    chunks = c;
+                }
+            }
+        }
+        chunks = std::max(1, std::min(chunks, G));
+        geo.chunk_len = (G + chunks - 1)/chunks;
+        geo.chunks = (G + geo.chunk_len - 1)/geo.chunk_len;
+        return geo;
+    }
+    // d = 8: producer/consumer kernel with column-split consumers (ctrl_pcw.hip); FFK_TUNE_PCW=0
+    // or the tuning variants 1/2 select the symmetric kernel below
+    static const bool use_pcw = [] {
+        const char* e = std::getenv("FFK_TUNE_PCW");
+        return e == nullptr || e[0] != '0';
+    }();
+    if (use_pcw && g_use_gsplit && !g_use_wave_kernel && pcw_accumulate_supported(d, A) && !geo.mfma) {
+        const int nc = pcw_accumulate_ops_per_block();
+        geo.pcw = true;
+        geo.wave_kernel = false;
+        geo.nwaves = pcw_accumulate_waves();
+        geo.task_groups = (A + nc - 1)/nc;
+        geo.na_blk = nc;
+        geo.nbuf = 2;
+        geo.lds_bytes = pcw_accumulate_lds_bytes();
+        const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups;
+        int chunks = forced_chunks;
+        if (chunks <= 0) {
+            const long capacity = device_cu_count();          // one 16-wave block per CU
+            const int max_chunks = std::max(1, std::min((G + 7)/8, 256));
+            double best = 0.0;
+            chunks = 1;
+            for (int c = 1; c <= max_chunks; ++c) {
+                const long rounds = (tiles*c + capacity - 1)/capacity;
+                const double cost = static_cast<double>(rounds)*((G + c - 1)/c + 2);
                 if (c == 1 || cost < best*0.999) {
                     best = cost;
                     chunks = c;
@@ -862,6 +971,9 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
     if (geo.pc)
         return launch_accumulate_pc(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
                                     geo.chunk_len, Ypart, stream);
+    if (geo.pcw)
+        return launch_accumulate_pcw(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
+                                     stream);
     if (geo.mfma)
         return launch_accumulate_mfma(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len,
                                       geo.nwaves, Ypart, stream);

@@ -2016,10 +2016,10 @@ int ffk_resident_control_matrix_dev(ffk_resident* r, const double** control_matr
 }
 
 int ffk_resident_infidelity(ffk_resident* r, const double* spectrum, int s_ndim, int spectrum_is_real,
-                            const int32_t* idx, int n_idx, double* infid) {
+                            const int32_t* idx, int n_idx, int d, double* infid) {
     FFK_REQUIRE(r && r->valid, "no resident result");
     FFK_REQUIRE(spectrum && idx && infid, "NULL argument");
-    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3 && n_idx >= 1 && n_idx <= r->A, "bad spectrum arguments");
+    FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3 && n_idx >= 1 && n_idx <= r->A && d >= 1, "bad spectrum arguments");
     const int W = r->W, A = r->A;
     const size_t rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? size_t(n_idx) : size_t(n_idx)*n_idx);
     const size_t n_out = s_ndim == 3 ? size_t(n_idx)*n_idx : size_t(n_idx);
@@ -2058,7 +2058,7 @@ int ffk_resident_infidelity(ffk_resident* r, const double* spectrum, int s_ndim,
             rc = ffk_infidelity_dev(reinterpret_cast<const double*>(dp + L.F), A, W,
                                     reinterpret_cast<const double*>(dp + L.S), s_ndim,
                                     reinterpret_cast<const double*>(dp + L.omega),
-                                    reinterpret_cast<const int32_t*>(dp + L.idx), n_idx, r->d,
+                                    reinterpret_cast<const int32_t*>(dp + L.idx), n_idx, d,
                                     reinterpret_cast<double*>(dp + L.infid), iws, iwsb, s);
         if (!rc) {
             hipError_t e = hipMemcpyAsync(infid, dp + L.infid, 8*n_out, hipMemcpyDeviceToHost, s);

@@ -494,7 +494,7 @@ class PulseSequence:
         resident = self._resident
         if resident is None or resident.filter_function is not filter_function:
             return None
-        return resident.infidelity(spectrum, idx)
+        return resident.infidelity(spectrum, idx, self.d)
 
     # ---- cached-data properties ----------------------------------------------------------
     def _diagonalization_product(name):  # noqa: N805  (evaluated while the class body runs)

@@ -432,7 +432,8 @@ int ffk_eigensolver_status_dev(const void* workspace, size_t workspace_bytes, in
  * caller asks for it (ffk_resident_control_matrix), which is what the reference's cache
  * (`pulse._frequency_data['control_matrix']`) needs it for.  ffk_resident_infidelity integrates
  * the resident F against a host spectrum ((W,), (n_idx, W) or (n_idx, n_idx, W); real f64 if
- * spectrum_is_real, else c128) on the resident frequency grid.  Returns FFK_ENOCONV like
+ * spectrum_is_real, else c128) on the resident frequency grid, normalised by 1/(2 pi d) with the
+ * caller's d (pulse.d, which a user may override: tests/test_precision.py:300).  Returns FFK_ENOCONV like
  * ffk_diagonalize.  Device and pinned blocks come from grow-only pools
  * (ffk_resident_release_pools frees what is idle).                                             */
 typedef struct ffk_resident ffk_resident;
@@ -449,7 +450,8 @@ int ffk_resident_control_matrix(ffk_resident* handle, double* control_matrix);
 int ffk_resident_control_matrix_dev(ffk_resident* handle, const double** control_matrix,
                                     const double** filter_function, const double** omega);
 int ffk_resident_infidelity(ffk_resident* handle, const double* spectrum, int s_ndim,
-                            int spectrum_is_real, const int32_t* idx, int n_idx, double* infid);
+                            int spectrum_is_real, const int32_t* idx, int n_idx, int d,
+                            double* infid);
 
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Number of segment chunks the control-matrix kernel splits G into (0 = automatic).        */
