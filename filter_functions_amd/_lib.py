@@ -186,6 +186,7 @@ SIGNATURES = {
                                              c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                              c_void_p, POINTER(c_void_p), POINTER(c_void_p),
                                              POINTER(c_void_p), POINTER(c_void_p)]),
+    'ffk_resident_timing': (c_int, [c_void_p, c_void_p]),
     'ffk_resident_control_matrix': (c_int, [c_void_p, c_void_p]),
     'ffk_resident_control_matrix_dev': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),
                                                 POINTER(c_void_p)]),

@@ -119,6 +119,13 @@ class ResidentResult:
         self.filter_function = F
         return D, V, Q, F
 
+    def timing(self):
+        """Host-clock seconds of the last pass: (packing inputs, enqueueing copies and kernels,
+        waiting for the stream)."""
+        out = np.zeros(3)
+        check(self._lib.ffk_resident_timing(self._handle, ptr(out)))
+        return tuple(out)
+
     def control_matrix(self):
         """The resident control matrix (n_nops, n_basis, n_omega), copied to the host now."""
         G, d, W, N, A = self.shape

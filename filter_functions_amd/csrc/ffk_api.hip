@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
@@ -1902,6 +1903,7 @@ ResidentLayout resident_layout(int G, int d, int W, int N, int A) {
 }  // namespace
 
 struct ffk_resident {
+    double t_stage = 0, t_enqueue = 0, t_wait = 0;   // seconds, last pass (host clock)
     int device = -1;
     int G = 0, d = 0, W = 0, N = 0, A = 0;
     bool valid = false;
@@ -1957,6 +1959,7 @@ int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, con
     unsigned char* hp = static_cast<unsigned char*>(r->pin.ptr);
     unsigned char* dp = static_cast<unsigned char*>(r->dev.ptr);
     const size_t dd = size_t(d)*d;
+    const auto clock0 = std::chrono::steady_clock::now();
     std::memcpy(hp + L.H, hamiltonian, 16*size_t(G)*dd);
     std::memcpy(hp + L.dt, dt, 8*size_t(G));
     std::memcpy(hp + L.t, t, 8*size_t(G + 1));
@@ -1971,6 +1974,7 @@ int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, con
     const size_t wsb = ffk_pipeline_workspace_bytes(W, N, A, G, d, 0, 0);
     void* ws;
     if (int rc = arena_reserve(wsb, &ws)) return rc;
+    const auto clock1 = std::chrono::steady_clock::now();
     FFK_HIP(hipMemcpyAsync(dp, hp, L.inputs_end, hipMemcpyHostToDevice, s));
     auto dptr = [dp](size_t off) { return reinterpret_cast<double*>(dp + off); };
     if (int rc = ffk_pipeline_dev(dptr(L.H), dptr(L.dt), dptr(L.t), G, d, dptr(L.omega), W,
@@ -1981,7 +1985,12 @@ int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, con
     if (int rc = ffk_eigensolver_status_dev(ws, wsb, G, d, reinterpret_cast<int32_t*>(dp + L.status), s))
         return rc;
     FFK_HIP(hipMemcpyAsync(hp + L.D, dp + L.D, L.outputs_end - L.D, hipMemcpyDeviceToHost, s));
+    const auto clock2 = std::chrono::steady_clock::now();
     FFK_HIP(hipStreamSynchronize(s));
+    const auto clock3 = std::chrono::steady_clock::now();
+    r->t_stage = std::chrono::duration<double>(clock1 - clock0).count();
+    r->t_enqueue = std::chrono::duration<double>(clock2 - clock1).count();
+    r->t_wait = std::chrono::duration<double>(clock3 - clock2).count();
     const int32_t failed = *reinterpret_cast<const int32_t*>(hp + L.status);
     if (failed != 0)
         return fail(FFK_ENOCONV, "Jacobi eigensolver did not converge for %d segment(s)", int(failed));
@@ -1990,6 +1999,14 @@ int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, con
     *propagators = reinterpret_cast<double*>(hp + L.Q);
     *filter_function = reinterpret_cast<double*>(hp + L.F);
     r->valid = true;
+    return FFK_OK;
+}
+
+int ffk_resident_timing(ffk_resident* r, double* seconds) {
+    FFK_REQUIRE(r && seconds, "NULL argument");
+    seconds[0] = r->t_stage;
+    seconds[1] = r->t_enqueue;
+    seconds[2] = r->t_wait;
     return FFK_OK;
 }
 

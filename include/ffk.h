@@ -445,6 +445,9 @@ int ffk_resident_filter_function(ffk_resident* handle, const double* hamiltonian
                                  const double* basis, int N, const double* n_opers, int A,
                                  const double* n_coeffs, double** eigvals, double** eigvecs,
                                  double** propagators, double** filter_function);
+/* host-clock seconds of the last pass: [0] packing the inputs into the pinned block, [1] enqueueing
+ * the H2D copy, the kernels and the D2H copy, [2] waiting for the stream                         */
+int ffk_resident_timing(ffk_resident* handle, double* seconds);
 int ffk_resident_control_matrix(ffk_resident* handle, double* control_matrix);
 /* device pointers of the resident control matrix, filter function and frequencies (any may be NULL) */
 int ffk_resident_control_matrix_dev(ffk_resident* handle, const double** control_matrix,
