@@ -309,7 +309,11 @@ class PulseSequence:
 
     # ---- the hot path ----------------------------------------------------------------------
     def _hamiltonian(self):
-        return np.einsum('ijk,il->ljk', self.c_opers, self.c_coeffs)
+        """H[g] = sum_i a_i(t_g) A_i as one (n_dt x n_cops)(n_cops x d^2) matrix product (the
+        einsum formulation of the same sum costs 55 us at config 2, half the device pass)."""
+        opers = np.asarray(self.c_opers)          # (the user may override self.d: take the shape)
+        flat = np.asarray(self.c_coeffs).T @ opers.reshape(len(opers), -1)
+        return flat.reshape((-1,) + opers.shape[1:])
 
     def diagonalize(self):
         """Diagonalise the control Hamiltonian (reference pulse_sequence.py:577-586)."""
