@@ -370,6 +370,9 @@ def main():
     ap.add_argument('--no-pmc', action='store_true',
                     help='skip the rocprofv3 --pmc child runs that measure the HBM traffic')
     ap.add_argument('--no-configs', action='store_true', help='headline only (no configs 3-5)')
+    ap.add_argument('--streams', type=int, default=2,
+                    help='N = 1: independent passes in flight (round robin over this many HIP streams, '
+                         'one buffer set each); 1 = strictly one pass after the other')
     ap.add_argument('--no-prewarm', action='store_true')
     ap.add_argument('--prewarm-max-s', type=float, default=1.0)
     ap.add_argument('--child', action='store_true',
@@ -425,7 +428,8 @@ def main():
     # for it (0.163 ms/step on one rank), with more the collective falls into the window of the
     # small kernels between two accumulate launches.
     depth = max(2, args.pipeline_depth + (args.pipeline_depth & 1))      # even
-    pipes = [make_pipe() for _ in range(depth)] if use_dist else [make_pipe()]
+    n_streams = 1 if use_dist else max(1, args.streams)
+    pipes = [make_pipe() for _ in range(depth if use_dist else n_streams)]
     pipe = pipes[0]
     if use_dist:
         from filter_functions_amd.parallel import ShardedStepRing
@@ -437,6 +441,15 @@ def main():
         torch.cuda.synchronize(device)
         ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_stream,
                                comm_stream, world, rank)
+    elif n_streams > 1:
+        # Steps are independent passes (one pulse each): with two passes in flight on two HIP
+        # streams the five latency-bound launches of one pass (eigensolver, scan, prologue,
+        # expansion, integral: ~32 us on 256 wavefronts or fewer) run beside the accumulate kernel
+        # of the other, which leaves 20 KiB of LDS and half the wave slots of every CU free.
+        # Fusing those launches was tried and is slower (profiles/r02_a_fusion_attempts.md).
+        pass_streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
+        compute_stream = pass_streams[0]
+        torch.cuda.synchronize(device)
     else:
         compute_stream = torch.cuda.current_stream(device)
     stream = compute_stream.cuda_stream
@@ -449,13 +462,20 @@ def main():
     n_ev = max(1, min(args.steps, n_ev))
     timer = AccumulateTimer(lib, _lib, n_ev)
 
+    counter = [0]
+
     def step(i=None):
         if i is not None and i >= args.steps - n_ev:
             timer.arm(i - (args.steps - n_ev))
-        if not use_dist:
+        if use_dist:
+            return ring.step()
+        if n_streams == 1:
             pipe.launch(stream=stream, with_infidelity=True)
             return pipe.infid
-        return ring.step()
+        k = counter[0] % n_streams
+        counter[0] += 1
+        pipes[k].launch(stream=pass_streams[k].cuda_stream, with_infidelity=True)
+        return pipes[k].infid
 
     def sync():
         torch.cuda.synchronize(device)
@@ -486,6 +506,17 @@ def main():
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
     pipe.check_status()                          # eigensolver flags of the device-resident run
+    # latency of one pass on its own (one stream, nothing else in flight), for reference
+    latency_ms = None
+    if not use_dist:
+        one = torch.cuda.current_stream(device).cuda_stream if n_streams == 1 else pass_streams[0].cuda_stream
+        torch.cuda.synchronize(device)
+        reps = 200
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            pipe.launch(stream=one, with_infidelity=True)
+        torch.cuda.synchronize(device)
+        latency_ms = (time.perf_counter() - t1)/reps*1e3
 
     # dominant kernel: ctrl_accumulate, timed by HIP events on its own stream inside the region
     acc_ms = float(np.mean(timer.read_ms()))
@@ -537,7 +568,9 @@ def main():
                                    f'{A} noise ops, Pauli basis, {args.omega_per_gpu} omega per GPU '
                                    f'({W_total} total), seed 42; one step = diagonalize + control '
                                    'matrix + filter function + infidelity, HBM-resident',
-                       'sharding': 'omega blocks, RCCL all-gather of F' if use_dist else 'none'},
+                       'sharding': 'omega blocks, RCCL all-gather of F' if use_dist else 'none',
+                       'passes_in_flight': depth if use_dist else n_streams},
+            'single_stream_ms_per_step': latency_ms,
             'prewarm': prewarm,
             'roofline': {
                 'kernel': 'ffk::ctrl_accumulate_pc_kernel<4,3>', 'bound': 'fp64_valu',
