@@ -495,18 +495,20 @@ static int mfma_column_split(int d) {
     if (env < 0) return def;
     const bool ok = (d == 16 && (env == 0 || env == 2 || env == 4)) ||
                     (d == 12 && (env == 0 || env == 1 || env == 3)) ||
-                    (d == 8 && (env == 1 || env == 2));
+                    (d == 8 && (env == 1 || env == 2)) || (d == 4 && env == 1);
     return ok ? env : def;
 }
 
-bool mfma_accumulate_supported(int d) { return d == 8 || d == 12 || d == 16; }
+// d = 4 and d = 8 are served on request only (ffk_set_accumulate_variant(4)): the A/B against the
+// vector kernels (profiles/r02_c_*)
+bool mfma_accumulate_supported(int d) { return d == 4 || d == 8 || d == 12 || d == 16; }
 // waves (= noise operators) per block: 4 for the 16x16x4 kernel; for the 4x4x4 kernel (d = 8) the
 // count in 3..8 with the fewest idle wave slots (ties: the larger, which shares the generated
 // integral more widely)
 int mfma_accumulate_ops_per_block(int d, int A) {
     const int jh = mfma_column_split(d);
     if (jh == 0) return kMW;
-    if (d == 8 && jh == 1) {
+    if ((d == 8 || d == 4) && jh == 1) {
         // the count in 3..8 with the fewest idle wave slots (ties: the larger, which shares the
         // generated integral more widely)
         int best = 8, best_idle = 1 << 30;
@@ -529,6 +531,8 @@ int mfma_accumulate_waves(int d, int A) {
 int mfma_accumulate_lds_bytes(int d, int nw) {
     const int jh = mfma_column_split(d);
     switch (d) {
+        case 4:
+            return static_cast<int>(mfma4_lds_bytes<4, 1>(nw));
         case 8:
             if (jh == 2) return static_cast<int>(mfma4_lds_bytes<8, 2>(nw));
             return static_cast<int>(mfma4_lds_bytes<8, 1>(nw));
@@ -552,7 +556,7 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
 #define FFK_M4(D, JH) \
     if (d == D && jh == JH) \
         return launch_d4<D, JH>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);
-    FFK_M4(8, 1) FFK_M4(8, 2) FFK_M4(12, 1) FFK_M4(12, 3) FFK_M4(16, 1) FFK_M4(16, 2)
+    FFK_M4(4, 1) FFK_M4(8, 1) FFK_M4(8, 2) FFK_M4(12, 1) FFK_M4(12, 3) FFK_M4(16, 1) FFK_M4(16, 2)
 #undef FFK_M4
     if (d == 16 && jh == 4)
         return launch_d4<16, 4, 12>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);

@@ -729,7 +729,7 @@ def test_noise_operator_step_cache():
     assert rel_err(inter['noise_operators_step'].sum(axis=0), B) < 1e-13
 
 
-@pytest.mark.parametrize('d,G,A,W', [(8, 7, 3, 100), (12, 5, 5, 33), (16, 6, 2, 16), (16, 3, 9, 50),
+@pytest.mark.parametrize('d,G,A,W', [(4, 9, 3, 100), (4, 20, 5, 47), (8, 7, 3, 100), (12, 5, 5, 33), (16, 6, 2, 16), (16, 3, 9, 50),
                                       (8, 20, 1, 257)])
 def test_matrix_core_accumulate_kernel_matches_vector_kernel(d, G, A, W):
     """ctrl_mfma.hip (v_mfma_f64_16x16x4, frequency = tile column) against ctrl.hip on the same
