@@ -72,9 +72,14 @@ __global__ __launch_bounds__(64) void conjugate_basis_kernel(const cplx* __restr
     }
 }
 
-// One wavefront per 16x16 tile of L = Aop^T Bop.  v_mfma_f64_16x16x4_f64 operand maps
+// One wavefront per (16 TM) x (16 TN) tile of L = Aop^T Bop.  v_mfma_f64_16x16x4_f64 operand maps
 // (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
-// D[row = (lane>>4) + 4 r][col = lane&15] for result register r = 0..3.
+// D[row = (lane>>4) + 4 r][col = lane&15] for result register r = 0..3.  With one 16 x 16 tile per
+// wavefront every MFMA (2048 flops) waits for 1 KiB of operands from L2: 25.8 TFLOP/s, MFMA pipe
+// 34 % busy at d = 16 (profiles/r02_d_*).  TM x TN tiles per wavefront re-use each operand TN resp. TM
+// times from registers and keep TM*TN independent accumulators in flight (a dependent
+// v_mfma_f64_16x16x4 waits out the 16 passes of its predecessor).
+template <int TM, int TN>
 __global__ __launch_bounds__(64) void liouville_gemm_kernel(const double* __restrict__ AopRe,
                                                             const double* __restrict__ AopIm,
                                                             const double* __restrict__ Bop, int N,
@@ -83,30 +88,68 @@ __global__ __launch_bounds__(64) void liouville_gemm_kernel(const double* __rest
     const int lane = threadIdx.x;
     const int ti = blockIdx.x, tj = blockIdx.y, bt = blockIdx.z;
     const int l15 = lane & 15, lk = lane >> 4;
-    const double* are = AopRe + static_cast<size_t>(bt)*K*Npad + ti*16 + l15;
-    const double* aim = AopIm + static_cast<size_t>(bt)*K*Npad + ti*16 + l15;
-    const double* bop = Bop + tj*16 + l15;
-    f64x4 cre = {0.0, 0.0, 0.0, 0.0}, cim = {0.0, 0.0, 0.0, 0.0};
+    // tile columns beyond Npad (partial tile groups) are clamped: their results are not stored
+    const double* are[TM];
+    const double* aim[TM];
+    const double* bop[TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        const int col = min((ti*TM + m)*16 + l15, Npad - 1);
+        are[m] = AopRe + static_cast<size_t>(bt)*K*Npad + col;
+        aim[m] = AopIm + static_cast<size_t>(bt)*K*Npad + col;
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n) bop[n] = Bop + min((tj*TN + n)*16 + l15, Npad - 1);
+    f64x4 cre[TM][TN], cim[TM][TN];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            cre[m][n] = {0.0, 0.0, 0.0, 0.0};
+            cim[m][n] = {0.0, 0.0, 0.0, 0.0};
+        }
     for (int k0 = 0; k0 < K; k0 += 4) {
         const size_t row = static_cast<size_t>(k0 + lk)*Npad;
-        const double b = bop[row];
-        cre = __builtin_amdgcn_mfma_f64_16x16x4f64(are[row], b, cre, 0, 0, 0);
-        if (want_imag) cim = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[row], b, cim, 0, 0, 0);
-    }
-    const int col = tj*16 + l15;
-    if (col >= N) return;
+        double a[TM], ai[TM], b[TN];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int rowi = ti*16 + lk + 4*r;
-        if (rowi >= N) continue;
-        const size_t o = (static_cast<size_t>(bt)*N + rowi)*N + col;
+        for (int m = 0; m < TM; ++m) {
+            a[m] = are[m][row];
+            if (want_imag) ai[m] = aim[m][row];
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) b[n] = bop[n][row];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int n = 0; n < TN; ++n)
+                cre[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], cre[m][n], 0, 0, 0);
         if (want_imag) {
-            out[2*o] = cre[r];
-            out[2*o + 1] = cim[r];
-        } else {
-            out[o] = cre[r];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    cim[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[m], b[n], cim[m][n], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = (tj*TN + n)*16 + l15;
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rowi = (ti*TM + m)*16 + lk + 4*r;
+                if (rowi >= N) continue;
+                const size_t o = (static_cast<size_t>(bt)*N + rowi)*N + col;
+                if (want_imag) {
+                    out[2*o] = cre[m][n][r];
+                    out[2*o + 1] = cim[m][n][r];
+                } else {
+                    out[o] = cre[m][n][r];
+                }
+            }
+        }
 }
 
 }  // namespace
@@ -148,8 +191,20 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
         default:
             return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(liouville_gemm_kernel, dim3(Npad/16, Npad/16, batch), dim3(64), 0, stream,
-                       AopRe, AopIm, Bop, N, Npad, K, want_imag, out);
+    // tiles per wavefront by problem size: enough wavefronts to fill 1024 SIMDs first
+    const int tiles = Npad/16;
+    const long waves4 = static_cast<long>((tiles + 3)/4)*((tiles + 3)/4)*batch;
+    const long waves2 = static_cast<long>((tiles + 1)/2)*((tiles + 1)/2)*batch;
+    if (tiles >= 4 && waves4 >= 2048) {
+        hipLaunchKernelGGL((liouville_gemm_kernel<4, 4>), dim3((tiles + 3)/4, (tiles + 3)/4, batch),
+                           dim3(64), 0, stream, AopRe, AopIm, Bop, N, Npad, K, want_imag, out);
+    } else if (tiles >= 2 && waves2 >= 2048) {
+        hipLaunchKernelGGL((liouville_gemm_kernel<2, 2>), dim3((tiles + 1)/2, (tiles + 1)/2, batch),
+                           dim3(64), 0, stream, AopRe, AopIm, Bop, N, Npad, K, want_imag, out);
+    } else {
+        hipLaunchKernelGGL((liouville_gemm_kernel<1, 1>), dim3(tiles, tiles, batch), dim3(64), 0,
+                           stream, AopRe, AopIm, Bop, N, Npad, K, want_imag, out);
+    }
     return hipGetLastError();
 }
 

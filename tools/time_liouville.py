@@ -1,11 +1,77 @@
-import sys, time, numpy as np
-sys.path.insert(0, '.')
-import filter_functions_amd as ff
-rng = np.random.default_rng(0)
-for d, batch in ((2, 1), (2, 100), (2, 1000), (2, 10000), (4, 1000)):
-    U = np.linalg.qr(rng.standard_normal((batch, d, d)) + 1j*rng.standard_normal((batch, d, d)))[0]
-    basis = ff.Basis.pauli(int(np.log2(d)))
-    ff.liouville_representation(U, basis)
-    t0 = time.perf_counter()
-    for _ in range(20): ff.liouville_representation(U, basis)
-    print(d, batch, (time.perf_counter() - t0)/20*1e3, 'ms')
+"""K5 evidence: superoperator.liouville_representation on the FP64 matrix cores (liouville.hip),
+device resident and batched over the segments of a pulse as `concatenate` and the gradient call it.
+
+    python tools/time_liouville.py [--batch 512] [--d 4 8 16] [--reps 20]
+
+Prints, per dimension, the time of the whole launch sequence (memset, operand build, basis
+conjugation, GEMM) from HIP events, the real FP64 flops of the GEMM
+(batch * N * 2d^2 * N * 2, N = d^2, real part only for the Hermitian Pauli basis) and the rate.
+Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split and under
+`rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE` for the utilisation.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+import filter_functions_amd as ff  # noqa: E402
+from filter_functions_amd import _lib  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=512)
+    ap.add_argument('--d', type=int, nargs='*', default=[4, 8, 16])
+    ap.add_argument('--reps', type=int, default=20)
+    args = ap.parse_args()
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    for e in (e0, e1):
+        _lib.check(lib.ffk_event_create(ctypes.byref(e)))
+    ms = ctypes.c_float()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    for d in args.d:
+        N, B = d*d, args.batch
+        basis = ff.Basis.pauli(int(np.log2(d)))
+        U = np.linalg.qr(rng.standard_normal((B, d, d)) + 1j*rng.standard_normal((B, d, d)))[0]
+        Ud = torch.from_numpy(U).cuda()
+        Cd = torch.from_numpy(np.ascontiguousarray(np.asarray(basis))).cuda()
+        out = torch.empty((B, N, N), dtype=torch.float64, device='cuda')
+        need = lib.ffk_liouville_workspace_bytes(B, d, N)
+        ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+
+        def run():
+            _lib.check(lib.ffk_liouville_dev(p(Ud), B, d, p(Cd), N, 1, p(out), p(ws), need,
+                                             ctypes.c_void_p(stream)))
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(args.reps):
+            _lib.check(lib.ffk_event_record(e0, ctypes.c_void_p(stream)))
+            run()
+            _lib.check(lib.ffk_event_record(e1, ctypes.c_void_p(stream)))
+            torch.cuda.synchronize()
+            _lib.check(lib.ffk_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+            times.append(ms.value)
+        t = float(np.median(times))
+        flops = B*N*(2*d*d)*N*2.0
+        # parity on the first elements against the defining trace
+        L = out[:2].cpu().numpy()
+        C = np.asarray(basis)
+        ref = np.einsum('bka,ikl,blm,jma->bij', U[:2].conj(), C, U[:2], C).real
+        err = np.abs(L - ref).max()
+        print(f'd={d:2d} N={N:3d} batch={B}: {t*1e3:9.1f} us per call, GEMM {flops/1e9:8.3f} GFLOP '
+              f'-> {flops/(t*1e-3)/1e12:6.2f} TFLOP/s over the whole call; max abs err {err:.1e}')
+
+
+if __name__ == '__main__':
+    main()
