@@ -11,6 +11,7 @@ reads ``pulse.get_control_matrix`` / ``pulse.frequency_data['control_matrix']``
 """
 import copy
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -93,7 +94,7 @@ class ResidentResult:
         self._handle = ctypes.c_void_p()
         check(self._lib.ffk_resident_create(ctypes.byref(self._handle)))
         self.shape = None
-        self.filter_function = None
+        self._filter_function = None      # weak: the array's buffer owns this object, not vice versa
 
     def __del__(self):
         handle, self._handle = getattr(self, '_handle', None), None
@@ -116,8 +117,13 @@ class ResidentResult:
         V = _view(out[1].value, 2*G*d*d, np.complex128, (G, d, d), self)
         Q = _view(out[2].value, 2*(G + 1)*d*d, np.complex128, (G + 1, d, d), self)
         F = _view(out[3].value, 2*A*A*W, np.complex128, (A, A, W), self)
-        self.filter_function = F
+        self._filter_function = weakref.ref(F)
         return D, V, Q, F
+
+    @property
+    def filter_function(self):
+        """The host array of the resident F, if it is still alive."""
+        return None if self._filter_function is None else self._filter_function()
 
     def timing(self):
         """Host-clock seconds of the last pass: (packing inputs, enqueueing copies and kernels,

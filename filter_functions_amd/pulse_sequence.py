@@ -17,6 +17,7 @@ first time somebody reads them.  From the outside every entry is an ndarray, exa
 reference.
 """
 import copy
+import weakref
 from types import MappingProxyType
 from warnings import warn
 
@@ -346,13 +347,17 @@ class PulseSequence:
     def _defer_by_products(self):
         """What the reference's cache_control_matrix computes on the spot -- total phase factors and
         the Liouville representation of the total propagator -- becomes due on first read."""
+        # (the producers reach the pulse through a weak reference: a closure over `self` stored in
+        # the pulse's own cache would be a reference cycle, and the pulse -- with the device and
+        # pinned blocks of its resident result -- would live until the next pass of the cyclic GC)
+        me = weakref.ref(self)
         if 'total_phases' not in self._frequency_data:
             omega = self.omega
             self._frequency_data['total_phases'] = Deferred(
-                lambda: util.cexp(np.asarray(omega)*self.tau), 16*len(omega))
+                lambda: util.cexp(np.asarray(omega)*me().tau), 16*len(omega))
         if 'total_propagator_liouville' not in self._data:
             self._data['total_propagator_liouville'] = Deferred(
-                lambda: liouville_representation(self.total_propagator, self.basis),
+                lambda: liouville_representation(me().total_propagator, me().basis),
                 8*len(self.basis)**2)
 
     def _store_control_matrix(self, control_matrix):

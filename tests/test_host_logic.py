@@ -637,3 +637,53 @@ def test_lazy_cache_semantics():
     from types import MappingProxyType
     view = MappingProxyType(LazyCache(x=Deferred(lambda: 42)))
     assert view['x'] == 42 and dict(view.items()) == {'x': 42}
+
+
+def test_resident_result_is_released_with_the_pulse(monkeypatch):
+    """No reference cycle between a pulse, its deferred cache entries and its resident result: the
+    device and pinned blocks go back to the pool as soon as the pulse is dropped, without waiting
+    for the cyclic garbage collector (a stand-in result object: no GPU needed)."""
+    import gc
+    import weakref
+    from filter_functions_amd import pulse_sequence
+
+    class StandIn:
+        alive = 0
+
+        def __init__(self):
+            StandIn.alive += 1
+            self.shape = None
+
+        def __del__(self):
+            StandIn.alive -= 1
+
+        def evaluate(self, H, dt, t, omega, basis, n_opers, n_coeffs):
+            G, d, W, A = H.shape[0], H.shape[1], len(omega), len(n_opers)
+            F = np.zeros((A, A, W), complex)
+            self._f = weakref.ref(F)
+            return (np.zeros((G, d)), np.zeros((G, d, d), complex),
+                    np.tile(np.eye(d, dtype=complex), (G + 1, 1, 1)), F)
+
+        filter_function = property(lambda self: self._f())
+
+        def control_matrix_nbytes(self):
+            return 0
+
+        def control_matrix(self):
+            return np.zeros((1, 4, 2), complex)
+
+    monkeypatch.setattr(pulse_sequence, 'ResidentResult', StandIn)
+    X, Z = util.paulis[1], util.paulis[3]
+    gc.collect()
+    gc.disable()
+    try:
+        for _ in range(4):
+            pulse = ff.PulseSequence([[X, [1.0]]], [[Z, [1.0]]], [1.0])
+            F = pulse.get_filter_function([1.0, 2.0])
+            assert StandIn.alive == 1                      # the previous pulse's result is gone
+        assert pulse.is_cached('total_phases') and pulse.is_cached('control_matrix')
+        assert np.allclose(pulse.get_total_phases([1.0, 2.0]), np.exp(1j*np.array([1.0, 2.0])))
+        del pulse
+        assert StandIn.alive == 0 and F.shape == (1, 1, 2)
+    finally:
+        gc.enable()

@@ -19,6 +19,7 @@ import workloads as wl  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=200)
+    ap.add_argument('--profile', action='store_true', help='cProfile the call instead of timing it')
     args = ap.parse_args()
     cfg = wl.CONFIG2
     c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
@@ -26,6 +27,23 @@ def main():
     S = 1e-3/omega
     basis = ff.Basis.pauli(2)
     H_c, H_n = list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs))
+    if args.profile:
+        import cProfile
+        import pstats
+
+        def call():
+            pulse = ff.PulseSequence(H_c, H_n, dt, basis)
+            pulse.get_filter_function(omega)
+            ff.infidelity(pulse, S, omega)
+        for _ in range(5):
+            call()
+        prof = cProfile.Profile()
+        prof.enable()
+        for _ in range(args.reps):
+            call()
+        prof.disable()
+        pstats.Stats(prof).sort_stats('tottime').print_stats(22)
+        return
     rows = []
     for i in range(args.reps + 5):
         t0 = time.perf_counter()
