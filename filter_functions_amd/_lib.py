@@ -192,6 +192,15 @@ SIGNATURES = {
                                                 POINTER(c_void_p)]),
     'ffk_resident_infidelity': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                         c_void_p]),
+    'ffk_peer_last_error': (c_char_p, []),
+    'ffk_ipc_get_handle': (c_int, [c_void_p, c_void_p]),
+    'ffk_ipc_open_handle': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'ffk_ipc_close_handle': (c_int, [c_void_p]),
+    'ffk_peer_push_dev': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, ctypes.c_int64, c_int, c_int,
+                                  c_void_p, c_void_p]),
+    'ffk_peer_signal_dev': (c_int, [c_void_p, c_void_p, c_int, ctypes.c_int64, ctypes.c_int64,
+                                    c_void_p]),
+    'ffk_peer_wait_dev': (c_int, [c_void_p, c_int, ctypes.c_int64, c_void_p, c_void_p]),
     'ffk_set_segment_chunks': (c_int, [c_int]),
     'ffk_set_accumulate_variant': (c_int, [c_int]),
     'ffk_get_stats': (c_int, [POINTER(ffk_stats)]),

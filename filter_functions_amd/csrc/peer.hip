@@ -1,0 +1,166 @@
+// peer.hip -- one-sided all-gather of the filter-function blocks over xGMI, without RCCL.
+//
+// The frequency-sharded step (reference path: every omega of numeric.py:846-869 is
+// independent, only util.integrate couples them) ends in an all-gather of F (A x A x W/n complex
+// per rank).  RCCL's all-gather is a kernel with its own LDS and register budget; the accumulate
+// kernel holds 140 of every CU's 160 KiB of LDS, so the collective can only run in the gaps between
+// two accumulate launches or delays the next one.  Here every rank PUSHES its
+// block into the gather buffers of all ranks through IPC-mapped pointers with a plain copy kernel
+// (no LDS, 32 VGPRs: co-resident with the accumulate kernel), and completion travels as sequence
+// numbers in flag words that the consumer polls:
+//   push(c):  wait until every peer has acknowledged the step that used this buffer set last,
+//             copy F into slot `rank` of the set on every rank;
+//   signal(c): (next launch: the copy kernel has completed and released its writes) store c + 1 to
+//             flag[rank] on every rank, and "c steps consumed" to ack[rank] on every rank;
+//   wait(c):  poll the local flags until all ranks have signalled c + 1; then the integral runs.
+// Every poll loop has a wall-clock timeout (2 s) that raises an error word instead of hanging.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+#include "ffk.h"
+#include "ffk_internal.h"
+
+namespace ffk {
+namespace {
+
+constexpr long long kPollTimeoutTicks = 200000000LL;   // wall_clock64 ticks at 100 MHz: 2 s
+
+__device__ __forceinline__ long long load_system(const long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void store_system(long long* p, long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// true when *p >= want within the timeout
+__device__ bool poll_at_least(const long long* p, long long want) {
+    const long long t0 = wall_clock64();
+    while (load_system(p) < want) {
+        if (wall_clock64() - t0 > kPollTimeoutTicks) return false;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return true;
+}
+
+// grid (nblk, world): block (b, p) copies its share of src to dst[p]; 16 bytes per thread and step
+__global__ __launch_bounds__(256) void peer_push_kernel(const double2* __restrict__ src, size_t n16,
+                                                        double2* const* __restrict__ dst,
+                                                        const long long* __restrict__ acks,
+                                                        long long need_ack, int rank,
+                                                        int* __restrict__ error) {
+    const int p = blockIdx.y;
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        ok = 1;
+        if (p != rank && need_ack > 0 && !poll_at_least(acks + p, need_ack)) {
+            ok = 0;
+            atomicExch(error, 1);
+        }
+    }
+    __syncthreads();
+    if (!ok) return;
+    double2* out = dst[p];
+    for (size_t i = static_cast<size_t>(blockIdx.x)*blockDim.x + threadIdx.x; i < n16;
+         i += static_cast<size_t>(gridDim.x)*blockDim.x)
+        out[i] = src[i];
+}
+
+// one wavefront: lane p tells rank p "my block of step seq - 1 is in place" and "I have consumed
+// `consumed` steps"
+__global__ __launch_bounds__(64) void peer_signal_kernel(long long* const* __restrict__ flags,
+                                                         long long* const* __restrict__ acks,
+                                                         int world, long long seq, long long consumed) {
+    const int p = threadIdx.x;
+    if (p >= world) return;
+    __threadfence_system();
+    store_system(flags[p], seq);
+    store_system(acks[p], consumed);
+}
+
+// one wavefront: lane p waits for rank p's signal
+__global__ __launch_bounds__(64) void peer_wait_kernel(const long long* __restrict__ flags, int world,
+                                                       long long seq, int* __restrict__ error) {
+    const int p = threadIdx.x;
+    if (p < world && !poll_at_least(flags + p, seq)) atomicExch(error, 2);
+    __threadfence_system();
+}
+
+}  // namespace
+}  // namespace ffk
+
+extern "C" {
+
+namespace {
+thread_local char g_peer_error[256];
+int peer_fail(int code, const char* what, hipError_t e) {
+    snprintf(g_peer_error, sizeof g_peer_error, "%s failed: %s", what, hipGetErrorString(e));
+    return code;
+}
+}  // namespace
+
+const char* ffk_peer_last_error(void) { return g_peer_error; }
+
+int ffk_ipc_get_handle(const void* dptr, void* handle) {
+    if (!dptr || !handle) return FFK_EINVAL;
+    hipIpcMemHandle_t h;
+    hipError_t e = hipIpcGetMemHandle(&h, const_cast<void*>(dptr));
+    if (e != hipSuccess) return peer_fail(FFK_EHIP, "hipIpcGetMemHandle", e);
+    static_assert(sizeof(hipIpcMemHandle_t) == FFK_IPC_HANDLE_BYTES, "handle size");
+    std::memcpy(handle, &h, sizeof h);
+    return FFK_OK;
+}
+
+int ffk_ipc_open_handle(const void* handle, void** dptr) {
+    if (!dptr || !handle) return FFK_EINVAL;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof h);
+    hipError_t e = hipIpcOpenMemHandle(dptr, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return peer_fail(FFK_EHIP, "hipIpcOpenMemHandle", e);
+    return FFK_OK;
+}
+
+int ffk_ipc_close_handle(void* dptr) {
+    if (!dptr) return FFK_OK;
+    hipError_t e = hipIpcCloseMemHandle(dptr);
+    if (e != hipSuccess) return peer_fail(FFK_EHIP, "hipIpcCloseMemHandle", e);
+    return FFK_OK;
+}
+
+int ffk_peer_push_dev(const double* src, size_t bytes, void* const* dst, const int64_t* acks,
+                      int64_t need_ack, int world, int rank, int32_t* error, void* stream) {
+    if (!src || !dst || !acks || !error || world < 1 || world > 64 || rank < 0 || rank >= world ||
+        bytes % 16 != 0)
+        return FFK_EINVAL;
+    const size_t n16 = bytes/16;
+    const unsigned nblk = static_cast<unsigned>(std::min<size_t>(32, (n16 + 255)/256));
+    hipLaunchKernelGGL(ffk::peer_push_kernel, dim3(std::max(1u, nblk), world), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const double2*>(src), n16,
+                       reinterpret_cast<double2* const*>(dst),
+                       reinterpret_cast<const long long*>(acks), static_cast<long long>(need_ack), rank,
+                       error);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFK_OK : peer_fail(FFK_EHIP, "peer_push_kernel", e);
+}
+
+int ffk_peer_signal_dev(void* const* flags, void* const* acks, int world, int64_t seq, int64_t consumed,
+                        void* stream) {
+    if (!flags || !acks || world < 1 || world > 64) return FFK_EINVAL;
+    hipLaunchKernelGGL(ffk::peer_signal_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<long long* const*>(flags),
+                       reinterpret_cast<long long* const*>(acks), world, static_cast<long long>(seq),
+                       static_cast<long long>(consumed));
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFK_OK : peer_fail(FFK_EHIP, "peer_signal_kernel", e);
+}
+
+int ffk_peer_wait_dev(const int64_t* flags, int world, int64_t seq, int32_t* error, void* stream) {
+    if (!flags || !error || world < 1 || world > 64) return FFK_EINVAL;
+    hipLaunchKernelGGL(ffk::peer_wait_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const long long*>(flags), world, static_cast<long long>(seq),
+                       error);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFK_OK : peer_fail(FFK_EHIP, "peer_wait_kernel", e);
+}
+
+}  // extern "C"

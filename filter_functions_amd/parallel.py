@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 __all__ = ['shard_bounds', 'gather_omega_shards', 'sharded_filter_function', 'sum_omega_shards',
-           'sharded_error_transfer_matrix', 'ShardedStepRing']
+           'sharded_error_transfer_matrix', 'ShardedStepRing', 'PeerGather']
 
 
 def shard_bounds(n_omega, world_size, rank):
@@ -131,6 +131,132 @@ def sharded_error_transfer_matrix(pipe, omega_global, w_offset, single_qubit=Fal
     return gamma, K, U
 
 
+class _RawDeviceBuffer:
+    """Device memory straight from hipMalloc (libffk ``ffk_malloc``): an IPC handle names a whole
+    allocation, so buffers that other ranks map must not be sub-allocations of PyTorch's caching
+    allocator.  ``tensor()`` views the memory as a torch tensor (``__cuda_array_interface__``)."""
+
+    def __init__(self, shape, typestr, itemsize):
+        import ctypes
+        from . import _lib
+        self._lib = _lib.load()
+        self.shape = tuple(int(n) for n in shape)
+        self.nbytes = int(np.prod(self.shape))*itemsize
+        ptr = ctypes.c_void_p()
+        _lib.check(self._lib.ffk_malloc(ctypes.byref(ptr), max(self.nbytes, 16)))
+        self.ptr = ptr.value
+        _lib.check(self._lib.ffk_memset(ctypes.c_void_p(self.ptr), 0, max(self.nbytes, 16), None))
+        _lib.check(self._lib.ffk_device_synchronize())
+        self.__cuda_array_interface__ = {'shape': self.shape, 'typestr': typestr,
+                                         'data': (self.ptr, False), 'version': 2}
+
+    def tensor(self, device):
+        import torch
+        return torch.as_tensor(self, device=device)
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, 'ptr', None), None
+        if ptr:
+            import ctypes
+            self._lib.ffk_free(ctypes.c_void_p(ptr))
+
+
+class PeerGather:
+    """One-sided all-gather of the ranks' F blocks (``csrc/peer.hip``): every rank pushes its block
+    into slot ``rank`` of a buffer set on every rank through IPC-mapped pointers, completion and
+    buffer reuse travel as sequence numbers in flag words.  No RCCL kernel, no LDS: the copy shares
+    the CUs with the accumulate kernel.
+
+    Protocol of step c (buffer set k = c mod depth), all on the communication stream:
+      push:   wait until every peer has consumed step c - depth (ack word >= c - depth + 1), copy
+              the block to every rank's set k;
+      signal: store c + 1 to this rank's flag word and "c steps consumed" to its ack word on every
+              rank (the previous launch -- the copy -- has completed and released its writes);
+      wait:   poll the local flag words until every rank has signalled >= c + 1.
+    The rank that is furthest behind never waits for anybody, so the scheme cannot deadlock; every
+    poll has a 2 s timeout that sets ``error`` instead of hanging.
+    """
+
+    def __init__(self, depth, world, rank, block_shape, device, group=None):
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        self._lib, self._check = _lib.load(), _lib.check
+        self.depth, self.world, self.rank, self.device = depth, world, rank, device
+        self.block_bytes = int(np.prod(block_shape))*16
+        if self.block_bytes % 16:
+            raise ValueError('blocks are complex128')
+        self._sets = [_RawDeviceBuffer((world,) + tuple(block_shape), '<c16', 16) for _ in range(depth)]
+        self._words = _RawDeviceBuffer((2, world), '<i8', 8)          # [flags | acks]
+        self.gathered = [b.tensor(device) for b in self._sets]
+        words = self._words.tensor(device)
+        self.flags, self.acks = words[0], words[1]
+        self.error = torch.zeros(1, dtype=torch.int32, device=device)
+        # exchange the IPC handles of the depth buffer sets and of the word block
+        mine = []
+        for buf in self._sets + [self._words]:
+            handle = ctypes.create_string_buffer(64)
+            self._check(self._lib.ffk_ipc_get_handle(ctypes.c_void_p(buf.ptr), handle))
+            mine.append(handle.raw)
+        everyone = [None]*world
+        dist.all_gather_object(everyone, mine, group=group)
+        self._opened = []
+        bases = np.zeros((world, depth + 1), dtype=np.int64)
+        for p in range(world):
+            for j in range(depth + 1):
+                if p == rank:
+                    bases[p, j] = (self._sets + [self._words])[j].ptr
+                else:
+                    out = ctypes.c_void_p()
+                    self._check(self._lib.ffk_ipc_open_handle(everyone[p][j], ctypes.byref(out)))
+                    self._opened.append(out.value)
+                    bases[p, j] = out.value
+        # device tables: where, on rank p, this rank's slot / flag word / ack word lives
+        dst = bases[:, :depth].T + rank*self.block_bytes                          # (depth, world)
+        self._dst = torch.from_numpy(np.ascontiguousarray(dst)).to(device)
+        self._flag_at = torch.from_numpy(bases[:, depth] + 8*rank).to(device)     # (world,)
+        self._ack_at = torch.from_numpy(bases[:, depth] + 8*(world + rank)).to(device)
+        if group is not None or dist.is_initialized():
+            dist.barrier(group=group)            # every rank has mapped every buffer
+
+    @staticmethod
+    def _p(tensor):
+        import ctypes
+        return ctypes.c_void_p(tensor.data_ptr())
+
+    def step(self, c, block, stream):
+        """Push *block* (this rank's F of step *c*) to every rank and wait for everybody's; returns
+        the buffer set (world, ...) that holds step c once the stream has passed."""
+        import ctypes
+        k = c % self.depth
+        s = ctypes.c_void_p(stream)
+        need_ack = max(0, c - self.depth + 1)
+        self._check(self._lib.ffk_peer_push_dev(self._p(block), self.block_bytes, self._p(self._dst[k]),
+                                                self._p(self.acks), need_ack, self.world, self.rank,
+                                                self._p(self.error), s))
+        self._check(self._lib.ffk_peer_signal_dev(self._p(self._flag_at), self._p(self._ack_at),
+                                                  self.world, c + 1, c, s))
+        self._check(self._lib.ffk_peer_wait_dev(self._p(self.flags), self.world, c + 1,
+                                                self._p(self.error), s))
+        return self.gathered[k]
+
+    def check(self):
+        """Raise if a poll timed out (reads one word; synchronises the device)."""
+        import torch
+        torch.cuda.synchronize(self.device)
+        code = int(self.error.cpu().item())
+        if code:
+            raise RuntimeError(f'one-sided all-gather timed out ({"acknowledgement" if code == 1 else "signal"} '
+                               f'not received within 2 s on rank {self.rank})')
+
+    def close(self):
+        import ctypes
+        for ptr in self._opened:
+            self._lib.ffk_ipc_close_handle(ctypes.c_void_p(ptr))
+        self._opened = []
+
+
 class _CudaStreams:
     """Stream plumbing of :class:`ShardedStepRing` on PyTorch-ROCm streams and events."""
 
@@ -171,7 +297,7 @@ class ShardedStepRing:
     """
 
     def __init__(self, pipes, n_omega, omega_full, spectrum_full, compute_stream, comm_stream,
-                 world, rank, group=None, streams=None):
+                 world, rank, group=None, streams=None, gather='rccl'):
         import torch
         self.torch = torch
         self.pipes = list(pipes)
@@ -199,6 +325,57 @@ class ShardedStepRing:
                       for _ in range(self.depth)]
         self.free_events = [None]*self.depth
         self.count = 0
+        self.count_offset = 0
+        # gather = 'push': the one-sided all-gather (PeerGather) instead of the collective; needs
+        # equal blocks and real streams; 'auto': try it, verify one round, else the collective
+        self.peer = None
+        if gather in ('push', 'auto') and self.equal_shards and streams is None and world > 1:
+            try:
+                self.peer = self._try_peer_gather(first, group, required=(gather == 'push'))
+            except Exception:
+                if gather == 'push':
+                    raise
+                self.peer = None
+        if self.peer is not None:
+            self.gathered = self.peer.gathered
+        self.gather = 'push' if self.peer is not None else 'rccl'
+
+    def _try_peer_gather(self, first, group, required):
+        """Set the one-sided gather up and verify one round trip of a known pattern on every rank;
+        all ranks agree (minimum over ranks) whether to use it."""
+        import torch.distributed as dist
+        torch = self.torch
+        ok = 1
+        peer = None
+        try:
+            peer = PeerGather(self.depth, self.world, self.rank, first.filter_function.shape,
+                              first.filter_function.device, group=group)
+            probe = torch.full_like(first.filter_function, complex(self.rank + 1, -(self.rank + 1)))
+            torch.cuda.synchronize(probe.device)
+            with self.streams.on(self.comm_stream):
+                got = peer.step(0, probe, self.streams.handle(self.comm_stream))
+            peer.check()
+            expect = torch.arange(1, self.world + 1, dtype=torch.float64, device=got.device)
+            good = (got.real.amax(dim=(1, 2, 3)) == expect).all() and \
+                (got.real.amin(dim=(1, 2, 3)) == expect).all() and \
+                (got.imag.amax(dim=(1, 2, 3)) == -expect).all()
+            ok = int(bool(good))
+        except Exception:
+            if required:
+                raise
+            ok = 0
+        on_gpu = dist.get_backend(group) != 'gloo'
+        verdict = torch.tensor([ok], dtype=torch.int32,
+                               device=first.filter_function.device if on_gpu else 'cpu')
+        dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+        if int(verdict.item()) != 1:
+            if peer is not None:
+                peer.close()
+            if required:
+                raise RuntimeError('one-sided all-gather failed its round-trip check')
+            return None
+        self.count_offset = 1          # the probe was step 0 of the peer protocol
+        return peer
 
     def step(self):
         """Enqueue one sharded step; returns the tensor that will hold its infidelities (valid
@@ -216,7 +393,13 @@ class ShardedStepRing:
         ready = st.record(self.compute_stream)
         with st.on(self.comm_stream):
             st.wait(self.comm_stream, ready)
-            if self.equal_shards:
+            if self.peer is not None:
+                # one-sided: push this rank's block everywhere, poll for everybody's
+                recv = self.peer.step(c + self.count_offset, pipe.filter_function,
+                                      st.handle(self.comm_stream))
+                out = pipe.infidelity_from_shards(recv, self.omega_full, self.spectrum_full, self.idx,
+                                                  self.infid[k], stream=st.handle(self.comm_stream))
+            elif self.equal_shards:
                 # one collective into a preallocated buffer; the integral reads the shards in place
                 send, recv = pipe.filter_function, self.gathered[k]
                 if dist.get_backend(self.group) == 'gloo':         # gloo has no flat all-gather

@@ -456,6 +456,28 @@ int ffk_resident_infidelity(ffk_resident* handle, const double* spectrum, int s_
                             int spectrum_is_real, const int32_t* idx, int n_idx, int d,
                             double* infid);
 
+/* ---- one-sided all-gather of the F blocks over xGMI (frequency-sharded step; the
+ *      reference has no multi-device path: numeric.py:846-869 is embarrassingly parallel in omega
+ *      and this is the exchange that reassembles F(omega) for util.integrate, util.py:880-906) ----
+ * Every rank pushes its block into slot `rank` of a gather buffer on every rank through pointers
+ * obtained with ffk_ipc_open_handle, with a copy kernel that needs no LDS (it shares the CUs with
+ * the accumulate kernel, which an RCCL all-gather kernel cannot), and completion travels as
+ * sequence numbers in 64-bit flag words polled with a 2 s timeout (error word: 1 = acknowledgement
+ * timed out in push, 2 = signal timed out in wait).  dst / flags / acks are DEVICE arrays of
+ * `world` device pointers (addresses on rank p of: the slot of this rank in the buffer set, the flag
+ * word of this rank, the acknowledgement word of this rank); `acks` / `flags` of push / wait are
+ * this rank's own words, one per peer.  filter_functions_amd/parallel.py holds the protocol.     */
+#define FFK_IPC_HANDLE_BYTES 64
+const char* ffk_peer_last_error(void);
+int ffk_ipc_get_handle(const void* dptr, void* handle);
+int ffk_ipc_open_handle(const void* handle, void** dptr);
+int ffk_ipc_close_handle(void* dptr);
+int ffk_peer_push_dev(const double* src, size_t bytes, void* const* dst, const int64_t* acks,
+                      int64_t need_ack, int world, int rank, int32_t* error, void* stream);
+int ffk_peer_signal_dev(void* const* flags, void* const* acks, int world, int64_t seq,
+                        int64_t consumed, void* stream);
+int ffk_peer_wait_dev(const int64_t* flags, int world, int64_t seq, int32_t* error, void* stream);
+
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Number of segment chunks the control-matrix kernel splits G into (0 = automatic).        */
 int ffk_set_segment_chunks(int chunks);

@@ -1,0 +1,80 @@
+"""The one-sided all-gather of the frequency-sharded step (csrc/peer.hip, parallel.PeerGather) with
+two ranks.  A gpurun box has one GPU: both ranks use device 0 (IPC mappings between processes work
+on one device as across devices; RCCL refuses two ranks on one device, so the control plane is
+gloo).  The 8-GPU run itself is the driver's."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.multiprocessing as mp  # noqa: E402
+
+from conftest import ROOT  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, depth, n_steps, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+
+    import filter_functions_amd as ff
+    import workloads as wl
+    from filter_functions_amd.device import DevicePipeline
+    from filter_functions_amd.parallel import ShardedStepRing, shard_bounds
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    device = torch.device('cuda', 0)
+    cfg = dict(wl.CONFIG2, G=24)
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
+    W = 512
+    omega = wl.random_pulse_omega(dt, W)
+    S = 1e-3/omega
+    basis = ff.Basis.pauli(2)
+    w0, w1 = shard_bounds(W, world, rank)
+    pipes = [DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega[w0:w1],
+                            device=device) for _ in range(depth)]
+    compute, comm = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+    ring = ShardedStepRing(pipes, W, omega, S, compute, comm, world, rank, gather='push')
+    assert ring.gather == 'push'
+    outs = [ring.step() for _ in range(n_steps)]
+    torch.cuda.synchronize(device)
+    ring.peer.check()
+    results = np.array([o.cpu().numpy() for o in outs[-depth:]])
+    F_gathered = ring.peer.gathered[(n_steps - 1 + ring.count_offset) % depth].cpu().numpy()
+    whole = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum=S,
+                           device=device)
+    whole.launch()
+    torch.cuda.synchronize(device)
+    np.savez(os.path.join(out_dir, f'peer{rank}.npz'), results=results, F_gathered=F_gathered,
+             F_whole=whole.filter_function.cpu().numpy(), infid_whole=whole.infid.cpu().numpy())
+    dist.barrier()
+    ring.peer.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('depth,n_steps', [(2, 7), (4, 13)])
+def test_one_sided_gather_two_ranks_on_one_device(tmp_path, depth, n_steps):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), depth, n_steps, str(tmp_path)), nprocs=world,
+             join=True)
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f'peer{rank}.npz'))
+        F = got['F_gathered']                                    # (world, A, A, W/world)
+        F = F.transpose(1, 2, 0, 3).reshape(3, 3, -1)
+        # the blocks are evaluated with a chunk count that depends on the block width: equal up to
+        # the re-association of the segment sum
+        assert np.abs(F - got['F_whole']).max() <= 1e-13*np.abs(got['F_whole']).max()
+        for infid in got['results']:                             # every step computes the same pulse
+            assert np.abs(infid - got['infid_whole']).max() <= 1e-13*np.abs(got['infid_whole']).max()
