@@ -439,8 +439,10 @@ def main():
         compute_stream = torch.cuda.Stream(device=device)
         comm_stream = torch.cuda.Stream(device=device)
         torch.cuda.synchronize(device)
+        # FFK_GATHER: 'auto' (default: the one-sided all-gather of csrc/peer.hip if its set-up and a
+        # verified round trip succeed on every rank, else the RCCL collective), 'push', 'rccl'
         ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_stream,
-                               comm_stream, world, rank)
+                               comm_stream, world, rank, gather=os.environ.get('FFK_GATHER', 'auto'))
     elif n_streams > 1:
         # Steps are independent passes (one pulse each): with two passes in flight on two HIP
         # streams the five latency-bound launches of one pass (eigensolver, scan, prologue,
@@ -506,6 +508,31 @@ def main():
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
     pipe.check_status()                          # eigensolver flags of the device-resident run
+    gather_ab = None
+    if use_dist:
+        if ring.peer is not None:
+            ring.peer.check()                    # no poll of the one-sided gather timed out
+        # the other gather method on the same workload, 200 steps, for the record
+        other = 'rccl' if ring.gather == 'push' else 'push'
+        try:
+            ring_b = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_stream,
+                                     comm_stream, world, rank,
+                                     gather=other if other == 'rccl' else 'auto')
+            if ring_b.gather == other:
+                for _ in range(50):
+                    ring_b.step()
+                torch.cuda.synchronize(device)
+                dist.barrier()
+                tb = time.perf_counter()
+                for _ in range(200):
+                    ring_b.step()
+                torch.cuda.synchronize(device)
+                dist.barrier()
+                tb = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=device)
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+                gather_ab = {'headline': ring.gather, other + '_ms_per_step': float(tb.item())/200*1e3}
+        except RuntimeError as err:
+            gather_ab = {'headline': ring.gather, other: f'failed: {err}'}
     # latency of one pass on its own (one stream, nothing else in flight), for reference
     latency_ms = None
     if not use_dist:
@@ -568,9 +595,11 @@ def main():
                                    f'{A} noise ops, Pauli basis, {args.omega_per_gpu} omega per GPU '
                                    f'({W_total} total), seed 42; one step = diagonalize + control '
                                    'matrix + filter function + infidelity, HBM-resident',
-                       'sharding': 'omega blocks, RCCL all-gather of F' if use_dist else 'none',
+                       'sharding': ('omega blocks, ' + ('one-sided all-gather of F over IPC-mapped '
+                                    'peer memory (csrc/peer.hip)' if ring.gather == 'push' else
+                                    'RCCL all-gather of F')) if use_dist else 'none',
                        'passes_in_flight': depth if use_dist else n_streams},
-            'single_stream_ms_per_step': latency_ms,
+            'single_stream_ms_per_step': latency_ms, 'gather_ab': gather_ab,
             'prewarm': prewarm,
             'roofline': {
                 'kernel': 'ffk::ctrl_accumulate_pc_kernel<4,3>', 'bound': 'fp64_valu',
@@ -630,7 +659,7 @@ def main():
 def bench_config4_strong(ff, torch, dist, lib, _lib, DevicePipeline, device, compute_stream,
                          comm_stream, world, rank, depth):
     """Config 4 as BASELINE states it: the 65536-omega grid split over the ranks (strong scaling),
-    RCCL all-gather of F (9 x 9 x 65536/N c128 per rank), infidelity over the full grid."""
+    all-gather of F (9 x 9 x 65536/N c128 per rank), infidelity over the full grid."""
     from filter_functions_amd.parallel import ShardedStepRing, shard_bounds
     cfg = wl.CONFIG4
     c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
@@ -644,7 +673,8 @@ def bench_config4_strong(ff, torch, dist, lib, _lib, DevicePipeline, device, com
     pipes = [DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, basis,
                             omega_full[w0:w1], spectrum=S_full[w0:w1], device=device)
              for _ in range(depth)]
-    ring = ShardedStepRing(pipes, W, omega_full, S_full, compute_stream, comm_stream, world, rank)
+    ring = ShardedStepRing(pipes, W, omega_full, S_full, compute_stream, comm_stream, world, rank,
+                           gather=os.environ.get('FFK_GATHER', 'auto'))
     reps = 6
     for _ in range(2):
         ring.step()
@@ -661,9 +691,11 @@ def bench_config4_strong(ff, torch, dist, lib, _lib, DevicePipeline, device, com
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item())/reps*1e3
     E = cfg['G']*W*cfg['A']*cfg['d']**2
-    return dict(config=4, scaling='strong', n_gpus=world,
+    if ring.peer is not None:
+        ring.peer.check()
+    return dict(config=4, scaling='strong', n_gpus=world, gather=ring.gather,
                 workload=f'd=8, 512 segments, 9 noise ops, 65536 omega split over {world} ranks '
-                         f'({w1 - w0} per rank), RCCL all-gather of F, infidelity over the full grid',
+                         f'({w1 - w0} per rank), all-gather of F, infidelity over the full grid',
                 ms=ms, elements_per_s=E/(ms*1e-3))
 
 

@@ -187,38 +187,50 @@ class PeerGather:
         self.block_bytes = int(np.prod(block_shape))*16
         if self.block_bytes % 16:
             raise ValueError('blocks are complex128')
-        self._sets = [_RawDeviceBuffer((world,) + tuple(block_shape), '<c16', 16) for _ in range(depth)]
-        self._words = _RawDeviceBuffer((2, world), '<i8', 8)          # [flags | acks]
-        self.gathered = [b.tensor(device) for b in self._sets]
-        words = self._words.tensor(device)
-        self.flags, self.acks = words[0], words[1]
-        self.error = torch.zeros(1, dtype=torch.int32, device=device)
-        # exchange the IPC handles of the depth buffer sets and of the word block
-        mine = []
-        for buf in self._sets + [self._words]:
-            handle = ctypes.create_string_buffer(64)
-            self._check(self._lib.ffk_ipc_get_handle(ctypes.c_void_p(buf.ptr), handle))
-            mine.append(handle.raw)
+        # Every rank takes part in every collective of the set-up whatever happens locally: a rank
+        # that fails publishes None / ok = False instead of leaving the others waiting.
+        self.ok = True
+        self._opened = []
+        mine = None
+        try:
+            self._sets = [_RawDeviceBuffer((world,) + tuple(block_shape), '<c16', 16)
+                          for _ in range(depth)]
+            self._words = _RawDeviceBuffer((2, world), '<i8', 8)          # [flags | acks]
+            self.gathered = [b.tensor(device) for b in self._sets]
+            words = self._words.tensor(device)
+            self.flags, self.acks = words[0], words[1]
+            self.error = torch.zeros(1, dtype=torch.int32, device=device)
+            mine = []
+            for buf in self._sets + [self._words]:
+                handle = ctypes.create_string_buffer(64)
+                self._check(self._lib.ffk_ipc_get_handle(ctypes.c_void_p(buf.ptr), handle))
+                mine.append(handle.raw)
+        except Exception as err:          # noqa: BLE001 -- reported through self.ok / self.reason
+            self.ok, self.reason, mine = False, f'local set-up failed: {err}', None
         everyone = [None]*world
         dist.all_gather_object(everyone, mine, group=group)
-        self._opened = []
-        bases = np.zeros((world, depth + 1), dtype=np.int64)
-        for p in range(world):
-            for j in range(depth + 1):
-                if p == rank:
-                    bases[p, j] = (self._sets + [self._words])[j].ptr
-                else:
-                    out = ctypes.c_void_p()
-                    self._check(self._lib.ffk_ipc_open_handle(everyone[p][j], ctypes.byref(out)))
-                    self._opened.append(out.value)
-                    bases[p, j] = out.value
-        # device tables: where, on rank p, this rank's slot / flag word / ack word lives
-        dst = bases[:, :depth].T + rank*self.block_bytes                          # (depth, world)
-        self._dst = torch.from_numpy(np.ascontiguousarray(dst)).to(device)
-        self._flag_at = torch.from_numpy(bases[:, depth] + 8*rank).to(device)     # (world,)
-        self._ack_at = torch.from_numpy(bases[:, depth] + 8*(world + rank)).to(device)
-        if group is not None or dist.is_initialized():
-            dist.barrier(group=group)            # every rank has mapped every buffer
+        if any(entry is None for entry in everyone):
+            self.ok = False
+            self.reason = getattr(self, 'reason', 'a peer could not export its buffers')
+            return
+        try:
+            bases = np.zeros((world, depth + 1), dtype=np.int64)
+            for p in range(world):
+                for j in range(depth + 1):
+                    if p == rank:
+                        bases[p, j] = (self._sets + [self._words])[j].ptr
+                    else:
+                        out = ctypes.c_void_p()
+                        self._check(self._lib.ffk_ipc_open_handle(everyone[p][j], ctypes.byref(out)))
+                        self._opened.append(out.value)
+                        bases[p, j] = out.value
+            # device tables: where, on rank p, this rank's slot / flag word / ack word lives
+            dst = bases[:, :depth].T + rank*self.block_bytes                          # (depth, world)
+            self._dst = torch.from_numpy(np.ascontiguousarray(dst)).to(device)
+            self._flag_at = torch.from_numpy(bases[:, depth] + 8*rank).to(device)     # (world,)
+            self._ack_at = torch.from_numpy(bases[:, depth] + 8*(world + rank)).to(device)
+        except Exception as err:          # noqa: BLE001
+            self.ok, self.reason = False, f'mapping the peers\' buffers failed: {err}'
 
     @staticmethod
     def _p(tensor):
@@ -330,12 +342,7 @@ class ShardedStepRing:
         # equal blocks and real streams; 'auto': try it, verify one round, else the collective
         self.peer = None
         if gather in ('push', 'auto') and self.equal_shards and streams is None and world > 1:
-            try:
-                self.peer = self._try_peer_gather(first, group, required=(gather == 'push'))
-            except Exception:
-                if gather == 'push':
-                    raise
-                self.peer = None
+            self.peer = self._try_peer_gather(first, group, required=(gather == 'push'))
         if self.peer is not None:
             self.gathered = self.peer.gathered
         self.gather = 'push' if self.peer is not None else 'rccl'
@@ -345,34 +352,30 @@ class ShardedStepRing:
         all ranks agree (minimum over ranks) whether to use it."""
         import torch.distributed as dist
         torch = self.torch
-        ok = 1
-        peer = None
-        try:
-            peer = PeerGather(self.depth, self.world, self.rank, first.filter_function.shape,
-                              first.filter_function.device, group=group)
-            probe = torch.full_like(first.filter_function, complex(self.rank + 1, -(self.rank + 1)))
-            torch.cuda.synchronize(probe.device)
-            with self.streams.on(self.comm_stream):
+        block = first.filter_function
+        peer = PeerGather(self.depth, self.world, self.rank, block.shape, block.device, group=group)
+        ok = 0
+        if peer.ok:
+            try:
+                probe = torch.full_like(block, complex(self.rank + 1, -(self.rank + 1)))
+                torch.cuda.synchronize(probe.device)
                 got = peer.step(0, probe, self.streams.handle(self.comm_stream))
-            peer.check()
-            expect = torch.arange(1, self.world + 1, dtype=torch.float64, device=got.device)
-            good = (got.real.amax(dim=(1, 2, 3)) == expect).all() and \
-                (got.real.amin(dim=(1, 2, 3)) == expect).all() and \
-                (got.imag.amax(dim=(1, 2, 3)) == -expect).all()
-            ok = int(bool(good))
-        except Exception:
-            if required:
-                raise
-            ok = 0
+                peer.check()
+                expect = torch.arange(1, self.world + 1, dtype=torch.float64, device=got.device)
+                good = (got.real.amax(dim=(1, 2, 3)) == expect).all() and \
+                    (got.real.amin(dim=(1, 2, 3)) == expect).all() and \
+                    (got.imag.amax(dim=(1, 2, 3)) == -expect).all()
+                ok = int(bool(good))
+            except Exception:             # noqa: BLE001 -- the verdict below is collective
+                ok = 0
         on_gpu = dist.get_backend(group) != 'gloo'
-        verdict = torch.tensor([ok], dtype=torch.int32,
-                               device=first.filter_function.device if on_gpu else 'cpu')
+        verdict = torch.tensor([ok], dtype=torch.int32, device=block.device if on_gpu else 'cpu')
         dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
         if int(verdict.item()) != 1:
-            if peer is not None:
-                peer.close()
+            peer.close()
             if required:
-                raise RuntimeError('one-sided all-gather failed its round-trip check')
+                raise RuntimeError('one-sided all-gather failed its round-trip check: '
+                                   + getattr(peer, 'reason', 'pattern mismatch or timeout'))
             return None
         self.count_offset = 1          # the probe was step 0 of the peer protocol
         return peer
