@@ -1915,3 +1915,43 @@ def test_decay_amplitudes_complex_spectrum_below_three_dimensions(s_ndim):
     real = numeric._decay_amplitudes(R, S.real, omega, np.arange(A), 'total')
     assert rel_err(real, orc.decay_amplitudes(R, S.real, omega, np.arange(A))) < 1e-12
     assert rel_err(real, real.swapaxes(-1, -2)) < 1e-14          # symmetric again for a real spectrum
+
+
+@pytest.mark.parametrize('G,A,W', [(1, 1, 1), (2, 2, 65), (3, 4, 100), (5, 7, 64), (9, 10, 130),
+                                    (33, 3, 7)])
+def test_d8_producer_consumer_kernel_ragged_shapes(G, A, W):
+    """ctrl_pcw.hip (d = 8): operator counts that do not fill the three-operator blocks, frequency
+    tiles that are not full, one- and two-segment chunks, several chunks -- against the oracle and
+    against the symmetric kernel (tuning variant 2)."""
+    d = 8
+    rng = np.random.default_rng(800 + G*A + W)
+    basis = ff.Basis.pauli(3)
+    c_opers = rng.standard_normal((3, d, d)) + 1j*rng.standard_normal((3, d, d))
+    c_opers = c_opers + c_opers.conj().transpose(0, 2, 1)
+    n_opers = rng.standard_normal((A, d, d)) + 1j*rng.standard_normal((A, d, d))
+    n_opers = n_opers + n_opers.conj().transpose(0, 2, 1)
+    H = np.einsum('ijk,il->ljk', c_opers, rng.standard_normal((3, G)))
+    dt = 0.5 + rng.random(G)
+    n_coeffs = rng.random((A, G)) + 0.5
+    omega = np.concatenate(([0.0], np.geomspace(1e-3, 50, W - 1))) if W > 1 else np.array([0.3])
+    D, V, Q = numeric.diagonalize(H, dt)
+    lib = _lib.load()
+    R = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+    assert _lib.stats()['block'] == 1024                          # the 16-wave kernel ran
+    R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), n_opers, n_coeffs, dt)
+    assert rel_err(R, R_ref) < 1e-12
+    try:
+        for chunks in (1, 2, 3):
+            _lib.check(lib.ffk_set_segment_chunks(chunks))
+            R_c = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers,
+                                                                n_coeffs, dt)
+            assert rel_err(R_c, R_ref) < 1e-12
+        _lib.check(lib.ffk_set_segment_chunks(0))
+        _lib.check(lib.ffk_set_accumulate_variant(2))
+        R_sym = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers,
+                                                              n_coeffs, dt)
+        assert _lib.stats()['block'] != 1024
+        assert rel_err(R_sym, R) < 1e-13
+    finally:
+        lib.ffk_set_segment_chunks(0)
+        lib.ffk_set_accumulate_variant(0)
