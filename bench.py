@@ -557,6 +557,7 @@ def main():
             configs.append(bench_config4_strong(ff, torch, dist, lib, _lib, DevicePipeline, device,
                                                 compute_stream, comm_stream, world, rank,
                                                 args.pipeline_depth))
+            configs.append(bench_config5_strong(ff, torch, dist, DevicePipeline, device, world, rank))
         elif rank == 0:
             configs.append(bench_config3(ff))
             configs.append(bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream)[1])
@@ -697,6 +698,48 @@ def bench_config4_strong(ff, torch, dist, lib, _lib, DevicePipeline, device, com
                 workload=f'd=8, 512 segments, 9 noise ops, 65536 omega split over {world} ranks '
                          f'({w1 - w0} per rank), all-gather of F, infidelity over the full grid',
                 ms=ms, elements_per_s=E/(ms*1e-3))
+
+
+def bench_config5_strong(ff, torch, dist, DevicePipeline, device, world, rank):
+    """Config 5 as BASELINE states it: the QFT's 16384 omega split over the ranks; every rank
+    integrates its block of the decay amplitudes with the global trapezoid weights, the (18, 256,
+    256) partial results are all-gathered and summed in rank order, cumulant function and matrix
+    exponential run redundantly on every rank (parallel.sharded_error_transfer_matrix)."""
+    from filter_functions_amd.parallel import shard_bounds, sharded_error_transfer_matrix
+    W = wl.CONFIG5['W']
+    omega = np.logspace(-2, 2, W)
+    qft = wl.qft_pulse(ff)
+    A = len(qft.n_opers)
+    S = np.outer(1e-6*(np.arange(A) + 1), 1/omega)
+    w0, w1 = shard_bounds(W, world, rank)
+    pipe = DevicePipeline(qft.c_opers, qft.c_coeffs, qft.n_opers, qft.n_coeffs, qft.dt, qft.basis,
+                          omega[w0:w1], spectrum=S[:, w0:w1], device=device)
+    omega_dev = torch.from_numpy(omega).to(device)
+
+    def one():
+        pipe.launch(with_infidelity=False)
+        return sharded_error_transfer_matrix(pipe, omega_dev, w0)
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gamma, K, U = one()
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item())/reps*1e3
+    E = len(qft.dt)*W*A*qft.d**2
+    return dict(config=5, scaling='strong', n_gpus=world,
+                workload=f'examples/qft.py 4-qubit QFT, d=16, 13 segments, 18 noise ops, 16384 omega '
+                         f'split over {world} ranks ({w1 - w0} per rank): control matrix -> decay '
+                         'amplitudes (all-gather of the partial integrals, rank-ordered sum) -> '
+                         'cumulant function -> exp on every rank',
+                ms=ms, elements_per_s=E/(ms*1e-3),
+                entanglement_infidelity=float(1 - np.trace(U)/qft.d**2))
 
 
 if __name__ == '__main__':
