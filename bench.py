@@ -265,7 +265,7 @@ def bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream, ra
         geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')})
 
 
-def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, stream):
+def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
     """examples/qft.py: d = 16, 13 segments, 18 noise operators, 16384 omega: control matrix ->
     decay amplitudes -> cumulant function -> error transfer matrix."""
     W = wl.CONFIG5['W']
@@ -275,12 +275,17 @@ def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, stream):
     S = np.outer(1e-6*(np.arange(A) + 1), 1/omega)
     pipe = DevicePipeline(qft.c_opers, qft.c_coeffs, qft.n_opers, qft.n_coeffs, qft.dt, qft.basis,
                           omega, spectrum=S, device=device)
+    stream = torch_stream.cuda_stream
     result = {}
 
     def etm():
-        gamma = pipe.decay_amplitudes(stream=stream)
-        K = pipe.cumulant_function(gamma, stream=stream)
-        result['U'] = ff.error_transfer_matrix(cumulant_function=K.sum(dim=0).cpu().numpy()[None])
+        # everything of one pass on ONE stream: the sum over the operators and the copy to the host
+        # must see this pass's cumulant function (torch's own ops follow torch's current stream)
+        with torch.cuda.stream(torch_stream):
+            gamma = pipe.decay_amplitudes(stream=stream)
+            K = pipe.cumulant_function(gamma, stream=stream)
+            K_total = K.sum(dim=0).cpu().numpy()
+        result['U'] = ff.error_transfer_matrix(cumulant_function=K_total[None])
     ms, kernel_ms = time_pipeline(pipe, torch, lib, _lib, stream, reps=5, extra=etm)
     st = _lib.stats()
     E = len(qft.dt)*W*A*qft.d**2
@@ -561,7 +566,7 @@ def main():
         elif rank == 0:
             configs.append(bench_config3(ff))
             configs.append(bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream)[1])
-            configs.append(bench_config5(ff, torch, lib, _lib, DevicePipeline, device, stream))
+            configs.append(bench_config5(ff, torch, lib, _lib, DevicePipeline, device, compute_stream))
 
     if rank == 0:
         E_step = G*W_total*A*d*d
