@@ -592,6 +592,17 @@ def _merge_constant_segments(pulse):
     return np.delete(pulse.c_coeffs, same, axis=1), np.delete(pulse.n_coeffs, same, axis=1), dt
 
 
+def _running_products(matrices):
+    """P[g] = M[g] M[g-1] ... M[0] for a stack (G, d, d), as a log-depth (Hillis-Steele) scan:
+    ceil(log2 G) batched matrix products instead of G - 1 dependent ones."""
+    P = np.array(matrices)
+    shift = 1
+    while shift < len(P):
+        P[shift:] = P[shift:] @ P[:-shift]
+        shift *= 2
+    return P
+
+
 def _all_bases_equal(pulses):
     first = pulses[0].basis
     # the same Basis object (or one already compared) needs no element-wise comparison: a long
@@ -607,7 +618,8 @@ def _all_bases_equal(pulses):
 
 
 def _concatenate_hamiltonian(opers, identifiers, coeffs, kind):
-    """Merge the operator tables of several pulses (reference pulse_sequence.py:1340-1483).
+    """Merge the operator tables of several pulses (contract of reference
+    pulse_sequence.py:1340-1483).
 
     Operators with identical matrices are one operator of the new pulse (they must then carry
     the same identifier in every pulse, else ValueError); an identifier that names different
@@ -616,44 +628,53 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind):
     coefficient table -- zero-filled for control terms a pulse lacks, filled with the common
     constant for noise sensitivities (ValueError if it is not constant) -- and, per pulse, the
     map old identifier -> new identifier.
+
+    A long sequence is typically drawn from a handful of pulse objects (1000 gates from 24
+    Cliffords): all bookkeeping runs over the DISTINCT (operators, identifiers, coefficients)
+    triples, in order of first appearance, and the coefficient table is assembled by one
+    concatenation of per-triple blocks.
     """
-    n_segments = [np.shape(c)[1] for c in coeffs]
-    offsets = np.concatenate(([0], np.cumsum(n_segments)))
-    # one record per (pulse, operator)
-    keys = {}                  # operator tables of repeated pulse objects are hashed once
-    def table_keys(ops):
-        cached = keys.get(id(ops))
-        if cached is None:
-            cached = keys[id(ops)] = [np.ascontiguousarray(op).tobytes() for op in ops]
-        return cached
-    records = [(p, i, key, str(ident))
-               for p, (ops, ids) in enumerate(zip(opers, identifiers))
-               for i, (key, ident) in enumerate(zip(table_keys(ops), ids))]
-    idents_of_matrix, matrices_of_ident = {}, {}
-    for _, _, key, ident in records:
+    # distinct triples by object identity, first position of each
+    slot_of, first_pos, slot = {}, [], []
+    for p in range(len(opers)):
+        key = (id(opers[p]), id(identifiers[p]), id(coeffs[p]))
+        k = slot_of.get(key)
+        if k is None:
+            k = slot_of[key] = len(first_pos)
+            first_pos.append(p)
+        slot.append(k)
+    # one record per (distinct triple, operator): (first position, row in the pulse, matrix, name)
+    records = [(p, i, np.ascontiguousarray(op).tobytes(), str(ident))
+               for p in first_pos
+               for i, (op, ident) in enumerate(zip(opers[p], identifiers[p]))]
+    idents_of_matrix, matrices_of_ident, first_seen = {}, {}, {}
+    for p, i, key, ident in records:
         idents_of_matrix.setdefault(key, set()).add(ident)
         matrices_of_ident.setdefault(ident, set()).add(key)
+        first_seen.setdefault(key, (p, i, ident))
     if any(len(v) > 1 for v in idents_of_matrix.values()):
         raise ValueError(f'Trying to concatenate pulses with equal {kind} operators but '
                          f'different identifiers. Please choose unique {kind} identifiers!')
     # new identifier of every distinct matrix
-    first_seen = {}
+    new_ident = {key: (f'{ident}_{p}' if len(matrices_of_ident[ident]) > 1 else ident)
+                 for key, (p, i, ident) in first_seen.items()}
+    ordered = sorted(first_seen, key=new_ident.get)
+    row = {key: r for r, key in enumerate(ordered)}
+    concat_identifiers = np.array([new_ident[key] for key in ordered])
+    concat_opers = np.array([np.asarray(opers[first_seen[key][0]][first_seen[key][1]])
+                             for key in ordered])
+    # per distinct triple: its block of the coefficient table (NaN where it lacks an operator) and
+    # its identifier map; per pulse position: a reference to those
+    blocks, maps = {}, {}
     for p, i, key, ident in records:
-        first_seen.setdefault(key, (p, i, ident))
-    new_ident = {}
-    for key, (p, i, ident) in first_seen.items():
-        clash = len(matrices_of_ident[ident]) > 1
-        new_ident[key] = f'{ident}_{p}' if clash else ident
-    mapping = {p: {} for p in range(len(opers))}
-    for p, i, key, ident in records:
-        mapping[p][ident] = new_ident[key]
-    keys = sorted(first_seen, key=lambda k: new_ident[k])
-    concat_identifiers = np.array([new_ident[k] for k in keys])
-    concat_opers = np.array([np.asarray(opers[first_seen[k][0]][first_seen[k][1]]) for k in keys])
-    table = np.full((len(keys), int(offsets[-1])), np.nan)
-    row = {k: r for r, k in enumerate(keys)}
-    for p, i, key, _ in records:
-        table[row[key], offsets[p]:offsets[p + 1]] = np.asarray(coeffs[p])[i]
+        block = blocks.get(p)
+        if block is None:
+            block = blocks[p] = np.full((len(ordered), np.shape(coeffs[p])[1]), np.nan)
+            maps[p] = {}
+        block[row[key]] = np.asarray(coeffs[p])[i]
+        maps[p][ident] = new_ident[key]
+    table = np.concatenate([blocks[first_pos[k]] for k in slot], axis=1)
+    mapping = {p: maps[first_pos[k]] for p, k in enumerate(slot)}
     missing = np.isnan(table)
     if kind == 'noise':
         for r in np.nonzero(missing.any(axis=1))[0]:
@@ -662,7 +683,7 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind):
                 raise ValueError('Not all pulses have the same noise operators and '
                                  'non-trivial noise sensitivities so I cannot infer them.')
             table[r, missing[r]] = known[0]
-    else:
+    elif missing.any():
         table[missing] = 0
     return concat_opers, concat_identifiers, table, mapping
 
@@ -690,7 +711,11 @@ def concatenate_without_filter_function(pulses, return_identifier_mappings=False
     dt = np.concatenate(tuple(pulse.dt for pulse in pulses))
     newpulse = PulseSequence.from_arrays(c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt,
                                          pulses[0].basis)
-    newpulse.tau = sum(pulse.tau for pulse in pulses)
+    durations = {}
+    for pulse in pulses:
+        if id(pulse) not in durations:
+            durations[id(pulse)] = pulse.tau
+    newpulse.tau = sum(durations[id(pulse)] for pulse in pulses)
     if return_identifier_mappings:
         return newpulse, c_map, n_map
     return newpulse
@@ -717,22 +742,40 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
         return copy.deepcopy(pulses[0])  # nothing to concatenate: an independent copy, caches kept
     newpulse, _, n_map = concatenate_without_filter_function(pulses, return_identifier_mappings=True)
 
-    def chain_total_propagators():
-        # U = U_n ... U_2 U_1
-        return util.mdot([pls.total_propagator for pls in reversed(pulses)])
+    cumulative = []
+
+    def cumulative_propagators():
+        """U_g ... U_2 U_1 for every g, once (log-depth scan over the sequence)."""
+        if not cumulative:
+            per_object = {}
+            for pls in pulses:
+                if id(pls) not in per_object:
+                    per_object[id(pls)] = pls.total_propagator
+            cumulative.append(_running_products(np.array([per_object[id(pls)] for pls in pulses])))
+        return cumulative[0]
     if all('total_propagator' in pls._data for pls in pulses):
-        newpulse.total_propagator = chain_total_propagators()
+        newpulse.total_propagator = cumulative_propagators()[-1]
     if calc_pulse_correlation_FF or calc_second_order_FF is True:
         calc_filter_function = True         # both need every summand of the control matrix
     elif calc_filter_function is False:
         return newpulse
 
+    # distinct pulse objects (a randomized-benchmarking sequence draws 1000 gates from 24
+    # Cliffords): every per-pulse question below is asked once per object
+    position = {}
+    index = np.array([position.setdefault(id(pls), len(position)) for pls in pulses], dtype=np.int32)
+    distinct = [None]*len(position)
+    for pls, k in zip(pulses, index):
+        distinct[k] = pls
+    first_position = [int(p) for p in np.unique(index, return_index=True)[1]]
+
     # which noise operators of the new pulse does each pulse carry?
     new_ids = list(newpulse.n_oper_identifiers)
-    present = np.zeros((len(pulses), len(new_ids)), dtype=bool)
-    for p in range(len(pulses)):
-        for ident in n_map[p].values():
-            present[p, new_ids.index(ident)] = True
+    column = {ident: c for c, ident in enumerate(new_ids)}
+    carried = np.zeros((len(distinct), len(new_ids)), dtype=bool)
+    for k, p in enumerate(first_position):
+        carried[k, [column[ident] for ident in n_map[p].values()]] = True
+    present = carried[index]
     shared_n_opers = bool((present.sum(axis=0) > 1).any())
     if calc_second_order_FF and not present.all():
         warn('Second order FF requested but not all pulses have the same n_opers. '
@@ -740,11 +783,11 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
         calc_second_order_FF = False
 
     if omega is None:
-        cached_R = [pls.is_cached('control_matrix') for pls in pulses]
-        cached_w = [pls.is_cached('omega') for pls in pulses]
-        candidates = [pls.omega for pls, c in zip(pulses, cached_R if any(cached_R) else cached_w) if c]
-        distinct = {id(w): w for w in candidates}           # repeated pulse objects share arrays
-        equal_omega = all(np.array_equal(candidates[0], w) for w in distinct.values())
+        cached_R = [pls.is_cached('control_matrix') for pls in distinct]
+        cached_w = [pls.is_cached('omega') for pls in distinct]
+        candidates = [pls.omega for pls, c in zip(distinct, cached_R if any(cached_R) else cached_w)
+                      if c]
+        equal_omega = all(np.array_equal(candidates[0], w) for w in candidates[1:])
         if not equal_omega or not candidates:
             if calc_filter_function:
                 raise ValueError('Calculation of filter function forced but not all pulses '
@@ -764,14 +807,8 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
             newpulse.cache_filter_function(omega, order=2)
         return newpulse
 
-    # distinct pulse objects (a randomized-benchmarking sequence draws 1000 gates from 24
-    # Cliffords): evaluate / fetch each control matrix once
-    position = {}
-    index = np.array([position.setdefault(id(pls), len(position)) for pls in pulses], dtype=np.int32)
-    distinct = [None]*len(position)
-    for pls, k in zip(pulses, index):
-        distinct[k] = pls
-    seg = np.concatenate(([0], np.cumsum([len(pls.dt) for pls in pulses])))
+    # every distinct control matrix is evaluated / fetched once
+    seg = np.concatenate(([0], np.cumsum(np.array([len(pls.dt) for pls in distinct])[index])))
 
     def atomic_control_matrix(i):
         """Control matrix of the pulse at position i in the new pulse's operator order."""
@@ -789,18 +826,18 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
                 t=pls.t)
         return R
 
-    # Liouville representation of the propagators accumulated before each pulse
-    propagators_liouville = util.adot(
-        np.array([pls.total_propagator_liouville for pls in pulses[:-1]]))
+    # Liouville representation of the propagators accumulated before each pulse: the cumulative
+    # propagators in one batched device call (the representation is a homomorphism; the reference
+    # multiplies the pulses' Liouville propagators up instead, pulse_sequence.py:1827)
+    propagators_liouville = liouville_representation(cumulative_propagators()[:-1], newpulse.basis)
     if 'total_propagator' not in newpulse._data:
-        newpulse.total_propagator = chain_total_propagators()
+        newpulse.total_propagator = cumulative_propagators()[-1]
     newpulse.omega = omega
     newpulse._defer_by_products()           # total phases, Liouville propagator: on first read
     mode = 'correlations' if calc_pulse_correlation_FF or calc_second_order_FF else 'total'
     # the indexed kernel assumes a repeated pulse contributes the same rows everywhere, which
     # holds when every pulse carries every noise operator (else fall back to the plain rule)
     if len(distinct) < len(pulses) and present.all():
-        first_position = [int(np.nonzero(index == k)[0][0]) for k in range(len(distinct))]
         table = np.array([atomic_control_matrix(i) for i in first_position])
         total_phases = np.array([pls.get_total_phases(omega) for pls in distinct])
         control_matrix = numeric.calculate_control_matrix_from_atomic_indexed(

@@ -224,4 +224,6 @@ def test_config3_thousand_gate_sequence_by_concatenation():
     assert rel_err(scratch.get_filter_function(omega), F) < TOL
     # the plain (non-indexed) rule on the device as well
     R_plain = numeric.calculate_control_matrix_from_atomic(phases, table[draw], L)
-    assert rel_err(R_plain, R) < 1e-13
+    # (concatenate() takes the Liouville representation of the cumulative propagators, L above is the
+    # cumulative product of the pulses' Liouville propagators: 1000 products associated differently)
+    assert rel_err(R_plain, R) < 1e-11
