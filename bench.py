@@ -160,8 +160,13 @@ class AccumulateTimer:
             for e in pair:
                 _lib.check(lib.ffk_event_create(ctypes.byref(e)))
 
-    def arm(self, j):
+    def arm(self, j, gate_on_previous=False):
+        """Events of launch j; gate_on_previous: the launch stream first waits for the stop event of
+        launch j - 1 (another stream's accumulate kernel), so that the interval is this kernel's
+        execution, not its wait for the other pass's blocks to retire."""
         self._lib.check(self.lib.ffk_set_accumulate_events(self.pairs[j][0], self.pairs[j][1]))
+        if gate_on_previous and j > 0:
+            self._lib.check(self.lib.ffk_set_accumulate_gate(self.pairs[j - 1][1]))
 
     def disarm(self):
         self._lib.check(self.lib.ffk_set_accumulate_events(None, None))
@@ -190,6 +195,7 @@ def prewarm_clocks(step, sync, timer, max_s, adaptive, batch=100):
     while True:
         for i in range(batch):
             if i == batch - 1:
+                sync()              # the instrumented launch runs alone: a clean kernel time
                 timer.arm(0)
             step()
         timer.disarm()
@@ -473,7 +479,7 @@ def main():
 
     def step(i=None):
         if i is not None and i >= args.steps - n_ev:
-            timer.arm(i - (args.steps - n_ev))
+            timer.arm(i - (args.steps - n_ev), gate_on_previous=n_streams > 1)
         if use_dist:
             return ring.step()
         if n_streams == 1:

@@ -205,6 +205,7 @@ SIGNATURES = {
     'ffk_set_accumulate_variant': (c_int, [c_int]),
     'ffk_get_stats': (c_int, [POINTER(ffk_stats)]),
     'ffk_set_accumulate_events': (c_int, [c_void_p, c_void_p]),
+    'ffk_set_accumulate_gate': (c_int, [c_void_p]),
 }
 
 _lib = None

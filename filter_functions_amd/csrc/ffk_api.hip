@@ -25,7 +25,7 @@ namespace {
 thread_local std::string g_error;
 thread_local ffk_stats g_stats = {};
 int g_forced_chunks = 0;
-thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr, g_ev_gate = nullptr;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -263,6 +263,11 @@ int ffk_set_accumulate_variant(int variant) {
 int ffk_set_accumulate_events(void* start, void* stop) {
     g_ev_start = static_cast<hipEvent_t>(start);
     g_ev_stop = static_cast<hipEvent_t>(stop);
+    g_ev_gate = nullptr;
+    return FFK_OK;
+}
+int ffk_set_accumulate_gate(void* event) {
+    g_ev_gate = static_cast<hipEvent_t>(event);
     return FFK_OK;
 }
 int ffk_get_stats(ffk_stats* out) {
@@ -400,7 +405,13 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
                                      reinterpret_cast<const cplx*>(propagators),
                                      reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G, d, A,
                                      segtab, Tc, ops, nullptr, nullptr, s));
-    if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_start, s));
+    if (g_ev_start && g_ev_stop) {
+        // `gate`: an event of ANOTHER stream (the previous pass's accumulate kernel) that this
+        // stream waits for first, so that start..stop spans this kernel's execution and not its
+        // wait for the other pass's blocks to retire
+        if (g_ev_gate) FFK_HIP(hipStreamWaitEvent(s, g_ev_gate, 0));
+        FFK_HIP(hipEventRecord(g_ev_start, s));
+    }
     FFK_HIP(ffk::launch_accumulate(omega, W, segtab, ops, G, d, A, geo, Ypart, s));
     if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_stop, s));
     const size_t slab = size_t(A)*d*d*W;

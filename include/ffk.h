@@ -502,6 +502,12 @@ int ffk_get_stats(ffk_stats* out);
  * immediately after the accumulate kernel, on the stream it is launched on (so that a caller
  * can time the dominant kernel inside its own timed region).  Pass NULLs to switch off.     */
 int ffk_set_accumulate_events(void* start, void* stop);
+/* With several passes in flight on several streams, the accumulate kernel of one pass waits for the
+ * blocks of the other pass's to retire, and a start event recorded on its own stream would include
+ * that wait.  `event` (recorded on another stream; NULL = none) is waited for on the launch stream
+ * right before `start` is recorded; it applies to the calls that follow until reset, and
+ * ffk_set_accumulate_events resets it.                                                          */
+int ffk_set_accumulate_gate(void* event);
 
 #ifdef __cplusplus
 }
