@@ -101,6 +101,15 @@ class ResidentResult:
         if handle:
             self._lib.ffk_resident_destroy(handle)
 
+    # A copy of a pulse does not own device memory: deep copies and pickles of the owner drop the
+    # resident result (their cache entries are ordinary host arrays by then; the integral then takes
+    # the array route).  Sharing by reference (copy.copy of a pulse) is fine: one owner, refcounted.
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
     def evaluate(self, hamiltonian, dt, t, omega, basis, n_opers, n_coeffs):
         """One pass; returns (eigvals, eigvecs, propagators, filter_function) as arrays that view
         the handle's pinned memory (no copy)."""

@@ -60,6 +60,18 @@ class Basis(np.ndarray):
         self._atol = self._eps*self.d**3
         self._rtol = 0
 
+    def __reduce__(self):
+        # ndarray's pickle state plus the attributes of this subclass
+        reconstruct, args, state = super().__reduce__()
+        return reconstruct, args, state + ({'btype': self.btype, 'labels': self.labels, 'd': self.d},)
+
+    def __setstate__(self, state):
+        super().__setstate__(state[:-1])
+        self.btype, self.labels, self.d = state[-1]['btype'], state[-1]['labels'], state[-1]['d']
+        self._eps = np.finfo(complex).eps
+        self._atol = self._eps*self.d**3
+        self._rtol = 0
+
     def __array_wrap__(self, arr, context=None, return_scalar=False):
         # ufunc reductions to 0-d should give scalars, not 0-d Basis objects
         if np.ndim(arr) == 0:

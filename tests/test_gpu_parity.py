@@ -1955,3 +1955,26 @@ def test_d8_producer_consumer_kernel_ragged_shapes(G, A, W):
     finally:
         lib.ffk_set_segment_chunks(0)
         lib.ffk_set_accumulate_variant(0)
+
+
+def test_copies_and_pickles_of_a_pulse_with_a_resident_result():
+    """deepcopy / pickle of a pulse whose control matrix still lives in HBM: the copy holds host
+    arrays and no device memory, the original keeps working, both give the same numbers."""
+    import copy
+    import pickle
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs(G=12, W=200)
+    basis = ff.Basis.pauli(2)
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
+    F = pulse.get_filter_function(omega)
+    S = 1e-3/omega
+    ref = ff.infidelity(pulse, S, omega)
+    for clone in (copy.deepcopy(pulse), pickle.loads(pickle.dumps(pulse)), ff.concatenate([pulse])):
+        assert clone._resident is None and clone == pulse
+        assert clone.is_cached('control_matrix') and clone.is_cached('filter_function')
+        assert np.array_equal(clone.get_filter_function(omega), F)
+        assert rel_err(ff.infidelity(clone, S, omega), ref) < 1e-14          # array route
+        assert np.array_equal(clone.get_control_matrix(omega), pulse.get_control_matrix(omega))
+    shallow = copy.copy(pulse)
+    assert shallow._resident is pulse._resident
+    del pulse
+    assert rel_err(ff.infidelity(shallow, S, omega), ref) == 0                # resident route

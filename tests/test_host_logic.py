@@ -687,3 +687,16 @@ def test_resident_result_is_released_with_the_pulse(monkeypatch):
         assert StandIn.alive == 0 and F.shape == (1, 1, 2)
     finally:
         gc.enable()
+
+
+def test_basis_and_pulse_survive_pickling():
+    import copy
+    import pickle
+    for basis in (Basis.pauli(2), Basis.ggm(3)):
+        for clone in (pickle.loads(pickle.dumps(basis)), copy.deepcopy(basis)):
+            assert clone.btype == basis.btype and clone.d == basis.d and clone.labels == basis.labels
+            assert clone == basis and np.array_equal(np.asarray(clone), np.asarray(basis))
+    X, Z = util.paulis[1], util.paulis[3]
+    pulse = ff.PulseSequence([[X, [1.0, 2.0], 'X']], [[Z, [1.0, 1.0], 'Z']], [1.0, 0.5])
+    clone = pickle.loads(pickle.dumps(pulse))
+    assert clone == pulse and list(clone.n_oper_identifiers) == ['Z'] and clone.tau == 1.5
