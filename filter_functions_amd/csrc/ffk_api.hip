@@ -1820,6 +1820,7 @@ namespace {
 struct Block {
     void* ptr;
     size_t size;
+    int device = -1;      // device blocks belong to one device; pinned host blocks are portable
 };
 
 // Grow-only pools of device and pinned-host blocks: a PulseSequence is short-lived in user code
@@ -1829,11 +1830,12 @@ struct BlockPool {
     std::vector<Block> free_blocks;
     bool pinned;
     explicit BlockPool(bool p) : pinned(p) {}
-    int take(size_t bytes, Block* out) {
+    int take(size_t bytes, int device, Block* out) {
         std::lock_guard<std::mutex> lock(mu);
         int best = -1;
         for (int i = 0; i < int(free_blocks.size()); ++i)
             if (free_blocks[i].size >= bytes && free_blocks[i].size <= 2*bytes + (1 << 16) &&
+                (pinned || free_blocks[i].device == device) &&
                 (best < 0 || free_blocks[i].size < free_blocks[best].size))
                 best = i;
         if (best >= 0) {
@@ -1844,10 +1846,10 @@ struct BlockPool {
         const size_t want = align_up(bytes, size_t(1) << 16);
         void* p = nullptr;
         if (pinned)
-            FFK_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+            FFK_HIP(hipHostMalloc(&p, want, hipHostMallocPortable));
         else
             FFK_HIP(hipMalloc(&p, want));
-        *out = {p, want};
+        *out = {p, want, pinned ? -1 : device};
         return FFK_OK;
     }
     void give(Block b) {
@@ -1869,12 +1871,18 @@ struct BlockPool {
     }
 };
 BlockPool g_dev_pool(false), g_pin_pool(true);
-hipStream_t g_resident_stream = nullptr;
+// one stream per device for the resident passes, created on first use
+std::mutex g_resident_stream_mu;
+hipStream_t g_resident_streams[64] = {};
 
 int resident_stream(hipStream_t* out) {
-    if (!g_resident_stream)
-        FFK_HIP(hipStreamCreateWithFlags(&g_resident_stream, hipStreamNonBlocking));
-    *out = g_resident_stream;
+    int dev = 0;
+    FFK_HIP(hipGetDevice(&dev));
+    FFK_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_resident_stream_mu);
+    if (!g_resident_streams[dev])
+        FFK_HIP(hipStreamCreateWithFlags(&g_resident_streams[dev], hipStreamNonBlocking));
+    *out = g_resident_streams[dev];
     return FFK_OK;
 }
 
@@ -1918,7 +1926,7 @@ struct ffk_resident {
     int device = -1;
     int G = 0, d = 0, W = 0, N = 0, A = 0;
     bool valid = false;
-    Block dev = {nullptr, 0}, pin = {nullptr, 0};
+    Block dev = {nullptr, 0, -1}, pin = {nullptr, 0, -1};
     ResidentLayout L = {};
 };
 
@@ -1961,9 +1969,9 @@ int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, con
     if (r->device != dev || r->dev.size < L.end || r->pin.size < L.outputs_end) {
         g_dev_pool.give(r->dev);
         g_pin_pool.give(r->pin);
-        r->dev = r->pin = {nullptr, 0};
-        if (int rc = g_dev_pool.take(L.end, &r->dev)) return rc;
-        if (int rc = g_pin_pool.take(L.outputs_end, &r->pin)) return rc;
+        r->dev = r->pin = Block{nullptr, 0, -1};
+        if (int rc = g_dev_pool.take(L.end, dev, &r->dev)) return rc;
+        if (int rc = g_pin_pool.take(L.outputs_end, dev, &r->pin)) return rc;
         r->device = dev;
     }
     r->G = G; r->d = d; r->W = W; r->N = N; r->A = A; r->L = L;
@@ -2021,9 +2029,20 @@ int ffk_resident_timing(ffk_resident* r, double* seconds) {
     return FFK_OK;
 }
 
+namespace {
+int on_owning_device(const ffk_resident* r) {
+    int dev = -1;
+    FFK_HIP(hipGetDevice(&dev));
+    FFK_REQUIRE(dev == r->device, "resident result lives on device %d, current device is %d",
+                r->device, dev);
+    return FFK_OK;
+}
+}  // namespace
+
 int ffk_resident_control_matrix(ffk_resident* r, double* control_matrix) {
     FFK_REQUIRE(r && r->valid, "no resident result");
     FFK_REQUIRE(control_matrix, "NULL argument");
+    if (int rc = on_owning_device(r)) return rc;
     hipStream_t s;
     if (int rc = resident_stream(&s)) return rc;
     const unsigned char* dp = static_cast<const unsigned char*>(r->dev.ptr);
@@ -2048,6 +2067,7 @@ int ffk_resident_infidelity(ffk_resident* r, const double* spectrum, int s_ndim,
     FFK_REQUIRE(r && r->valid, "no resident result");
     FFK_REQUIRE(spectrum && idx && infid, "NULL argument");
     FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3 && n_idx >= 1 && n_idx <= r->A && d >= 1, "bad spectrum arguments");
+    if (int rc = on_owning_device(r)) return rc;
     const int W = r->W, A = r->A;
     const size_t rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? size_t(n_idx) : size_t(n_idx)*n_idx);
     const size_t n_out = s_ndim == 3 ? size_t(n_idx)*n_idx : size_t(n_idx);
@@ -2060,10 +2080,10 @@ int ffk_resident_infidelity(ffk_resident* r, const double* spectrum, int s_ndim,
     hipStream_t s;
     if (int rc = resident_stream(&s)) return rc;
     const bool fits = stage <= L.inputs_end;
-    Block extra = {nullptr, 0};
+    Block extra = {nullptr, 0, -1};
     unsigned char* stage_ptr = hp;
     if (!fits) {
-        if (int rc = g_pin_pool.take(stage, &extra)) return rc;
+        if (int rc = g_pin_pool.take(stage, r->device, &extra)) return rc;
         stage_ptr = static_cast<unsigned char*>(extra.ptr);
     }
     double* hs = reinterpret_cast<double*>(stage_ptr);
