@@ -53,8 +53,16 @@ for case in range(n_cases):
     D, V, Q = orc.diagonalize(H, dt)
     R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), pulse.n_opers,
                                             pulse.n_coeffs, dt)
-    errs = {'R': rel(pulse.get_control_matrix(omega), R_ref),
-            'F': rel(pulse.get_filter_function(omega), orc.filter_function(R_ref))}
+    if case % 2:
+        # array route: control matrix first, filter function from it
+        errs = {'R': rel(pulse.get_control_matrix(omega), R_ref),
+                'F': rel(pulse.get_filter_function(omega), orc.filter_function(R_ref))}
+    else:
+        # resident route (round 2): one library call, control matrix fetched from HBM afterwards,
+        # infidelity below integrated on the resident F
+        errs = {'F': rel(pulse.get_filter_function(omega), orc.filter_function(R_ref))}
+        assert W == 0 or pulse._resident is not None
+        errs['R'] = rel(pulse.get_control_matrix(omega), R_ref)
     if W > 1:
         S = 1/(1 + omega**2)
         idx = np.arange(A)
