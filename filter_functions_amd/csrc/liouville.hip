@@ -32,42 +32,48 @@ __global__ void build_bop_kernel(const cplx* __restrict__ basis, int N, int d, i
     Bop[static_cast<size_t>(d*d + ab)*Npad + j] = v.im;
 }
 
+constexpr int kConjPerBlock = 8;
+
 template <int D>
 __global__ __launch_bounds__(64) void conjugate_basis_kernel(const cplx* __restrict__ U,
                                                              const cplx* __restrict__ basis, int N,
                                                              int Npad, int want_imag,
                                                              double* __restrict__ AopRe,
                                                              double* __restrict__ AopIm) {
+    // one block conjugates kConjPerBlock basis elements with the same unitary (U staged once; one
+    // block per element was launch-rate bound: 131072 blocks for d = 16, batch 512)
     __shared__ cplx Us[D][D];
     __shared__ cplx C[D][D];
     __shared__ cplx CU[D][D];
-    const int i = blockIdx.x, bt = blockIdx.y, lane = threadIdx.x;
-    for (int e = lane; e < D*D; e += 64) {
-        Us[e / D][e % D] = U[static_cast<size_t>(bt)*D*D + e];
-        C[e / D][e % D] = basis[static_cast<size_t>(i)*D*D + e];
-    }
-    __syncthreads();
-    for (int e = lane; e < D*D; e += 64) {
-        const int r = e / D, c = e % D;
-        cplx acc = {0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < D; ++k) cmac(acc, C[r][k], Us[k][c]);
-        CU[r][c] = acc;
-    }
-    __syncthreads();
+    const int bt = blockIdx.y, lane = threadIdx.x;
+    for (int e = lane; e < D*D; e += 64) Us[e / D][e % D] = U[static_cast<size_t>(bt)*D*D + e];
     const size_t K = (2*D*D + 3)/4*4;  // padded to the MFMA k-step; pad rows stay zero
     double* are = AopRe + static_cast<size_t>(bt)*K*Npad;
     double* aim = AopIm + static_cast<size_t>(bt)*K*Npad;
-    for (int e = lane; e < D*D; e += 64) {
-        const int a = e / D, b = e % D;  // CB[a][b] = sum_k conj(U[k][a]) CU[k][b]
-        cplx acc = {0.0, 0.0};
+    const int i1 = min(N, static_cast<int>(blockIdx.x + 1)*kConjPerBlock);
+    for (int i = blockIdx.x*kConjPerBlock; i < i1; ++i) {
+        __syncthreads();                 // Us staged / previous element's C and CU consumed
+        for (int e = lane; e < D*D; e += 64) C[e / D][e % D] = basis[static_cast<size_t>(i)*D*D + e];
+        __syncthreads();
+        for (int e = lane; e < D*D; e += 64) {
+            const int r = e / D, c = e % D;
+            cplx acc = {0.0, 0.0};
 #pragma unroll
-        for (int k = 0; k < D; ++k) cmac_conj(acc, Us[k][a], CU[k][b]);
-        are[static_cast<size_t>(e)*Npad + i] = acc.re;
-        are[static_cast<size_t>(D*D + e)*Npad + i] = -acc.im;
-        if (want_imag) {
-            aim[static_cast<size_t>(e)*Npad + i] = acc.im;
-            aim[static_cast<size_t>(D*D + e)*Npad + i] = acc.re;
+            for (int k = 0; k < D; ++k) cmac(acc, C[r][k], Us[k][c]);
+            CU[r][c] = acc;
+        }
+        __syncthreads();
+        for (int e = lane; e < D*D; e += 64) {
+            const int a = e / D, b = e % D;  // CB[a][b] = sum_k conj(U[k][a]) CU[k][b]
+            cplx acc = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < D; ++k) cmac_conj(acc, Us[k][a], CU[k][b]);
+            are[static_cast<size_t>(e)*Npad + i] = acc.re;
+            are[static_cast<size_t>(D*D + e)*Npad + i] = -acc.im;
+            if (want_imag) {
+                aim[static_cast<size_t>(e)*Npad + i] = acc.im;
+                aim[static_cast<size_t>(D*D + e)*Npad + i] = acc.re;
+            }
         }
     }
 }
@@ -173,15 +179,19 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
     double* AopIm = reinterpret_cast<double*>(p);
     if (batch > 65535 || d*d > 65535) return hipErrorInvalidValue;
 
-    // zero everything once: padding rows (K) and columns (N -> Npad) must contribute nothing
-    hipError_t err = hipMemsetAsync(ws, 0, liouville_workspace_bytes(batch, d, N), stream);
-    if (err != hipSuccess) return err;
+    // padding rows (K) and columns (N -> Npad) must contribute nothing: zero the operands once --
+    // unless there is no padding at all (d^2 a multiple of 16, e.g. d = 4, 8, 16)
+    if (Npad != N || K != 2*d*d) {
+        hipError_t err = hipMemsetAsync(ws, 0, liouville_workspace_bytes(batch, d, N), stream);
+        if (err != hipSuccess) return err;
+    }
     hipLaunchKernelGGL(build_bop_kernel, dim3((Npad + 63)/64, d*d), dim3(64), 0, stream, basis, N, d,
                        Npad, Bop);
     switch (d) {
 #define FFK_CASE(D)                                                                              \
     case D:                                                                                      \
-        hipLaunchKernelGGL(conjugate_basis_kernel<D>, dim3(N, batch), dim3(64), 0, stream, U,    \
+        hipLaunchKernelGGL(conjugate_basis_kernel<D>,                                            \
+                           dim3((N + kConjPerBlock - 1)/kConjPerBlock, batch), dim3(64), 0, stream, U, \
                            basis, N, Npad, want_imag, AopRe, AopIm);                             \
         break;
         FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
