@@ -439,6 +439,7 @@ def main():
     # for it (0.163 ms/step on one rank), with more the collective falls into the window of the
     # small kernels between two accumulate launches.
     depth = max(2, args.pipeline_depth + (args.pipeline_depth & 1))      # even
+    depth = max(depth, 2*max(1, args.streams))
     n_streams = 1 if use_dist else max(1, args.streams)
     pipes = [make_pipe() for _ in range(depth if use_dist else n_streams)]
     pipe = pipes[0]
@@ -447,12 +448,13 @@ def main():
         # Two explicitly created streams: HIP spreads created streams over the hardware queues,
         # whereas torch's default stream and one side stream shared a queue on this system (every
         # kernel of the trace on one queue, in submission order: nothing overlapped).
-        compute_stream = torch.cuda.Stream(device=device)
+        compute_streams = [torch.cuda.Stream(device=device) for _ in range(max(1, args.streams))]
+        compute_stream = compute_streams[0]
         comm_stream = torch.cuda.Stream(device=device)
         torch.cuda.synchronize(device)
         # FFK_GATHER: 'auto' (default: the one-sided all-gather of csrc/peer.hip if its set-up and a
         # verified round trip succeed on every rank, else the RCCL collective), 'push', 'rccl'
-        ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_stream,
+        ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_streams,
                                comm_stream, world, rank, gather=os.environ.get('FFK_GATHER', 'auto'))
     elif n_streams > 1:
         # Steps are independent passes (one pulse each): with two passes in flight on two HIP
@@ -479,7 +481,7 @@ def main():
 
     def step(i=None):
         if i is not None and i >= args.steps - n_ev:
-            timer.arm(i - (args.steps - n_ev), gate_on_previous=n_streams > 1)
+            timer.arm(i - (args.steps - n_ev), gate_on_previous=max(1, args.streams) > 1)
         if use_dist:
             return ring.step()
         if n_streams == 1:
@@ -526,7 +528,7 @@ def main():
         # the other gather method on the same workload, 200 steps, for the record
         other = 'rccl' if ring.gather == 'push' else 'push'
         try:
-            ring_b = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_stream,
+            ring_b = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_streams,
                                      comm_stream, world, rank,
                                      gather=other if other == 'rccl' else 'auto')
             if ring_b.gather == other:
@@ -610,7 +612,7 @@ def main():
                        'sharding': ('omega blocks, ' + ('one-sided all-gather of F over IPC-mapped '
                                     'peer memory (csrc/peer.hip)' if ring.gather == 'push' else
                                     'RCCL all-gather of F')) if use_dist else 'none',
-                       'passes_in_flight': depth if use_dist else n_streams},
+                       'passes_in_flight': max(1, args.streams)},
             'single_stream_ms_per_step': latency_ms, 'gather_ab': gather_ab,
             'prewarm': prewarm,
             'roofline': {

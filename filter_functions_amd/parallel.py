@@ -317,8 +317,13 @@ class ShardedStepRing:
         if self.depth < 2 or self.depth % 2:
             raise ValueError('the ring needs an even number (>= 2) of buffer sets')
         self.world, self.rank, self.group, self.n_omega = world, rank, group, n_omega
-        self.compute_stream, self.comm_stream = compute_stream, comm_stream
-        self.streams = streams if streams is not None else _CudaStreams(compute_stream, comm_stream)
+        # compute_stream may be a list: consecutive steps then go to the streams round robin, so that
+        # the latency-bound launches of one pass run beside the accumulate kernel of another (as in
+        # the N = 1 bench); every step then waits for the release of its own buffer set
+        self.compute_streams = list(compute_stream) if isinstance(compute_stream, (list, tuple)) \
+            else [compute_stream]
+        self.compute_stream, self.comm_stream = self.compute_streams[0], comm_stream
+        self.streams = streams if streams is not None else _CudaStreams(self.compute_stream, comm_stream)
         first = self.pipes[0]
         device, A = first.filter_function.device, first.A
         w0, w1 = shard_bounds(n_omega, world, rank)
@@ -390,10 +395,14 @@ class ShardedStepRing:
         k = c % self.depth
         pipe = self.pipes[k]
         half = self.depth//2
-        if c >= half and c % half == 0:
-            st.wait(self.compute_stream, self.free_events[(c - half) % self.depth])
-        pipe.launch(stream=st.handle(self.compute_stream), with_infidelity=False)
-        ready = st.record(self.compute_stream)
+        compute = self.compute_streams[c % len(self.compute_streams)]
+        if len(self.compute_streams) == 1:
+            if c >= half and c % half == 0:
+                st.wait(compute, self.free_events[(c - half) % self.depth])
+        elif c >= self.depth:
+            st.wait(compute, self.free_events[k])       # the gather of step c - depth read set k
+        pipe.launch(stream=st.handle(compute), with_infidelity=False)
+        ready = st.record(compute)
         with st.on(self.comm_stream):
             st.wait(self.comm_stream, ready)
             if self.peer is not None:

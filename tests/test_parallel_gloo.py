@@ -132,10 +132,11 @@ class _RecordingStreams:
     checked: before step c overwrites buffer set c % depth, the compute stream must have waited
     for the communication work of step c - depth."""
 
-    def __init__(self, depth):
+    def __init__(self, depth, compute_names=('compute',)):
         self.depth = depth
-        self.position = {'compute': 0, 'comm': 0}      # ops recorded so far per stream
-        self.waited = {'compute': {}, 'comm': {}}      # stream -> {other stream: position}
+        names = tuple(compute_names) + ('comm',)
+        self.position = {name: 0 for name in names}    # ops recorded so far per stream
+        self.waited = {name: {} for name in names}     # stream -> {other stream: position}
         self.done_position = []                         # comm position after gather + integral of step i
         self.launches = 0
         self.waits_on_compute = 0
@@ -149,7 +150,7 @@ class _RecordingStreams:
     def wait(self, stream, event):
         other, pos = event
         self.waited[stream][other] = max(self.waited[stream].get(other, 0), pos)
-        if stream == 'compute':
+        if stream != 'comm':
             self.waits_on_compute += 1
 
     def on(self, stream):
@@ -159,11 +160,11 @@ class _RecordingStreams:
     def handle(self, stream):
         return stream
 
-    def check_launch(self):
+    def check_launch(self, stream='compute'):
         c = self.launches
         self.launches += 1
         if c >= self.depth:
-            assert self.waited['compute'].get('comm', 0) >= self.done_position[c - self.depth], \
+            assert self.waited[stream].get('comm', 0) >= self.done_position[c - self.depth], \
                 f'step {c} reuses buffer set {c % self.depth} before the gather of step {c - self.depth}'
 
 
@@ -183,8 +184,8 @@ class _FakePipe:
         return coeff[:, :, None]*omega[None, None, :]*(step + 1)
 
     def launch(self, stream, with_infidelity):
-        assert stream == 'compute' and not with_infidelity
-        self.streams.check_launch()
+        assert stream.startswith('compute') and not with_infidelity
+        self.streams.check_launch(stream)
         self.filter_function.copy_(self.model(self.omega_block, self.A, self.step_counter[0]))
         self.step_counter[0] += 1
 
@@ -205,7 +206,7 @@ class _FakePipe:
         return self.integrate(F_full, omega, S, self.d)
 
 
-def _ring_worker(rank, world, port, n_omega, depth, n_steps, out_dir):
+def _ring_worker(rank, world, port, n_omega, depth, n_steps, out_dir, n_compute=1):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -217,10 +218,12 @@ def _ring_worker(rank, world, port, n_omega, depth, n_steps, out_dir):
     omega = np.geomspace(0.1, 50.0, n_omega)
     S = 1e-3/omega
     w0, w1 = shard_bounds(n_omega, world, rank)
-    streams = _RecordingStreams(depth)
+    names = ['compute'] if n_compute == 1 else [f'compute{j}' for j in range(n_compute)]
+    streams = _RecordingStreams(depth, names)
     counter = [0]
     pipes = [_FakePipe(omega[w0:w1], A, d, streams, counter) for _ in range(depth)]
-    ring = ShardedStepRing(pipes, n_omega, omega, S, 'compute', 'comm', world, rank, streams=streams)
+    ring = ShardedStepRing(pipes, n_omega, omega, S, names if n_compute > 1 else 'compute', 'comm',
+                           world, rank, streams=streams)
     results = [ring.step().clone().numpy() for _ in range(n_steps)]
     np.savez(os.path.join(out_dir, f'ring{rank}.npz'), results=np.array(results),
              waits=streams.waits_on_compute)
@@ -244,3 +247,19 @@ def test_sharded_step_ring(tmp_path, n_omega, depth):
         assert got['results'].shape == ref.shape
         assert np.abs(got['results'] - ref).max() <= 1e-14*np.abs(ref).max()
         assert int(got['waits']) == (n_steps - 1)//(depth//2)
+
+
+def test_sharded_step_ring_with_several_compute_streams(tmp_path):
+    """Steps distributed round robin over three compute streams (passes in flight): every step's
+    stream waits for the release of its own buffer set, results unchanged."""
+    world, depth, n_steps, n_omega = 2, 6, 20, 24
+    mp.spawn(_ring_worker, args=(world, _free_port(), n_omega, depth, n_steps, str(tmp_path), 3),
+             nprocs=world, join=True)
+    omega = torch.from_numpy(np.geomspace(0.1, 50.0, n_omega))
+    S = 1e-3/omega
+    ref = np.array([_FakePipe.integrate(_FakePipe.model(omega, 3, step), omega, S, 4).numpy()
+                    for step in range(n_steps)])
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f'ring{rank}.npz'))
+        assert np.abs(got['results'] - ref).max() <= 1e-14*np.abs(ref).max()
+        assert int(got['waits']) == n_steps - depth
