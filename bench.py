@@ -189,7 +189,7 @@ def prewarm_clocks(step, sync, timer, max_s, adaptive, batch=100):
     """Untimed: run `step` in batches until the accumulate kernel's HIP-event time (last step of a
     batch) changes by less than 1 % between batches twice in a row and at least 0.3 s have
     passed, or `max_s` seconds are over.  Not adaptive (N > 1: every rank must issue the same
-    collectives): a fixed 3 batches."""
+    collectives): a fixed 30 batches."""
     t0 = time.perf_counter()
     trace, steps, stable = [], 0, 0
     while True:
@@ -204,7 +204,7 @@ def prewarm_clocks(step, sync, timer, max_s, adaptive, batch=100):
         trace.append(timer.read_ms(1)[0])
         elapsed = time.perf_counter() - t0
         if not adaptive:
-            if steps >= 3*batch:
+            if steps >= 30*batch:
                 break
             continue
         if len(trace) > 1 and abs(trace[-1] - trace[-2]) <= 0.01*trace[-1]:
@@ -217,7 +217,7 @@ def prewarm_clocks(step, sync, timer, max_s, adaptive, batch=100):
                 accumulate_ms_first_batch=trace[0], accumulate_ms_last_batch=trace[-1],
                 rule=('adaptive: batches of 100 steps until the accumulate kernel time is stable '
                       f'within 1 % twice in a row and 0.3 s have passed or {max_s} s' if adaptive
-                      else 'fixed 300 steps (N > 1: ranks must issue identical collectives)'))
+                      else 'fixed 3000 steps (N > 1: ranks must issue identical collectives)'))
 
 
 # ---- the other BASELINE configurations, timed in-process after the headline -----------------------
