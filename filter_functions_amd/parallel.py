@@ -343,6 +343,8 @@ class ShardedStepRing:
         self.free_events = [None]*self.depth
         self.count = 0
         self.count_offset = 0
+        self._gloo = None
+        self._real_views = {}
         # gather = 'push': the one-sided all-gather (PeerGather) instead of the collective; needs
         # equal blocks and real streams; 'auto': try it, verify one round, else the collective
         self.peer = None
@@ -414,11 +416,16 @@ class ShardedStepRing:
             elif self.equal_shards:
                 # one collective into a preallocated buffer; the integral reads the shards in place
                 send, recv = pipe.filter_function, self.gathered[k]
-                if dist.get_backend(self.group) == 'gloo':         # gloo has no flat all-gather
+                if self._gloo is None:
+                    self._gloo = dist.get_backend(self.group) == 'gloo'
+                if self._gloo:                                     # gloo has no flat all-gather
                     dist.all_gather(list(recv.unbind(0)), send, group=self.group)
                 else:
-                    dist.all_gather_into_tensor(self.torch.view_as_real(recv),
-                                                self.torch.view_as_real(send), group=self.group)
+                    views = self._real_views.get(k)
+                    if views is None:      # complex tensors travel as interleaved reals; views cached
+                        views = self._real_views[k] = (self.torch.view_as_real(recv),
+                                                       self.torch.view_as_real(send))
+                    dist.all_gather_into_tensor(views[0], views[1], group=self.group)
                 out = pipe.infidelity_from_shards(recv, self.omega_full, self.spectrum_full, self.idx,
                                                   self.infid[k], stream=st.handle(self.comm_stream))
             else:
