@@ -49,6 +49,7 @@ SIGNATURES = {
     'ffk_get_device': (c_int, [POINTER(c_int)]),
     'ffk_device_info': (c_int, [ctypes.c_char_p, c_int, POINTER(c_int), POINTER(c_size_t)]),
     'ffk_malloc': (c_int, [POINTER(c_void_p), c_size_t]),
+    'ffk_malloc_finegrained': (c_int, [POINTER(c_void_p), c_size_t]),
     'ffk_free': (c_int, [c_void_p]),
     'ffk_memset': (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
     'ffk_memcpy_h2d': (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -174,6 +174,17 @@ int ffk_malloc(void** dptr, size_t bytes) {
     FFK_HIP(hipMalloc(dptr, bytes ? bytes : 1));
     return FFK_OK;
 }
+int ffk_malloc_finegrained(void** dptr, size_t bytes) {
+    FFK_REQUIRE(dptr, "dptr is NULL");
+    // fine-grained (uncached at L2 for other agents' writes): flag words polled by a running kernel
+    // while a peer GPU writes them must not be served from a stale L2 line
+    hipError_t e = hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        FFK_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    }
+    return FFK_OK;
+}
 int ffk_free(void* dptr) {
     FFK_HIP(hipFree(dptr));
     return FFK_OK;

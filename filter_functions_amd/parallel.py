@@ -136,14 +136,15 @@ class _RawDeviceBuffer:
     allocation, so buffers that other ranks map must not be sub-allocations of PyTorch's caching
     allocator.  ``tensor()`` views the memory as a torch tensor (``__cuda_array_interface__``)."""
 
-    def __init__(self, shape, typestr, itemsize):
+    def __init__(self, shape, typestr, itemsize, finegrained=False):
         import ctypes
         from . import _lib
         self._lib = _lib.load()
         self.shape = tuple(int(n) for n in shape)
         self.nbytes = int(np.prod(self.shape))*itemsize
         ptr = ctypes.c_void_p()
-        _lib.check(self._lib.ffk_malloc(ctypes.byref(ptr), max(self.nbytes, 16)))
+        allocate = self._lib.ffk_malloc_finegrained if finegrained else self._lib.ffk_malloc
+        _lib.check(allocate(ctypes.byref(ptr), max(self.nbytes, 16)))
         self.ptr = ptr.value
         _lib.check(self._lib.ffk_memset(ctypes.c_void_p(self.ptr), 0, max(self.nbytes, 16), None))
         _lib.check(self._lib.ffk_device_synchronize())
@@ -193,9 +194,12 @@ class PeerGather:
         self._opened = []
         mine = None
         try:
-            self._sets = [_RawDeviceBuffer((world,) + tuple(block_shape), '<c16', 16)
+            # the gather buffers are written by peer GPUs and read by local kernels every `depth`
+            # steps: fine-grained as well, so that no reader depends on an L2 line of an earlier step
+            self._sets = [_RawDeviceBuffer((world,) + tuple(block_shape), '<c16', 16, finegrained=True)
                           for _ in range(depth)]
-            self._words = _RawDeviceBuffer((2, world), '<i8', 8)          # [flags | acks]
+            # [flags | acks]: polled by running kernels while peers write them -> fine-grained
+            self._words = _RawDeviceBuffer((2, world), '<i8', 8, finegrained=True)
             self.gathered = [b.tensor(device) for b in self._sets]
             words = self._words.tensor(device)
             self.flags, self.acks = words[0], words[1]

@@ -66,6 +66,9 @@ int ffk_device_info(char* name, int len, int* compute_units, size_t* global_mem_
 /* ---- device memory, streams, events (so a host language without a HIP binding can keep
  *      data resident and time kernels on the stream they run on) --------------------------- */
 int ffk_malloc(void** dptr, size_t bytes);
+/* device memory that other agents (peer GPUs) may write while a local kernel polls it: fine-grained
+ * coherence (hipExtMallocWithFlags), plain hipMalloc if the runtime refuses */
+int ffk_malloc_finegrained(void** dptr, size_t bytes);
 int ffk_free(void* dptr);
 int ffk_memset(void* dptr, int value, size_t bytes, void* stream);
 int ffk_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
