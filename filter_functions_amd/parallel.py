@@ -352,7 +352,9 @@ class ShardedStepRing:
         # gather = 'push': the one-sided all-gather (PeerGather) instead of the collective; needs
         # equal blocks and real streams; 'auto': try it, verify one round, else the collective
         self.peer = None
-        if gather in ('push', 'auto') and self.equal_shards and streams is None and world > 1:
+        # (one rank: only with the test hook FFK_FORCE_COLLECTIVE, to exercise / time the path)
+        if gather in ('push', 'auto') and self.equal_shards and streams is None and \
+                (world > 1 or os.environ.get('FFK_FORCE_COLLECTIVE')):
             self.peer = self._try_peer_gather(first, group, required=(gather == 'push'))
         if self.peer is not None:
             self.gathered = self.peer.gathered
