@@ -381,7 +381,7 @@ def main():
     ap.add_argument('--no-pmc', action='store_true',
                     help='skip the rocprofv3 --pmc child runs that measure the HBM traffic')
     ap.add_argument('--no-configs', action='store_true', help='headline only (no configs 3-5)')
-    ap.add_argument('--streams', type=int, default=3,
+    ap.add_argument('--streams', type=int, default=2,
                     help='N = 1: independent passes in flight (round robin over this many HIP streams, '
                          'one buffer set each); 1 = strictly one pass after the other')
     ap.add_argument('--no-prewarm', action='store_true')
