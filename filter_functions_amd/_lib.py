@@ -193,7 +193,6 @@ SIGNATURES = {
                                                 POINTER(c_void_p)]),
     'ffk_resident_infidelity': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                         c_void_p]),
-    'ffk_peer_last_error': (c_char_p, []),
     'ffk_ipc_get_handle': (c_int, [c_void_p, c_void_p]),
     'ffk_ipc_open_handle': (c_int, [c_void_p, POINTER(c_void_p)]),
     'ffk_ipc_close_handle': (c_int, [c_void_p]),

@@ -133,6 +133,11 @@ double accumulate_flops(int W, int A, int G, int d) {
 
 }  // namespace
 
+namespace ffk {
+// for the translation units that implement part of the C ABI themselves (peer.hip)
+void set_last_error(const char* message) { g_error = message; }
+}  // namespace ffk
+
 extern "C" {
 
 const char* ffk_last_error(void) { return g_error.c_str(); }

@@ -40,6 +40,9 @@ __host__ __device__ constexpr int accum_jb(int d) {
 
 inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1)/a*a; }
 
+// message behind ffk_last_error() (thread local; ffk_api.hip)
+void set_last_error(const char* message);
+
 // ---- eigh.hip --------------------------------------------------------------------------------
 // eigvals (G,d), eigvecs (G,d,d), seg_prop (G,d,d) = V exp(-i D dt) V^dag; status (G) ints:
 // 1 for every segment whose Jacobi iteration failed to converge, else 0.

@@ -92,14 +92,13 @@ __global__ __launch_bounds__(64) void peer_wait_kernel(const long long* __restri
 extern "C" {
 
 namespace {
-thread_local char g_peer_error[256];
 int peer_fail(int code, const char* what, hipError_t e) {
-    snprintf(g_peer_error, sizeof g_peer_error, "%s failed: %s", what, hipGetErrorString(e));
+    char message[256];
+    snprintf(message, sizeof message, "%s failed: %s", what, hipGetErrorString(e));
+    ffk::set_last_error(message);
     return code;
 }
 }  // namespace
-
-const char* ffk_peer_last_error(void) { return g_peer_error; }
 
 int ffk_ipc_get_handle(const void* dptr, void* handle) {
     if (!dptr || !handle) return FFK_EINVAL;

@@ -471,7 +471,6 @@ int ffk_resident_infidelity(ffk_resident* handle, const double* spectrum, int s_
  * word of this rank, the acknowledgement word of this rank); `acks` / `flags` of push / wait are
  * this rank's own words, one per peer.  filter_functions_amd/parallel.py holds the protocol.     */
 #define FFK_IPC_HANDLE_BYTES 64
-const char* ffk_peer_last_error(void);
 int ffk_ipc_get_handle(const void* dptr, void* handle);
 int ffk_ipc_open_handle(const void* handle, void** dptr);
 int ffk_ipc_close_handle(void* dptr);
