@@ -97,6 +97,26 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
     const int g0 = blockIdx.z*chunk_len + sub*sub_len;
     const int g1 = min(min(G, static_cast<int>(blockIdx.z + 1)*chunk_len), g0 + sub_len);
 
+    // Tile of the FIRST segment: generated by all waves of the sub-chunk together (every NWS-th entry
+    // each, the per-frequency trigonometry recomputed by each wave), after the producer has staged
+    // the table rows.  Left to the producer alone, its dependent chains kept the twelve consumer
+    // waves of a block waiting ~2.5 us of the block's ~83 us.
+    auto generate_first_share = [&]() {
+        const double* st = rows;                          // slot 0 = row g0
+        cplx* tile = lds + lane;                          // buffer 0
+        const double dtg = st[0];
+        cplx ph;
+        sincos_pi<true>(om*st[1], &ph.im, &ph.re);
+        double sa, ca;
+        sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
+        constexpr auto& sl = PcEntries<D>::slots;
+        for (int k = wl; k < PcEntries<D>::count; k += NWS) {
+            const int e = sl.v[k];
+            const double* r = st + seg_rec(e);
+            tile[e*64] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+        }
+    };
+
     if (producer) {
         // ---- producer: operands + table rows -> LDS, integral tile of the next segment ----------
         // Static issue priority: the producer's work is a chain of dependent operations (argument
@@ -159,10 +179,9 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
                 reinterpret_cast<cplx*>(rows + S)[lane] = r1;
             }
             store_ops(lds + TILE, o0);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            generate(0, 0);
         }
+        __syncthreads();                              // rows of g0 visible to the whole sub-chunk
+        if (g0 < g1) generate_first_share();
         __syncthreads();
         for (int it = 0; it < sub_len; ++it) {
             const int g = g0 + it;
@@ -204,6 +223,8 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
         };
         if (g0 < g1) load_T(g0);
 #endif
+        __syncthreads();
+        if (g0 < g1) generate_first_share();
         __syncthreads();
         for (int it = 0; it < sub_len; ++it) {
             const int g = g0 + it;
