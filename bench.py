@@ -495,36 +495,54 @@ def main():
     def sync():
         torch.cuda.synchronize(device)
 
-    prewarm = None
-    if not args.no_prewarm:
-        prewarm = prewarm_clocks(step, sync, timer, args.prewarm_max_s, adaptive=not use_dist)
-    for _ in range(args.warmup):
-        step()
-    timer.disarm()
-    torch.cuda.synchronize(device)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        infid = step(i)
-    t_issue = time.perf_counter() - t0          # host time to enqueue all steps
-    torch.cuda.synchronize(device)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    elapsed = time.perf_counter() - t0
-    timer.disarm()
+    def measure():
+        """Pre-warm, W warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize."""
+        warm = None
+        if not args.no_prewarm:
+            warm = prewarm_clocks(step, sync, timer, args.prewarm_max_s, adaptive=not use_dist)
+        for _ in range(args.warmup):
+            step()
+        timer.disarm()
+        torch.cuda.synchronize(device)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            last = step(i)
+        issue = time.perf_counter() - t0        # host time to enqueue all steps
+        torch.cuda.synchronize(device)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        total = time.perf_counter() - t0
+        timer.disarm()
+        return warm, last, issue, total
+
+    prewarm, infid, t_issue, elapsed = measure()
+    gather_fallback = None
+    if use_dist and ring.peer is not None:
+        # did a poll of the one-sided gather time out on ANY rank?  (collective decision; the error
+        # word is 0 / 1 / 2)  If so the numbers above are void: measure again through RCCL.
+        torch.cuda.synchronize(device)
+        code = ring.peer.error.to(torch.int32).clone()
+        dist.all_reduce(code, op=dist.ReduceOp.MAX)
+        if int(code.item()) != 0:
+            gather_fallback = f'one-sided all-gather timed out (code {int(code.item())}); measured again with RCCL'
+            ring.peer.close()
+            ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_streams,
+                                   comm_stream, world, rank, gather='rccl')
+            prewarm, infid, t_issue, elapsed = measure()
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
     pipe.check_status()                          # eigensolver flags of the device-resident run
-    gather_ab = None
-    if use_dist:
-        if ring.peer is not None:
-            ring.peer.check()                    # no poll of the one-sided gather timed out
+    gather_ab = {'fallback': gather_fallback} if gather_fallback else None
+    if gather_fallback:
+        os.environ['FFK_GATHER'] = 'rccl'        # the strong-scaled configs below follow suit
+    if use_dist and not gather_fallback:
         # the other gather method on the same workload, 200 steps, for the record
         other = 'rccl' if ring.gather == 'push' else 'push'
         try:
@@ -544,6 +562,8 @@ def main():
                 tb = torch.tensor([time.perf_counter() - tb], dtype=torch.float64, device=device)
                 dist.all_reduce(tb, op=dist.ReduceOp.MAX)
                 gather_ab = {'headline': ring.gather, other + '_ms_per_step': float(tb.item())/200*1e3}
+                if ring_b.peer is not None:
+                    gather_ab['push_error_word'] = int(ring_b.peer.error.cpu().item())
         except RuntimeError as err:
             gather_ab = {'headline': ring.gather, other: f'failed: {err}'}
     # latency of one pass on its own (one stream, nothing else in flight), for reference
@@ -705,9 +725,11 @@ def bench_config4_strong(ff, torch, dist, lib, _lib, DevicePipeline, device, com
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item())/reps*1e3
     E = cfg['G']*W*cfg['A']*cfg['d']**2
+    push_error = None
     if ring.peer is not None:
-        ring.peer.check()
-    return dict(config=4, scaling='strong', n_gpus=world, gather=ring.gather,
+        torch.cuda.synchronize(device)
+        push_error = int(ring.peer.error.cpu().item())       # 0 = no poll timed out
+    return dict(config=4, scaling='strong', n_gpus=world, gather=ring.gather, push_error_word=push_error,
                 workload=f'd=8, 512 segments, 9 noise ops, 65536 omega split over {world} ranks '
                          f'({w1 - w0} per rank), all-gather of F, infidelity over the full grid',
                 ms=ms, elements_per_s=E/(ms*1e-3))
