@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void from_atomic_kernel(const cplx* __restrict_
         run.re = rr - ii;
         run.im = ri + ir;
     };
-    if (INDEXED)
+    if (INDEXED && g0 < G)   // (an empty trailing slab must not walk index[] past its end)
         for (int g = 0; g + 1 < g0; ++g) advance(g);
     for (int g = g0; g < g1; ++g) {
         const cplx* Rg = Ratomic + (INDEXED ? index[g] : g)*pulse_stride + static_cast<size_t>(a)*N*W + w;
@@ -135,7 +135,9 @@ int from_atomic_gsplit(int G, int A, int N, int W) {
     if (waves >= 2048 || G < 16) return 1;
     long s = (2048 + waves - 1)/waves;
     if (s > G/8) s = G/8;
-    return static_cast<int>(s < 1 ? 1 : s);
+    if (s < 1) s = 1;
+    const long glen = (G + s - 1)/s;
+    return static_cast<int>((G + glen - 1)/glen);   // no empty slabs: ceil(G/glen) of them cover G
 }
 
 size_t from_atomic_workspace_bytes(int G, int A, int N, int W) {

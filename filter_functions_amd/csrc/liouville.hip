@@ -12,6 +12,8 @@
 // Operands are stored K-major so that the 16 lanes of an MFMA row group read 128 contiguous bytes.
 // The imaginary GEMM is skipped for Hermitian bases, where the reference returns the real part
 // only (basis.py:692 `cast`).
+#include <algorithm>
+
 #include "ffk_internal.h"
 
 namespace ffk {
@@ -177,7 +179,7 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
     double* AopRe = reinterpret_cast<double*>(p);
     p += align_up(static_cast<size_t>(batch)*K*Npad*sizeof(double));
     double* AopIm = reinterpret_cast<double*>(p);
-    if (batch > 65535 || d*d > 65535) return hipErrorInvalidValue;
+    if (d*d > 65535) return hipErrorInvalidValue;
 
     // padding rows (K) and columns (N -> Npad) must contribute nothing: zero the operands once --
     // unless there is no padding at all (d^2 a multiple of 16, e.g. d = 4, 8, 16)
@@ -187,33 +189,42 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
     }
     hipLaunchKernelGGL(build_bop_kernel, dim3((Npad + 63)/64, d*d), dim3(64), 0, stream, basis, N, d,
                        Npad, Bop);
-    switch (d) {
+    // the batch axis rides on grid.y / grid.z (at most 65535 blocks): longer batches (the
+    // propagators of a 200 000-segment pulse) go in slabs
+    const int tiles = Npad/16;
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = std::min(65535, batch - b0);
+        const cplx* Us = U + static_cast<size_t>(b0)*d*d;
+        double* are = AopRe + static_cast<size_t>(b0)*K*Npad;
+        double* aim = AopIm + static_cast<size_t>(b0)*K*Npad;
+        double* o = out + static_cast<size_t>(b0)*N*N*(want_imag ? 2 : 1);
+        switch (d) {
 #define FFK_CASE(D)                                                                              \
     case D:                                                                                      \
         hipLaunchKernelGGL(conjugate_basis_kernel<D>,                                            \
-                           dim3((N + kConjPerBlock - 1)/kConjPerBlock, batch), dim3(64), 0, stream, U, \
-                           basis, N, Npad, want_imag, AopRe, AopIm);                             \
+                           dim3((N + kConjPerBlock - 1)/kConjPerBlock, nb), dim3(64), 0, stream, Us, \
+                           basis, N, Npad, want_imag, are, aim);                                 \
         break;
-        FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
-        FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
-        FFK_CASE(15) FFK_CASE(16)
+            FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
+            FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
+            FFK_CASE(15) FFK_CASE(16)
 #undef FFK_CASE
-        default:
-            return hipErrorInvalidValue;
-    }
-    // tiles per wavefront by problem size: enough wavefronts to fill 1024 SIMDs first
-    const int tiles = Npad/16;
-    const long waves4 = static_cast<long>((tiles + 3)/4)*((tiles + 3)/4)*batch;
-    const long waves2 = static_cast<long>((tiles + 1)/2)*((tiles + 1)/2)*batch;
-    if (tiles >= 4 && waves4 >= 2048) {
-        hipLaunchKernelGGL((liouville_gemm_kernel<4, 4>), dim3((tiles + 3)/4, (tiles + 3)/4, batch),
-                           dim3(64), 0, stream, AopRe, AopIm, Bop, N, Npad, K, want_imag, out);
-    } else if (tiles >= 2 && waves2 >= 2048) {
-        hipLaunchKernelGGL((liouville_gemm_kernel<2, 2>), dim3((tiles + 1)/2, (tiles + 1)/2, batch),
-                           dim3(64), 0, stream, AopRe, AopIm, Bop, N, Npad, K, want_imag, out);
-    } else {
-        hipLaunchKernelGGL((liouville_gemm_kernel<1, 1>), dim3(tiles, tiles, batch), dim3(64), 0,
-                           stream, AopRe, AopIm, Bop, N, Npad, K, want_imag, out);
+            default:
+                return hipErrorInvalidValue;
+        }
+        // tiles per wavefront by problem size: enough wavefronts to fill 1024 SIMDs first
+        const long waves4 = static_cast<long>((tiles + 3)/4)*((tiles + 3)/4)*nb;
+        const long waves2 = static_cast<long>((tiles + 1)/2)*((tiles + 1)/2)*nb;
+        if (tiles >= 4 && waves4 >= 2048) {
+            hipLaunchKernelGGL((liouville_gemm_kernel<4, 4>), dim3((tiles + 3)/4, (tiles + 3)/4, nb),
+                               dim3(64), 0, stream, are, aim, Bop, N, Npad, K, want_imag, o);
+        } else if (tiles >= 2 && waves2 >= 2048) {
+            hipLaunchKernelGGL((liouville_gemm_kernel<2, 2>), dim3((tiles + 1)/2, (tiles + 1)/2, nb),
+                               dim3(64), 0, stream, are, aim, Bop, N, Npad, K, want_imag, o);
+        } else {
+            hipLaunchKernelGGL((liouville_gemm_kernel<1, 1>), dim3(tiles, tiles, nb), dim3(64), 0,
+                               stream, are, aim, Bop, N, Npad, K, want_imag, o);
+        }
     }
     return hipGetLastError();
 }

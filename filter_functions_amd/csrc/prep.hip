@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void basis_transformed_kernel(const cplx* __res
     __shared__ cplx T[D][D];
     __shared__ cplx C[D][D];
     __shared__ cplx TC[D][D];
-    const int k = blockIdx.x, g = blockIdx.y, lane = threadIdx.x;
+    const int g = blockIdx.x, k = blockIdx.y, lane = threadIdx.x;   // g on x: G may exceed 65535
     for (int e = lane; e < D*D; e += 64) {
         const cplx v = Tc[static_cast<size_t>(g)*D*D + e];
         T[e / D][e % D] = {v.re, -v.im};
@@ -271,8 +271,8 @@ __global__ void phase_integral_kernel(const double* __restrict__ omega, int W,
                                       const double* __restrict__ segtab, int d, int S,
                                       cplx* __restrict__ phase_factors,
                                       cplx* __restrict__ integral) {
-    const int g = blockIdx.y;
-    const int w = blockIdx.x*blockDim.x + threadIdx.x;
+    const int g = blockIdx.x;   // segments on x: G may exceed 65535
+    const int w = blockIdx.y*blockDim.x + threadIdx.x;
     if (w >= W) return;
     const double* st = segtab + static_cast<size_t>(g)*S;
     const double om = omega[w];
@@ -349,10 +349,11 @@ hipError_t launch_apply_prologue(const cplx* Qloc, const cplx* totals, int G, in
 
 hipError_t launch_basis_transformed(const cplx* Tc, const cplx* basis, int G, int N, int d,
                                     cplx* out, hipStream_t stream) {
+    if (N > 65535) return hipErrorInvalidValue;
     switch (d) {
 #define FFK_CASE(D)                                                                            \
     case D:                                                                                    \
-        hipLaunchKernelGGL(basis_transformed_kernel<D>, dim3(N, G), dim3(64), 0, stream, Tc,   \
+        hipLaunchKernelGGL(basis_transformed_kernel<D>, dim3(G, N), dim3(64), 0, stream, Tc,   \
                            basis, N, out);                                                     \
         break;
         FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
@@ -370,7 +371,8 @@ hipError_t launch_phase_and_integral(const double* omega, int W, const double* s
                                      hipStream_t stream) {
     if (!phase_factors && !integral) return hipSuccess;
     const int block = 128;
-    hipLaunchKernelGGL(phase_integral_kernel, dim3((W + block - 1)/block, G), dim3(block), 0,
+    if ((W + block - 1)/block > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(phase_integral_kernel, dim3(G, (W + block - 1)/block), dim3(block), 0,
                        stream, omega, W, segtab, d, seg_stride(d), phase_factors, integral);
     return hipGetLastError();
 }

@@ -407,6 +407,26 @@ def control_matrix_from_atomic(phases, R_atomic, Q_liouville, which='total'):
     return steps.sum(axis=0)
 
 
+def control_matrix_periodic(phases, control_matrix, total_propagator_liouville, repeats):
+    """R_G = R_1 sum_{g<G} (e^{i w T} Q_1)^g, the geometric series in closed form with one linear
+    solve per frequency: (I - T) S = I - T^G  (numeric.py:886-954, the well-conditioned branch;
+    where cond(I - T) >= 1e8 the reference sums the series term by term, as done here too)."""
+    L = np.asarray(total_propagator_liouville)
+    eye = np.eye(len(L))
+    T = np.multiply.outer(np.asarray(phases), L)
+    M = eye - T
+    good = np.linalg.cond(M) < 1e8
+    S = np.empty_like(T)
+    S[good] = np.linalg.solve(M[good], eye - np.linalg.matrix_power(T[good], repeats))
+    for w in np.flatnonzero(~good):
+        term, total = eye.astype(complex), eye.astype(complex)
+        for _ in range(repeats - 1):
+            term = term @ T[w]
+            total = total + term
+        S[w] = total
+    return (np.asarray(control_matrix).transpose(2, 0, 1) @ S).transpose(1, 2, 0)
+
+
 # ---------------------------------------------------------------------------------------------
 # Decay amplitudes -> cumulant function -> error transfer matrix (SURVEY 8f.2)
 # ---------------------------------------------------------------------------------------------

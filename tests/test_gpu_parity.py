@@ -1649,6 +1649,44 @@ def test_concatenate_periodic(name):
         ff.concatenate_periodic('pulse', 2)
 
 
+@pytest.mark.parametrize('repeats', [1001, 10000])
+def test_concatenate_periodic_many_repeats(repeats):
+    """Thousands of periods (the reference's periodic_driving example repeats a 20-segment period
+    10 000 times): against the closed form of the oracle, and -- for 1001 -- against the same pulse
+    object concatenated 1001 times, a position count the pulse-axis slabs of the concatenation
+    kernel do not divide."""
+    g = load_golden('periodic')
+    omega = g['q1_omega']
+    pulse = etm_pulse(g, 'q1')
+    pulse.cache_filter_function(omega)
+    per = ff.concatenate_periodic(pulse, repeats)
+    want = orc.control_matrix_periodic(pulse.get_total_phases(omega), pulse.get_control_matrix(omega),
+                                       pulse.total_propagator_liouville, repeats)
+    # both sides accumulate ~repeats*eps in the phase factor's power
+    assert rel_err(per.get_control_matrix(omega), want) < 1e-9
+    assert rel_err(per.total_propagator, np.linalg.matrix_power(pulse.total_propagator, repeats)) < 1e-10
+    if repeats == 1001:
+        seq = ff.concatenate([pulse]*repeats)
+        assert rel_err(seq.get_control_matrix(omega), want) < 1e-9
+        assert rel_err(seq.get_filter_function(omega), per.get_filter_function(omega)) < 1e-9
+
+
+@pytest.mark.parametrize('G,T', [(1001, 3), (999, 1), (137, 5)])
+def test_indexed_concatenation_with_uneven_slabs(G, T):
+    """Gather-from-table concatenation at position counts that leave the last pulse-axis slab short
+    (or, before the slab count was derived from the slab length, empty)."""
+    rng = np.random.default_rng(G)
+    A, N, W = 2, 4, 300
+    table = rng.standard_normal((T, A, N, W)) + 1j*rng.standard_normal((T, A, N, W))
+    phases = np.exp(1j*rng.uniform(0, 2*np.pi, (T, W)))
+    index = rng.integers(0, T, G).astype(np.int32)
+    rot = np.linalg.qr(rng.standard_normal((G - 1, N, N)))[0]
+    got = numeric.calculate_control_matrix_from_atomic_indexed(phases, table, index, rot)
+    cum = np.cumprod(phases[index[:-1]], axis=0)
+    want = orc.control_matrix_from_atomic(cum, table[index], rot)
+    assert rel_err(got, want) < 1e-12
+
+
 @pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
 def test_device_resident_infidelity_gradient_with_logical_omega_shards(name):
     """DevicePipeline.infidelity_gradient (device pointers, no host transfers): the whole grid and

@@ -445,3 +445,20 @@ def test_config3_subgrid_fixture_against_oracle():
     assert rel_err(F, g['filter_function']) < 1e-11
     infid = orc.infidelity_from_filter_function(F, wl.rb_spectrum(omega), omega, np.arange(1), 2)
     assert rel_err(infid, g['infidelity']) < 1e-11
+
+
+@pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
+def test_oracle_periodic_closed_form(name):
+    """orc.control_matrix_periodic against the reference's concatenate_periodic outputs."""
+    g = load_golden('periodic')
+    omega = g[f'{name}_omega']
+    R1 = g[f'{name}_control_matrix_x1']
+    # one period's total phases and Liouville propagator, rebuilt with the oracle
+    H = orc.hamiltonian(g[f'{name}_c_opers'], g[f'{name}_c_coeffs'])
+    dt = g[f'{name}_dt']
+    D, V, Q = orc.diagonalize(H, dt)
+    L = orc.liouville_representation(Q[-1], g[f'{name}_basis'])
+    phases = orc.cexp(omega*dt.sum())
+    for reps in (2, 9):
+        got = orc.control_matrix_periodic(phases, R1, L, reps)
+        assert rel_err(got, g[f'{name}_control_matrix_x{reps}']) < 1e-10

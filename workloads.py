@@ -11,6 +11,9 @@ cfg 2  random 2-qubit pulse, seed 42        -> :func:`random_pulse_inputs` (d=4,
 cfg 3  1000-gate RB sequence (naive gates)  -> :func:`rb_cliffords`, :func:`rb_sequence`
 cfg 4  random 3-qubit pulse, seed 43        -> :func:`random_pulse_inputs` (d=8, G=512, A=9)
 cfg 5  4-qubit QFT                          -> :func:`qft_pulse`
+
+plus the one workload for which the reference documents wall-clock times of its own
+(doc/source/examples/periodic_driving.ipynb): :func:`periodic_driving`.
 """
 import numpy as np
 
@@ -150,3 +153,34 @@ def bit_reversal(N=4):
     for j in range(dim):
         P[int(format(j, f'0{N}b')[::-1], 2), j] = 1
     return P
+
+
+# ---- the reference's own timed example: doc/source/examples/periodic_driving.ipynb -----------------
+PERIODIC_DRIVING = dict(n_periods=10000, n_per_period=20, W=500,
+                        published_s=dict(atomic_filter_function=0.0157, concatenate_periodic=0.0286,
+                                         concatenate_standard=0.9008, echo_concatenation=0.0093,
+                                         brute_force=38.38))
+
+
+def periodic_driving(ff, n_periods=10000, n_per_period=20, W=500):
+    """Weak resonant Rabi driving of one qubit in the lab frame (20 GHz drive, 1 MHz Rabi frequency):
+    returns (X_ATOMIC, WAIT, NOT_FULL, omega): one drive period as a 20-segment pulse, a 1 ms idle
+    pulse, the NOT gate written out as n_periods*n_per_period segments (200 000 in the notebook), and
+    the 500 frequencies of the notebook.  Control on Z (static) and X (drive), noise on Z and X."""
+    omega_d = 20e9*2*np.pi
+    omega_0 = omega_d
+    phi = np.pi/2
+    amplitude = 1e6*2*np.pi
+    T = 2*np.pi/omega_d
+    X, _, Z = ff.util.paulis[1:]
+
+    def drive(t):
+        dt = np.diff(t)
+        H_c = [[Z, [omega_0/2]*len(dt), 'Z'], [X, amplitude*np.sin(omega_d*t[1:] + phi), 'X']]
+        H_n = [[Z, np.ones_like(dt), 'Z'], [X, np.ones_like(dt), 'X']]
+        return ff.PulseSequence(H_c, H_n, dt)
+    atomic = drive(np.linspace(0, T, n_per_period + 1))
+    full = drive(np.linspace(0, T*n_periods, n_per_period*n_periods + 1))
+    wait = ff.PulseSequence([[X, [0], 'X']], [[Z, [1.0], 'Z'], [X, [1.0], 'X']], [1e-3])
+    omega = np.geomspace(1e-8*omega_0, 1e2*omega_0, W)
+    return atomic, wait, full, omega
