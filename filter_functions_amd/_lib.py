@@ -99,6 +99,11 @@ SIGNATURES = {
                                                            c_int, c_int, c_int, c_int, c_int, c_int,
                                                            c_int, c_void_p, c_void_p, c_size_t,
                                                            c_void_p]),
+    'ffk_control_matrix_periodic': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                            c_int, c_void_p]),
+    'ffk_control_matrix_periodic_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'ffk_control_matrix_periodic_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ffk_filter_function': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     'ffk_filter_function_dev': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'ffk_filter_function_weighted': (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_double,

@@ -170,6 +170,170 @@ hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int
 }
 
 
+// ---- numeric.calculate_control_matrix_periodic (numeric.py:886-954) ----------------------------
+//   R_G = R_1 S_G,  S_G = sum_{g<G} T^g,  T(w) = z(w) L,  z = exp(i w tau), L the period's
+//   Liouville propagator.
+// The reference sums the series in closed form with one N x N solve per frequency and falls back
+// to the term-by-term sum where I - T is ill conditioned.  Here the sum is built by doubling,
+//   S_2n = S_n + T^n S_n,   S_n+1 = I + T S_n      (S_n commutes with T),
+// applied to the rows r_n = R_1 S_n directly:
+//   r_2n = r_n + z^n (r_n L^n),   r_n+1 = R_1 + z (r_n L),
+// so a step is one (A W) x N by N x N product with an omega-independent matrix: ~2 log2(G)
+// streaming passes over the control matrix, no inverse, no conditioning branch.  L^n (N x N) and
+// z^n (W) are advanced by their own small kernels.
+namespace {
+
+// out[a,l,w] = base[a,l,w] + zf[w] * sum_k r[a,k,w] M[k,l]; one lane per frequency
+template <int LT, bool LCPLX>
+__global__ __launch_bounds__(64) void periodic_step_kernel(const cplx* __restrict__ base,
+                                                           const cplx* __restrict__ r,
+                                                           const cplx* __restrict__ zf,
+                                                           const double* __restrict__ M, int N, int W,
+                                                           cplx* __restrict__ out) {
+    const int w = blockIdx.x*64 + threadIdx.x;
+    const int a = blockIdx.y;
+    const int l0 = blockIdx.z*LT;
+    if (w >= W) return;
+    const size_t row0 = static_cast<size_t>(a)*N*W + w;
+    const cplx z = zf[w];
+    cplx acc[LT];
+#pragma unroll
+    for (int j = 0; j < LT; ++j) acc[j] = {0.0, 0.0};
+    for (int k = 0; k < N; ++k) {
+        const cplx v = cmul(z, r[row0 + static_cast<size_t>(k)*W]);
+#pragma unroll
+        for (int j = 0; j < LT; ++j) {
+            if (l0 + j < N) {
+                if (LCPLX) {
+                    const cplx q = {M[2*(k*N + l0 + j)], M[2*(k*N + l0 + j) + 1]};
+                    cmac(acc[j], q, v);
+                } else {
+                    const double q = M[k*N + l0 + j];
+                    acc[j].re = fma(q, v.re, acc[j].re);
+                    acc[j].im = fma(q, v.im, acc[j].im);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LT; ++j)
+        if (l0 + j < N) {
+            const size_t o = row0 + static_cast<size_t>(l0 + j)*W;
+            const cplx b = base[o];
+            out[o] = {b.re + acc[j].re, b.im + acc[j].im};
+        }
+}
+
+// C = A B for N x N matrices (real, or complex interleaved); one thread per entry
+template <bool LCPLX>
+__global__ void small_matmul_kernel(const double* __restrict__ Am, const double* __restrict__ Bm,
+                                    int N, double* __restrict__ C) {
+    const int e = blockIdx.x*blockDim.x + threadIdx.x;
+    if (e >= N*N) return;
+    const int i = e / N, j = e % N;
+    if (LCPLX) {
+        cplx acc = {0.0, 0.0};
+        for (int k = 0; k < N; ++k) {
+            const cplx x = {Am[2*(i*N + k)], Am[2*(i*N + k) + 1]};
+            const cplx y = {Bm[2*(k*N + j)], Bm[2*(k*N + j) + 1]};
+            cmac(acc, x, y);
+        }
+        C[2*e] = acc.re;
+        C[2*e + 1] = acc.im;
+    } else {
+        double acc = 0.0;
+        for (int k = 0; k < N; ++k) acc = fma(Am[i*N + k], Bm[k*N + j], acc);
+        C[e] = acc;
+    }
+}
+
+// (other may be zn itself: squaring)
+__global__ void phase_product_kernel(cplx* zn, const cplx* other, int W) {
+    const int w = blockIdx.x*blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    zn[w] = cmul(zn[w], other[w]);
+}
+
+template <bool LCPLX>
+void periodic_step(const cplx* base, const cplx* r, const cplx* zf, const double* M, int A, int N,
+                   int W, cplx* out, hipStream_t stream) {
+    const unsigned tiles = (W + 63)/64;
+    if (N <= 4)
+        hipLaunchKernelGGL((periodic_step_kernel<4, LCPLX>), dim3(tiles, A, 1), dim3(64), 0, stream,
+                           base, r, zf, M, N, W, out);
+    else
+        hipLaunchKernelGGL((periodic_step_kernel<16, LCPLX>), dim3(tiles, A, (N + 15)/16), dim3(64), 0,
+                           stream, base, r, zf, M, N, W, out);
+}
+
+template <bool LCPLX>
+hipError_t periodic_c(const cplx* z, const cplx* R1, const double* L, int repeats, int A, int N,
+                      int W, cplx* out, void* ws, hipStream_t stream) {
+    const size_t nR = static_cast<size_t>(A)*N*W;
+    const size_t nL = static_cast<size_t>(N)*N*(LCPLX ? 2 : 1);
+    unsigned char* p = static_cast<unsigned char*>(ws);
+    cplx* buf[2] = {reinterpret_cast<cplx*>(p), reinterpret_cast<cplx*>(p + align_up(nR*sizeof(cplx)))};
+    p += 2*align_up(nR*sizeof(cplx));
+    double* Lb[2] = {reinterpret_cast<double*>(p), reinterpret_cast<double*>(p + align_up(nL*sizeof(double)))};
+    p += 2*align_up(nL*sizeof(double));
+    cplx* zn = reinterpret_cast<cplx*>(p);
+    hipError_t err = hipMemcpyAsync(zn, z, sizeof(cplx)*W, hipMemcpyDeviceToDevice, stream);
+    if (err != hipSuccess) return err;
+    int top = 30;
+    while (!((repeats >> top) & 1)) --top;
+    // the steps left after the current one decide whether L^n and z^n are still needed
+    int steps_left = 0;
+    for (int b = top - 1; b >= 0; --b) steps_left += 1 + ((repeats >> b) & 1);
+    const cplx* r = R1;          // r_1
+    const double* Ln = L;        // L^1
+    int cur = 0, lcur = 0;
+    auto target = [&]() { return steps_left == 1 ? out : buf[cur]; };   // the last step writes `out`
+    auto advance_powers = [&](const double* other_L, const cplx* other_z) {
+        if (steps_left == 0) return;
+        hipLaunchKernelGGL((small_matmul_kernel<LCPLX>), dim3((N*N + 255)/256), dim3(256), 0, stream, Ln,
+                           other_L, N, Lb[lcur]);
+        Ln = Lb[lcur];
+        lcur ^= 1;
+        hipLaunchKernelGGL(phase_product_kernel, dim3((W + 255)/256), dim3(256), 0, stream, zn, other_z, W);
+    };
+    for (int b = top - 1; b >= 0; --b) {
+        cplx* o = target();
+        periodic_step<LCPLX>(r, r, zn, Ln, A, N, W, o, stream);        // r_2n = r_n + z^n r_n L^n
+        r = o;
+        cur ^= 1;
+        --steps_left;
+        advance_powers(Ln, zn);                                        // L^2n, z^2n
+        if ((repeats >> b) & 1) {
+            o = target();
+            periodic_step<LCPLX>(R1, r, z, L, A, N, W, o, stream);     // r_n+1 = R_1 + z r_n L
+            r = o;
+            cur ^= 1;
+            --steps_left;
+            advance_powers(L, z);                                      // L^(n+1), z^(n+1)
+        }
+    }
+    if (repeats == 1) {
+        err = hipMemcpyAsync(out, R1, sizeof(cplx)*nR, hipMemcpyDeviceToDevice, stream);
+        if (err != hipSuccess) return err;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t periodic_workspace_bytes(int A, int N, int W) {
+    return 2*align_up(sizeof(cplx)*static_cast<size_t>(A)*N*W) +
+           2*align_up(2*sizeof(double)*static_cast<size_t>(N)*N) + align_up(sizeof(cplx)*static_cast<size_t>(W));
+}
+
+hipError_t launch_periodic(const cplx* phases, const cplx* R1, const double* L, int l_is_complex,
+                           int repeats, int A, int N, int W, cplx* out, void* ws, hipStream_t stream) {
+    if (A > 65535 || (N + 15)/16 > 65535 || repeats < 1) return hipErrorInvalidValue;
+    return l_is_complex ? periodic_c<true>(phases, R1, L, repeats, A, N, W, out, ws, stream)
+                        : periodic_c<false>(phases, R1, L, repeats, A, N, W, out, ws, stream);
+}
+
+
 // ---- Hilbert-space twin: calculate_noise_operators_from_atomic (numeric.py:377-453) ------------
 //   B(w, a) = B^(0)(w, a) + sum_{g >= 1} phases[g-1, w] P_{g-1}^dag B^(g)(w, a) P_{g-1}
 // One wavefront per (w, a): the d x d operator, the propagator and the half product live in LDS.

@@ -776,6 +776,54 @@ int ffk_control_matrix_from_atomic_indexed(const double* total_phases,
     return FFK_OK;
 }
 
+size_t ffk_control_matrix_periodic_workspace_bytes(int A, int N, int W) {
+    if (A < 1 || N < 1 || W < 1) return 0;
+    return ffk::periodic_workspace_bytes(A, N, W);
+}
+
+int ffk_control_matrix_periodic_dev(const double* phases, const double* control_matrix,
+                                    const double* total_propagator_liouville, int l_is_complex,
+                                    int repeats, int A, int N, int W, double* out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(A >= 1 && N >= 1 && W >= 1, "empty axis: A=%d N=%d W=%d", A, N, W);
+    FFK_REQUIRE(repeats >= 1, "repeats = %d: need at least one period", repeats);
+    FFK_REQUIRE(phases && control_matrix && total_propagator_liouville && out && workspace, "NULL argument");
+    FFK_REQUIRE(out != control_matrix, "out must not alias control_matrix");
+    FFK_REQUIRE(workspace_bytes >= ffk_control_matrix_periodic_workspace_bytes(A, N, W), "workspace too small");
+    FFK_HIP(ffk::launch_periodic(reinterpret_cast<const cplx*>(phases),
+                                 reinterpret_cast<const cplx*>(control_matrix),
+                                 total_propagator_liouville, l_is_complex, repeats, A, N, W,
+                                 reinterpret_cast<cplx*>(out), workspace, static_cast<hipStream_t>(stream)));
+    return FFK_OK;
+}
+
+int ffk_control_matrix_periodic(const double* phases, const double* control_matrix,
+                                const double* total_propagator_liouville, int l_is_complex, int repeats,
+                                int A, int N, int W, double* out) {
+    FFK_REQUIRE(A >= 1 && N >= 1 && W >= 1, "empty axis: A=%d N=%d W=%d", A, N, W);
+    FFK_REQUIRE(repeats >= 1, "repeats = %d: need at least one period", repeats);
+    FFK_REQUIRE(phases && control_matrix && total_propagator_liouville && out, "NULL argument");
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t nP = 16*size_t(W), nR = 16*size_t(A)*N*W, nL = (l_is_complex ? 16 : 8)*size_t(N)*N;
+    const size_t wsb = ffk_control_matrix_periodic_workspace_bytes(A, N, W);
+    void* base;
+    if (int rc = arena_reserve(align_up(nP) + 2*align_up(nR) + align_up(nL) + wsb, &base)) return rc;
+    Bump a(base, g_arena.size);
+    double* dP = a.take<double>(nP/8);
+    double* dR = a.take<double>(nR/8);
+    double* dL = a.take<double>(nL/8);
+    double* dO = a.take<double>(nR/8);
+    void* ws = a.take<unsigned char>(wsb);
+    FFK_HIP(hipMemcpyAsync(dP, phases, nP, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dR, control_matrix, nR, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dL, total_propagator_liouville, nL, hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_control_matrix_periodic_dev(dP, dR, dL, l_is_complex, repeats, A, N, W, dO, ws, wsb, nullptr))
+        return rc;
+    FFK_HIP(hipMemcpyAsync(out, dO, nR, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
 int ffk_noise_operators_from_atomic(const double* phases, const double* noise_operators_atomic,
                                     const double* propagators, int G, int W, int A, int d,
                                     double* noise_operators) {

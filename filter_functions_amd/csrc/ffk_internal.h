@@ -219,6 +219,9 @@ hipError_t launch_second_order_filter_function(const double* omega, int W, const
                                                void* ws, hipStream_t stream);
 // concatenation rule: F2_atomic (G,A,A,N,N,W), step (G,A,N,W) = summands of the sequence's control
 // matrix, L (G-1,N,N) f64 = Liouville matrices of the cumulative propagators -> out (A,A,N,N,W)
+size_t periodic_workspace_bytes(int A, int N, int W);
+hipError_t launch_periodic(const cplx* phases, const cplx* R1, const double* L, int l_is_complex,
+                           int repeats, int A, int N, int W, cplx* out, void* ws, hipStream_t stream);
 size_t second_order_from_atomic_workspace_bytes(int G, int A, int N, int W);
 hipError_t launch_second_order_from_atomic(const cplx* F2_atomic, const cplx* step, const double* L,
                                            int G, int A, int N, int W, cplx* out, void* ws,

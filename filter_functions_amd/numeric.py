@@ -419,19 +419,29 @@ def calculate_control_matrix_periodic(phases, control_matrix, total_propagator_l
                                       check_invertible=True):
     r"""Control matrix of *repeats* periods of a pulse from the control matrix (n_nops, d**2,
     n_omega), total phase factors (n_omega,) and Liouville total propagator (d**2, d**2) of one
-    period (reference numeric.py ``calculate_control_matrix_periodic``): :math:`\tilde{\mathcal
-    B}^{(1)}\sum_{g<G}(e^{i\omega T}\mathcal Q^{(1)})^g`.  The series is summed on the device by the
-    gather-from-table concatenation kernel; no per-frequency inverse, so *check_invertible* has
-    nothing to check."""
+    period (reference numeric.py:886-954): :math:`\tilde{\mathcal B}^{(1)}\sum_{g<G}(e^{i\omega T}
+    \mathcal Q^{(1)})^g`.
+
+    The reference sums the series in closed form with one inverse per frequency, falling back to
+    the explicit sum where :math:`\mathbb I - e^{i\omega T}\mathcal Q^{(1)}` is ill conditioned
+    (*check_invertible*).  Here the series is summed on the device by doubling -- about
+    :math:`2\log_2 G` passes over the control matrix, no inverse -- so *check_invertible* has
+    nothing to check and is ignored."""
     L = np.asarray(total_propagator_liouville)
+    z, R = as_c128(phases), as_c128(control_matrix)
     repeats = int(repeats)
     if repeats < 1:
         raise ValueError('repeats must be a positive integer')
-    cumulative = util.adot(np.broadcast_to(L, (repeats - 1,) + L.shape)) if repeats > 1 \
-        else np.empty((0,) + L.shape, dtype=L.dtype)
-    return calculate_control_matrix_from_atomic_indexed(
-        np.asarray(phases)[None], np.asarray(control_matrix)[None],
-        np.zeros(repeats, dtype=np.int32), cumulative)
+    if R.ndim != 3 or z.shape != R.shape[2:] or L.shape != (R.shape[1],)*2:
+        raise ValueError('Expected control_matrix (n_nops, n_basis, n_omega), phases (n_omega,) and '
+                         f'a (n_basis, n_basis) propagator, not {R.shape}, {z.shape} and {L.shape}.')
+    l_is_complex = np.iscomplexobj(L)
+    L = as_c128(L) if l_is_complex else as_f64(L)
+    A, N, W = R.shape
+    out = np.empty_like(R)
+    check(_lib.load().ffk_control_matrix_periodic(ptr(z), ptr(R), ptr(L), int(l_is_complex), repeats,
+                                                  A, N, W, ptr(out)))
+    return out
 
 
 @util.parse_optional_parameters(which=('fidelity', 'generalized'))

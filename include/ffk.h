@@ -179,6 +179,21 @@ int ffk_control_matrix_from_atomic_indexed_dev(const double* total_phases,
                                                int which, double* out, void* workspace,
                                                size_t workspace_bytes, void* stream);
 
+/* ---- numeric.calculate_control_matrix_periodic (numeric.py:886-954) ----------------------
+ * phases (W,) c128 = exp(i omega T) of one period, control_matrix (A, N, W) c128 of one period,
+ * total_propagator_liouville (N, N) f64 (or c128 if l_is_complex) of one period -> the control
+ * matrix (A, N, W) c128 of `repeats` periods.  The reference evaluates the geometric series in
+ * closed form (one inverse per frequency, with a term-by-term fallback where it is ill
+ * conditioned); here it is summed by doubling in ~2 log2(repeats) streaming passes, no inverse. */
+int ffk_control_matrix_periodic(const double* phases, const double* control_matrix,
+                                const double* total_propagator_liouville, int l_is_complex, int repeats,
+                                int A, int N, int W, double* out);
+size_t ffk_control_matrix_periodic_workspace_bytes(int A, int N, int W);
+int ffk_control_matrix_periodic_dev(const double* phases, const double* control_matrix,
+                                    const double* total_propagator_liouville, int l_is_complex,
+                                    int repeats, int A, int N, int W, double* out, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+
 /* ---- numeric.calculate_filter_function (numeric.py:1413-1467) --------------------------
  * control_matrix (A, N, W) c128 -> fidelity: (A, A, W) c128,
  *                                  generalized: (A, A, N, N, W) c128.                       */

@@ -623,7 +623,34 @@ def make_baseline_configs():
          clifford_control_matrices=np.array([c.get_control_matrix(omega) for c in cliffords]))
 
 
+def make_periodic_driving():
+    """The reference's timed example doc/source/examples/periodic_driving.ipynb at full size (inputs
+    from workloads.periodic_driving): its own concatenate_periodic / concatenate outputs on all 500
+    frequencies, and the written-out 200 002-segment sequence evaluated from scratch on 6 of them."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import workloads as wl
+    cfg = wl.PERIODIC_DRIVING
+    atomic, wait, full, omega = wl.periodic_driving(ff)
+    atomic.cache_filter_function(omega)
+    periodic = ff.concatenate_periodic(atomic, cfg['n_periods'])
+    echo = ff.concatenate((wait, periodic, wait))
+    sub = np.linspace(0, len(omega) - 1, 6).astype(int)
+    written_out = ff.concatenate((wait, full, wait), calc_filter_function=False)
+    save('periodic_driving',
+         omega=omega, atomic_dt=atomic.dt, atomic_c_coeffs=atomic.c_coeffs,
+         atomic_filter_function=atomic.get_filter_function(omega),
+         periodic_control_matrix=periodic.get_control_matrix(omega),
+         periodic_filter_function=periodic.get_filter_function(omega),
+         periodic_total_propagator=periodic.total_propagator,
+         echo_filter_function=echo.get_filter_function(omega),
+         omega_index=sub, written_out_filter_function=written_out.get_filter_function(omega[sub]),
+         written_out_total_propagator=written_out.total_propagator)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'periodic_driving':
+        make_periodic_driving()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'configs':
         make_baseline_configs()
         return
@@ -884,6 +911,7 @@ def main():
     make_noise_operators_from_atomic()
     make_cnot()
     make_baseline_configs()
+    make_periodic_driving()
 
 
 if __name__ == '__main__':

@@ -227,3 +227,39 @@ def test_config3_thousand_gate_sequence_by_concatenation():
     # (concatenate() takes the Liouville representation of the cumulative propagators, L above is the
     # cumulative product of the pulses' Liouville propagators: 1000 products associated differently)
     assert rel_err(R_plain, R) < 1e-11
+
+
+def test_published_example_periodic_driving():
+    """The reference's timed example (doc/source/examples/periodic_driving.ipynb) at full size:
+    10 000 periods by concatenate_periodic, by ff.concatenate, and the 200 002 segments written out
+    and evaluated from scratch, against each other and (on a frequency sub-grid) the oracle."""
+    from itertools import repeat
+    cfg = wl.PERIODIC_DRIVING
+    atomic, wait, full, omega = wl.periodic_driving(ff)
+    atomic.cache_filter_function(omega)
+    periodic = ff.concatenate_periodic(atomic, cfg['n_periods'])
+    standard = ff.concatenate(repeat(atomic, cfg['n_periods']))
+    assert len(periodic) == len(standard) == len(full) == cfg['n_periods']*cfg['n_per_period']
+    assert rel_err(periodic.get_filter_function(omega), standard.get_filter_function(omega)) < 1e-10
+    echo = ff.concatenate((wait, periodic, wait))
+    written_out = ff.concatenate((wait, full, wait), calc_filter_function=False)
+    assert len(written_out) == 200002 and not written_out.is_cached('filter_function')
+    F = written_out.get_filter_function(omega)
+    assert rel_err(echo.get_filter_function(omega), F) < 1e-9
+    sub = np.linspace(0, len(omega) - 1, 5).astype(int)
+    D, V, Q = orc.diagonalize(orc.hamiltonian(written_out.c_opers, written_out.c_coeffs), written_out.dt)
+    assert rel_err(written_out.propagators, Q) < 1e-10
+    R = orc.control_matrix_from_scratch(D, V, Q, omega[sub], np.asarray(written_out.basis),
+                                        written_out.n_opers, written_out.n_coeffs, written_out.dt)
+    assert rel_err(written_out.get_control_matrix(omega)[..., sub], R) < 1e-9
+    assert rel_err(F[..., sub], orc.filter_function(R)) < 1e-9
+    # and the reference's own outputs on the same inputs (oracle/make_golden.py periodic_driving)
+    g = load_golden('periodic_driving')
+    assert np.array_equal(omega, g['omega'])
+    assert rel_err(atomic.get_filter_function(omega), g['atomic_filter_function']) < 1e-11
+    assert rel_err(periodic.get_control_matrix(omega), g['periodic_control_matrix']) < 1e-8
+    assert rel_err(periodic.get_filter_function(omega), g['periodic_filter_function']) < 1e-8
+    assert rel_err(periodic.total_propagator, g['periodic_total_propagator']) < 1e-9
+    assert rel_err(echo.get_filter_function(omega), g['echo_filter_function']) < 1e-8
+    assert rel_err(F[..., g['omega_index']], g['written_out_filter_function']) < 1e-8
+    assert rel_err(written_out.total_propagator, g['written_out_total_propagator']) < 1e-9

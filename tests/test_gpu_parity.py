@@ -1671,6 +1671,47 @@ def test_concatenate_periodic_many_repeats(repeats):
         assert rel_err(seq.get_filter_function(omega), per.get_filter_function(omega)) < 1e-9
 
 
+@pytest.mark.parametrize('N,complex_L', [(4, False), (9, False), (16, True), (64, False)])
+def test_control_matrix_periodic_by_doubling(N, complex_L):
+    """The doubling sum against the term-by-term sum (every bit pattern of small repeat counts) and
+    against the oracle's closed form (large counts); real and complex Liouville propagators."""
+    rng = np.random.default_rng(N)
+    A, W = 3, 200
+    R1 = rng.standard_normal((A, N, W)) + 1j*rng.standard_normal((A, N, W))
+    z = np.exp(1j*rng.uniform(0, 2*np.pi, W))
+    if complex_L:
+        L = np.linalg.qr(rng.standard_normal((N, N)) + 1j*rng.standard_normal((N, N)))[0]
+    else:
+        L = np.linalg.qr(rng.standard_normal((N, N)))[0]
+    T = np.multiply.outer(z, L)
+    term, total = np.broadcast_to(np.eye(N, dtype=complex), T.shape), np.zeros_like(T)
+    for reps in range(1, 20):
+        total = total + term
+        term = term @ T
+        want = (R1.transpose(2, 0, 1) @ total).transpose(1, 2, 0)
+        got = numeric.calculate_control_matrix_periodic(z, R1, L, reps)
+        assert rel_err(got, want) < 1e-13, reps
+    for reps in (255, 256, 1000, 12345):
+        got = numeric.calculate_control_matrix_periodic(z, R1, L, reps)
+        assert rel_err(got, orc.control_matrix_periodic(z, R1, L, reps)) < 1e-10, reps
+    with pytest.raises(ValueError):
+        numeric.calculate_control_matrix_periodic(z, R1, L, 0)
+    with pytest.raises(ValueError):
+        numeric.calculate_control_matrix_periodic(z[:-1], R1, L, 3)
+
+
+def test_control_matrix_periodic_where_the_closed_form_is_singular():
+    """exp(i w T) Q = 1 (idle pulse at w = 0, or w T a multiple of 2 pi): the reference has to fall
+    back to the explicit sum there; the doubling sum needs no special case -- G identical terms."""
+    rng = np.random.default_rng(5)
+    A, N, W = 2, 4, 64
+    R1 = rng.standard_normal((A, N, W)) + 1j*rng.standard_normal((A, N, W))
+    z = np.ones(W, dtype=complex)
+    got = numeric.calculate_control_matrix_periodic(z, R1, np.eye(N), 1000)
+    assert rel_err(got, 1000*R1) < 1e-15
+    assert rel_err(got, orc.control_matrix_periodic(z, R1, np.eye(N), 1000)) < 1e-15
+
+
 @pytest.mark.parametrize('G,T', [(1001, 3), (999, 1), (137, 5)])
 def test_indexed_concatenation_with_uneven_slabs(G, T):
     """Gather-from-table concatenation at position counts that leave the last pulse-axis slab short

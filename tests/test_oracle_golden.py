@@ -462,3 +462,23 @@ def test_oracle_periodic_closed_form(name):
     for reps in (2, 9):
         got = orc.control_matrix_periodic(phases, R1, L, reps)
         assert rel_err(got, g[f'{name}_control_matrix_x{reps}']) < 1e-10
+
+
+def test_oracle_periodic_driving_example():
+    """The reference's outputs on its timed example (doc/source/examples/periodic_driving.ipynb,
+    10 000 periods): the oracle's from-scratch control matrix of one period pushed through the
+    oracle's closed-form periodic sum."""
+    import filter_functions_amd as ff
+    import workloads as wl
+    g = load_golden('periodic_driving')
+    atomic, wait, full, omega = wl.periodic_driving(ff)
+    assert np.array_equal(omega, g['omega']) and np.array_equal(atomic.dt, g['atomic_dt'])
+    assert np.array_equal(atomic.c_coeffs, g['atomic_c_coeffs'])
+    basis = np.asarray(atomic.basis)
+    D, V, Q = orc.diagonalize(orc.hamiltonian(atomic.c_opers, atomic.c_coeffs), atomic.dt)
+    R1 = orc.control_matrix_from_scratch(D, V, Q, omega, basis, atomic.n_opers, atomic.n_coeffs, atomic.dt)
+    assert rel_err(orc.filter_function(R1), g['atomic_filter_function']) < 1e-11
+    L = orc.liouville_representation(Q[-1], basis)
+    R = orc.control_matrix_periodic(orc.cexp(omega*atomic.dt.sum()), R1, L, wl.PERIODIC_DRIVING['n_periods'])
+    assert rel_err(R, g['periodic_control_matrix']) < 1e-8
+    assert rel_err(orc.filter_function(R), g['periodic_filter_function']) < 1e-8
