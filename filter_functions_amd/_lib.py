@@ -192,6 +192,11 @@ SIGNATURES = {
                                              c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                              c_void_p, POINTER(c_void_p), POINTER(c_void_p),
                                              POINTER(c_void_p), POINTER(c_void_p)]),
+    'ffk_resident_filter_function_from_controls': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                           c_void_p, c_int, c_int, c_void_p, c_int,
+                                                           c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                                           POINTER(c_void_p), POINTER(c_void_p),
+                                                           POINTER(c_void_p), POINTER(c_void_p)]),
     'ffk_resident_timing': (c_int, [c_void_p, c_void_p]),
     'ffk_resident_control_matrix': (c_int, [c_void_p, c_void_p]),
     'ffk_resident_control_matrix_dev': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),

@@ -110,17 +110,27 @@ class ResidentResult:
     def __reduce__(self):
         return (type(None), ())
 
-    def evaluate(self, hamiltonian, dt, t, omega, basis, n_opers, n_coeffs):
+    def evaluate(self, hamiltonian, dt, t, omega, basis, n_opers, n_coeffs, c_coeffs=None):
         """One pass; returns (eigvals, eigvecs, propagators, filter_function) as arrays that view
-        the handle's pinned memory (no copy)."""
+        the handle's pinned memory (no copy).  *hamiltonian* is the summed (G, d, d) array, or --
+        with *c_coeffs* (n_cops, G) -- the control operators (n_cops, d, d), summed on the device."""
         H, dt, t, omega = as_c128(hamiltonian), as_f64(dt), as_f64(t), as_f64(omega)
         C, B, s = as_c128(basis), as_c128(n_opers), as_f64(n_coeffs)
-        G, d = H.shape[0], H.shape[1]
-        W, N, A = len(omega), len(C), len(B)
+        d = H.shape[1]
+        G, W, N, A = len(dt), len(omega), len(C), len(B)
         out = [ctypes.c_void_p() for _ in range(4)]
-        check(self._lib.ffk_resident_filter_function(
-            self._handle, ptr(H), ptr(dt), ptr(t), G, d, ptr(omega), W, ptr(C), N, ptr(B), A, ptr(s),
-            *(ctypes.byref(p) for p in out)))
+        results = tuple(ctypes.byref(p) for p in out)
+        if c_coeffs is None:
+            check(self._lib.ffk_resident_filter_function(
+                self._handle, ptr(H), ptr(dt), ptr(t), G, d, ptr(omega), W, ptr(C), N, ptr(B), A, ptr(s),
+                *results))
+        else:
+            c = as_f64(c_coeffs)
+            if c.shape != (len(H), G):
+                raise ValueError(f'Expected c_coeffs of shape ({len(H)}, {G}), not {c.shape}.')
+            check(self._lib.ffk_resident_filter_function_from_controls(
+                self._handle, ptr(H), len(H), ptr(c), ptr(dt), ptr(t), G, d, ptr(omega), W, ptr(C), N,
+                ptr(B), A, ptr(s), *results))
         self.shape = (G, d, W, N, A)
         D = _view(out[0].value, G*d, np.float64, (G, d), self)
         V = _view(out[1].value, 2*G*d*d, np.complex128, (G, d, d), self)

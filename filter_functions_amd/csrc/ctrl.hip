@@ -36,6 +36,7 @@ namespace ffk {
 namespace {
 
 constexpr int kWaveKernelMaxD = 4;
+constexpr int kLongSequenceD2 = 1024;   // d = 2 sequences from this length on take the one-wave kernel
 // in-block segment split (template GS of the block kernel): instantiated for small d only
 constexpr int kGsplit = 4;
 constexpr int kGsplitMaxD = 4;
@@ -871,7 +872,14 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         geo.chunks = (G + geo.chunk_len - 1)/geo.chunk_len;
         return geo;
     }
-    geo.wave_kernel = d <= kWaveKernelMaxD && g_use_wave_kernel;
+    // d = 2, long sequences: the one-wave kernel (no barrier, nothing shared between waves) with
+    // enough segment chunks for eight waves per SIMD -- every wave-segment is a dependent chain
+    // (two sincos, two integrals, 80 FMAs per operator) that only other waves can hide.  The
+    // reference's periodic_driving example written out (200 002 segments, 500 omega, 2 operators):
+    // 1.13 ms against 1.97 ms for the block kernel at its 256 sub-chunks (profiles/r02_k_*); at
+    // 256 segments the two are level (37 / 40 us), so short sequences stay on the block kernel.
+    const bool long_d2 = d == 2 && G >= kLongSequenceD2 && g_use_gsplit && forced_chunks <= 0;
+    geo.wave_kernel = d <= kWaveKernelMaxD && (g_use_wave_kernel || long_d2);
     if (geo.wave_kernel) {
         // one wave per block, up to 3 noise operators per lane; blocks per CU = 4 (1 wave/SIMD)
         geo.na_blk = A <= 3 ? A : (A % 3 == 0 ? 3 : (A % 2 == 0 ? 2 : 3));
@@ -882,7 +890,8 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups;
         int chunks = forced_chunks;
         if (chunks <= 0) {
-            const long slots = 1024;     // 256 CUs x 4 SIMDs, one fat wave each
+            // 256 CUs x 4 SIMDs: one fat wave each (d = 4: up to 512 VGPRs), eight thin ones at d = 2
+            const long slots = long_d2 ? 8192 : 1024;
             chunks = static_cast<int>(std::max<long>(1, slots / tiles));
             const int max_chunks = (G + 3)/4;
             if (chunks > max_chunks) chunks = std::max(1, max_chunks);

@@ -6,6 +6,8 @@
 // Jacobi method are computed and applied by the 64 lanes in parallel (complex Hermitian
 // rotations, rows then columns).  Only the lower triangle of the input is read, like
 // LAPACK's UPLO='L' default; eigenvalues are returned ascending.
+#include <algorithm>
+
 #include "ffk_internal.h"
 
 namespace ffk {
@@ -299,23 +301,28 @@ hipError_t launch_d(const cplx* H, const double* dt, int G, double* eigvals, cpl
     return hipGetLastError();
 }
 
-// Number of segments flagged by the eigensolver, as one device integer (one block).
+// Number of segments flagged by the eigensolver, as one device integer (integer sum: the order of
+// the atomics does not matter).  One block per 64 Ki segments: a single block took 207 us over the
+// 200 002 flags of a long sequence.
 __global__ __launch_bounds__(256) void count_failures_kernel(const int* __restrict__ status, int G,
                                                             int32_t* __restrict__ out) {
     __shared__ int total;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     int mine = 0;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) mine += status[g] != 0;
+    for (int g = blockIdx.x*blockDim.x + threadIdx.x; g < G; g += gridDim.x*blockDim.x) mine += status[g] != 0;
     if (mine) atomicAdd(&total, mine);
     __syncthreads();
-    if (threadIdx.x == 0) *out = total;
+    if (threadIdx.x == 0 && total) atomicAdd(out, total);
 }
 
 }  // namespace
 
 hipError_t launch_count_failures(const int* status, int G, int32_t* out, hipStream_t stream) {
-    hipLaunchKernelGGL(count_failures_kernel, dim3(1), dim3(256), 0, stream, status, G, out);
+    hipError_t err = hipMemsetAsync(out, 0, sizeof(int32_t), stream);
+    if (err != hipSuccess) return err;
+    const int blocks = std::max(1, std::min(256, (G + 65535)/65536*16));
+    hipLaunchKernelGGL(count_failures_kernel, dim3(blocks), dim3(256), 0, stream, status, G, out);
     return hipGetLastError();
 }
 

@@ -2016,15 +2016,40 @@ int ffk_resident_release_pools(void) {
     return g_pin_pool.release();
 }
 
-int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, const double* dt,
-                                 const double* t, int G, int d, const double* omega, int W,
-                                 const double* basis, int N, const double* n_opers, int A,
-                                 const double* n_coeffs, double** eigvals, double** eigvecs,
-                                 double** propagators, double** filter_function) {
+}  // extern "C"
+
+namespace {
+
+// H[g] = sum_i c_coeffs[i, g] c_opers[i]  (pulse_sequence.py:1300-1302, 'ijk,il->ljk'), summed in
+// operator order
+__global__ void assemble_hamiltonian_kernel(const cplx* __restrict__ opers, const double* __restrict__ coeffs,
+                                            int n_c, int G, int dd, cplx* __restrict__ H) {
+    const size_t e = static_cast<size_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+    if (e >= static_cast<size_t>(G)*dd) return;
+    const int g = static_cast<int>(e / dd), k = static_cast<int>(e % dd);
+    cplx acc = {0.0, 0.0};
+    for (int i = 0; i < n_c; ++i) {
+        const double c = coeffs[static_cast<size_t>(i)*G + g];
+        const cplx o = opers[i*dd + k];
+        acc.re = fma(c, o.re, acc.re);
+        acc.im = fma(c, o.im, acc.im);
+    }
+    H[e] = acc;
+}
+
+// One resident pass; the Hamiltonian either given (G, d, d) or as control operators and
+// amplitudes, in which case only the amplitudes cross PCIe (8 n_c B per segment instead of
+// 16 d^2) and the sum runs on the device.
+int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_opers, int n_c,
+                  const double* c_coeffs, const double* dt, const double* t, int G, int d,
+                  const double* omega, int W, const double* basis, int N, const double* n_opers, int A,
+                  const double* n_coeffs, double** eigvals, double** eigvecs, double** propagators,
+                  double** filter_function) {
     FFK_REQUIRE(r, "NULL handle");
     FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
-    FFK_REQUIRE(hamiltonian && dt && t && omega && basis && n_opers && n_coeffs, "NULL argument");
+    FFK_REQUIRE(hamiltonian || (c_opers && c_coeffs && n_c >= 1), "NULL argument");
+    FFK_REQUIRE(dt && t && omega && basis && n_opers && n_coeffs, "NULL argument");
     FFK_REQUIRE(eigvals && eigvecs && propagators && filter_function, "NULL output argument");
     r->valid = false;
     int dev = 0;
@@ -2043,7 +2068,30 @@ int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, con
     unsigned char* dp = static_cast<unsigned char*>(r->dev.ptr);
     const size_t dd = size_t(d)*d;
     const auto clock0 = std::chrono::steady_clock::now();
-    std::memcpy(hp + L.H, hamiltonian, 16*size_t(G)*dd);
+    // controls travel in the slot of the Hamiltonian they replace (if they fit: always, but for
+    // one- or two-segment pulses with many control operators, which are summed here instead)
+    const size_t ctrl_opers = 16*size_t(hamiltonian ? 0 : n_c)*dd;
+    const size_t ctrl_bytes = ctrl_opers + 8*size_t(hamiltonian ? 0 : n_c)*G;
+    const bool on_device = !hamiltonian && ctrl_bytes <= 16*size_t(G)*dd;
+    if (hamiltonian) {
+        std::memcpy(hp + L.H, hamiltonian, 16*size_t(G)*dd);
+    } else if (on_device) {
+        std::memcpy(hp + L.H, c_opers, ctrl_opers);
+        std::memcpy(hp + L.H + ctrl_opers, c_coeffs, 8*size_t(n_c)*G);
+    } else {
+        double* H = reinterpret_cast<double*>(hp + L.H);
+        for (int g = 0; g < G; ++g)
+            for (size_t k = 0; k < dd; ++k) {
+                double re = 0.0, im = 0.0;
+                for (int i = 0; i < n_c; ++i) {
+                    const double c = c_coeffs[size_t(i)*G + g];
+                    re = std::fma(c, c_opers[2*(i*dd + k)], re);
+                    im = std::fma(c, c_opers[2*(i*dd + k) + 1], im);
+                }
+                H[2*(g*dd + k)] = re;
+                H[2*(g*dd + k) + 1] = im;
+            }
+    }
     std::memcpy(hp + L.dt, dt, 8*size_t(G));
     std::memcpy(hp + L.t, t, 8*size_t(G + 1));
     std::memcpy(hp + L.omega, omega, 8*size_t(W));
@@ -2055,12 +2103,27 @@ int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, con
     // scratch of the pass from the shared arena (held only for the duration of this call)
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t wsb = ffk_pipeline_workspace_bytes(W, N, A, G, d, 0, 0);
+    const size_t hsb = on_device ? align_up(16*size_t(G)*dd) : 0;
     void* ws;
-    if (int rc = arena_reserve(wsb, &ws)) return rc;
+    if (int rc = arena_reserve(wsb + hsb, &ws)) return rc;
     const auto clock1 = std::chrono::steady_clock::now();
-    FFK_HIP(hipMemcpyAsync(dp, hp, L.inputs_end, hipMemcpyHostToDevice, s));
     auto dptr = [dp](size_t off) { return reinterpret_cast<double*>(dp + off); };
-    if (int rc = ffk_pipeline_dev(dptr(L.H), dptr(L.dt), dptr(L.t), G, d, dptr(L.omega), W,
+    const double* Hdev = dptr(L.H);
+    if (on_device) {
+        // the controls first, so that the sum runs while the rest of the inputs is still in flight
+        FFK_HIP(hipMemcpyAsync(dp + L.H, hp + L.H, ctrl_bytes, hipMemcpyHostToDevice, s));
+        cplx* Hsum = reinterpret_cast<cplx*>(static_cast<unsigned char*>(ws) + wsb);
+        const size_t n = size_t(G)*dd;
+        hipLaunchKernelGGL(assemble_hamiltonian_kernel, dim3(static_cast<unsigned>((n + 255)/256)), dim3(256),
+                           0, s, reinterpret_cast<const cplx*>(dp + L.H),
+                           reinterpret_cast<const double*>(dp + L.H + ctrl_opers), n_c, G, d*d, Hsum);
+        FFK_HIP(hipGetLastError());
+        FFK_HIP(hipMemcpyAsync(dp + L.dt, hp + L.dt, L.inputs_end - L.dt, hipMemcpyHostToDevice, s));
+        Hdev = reinterpret_cast<const double*>(Hsum);
+    } else {
+        FFK_HIP(hipMemcpyAsync(dp, hp, L.inputs_end, hipMemcpyHostToDevice, s));
+    }
+    if (int rc = ffk_pipeline_dev(Hdev, dptr(L.dt), dptr(L.t), G, d, dptr(L.omega), W,
                                   dptr(L.basis), N, dptr(L.n_opers), A, dptr(L.n_coeffs), nullptr, 0,
                                   nullptr, 0, dptr(L.D), dptr(L.V), dptr(L.Q), dptr(L.R), dptr(L.F),
                                   nullptr, ws, wsb, s))
@@ -2083,6 +2146,32 @@ int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, con
     *filter_function = reinterpret_cast<double*>(hp + L.F);
     r->valid = true;
     return FFK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, const double* dt,
+                                 const double* t, int G, int d, const double* omega, int W,
+                                 const double* basis, int N, const double* n_opers, int A,
+                                 const double* n_coeffs, double** eigvals, double** eigvecs,
+                                 double** propagators, double** filter_function) {
+    FFK_REQUIRE(hamiltonian, "NULL argument");
+    return resident_pass(r, hamiltonian, nullptr, 0, nullptr, dt, t, G, d, omega, W, basis, N, n_opers, A,
+                         n_coeffs, eigvals, eigvecs, propagators, filter_function);
+}
+
+int ffk_resident_filter_function_from_controls(ffk_resident* r, const double* c_opers, int n_cops,
+                                               const double* c_coeffs, const double* dt,
+                                               const double* t, int G, int d, const double* omega,
+                                               int W, const double* basis, int N,
+                                               const double* n_opers, int A, const double* n_coeffs,
+                                               double** eigvals, double** eigvecs,
+                                               double** propagators, double** filter_function) {
+    FFK_REQUIRE(c_opers && c_coeffs && n_cops >= 1, "NULL or empty control Hamiltonian");
+    return resident_pass(r, nullptr, c_opers, n_cops, c_coeffs, dt, t, G, d, omega, W, basis, N, n_opers, A,
+                         n_coeffs, eigvals, eigvecs, propagators, filter_function);
 }
 
 int ffk_resident_timing(ffk_resident* r, double* seconds) {

@@ -463,6 +463,17 @@ int ffk_resident_filter_function(ffk_resident* handle, const double* hamiltonian
                                  const double* basis, int N, const double* n_opers, int A,
                                  const double* n_coeffs, double** eigvals, double** eigvecs,
                                  double** propagators, double** filter_function);
+/* The same pass with the control Hamiltonian given as PulseSequence holds it -- c_opers
+ * (n_cops, d, d) c128 and c_coeffs (n_cops, G) f64 -- instead of the summed (G, d, d) array of
+ * numeric.diagonalize (pulse_sequence.py:1300-1302, einsum 'ijk,il->ljk'): the sum runs on the
+ * device, 8 n_cops bytes per segment cross PCIe instead of 16 d^2.                               */
+int ffk_resident_filter_function_from_controls(ffk_resident* handle, const double* c_opers, int n_cops,
+                                               const double* c_coeffs, const double* dt,
+                                               const double* t, int G, int d, const double* omega,
+                                               int W, const double* basis, int N,
+                                               const double* n_opers, int A, const double* n_coeffs,
+                                               double** eigvals, double** eigvecs,
+                                               double** propagators, double** filter_function);
 /* host-clock seconds of the last pass: [0] packing the inputs into the pinned block, [1] enqueueing
  * the H2D copy, the kernels and the D2H copy, [2] waiting for the stream                         */
 int ffk_resident_timing(ffk_resident* handle, double* seconds);

@@ -2036,6 +2036,38 @@ def test_d8_producer_consumer_kernel_ragged_shapes(G, A, W):
         lib.ffk_set_accumulate_variant(0)
 
 
+@pytest.mark.parametrize('d,G,n_c', [(2, 1, 5), (2, 700, 2), (4, 33, 3), (3, 2, 20), (8, 16, 6)])
+def test_resident_pass_from_controls(d, G, n_c):
+    """ffk_resident_filter_function_from_controls (control operators and amplitudes in, the
+    Hamiltonian summed on the device -- or on the host for the one- and two-segment pulses whose
+    controls do not fit the Hamiltonian's slot) against the same pass on the summed Hamiltonian."""
+    from filter_functions_amd._resident import ResidentResult
+    rng = np.random.default_rng(100*d + G)
+
+    def rand_herm(n):
+        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+        return (M + M.conj().transpose(0, 2, 1))/2
+    c_opers = rand_herm(n_c)
+    c_coeffs = rng.standard_normal((n_c, G))
+    n_opers = rand_herm(2)
+    n_coeffs = rng.random((2, G)) + 0.5
+    dt = rng.random(G) + 0.1
+    t = np.concatenate([[0.0], dt.cumsum()])
+    omega = np.geomspace(1e-2, 1e2, 130)
+    basis = np.asarray(ff.Basis.ggm(d))
+    H = np.einsum('ijk,il->ljk', c_opers, c_coeffs)
+    a, b = ResidentResult(), ResidentResult()
+    Da, Va, Qa, Fa = a.evaluate(H, dt, t, omega, basis, n_opers, n_coeffs)
+    Db, Vb, Qb, Fb = b.evaluate(c_opers, dt, t, omega, basis, n_opers, n_coeffs, c_coeffs=c_coeffs)
+    assert rel_err(Db, Da) < 1e-13 and rel_err(Qb, Qa) < 1e-13 and rel_err(Fb, Fa) < 1e-12
+    assert rel_err(b.control_matrix(), a.control_matrix()) < 1e-12
+    D, V, Q = orc.diagonalize(H, dt)
+    R = orc.control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+    assert rel_err(b.control_matrix(), R) < 1e-11 and rel_err(Fb, orc.filter_function(R)) < 1e-11
+    with pytest.raises(ValueError):
+        b.evaluate(c_opers, dt, t, omega, basis, n_opers, n_coeffs, c_coeffs=c_coeffs[:, :-1])
+
+
 def test_copies_and_pickles_of_a_pulse_with_a_resident_result():
     """deepcopy / pickle of a pulse whose control matrix still lives in HBM: the copy holds host
     arrays and no device memory, the original keeps working, both give the same numbers."""

@@ -657,8 +657,8 @@ def test_resident_result_is_released_with_the_pulse(monkeypatch):
         def __del__(self):
             StandIn.alive -= 1
 
-        def evaluate(self, H, dt, t, omega, basis, n_opers, n_coeffs):
-            G, d, W, A = H.shape[0], H.shape[1], len(omega), len(n_opers)
+        def evaluate(self, c_opers, dt, t, omega, basis, n_opers, n_coeffs, c_coeffs=None):
+            G, d, W, A = len(dt), c_opers.shape[1], len(omega), len(n_opers)
             F = np.zeros((A, A, W), complex)
             self._f = weakref.ref(F)
             return (np.zeros((G, d)), np.zeros((G, d, d), complex),

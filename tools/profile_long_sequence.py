@@ -21,3 +21,20 @@ for i in range(6):
     timing = written_out._resident.timing() if getattr(written_out, '_resident', None) else None
     print(f'pass {i}: {1e3*(t1 - t0):.2f} ms', 'stage/enqueue/wait ms:',
           None if timing is None else [round(1e3*x, 3) for x in timing], flush=True)
+
+if '--cprofile' in sys.argv:
+    import cProfile
+    import pstats
+    prof = cProfile.Profile()
+    prof.enable()
+    for _ in range(5):
+        written_out.cleanup('all')
+        written_out.get_filter_function(omega)
+    prof.disable()
+    pstats.Stats(prof).sort_stats('tottime').print_stats(18)
+    prof = cProfile.Profile()
+    prof.enable()
+    for _ in range(5):
+        ff.concatenate((wait, full, wait), calc_filter_function=False)
+    prof.disable()
+    pstats.Stats(prof).sort_stats('tottime').print_stats(12)
