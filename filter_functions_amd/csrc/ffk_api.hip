@@ -776,6 +776,93 @@ int ffk_control_matrix_from_atomic_indexed(const double* total_phases,
     return FFK_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// P[g] = table[index[g]]: the per-position total propagators of a sequence drawn from T pulses
+__global__ void gather_propagators_kernel(const cplx* __restrict__ table, const int32_t* __restrict__ index,
+                                          int G, int dd, cplx* __restrict__ P) {
+    const size_t e = static_cast<size_t>(blockIdx.x)*blockDim.x + threadIdx.x;
+    if (e >= static_cast<size_t>(G)*dd) return;
+    P[e] = table[static_cast<size_t>(index[e / dd])*dd + e % dd];
+}
+}  // namespace
+
+extern "C" {
+
+// ---- pulse_sequence.concatenate for a sequence drawn from T distinct pulses, in one call --------
+// (pulse_sequence.py:1812-1840: the cumulative propagators, their Liouville representations, the
+// cumulative phase factors and the concatenation rule).  total_propagators (T, d, d) c128,
+// total_phases (T, W) c128, control_matrix_table (T, A, N, W) c128, index (G,) int32.  On the
+// device: gather -> prefix products (scan.hip) -> Liouville representation of the first G - 1
+// (liouville.hip) -> the gather-from-table rule (atomic.hip); nothing but the tables goes in and
+// the results come out.  Outputs: control matrix ((A, N, W), or (G, A, N, W) for which = 1), the
+// sequence's total propagator (d, d) and -- if not NULL -- the (G - 1, N, N) Liouville propagators
+// (f64 for a Hermitian basis, else c128).
+int ffk_concatenate_sequence(const double* total_propagators, const double* total_phases,
+                             const double* control_matrix_table, const int32_t* index,
+                             const double* basis, int hermitian_basis, int T, int G, int d, int A,
+                             int N, int W, int which, double* control_matrix,
+                             double* total_propagator, double* propagators_liouville) {
+    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(T >= 1 && G >= 1 && A >= 1 && N >= 1 && W >= 1, "empty axis");
+    FFK_REQUIRE(total_propagators && total_phases && control_matrix_table && index && basis &&
+                control_matrix && total_propagator, "NULL argument");
+    FFK_REQUIRE(which == 0 || which == 1, "invalid which=%d", which);
+    for (int g = 0; g < G; ++g)
+        FFK_REQUIRE(index[g] >= 0 && index[g] < T, "index[%d] = %d outside [0, %d)", g, index[g], T);
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t dd = size_t(d)*d;
+    const int l_is_complex = hermitian_basis ? 0 : 1;
+    const int nl = G > 1 ? G - 1 : 1;
+    const size_t nU = 16*size_t(T)*dd, nP = 16*size_t(T)*W, nR = 16*size_t(T)*A*N*W, nI = 4*size_t(G);
+    const size_t nB = 16*size_t(N)*dd, nSeq = 16*size_t(G)*dd, nQ = 16*size_t(G + 1)*dd;
+    const size_t nL = (l_is_complex ? 16 : 8)*size_t(nl)*N*N;
+    const size_t nO = which ? 16*size_t(G)*A*N*W : 16*size_t(A)*N*W;
+    const size_t sws = ffk::scan_workspace_bytes(G, d), lws = ffk::liouville_workspace_bytes(nl, d, N);
+    const size_t aws = ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W);
+    void* base;
+    if (int rc = arena_reserve(align_up(nU) + align_up(nP) + align_up(nR) + align_up(nI) + align_up(nB) +
+                               align_up(nSeq) + align_up(nQ) + align_up(nL) + align_up(nO) +
+                               align_up(sws) + align_up(lws) + align_up(aws), &base))
+        return rc;
+    Bump a(base, g_arena.size);
+    double* dU = a.take<double>(nU/8);
+    double* dP = a.take<double>(nP/8);
+    double* dR = a.take<double>(nR/8);
+    int32_t* dI = a.take<int32_t>(G);
+    double* dB = a.take<double>(nB/8);
+    cplx* dSeq = a.take<cplx>(nSeq/16);
+    cplx* dQ = a.take<cplx>(nQ/16);
+    double* dL = a.take<double>(nL/8);
+    double* dO = a.take<double>(nO/8);
+    void* wscan = a.take<unsigned char>(sws);
+    void* wliou = a.take<unsigned char>(lws);
+    void* watom = a.take<unsigned char>(aws);
+    FFK_HIP(hipMemcpyAsync(dU, total_propagators, nU, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dI, index, nI, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dB, basis, nB, hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(gather_propagators_kernel, dim3(static_cast<unsigned>((size_t(G)*dd + 255)/256)),
+                       dim3(256), 0, nullptr, reinterpret_cast<const cplx*>(dU), dI, G, d*d, dSeq);
+    FFK_HIP(hipGetLastError());
+    FFK_HIP(ffk::launch_prefix_products(dSeq, G, d, dQ, wscan, nullptr));
+    if (G > 1)
+        FFK_HIP(ffk::launch_liouville(dQ + dd, G - 1, d, reinterpret_cast<const cplx*>(dB), N,
+                                      hermitian_basis, dL, wliou, nullptr));
+    FFK_HIP(hipMemcpyAsync(dP, total_phases, nP, hipMemcpyHostToDevice, nullptr));
+    FFK_HIP(hipMemcpyAsync(dR, control_matrix_table, nR, hipMemcpyHostToDevice, nullptr));
+    if (int rc = ffk_control_matrix_from_atomic_indexed_dev(dP, dR, dI, dL, l_is_complex, T, G, A, N, W,
+                                                            which, dO, watom, aws, nullptr))
+        return rc;
+    FFK_HIP(hipMemcpyAsync(control_matrix, dO, nO, hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipMemcpyAsync(total_propagator, dQ + size_t(G)*dd, 16*dd, hipMemcpyDeviceToHost, nullptr));
+    if (propagators_liouville && G > 1)
+        FFK_HIP(hipMemcpyAsync(propagators_liouville, dL, (l_is_complex ? 16 : 8)*size_t(G - 1)*N*N,
+                               hipMemcpyDeviceToHost, nullptr));
+    FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
 size_t ffk_control_matrix_periodic_workspace_bytes(int A, int N, int W) {
     if (A < 1 || N < 1 || W < 1) return 0;
     return ffk::periodic_workspace_bytes(A, N, W);

@@ -415,6 +415,51 @@ def calculate_control_matrix_from_atomic_indexed(total_phases, control_matrix_ta
     return out
 
 
+def concatenate_sequence_indexed(total_propagators, total_phases, control_matrix_table, index, basis,
+                                 which='total', return_liouville=False):
+    """The concatenation rule for a sequence drawn from T distinct pulses in ONE library call
+    (reference pulse_sequence.py:1812-1840, spread there over ``util.adot``,
+    ``liouville_representation``, ``cumprod`` and ``calculate_control_matrix_from_atomic``): the
+    cumulative propagators of the sequence, their Liouville representations, the cumulative phases
+    and the sum all stay on the device.
+
+    total_propagators: (T, d, d); total_phases: (T, n_omega); control_matrix_table:
+    (T, n_nops, d², n_omega); index: (G,) position -> distinct pulse.  Returns the control matrix
+    ((n_nops, d², n_omega), or (G, ...) for which='correlations'), the sequence's total propagator
+    and -- with *return_liouville* -- the (G-1, d², d²) cumulative Liouville propagators (else
+    None)."""
+    U = as_c128(total_propagators)
+    tp = as_c128(total_phases)
+    table = as_c128(control_matrix_table)
+    barr = as_c128(np.asarray(basis))
+    index = np.ascontiguousarray(index, dtype=np.int32)
+    if (table.ndim != 4 or tp.shape != (table.shape[0], table.shape[3]) or U.ndim != 3
+            or len(U) != len(table) or U.shape[1] != U.shape[2]):
+        raise ValueError('Expected total_propagators (T, d, d), total_phases (T, n_omega) and '
+                         f'control_matrix_table (T, n_nops, n_basis, n_omega), not {U.shape}, '
+                         f'{tp.shape} and {table.shape}.')
+    T, A, N, W = table.shape
+    d = U.shape[-1]
+    G = len(index)
+    if barr.shape != (N, d, d):
+        raise ValueError(f'Expected basis of shape ({N}, {d}, {d}), not {barr.shape}.')
+    if G < 1 or index.min() < 0 or index.max() >= T:
+        raise ValueError('index must be a non-empty sequence of values in [0, T).')
+    hermitian = getattr(basis, 'isherm', None)
+    if hermitian is None:
+        hermitian = np.allclose(barr, barr.conj().swapaxes(-1, -2), atol=np.finfo(complex).eps*d**3, rtol=0)
+    out = np.empty((G, A, N, W) if which == 'correlations' else (A, N, W), dtype=np.complex128)
+    total = np.empty((d, d), dtype=np.complex128)
+    L = None
+    if return_liouville:
+        L = np.empty((max(G - 1, 0), N, N), dtype=np.float64 if hermitian else np.complex128)
+    check(_lib.load().ffk_concatenate_sequence(
+        ptr(U), ptr(tp), ptr(table), index.ctypes.data_as(ctypes.c_void_p), ptr(barr), int(bool(hermitian)),
+        T, G, d, A, N, W, int(which == 'correlations'), ptr(out), ptr(total),
+        ptr(L) if L is not None and G > 1 else None))
+    return out, total, L
+
+
 def calculate_control_matrix_periodic(phases, control_matrix, total_propagator_liouville, repeats,
                                       check_invertible=True):
     r"""Control matrix of *repeats* periods of a pulse from the control matrix (n_nops, d**2,

@@ -620,7 +620,18 @@ def _all_bases_equal(pulses):
     return True
 
 
-def _concatenate_hamiltonian(opers, identifiers, coeffs, kind):
+def _distinct_objects(objects):
+    """Positions -> distinct objects (by identity, in order of first appearance): returns (distinct,
+    first position of each, index) with objects[p] is distinct[index[p]]."""
+    slot = {}
+    index = np.fromiter((slot.setdefault(id(obj), len(slot)) for obj in objects), dtype=np.int32,
+                        count=len(objects))
+    first = np.full(len(slot), -1, dtype=np.intp)
+    first[index[::-1]] = np.arange(len(objects) - 1, -1, -1)      # the earliest position wins
+    return [objects[p] for p in first], first, index
+
+
+def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index=None):
     """Merge the operator tables of several pulses (contract of reference
     pulse_sequence.py:1340-1483).
 
@@ -629,55 +640,50 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind):
     matrices in different pulses is disambiguated by appending the pulse position.  Returns the
     operators sorted by their new identifiers, the identifiers, the (n_opers, sum n_dt)
     coefficient table -- zero-filled for control terms a pulse lacks, filled with the common
-    constant for noise sensitivities (ValueError if it is not constant) -- and, per pulse, the
-    map old identifier -> new identifier.
+    constant for noise sensitivities (ValueError if it is not constant) -- and, per pulse
+    position, the map old identifier -> new identifier.
 
     A long sequence is typically drawn from a handful of pulse objects (1000 gates from 24
-    Cliffords): all bookkeeping runs over the DISTINCT (operators, identifiers, coefficients)
-    triples, in order of first appearance, and the coefficient table is assembled by one
-    concatenation of per-triple blocks.
+    Cliffords): the three lists hold one entry per DISTINCT pulse, ``first[k]`` is the sequence
+    position where entry k first appears and ``index[p]`` the entry at position p (default: every
+    entry once, in order).  All bookkeeping runs over the entries; the coefficient table is
+    assembled by one gather of per-entry blocks.
     """
-    # distinct triples by object identity, first position of each
-    slot_of, first_pos, slot = {}, [], []
-    for p in range(len(opers)):
-        key = (id(opers[p]), id(identifiers[p]), id(coeffs[p]))
-        k = slot_of.get(key)
-        if k is None:
-            k = slot_of[key] = len(first_pos)
-            first_pos.append(p)
-        slot.append(k)
-    # one record per (distinct triple, operator): (first position, row in the pulse, matrix, name)
-    records = [(p, i, np.ascontiguousarray(op).tobytes(), str(ident))
-               for p in first_pos
-               for i, (op, ident) in enumerate(zip(opers[p], identifiers[p]))]
+    if index is None:
+        first, index = np.arange(len(opers)), np.arange(len(opers))
+    # one record per (entry, operator): (entry, row in the pulse, matrix, name)
+    records = [(k, i, np.ascontiguousarray(op).tobytes(), str(ident))
+               for k in range(len(opers))
+               for i, (op, ident) in enumerate(zip(opers[k], identifiers[k]))]
     idents_of_matrix, matrices_of_ident, first_seen = {}, {}, {}
-    for p, i, key, ident in records:
+    for k, i, key, ident in records:
         idents_of_matrix.setdefault(key, set()).add(ident)
         matrices_of_ident.setdefault(ident, set()).add(key)
-        first_seen.setdefault(key, (p, i, ident))
+        first_seen.setdefault(key, (k, i, ident))
     if any(len(v) > 1 for v in idents_of_matrix.values()):
         raise ValueError(f'Trying to concatenate pulses with equal {kind} operators but '
                          f'different identifiers. Please choose unique {kind} identifiers!')
     # new identifier of every distinct matrix
-    new_ident = {key: (f'{ident}_{p}' if len(matrices_of_ident[ident]) > 1 else ident)
-                 for key, (p, i, ident) in first_seen.items()}
+    new_ident = {key: (f'{ident}_{first[k]}' if len(matrices_of_ident[ident]) > 1 else ident)
+                 for key, (k, i, ident) in first_seen.items()}
     ordered = sorted(first_seen, key=new_ident.get)
     row = {key: r for r, key in enumerate(ordered)}
     concat_identifiers = np.array([new_ident[key] for key in ordered])
     concat_opers = np.array([np.asarray(opers[first_seen[key][0]][first_seen[key][1]])
                              for key in ordered])
-    # per distinct triple: its block of the coefficient table (NaN where it lacks an operator) and
-    # its identifier map; per pulse position: a reference to those
-    blocks, maps = {}, {}
-    for p, i, key, ident in records:
-        block = blocks.get(p)
-        if block is None:
-            block = blocks[p] = np.full((len(ordered), np.shape(coeffs[p])[1]), np.nan)
-            maps[p] = {}
-        block[row[key]] = np.asarray(coeffs[p])[i]
-        maps[p][ident] = new_ident[key]
-    table = np.concatenate([blocks[first_pos[k]] for k in slot], axis=1)
-    mapping = {p: maps[first_pos[k]] for p, k in enumerate(slot)}
+    # per entry: its block of the coefficient table (NaN where it lacks an operator) and its
+    # identifier map; per pulse position: a reference to those
+    blocks = [np.full((len(ordered), np.shape(c)[1]), np.nan) for c in coeffs]
+    maps = [{} for _ in coeffs]
+    for k, i, key, ident in records:
+        blocks[k][row[key]] = np.asarray(coeffs[k])[i]
+        maps[k][ident] = new_ident[key]
+    if len({block.shape[1] for block in blocks}) == 1:
+        # equal segment counts: one gather (positions, operators, segments) -> (operators, all segments)
+        table = np.stack(blocks)[index].transpose(1, 0, 2).reshape(len(ordered), -1)
+    else:
+        table = np.concatenate([blocks[k] for k in index], axis=1)
+    mapping = dict(zip(range(len(index)), map(maps.__getitem__, index)))
     missing = np.isnan(table)
     if kind == 'noise':
         for r in np.nonzero(missing.any(axis=1))[0]:
@@ -691,34 +697,48 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind):
     return concat_opers, concat_identifiers, table, mapping
 
 
+def _validated_sequence(pulses):
+    """The pulses as a tuple, their distinct objects, first positions and position -> object index
+    (TypeError / ValueError of reference pulse_sequence.py:1626-1640)."""
+    try:
+        pulses = tuple(pulses)           # any iterable, also a generator: consumed exactly once
+    except TypeError:
+        raise TypeError(f'Expected pulses to be iterable, not {type(pulses)}') from None
+    distinct, first, index = _distinct_objects(pulses)
+    for pulse in distinct:
+        if not isinstance(pulse, PulseSequence):
+            raise TypeError('Can only concatenate PulseSequences!')
+    return pulses, distinct, first, index
+
+
+def _concatenate_distinct(pulses, distinct, first, index):
+    """concatenate_without_filter_function on an already validated sequence."""
+    if any(pulse.d != distinct[0].d for pulse in distinct):
+        raise ValueError('Trying to concatenate PulseSequence instances with different dimension!')
+    if not _all_bases_equal(distinct):
+        raise ValueError('Trying to concatenate PulseSequence instances with different bases!')
+    c_opers, c_ids, c_coeffs, c_map = _concatenate_hamiltonian(
+        [p.c_opers for p in distinct], [p.c_oper_identifiers for p in distinct],
+        [p.c_coeffs for p in distinct], 'control', first, index)
+    n_opers, n_ids, n_coeffs, n_map = _concatenate_hamiltonian(
+        [p.n_opers for p in distinct], [p.n_oper_identifiers for p in distinct],
+        [p.n_coeffs for p in distinct], 'noise', first, index)
+    lengths = np.array([len(p.dt) for p in distinct])
+    if (lengths == lengths[0]).all():
+        dt = np.stack([p.dt for p in distinct])[index].reshape(-1)
+    else:
+        dt = np.concatenate([distinct[k].dt for k in index])
+    newpulse = PulseSequence.from_arrays(c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt,
+                                         distinct[0].basis)
+    # (summed position by position like the reference's sum over the pulses)
+    newpulse.tau = sum(np.array([p.tau for p in distinct])[index].tolist())
+    return newpulse, c_map, n_map
+
+
 def concatenate_without_filter_function(pulses, return_identifier_mappings=False):
     """Concatenate pulses without touching any filter function
     (reference pulse_sequence.py:1534-1665)."""
-    try:
-        pulses = tuple(pulses)
-    except TypeError:
-        raise TypeError(f'Expected pulses to be iterable, not {type(pulses)}') from None
-    for pulse in pulses:
-        if not isinstance(pulse, PulseSequence):
-            raise TypeError('Can only concatenate PulseSequences!')
-    if any(pulse.d != pulses[0].d for pulse in pulses):
-        raise ValueError('Trying to concatenate PulseSequence instances with different dimension!')
-    if not _all_bases_equal(pulses):
-        raise ValueError('Trying to concatenate PulseSequence instances with different bases!')
-    c_opers, c_ids, c_coeffs, c_map = _concatenate_hamiltonian(
-        [p.c_opers for p in pulses], [p.c_oper_identifiers for p in pulses],
-        [p.c_coeffs for p in pulses], kind='control')
-    n_opers, n_ids, n_coeffs, n_map = _concatenate_hamiltonian(
-        [p.n_opers for p in pulses], [p.n_oper_identifiers for p in pulses],
-        [p.n_coeffs for p in pulses], kind='noise')
-    dt = np.concatenate(tuple(pulse.dt for pulse in pulses))
-    newpulse = PulseSequence.from_arrays(c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt,
-                                         pulses[0].basis)
-    durations = {}
-    for pulse in pulses:
-        if id(pulse) not in durations:
-            durations[id(pulse)] = pulse.tau
-    newpulse.tau = sum(durations[id(pulse)] for pulse in pulses)
+    newpulse, c_map, n_map = _concatenate_distinct(*_validated_sequence(pulses))
     if return_identifier_mappings:
         return newpulse, c_map, n_map
     return newpulse
@@ -737,40 +757,36 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     two pulses share a noise operator.  ``calc_pulse_correlation_FF`` keeps every summand and
     caches the pulse correlation filter function.
     """
-    try:
-        pulses = tuple(pulses)           # any iterable, also a generator: consumed exactly once
-    except TypeError:
-        raise TypeError(f'Expected pulses to be iterable, not {type(pulses)}') from None
-    if len(pulses) == 1 and isinstance(pulses[0], PulseSequence):
+    pulses, distinct, first_position, index = _validated_sequence(pulses)
+    if len(pulses) == 1:
         return copy.deepcopy(pulses[0])  # nothing to concatenate: an independent copy, caches kept
-    newpulse, _, n_map = concatenate_without_filter_function(pulses, return_identifier_mappings=True)
+    newpulse, _, n_map = _concatenate_distinct(pulses, distinct, first_position, index)
 
     cumulative = []
 
     def cumulative_propagators():
-        """U_g ... U_2 U_1 for every g, once (log-depth scan over the sequence)."""
+        """U_g ... U_2 U_1 for every g, once (log-depth scan over the sequence, on the host: the
+        routes that do not end in the fused device call)."""
         if not cumulative:
-            per_object = {}
-            for pls in pulses:
-                if id(pls) not in per_object:
-                    per_object[id(pls)] = pls.total_propagator
-            cumulative.append(_running_products(np.array([per_object[id(pls)] for pls in pulses])))
+            cumulative.append(_running_products(
+                np.array([pls.total_propagator for pls in distinct])[index]))
         return cumulative[0]
-    if all('total_propagator' in pls._data for pls in pulses):
-        newpulse.total_propagator = cumulative_propagators()[-1]
+
+    def finished(pulse):
+        """The new pulse with its total propagator, if every pulse knows its own (contract of the
+        reference, pulse_sequence.py:1753-1754)."""
+        if 'total_propagator' not in pulse._data and all('total_propagator' in pls._data
+                                                         for pls in distinct):
+            pulse.total_propagator = cumulative_propagators()[-1]
+        return pulse
     if calc_pulse_correlation_FF or calc_second_order_FF is True:
         calc_filter_function = True         # both need every summand of the control matrix
     elif calc_filter_function is False:
-        return newpulse
+        return finished(newpulse)
 
     # distinct pulse objects (a randomized-benchmarking sequence draws 1000 gates from 24
     # Cliffords): every per-pulse question below is asked once per object
-    position = {}
-    index = np.array([position.setdefault(id(pls), len(position)) for pls in pulses], dtype=np.int32)
-    distinct = [None]*len(position)
-    for pls, k in zip(pulses, index):
-        distinct[k] = pls
-    first_position = [int(p) for p in np.unique(index, return_index=True)[1]]
+    first_position = [int(p) for p in first_position]
 
     # which noise operators of the new pulse does each pulse carry?
     new_ids = list(newpulse.n_oper_identifiers)
@@ -798,13 +814,14 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
             if calc_pulse_correlation_FF:
                 raise ValueError('Cannot compute the pulse correlation filter functions; do not '
                                  'have the frequencies at which to evaluate.')
-            return newpulse
+            return finished(newpulse)
         if calc_filter_function is None and (not shared_n_opers or not any(cached_R)):
-            return newpulse
+            return finished(newpulse)
         omega = candidates[0]
 
     if not shared_n_opers:
         # nothing to reuse: plain from-scratch evaluation of the long sequence
+        finished(newpulse)
         newpulse.cache_filter_function(omega, which=which)
         if calc_second_order_FF:
             newpulse.cache_filter_function(omega, order=2)
@@ -816,11 +833,14 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     def atomic_control_matrix(i):
         """Control matrix of the pulse at position i in the new pulse's operator order."""
         pls, here = pulses[i], present[i]
-        R = np.empty((len(newpulse.n_opers), len(newpulse.basis), len(omega)), dtype=complex)
         own_order = [list(pls.n_oper_identifiers).index(old)
                      for new in np.asarray(new_ids)[here]
                      for old, mapped in n_map[i].items() if mapped == new]
-        R[here] = pls.get_control_matrix(omega, show_progressbar)[own_order]
+        own = pls.get_control_matrix(omega, show_progressbar)
+        if here.all() and own_order == list(range(len(own))):
+            return own                       # same operators in the same order: no copy
+        R = np.empty((len(newpulse.n_opers), len(newpulse.basis), len(omega)), dtype=complex)
+        R[here] = own[own_order]
         if not here.all():
             # noise operators this pulse does not know: evaluate them on its control Hamiltonian
             R[~here] = numeric.calculate_control_matrix_from_scratch(
@@ -829,23 +849,27 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
                 t=pls.t)
         return R
 
-    # Liouville representation of the propagators accumulated before each pulse: the cumulative
-    # propagators in one batched device call (the representation is a homomorphism; the reference
-    # multiplies the pulses' Liouville propagators up instead, pulse_sequence.py:1827)
-    propagators_liouville = liouville_representation(cumulative_propagators()[:-1], newpulse.basis)
-    if 'total_propagator' not in newpulse._data:
-        newpulse.total_propagator = cumulative_propagators()[-1]
     newpulse.omega = omega
     newpulse._defer_by_products()           # total phases, Liouville propagator: on first read
     mode = 'correlations' if calc_pulse_correlation_FF or calc_second_order_FF else 'total'
     # the indexed kernel assumes a repeated pulse contributes the same rows everywhere, which
     # holds when every pulse carries every noise operator (else fall back to the plain rule)
     if len(distinct) < len(pulses) and present.all():
+        # the whole rule in one library call: cumulative propagators, their Liouville
+        # representations, cumulative phases and the sum stay on the device
         table = np.array([atomic_control_matrix(i) for i in first_position])
-        total_phases = np.array([pls.get_total_phases(omega) for pls in distinct])
-        control_matrix = numeric.calculate_control_matrix_from_atomic_indexed(
-            total_phases, table, index, propagators_liouville, which=mode)
+        control_matrix, total_propagator, propagators_liouville = numeric.concatenate_sequence_indexed(
+            np.array([pls.total_propagator for pls in distinct]),
+            np.array([pls.get_total_phases(omega) for pls in distinct]), table, index, newpulse.basis,
+            which=mode, return_liouville=bool(calc_second_order_FF))
+        newpulse.total_propagator = total_propagator
     else:
+        # Liouville representation of the propagators accumulated before each pulse: the
+        # cumulative propagators in one batched device call (the representation is a
+        # homomorphism; the reference multiplies the pulses' Liouville propagators up instead,
+        # pulse_sequence.py:1827)
+        propagators_liouville = liouville_representation(cumulative_propagators()[:-1], newpulse.basis)
+        newpulse.total_propagator = cumulative_propagators()[-1]
         phases = np.array([pls.get_total_phases(omega) for pls in pulses[:-1]]).cumprod(axis=0)
         R_atomic = np.array([atomic_control_matrix(i) for i in range(len(pulses))])
         control_matrix = numeric.calculate_control_matrix_from_atomic(
@@ -879,10 +903,9 @@ def concatenate_periodic(pulse, repeats, check_invertible=True):
 
     The reference sums the geometric series :math:`\tilde{\mathcal B}^{(1)}\sum_g(e^{i\omega T}
     \mathcal Q^{(1)})^g` in closed form with one matrix inverse per frequency (and falls back to
-    the plain sum where the inverse fails, *check_invertible*); here the sum itself runs on the
-    device through the gather-from-table concatenation kernel (one control-matrix table, *repeats*
-    positions), which needs no inverse and no fallback -- *check_invertible* is accepted and
-    ignored."""
+    the plain sum where the inverse fails, *check_invertible*); here the series is summed on the
+    device by doubling (:func:`numeric.calculate_control_matrix_periodic`), which needs no inverse
+    and no fallback -- *check_invertible* is accepted and ignored."""
     if not isinstance(pulse, PulseSequence):
         raise TypeError('Can only concatenate PulseSequences!')
     repeats = int(repeats)

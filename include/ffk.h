@@ -179,6 +179,21 @@ int ffk_control_matrix_from_atomic_indexed_dev(const double* total_phases,
                                                int which, double* out, void* workspace,
                                                size_t workspace_bytes, void* stream);
 
+/* ---- pulse_sequence.concatenate (pulse_sequence.py:1668-1887) for a sequence of G positions drawn
+ * from T distinct pulses, the whole rule in one call: total_propagators (T, d, d) c128 of the
+ * distinct pulses, their total_phases (T, W) c128 and control_matrix_table (T, A, N, W) c128,
+ * index (G,) int32, basis (N, d, d) c128.  The cumulative propagators (util.adot, :1812), their
+ * Liouville representations (:1827), the cumulative phases (:1824) and the sum (:1836,
+ * numeric.calculate_control_matrix_from_atomic) all run on the device.  Returns the control matrix
+ * ((A, N, W); (G, A, N, W) for which = 1), the total propagator (d, d) and, if
+ * propagators_liouville is not NULL, the (G - 1, N, N) cumulative Liouville propagators (f64 if
+ * hermitian_basis, else c128).                                                                   */
+int ffk_concatenate_sequence(const double* total_propagators, const double* total_phases,
+                             const double* control_matrix_table, const int32_t* index,
+                             const double* basis, int hermitian_basis, int T, int G, int d, int A,
+                             int N, int W, int which, double* control_matrix,
+                             double* total_propagator, double* propagators_liouville);
+
 /* ---- numeric.calculate_control_matrix_periodic (numeric.py:886-954) ----------------------
  * phases (W,) c128 = exp(i omega T) of one period, control_matrix (A, N, W) c128 of one period,
  * total_propagator_liouville (N, N) f64 (or c128 if l_is_complex) of one period -> the control

@@ -1712,6 +1712,44 @@ def test_control_matrix_periodic_where_the_closed_form_is_singular():
     assert rel_err(got, orc.control_matrix_periodic(z, R1, np.eye(N), 1000)) < 1e-15
 
 
+@pytest.mark.parametrize('d,G,T,hermitian', [(2, 50, 3, True), (4, 300, 5, True), (3, 17, 17, False),
+                                              (2, 2, 1, True)])
+def test_concatenate_sequence_in_one_call(d, G, T, hermitian):
+    """ffk_concatenate_sequence (gather -> prefix products -> Liouville -> table rule, all on the
+    device) against the same steps done one by one: NumPy cumulative products, the oracle's
+    Liouville representation and concatenation rule."""
+    rng = np.random.default_rng(10*d + G)
+    A, W = 2, 150
+    N = d*d
+    basis = np.asarray(ff.Basis.ggm(d))
+    if not hermitian:        # a non-Hermitian orthonormal basis: complex Liouville propagators
+        mix = np.linalg.qr(rng.standard_normal((N, N)) + 1j*rng.standard_normal((N, N)))[0]
+        basis = np.tensordot(mix, basis, axes=[1, 0])
+    U = np.linalg.qr(rng.standard_normal((T, d, d)) + 1j*rng.standard_normal((T, d, d)))[0]
+    table = rng.standard_normal((T, A, N, W)) + 1j*rng.standard_normal((T, A, N, W))
+    phases = np.exp(1j*rng.uniform(0, 2*np.pi, (T, W)))
+    index = rng.integers(0, T, G).astype(np.int32)
+    cum = [U[index[0]]]
+    for g in range(1, G):
+        cum.append(U[index[g]] @ cum[-1])
+    cum = np.array(cum)
+    L = orc.liouville_representation(cum[:-1], basis)
+    if hermitian:
+        assert np.abs(L.imag).max() < 1e-13
+        L = L.real
+    want = orc.control_matrix_from_atomic(np.cumprod(phases[index[:-1]], axis=0), table[index], L)
+    R, total, Lgot = numeric.concatenate_sequence_indexed(U, phases, table, index, basis, return_liouville=True)
+    assert rel_err(total, cum[-1]) < 1e-13
+    assert Lgot.dtype == (np.float64 if hermitian else np.complex128) and rel_err(Lgot, L) < 1e-13
+    assert rel_err(R, want) < 1e-12
+    Rc, _, none = numeric.concatenate_sequence_indexed(U, phases, table, index, basis, which='correlations')
+    assert none is None and Rc.shape == (G, A, N, W) and rel_err(Rc.sum(axis=0), want) < 1e-12
+    with pytest.raises(ValueError):
+        numeric.concatenate_sequence_indexed(U, phases, table, index + T, basis)
+    with pytest.raises(ValueError):
+        numeric.concatenate_sequence_indexed(U[:-1] if T > 1 else U[:, :1], phases, table, index, basis)
+
+
 @pytest.mark.parametrize('G,T', [(1001, 3), (999, 1), (137, 5)])
 def test_indexed_concatenation_with_uneven_slabs(G, T):
     """Gather-from-table concatenation at position counts that leave the last pulse-axis slab short
