@@ -101,7 +101,7 @@ SIGNATURES = {
                                                            c_void_p]),
     'ffk_concatenate_sequence': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                         c_void_p]),
+                                         c_void_p, c_void_p]),
     'ffk_control_matrix_periodic': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                             c_int, c_void_p]),
     'ffk_control_matrix_periodic_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

@@ -803,9 +803,11 @@ int ffk_concatenate_sequence(const double* total_propagators, const double* tota
                              const double* control_matrix_table, const int32_t* index,
                              const double* basis, int hermitian_basis, int T, int G, int d, int A,
                              int N, int W, int which, double* control_matrix,
-                             double* total_propagator, double* propagators_liouville) {
+                             double* total_propagator, double* propagators_liouville,
+                             double* filter_function) {
     FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
     FFK_REQUIRE(T >= 1 && G >= 1 && A >= 1 && N >= 1 && W >= 1, "empty axis");
+    FFK_REQUIRE(!filter_function || which == 0, "the filter function needs the summed control matrix");
     FFK_REQUIRE(total_propagators && total_phases && control_matrix_table && index && basis &&
                 control_matrix && total_propagator, "NULL argument");
     FFK_REQUIRE(which == 0 || which == 1, "invalid which=%d", which);
@@ -821,10 +823,11 @@ int ffk_concatenate_sequence(const double* total_propagators, const double* tota
     const size_t nO = which ? 16*size_t(G)*A*N*W : 16*size_t(A)*N*W;
     const size_t sws = ffk::scan_workspace_bytes(G, d), lws = ffk::liouville_workspace_bytes(nl, d, N);
     const size_t aws = ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W);
+    const size_t nF = filter_function ? 16*size_t(A)*A*W : 0;
     void* base;
     if (int rc = arena_reserve(align_up(nU) + align_up(nP) + align_up(nR) + align_up(nI) + align_up(nB) +
                                align_up(nSeq) + align_up(nQ) + align_up(nL) + align_up(nO) +
-                               align_up(sws) + align_up(lws) + align_up(aws), &base))
+                               align_up(sws) + align_up(lws) + align_up(aws) + align_up(nF), &base))
         return rc;
     Bump a(base, g_arena.size);
     double* dU = a.take<double>(nU/8);
@@ -839,6 +842,7 @@ int ffk_concatenate_sequence(const double* total_propagators, const double* tota
     void* wscan = a.take<unsigned char>(sws);
     void* wliou = a.take<unsigned char>(lws);
     void* watom = a.take<unsigned char>(aws);
+    double* dF = nF ? a.take<double>(nF/8) : nullptr;
     FFK_HIP(hipMemcpyAsync(dU, total_propagators, nU, hipMemcpyHostToDevice, nullptr));
     FFK_HIP(hipMemcpyAsync(dI, index, nI, hipMemcpyHostToDevice, nullptr));
     FFK_HIP(hipMemcpyAsync(dB, basis, nB, hipMemcpyHostToDevice, nullptr));
@@ -854,6 +858,10 @@ int ffk_concatenate_sequence(const double* total_propagators, const double* tota
     if (int rc = ffk_control_matrix_from_atomic_indexed_dev(dP, dR, dI, dL, l_is_complex, T, G, A, N, W,
                                                             which, dO, watom, aws, nullptr))
         return rc;
+    if (dF) {
+        if (int rc = ffk_filter_function_dev(dO, A, N, W, FFK_FF_FIDELITY, dF, nullptr)) return rc;
+        FFK_HIP(hipMemcpyAsync(filter_function, dF, nF, hipMemcpyDeviceToHost, nullptr));
+    }
     FFK_HIP(hipMemcpyAsync(control_matrix, dO, nO, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipMemcpyAsync(total_propagator, dQ + size_t(G)*dd, 16*dd, hipMemcpyDeviceToHost, nullptr));
     if (propagators_liouville && G > 1)

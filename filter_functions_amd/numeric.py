@@ -416,7 +416,7 @@ def calculate_control_matrix_from_atomic_indexed(total_phases, control_matrix_ta
 
 
 def concatenate_sequence_indexed(total_propagators, total_phases, control_matrix_table, index, basis,
-                                 which='total', return_liouville=False):
+                                 which='total', return_liouville=False, return_filter_function=False):
     """The concatenation rule for a sequence drawn from T distinct pulses in ONE library call
     (reference pulse_sequence.py:1812-1840, spread there over ``util.adot``,
     ``liouville_representation``, ``cumprod`` and ``calculate_control_matrix_from_atomic``): the
@@ -427,7 +427,8 @@ def concatenate_sequence_indexed(total_propagators, total_phases, control_matrix
     (T, n_nops, d², n_omega); index: (G,) position -> distinct pulse.  Returns the control matrix
     ((n_nops, d², n_omega), or (G, ...) for which='correlations'), the sequence's total propagator
     and -- with *return_liouville* -- the (G-1, d², d²) cumulative Liouville propagators (else
-    None)."""
+    None); with *return_filter_function* (which='total') a fourth item, the fidelity filter function
+    of the result."""
     U = as_c128(total_propagators)
     tp = as_c128(total_phases)
     table = as_c128(control_matrix_table)
@@ -453,10 +454,13 @@ def concatenate_sequence_indexed(total_propagators, total_phases, control_matrix
     L = None
     if return_liouville:
         L = np.empty((max(G - 1, 0), N, N), dtype=np.float64 if hermitian else np.complex128)
+    F = np.empty((A, A, W), dtype=np.complex128) if return_filter_function else None
     check(_lib.load().ffk_concatenate_sequence(
         ptr(U), ptr(tp), ptr(table), index.ctypes.data_as(ctypes.c_void_p), ptr(barr), int(bool(hermitian)),
         T, G, d, A, N, W, int(which == 'correlations'), ptr(out), ptr(total),
-        ptr(L) if L is not None and G > 1 else None))
+        ptr(L) if L is not None and G > 1 else None, ptr(F) if F is not None else None))
+    if return_filter_function:
+        return out, total, L, F
     return out, total, L
 
 

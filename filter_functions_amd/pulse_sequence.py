@@ -544,9 +544,11 @@ class PulseSequence:
     def omega(self, value):
         """Remember (a copy of) the frequencies; a grid that differs from the remembered one
         invalidates everything that depends on frequency (reference pulse_sequence.py:1158-1169)."""
+        known = self._frequency_data.get('omega')
+        if known is not None and (value is known or np.array_equal(known, value)):
+            return                           # the remembered copy is the same grid: keep it
         grid = np.array(value, copy=True)
-        if not np.array_equal(self._frequency_data.get('omega'), grid):
-            self.cleanup('frequency dependent')
+        self.cleanup('frequency dependent')
         self._frequency_data['omega'] = grid
 
     @property
@@ -858,11 +860,16 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
         # the whole rule in one library call: cumulative propagators, their Liouville
         # representations, cumulative phases and the sum stay on the device
         table = np.array([atomic_control_matrix(i) for i in first_position])
-        control_matrix, total_propagator, propagators_liouville = numeric.concatenate_sequence_indexed(
+        with_F = mode == 'total' and which == 'fidelity'
+        control_matrix, total_propagator, propagators_liouville, *F = numeric.concatenate_sequence_indexed(
             np.array([pls.total_propagator for pls in distinct]),
             np.array([pls.get_total_phases(omega) for pls in distinct]), table, index, newpulse.basis,
-            which=mode, return_liouville=bool(calc_second_order_FF))
+            which=mode, return_liouville=bool(calc_second_order_FF), return_filter_function=with_F)
         newpulse.total_propagator = total_propagator
+        if with_F:
+            newpulse._store_control_matrix(control_matrix)
+            newpulse.cache_filter_function(omega, filter_function=F[0])
+            return newpulse
     else:
         # Liouville representation of the propagators accumulated before each pulse: the
         # cumulative propagators in one batched device call (the representation is a

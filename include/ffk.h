@@ -187,12 +187,14 @@ int ffk_control_matrix_from_atomic_indexed_dev(const double* total_phases,
  * numeric.calculate_control_matrix_from_atomic) all run on the device.  Returns the control matrix
  * ((A, N, W); (G, A, N, W) for which = 1), the total propagator (d, d) and, if
  * propagators_liouville is not NULL, the (G - 1, N, N) cumulative Liouville propagators (f64 if
- * hermitian_basis, else c128).                                                                   */
+ * hermitian_basis, else c128); if filter_function is not NULL (which = 0 only), also the fidelity
+ * filter function (A, A, W) of the result (numeric.calculate_filter_function).                    */
 int ffk_concatenate_sequence(const double* total_propagators, const double* total_phases,
                              const double* control_matrix_table, const int32_t* index,
                              const double* basis, int hermitian_basis, int T, int G, int d, int A,
                              int N, int W, int which, double* control_matrix,
-                             double* total_propagator, double* propagators_liouville);
+                             double* total_propagator, double* propagators_liouville,
+                             double* filter_function);
 
 /* ---- numeric.calculate_control_matrix_periodic (numeric.py:886-954) ----------------------
  * phases (W,) c128 = exp(i omega T) of one period, control_matrix (A, N, W) c128 of one period,

@@ -1742,6 +1742,9 @@ def test_concatenate_sequence_in_one_call(d, G, T, hermitian):
     assert rel_err(total, cum[-1]) < 1e-13
     assert Lgot.dtype == (np.float64 if hermitian else np.complex128) and rel_err(Lgot, L) < 1e-13
     assert rel_err(R, want) < 1e-12
+    R2, _, _, F = numeric.concatenate_sequence_indexed(U, phases, table, index, basis,
+                                                       return_filter_function=True)
+    assert np.array_equal(R2, R) and rel_err(F, orc.filter_function(want)) < 1e-12
     Rc, _, none = numeric.concatenate_sequence_indexed(U, phases, table, index, basis, which='correlations')
     assert none is None and Rc.shape == (G, A, N, W) and rel_err(Rc.sum(axis=0), want) < 1e-12
     with pytest.raises(ValueError):
