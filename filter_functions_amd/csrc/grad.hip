@@ -91,8 +91,8 @@ __global__ __launch_bounds__(64) void grad_kernel(
     cplx* As = Bs + A*D2;                                  // [H][D2]
     cplx* Es = As + H*D2;                                  // [H][D2]
     double* sec = reinterpret_cast<double*>(Es + H*D2);    // [H][64]  per-lane Re tr(E_h comm)
-    const int s = blockIdx.y;
-    const int w = blockIdx.x*64 + threadIdx.x;
+    const int s = blockIdx.x;            // segments on x: G may exceed 65535
+    const int w = blockIdx.y*64 + threadIdx.x;
     for (int e = threadIdx.x; e < D2; e += 64) {
         const double v = eigvals[static_cast<size_t>(s)*D + e / D] - eigvals[static_cast<size_t>(s)*D + e % D];
         dE[e] = v;
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(64) void grad_ctrlmat_kernel(
     cplx* As = Bs + A*D2;                                  // [H][D2]
     cplx* Es = As + H*D2;                                  // [H][D2]
     cplx* Cb = Es + H*D2;                                  // [N][D2]
-    const int s = blockIdx.y;
-    const int w = blockIdx.x*64 + threadIdx.x;
+    const int s = blockIdx.x;            // segments on x: G may exceed 65535
+    const int w = blockIdx.y*64 + threadIdx.x;
     for (int e = threadIdx.x; e < D2; e += 64) {
         const double v = eigvals[static_cast<size_t>(s)*D + e / D] - eigvals[static_cast<size_t>(s)*D + e % D];
         dE[e] = v;
@@ -461,7 +461,7 @@ hipError_t launch_grad(const double* omega, int W, const double* eigvals, const 
                                            static_cast<int>(lds));
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((grad_kernel<D>), dim3((W + 63)/64, G), dim3(64), lds, stream, omega, W, eigvals,
+    hipLaunchKernelGGL((grad_kernel<D>), dim3(G, (W + 63)/64), dim3(64), lds, stream, omega, W, eigvals,
                        dt, t, ops, abar, E, Ycum, ratio, G, A, H, out);
     return hipGetLastError();
 }
@@ -500,7 +500,7 @@ hipError_t launch_control_matrix_derivative(const double* omega, int W, const do
     if (err != hipSuccess) return err;
     const size_t lds = 2*size_t(d)*d*sizeof(double) + size_t(1 + A + 2*H + N)*d*d*sizeof(cplx);
     if (lds > 160*1024) return hipErrorInvalidValue;
-    const dim3 grid((W + 63)/64, G);
+    const dim3 grid(G, (W + 63)/64);
     switch (d) {
 #define FFK_GRADC_CASE(D)                                                                                 \
     case D: {                                                                                             \
