@@ -1,8 +1,9 @@
 """The reference's own timed example (doc/source/examples/periodic_driving.ipynb: 0.0286 s periodic,
 0.9008 s standard concatenation, 38.38 s brute force, hardware unstated) on the GPU, all three routes,
-with their mutual agreement and an oracle check of the brute-force route on a frequency subsample.
+with their mutual agreement (the check against the oracle and the reference's own outputs is
+tests/test_baseline_configs.py::test_published_example_periodic_driving).
 
-    python tools/periodic_driving.py [--oracle 6]
+    python tools/periodic_driving.py
 """
 import argparse
 import functools
@@ -15,7 +16,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 
 import filter_functions_amd as ff  # noqa: E402
 import workloads as wl  # noqa: E402
@@ -35,9 +35,7 @@ def timed(fn, reps=3):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--oracle', type=int, default=6, help='frequencies checked against the oracle')
-    args = ap.parse_args()
+    argparse.ArgumentParser(description=__doc__).parse_args()
     cfg = wl.PERIODIC_DRIVING
     atomic, wait, full, omega = wl.periodic_driving(ff)
     pub = cfg['published_s']
@@ -67,15 +65,6 @@ def main():
     print('periodic vs standard concatenation :', rel(not_periodic.get_filter_function(omega),
                                                       not_standard.get_filter_function(omega)))
     print('concatenated echo vs brute force   :', rel(F_echo, F_brute))
-    if args.oracle:
-        import ff_oracle as orc
-        sub = np.linspace(0, len(omega) - 1, args.oracle).astype(int)
-        t0 = time.perf_counter()
-        D, V, Q = orc.diagonalize(orc.hamiltonian(echo_full.c_opers, echo_full.c_coeffs), echo_full.dt)
-        R = orc.control_matrix_from_scratch(D, V, Q, omega[sub], np.asarray(echo_full.basis),
-                                            echo_full.n_opers, echo_full.n_coeffs, echo_full.dt)
-        print(f'brute force vs oracle on {args.oracle} frequencies:', rel(F_brute[..., sub], orc.filter_function(R)),
-              f'(oracle: {time.perf_counter() - t0:.1f} s)')
 
 
 if __name__ == '__main__':
