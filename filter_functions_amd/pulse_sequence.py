@@ -854,9 +854,9 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     newpulse.omega = omega
     newpulse._defer_by_products()           # total phases, Liouville propagator: on first read
     mode = 'correlations' if calc_pulse_correlation_FF or calc_second_order_FF else 'total'
-    # the indexed kernel assumes a repeated pulse contributes the same rows everywhere, which
-    # holds when every pulse carries every noise operator (else fall back to the plain rule)
-    if len(distinct) < len(pulses) and present.all():
+    # the table rule assumes a pulse contributes the same rows wherever it stands, which holds
+    # when every pulse carries every noise operator (else fall back to the plain rule)
+    if present.all():
         # the whole rule in one library call: cumulative propagators, their Liouville
         # representations, cumulative phases and the sum stay on the device
         table = np.array([atomic_control_matrix(i) for i in first_position])
