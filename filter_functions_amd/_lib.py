@@ -102,6 +102,9 @@ SIGNATURES = {
     'ffk_concatenate_sequence': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),
+    'ffk_concatenate_sequence_resident': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                  c_void_p]),
     'ffk_control_matrix_periodic': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                             c_int, c_void_p]),
     'ffk_control_matrix_periodic_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),

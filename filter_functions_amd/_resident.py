@@ -139,6 +139,17 @@ class ResidentResult:
         self._filter_function = weakref.ref(F)
         return D, V, Q, F
 
+    def adopt(self, shape, filter_function):
+        """The handle was filled by another library call (a concatenation that left its control
+        matrix and filter function resident): remember the shape and which host array is F."""
+        self.shape = tuple(shape)
+        self._filter_function = weakref.ref(filter_function)
+
+    @property
+    def handle(self):
+        """The ``ffk_resident*`` (for calls that read several resident results)."""
+        return self._handle
+
     @property
     def filter_function(self):
         """The host array of the resident F, if it is still alive."""

@@ -788,8 +788,6 @@ __global__ void gather_propagators_kernel(const cplx* __restrict__ table, const 
 }
 }  // namespace
 
-extern "C" {
-
 // ---- pulse_sequence.concatenate for a sequence drawn from T distinct pulses, in one call --------
 // (pulse_sequence.py:1812-1840: the cumulative propagators, their Liouville representations, the
 // cumulative phase factors and the concatenation rule).  total_propagators (T, d, d) c128,
@@ -798,7 +796,74 @@ extern "C" {
 // (liouville.hip) -> the gather-from-table rule (atomic.hip); nothing but the tables goes in and
 // the results come out.  Outputs: control matrix ((A, N, W), or (G, A, N, W) for which = 1), the
 // sequence's total propagator (d, d) and -- if not NULL -- the (G - 1, N, N) Liouville propagators
-// (f64 for a Hermitian basis, else c128).
+// (f64 for a Hermitian basis, else c128), and -- if not NULL, which = 0 -- the fidelity filter
+// function (A, A, W) of the summed control matrix.
+namespace {
+
+// temporaries of one sequence run, in arena order
+size_t sequence_scratch_bytes(int G, int d, int A, int N, int W, int which, bool hermitian, bool want_F) {
+    const size_t dd = size_t(d)*d;
+    const int nl = G > 1 ? G - 1 : 1;
+    return align_up(16*size_t(G)*dd) + align_up(16*size_t(G + 1)*dd) +
+           align_up((hermitian ? 8 : 16)*size_t(nl)*N*N) +
+           align_up(which ? 16*size_t(G)*A*N*W : 16*size_t(A)*N*W) +
+           align_up(ffk::scan_workspace_bytes(G, d)) + align_up(ffk::liouville_workspace_bytes(nl, d, N)) +
+           align_up(ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W)) +
+           (want_F ? align_up(16*size_t(A)*A*W) : 0);
+}
+
+// gather -> prefix products -> Liouville representation -> table rule (-> F) on `s`, all operands
+// already on the device; results to the host pointers (asynchronously: the caller synchronises)
+int sequence_on_device(const double* dU, const double* dP, const double* dR, const int32_t* dI,
+                       const double* dB, int hermitian_basis, int T, int G, int d, int A, int N, int W,
+                       int which, Bump& a, double* control_matrix, double* total_propagator,
+                       double* propagators_liouville, double* filter_function, hipStream_t s,
+                       double* resident_R = nullptr, double* resident_F = nullptr) {
+    const size_t dd = size_t(d)*d;
+    const int l_is_complex = hermitian_basis ? 0 : 1;
+    const int nl = G > 1 ? G - 1 : 1;
+    const size_t nL = (l_is_complex ? 16 : 8)*size_t(nl)*N*N;
+    const size_t nO = which ? 16*size_t(G)*A*N*W : 16*size_t(A)*N*W;
+    const size_t sws = ffk::scan_workspace_bytes(G, d), lws = ffk::liouville_workspace_bytes(nl, d, N);
+    const size_t aws = ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W);
+    const size_t nF = filter_function ? 16*size_t(A)*A*W : 0;
+    cplx* dSeq = a.take<cplx>(size_t(G)*dd);
+    cplx* dQ = a.take<cplx>(size_t(G + 1)*dd);
+    double* dL = a.take<double>(nL/8);
+    double* dO = a.take<double>(nO/8);
+    void* wscan = a.take<unsigned char>(sws);
+    void* wliou = a.take<unsigned char>(lws);
+    void* watom = a.take<unsigned char>(aws);
+    double* dF = nF ? a.take<double>(nF/8) : nullptr;
+    FFK_REQUIRE(watom && (!nF || dF), "workspace too small");
+    if (resident_R) dO = resident_R;          // results that stay in a handle's device block
+    if (resident_F) dF = resident_F;
+    hipLaunchKernelGGL(gather_propagators_kernel, dim3(static_cast<unsigned>((size_t(G)*dd + 255)/256)),
+                       dim3(256), 0, s, reinterpret_cast<const cplx*>(dU), dI, G, d*d, dSeq);
+    FFK_HIP(hipGetLastError());
+    FFK_HIP(ffk::launch_prefix_products(dSeq, G, d, dQ, wscan, s));
+    if (G > 1)
+        FFK_HIP(ffk::launch_liouville(dQ + dd, G - 1, d, reinterpret_cast<const cplx*>(dB), N,
+                                      hermitian_basis, dL, wliou, s));
+    if (int rc = ffk_control_matrix_from_atomic_indexed_dev(dP, dR, dI, dL, l_is_complex, T, G, A, N, W,
+                                                            which, dO, watom, aws, s))
+        return rc;
+    if (dF) {
+        if (int rc = ffk_filter_function_dev(dO, A, N, W, FFK_FF_FIDELITY, dF, s)) return rc;
+        FFK_HIP(hipMemcpyAsync(filter_function, dF, nF, hipMemcpyDeviceToHost, s));
+    }
+    if (control_matrix) FFK_HIP(hipMemcpyAsync(control_matrix, dO, nO, hipMemcpyDeviceToHost, s));
+    FFK_HIP(hipMemcpyAsync(total_propagator, dQ + size_t(G)*dd, 16*dd, hipMemcpyDeviceToHost, s));
+    if (propagators_liouville && G > 1)
+        FFK_HIP(hipMemcpyAsync(propagators_liouville, dL, (l_is_complex ? 16 : 8)*size_t(G - 1)*N*N,
+                               hipMemcpyDeviceToHost, s));
+    return FFK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int ffk_concatenate_sequence(const double* total_propagators, const double* total_phases,
                              const double* control_matrix_table, const int32_t* index,
                              const double* basis, int hermitian_basis, int T, int G, int d, int A,
@@ -815,19 +880,12 @@ int ffk_concatenate_sequence(const double* total_propagators, const double* tota
         FFK_REQUIRE(index[g] >= 0 && index[g] < T, "index[%d] = %d outside [0, %d)", g, index[g], T);
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t dd = size_t(d)*d;
-    const int l_is_complex = hermitian_basis ? 0 : 1;
-    const int nl = G > 1 ? G - 1 : 1;
     const size_t nU = 16*size_t(T)*dd, nP = 16*size_t(T)*W, nR = 16*size_t(T)*A*N*W, nI = 4*size_t(G);
-    const size_t nB = 16*size_t(N)*dd, nSeq = 16*size_t(G)*dd, nQ = 16*size_t(G + 1)*dd;
-    const size_t nL = (l_is_complex ? 16 : 8)*size_t(nl)*N*N;
-    const size_t nO = which ? 16*size_t(G)*A*N*W : 16*size_t(A)*N*W;
-    const size_t sws = ffk::scan_workspace_bytes(G, d), lws = ffk::liouville_workspace_bytes(nl, d, N);
-    const size_t aws = ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W);
-    const size_t nF = filter_function ? 16*size_t(A)*A*W : 0;
+    const size_t nB = 16*size_t(N)*dd;
     void* base;
     if (int rc = arena_reserve(align_up(nU) + align_up(nP) + align_up(nR) + align_up(nI) + align_up(nB) +
-                               align_up(nSeq) + align_up(nQ) + align_up(nL) + align_up(nO) +
-                               align_up(sws) + align_up(lws) + align_up(aws) + align_up(nF), &base))
+                               sequence_scratch_bytes(G, d, A, N, W, which, hermitian_basis != 0,
+                                                      filter_function != nullptr), &base))
         return rc;
     Bump a(base, g_arena.size);
     double* dU = a.take<double>(nU/8);
@@ -835,38 +893,15 @@ int ffk_concatenate_sequence(const double* total_propagators, const double* tota
     double* dR = a.take<double>(nR/8);
     int32_t* dI = a.take<int32_t>(G);
     double* dB = a.take<double>(nB/8);
-    cplx* dSeq = a.take<cplx>(nSeq/16);
-    cplx* dQ = a.take<cplx>(nQ/16);
-    double* dL = a.take<double>(nL/8);
-    double* dO = a.take<double>(nO/8);
-    void* wscan = a.take<unsigned char>(sws);
-    void* wliou = a.take<unsigned char>(lws);
-    void* watom = a.take<unsigned char>(aws);
-    double* dF = nF ? a.take<double>(nF/8) : nullptr;
     FFK_HIP(hipMemcpyAsync(dU, total_propagators, nU, hipMemcpyHostToDevice, nullptr));
     FFK_HIP(hipMemcpyAsync(dI, index, nI, hipMemcpyHostToDevice, nullptr));
     FFK_HIP(hipMemcpyAsync(dB, basis, nB, hipMemcpyHostToDevice, nullptr));
-    hipLaunchKernelGGL(gather_propagators_kernel, dim3(static_cast<unsigned>((size_t(G)*dd + 255)/256)),
-                       dim3(256), 0, nullptr, reinterpret_cast<const cplx*>(dU), dI, G, d*d, dSeq);
-    FFK_HIP(hipGetLastError());
-    FFK_HIP(ffk::launch_prefix_products(dSeq, G, d, dQ, wscan, nullptr));
-    if (G > 1)
-        FFK_HIP(ffk::launch_liouville(dQ + dd, G - 1, d, reinterpret_cast<const cplx*>(dB), N,
-                                      hermitian_basis, dL, wliou, nullptr));
     FFK_HIP(hipMemcpyAsync(dP, total_phases, nP, hipMemcpyHostToDevice, nullptr));
     FFK_HIP(hipMemcpyAsync(dR, control_matrix_table, nR, hipMemcpyHostToDevice, nullptr));
-    if (int rc = ffk_control_matrix_from_atomic_indexed_dev(dP, dR, dI, dL, l_is_complex, T, G, A, N, W,
-                                                            which, dO, watom, aws, nullptr))
+    if (int rc = sequence_on_device(dU, dP, dR, dI, dB, hermitian_basis, T, G, d, A, N, W, which, a,
+                                    control_matrix, total_propagator, propagators_liouville,
+                                    filter_function, nullptr))
         return rc;
-    if (dF) {
-        if (int rc = ffk_filter_function_dev(dO, A, N, W, FFK_FF_FIDELITY, dF, nullptr)) return rc;
-        FFK_HIP(hipMemcpyAsync(filter_function, dF, nF, hipMemcpyDeviceToHost, nullptr));
-    }
-    FFK_HIP(hipMemcpyAsync(control_matrix, dO, nO, hipMemcpyDeviceToHost, nullptr));
-    FFK_HIP(hipMemcpyAsync(total_propagator, dQ + size_t(G)*dd, 16*dd, hipMemcpyDeviceToHost, nullptr));
-    if (propagators_liouville && G > 1)
-        FFK_HIP(hipMemcpyAsync(propagators_liouville, dL, (l_is_complex ? 16 : 8)*size_t(G - 1)*N*N,
-                               hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipStreamSynchronize(nullptr));
     return FFK_OK;
 }
@@ -2286,6 +2321,144 @@ int on_owning_device(const ffk_resident* r) {
     return FFK_OK;
 }
 }  // namespace
+
+}  // extern "C"
+
+namespace {
+// phases[k, w] = exp(i omega[w] tau[k]) (pulse_sequence.py:1156, util.cexp)
+__global__ void total_phases_kernel(const double* __restrict__ omega, const double* __restrict__ tau, int T,
+                                    int W, cplx* __restrict__ phases) {
+    const int w = blockIdx.x*blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (w >= W || k >= T) return;
+    phases[static_cast<size_t>(k)*W + w] = ffk::cexp(omega[w]*tau[k]);
+}
+}  // namespace
+
+extern "C" {
+
+// ffk_concatenate_sequence for distinct pulses whose control matrices are still resident (every one
+// evaluated by ffk_resident_filter_function* on the same frequency grid): the table is assembled
+// by device-to-device copies, the total propagators come from the handles' host blocks, the total
+// phase factors exp(i omega tau_k) are formed on the device -- per call only index, basis and tau
+// cross PCIe.  With `result` (which = 0, filter_function wanted) the summed control matrix, its filter
+// function and the grid STAY in that handle (control_matrix may then be NULL): the new pulse is as
+// resident as its parts -- ffk_resident_control_matrix / _infidelity serve it, and it can be an
+// input of the next concatenation.
+int ffk_concatenate_sequence_resident(ffk_resident* const* pulses, const double* tau,
+                                      const int32_t* index, const double* basis, int hermitian_basis,
+                                      int T, int G, int which, double* control_matrix,
+                                      double* total_propagator, double* propagators_liouville,
+                                      double* filter_function, ffk_resident* result) {
+    FFK_REQUIRE(pulses && tau && index && basis && total_propagator, "NULL argument");
+    FFK_REQUIRE(control_matrix || result, "NULL argument");
+    FFK_REQUIRE(!result || (which == 0 && filter_function), "a resident result holds the summed control "
+                "matrix and its filter function");
+    for (int k = 0; result && k < T; ++k) FFK_REQUIRE(pulses[k] != result, "result must not be an input");
+    FFK_REQUIRE(T >= 1 && T <= 65535 && G >= 1, "empty or oversized axis: T=%d G=%d", T, G);
+    FFK_REQUIRE(which == 0 || which == 1, "invalid which=%d", which);
+    FFK_REQUIRE(!filter_function || which == 0, "the filter function needs the summed control matrix");
+    for (int k = 0; k < T; ++k) FFK_REQUIRE(pulses[k] && pulses[k]->valid, "pulse %d has no resident result", k);
+    const ffk_resident* first = pulses[0];
+    const int d = first->d, A = first->A, N = first->N, W = first->W;
+    for (int k = 0; k < T; ++k) {
+        const ffk_resident* r = pulses[k];
+        FFK_REQUIRE(r->d == d && r->A == A && r->N == N && r->W == W && r->device == first->device,
+                    "pulse %d: shape (d=%d, A=%d, N=%d, W=%d) or device differs from pulse 0", k, r->d,
+                    r->A, r->N, r->W);
+    }
+    for (int g = 0; g < G; ++g)
+        FFK_REQUIRE(index[g] >= 0 && index[g] < T, "index[%d] = %d outside [0, %d)", g, index[g], T);
+    if (int rc = on_owning_device(first)) return rc;
+    hipStream_t s;
+    if (int rc = resident_stream(&s)) return rc;
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t dd = size_t(d)*d;
+    const size_t nU = 16*size_t(T)*dd, nP = 16*size_t(T)*W, nR1 = 16*size_t(A)*N*W, nI = 4*size_t(G);
+    const size_t nB = 16*size_t(N)*dd, nT = 8*size_t(T);
+    // host staging (propagators | tau | index | basis) in one pinned block, one H2D
+    const size_t oU = 0, oT = oU + align_up(nU), oI = oT + align_up(nT), oB = oI + align_up(nI);
+    const size_t stage = oB + align_up(nB);
+    Block pin = {nullptr, 0, -1};
+    if (int rc = g_pin_pool.take(stage, first->device, &pin)) return rc;
+    unsigned char* hp = static_cast<unsigned char*>(pin.ptr);
+    for (int k = 0; k < T; ++k) {
+        const ffk_resident* r = pulses[k];
+        const unsigned char* q = static_cast<const unsigned char*>(r->pin.ptr) + r->L.Q + 16*size_t(r->G)*dd;
+        std::memcpy(hp + oU + 16*size_t(k)*dd, q, 16*dd);         // Q[-1]: the pulse's total propagator
+    }
+    std::memcpy(hp + oT, tau, nT);
+    std::memcpy(hp + oI, index, nI);
+    std::memcpy(hp + oB, basis, nB);
+    void* base;
+    int rc = arena_reserve(stage + align_up(nP) + align_up(nR1*T) +
+                           sequence_scratch_bytes(G, d, A, N, W, which, hermitian_basis != 0,
+                                                  filter_function != nullptr), &base);
+    if (rc) { g_pin_pool.give(pin); return rc; }
+    Bump a(base, g_arena.size);
+    unsigned char* dS = a.take<unsigned char>(stage);
+    double* dP = a.take<double>(nP/8);
+    double* dR = a.take<double>(nR1*T/8);
+    // a result handle takes the layout of a one-segment pass: R, F and the grid in its device block,
+    // (identity, total propagator) where the propagators of a pass sit in its host block
+    ResidentLayout RL = {};
+    double* keep_R = nullptr;
+    double* keep_F = nullptr;
+    if (result) {
+        result->valid = false;
+        RL = resident_layout(1, d, W, N, A);
+        if (result->device != first->device || result->dev.size < RL.end || result->pin.size < RL.outputs_end) {
+            g_dev_pool.give(result->dev);
+            g_pin_pool.give(result->pin);
+            result->dev = result->pin = Block{nullptr, 0, -1};
+            rc = g_dev_pool.take(RL.end, first->device, &result->dev);
+            if (!rc) rc = g_pin_pool.take(RL.outputs_end, first->device, &result->pin);
+            if (rc) { g_pin_pool.give(pin); return rc; }
+            result->device = first->device;
+        }
+        result->G = 1; result->d = d; result->W = W; result->N = N; result->A = A; result->L = RL;
+        unsigned char* rp = static_cast<unsigned char*>(result->dev.ptr);
+        keep_R = reinterpret_cast<double*>(rp + RL.R);
+        keep_F = reinterpret_cast<double*>(rp + RL.F);
+    }
+    auto run = [&]() -> int {
+        FFK_HIP(hipMemcpyAsync(dS, hp, stage, hipMemcpyHostToDevice, s));
+        if (result)
+            FFK_HIP(hipMemcpyAsync(static_cast<unsigned char*>(result->dev.ptr) + RL.omega,
+                                   static_cast<const unsigned char*>(first->dev.ptr) + first->L.omega,
+                                   8*size_t(W), hipMemcpyDeviceToDevice, s));
+        for (int k = 0; k < T; ++k)
+            FFK_HIP(hipMemcpyAsync(reinterpret_cast<unsigned char*>(dR) + nR1*k,
+                                   static_cast<const unsigned char*>(pulses[k]->dev.ptr) + pulses[k]->L.R,
+                                   nR1, hipMemcpyDeviceToDevice, s));
+        const double* dOmega = reinterpret_cast<const double*>(
+            static_cast<const unsigned char*>(first->dev.ptr) + first->L.omega);
+        hipLaunchKernelGGL(total_phases_kernel, dim3((W + 255)/256, T), dim3(256), 0, s, dOmega,
+                           reinterpret_cast<const double*>(dS + oT), T, W, reinterpret_cast<cplx*>(dP));
+        FFK_HIP(hipGetLastError());
+        if (int rc2 = sequence_on_device(reinterpret_cast<const double*>(dS + oU), dP, dR,
+                                         reinterpret_cast<const int32_t*>(dS + oI),
+                                         reinterpret_cast<const double*>(dS + oB), hermitian_basis, T, G, d,
+                                         A, N, W, which, a, control_matrix, total_propagator,
+                                         propagators_liouville, filter_function, s, keep_R, keep_F))
+            return rc2;
+        FFK_HIP(hipStreamSynchronize(s));
+        return FFK_OK;
+    };
+    rc = run();
+    g_pin_pool.give(pin);
+    if (!rc && result) {
+        double* q = reinterpret_cast<double*>(static_cast<unsigned char*>(result->pin.ptr) + RL.Q);
+        for (size_t e = 0; e < dd; ++e) {
+            q[2*e] = (e / d == e % d) ? 1.0 : 0.0;
+            q[2*e + 1] = 0.0;
+        }
+        std::memcpy(q + 2*dd, total_propagator, 16*dd);
+        result->t_stage = result->t_enqueue = result->t_wait = 0.0;
+        result->valid = true;
+    }
+    return rc;
+}
 
 int ffk_resident_control_matrix(ffk_resident* r, double* control_matrix) {
     FFK_REQUIRE(r && r->valid, "no resident result");

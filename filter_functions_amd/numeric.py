@@ -464,6 +464,49 @@ def concatenate_sequence_indexed(total_propagators, total_phases, control_matrix
     return out, total, L
 
 
+def concatenate_sequence_resident(residents, tau, index, basis, which='total', return_liouville=False,
+                                  return_filter_function=False, keep=None):
+    """:func:`concatenate_sequence_indexed` for distinct pulses whose control matrices are still
+    resident in HBM (``_resident.ResidentResult`` objects, all on one frequency grid): the table
+    never crosses PCIe, the total phases ``exp(i omega tau_k)`` are formed on the device.  *tau*:
+    (T,) total durations.  Same return values -- except with *keep* (a fresh ``ResidentResult``;
+    which='total' with the filter function): the summed control matrix then STAYS in HBM, owned by
+    *keep* (fetch it with ``keep.control_matrix()``), and None is returned in its place."""
+    index = np.ascontiguousarray(index, dtype=np.int32)
+    tau = as_f64(tau)
+    barr = as_c128(np.asarray(basis))
+    T, G = len(residents), len(index)
+    _, d, W, N, A = residents[0].shape
+    if barr.shape != (N, d, d) or tau.shape != (T,):
+        raise ValueError(f'Expected basis of shape ({N}, {d}, {d}) and tau ({T},), not {barr.shape} and {tau.shape}.')
+    if G < 1 or index.min() < 0 or index.max() >= T:
+        raise ValueError('index must be a non-empty sequence of values in [0, T).')
+    hermitian = getattr(basis, 'isherm', None)
+    if hermitian is None:
+        hermitian = np.allclose(barr, barr.conj().swapaxes(-1, -2), atol=np.finfo(complex).eps*d**3, rtol=0)
+    handles = (ctypes.c_void_p*T)(*(r.handle for r in residents))
+    if keep is not None and (which != 'total' or not return_filter_function):
+        raise ValueError("keep needs which='total' and return_filter_function=True")
+    out = None
+    if keep is None:
+        out = np.empty((G, A, N, W) if which == 'correlations' else (A, N, W), dtype=np.complex128)
+    total = np.empty((d, d), dtype=np.complex128)
+    L = None
+    if return_liouville:
+        L = np.empty((max(G - 1, 0), N, N), dtype=np.float64 if hermitian else np.complex128)
+    F = np.empty((A, A, W), dtype=np.complex128) if return_filter_function else None
+    check(_lib.load().ffk_concatenate_sequence_resident(
+        handles, ptr(tau), index.ctypes.data_as(ctypes.c_void_p), ptr(barr), int(bool(hermitian)), T, G,
+        int(which == 'correlations'), ptr(out) if out is not None else None, ptr(total),
+        ptr(L) if L is not None and G > 1 else None, ptr(F) if F is not None else None,
+        keep.handle if keep is not None else None))
+    if keep is not None:
+        keep.adopt((1, d, W, N, A), F)
+    if return_filter_function:
+        return out, total, L, F
+    return out, total, L
+
+
 def calculate_control_matrix_periodic(phases, control_matrix, total_propagator_liouville, repeats,
                                       check_invertible=True):
     r"""Control matrix of *repeats* periods of a pulse from the control matrix (n_nops, d**2,

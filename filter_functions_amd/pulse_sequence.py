@@ -334,16 +334,18 @@ class PulseSequence:
                 and not any(key in self._frequency_data
                             for key in ('control_matrix', 'control_matrix_pc')))
 
-    def _resident_pass(self):
+    def _resident_pass(self, keep_filter_function=True):
         """diagonalize + control matrix + filter function in one library call; the control matrix
-        stays on the device behind a :class:`Deferred` cache entry."""
+        stays on the device behind a :class:`Deferred` cache entry.  (``cache_control_matrix`` caches
+        no filter function in the reference: *keep_filter_function* False leaves it out.)"""
         result = ResidentResult()
         D, V, Q, F = result.evaluate(self.c_opers, self.dt, self.t, self.omega, np.asarray(self.basis),
                                      self.n_opers, self.n_coeffs, c_coeffs=self.c_coeffs)
         self._data.update(eigvals=D, eigvecs=V, propagators=Q, total_propagator=Q[-1])
         self._frequency_data['control_matrix'] = Deferred(result.control_matrix,
                                                           result.control_matrix_nbytes())
-        self._frequency_data['filter_function'] = F
+        if keep_filter_function:
+            self._frequency_data['filter_function'] = F
         self._defer_by_products()
         self._resident = result
 
@@ -366,6 +368,7 @@ class PulseSequence:
     def _store_control_matrix(self, control_matrix):
         slot = 'control_matrix_pc' if control_matrix.ndim == 4 else 'control_matrix'
         self._frequency_data[slot] = control_matrix
+        self._resident = None                 # (a resident result would describe another control matrix)
         self._defer_by_products()
 
     def get_control_matrix(self, omega, show_progressbar=False, cache_intermediates=False):
@@ -392,10 +395,12 @@ class PulseSequence:
         """Cache the control matrix -- computed now if not given --, the total phases and the
         total Liouville propagator (reference pulse_sequence.py:638-677)."""
         self.omega = omega
-        if control_matrix is None:
-            self.get_control_matrix(self.omega, show_progressbar, cache_intermediates)
-        else:
+        if control_matrix is not None:
             self._store_control_matrix(control_matrix)
+        elif self._resident_pass_applies('fidelity', 1, cache_intermediates):
+            self._resident_pass(keep_filter_function=False)   # stays in HBM until somebody reads it
+        else:
+            self.get_control_matrix(self.omega, show_progressbar, cache_intermediates)
 
     def get_pulse_correlation_control_matrix(self):
         if 'control_matrix_pc' not in self._frequency_data:
@@ -441,6 +446,10 @@ class PulseSequence:
             known['filter_function_2'] = filter_function
             return
         generalized = which == 'generalized'
+        if (filter_function is None and control_matrix is None
+                and self._resident_pass_applies(which, order, cache_intermediates)):
+            self._resident_pass()
+            return
         if filter_function is None:
             if control_matrix is None:
                 control_matrix = self.get_control_matrix(self.omega, show_progressbar,
@@ -832,12 +841,17 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     # every distinct control matrix is evaluated / fetched once
     seg = np.concatenate(([0], np.cumsum(np.array([len(pls.dt) for pls in distinct])[index])))
 
+    def own_rows(i):
+        """Rows of pulse i's control matrix in the order of the new pulse's noise operators."""
+        pls = pulses[i]
+        return [list(pls.n_oper_identifiers).index(old)
+                for new in np.asarray(new_ids)[present[i]]
+                for old, mapped in n_map[i].items() if mapped == new]
+
     def atomic_control_matrix(i):
         """Control matrix of the pulse at position i in the new pulse's operator order."""
         pls, here = pulses[i], present[i]
-        own_order = [list(pls.n_oper_identifiers).index(old)
-                     for new in np.asarray(new_ids)[here]
-                     for old, mapped in n_map[i].items() if mapped == new]
+        own_order = own_rows(i)
         own = pls.get_control_matrix(omega, show_progressbar)
         if here.all() and own_order == list(range(len(own))):
             return own                       # same operators in the same order: no copy
@@ -859,12 +873,31 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     if present.all():
         # the whole rule in one library call: cumulative propagators, their Liouville
         # representations, cumulative phases and the sum stay on the device
-        table = np.array([atomic_control_matrix(i) for i in first_position])
         with_F = mode == 'total' and which == 'fidelity'
-        control_matrix, total_propagator, propagators_liouville, *F = numeric.concatenate_sequence_indexed(
-            np.array([pls.total_propagator for pls in distinct]),
-            np.array([pls.get_total_phases(omega) for pls in distinct]), table, index, newpulse.basis,
-            which=mode, return_liouville=bool(calc_second_order_FF), return_filter_function=with_F)
+        wanted = dict(which=mode, return_liouville=bool(calc_second_order_FF), return_filter_function=with_F)
+        residents = [pls._resident for pls in distinct]
+        if (all(res is not None and res.shape is not None and res.shape[1:] == residents[0].shape[1:]
+                and np.array_equal(pls.omega, omega) for res, pls in zip(residents, distinct))
+                and all(own_rows(i) == list(range(len(new_ids))) for i in first_position)):
+            # every distinct pulse still has its control matrix in HBM (evaluated by the resident
+            # pass on this grid): the table is assembled there, nothing but index, basis and the
+            # durations goes in
+            keep = ResidentResult() if with_F else None       # the result stays resident as well
+            control_matrix, total_propagator, propagators_liouville, *F = numeric.concatenate_sequence_resident(
+                residents, [pls.tau for pls in distinct], index, newpulse.basis, keep=keep, **wanted)
+            if keep is not None:
+                newpulse.total_propagator = total_propagator
+                newpulse._frequency_data['control_matrix'] = Deferred(keep.control_matrix,
+                                                                      keep.control_matrix_nbytes())
+                newpulse.cache_filter_function(omega, filter_function=F[0])
+                newpulse._resident = keep
+                return newpulse
+        else:
+            table = np.array([atomic_control_matrix(i) for i in first_position])
+            control_matrix, total_propagator, propagators_liouville, *F = numeric.concatenate_sequence_indexed(
+                np.array([pls.total_propagator for pls in distinct]),
+                np.array([pls.get_total_phases(omega) for pls in distinct]), table, index, newpulse.basis,
+                **wanted)
         newpulse.total_propagator = total_propagator
         if with_F:
             newpulse._store_control_matrix(control_matrix)

@@ -196,6 +196,21 @@ int ffk_concatenate_sequence(const double* total_propagators, const double* tota
                              double* total_propagator, double* propagators_liouville,
                              double* filter_function);
 
+/* The same for distinct pulses whose control matrices are still resident in HBM (each evaluated by
+ * ffk_resident_filter_function[_from_controls] on the same frequency grid, same device): handles
+ * (T,), tau (T,) f64 total durations (the total phases exp(i omega tau) are formed on the device
+ * from the resident grid), index (G,) int32, basis (N, d, d) c128.  The table of control matrices
+ * is assembled by device-to-device copies; shapes come from the handles.  With `result` (another
+ * handle; which = 0 and filter_function required, control_matrix may be NULL) the summed control
+ * matrix, its filter function and the grid stay resident in it: ffk_resident_control_matrix and
+ * ffk_resident_infidelity serve the concatenated pulse, and it can be an input of a further call. */
+struct ffk_resident;
+int ffk_concatenate_sequence_resident(struct ffk_resident* const* pulses, const double* tau,
+                                      const int32_t* index, const double* basis, int hermitian_basis,
+                                      int T, int G, int which, double* control_matrix,
+                                      double* total_propagator, double* propagators_liouville,
+                                      double* filter_function, struct ffk_resident* result);
+
 /* ---- numeric.calculate_control_matrix_periodic (numeric.py:886-954) ----------------------
  * phases (W,) c128 = exp(i omega T) of one period, control_matrix (A, N, W) c128 of one period,
  * total_propagator_liouville (N, N) f64 (or c128 if l_is_complex) of one period -> the control

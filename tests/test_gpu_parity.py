@@ -1753,6 +1753,74 @@ def test_concatenate_sequence_in_one_call(d, G, T, hermitian):
         numeric.concatenate_sequence_indexed(U[:-1] if T > 1 else U[:, :1], phases, table, index, basis)
 
 
+@pytest.mark.parametrize('d', [2, 4])
+def test_concatenate_from_resident_control_matrices(d, monkeypatch):
+    """Pulses evaluated by the resident pass keep their control matrices in HBM; ff.concatenate then
+    assembles the table there (ffk_concatenate_sequence_resident).  Same results as the route
+    through host tables (deep copies of the pulses carry host arrays only) and as the from-scratch
+    evaluation of the concatenated pulse; the resident route is actually the one taken."""
+    import copy
+    rng = np.random.default_rng(d)
+    basis = ff.Basis.pauli(int(np.log2(d)))
+
+    def herm(n):
+        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+        return M + M.conj().transpose(0, 2, 1)
+    c_opers, n_opers = herm(2), herm(3)
+    omega = np.geomspace(1e-2, 1e2, 300)
+    pulses = []
+    for k in range(4):
+        n_dt = int(rng.integers(1, 6))
+        pulses.append(ff.PulseSequence(
+            [[c_opers[i], rng.standard_normal(n_dt), f'c{i}'] for i in range(2)],
+            [[n_opers[a], np.full(n_dt, 1.0 + a), f'n{a}'] for a in range(3)],
+            rng.random(n_dt) + 0.1, basis))
+        pulses[-1].get_filter_function(omega)
+        assert pulses[-1]._resident is not None
+    index = rng.integers(0, 4, 60)
+    calls = []
+    real = numeric.concatenate_sequence_resident
+    monkeypatch.setattr(numeric, 'concatenate_sequence_resident',
+                        lambda *args, **kwargs: calls.append(1) or real(*args, **kwargs))
+    total = ff.concatenate([pulses[k] for k in index])
+    assert calls == [1]
+    # the concatenated pulse is as resident as its parts: control matrix still in HBM, infidelity on
+    # the resident F, and it can take part in the next concatenation without leaving the device
+    from filter_functions_amd._resident import Deferred
+    assert total._resident is not None and isinstance(total._frequency_data.peek('control_matrix'), Deferred)
+    S = 1e-3/omega
+    infid_resident = ff.infidelity(total, S, omega)
+    nested = ff.concatenate([total, pulses[1], total])
+    assert calls == [1, 1] and nested._resident is not None
+    calls.pop()
+    copies = [copy.deepcopy(p) for p in pulses]
+    assert all(c._resident is None and c.is_cached('control_matrix') for c in copies)
+    via_host = ff.concatenate([copies[k] for k in index])
+    assert calls == [1]
+    scratch = ff.concatenate_without_filter_function([pulses[k] for k in index])
+    assert rel_err(total.get_control_matrix(omega), via_host.get_control_matrix(omega)) < 1e-13
+    assert rel_err(total.get_filter_function(omega), via_host.get_filter_function(omega)) < 1e-13
+    assert rel_err(total.total_propagator, via_host.total_propagator) < 1e-13
+    assert rel_err(total.get_control_matrix(omega), scratch.get_control_matrix(omega)) < 1e-11
+    assert not isinstance(total._frequency_data.peek('control_matrix'), Deferred)     # fetched by now
+    assert rel_err(infid_resident, ff.infidelity(via_host, S, omega)) < 1e-13
+    nested_host = ff.concatenate([via_host, copies[1], via_host])
+    assert rel_err(nested.get_control_matrix(omega), nested_host.get_control_matrix(omega)) < 1e-13
+    assert rel_err(nested.total_propagator, nested_host.total_propagator) < 1e-13
+    assert rel_err(ff.infidelity(nested, S, omega), ff.infidelity(nested_host, S, omega)) < 1e-13
+    clone = copy.deepcopy(total)                  # copies own host arrays only
+    assert clone._resident is None and rel_err(clone.get_control_matrix(omega), total.get_control_matrix(omega)) == 0
+    # pulse correlations and a changed grid on one pulse (host route again, transparently)
+    pc = ff.concatenate([pulses[k] for k in index[:7]], calc_pulse_correlation_FF=True)
+    assert calls == [1, 1]
+    ref = ff.concatenate([copies[k] for k in index[:7]], calc_pulse_correlation_FF=True)
+    assert rel_err(pc.get_pulse_correlation_filter_function(), ref.get_pulse_correlation_filter_function()) < 1e-13
+    pulses[0].cache_control_matrix(omega, pulses[0].get_control_matrix(omega))     # explicit store
+    assert pulses[0]._resident is None
+    again = ff.concatenate([pulses[k] for k in index])
+    assert calls == [1, 1] and rel_err(again.get_control_matrix(omega), total.get_control_matrix(omega)) < 1e-13
+
+
 @pytest.mark.parametrize('G,T', [(1001, 3), (999, 1), (137, 5)])
 def test_indexed_concatenation_with_uneven_slabs(G, T):
     """Gather-from-table concatenation at position counts that leave the last pulse-axis slab short
