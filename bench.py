@@ -221,15 +221,19 @@ def prewarm_clocks(step, sync, timer, max_s, adaptive, batch=100):
 
 
 # ---- the other BASELINE configurations, timed in-process after the headline -----------------------
-def time_pipeline(pipe, torch, lib, _lib, stream, reps, extra=None):
-    """ms per pass of `pipe.launch` (+ `extra()` per pass), and of its accumulate kernel."""
+def time_pipeline(pipe, torch, lib, _lib, stream, reps, extra=None, warm_s=0.25):
+    """ms per pass of `pipe.launch` (+ `extra()` per pass), and of its accumulate kernel.  Untimed
+    passes for `warm_s` seconds first (at least three): like the headline's pre-warm, so that the
+    configs are timed at the sustained clock whatever ran (or idled) before them."""
     def run():
         pipe.launch(stream=stream)
         if extra is not None:
             extra()
-    for _ in range(3):
+    t_warm, n_warm = time.perf_counter(), 0
+    while n_warm < 3 or time.perf_counter() - t_warm < warm_s:
         run()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        n_warm += 1
     timer = AccumulateTimer(lib, _lib, 1)
     t0 = time.perf_counter()
     for i in range(reps):

@@ -2049,9 +2049,10 @@ struct BlockPool {
     void give(Block b) {
         if (!b.ptr) return;
         std::lock_guard<std::mutex> lock(mu);
-        if (free_blocks.size() >= 16) {       // bound what an idle process keeps
-            if (pinned) (void)hipHostFree(b.ptr); else (void)hipFree(b.ptr);
-            return;
+        if (free_blocks.size() >= 16) {       // bound what an idle process keeps: the OLDEST idle
+            const Block old = free_blocks.front();   // block goes (a loop over fresh pulses of one
+            free_blocks.erase(free_blocks.begin());  // shape must find its block again even after
+            if (pinned) (void)hipHostFree(old.ptr); else (void)hipFree(old.ptr);   // other shapes filled the pool)
         }
         free_blocks.push_back(b);
     }
