@@ -460,6 +460,12 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+    # FFK_BENCH_REHEARSE=1: every rank on device 0 with gloo as the control plane -- a dry run of the
+    # whole N > 1 flow (ring, one-sided gather over IPC, strong-scaled configs) on a one-GPU box;
+    # the numbers of such a run mean nothing
+    rehearse = bool(os.environ.get('FFK_BENCH_REHEARSE'))
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     lib = _lib.load()
@@ -469,7 +475,9 @@ def main():
     # under torch.distributed.run a process group exists even for one rank (lets a 1-GPU box
     # exercise the RCCL path with FFK_FORCE_COLLECTIVE=1)
     use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('FFK_FORCE_COLLECTIVE'))
-    if use_dist:
+    if use_dist and rehearse:
+        dist.init_process_group('gloo')
+    elif use_dist:
         dist.init_process_group('nccl', device_id=device)
 
     cfg = wl.CONFIG2
@@ -688,7 +696,9 @@ def main():
                        'sharding': ('omega blocks, ' + ('one-sided all-gather of F over IPC-mapped '
                                     'peer memory (csrc/peer.hip)' if ring.gather == 'push' else
                                     'RCCL all-gather of F')) if use_dist else 'none',
-                       'passes_in_flight': max(1, args.streams)},
+                       'passes_in_flight': max(1, args.streams),
+                       **({'REHEARSAL': 'all ranks on one GPU over gloo (FFK_BENCH_REHEARSE): the '
+                                        'numbers of this line mean nothing'} if rehearse else {})},
             'single_stream_ms_per_step': latency_ms, 'gather_ab': gather_ab,
             'prewarm': prewarm,
             'roofline': {

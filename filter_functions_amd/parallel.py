@@ -26,6 +26,22 @@ def shard_bounds(n_omega, world_size, rank):
     return w0, w0 + base + (1 if rank < extra else 0)
 
 
+def _all_gather(recv, send, group=None):
+    """recv[r] <- send of rank r.  nccl (= RCCL): one collective into one buffer.  gloo has no flat
+    all-gather, and none at all for device tensors: those (rehearsals of the N > 1 flow with several
+    ranks on one GPU, bench.py FFK_BENCH_REHEARSE) are staged through the host."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend(group) != 'gloo':
+        dist.all_gather_into_tensor(recv, send, group=group)
+    elif send.is_cuda:
+        parts = [torch.empty(send.shape, dtype=send.dtype) for _ in range(recv.shape[0])]
+        dist.all_gather(parts, send.cpu(), group=group)
+        recv.copy_(torch.stack(parts))
+    else:
+        dist.all_gather(list(recv.unbind(0)), send, group=group)
+
+
 def gather_omega_shards(local, n_omega, group=None):
     """All-gather tensors whose LAST axis is this rank's omega block into the full
     (..., n_omega) tensor, omega fastest, on every rank.
@@ -50,10 +66,7 @@ def gather_omega_shards(local, n_omega, group=None):
     # complex dtypes travel as interleaved reals
     flat = torch.view_as_real(send.contiguous()) if send.is_complex() else send.contiguous()
     recv = torch.empty((world,) + flat.shape, dtype=flat.dtype, device=flat.device)
-    if dist.get_backend(group) == 'gloo':       # gloo has no flat all-gather
-        dist.all_gather(list(recv.unbind(0)), flat, group=group)
-    else:                                       # nccl = RCCL: one collective into one buffer
-        dist.all_gather_into_tensor(recv, flat, group=group)
+    _all_gather(recv, flat, group)
     if send.is_complex():
         recv = torch.view_as_complex(recv)
     # (world, ..., wmax) -> (..., world, wmax) -> (..., n_omega)
@@ -92,10 +105,7 @@ def sum_omega_shards(local, group=None):
         return local
     flat = local.contiguous()
     recv = torch.empty((world,) + flat.shape, dtype=flat.dtype, device=flat.device)
-    if dist.get_backend(group) == 'gloo':
-        dist.all_gather(list(recv.unbind(0)), flat, group=group)
-    else:
-        dist.all_gather_into_tensor(recv, flat, group=group)
+    _all_gather(recv, flat, group)
     total = recv[0].clone()
     for r in range(1, world):
         total += recv[r]
@@ -425,7 +435,11 @@ class ShardedStepRing:
                 if self._gloo is None:
                     self._gloo = dist.get_backend(self.group) == 'gloo'
                 if self._gloo:                                     # gloo has no flat all-gather
-                    dist.all_gather(list(recv.unbind(0)), send, group=self.group)
+                    if send.is_cuda:       # (nor device tensors: complex ones staged as reals)
+                        _all_gather(self.torch.view_as_real(recv), self.torch.view_as_real(send),
+                                    self.group)
+                    else:
+                        dist.all_gather(list(recv.unbind(0)), send, group=self.group)
                 else:
                     views = self._real_views.get(k)
                     if views is None:      # complex tensors travel as interleaved reals; views cached
