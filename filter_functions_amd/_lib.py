@@ -217,6 +217,8 @@ SIGNATURES = {
     'ffk_peer_signal_dev': (c_int, [c_void_p, c_void_p, c_int, ctypes.c_int64, ctypes.c_int64,
                                     c_void_p]),
     'ffk_peer_wait_dev': (c_int, [c_void_p, c_int, ctypes.c_int64, c_void_p, c_void_p]),
+    'ffk_peer_step_dev': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p,
+                                  c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),
     'ffk_set_segment_chunks': (c_int, [c_int]),
     'ffk_set_accumulate_variant': (c_int, [c_int]),
     'ffk_get_stats': (c_int, [POINTER(ffk_stats)]),

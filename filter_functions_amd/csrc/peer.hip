@@ -162,4 +162,15 @@ int ffk_peer_wait_dev(const int64_t* flags, int world, int64_t seq, int32_t* err
     return e == hipSuccess ? FFK_OK : peer_fail(FFK_EHIP, "peer_wait_kernel", e);
 }
 
+// push + signal + wait of one step in one call (three launches on `stream`; one trip through the
+// binding instead of three: the host side of a sharded step is what bounds its rate)
+int ffk_peer_step_dev(const double* src, size_t bytes, void* const* dst, const int64_t* own_acks,
+                      int64_t need_ack, void* const* flag_at, void* const* ack_at,
+                      const int64_t* own_flags, int world, int rank, int64_t step, int32_t* error,
+                      void* stream) {
+    if (int rc = ffk_peer_push_dev(src, bytes, dst, own_acks, need_ack, world, rank, error, stream)) return rc;
+    if (int rc = ffk_peer_signal_dev(flag_at, ack_at, world, step + 1, step, stream)) return rc;
+    return ffk_peer_wait_dev(own_flags, world, step + 1, error, stream);
+}
+
 }  // extern "C"

@@ -41,6 +41,7 @@ class DevicePipeline:
         self.c_opers = up(c_opers, complex)
         self.s_ndim, self.n_idx = 0, 0
         self.spectrum = self.idx = self.infid = None
+        self._launch_args = {}
         if spectrum is not None:
             self.set_spectrum(spectrum, idx)
         kw = dict(device=self.device)
@@ -61,6 +62,7 @@ class DevicePipeline:
 
     def set_spectrum(self, spectrum, idx=None):
         from . import util
+        self._launch_args = {}
         idx = np.arange(self.A) if idx is None else np.asarray(idx)
         S = util.parse_spectrum(np.asanyarray(spectrum), np.empty(self.W), idx)
         self.s_ndim, self.n_idx = S.ndim, len(idx)
@@ -76,15 +78,21 @@ class DevicePipeline:
     def launch(self, stream=None, with_infidelity=True):
         """Enqueue one pass of the hot path on *stream* (default: torch's current stream)."""
         s = self.torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
-        p = self._p
         do_inf = with_infidelity and self.spectrum is not None
-        check(_lib.load().ffk_pipeline_dev(
-            p(self.H), p(self.dt), p(self.t), self.G, self.d, p(self.omega), self.W, p(self.basis),
-            self.N, p(self.n_opers), self.A, p(self.n_coeffs),
-            p(self.spectrum) if do_inf else None, self.s_ndim, p(self.idx) if do_inf else None,
-            self.n_idx, p(self.eigvals), p(self.eigvecs), p(self.propagators),
-            p(self.control_matrix), p(self.filter_function), p(self.infid) if do_inf else None,
-            p(self.workspace), self.ws_bytes, ctypes.c_void_p(s)))
+        args = self._launch_args.get(do_inf)
+        if args is None:
+            # the buffers of a pipeline never move: their addresses are converted once (set_spectrum,
+            # which replaces three of them, drops this cache)
+            p = self._p
+            args = self._launch_args[do_inf] = (
+                _lib.load().ffk_pipeline_dev,
+                (p(self.H), p(self.dt), p(self.t), self.G, self.d, p(self.omega), self.W, p(self.basis),
+                 self.N, p(self.n_opers), self.A, p(self.n_coeffs),
+                 p(self.spectrum) if do_inf else None, self.s_ndim, p(self.idx) if do_inf else None,
+                 self.n_idx, p(self.eigvals), p(self.eigvecs), p(self.propagators),
+                 p(self.control_matrix), p(self.filter_function), p(self.infid) if do_inf else None,
+                 p(self.workspace), self.ws_bytes))
+        check(args[0](*args[1], s))
 
     def check_status(self, stream=None):
         """Raise ``numpy.linalg.LinAlgError`` if the eigensolver of the last :meth:`launch` flagged

@@ -202,6 +202,7 @@ class PeerGather:
         # that fails publishes None / ok = False instead of leaving the others waiting.
         self.ok = True
         self._opened = []
+        self._fixed = None
         mine = None
         try:
             # the gather buffers are written by peer GPUs and read by local kernels every `depth`
@@ -254,17 +255,16 @@ class PeerGather:
     def step(self, c, block, stream):
         """Push *block* (this rank's F of step *c*) to every rank and wait for everybody's; returns
         the buffer set (world, ...) that holds step c once the stream has passed."""
-        import ctypes
         k = c % self.depth
-        s = ctypes.c_void_p(stream)
-        need_ack = max(0, c - self.depth + 1)
-        self._check(self._lib.ffk_peer_push_dev(self._p(block), self.block_bytes, self._p(self._dst[k]),
-                                                self._p(self.acks), need_ack, self.world, self.rank,
-                                                self._p(self.error), s))
-        self._check(self._lib.ffk_peer_signal_dev(self._p(self._flag_at), self._p(self._ack_at),
-                                                  self.world, c + 1, c, s))
-        self._check(self._lib.ffk_peer_wait_dev(self._p(self.flags), self.world, c + 1,
-                                                self._p(self.error), s))
+        fixed = self._fixed
+        if fixed is None:      # device addresses that never change, converted once
+            fixed = self._fixed = ([self._dst[j].data_ptr() for j in range(self.depth)],
+                                   self.acks.data_ptr(), self._flag_at.data_ptr(),
+                                   self._ack_at.data_ptr(), self.flags.data_ptr(), self.error.data_ptr())
+        dst, acks, flag_at, ack_at, flags, error = fixed
+        self._check(self._lib.ffk_peer_step_dev(block.data_ptr(), self.block_bytes, dst[k], acks,
+                                                max(0, c - self.depth + 1), flag_at, ack_at, flags,
+                                                self.world, self.rank, c, error, stream))
         return self.gathered[k]
 
     def check(self):
@@ -286,12 +286,17 @@ class PeerGather:
 class _CudaStreams:
     """Stream plumbing of :class:`ShardedStepRing` on PyTorch-ROCm streams and events."""
 
-    def __init__(self, compute, comm):
+    def __init__(self, compute, comm, events=64):
         import torch
         self.torch, self.compute, self.comm = torch, compute, comm
+        # a ring of reusable events: a step needs its two events for `depth` steps at most, and
+        # creating one per record cost more host time than recording it
+        self._events = [torch.cuda.Event() for _ in range(events)]
+        self._next = 0
 
     def record(self, stream):
-        event = self.torch.cuda.Event()
+        event = self._events[self._next]
+        self._next = (self._next + 1) % len(self._events)
         event.record(stream)
         return event
 
@@ -337,7 +342,7 @@ class ShardedStepRing:
         self.compute_streams = list(compute_stream) if isinstance(compute_stream, (list, tuple)) \
             else [compute_stream]
         self.compute_stream, self.comm_stream = self.compute_streams[0], comm_stream
-        self.streams = streams if streams is not None else _CudaStreams(self.compute_stream, comm_stream)
+        self.streams = streams if streams is not None else _CudaStreams(self.compute_stream, comm_stream, events=max(64, 8*self.depth))
         first = self.pipes[0]
         device, A = first.filter_function.device, first.A
         w0, w1 = shard_bounds(n_omega, world, rank)
@@ -421,15 +426,19 @@ class ShardedStepRing:
             st.wait(compute, self.free_events[k])       # the gather of step c - depth read set k
         pipe.launch(stream=st.handle(compute), with_infidelity=False)
         ready = st.record(compute)
+        if self.peer is not None:
+            # one-sided: push this rank's block everywhere, poll for everybody's.  Every call names
+            # its stream: no "current stream" context to enter (15 us of host time per step)
+            st.wait(self.comm_stream, ready)
+            comm = st.handle(self.comm_stream)
+            recv = self.peer.step(c + self.count_offset, pipe.filter_function, comm)
+            out = pipe.infidelity_from_shards(recv, self.omega_full, self.spectrum_full, self.idx,
+                                              self.infid[k], stream=comm)
+            self.free_events[k] = st.record(self.comm_stream)
+            return out
         with st.on(self.comm_stream):
             st.wait(self.comm_stream, ready)
-            if self.peer is not None:
-                # one-sided: push this rank's block everywhere, poll for everybody's
-                recv = self.peer.step(c + self.count_offset, pipe.filter_function,
-                                      st.handle(self.comm_stream))
-                out = pipe.infidelity_from_shards(recv, self.omega_full, self.spectrum_full, self.idx,
-                                                  self.infid[k], stream=st.handle(self.comm_stream))
-            elif self.equal_shards:
+            if self.equal_shards:
                 # one collective into a preallocated buffer; the integral reads the shards in place
                 send, recv = pipe.filter_function, self.gathered[k]
                 if self._gloo is None:

@@ -537,6 +537,12 @@ int ffk_peer_push_dev(const double* src, size_t bytes, void* const* dst, const i
 int ffk_peer_signal_dev(void* const* flags, void* const* acks, int world, int64_t seq,
                         int64_t consumed, void* stream);
 int ffk_peer_wait_dev(const int64_t* flags, int world, int64_t seq, int32_t* error, void* stream);
+/* the three of step `step` in one call: push (after acknowledgements >= need_ack), signal
+ * (flags = step + 1, acknowledging `step` buffers consumed), wait (flags of every peer >= step + 1) */
+int ffk_peer_step_dev(const double* src, size_t bytes, void* const* dst, const int64_t* own_acks,
+                      int64_t need_ack, void* const* flag_at, void* const* ack_at,
+                      const int64_t* own_flags, int world, int rank, int64_t step, int32_t* error,
+                      void* stream);
 
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Number of segment chunks the control-matrix kernel splits G into (0 = automatic).        */
