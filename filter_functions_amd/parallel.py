@@ -168,8 +168,7 @@ class _RawDeviceBuffer:
     def __del__(self):
         ptr, self.ptr = getattr(self, 'ptr', None), None
         if ptr:
-            import ctypes
-            self._lib.ffk_free(ctypes.c_void_p(ptr))
+            self._lib.ffk_free(ptr)      # (argtypes declare the pointer: no import at shutdown)
 
 
 class PeerGather:

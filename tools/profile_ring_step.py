@@ -19,6 +19,8 @@ from filter_functions_amd.device import DevicePipeline  # noqa: E402
 from filter_functions_amd.parallel import ShardedStepRing  # noqa: E402
 
 gather = sys.argv[1] if len(sys.argv) > 1 else 'push'
+n_streams = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+depth = int(sys.argv[3]) if len(sys.argv) > 3 else 2*n_streams
 device = torch.device('cuda', 0)
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', device_id=device)
@@ -27,8 +29,8 @@ c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
 omega = wl.random_pulse_omega(dt, 4096)
 pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, ff.Basis.pauli(2))
 pipes = [DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, pulse.basis,
-                        omega, spectrum=1e-3/omega, device=device) for _ in range(4)]
-streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+                        omega, spectrum=1e-3/omega, device=device) for _ in range(depth)]
+streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
 comm = torch.cuda.Stream(device=device)
 ring = ShardedStepRing(pipes, 4096, omega, 1e-3/omega, streams, comm, 1, 0, gather=gather)
 for _ in range(500):
@@ -40,7 +42,10 @@ for _ in range(2000):
 issue = time.perf_counter() - t0
 torch.cuda.synchronize()
 total = time.perf_counter() - t0
-print(f'gather={ring.gather}: host enqueue {issue/2000*1e6:.1f} us/step, step {total/2000*1e6:.1f} us')
+print(f'gather={ring.gather} streams={n_streams} depth={depth}: host enqueue {issue/2000*1e6:.1f} us/step, step {total/2000*1e6:.1f} us')
+if len(sys.argv) > 4:
+    dist.destroy_process_group()
+    sys.exit(0)
 prof = cProfile.Profile()
 prof.enable()
 for _ in range(2000):
