@@ -503,10 +503,15 @@ def main():
     # small kernels between two accumulate launches.
     depth = max(2, args.pipeline_depth + (args.pipeline_depth & 1))      # even
     depth = max(depth, 2*max(1, args.streams))
-    n_streams = 1 if use_dist else max(1, args.streams)
-    pipes = [make_pipe() for _ in range(depth if use_dist else n_streams)]
+    n_streams = max(1, args.streams)
+    # one rank with several passes in flight runs the same schedule as the sharded step, without
+    # the exchange (gather = 'none'): passes round robin on the compute streams, the integral of
+    # each pass on a stream of its own, so that the front of the next-but-one pass does not queue
+    # behind it (89.1 against 92.7 us per step for everything on the pass's own stream)
+    use_ring = use_dist or n_streams > 1
+    pipes = [make_pipe() for _ in range(depth if use_ring else 1)]
     pipe = pipes[0]
-    if use_dist:
+    if use_ring:
         from filter_functions_amd.parallel import ShardedStepRing
         # Two explicitly created streams: HIP spreads created streams over the hardware queues,
         # whereas torch's default stream and one side stream shared a queue on this system (every
@@ -517,17 +522,13 @@ def main():
         torch.cuda.synchronize(device)
         # FFK_GATHER: 'auto' (default: the one-sided all-gather of csrc/peer.hip if its set-up and a
         # verified round trip succeed on every rank, else the RCCL collective), 'push', 'rccl'
-        ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_streams,
-                               comm_stream, world, rank, gather=os.environ.get('FFK_GATHER', 'auto'))
-    elif n_streams > 1:
         # Steps are independent passes (one pulse each): with two passes in flight on two HIP
-        # streams the five latency-bound launches of one pass (eigensolver, scan, prologue,
-        # expansion, integral: ~32 us on 256 wavefronts or fewer) run beside the accumulate kernel
-        # of the other, which leaves 20 KiB of LDS and half the wave slots of every CU free.
-        # Fusing those launches was tried and is slower (profiles/r02_a_fusion_attempts.md).
-        pass_streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
-        compute_stream = pass_streams[0]
-        torch.cuda.synchronize(device)
+        # streams the latency-bound launches of one pass (eigensolver, scan, prologue, expansion,
+        # integral: ~32 us on 256 wavefronts or fewer) run beside the accumulate kernel of the
+        # other.  Fusing those launches was tried and is slower (profiles/r02_a_fusion_attempts.md).
+        ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_streams,
+                               comm_stream, world, rank,
+                               gather=os.environ.get('FFK_GATHER', 'auto') if use_dist else 'none')
     else:
         compute_stream = torch.cuda.current_stream(device)
     stream = compute_stream.cuda_stream
@@ -540,20 +541,13 @@ def main():
     n_ev = max(1, min(args.steps, n_ev))
     timer = AccumulateTimer(lib, _lib, n_ev)
 
-    counter = [0]
-
     def step(i=None):
         if i is not None and i >= args.steps - n_ev:
             timer.arm(i - (args.steps - n_ev), gate_on_previous=max(1, args.streams) > 1)
-        if use_dist:
+        if use_ring:
             return ring.step()
-        if n_streams == 1:
-            pipe.launch(stream=stream, with_infidelity=True)
-            return pipe.infid
-        k = counter[0] % n_streams
-        counter[0] += 1
-        pipes[k].launch(stream=pass_streams[k].cuda_stream, with_infidelity=True)
-        return pipes[k].infid
+        pipe.launch(stream=stream, with_infidelity=True)
+        return pipe.infid
 
     def sync():
         torch.cuda.synchronize(device)
@@ -632,7 +626,7 @@ def main():
     # latency of one pass on its own (one stream, nothing else in flight), for reference
     latency_ms = None
     if not use_dist:
-        one = torch.cuda.current_stream(device).cuda_stream if n_streams == 1 else pass_streams[0].cuda_stream
+        one = stream
         torch.cuda.synchronize(device)
         reps = 200
         t1 = time.perf_counter()
@@ -697,6 +691,9 @@ def main():
                                     'peer memory (csrc/peer.hip)' if ring.gather == 'push' else
                                     'RCCL all-gather of F')) if use_dist else 'none',
                        'passes_in_flight': max(1, args.streams),
+                       'schedule': ('passes round robin on %d compute streams, the integral of each pass '
+                                    'on a stream of its own, %d buffer sets' % (max(1, args.streams), depth))
+                       if use_ring else 'one stream',
                        **({'REHEARSAL': 'all ranks on one GPU over gloo (FFK_BENCH_REHEARSE): the '
                                         'numbers of this line mean nothing'} if rehearse else {})},
             'single_stream_ms_per_step': latency_ms, 'gather_ab': gather_ab,

@@ -366,13 +366,19 @@ class ShardedStepRing:
         # gather = 'push': the one-sided all-gather (PeerGather) instead of the collective; needs
         # equal blocks and real streams; 'auto': try it, verify one round, else the collective
         self.peer = None
+        # gather = 'none' (one rank): nothing to exchange, the integral reads the pass's own F -- the
+        # ring is then just the schedule: passes on the compute streams, integrals on their own stream
+        self.local_only = gather == 'none'
+        if self.local_only and world != 1:
+            raise ValueError("gather='none' is for one rank")
+        self._own_shard = [pipe.filter_function.unsqueeze(0) for pipe in self.pipes] if self.local_only else None
         # (one rank: only with the test hook FFK_FORCE_COLLECTIVE, to exercise / time the path)
         if gather in ('push', 'auto') and self.equal_shards and streams is None and \
                 (world > 1 or os.environ.get('FFK_FORCE_COLLECTIVE')):
             self.peer = self._try_peer_gather(first, group, required=(gather == 'push'))
         if self.peer is not None:
             self.gathered = self.peer.gathered
-        self.gather = 'push' if self.peer is not None else 'rccl'
+        self.gather = 'none' if self.local_only else ('push' if self.peer is not None else 'rccl')
 
     def _try_peer_gather(self, first, group, required):
         """Set the one-sided gather up and verify one round trip of a known pattern on every rank;
@@ -425,12 +431,13 @@ class ShardedStepRing:
             st.wait(compute, self.free_events[k])       # the gather of step c - depth read set k
         pipe.launch(stream=st.handle(compute), with_infidelity=False)
         ready = st.record(compute)
-        if self.peer is not None:
+        if self.peer is not None or self.local_only:
             # one-sided: push this rank's block everywhere, poll for everybody's.  Every call names
             # its stream: no "current stream" context to enter (15 us of host time per step)
             st.wait(self.comm_stream, ready)
             comm = st.handle(self.comm_stream)
-            recv = self.peer.step(c + self.count_offset, pipe.filter_function, comm)
+            recv = self._own_shard[k] if self.local_only else \
+                self.peer.step(c + self.count_offset, pipe.filter_function, comm)
             out = pipe.infidelity_from_shards(recv, self.omega_full, self.spectrum_full, self.idx,
                                               self.infid[k], stream=comm)
             self.free_events[k] = st.record(self.comm_stream)

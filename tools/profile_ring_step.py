@@ -23,7 +23,8 @@ n_streams = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 depth = int(sys.argv[3]) if len(sys.argv) > 3 else 2*n_streams
 device = torch.device('cuda', 0)
 torch.cuda.set_device(0)
-dist.init_process_group('nccl', device_id=device)
+if gather != 'none':
+    dist.init_process_group('nccl', device_id=device)
 cfg = wl.CONFIG2
 c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
 omega = wl.random_pulse_omega(dt, 4096)
@@ -44,7 +45,8 @@ torch.cuda.synchronize()
 total = time.perf_counter() - t0
 print(f'gather={ring.gather} streams={n_streams} depth={depth}: host enqueue {issue/2000*1e6:.1f} us/step, step {total/2000*1e6:.1f} us')
 if len(sys.argv) > 4:
-    dist.destroy_process_group()
+    if gather != 'none':
+        dist.destroy_process_group()
     sys.exit(0)
 prof = cProfile.Profile()
 prof.enable()
@@ -53,4 +55,5 @@ for _ in range(2000):
 prof.disable()
 torch.cuda.synchronize()
 pstats.Stats(prof).sort_stats('tottime').print_stats(16)
-dist.destroy_process_group()
+if gather != 'none':
+    dist.destroy_process_group()
