@@ -61,6 +61,18 @@ struct PcEntries {          // every entry once, the (coinciding) diagonal entri
         return s;
     }
     static constexpr Slots slots = make();
+    // position of entry e = m*D + n in the tile: the list index (diagonal entries: 0)
+    static constexpr Slots make_table() {
+        Slots t{};
+        for (int e = 0; e < D*D; ++e) {
+            int k = 0;
+            for (int x = 0; x < e; ++x)
+                if (x == 0 || x / D != x % D) ++k;
+            t.v[e] = (e / D == e % D) ? 0 : k;
+        }
+        return t;
+    }
+    static constexpr Slots slot_table = make_table();
 };
 
 template <int D, int NC>
@@ -69,7 +81,11 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
     const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
     constexpr int GS = kPcSub, NWS = NC + 1;
     constexpr int S = seg_stride(D), DD = D*D;
-    constexpr int TILE = DD*64;                       // cplx per integral tile
+    // cplx per integral tile: the D (D - 1) + 1 distinct entries only.  (With all D^2 slots the block
+    // held 140.5 KiB of LDS; a kernel of another pass needing more than ~8 KiB -- the scan: 9.5 KiB,
+    // the prologue: 17.5 KiB -- could then not be placed beside it and waited the whole 83 us for it
+    // to retire, tools/corun.hip and profiles/r02_q_*.)
+    constexpr int TILE = PcEntries<D>::count*64;
 #if FFK_PC_WFOLD
     constexpr int OPS = DD + NC*D*DD;                 // T_g | W_a[m][n][j] = Bbar_a[m][n] T_g[n][j]
 #else
@@ -113,7 +129,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
         for (int k = wl; k < PcEntries<D>::count; k += NWS) {
             const int e = sl.v[k];
             const double* r = st + seg_rec(e);
-            tile[e*64] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+            tile[k*64] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
         }
     };
 
@@ -165,7 +181,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
                 constexpr auto& sl = PcEntries<D>::slots;
                 const int e = sl.v[k];
                 const double* r = st + seg_rec(e);
-                tile[e*64] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+                tile[k*64] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
             }
         };
         static_assert((1 + NC)*DD <= 64 && S/2 <= 64, "one staging element per lane");
@@ -250,7 +266,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
                     // Z_j = sum_n E_mn (Bbar_mn T_nj): no separate Bbar o E pass
 #pragma unroll
                     for (int n = 0; n < D; ++n) {
-                        const int slot = (m == n) ? 0 : m*D + n;
+                        const int slot = PcEntries<D>::slot_table.v[m*D + n];
                         const cplx e = src[slot*64];
 #pragma unroll
                         for (int j = 0; j < D; ++j) cmac(Z[j], opW[(m*D + n)*D + j], e);
@@ -259,7 +275,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
                     cplx X[D];
 #pragma unroll
                     for (int n = 0; n < D; ++n) {
-                        const int slot = (m == n) ? 0 : m*D + n;
+                        const int slot = PcEntries<D>::slot_table.v[m*D + n];
                         X[n] = cmul(opB[m*D + n], src[slot*64]);
                     }
 #pragma unroll
@@ -355,7 +371,8 @@ int pc_accumulate_subchunks() { return kPcSub; }
 int pc_accumulate_lds_bytes(int d, int nc) {
     const int S = seg_stride(d), dd = d*d;
     const int ops = FFK_PC_WFOLD ? dd + nc*d*dd : (1 + nc)*dd;
-    return static_cast<int>(kPcSub*(2*(dd*64 + ops) + S)*sizeof(cplx));
+    const int entries = d*(d - 1) + 1;                // distinct integral entries (PcEntries<D>::count)
+    return static_cast<int>(kPcSub*(2*(entries*64 + ops) + S)*sizeof(cplx));
 }
 
 hipError_t launch_accumulate_pc(const double* omega, int W, const double* segtab, const cplx* ops,

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(64) void eigh_expm_kernel(const cplx* __restrict__ 
                                                        cplx* __restrict__ seg_prop,
                                                        int* __restrict__ status) {
     __shared__ EighState<D> st;
+    __builtin_amdgcn_s_setprio(3);     // see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     const bool ok = eigh_expm_wave<D>(st, H + static_cast<size_t>(g)*D*D, dt[g], lane,

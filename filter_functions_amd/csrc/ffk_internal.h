@@ -52,6 +52,13 @@ hipError_t launch_eigh_expm(const cplx* H, const double* dt, int G, int d, doubl
 hipError_t launch_count_failures(const int* status, int G, int32_t* out, hipStream_t stream);
 // Chunk length of the two-kernel scan used by the fused front end (scan_local + fix-up fused
 // with the prologue): both serial parts are ~sqrt(G) long at G = 256.
+// FFK_SMALL_KERNEL_PRIORITY: the latency-bound kernels of a pass (eigensolver, scans, prologue,
+// expansion, integral: a few hundred waves) raise their issue priority with s_setprio 3 on entry.
+// Passes are kept in flight side by side so that these kernels run beside another pass's
+// accumulate kernel -- but the SIMD's arbiter serves the OLDEST ready wave first, and an FMA-dense
+// kernel always has one: at equal priority a younger wave on the same SIMD does not get a single
+// issue slot until the dense kernel retires (tools/corun.hip: a 64-thread kernel launched beside a
+// 16-wave FMA loop finished 3 us after the loop ended, 230 us later; with s_setprio 3 after 7 us).
 __host__ __device__ constexpr int front_chunk(int d) { return d <= 8 ? 16 : 8; }
 // The fused front end is used while the serial part of its second kernel stays short.
 inline bool use_fused_front(int G, int d) { return (G + front_chunk(d) - 1)/front_chunk(d) <= 64; }

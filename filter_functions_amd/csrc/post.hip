@@ -224,17 +224,24 @@ __global__ void ff_generalized_kernel(const cplx* __restrict__ R, int A, int N, 
 // ---- infidelity ------------------------------------------------------------------------------
 // integrand_p[w] = Re(F[ia, ib, w] S_p[w]); partial[p, blk] = sum over the block's omega tile of
 // (f[w+1] + f[w]) (omega[w+1] - omega[w])   (util.integrate, util.py:903-906, before the /2).
-// One block per output element p: the whole omega axis is reduced by 1024 threads in fixed order
-// (thread t sums intervals t, t+1024, ...; then a tree over the block): deterministic, one launch.
+// One block per output element p: the whole omega axis is reduced over 1024 slots in fixed order
+// (slot v sums intervals v, v+1024, ...; then a tree over the slots): deterministic, one launch.
+// The block has 256 threads, four slots each (bit-identical to one thread per slot): a
+// 1024-thread block cannot be placed on a CU that an accumulate block of another pass occupies
+// (16 + 16 waves fit, their registers do not), and a workgroup that cannot be placed anywhere
+// stalls the dispatcher for every queue -- the scan and prologue of the next pass then waited for
+// the accumulate kernel to retire as well (profiles/r02_q_*).
 // shard_width > 0: F is the raw all-gather buffer (n_shards, A, A, shard_width) of omega blocks
 // (one block per rank) instead of (A, A, W): global frequency w lives in shard w / shard_width.
-__global__ __launch_bounds__(1024) void infid_kernel(const cplx* __restrict__ F, int A, int W,
-                                                     const cplx* __restrict__ S, int s_ndim,
-                                                     const double* __restrict__ omega,
-                                                     const int32_t* __restrict__ idx, int n_idx,
-                                                     int d, int shard_width,
-                                                     double* __restrict__ infid) {
-    __shared__ double red[1024];
+constexpr int kInfidSlots = 1024, kInfidThreads = 256;
+__global__ __launch_bounds__(kInfidThreads) void infid_kernel(const cplx* __restrict__ F, int A, int W,
+                                                              const cplx* __restrict__ S, int s_ndim,
+                                                              const double* __restrict__ omega,
+                                                              const int32_t* __restrict__ idx, int n_idx,
+                                                              int d, int shard_width,
+                                                              double* __restrict__ infid) {
+    __shared__ double red[kInfidSlots];
+    __builtin_amdgcn_s_setprio(3);     // see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
     const int p = blockIdx.x;  // output element
     int ia, ib;
     const cplx* Sp;
@@ -253,17 +260,19 @@ __global__ __launch_bounds__(1024) void infid_kernel(const cplx* __restrict__ F,
         }
         return F[(static_cast<size_t>(ia)*A + ib)*W + w];
     };
-    double acc = 0.0;
-    for (int w = threadIdx.x; w < W - 1; w += 1024) {
-        const cplx f0 = Fat(w), f1 = Fat(w + 1), s0 = Sp[w], s1 = Sp[w + 1];
-        const double i0 = f0.re*s0.re - f0.im*s0.im;
-        const double i1 = f1.re*s1.re - f1.im*s1.im;
-        acc += (i1 + i0)*(omega[w + 1] - omega[w]);
+    for (int v = threadIdx.x; v < kInfidSlots; v += kInfidThreads) {
+        double acc = 0.0;
+        for (int w = v; w < W - 1; w += kInfidSlots) {
+            const cplx f0 = Fat(w), f1 = Fat(w + 1), s0 = Sp[w], s1 = Sp[w + 1];
+            const double i0 = f0.re*s0.re - f0.im*s0.im;
+            const double i1 = f1.re*s1.re - f1.im*s1.im;
+            acc += (i1 + i0)*(omega[w + 1] - omega[w]);
+        }
+        red[v] = acc;
     }
-    red[threadIdx.x] = acc;
     __syncthreads();
-    for (int s2 = 512; s2 > 0; s2 >>= 1) {
-        if (threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+    for (int s2 = kInfidSlots/2; s2 > 0; s2 >>= 1) {
+        for (int v = threadIdx.x; v < s2; v += kInfidThreads) red[v] += red[v + s2];
         __syncthreads();
     }
     if (threadIdx.x == 0) infid[p] = (red[0]/2.0)/(2.0*3.141592653589793*d);
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(64) void expand_chunks_kernel(const cplx* __restric
 // The same expansion followed, in the same launch, by the fidelity filter function of the block's
 // 16 frequencies: F[a,b,w] = sum_k conj(R[a,k,w]) R[b,k,w] (a <= b, mirrored; the summation order
 // of ff_fidelity_kernel).  Block = 16 frequencies x `kt` basis-element lanes; R passes through LDS.
-__global__ __launch_bounds__(1024) void expand_ff_kernel(const cplx* __restrict__ Ypart, int chunks,
+__global__ __launch_bounds__(256) void expand_ff_kernel(const cplx* __restrict__ Ypart, int chunks,
                                                          size_t slab, const int* __restrict__ nnz,
                                                          const int* __restrict__ rows,
                                                          const cplx* __restrict__ vals, int N, int dd,
@@ -367,6 +376,7 @@ __global__ __launch_bounds__(1024) void expand_ff_kernel(const cplx* __restrict_
                                                          cplx* __restrict__ F) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     cplx* rl = reinterpret_cast<cplx*>(lds_raw);       // [A][N][16]
+    __builtin_amdgcn_s_setprio(3);     // see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
     cplx* ys = rl + static_cast<size_t>(A)*N*16;        // [A][dd][16]: chunk partials summed
     // thread = (frequency wl, basis-element lane kl, noise operator lane al)
     const int wl = threadIdx.x & 15;
@@ -437,7 +447,11 @@ hipError_t launch_expand_ff(const cplx* Ypart, int chunks, size_t slab, int A, i
     if (!expand_ff_supported(A, N)) return hipErrorInvalidValue;
     const CompactWs cw = slice_compact_ws(ws, N, d);
     const int kt = N >= 16 ? 16 : (N >= 8 ? 8 : 4);
-    const int at = std::max(1, std::min(A, 64/kt));          // block = 16 x kt x at <= 1024 threads
+    // block = 16 x kt x at <= 256 threads (one wave per SIMD): a 768-thread block of this kernel does
+    // not fit beside an accumulate block of another pass (3 + 4 waves per SIMD would, their registers
+    // do not) and then waits for that whole kernel -- with the front of the next-but-one pass queued
+    // behind it on the same stream
+    const int at = std::max(1, std::min(A, 16/kt));
     const size_t lds = static_cast<size_t>(A)*(N + d*d)*16*sizeof(cplx);
     if (lds > 160*1024) return hipErrorInvalidValue;
     if (lds > 48*1024) {
@@ -600,7 +614,7 @@ hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_n
                              int shard_width, double* infid, void* ws, hipStream_t stream) {
     (void)ws;
     const int nout = s_ndim == 3 ? n_idx*n_idx : n_idx;
-    hipLaunchKernelGGL(infid_kernel, dim3(nout), dim3(1024), 0, stream, F, A, W, S, s_ndim, omega,
+    hipLaunchKernelGGL(infid_kernel, dim3(nout), dim3(kInfidThreads), 0, stream, F, A, W, S, s_ndim, omega,
                        idx, n_idx, d, shard_width, infid);
     return hipGetLastError();
 }

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
         basis_compact_one(basis, D, static_cast<int>(blockIdx.x) - G, threadIdx.x, nnz, rows, vals);
         return;
     }
+    __builtin_amdgcn_s_setprio(3);     // see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
     __shared__ cplx E[2][D][D];
     __shared__ cplx M[D][D];
     __shared__ cplx V[D][D];
@@ -133,8 +134,12 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
     __shared__ cplx BV[D][D];
     constexpr int kBatch = 16;
     constexpr bool kTree = D <= 8;                 // a whole matrix fits one pass of the 64 lanes
-    constexpr int kTot = kTree ? 64 : kBatch;      // use_fused_front: at most 64 chunks
-    __shared__ cplx tot[kTot][D][D];
+    // the chunk totals: for the tree as many as the launch has chunks (dynamic LDS: 4 KiB at config 2;
+    // a static array for the 64 chunks use_fused_front allows took 16 KiB, and a kernel with more
+    // than 8 KiB of static LDS is not placed beside an accumulate block of another pass,
+    // tools/corun.hip), else one batch
+    extern __shared__ __attribute__((aligned(16))) unsigned char tot_raw[];
+    cplx (*tot)[D][D] = reinterpret_cast<cplx (*)[D][D]>(tot_raw);
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     const int c = g / L;
@@ -325,7 +330,14 @@ hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, i
     switch (d) {
 #define FFK_CASE(D)                                                                              \
     case D:                                                                                      \
-        hipLaunchKernelGGL(apply_prologue_kernel<D>, dim3(G + extra), dim3(64), 0, stream, Qloc, \
+        if (D > 8) {   /* (static 7 D^2 + dynamic 16 D^2 complex numbers: beyond the default limit) */ \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(apply_prologue_kernel<D>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                               static_cast<int>(sizeof(cplx)*D*D*16));           \
+            if (e != hipSuccess) return e;                                                       \
+        }                                                                                        \
+        hipLaunchKernelGGL(apply_prologue_kernel<D>, dim3(G + extra), dim3(64),                  \
+                           sizeof(cplx)*D*D*(D <= 8 ? (G + L - 1)/L : 16), stream, Qloc,         \
                            totals, G, L, Q, eigvals, eigvecs, n_opers, n_coeffs, dt, t, A,       \
                            segtab, Tc, ops, basis, nnz, rows, vals);                             \
         break;

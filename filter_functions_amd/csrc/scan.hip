@@ -42,6 +42,7 @@ __global__ __launch_bounds__(64) void scan_local_kernel(const cplx* __restrict__
                                                         cplx* __restrict__ totals) {
     __shared__ cplx cur[2][D][D];
     __shared__ cplx pg[kScanBatch][D][D];
+    __builtin_amdgcn_s_setprio(3);     // see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
     const int lane = threadIdx.x;
     const int c = blockIdx.x;
     const int g0 = c*L, g1 = min(G, g0 + L);
@@ -55,7 +56,11 @@ __global__ __launch_bounds__(64) void scan_local_kernel(const cplx* __restrict__
         // products instead of 16.  Segments beyond the end count as identity.
         constexpr int DD = D*D, NG = 4, GL = kScanBatch/NG;
         if (L == kScanBatch) {
-            __shared__ cplx lp[NG][GL][D][D];
+            // the group-local prefixes overwrite the staged propagators in place (same layout:
+            // segment k*GL + sg of the chunk): with a second 4 KiB array the kernel held 9.5 KiB of
+            // static LDS, and a kernel with more than 8 KiB is not placed beside an accumulate block
+            // of another pass (tools/corun.hip)
+            cplx (*lp)[GL][D][D] = reinterpret_cast<cplx (*)[GL][D][D]>(&pg[0][0][0]);
             __shared__ cplx xg[NG][D][D];
             for (int e = lane; e < kScanBatch*DD; e += 64) {
                 const int sg = e / DD, ent = e % DD;
@@ -66,15 +71,14 @@ __global__ __launch_bounds__(64) void scan_local_kernel(const cplx* __restrict__
             __syncthreads();
             const int k = (lane / DD) % NG, e = lane % DD, i = e / D, j = e % D;
             const bool act = lane < NG*DD;
-            if (act) lp[k][0][i][j] = pg[k*GL][i][j];
-            __syncthreads();
-            for (int sg = 1; sg < GL; ++sg) {
+            for (int sg = 1; sg < GL; ++sg) {      // (lp[k][0] is pg[k*GL] already)
                 cplx acc = {0.0, 0.0};
                 if (act) {
 #pragma unroll
                     for (int x = 0; x < D; ++x) cmac(acc, pg[k*GL + sg][i][x], lp[k][sg - 1][x][j]);
-                    lp[k][sg][i][j] = acc;
                 }
+                __syncthreads();                   // every read of segment (k, sg) before its overwrite
+                if (act) lp[k][sg][i][j] = acc;
                 __syncthreads();
             }
             if (lane < DD) {
