@@ -707,8 +707,10 @@ def main():
                 'flops_per_launch': stats['accumulate_flops'],
                 'note': 'FP64 vector-FMA issue bound (the kernel issues v_fma_f64 only; vector = '
                         'matrix FP64 peak 78.6 TFLOP/s on MI355X); flops = FMA-counted flops of the '
-                        'Hilbert-space algorithm actually run; frac = dominant kernel, frac_step = '
-                        'the same flops over the whole step time; a pure v_fma_f64 stream on '
+                        'Hilbert-space algorithm actually run; frac = dominant kernel alone (HIP events, '
+                        'each instrumented launch gated on the previous accumulate kernel), frac_step = '
+                        'the same flops over the whole step time -- above frac when passes pipeline: '
+                        'consecutive accumulate kernels then overlap ramp and tail; a pure v_fma_f64 stream on '
                         'pseudo-random operands sustains 55 TFLOP/s on this part '
                         '(tools/fp64_data_probe.hip, profiles/r01_k_*)',
             },
