@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void peer_push_kernel(const double2* __restric
                                                         const long long* __restrict__ acks,
                                                         long long need_ack, int rank,
                                                         int* __restrict__ error) {
+    __builtin_amdgcn_s_setprio(3);     // runs beside accumulate kernels: see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
     const int p = blockIdx.y;
     __shared__ int ok;
     if (threadIdx.x == 0) {
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) void peer_push_kernel(const double2* __restric
 __global__ __launch_bounds__(64) void peer_signal_kernel(long long* const* __restrict__ flags,
                                                          long long* const* __restrict__ acks,
                                                          int world, long long seq, long long consumed) {
+    __builtin_amdgcn_s_setprio(3);
     const int p = threadIdx.x;
     if (p >= world) return;
     __threadfence_system();
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(64) void peer_signal_kernel(long long* const* __res
 // one wavefront: lane p waits for rank p's signal
 __global__ __launch_bounds__(64) void peer_wait_kernel(const long long* __restrict__ flags, int world,
                                                        long long seq, int* __restrict__ error) {
+    __builtin_amdgcn_s_setprio(3);     // (the poll sleeps between reads: it does not take the slots it may)
     const int p = threadIdx.x;
     if (p < world && !poll_at_least(flags + p, seq)) atomicExch(error, 2);
     __threadfence_system();
