@@ -453,7 +453,7 @@ def main():
     import filter_functions_amd as ff
     from filter_functions_amd import _lib
     from filter_functions_amd.device import DevicePipeline
-    from filter_functions_amd.parallel import gather_omega_shards, shard_bounds
+    from filter_functions_amd.parallel import shard_bounds
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

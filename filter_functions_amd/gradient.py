@@ -23,7 +23,6 @@ are served for callers that want the tensor itself:
 :func:`calculate_filter_function_derivative`                 gradient.py:526-556
 =====================================================  =====================================
 """
-import ctypes
 
 import numpy as np
 

@@ -1,4 +1,4 @@
-import os, time, torch, torch.distributed as dist
+import time, torch, torch.distributed as dist
 torch.cuda.set_device(0)
 dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
 x = torch.zeros(1, device='cuda')
