@@ -71,9 +71,19 @@ for case in range(n_cases):
     D, V, Q = orc.diagonalize(H, scratch.dt)
     R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), scratch.n_opers,
                                             scratch.n_coeffs, scratch.dt)
-    errs = {'R_vs_oracle': rel(total.get_control_matrix(omega), R_ref),
-            'F_vs_oracle': rel(total.get_filter_function(omega), orc.filter_function(R_ref)),
-            'R_vs_scratch': rel(total.get_control_matrix(omega), scratch.get_control_matrix(omega)),
+    # Conditioning: the rule sums G terms of magnitude |R_atomic| whose phase errors grow like
+    # g*eps; off resonance the sum itself may be much smaller than its terms (one frequency sampled
+    # where 300 periods interfere destructively: 9e-10 relative to the sum, 2e-13 relative to the
+    # terms).  Deviations from the from-scratch evaluation are therefore measured against the size
+    # of the summed terms, G * max |R_atomic| (a NumPy restatement of the rule shows the same
+    # deviations, profiles/r02_m_*).
+    terms = G*max(np.abs(p.get_control_matrix(omega)).max() for p in pulses)
+
+    def against_terms(got, ref, power=1):
+        return np.abs(got - ref).max()/terms**power
+    errs = {'R_vs_oracle': against_terms(total.get_control_matrix(omega), R_ref),
+            'F_vs_oracle': against_terms(total.get_filter_function(omega), orc.filter_function(R_ref), 2),
+            'R_vs_scratch': against_terms(total.get_control_matrix(omega), scratch.get_control_matrix(omega)),
             'U_total': rel(total.total_propagator, Q[-1])}
     if G <= 40:
         pc = ff.concatenate(seq, calc_pulse_correlation_FF=True, omega=omega)
@@ -83,8 +93,12 @@ for case in range(n_cases):
         reps = int(rng.choice([1, 2, 5, 64, 1000]))
         per = ff.concatenate_periodic(pulses[0], reps)
         rep = ff.concatenate([pulses[0]]*reps, calc_filter_function=True, omega=omega) if reps > 1 else pulses[0]
-        errs['periodic_vs_repeated'] = rel(per.get_control_matrix(omega), rep.get_control_matrix(omega))
-    bad = {k: v for k, v in errs.items() if not v < 1e-9}
+        size = reps*np.abs(pulses[0].get_control_matrix(omega)).max()
+        errs['periodic_vs_repeated'] = (np.abs(per.get_control_matrix(omega) - rep.get_control_matrix(omega)).max()
+                                        / size * min(1.0, G/reps))      # (judged with the tolerance of reps terms)
+    # every evaluation route rounds its phases omega*t to eps*|omega t| radians: routes differ by that
+    tolerance = max(1e-11, 8*np.finfo(float).eps*np.abs(omega).max()*scratch.tau)
+    bad = {k: v for k, v in errs.items() if not v < tolerance}
     if bad:
         print('FAIL', tag, bad, flush=True)
         sys.exit(1)
