@@ -22,7 +22,7 @@ __device__ void prologue_segment(const cplx (*V)[D], const cplx (*Q)[D], cplx (*
                                  const double* __restrict__ dt, const double* __restrict__ t, int G,
                                  int A, double* __restrict__ segtab, cplx* __restrict__ Tc,
                                  cplx* __restrict__ ops, cplx* __restrict__ n_opers_transformed,
-                                 cplx* __restrict__ eigvecs_propagated) {
+                                 cplx* __restrict__ eigvecs_propagated, bool with_noise_ops = true) {
     constexpr int S = seg_stride(D);
     double* st = segtab + static_cast<size_t>(g)*S;
     if (lane == 0) {
@@ -56,6 +56,7 @@ __device__ void prologue_segment(const cplx (*V)[D], const cplx (*Q)[D], cplx (*
     }
     __syncthreads();
 
+    if (!with_noise_ops) return;        // (large d: noise_ops_kernel, one block per operator)
     for (int a = 0; a < A; ++a) {
         const cplx* B = n_opers + static_cast<size_t>(a)*D*D;
         const double s = n_coeffs ? n_coeffs[static_cast<size_t>(a)*G + g] : 1.0;   // NULL: unit
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(64) void prologue_kernel(
     const double* __restrict__ n_coeffs, const double* __restrict__ dt,
     const double* __restrict__ t, int G, int A, double* __restrict__ segtab,
     cplx* __restrict__ Tc, cplx* __restrict__ ops, cplx* __restrict__ n_opers_transformed,
-    cplx* __restrict__ eigvecs_propagated) {
+    cplx* __restrict__ eigvecs_propagated, bool with_noise_ops) {
     __shared__ cplx V[D][D];
     __shared__ cplx Q[D][D];
     __shared__ cplx T[D][D];
@@ -104,8 +105,50 @@ __global__ __launch_bounds__(64) void prologue_kernel(
     }
     __syncthreads();
     prologue_segment<D>(V, Q, T, BV, g, lane, eigvals, n_opers, n_coeffs, dt, t, G, A, segtab, Tc,
-                        ops, n_opers_transformed, eigvecs_propagated);
+                        ops, n_opers_transformed, eigvecs_propagated, with_noise_ops);
 }
+
+// Bbar_a^(g) = s_a(t_g) V_g^dag B_a V_g for one (segment, noise operator) per block.  For large d the
+// two d^3 products per operator dominate the prologue (d = 16, 18 operators: 172 us for 13 blocks
+// of one wavefront each); spread over G x A blocks they take as long as one operator.
+template <int D>
+__global__ __launch_bounds__(64) void noise_ops_kernel(const cplx* __restrict__ eigvecs,
+                                                       const cplx* __restrict__ n_opers,
+                                                       const double* __restrict__ n_coeffs, int G,
+                                                       int A, cplx* __restrict__ ops,
+                                                       cplx* __restrict__ n_opers_transformed) {
+    __shared__ cplx V[D][D];
+    __shared__ cplx BV[D][D];
+    __builtin_amdgcn_s_setprio(3);     // see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
+    const int g = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+    for (int e = lane; e < D*D; e += 64) V[e / D][e % D] = eigvecs[static_cast<size_t>(g)*D*D + e];
+    __syncthreads();
+    const cplx* B = n_opers + static_cast<size_t>(a)*D*D;
+    const double s = n_coeffs ? n_coeffs[static_cast<size_t>(a)*G + g] : 1.0;   // NULL: unit
+    for (int e = lane; e < D*D; e += 64) {
+        const int i = e / D, n = e % D;
+        cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < D; ++k) cmac(acc, B[i*D + k], V[k][n]);
+        BV[i][n] = acc;
+    }
+    __syncthreads();
+    for (int e = lane; e < D*D; e += 64) {
+        const int m = e / D, n = e % D;
+        cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < D; ++k) cmac_conj(acc, V[k][m], BV[k][n]);
+        acc.re *= s;
+        acc.im *= s;
+        ops[(static_cast<size_t>(g)*(1 + A) + 1 + a)*D*D + e] = acc;
+        if (n_opers_transformed)
+            n_opers_transformed[(static_cast<size_t>(a)*G + g)*D*D + e] = acc;
+    }
+}
+
+// noise operators by their own launch from this dimension on (and only with several of them)
+constexpr int kNoiseOpsKernelMinD = 12;
+inline bool split_noise_ops(int d, int A) { return d >= kNoiseOpsKernelMinD && A >= 2 && A <= 65535; }
 
 // Fused scan fix-up + prologue, one wavefront per segment:
 //   E_c = T_{c-1} ... T_0 rebuilt serially from the chunk totals (<= 63 small products, done
@@ -119,7 +162,7 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
     const double* __restrict__ dt, const double* __restrict__ t, int A,
     double* __restrict__ segtab, cplx* __restrict__ Tc, cplx* __restrict__ ops,
     const cplx* __restrict__ basis, int* __restrict__ nnz, int* __restrict__ rows,
-    cplx* __restrict__ vals) {
+    cplx* __restrict__ vals, bool with_noise_ops) {
     // extra blocks (launch_apply_prologue_compact): basis compaction
     if (static_cast<int>(blockIdx.x) >= G) {
         basis_compact_one(basis, D, static_cast<int>(blockIdx.x) - G, threadIdx.x, nnz, rows, vals);
@@ -233,7 +276,7 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
     for (int e = lane; e < D*D; e += 64) V[e / D][e % D] = eigvecs[static_cast<size_t>(g)*D*D + e];
     __syncthreads();
     prologue_segment<D>(V, Q, T, BV, g, lane, eigvals, n_opers, n_coeffs, dt, t, G, A, segtab, Tc,
-                        ops, nullptr, nullptr);
+                        ops, nullptr, nullptr, with_noise_ops);
 }
 
 // out[g,k] = T_g C_k T_g^dag with T_g = conj(Tc[g])   (= (Q^dag V)^dag C_k (Q^dag V))
@@ -300,7 +343,10 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
     case D:                                                                                     \
         hipLaunchKernelGGL(prologue_kernel<D>, dim3(G), dim3(64), 0, stream, eigvals, eigvecs,  \
                            propagators, n_opers, n_coeffs, dt, t, G, A, segtab, Tc, ops,        \
-                           n_opers_transformed, eigvecs_propagated);                            \
+                           n_opers_transformed, eigvecs_propagated, !split_noise_ops(D, A));    \
+        if (split_noise_ops(D, A))                                                              \
+            hipLaunchKernelGGL(noise_ops_kernel<D>, dim3(G, A), dim3(64), 0, stream, eigvecs,   \
+                               n_opers, n_coeffs, G, A, ops, n_opers_transformed);              \
         break;
         FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
         FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
@@ -339,7 +385,10 @@ hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, i
         hipLaunchKernelGGL(apply_prologue_kernel<D>, dim3(G + extra), dim3(64),                  \
                            sizeof(cplx)*D*D*(D <= 8 ? (G + L - 1)/L : 16), stream, Qloc,         \
                            totals, G, L, Q, eigvals, eigvecs, n_opers, n_coeffs, dt, t, A,       \
-                           segtab, Tc, ops, basis, nnz, rows, vals);                             \
+                           segtab, Tc, ops, basis, nnz, rows, vals, !split_noise_ops(D, A));     \
+        if (split_noise_ops(D, A))                                                               \
+            hipLaunchKernelGGL(noise_ops_kernel<D>, dim3(G, A), dim3(64), 0, stream, eigvecs,    \
+                               n_opers, n_coeffs, G, A, ops, nullptr);                           \
         break;
         FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
         FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
