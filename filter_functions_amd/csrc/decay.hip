@@ -206,33 +206,47 @@ struct GemmDesc {
     int a_real, c_real;
 };
 
+// 16 x 16 outputs per block, one per thread; the k axis goes through LDS in tiles of 64: four
+// independent (strided, often uncoalesced) global loads per operand and thread are in flight per
+// tile instead of one -- with 16-wide tiles the 256^3 products of the d = 16 cumulant function took
+// 122 us each, bound by sixteen dependent load round trips
+constexpr int kGemmKT = 64;
 __global__ __launch_bounds__(256) void gemm_small_kernel(const double* __restrict__ A,
                                                          const double* __restrict__ B,
                                                          double* __restrict__ C, GemmDesc g) {
-    __shared__ cplx As[16][17];
-    __shared__ cplx Bs[16][17];
+    __shared__ cplx As[16][kGemmKT + 1];
+    __shared__ cplx Bs[kGemmKT][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m = blockIdx.y*16 + ty, n = blockIdx.x*16 + tx;
     const long b = blockIdx.z;
     const double* Ab = A + (g.a_real ? 1 : 2)*b*g.sAb;
     const cplx* Bb = reinterpret_cast<const cplx*>(B) + b*g.sBb;
     cplx acc = {0.0, 0.0};
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
-        // A tile: rows m (ty), columns k0 + tx;  B tile: rows k0 + ty, columns n (tx)
-        cplx av = {0.0, 0.0}, bv = {0.0, 0.0};
-        if (m < g.M && k0 + tx < g.K) {
-            const long o = m*g.sAm + (k0 + tx)*g.sAk;
-            if (g.a_real)
-                av = {Ab[o], 0.0};
-            else
-                av = reinterpret_cast<const cplx*>(Ab)[o];
-        }
-        if (k0 + ty < g.K && n < g.N) bv = Bb[(k0 + ty)*g.sBk + n*g.sBn];
-        As[ty][tx] = av;
-        Bs[ty][tx] = bv;
-        __syncthreads();
+    for (int k0 = 0; k0 < g.K; k0 += kGemmKT) {
+        // A tile: row m (ty), columns k0 + tx + 16 q;  B tile: rows k0 + ty + 16 q, column n (tx)
+        cplx av[kGemmKT/16], bv[kGemmKT/16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) cmac(acc, As[ty][k], Bs[k][tx]);
+        for (int q = 0; q < kGemmKT/16; ++q) {
+            av[q] = {0.0, 0.0};
+            bv[q] = {0.0, 0.0};
+            const int ka = k0 + tx + 16*q, kb = k0 + ty + 16*q;
+            if (m < g.M && ka < g.K) {
+                const long o = m*g.sAm + ka*g.sAk;
+                if (g.a_real)
+                    av[q] = {Ab[o], 0.0};
+                else
+                    av[q] = reinterpret_cast<const cplx*>(Ab)[o];
+            }
+            if (kb < g.K && n < g.N) bv[q] = Bb[kb*g.sBk + n*g.sBn];
+        }
+#pragma unroll
+        for (int q = 0; q < kGemmKT/16; ++q) {
+            As[ty][tx + 16*q] = av[q];
+            Bs[ty + 16*q][tx] = bv[q];
+        }
+        __syncthreads();
+#pragma unroll 16
+        for (int k = 0; k < kGemmKT; ++k) cmac(acc, As[ty][k], Bs[k][tx]);
         __syncthreads();
     }
     if (m < g.M && n < g.N) {
