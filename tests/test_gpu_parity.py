@@ -1821,6 +1821,66 @@ def test_concatenate_from_resident_control_matrices(d, monkeypatch):
     assert calls == [1, 1] and rel_err(again.get_control_matrix(omega), total.get_control_matrix(omega)) < 1e-13
 
 
+def test_round2_entry_points_reject_bad_arguments():
+    """The entry points added late in round 2 answer malformed calls with FFK_EINVAL (ValueError in
+    the binding) and a message, not with a fault: NULL pointers, empty axes, aliasing outputs,
+    mismatched or missing resident results."""
+    import ctypes
+    from filter_functions_amd._resident import ResidentResult
+    lib = _lib.load()
+    z = np.ones(8, complex)
+    R = np.ones((2, 4, 8), complex)
+    L = np.eye(4)
+    out = np.empty_like(R)
+    args = (_lib.ptr(z), _lib.ptr(R), _lib.ptr(L), 0)
+    for bad in ((*args, 0, 2, 4, 8, _lib.ptr(out)),            # repeats < 1
+                (*args, 3, 0, 4, 8, _lib.ptr(out)),            # empty axis
+                (*args, 3, 2, 4, 8, None)):                    # NULL output
+        with pytest.raises(ValueError):
+            _lib.check(lib.ffk_control_matrix_periodic(*bad))
+    assert b'' != lib.ffk_last_error()
+    # sequence call: index out of range, NULL table, filter function asked for with which = 1
+    U = np.tile(np.eye(2, dtype=complex), (2, 1, 1))
+    table = np.ones((2, 1, 4, 8), complex)
+    ph = np.ones((2, 8), complex)
+    basis = np.asarray(ff.Basis.pauli(1))
+    idx = np.array([0, 1, 2], dtype=np.int32)
+    Rt, tot, F = np.empty((1, 4, 8), complex), np.empty((2, 2), complex), np.empty((1, 1, 8), complex)
+
+    def sequence(index, table_ptr, which, F_ptr):
+        return lib.ffk_concatenate_sequence(_lib.ptr(U), _lib.ptr(ph), table_ptr,
+                                            index.ctypes.data_as(ctypes.c_void_p), _lib.ptr(basis), 1, 2,
+                                            len(index), 2, 1, 4, 8, which, _lib.ptr(Rt), _lib.ptr(tot), None, F_ptr)
+    for status in (sequence(idx, _lib.ptr(table), 0, None), sequence(idx[:2], None, 0, None),
+                   sequence(idx[:2], _lib.ptr(table), 1, _lib.ptr(F))):
+        with pytest.raises(ValueError):
+            _lib.check(status)
+    _lib.check(sequence(idx[:2], _lib.ptr(table), 0, _lib.ptr(F)))          # and the well-formed call works
+    # resident variants: a handle without a result, a result that is also an input
+    empty, other = ResidentResult(), ResidentResult()
+    handles = (ctypes.c_void_p*1)(empty.handle)
+    tau = np.ones(1)
+    one = np.zeros(2, dtype=np.int32)
+
+    def resident(handle_array, result):
+        return lib.ffk_concatenate_sequence_resident(handle_array, _lib.ptr(tau), one.ctypes.data_as(ctypes.c_void_p),
+                                                     _lib.ptr(basis), 1, 1, 2, 0, _lib.ptr(Rt), _lib.ptr(tot),
+                                                     None, _lib.ptr(F), result)
+    with pytest.raises(ValueError):
+        _lib.check(resident(handles, None))                     # no resident result in the handle
+    pulse = ff.PulseSequence([[util.paulis[1], [1.0]]], [[util.paulis[3], [1.0]]], [1.0])
+    pulse.get_filter_function(np.linspace(0.1, 1, 8))
+    handles = (ctypes.c_void_p*1)(pulse._resident.handle)
+    with pytest.raises(ValueError):
+        _lib.check(resident(handles, pulse._resident.handle))   # result must not be an input
+    _lib.check(resident(handles, other.handle))                 # well formed: result kept in `other`
+    with pytest.raises(ValueError):                             # controls route: NULL operators
+        _lib.check(lib.ffk_resident_filter_function_from_controls(
+            empty.handle, None, 1, _lib.ptr(tau), _lib.ptr(tau), _lib.ptr(np.array([0.0, 1.0])), 1, 2,
+            _lib.ptr(tau), 1, _lib.ptr(basis), 4, _lib.ptr(basis[3:]), 1, _lib.ptr(tau),
+            *(ctypes.byref(ctypes.c_void_p()) for _ in range(4))))
+
+
 @pytest.mark.parametrize('G,T', [(1001, 3), (999, 1), (137, 5)])
 def test_indexed_concatenation_with_uneven_slabs(G, T):
     """Gather-from-table concatenation at position counts that leave the last pulse-axis slab short
