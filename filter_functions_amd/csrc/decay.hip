@@ -433,58 +433,92 @@ hipError_t launch_cumulant_function(const double* gamma, size_t batch, int N, in
 
 
 // ---- matrix exponential of a real N x N matrix (error_transfer_matrix, numeric.py:2049-2053) ----
-// C = alpha A B + (add_identity ? 1 : 0), real FP64, row-major, one 16x16 tile per wavefront on
-// v_mfma_f64_16x16x4 (operand maps as in decay_gemm_kernel); edges are zero-padded by the loads.
+// C = alpha A B + c0 I + c1 X1 + c2 X2 + c3 X3, real FP64, row-major, one 16x16 tile per wavefront
+// on v_mfma_f64_16x16x4 (operand maps as in decay_gemm_kernel); edges are zero-padded by the loads.
+// (X pointers with a zero coefficient are not read.)
 namespace {
-__global__ __launch_bounds__(64) void dgemm_eye_kernel(const double* __restrict__ A,
-                                                       const double* __restrict__ B, int N,
-                                                       double alpha, int add_identity,
-                                                       double* __restrict__ C) {
+struct PolyTerms {
+    double c0, c1, c2, c3;
+    const double *X1, *X2, *X3;
+};
+
+__global__ __launch_bounds__(64) void dgemm_poly_kernel(const double* __restrict__ A,
+                                                        const double* __restrict__ B, int N,
+                                                        double alpha, PolyTerms p,
+                                                        double* __restrict__ C) {
     const int lane = threadIdx.x;
     const int l15 = lane & 15, lk = lane >> 4;
     const int ti = blockIdx.y, tj = blockIdx.x;
     const int row = ti*16 + l15, col = tj*16 + l15;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < N; k0 += 4) {
-        const int k = k0 + lk;
-        const double a = (row < N && k < N) ? A[static_cast<size_t>(row)*N + k] : 0.0;
-        const double b = (k < N && col < N) ? B[static_cast<size_t>(k)*N + col] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    if (alpha != 0.0) {
+        for (int k0 = 0; k0 < N; k0 += 4) {
+            const int k = k0 + lk;
+            const double a = (row < N && k < N) ? A[static_cast<size_t>(row)*N + k] : 0.0;
+            const double b = (k < N && col < N) ? B[static_cast<size_t>(k)*N + col] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
     }
     if (col >= N) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = ti*16 + lk + 4*r;
-        if (i < N) C[static_cast<size_t>(i)*N + col] = alpha*acc[r] + ((add_identity && i == col) ? 1.0 : 0.0);
+        if (i >= N) continue;
+        const size_t o = static_cast<size_t>(i)*N + col;
+        double v = alpha*acc[r];
+        if (i == col) v += p.c0;
+        if (p.c1 != 0.0) v = fma(p.c1, p.X1[o], v);
+        if (p.c2 != 0.0) v = fma(p.c2, p.X2[o], v);
+        if (p.c3 != 0.0) v = fma(p.c3, p.X3[o], v);
+        C[o] = v;
     }
 }
 }  // namespace
 
 // out = exp(A) by scaling and squaring: B = A / 2^s with |B|_1 <= 1/2, Taylor polynomial of degree
-// 18 in Horner form (remainder < 2^-19/19! ~ 1e-23), then s squarings.  A, out, and two N x N
-// scratch matrices are device pointers; `squarings` = s is chosen by the caller from the norm.
-hipError_t launch_expm_real(const double* A, int N, int squarings, double* out, double* t0, double* t1,
+// 18 (remainder < 2^-19/19! ~ 1e-23) evaluated the Paterson-Stockmeyer way -- B^2, B^3, B^4 once,
+// then Horner in B^4 over five cubic blocks whose linear combinations ride in the products'
+// epilogue: 7 products instead of the 18 of plain Horner (every product is one launch-latency-bound
+// kernel of ~16 us at N = 256) --, then s squarings.  A, out and the five N x N scratch matrices
+// w[0..4] are device pointers; `squarings` = s is chosen by the caller from the norm.
+hipError_t launch_expm_real(const double* A, int N, int squarings, double* out, double* const w[5],
                             hipStream_t stream) {
     const dim3 grid((N + 15)/16, (N + 15)/16);
     const double scale = std::ldexp(1.0, -squarings);
-    constexpr int kDegree = 18;
-    // T = 1 + B/kDegree;  T <- 1 + (B T)/m for m = kDegree-1 .. 1
-    double* cur = t0;
-    double* nxt = t1;
-    // first step: B * 1 / kDegree + 1  ==  (A * I) needs no product: use alpha on A itself via A*A? no:
-    // start from T = 1 (identity built by a product with alpha = 0)
-    hipLaunchKernelGGL(dgemm_eye_kernel, grid, dim3(64), 0, stream, A, A, N, 0.0, 1, cur);
-    for (int m = kDegree; m >= 1; --m) {
-        hipLaunchKernelGGL(dgemm_eye_kernel, grid, dim3(64), 0, stream, A, cur, N, scale/m, 1, nxt);
+    double coeff[19];                     // 1/k!
+    coeff[0] = 1.0;
+    for (int k = 1; k <= 18; ++k) coeff[k] = coeff[k - 1]/k;
+    double *X1 = w[0], *X2 = w[1], *X3 = w[2], *X4 = w[3], *S = w[4];
+    const PolyTerms none = {0.0, 0.0, 0.0, 0.0, nullptr, nullptr, nullptr};
+    auto launch = [&](const double* a, const double* b, double alpha, const PolyTerms& p, double* c) {
+        hipLaunchKernelGGL(dgemm_poly_kernel, grid, dim3(64), 0, stream, a, b, N, alpha, p, c);
+    };
+    // X1 = B = scale A (as a linear combination: no product), X2 = B B, X3 = X2 B, X4 = X2 X2
+    launch(A, A, 0.0, PolyTerms{0.0, scale, 0.0, 0.0, A, nullptr, nullptr}, X1);
+    launch(X1, X1, 1.0, none, X2);
+    launch(X2, X1, 1.0, none, X3);
+    launch(X2, X2, 1.0, none, X4);
+    auto block = [&](int j) {             // P_j = sum_{i<4} coeff[4j+i] B^i  (j = 4: three terms)
+        return PolyTerms{coeff[4*j], coeff[4*j + 1], coeff[4*j + 2], 4*j + 3 <= 18 ? coeff[4*j + 3] : 0.0,
+                         X1, X2, X3};
+    };
+    // S = P_4;  S <- S X4 + P_j, j = 3 .. 0   (ping-pong between S and out)
+    double* cur = S;
+    double* nxt = out;
+    launch(X1, X1, 0.0, block(4), cur);
+    for (int j = 3; j >= 0; --j) {
+        launch(cur, X4, 1.0, block(j), nxt);
         std::swap(cur, nxt);
     }
     for (int q = 0; q < squarings; ++q) {
-        hipLaunchKernelGGL(dgemm_eye_kernel, grid, dim3(64), 0, stream, cur, cur, N, 1.0, 0, nxt);
+        launch(cur, cur, 1.0, none, nxt);
         std::swap(cur, nxt);
     }
-    hipError_t err = hipMemcpyAsync(out, cur, sizeof(double)*static_cast<size_t>(N)*N,
-                                    hipMemcpyDeviceToDevice, stream);
-    if (err != hipSuccess) return err;
+    if (cur != out) {
+        hipError_t err = hipMemcpyAsync(out, cur, sizeof(double)*static_cast<size_t>(N)*N,
+                                        hipMemcpyDeviceToDevice, stream);
+        if (err != hipSuccess) return err;
+    }
     return hipGetLastError();
 }
 

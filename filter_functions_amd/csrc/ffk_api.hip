@@ -1850,14 +1850,14 @@ int ffk_expm_real(const double* matrix, int N, double* result) {
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t nb = 8*size_t(N)*N;
     void* base;
-    if (int rc = arena_reserve(4*align_up(nb), &base)) return rc;
+    if (int rc = arena_reserve(7*align_up(nb), &base)) return rc;
     Bump a(base, g_arena.size);
     double* dA = a.take<double>(nb/8);
     double* dO = a.take<double>(nb/8);
-    double* t0 = a.take<double>(nb/8);
-    double* t1 = a.take<double>(nb/8);
+    double* w[5];
+    for (double*& m : w) m = a.take<double>(nb/8);
     FFK_HIP(hipMemcpyAsync(dA, matrix, nb, hipMemcpyHostToDevice, nullptr));
-    FFK_HIP(ffk::launch_expm_real(dA, N, squarings, dO, t0, t1, nullptr));
+    FFK_HIP(ffk::launch_expm_real(dA, N, squarings, dO, w, nullptr));
     FFK_HIP(hipMemcpyAsync(result, dO, nb, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipStreamSynchronize(nullptr));
     return FFK_OK;

@@ -272,7 +272,7 @@ hipError_t launch_noise_ops_from_atomic(const cplx* phases, const cplx* atomic, 
                                         int G, int W, int A, int d, cplx* out, hipStream_t stream);
 
 // exp of a real N x N matrix (device pointers; t0, t1: N*N scratch each); see decay.hip
-hipError_t launch_expm_real(const double* A, int N, int squarings, double* out, double* t0, double* t1,
+hipError_t launch_expm_real(const double* A, int N, int squarings, double* out, double* const w[5],
                             hipStream_t stream);
 
 // ---- liouville.hip ---------------------------------------------------------------------------
