@@ -261,7 +261,7 @@ def bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream, ra
     pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
     pipe = DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, basis,
                           omega, spectrum=1e-3/omega, device=device)
-    ms, kernel_ms = time_pipeline(pipe, torch, lib, _lib, stream, reps=6)
+    ms, kernel_ms = time_pipeline(pipe, torch, lib, _lib, stream, reps=10)
     st = _lib.stats()
     E = cfg['G']*len(omega)*cfg['A']*cfg['d']**2
     return pipe, dict(
@@ -296,7 +296,7 @@ def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
             K = pipe.cumulant_function(gamma, stream=stream)
             K_total = K.sum(dim=0).cpu().numpy()
         result['U'] = ff.error_transfer_matrix(cumulant_function=K_total[None])
-    ms, kernel_ms = time_pipeline(pipe, torch, lib, _lib, stream, reps=5, extra=etm)
+    ms, kernel_ms = time_pipeline(pipe, torch, lib, _lib, stream, reps=10, extra=etm)
     st = _lib.stats()
     E = len(qft.dt)*W*A*qft.d**2
     U = result['U']
@@ -420,6 +420,58 @@ def bench_api_call(ff, c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, s
                 infidelity_ms=float(np.median(t_inf)*1e3)), infid
 
 
+GPU_MODULES = ('torch', 'filter_functions_amd')
+
+
+def self_launch_command(n_gpus, argv, port):
+    """Command line of the child that runs the N ranks: one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+            f'--nproc-per-node={n_gpus}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+            os.path.abspath(__file__), *argv]
+
+
+def pick_json_line(text):
+    """Rank 0's result line among everything the ranks wrote to stdout (the last one, should a
+    library have printed a JSON-looking line of its own)."""
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith('{"metric"'):
+            return line
+    return None
+
+
+def self_launch(n_gpus, argv, run=None):
+    """`bench.py --gpus N` started WITHOUT torch.distributed.run (no WORLD_SIZE in the environment):
+    start the N ranks as a fresh child (`python -m torch.distributed.run ... bench.py <same
+    arguments>`; a child process, never os.exec*), pass its stderr through, print rank 0's one JSON
+    line as this process's single stdout line and return the child's exit code.  This process must
+    not have initialised the GPU (it is the parent of processes that will): checked."""
+    import socket
+    import subprocess
+    loaded = [m for m in GPU_MODULES if m in sys.modules]
+    if loaded:
+        raise RuntimeError(f'the launcher process imported {loaded}: it must stay off the GPU')
+    with socket.socket() as s:                   # a free port for the rendezvous
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = self_launch_command(n_gpus, argv, port)
+    env = dict(os.environ, FFK_BENCH_LAUNCHER='self', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '4'))
+    for key in ('RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(key, None)
+    print('bench.py: launching ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    res = (run or subprocess.run)(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = pick_json_line(res.stdout or '')
+    if line is not None:
+        print(line, flush=True)
+    else:                                        # nothing to relay: show what the ranks said
+        sys.stderr.write(res.stdout or '')
+    if res.returncode == 0 and line is None:
+        return 1
+    return res.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -446,6 +498,10 @@ def main():
     args = ap.parse_args()
     if args.child:
         args.no_cpu_baseline = args.no_pmc = args.no_configs = True
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python3 bench.py --gpus N` as the driver types it: this process becomes the launcher and
+        # never touches the GPU (no torch, no libffk); the ranks are fresh child processes
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -543,7 +599,12 @@ def main():
     # discarded: it gives the first measured launch a stop event to be gated on (ungated, that launch
     # overlaps its predecessor and reads its wait for free CUs as well: 122 instead of 84 us)
     lead = 1 if (max(1, args.streams) > 1 and args.steps > n_ev) else 0
-    timer = AccumulateTimer(lib, _lib, n_ev + lead)
+    # a short timed region (the driver's --steps 20) instruments 3 launches only: further launches
+    # of the same schedule are instrumented right AFTER the closing bracket (untimed steps, queue
+    # kept full by a few plain steps first) so that the mean is over at least 8 launches
+    n_extra = max(0, 8 - n_ev)
+    lead_extra = 1 if (n_extra and max(1, args.streams) > 1) else 0
+    timer = AccumulateTimer(lib, _lib, n_ev + lead + n_extra + lead_extra)
 
     def step(i=None):
         if i is not None and i >= args.steps - n_ev - lead:
@@ -578,6 +639,14 @@ def main():
         torch.cuda.synchronize(device)
         total = time.perf_counter() - t0
         timer.disarm()
+        if n_extra:
+            for _ in range(2*depth):
+                step()
+            for j in range(n_extra + lead_extra):
+                timer.arm(n_ev + lead + j, gate_on_previous=max(1, args.streams) > 1 and j > 0)
+                step()
+            timer.disarm()
+            torch.cuda.synchronize(device)
         return warm, last, issue, total
 
     prewarm, infid, t_issue, elapsed = measure()
@@ -599,6 +668,21 @@ def main():
     if use_dist:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
+    # what lets the driver verify the run: the ranks that took part and the device each one used
+    prop = torch.cuda.get_device_properties(local_rank)
+    mine = dict(rank=rank, local_rank=local_rank, pid=os.getpid(),
+                pci_bus_id='%04x:%02x:%02x' % (prop.pci_domain_id, prop.pci_bus_id, prop.pci_device_id),
+                uuid=str(getattr(prop, 'uuid', '')))
+    rank_devices = [mine]
+    push_error_word = None
+    if use_dist:
+        rank_devices = [None]*world
+        dist.all_gather_object(rank_devices, mine)
+        if ring.peer is not None:
+            torch.cuda.synchronize(device)
+            word = ring.peer.error.to(torch.int32).clone()
+            dist.all_reduce(word, op=dist.ReduceOp.MAX)
+            push_error_word = int(word.item())
     pipe.check_status()                          # eigensolver flags of the device-resident run
     gather_ab = {'fallback': gather_fallback} if gather_fallback else None
     if gather_fallback:
@@ -640,7 +724,10 @@ def main():
         latency_ms = (time.perf_counter() - t1)/reps*1e3
 
     # dominant kernel: ctrl_accumulate, timed by HIP events on its own stream inside the region
-    acc_ms = float(np.mean(timer.read_ms()[lead:]))
+    all_ms = timer.read_ms()
+    in_region_ms = all_ms[lead:lead + n_ev]
+    extra_ms = all_ms[lead + n_ev + lead_extra:]
+    acc_ms = float(np.mean(in_region_ms + extra_ms))
     stats = _lib.stats()
     timer.close()
 
@@ -701,13 +788,24 @@ def main():
                        **({'REHEARSAL': 'all ranks on one GPU over gloo (FFK_BENCH_REHEARSE): the '
                                         'numbers of this line mean nothing'} if rehearse else {})},
             'single_stream_ms_per_step': latency_ms, 'gather_ab': gather_ab,
+            'ranks_seen': dist.get_world_size() if use_dist else 1,
+            'rank_devices': rank_devices,
+            'distinct_devices': len({r['pci_bus_id'] for r in rank_devices}),
+            'gather': ring.gather if use_ring else 'none', 'push_error_word': push_error_word,
+            'launcher': ('self: bench.py started torch.distributed.run as a child process'
+                         if os.environ.get('FFK_BENCH_LAUNCHER') == 'self' else
+                         ('torch.distributed.run' if 'RANK' in os.environ else 'direct')),
             'prewarm': prewarm,
             'roofline': {
                 'kernel': 'ffk::ctrl_accumulate_pc_kernel<4,3>', 'bound': 'fp64_valu',
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved/FP64_PEAK_TFLOPS, 'frac_step': step_tflops/FP64_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_source': traffic_src,
-                'avg_launch_ms': acc_ms, 'launches_timed': n_ev,
+                'avg_launch_ms': acc_ms, 'launches_timed': n_ev + n_extra,
+                'launches_in_timed_region': n_ev,
+                'avg_launch_ms_in_timed_region': float(np.mean(in_region_ms)),
+                'launch_ms_min_max': [float(np.min(in_region_ms + extra_ms)),
+                                      float(np.max(in_region_ms + extra_ms))],
                 'flops_per_launch': stats['accumulate_flops'],
                 'note': 'FP64 vector-FMA issue bound (the kernel issues v_fma_f64 only; vector = '
                         'matrix FP64 peak 78.6 TFLOP/s on MI355X); flops = FMA-counted flops of the '
@@ -778,7 +876,7 @@ def bench_config4_strong(ff, torch, dist, lib, _lib, DevicePipeline, device, com
              for _ in range(depth)]
     ring = ShardedStepRing(pipes, W, omega_full, S_full, compute_stream, comm_stream, world, rank,
                            gather=os.environ.get('FFK_GATHER', 'auto'))
-    reps = 6
+    reps = 10
     for _ in range(2):
         ring.step()
     torch.cuda.synchronize(device)
@@ -827,7 +925,7 @@ def bench_config5_strong(ff, torch, dist, DevicePipeline, device, world, rank):
         one()
     torch.cuda.synchronize(device)
     dist.barrier()
-    reps = 5
+    reps = 10
     t0 = time.perf_counter()
     for _ in range(reps):
         gamma, K, U = one()
