@@ -584,7 +584,7 @@ def main():
         # other.  Fusing those launches was tried and is slower (profiles/r02_a_fusion_attempts.md).
         ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_streams,
                                comm_stream, world, rank,
-                               gather=os.environ.get('FFK_GATHER', 'auto') if use_dist else 'none')
+                               gather=os.environ.get('FFK_GATHER', 'rccl') if use_dist else 'none')
     else:
         compute_stream = torch.cuda.current_stream(device)
     stream = compute_stream.cuda_stream
@@ -875,7 +875,7 @@ def bench_config4_strong(ff, torch, dist, lib, _lib, DevicePipeline, device, com
                             omega_full[w0:w1], spectrum=S_full[w0:w1], device=device)
              for _ in range(depth)]
     ring = ShardedStepRing(pipes, W, omega_full, S_full, compute_stream, comm_stream, world, rank,
-                           gather=os.environ.get('FFK_GATHER', 'auto'))
+                           gather=os.environ.get('FFK_GATHER', 'rccl'))
     reps = 10
     for _ in range(2):
         ring.step()

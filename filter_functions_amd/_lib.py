@@ -215,7 +215,8 @@ SIGNATURES = {
     'ffk_peer_push_dev': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, ctypes.c_int64, c_int, c_int,
                                   c_void_p, c_void_p]),
     'ffk_peer_signal_dev': (c_int, [c_void_p, c_void_p, c_int, ctypes.c_int64, ctypes.c_int64,
-                                    c_void_p]),
+                                    c_void_p, c_void_p]),
+    'ffk_peer_set_timeout_ms': (c_int, [c_double]),
     'ffk_peer_wait_dev': (c_int, [c_void_p, c_int, ctypes.c_int64, c_void_p, c_void_p]),
     'ffk_peer_step_dev': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p,
                                   c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),

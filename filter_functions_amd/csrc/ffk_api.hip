@@ -183,11 +183,8 @@ int ffk_malloc_finegrained(void** dptr, size_t bytes) {
     FFK_REQUIRE(dptr, "dptr is NULL");
     // fine-grained (uncached at L2 for other agents' writes): flag words polled by a running kernel
     // while a peer GPU writes them must not be served from a stale L2 line
-    hipError_t e = hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocFinegrained);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        FFK_HIP(hipMalloc(dptr, bytes ? bytes : 1));
-    }
+    // (no coarse-grained substitute: the caller falls back to the RCCL collective instead)
+    FFK_HIP(hipExtMallocWithFlags(dptr, bytes ? bytes : 1, hipDeviceMallocFinegrained));
     return FFK_OK;
 }
 int ffk_free(void* dptr) {

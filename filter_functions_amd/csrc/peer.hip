@@ -13,9 +13,13 @@
 //   signal(c): (next launch: the copy kernel has completed and released its writes) store c + 1 to
 //             flag[rank] on every rank, and "c steps consumed" to ack[rank] on every rank;
 //   wait(c):  poll the local flags until all ranks have signalled c + 1; then the integral runs.
-// Every poll loop has a wall-clock timeout (2 s) that raises an error word instead of hanging.
+// Every poll loop has a wall-clock timeout (2 s by default: FFK_PEER_TIMEOUT_MS / ffk_peer_set_timeout_ms)
+// that raises a STICKY error word instead of hanging; a rank whose error word is set publishes a
+// poison value instead of sequence numbers from then on, so its peers fail as well (code 3) instead
+// of integrating a slot that was never filled.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "ffk.h"
@@ -24,7 +28,8 @@
 namespace ffk {
 namespace {
 
-constexpr long long kPollTimeoutTicks = 200000000LL;   // wall_clock64 ticks at 100 MHz: 2 s
+constexpr long long kPoison = -1;      // a rank that failed publishes this instead of a sequence number
+long long g_poll_timeout_ticks = 0;    // wall_clock64 ticks (100 MHz); 0 = not initialised yet
 
 __device__ __forceinline__ long long load_system(const long long* p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -32,15 +37,20 @@ __device__ __forceinline__ long long load_system(const long long* p) {
 __device__ __forceinline__ void store_system(long long* p, long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// the first failure stays: 1 = acknowledgement timed out (push), 2 = signal timed out (wait),
+// 3 = a peer reported a failure of its own
+__device__ __forceinline__ void raise_error(int* error, int code) { atomicCAS(error, 0, code); }
 
-// true when *p >= want within the timeout
-__device__ bool poll_at_least(const long long* p, long long want) {
+// 0 when *p >= want within the timeout, 1 on timeout, 3 when the word holds the poison value
+__device__ int poll_at_least(const long long* p, long long want, long long timeout_ticks) {
     const long long t0 = wall_clock64();
-    while (load_system(p) < want) {
-        if (wall_clock64() - t0 > kPollTimeoutTicks) return false;
+    for (;;) {
+        const long long v = load_system(p);
+        if (v == kPoison) return 3;
+        if (v >= want) return 0;
+        if (wall_clock64() - t0 > timeout_ticks) return 1;
         __builtin_amdgcn_s_sleep(8);
     }
-    return true;
 }
 
 // grid (nblk, world): block (b, p) copies its share of src to dst[p]; 16 bytes per thread and step
@@ -48,19 +58,23 @@ __global__ __launch_bounds__(256) void peer_push_kernel(const double2* __restric
                                                         double2* const* __restrict__ dst,
                                                         const long long* __restrict__ acks,
                                                         long long need_ack, int rank,
+                                                        long long timeout_ticks,
                                                         int* __restrict__ error) {
     __builtin_amdgcn_s_setprio(3);     // runs beside accumulate kernels: see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
     const int p = blockIdx.y;
     __shared__ int ok;
     if (threadIdx.x == 0) {
         ok = 1;
-        if (p != rank && need_ack > 0 && !poll_at_least(acks + p, need_ack)) {
-            ok = 0;
-            atomicExch(error, 1);
+        if (p != rank && need_ack > 0) {
+            const int bad = poll_at_least(acks + p, need_ack, timeout_ticks);
+            if (bad) {
+                ok = 0;
+                raise_error(error, bad);
+            }
         }
     }
     __syncthreads();
-    if (!ok) return;
+    if (!ok) return;       // the slot on rank p may still be read: nothing is written there
     double2* out = dst[p];
     for (size_t i = static_cast<size_t>(blockIdx.x)*blockDim.x + threadIdx.x; i < n16;
          i += static_cast<size_t>(gridDim.x)*blockDim.x)
@@ -68,25 +82,46 @@ __global__ __launch_bounds__(256) void peer_push_kernel(const double2* __restric
 }
 
 // one wavefront: lane p tells rank p "my block of step seq - 1 is in place" and "I have consumed
-// `consumed` steps"
+// `consumed` steps".  If this rank's error word is set (a push of this or an earlier step was
+// skipped, a wait timed out) it publishes the poison value instead: the peers' polls then fail at
+// once with code 3 rather than integrating a slot this rank never filled, and since the error word
+// is sticky every later step says the same.
 __global__ __launch_bounds__(64) void peer_signal_kernel(long long* const* __restrict__ flags,
                                                          long long* const* __restrict__ acks,
-                                                         int world, long long seq, long long consumed) {
+                                                         int world, long long seq, long long consumed,
+                                                         const int* __restrict__ error) {
     __builtin_amdgcn_s_setprio(3);
     const int p = threadIdx.x;
     if (p >= world) return;
+    const bool failed = __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     __threadfence_system();
-    store_system(flags[p], seq);
-    store_system(acks[p], consumed);
+    store_system(flags[p], failed ? kPoison : seq);
+    store_system(acks[p], failed ? kPoison : consumed);
 }
 
 // one wavefront: lane p waits for rank p's signal
 __global__ __launch_bounds__(64) void peer_wait_kernel(const long long* __restrict__ flags, int world,
-                                                       long long seq, int* __restrict__ error) {
+                                                       long long seq, long long timeout_ticks,
+                                                       int* __restrict__ error) {
     __builtin_amdgcn_s_setprio(3);     // (the poll sleeps between reads: it does not take the slots it may)
     const int p = threadIdx.x;
-    if (p < world && !poll_at_least(flags + p, seq)) atomicExch(error, 2);
+    if (p < world) {
+        const int bad = poll_at_least(flags + p, seq, timeout_ticks);
+        if (bad) raise_error(error, bad == 1 ? 2 : bad);
+    }
     __threadfence_system();
+}
+
+long long poll_timeout_ticks() {
+    if (g_poll_timeout_ticks <= 0) {
+        double ms = 2000.0;
+        if (const char* env = std::getenv("FFK_PEER_TIMEOUT_MS")) {
+            const double v = std::atof(env);
+            if (v > 0) ms = v;
+        }
+        g_poll_timeout_ticks = static_cast<long long>(ms*1e5);
+    }
+    return g_poll_timeout_ticks;
 }
 
 }  // namespace
@@ -140,18 +175,24 @@ int ffk_peer_push_dev(const double* src, size_t bytes, void* const* dst, const i
                        static_cast<hipStream_t>(stream), reinterpret_cast<const double2*>(src), n16,
                        reinterpret_cast<double2* const*>(dst),
                        reinterpret_cast<const long long*>(acks), static_cast<long long>(need_ack), rank,
-                       error);
+                       ffk::poll_timeout_ticks(), error);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFK_OK : peer_fail(FFK_EHIP, "peer_push_kernel", e);
 }
 
+int ffk_peer_set_timeout_ms(double ms) {
+    if (!(ms > 0)) return FFK_EINVAL;
+    ffk::g_poll_timeout_ticks = static_cast<long long>(ms*1e5);
+    return FFK_OK;
+}
+
 int ffk_peer_signal_dev(void* const* flags, void* const* acks, int world, int64_t seq, int64_t consumed,
-                        void* stream) {
-    if (!flags || !acks || world < 1 || world > 64) return FFK_EINVAL;
+                        const int32_t* error, void* stream) {
+    if (!flags || !acks || !error || world < 1 || world > 64) return FFK_EINVAL;
     hipLaunchKernelGGL(ffk::peer_signal_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<long long* const*>(flags),
                        reinterpret_cast<long long* const*>(acks), world, static_cast<long long>(seq),
-                       static_cast<long long>(consumed));
+                       static_cast<long long>(consumed), error);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFK_OK : peer_fail(FFK_EHIP, "peer_signal_kernel", e);
 }
@@ -160,7 +201,7 @@ int ffk_peer_wait_dev(const int64_t* flags, int world, int64_t seq, int32_t* err
     if (!flags || !error || world < 1 || world > 64) return FFK_EINVAL;
     hipLaunchKernelGGL(ffk::peer_wait_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const long long*>(flags), world, static_cast<long long>(seq),
-                       error);
+                       ffk::poll_timeout_ticks(), error);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFK_OK : peer_fail(FFK_EHIP, "peer_wait_kernel", e);
 }
@@ -172,7 +213,7 @@ int ffk_peer_step_dev(const double* src, size_t bytes, void* const* dst, const i
                       const int64_t* own_flags, int world, int rank, int64_t step, int32_t* error,
                       void* stream) {
     if (int rc = ffk_peer_push_dev(src, bytes, dst, own_acks, need_ack, world, rank, error, stream)) return rc;
-    if (int rc = ffk_peer_signal_dev(flag_at, ack_at, world, step + 1, step, stream)) return rc;
+    if (int rc = ffk_peer_signal_dev(flag_at, ack_at, world, step + 1, step, error, stream)) return rc;
     return ffk_peer_wait_dev(own_flags, world, step + 1, error, stream);
 }
 

@@ -184,7 +184,9 @@ class PeerGather:
               rank (the previous launch -- the copy -- has completed and released its writes);
       wait:   poll the local flag words until every rank has signalled >= c + 1.
     The rank that is furthest behind never waits for anybody, so the scheme cannot deadlock; every
-    poll has a 2 s timeout that sets ``error`` instead of hanging.
+    poll has a timeout (2 s, :meth:`set_timeout_ms`) that sets the sticky ``error`` word instead of
+    hanging, and a rank whose word is set signals a poison value from then on, so that its peers
+    fail too instead of integrating a slot that was never filled (``csrc/peer.hip``).
     """
 
     def __init__(self, depth, world, rank, block_shape, device, group=None):
@@ -266,14 +268,29 @@ class PeerGather:
                                                 self.world, self.rank, c, error, stream))
         return self.gathered[k]
 
-    def check(self):
-        """Raise if a poll timed out (reads one word; synchronises the device)."""
+    ERRORS = {1: 'an acknowledgement was not received in time (the copy to that peer was skipped)',
+              2: 'a peer\'s signal was not received in time',
+              3: 'a peer reported a failure of its own (poisoned sequence word)'}
+
+    def error_code(self):
+        """This rank's sticky error word (0 = no poll has failed); synchronises the device."""
         import torch
         torch.cuda.synchronize(self.device)
-        code = int(self.error.cpu().item())
+        return int(self.error.cpu().item())
+
+    def check(self):
+        """Raise if a poll of THIS rank failed (reads one word; synchronises the device).  A rank
+        whose word is set poisons its signals, so every peer's word is set one step later; for a
+        verdict that is the same on all ranks at once use :meth:`ShardedStepRing.check`."""
+        code = self.error_code()
         if code:
-            raise RuntimeError(f'one-sided all-gather timed out ({"acknowledgement" if code == 1 else "signal"} '
-                               f'not received within 2 s on rank {self.rank})')
+            raise RuntimeError(f'one-sided all-gather failed on rank {self.rank}: '
+                               + self.ERRORS.get(code, f'error word {code}'))
+
+    def set_timeout_ms(self, ms):
+        """Timeout of every poll from now on (default 2 s / FFK_PEER_TIMEOUT_MS): it must cover
+        legitimate host stalls of a peer (first-launch compilation, profilers, GC pauses)."""
+        self._check(self._lib.ffk_peer_set_timeout_ms(float(ms)))
 
     def close(self):
         import ctypes
@@ -413,9 +430,31 @@ class ShardedStepRing:
         self.count_offset = 1          # the probe was step 0 of the peer protocol
         return peer
 
+    def check(self):
+        """COLLECTIVE: raise on every rank if the one-sided all-gather failed on any rank since the
+        ring was built (MAX all-reduce of the sticky error words).  Results of ``step()`` must not
+        be consumed without it: a rank whose push was skipped poisons its signals, but the step in
+        which that happens may already have been integrated elsewhere.  With the RCCL collective
+        (or one rank) there is nothing to check.  Synchronises the device."""
+        if self.peer is None:
+            return
+        import torch.distributed as dist
+        torch = self.torch
+        torch.cuda.synchronize(self.peer.device)
+        on_gpu = dist.get_backend(self.group) != 'gloo'
+        word = self.peer.error.to(torch.int32).clone()
+        word = word if on_gpu else word.cpu()
+        dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.group)
+        code = int(word.item())
+        if code:
+            raise RuntimeError('one-sided all-gather failed on some rank: '
+                               + PeerGather.ERRORS.get(code, f'error word {code}')
+                               + '; results since the last successful check are void')
+
     def step(self):
         """Enqueue one sharded step; returns the tensor that will hold its infidelities (valid
-        once the communication stream has passed the step)."""
+        once the communication stream has passed the step AND -- with the one-sided gather -- a
+        later :meth:`check` has passed)."""
         import torch.distributed as dist
         st = self.streams
         c = self.count

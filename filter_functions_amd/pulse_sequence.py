@@ -209,6 +209,15 @@ class PulseSequence:
         twin.__dict__.update(self.__dict__)
         for cache in ('_data', '_frequency_data', '_intermediates'):
             setattr(twin, cache, getattr(self, cache).copy())
+        # by-products still due are re-deferred on the twin (their producers must not depend on
+        # the original staying alive)
+        due = [(cache, key) for cache, key in ((twin._frequency_data, 'total_phases'),
+                                               (twin._data, 'total_propagator_liouville'))
+               if key in cache and type(cache.peek(key)) is Deferred]
+        for cache, key in due:
+            dict.__delitem__(cache, key)
+        if due:
+            twin._defer_by_products()
         return twin
 
     def copy(self):
@@ -352,18 +361,28 @@ class PulseSequence:
     def _defer_by_products(self):
         """What the reference's cache_control_matrix computes on the spot -- total phase factors and
         the Liouville representation of the total propagator -- becomes due on first read."""
-        # (the producers reach the pulse through a weak reference: a closure over `self` stored in
-        # the pulse's own cache would be a reference cycle, and the pulse -- with the device and
-        # pinned blocks of its resident result -- would live until the next pass of the cyclic GC)
-        me = weakref.ref(self)
+        # The producers close over the VALUES they need, as the reference's eager evaluation would
+        # have seen them -- never over the pulse: a closure over `self` stored in the pulse's own
+        # cache would be a reference cycle (the pulse, with the device and pinned blocks of its
+        # resident result, would live until the next pass of the cyclic GC), and a weak reference
+        # would dangle in a shallow copy that outlives the original.
         if 'total_phases' not in self._frequency_data:
-            omega = self.omega
+            omega, tau = self.omega, self.tau
             self._frequency_data['total_phases'] = Deferred(
-                lambda: util.cexp(np.asarray(omega)*me().tau), 16*len(omega))
+                lambda: util.cexp(np.asarray(omega)*tau), 16*len(omega))
         if 'total_propagator_liouville' not in self._data:
-            self._data['total_propagator_liouville'] = Deferred(
-                lambda: liouville_representation(me().total_propagator, me().basis),
-                8*len(self.basis)**2)
+            basis = self.basis
+            known = 'total_propagator' in self._data
+            total = self._data['total_propagator'] if known else None
+            if known:
+                produce = lambda: liouville_representation(total, basis)     # noqa: E731
+            else:
+                # not diagonalised yet (a control matrix handed to cache_control_matrix): the
+                # diagonalisation itself is deferred with it, through a weak reference that
+                # __copy__ re-points at the twin
+                me = weakref.ref(self)
+                produce = lambda: liouville_representation(me().total_propagator, basis)  # noqa: E731
+            self._data['total_propagator_liouville'] = Deferred(produce, 8*len(basis)**2)
 
     def _store_control_matrix(self, control_matrix):
         slot = 'control_matrix_pc' if control_matrix.ndim == 4 else 'control_matrix'

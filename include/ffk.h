@@ -67,7 +67,8 @@ int ffk_device_info(char* name, int len, int* compute_units, size_t* global_mem_
  *      data resident and time kernels on the stream they run on) --------------------------- */
 int ffk_malloc(void** dptr, size_t bytes);
 /* device memory that other agents (peer GPUs) may write while a local kernel polls it: fine-grained
- * coherence (hipExtMallocWithFlags), plain hipMalloc if the runtime refuses */
+ * coherence (hipExtMallocWithFlags).  FFK_EHIP if the runtime refuses: there is no silent
+ * coarse-grained substitute (flag words polled by a running kernel would not be coherent) */
 int ffk_malloc_finegrained(void** dptr, size_t bytes);
 int ffk_free(void* dptr);
 int ffk_memset(void* dptr, int value, size_t bytes, void* stream);
@@ -523,8 +524,11 @@ int ffk_resident_infidelity(ffk_resident* handle, const double* spectrum, int s_
  * Every rank pushes its block into slot `rank` of a gather buffer on every rank through pointers
  * obtained with ffk_ipc_open_handle, with a copy kernel that needs no LDS (it shares the CUs with
  * the accumulate kernel, which an RCCL all-gather kernel cannot), and completion travels as
- * sequence numbers in 64-bit flag words polled with a 2 s timeout (error word: 1 = acknowledgement
- * timed out in push, 2 = signal timed out in wait).  dst / flags / acks are DEVICE arrays of
+ * sequence numbers in 64-bit flag words polled with a timeout (error word, sticky -- the first
+ * failure stays: 1 = acknowledgement timed out in push, the copy to that peer was skipped; 2 =
+ * signal timed out in wait; 3 = a peer published the poison value).  A rank whose error word is set
+ * signals the poison value (-1) instead of sequence numbers from then on, so that no peer
+ * integrates a slot that was never filled: the failure reaches every rank within one step.  dst / flags / acks are DEVICE arrays of
  * `world` device pointers (addresses on rank p of: the slot of this rank in the buffer set, the flag
  * word of this rank, the acknowledgement word of this rank); `acks` / `flags` of push / wait are
  * this rank's own words, one per peer.  filter_functions_amd/parallel.py holds the protocol.     */
@@ -535,7 +539,11 @@ int ffk_ipc_close_handle(void* dptr);
 int ffk_peer_push_dev(const double* src, size_t bytes, void* const* dst, const int64_t* acks,
                       int64_t need_ack, int world, int rank, int32_t* error, void* stream);
 int ffk_peer_signal_dev(void* const* flags, void* const* acks, int world, int64_t seq,
-                        int64_t consumed, void* stream);
+                        int64_t consumed, const int32_t* error, void* stream);
+/* timeout of every poll of the protocol (default 2000 ms, or the environment variable
+ * FFK_PEER_TIMEOUT_MS); legitimate host stalls on a peer (first-launch compilation, a profiler, a
+ * garbage collection) must fit into it */
+int ffk_peer_set_timeout_ms(double ms);
 int ffk_peer_wait_dev(const int64_t* flags, int world, int64_t seq, int32_t* error, void* stream);
 /* the three of step `step` in one call: push (after acknowledgements >= need_ack), signal
  * (flags = step + 1, acknowledging `step` buffers consumed), wait (flags of every peer >= step + 1) */

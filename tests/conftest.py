@@ -12,8 +12,25 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
         sys.path.insert(0, p)
 
 
+def pytest_addoption(parser):
+    parser.addoption('--runslow', action='store_true', default=False,
+                     help='also run the tests marked slow (kernels outside SURVEY section 8)')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: GPU tests of what lies outside the hot-path scope table '
+                                       '(second order, gradient, periodic, remap/extend): run with '
+                                       '--runslow or FFK_RUN_SLOW=1')
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption('--runslow') or os.environ.get('FFK_RUN_SLOW'):
+        return
+    skip = pytest.mark.skip(reason='outside SURVEY section 8: needs --runslow / FFK_RUN_SLOW=1')
+    for item in items:
+        if 'slow' in item.keywords:
+            item.add_marker(skip)
 
 
 def load_golden(name):

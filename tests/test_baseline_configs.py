@@ -229,6 +229,7 @@ def test_config3_thousand_gate_sequence_by_concatenation():
     assert rel_err(R_plain, R) < 1e-11
 
 
+@pytest.mark.slow
 def test_published_example_periodic_driving():
     """The reference's timed example (doc/source/examples/periodic_driving.ipynb) at full size:
     10 000 periods by concatenate_periodic, by ff.concatenate, and the 200 002 segments written out

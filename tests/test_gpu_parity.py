@@ -1128,6 +1128,7 @@ def test_filter_function_scratch_vs_atomic_and_getters(d, n_dt):
 
 
 # ---- second order: F2 -> frequency shifts -> cumulant function / error transfer matrix ----------
+@pytest.mark.slow
 @pytest.mark.parametrize('name', ['q1', 'g3', 'p4', 'p4idle'])
 def test_second_order_chain_against_reference(name):
     """Second-order filter function (incl. negative and zero frequencies, an idle segment with fully
@@ -1179,6 +1180,7 @@ def test_second_order_chain_against_reference(name):
     assert rel_err(sub, g[f'{name}_frequency_shifts_S2'][1:]) < TOL
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize('seed', range(6))
 def test_second_order_filter_function_random_shapes(seed):
     """Random shapes against the oracle: output tiles of every register-tile size (A N from 4 to
@@ -1222,6 +1224,7 @@ def test_second_order_filter_function_random_shapes(seed):
             assert np.abs(contrib + contrib.swapaxes(-1, -2)).max() < 1e-14*np.abs(delta).max(), tag
 
 
+@pytest.mark.slow
 def test_second_order_matrix_core_kernel_matches_vector_kernel(monkeypatch):
     """The MFMA kernel (default where its operands fit in LDS) against the register-tiled vector
     kernel on the same inputs; both are compared with the oracle elsewhere."""
@@ -1247,6 +1250,7 @@ def test_second_order_matrix_core_kernel_matches_vector_kernel(monkeypatch):
         assert rel_err(F_mfma, F_vec) < 1e-12, f'd={d} A={A} G={G} W={W}'
 
 
+@pytest.mark.slow
 def test_second_order_free_induction_decay_closed_form():
     """Reference tests/test_precision.py:218-270: an idle qubit under white and quasistatic noise.
     F2 of the single segment is known in closed form, splitting the segment changes nothing, and
@@ -1285,6 +1289,7 @@ def test_second_order_free_induction_decay_closed_form():
         assert np.abs(d_1[~mask]).max() < 1e-12
 
 
+@pytest.mark.slow
 def test_second_order_error_behaviour():
     """Argument errors of the reference (tests/test_core.py:1019-1046)."""
     g = load_golden('second_order')
@@ -1308,6 +1313,7 @@ def test_second_order_error_behaviour():
         numeric.calculate_frequency_shifts(pulse, S[:-1], omega)
 
 
+@pytest.mark.slow
 def test_second_order_config2_size_against_oracle_subsample():
     """BASELINE config-2 shape (d=4, 256 segments, 3 noise operators, 4096 frequencies; F2 is 151 MB).
     Every frequency is independent, so the oracle on a 16-frequency subsample pins the full-size
@@ -1335,6 +1341,7 @@ def test_second_order_config2_size_against_oracle_subsample():
     assert np.abs(contrib + contrib.swapaxes(-1, -2)).max() < 1e-13*np.abs(delta).max()
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize('name', ['q1', 'p4', 'p4idle'])
 def test_device_resident_second_order_with_logical_omega_shards(name):
     """The multi-GPU second-order path on one GPU: F2 and the frequency shifts stay in HBM
@@ -1381,6 +1388,7 @@ def test_device_resident_second_order_with_logical_omega_shards(name):
     assert np.abs(U - U_ref).max() < TOL*np.abs(U_ref - np.eye(len(U_ref))).max() + 1e-15
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
 def test_second_order_concatenation(name):
     """concatenate(calc_second_order_FF=True) against the reference's result and against the
@@ -1439,6 +1447,7 @@ def test_second_order_concatenation(name):
 
 
 # ---- gradient: derivative of the filter function / infidelity by the control amplitudes ----------
+@pytest.mark.slow
 @pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
 def test_filter_function_and_infidelity_derivative_against_reference(name):
     """get_filter_function_derivative / gradient.infidelity_derivative against the reference's
@@ -1469,6 +1478,7 @@ def test_filter_function_and_infidelity_derivative_against_reference(name):
         pulse.get_filter_function_derivative(omega, n_coeffs_deriv=ncd[:, :1])
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize('seed', range(4))
 def test_gradient_random_shapes_against_oracle_and_finite_differences(seed):
     """Random shapes (d = 2..8, idle segments with degenerate spectra, w = 0 and negative
@@ -1530,6 +1540,7 @@ def test_gradient_random_shapes_against_oracle_and_finite_differences(seed):
             assert np.allclose(grad[:, s, order[h]], fd, rtol=1e-5, atol=1e-9), (s, h)
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize('name', ['q1', 'g3', 'p4', 'g5'])
 def test_control_matrix_derivative_against_reference(name):
     """gradient.calculate_derivative_of_control_matrix_from_scratch and
@@ -1562,6 +1573,7 @@ def test_control_matrix_derivative_against_reference(name):
         gradient.calculate_filter_function_derivative(R[:, :-1], ref)
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize('seed', range(3))
 def test_control_matrix_derivative_random_shapes_against_oracle(seed):
     """Random shapes (d = 2..8, an idle segment, w = 0 and negative frequencies, W not a multiple
@@ -1628,6 +1640,7 @@ def test_control_matrix_derivative_random_shapes_against_oracle(seed):
             assert np.allclose(dR[h, :, s].transpose(1, 2, 0), fd, rtol=1e-5, atol=atol), (s, h)
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
 def test_concatenate_periodic(name):
     """concatenate_periodic against the reference's closed-form result (pulse_sequence.py:1890-1973)
@@ -1649,6 +1662,7 @@ def test_concatenate_periodic(name):
         ff.concatenate_periodic('pulse', 2)
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize('repeats', [1001, 10000])
 def test_concatenate_periodic_many_repeats(repeats):
     """Thousands of periods (the reference's periodic_driving example repeats a 20-segment period
@@ -1671,6 +1685,7 @@ def test_concatenate_periodic_many_repeats(repeats):
         assert rel_err(seq.get_filter_function(omega), per.get_filter_function(omega)) < 1e-9
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize('N,complex_L', [(4, False), (9, False), (16, True), (64, False)])
 def test_control_matrix_periodic_by_doubling(N, complex_L):
     """The doubling sum against the term-by-term sum (every bit pattern of small repeat counts) and
@@ -1700,6 +1715,7 @@ def test_control_matrix_periodic_by_doubling(N, complex_L):
         numeric.calculate_control_matrix_periodic(z[:-1], R1, L, 3)
 
 
+@pytest.mark.slow
 def test_control_matrix_periodic_where_the_closed_form_is_singular():
     """exp(i w T) Q = 1 (idle pulse at w = 0, or w T a multiple of 2 pi): the reference has to fall
     back to the explicit sum there; the doubling sum needs no special case -- G identical terms."""
@@ -1897,6 +1913,7 @@ def test_indexed_concatenation_with_uneven_slabs(G, T):
     assert rel_err(got, want) < 1e-12
 
 
+@pytest.mark.slow
 @pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
 def test_device_resident_infidelity_gradient_with_logical_omega_shards(name):
     """DevicePipeline.infidelity_gradient (device pointers, no host transfers): the whole grid and
@@ -1961,6 +1978,7 @@ def _check_register(g, prefix, pulse, tol=TOL):
     assert rel_err(pulse.get_filter_function(omega), fresh.get_filter_function(omega)) < tol
 
 
+@pytest.mark.slow
 def test_remap_retains_cached_filter_functions():
     """remap (reference pulse_sequence.py:1976-2120): permuted tensor factors, identifier mapping,
     cached diagonalisation, control matrix and Liouville propagator through the Pauli basis
@@ -1977,6 +1995,7 @@ def test_remap_retains_cached_filter_functions():
         ff.remap(p['p2'], (0, 0))
 
 
+@pytest.mark.slow
 def test_extend_retains_cached_filter_functions():
     """extend (reference pulse_sequence.py:2123-2625): single- and multi-qubit pulses on a larger
     register, a permuted two-qubit pulse, an additional noise Hamiltonian on the whole register."""

@@ -700,3 +700,46 @@ def test_basis_and_pulse_survive_pickling():
     pulse = ff.PulseSequence([[X, [1.0, 2.0], 'X']], [[Z, [1.0, 1.0], 'Z']], [1.0, 0.5])
     clone = pickle.loads(pickle.dumps(pulse))
     assert clone == pulse and list(clone.n_oper_identifiers) == ['Z'] and clone.tau == 1.5
+
+
+def test_shallow_copy_outlives_the_original_with_by_products_still_due(monkeypatch):
+    """total phases and the Liouville propagator are produced on first read; a shallow
+    copy must be able to produce them after the original pulse is gone (the reference computes
+    them eagerly, so its copies always can)."""
+    import copy
+    import gc
+    from filter_functions_amd import pulse_sequence
+    X, Z = util.paulis[1], util.paulis[3]
+    omega = np.array([0.5, 1.0, 2.0])
+    R = np.arange(1*4*3, dtype=complex).reshape(1, 4, 3)
+    seen = []
+    monkeypatch.setattr(pulse_sequence, 'liouville_representation',
+                        lambda U, basis: seen.append((U, basis)) or np.eye(len(basis)))
+    # (a) control matrix handed in, pulse not diagonalised: phases from captured values
+    pulse = ff.PulseSequence([[X, [1.0, 2.0]]], [[Z, [1.0, 1.0]]], [1.0, 0.5])
+    pulse.cache_control_matrix(omega, R)
+    twin = copy.copy(pulse)
+    del pulse
+    gc.collect()
+    assert np.allclose(twin.get_total_phases(omega), np.exp(1j*omega*1.5))
+    assert twin.get_control_matrix(omega) is R
+    # (b) total propagator known when the by-products were deferred: captured by value
+    pulse = ff.PulseSequence([[X, [1.0, 2.0]]], [[Z, [1.0, 1.0]]], [1.0, 0.5])
+    U = np.array([[0, 1], [1, 0]], complex)
+    pulse.total_propagator = U
+    pulse.cache_control_matrix(omega, R)
+    twin = copy.copy(pulse)
+    del pulse
+    gc.collect()
+    assert np.array_equal(twin.total_propagator_liouville, np.eye(4))
+    assert seen[-1][0] is U
+    # (c) not diagonalised: the deferred entry of the twin diagonalises the TWIN
+    pulse = ff.PulseSequence([[X, [1.0, 2.0]]], [[Z, [1.0, 1.0]]], [1.0, 0.5])
+    pulse.cache_control_matrix(omega, R)
+    twin = copy.copy(pulse)
+    del pulse
+    gc.collect()
+    monkeypatch.setattr(pulse_sequence.PulseSequence, 'diagonalize',
+                        lambda self: self._data.update(total_propagator=2*U))
+    assert np.array_equal(twin.total_propagator_liouville, np.eye(4))
+    assert np.array_equal(seen[-1][0], 2*U)

@@ -78,3 +78,72 @@ def test_one_sided_gather_two_ranks_on_one_device(tmp_path, depth, n_steps):
         assert np.abs(F - got['F_whole']).max() <= 1e-13*np.abs(got['F_whole']).max()
         for infid in got['results']:                             # every step computes the same pulse
             assert np.abs(infid - got['infid_whole']).max() <= 1e-13*np.abs(got['infid_whole']).max()
+
+
+def _failing_worker(rank, world, port, out_dir):
+    """Rank 1 stalls (host side) for longer than the poll timeout: rank 0's wait must time out
+    (code 2), rank 0 must then POISON its signals instead of announcing blocks it could not
+    exchange, rank 1 must fail on the poison (code 3) when it resumes, and the collective check
+    must raise on both ranks (a skipped push used to be signalled as delivered)."""
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+
+    import filter_functions_amd as ff
+    import workloads as wl
+    from filter_functions_amd.device import DevicePipeline
+    from filter_functions_amd.parallel import ShardedStepRing, shard_bounds
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    device = torch.device('cuda', 0)
+    cfg = dict(wl.CONFIG2, G=8)
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
+    W = 256
+    omega = wl.random_pulse_omega(dt, W)
+    basis = ff.Basis.pauli(2)
+    w0, w1 = shard_bounds(W, world, rank)
+    depth = 2
+    pipes = [DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega[w0:w1],
+                            device=device) for _ in range(depth)]
+    compute, comm = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+    ring = ShardedStepRing(pipes, W, omega, 1e-3/omega, compute, comm, world, rank, gather='push')
+    for _ in range(4):
+        ring.step()
+    ring.check()                                  # collective, healthy so far
+    ring.peer.set_timeout_ms(150.0)
+    dist.barrier()
+    if rank == 0:
+        for _ in range(3):                        # rank 1 is not stepping: wait(c) times out
+            ring.step()
+        code_before = ring.peer.error_code()
+    else:
+        time.sleep(1.5)
+        code_before = ring.peer.error_code()      # nothing has failed HERE yet
+    dist.barrier()
+    for _ in range(2):                            # both step again: rank 1 meets the poison
+        ring.step()
+    code_after = ring.peer.error_code()
+    raised = False
+    try:
+        ring.check()
+    except RuntimeError:
+        raised = True
+    np.savez(os.path.join(out_dir, f'fail{rank}.npz'), before=code_before, after=code_after,
+             raised=raised)
+    dist.barrier()
+    ring.peer.close()
+    dist.destroy_process_group()
+
+
+def test_one_sided_gather_failure_reaches_every_rank(tmp_path):
+    world = 2
+    mp.spawn(_failing_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), 'fail0.npz'))
+    r1 = np.load(os.path.join(str(tmp_path), 'fail1.npz'))
+    assert int(r0['before']) == 2                 # rank 0: its peer's signal never came
+    assert int(r1['before']) == 0
+    assert int(r0['after']) == 2                  # sticky: the first failure stays
+    assert int(r1['after']) == 3                  # rank 1: told by the poison, not by a timeout
+    assert bool(r0['raised']) and bool(r1['raised'])
