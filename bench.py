@@ -155,6 +155,7 @@ class AccumulateTimer:
 
     def __init__(self, lib, _lib, n):
         self.lib, self._lib = lib, _lib
+        self.armed = False      # while armed, steps must be enqueued call by call (not replayed)
         self.pairs = [[ctypes.c_void_p(), ctypes.c_void_p()] for _ in range(n)]
         for pair in self.pairs:
             for e in pair:
@@ -165,11 +166,13 @@ class AccumulateTimer:
         launch j - 1 (another stream's accumulate kernel), so that the interval is this kernel's
         execution, not its wait for the other pass's blocks to retire."""
         self._lib.check(self.lib.ffk_set_accumulate_events(self.pairs[j][0], self.pairs[j][1]))
+        self.armed = True
         if gate_on_previous and j > 0:
             self._lib.check(self.lib.ffk_set_accumulate_gate(self.pairs[j - 1][1]))
 
     def disarm(self):
         self._lib.check(self.lib.ffk_set_accumulate_events(None, None))
+        self.armed = False
 
     def read_ms(self, upto=None):
         ms = ctypes.c_float()
@@ -491,6 +494,8 @@ def main():
     ap.add_argument('--streams', type=int, default=2,
                     help='N = 1: independent passes in flight (round robin over this many HIP streams, '
                          'one buffer set each); 1 = strictly one pass after the other')
+    ap.add_argument('--no-graph', action='store_true',
+                    help='enqueue every step call by call instead of replaying captured hipGraphs')
     ap.add_argument('--no-prewarm', action='store_true')
     ap.add_argument('--prewarm-max-s', type=float, default=1.0)
     ap.add_argument('--child', action='store_true',
@@ -584,7 +589,8 @@ def main():
         # other.  Fusing those launches was tried and is slower (profiles/r02_a_fusion_attempts.md).
         ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_streams,
                                comm_stream, world, rank,
-                               gather=os.environ.get('FFK_GATHER', 'rccl') if use_dist else 'none')
+                               gather=os.environ.get('FFK_GATHER', 'rccl') if use_dist else 'none',
+                               use_graph=not args.no_graph)
     else:
         compute_stream = torch.cuda.current_stream(device)
     stream = compute_stream.cuda_stream
@@ -609,9 +615,14 @@ def main():
     def step(i=None):
         if i is not None and i >= args.steps - n_ev - lead:
             timer.arm(i - (args.steps - n_ev - lead), gate_on_previous=max(1, args.streams) > 1)
+        # instrumented launches go call by call (the events are recorded around the kernel inside
+        # ffk_control_matrix_dev); everything else is replayed from captured graphs
         if use_ring:
-            return ring.step()
-        pipe.launch(stream=stream, with_infidelity=True)
+            return ring.step(eager=timer.armed)
+        if args.no_graph or timer.armed:
+            pipe.launch(stream=stream, with_infidelity=True)
+        else:
+            pipe.graph(with_infidelity=True).launch(stream)
         return pipe.infid
 
     def sync():
@@ -661,7 +672,7 @@ def main():
             gather_fallback = f'one-sided all-gather timed out (code {int(code.item())}); measured again with RCCL'
             ring.peer.close()
             ring = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_streams,
-                                   comm_stream, world, rank, gather='rccl')
+                                   comm_stream, world, rank, gather='rccl', use_graph=not args.no_graph)
             prewarm, infid, t_issue, elapsed = measure()
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -693,7 +704,8 @@ def main():
         try:
             ring_b = ShardedStepRing(pipes, W_total, omega_full, spectrum_full, compute_streams,
                                      comm_stream, world, rank,
-                                     gather=other if other == 'rccl' else 'auto')
+                                     gather=other if other == 'rccl' else 'auto',
+                                     use_graph=not args.no_graph)
             if ring_b.gather == other:
                 for _ in range(50):
                     ring_b.step()
@@ -719,7 +731,10 @@ def main():
         reps = 200
         t1 = time.perf_counter()
         for _ in range(reps):
-            pipe.launch(stream=one, with_infidelity=True)
+            if args.no_graph:
+                pipe.launch(stream=one, with_infidelity=True)
+            else:
+                pipe.graph(with_infidelity=True).launch(one)
         torch.cuda.synchronize(device)
         latency_ms = (time.perf_counter() - t1)/reps*1e3
 
@@ -782,6 +797,9 @@ def main():
                                     'peer memory (csrc/peer.hip)' if ring.gather == 'push' else
                                     'RCCL all-gather of F')) if use_dist else 'none',
                        'passes_in_flight': max(1, args.streams),
+                       'enqueue': ('call by call' if args.no_graph else
+                                   'hipGraph replay: one hipGraphLaunch per step (pass + integral); the '
+                                   'HIP-event-instrumented launches call by call'),
                        'schedule': ('passes round robin on %d compute streams, the integral of each pass '
                                     'on a stream of its own, %d buffer sets' % (max(1, args.streams), depth))
                        if use_ring else 'one stream',

@@ -220,6 +220,13 @@ SIGNATURES = {
     'ffk_peer_wait_dev': (c_int, [c_void_p, c_int, ctypes.c_int64, c_void_p, c_void_p]),
     'ffk_peer_step_dev': (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, ctypes.c_int64, c_void_p, c_void_p,
                                   c_void_p, c_int, c_int, ctypes.c_int64, c_void_p, c_void_p]),
+    'ffk_graph_capture_begin': (c_int, [c_void_p]),
+    'ffk_graph_capture_end': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'ffk_graph_capture_abort': (c_int, [c_void_p]),
+    'ffk_graph_launch': (c_int, [c_void_p, c_void_p]),
+    'ffk_graph_node_count': (c_int, [c_void_p, POINTER(c_int)]),
+    'ffk_graph_destroy': (c_int, [c_void_p]),
+    'ffk_stream_wait_event': (c_int, [c_void_p, c_void_p]),
     'ffk_set_segment_chunks': (c_int, [c_int]),
     'ffk_set_accumulate_variant': (c_int, [c_int]),
     'ffk_get_stats': (c_int, [POINTER(ffk_stats)]),

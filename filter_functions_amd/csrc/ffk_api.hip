@@ -241,6 +241,11 @@ int ffk_event_record(void* event, void* stream) {
     FFK_HIP(hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream)));
     return FFK_OK;
 }
+int ffk_stream_wait_event(void* stream, void* event) {
+    FFK_REQUIRE(event, "event is NULL");
+    FFK_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
+    return FFK_OK;
+}
 int ffk_event_synchronize(void* event) {
     FFK_HIP(hipEventSynchronize(static_cast<hipEvent_t>(event)));
     return FFK_OK;

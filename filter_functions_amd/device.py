@@ -13,7 +13,57 @@ import numpy as np
 from . import _lib
 from ._lib import check
 
-__all__ = ['DevicePipeline']
+__all__ = ['DevicePipeline', 'CapturedGraph', 'capture']
+
+_capture_streams = {}
+
+
+class CapturedGraph:
+    """An instantiated hipGraph of ``_dev`` calls (``ffk_graph_*``, include/ffk.h): one runtime
+    call replays what was captured.  The buffers the captured calls named must outlive it -- keep
+    the owning objects referenced (*keep*)."""
+
+    def __init__(self, handle, keep=None):
+        self._lib = _lib.load()
+        self._handle = handle
+        self._keep = keep
+        n = ctypes.c_int(0)
+        check(self._lib.ffk_graph_node_count(handle, ctypes.byref(n)))
+        self.nodes = n.value
+
+    def launch(self, stream):
+        """Replay on *stream* (a raw stream handle: an int or ``None`` for the null stream)."""
+        check(self._lib.ffk_graph_launch(self._handle, stream))
+
+    def __del__(self):
+        handle, self._handle = getattr(self, '_handle', None), None
+        if handle:
+            self._lib.ffk_graph_destroy(handle)
+
+
+def capture(enqueue, stream=None, keep=None):
+    """Capture what ``enqueue(stream_handle)`` enqueues -- any sequence of device-pointer calls of
+    the library on that stream, and on streams forked from and joined back to it with events --
+    into a :class:`CapturedGraph`.  *stream*: raw handle of a created stream; default: a private
+    capture stream of the current device."""
+    lib = _lib.load()
+    if stream is None:
+        dev = ctypes.c_int(0)
+        check(lib.ffk_get_device(ctypes.byref(dev)))
+        stream = _capture_streams.get(dev.value)
+        if stream is None:
+            made = ctypes.c_void_p()
+            check(lib.ffk_stream_create(ctypes.byref(made)))
+            stream = _capture_streams[dev.value] = made.value
+    check(lib.ffk_graph_capture_begin(stream))
+    try:
+        enqueue(stream)
+    except BaseException:
+        lib.ffk_graph_capture_abort(stream)
+        raise
+    handle = ctypes.c_void_p()
+    check(lib.ffk_graph_capture_end(stream, ctypes.byref(handle)))
+    return CapturedGraph(handle, keep=keep)
 
 
 class DevicePipeline:
@@ -93,6 +143,16 @@ class DevicePipeline:
                  p(self.control_matrix), p(self.filter_function), p(self.infid) if do_inf else None,
                  p(self.workspace), self.ws_bytes))
         check(args[0](*args[1], s))
+
+    def graph(self, with_infidelity=True):
+        """The pass of :meth:`launch` as a captured hipGraph (cached; ``set_spectrum`` drops it):
+        ``pipe.graph().launch(stream)`` enqueues the 6 launches of a pass with one runtime call."""
+        do_inf = bool(with_infidelity and self.spectrum is not None)
+        graphs = self._launch_args.setdefault('graphs', {})
+        g = graphs.get(do_inf)
+        if g is None:
+            g = graphs[do_inf] = capture(lambda s: self.launch(stream=s, with_infidelity=do_inf))
+        return g
 
     def check_status(self, stream=None):
         """Raise ``numpy.linalg.LinAlgError`` if the eigensolver of the last :meth:`launch` flagged

@@ -344,9 +344,15 @@ class ShardedStepRing:
     """
 
     def __init__(self, pipes, n_omega, omega_full, spectrum_full, compute_stream, comm_stream,
-                 world, rank, group=None, streams=None, gather='rccl'):
+                 world, rank, group=None, streams=None, gather='rccl', use_graph=False):
         import torch
         self.torch = torch
+        # use_graph: the pass of a step is replayed from a captured hipGraph (one runtime call
+        # instead of 5-6 launches through the binding); on one rank without an exchange the
+        # integral is part of the same graph.  step(eager=True) enqueues that step call by call
+        # (bench.py's HIP-event instrumentation of the accumulate kernel needs the calls).
+        self.use_graph = bool(use_graph) and streams is None
+        self._step_graphs = {}
         self.pipes = list(pipes)
         self.depth = len(self.pipes)
         if self.depth < 2 or self.depth % 2:
@@ -451,7 +457,23 @@ class ShardedStepRing:
                                + PeerGather.ERRORS.get(code, f'error word {code}')
                                + '; results since the last successful check are void')
 
-    def step(self):
+    def _local_step_graph(self, k):
+        """One rank, nothing to exchange: pass + integral of buffer set k as ONE graph, in stream
+        order (a set always returns to the same compute stream when the number of sets is a
+        multiple of the number of streams, so no events are needed either)."""
+        g = self._step_graphs.get(k)
+        if g is None:
+            from .device import capture
+            pipe = self.pipes[k]
+
+            def enqueue(s):
+                pipe.launch(stream=s, with_infidelity=False)
+                pipe.infidelity_from_shards(self._own_shard[k], self.omega_full, self.spectrum_full,
+                                            self.idx, self.infid[k], stream=s)
+            g = self._step_graphs[k] = capture(enqueue)
+        return g
+
+    def step(self, eager=False):
         """Enqueue one sharded step; returns the tensor that will hold its infidelities (valid
         once the communication stream has passed the step AND -- with the one-sided gather -- a
         later :meth:`check` has passed)."""
@@ -463,12 +485,25 @@ class ShardedStepRing:
         pipe = self.pipes[k]
         half = self.depth//2
         compute = self.compute_streams[c % len(self.compute_streams)]
+        graphed = self.use_graph and not eager
+        if self.local_only and self.use_graph and self.depth % len(self.compute_streams) == 0:
+            # (eager or replayed: everything of the step on its compute stream)
+            if graphed:
+                self._local_step_graph(k).launch(st.handle(compute))
+                return self.infid[k]
+            s = st.handle(compute)
+            pipe.launch(stream=s, with_infidelity=False)
+            return pipe.infidelity_from_shards(self._own_shard[k], self.omega_full,
+                                               self.spectrum_full, self.idx, self.infid[k], stream=s)
         if len(self.compute_streams) == 1:
             if c >= half and c % half == 0:
                 st.wait(compute, self.free_events[(c - half) % self.depth])
         elif c >= self.depth:
             st.wait(compute, self.free_events[k])       # the gather of step c - depth read set k
-        pipe.launch(stream=st.handle(compute), with_infidelity=False)
+        if graphed:
+            pipe.graph(with_infidelity=False).launch(st.handle(compute))
+        else:
+            pipe.launch(stream=st.handle(compute), with_infidelity=False)
         ready = st.record(compute)
         if self.peer is not None or self.local_only:
             # one-sided: push this rank's block everywhere, poll for everybody's.  Every call names

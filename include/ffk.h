@@ -552,6 +552,28 @@ int ffk_peer_step_dev(const double* src, size_t bytes, void* const* dst, const i
                       const int64_t* own_flags, int world, int rank, int64_t step, int32_t* error,
                       void* stream);
 
+/* ---- hipGraph capture of device-pointer calls ------------------------------------------------
+ * The reference's user-facing call (PulseSequence.get_filter_function, pulse_sequence.py:691-805 ->
+ * numeric.calculate_control_matrix_from_scratch, numeric.py:707-881) is one Python call; here a
+ * pass is 6 kernel launches whose host-side enqueue cost rivals their device time.  Any sequence
+ * of `_dev` calls issued on `stream` between ffk_graph_capture_begin and ffk_graph_capture_end is
+ * recorded instead of executed and comes back as one graph; ffk_graph_launch replays it on any
+ * stream with a single runtime call.  Work forked onto other streams inside the capture
+ * (ffk_event_record on the captured stream, a wait for that event on the other stream) is captured
+ * too, provided it is joined back the same way before the end.  Arguments are frozen at capture:
+ * every buffer a captured call names (inputs, outputs, workspace) must stay allocated and in place
+ * while the graph lives; their CONTENTS may change between replays.  `stream` must be a created
+ * stream (ffk_stream_create or any hipStream_t), not the null stream.  ffk_graph_capture_abort
+ * leaves capture mode after a failed call. */
+typedef struct ffk_graph ffk_graph;
+int ffk_graph_capture_begin(void* stream);
+int ffk_graph_capture_end(void* stream, ffk_graph** graph);
+int ffk_graph_capture_abort(void* stream);
+int ffk_graph_launch(ffk_graph* graph, void* stream);
+int ffk_graph_node_count(const ffk_graph* graph, int* nodes);
+int ffk_graph_destroy(ffk_graph* graph);
+int ffk_stream_wait_event(void* stream, void* event);
+
 /* ---- tuning / introspection ------------------------------------------------------------ */
 /* Number of segment chunks the control-matrix kernel splits G into (0 = automatic).        */
 int ffk_set_segment_chunks(int chunks);

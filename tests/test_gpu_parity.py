@@ -2277,3 +2277,70 @@ def test_copies_and_pickles_of_a_pulse_with_a_resident_result():
     assert shallow._resident is pulse._resident
     del pulse
     assert rel_err(ff.infidelity(shallow, S, omega), ref) == 0                # resident route
+
+
+def test_captured_pass_replays_bit_identically():
+    """A pass of the hot path captured into a hipGraph (ffk_graph_*) and replayed 100 times -- on
+    the capture stream's sibling, on the null stream, with the inputs changed between replays --
+    gives bit for bit what the same calls give enqueued one by one (reference
+    call: pulse_sequence.py:691-805)."""
+    import torch
+    import workloads as wl
+    from filter_functions_amd.device import DevicePipeline, capture
+    from filter_functions_amd.parallel import ShardedStepRing
+    device = torch.device('cuda', 0)
+    cfg = dict(wl.CONFIG2, G=48)
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
+    omega = wl.random_pulse_omega(dt, 640)
+    basis = ff.Basis.pauli(2)
+    S = 1e-3/omega
+
+    def make():
+        return DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum=S,
+                              device=device)
+    eager, replayed = make(), make()
+    eager.launch()
+    torch.cuda.synchronize(device)
+    want = [t.clone() for t in (eager.eigvals, eager.propagators, eager.control_matrix,
+                                eager.filter_function, eager.infid)]
+    graph = replayed.graph()
+    assert graph.nodes >= 5 and replayed.graph() is graph          # cached
+    side = torch.cuda.Stream(device=device)
+    for i in range(100):
+        for t in (replayed.control_matrix, replayed.filter_function, replayed.infid):
+            t.zero_()
+        torch.cuda.synchronize(device)
+        graph.launch(side.cuda_stream if i % 2 else None)
+        torch.cuda.synchronize(device)
+        got = (replayed.eigvals, replayed.propagators, replayed.control_matrix,
+               replayed.filter_function, replayed.infid)
+        assert all(torch.equal(a, b) for a, b in zip(got, want)), f'replay {i} differs'
+    # contents may change between replays, addresses may not: another pulse through the same graph
+    H2 = eager.H*0.5
+    replayed.H.copy_(H2)
+    eager.H.copy_(H2)
+    eager.launch()
+    graph.launch(side.cuda_stream)
+    torch.cuda.synchronize(device)
+    assert torch.equal(replayed.filter_function, eager.filter_function)
+    assert torch.equal(replayed.infid, eager.infid)
+    assert not torch.equal(replayed.infid, want[-1])
+    replayed.check_status()
+    # a failing call inside a capture leaves the stream usable (abort path)
+    with pytest.raises(ZeroDivisionError):
+        capture(lambda s: 1/0)
+    replayed.graph().launch(None)
+    torch.cuda.synchronize(device)
+    # the ring's one-rank step as a graph (pass + integral) against its eager form, interleaved
+    pipes = [make() for _ in range(4)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    comm = torch.cuda.Stream(device=device)
+    ring = ShardedStepRing(pipes, len(omega), omega, S, streams, comm, 1, 0, gather='none',
+                           use_graph=True)
+    outs = []
+    for i in range(24):
+        out = ring.step(eager=(i % 5 == 0))
+        torch.cuda.synchronize(device)
+        outs.append(out.clone())
+    assert all(torch.equal(o, outs[0]) for o in outs)           # (step 0 was enqueued call by call)
+    assert rel_err(outs[0].cpu().numpy(), want[-1].cpu().numpy()) < TIGHT
