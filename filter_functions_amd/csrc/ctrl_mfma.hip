@@ -26,37 +26,13 @@
 #include <cstdlib>
 
 #include "ffk_internal.h"
+#include "ffk_mfma_util.h"
 
 namespace ffk {
 namespace {
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 constexpr int kMW = 4;   // wavefronts (= noise operators) per block, one per SIMD
-
-// 2 x 2 transposes between two registers and the 16-lane rows (bit 0 / bit 1 of the row index)
-__device__ __forceinline__ void swap_rows16(double& a, double& b) {
-    unsigned alo = static_cast<unsigned>(__double2loint(a)), ahi = static_cast<unsigned>(__double2hiint(a));
-    unsigned blo = static_cast<unsigned>(__double2loint(b)), bhi = static_cast<unsigned>(__double2hiint(b));
-    auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-    auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-    a = __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0]));
-    b = __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
-}
-__device__ __forceinline__ void swap_rows32(double& a, double& b) {
-    unsigned alo = static_cast<unsigned>(__double2loint(a)), ahi = static_cast<unsigned>(__double2hiint(a));
-    unsigned blo = static_cast<unsigned>(__double2loint(b)), bhi = static_cast<unsigned>(__double2hiint(b));
-    auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    a = __hiloint2double(static_cast<int>(hi[0]), static_cast<int>(lo[0]));
-    b = __hiloint2double(static_cast<int>(hi[1]), static_cast<int>(lo[1]));
-}
-// v[k] in row q  <-  v[q] in row k   (rows = lane >> 4)
-__device__ __forceinline__ void transpose_rows(double (&v)[4]) {
-    swap_rows16(v[0], v[1]);
-    swap_rows16(v[2], v[3]);
-    swap_rows32(v[0], v[2]);
-    swap_rows32(v[1], v[3]);
-}
 
 template <int D>
 struct MfmaLayout {

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "ffk_internal.h"
+#include "ffk_mfma_util.h"
 
 namespace ffk {
 namespace {
@@ -75,7 +76,9 @@ struct PcEntries {          // every entry once, the (coinciding) diagonal entri
     static constexpr Slots slot_table = make_table();
 };
 
-template <int D, int NC>
+// MF: the consumers contract on the FP64 matrix cores (v_mfma_f64_4x4x4_4b, 16 frequencies per
+// instruction, four groups per wavefront) instead of v_fma_f64; layout in ffk_mfma_util.h.
+template <int D, int NC, bool MF = false>
 __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
@@ -216,6 +219,110 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
             }
             __syncthreads();
         }
+    } else if constexpr (MF) {
+        // ---- matrix-core consumers ---------------------------------------------------------------
+        // lane (cl = lane & 15, q = lane >> 4); per group wg of 16 frequencies (column cl):
+        //   step 1:  Z_m[j = q]  = sum_n T[n, j] X_m[n],  X_m[n = q] = Bbar[m, q] E[m, q]     (m = 0..3)
+        //   4 x 4 transpose of (m, q) across the 16-lane rows
+        //   step 2:  Y[i = q, j] += sum_m conj(T[m, i]) Z_m[j]
+        // Both steps take the SAME A operand, T[q][cl & 3] (conjugation through the NEG bits): one
+        // complex per lane and segment.  32 matrix instructions per group replace 128 v_fma_f64.
+        static_assert(D == 4, "one 4 x 4 block per matrix");
+        const int cl = lane & 15, q = lane >> 4, c4 = cl & 3;
+        double Yr[4][D], Yi[4][D];                    // [frequency group][column j], row i = q
+#pragma unroll
+        for (int wg = 0; wg < 4; ++wg)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                Yr[wg][j] = 0.0;
+                Yi[wg][j] = 0.0;
+            }
+        // tile slot of entry (m, n = q): the diagonal entries share slot 0
+        int slot[D];
+#pragma unroll
+        for (int m = 0; m < D; ++m) {
+            const int e = m*D + q;
+            slot[m] = (m == q) ? 0 : e - (e > 5) - (e > 10);
+        }
+        __syncthreads();
+        if (g0 < g1) generate_first_share();
+        __syncthreads();
+        for (int it = 0; it < sub_len; ++it) {
+            const int g = g0 + it;
+            if (active && g < g1) {
+                const cplx* tile = lds + static_cast<size_t>(it & 1)*BUF;
+                const cplx* opT = tile + TILE;
+                const cplx* opB = opT + (1 + cidx)*DD;
+                const cplx t = opT[q*D + c4];
+                cplx b[D];
+#pragma unroll
+                for (int m = 0; m < D; ++m) b[m] = opB[m*D + q];
+#pragma unroll
+                for (int wg = 0; wg < 4; ++wg) {
+                    const cplx* ecol = tile + 16*wg + cl;
+                    double zr[4], zi[4];
+#pragma unroll
+                    for (int m = 0; m < D; ++m) {
+                        const cplx x = cmul(b[m], ecol[slot[m]*64]);
+                        zr[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.re, x.re, 0.0, 0, 0, 0);
+                        zi[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.re, x.im, 0.0, 0, 0, 0);
+                        zr[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.im, x.im, zr[m], 0, 0, 1);
+                        zi[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.im, x.re, zi[m], 0, 0, 0);
+                    }
+                    transpose_rows(zr);
+                    transpose_rows(zi);
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        Yr[wg][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.re, zr[j], Yr[wg][j], 0, 0, 0);
+                        Yi[wg][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.re, zi[j], Yi[wg][j], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        Yr[wg][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.im, zi[j], Yr[wg][j], 0, 0, 0);
+                        Yi[wg][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.im, zr[j], Yi[wg][j], 0, 0, 1);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // sub-chunks > 0 hand their accumulators to sub-chunk 0 through LDS (tiles are dead now)
+        cplx* red = reinterpret_cast<cplx*>(lds_raw);
+        constexpr int YSZ = DD*64;
+#pragma unroll
+        for (int s = 1; s < GS; ++s) {
+            if (sub == s) {
+                cplx* dst = red + static_cast<size_t>(cidx)*YSZ + lane;
+#pragma unroll
+                for (int wg = 0; wg < 4; ++wg)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) dst[(wg*D + j)*64] = {Yr[wg][j], Yi[wg][j]};
+            }
+            __syncthreads();
+            if (sub == 0) {
+                const cplx* srcy = red + static_cast<size_t>(cidx)*YSZ + lane;
+#pragma unroll
+                for (int wg = 0; wg < 4; ++wg)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const cplx v = srcy[(wg*D + j)*64];
+                        Yr[wg][j] += v.re;
+                        Yi[wg][j] += v.im;
+                    }
+            }
+            __syncthreads();
+        }
+        if (sub == 0 && active) {
+#pragma unroll
+            for (int wg = 0; wg < 4; ++wg) {
+                const int iwm = blockIdx.x*64 + 16*wg + cl;
+                if (iwm < W) {
+                    cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W + iwm;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) out[static_cast<size_t>(q*D + j)*W] = {Yr[wg][j], Yi[wg][j]};
+                }
+            }
+        }
+        return;
     } else {
         // ---- consumers: Y += T^dag [Bbar o E] T on the tile of the current segment -------------
 #if defined(FFK_PC_PRIO_CONSUMER)     /* tuning builds */
@@ -353,7 +460,12 @@ template <int D, int NC>
 hipError_t launch_pc(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                      int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
     const int lds = pc_accumulate_lds_bytes(D, NC);
-    auto kern = ctrl_accumulate_pc_kernel<D, NC>;
+    // FFK_TUNE_PC_MFMA=1: matrix-core consumers (tuning / A-B)
+    static const bool mfma_consumers = [] {
+        const char* e = std::getenv("FFK_TUNE_PC_MFMA");
+        return e != nullptr && e[0] == '1';
+    }();
+    auto kern = mfma_consumers ? ctrl_accumulate_pc_kernel<D, NC, true> : ctrl_accumulate_pc_kernel<D, NC, false>;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (err != hipSuccess) return err;

@@ -33,7 +33,8 @@ pipes = [DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_co
                         omega, spectrum=1e-3/omega, device=device) for _ in range(depth)]
 streams = [torch.cuda.Stream(device=device) for _ in range(n_streams)]
 comm = torch.cuda.Stream(device=device)
-ring = ShardedStepRing(pipes, 4096, omega, 1e-3/omega, streams, comm, 1, 0, gather=gather)
+ring = ShardedStepRing(pipes, 4096, omega, 1e-3/omega, streams, comm, 1, 0, gather=gather,
+                       use_graph=not os.environ.get("FFK_NO_GRAPH"))
 for _ in range(500):
     ring.step()
 torch.cuda.synchronize()
