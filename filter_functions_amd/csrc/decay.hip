@@ -17,7 +17,9 @@
 // evaluated without the N^4 trace tensor: with D_k = sum_l Gamma_kl C_l the cumulant
 // superoperator is  K(X) = -1/2 sum_k (C_k D_k X - C_k X D_k - D_k X C_k + X D_k C_k)  and
 // K_ij = tr(C_i K(C_j)): four small complex GEMMs (O(d^6)) per noise-operator pair.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 
 #include "ffk_internal.h"
@@ -151,6 +153,138 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
         }
 }
 
+// The same product for N >= 128 with operands staged through LDS: a 256-thread block (four
+// wavefronts, one per SIMD) owns a 128 x 128 tile of Gamma, each wavefront a 64 x 64 quarter (4 x 4
+// MFMA tiles, 16 independent accumulators).  Per step of 16 frequencies the block copies 128 rows
+// x 16 frequencies of each operand (2 x 32 KiB) global -> registers -> LDS, one step AHEAD of the
+// matrix instructions that consume them (double-buffered image, one barrier per step); the spectral
+// weight is multiplied in once on the way (the register-fed kernel does it per wavefront).  Against
+// decay_gemm_kernel<4,4>: every operand byte is fetched from L2 once per block instead of once per
+// wavefront (half the traffic), and the fetch of step s + 1 overlaps the 128 MFMAs of step s instead
+// of preceding them (profiles/r02_*: 1.59 ms, matrix pipe ~36 % busy at config 5).
+// LDS image: [row][16 frequencies + 1 pad] complex -- rows 272 B apart, so the sixteen rows a
+// ds_read_b128 lane group touches fall on different banks.
+constexpr int kDgRows = 128, kDgStep = 16, kDgStride = kDgStep + 1;
+__global__ __launch_bounds__(256) void decay_gemm_lds_kernel(
+    const cplx* __restrict__ R, int Gp, int A, int N, int W, const cplx* __restrict__ scale,
+    int s_ndim, const int32_t* __restrict__ idx, int n_idx, int kchunk, int tiles,
+    double* __restrict__ out, size_t split_stride, int mirror_in_store,
+    const int* __restrict__ complex_weights) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    cplx* As = reinterpret_cast<cplx*>(lds_raw);                       // [2][128][17]
+    cplx* Bs = As + 2*kDgRows*kDgStride;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int ntile = tiles*tiles;
+    const int tile = blockIdx.x % ntile;
+    int z = blockIdx.x / ntile;
+    const int ti = tile / tiles, tj = tile % tiles;
+    const int nb = s_ndim == 3 ? n_idx : 1;
+    const int ib0 = z % nb;
+    z /= nb;
+    const int ia = z % n_idx;
+    z /= n_idx;
+    const int h = z % Gp, g = z / Gp;
+    const int ib = s_ndim == 3 ? ib0 : ia;
+    const bool symmetric = s_ndim != 3 && g == h && *complex_weights == 0;
+    if (symmetric && ti > tj) return;                 // (whole block: no barrier is left waiting)
+    // 64 x 64 quarters strictly below the diagonal are mirrored, not computed
+    const bool compute = !(symmetric && ti == tj && wm > wn);
+    const int srow = s_ndim == 1 ? 0 : (s_ndim == 2 ? ia : ia*n_idx + ib);
+    const cplx* sp = scale + static_cast<size_t>(srow)*W;
+    // staging: thread t copies 8 frequencies (half a step) of row t / 2 of both operands
+    const int srow_l = tid >> 1, shalf = tid & 1;
+    const cplx* La = R + ((static_cast<size_t>(g)*A + idx[ia])*N + min(N - 1, ti*kDgRows + srow_l))*W;
+    const cplx* Rb = R + ((static_cast<size_t>(h)*A + idx[ib])*N + min(N - 1, tj*kDgRows + srow_l))*W;
+    const int wbeg = blockIdx.y*kchunk;
+    const int wend = min(W, wbeg + kchunk);
+    // fetch only LOADS (nothing here may wait for the data: the MFMAs of the current step are issued
+    // between fetch and park); masking and the spectral weight are applied in park
+    cplx ra[8], rb[8], rs[8];
+    auto fetch = [&](int w0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int wc = min(w0 + 8*shalf + c, wend - 1);
+            rs[c] = sp[wc];
+            ra[c] = La[wc];
+            rb[c] = Rb[wc];
+        }
+    };
+    auto park = [&](int buf, int w0) {
+        cplx* da = As + (static_cast<size_t>(buf)*kDgRows + srow_l)*kDgStride + 8*shalf;
+        cplx* db = Bs + (static_cast<size_t>(buf)*kDgRows + srow_l)*kDgStride + 8*shalf;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bool ok = w0 + 8*shalf + c < wend;
+            da[c] = ok ? ra[c] : cplx{0.0, 0.0};
+            db[c] = ok ? cmul(rs[c], rb[c]) : cplx{0.0, 0.0};
+        }
+    };
+    f64x4 acc[4][4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = {0.0, 0.0, 0.0, 0.0};
+
+    if (wbeg < wend) {
+        fetch(wbeg);
+        park(0, wbeg);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int w0 = wbeg; w0 < wend; w0 += kDgStep, buf ^= 1) {
+        const bool more = w0 + kDgStep < wend;
+        if (more) fetch(w0 + kDgStep);                // global loads in flight during the MFMAs
+        if (compute) {
+            const cplx* ap = As + (static_cast<size_t>(buf)*kDgRows + wm*64 + l15)*kDgStride + 4*lk;
+            const cplx* bp = Bs + (static_cast<size_t>(buf)*kDgRows + wn*64 + l15)*kDgStride + 4*lk;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                cplx a[4], b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    a[t] = ap[t*16*kDgStride + c];
+                    b[t] = bp[t*16*kDgStride + c];
+                }
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].re, b[tn].re, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].im, b[tn].im, acc[tm][tn], 0, 0, 0);
+            }
+        }
+        if (more) park(buf ^ 1, w0 + kDgStep);        // (last read in the previous step: barrier below)
+        __syncthreads();
+    }
+    if (!compute) return;
+    double* o = out + static_cast<size_t>(blockIdx.y)*split_stride +
+                static_cast<size_t>(blockIdx.x / ntile)*N*N;
+    const bool mirror = mirror_in_store && symmetric && (ti < tj || wm < wn);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int col = tj*kDgRows + wn*64 + tn*16 + l15;
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ti*kDgRows + wm*64 + tm*16 + lk + 4*r;
+                if (row < N) {
+                    o[static_cast<size_t>(row)*N + col] = acc[tm][tn][r];
+                    if (mirror) o[static_cast<size_t>(col)*N + row] = acc[tm][tn][r];
+                }
+            }
+        }
+}
+constexpr size_t kDgLdsBytes = 2*2*static_cast<size_t>(kDgRows)*kDgStride*sizeof(cplx);
+
 // out[i] = sum_s part[s][i], fixed order.  tile > 0: batches of a pulse with itself (g == h in the
 // batch index (g*Gp + h)*n_idx + a) are symmetric matrices of which only the tiles (of `tile`
 // rows/columns) on or above the diagonal were computed; the rest is read transposed.
@@ -176,10 +310,53 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const double* __rest
 struct DecayPlan {
     int tm, tn, tiles_m, tiles_n, ksplit, kchunk;
     size_t batch;
+    bool lds;       // decay_gemm_lds_kernel: 128 x 128 block tiles (tiles_m = tiles_n = ceil(N / 128))
 };
+
+// FFK_TUNE_DECAY_LDS=1 selects the LDS-staged kernel (tuning / A-B).  Measured at config 5 (d = 16,
+// 18 operators, 16384 omega; profiles/r03_e_*): 2.40 ms against 1.69 ms for the register-fed kernel --
+// with 128 accumulator + 96 staging registers it runs ONE wavefront per SIMD, and a single
+// wavefront issues v_mfma_f64_16x16x4 at well under half the pipe's rate
+// (tools/mfma_occupancy_probe.hip: 34 TFLOP/s at one wavefront per SIMD, 46 at two), which costs
+// more than the halved operand traffic and the overlapped fetch buy.  Not the default.
+bool decay_lds_enabled() {
+    static const bool on = [] {
+        const char* e = std::getenv("FFK_TUNE_DECAY_LDS");
+        return e != nullptr && e[0] == '1';
+    }();
+    return on;
+}
 
 DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
     DecayPlan p;
+    p.lds = false;
+    if (N >= 128 && decay_lds_enabled()) {
+        p.lds = true;
+        p.tm = p.tn = 4;
+        p.tiles_m = p.tiles_n = (N + kDgRows - 1)/kDgRows;
+        p.batch = static_cast<size_t>(Gp)*Gp*n_idx*(s_ndim == 3 ? n_idx : 1);
+        // blocks that do work: the upper triangle of tiles for a pulse with itself (the common case)
+        const size_t per = s_ndim != 3 && Gp == 1 ? static_cast<size_t>(p.tiles_m)*(p.tiles_m + 1)/2
+                                                  : static_cast<size_t>(p.tiles_m)*p.tiles_n;
+        const size_t blocks = p.batch*per;
+        // split the frequency axis so that the grid is a whole number of rounds of one block per
+        // CU (256), at least 256 frequencies per split; fewest steps per CU wins
+        const int max_split = std::max(1, (W + 255)/256);
+        long best = -1;
+        int best_split = 1;
+        for (int split = 1; split <= max_split; ++split) {
+            const int chunk = ((W + split - 1)/split + kDgStep - 1)/kDgStep*kDgStep;
+            const long rounds = static_cast<long>((blocks*split + 255)/256);
+            const long cost = rounds*(chunk/kDgStep + 8);
+            if (best < 0 || cost < best) {
+                best = cost;
+                best_split = split;
+            }
+        }
+        p.kchunk = ((W + best_split - 1)/best_split + kDgStep - 1)/kDgStep*kDgStep;
+        p.ksplit = (W + p.kchunk - 1)/p.kchunk;
+        return p;
+    }
     const int t = N <= 16 ? 1 : (N < 128 ? 2 : 4);
     p.tm = p.tn = t;
     p.tiles_m = p.tiles_n = (N + 16*t - 1)/(16*t);
@@ -364,7 +541,15 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
     double* dst = p.ksplit > 1 ? part : gamma;
     const int mirror = p.ksplit > 1 ? 0 : 1;    // with split-K the reduction fills the lower tiles
     const dim3 grid(static_cast<unsigned>(blocks), p.ksplit);
-    if (p.tm == 1)
+    if (p.lds) {
+        hipError_t aerr = hipFuncSetAttribute(reinterpret_cast<const void*>(decay_gemm_lds_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(kDgLdsBytes));
+        if (aerr != hipSuccess) return aerr;
+        hipLaunchKernelGGL(decay_gemm_lds_kernel, grid, dim3(256), kDgLdsBytes, stream, R, Gp, A, N, W,
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, dst, n, mirror,
+                           complex_weights);
+    } else if (p.tm == 1)
         hipLaunchKernelGGL((decay_gemm_kernel<1, 1>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
                            scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror,
                            complex_weights);
@@ -379,7 +564,7 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
     if (p.ksplit > 1)
         hipLaunchKernelGGL(reduce_splits_kernel, dim3(static_cast<unsigned>((n + 255)/256)),
                            dim3(256), 0, stream, part, p.ksplit, n, N,
-                           s_ndim != 3 ? 16*p.tm : 0, Gp, n_idx, complex_weights, gamma);
+                           s_ndim != 3 ? 16*p.tm : 0, Gp, n_idx, complex_weights, gamma);   // (64-row mirror tiles in both kernels)
     return hipGetLastError();
 }
 
