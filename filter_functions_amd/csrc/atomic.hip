@@ -11,6 +11,9 @@
 // elements); the pulse axis can additionally be split into `gsplit` slabs whose partial sums
 // are combined in fixed order by a second pass when the omega axis alone cannot fill the chip.
 // which = 'correlations' writes every summand (G, A, N, W) instead of their sum.
+#include <algorithm>
+#include <cstdlib>
+
 #include "ffk_internal.h"
 
 namespace ffk {
@@ -28,7 +31,10 @@ __global__ __launch_bounds__(64) void from_atomic_kernel(const cplx* __restrict_
                                                          const int32_t* __restrict__ index,
                                                          const double* __restrict__ L, int G, int A,
                                                          int N, int W, int glen, int correlations,
-                                                         cplx* __restrict__ out) {
+                                                         cplx* __restrict__ out,
+                                                         const cplx* const* __restrict__ Rtab) {
+    // Rtab (INDEXED only, may be NULL): the distinct pulses' control matrices where they lie (one
+    // device pointer each) instead of one contiguous table -- resident results are not copied
     const int w = blockIdx.x*64 + threadIdx.x;
     const int a = blockIdx.y;
     const int nlt = (N + LT - 1)/LT;
@@ -52,7 +58,8 @@ __global__ __launch_bounds__(64) void from_atomic_kernel(const cplx* __restrict_
     if (INDEXED && g0 < G)   // (an empty trailing slab must not walk index[] past its end)
         for (int g = 0; g + 1 < g0; ++g) advance(g);
     for (int g = g0; g < g1; ++g) {
-        const cplx* Rg = Ratomic + (INDEXED ? index[g] : g)*pulse_stride + static_cast<size_t>(a)*N*W + w;
+        const cplx* Rg = ((INDEXED && Rtab) ? Rtab[index[g]] : Ratomic + (INDEXED ? index[g] : g)*pulse_stride) +
+                         static_cast<size_t>(a)*N*W + w;
         cplx step[LT];
         if (g == 0) {
 #pragma unroll
@@ -106,28 +113,371 @@ __global__ __launch_bounds__(64) void from_atomic_kernel(const cplx* __restrict_
     }
 }
 
+// Slab reduction and fidelity filter function in one launch for few rows (A N <= 16): one thread per
+// frequency sums the partial control matrices in slab order (the order of reduce_chunks_kernel),
+// writes R and forms F[a,b] = sum_k conj(R[a,k]) R[b,k] from registers with the arithmetic of
+// ff_fidelity_kernel (a <= b summed over k in order, mirrored, diagonal imaginary part 0): results
+// are bit-identical to the two separate launches.
+constexpr int kReduceFfRows = 16;
+__global__ __launch_bounds__(128) void reduce_ff_small_kernel(const cplx* __restrict__ part, int nslab,
+                                                              int A, int N, int W,
+                                                              cplx* __restrict__ R,
+                                                              cplx* __restrict__ F) {
+    __builtin_amdgcn_s_setprio(3);     // see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
+    const int w = blockIdx.x*blockDim.x + threadIdx.x;
+    if (w >= W) return;
+    const int rows = A*N;
+    const size_t slab = static_cast<size_t>(rows)*W;
+    cplx r[kReduceFfRows];
+#pragma unroll
+    for (int e = 0; e < kReduceFfRows; ++e) {
+        if (e < rows) {
+            cplx acc = part[static_cast<size_t>(e)*W + w];
+            for (int z = 1; z < nslab; ++z) {
+                const cplx v = part[static_cast<size_t>(z)*slab + static_cast<size_t>(e)*W + w];
+                acc.re += v.re;
+                acc.im += v.im;
+            }
+            r[e] = acc;
+            R[static_cast<size_t>(e)*W + w] = acc;
+        }
+    }
+    for (int a = 0; a < A; ++a)
+        for (int b = a; b < A; ++b) {
+            cplx acc = {0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < kReduceFfRows; ++e) {      // (registers: every index a compile-time constant)
+                const int k = e;
+                if (k < N) {
+                    cplx ra = {0.0, 0.0}, rb = {0.0, 0.0};
+#pragma unroll
+                    for (int q = 0; q < kReduceFfRows; ++q) {
+                        if (q == a*N + k) ra = r[q];
+                        if (q == b*N + k) rb = r[q];
+                    }
+                    cmac_conj(acc, ra, rb);
+                }
+            }
+            if (a == b) acc.im = 0.0;
+            F[(static_cast<size_t>(a)*A + b)*W + w] = acc;
+            if (a != b) F[(static_cast<size_t>(b)*A + a)*W + w] = {acc.re, -acc.im};
+        }
+}
+
+// ---- the table rule for few rows, one block per 64 frequencies ------------------------------------------
+// A sequence drawn from T distinct pulses with A N <= 16 rows per control matrix (a single-qubit
+// randomized-benchmarking sequence: T = 24, A N = 4) does ~60 instructions of arithmetic per position
+// and frequency; in from_atomic_kernel every position costs a dependent trip to L2 (index -> table
+// row), and a slab that starts at position g0 first replays g0 phase products at one such trip each.
+// Here a block owns 64 frequencies and ALL positions: the T control matrices and total phase
+// factors of those frequencies are staged in LDS once (T (A N + 1) KiB), sixteen wavefronts take
+// one slab of positions each, the slabs' phase products are combined by a two-level product
+// (slab-local products, then the prefix over slabs: the running product of NumPy's cumprod
+// re-associated at slab boundaries, ~1e-16 relative), and the slab sums are added in slab order in
+// LDS, from where the block writes R and -- optionally -- the fidelity filter function with the
+// arithmetic of ff_fidelity_kernel.  One launch instead of rule + reduction + filter function.
+template <int A, int N, bool LCPLX>
+__global__ __launch_bounds__(1024) void from_atomic_block_kernel(
+    const cplx* __restrict__ phases, const cplx* __restrict__ Ratomic, const cplx* const* __restrict__ Rtab,
+    const int32_t* __restrict__ index, const double* __restrict__ L, int G, int T, int W, int glen,
+    cplx* __restrict__ out, cplx* __restrict__ F) {
+    constexpr int ROWS = A*N;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nslab = blockDim.x >> 6;
+    cplx* Rs = reinterpret_cast<cplx*>(lds_raw);                       // [T][ROWS][64]; later red[nslab][ROWS][64]
+    const size_t big = static_cast<size_t>(max(T*ROWS, nslab*ROWS + ROWS))*64;
+    cplx* Ps = Rs + big;                                               // [T][64]
+    cplx* Pslab = Ps + static_cast<size_t>(T)*64;                      // [nslab][64]
+    const int w = blockIdx.x*64 + lane;
+    const int wc = w < W ? w : W - 1;
+    const size_t pulse_stride = static_cast<size_t>(ROWS)*W;
+    for (int e = wave; e < T*ROWS; e += nslab) {
+        const int k = e / ROWS, r = e % ROWS;
+        const cplx* src = (Rtab ? Rtab[k] : Ratomic + k*pulse_stride) + static_cast<size_t>(r)*W;
+        Rs[static_cast<size_t>(e)*64 + lane] = src[wc];
+    }
+    for (int k = wave; k < T; k += nslab) Ps[k*64 + lane] = phases[static_cast<size_t>(k)*W + wc];
+    __syncthreads();
+    const int g0 = wave*glen, g1 = min(G, g0 + glen);
+    auto times = [](cplx& acc, cplx tp) {           // plain multiply/subtract like NumPy's complex cumprod
+        const double rr = acc.re*tp.re, ii = acc.im*tp.im, ri = acc.re*tp.im, ir = acc.im*tp.re;
+        acc.re = rr - ii;
+        acc.im = ri + ir;
+    };
+    // product of the total phases of this slab's positions, then of all earlier slabs
+    // (index[] is wave uniform: scalar loads, a trip to the scalar cache per position)
+    cplx loc = {1.0, 0.0};
+    for (int g = g0; g < g1; ++g) times(loc, Ps[index[g]*64 + lane]);
+    Pslab[wave*64 + lane] = loc;
+    __syncthreads();
+    cplx run = {1.0, 0.0};
+    for (int s = 0; s < wave; ++s) times(run, Pslab[s*64 + lane]);
+    cplx acc[ROWS];
+#pragma unroll
+    for (int e = 0; e < ROWS; ++e) acc[e] = {0.0, 0.0};
+    // the position's pulse number and propagator are wave uniform (scalar loads); those of position
+    // g + 1 are requested before position g is worked on, so that a trip to L2 overlaps the
+    // arithmetic instead of preceding it
+    constexpr int LN = N*N*(LCPLX ? 2 : 1);
+    double Lnext[LN];
+    int k_next = g0 < g1 ? index[g0] : 0;
+    auto request = [&](int g) {
+        const double* Lg = L + static_cast<size_t>(g > 0 ? g - 1 : 0)*LN;
+#pragma unroll
+        for (int e = 0; e < LN; ++e) Lnext[e] = Lg[e];
+    };
+    if (g0 < g1) request(g0);
+    for (int g = g0; g < g1; ++g) {
+        const int k = k_next;
+        double Lg[LN];
+#pragma unroll
+        for (int e = 0; e < LN; ++e) Lg[e] = Lnext[e];
+        if (g + 1 < g1) {
+            k_next = index[g + 1];
+            request(g + 1);
+        }
+        const cplx* Rg = Rs + static_cast<size_t>(k)*ROWS*64 + lane;
+        if (g == 0) {
+#pragma unroll
+            for (int e = 0; e < ROWS; ++e) {
+                const cplx v = Rg[e*64];
+                acc[e].re += v.re;
+                acc[e].im += v.im;
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                cplx step[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) step[j] = {0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < N; ++kk) {
+                    const cplx v = cmul(run, Rg[(a*N + kk)*64]);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        if (LCPLX) {
+                            const cplx q = {Lg[2*(kk*N + j)], Lg[2*(kk*N + j) + 1]};
+                            cmac(step[j], q, v);
+                        } else {
+                            const double q = Lg[kk*N + j];
+                            step[j].re = fma(q, v.re, step[j].re);
+                            step[j].im = fma(q, v.im, step[j].im);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    acc[a*N + j].re += step[j].re;
+                    acc[a*N + j].im += step[j].im;
+                }
+            }
+        }
+        times(run, Ps[k*64 + lane]);                // run <- run * total_phase[pulse at position g]
+    }
+    __syncthreads();                                // tables dead: the slab sums take their place
+    cplx* red = Rs;
+#pragma unroll
+    for (int e = 0; e < ROWS; ++e) red[(static_cast<size_t>(wave)*ROWS + e)*64 + lane] = acc[e];
+    __syncthreads();
+    cplx* rsum = red + static_cast<size_t>(nslab)*ROWS*64;             // [ROWS][64]
+    for (int e = wave; e < ROWS; e += nslab) {
+        cplx v = red[static_cast<size_t>(e)*64 + lane];
+        for (int s = 1; s < nslab; ++s) {
+            const cplx u = red[(static_cast<size_t>(s)*ROWS + e)*64 + lane];
+            v.re += u.re;
+            v.im += u.im;
+        }
+        rsum[e*64 + lane] = v;
+        if (w < W) out[static_cast<size_t>(e)*W + w] = v;
+    }
+    if (!F) return;
+    __syncthreads();
+    for (int pair = wave; pair < A*A; pair += nslab) {
+        const int a = pair / A, b = pair % A;
+        if (a > b) continue;
+        cplx f = {0.0, 0.0};
+        for (int kk = 0; kk < N; ++kk) cmac_conj(f, rsum[(a*N + kk)*64 + lane], rsum[(b*N + kk)*64 + lane]);
+        if (a == b) f.im = 0.0;
+        if (w < W) {
+            F[(static_cast<size_t>(a)*A + b)*W + w] = f;
+            if (a != b) F[(static_cast<size_t>(b)*A + a)*W + w] = {f.re, -f.im};
+        }
+    }
+}
+
+// ---- the front of a sequence concatenation for small d in ONE launch --------------------------------
+// (pulse_sequence.py:1812-1840: total propagators of the positions, their running products, the
+// Liouville representations of the first G - 1 of them; plus the distinct pulses' total phase factors
+// exp(i omega tau_k), util.cexp, and -- for a resident result -- its copy of the grid).
+// Block 0: thread g holds U_g = table[index[g]]; an inclusive Hillis-Steele scan over the positions
+// in LDS (ceil(log2 G) steps, Q_{g+1} = U_g ... U_0) replaces gather + scan kernels; then thread g
+// forms L_g[i,j] = tr(Q_{g+1}^dag C_i Q_{g+1} C_j) for g < G - 1 (superoperator.py:51-84) from the
+// basis in LDS.  Blocks >= 1: phases (T, W) and the grid copy.  G <= 1024, d <= 4, N <= 16.
+template <int D>
+__global__ __launch_bounds__(1024) void sequence_front_kernel(
+    const cplx* __restrict__ U, const int32_t* __restrict__ index, int G, const cplx* __restrict__ basis,
+    int N, int l_is_complex, cplx* __restrict__ Q, double* __restrict__ L,
+    const double* __restrict__ tau, const double* __restrict__ omega, int T, int W,
+    cplx* __restrict__ phases, double* __restrict__ omega_copy) {
+    constexpr int DD = D*D;
+    __builtin_amdgcn_s_setprio(3);
+    if (blockIdx.x > 0) {
+        const size_t e = static_cast<size_t>(blockIdx.x - 1)*blockDim.x + threadIdx.x;
+        if (e < static_cast<size_t>(T)*W) {
+            const int k = static_cast<int>(e / W), w = static_cast<int>(e % W);
+            phases[e] = cexp(omega[w]*tau[k]);
+            if (omega_copy && k == 0) omega_copy[w] = omega[w];
+        }
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    cplx* buf0 = reinterpret_cast<cplx*>(lds_raw);             // [G][DD]
+    cplx* buf1 = buf0 + static_cast<size_t>(blockDim.x)*DD;    // [G][DD]
+    cplx* Cs = buf1 + static_cast<size_t>(blockDim.x)*DD;      // [N][DD]
+    const int g = threadIdx.x;
+    for (int e = g; e < N*DD; e += blockDim.x) Cs[e] = basis[e];
+    cplx M[DD];
+#pragma unroll
+    for (int e = 0; e < DD; ++e) M[e] = {e / D == e % D ? 1.0 : 0.0, 0.0};
+    if (g < G) {
+        const cplx* src = U + static_cast<size_t>(index[g])*DD;
+#pragma unroll
+        for (int e = 0; e < DD; ++e) M[e] = src[e];
+    }
+    cplx* cur = buf0;
+    cplx* nxt = buf1;
+#pragma unroll
+    for (int e = 0; e < DD; ++e) cur[g*DD + e] = M[e];
+    __syncthreads();
+    for (int shift = 1; shift < G; shift <<= 1) {
+        if (g >= shift && g < G) {
+            // M <- M (the later factors) x cur[g - shift] (the earlier ones)
+            cplx P[DD];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    cplx acc = {0.0, 0.0};
+#pragma unroll
+                    for (int k = 0; k < D; ++k) cmac(acc, M[i*D + k], cur[(g - shift)*DD + k*D + j]);
+                    P[i*D + j] = acc;
+                }
+#pragma unroll
+            for (int e = 0; e < DD; ++e) M[e] = P[e];
+        }
+#pragma unroll
+        for (int e = 0; e < DD; ++e) nxt[g*DD + e] = M[e];
+        __syncthreads();
+        cplx* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    if (g == 0)
+#pragma unroll
+        for (int e = 0; e < DD; ++e) Q[e] = {e / D == e % D ? 1.0 : 0.0, 0.0};
+    if (g < G) {
+#pragma unroll
+        for (int e = 0; e < DD; ++e) Q[static_cast<size_t>(g + 1)*DD + e] = M[e];
+    }
+    if (g + 1 < G) {
+        // L_g = representation of Q_{g+1} = M:  CB_i = M^dag C_i M,  L[i,j] = tr(CB_i C_j)
+        for (int i = 0; i < N; ++i) {
+            const cplx* Ci = Cs + i*DD;
+            cplx CM[DD], CB[DD];
+#pragma unroll
+            for (int r = 0; r < D; ++r)
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    cplx acc = {0.0, 0.0};
+#pragma unroll
+                    for (int k = 0; k < D; ++k) cmac(acc, Ci[r*D + k], M[k*D + c]);
+                    CM[r*D + c] = acc;
+                }
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b = 0; b < D; ++b) {
+                    cplx acc = {0.0, 0.0};
+#pragma unroll
+                    for (int k = 0; k < D; ++k) cmac_conj(acc, M[k*D + a], CM[k*D + b]);
+                    CB[a*D + b] = acc;
+                }
+            for (int j = 0; j < N; ++j) {
+                const cplx* Cj = Cs + j*DD;
+                cplx acc = {0.0, 0.0};
+#pragma unroll
+                for (int a = 0; a < D; ++a)
+#pragma unroll
+                    for (int b = 0; b < D; ++b) cmac(acc, CB[a*D + b], Cj[b*D + a]);
+                const size_t o = (static_cast<size_t>(g)*N + i)*N + j;
+                if (l_is_complex) {
+                    L[2*o] = acc.re;
+                    L[2*o + 1] = acc.im;
+                } else {
+                    L[o] = acc.re;
+                }
+            }
+        }
+    }
+}
+
 template <bool LCPLX, bool INDEXED>
 hipError_t launch_c(const cplx* phases, const cplx* Ratomic, const int32_t* index, const double* L,
                     int G, int A, int N, int W, int gsplit, int correlations, cplx* out,
-                    hipStream_t stream) {
+                    hipStream_t stream, const cplx* const* Rtab) {
     const int glen = (G + gsplit - 1)/gsplit;
     const unsigned tiles = (W + 63)/64;
     if (N <= 4) {
         hipLaunchKernelGGL((from_atomic_kernel<4, LCPLX, INDEXED>), dim3(tiles, A, gsplit), dim3(64),
-                           0, stream, phases, Ratomic, index, L, G, A, N, W, glen, correlations, out);
+                           0, stream, phases, Ratomic, index, L, G, A, N, W, glen, correlations, out, Rtab);
     } else if (N <= 16) {
         hipLaunchKernelGGL((from_atomic_kernel<16, LCPLX, INDEXED>), dim3(tiles, A, gsplit), dim3(64),
-                           0, stream, phases, Ratomic, index, L, G, A, N, W, glen, correlations, out);
+                           0, stream, phases, Ratomic, index, L, G, A, N, W, glen, correlations, out, Rtab);
     } else {
         const int nlt = (N + 15)/16;
         hipLaunchKernelGGL((from_atomic_kernel<16, LCPLX, INDEXED>), dim3(tiles, A, gsplit*nlt),
                            dim3(64), 0, stream, phases, Ratomic, index, L, G, A, N, W, glen,
-                           correlations, out);
+                           correlations, out, Rtab);
     }
     return hipGetLastError();
 }
 
 }  // namespace
+
+bool sequence_front_supported(int d, int G, int N) { return d >= 2 && d <= 4 && G >= 1 && G <= 1024 && N <= 16; }
+
+hipError_t launch_sequence_front(const cplx* U, const int32_t* index, int G, int d, const cplx* basis,
+                                 int N, int l_is_complex, cplx* Q, double* L, const double* tau,
+                                 const double* omega, int T, int W, cplx* phases, double* omega_copy,
+                                 hipStream_t stream) {
+    if (!sequence_front_supported(d, G, N)) return hipErrorInvalidValue;
+    int threads = 64;
+    while (threads < G) threads <<= 1;
+    const size_t lds = (2*static_cast<size_t>(threads) + N)*d*d*sizeof(cplx);
+    const unsigned blocks = 1 + static_cast<unsigned>((static_cast<size_t>(T)*W + threads - 1)/threads);
+#define FFK_FRONT(D)                                                                                   \
+    case D: {                                                                                          \
+        auto kern = sequence_front_kernel<D>;                                                          \
+        if (lds > 48*1024) {                                                                           \
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                  \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize,           \
+                                                 static_cast<int>(lds));                               \
+            if (err != hipSuccess) return err;                                                         \
+        }                                                                                              \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, U, index, G, basis, N,      \
+                           l_is_complex, Q, L, tau, omega, T, W, phases, omega_copy);                  \
+        break;                                                                                         \
+    }
+    switch (d) {
+        FFK_FRONT(2) FFK_FRONT(3) FFK_FRONT(4)
+        default: return hipErrorInvalidValue;
+    }
+#undef FFK_FRONT
+    return hipGetLastError();
+}
 
 // number of pulse-axis slabs used for which='total' (1 = single pass straight into the output)
 int from_atomic_gsplit(int G, int A, int N, int W) {
@@ -147,25 +497,67 @@ size_t from_atomic_workspace_bytes(int G, int A, int N, int W) {
 
 hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int32_t* index,
                               const double* L, int l_is_complex, int G, int A, int N, int W,
-                              int correlations, cplx* out, void* ws, hipStream_t stream) {
+                              int correlations, cplx* out, void* ws, hipStream_t stream,
+                              const cplx* const* Rtab, cplx* F, int T) {
     if (A > 65535) return hipErrorInvalidValue;
+    if (index && !correlations && T > 0 && N == 4 && A <= 4 && G >= 64) {
+        // single-qubit rows, tables that fit LDS: one block per 64 frequencies does rule, reduction and F
+        const int nslab = 16;
+        const int glen = (G + nslab - 1)/nslab;
+        const int rows = A*N;
+        const size_t lds = (static_cast<size_t>(std::max(T*rows, nslab*rows + rows)) + T + nslab)*64*sizeof(cplx);
+        static const bool enabled = [] {
+            const char* e = std::getenv("FFK_TUNE_ATOMIC_BLOCK");
+            return e == nullptr || e[0] != '0';
+        }();
+        if (enabled && lds <= 150*1024) {
+            auto launch = [&](auto kern) -> hipError_t {
+                hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    static_cast<int>(lds));
+                if (e2 != hipSuccess) return e2;
+                hipLaunchKernelGGL(kern, dim3((W + 63)/64), dim3(nslab*64), lds, stream, phases, Ratomic, Rtab,
+                                   index, L, G, T, W, glen, out, F);
+                return hipGetLastError();
+            };
+#define FFK_BLK(AA)                                                                             \
+    case AA:                                                                                    \
+        return l_is_complex ? launch(from_atomic_block_kernel<AA, 4, true>)                     \
+                            : launch(from_atomic_block_kernel<AA, 4, false>);
+            switch (A) {
+                FFK_BLK(1) FFK_BLK(2) FFK_BLK(3) FFK_BLK(4)
+                default: break;
+            }
+#undef FFK_BLK
+        }
+    }
     const int gsplit = correlations ? 1 : from_atomic_gsplit(G, A, N, W);
     cplx* target = (gsplit > 1) ? static_cast<cplx*>(ws) : out;
     hipError_t err;
     if (index) {
         err = l_is_complex ? launch_c<true, true>(phases, Ratomic, index, L, G, A, N, W, gsplit,
-                                                  correlations, target, stream)
+                                                  correlations, target, stream, Rtab)
                            : launch_c<false, true>(phases, Ratomic, index, L, G, A, N, W, gsplit,
-                                                   correlations, target, stream);
+                                                   correlations, target, stream, Rtab);
     } else {
         err = l_is_complex ? launch_c<true, false>(phases, Ratomic, index, L, G, A, N, W, gsplit,
-                                                   correlations, target, stream)
+                                                   correlations, target, stream, nullptr)
                            : launch_c<false, false>(phases, Ratomic, index, L, G, A, N, W, gsplit,
-                                                    correlations, target, stream);
+                                                    correlations, target, stream, nullptr);
     }
     if (err != hipSuccess) return err;
-    if (gsplit > 1)
-        return launch_reduce_chunks(target, gsplit, static_cast<size_t>(A)*N*W, out, stream);
+    // F (optional, which = 'total'): the fidelity filter function of the sum.  For few rows (A N <= 16)
+    // the slab reduction and F are one launch; otherwise the caller's F launch follows the reduction
+    if (F && !correlations && gsplit > 1 && A*N <= kReduceFfRows) {
+        hipLaunchKernelGGL(reduce_ff_small_kernel, dim3((W + 127)/128), dim3(128), 0, stream, target, gsplit,
+                           A, N, W, out, F);
+        return hipGetLastError();
+    }
+    if (gsplit > 1) {
+        err = launch_reduce_chunks(target, gsplit, static_cast<size_t>(A)*N*W, out, stream);
+        if (err != hipSuccess) return err;
+    }
+    if (F && !correlations) return launch_filter_function(out, A, N, W, 0, F, stream);
     return hipSuccess;
 }
 

@@ -732,7 +732,7 @@ int ffk_control_matrix_from_atomic_indexed_dev(const double* total_phases,
                                     reinterpret_cast<const cplx*>(control_matrix_table), index,
                                     propagators_liouville, l_is_complex, G, A, N, W, which,
                                     reinterpret_cast<cplx*>(out), workspace,
-                                    static_cast<hipStream_t>(stream)));
+                                    static_cast<hipStream_t>(stream), nullptr, nullptr, T));
     return FFK_OK;
 }
 
@@ -781,6 +781,14 @@ int ffk_control_matrix_from_atomic_indexed(const double* total_phases,
 }  // extern "C"
 
 namespace {
+// phases[k, w] = exp(i omega[w] tau[k]) (pulse_sequence.py:1156, util.cexp)
+__global__ void total_phases_kernel(const double* __restrict__ omega, const double* __restrict__ tau, int T,
+                                    int W, cplx* __restrict__ phases) {
+    const int w = blockIdx.x*blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (w >= W || k >= T) return;
+    phases[static_cast<size_t>(k)*W + w] = ffk::cexp(omega[w]*tau[k]);
+}
 // P[g] = table[index[g]]: the per-position total propagators of a sequence drawn from T pulses
 __global__ void gather_propagators_kernel(const cplx* __restrict__ table, const int32_t* __restrict__ index,
                                           int G, int dd, cplx* __restrict__ P) {
@@ -820,7 +828,12 @@ int sequence_on_device(const double* dU, const double* dP, const double* dR, con
                        const double* dB, int hermitian_basis, int T, int G, int d, int A, int N, int W,
                        int which, Bump& a, double* control_matrix, double* total_propagator,
                        double* propagators_liouville, double* filter_function, hipStream_t s,
-                       double* resident_R = nullptr, double* resident_F = nullptr) {
+                       double* resident_R = nullptr, double* resident_F = nullptr,
+                       const cplx* const* dRtab = nullptr, const double* dTau = nullptr,
+                       const double* dOmega = nullptr, double* omega_copy = nullptr) {
+    // dRtab: device array of T pointers to the distinct control matrices (dR is then unused);
+    // dTau / dOmega: durations (T) and grid (W) on the device -- the total phases are then formed
+    // here (dP is the buffer they go to), by the fused front launch where it applies
     const size_t dd = size_t(d)*d;
     const int l_is_complex = hermitian_basis ? 0 : 1;
     const int nl = G > 1 ? G - 1 : 1;
@@ -840,20 +853,32 @@ int sequence_on_device(const double* dU, const double* dP, const double* dR, con
     FFK_REQUIRE(watom && (!nF || dF), "workspace too small");
     if (resident_R) dO = resident_R;          // results that stay in a handle's device block
     if (resident_F) dF = resident_F;
-    hipLaunchKernelGGL(gather_propagators_kernel, dim3(static_cast<unsigned>((size_t(G)*dd + 255)/256)),
-                       dim3(256), 0, s, reinterpret_cast<const cplx*>(dU), dI, G, d*d, dSeq);
-    FFK_HIP(hipGetLastError());
-    FFK_HIP(ffk::launch_prefix_products(dSeq, G, d, dQ, wscan, s));
-    if (G > 1)
-        FFK_HIP(ffk::launch_liouville(dQ + dd, G - 1, d, reinterpret_cast<const cplx*>(dB), N,
-                                      hermitian_basis, dL, wliou, s));
-    if (int rc = ffk_control_matrix_from_atomic_indexed_dev(dP, dR, dI, dL, l_is_complex, T, G, A, N, W,
-                                                            which, dO, watom, aws, s))
-        return rc;
-    if (dF) {
-        if (int rc = ffk_filter_function_dev(dO, A, N, W, FFK_FF_FIDELITY, dF, s)) return rc;
-        FFK_HIP(hipMemcpyAsync(filter_function, dF, nF, hipMemcpyDeviceToHost, s));
+    if (dTau && ffk::sequence_front_supported(d, G, N)) {
+        // gather + running products + Liouville representations + total phases (+ grid copy): one launch
+        FFK_HIP(ffk::launch_sequence_front(reinterpret_cast<const cplx*>(dU), dI, G, d,
+                                           reinterpret_cast<const cplx*>(dB), N, l_is_complex, dQ, dL, dTau,
+                                           dOmega, T, W, reinterpret_cast<cplx*>(const_cast<double*>(dP)),
+                                           omega_copy, s));
+    } else {
+        if (dTau) {
+            hipLaunchKernelGGL(total_phases_kernel, dim3((W + 255)/256, T), dim3(256), 0, s, dOmega, dTau, T,
+                               W, reinterpret_cast<cplx*>(const_cast<double*>(dP)));
+            FFK_HIP(hipGetLastError());
+            if (omega_copy) FFK_HIP(hipMemcpyAsync(omega_copy, dOmega, 8*size_t(W), hipMemcpyDeviceToDevice, s));
+        }
+        hipLaunchKernelGGL(gather_propagators_kernel, dim3(static_cast<unsigned>((size_t(G)*dd + 255)/256)),
+                           dim3(256), 0, s, reinterpret_cast<const cplx*>(dU), dI, G, d*d, dSeq);
+        FFK_HIP(hipGetLastError());
+        FFK_HIP(ffk::launch_prefix_products(dSeq, G, d, dQ, wscan, s));
+        if (G > 1)
+            FFK_HIP(ffk::launch_liouville(dQ + dd, G - 1, d, reinterpret_cast<const cplx*>(dB), N,
+                                          hermitian_basis, dL, wliou, s));
     }
+    // the table rule, the slab reduction and (which = 0) the filter function of the sum
+    FFK_HIP(ffk::launch_from_atomic(reinterpret_cast<const cplx*>(dP), reinterpret_cast<const cplx*>(dR), dI,
+                                    dL, l_is_complex, G, A, N, W, which, reinterpret_cast<cplx*>(dO), watom,
+                                    s, dRtab, reinterpret_cast<cplx*>(dF), T));
+    if (dF) FFK_HIP(hipMemcpyAsync(filter_function, dF, nF, hipMemcpyDeviceToHost, s));
     if (control_matrix) FFK_HIP(hipMemcpyAsync(control_matrix, dO, nO, hipMemcpyDeviceToHost, s));
     FFK_HIP(hipMemcpyAsync(total_propagator, dQ + size_t(G)*dd, 16*dd, hipMemcpyDeviceToHost, s));
     if (propagators_liouville && G > 1)
@@ -2327,16 +2352,6 @@ int on_owning_device(const ffk_resident* r) {
 
 }  // extern "C"
 
-namespace {
-// phases[k, w] = exp(i omega[w] tau[k]) (pulse_sequence.py:1156, util.cexp)
-__global__ void total_phases_kernel(const double* __restrict__ omega, const double* __restrict__ tau, int T,
-                                    int W, cplx* __restrict__ phases) {
-    const int w = blockIdx.x*blockDim.x + threadIdx.x;
-    const int k = blockIdx.y;
-    if (w >= W || k >= T) return;
-    phases[static_cast<size_t>(k)*W + w] = ffk::cexp(omega[w]*tau[k]);
-}
-}  // namespace
 
 extern "C" {
 
@@ -2378,10 +2393,13 @@ int ffk_concatenate_sequence_resident(ffk_resident* const* pulses, const double*
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t dd = size_t(d)*d;
     const size_t nU = 16*size_t(T)*dd, nP = 16*size_t(T)*W, nR1 = 16*size_t(A)*N*W, nI = 4*size_t(G);
-    const size_t nB = 16*size_t(N)*dd, nT = 8*size_t(T);
-    // host staging (propagators | tau | index | basis) in one pinned block, one H2D
+    const size_t nB = 16*size_t(N)*dd, nT = 8*size_t(T), nX = 8*size_t(T);
+    // host staging (propagators | tau | index | basis | pointers to the resident control matrices) in
+    // one pinned block, one H2D.  The control matrices are read where they lie (round 3: assembling
+    // a contiguous table cost T device-to-device copies per call, 24 of ~0.5 MB at config 3)
     const size_t oU = 0, oT = oU + align_up(nU), oI = oT + align_up(nT), oB = oI + align_up(nI);
-    const size_t stage = oB + align_up(nB);
+    const size_t oX = oB + align_up(nB);
+    const size_t stage = oX + align_up(nX);
     Block pin = {nullptr, 0, -1};
     if (int rc = g_pin_pool.take(stage, first->device, &pin)) return rc;
     unsigned char* hp = static_cast<unsigned char*>(pin.ptr);
@@ -2393,15 +2411,19 @@ int ffk_concatenate_sequence_resident(ffk_resident* const* pulses, const double*
     std::memcpy(hp + oT, tau, nT);
     std::memcpy(hp + oI, index, nI);
     std::memcpy(hp + oB, basis, nB);
+    for (int k = 0; k < T; ++k) {
+        const unsigned char* rk = static_cast<const unsigned char*>(pulses[k]->dev.ptr) + pulses[k]->L.R;
+        std::memcpy(hp + oX + 8*size_t(k), &rk, 8);
+    }
+    (void)nR1;
     void* base;
-    int rc = arena_reserve(stage + align_up(nP) + align_up(nR1*T) +
+    int rc = arena_reserve(stage + align_up(nP) +
                            sequence_scratch_bytes(G, d, A, N, W, which, hermitian_basis != 0,
                                                   filter_function != nullptr), &base);
     if (rc) { g_pin_pool.give(pin); return rc; }
     Bump a(base, g_arena.size);
     unsigned char* dS = a.take<unsigned char>(stage);
     double* dP = a.take<double>(nP/8);
-    double* dR = a.take<double>(nR1*T/8);
     // a result handle takes the layout of a one-segment pass: R, F and the grid in its device block,
     // (identity, total propagator) where the propagators of a pass sit in its host block
     ResidentLayout RL = {};
@@ -2426,24 +2448,17 @@ int ffk_concatenate_sequence_resident(ffk_resident* const* pulses, const double*
     }
     auto run = [&]() -> int {
         FFK_HIP(hipMemcpyAsync(dS, hp, stage, hipMemcpyHostToDevice, s));
-        if (result)
-            FFK_HIP(hipMemcpyAsync(static_cast<unsigned char*>(result->dev.ptr) + RL.omega,
-                                   static_cast<const unsigned char*>(first->dev.ptr) + first->L.omega,
-                                   8*size_t(W), hipMemcpyDeviceToDevice, s));
-        for (int k = 0; k < T; ++k)
-            FFK_HIP(hipMemcpyAsync(reinterpret_cast<unsigned char*>(dR) + nR1*k,
-                                   static_cast<const unsigned char*>(pulses[k]->dev.ptr) + pulses[k]->L.R,
-                                   nR1, hipMemcpyDeviceToDevice, s));
         const double* dOmega = reinterpret_cast<const double*>(
             static_cast<const unsigned char*>(first->dev.ptr) + first->L.omega);
-        hipLaunchKernelGGL(total_phases_kernel, dim3((W + 255)/256, T), dim3(256), 0, s, dOmega,
-                           reinterpret_cast<const double*>(dS + oT), T, W, reinterpret_cast<cplx*>(dP));
-        FFK_HIP(hipGetLastError());
-        if (int rc2 = sequence_on_device(reinterpret_cast<const double*>(dS + oU), dP, dR,
+        double* omega_copy = result ? reinterpret_cast<double*>(static_cast<unsigned char*>(result->dev.ptr) + RL.omega)
+                                    : nullptr;
+        if (int rc2 = sequence_on_device(reinterpret_cast<const double*>(dS + oU), dP, nullptr,
                                          reinterpret_cast<const int32_t*>(dS + oI),
                                          reinterpret_cast<const double*>(dS + oB), hermitian_basis, T, G, d,
                                          A, N, W, which, a, control_matrix, total_propagator,
-                                         propagators_liouville, filter_function, s, keep_R, keep_F))
+                                         propagators_liouville, filter_function, s, keep_R, keep_F,
+                                         reinterpret_cast<const cplx* const*>(dS + oX),
+                                         reinterpret_cast<const double*>(dS + oT), dOmega, omega_copy))
             return rc2;
         FFK_HIP(hipStreamSynchronize(s));
         return FFK_OK;

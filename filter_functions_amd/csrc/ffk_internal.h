@@ -194,9 +194,23 @@ size_t from_atomic_workspace_bytes(int G, int A, int N, int W);
 // out: (A,N,W) for the sum, (G,A,N,W) for correlations != 0; L is (G-1,N,N) f64 or c128.
 // index == NULL: phases (G-1,W) cumulated, Ratomic (G,A,N,W).  index != NULL (G int32): phases
 // (T,W) total phase factors and Ratomic (T,A,N,W) tables over the distinct pulses.
+// Rtab (indexed form only, may be NULL): T device pointers to the distinct control matrices where
+// they lie, instead of the contiguous table Ratomic.  F (may be NULL; sum only): the fidelity filter
+// function (A,A,W) of the result -- for A N <= 16 formed by the slab-reduction launch itself.
 hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int32_t* index,
                               const double* L, int l_is_complex, int G, int A, int N, int W,
-                              int correlations, cplx* out, void* ws, hipStream_t stream);
+                              int correlations, cplx* out, void* ws, hipStream_t stream,
+                              const cplx* const* Rtab = nullptr, cplx* F = nullptr, int T = 0);
+// (T: number of distinct pulses of the indexed form; with it, few rows and tables that fit LDS the
+// rule, its slab reduction and F are ONE launch, from_atomic_block_kernel)
+// The front of a sequence concatenation in one launch (d <= 4, G <= 1024, N <= 16): Q (G+1,d,d)
+// running products of U[index[g]], L (G-1,N,N) their Liouville representations, phases (T,W) =
+// exp(i omega tau_k), and optionally a copy of omega.
+bool sequence_front_supported(int d, int G, int N);
+hipError_t launch_sequence_front(const cplx* U, const int32_t* index, int G, int d, const cplx* basis,
+                                 int N, int l_is_complex, cplx* Q, double* L, const double* tau,
+                                 const double* omega, int T, int W, cplx* phases, double* omega_copy,
+                                 hipStream_t stream);
 
 // ---- decay.hip -------------------------------------------------------------------------------
 // Gamma (Gp,Gp,n_idx[,n_idx],N,N) f64 from R (Gp,A,N,W) c128 (Gp = 1: the total control matrix),

@@ -573,9 +573,18 @@ class PulseSequence:
         """Remember (a copy of) the frequencies; a grid that differs from the remembered one
         invalidates everything that depends on frequency (reference pulse_sequence.py:1158-1169)."""
         known = self._frequency_data.get('omega')
-        if known is not None and (value is known or np.array_equal(known, value)):
+        if known is not None and _same_grid(known, value):
             return                           # the remembered copy is the same grid: keep it
-        grid = np.array(value, copy=True)
+        if (isinstance(value, np.ndarray) and not value.flags.writeable and value.ndim == 1
+                and value.dtype == np.float64):
+            # an immutable grid -- in practice another pulse's remembered copy, handed on by
+            # concatenate / remap / extend -- is shared, not copied again: the pulses of a long
+            # sequence then hold ONE grid object and comparing their grids is an identity test
+            grid = value
+        else:
+            grid = np.array(value, dtype=None, copy=True)
+            if grid.dtype == np.float64 and grid.ndim == 1:
+                grid.flags.writeable = False
         self.cleanup('frequency dependent')
         self._frequency_data['omega'] = grid
 
@@ -612,6 +621,11 @@ class PulseSequence:
 # identifiers and coefficient tables; the arithmetic -- atomic control matrices, Liouville
 # propagators, the concatenation rule and the filter functions -- runs in libffk.
 # --------------------------------------------------------------------------------------------
+def _same_grid(a, b):
+    """Two frequency grids are the same object or hold the same values."""
+    return a is b or np.array_equal(a, b)
+
+
 def _merge_constant_segments(pulse):
     """(c_coeffs, n_coeffs, dt) with runs of segments whose control amplitudes do not change
     merged into one (their durations added), so that equality does not depend on how a constant
@@ -653,12 +667,24 @@ def _all_bases_equal(pulses):
 def _distinct_objects(objects):
     """Positions -> distinct objects (by identity, in order of first appearance): returns (distinct,
     first position of each, index) with objects[p] is distinct[index[p]]."""
-    slot = {}
-    index = np.fromiter((slot.setdefault(id(obj), len(slot)) for obj in objects), dtype=np.int32,
-                        count=len(objects))
-    first = np.full(len(slot), -1, dtype=np.intp)
-    first[index[::-1]] = np.arange(len(objects) - 1, -1, -1)      # the earliest position wins
-    return [objects[p] for p in first], first, index
+    # (no Python-level loop over the positions: a 1000-gate sequence is the common case)
+    ids = np.fromiter(map(id, objects), dtype=np.int64, count=len(objects))
+    _, first, inverse = np.unique(ids, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind='stable')                      # distinct objects by first appearance
+    rank = np.empty(len(order), dtype=np.int32)
+    rank[order] = np.arange(len(order), dtype=np.int32)
+    first = first[order].astype(np.intp)
+    return [objects[p] for p in first], first, rank[inverse.reshape(-1)]
+
+
+def _ragged_columns(lengths, index):
+    """Column numbers that gather, from the blocks of the distinct entries laid side by side
+    (entry k occupying ``lengths[k]`` columns), the blocks of the entries ``index`` in sequence."""
+    lengths = np.asarray(lengths, dtype=np.intp)
+    offsets = np.cumsum(lengths) - lengths
+    lens = lengths[index]
+    starts = np.cumsum(lens) - lens
+    return np.repeat(offsets[index] - starts, lens) + np.arange(int(lens.sum()), dtype=np.intp)
 
 
 def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index=None):
@@ -712,8 +738,9 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index
         # equal segment counts: one gather (positions, operators, segments) -> (operators, all segments)
         table = np.stack(blocks)[index].transpose(1, 0, 2).reshape(len(ordered), -1)
     else:
-        table = np.concatenate([blocks[k] for k in index], axis=1)
-    mapping = dict(zip(range(len(index)), map(maps.__getitem__, index)))
+        # ragged: the distinct blocks side by side, then one gather of columns
+        table = np.concatenate(blocks, axis=1)[:, _ragged_columns([b.shape[1] for b in blocks], index)]
+    mapping = _PositionMap(maps, index)
     missing = np.isnan(table)
     if kind == 'noise':
         for r in np.nonzero(missing.any(axis=1))[0]:
@@ -725,6 +752,39 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index
     elif missing.any():
         table[missing] = 0
     return concat_opers, concat_identifiers, table, mapping
+
+
+class _PositionMap:
+    """position -> identifier map of the pulse standing there, without materialising one dict
+    entry per position (read like the dict the reference returns: ``mapping[p]``, ``len``,
+    iteration over the positions, ``items()``)."""
+
+    def __init__(self, maps, index):
+        self._maps, self._index = maps, index
+
+    def __getitem__(self, position):
+        return self._maps[self._index[position]]
+
+    def __len__(self):
+        return len(self._index)
+
+    def __iter__(self):
+        return iter(range(len(self._index)))
+
+    def keys(self):
+        return range(len(self._index))
+
+    def values(self):
+        return [self._maps[k] for k in self._index]
+
+    def items(self):
+        return [(p, self._maps[k]) for p, k in enumerate(self._index)]
+
+    def __eq__(self, other):
+        return dict(self.items()) == (dict(other.items()) if hasattr(other, 'items') else other)
+
+    def __repr__(self):
+        return repr(dict(self.items()))
 
 
 def _validated_sequence(pulses):
@@ -757,7 +817,7 @@ def _concatenate_distinct(pulses, distinct, first, index):
     if (lengths == lengths[0]).all():
         dt = np.stack([p.dt for p in distinct])[index].reshape(-1)
     else:
-        dt = np.concatenate([distinct[k].dt for k in index])
+        dt = np.concatenate([p.dt for p in distinct])[_ragged_columns(lengths, index)]
     newpulse = PulseSequence.from_arrays(c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt,
                                          distinct[0].basis)
     # (summed position by position like the reference's sum over the pulses)
@@ -836,7 +896,7 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
         cached_w = [pls.is_cached('omega') for pls in distinct]
         candidates = [pls.omega for pls, c in zip(distinct, cached_R if any(cached_R) else cached_w)
                       if c]
-        equal_omega = all(np.array_equal(candidates[0], w) for w in candidates[1:])
+        equal_omega = all(_same_grid(candidates[0], w) for w in candidates[1:])
         if not equal_omega or not candidates:
             if calc_filter_function:
                 raise ValueError('Calculation of filter function forced but not all pulses '
@@ -896,7 +956,7 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
         wanted = dict(which=mode, return_liouville=bool(calc_second_order_FF), return_filter_function=with_F)
         residents = [pls._resident for pls in distinct]
         if (all(res is not None and res.shape is not None and res.shape[1:] == residents[0].shape[1:]
-                and np.array_equal(pls.omega, omega) for res, pls in zip(residents, distinct))
+                and _same_grid(pls.omega, omega) for res, pls in zip(residents, distinct))
                 and all(own_rows(i) == list(range(len(new_ids))) for i in first_position)):
             # every distinct pulse still has its control matrix in HBM (evaluated by the resident
             # pass on this grid): the table is assembled there, nothing but index, basis and the
@@ -1122,7 +1182,7 @@ def extend(pulse_to_qubit_mapping, N=None, d_per_qubit=2, additional_noise_Hamil
     if cache_filter_function is not False:
         # the grid the pulses agree on, if they do
         grids = [pulse._frequency_data.get('omega') for pulse in pulses]
-        common = grids[0] if all(g is not None and np.array_equal(g, grids[0]) for g in grids) \
+        common = grids[0] if all(g is not None and _same_grid(g, grids[0]) for g in grids) \
             else None
         if cache_filter_function is None:
             # by default the filter function is carried over exactly when every pulse brings one
