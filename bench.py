@@ -339,18 +339,57 @@ def bench_config3(ff):
         numeric.calculate_control_matrix_from_atomic_indexed(phases, table, draw.astype(np.int32), L)
         rule.append(time.perf_counter() - t0)
     E = cfg['n_gates']*cfg['W']*1*4
-    # HBM model of the rule: the 24 control-matrix tables stay cache resident, R is written once
+    # the device call alone (ffk_concatenate_sequence_resident: one H2D of index/basis/durations,
+    # front launch, rule launch, F and the total propagator back), result left resident
+    from filter_functions_amd import pulse_sequence as ps
+    from filter_functions_amd._resident import ResidentResult
+    _, distinct, _, index = ps._validated_sequence(seq)
+    residents, taus = [p._resident for p in distinct], [p.tau for p in distinct]
+    dev = []
+    for _ in range(8):
+        keep = ResidentResult()
+        t0 = time.perf_counter()
+        numeric.concatenate_sequence_resident(residents, taus, index, distinct[0].basis, which='total',
+                                              return_filter_function=True, keep=keep)
+        dev.append(time.perf_counter() - t0)
+    # executed work of the rule kernel (from_atomic_block_kernel<1,4>): per position and frequency
+    # 4 complex products with the running phase (24 flop), a real 4 x 4 matrix on 4 complex numbers
+    # (64), the phase update (6) and the accumulation (8); bytes: the 24 control-matrix and phase
+    # tables once per 64 frequencies (LDS-staged), R and F out
+    G, W, T = cfg['n_gates'], cfg['W'], len(distinct)
+    rule_flops = 102.0*G*W
+    rule_bytes = 16.0*W*(T*5 + 4 + 1)
+    kernel_ms, kernel_src = None, None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r03_f_config3_kernel_stats.txt')) as fh:
+            for line in fh:
+                if line.startswith('from_atomic_block_kernel'):
+                    kernel_ms = float(line.split('avg_us=')[1].split()[0])*1e-3
+                    kernel_src = ('committed rocprofv3 --kernel-trace --stats summary of tools/time_config3.py '
+                                  '(profiles/r03_f_config3_kernel_stats.txt); not measured in this run')
+    except (OSError, ValueError, IndexError):
+        pass
+    roof = None
+    if kernel_ms:
+        t_fp64 = rule_flops/(FP64_PEAK_TFLOPS*1e12)*1e3
+        t_hbm = rule_bytes/(HBM_PEAK_GBS*1e9)*1e3
+        roof = dict(bound='fp64_valu', executed_flops=rule_flops, algorithmic_bytes=rule_bytes,
+                    bound_ms=max(t_fp64, t_hbm), frac=max(t_fp64, t_hbm)/kernel_ms,
+                    note='a latency-bound launch: 128 blocks of 16 wavefronts, each a chain of 62 dependent '
+                         'positions after staging 120 KiB of tables; see DESIGN.md')
     return dict(
+        device_call_ms=min(dev)*1e3, kernel_ms=kernel_ms, kernel_ms_source=kernel_src, roofline=roof,
         config=3, workload='1000-gate randomized-benchmarking sequence (24 Cliffords from X/2, Y/2), '
                            'd=2, 1 noise op, 8192 omega, ff.concatenate + get_filter_function on host '
                            'arrays',
         ms=min(times)*1e3, elements_per_s=E/min(times),
-        dominant_kernel='ffk::from_atomic_kernel (gather-from-table concatenation rule)',
+        dominant_kernel='ffk::from_atomic_block_kernel<1,4> (table rule + reduction + F, LDS-staged tables)',
         rule_call_ms=min(rule)*1e3,
         note='ms = whole Python call incl. host bookkeeping over 1000 pulse objects; the 24 Cliffords '
-             'keep their control matrices resident in HBM, the rule with cumulative propagators, Liouville '
-             'representations and F is one device call (ffk_concatenate_sequence_resident); rule_call_ms = '
-             'the indexed concatenation rule alone on host arrays (tables H2D + kernel + R D2H)')
+             'keep their control matrices resident in HBM and are read in place; device_call_ms = '
+             'ffk_concatenate_sequence_resident alone (two launches: front = gather + running products + '
+             'Liouville representations + total phases, rule = table rule + slab reduction + F); '
+             'rule_call_ms = the indexed concatenation rule alone on host arrays (tables H2D + kernel + R D2H)')
 
 
 def bench_published_example(ff):

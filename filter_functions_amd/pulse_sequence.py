@@ -737,8 +737,12 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index
     if len({block.shape[1] for block in blocks}) == 1:
         # equal segment counts: one gather (positions, operators, segments) -> (operators, all segments)
         table = np.stack(blocks)[index].transpose(1, 0, 2).reshape(len(ordered), -1)
+    elif len(index) <= 4*len(blocks):
+        # few positions (possibly long pulses): plain block copies
+        table = np.concatenate([blocks[k] for k in index], axis=1)
     else:
-        # ragged: the distinct blocks side by side, then one gather of columns
+        # many positions drawn from few pulses, ragged: the distinct blocks side by side, then one
+        # gather of columns (no Python-level loop over the positions)
         table = np.concatenate(blocks, axis=1)[:, _ragged_columns([b.shape[1] for b in blocks], index)]
     mapping = _PositionMap(maps, index)
     missing = np.isnan(table)
@@ -816,6 +820,8 @@ def _concatenate_distinct(pulses, distinct, first, index):
     lengths = np.array([len(p.dt) for p in distinct])
     if (lengths == lengths[0]).all():
         dt = np.stack([p.dt for p in distinct])[index].reshape(-1)
+    elif len(index) <= 4*len(distinct):
+        dt = np.concatenate([distinct[k].dt for k in index])
     else:
         dt = np.concatenate([p.dt for p in distinct])[_ragged_columns(lengths, index)]
     newpulse = PulseSequence.from_arrays(c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt,
