@@ -17,6 +17,31 @@
 #include "ffk.h"
 #include "ffk_internal.h"
 
+#if defined(FFK_HOST_SANITIZE)
+// Host-side sanitizer variant (make VARIANT=asan ...; tools/build_asan.sh): the allocation calls of
+// the arena and of the block pools go to the C heap, so that their bookkeeping -- growth, reuse,
+// eviction, the slicing of every workspace layout -- can run under AddressSanitizer / UBSan on a
+// machine without a GPU (ffk_selftest_host below).  Never part of the shipped library.
+#include <cstdlib>
+namespace {
+hipError_t stub_alloc(void** p, size_t n) {
+    *p = std::malloc(n ? n : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t stub_free(void* p) {
+    std::free(p);
+    return hipSuccess;
+}
+}  // namespace
+#define hipMalloc(p, n) stub_alloc(reinterpret_cast<void**>(p), (n))
+#define hipHostMalloc(p, n, flags) stub_alloc(reinterpret_cast<void**>(p), (n))
+#define hipFree(p) stub_free(p)
+#define hipHostFree(p) stub_free(p)
+#define hipGetDevice(d) ((*(d) = 0), hipSuccess)
+#define hipSetDevice(d) hipSuccess
+#define hipDeviceSynchronize() hipSuccess
+#endif
+
 using ffk::align_up;
 using ffk::cplx;
 
@@ -2558,3 +2583,160 @@ int ffk_resident_infidelity(ffk_resident* r, const double* spectrum, int s_ndim,
 }
 
 }  // extern "C"
+
+#if defined(FFK_HOST_SANITIZE)
+// ---------------------------------------------------------------------------------------------
+// Host-logic self test for the sanitizer variant: arena growth, block-pool reuse and eviction, every
+// workspace layout sliced with the size its *_workspace_bytes query reports and each slice written
+// end to end (an overrun of a slice or of the reservation is a heap-buffer-overflow under ASan).
+// ---------------------------------------------------------------------------------------------
+#include <cstring>
+#include <random>
+extern "C" int ffk_selftest_host(int rounds, unsigned seed, char* report, int report_len) {
+    if (rounds < 0) {
+        // negative control: a deliberate one-byte overrun, which the sanitizer must report
+        volatile unsigned char* p = static_cast<unsigned char*>(std::malloc(16));
+        p[16] = 1;
+        std::free(const_cast<unsigned char*>(p));
+        return 0;
+    }
+    std::mt19937 rng(seed);
+    auto pick = [&](int lo, int hi) { return lo + static_cast<int>(rng() % static_cast<unsigned>(hi - lo + 1)); };
+    long checked = 0;
+    auto touch = [&](void* p, size_t n) {
+        if (p && n) {
+            std::memset(p, 0xA5, n);
+            ++checked;
+        }
+    };
+    for (int r = 0; r < rounds; ++r) {
+        const int d = pick(2, FFK_MAX_D), G = pick(1, 300), A = pick(1, 9), W = pick(1, 700);
+        const int N = pick(1, d*d);
+        // (a) arena: reserve, write all of it, grow, shrink requests
+        void* base = nullptr;
+        const size_t want = size_t(pick(1, 1 << 20))*pick(1, 8);
+        {
+            std::lock_guard<std::mutex> lock(g_arena.mu);
+            if (arena_reserve(want, &base) != FFK_OK) return -1;
+            touch(base, g_arena.size);
+        }
+        // (b) control-matrix workspace: the slices of ffk_control_matrix_dev
+        {
+            const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, 0);
+            const size_t bytes = ffk_control_matrix_workspace_bytes(W, N, A, G, d);
+            if (bytes < ctrl_ws_bytes(W, N, A, G, d, geo.chunks)) return -2;
+            void* ws = std::malloc(bytes);
+            Bump b(ws, bytes);
+            double* segtab = b.take<double>(size_t(G)*ffk::seg_stride(d));
+            cplx* Tc = b.take<cplx>(size_t(G)*d*d);
+            cplx* ops = b.take<cplx>(size_t(G)*(1 + A)*d*d);
+            cplx* Ypart = b.take<cplx>(size_t(geo.chunks)*A*d*d*W);
+            cplx* Bt = b.take<cplx>(size_t(A)*d*d*W);
+            void* ews = b.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
+            if (!segtab || !Tc || !ops || !Ypart || !Bt || !ews) { std::free(ws); return -3; }
+            touch(segtab, sizeof(double)*size_t(G)*ffk::seg_stride(d));
+            touch(Tc, sizeof(cplx)*size_t(G)*d*d);
+            touch(ops, sizeof(cplx)*size_t(G)*(1 + A)*d*d);
+            touch(Ypart, sizeof(cplx)*size_t(geo.chunks)*A*d*d*W);
+            touch(Bt, sizeof(cplx)*size_t(A)*d*d*W);
+            touch(ews, ffk::expand_workspace_bytes(N, d));
+            int *nnz, *rows;
+            cplx* vals;
+            ffk::expand_workspace_slices(ews, N, d, &nnz, &rows, &vals);
+            touch(nnz, sizeof(int)*N);
+            touch(rows, sizeof(int)*size_t(N)*d*d);
+            touch(vals, sizeof(cplx)*size_t(N)*d*d);
+            std::free(ws);
+        }
+        // (c) diagonalize + pipeline workspaces
+        {
+            const size_t dwsb = ffk_diagonalize_workspace_bytes(G, d);
+            void* ws = std::malloc(dwsb);
+            const DiagWs w = slice_diag_ws(ws, dwsb, G, d);
+            touch(w.status, sizeof(int)*G);
+            touch(w.seg_prop, sizeof(cplx)*size_t(G)*d*d);
+            touch(w.qloc, sizeof(cplx)*size_t(G + 1)*d*d);
+            std::free(ws);
+            const int n_idx = pick(1, A), s_ndim = pick(1, 3);
+            const size_t pb = ffk_pipeline_workspace_bytes(W, N, A, G, d, n_idx, s_ndim);
+            if (pb < dwsb + ffk_control_matrix_workspace_bytes(W, N, A, G, d)) return -4;
+            void* pws = std::malloc(pb);
+            Bump b(pws, pb);
+            void* a1 = b.take<unsigned char>(dwsb);
+            void* a2 = b.take<unsigned char>(ffk_control_matrix_workspace_bytes(W, N, A, G, d));
+            double* D = b.take<double>(size_t(G)*d);
+            double* V = b.take<double>(2*size_t(G)*d*d);
+            double* Q = b.take<double>(2*size_t(G + 1)*d*d);
+            double* R = b.take<double>(2*size_t(A)*N*W);
+            double* F = b.take<double>(2*size_t(A)*A*W);
+            void* iws = b.take<unsigned char>(ffk_infidelity_workspace_bytes(W, n_idx, s_ndim));
+            if (!a1 || !a2 || !D || !V || !Q || !R || !F || !iws) { std::free(pws); return -5; }
+            touch(F, 16*size_t(A)*A*W);
+            touch(iws, ffk_infidelity_workspace_bytes(W, n_idx, s_ndim));
+            std::free(pws);
+        }
+        // (d) sequence scratch of the concatenation entry points
+        {
+            const int T = pick(1, 30), Gs = pick(1, 1200), which = pick(0, 1);
+            const bool herm = pick(0, 1) != 0, wantF = which == 0 && pick(0, 1);
+            const int d2 = pick(2, 4), N2 = d2*d2, A2 = pick(1, 3), W2 = pick(1, 300);
+            (void)T;
+            const size_t sb = sequence_scratch_bytes(Gs, d2, A2, N2, W2, which, herm, wantF);
+            void* ws = std::malloc(sb);
+            Bump a(ws, sb);
+            const size_t dd = size_t(d2)*d2;
+            const int nl = Gs > 1 ? Gs - 1 : 1;
+            cplx* dSeq = a.take<cplx>(size_t(Gs)*dd);
+            cplx* dQ = a.take<cplx>(size_t(Gs + 1)*dd);
+            double* dL = a.take<double>((herm ? 1 : 2)*size_t(nl)*N2*N2);
+            double* dO = a.take<double>(2*(which ? size_t(Gs) : 1)*A2*N2*W2);
+            void* w1 = a.take<unsigned char>(ffk::scan_workspace_bytes(Gs, d2));
+            void* w2 = a.take<unsigned char>(ffk::liouville_workspace_bytes(nl, d2, N2));
+            void* w3 = a.take<unsigned char>(ffk_control_matrix_from_atomic_workspace_bytes(Gs, A2, N2, W2));
+            double* dF = wantF ? a.take<double>(2*size_t(A2)*A2*W2) : nullptr;
+            if (!dSeq || !dQ || !dL || !dO || !w1 || !w2 || !w3 || (wantF && !dF)) { std::free(ws); return -6; }
+            touch(dSeq, 16*size_t(Gs)*dd);
+            touch(dQ, 16*size_t(Gs + 1)*dd);
+            touch(dL, (herm ? 8 : 16)*size_t(nl)*N2*N2);
+            touch(dO, 16*(which ? size_t(Gs) : 1)*A2*N2*W2);
+            touch(w3, ffk_control_matrix_from_atomic_workspace_bytes(Gs, A2, N2, W2));
+            if (dF) touch(dF, 16*size_t(A2)*A2*W2);
+            std::free(ws);
+        }
+        // (e) block pools: take / write / give in random order, past the eviction bound
+        {
+            std::vector<Block> held;
+            for (int k = 0; k < 40; ++k) {
+                if (held.empty() || pick(0, 2)) {
+                    Block b = {nullptr, 0, -1};
+                    BlockPool& pool = pick(0, 1) ? g_dev_pool : g_pin_pool;
+                    const size_t bytes = size_t(pick(1, 1 << 18));
+                    if (pool.take(bytes, 0, &b) != FFK_OK || b.size < bytes) return -7;
+                    touch(b.ptr, b.size);
+                    b.device = (&pool == &g_dev_pool) ? 0 : -1;
+                    held.push_back(b);
+                } else {
+                    const int i = pick(0, int(held.size()) - 1);
+                    (held[i].device == 0 ? g_dev_pool : g_pin_pool).give(held[i]);
+                    held.erase(held.begin() + i);
+                }
+            }
+            for (const Block& b : held) (b.device == 0 ? g_dev_pool : g_pin_pool).give(b);
+        }
+        // (f) resident layout: offsets ascending, inside the block
+        {
+            const ResidentLayout RL = resident_layout(G, d, W, N, A);
+            if (!(RL.inputs_end <= RL.D && RL.outputs_end <= RL.R && RL.R < RL.end && RL.F + 16*size_t(A)*A*W <= RL.end))
+                return -8;
+            ffk_resident* h = nullptr;
+            if (ffk_resident_create(&h) != FFK_OK) return -9;
+            if (ffk_resident_destroy(h) != FFK_OK) return -10;
+        }
+    }
+    if (g_dev_pool.release() != FFK_OK || g_pin_pool.release() != FFK_OK) return -11;
+    if (ffk_release_arena() != FFK_OK) return -12;
+    if (report && report_len > 0)
+        snprintf(report, report_len, "%d rounds, %ld regions written end to end, pools and arena released", rounds, checked);
+    return 0;
+}
+#endif
