@@ -136,6 +136,10 @@ class ResidentResult:
         V = _view(out[1].value, 2*G*d*d, np.complex128, (G, d, d), self)
         Q = _view(out[2].value, 2*(G + 1)*d*d, np.complex128, (G + 1, d, d), self)
         F = _view(out[3].value, 2*A*A*W, np.complex128, (A, A, W), self)
+        # F is integrated on the DEVICE copy when infidelity() is handed this very array: it must not
+        # be edited in place behind the device's back (an edit raises instead of being ignored;
+        # `F.copy()` is an ordinary writable array that takes the array route)
+        F.flags.writeable = False
         self._filter_function = weakref.ref(F)
         return D, V, Q, F
 

@@ -87,6 +87,15 @@ constexpr unsigned FFK_INTERNAL_COMPACT_DONE = 0x40000000u;
 thread_local cplx* g_fuse_F = nullptr;
 thread_local bool g_fuse_F_done = false;
 
+// Scratch from the shared arena is handed to kernels on a non-blocking stream while g_arena.mu is
+// held; the lock may only be dropped once that stream has drained -- on EVERY exit path, also the
+// early error returns after the first enqueue: the next holder may reuse or reallocate
+// the arena.  Declared after the lock_guard, so it runs before the lock is released.
+struct StreamDrain {
+    hipStream_t stream;
+    ~StreamDrain() { (void)hipStreamSynchronize(stream); }
+};
+
 // bump allocator over a caller- or arena-provided workspace
 struct Bump {
     unsigned char* base;
@@ -2289,6 +2298,7 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
     const size_t hsb = on_device ? align_up(16*size_t(G)*dd) : 0;
     void* ws;
     if (int rc = arena_reserve(wsb + hsb, &ws)) return rc;
+    StreamDrain drain{s};      // (the successful path has synchronised already: a no-op then)
     const auto clock1 = std::chrono::steady_clock::now();
     auto dptr = [dp](size_t off) { return reinterpret_cast<double*>(dp + off); };
     const double* Hdev = dptr(L.H);
@@ -2472,6 +2482,7 @@ int ffk_concatenate_sequence_resident(ffk_resident* const* pulses, const double*
         keep_F = reinterpret_cast<double*>(rp + RL.F);
     }
     auto run = [&]() -> int {
+        StreamDrain drain{s};
         FFK_HIP(hipMemcpyAsync(dS, hp, stage, hipMemcpyHostToDevice, s));
         const double* dOmega = reinterpret_cast<const double*>(
             static_cast<const unsigned char*>(first->dev.ptr) + first->L.omega);
