@@ -52,6 +52,19 @@ __global__ __launch_bounds__(256) void spectral_weights_kernel(const cplx* __res
     if (complex_weights && any_imag) atomicOr(complex_weights, 1);
 }
 
+// XCD-aware block order.  Workgroups are dealt round robin over the 8 XCDs (block b and b + 8 share an
+// L2); the tiles of one (operator pair, frequency chunk) read the same row strips of R, so they should
+// meet in ONE L2.  Linear block id L -> virtual id v = (L mod 8) * (total / 8) + L / 8: the blocks of
+// one XCD work through consecutive virtual ids, i.e. through the tiles of the same strips, at about
+// the same time.  (Placement is a speed matter only; any bijection is correct.)
+__device__ __forceinline__ void xcd_block(unsigned& bx, unsigned& by) {
+    const unsigned total = gridDim.x*gridDim.y, per = total/8;
+    const unsigned L = blockIdx.x + gridDim.x*blockIdx.y;
+    const unsigned v = L < 8*per ? (L % 8)*per + L/8 : L;
+    bx = v % gridDim.x;
+    by = v / gridDim.x;
+}
+
 // One wavefront: a (16 TM) x (16 TN) tile of one Gamma[g,h,a,b] over the block's frequency range.
 // MFMA operand maps: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // D[row = (lane>>4) + 4 r][col = lane&15] (cdna_hip_programming.md section 3).
@@ -64,8 +77,10 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
     const int lane = threadIdx.x;
     const int l15 = lane & 15, lk = lane >> 4;
     const int tiles = tiles_m*tiles_n;
-    const int tile = blockIdx.x % tiles;
-    int z = blockIdx.x / tiles;
+    unsigned bx, by;
+    xcd_block(bx, by);
+    const int tile = bx % tiles;
+    int z = bx / tiles;
     const int ti = tile / tiles_n, tj = tile % tiles_n;
     const int nb = s_ndim == 3 ? n_idx : 1;
     const int ib0 = z % nb;
@@ -78,7 +93,9 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
     // and above the diagonal are computed, the rest mirrored at the store.  (A complex spectrum of
     // one or two dimensions adds an antisymmetric part: no shortcut then.)
     const bool symmetric = s_ndim != 3 && g == h && *complex_weights == 0;
-    if (symmetric && ti > tj) return;
+    // (rectangular tiles, TN < TM: the mirror granule is the tile's ROW count, 16 TM)
+    const int tjg = (tj*TN)/TM;              // row-granule index of this tile's columns
+    if (symmetric && ti > tjg) return;
     const int srow = s_ndim == 1 ? 0 : (s_ndim == 2 ? ia : ia*n_idx + ib);
     const cplx* sp = scale + static_cast<size_t>(srow)*W;
     const cplx* Lp[TM];
@@ -99,7 +116,7 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = {0.0, 0.0, 0.0, 0.0};
 
-    const int wbeg = blockIdx.y*kchunk;
+    const int wbeg = by*kchunk;
     const int wend = min(W, wbeg + kchunk);
     for (int w0 = wbeg; w0 < wend; w0 += 16) {
         cplx a[TM][4], b[TN][4];
@@ -133,8 +150,7 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
                                                                        acc[tm][tn], 0, 0, 0);
         }
     }
-    double* o = out + static_cast<size_t>(blockIdx.y)*split_stride +
-                static_cast<size_t>(blockIdx.x / tiles)*N*N;
+    double* o = out + static_cast<size_t>(by)*split_stride + static_cast<size_t>(bx / tiles)*N*N;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
                 const int row = (ti*TM + tm)*16 + lk + 4*r;
                 if (row < N) {
                     o[static_cast<size_t>(row)*N + col] = acc[tm][tn][r];
-                    if (mirror_in_store && symmetric && ti < tj)
+                    if (mirror_in_store && symmetric && ti < tjg)
                         o[static_cast<size_t>(col)*N + row] = acc[tm][tn][r];
                 }
             }
@@ -164,8 +180,12 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
 // of preceding them (profiles/r02_*: 1.59 ms, matrix pipe ~36 % busy at config 5).
 // LDS image: [row][16 frequencies + 1 pad] complex -- rows 272 B apart, so the sixteen rows a
 // ds_read_b128 lane group touches fall on different banks.
+#ifndef FFK_DG_WAVES             /* wavefronts per SIMD the LDS-staged kernel is compiled for (blocks per CU) */
+#define FFK_DG_WAVES 1
+#endif
 constexpr int kDgRows = 128, kDgStep = 16, kDgStride = kDgStep + 1;
-__global__ __launch_bounds__(256) void decay_gemm_lds_kernel(
+template <bool M4>
+__global__ __launch_bounds__(256, FFK_DG_WAVES) void decay_gemm_lds_kernel(
     const cplx* __restrict__ R, int Gp, int A, int N, int W, const cplx* __restrict__ scale,
     int s_ndim, const int32_t* __restrict__ idx, int n_idx, int kchunk, int tiles,
     double* __restrict__ out, size_t split_stride, int mirror_in_store,
@@ -178,8 +198,10 @@ __global__ __launch_bounds__(256) void decay_gemm_lds_kernel(
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lk = lane >> 4;
     const int ntile = tiles*tiles;
-    const int tile = blockIdx.x % ntile;
-    int z = blockIdx.x / ntile;
+    unsigned bx, by;
+    xcd_block(bx, by);
+    const int tile = bx % ntile;
+    int z = bx / ntile;
     const int ti = tile / tiles, tj = tile % tiles;
     const int nb = s_ndim == 3 ? n_idx : 1;
     const int ib0 = z % nb;
@@ -194,34 +216,101 @@ __global__ __launch_bounds__(256) void decay_gemm_lds_kernel(
     const bool compute = !(symmetric && ti == tj && wm > wn);
     const int srow = s_ndim == 1 ? 0 : (s_ndim == 2 ? ia : ia*n_idx + ib);
     const cplx* sp = scale + static_cast<size_t>(srow)*W;
-    // staging: thread t copies 8 frequencies (half a step) of row t / 2 of both operands
-    const int srow_l = tid >> 1, shalf = tid & 1;
-    const cplx* La = R + ((static_cast<size_t>(g)*A + idx[ia])*N + min(N - 1, ti*kDgRows + srow_l))*W;
-    const cplx* Rb = R + ((static_cast<size_t>(h)*A + idx[ib])*N + min(N - 1, tj*kDgRows + srow_l))*W;
-    const int wbeg = blockIdx.y*kchunk;
+    // staging: element e = j 256 + tid (j = 0..7) of the 128 x 16 step image, row e / 16, frequency
+    // e % 16: the sixteen lanes of a row read 256 contiguous bytes (four rows, eight full 128-byte
+    // lines per wave instruction); a thread keeps ONE frequency column, hence one spectral weight
+    const int scol = tid & 15, srow0 = tid >> 4;           // rows srow0 + 16 j
+    const cplx* La[8];
+    const cplx* Rb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        La[j] = R + ((static_cast<size_t>(g)*A + idx[ia])*N + min(N - 1, ti*kDgRows + srow0 + 16*j))*W;
+        Rb[j] = R + ((static_cast<size_t>(h)*A + idx[ib])*N + min(N - 1, tj*kDgRows + srow0 + 16*j))*W;
+    }
+    const int wbeg = by*kchunk;
     const int wend = min(W, wbeg + kchunk);
     // fetch only LOADS (nothing here may wait for the data: the MFMAs of the current step are issued
     // between fetch and park); masking and the spectral weight are applied in park
-    cplx ra[8], rb[8], rs[8];
+    cplx ra[8], rb[8], rs;
     auto fetch = [&](int w0) {
+        const int wc = min(w0 + scol, wend - 1);
+        rs = sp[wc];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int wc = min(w0 + 8*shalf + c, wend - 1);
-            rs[c] = sp[wc];
-            ra[c] = La[wc];
-            rb[c] = Rb[wc];
+        for (int j = 0; j < 8; ++j) {
+            ra[j] = La[j][wc];
+            rb[j] = Rb[j][wc];
         }
     };
     auto park = [&](int buf, int w0) {
-        cplx* da = As + (static_cast<size_t>(buf)*kDgRows + srow_l)*kDgStride + 8*shalf;
-        cplx* db = Bs + (static_cast<size_t>(buf)*kDgRows + srow_l)*kDgStride + 8*shalf;
+        const bool ok = w0 + scol < wend;
+        cplx* da = As + (static_cast<size_t>(buf)*kDgRows + srow0)*kDgStride + scol;
+        cplx* db = Bs + (static_cast<size_t>(buf)*kDgRows + srow0)*kDgStride + scol;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const bool ok = w0 + 8*shalf + c < wend;
-            da[c] = ok ? ra[c] : cplx{0.0, 0.0};
-            db[c] = ok ? cmul(rs[c], rb[c]) : cplx{0.0, 0.0};
+        for (int j = 0; j < 8; ++j) {
+            da[16*j*kDgStride] = ok ? ra[j] : cplx{0.0, 0.0};
+            db[16*j*kDgStride] = ok ? cmul(rs, rb[j]) : cplx{0.0, 0.0};
         }
     };
+    if constexpr (M4) {
+        // The same block tile on v_mfma_f64_4x4x4_4b (4 rows x 16 columns per instruction, the A operand
+        // replicated over the four 4-column blocks): ONE wavefront per SIMD saturates this instruction
+        // (tools/mfma4_occupancy_probe.hip), which it does not for the 64-cycle 16x16x4 form (34 TFLOP/s
+        // at one wavefront per SIMD), and it holds its clock on random data (72.7 against ~60 TFLOP/s).
+        // acc4[rg][cg] is element (row 4 rg + q, column 16 cg + cl) of the wavefront's 64 x 64 quarter.
+        const int cl = lane & 15, q = lane >> 4, c4 = cl & 3;
+        double acc4[16][4];
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) acc4[rg][cg] = 0.0;
+        if (wbeg < wend) {
+            fetch(wbeg);
+            park(0, wbeg);
+        }
+        __syncthreads();
+        int buf4 = 0;
+        for (int w0 = wbeg; w0 < wend; w0 += kDgStep, buf4 ^= 1) {
+            const bool more = w0 + kDgStep < wend;
+            if (more) fetch(w0 + kDgStep);
+            if (compute) {
+                const cplx* ap = As + (static_cast<size_t>(buf4)*kDgRows + wm*64 + c4)*kDgStride + 4*q;
+                const cplx* bp = Bs + (static_cast<size_t>(buf4)*kDgRows + wn*64 + cl)*kDgStride + 4*q;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    cplx b[4];
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg) b[cg] = bp[cg*16*kDgStride + cc];
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const cplx a = ap[rg*4*kDgStride + cc];
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg)
+                            acc4[rg][cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.re, b[cg].re, acc4[rg][cg], 0, 0, 0);
+#pragma unroll
+                        for (int cg = 0; cg < 4; ++cg)
+                            acc4[rg][cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.im, b[cg].im, acc4[rg][cg], 0, 0, 0);
+                    }
+                }
+            }
+            if (more) park(buf4 ^ 1, w0 + kDgStep);
+            __syncthreads();
+        }
+        if (!compute) return;
+        double* o4 = out + static_cast<size_t>(by)*split_stride + static_cast<size_t>(bx / ntile)*N*N;
+        const bool mirror4 = mirror_in_store && symmetric && (ti < tj || wm < wn);
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+                const int row = ti*kDgRows + wm*64 + 4*rg + q;
+                const int col = tj*kDgRows + wn*64 + 16*cg + cl;
+                if (row < N && col < N) {
+                    o4[static_cast<size_t>(row)*N + col] = acc4[rg][cg];
+                    if (mirror4) o4[static_cast<size_t>(col)*N + row] = acc4[rg][cg];
+                }
+            }
+        return;
+    }
     f64x4 acc[4][4];
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
@@ -264,8 +353,7 @@ __global__ __launch_bounds__(256) void decay_gemm_lds_kernel(
         __syncthreads();
     }
     if (!compute) return;
-    double* o = out + static_cast<size_t>(blockIdx.y)*split_stride +
-                static_cast<size_t>(blockIdx.x / ntile)*N*N;
+    double* o = out + static_cast<size_t>(by)*split_stride + static_cast<size_t>(bx / ntile)*N*N;
     const bool mirror = mirror_in_store && symmetric && (ti < tj || wm < wn);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm)
@@ -359,7 +447,18 @@ DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
     }
     const int t = N <= 16 ? 1 : (N < 128 ? 2 : 4);
     p.tm = p.tn = t;
-    p.tiles_m = p.tiles_n = (N + 16*t - 1)/(16*t);
+    // N >= 128: 64 x 64 tiles per wavefront (one wavefront per SIMD: 128 accumulator + 128 operand
+    // registers).  FFK_TUNE_DECAY_TN=2 selects 64 x 32 tiles (two wavefronts per SIMD): measured SLOWER at
+    // config 5, 2.44 against 1.68 ms -- both forms move ~3.65 TB/s of operands from L2 / Infinity Cache
+    // (6.0 GB resp. 9.0 GB per call): the product is bound by operand delivery, and the smaller tile
+    // re-reads more (profiles/r03_e_*)
+    static const int tn_big = [] {
+        const char* e = std::getenv("FFK_TUNE_DECAY_TN");
+        return e && e[0] == '2' ? 2 : 4;
+    }();
+    if (t == 4) p.tn = tn_big;
+    p.tiles_m = (N + 16*p.tm - 1)/(16*p.tm);
+    p.tiles_n = (N + 16*p.tn - 1)/(16*p.tn);
     p.batch = static_cast<size_t>(Gp)*Gp*n_idx*(s_ndim == 3 ? n_idx : 1);
     const size_t waves = p.batch*p.tiles_m*p.tiles_n;
     // enough wavefronts for 256 CUs x 8, at least 64 frequencies per split
@@ -368,6 +467,10 @@ DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
     p.kchunk = static_cast<int>(((W + want - 1)/want + 15)/16*16);
+    if (const char* e = std::getenv("FFK_TUNE_DECAY_KCHUNK")) {      // tuning
+        const int v = std::atoi(e);
+        if (v >= 64) p.kchunk = std::min((v + 15)/16*16, (W + 15)/16*16);
+    }
     p.ksplit = (W + p.kchunk - 1)/p.kchunk;
     return p;
 }
@@ -542,11 +645,16 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
     const int mirror = p.ksplit > 1 ? 0 : 1;    // with split-K the reduction fills the lower tiles
     const dim3 grid(static_cast<unsigned>(blocks), p.ksplit);
     if (p.lds) {
-        hipError_t aerr = hipFuncSetAttribute(reinterpret_cast<const void*>(decay_gemm_lds_kernel),
+        static const bool m4 = [] {              // FFK_TUNE_DECAY_M4=0: the 16x16x4 instruction
+            const char* e = std::getenv("FFK_TUNE_DECAY_M4");
+            return e == nullptr || e[0] != '0';
+        }();
+        auto kern = m4 ? decay_gemm_lds_kernel<true> : decay_gemm_lds_kernel<false>;
+        hipError_t aerr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(kDgLdsBytes));
         if (aerr != hipSuccess) return aerr;
-        hipLaunchKernelGGL(decay_gemm_lds_kernel, grid, dim3(256), kDgLdsBytes, stream, R, Gp, A, N, W,
+        hipLaunchKernelGGL(kern, grid, dim3(256), kDgLdsBytes, stream, R, Gp, A, N, W,
                            scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, dst, n, mirror,
                            complex_weights);
     } else if (p.tm == 1)
@@ -555,6 +663,10 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
                            complex_weights);
     else if (p.tm == 2)
         hipLaunchKernelGGL((decay_gemm_kernel<2, 2>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
+                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror,
+                           complex_weights);
+    else if (p.tn == 2)
+        hipLaunchKernelGGL((decay_gemm_kernel<4, 2>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
                            scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror,
                            complex_weights);
     else
