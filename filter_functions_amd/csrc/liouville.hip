@@ -80,6 +80,72 @@ __global__ __launch_bounds__(64) void conjugate_basis_kernel(const cplx* __restr
     }
 }
 
+// The same conjugation with COALESCED operand stores.  The GEMM wants its A operand K-major,
+// Aop[kk][i]: one basis element is a column, and conjugate_basis_kernel writes each of its 2 d^2
+// numbers to a line of its own (8 bytes per 2 KiB at d = 16: 4.3 GB of write transactions for 0.5 GB of
+// payload at batch 512 -- 862 us, more than the GEMM).  Here a 256-thread block conjugates EPB
+// consecutive elements with one unitary, one matrix entry per thread, parks the results in an LDS
+// tile [kk][EPB] (rows padded by one double: conflict free) and writes rows of EPB doubles -- 128
+// contiguous bytes per kk for EPB = 16.
+template <int D, int EPB>
+__global__ __launch_bounds__(256) void conjugate_basis_tile_kernel(const cplx* __restrict__ U,
+                                                                   const cplx* __restrict__ basis, int N,
+                                                                   int Npad, int want_imag,
+                                                                   double* __restrict__ AopRe,
+                                                                   double* __restrict__ AopIm) {
+    constexpr int DD = D*D, ROW = EPB + 1;
+    __shared__ cplx Us[DD];
+    __shared__ cplx Cs[DD];
+    __shared__ cplx CUs[DD];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double* tre = reinterpret_cast<double*>(lds_raw);                  // [2 DD][ROW]
+    double* tim = tre + 2*DD*ROW;                                      // [2 DD][ROW] (want_imag only)
+    const int bt = blockIdx.y, tid = threadIdx.x;
+    const int i0 = blockIdx.x*EPB;
+    for (int e = tid; e < DD; e += 256) Us[e] = U[static_cast<size_t>(bt)*DD + e];
+    for (int j = 0; j < EPB; ++j) {
+        const int i = i0 + j;
+        __syncthreads();                 // Us staged / previous element's Cs and CUs consumed
+        if (i < N)
+            for (int e = tid; e < DD; e += 256) Cs[e] = basis[static_cast<size_t>(i)*DD + e];
+        __syncthreads();
+        if (i < N)
+            for (int e = tid; e < DD; e += 256) {
+                const int r = e / D, c = e % D;
+                cplx acc = {0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < D; ++k) cmac(acc, Cs[r*D + k], Us[k*D + c]);
+                CUs[e] = acc;
+            }
+        __syncthreads();
+        for (int e = tid; e < DD; e += 256) {
+            cplx acc = {0.0, 0.0};
+            if (i < N) {
+                const int a = e / D, b = e % D;  // CB[a][b] = sum_k conj(U[k][a]) CU[k][b]
+#pragma unroll
+                for (int k = 0; k < D; ++k) cmac_conj(acc, Us[k*D + a], CUs[k*D + b]);
+            }
+            tre[e*ROW + j] = acc.re;
+            tre[(DD + e)*ROW + j] = -acc.im;
+            if (want_imag) {
+                tim[e*ROW + j] = acc.im;
+                tim[(DD + e)*ROW + j] = acc.re;
+            }
+        }
+    }
+    __syncthreads();
+    const size_t K = (2*DD + 3)/4*4;     // padded to the MFMA k-step; pad rows stay zero
+    double* are = AopRe + static_cast<size_t>(bt)*K*Npad;
+    double* aim = AopIm + static_cast<size_t>(bt)*K*Npad;
+    for (int idx = tid; idx < 2*DD*EPB; idx += 256) {
+        const int kk = idx / EPB, j = idx % EPB;
+        if (i0 + j < N) {
+            are[static_cast<size_t>(kk)*Npad + i0 + j] = tre[kk*ROW + j];
+            if (want_imag) aim[static_cast<size_t>(kk)*Npad + i0 + j] = tim[kk*ROW + j];
+        }
+    }
+}
+
 // One wavefront per (16 TM) x (16 TN) tile of L = Aop^T Bop.  v_mfma_f64_16x16x4_f64 operand maps
 // (cdna_hip_programming.md section 3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // D[row = (lane>>4) + 4 r][col = lane&15] for result register r = 0..3.  With one 16 x 16 tile per
@@ -87,12 +153,17 @@ __global__ __launch_bounds__(64) void conjugate_basis_kernel(const cplx* __restr
 // 34 % busy at d = 16 (profiles/r02_d_*).  TM x TN tiles per wavefront re-use each operand TN resp. TM
 // times from registers and keep TM*TN independent accumulators in flight (a dependent
 // v_mfma_f64_16x16x4 waits out the 16 passes of its predecessor).
-template <int TM, int TN>
-__global__ __launch_bounds__(64) void liouville_gemm_kernel(const double* __restrict__ AopRe,
+// IMAG is a template parameter: for Hermitian bases (the common case) the imaginary accumulators do
+// not exist, which halves the register count -- 4 x 4 tiles then fit 3 wavefronts per SIMD instead of
+// one, and a wavefront's operand fetches (straight from L2, nothing prefetched) are covered by the
+// others' matrix instructions.
+template <int TM, int TN, bool IMAG>
+__global__ __launch_bounds__(64, (TM == 4 && !IMAG) ? 3 : 1) void liouville_gemm_kernel(const double* __restrict__ AopRe,
                                                             const double* __restrict__ AopIm,
                                                             const double* __restrict__ Bop, int N,
-                                                            int Npad, int K, int want_imag,
+                                                            int Npad, int K,
                                                             double* __restrict__ out) {
+    constexpr bool want_imag = IMAG;
     const int lane = threadIdx.x;
     const int ti = blockIdx.x, tj = blockIdx.y, bt = blockIdx.z;
     const int l15 = lane & 15, lk = lane >> 4;
@@ -108,13 +179,13 @@ __global__ __launch_bounds__(64) void liouville_gemm_kernel(const double* __rest
     }
 #pragma unroll
     for (int n = 0; n < TN; ++n) bop[n] = Bop + min((tj*TN + n)*16 + l15, Npad - 1);
-    f64x4 cre[TM][TN], cim[TM][TN];
+    f64x4 cre[TM][TN], cim[IMAG ? TM : 1][IMAG ? TN : 1];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int n = 0; n < TN; ++n) {
             cre[m][n] = {0.0, 0.0, 0.0, 0.0};
-            cim[m][n] = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (IMAG) cim[m][n] = {0.0, 0.0, 0.0, 0.0};
         }
     for (int k0 = 0; k0 < K; k0 += 4) {
         const size_t row = static_cast<size_t>(k0 + lk)*Npad;
@@ -122,7 +193,7 @@ __global__ __launch_bounds__(64) void liouville_gemm_kernel(const double* __rest
 #pragma unroll
         for (int m = 0; m < TM; ++m) {
             a[m] = are[m][row];
-            if (want_imag) ai[m] = aim[m][row];
+            if constexpr (IMAG) ai[m] = aim[m][row];
         }
 #pragma unroll
         for (int n = 0; n < TN; ++n) b[n] = bop[n][row];
@@ -131,7 +202,7 @@ __global__ __launch_bounds__(64) void liouville_gemm_kernel(const double* __rest
 #pragma unroll
             for (int n = 0; n < TN; ++n)
                 cre[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], cre[m][n], 0, 0, 0);
-        if (want_imag) {
+        if constexpr (IMAG) {
 #pragma unroll
             for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -150,7 +221,7 @@ __global__ __launch_bounds__(64) void liouville_gemm_kernel(const double* __rest
                 const int rowi = (ti*TM + m)*16 + lk + 4*r;
                 if (rowi >= N) continue;
                 const size_t o = (static_cast<size_t>(bt)*N + rowi)*N + col;
-                if (want_imag) {
+                if constexpr (IMAG) {
                     out[2*o] = cre[m][n][r];
                     out[2*o + 1] = cim[m][n][r];
                 } else {
@@ -200,11 +271,20 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
         double* o = out + static_cast<size_t>(b0)*N*N*(want_imag ? 2 : 1);
         switch (d) {
 #define FFK_CASE(D)                                                                              \
-    case D:                                                                                      \
-        hipLaunchKernelGGL(conjugate_basis_kernel<D>,                                            \
-                           dim3((N + kConjPerBlock - 1)/kConjPerBlock, nb), dim3(64), 0, stream, Us, \
-                           basis, N, Npad, want_imag, are, aim);                                 \
-        break;
+    case D: {                                                                                    \
+        constexpr int EPB = 16;                                                                  \
+        const size_t lds = static_cast<size_t>(want_imag ? 2 : 1)*2*D*D*(EPB + 1)*sizeof(double); \
+        auto kern = conjugate_basis_tile_kernel<D, EPB>;                                         \
+        if (lds > 40*1024) {                                                                     \
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),             \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                                static_cast<int>(lds));                          \
+            if (e2 != hipSuccess) return e2;                                                     \
+        }                                                                                        \
+        hipLaunchKernelGGL(kern, dim3((N + EPB - 1)/EPB, nb), dim3(256), lds, stream, Us, basis, \
+                           N, Npad, want_imag, are, aim);                                        \
+        break;                                                                                   \
+    }
             FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
             FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
             FFK_CASE(15) FFK_CASE(16)
@@ -215,15 +295,19 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
         // tiles per wavefront by problem size: enough wavefronts to fill 1024 SIMDs first
         const long waves4 = static_cast<long>((tiles + 3)/4)*((tiles + 3)/4)*nb;
         const long waves2 = static_cast<long>((tiles + 1)/2)*((tiles + 1)/2)*nb;
+        auto launch = [&](auto kern, int t) {
+            hipLaunchKernelGGL(kern, dim3((tiles + t - 1)/t, (tiles + t - 1)/t, nb), dim3(64), 0, stream, are,
+                               aim, Bop, N, Npad, K, o);
+        };
         if (tiles >= 4 && waves4 >= 2048) {
-            hipLaunchKernelGGL((liouville_gemm_kernel<4, 4>), dim3((tiles + 3)/4, (tiles + 3)/4, nb),
-                               dim3(64), 0, stream, are, aim, Bop, N, Npad, K, want_imag, o);
+            if (want_imag) launch(liouville_gemm_kernel<4, 4, true>, 4);
+            else launch(liouville_gemm_kernel<4, 4, false>, 4);
         } else if (tiles >= 2 && waves2 >= 2048) {
-            hipLaunchKernelGGL((liouville_gemm_kernel<2, 2>), dim3((tiles + 1)/2, (tiles + 1)/2, nb),
-                               dim3(64), 0, stream, are, aim, Bop, N, Npad, K, want_imag, o);
+            if (want_imag) launch(liouville_gemm_kernel<2, 2, true>, 2);
+            else launch(liouville_gemm_kernel<2, 2, false>, 2);
         } else {
-            hipLaunchKernelGGL((liouville_gemm_kernel<1, 1>), dim3(tiles, tiles, nb), dim3(64), 0,
-                               stream, are, aim, Bop, N, Npad, K, want_imag, o);
+            if (want_imag) launch(liouville_gemm_kernel<1, 1, true>, 1);
+            else launch(liouville_gemm_kernel<1, 1, false>, 1);
         }
     }
     return hipGetLastError();
