@@ -447,16 +447,29 @@ hipError_t launch_c(const cplx* phases, const cplx* Ratomic, const int32_t* inde
 
 }  // namespace
 
-bool sequence_front_supported(int d, int G, int N) { return d >= 2 && d <= 4 && G >= 1 && G <= 1024 && N <= 16; }
+namespace {
+int front_threads(int G) {
+    int threads = 64;
+    while (threads < G) threads <<= 1;
+    return threads;
+}
+size_t front_lds_bytes(int G, int d, int N) {
+    return (2*static_cast<size_t>(front_threads(G)) + N)*d*d*sizeof(cplx);
+}
+}  // namespace
+
+// (the two scan buffers of block 0 must fit LDS: 1024 positions at d = 2, 512 at d = 3, 256 at d = 4)
+bool sequence_front_supported(int d, int G, int N) {
+    return d >= 2 && d <= 4 && G >= 1 && G <= 1024 && N <= 16 && front_lds_bytes(G, d, N) <= 144*1024;
+}
 
 hipError_t launch_sequence_front(const cplx* U, const int32_t* index, int G, int d, const cplx* basis,
                                  int N, int l_is_complex, cplx* Q, double* L, const double* tau,
                                  const double* omega, int T, int W, cplx* phases, double* omega_copy,
                                  hipStream_t stream) {
     if (!sequence_front_supported(d, G, N)) return hipErrorInvalidValue;
-    int threads = 64;
-    while (threads < G) threads <<= 1;
-    const size_t lds = (2*static_cast<size_t>(threads) + N)*d*d*sizeof(cplx);
+    const int threads = front_threads(G);
+    const size_t lds = front_lds_bytes(G, d, N);
     const unsigned blocks = 1 + static_cast<unsigned>((static_cast<size_t>(T)*W + threads - 1)/threads);
 #define FFK_FRONT(D)                                                                                   \
     case D: {                                                                                          \

@@ -2344,3 +2344,37 @@ def test_captured_pass_replays_bit_identically():
         outs.append(out.clone())
     assert all(torch.equal(o, outs[0]) for o in outs)           # (step 0 was enqueued call by call)
     assert rel_err(outs[0].cpu().numpy(), want[-1].cpu().numpy()) < TIGHT
+
+
+@pytest.mark.parametrize('d,n_positions', [(2, 1000), (2, 1025), (3, 600), (4, 300), (4, 200)])
+def test_long_resident_concatenations_around_the_one_launch_front(d, n_positions):
+    """The one-launch front of a sequence concatenation (sequence_front_kernel: scan over the
+    positions in LDS) holds two buffers of one matrix per position: 1024 positions at d = 2, 512 at
+    d = 3, 256 at d = 4; beyond that the call must fall back to the gather / scan / Liouville
+    launches (round 3: the fuzz sweep found the missing bound as a launch failure).  Either way the
+    result equals the route through host tables."""
+    import copy
+    rng = np.random.default_rng(100*d + n_positions)
+    basis = ff.Basis.ggm(d)
+
+    def herm(n):
+        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+        return M + M.conj().transpose(0, 2, 1)
+    c_opers, n_opers = herm(2), herm(2)
+    omega = np.geomspace(1e-2, 1e1, 130)
+    pulses = []
+    for k in range(3):
+        n_dt = int(rng.integers(1, 4))
+        pulses.append(ff.PulseSequence(
+            [[c_opers[i], rng.standard_normal(n_dt), f'c{i}'] for i in range(2)],
+            [[n_opers[a], np.full(n_dt, 1.0 + a), f'n{a}'] for a in range(2)],
+            0.01*rng.random(n_dt) + 0.001, basis))
+        pulses[-1].get_filter_function(omega)
+        assert pulses[-1]._resident is not None
+    index = rng.integers(0, 3, n_positions)
+    total = ff.concatenate([pulses[k] for k in index])
+    copies = [copy.deepcopy(p) for p in pulses]
+    via_host = ff.concatenate([copies[k] for k in index])
+    assert rel_err(total.get_filter_function(omega), via_host.get_filter_function(omega)) < 1e-11
+    assert rel_err(total.get_control_matrix(omega), via_host.get_control_matrix(omega)) < 1e-11
+    assert rel_err(total.total_propagator, via_host.total_propagator) < 1e-11
