@@ -149,6 +149,37 @@ def measure_hbm_traffic(omega_per_gpu):
                      f"WRITE_SIZE {means['WRITE_SIZE']:.0f} KiB")
 
 
+def probe_sharded_step_one_rank():
+    """Host cost of the frequency-sharded step on ONE rank (RCCL process group of size 1, test hook
+    FFK_FORCE_COLLECTIVE): tools/profile_ring_step.py in a child process with a timeout, once with the
+    whole step -- pass, all-gather, integral -- replayed from one hipGraph (FFK_GRAPH_COLLECTIVE=1) and
+    once with the exchange enqueued call by call (the default for N > 1).  Returns a dict for the
+    JSON line; a failure or timeout of the child is reported, never raised."""
+    import re
+    import socket
+    import subprocess
+    script = os.path.join(ROOT, 'tools', 'profile_ring_step.py')
+    out = {}
+    for label, graph_collective in (('graph_incl_collective', '1'), ('pass_graph_exchange_call_by_call', '')):
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, FFK_FORCE_COLLECTIVE='1', FFK_GRAPH_COLLECTIVE=graph_collective, RANK='0',
+                   WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        try:
+            res = subprocess.run([sys.executable, script, 'rccl', '2', '8', 'x'], env=env, capture_output=True,
+                                 text=True, timeout=120)
+            m = re.search(r'host enqueue ([0-9.]+) us/step, step ([0-9.]+) us', res.stdout)
+            out[label] = ({'host_enqueue_ms_per_step': float(m.group(1))*1e-3, 'ms_per_step': float(m.group(2))*1e-3}
+                          if m else {'error': (res.stderr or res.stdout)[-300:]})
+        except (OSError, subprocess.SubprocessError) as err:
+            out[label] = {'error': str(err)[:300]}
+    out['note'] = ('one rank, RCCL all-gather of size 1 (test hook): what the host pays per sharded step; with N > 1 '
+                   'the exchange stays call by call unless FFK_GRAPH_COLLECTIVE=1 (a multi-rank capture of the '
+                   'collective cannot be rehearsed on a one-GPU box)')
+    return out
+
+
 class AccumulateTimer:
     """HIP events around the accumulate kernel, recorded by libffk on the stream the kernel is
     launched on (ffk_set_accumulate_events)."""
@@ -893,6 +924,8 @@ def main():
             api, infid_api = bench_api_call(ff, c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega,
                                             spectrum_full)
             out.update(api)
+        if world == 1 and not args.child and not args.no_configs:
+            out['sharded_step_one_rank'] = probe_sharded_step_one_rank()
         if world == 1 and not args.no_cpu_baseline:
             base, (R_ref, F_ref, infid_ref) = cpu_baseline(
                 pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, np.asarray(basis),

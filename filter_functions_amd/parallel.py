@@ -353,6 +353,12 @@ class ShardedStepRing:
         # (bench.py's HIP-event instrumentation of the accumulate kernel needs the calls).
         self.use_graph = bool(use_graph) and streams is None
         self._step_graphs = {}
+        # FFK_GRAPH_COLLECTIVE=1 (experimental, equal blocks only): the WHOLE sharded step -- pass,
+        # hand-over to the communication stream, RCCL all-gather, integral, join -- is captured as one
+        # graph per buffer set and replayed with one runtime call.  Rehearsed on one rank only (RCCL
+        # refuses several ranks on one device, so a multi-rank capture cannot be tried on a one-GPU
+        # box): not the default.
+        self.graph_collective = self.use_graph and bool(os.environ.get('FFK_GRAPH_COLLECTIVE'))
         self.pipes = list(pipes)
         self.depth = len(self.pipes)
         if self.depth < 2 or self.depth % 2:
@@ -473,6 +479,30 @@ class ShardedStepRing:
             g = self._step_graphs[k] = capture(enqueue)
         return g
 
+    def _collective_step_graph(self, k, compute):
+        """Pass + all-gather + integral of buffer set k as one graph, captured on *compute* (the
+        communication stream is forked from and joined back to it with events)."""
+        g = self._step_graphs.get(('coll', k))
+        if g is None:
+            import torch.distributed as dist
+            from .device import capture
+            st, pipe = self.streams, self.pipes[k]
+            send, recv = pipe.filter_function, self.gathered[k]
+            views = (self.torch.view_as_real(recv), self.torch.view_as_real(send))
+
+            def enqueue(s):
+                pipe.launch(stream=s, with_infidelity=False)
+                ready = st.record(compute)
+                with st.on(self.comm_stream):
+                    st.wait(self.comm_stream, ready)
+                    dist.all_gather_into_tensor(views[0], views[1], group=self.group)
+                    pipe.infidelity_from_shards(recv, self.omega_full, self.spectrum_full, self.idx,
+                                                self.infid[k], stream=st.handle(self.comm_stream))
+                    done = st.record(self.comm_stream)
+                st.wait(compute, done)
+            g = self._step_graphs[('coll', k)] = capture(enqueue, stream=st.handle(compute), keep=views)
+        return g
+
     def step(self, eager=False):
         """Enqueue one sharded step; returns the tensor that will hold its infidelities (valid
         once the communication stream has passed the step AND -- with the one-sided gather -- a
@@ -495,6 +525,28 @@ class ShardedStepRing:
             pipe.launch(stream=s, with_infidelity=False)
             return pipe.infidelity_from_shards(self._own_shard[k], self.omega_full,
                                                self.spectrum_full, self.idx, self.infid[k], stream=s)
+        if (self.graph_collective and self.peer is None and not self.local_only and self.equal_shards
+                and self.depth % len(self.compute_streams) == 0):
+            # whole step from one graph (or, for an instrumented step, the same calls in the same
+            # stream order); a set always returns to the same compute stream and the graph joins the
+            # communication stream back: stream order alone protects the buffer set
+            if graphed:
+                self._collective_step_graph(k, compute).launch(st.handle(compute))
+                return self.infid[k]
+            pipe.launch(stream=st.handle(compute), with_infidelity=False)
+            ready = st.record(compute)
+            with st.on(self.comm_stream):
+                st.wait(self.comm_stream, ready)
+                views = self._real_views.get(k)
+                if views is None:
+                    views = self._real_views[k] = (self.torch.view_as_real(self.gathered[k]),
+                                                   self.torch.view_as_real(pipe.filter_function))
+                dist.all_gather_into_tensor(views[0], views[1], group=self.group)
+                out = pipe.infidelity_from_shards(self.gathered[k], self.omega_full, self.spectrum_full,
+                                                  self.idx, self.infid[k], stream=st.handle(self.comm_stream))
+                done = st.record(self.comm_stream)
+            st.wait(compute, done)
+            return out
         if len(self.compute_streams) == 1:
             if c >= half and c % half == 0:
                 st.wait(compute, self.free_events[(c - half) % self.depth])

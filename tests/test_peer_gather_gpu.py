@@ -147,3 +147,55 @@ def test_one_sided_gather_failure_reaches_every_rank(tmp_path):
     assert int(r0['after']) == 2                  # sticky: the first failure stays
     assert int(r1['after']) == 3                  # rank 1: told by the poison, not by a timeout
     assert bool(r0['raised']) and bool(r1['raised'])
+
+
+def _captured_collective_worker(rank, world, port, out_dir):
+    """One rank, nccl (= RCCL) backend: the whole sharded step -- pass, all-gather, integral -- replayed
+    from one hipGraph per buffer set (FFK_GRAPH_COLLECTIVE=1) against the same steps enqueued call by
+    call.  (A multi-rank capture cannot be rehearsed on a one-GPU box: RCCL refuses two ranks on one
+    device.)"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), FFK_FORCE_COLLECTIVE='1',
+                      FFK_GRAPH_COLLECTIVE='1')
+    import torch.distributed as dist
+
+    import filter_functions_amd as ff
+    import workloads as wl
+    from filter_functions_amd.device import DevicePipeline
+    from filter_functions_amd.parallel import ShardedStepRing
+    torch.cuda.set_device(0)
+    device = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    cfg = dict(wl.CONFIG2, G=16)
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
+    W = 320
+    omega = wl.random_pulse_omega(dt, W)
+    basis = ff.Basis.pauli(2)
+    pipes = [DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, device=device)
+             for _ in range(4)]
+    streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+    comm = torch.cuda.Stream(device=device)
+    ring = ShardedStepRing(pipes, W, omega, 1e-3/omega, streams, comm, world, rank, gather='rccl',
+                           use_graph=True)
+    assert ring.graph_collective
+    outs = []
+    for i in range(30):
+        out = ring.step(eager=(i % 7 == 0))
+        torch.cuda.synchronize(device)
+        outs.append(out.cpu().numpy().copy())
+    whole = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum=1e-3/omega,
+                           device=device)
+    whole.launch()
+    torch.cuda.synchronize(device)
+    np.savez(os.path.join(out_dir, 'captured.npz'), outs=np.array(outs), ref=whole.infid.cpu().numpy(),
+             nodes=ring._step_graphs[('coll', 1)].nodes)
+    dist.destroy_process_group()
+
+
+def test_sharded_step_with_the_collective_captured_in_a_graph(tmp_path):
+    mp.spawn(_captured_collective_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(os.path.join(str(tmp_path), 'captured.npz'))
+    assert int(got['nodes']) >= 7                          # pass (5) + collective + integral
+    for out in got['outs']:
+        assert np.array_equal(out, got['outs'][0])         # replayed == call by call (step 0), bit for bit
+    assert np.abs(got['outs'][0] - got['ref']).max() <= 1e-13*np.abs(got['ref']).max()
