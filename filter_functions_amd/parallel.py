@@ -359,6 +359,9 @@ class ShardedStepRing:
         # refuses several ranks on one device, so a multi-rank capture cannot be tried on a one-GPU
         # box): not the default.
         self.graph_collective = self.use_graph and bool(os.environ.get('FFK_GRAPH_COLLECTIVE'))
+        if self.graph_collective:
+            import torch.distributed as dist
+            self.graph_collective = dist.is_initialized() and dist.get_backend(group) == 'nccl'
         self.pipes = list(pipes)
         self.depth = len(self.pipes)
         if self.depth < 2 or self.depth % 2:
