@@ -159,6 +159,9 @@ def probe_sharded_step_one_rank():
     import socket
     import subprocess
     script = os.path.join(ROOT, 'tools', 'profile_ring_step.py')
+    if any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or \
+            'rocprof' in os.environ.get('LD_PRELOAD', ''):
+        return {'skipped': 'running under a profiler'}
     out = {}
     for label, graph_collective in (('graph_incl_collective', '1'), ('pass_graph_exchange_call_by_call', '')):
         with socket.socket() as sock:
