@@ -583,9 +583,7 @@ class PulseSequence:
             # sequence then hold ONE grid object and comparing their grids is an identity test
             grid = value
         else:
-            grid = np.array(value, dtype=None, copy=True)
-            if grid.dtype == np.float64 and grid.ndim == 1:
-                grid.flags.writeable = False
+            grid = _interned_grid(value)
         self.cleanup('frequency dependent')
         self._frequency_data['omega'] = grid
 
@@ -622,6 +620,25 @@ class PulseSequence:
 # identifiers and coefficient tables; the arithmetic -- atomic control matrices, Liouville
 # propagators, the concatenation rule and the filter functions -- runs in libffk.
 # --------------------------------------------------------------------------------------------
+_GRIDS = weakref.WeakValueDictionary()
+
+
+def _interned_grid(value):
+    """The remembered copy of a frequency grid handed in by the user: read-only, and ONE object per
+    distinct content for as long as some pulse holds it (pulses built separately on the same grid -- the
+    X/2 and Y/2 atoms of a gate set -- then share it, and every later comparison is an identity test)."""
+    grid = np.array(value, dtype=None, copy=True)
+    if grid.dtype != np.float64 or grid.ndim != 1:
+        return grid
+    key = (grid.shape[0], hash(grid.tobytes()))
+    known = _GRIDS.get(key)
+    if known is not None and np.array_equal(known, grid):
+        return known
+    grid.flags.writeable = False
+    _GRIDS[key] = grid
+    return grid
+
+
 def _same_grid(a, b):
     """Two frequency grids are the same object or hold the same values."""
     return a is b or np.array_equal(a, b)
@@ -728,34 +745,40 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index
     concat_identifiers = np.array([new_ident[key] for key in ordered])
     concat_opers = np.array([np.asarray(opers[first_seen[key][0]][first_seen[key][1]])
                              for key in ordered])
-    # per entry: its block of the coefficient table (NaN where it lacks an operator) and its
-    # identifier map; per pulse position: a reference to those
-    blocks = [np.full((len(ordered), np.shape(c)[1]), np.nan) for c in coeffs]
+    # per entry: its block of the coefficient table (NaN where it lacks an operator) -- all blocks
+    # side by side in ONE array -- and its identifier map; per pulse position: a reference to those
+    lengths = np.array([np.shape(c)[1] for c in coeffs], dtype=np.intp)
+    offsets = np.concatenate(([0], np.cumsum(lengths)))
+    side_by_side = np.full((len(ordered), int(offsets[-1])), np.nan)
     maps = [{} for _ in coeffs]
+    carried = np.zeros((len(ordered), len(coeffs)), dtype=bool)
     for k, i, key, ident in records:
-        blocks[k][row[key]] = np.asarray(coeffs[k])[i]
+        side_by_side[row[key], offsets[k]:offsets[k + 1]] = np.asarray(coeffs[k])[i]
         maps[k][ident] = new_ident[key]
-    if len({block.shape[1] for block in blocks}) == 1:
-        # equal segment counts: one gather (positions, operators, segments) -> (operators, all segments)
-        table = np.stack(blocks)[index].transpose(1, 0, 2).reshape(len(ordered), -1)
-    elif len(index) <= 4*len(blocks):
+        carried[row[key], k] = True
+    complete = bool(carried.all())                     # every pulse carries every operator: no NaN
+    if (lengths == lengths[0]).all():
+        # equal segment counts: one gather (operators, entries, segments)[:, index] -> (operators, all segments)
+        table = side_by_side.reshape(len(ordered), len(coeffs), -1)[:, index].reshape(len(ordered), -1)
+    elif len(index) <= 4*len(coeffs):
         # few positions (possibly long pulses): plain block copies
-        table = np.concatenate([blocks[k] for k in index], axis=1)
+        table = np.concatenate([side_by_side[:, offsets[k]:offsets[k + 1]] for k in index], axis=1)
     else:
-        # many positions drawn from few pulses, ragged: the distinct blocks side by side, then one
-        # gather of columns (no Python-level loop over the positions)
-        table = np.concatenate(blocks, axis=1)[:, _ragged_columns([b.shape[1] for b in blocks], index)]
+        # many positions drawn from few pulses, ragged: one gather of columns (no Python-level loop
+        # over the positions)
+        table = side_by_side[:, _ragged_columns(lengths, index)]
     mapping = _PositionMap(maps, index)
-    missing = np.isnan(table)
-    if kind == 'noise':
-        for r in np.nonzero(missing.any(axis=1))[0]:
-            known = table[r][~missing[r]]
-            if not (known == known[0]).all():
-                raise ValueError('Not all pulses have the same noise operators and '
-                                 'non-trivial noise sensitivities so I cannot infer them.')
-            table[r, missing[r]] = known[0]
-    elif missing.any():
-        table[missing] = 0
+    if not complete:
+        missing = np.isnan(table)
+        if kind == 'noise':
+            for r in np.nonzero(missing.any(axis=1))[0]:
+                known = table[r][~missing[r]]
+                if not (known == known[0]).all():
+                    raise ValueError('Not all pulses have the same noise operators and '
+                                     'non-trivial noise sensitivities so I cannot infer them.')
+                table[r, missing[r]] = known[0]
+        elif missing.any():
+            table[missing] = 0
     return concat_opers, concat_identifiers, table, mapping
 
 
