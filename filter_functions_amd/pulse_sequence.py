@@ -17,6 +17,7 @@ first time somebody reads them.  From the outside every entry is an ndarray, exa
 reference.
 """
 import copy
+import functools
 import weakref
 from types import MappingProxyType
 from warnings import warn
@@ -102,9 +103,19 @@ def _checked_durations(dt):
     return dt
 
 
+@functools.lru_cache(maxsize=32)
+def _default_basis(d):
+    """The default basis of dimension d, ONE read-only object per d: pulses built without a basis
+    share it, so that concatenating them compares bases by identity (the arrays are what
+    ``Basis.ggm(d)`` returns; writing into a default basis in place raises)."""
+    basis = Basis.ggm(d)
+    basis.flags.writeable = False
+    return basis
+
+
 def _checked_basis(basis, d):
     if basis is None:
-        return Basis.ggm(d)
+        return _default_basis(d)
     if not isinstance(basis, Basis):
         raise ValueError("Expected basis to be an instance of the "
                          f"'filter_functions_amd.basis.Basis' class, not {type(basis)}!")
@@ -162,7 +173,7 @@ class PulseSequence:
         for name, value in given.items():
             setattr(new, name, np.asanyarray(value))
         new.d = new.c_opers.shape[-1]
-        new.basis = Basis.ggm(new.d) if basis is None else np.asanyarray(basis).view(Basis)
+        new.basis = _default_basis(new.d) if basis is None else np.asanyarray(basis).view(Basis)
         n_control = {len(new.c_opers), len(new.c_oper_identifiers), len(new.c_coeffs)}
         n_noise = {len(new.n_opers), len(new.n_oper_identifiers), len(new.n_coeffs)}
         extents = set(new.c_opers.shape[1:] + new.n_opers.shape[1:])
