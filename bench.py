@@ -892,6 +892,7 @@ def main():
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved/FP64_PEAK_TFLOPS, 'frac_step': step_tflops/FP64_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_source': traffic_src,
+                'frac_contraction_only': (16.0*d**3 + 6.0*d*d)*A*G*args.omega_per_gpu/(acc_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
                 'avg_launch_ms': acc_ms, 'launches_timed': n_ev + n_extra,
                 'launches_in_timed_region': n_ev,
                 'avg_launch_ms_in_timed_region': float(np.mean(in_region_ms)),
@@ -903,9 +904,12 @@ def main():
                         'Hilbert-space algorithm actually run; frac = dominant kernel alone (HIP events, '
                         'each instrumented launch gated on the previous accumulate kernel), frac_step = '
                         'the same flops over the whole step time -- above frac when passes pipeline: '
-                        'consecutive accumulate kernels then overlap ramp and tail; a pure v_fma_f64 stream on '
-                        'pseudo-random operands sustains 55 TFLOP/s on this part '
-                        '(tools/fp64_data_probe.hip, profiles/r01_k_*)',
+                        'consecutive accumulate kernels then overlap ramp and tail; frac_contraction_only = the '
+                        'contraction FMAs alone, (16 d^3 + 6 d^2) A per (segment, omega), without the modelled 55 flop '
+                        'per integral entry; SURVEY 8(d)\'s (8 d^2 + 8) flop per element is the Liouville-space form, '
+                        'which this kernel does not execute, and is not used here.  A pure v_fma_f64 stream on random '
+                        'operands sustains 59 TFLOP/s on this part at an in-kernel clock of 1.89 GHz (2.38 GHz on '
+                        'constants: tools/fp64_ceiling_probe.hip, profiles/r03_d_*)',
             },
             'roofline_hbm': {
                 'bound': 'hbm', 'achieved': stats['accumulate_bytes']/(acc_ms*1e-3)/1e9,

@@ -147,6 +147,20 @@ FFK_HD double rcp(double x) {
 #endif
 }
 
+// Reciprocal to ~1e-15 relative (10 ulp): v_rcp_f64 (4.6e-8 on gfx950, measured over 2^20 random
+// arguments of either sign and 40 binades) + ONE Newton step.  For the integral entries of the
+// accumulate kernels, where the factor 1/x multiplies a sine that is itself good to ~1 ulp and
+// 256 segments are summed: two instructions less per entry and frequency.
+FFK_HD double rcp_fast(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+#else
+    return 1.0/x;
+#endif
+}
+
 // 1/sqrt(x) to ~1 ulp for normal x > 0.  Device: v_rsq_f64 seed + two Newton steps.
 FFK_HD double rsqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -198,7 +212,7 @@ FFK_HD cplx first_order_integral_aa(double omega, double dE, double dt, double s
     double s = fma(sa, cb, ca*sb);
     double c = fma(ca, cb, -(sa*sb));
     if (fabs(h) < 0.03125) sincos_small<true>(h, &s, &c);   // no range reduction needed here
-    const double q = 2.0*s*rcp(x);
+    const double q = 2.0*s*rcp_fast(x);
     cplx out = {q*c, q*s};
     if (x == 0.0) {
         out.re = dt;
