@@ -3,6 +3,8 @@
 // All of these are single-pass, HBM-streaming kernels with omega as the fastest (lane) axis.
 #include <algorithm>
 
+#include <cstdlib>
+
 #include "ffk_internal.h"
 
 namespace ffk {
@@ -62,13 +64,30 @@ __global__ __launch_bounds__(256) void reduce_compact_kernel(const cplx* __restr
     Bt[e] = acc;
 }
 
+// Large d, which expansion?  A basis whose elements have few non-zeros (GGM: 2.5 d^2 in all) is
+// expanded fastest by the per-element kernel with 64 frequencies per wavefront (1-KiB row runs, every
+// entry of Y read ~2.5 times, from L2 after the first); a dense-ish one (Pauli: d^3 non-zeros) by the
+// LDS-staged kernel that reads Y exactly once in 256-byte runs.  The non-zero count lives on the
+// device (the compaction runs there), so BOTH kernels are launched for d >= 8 and each wavefront
+// decides from the count whether it is the one to work (`want_sparse`: 1 / 0 = this kernel is the
+// sparse / the dense form, -1 = unconditional).  Config 5 (GGM, d = 16): 0.97 -> 0.76 ms.
+__device__ __forceinline__ bool basis_is_sparse(const int* __restrict__ nnz, int N, int dd) {
+    int part = 0;
+    for (int k = threadIdx.x & 63; k < N; k += 64) part += nnz[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    return part <= 3*dd;
+}
+
 // one lane per omega; blockIdx.y = a; blockIdx.z = basis element group of KT
 template <int KT>
 __global__ __launch_bounds__(64) void expand_sparse_kernel(const cplx* __restrict__ Bt,
                                                            const int* __restrict__ nnz,
                                                            const int* __restrict__ rows,
                                                            const cplx* __restrict__ vals, int N,
-                                                           int dd, int W, cplx* __restrict__ R) {
+                                                           int dd, int W, cplx* __restrict__ R,
+                                                           int want_sparse) {
+    if (want_sparse >= 0 && basis_is_sparse(nnz, N, dd) != (want_sparse != 0)) return;
     const int w = blockIdx.x*64 + threadIdx.x;
     const int a = blockIdx.y;
     if (w >= W) return;
@@ -473,8 +492,9 @@ __global__ __launch_bounds__(256) void expand_lds_kernel(const cplx* __restrict_
                                                          size_t slab, const int* __restrict__ nnz,
                                                          const int* __restrict__ rows,
                                                          const cplx* __restrict__ vals, int N, int dd,
-                                                         int W, cplx* __restrict__ R) {
+                                                         int W, cplx* __restrict__ R, int want_sparse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    if (want_sparse >= 0 && basis_is_sparse(nnz, N, dd) != (want_sparse != 0)) return;   // (block uniform)
     cplx* yl = reinterpret_cast<cplx*>(lds_raw);       // [dd][16]
     const int wl = threadIdx.x & 15, kl = threadIdx.x >> 4;
     const int a = blockIdx.y;
@@ -508,7 +528,7 @@ __global__ __launch_bounds__(256) void expand_lds_kernel(const cplx* __restrict_
 }
 
 hipError_t launch_expand_lds(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d, int W,
-                             cplx* R, void* ws, hipStream_t stream) {
+                             cplx* R, void* ws, hipStream_t stream, int want_sparse = -1) {
     if (A > 65535) return hipErrorInvalidValue;
     const CompactWs cw = slice_compact_ws(ws, N, d);
     const size_t lds = static_cast<size_t>(d)*d*16*sizeof(cplx);
@@ -519,14 +539,24 @@ hipError_t launch_expand_lds(const cplx* Ypart, int chunks, size_t slab, int A, 
         if (err != hipSuccess) return err;
     }
     hipLaunchKernelGGL(expand_lds_kernel, dim3((W + 15)/16, A), dim3(256), lds, stream, Ypart, chunks,
-                       slab, cw.nnz, cw.rows, cw.vals, N, d*d, W, R);
+                       slab, cw.nnz, cw.rows, cw.vals, N, d*d, W, R, want_sparse);
     return hipGetLastError();
 }
+
+namespace {
+bool expand_force_sparse() {          // FFK_TUNE_EXPAND_SPARSE=1: 64-frequency lanes, no LDS, also for d >= 8
+    static const bool on = [] {
+        const char* e = std::getenv("FFK_TUNE_EXPAND_SPARSE");
+        return e != nullptr && e[0] == '1';
+    }();
+    return on;
+}
+}  // namespace
 
 hipError_t launch_expand_chunks(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d,
                                 int W, cplx* R, void* ws, hipStream_t stream) {
     if (A > 65535 || N > 65535) return hipErrorInvalidValue;
-    if (d >= 8) return launch_expand_lds(Ypart, chunks, slab, A, N, d, W, R, ws, stream);
+    if (d >= 8 && !expand_force_sparse()) return launch_expand_lds(Ypart, chunks, slab, A, N, d, W, R, ws, stream);
     const CompactWs cw = slice_compact_ws(ws, N, d);
     hipLaunchKernelGGL(expand_chunks_kernel, dim3((W + 63)/64, A, N), dim3(64), 0, stream, Ypart,
                        chunks, slab, cw.nnz, cw.rows, cw.vals, N, d*d, W, R);
@@ -543,19 +573,24 @@ hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d
     cplx* vals = cw.vals;
     if (!compacted)
         hipLaunchKernelGGL(basis_compact_kernel, dim3(N), dim3(64), 0, stream, basis, d, nnz, rows, vals);
-    if (d >= 8) {
-        hipError_t err = launch_expand_lds(Bt, 1, 0, A2, N, d, W, R, ws, stream);
-        return err;
+    if (d >= 8 && !expand_force_sparse()) {
+        // both forms, each deciding on the device whether the basis is its kind (see basis_is_sparse)
+        hipError_t err = launch_expand_lds(Bt, 1, 0, A2, N, d, W, R, ws, stream, 0);
+        if (err != hipSuccess) return err;
+        constexpr int KT = 8;
+        hipLaunchKernelGGL(expand_sparse_kernel<KT>, dim3((W + 63)/64, A2, (N + KT - 1)/KT), dim3(64),
+                           0, stream, Bt, nnz, rows, vals, N, static_cast<int>(dd), W, R, 1);
+        return hipGetLastError();
     }
     // few basis elements per thread when the grid would otherwise be small
     const long blocks1 = static_cast<long>((W + 63)/64)*A2;
     if (blocks1*N <= 16384 || N <= 16) {
         hipLaunchKernelGGL(expand_sparse_kernel<1>, dim3((W + 63)/64, A2, N), dim3(64), 0, stream, Bt,
-                           nnz, rows, vals, N, static_cast<int>(dd), W, R);
+                           nnz, rows, vals, N, static_cast<int>(dd), W, R, -1);
     } else {
         constexpr int KT = 8;
         hipLaunchKernelGGL(expand_sparse_kernel<KT>, dim3((W + 63)/64, A2, (N + KT - 1)/KT), dim3(64),
-                           0, stream, Bt, nnz, rows, vals, N, static_cast<int>(dd), W, R);
+                           0, stream, Bt, nnz, rows, vals, N, static_cast<int>(dd), W, R, -1);
     }
     return hipGetLastError();
 }
