@@ -2378,3 +2378,52 @@ def test_long_resident_concatenations_around_the_one_launch_front(d, n_positions
     assert rel_err(total.get_filter_function(omega), via_host.get_filter_function(omega)) < 1e-11
     assert rel_err(total.get_control_matrix(omega), via_host.get_control_matrix(omega)) < 1e-11
     assert rel_err(total.total_propagator, via_host.total_propagator) < 1e-11
+
+
+@pytest.mark.parametrize('n_nops', [1, 3, 4])
+def test_block_rule_kernel_with_a_non_hermitian_basis(n_nops):
+    """from_atomic_block_kernel<A,4,LCPLX> (one block per 64 frequencies: rule + slab reduction + F)
+    with COMPLEX Liouville propagators -- a basis that is not Hermitian -- and 1, 3, 4 noise
+    operators, through both routes that reach it (resident control matrices read in place; host
+    tables), against the oracle's concatenation rule fed with the same atomic control matrices.
+    (For such a basis the rule and the from-scratch evaluation of the long pulse differ in the
+    reference itself -- its expansion tr(X C_k) is only a projection for Hermitian C_k -- so the
+    from-scratch result is not the yardstick here.)"""
+    import copy
+    rng = np.random.default_rng(40 + n_nops)
+    d = 2
+    basis = ff.Basis(np.array([[[0, 1], [0, 0]], [[0, 0], [1, 0]], [[1, 0], [0, 0]], [[0, 0], [0, 1]]],
+                              dtype=complex))
+    assert not basis.isherm
+
+    def herm(n):
+        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+        return M + M.conj().transpose(0, 2, 1)
+    c_opers, n_opers = herm(2), herm(n_nops)
+    omega = np.geomspace(1e-2, 1e1, 150)
+    pulses = []
+    for k in range(3):
+        n_dt = int(rng.integers(1, 4))
+        pulses.append(ff.PulseSequence(
+            [[c_opers[i], rng.standard_normal(n_dt), f'c{i}'] for i in range(2)],
+            [[n_opers[a], np.full(n_dt, 1.0 + 0.5*a), f'n{a}'] for a in range(n_nops)],
+            0.05*rng.random(n_dt) + 0.01, basis))
+        pulses[-1].get_filter_function(omega)
+    index = rng.integers(0, 3, 150)
+    resident = ff.concatenate([pulses[k] for k in index])
+    copies = [copy.deepcopy(p) for p in pulses]
+    via_host = ff.concatenate([copies[k] for k in index])
+    # the oracle's rule on the same atomic control matrices, cumulative phases and propagators
+    R_atomic = np.array([copies[k].get_control_matrix(omega) for k in index])
+    phases = np.cumprod([np.exp(1j*omega*copies[k].tau) for k in index[:-1]], axis=0)
+    U = np.eye(d, dtype=complex)
+    L = []
+    for k in index[:-1]:
+        U = copies[k].total_propagator @ U
+        L.append(orc.liouville_representation(U, np.asarray(basis)))
+    R_ref = orc.control_matrix_from_atomic(phases, R_atomic, np.array(L))
+    F_ref = orc.filter_function(R_ref)
+    assert np.iscomplexobj(np.array(L)) and np.abs(np.array(L).imag).max() > 1e-3
+    for got in (resident, via_host):
+        assert rel_err(got.get_control_matrix(omega), R_ref) < 1e-11
+        assert rel_err(got.get_filter_function(omega), F_ref) < 1e-11
