@@ -1,8 +1,8 @@
 // liouville.hip -- K5: superoperator.liouville_representation (superoperator.py:51-84 followed
 // by Basis.expand basis.py:650-698):  L[b,i,j] = tr(U_b^dag C_i U_b C_j).
 //
-// Two steps.  (1) conjugate the basis, CB[b,i] = U_b^dag C_i U_b, one wavefront per (b, i), and
-// scatter it as a REAL operand matrix.  (2) the contraction over the d^2 matrix entries is the
+// Two steps.  (1) conjugate the basis, CB[b,i] = U_b^dag C_i U_b, sixteen elements per block, and
+// lay it out as a REAL operand matrix.  (2) the contraction over the d^2 matrix entries is the
 // one genuine dense GEMM of the path (N x 2d^2 by 2d^2 x N per batch element); it runs on the
 // FP64 matrix cores, v_mfma_f64_16x16x4_f64, one 16 x 16 output tile per wavefront.
 //   Re L[i,j] = sum_ab  Re CB_i[a,b] Re C_j[b,a] - Im CB_i[a,b] Im C_j[b,a]
@@ -34,56 +34,10 @@ __global__ void build_bop_kernel(const cplx* __restrict__ basis, int N, int d, i
     Bop[static_cast<size_t>(d*d + ab)*Npad + j] = v.im;
 }
 
-constexpr int kConjPerBlock = 8;
-
-template <int D>
-__global__ __launch_bounds__(64) void conjugate_basis_kernel(const cplx* __restrict__ U,
-                                                             const cplx* __restrict__ basis, int N,
-                                                             int Npad, int want_imag,
-                                                             double* __restrict__ AopRe,
-                                                             double* __restrict__ AopIm) {
-    // one block conjugates kConjPerBlock basis elements with the same unitary (U staged once; one
-    // block per element was launch-rate bound: 131072 blocks for d = 16, batch 512)
-    __shared__ cplx Us[D][D];
-    __shared__ cplx C[D][D];
-    __shared__ cplx CU[D][D];
-    const int bt = blockIdx.y, lane = threadIdx.x;
-    for (int e = lane; e < D*D; e += 64) Us[e / D][e % D] = U[static_cast<size_t>(bt)*D*D + e];
-    const size_t K = (2*D*D + 3)/4*4;  // padded to the MFMA k-step; pad rows stay zero
-    double* are = AopRe + static_cast<size_t>(bt)*K*Npad;
-    double* aim = AopIm + static_cast<size_t>(bt)*K*Npad;
-    const int i1 = min(N, static_cast<int>(blockIdx.x + 1)*kConjPerBlock);
-    for (int i = blockIdx.x*kConjPerBlock; i < i1; ++i) {
-        __syncthreads();                 // Us staged / previous element's C and CU consumed
-        for (int e = lane; e < D*D; e += 64) C[e / D][e % D] = basis[static_cast<size_t>(i)*D*D + e];
-        __syncthreads();
-        for (int e = lane; e < D*D; e += 64) {
-            const int r = e / D, c = e % D;
-            cplx acc = {0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < D; ++k) cmac(acc, C[r][k], Us[k][c]);
-            CU[r][c] = acc;
-        }
-        __syncthreads();
-        for (int e = lane; e < D*D; e += 64) {
-            const int a = e / D, b = e % D;  // CB[a][b] = sum_k conj(U[k][a]) CU[k][b]
-            cplx acc = {0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < D; ++k) cmac_conj(acc, Us[k][a], CU[k][b]);
-            are[static_cast<size_t>(e)*Npad + i] = acc.re;
-            are[static_cast<size_t>(D*D + e)*Npad + i] = -acc.im;
-            if (want_imag) {
-                aim[static_cast<size_t>(e)*Npad + i] = acc.im;
-                aim[static_cast<size_t>(D*D + e)*Npad + i] = acc.re;
-            }
-        }
-    }
-}
-
-// The same conjugation with COALESCED operand stores.  The GEMM wants its A operand K-major,
-// Aop[kk][i]: one basis element is a column, and conjugate_basis_kernel writes each of its 2 d^2
-// numbers to a line of its own (8 bytes per 2 KiB at d = 16: 4.3 GB of write transactions for 0.5 GB of
-// payload at batch 512 -- 862 us, more than the GEMM).  Here a 256-thread block conjugates EPB
+// Conjugation of the basis with COALESCED operand stores.  The GEMM wants its A operand K-major,
+// Aop[kk][i]: one basis element is a column, and the round-2 kernel (one wavefront per element) wrote
+// each of its 2 d^2 numbers to a line of its own (8 bytes per 2 KiB at d = 16: 4.3 GB of write
+// transactions for 0.5 GB of payload at batch 512 -- 862 us, more than the GEMM).  Here a 256-thread block conjugates EPB
 // consecutive elements with one unitary, one matrix entry per thread, parks the results in an LDS
 // tile [kk][EPB] (rows padded by one double: conflict free) and writes rows of EPB doubles -- 128
 // contiguous bytes per kk for EPB = 16.
@@ -163,7 +117,6 @@ __global__ __launch_bounds__(64, (TM == 4 && !IMAG) ? 3 : 1) void liouville_gemm
                                                             const double* __restrict__ Bop, int N,
                                                             int Npad, int K,
                                                             double* __restrict__ out) {
-    constexpr bool want_imag = IMAG;
     const int lane = threadIdx.x;
     const int ti = blockIdx.x, tj = blockIdx.y, bt = blockIdx.z;
     const int l15 = lane & 15, lk = lane >> 4;
