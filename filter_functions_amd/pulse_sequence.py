@@ -19,6 +19,7 @@ reference.
 import copy
 import functools
 import weakref
+from collections.abc import Mapping
 from types import MappingProxyType
 from warnings import warn
 
@@ -793,15 +794,17 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index
     return concat_opers, concat_identifiers, table, mapping
 
 
-class _PositionMap:
+class _PositionMap(Mapping):
     """position -> identifier map of the pulse standing there, without materialising one dict
-    entry per position (read like the dict the reference returns: ``mapping[p]``, ``len``,
-    iteration over the positions, ``items()``)."""
+    entry per position: a read-only ``Mapping`` (``mapping[p]``, ``len``, iteration over the
+    positions, ``keys/values/items/get``, ``==`` against a dict) over the maps of the DISTINCT pulses."""
 
     def __init__(self, maps, index):
         self._maps, self._index = maps, index
 
     def __getitem__(self, position):
+        if not isinstance(position, (int, np.integer)) or not -len(self._index) <= position < len(self._index):
+            raise KeyError(position)
         return self._maps[self._index[position]]
 
     def __len__(self):
@@ -809,18 +812,6 @@ class _PositionMap:
 
     def __iter__(self):
         return iter(range(len(self._index)))
-
-    def keys(self):
-        return range(len(self._index))
-
-    def values(self):
-        return [self._maps[k] for k in self._index]
-
-    def items(self):
-        return [(p, self._maps[k]) for p, k in enumerate(self._index)]
-
-    def __eq__(self, other):
-        return dict(self.items()) == (dict(other.items()) if hasattr(other, 'items') else other)
 
     def __repr__(self):
         return repr(dict(self.items()))
