@@ -76,9 +76,14 @@ struct PcEntries {          // every entry once, the (coinciding) diagonal entri
     static constexpr Slots slot_table = make_table();
 };
 
-// MF: the consumers contract on the FP64 matrix cores (v_mfma_f64_4x4x4_4b, 16 frequencies per
-// instruction, four groups per wavefront) instead of v_fma_f64; layout in ffk_mfma_util.h.
-template <int D, int NC, bool MF = false>
+// MF != 0: the consumers contract on the FP64 matrix cores (v_mfma_f64_4x4x4_4b) instead of
+// v_fma_f64.  MF = 1: 16 frequencies on the instruction's columns, four groups per wavefront, a
+// 4 x 4 transpose across lanes between the two products (layout in ffk_mfma_util.h).  MF = 2: one
+// frequency per 4 x 4 x 4 block, the first product's result is the second's A operand as it stands.
+// The integral tile's slots are TS complex apart: 64 frequencies (+ 4 of padding for MF = 2, whose
+// lanes read 16 slots x 4 frequencies at once).
+constexpr int pc_tile_stride(int mf) { return mf == 2 ? 68 : 64; }
+template <int D, int NC, int MF = 0>
 __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
@@ -88,7 +93,8 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
     // held 140.5 KiB of LDS; a kernel of another pass needing more than ~8 KiB -- the scan: 9.5 KiB,
     // the prologue: 17.5 KiB -- could then not be placed beside it and waited the whole 83 us for it
     // to retire, tools/corun.hip and profiles/r02_q_*.)
-    constexpr int TILE = PcEntries<D>::count*64;
+    constexpr int TS = pc_tile_stride(MF);
+    constexpr int TILE = PcEntries<D>::count*TS;
 #if FFK_PC_WFOLD
     constexpr int OPS = DD + NC*D*DD;                 // T_g | W_a[m][n][j] = Bbar_a[m][n] T_g[n][j]
 #else
@@ -132,7 +138,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
         for (int k = wl; k < PcEntries<D>::count; k += NWS) {
             const int e = sl.v[k];
             const double* r = st + seg_rec(e);
-            tile[k*64] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+            tile[k*TS] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
         }
     };
 
@@ -184,7 +190,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
                 constexpr auto& sl = PcEntries<D>::slots;
                 const int e = sl.v[k];
                 const double* r = st + seg_rec(e);
-                tile[k*64] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+                tile[k*TS] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
             }
         };
         static_assert((1 + NC)*DD <= 64 && S/2 <= 64, "one staging element per lane");
@@ -219,7 +225,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
             }
             __syncthreads();
         }
-    } else if constexpr (MF) {
+    } else if constexpr (MF == 1) {
         // ---- matrix-core consumers ---------------------------------------------------------------
         // lane (cl = lane & 15, q = lane >> 4); per group wg of 16 frequencies (column cl):
         //   step 1:  Z_m[j = q]  = sum_n T[n, j] X_m[n],  X_m[n = q] = Bbar[m, q] E[m, q]     (m = 0..3)
@@ -320,6 +326,82 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
 #pragma unroll
                     for (int j = 0; j < D; ++j) out[static_cast<size_t>(q*D + j)*W] = {Yr[wg][j], Yi[wg][j]};
                 }
+            }
+        }
+        return;
+    } else if constexpr (MF == 2) {
+        // ---- matrix-core consumers, one frequency per 4 x 4 x 4 block ----------------------------
+        // lane (c = lane & 15, q = lane >> 4) supplies A_b[c & 3][q], B_b[q][c & 3] of block
+        // b = c >> 2 and receives D_b[q][c & 3]: a product's result is the transpose of an A operand.
+        //   step 1:  P[n, i] = sum_m X[m, n] conj(T[m, i])     A = X^T: lane holds X[q][c & 3]
+        //   step 2:  Y[i, j] += sum_n P[n, i] T[n, j]          A = P^T: step 1's registers
+        // B is T[q][c & 3] in both steps (conjugation through the NEG bit), Bbar[q][c & 3] is read
+        // once per segment: 16 + 2 LDS reads and 16 complex products per lane and segment, 8 matrix
+        // instructions per set of four frequencies, 16 sets per wavefront.
+        static_assert(D == 4, "one 4 x 4 block per matrix");
+        const int cl = lane & 15, q = lane >> 4, c4 = cl & 3, b = cl >> 2;
+        double Yr[16], Yi[16];                        // [set]: Y[q][c4] at frequency 4 set + b
+#pragma unroll
+        for (int set = 0; set < 16; ++set) {
+            Yr[set] = 0.0;
+            Yi[set] = 0.0;
+        }
+        const int e_mine = q*D + c4;
+        const int slot = (q == c4) ? 0 : e_mine - (e_mine > 5) - (e_mine > 10);
+        __syncthreads();
+        if (g0 < g1) generate_first_share();
+        __syncthreads();
+        for (int it = 0; it < sub_len; ++it) {
+            const int g = g0 + it;
+            if (active && g < g1) {
+                const cplx* tile = lds + static_cast<size_t>(it & 1)*BUF;
+                const cplx* opT = tile + TILE;
+                const cplx t = opT[e_mine];
+                const cplx bb = opT[(1 + cidx)*DD + e_mine];
+                const cplx* ecol = tile + slot*TS + b;
+#pragma unroll
+                for (int set = 0; set < 16; ++set) {
+                    const cplx x = cmul(bb, ecol[4*set]);
+                    double pr = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, t.re, 0.0, 0, 0, 0);
+                    double pi = __builtin_amdgcn_mfma_f64_4x4x4f64(x.im, t.re, 0.0, 0, 0, 0);
+                    pr = __builtin_amdgcn_mfma_f64_4x4x4f64(x.im, t.im, pr, 0, 0, 0);
+                    pi = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, t.im, pi, 0, 0, 1);
+                    Yr[set] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr, t.re, Yr[set], 0, 0, 0);
+                    Yi[set] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr, t.im, Yi[set], 0, 0, 0);
+                    Yr[set] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi, t.im, Yr[set], 0, 0, 1);
+                    Yi[set] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi, t.re, Yi[set], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // sub-chunks > 0 hand their accumulators to sub-chunk 0 through LDS (tiles are dead now)
+        cplx* red = reinterpret_cast<cplx*>(lds_raw);
+        constexpr int YSZ = DD*64;
+#pragma unroll
+        for (int s = 1; s < GS; ++s) {
+            if (sub == s) {
+                cplx* dst = red + static_cast<size_t>(cidx)*YSZ + lane;
+#pragma unroll
+                for (int set = 0; set < 16; ++set) dst[set*64] = {Yr[set], Yi[set]};
+            }
+            __syncthreads();
+            if (sub == 0) {
+                const cplx* srcy = red + static_cast<size_t>(cidx)*YSZ + lane;
+#pragma unroll
+                for (int set = 0; set < 16; ++set) {
+                    const cplx v = srcy[set*64];
+                    Yr[set] += v.re;
+                    Yi[set] += v.im;
+                }
+            }
+            __syncthreads();
+        }
+        if (sub == 0 && active) {
+            cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD + e_mine)*W;
+#pragma unroll
+            for (int set = 0; set < 16; ++set) {
+                const int iws = blockIdx.x*64 + 4*set + b;
+                if (iws < W) out[iws] = {Yr[set], Yi[set]};
             }
         }
         return;
@@ -456,16 +538,23 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
     }
 }
 
+// FFK_TUNE_PC_MFMA: 0 vector consumers (default), 1 / 2 the matrix-core forms (tuning / A-B)
+int pc_consumer_form() {
+    static const int form = [] {
+        const char* e = std::getenv("FFK_TUNE_PC_MFMA");
+        return (e != nullptr && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
+    }();
+    return form;
+}
+
 template <int D, int NC>
 hipError_t launch_pc(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                      int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
     const int lds = pc_accumulate_lds_bytes(D, NC);
-    // FFK_TUNE_PC_MFMA=1: matrix-core consumers (tuning / A-B)
-    static const bool mfma_consumers = [] {
-        const char* e = std::getenv("FFK_TUNE_PC_MFMA");
-        return e != nullptr && e[0] == '1';
-    }();
-    auto kern = mfma_consumers ? ctrl_accumulate_pc_kernel<D, NC, true> : ctrl_accumulate_pc_kernel<D, NC, false>;
+    const int form = pc_consumer_form();
+    auto kern = form == 2   ? ctrl_accumulate_pc_kernel<D, NC, 2>
+                : form == 1 ? ctrl_accumulate_pc_kernel<D, NC, 1>
+                            : ctrl_accumulate_pc_kernel<D, NC, 0>;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (err != hipSuccess) return err;
@@ -484,7 +573,7 @@ int pc_accumulate_lds_bytes(int d, int nc) {
     const int S = seg_stride(d), dd = d*d;
     const int ops = FFK_PC_WFOLD ? dd + nc*d*dd : (1 + nc)*dd;
     const int entries = d*(d - 1) + 1;                // distinct integral entries (PcEntries<D>::count)
-    return static_cast<int>(kPcSub*(2*(entries*64 + ops) + S)*sizeof(cplx));
+    return static_cast<int>(kPcSub*(2*(entries*pc_tile_stride(pc_consumer_form()) + ops) + S)*sizeof(cplx));
 }
 
 hipError_t launch_accumulate_pc(const double* omega, int W, const double* segtab, const cplx* ops,
