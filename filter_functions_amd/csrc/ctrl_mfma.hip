@@ -31,6 +31,9 @@
 namespace ffk {
 namespace {
 
+#ifndef FFK_MFMA_BF_DEFAULT     /* 1: the block-frequency form is the default for d = 12, 16 */
+#define FFK_MFMA_BF_DEFAULT 1
+#endif
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 constexpr int kMW = 4;   // wavefronts (= noise operators) per block, one per SIMD
 
@@ -88,10 +91,10 @@ __global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
 #pragma unroll
         for (int k = 0; k < L::kStagePerThread; ++k) {
             const int e = tid + k*kMW*64;
-            if (e < n_ops)
-                staged[k] = src_ops[e < DD ? e : e + alpha0*DD];
-            else if (e < n_ops + S/2)
-                staged[k] = src_tab[e - n_ops];
+            // (one unconditional assignment per element: with the two guarded ones the array stayed in
+            // scratch memory)
+            const cplx* src = e < n_ops ? src_ops + (e < DD ? e : e + alpha0*DD) : src_tab + (e - n_ops);
+            staged[k] = e < n_ops + S/2 ? *src : cplx{0.0, 0.0};
         }
     };
     auto park = [&](int buf) {
@@ -236,20 +239,36 @@ __global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
 // for its own row groups -- the 4-row instruction has no tile to leave half empty), which halves
 // the accumulators per wave: d = 16 fits 256 registers, i.e. two wavefronts per SIMD.
 // `nw` counts wavefronts; a block serves nw / JH noise operators.
-template <int D, int JH, int MAXW = 8>
+// ---------------------------------------------------------------------------------------------
+// BF ("block frequency"): the other way to lay the problem on the same instruction -- ONE frequency
+// per 4 x 4 x 4 block (b = c >> 2) instead of one per column.  Lane (c, q) supplies A_b[c & 3][q] and
+// B_b[q][c & 3] and receives D_b[q][c & 3], so a product's result is, register for register, the
+// transpose of an A operand:
+//     step 1:  P[n, i] = sum_m X[m, n] conj(T[m, i])      A = X^T (formed per lane), B = conj T
+//     step 2:  Y[i, j] += sum_n P[n, i] T[n, j]            A = P^T = step 1's registers, B = T
+// No transposes between the steps, both take the same (d/4)^2 entries of T per lane as B operand
+// (held in registers for the whole segment), X is formed once per operator, and a wavefront's
+// frequencies come as 4 / JH sets of four: the JH wavefronts of an operator split the tile's 16
+// frequencies, not the columns of Y.  The tile's slots are 20 complex apart (16 frequencies + 4 of
+// padding: a 16-lane row reads 4 slots x 4 frequencies, banks (4 (c & 3) + (c >> 2)) mod 16).
+constexpr int mfma4_tile_stride(bool bf) { return bf ? 20 : 16; }
+template <int D, int JH, int MAXW = 8, bool BF = false>
 __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
-    const cplx* __restrict__ ops, int G, int A, int chunk_len, int nw, cplx* __restrict__ Ypart) {
+    const cplx* __restrict__ ops, int G, int A, int chunk_len, int nw, cplx* __restrict__ Ypart,
+    int alpha_base, int alpha_end) {
     static_assert(D % 4 == 0 && D >= 4 && D <= 16, "d must be a multiple of 4");
-    static_assert((D/4) % JH == 0, "row groups must split evenly");
+    static_assert(BF ? 4 % JH == 0 : (D/4) % JH == 0, "row groups / frequency sets must split evenly");
     constexpr int S = seg_stride(D), DD = D*D, NS = D/4;
-    constexpr int NJG = NS/JH;        // row groups (of 4 columns of Y) owned by this wave
-    constexpr int kMaxStage = D == 16 ? 4 : 8;   // staged elements per thread (see launch_d4)
+    constexpr int NJG = BF ? NS : NS/JH;   // row groups (of 4 columns of Y) owned by this wave
+    constexpr int NSET = BF ? 4/JH : 1;    // BF: sets of four frequencies owned by this wave
+    constexpr int TS = mfma4_tile_stride(BF);
+    constexpr int kMaxStage = D == 16 ? (MAXW < 8 ? 8 : 4) : 8;   // staged elements per thread (see launch_d4)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int na = nw/JH;             // noise operators per block
     const int kops = (1 + na)*DD;
     cplx* tile = reinterpret_cast<cplx*>(lds_raw);
-    cplx* opsb = tile + DD*16;
+    cplx* opsb = tile + DD*TS;
     double* rows = reinterpret_cast<double*>(opsb + 2*kops);
 
     const int tid = threadIdx.x;
@@ -259,20 +278,23 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     const int c = lane & 15, q = lane >> 4, c4 = c & 3;
     const int iw = blockIdx.x*16 + c;
     const double om = omega[iw < W ? iw : W - 1];
-    const int alpha0 = blockIdx.y*na;
+    const int alpha0 = alpha_base + blockIdx.y*na;   // the launch serves operators [alpha_base, alpha_end)
     const int alpha_l = wave / JH, jh = wave % JH;
     const int alpha = alpha0 + alpha_l;
-    const bool active = alpha < A;
-    const int n_alpha = min(na, A - alpha0);
+    const bool active = alpha < alpha_end;
+    const int n_alpha = min(na, alpha_end - alpha0);
     const int n_ops = (1 + n_alpha)*DD;
     const int g0 = blockIdx.z*chunk_len;
     const int g1 = min(G, g0 + chunk_len);
 
-    double Yr[NS][4*NJG], Yi[NS][4*NJG];   // [row group ig][own column]
+    // [row group ig][own column]; BF: [set*NS + ig][jg] = Y[4 ig + q][4 jg + (c & 3)] of frequency
+    // 4 (jh NSET + set) + (c >> 2)
+    constexpr int YA = BF ? NSET*NS : NS, YB = BF ? NS : 4*NJG;
+    double Yr[YA][YB], Yi[YA][YB];
 #pragma unroll
-    for (int ig = 0; ig < NS; ++ig)
+    for (int ig = 0; ig < YA; ++ig)
 #pragma unroll
-        for (int j = 0; j < 4*NJG; ++j) {
+        for (int j = 0; j < YB; ++j) {
             Yr[ig][j] = 0.0;
             Yi[ig][j] = 0.0;
         }
@@ -284,10 +306,10 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
 #pragma unroll
         for (int k = 0; k < kMaxStage; ++k) {
             const int e = tid + k*nthreads;
-            if (e < n_ops)
-                staged[k] = src_ops[e < DD ? e : e + alpha0*DD];
-            else if (e < n_ops + S/2)
-                staged[k] = src_tab[e - n_ops];
+            // (one unconditional assignment per element: with the two guarded ones the array stayed in
+            // scratch memory)
+            const cplx* src = e < n_ops ? src_ops + (e < DD ? e : e + alpha0*DD) : src_tab + (e - n_ops);
+            staged[k] = e < n_ops + S/2 ? *src : cplx{0.0, 0.0};
         }
     };
     auto park = [&](int buf) {
@@ -311,7 +333,7 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
         sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
         for (int e = wave*4 + q; e < DD; e += 4*nw) {
             const double* r = st + seg_rec(e);
-            tile[e*16 + c] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+            tile[e*TS + c] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
         }
     };
     // v_mfma_f64: the last builtin argument carries the NEG bits of the operands (bit 0 = A)
@@ -386,6 +408,63 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
         }
     };
 
+    auto contract_bf = [&](int buf) {
+        const cplx* opT = opsb + buf*kops;
+        const cplx* opB = opT + (1 + alpha_l)*DD;
+        cplx tq[NS][NS];                              // T[4 s + q][4 g + c4]
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int g = 0; g < NS; ++g) tq[s][g] = opT[(4*s + q)*D + 4*g + c4];
+        // One set of four frequencies at a time, one column group ng of X at a time: next to the
+        // accumulators and T only (d/4) products P and one X entry are live (d = 16: 128 + 64 + 16
+        // registers).  Bbar's entry is read again per set -- holding the d^2/16 of them does not fit.
+#pragma unroll
+        for (int set = 0; set < NSET; ++set) {
+            const cplx* ecol = tile + 4*(jh*NSET + set) + (c >> 2);     // + slot*TS
+#pragma unroll
+            for (int ng = 0; ng < NS; ++ng) {
+                // (keeps the scheduler from hoisting the LDS reads of later groups over this one's
+                // products: without it the fully unrolled body spills)
+                __builtin_amdgcn_sched_barrier(0);
+                double pr[NS], pi[NS];                // P[4 ng + q][4 ig + c4]
+#pragma unroll
+                for (int ig = 0; ig < NS; ++ig) {
+                    pr[ig] = 0.0;
+                    pi[ig] = 0.0;
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int e = (4*s + q)*D + 4*ng + c4;
+                    const cplx x = cmul(opB[e], ecol[e*TS]);  // X[4 s + q][4 ng + c4]
+#pragma unroll
+                    for (int ig = 0; ig < NS; ++ig) {
+                        pr[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, tq[s][ig].re, pr[ig], 0, 0, 0);
+                        pi[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.im, tq[s][ig].re, pi[ig], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int ig = 0; ig < NS; ++ig) {
+                        pr[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.im, tq[s][ig].im, pr[ig], 0, 0, 0);
+                        pi[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, tq[s][ig].im, pi[ig], 0, 0, 1);
+                    }
+                }
+#pragma unroll
+                for (int ig = 0; ig < NS; ++ig) {
+#pragma unroll
+                    for (int jg = 0; jg < NS; ++jg) {
+                        Yr[set*NS + ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr[ig], tq[ng][jg].re, Yr[set*NS + ig][jg], 0, 0, 0);
+                        Yi[set*NS + ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr[ig], tq[ng][jg].im, Yi[set*NS + ig][jg], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int jg = 0; jg < NS; ++jg) {
+                        Yr[set*NS + ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi[ig], tq[ng][jg].im, Yr[set*NS + ig][jg], 0, 0, 1);
+                        Yi[set*NS + ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi[ig], tq[ng][jg].re, Yi[set*NS + ig][jg], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
     if (g0 < g1) {
         issue_stage(g0);
         park(0);
@@ -393,18 +472,44 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     for (int g = g0; g < g1; ++g) {
         const int buf = (g - g0) & 1;
         __syncthreads();
+        if constexpr (BF) {
+            // the staging loads of segment g + 1 fly during the generation, not the contraction,
+            // whose accumulators, T entries and products leave no registers for them (d = 16)
+            if (g + 1 < g1) issue_stage(g + 1);
+            generate(buf);
+            if (g + 1 < g1) park(buf ^ 1);   // buffer buf ^ 1: last read before this barrier interval
+            __syncthreads();
+            if (active) contract_bf(buf);
+        } else {
 #if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 1)
-        generate(buf);
+            generate(buf);
 #endif
-        __syncthreads();
-        if (g + 1 < g1) issue_stage(g + 1);
+            __syncthreads();
+            if (g + 1 < g1) issue_stage(g + 1);
 #if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 2)
-        if (active) contract(buf);
+            if (active) contract(buf);
 #endif
-        if (g + 1 < g1) park(buf ^ 1);
+            if (g + 1 < g1) park(buf ^ 1);
+        }
     }
 
-    if (active && iw < W) {
+    if constexpr (BF) {
+        if (active) {
+            cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W;
+#pragma unroll
+            for (int set = 0; set < NSET; ++set) {
+                const int iws = blockIdx.x*16 + 4*(jh*NSET + set) + (c >> 2);
+                if (iws < W) {
+#pragma unroll
+                    for (int ig = 0; ig < NS; ++ig)
+#pragma unroll
+                        for (int jg = 0; jg < NS; ++jg)
+                            out[static_cast<size_t>((4*ig + q)*D + 4*jg + c4)*W + iws] =
+                                {Yr[set*NS + ig][jg], Yi[set*NS + ig][jg]};
+                }
+            }
+        }
+    } else if (active && iw < W) {
         cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W + iw;
 #pragma unroll
         for (int ig = 0; ig < NS; ++ig)
@@ -414,20 +519,21 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     }
 }
 
-template <int D, int JH>
+template <int D, int JH, bool BF = false>
 size_t mfma4_lds_bytes(int nw) {
-    return (static_cast<size_t>(D*D)*16 + 2*static_cast<size_t>(1 + nw/JH)*D*D)*sizeof(cplx) +
+    return (static_cast<size_t>(D*D)*mfma4_tile_stride(BF) + 2*static_cast<size_t>(1 + nw/JH)*D*D)*sizeof(cplx) +
            2*static_cast<size_t>(seg_stride(D))*sizeof(double);
 }
 
-template <int D, int JH, int MAXW = 8>
+template <int D, int JH, int MAXW = 8, bool BF = false>
 hipError_t launch_d4(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
-                     int chunks, int chunk_len, int nw, cplx* Ypart, hipStream_t stream) {
-    auto kern = ctrl_accumulate_mfma4_kernel<D, JH, MAXW>;
+                     int chunks, int chunk_len, int nw, cplx* Ypart, hipStream_t stream,
+                     int alpha_base = 0, int alpha_end = -1) {
+    auto kern = ctrl_accumulate_mfma4_kernel<D, JH, MAXW, BF>;
     if (nw > MAXW) return hipErrorInvalidValue;
-    const int lds = static_cast<int>(mfma4_lds_bytes<D, JH>(nw));
+    const int lds = static_cast<int>(mfma4_lds_bytes<D, JH, BF>(nw));
     // staging: (1 + na) d^2 + row/2 elements over nw*64 threads must fit kMaxStage per thread
-    constexpr int kMaxStage = D == 16 ? 4 : 8;
+    constexpr int kMaxStage = D == 16 ? (MAXW < 8 ? 8 : 4) : 8;
     if (nw % JH != 0 || (1 + nw/JH)*D*D + seg_stride(D)/2 > kMaxStage*nw*64) return hipErrorInvalidValue;
     if (lds > 48*1024) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -435,9 +541,11 @@ hipError_t launch_d4(const double* omega, int W, const double* segtab, const cpl
         if (err != hipSuccess) return err;
     }
     const int na = nw/JH;
-    const dim3 grid((W + 15)/16, (A + na - 1)/na, chunks);
+    // operators [alpha_base, alpha_end) of the A the arrays are laid out for
+    if (alpha_end < 0) alpha_end = A;
+    const dim3 grid((W + 15)/16, (alpha_end - alpha_base + na - 1)/na, chunks);
     hipLaunchKernelGGL(kern, grid, dim3(nw*64), lds, stream, omega, W, segtab, ops, G, A, chunk_len,
-                       nw, Ypart);
+                       nw, Ypart, alpha_base, alpha_end);
     return hipGetLastError();
 }
 
@@ -462,11 +570,23 @@ hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx
 //   d = 16 (13 segments, 18 operators, 16384 omega): 16x16x4 6.7 ms, JH = 2 5.4 ms, JH = 4 6.5 ms
 //   d = 12 (64 segments, 6 operators, 8192 omega):   16x16x4 3.4 ms, JH = 1 2.4 ms, JH = 3 3.3 ms
 // -- two wavefronts per SIMD beat the wider tile.  FFK_TUNE_MFMA_JH overrides (tuning).
+// FFK_TUNE_MFMA_BF: 1 = the block-frequency form of the 4x4x4 kernel (d = 12, 16), 0 = frequency on
+// the columns.  With it JH counts the wavefronts that share an operator's 16 frequencies (1, 2, 4).
+static bool mfma_block_frequency(int d) {
+    static const int env = [] {
+        const char* e = std::getenv("FFK_TUNE_MFMA_BF");
+        return e ? std::atoi(e) : -1;
+    }();
+    if (d != 12 && d != 16) return false;
+    return env < 0 ? FFK_MFMA_BF_DEFAULT : env != 0;
+}
+
 static int mfma_column_split(int d) {
     static const int env = [] {
         const char* e = std::getenv("FFK_TUNE_MFMA_JH");
         return e ? std::atoi(e) : -1;
     }();
+    if (mfma_block_frequency(d)) return (env == 1 || env == 2 || env == 4) ? env : 2;
     const int def = d == 16 ? 2 : 1;
     if (env < 0) return def;
     const bool ok = (d == 16 && (env == 0 || env == 2 || env == 4)) ||
@@ -497,7 +617,8 @@ int mfma_accumulate_ops_per_block(int d, int A) {
         }
         return std::min(best, std::max(A, 3));
     }
-    if (d == 16 && jh == 4) return 3;  // twelve wavefronts per block (tuning variant)
+    if (d == 16 && jh == 4 && !mfma_block_frequency(d)) return 3;  // twelve wavefronts per block (tuning variant)
+    if (d == 16 && jh == 1 && mfma_block_frequency(d)) return 4;   // one wavefront per SIMD, 512 registers
     return std::max(1, 8/jh);         // eight wavefronts per block
 }
 int mfma_accumulate_waves(int d, int A) {
@@ -506,6 +627,11 @@ int mfma_accumulate_waves(int d, int A) {
 }
 int mfma_accumulate_lds_bytes(int d, int nw) {
     const int jh = mfma_column_split(d);
+    if (mfma_block_frequency(d)) {
+#define FFK_BF_LDS(D, JH) if (d == D && jh == JH) return static_cast<int>(mfma4_lds_bytes<D, JH, true>(nw));
+        FFK_BF_LDS(12, 1) FFK_BF_LDS(12, 2) FFK_BF_LDS(12, 4) FFK_BF_LDS(16, 1) FFK_BF_LDS(16, 2) FFK_BF_LDS(16, 4)
+#undef FFK_BF_LDS
+    }
     switch (d) {
         case 4:
             return static_cast<int>(mfma4_lds_bytes<4, 1>(nw));
@@ -529,6 +655,40 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
                                   int G, int d, int A, int chunks, int chunk_len, int nw,
                                   cplx* Ypart, hipStream_t stream) {
     const int jh = mfma_column_split(d);
+    if (mfma_block_frequency(d)) {
+        // Two wavefronts per operator make blocks of four operators: one or two left over would
+        // leave a whole row of blocks half or three quarters idle (config 5: 18 = 4 x 4 + 2).  They
+        // get a launch of their own with four wavefronts per operator (one set of four frequencies
+        // each), i.e. blocks of two operators (a single one leaves four of the eight wavefronts without a
+        // contraction; they still generate): 4.77 -> 4.66 ms at config 5.
+        static const bool split_rest = [] {
+            const char* e = std::getenv("FFK_TUNE_MFMA_REST");
+            return e == nullptr || e[0] != '0';
+        }();
+        const int rest = A % 4;
+        if (split_rest && jh == 2 && nw == 8 && (rest == 1 || rest == 2)) {
+            const int main_ops = A - rest;
+#define FFK_BF_SPLIT(D) \
+    if (d == D) { \
+        if (main_ops > 0) { \
+            const hipError_t err = launch_d4<D, 2, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, 8, \
+                                                            Ypart, stream, 0, main_ops); \
+            if (err != hipSuccess) return err; \
+        } \
+        return launch_d4<D, 4, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, 8, Ypart, stream, \
+                                        main_ops, A); \
+    }
+            FFK_BF_SPLIT(12) FFK_BF_SPLIT(16)
+#undef FFK_BF_SPLIT
+        }
+#define FFK_BF(D, JH) \
+    if (d == D && jh == JH) \
+        return launch_d4<D, JH, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);
+        FFK_BF(12, 1) FFK_BF(12, 2) FFK_BF(12, 4) FFK_BF(16, 2) FFK_BF(16, 4)
+#undef FFK_BF
+        if (d == 16 && jh == 1)
+            return launch_d4<16, 1, 4, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);
+    }
 #define FFK_M4(D, JH) \
     if (d == D && jh == JH) \
         return launch_d4<D, JH>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);

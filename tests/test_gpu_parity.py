@@ -730,11 +730,13 @@ def test_noise_operator_step_cache():
 
 
 @pytest.mark.parametrize('d,G,A,W', [(4, 9, 3, 100), (4, 20, 5, 47), (8, 7, 3, 100), (12, 5, 5, 33), (16, 6, 2, 16), (16, 3, 9, 50),
-                                      (8, 20, 1, 257)])
+                                      (8, 20, 1, 257), (16, 4, 6, 35), (12, 4, 1, 20), (12, 3, 3, 17),
+                                      (16, 2, 7, 19), (12, 6, 10, 64)])
 def test_matrix_core_accumulate_kernel_matches_vector_kernel(d, G, A, W):
-    """ctrl_mfma.hip (v_mfma_f64_16x16x4, frequency = tile column) against ctrl.hip on the same
-    inputs: ragged frequency tiles (W not a multiple of 16), operator counts that do not fill a
-    block, d = 12 (partial tiles), several segment chunks."""
+    """ctrl_mfma.hip (matrix cores; d = 12, 16: one frequency per 4 x 4 x 4 block) against ctrl.hip
+    on the same inputs: ragged frequency tiles (W not a multiple of 16), operator counts that do not
+    fill a block -- with and without the separate launch for the one or two operators left over
+    from blocks of four --, d = 12, several segment chunks."""
     rng = np.random.default_rng(d*1000 + W)
     basis = ff.Basis.ggm(d)
     c_opers = rng.standard_normal((3, d, d)) + 1j*rng.standard_normal((3, d, d))
