@@ -741,6 +741,8 @@ int query_blocks_per_cu(int d, int nwaves, int nbuf, int lds_bytes) {
     return n;
 }
 
+}  // namespace
+
 int device_cu_count() {
     static int cus = 0;
     if (cus == 0) {
@@ -752,6 +754,8 @@ int device_cu_count() {
     }
     return cus;
 }
+
+namespace {
 
 }  // namespace
 

@@ -65,6 +65,30 @@ __device__ __forceinline__ void xcd_block(unsigned& bx, unsigned& by) {
     by = v / gridDim.x;
 }
 
+#ifdef FFK_DG_CLOCK   /* tuning build: which clock does the chip hold inside the decay GEMM? */
+__device__ unsigned long long g_dg_clock[3];
+#define FFK_DG_CLOCK_BEGIN \
+    const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
+__device__ unsigned long long g_dg_trace[3*8192];   // per block: start, end (100 MHz ticks), HW_ID | XCC_ID << 32
+#define FFK_DG_CLOCK_END \
+    if (threadIdx.x == 0) { \
+        const unsigned long long dg_r1 = __builtin_amdgcn_s_memrealtime(); \
+        atomicAdd(&g_dg_clock[0], __builtin_amdgcn_s_memtime() - dg_c0); \
+        atomicAdd(&g_dg_clock[1], dg_r1 - dg_r0); \
+        atomicAdd(&g_dg_clock[2], 1ull); \
+        const unsigned dg_l = blockIdx.x + gridDim.x*blockIdx.y; \
+        if (dg_l < 8192) { \
+            g_dg_trace[3*dg_l] = dg_r0; \
+            g_dg_trace[3*dg_l + 1] = dg_r1; \
+            g_dg_trace[3*dg_l + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | \
+                                     (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11))) << 32); \
+        } \
+    }
+#else
+#define FFK_DG_CLOCK_BEGIN
+#define FFK_DG_CLOCK_END
+#endif
+
 // One wavefront: a (16 TM) x (16 TN) tile of one Gamma[g,h,a,b] over the block's frequency range.
 // MFMA operand maps: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
 // D[row = (lane>>4) + 4 r][col = lane&15] (cdna_hip_programming.md section 3).
@@ -73,15 +97,43 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
     const cplx* __restrict__ R, int Gp, int A, int N, int W, const cplx* __restrict__ scale,
     int s_ndim, const int32_t* __restrict__ idx, int n_idx, int kchunk, int tiles_m, int tiles_n,
     double* __restrict__ out, size_t split_stride, int mirror_in_store,
-    const int* __restrict__ complex_weights) {
+    const int* __restrict__ complex_weights, int tri) {
     const int lane = threadIdx.x;
     const int l15 = lane & 15, lk = lane >> 4;
-    const int tiles = tiles_m*tiles_n;
+    // tri: which tiles of a Gamma block the grid enumerates -- 0 all tiles_m x tiles_n, 1 those on
+    // and above the diagonal, 2 those strictly below it (square tiles).  A grid must not contain
+    // blocks that return at once next to blocks that work: the dispatcher hands blocks to wavefront
+    // slots in strict rotation, and the slots that received an empty block stay empty until the
+    // rotation comes round again.  With all 16 tiles of config 5's 256 x 256 blocks in one grid and
+    // the six below the diagonal returning, 80 of an XCD's 128 slots (= 10/16) held a wavefront at
+    // any time and the kernel took 1.63 ms instead of 0.9 (profiles/r03_m_*).
+    const int tiles = tri == 0 ? tiles_m*tiles_n : (tri == 1 ? tiles_m*(tiles_m + 1)/2 : tiles_m*(tiles_m - 1)/2);
     unsigned bx, by;
     xcd_block(bx, by);
     const int tile = bx % tiles;
-    int z = bx / tiles;
-    const int ti = tile / tiles_n, tj = tile % tiles_n;
+    const int z0 = bx / tiles;
+    int z = z0;
+    int ti, tj;
+    if (tri == 0) {
+        ti = tile / tiles_n;
+        tj = tile % tiles_n;
+    } else if (tri == 1) {
+        ti = 0;
+        int rem = tile;
+        while (rem >= tiles_m - ti) {
+            rem -= tiles_m - ti;
+            ++ti;
+        }
+        tj = ti + rem;
+    } else {
+        ti = 1;
+        int rem = tile;
+        while (rem >= ti) {
+            rem -= ti;
+            ++ti;
+        }
+        tj = rem;
+    }
     const int nb = s_ndim == 3 ? n_idx : 1;
     const int ib0 = z % nb;
     z /= nb;
@@ -118,6 +170,7 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
 
     const int wbeg = by*kchunk;
     const int wend = min(W, wbeg + kchunk);
+    FFK_DG_CLOCK_BEGIN
     for (int w0 = wbeg; w0 < wend; w0 += 16) {
         cplx a[TM][4], b[TN][4];
 #pragma unroll
@@ -150,7 +203,8 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
                                                                        acc[tm][tn], 0, 0, 0);
         }
     }
-    double* o = out + static_cast<size_t>(by)*split_stride + static_cast<size_t>(bx / tiles)*N*N;
+    FFK_DG_CLOCK_END
+    double* o = out + static_cast<size_t>(by)*split_stride + static_cast<size_t>(z0)*N*N;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -398,6 +452,7 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const double* __rest
 struct DecayPlan {
     int tm, tn, tiles_m, tiles_n, ksplit, kchunk;
     size_t batch;
+    bool tri;       // register-fed kernel: one grid for the tiles on and above the diagonal, one for the rest
     bool lds;       // decay_gemm_lds_kernel: 128 x 128 block tiles (tiles_m = tiles_n = ceil(N / 128))
 };
 
@@ -418,6 +473,7 @@ bool decay_lds_enabled() {
 DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
     DecayPlan p;
     p.lds = false;
+    p.tri = false;
     if (N >= 128 && decay_lds_enabled()) {
         p.lds = true;
         p.tm = p.tn = 4;
@@ -460,12 +516,29 @@ DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
     p.tiles_m = (N + 16*p.tm - 1)/(16*p.tm);
     p.tiles_n = (N + 16*p.tn - 1)/(16*p.tn);
     p.batch = static_cast<size_t>(Gp)*Gp*n_idx*(s_ndim == 3 ? n_idx : 1);
-    const size_t waves = p.batch*p.tiles_m*p.tiles_n;
-    // enough wavefronts for 256 CUs x 8, at least 64 frequencies per split
-    size_t want = (4096 + waves - 1)/waves;
-    const size_t max_split = static_cast<size_t>((W + 63)/64);
-    if (want > max_split) want = max_split;
-    if (want < 1) want = 1;
+    // one pulse with itself, spectrum of one or two dimensions: Gamma is symmetric for real weights
+    // and only the tiles on and above the diagonal work (see the kernel's `tri`)
+    p.tri = p.tm == p.tn && s_ndim != 3 && Gp == 1;
+    const size_t waves = p.batch*(p.tri ? static_cast<size_t>(p.tiles_m)*(p.tiles_m + 1)/2
+                                        : static_cast<size_t>(p.tiles_m)*p.tiles_n);
+    // Split the frequency axis so that the working wavefronts fill whole rounds of the chip's
+    // wavefront slots (64 x 64 tiles: 332 registers, one per SIMD; 32 x 32: three; 16 x 16: six), at
+    // least 64 frequencies per split.  Cost in steps of 16 frequencies: rounds x (steps per
+    // wavefront + its prologue / epilogue) + one step's worth per split for the reduction kernel.
+    const size_t slots = static_cast<size_t>(device_cu_count())*4*(t == 4 ? (p.tn == 4 ? 1 : 2) : (t == 2 ? 3 : 6));
+    const int max_split = std::max(1, (W + 63)/64);
+    long best = -1;
+    int want = 1;
+    for (int split = 1; split <= max_split; ++split) {
+        const int chunk = ((W + split - 1)/split + 15)/16*16;
+        const int nsplit = (W + chunk - 1)/chunk;
+        const long rounds = static_cast<long>((waves*nsplit + slots - 1)/slots);
+        const long cost = rounds*(chunk/16 + 8) + (nsplit > 1 ? nsplit : 0);
+        if (best < 0 || cost < best) {
+            best = cost;
+            want = split;
+        }
+    }
     p.kchunk = static_cast<int>(((W + want - 1)/want + 15)/16*16);
     if (const char* e = std::getenv("FFK_TUNE_DECAY_KCHUNK")) {      // tuning
         const int v = std::atoi(e);
@@ -657,22 +730,28 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
         hipLaunchKernelGGL(kern, grid, dim3(256), kDgLdsBytes, stream, R, Gp, A, N, W,
                            scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, dst, n, mirror,
                            complex_weights);
-    } else if (p.tm == 1)
-        hipLaunchKernelGGL((decay_gemm_kernel<1, 1>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror,
-                           complex_weights);
-    else if (p.tm == 2)
-        hipLaunchKernelGGL((decay_gemm_kernel<2, 2>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror,
-                           complex_weights);
-    else if (p.tn == 2)
-        hipLaunchKernelGGL((decay_gemm_kernel<4, 2>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror,
-                           complex_weights);
-    else
-        hipLaunchKernelGGL((decay_gemm_kernel<4, 4>), grid, dim3(64), 0, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror,
-                           complex_weights);
+    } else {
+        // p.tri: the tiles on and above the diagonal, then (if there are any) those below it, whose
+        // blocks all return at once when the weights are real
+        const int t_all = p.tiles_m*p.tiles_n, t_up = p.tiles_m*(p.tiles_m + 1)/2;
+        for (int pass = 0; pass < (p.tri && p.tiles_m > 1 ? 2 : 1); ++pass) {
+            const int tri = p.tri ? 1 + pass : 0;
+            const size_t nblk = p.batch*(tri == 0 ? t_all : (tri == 1 ? t_up : t_all - t_up));
+            const dim3 g(static_cast<unsigned>(nblk), p.ksplit);
+#define FFK_DG_LAUNCH(TM, TN) \
+    hipLaunchKernelGGL((decay_gemm_kernel<TM, TN>), g, dim3(64), 0, stream, R, Gp, A, N, W, scale, s_ndim, \
+                       idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror, complex_weights, tri)
+            if (p.tm == 1)
+                FFK_DG_LAUNCH(1, 1);
+            else if (p.tm == 2)
+                FFK_DG_LAUNCH(2, 2);
+            else if (p.tn == 2)
+                FFK_DG_LAUNCH(4, 2);
+            else
+                FFK_DG_LAUNCH(4, 4);
+#undef FFK_DG_LAUNCH
+        }
+    }
     if (p.ksplit > 1)
         hipLaunchKernelGGL(reduce_splits_kernel, dim3(static_cast<unsigned>((n + 255)/256)),
                            dim3(256), 0, stream, part, p.ksplit, n, N,
@@ -820,3 +899,18 @@ hipError_t launch_expm_real(const double* A, int N, int squarings, double* out, 
 }
 
 }  // namespace ffk
+
+#ifdef FFK_DG_CLOCK
+// (tuning build only, not in include/ffk.h) sums since the last call: shader-clock ticks,
+// 100 MHz ticks, wavefronts
+extern "C" int ffk_debug_dg_clock(unsigned long long* out3) {
+    unsigned long long zero[3] = {0, 0, 0};
+    if (hipMemcpyFromSymbol(out3, HIP_SYMBOL(ffk::g_dg_clock), sizeof(zero)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(ffk::g_dg_clock), zero, sizeof(zero)) != hipSuccess;
+}
+extern "C" int ffk_debug_dg_trace(unsigned long long* out, int n_blocks) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ffk::g_dg_trace), sizeof(unsigned long long)*3*n_blocks) != hipSuccess)
+        return 1;
+    return hipMemset(nullptr, 0, 0) != hipSuccess && false;
+}
+#endif

@@ -131,6 +131,7 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
                              hipStream_t stream);
 
 // ---- ctrl_mfma.hip ---------------------------------------------------------------------------
+int device_cu_count();   // compute units of the current device (ctrl.hip)
 bool mfma_accumulate_supported(int d);
 int mfma_accumulate_waves(int d, int A);
 int mfma_accumulate_ops_per_block(int d, int A);

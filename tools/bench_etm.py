@@ -68,6 +68,40 @@ def main():
             ts.append(e0.elapsed_time(e1))
         t = float(np.median(ts))
         print(f'{name:18s} d={d} A={A} W={W}: {t:8.3f} ms  {flops/t/1e9:8.2f} TFLOP/s')
+        if name.startswith('decay') and hasattr(lib, 'ffk_debug_dg_clock'):
+            # tuning build -DFFK_DG_CLOCK: shader-clock and 100 MHz ticks summed over the GEMM's wavefronts
+            c = (ctypes.c_ulonglong*3)()
+            lib.ffk_debug_dg_clock(c)
+            print(f'  in-kernel clock of the GEMM wavefronts: {c[0]/max(c[1], 1)*100:.0f} MHz '
+                  f'({c[2]} wavefronts, {c[1]/max(c[2], 1)/100:.1f} us each)')
+            if hasattr(lib, 'ffk_debug_dg_trace'):
+                # per-block start / end / hardware id of the LAST launch: who ran where and when
+                nblk = 8192
+                tr = (ctypes.c_ulonglong*(3*nblk))()
+                lib.ffk_debug_dg_trace(tr, nblk)
+                tr = np.array(tr, dtype=np.uint64).reshape(nblk, 3)
+                tr = tr[tr[:, 1] > 0]
+                t0 = tr[:, 0].min()
+                start = (tr[:, 0] - t0)/100.0
+                end = (tr[:, 1] - t0)/100.0
+                hw = tr[:, 2] & 0xffffffff
+                xcc = (tr[:, 2] >> 32) & 0xf
+                cu = (hw >> 8) & 0xf
+                sh = (hw >> 12) & 0x1
+                se = (hw >> 13) & 0x7
+                simd = (hw >> 4) & 0x3
+                print(f'  trace: {len(tr)} working blocks, span {end.max():.0f} us')
+                edges = np.linspace(0, end.max(), 21)
+                for lo, hi in zip(edges[:-1], edges[1:]):
+                    mid = 0.5*(lo + hi)
+                    live = (start <= mid) & (end > mid)
+                    per_xcc = [int((live & (xcc == x)).sum()) for x in range(8)]
+                    print(f'    t = {mid:7.1f} us: {int(live.sum()):5d} wavefronts live, per XCD {per_xcc}')
+                slot = xcc*4096 + se*512 + sh*256 + cu*4 + simd
+                print(f'  distinct (XCD, SE, SH, CU, SIMD) slots used: {len(np.unique(slot))}; '
+                      f'distinct (XCD, SE, SH, CU): {len(np.unique(slot >> 2))}')
+                first = start < 5.0
+                print(f'  blocks started in the first 5 us: {int(first.sum())}')
     # spot check against float64 torch on one operator
     wgt = torch.zeros(W, dtype=torch.float64, device=dev)
     wgt[:-1] += 0.5*(omega[1:] - omega[:-1])
