@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, FFK_DG_WAVES) void decay_gemm_lds_kernel(
     const cplx* __restrict__ R, int Gp, int A, int N, int W, const cplx* __restrict__ scale,
     int s_ndim, const int32_t* __restrict__ idx, int n_idx, int kchunk, int tiles,
     double* __restrict__ out, size_t split_stride, int mirror_in_store,
-    const int* __restrict__ complex_weights) {
+    const int* __restrict__ complex_weights, int tri) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     cplx* As = reinterpret_cast<cplx*>(lds_raw);                       // [2][128][17]
     cplx* Bs = As + 2*kDgRows*kDgStride;
@@ -251,12 +251,33 @@ __global__ __launch_bounds__(256, FFK_DG_WAVES) void decay_gemm_lds_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lk = lane >> 4;
-    const int ntile = tiles*tiles;
+    // (tri as in decay_gemm_kernel: 0 all block tiles, 1 on and above the diagonal, 2 below it)
+    const int ntile = tri == 0 ? tiles*tiles : (tri == 1 ? tiles*(tiles + 1)/2 : tiles*(tiles - 1)/2);
     unsigned bx, by;
     xcd_block(bx, by);
     const int tile = bx % ntile;
     int z = bx / ntile;
-    const int ti = tile / tiles, tj = tile % tiles;
+    int ti, tj;
+    if (tri == 0) {
+        ti = tile / tiles;
+        tj = tile % tiles;
+    } else if (tri == 1) {
+        ti = 0;
+        int rem = tile;
+        while (rem >= tiles - ti) {
+            rem -= tiles - ti;
+            ++ti;
+        }
+        tj = ti + rem;
+    } else {
+        ti = 1;
+        int rem = tile;
+        while (rem >= ti) {
+            rem -= ti;
+            ++ti;
+        }
+        tj = rem;
+    }
     const int nb = s_ndim == 3 ? n_idx : 1;
     const int ib0 = z % nb;
     z /= nb;
@@ -727,9 +748,15 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
                                               hipFuncAttributeMaxDynamicSharedMemorySize,
                                               static_cast<int>(kDgLdsBytes));
         if (aerr != hipSuccess) return aerr;
-        hipLaunchKernelGGL(kern, grid, dim3(256), kDgLdsBytes, stream, R, Gp, A, N, W,
-                           scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, dst, n, mirror,
-                           complex_weights);
+        const bool tri_ok = s_ndim != 3 && Gp == 1;
+        const int t_all = p.tiles_m*p.tiles_m, t_up = p.tiles_m*(p.tiles_m + 1)/2;
+        for (int pass = 0; pass < (tri_ok && p.tiles_m > 1 ? 2 : 1); ++pass) {
+            const int tri = tri_ok ? 1 + pass : 0;
+            const size_t nblk = p.batch*(tri == 0 ? t_all : (tri == 1 ? t_up : t_all - t_up));
+            hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblk), p.ksplit), dim3(256), kDgLdsBytes, stream,
+                               R, Gp, A, N, W, scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, dst, n, mirror,
+                               complex_weights, tri);
+        }
     } else {
         // p.tri: the tiles on and above the diagonal, then (if there are any) those below it, whose
         // blocks all return at once when the weights are real
