@@ -109,6 +109,43 @@ __global__ __launch_bounds__(64) void expand_sparse_kernel(const cplx* __restric
     }
 }
 
+// The same with ALL basis elements of an (operator, 64 frequencies) tile in one block of four
+// wavefronts, each walking a contiguous quarter of the elements in step with the others.  Elements
+// that share their support are then read close together in time and the second reader finds the
+// rows of Y in L2: GGM's symmetric element of a pair (i, j) is number 1 + p, the antisymmetric one
+// d(d-1)/2 + 1 + p -- a quarter and a bit apart, i.e. a few steps.  With the elements spread over
+// grid.z (above) the second read came from HBM: config 5 0.80 -> 0.69 ms.  (Two elements per trip, their four
+// rows requested together: no further gain.)
+__global__ __launch_bounds__(256) void expand_sparse_quarters_kernel(const cplx* __restrict__ Bt,
+                                                                     const int* __restrict__ nnz,
+                                                                     const int* __restrict__ rows,
+                                                                     const cplx* __restrict__ vals,
+                                                                     int N, int dd, int W,
+                                                                     cplx* __restrict__ R, int want_sparse) {
+    if (want_sparse >= 0 && basis_is_sparse(nnz, N, dd) != (want_sparse != 0)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = blockIdx.x*64 + lane;
+    const int a = blockIdx.y;
+    if (w >= W) return;
+    const cplx* b = Bt + static_cast<size_t>(a)*dd*W + w;
+    const int quarter = (N + 3)/4;
+    const int k1 = min(N, (wave + 1)*quarter);
+    for (int k = wave*quarter; k < k1; ++k) {
+        const int n = nnz[k];
+        const int* rk = rows + static_cast<size_t>(k)*dd;
+        const cplx* vk = vals + static_cast<size_t>(k)*dd;
+        cplx acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+        int q = 0;
+        for (; q + 1 < n; q += 2) {
+            cmac(acc0, vk[q], b[static_cast<size_t>(rk[q])*W]);
+            cmac(acc1, vk[q + 1], b[static_cast<size_t>(rk[q + 1])*W]);
+        }
+        if (q < n) cmac(acc0, vk[q], b[static_cast<size_t>(rk[q])*W]);
+        R[(static_cast<size_t>(a)*N + k)*W + w] = {acc0.re + acc1.re, acc0.im + acc1.im};
+    }
+}
+
 // out[w,a,i,j] = Bt[a,i,j,w]; a (A*d*d) x W transpose through LDS, 64 x 64 tiles
 __global__ __launch_bounds__(256) void transpose_kernel(const cplx* __restrict__ in, int rows,
                                                         int cols, cplx* __restrict__ out) {
@@ -577,6 +614,15 @@ hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d
         // both forms, each deciding on the device whether the basis is its kind (see basis_is_sparse)
         hipError_t err = launch_expand_lds(Bt, 1, 0, A2, N, d, W, R, ws, stream, 0);
         if (err != hipSuccess) return err;
+        static const bool quarters = [] {             // FFK_TUNE_EXPAND_QUARTERS=0: elements over grid.z
+            const char* e = std::getenv("FFK_TUNE_EXPAND_QUARTERS");
+            return e == nullptr || e[0] != '0';
+        }();
+        if (quarters && N >= 64 && static_cast<long>((W + 63)/64)*A2 >= 1024) {
+            hipLaunchKernelGGL(expand_sparse_quarters_kernel, dim3((W + 63)/64, A2), dim3(256), 0, stream, Bt,
+                               nnz, rows, vals, N, static_cast<int>(dd), W, R, 1);
+            return hipGetLastError();
+        }
         constexpr int KT = 8;
         hipLaunchKernelGGL(expand_sparse_kernel<KT>, dim3((W + 63)/64, A2, (N + KT - 1)/KT), dim3(64),
                            0, stream, Bt, nnz, rows, vals, N, static_cast<int>(dd), W, R, 1);
