@@ -476,10 +476,14 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
             // the staging loads of segment g + 1 fly during the generation, not the contraction,
             // whose accumulators, T entries and products leave no registers for them (d = 16)
             if (g + 1 < g1) issue_stage(g + 1);
+#if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 1)   /* diagnostic build 1: no generation */
             generate(buf);
+#endif
             if (g + 1 < g1) park(buf ^ 1);   // buffer buf ^ 1: last read before this barrier interval
             __syncthreads();
+#if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 2)   /* diagnostic build 2: no contraction */
             if (active) contract_bf(buf);
+#endif
         } else {
 #if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 1)
             generate(buf);
