@@ -120,17 +120,19 @@ class ResidentResult:
         G, W, N, A = len(dt), len(omega), len(C), len(B)
         out = [ctypes.c_void_p() for _ in range(4)]
         results = tuple(ctypes.byref(p) for p in out)
+        # (plain addresses: every array is bound to a local name until the call has returned, and
+        # `.ctypes.data` is half the price of `.ctypes.data_as(c_void_p)` -- ten arguments per call)
         if c_coeffs is None:
             check(self._lib.ffk_resident_filter_function(
-                self._handle, ptr(H), ptr(dt), ptr(t), G, d, ptr(omega), W, ptr(C), N, ptr(B), A, ptr(s),
-                *results))
+                self._handle, H.ctypes.data, dt.ctypes.data, t.ctypes.data, G, d, omega.ctypes.data, W,
+                C.ctypes.data, N, B.ctypes.data, A, s.ctypes.data, *results))
         else:
             c = as_f64(c_coeffs)
             if c.shape != (len(H), G):
                 raise ValueError(f'Expected c_coeffs of shape ({len(H)}, {G}), not {c.shape}.')
             check(self._lib.ffk_resident_filter_function_from_controls(
-                self._handle, ptr(H), len(H), ptr(c), ptr(dt), ptr(t), G, d, ptr(omega), W, ptr(C), N,
-                ptr(B), A, ptr(s), *results))
+                self._handle, H.ctypes.data, len(H), c.ctypes.data, dt.ctypes.data, t.ctypes.data, G, d,
+                omega.ctypes.data, W, C.ctypes.data, N, B.ctypes.data, A, s.ctypes.data, *results))
         self.shape = (G, d, W, N, A)
         D = _view(out[0].value, G*d, np.float64, (G, d), self)
         V = _view(out[1].value, 2*G*d*d, np.complex128, (G, d, d), self)
@@ -190,7 +192,6 @@ class ResidentResult:
         if W < 2:
             out[...] = 0.0
             return out
-        check(self._lib.ffk_resident_infidelity(self._handle, ptr(S), S.ndim, int(real),
-                                                idx.ctypes.data_as(ctypes.c_void_p), n_idx, int(d),
-                                                ptr(out)))
+        check(self._lib.ffk_resident_infidelity(self._handle, S.ctypes.data, S.ndim, int(real),
+                                                idx.ctypes.data, n_idx, int(d), out.ctypes.data))
         return out

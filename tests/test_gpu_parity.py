@@ -2066,6 +2066,45 @@ def test_many_noise_operators_fused_expansion():
 
 
 # ---- round 2: resident evaluation, large pair grids, complex spectra, device-side status ---------
+def test_resident_pass_replayed_from_its_captured_graph():
+    """The user-facing pass is captured as a hipGraph the first time a shape runs on a pair of pooled
+    blocks and REPLAYED afterwards (ffk_api.hip::resident_pass): pulses of one shape evaluated one
+    after the other (each on a new handle that gets the previous one's blocks), another shape in
+    between, a tuning knob changed in between -- every result against the array route."""
+    import gc
+    lib = _lib.load()
+    basis = ff.Basis.pauli(2)
+
+    def one(seed, G, W, controls=True):
+        c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs(G=G, W=W, seed=seed)
+        H_c, H_n = list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs))
+        fast = ff.PulseSequence(H_c, H_n, dt, basis)
+        slow = ff.PulseSequence(H_c, H_n, dt, basis)
+        slow.diagonalize()
+        F = fast.get_filter_function(omega)
+        assert fast._resident is not None and slow._resident is None
+        assert rel_err(F, slow.get_filter_function(omega)) < 1e-13
+        assert rel_err(fast.propagators, slow.propagators) < 1e-13
+        S = 1e-3/omega
+        assert rel_err(ff.infidelity(fast, S, omega), ff.infidelity(slow, S, omega)) < 1e-13
+        assert rel_err(fast.get_control_matrix(omega), slow.get_control_matrix(omega)) < 1e-13
+        del fast, slow
+        gc.collect()
+
+    for seed in (1, 2, 3):
+        one(seed, 24, 300)
+    one(4, 7, 65)                       # another shape: its own capture
+    one(5, 24, 300)                     # the first shape again
+    try:
+        _lib.check(lib.ffk_set_segment_chunks(3))
+        one(6, 24, 300)                 # knob changed: must not replay the old geometry
+        assert _lib.stats()['chunks'] == 3
+    finally:
+        _lib.check(lib.ffk_set_segment_chunks(0))
+    one(7, 24, 300)
+    assert _lib.stats()['chunks'] != 3
+
+
 def test_resident_pass_matches_array_path():
     """get_filter_function on a fresh pulse runs as one library call (ffk_resident_*): same
     results as the array-in/array-out route, control matrix fetched from HBM only on demand,
