@@ -1,27 +1,26 @@
-// ctrl_mfma.hip -- K3m: the control-matrix accumulation for large Hilbert spaces (d = 8, 12, 16) on
-// the FP64 matrix cores.  Same mathematics, inputs and output layout as ctrl.hip:
+// ctrl_mfma.hip -- K3m: the control-matrix accumulation for large Hilbert spaces (d = 12, 16; d = 4, 8
+// on request) on the FP64 matrix cores.  Same mathematics, inputs and output layout as ctrl.hip:
 //     Y_a(w) = sum_g T_g^dag [ Bbar_a^(g) o E^(g)(w) ] T_g ,   E = e^{i w t_g} I^(g)(w),
-// but the two d x d products per (segment, frequency, noise operator) run on MFMA with the
-// FREQUENCY as the column index of the tile:
-//     step 1, per row m:   Z_m[j, w]  = sum_n  T[n, j]        X_m[n, w],   X_m[n, w] = Bbar[m, n] E[m, n](w)
-//     step 2, per column j: Y[i, j, w] += sum_m conj(T[m, i]) Z_m[j, w].
-// A operands are the frequency-independent T, B operands the per-frequency X / Z; an instruction
-// covers 16 frequencies.  Step 1 leaves Z_m[j = q + 4r, w_c] in lane (c, q) (c = lane & 15,
-// q = lane >> 4), step 2 wants Z_{m = 4 mg + q}[j, w_c] there: a 4 x 4 transpose across the four
-// 16-lane rows of the wavefront, done with v_permlane16_swap / v_permlane32_swap (gfx950) -- no LDS
-// round trip.  The waves of a block share the generated E tile (d^2 entries x 16 frequencies,
-// 64 KiB at d = 16) through LDS.
-//
-// Two instruction forms, both kept:
-//   * ctrl_accumulate_mfma4_kernel<D, JH> -- v_mfma_f64_4x4x4_4b (four 4 x 4 x 4 blocks = 16
-//     frequency columns, 4 rows per instruction, conjugation through the NEG bits).  No 16-row
-//     tile to leave partly empty, and the columns of Y can be split over JH wavefronts per noise
-//     operator without duplicating work, so the accumulators fit 256 registers and two wavefronts
-//     share a SIMD.  The default for d = 12 (JH = 1) and d = 16 (JH = 2).
+// with the two d x d products per (segment, frequency, noise operator) on MFMA.  The waves of a
+// block share the generated E tile (d^2 entries x 16 frequencies) through LDS.  Three forms, all kept:
+//   * ctrl_accumulate_mfma4_kernel<D, JH, MAXW, BF = true> -- THE DEFAULT for d = 12, 16 (round 3).
+//     v_mfma_f64_4x4x4_4b with ONE FREQUENCY PER 4 x 4 x 4 BLOCK: the result of the first product
+//     P = X^T conj(T) is, register for register, the transposed A operand of the second,
+//     Y += P^T T -- nothing moves between the two products, both take the same entries of T (held in
+//     registers for the whole segment) as B operand, X = Bbar o E is formed once per operator.  The
+//     JH wavefronts of an operator split the tile's 16 frequencies.  See the comment above the
+//     kernel; d = 16: 4.65 ms at config 5 (0.71 of the FP64 peak), d = 12: 1.80 ms.
+//   * ... BF = false -- the same instruction with the FREQUENCY AS THE COLUMN of the tile (round 2):
+//       step 1, per row m:    Z_m[j, w]  = sum_n  T[n, j]        X_m[n, w],   X_m[n, w] = Bbar[m, n] E[m, n](w)
+//       step 2, per column j: Y[i, j, w] += sum_m conj(T[m, i]) Z_m[j, w].
+//     A operands are entries of T (read from LDS per use), B operands the per-frequency X / Z.  Step 1
+//     leaves Z_m[j = q + 4r, w_c] in lane (c, q) (c = lane & 15, q = lane >> 4), step 2 wants
+//     Z_{m = 4 mg + q}[j, w_c] there: a 4 x 4 transpose across the four 16-lane rows of the wavefront
+//     (v_permlane16_swap / v_permlane32_swap, ffk_mfma_util.h).  The columns of Y are split over JH
+//     wavefronts per operator.  5.18 ms / 2.41 ms on the same shapes (FFK_TUNE_MFMA_BF=0).
 //   * ctrl_accumulate_mfma_kernel<D> -- v_mfma_f64_16x16x4, one wavefront per noise operator with
-//     all d x d x 16 accumulators (256 registers: one wavefront per SIMD).  24 % slower at d = 16
-//     (a bare MFMA stream runs 35 % faster with two wavefronts per SIMD than with one); kept as a
-//     tuning reference (FFK_TUNE_MFMA_JH=0).
+//     all d x d x 16 accumulators (one wavefront per SIMD): 6.7 ms at d = 16; a tuning reference
+//     (FFK_TUNE_MFMA_BF=0 FFK_TUNE_MFMA_JH=0).
 #include <algorithm>
 #include <cstdlib>
 

@@ -478,11 +478,9 @@ struct DecayPlan {
 };
 
 // FFK_TUNE_DECAY_LDS=1 selects the LDS-staged kernel (tuning / A-B).  Measured at config 5 (d = 16,
-// 18 operators, 16384 omega; profiles/r03_e_*): 2.40 ms against 1.69 ms for the register-fed kernel --
-// with 128 accumulator + 96 staging registers it runs ONE wavefront per SIMD, and a single
-// wavefront issues v_mfma_f64_16x16x4 at well under half the pipe's rate
-// (tools/mfma_occupancy_probe.hip: 34 TFLOP/s at one wavefront per SIMD, 46 at two), which costs
-// more than the halved operand traffic and the overlapped fetch buy.  Not the default.
+// 18 operators, 16384 omega; profiles/r03_m_*), both with the triangle grids: 1.20 ms against 1.07 ms
+// for the register-fed kernel -- half the operand traffic, but ten of its twelve wavefronts work on
+// the symmetric half and its own loop keeps the matrix pipe 74 % busy.  Not the default.
 bool decay_lds_enabled() {
     static const bool on = [] {
         const char* e = std::getenv("FFK_TUNE_DECAY_LDS");
@@ -525,10 +523,9 @@ DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
     const int t = N <= 16 ? 1 : (N < 128 ? 2 : 4);
     p.tm = p.tn = t;
     // N >= 128: 64 x 64 tiles per wavefront (one wavefront per SIMD: 128 accumulator + 128 operand
-    // registers).  FFK_TUNE_DECAY_TN=2 selects 64 x 32 tiles (two wavefronts per SIMD): measured SLOWER at
-    // config 5, 2.44 against 1.68 ms -- both forms move ~3.65 TB/s of operands from L2 / Infinity Cache
-    // (6.0 GB resp. 9.0 GB per call): the product is bound by operand delivery, and the smaller tile
-    // re-reads more (profiles/r03_e_*)
+    // registers).  FFK_TUNE_DECAY_TN=2 selects 64 x 32 tiles (two wavefronts per SIMD; no triangle grid
+    // for rectangular tiles): 9.0 instead of 6.0 GB of operand reads per call at config 5, where the
+    // square tiles already run at the rate the operands are delivered (profiles/r03_e_*, r03_m_*)
     static const int tn_big = [] {
         const char* e = std::getenv("FFK_TUNE_DECAY_TN");
         return e && e[0] == '2' ? 2 : 4;
