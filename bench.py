@@ -893,6 +893,7 @@ def main():
                 'frac': achieved/FP64_PEAK_TFLOPS, 'frac_step': step_tflops/FP64_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_source': traffic_src,
                 'frac_contraction_only': (16.0*d**3 + 6.0*d*d)*A*G*args.omega_per_gpu/(acc_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+                'frac_executed': ((16.0*d**3 + 6.0*d*d)*A + 18.0*(d*(d - 1) + 1) + 62.0)*G*args.omega_per_gpu/(acc_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
                 'avg_launch_ms': acc_ms, 'launches_timed': n_ev + n_extra,
                 'launches_in_timed_region': n_ev,
                 'avg_launch_ms_in_timed_region': float(np.mean(in_region_ms)),
@@ -906,7 +907,10 @@ def main():
                         'the same flops over the whole step time -- above frac when passes pipeline: '
                         'consecutive accumulate kernels then overlap ramp and tail; frac_contraction_only = the '
                         'contraction FMAs alone, (16 d^3 + 6 d^2) A per (segment, omega), without the modelled 55 flop '
-                        'per integral entry; SURVEY 8(d)\'s (8 d^2 + 8) flop per element is the Liouville-space form, '
+                        'per integral entry (a direct evaluation: sincos 26 + reciprocal 9 + 20; the model has been the '
+                        'same since round 1 so that rounds compare); frac_executed = what the kernel executes since the '
+                        'round-3 generator (ffk_math.h::phased_integral_aa): 18 flop per entry + 62 per (segment, omega) '
+                        'for the two sincos and the phase; SURVEY 8(d)\'s (8 d^2 + 8) flop per element is the Liouville-space form, '
                         'which this kernel does not execute, and is not used here.  A pure v_fma_f64 stream on random '
                         'operands sustains 59 TFLOP/s on this part at an in-kernel clock of 1.89 GHz (2.38 GHz on '
                         'constants: tools/fp64_ceiling_probe.hip, profiles/r03_d_*)',

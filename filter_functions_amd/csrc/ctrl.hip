@@ -233,12 +233,13 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
             sincos_pi(0.5*(om*dtg), &sa, &ca);
         }
         cplx* dst = tile + lane;
+        const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
         auto gen = [&](int slot, int e) {   // slot: LDS slot, e: matrix entry m*D + n
             const double* r = st + seg_rec(e);
 #if defined(FFK_ABLATE) && FFK_ABLATE == 1   /* diagnostic build: no integral generation */
             dst[slot*64] = {om, dtg + ph.re + r[0]};
 #else
-            dst[slot*64] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+            dst[slot*64] = phased_integral_aa(pf, r[0], r[1], r[2]);
 #endif
         };
         if constexpr (MR == D) {

@@ -118,11 +118,12 @@ __global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
         double sa, ca;
         sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
         const int eg = wave*4 + q;
+        const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
 #pragma unroll 4
         for (int s = 0; s < DD/16; ++s) {
             const int e = eg + 16*s;
             const double* r = st + seg_rec(e);
-            tile[e*16 + c] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+            tile[e*16 + c] = phased_integral_aa(pf, r[0], r[1], r[2]);
         }
     };
 
@@ -330,9 +331,10 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
         sincos_pi<true>(om*st[1], &ph.im, &ph.re);
         double sa, ca;
         sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
+        const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
         for (int e = wave*4 + q; e < DD; e += 4*nw) {
             const double* r = st + seg_rec(e);
-            tile[e*TS + c] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+            tile[e*TS + c] = phased_integral_aa(pf, r[0], r[1], r[2]);
         }
     };
     // v_mfma_f64: the last builtin argument carries the NEG bits of the operands (bit 0 = A)

@@ -135,10 +135,11 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
         double sa, ca;
         sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
         constexpr auto& sl = PcEntries<D>::slots;
+        const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
         for (int k = wl; k < PcEntries<D>::count; k += NWS) {
             const int e = sl.v[k];
             const double* r = st + seg_rec(e);
-            tile[k*TS] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+            tile[k*TS] = phased_integral_aa(pf, r[0], r[1], r[2]);
         }
     };
 
@@ -185,12 +186,13 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
             sincos_pi<true>(om*st[1], &ph.im, &ph.re);
             double sa, ca;
             sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
+            const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
 #pragma unroll
             for (int k = 0; k < PcEntries<D>::count; ++k) {
                 constexpr auto& sl = PcEntries<D>::slots;
                 const int e = sl.v[k];
                 const double* r = st + seg_rec(e);
-                tile[k*TS] = cmul(ph, first_order_integral_aa(om, r[0], dtg, sa, ca, r[1], r[2]));
+                tile[k*TS] = phased_integral_aa(pf, r[0], r[1], r[2]);
             }
         };
         static_assert((1 + NC)*DD <= 64 && S/2 <= 64, "one staging element per lane");

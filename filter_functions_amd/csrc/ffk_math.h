@@ -221,6 +221,47 @@ FFK_HD cplx first_order_integral_aa(double omega, double dE, double dt, double s
     return out;
 }
 
+// The accumulate kernels need E = e^{i omega t_g} I, not I: with h = (omega + dE) dt / 2,
+//     I = e^{ih} 2 sin(h)/x      =>      E = e^{i(omega t_g + a)} e^{ib} (2 sin(a + b)/x),
+// a = fl(omega dt)/2 per (segment, frequency), b = fl(dE dt)/2 per (segment, entry).  Per frequency
+// and segment (PhasedFrequency): psi = e^{i omega t_g} e^{ia} and 2 sin a, 2 cos a; per entry one
+// rotation of psi by b (4 flops), 2 sin(a + b) by the addition theorem (2), a reciprocal, 3 products:
+// 13 instructions and no select, against 25 for "I, then multiply by the phase" (cos(a + b) is never
+// formed, the phase costs nothing extra, the x == 0 limit lives in the rare branch).  Near a
+// resonance (|x dt| < 2^-4, which includes x == 0 and zero-length segments) the sine comes from the
+// short polynomial -- the sum would cancel -- as in first_order_integral_aa.
+struct PhasedFrequency {
+    double om, dt, thr;        // frequency, segment length, 2^-4/dt
+    double pr, pi;             // psi = e^{i omega t_g} e^{i a}
+    double sa2, ca2;           // 2 sin a, 2 cos a
+};
+FFK_HD PhasedFrequency phased_frequency(double om, double dt, cplx ph, double sa, double ca) {
+    PhasedFrequency f;
+    f.om = om;
+    f.dt = dt;
+    // (a zero-length segment: every entry takes the exact branch, which yields I = 0 also at x == 0)
+    f.thr = dt > 0.0 ? 0.0625*rcp(dt) : __builtin_huge_val();
+    f.pr = fma(ph.re, ca, -(ph.im*sa));
+    f.pi = fma(ph.re, sa, ph.im*ca);
+    f.sa2 = sa + sa;
+    f.ca2 = ca + ca;
+    return f;
+}
+FFK_HD cplx phased_integral_aa(const PhasedFrequency& f, double dE, double sb, double cb) {
+    const double x = f.om + dE;
+    const double er = fma(f.pr, cb, -(f.pi*sb));
+    const double ei = fma(f.pr, sb, f.pi*cb);
+    double q;
+    if (fabs(x) < f.thr) {
+        double s, c;
+        sincos_small<true>(0.5*(x*f.dt), &s, &c);     // (the cosine is dead code)
+        q = x == 0.0 ? f.dt : 2.0*s*rcp_fast(x);
+    } else {
+        q = fma(f.sa2, cb, f.ca2*sb)*rcp_fast(x);
+    }
+    return {q*er, q*ei};
+}
+
 // exp(i x) as (cos, sin), util.py:136-162
 FFK_HD cplx cexp(double x) {
     cplx out;

@@ -2066,6 +2066,44 @@ def test_many_noise_operators_fused_expansion():
 
 
 # ---- round 2: resident evaluation, large pair grids, complex spectra, device-side status ---------
+@pytest.mark.parametrize('d,G,A', [(4, 6, 3), (8, 5, 3), (3, 7, 2), (16, 3, 4), (12, 3, 5), (2, 9, 1)])
+def test_frequencies_on_and_around_the_resonances(d, G, A):
+    """The generated integral e^{i w t} (e^{i x dt} - 1)/(i x), x = w + (D_m - D_n), at frequencies
+    that hit a resonance x = 0 exactly, miss it by a few ulp, and sit on either side of the switch
+    between the addition-theorem form and the direct evaluation (|x dt| = 2^-4): control matrix
+    against the oracle.  (ffk_math.h::phased_integral_aa; every accumulate kernel.)"""
+    rng = np.random.default_rng(77*d + G)
+    basis = ff.Basis.ggm(d)
+    c_opers = rng.standard_normal((3, d, d)) + 1j*rng.standard_normal((3, d, d))
+    c_opers = c_opers + c_opers.conj().transpose(0, 2, 1)
+    n_opers = rng.standard_normal((A, d, d)) + 1j*rng.standard_normal((A, d, d))
+    n_opers = n_opers + n_opers.conj().transpose(0, 2, 1)
+    H = np.einsum('ijk,il->ljk', c_opers, rng.standard_normal((3, G)))
+    H[1] = 0.0                                            # an idle segment: all differences zero
+    dt = 0.5 + rng.random(G)
+    n_coeffs = rng.random((A, G)) + 0.5
+    D, V, Q = numeric.diagonalize(H, dt)
+    omega = [0.0]
+    for g in (0, G - 1):
+        dE = (D[g][:, None] - D[g][None, :]).ravel()
+        dE = dE[dE != 0][:6]
+        for eps in (0.0, 2.0**-52, -2.0**-50, 1e-12, -1e-9, 1e-6):
+            omega.extend(-dE*(1 + eps))
+        for edge in (2.0**-4, -2.0**-4):                  # |x dt| on either side of the switch
+            for nudge in (1 - 2.0**-40, 1 + 2.0**-40):
+                omega.extend(-dE + edge*nudge/dt[g])
+    omega = np.array(sorted(set(omega)))
+    R = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+    t = np.concatenate(([0], dt.cumsum()))
+    R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), n_opers, n_coeffs, dt, t)
+    assert np.isfinite(R).all()
+    assert rel_err(R, R_ref) < 1e-12
+    # frequency by frequency, so that one bad column cannot hide behind the norm of the rest
+    num = np.abs(R - R_ref).max(axis=(0, 1))
+    den = np.abs(R_ref).max(axis=(0, 1))
+    assert (num <= 1e-11*den).all(), omega[np.argmax(num/den)]
+
+
 def test_resident_pass_replayed_from_its_captured_graph():
     """The user-facing pass is captured as a hipGraph the first time a shape runs on a pair of pooled
     blocks and REPLAYED afterwards (ffk_api.hip::resident_pass): pulses of one shape evaluated one
