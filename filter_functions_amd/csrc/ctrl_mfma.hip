@@ -524,6 +524,186 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The block-frequency form with TWO OPERATORS per wavefront and tiles of EIGHT frequencies: wave
+// (pair, set) contracts operators 2 pair and 2 pair + 1 on the four frequencies of its set.  The
+// registers are those of the <D, 2, 8, true> kernel (two 4-frequency accumulator sets, T shared),
+// but the generated tile now serves eight operators instead of four -- the tile generation was 14 %
+// of that kernel (profiles/r03_l_*), regenerated by every row of operator blocks.
+template <int D>
+__global__ __launch_bounds__(512) void ctrl_accumulate_mfma4x2_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ segtab,
+    const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart, int alpha_base,
+    int alpha_end) {
+    static_assert(D == 12 || D == 16, "d = 12, 16");
+    constexpr int S = seg_stride(D), DD = D*D, NS = D/4;
+    constexpr int NA = 8, TW = 8, TS = TW + 4, NT = 512;
+    constexpr int kops = (1 + NA)*DD;
+    constexpr int kStage = (kops + S/2 + NT - 1)/NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    cplx* tile = reinterpret_cast<cplx*>(lds_raw);
+    cplx* opsb = tile + DD*TS;
+    double* rows = reinterpret_cast<double*>(opsb + 2*kops);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4, c4 = c & 3, b = c >> 2;
+    const int wq = c & 7, half = c >> 3;              // generation: frequency, half of the entries
+    const int iw = blockIdx.x*TW + wq;
+    const double om = omega[iw < W ? iw : W - 1];
+    const int pair = wave >> 1, set = wave & 1;
+    const int alpha0 = alpha_base + blockIdx.y*NA;    // the launch serves operators [alpha_base, alpha_end)
+    const int n_alpha = min(NA, alpha_end - alpha0);
+    const int n_ops = (1 + n_alpha)*DD;
+    const int g0 = blockIdx.z*chunk_len;
+    const int g1 = min(G, g0 + chunk_len);
+
+    double Yr[2*NS][NS], Yi[2*NS][NS];                // [k*NS + ig][jg]: operator 2 pair + k
+#pragma unroll
+    for (int i = 0; i < 2*NS; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            Yr[i][j] = 0.0;
+            Yi[i][j] = 0.0;
+        }
+
+    cplx staged[kStage];
+    auto issue_stage = [&](int g) {
+        const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*DD;
+        const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {
+            const int e = tid + k*NT;
+            const cplx* src = e < n_ops ? src_ops + (e < DD ? e : e + alpha0*DD) : src_tab + (e - n_ops);
+            staged[k] = e < n_ops + S/2 ? *src : cplx{0.0, 0.0};
+        }
+    };
+    auto park = [&](int buf) {
+        cplx* dst_ops = opsb + buf*kops;
+        cplx* dst_tab = reinterpret_cast<cplx*>(rows + buf*S);
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {
+            const int e = tid + k*NT;
+            if (e < n_ops)
+                dst_ops[e] = staged[k];
+            else if (e < n_ops + S/2)
+                dst_tab[e - n_ops] = staged[k];
+        }
+    };
+    // thread (wave, q, c): frequency c & 7, entries 2 (4 wave + q) + (c >> 3) + 64 k
+    auto generate = [&](int slot) {
+        const double* st = rows + slot*S;
+        const double dtg = st[0];
+        cplx ph;
+        sincos_pi<true>(om*st[1], &ph.im, &ph.re);
+        double sa, ca;
+        sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
+        const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
+        for (int e = 2*(wave*4 + q) + half; e < DD; e += 64) {
+            const double* r = st + seg_rec(e);
+            tile[e*TS + wq] = phased_integral_aa(pf, r[0], r[1], r[2]);
+        }
+    };
+    auto contract = [&](int buf) {
+        const cplx* opT = opsb + buf*kops;
+        cplx tq[NS][NS];                              // T[4 s + q][4 g + c4]
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int g = 0; g < NS; ++g) tq[s][g] = opT[(4*s + q)*D + 4*g + c4];
+        const cplx* ecol = tile + 4*set + b;          // + slot*TS
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (alpha0 + 2*pair + k >= alpha_end) continue;       // (wave uniform)
+            const cplx* opB = opT + (1 + 2*pair + k)*DD;
+#pragma unroll
+            for (int ng = 0; ng < NS; ++ng) {
+                __builtin_amdgcn_sched_barrier(0);    // (as in the one-operator form: no hoisting across groups)
+                double pr[NS], pi[NS];                // P[4 ng + q][4 ig + c4]
+#pragma unroll
+                for (int ig = 0; ig < NS; ++ig) {
+                    pr[ig] = 0.0;
+                    pi[ig] = 0.0;
+                }
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int e = (4*s + q)*D + 4*ng + c4;
+                    const cplx x = cmul(opB[e], ecol[e*TS]);      // X[4 s + q][4 ng + c4]
+#pragma unroll
+                    for (int ig = 0; ig < NS; ++ig) {
+                        pr[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, tq[s][ig].re, pr[ig], 0, 0, 0);
+                        pi[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.im, tq[s][ig].re, pi[ig], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int ig = 0; ig < NS; ++ig) {
+                        pr[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.im, tq[s][ig].im, pr[ig], 0, 0, 0);
+                        pi[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, tq[s][ig].im, pi[ig], 0, 0, 1);
+                    }
+                }
+#pragma unroll
+                for (int ig = 0; ig < NS; ++ig) {
+#pragma unroll
+                    for (int jg = 0; jg < NS; ++jg) {
+                        Yr[k*NS + ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr[ig], tq[ng][jg].re, Yr[k*NS + ig][jg], 0, 0, 0);
+                        Yi[k*NS + ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr[ig], tq[ng][jg].im, Yi[k*NS + ig][jg], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int jg = 0; jg < NS; ++jg) {
+                        Yr[k*NS + ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi[ig], tq[ng][jg].im, Yr[k*NS + ig][jg], 0, 0, 1);
+                        Yi[k*NS + ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi[ig], tq[ng][jg].re, Yi[k*NS + ig][jg], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    if (g0 < g1) {
+        issue_stage(g0);
+        park(0);
+    }
+    for (int g = g0; g < g1; ++g) {
+        const int buf = (g - g0) & 1;
+        __syncthreads();
+        if (g + 1 < g1) issue_stage(g + 1);           // (in flight during the generation, see the BF form)
+        generate(buf);
+        if (g + 1 < g1) park(buf ^ 1);
+        __syncthreads();
+        contract(buf);
+    }
+
+    const int iws = blockIdx.x*TW + 4*set + b;
+    if (iws < W) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int alpha = alpha0 + 2*pair + k;
+            if (alpha >= alpha_end) continue;
+            cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W + iws;
+#pragma unroll
+            for (int ig = 0; ig < NS; ++ig)
+#pragma unroll
+                for (int jg = 0; jg < NS; ++jg)
+                    out[static_cast<size_t>((4*ig + q)*D + 4*jg + c4)*W] = {Yr[k*NS + ig][jg], Yi[k*NS + ig][jg]};
+        }
+    }
+}
+
+template <int D>
+hipError_t launch_x2(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
+                     int chunks, int chunk_len, cplx* Ypart, hipStream_t stream, int alpha_end) {
+    constexpr int DD = D*D, NA = 8, TW = 8;
+    const int lds = static_cast<int>((static_cast<size_t>(DD)*(TW + 4) + 2*static_cast<size_t>(1 + NA)*DD)*sizeof(cplx) +
+                                     2*static_cast<size_t>(seg_stride(D))*sizeof(double));
+    auto kern = ctrl_accumulate_mfma4x2_kernel<D>;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) return err;
+    const dim3 grid((W + TW - 1)/TW, alpha_end/NA, chunks);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, omega, W, segtab, ops, G, A, chunk_len, Ypart, 0,
+                       alpha_end);
+    return hipGetLastError();
+}
+
 template <int D, int JH, bool BF = false>
 size_t mfma4_lds_bytes(int nw) {
     return (static_cast<size_t>(D*D)*mfma4_tile_stride(BF) + 2*static_cast<size_t>(1 + nw/JH)*D*D)*sizeof(cplx) +
@@ -670,15 +850,33 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
             const char* e = std::getenv("FFK_TUNE_MFMA_REST");
             return e == nullptr || e[0] != '0';
         }();
-        const int rest = A % 4;
-        if (split_rest && jh == 2 && nw == 8 && (rest == 1 || rest == 2)) {
-            const int main_ops = A - rest;
+        // Eight operators per tile first (two per wavefront, 8-frequency tiles), the block-of-four
+        // form for what is left.  Measured (profiles/r03_s_*): d = 12, 8 operators 2.19 -> 2.09 ms;
+        // d = 16, 18 operators 4.61 -> 5.04 ms (256 registers with 91 spilled, and nine 4-KiB operand
+        // matrices staged per 8-frequency tile instead of five per 16) -- so the default is d = 12 only.
+        // FFK_TUNE_MFMA_X2=0 / 1: never / also at d = 16.
+        static const int x2_env = [] {
+            const char* e = std::getenv("FFK_TUNE_MFMA_X2");
+            return e ? std::atoi(e) : -1;
+        }();
+        const bool x2 = x2_env < 0 ? d == 12 : x2_env != 0;
+        int base = 0;
+        if (x2 && jh == 2 && nw == 8 && A >= 8) {
+            base = A/8*8;
+            const hipError_t err = d == 16 ? launch_x2<16>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream, base)
+                                           : launch_x2<12>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream, base);
+            if (err != hipSuccess || base == A) return err;
+        }
+        const int rest = (A - base) % 4;
+        if (jh == 2 && nw == 8 && (base > 0 || (split_rest && (rest == 1 || rest == 2)))) {
+            const bool own_launch = split_rest && (rest == 1 || rest == 2);
+            const int main_ops = own_launch ? A - rest : A;
 #define FFK_BF_SPLIT(D) \
     if (d == D) { \
-        if (main_ops > 0) { \
+        if (main_ops > base) { \
             const hipError_t err = launch_d4<D, 2, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, 8, \
-                                                            Ypart, stream, 0, main_ops); \
-            if (err != hipSuccess) return err; \
+                                                            Ypart, stream, base, main_ops); \
+            if (err != hipSuccess || main_ops == A) return err; \
         } \
         return launch_d4<D, 4, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, 8, Ypart, stream, \
                                         main_ops, A); \

@@ -731,7 +731,8 @@ def test_noise_operator_step_cache():
 
 @pytest.mark.parametrize('d,G,A,W', [(4, 9, 3, 100), (4, 20, 5, 47), (8, 7, 3, 100), (12, 5, 5, 33), (16, 6, 2, 16), (16, 3, 9, 50),
                                       (8, 20, 1, 257), (16, 4, 6, 35), (12, 4, 1, 20), (12, 3, 3, 17),
-                                      (16, 2, 7, 19), (12, 6, 10, 64)])
+                                      (16, 2, 7, 19), (12, 6, 10, 64), (16, 3, 8, 9), (16, 2, 17, 21), (12, 3, 19, 40),
+                                      (16, 2, 11, 5), (12, 2, 8, 8)])
 def test_matrix_core_accumulate_kernel_matches_vector_kernel(d, G, A, W):
     """ctrl_mfma.hip (matrix cores; d = 12, 16: one frequency per 4 x 4 x 4 block) against ctrl.hip
     on the same inputs: ragged frequency tiles (W not a multiple of 16), operator counts that do not
