@@ -2245,12 +2245,14 @@ def test_filter_function_pair_grids_beyond_65535():
     assert Fpc.shape == ref.shape and rel_err(Fpc, ref) < 1e-15
 
 
-@pytest.mark.parametrize('s_ndim', [1, 2])
-def test_decay_amplitudes_complex_spectrum_below_three_dimensions(s_ndim):
+@pytest.mark.parametrize('s_ndim,N,W', [(1, 40, 300), (2, 40, 300), (1, 144, 200), (2, 200, 130), (2, 256, 70)])
+def test_decay_amplitudes_complex_spectrum_below_three_dimensions(s_ndim, N, W):
     """A complex spectrum of one or two dimensions makes Gamma_aa non-symmetric in (k, l): the
-    GEMM's mirror shortcut must switch itself off; N = 40 spans several tiles."""
-    rng = np.random.default_rng(40 + s_ndim)
-    A, N, W = 2, 40, 300
+    GEMM's mirror shortcut must switch itself off -- the tiles below the diagonal, which
+    have a launch of their own that returns at once for real weights, must then all be computed.
+    N = 40: several 32 x 32 tiles; N >= 128: 64 x 64 tiles, also with a ragged last tile."""
+    rng = np.random.default_rng(40 + s_ndim + N)
+    A = 2
     R = rng.standard_normal((A, N, W)) + 1j*rng.standard_normal((A, N, W))
     omega = np.sort(rng.random(W))*20 + 1e-3
     shape = (W,) if s_ndim == 1 else (A, W)
