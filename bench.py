@@ -309,7 +309,11 @@ def bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream, ra
         kernel_ms=kernel_ms, executed_flops=st['accumulate_flops'],
         tflops=st['accumulate_flops']/(kernel_ms*1e-3)/1e12,
         frac=st['accumulate_flops']/(kernel_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
-        geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')})
+        geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')},
+        geometry_note='two launches since round 3 (six operators per 32-omega tile: grid '
+                      f"({(len(omega) + 31)//32}, {cfg['A']//6}, {st['chunks']}), then the remaining "
+                      f"{cfg['A'] % 6} on 64-omega tiles); `geometry` is the planner's three-operator "
+                      'shape, which fixes the segment chunks' if cfg['A'] >= 6 else None)
 
 
 def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
