@@ -629,12 +629,93 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const double* __restric
     }
 }
 
+// 32 x 32 outputs per block of 256 threads, 2 x 2 per thread (rows ty, ty + 16; columns tx, tx + 16):
+// four products per four LDS operand reads -- with one output per thread (rounds 1-2) it was two reads
+// per product and the LDS pipe set the pace (22 TFLOP/s on the 256^3 products of the d = 16 cumulant
+// function).  The k axis goes through LDS in tiles of 32: two independent (strided, often
+// uncoalesced) global loads per operand row/column and thread are in flight per tile.
+constexpr int kGemmKT2 = 32;
+__global__ __launch_bounds__(256) void gemm_small_2x2_kernel(const double* __restrict__ A,
+                                                         const double* __restrict__ B,
+                                                         double* __restrict__ C, GemmDesc g) {
+    __shared__ cplx As[32][kGemmKT2 + 1];
+    __shared__ cplx Bs[kGemmKT2][33];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y*32, n0 = blockIdx.x*32;
+    const long b = blockIdx.z;
+    const double* Ab = A + (g.a_real ? 1 : 2)*b*g.sAb;
+    const cplx* Bb = reinterpret_cast<const cplx*>(B) + b*g.sBb;
+    cplx acc[2][2] = {{{0.0, 0.0}, {0.0, 0.0}}, {{0.0, 0.0}, {0.0, 0.0}}};
+    for (int k0 = 0; k0 < g.K; k0 += kGemmKT2) {
+        // A tile: rows m0 + ty + 16 r, columns k0 + tx + 16 q;  B tile: rows k0 + ty + 16 q, columns n0 + tx + 16 r
+        cplx av[2][kGemmKT2/16], bv[kGemmKT2/16][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < kGemmKT2/16; ++q) {
+                av[r][q] = {0.0, 0.0};
+                bv[q][r] = {0.0, 0.0};
+                const int m = m0 + ty + 16*r, ka = k0 + tx + 16*q;
+                if (m < g.M && ka < g.K) {
+                    const long o = m*g.sAm + ka*g.sAk;
+                    if (g.a_real)
+                        av[r][q] = {Ab[o], 0.0};
+                    else
+                        av[r][q] = reinterpret_cast<const cplx*>(Ab)[o];
+                }
+                const int kb = k0 + ty + 16*q, n = n0 + tx + 16*r;
+                if (kb < g.K && n < g.N) bv[q][r] = Bb[kb*g.sBk + n*g.sBn];
+            }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int q = 0; q < kGemmKT2/16; ++q) {
+                As[ty + 16*r][tx + 16*q] = av[r][q];
+                Bs[ty + 16*q][tx + 16*r] = bv[q][r];
+            }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < kGemmKT2; ++k) {
+            const cplx a0 = As[ty][k], a1 = As[ty + 16][k], b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
+            cmac(acc[0][0], a0, b0);
+            cmac(acc[0][1], a0, b1);
+            cmac(acc[1][0], a1, b0);
+            cmac(acc[1][1], a1, b1);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int m = m0 + ty + 16*r, n = n0 + tx + 16*c;
+            if (m < g.M && n < g.N) {
+                const long o = b*g.sCb + m*g.sCm + n*g.sCn;
+                if (g.c_real)
+                    C[o] = acc[r][c].re;
+                else
+                    reinterpret_cast<cplx*>(C)[o] = acc[r][c];
+            }
+        }
+}
+
 hipError_t launch_gemm_small(const void* A, const void* B, void* C, const GemmDesc& g, int batch,
                              hipStream_t stream) {
-    const dim3 grid((g.N + 15)/16, (g.M + 15)/16, batch);
-    hipLaunchKernelGGL(gemm_small_kernel, grid, dim3(256), 0, stream,
-                       static_cast<const double*>(A), static_cast<const double*>(B),
-                       static_cast<double*>(C), g);
+    // the 2 x 2 form when its 32 x 32 blocks still fill the chip twice over (d = 16 cumulant function:
+    // 0.45 -> 0.33 ms), else one output per thread (d = 12, 6 operators: 150 blocks of 32 x 32 would
+    // leave a third of the CUs idle: 0.071 ms against 0.089)
+    const long blocks2 = static_cast<long>((g.N + 31)/32)*((g.M + 31)/32)*batch;
+    if (blocks2 >= 2L*device_cu_count()) {
+        const dim3 grid((g.N + 31)/32, (g.M + 31)/32, batch);
+        hipLaunchKernelGGL(gemm_small_2x2_kernel, grid, dim3(256), 0, stream,
+                           static_cast<const double*>(A), static_cast<const double*>(B),
+                           static_cast<double*>(C), g);
+    } else {
+        const dim3 grid((g.N + 15)/16, (g.M + 15)/16, batch);
+        hipLaunchKernelGGL(gemm_small_kernel, grid, dim3(256), 0, stream,
+                           static_cast<const double*>(A), static_cast<const double*>(B),
+                           static_cast<double*>(C), g);
+    }
     return hipGetLastError();
 }
 
