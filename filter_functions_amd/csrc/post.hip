@@ -146,6 +146,80 @@ __global__ __launch_bounds__(256) void expand_sparse_quarters_kernel(const cplx*
     }
 }
 
+// The same, with elements that share their support computed TOGETHER: GGM's symmetric and
+// antisymmetric element of a pair (i, j) both read Y_ij and Y_ji, so the thread that expands one
+// expands the other from the same two loads (Y is then read once, not twice: the expansion is a
+// streaming kernel, 2.4 GB instead of 3.6 GB at config 5).  The grouping is found by the block
+// itself, in LDS, from the compacted lists -- no basis-specific code and no extra workspace: an
+// element with at most two non-zeros gets the key (count, row 0, row 1); the first element of every
+// key is a leader and chains the others behind it; leaders are dealt to the four wavefronts round
+// robin.  Elements with more non-zeros (GGM's diagonal ones) are leaders without followers.
+__global__ __launch_bounds__(256) void expand_sparse_groups_kernel(const cplx* __restrict__ Bt,
+                                                                   const int* __restrict__ nnz,
+                                                                   const int* __restrict__ rows,
+                                                                   const cplx* __restrict__ vals, int N,
+                                                                   int dd, int W, cplx* __restrict__ R,
+                                                                   int want_sparse) {
+    if (want_sparse >= 0 && basis_is_sparse(nnz, N, dd) != (want_sparse != 0)) return;
+    constexpr int kMaxN = 256;                        // d <= 16
+    __shared__ int keys[kMaxN], next[kMaxN], leaders[kMaxN], n_leaders;
+    const int tid = threadIdx.x;
+    if (tid == 0) n_leaders = 0;
+    if (tid < N) {
+        const int n = nnz[tid];
+        const int* rk = rows + static_cast<size_t>(tid)*dd;
+        keys[tid] = (n >= 1 && n <= 2) ? ((n << 28) | (rk[0] << 14) | (n == 2 ? rk[1] : 0x3fff)) : -1 - tid;
+    }
+    __syncthreads();
+    if (tid < N) {
+        const int key = keys[tid];
+        bool leader = true;
+        for (int k = 0; k < tid; ++k) leader &= keys[k] != key;
+        int nx = -1;
+        for (int k = N - 1; k > tid; --k)
+            if (keys[k] == key) nx = k;
+        next[tid] = nx;
+        // (order of the leader list does not matter for the result: every element is written once)
+        if (leader) leaders[atomicAdd(&n_leaders, 1)] = tid;
+    }
+    __syncthreads();
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = blockIdx.x*64 + lane;
+    const int a = blockIdx.y;
+    if (w >= W) return;
+    const cplx* b = Bt + static_cast<size_t>(a)*dd*W + w;
+    cplx* out = R + static_cast<size_t>(a)*N*W + w;
+    const int nl = n_leaders;
+    for (int idx = wave; idx < nl; idx += 4) {
+        const int k = __builtin_amdgcn_readfirstlane(leaders[idx]);
+        const int n = nnz[k];
+        const int* rk = rows + static_cast<size_t>(k)*dd;
+        if (n >= 1 && n <= 2) {
+            const cplx y0 = b[static_cast<size_t>(rk[0])*W];
+            const cplx y1 = n == 2 ? b[static_cast<size_t>(rk[1])*W] : cplx{0.0, 0.0};
+            for (int m = k; m >= 0; m = __builtin_amdgcn_readfirstlane(next[m])) {
+                const cplx* vm = vals + static_cast<size_t>(m)*dd;
+                // the same operation order as the per-element kernels: acc0 = v0 y0, acc1 = v1 y1, sum
+                cplx acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+                cmac(acc0, vm[0], y0);
+                if (n == 2) cmac(acc1, vm[1], y1);
+                out[static_cast<size_t>(m)*W] = {acc0.re + acc1.re, acc0.im + acc1.im};
+            }
+        } else {
+            const cplx* vk = vals + static_cast<size_t>(k)*dd;
+            cplx acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+            int q = 0;
+            for (; q + 1 < n; q += 2) {
+                cmac(acc0, vk[q], b[static_cast<size_t>(rk[q])*W]);
+                cmac(acc1, vk[q + 1], b[static_cast<size_t>(rk[q + 1])*W]);
+            }
+            if (q < n) cmac(acc0, vk[q], b[static_cast<size_t>(rk[q])*W]);
+            out[static_cast<size_t>(k)*W] = {acc0.re + acc1.re, acc0.im + acc1.im};
+        }
+    }
+}
+
 // out[w,a,i,j] = Bt[a,i,j,w]; a (A*d*d) x W transpose through LDS, 64 x 64 tiles
 __global__ __launch_bounds__(256) void transpose_kernel(const cplx* __restrict__ in, int rows,
                                                         int cols, cplx* __restrict__ out) {
@@ -619,8 +693,16 @@ hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d
             return e == nullptr || e[0] != '0';
         }();
         if (quarters && N >= 64 && static_cast<long>((W + 63)/64)*A2 >= 1024) {
-            hipLaunchKernelGGL(expand_sparse_quarters_kernel, dim3((W + 63)/64, A2), dim3(256), 0, stream, Bt,
-                               nnz, rows, vals, N, static_cast<int>(dd), W, R, 1);
+            static const bool groups = [] {           // FFK_TUNE_EXPAND_GROUPS=0: the quarters kernel
+                const char* e = std::getenv("FFK_TUNE_EXPAND_GROUPS");
+                return e == nullptr || e[0] != '0';
+            }();
+            if (groups && N <= 256 && dd <= 0x3fff)
+                hipLaunchKernelGGL(expand_sparse_groups_kernel, dim3((W + 63)/64, A2), dim3(256), 0, stream, Bt,
+                                   nnz, rows, vals, N, static_cast<int>(dd), W, R, 1);
+            else
+                hipLaunchKernelGGL(expand_sparse_quarters_kernel, dim3((W + 63)/64, A2), dim3(256), 0, stream, Bt,
+                                   nnz, rows, vals, N, static_cast<int>(dd), W, R, 1);
             return hipGetLastError();
         }
         constexpr int KT = 8;
