@@ -13,6 +13,7 @@
 // The imaginary GEMM is skipped for Hermitian bases, where the reference returns the real part
 // only (basis.py:692 `cast`).
 #include <algorithm>
+#include <cstdlib>
 
 #include "ffk_internal.h"
 
@@ -96,6 +97,186 @@ __global__ __launch_bounds__(256) void conjugate_basis_tile_kernel(const cplx* _
         if (i0 + j < N) {
             are[static_cast<size_t>(kk)*Npad + i0 + j] = tre[kk*ROW + j];
             if (want_imag) aim[static_cast<size_t>(kk)*Npad + i0 + j] = tim[kk*ROW + j];
+        }
+    }
+}
+
+// The same conjugation with the block's EPB = 256/D basis elements worked on AT ONCE: thread (j, r)
+// owns row r of element j -- U^dag C_j U as two products of a register-held row with U (read from LDS,
+// one address per wavefront and step: broadcast), meeting once in LDS in between.  The tile kernel
+// above walks its 16 elements one after the other with three barriers each; here a block has four.
+// Used at d = 8 (whole call at batch 512: 56.3 -> 49.4 us); at d = 16 it is no faster than the tile
+// kernel (both are bound by reading an entry of U from LDS per complex multiply-add): see the
+// matrix-core kernel below.
+template <int D>
+__global__ __launch_bounds__(256) void conjugate_basis_rows_kernel(const cplx* __restrict__ U,
+                                                                   const cplx* __restrict__ basis, int N,
+                                                                   int Npad, int want_imag,
+                                                                   double* __restrict__ AopRe,
+                                                                   double* __restrict__ AopIm) {
+    constexpr int DD = D*D, EPB = 256/D, ROW = EPB + 1;
+    constexpr int RS = D + 1;                         // row stride of a CU matrix in LDS (cplx)
+    constexpr int ES = D*RS + 1;                      // element stride (cplx): rows and elements on distinct banks
+    __shared__ cplx Us[DD];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    cplx* CUs = reinterpret_cast<cplx*>(lds_raw);                      // [EPB][D][RS], then reused as
+    double* tre = reinterpret_cast<double*>(lds_raw);                  // [2 DD][ROW]
+    double* tim = tre + 2*DD*ROW;                                      // [2 DD][ROW] (want_imag only)
+    const int bt = blockIdx.y, tid = threadIdx.x;
+    const int j = tid / D, r = tid % D;
+    const int i0 = blockIdx.x*EPB, i = i0 + j;
+    for (int e = tid; e < DD; e += 256) Us[e] = U[static_cast<size_t>(bt)*DD + e];
+    cplx crow[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) crow[k] = i < N ? basis[static_cast<size_t>(i)*DD + r*D + k] : cplx{0.0, 0.0};
+    __syncthreads();
+    // CU[r][c] = sum_k C[r][k] U[k][c]
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        cplx acc = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < D; ++k) cmac(acc, crow[k], Us[k*D + c]);
+        CUs[j*ES + r*RS + c] = acc;
+    }
+    __syncthreads();
+    // CB[a][b] = sum_k conj(U[k][a]) CU[k][b],  a = r
+    cplx cb[D];
+#pragma unroll
+    for (int b = 0; b < D; ++b) cb[b] = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const cplx ua = Us[k*D + r];
+#pragma unroll
+        for (int b = 0; b < D; ++b) cmac_conj(cb[b], ua, CUs[j*ES + k*RS + b]);
+    }
+    __syncthreads();                     // CU consumed by everybody: its space becomes the output tile
+    // tile slot of entry e = a D + b: b D + a, so that the 16 threads of an element write 16
+    // consecutive rows of the tile (ROW doubles apart: conflict free)
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+        const int slot = b*D + r;
+        tre[slot*ROW + j] = cb[b].re;
+        tre[(DD + slot)*ROW + j] = -cb[b].im;
+        if (want_imag) {
+            tim[slot*ROW + j] = cb[b].im;
+            tim[(DD + slot)*ROW + j] = cb[b].re;
+        }
+    }
+    __syncthreads();
+    const size_t K = (2*DD + 3)/4*4;     // padded to the MFMA k-step; pad rows stay zero
+    double* are = AopRe + static_cast<size_t>(bt)*K*Npad;
+    double* aim = AopIm + static_cast<size_t>(bt)*K*Npad;
+    for (int idx = tid; idx < 2*DD*EPB; idx += 256) {
+        const int kk = idx / EPB, jj = idx % EPB;
+        if (i0 + jj < N) {
+            const int half = kk / DD, e = kk % DD;
+            const int slot = half*DD + (e % D)*D + e / D;
+            are[static_cast<size_t>(kk)*Npad + i0 + jj] = tre[slot*ROW + jj];
+            if (want_imag) aim[static_cast<size_t>(kk)*Npad + i0 + jj] = tim[slot*ROW + jj];
+        }
+    }
+}
+
+// d = 16: the conjugation U^dag C_i U on the FP64 matrix cores, in the block-frequency form of the
+// accumulate kernels (ctrl_mfma.hip) with a BASIS ELEMENT per 4 x 4 x 4 block instead of a frequency:
+// v_mfma_f64_4x4x4_4b computes four independent products, lane (c, q) supplies A_b[c & 3][q] and
+// B_b[q][c & 3] of block b = c >> 2 and receives D_b[q][c & 3], so the first product
+// P = C_i^T conj(U) is, register for register, the transposed A operand of the second,
+// Y = P^T U = U^dag C_i U.  The entries of U a lane needs (16) live in registers for the whole
+// block; a wavefront conjugates four elements, a block of four wavefronts the same 16 elements as
+// the tile kernel, whose LDS output tile and coalesced copy-out it shares.  The vector kernels read
+// an entry of U from LDS per complex multiply-add and are bound by that (rows kernel above: no
+// faster than the tile kernel at d = 16).
+__global__ __launch_bounds__(256) void conjugate_basis_mfma16_kernel(const cplx* __restrict__ U,
+                                                                     const cplx* __restrict__ basis, int N,
+                                                                     int Npad, int want_imag,
+                                                                     double* __restrict__ AopRe,
+                                                                     double* __restrict__ AopIm) {
+    constexpr int D = 16, DD = 256, NS = 4, EPB = 16, ROW = EPB + 1;
+    __shared__ cplx Us[DD];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double* tre = reinterpret_cast<double*>(lds_raw);                  // [2 DD][ROW]
+    double* tim = tre + 2*DD*ROW;                                      // [2 DD][ROW] (want_imag only)
+    const int bt = blockIdx.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4, c4 = c & 3, b = c >> 2;
+    const int i0 = blockIdx.x*EPB;
+    const int j = 4*wave + b, i = i0 + j;             // this lane's basis element
+    Us[tid] = U[static_cast<size_t>(bt)*DD + tid];
+    __syncthreads();
+    cplx tq[NS][NS];                                  // U[4 s + q][4 g + c4]
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int g = 0; g < NS; ++g) tq[s][g] = Us[(4*s + q)*D + 4*g + c4];
+    const cplx* Ci = basis + static_cast<size_t>(min(i, N - 1))*DD;
+    double Yr[NS][NS], Yi[NS][NS];                    // Y[4 ig + q][4 jg + c4]
+#pragma unroll
+    for (int ig = 0; ig < NS; ++ig)
+#pragma unroll
+        for (int jg = 0; jg < NS; ++jg) {
+            Yr[ig][jg] = 0.0;
+            Yi[ig][jg] = 0.0;
+        }
+#pragma unroll
+    for (int ng = 0; ng < NS; ++ng) {
+        double pr[NS], pi[NS];                        // P[4 ng + q][4 ig + c4]
+#pragma unroll
+        for (int ig = 0; ig < NS; ++ig) {
+            pr[ig] = 0.0;
+            pi[ig] = 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const cplx x = Ci[(4*s + q)*D + 4*ng + c4];           // C_i[4 s + q][4 ng + c4]
+#pragma unroll
+            for (int ig = 0; ig < NS; ++ig) {
+                pr[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, tq[s][ig].re, pr[ig], 0, 0, 0);
+                pi[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.im, tq[s][ig].re, pi[ig], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ig = 0; ig < NS; ++ig) {
+                pr[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.im, tq[s][ig].im, pr[ig], 0, 0, 0);
+                pi[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, tq[s][ig].im, pi[ig], 0, 0, 1);
+            }
+        }
+#pragma unroll
+        for (int ig = 0; ig < NS; ++ig) {
+#pragma unroll
+            for (int jg = 0; jg < NS; ++jg) {
+                Yr[ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr[ig], tq[ng][jg].re, Yr[ig][jg], 0, 0, 0);
+                Yi[ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr[ig], tq[ng][jg].im, Yi[ig][jg], 0, 0, 0);
+            }
+#pragma unroll
+            for (int jg = 0; jg < NS; ++jg) {
+                Yr[ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi[ig], tq[ng][jg].im, Yr[ig][jg], 0, 0, 1);
+                Yi[ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi[ig], tq[ng][jg].re, Yi[ig][jg], 0, 0, 0);
+            }
+        }
+    }
+    const bool valid = i < N;
+#pragma unroll
+    for (int ig = 0; ig < NS; ++ig)
+#pragma unroll
+        for (int jg = 0; jg < NS; ++jg) {
+            const int e = (4*ig + q)*D + 4*jg + c4;
+            const double re = valid ? Yr[ig][jg] : 0.0, im = valid ? Yi[ig][jg] : 0.0;
+            tre[e*ROW + j] = re;
+            tre[(DD + e)*ROW + j] = -im;
+            if (want_imag) {
+                tim[e*ROW + j] = im;
+                tim[(DD + e)*ROW + j] = re;
+            }
+        }
+    __syncthreads();
+    const size_t K = 2*DD;               // (a multiple of the MFMA k-step already)
+    double* are = AopRe + static_cast<size_t>(bt)*K*Npad;
+    double* aim = AopIm + static_cast<size_t>(bt)*K*Npad;
+    for (int idx = tid; idx < 2*DD*EPB; idx += 256) {
+        const int kk = idx / EPB, jj = idx % EPB;
+        if (i0 + jj < N) {
+            are[static_cast<size_t>(kk)*Npad + i0 + jj] = tre[kk*ROW + jj];
+            if (want_imag) aim[static_cast<size_t>(kk)*Npad + i0 + jj] = tim[kk*ROW + jj];
         }
     }
 }
@@ -222,7 +403,47 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
         double* are = AopRe + static_cast<size_t>(b0)*K*Npad;
         double* aim = AopIm + static_cast<size_t>(b0)*K*Npad;
         double* o = out + static_cast<size_t>(b0)*N*N*(want_imag ? 2 : 1);
-        switch (d) {
+        // d = 8, 16: all elements of a block at once (FFK_TUNE_LIOUVILLE_ROWS=0: the tile kernel)
+        static const bool rows_form = [] {
+            const char* e = std::getenv("FFK_TUNE_LIOUVILLE_ROWS");
+            return e == nullptr || e[0] != '0';
+        }();
+        bool done = false;
+        static const bool mfma_form = [] {        // FFK_TUNE_LIOUVILLE_MFMA=0: vector conjugation at d = 16
+            const char* e = std::getenv("FFK_TUNE_LIOUVILLE_MFMA");
+            return e == nullptr || e[0] != '0';
+        }();
+        if (mfma_form && d == 16) {
+            const size_t lds = static_cast<size_t>(want_imag ? 2 : 1)*2*256*17*sizeof(double);
+            auto kern = conjugate_basis_mfma16_kernel;
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e2 != hipSuccess) return e2;
+            hipLaunchKernelGGL(kern, dim3((N + 15)/16, nb), dim3(256), lds, stream, Us, basis, N, Npad, want_imag,
+                               are, aim);
+            done = true;
+        }
+        if (!done && rows_form && d == 8) {
+            const int epb = 256/d, dd = d*d;
+            const size_t tile = static_cast<size_t>(want_imag ? 2 : 1)*2*dd*(epb + 1)*sizeof(double);
+            const size_t cus = (static_cast<size_t>(epb)*(d*(d + 1) + 1))*sizeof(cplx);
+            const size_t lds = std::max(tile, cus);
+            auto go = [&](auto kern) -> hipError_t {
+                if (lds > 40*1024) {
+                    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        static_cast<int>(lds));
+                    if (e2 != hipSuccess) return e2;
+                }
+                hipLaunchKernelGGL(kern, dim3((N + epb - 1)/epb, nb), dim3(256), lds, stream, Us, basis, N,
+                                   Npad, want_imag, are, aim);
+                return hipGetLastError();
+            };
+            const hipError_t e3 = d == 16 ? go(conjugate_basis_rows_kernel<16>) : go(conjugate_basis_rows_kernel<8>);
+            if (e3 != hipSuccess) return e3;
+            done = true;
+        }
+        if (!done) switch (d) {
 #define FFK_CASE(D)                                                                              \
     case D: {                                                                                    \
         constexpr int EPB = 16;                                                                  \
