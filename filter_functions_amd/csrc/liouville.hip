@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void conjugate_basis_rows_kernel(const cplx* _
     }
 }
 
-// d = 16: the conjugation U^dag C_i U on the FP64 matrix cores, in the block-frequency form of the
+// d = 12, 16 (8 on request): the conjugation U^dag C_i U on the FP64 matrix cores, in the block-frequency form of the
 // accumulate kernels (ctrl_mfma.hip) with a BASIS ELEMENT per 4 x 4 x 4 block instead of a frequency:
 // v_mfma_f64_4x4x4_4b computes four independent products, lane (c, q) supplies A_b[c & 3][q] and
 // B_b[q][c & 3] of block b = c >> 2 and receives D_b[q][c & 3], so the first product
@@ -187,12 +187,14 @@ __global__ __launch_bounds__(256) void conjugate_basis_rows_kernel(const cplx* _
 // the tile kernel, whose LDS output tile and coalesced copy-out it shares.  The vector kernels read
 // an entry of U from LDS per complex multiply-add and are bound by that (rows kernel above: no
 // faster than the tile kernel at d = 16).
-__global__ __launch_bounds__(256) void conjugate_basis_mfma16_kernel(const cplx* __restrict__ U,
+template <int D>
+__global__ __launch_bounds__(256) void conjugate_basis_mfma_kernel(const cplx* __restrict__ U,
                                                                      const cplx* __restrict__ basis, int N,
                                                                      int Npad, int want_imag,
                                                                      double* __restrict__ AopRe,
                                                                      double* __restrict__ AopIm) {
-    constexpr int D = 16, DD = 256, NS = 4, EPB = 16, ROW = EPB + 1;
+    static_assert(D % 4 == 0 && D <= 16, "d = 4, 8, 12, 16");
+    constexpr int DD = D*D, NS = D/4, EPB = 16, ROW = EPB + 1;
     __shared__ cplx Us[DD];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double* tre = reinterpret_cast<double*>(lds_raw);                  // [2 DD][ROW]
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void conjugate_basis_mfma16_kernel(const cplx*
     const int c = lane & 15, q = lane >> 4, c4 = c & 3, b = c >> 2;
     const int i0 = blockIdx.x*EPB;
     const int j = 4*wave + b, i = i0 + j;             // this lane's basis element
-    Us[tid] = U[static_cast<size_t>(bt)*DD + tid];
+    if (tid < DD) Us[tid] = U[static_cast<size_t>(bt)*DD + tid];
     __syncthreads();
     cplx tq[NS][NS];                                  // U[4 s + q][4 g + c4]
 #pragma unroll
@@ -409,18 +411,30 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
             return e == nullptr || e[0] != '0';
         }();
         bool done = false;
-        static const bool mfma_form = [] {        // FFK_TUNE_LIOUVILLE_MFMA=0: vector conjugation at d = 16
+        // FFK_TUNE_LIOUVILLE_MFMA=0: vector conjugation throughout; =8: the matrix-core kernel also at d = 8
+        static const int mfma_env = [] {
             const char* e = std::getenv("FFK_TUNE_LIOUVILLE_MFMA");
-            return e == nullptr || e[0] != '0';
+            return e ? std::atoi(e) : -1;
         }();
-        if (mfma_form && d == 16) {
-            const size_t lds = static_cast<size_t>(want_imag ? 2 : 1)*2*256*17*sizeof(double);
-            auto kern = conjugate_basis_mfma16_kernel;
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-            if (e2 != hipSuccess) return e2;
-            hipLaunchKernelGGL(kern, dim3((N + 15)/16, nb), dim3(256), lds, stream, Us, basis, N, Npad, want_imag,
-                               are, aim);
+        const bool mfma_form = mfma_env != 0;
+        const int mfma_also = mfma_env == 8 ? 8 : -1;
+        if (mfma_form && (d == 16 || d == 12 || d == mfma_also)) {
+            const size_t lds = static_cast<size_t>(want_imag ? 2 : 1)*2*d*d*17*sizeof(double);
+            auto go = [&](auto kern) -> hipError_t {
+                if (lds > 40*1024) {
+                    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        static_cast<int>(lds));
+                    if (e2 != hipSuccess) return e2;
+                }
+                hipLaunchKernelGGL(kern, dim3((N + 15)/16, nb), dim3(256), lds, stream, Us, basis, N, Npad,
+                                   want_imag, are, aim);
+                return hipGetLastError();
+            };
+            const hipError_t e3 = d == 16 ? go(conjugate_basis_mfma_kernel<16>)
+                                  : d == 12 ? go(conjugate_basis_mfma_kernel<12>)
+                                            : go(conjugate_basis_mfma_kernel<8>);
+            if (e3 != hipSuccess) return e3;
             done = true;
         }
         if (!done && rows_form && d == 8) {

@@ -209,6 +209,29 @@ def test_liouville_representation():
     assert np.allclose(L, np.diag([1, 1, -1, -1]), atol=1e-15)
 
 
+@pytest.mark.parametrize('d,batch,hermitian', [(8, 5, True), (8, 3, False), (12, 4, True), (12, 2, False),
+                                               (16, 3, True), (16, 2, False), (4, 7, False)])
+def test_liouville_representation_against_the_oracle(d, batch, hermitian):
+    """U^dag C_i U on the matrix cores (d = 12, 16: conjugate_basis_mfma_kernel) and all elements of a
+    block at once (d = 8), Hermitian and non-Hermitian bases (real resp. complex result), batch sizes
+    that leave the last element block partly empty -- against the oracle's einsum."""
+    rng = np.random.default_rng(1000*d + batch)
+    basis = np.array(ff.Basis.ggm(d))
+    if not hermitian:
+        # orthonormal but not Hermitian: unitary mixtures of pairs of GGM elements (as in the
+        # reference-generated d = 3 fixture)
+        for k in range(1, d*d - 1, 3):
+            a, b = basis[k].copy(), basis[k + 1].copy()
+            basis[k], basis[k + 1] = (a + 1j*b)/np.sqrt(2), (a - 1j*b)/np.sqrt(2)
+    H = rng.standard_normal((batch, d, d)) + 1j*rng.standard_normal((batch, d, d))
+    U = np.linalg.qr(H)[0]
+    L = ff.liouville_representation(U, ff.Basis(basis))
+    ref = orc.liouville_representation(U, basis)
+    assert L.shape == ref.shape
+    assert np.iscomplexobj(L) == (not hermitian)
+    assert rel_err(L, ref) < 1e-13
+
+
 @pytest.mark.parametrize('name', ['rand_d2_ggm', 'rand_d3_ggm', 'rand_d4_pauli', 'rand_d4_ggm',
                                   'edge_degenerate_d4'])
 def test_intermediates(name):
