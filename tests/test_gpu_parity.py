@@ -666,13 +666,23 @@ def test_decay_amplitudes_gemm_against_oracle(A, N, W, s_ndim):
     assert np.abs(got - ref).max() <= 1e-12*max(np.abs(ref).max(), 1e-300)
 
 
-@pytest.mark.parametrize('d,btype', [(3, 'GGM'), (4, 'Pauli'), (5, 'GGM'), (8, 'Pauli'), (16, 'GGM')])
+@pytest.mark.parametrize('d,btype', [(3, 'GGM'), (4, 'Pauli'), (5, 'GGM'), (8, 'Pauli'), (16, 'GGM'),
+                                     (16, 'Pauli'), (12, 'GGM'), (3, 'dense'), (4, 'dense'), (8, 'dense')])
 def test_cumulant_function_against_trace_free_oracle(d, btype):
     """The device contraction against the oracle's trace-free formulation (itself pinned against
     the reference's four-element-trace contraction for d <= 6), up to d = 16 where the N^4 trace
-    tensor would need 68 GB."""
+    tensor would need 68 GB.  GGM and Pauli bases take the sparse gathers, a dense (rotated)
+    orthonormal Hermitian basis the dense products (decay.hip: the device decides)."""
     rng = np.random.default_rng(d)
-    basis = ff.Basis.ggm(d) if btype == 'GGM' else ff.Basis.pauli(int(np.log2(d)))
+    if btype == 'dense':
+        # an orthogonal mixture of the GGM elements: orthonormal, Hermitian, traceless beyond the
+        # identity, and every element dense
+        ggm = np.asarray(ff.Basis.ggm(d))
+        O = np.linalg.qr(rng.standard_normal((d*d - 1, d*d - 1)))[0]
+        basis = ff.Basis(np.concatenate((ggm[:1], np.tensordot(O, ggm[1:], axes=1))))
+        assert np.count_nonzero(np.abs(np.asarray(basis)[1:]) > 1e-14) > 0.9*(d*d - 1)*d*d
+    else:
+        basis = ff.Basis.ggm(d) if btype == 'GGM' else ff.Basis.pauli(int(np.log2(d)))
     N = d*d
     gamma = rng.standard_normal((2, 3, N, N))
     got = numeric._cumulant_function(gamma, basis)
