@@ -207,6 +207,12 @@ SIGNATURES = {
     'ffk_resident_control_matrix': (c_int, [c_void_p, c_void_p]),
     'ffk_resident_control_matrix_dev': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p),
                                                 POINTER(c_void_p)]),
+    'ffk_resident_filter_function_infidelity': (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                                        c_void_p, c_int, c_int, c_void_p, c_int,
+                                                        c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                                        c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                                        POINTER(c_void_p), POINTER(c_void_p),
+                                                        POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
     'ffk_resident_infidelity': (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
                                         c_void_p]),
     'ffk_ipc_get_handle': (c_int, [c_void_p, c_void_p]),

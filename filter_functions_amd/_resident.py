@@ -110,10 +110,13 @@ class ResidentResult:
     def __reduce__(self):
         return (type(None), ())
 
-    def evaluate(self, hamiltonian, dt, t, omega, basis, n_opers, n_coeffs, c_coeffs=None):
+    def evaluate(self, hamiltonian, dt, t, omega, basis, n_opers, n_coeffs, c_coeffs=None,
+                 spectrum=None, idx=None, d_infidelity=None):
         """One pass; returns (eigvals, eigvecs, propagators, filter_function) as arrays that view
         the handle's pinned memory (no copy).  *hamiltonian* is the summed (G, d, d) array, or --
-        with *c_coeffs* (n_cops, G) -- the control operators (n_cops, d, d), summed on the device."""
+        with *c_coeffs* (n_cops, G) -- the control operators (n_cops, d, d), summed on the device.
+        With *spectrum* (validated, ``util.parse_spectrum``), *idx* and *d_infidelity* the infidelity
+        integral rides in the same pass and is returned as a fifth item (controls form only)."""
         H, dt, t, omega = as_c128(hamiltonian), as_f64(dt), as_f64(t), as_f64(omega)
         C, B, s = as_c128(basis), as_c128(n_opers), as_f64(n_coeffs)
         d = H.shape[1]
@@ -122,7 +125,21 @@ class ResidentResult:
         results = tuple(ctypes.byref(p) for p in out)
         # (plain addresses: every array is bound to a local name until the call has returned, and
         # `.ctypes.data` is half the price of `.ctypes.data_as(c_void_p)` -- ten arguments per call)
-        if c_coeffs is None:
+        infid = None
+        if spectrum is not None:
+            c = as_f64(c_coeffs)
+            if c.shape != (len(H), G):
+                raise ValueError(f'Expected c_coeffs of shape ({len(H)}, {G}), not {c.shape}.')
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            real = not np.iscomplexobj(spectrum)
+            S = as_f64(spectrum) if real else as_c128(spectrum)
+            n_idx = len(idx)
+            infid = np.empty((n_idx, n_idx) if S.ndim == 3 else (n_idx,), dtype=np.float64)
+            check(self._lib.ffk_resident_filter_function_infidelity(
+                self._handle, H.ctypes.data, len(H), c.ctypes.data, dt.ctypes.data, t.ctypes.data, G, d,
+                omega.ctypes.data, W, C.ctypes.data, N, B.ctypes.data, A, s.ctypes.data, S.ctypes.data,
+                S.ndim, int(real), idx.ctypes.data, n_idx, int(d_infidelity), *results, infid.ctypes.data))
+        elif c_coeffs is None:
             check(self._lib.ffk_resident_filter_function(
                 self._handle, H.ctypes.data, dt.ctypes.data, t.ctypes.data, G, d, omega.ctypes.data, W,
                 C.ctypes.data, N, B.ctypes.data, A, s.ctypes.data, *results))
@@ -143,6 +160,8 @@ class ResidentResult:
         # `F.copy()` is an ordinary writable array that takes the array route)
         F.flags.writeable = False
         self._filter_function = weakref.ref(F)
+        if infid is not None:
+            return D, V, Q, F, infid
         return D, V, Q, F
 
     def adopt(self, shape, filter_function):

@@ -2246,11 +2246,13 @@ __global__ void assemble_hamiltonian_kernel(const cplx* __restrict__ opers, cons
 // longer handed out simply never matches again and is evicted in turn (8 entries).
 struct ResidentGraphKey {
     int dev, G, d, W, N, A, n_c, on_device;
+    int s_ndim, n_idx, d_inf;                        // the integral riding in the pass (0: none)
     const void *dp, *hp, *ws;
     hipStream_t stream;
     unsigned long long epoch;
     bool operator==(const ResidentGraphKey& o) const {
         return dev == o.dev && G == o.G && d == o.d && W == o.W && N == o.N && A == o.A && n_c == o.n_c &&
+               s_ndim == o.s_ndim && n_idx == o.n_idx && d_inf == o.d_inf &&
                on_device == o.on_device && dp == o.dp && hp == o.hp && ws == o.ws && stream == o.stream &&
                epoch == o.epoch;
     }
@@ -2275,11 +2277,15 @@ bool resident_graphs_enabled() {
 // One resident pass; the Hamiltonian either given (G, d, d) or as control operators and
 // amplitudes, in which case only the amplitudes cross PCIe (8 n_c B per segment instead of
 // 16 d^2) and the sum runs on the device.
+// Optionally the infidelity integral rides in the same pass (spectrum != NULL): ff.infidelity on a
+// pulse with nothing cached is then ONE round trip to the device instead of two.
 int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_opers, int n_c,
                   const double* c_coeffs, const double* dt, const double* t, int G, int d,
                   const double* omega, int W, const double* basis, int N, const double* n_opers, int A,
                   const double* n_coeffs, double** eigvals, double** eigvecs, double** propagators,
-                  double** filter_function) {
+                  double** filter_function, const double* spectrum = nullptr, int s_ndim = 0,
+                  int spectrum_is_real = 0, const int32_t* idx = nullptr, int n_idx = 0, int d_inf = 0,
+                  double* infid = nullptr) {
     FFK_REQUIRE(r, "NULL handle");
     FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
@@ -2290,12 +2296,25 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
     int dev = 0;
     FFK_HIP(hipGetDevice(&dev));
     const ResidentLayout L = resident_layout(G, d, W, N, A);
-    if (r->device != dev || r->dev.size < L.end || r->pin.size < L.outputs_end) {
+    // spectrum (as c128), idx and the integrals live behind the outputs in the pinned block: the kernel
+    // reads and writes them there (mapped memory), nothing extra crosses PCIe by copy
+    size_t o_spec = 0, o_idx = 0, o_out = 0, pin_need = L.outputs_end, n_out = 0, s_rows = 0;
+    if (spectrum) {
+        FFK_REQUIRE(idx && infid && s_ndim >= 1 && s_ndim <= 3 && n_idx >= 1 && n_idx <= A && d_inf >= 1 && W >= 2,
+                    "bad spectrum arguments");
+        s_rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? size_t(n_idx) : size_t(n_idx)*n_idx);
+        n_out = s_ndim == 3 ? size_t(n_idx)*n_idx : size_t(n_idx);
+        o_spec = align_up(L.outputs_end);
+        o_idx = o_spec + align_up(16*s_rows*W);
+        o_out = o_idx + align_up(sizeof(int32_t)*size_t(n_idx));
+        pin_need = o_out + align_up(8*n_out);
+    }
+    if (r->device != dev || r->dev.size < L.end || r->pin.size < pin_need) {
         g_dev_pool.give(r->dev);
         g_pin_pool.give(r->pin);
         r->dev = r->pin = Block{nullptr, 0, -1};
         if (int rc = g_dev_pool.take(L.end, dev, &r->dev)) return rc;
-        if (int rc = g_pin_pool.take(L.outputs_end, dev, &r->pin)) return rc;
+        if (int rc = g_pin_pool.take(pin_need, dev, &r->pin)) return rc;
         r->device = dev;
     }
     r->G = G; r->d = d; r->W = W; r->N = N; r->A = A; r->L = L;
@@ -2333,14 +2352,24 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
     std::memcpy(hp + L.basis, basis, 16*size_t(N)*dd);
     std::memcpy(hp + L.n_opers, n_opers, 16*size_t(A)*dd);
     std::memcpy(hp + L.n_coeffs, n_coeffs, 8*size_t(A)*G);
+    if (spectrum) {
+        double* hs = reinterpret_cast<double*>(hp + o_spec);
+        if (spectrum_is_real) {
+            for (size_t i = 0; i < s_rows*W; ++i) { hs[2*i] = spectrum[i]; hs[2*i + 1] = 0.0; }
+        } else {
+            std::memcpy(hs, spectrum, 16*s_rows*W);
+        }
+        std::memcpy(hp + o_idx, idx, sizeof(int32_t)*size_t(n_idx));
+    }
     hipStream_t s;
     if (int rc = resident_stream(&s)) return rc;
     // scratch of the pass from the shared arena (held only for the duration of this call)
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t wsb = ffk_pipeline_workspace_bytes(W, N, A, G, d, 0, 0);
     const size_t hsb = on_device ? align_up(16*size_t(G)*dd) : 0;
+    const size_t iwsb = spectrum ? align_up(ffk_infidelity_workspace_bytes(W, n_idx, s_ndim)) : 0;
     void* ws;
-    if (int rc = arena_reserve(wsb + hsb, &ws)) return rc;
+    if (int rc = arena_reserve(wsb + hsb + iwsb, &ws)) return rc;
     StreamDrain drain{s};      // (the successful path has synchronised already: a no-op then)
     const auto clock1 = std::chrono::steady_clock::now();
     auto dptr = [dp](size_t off) { return reinterpret_cast<double*>(dp + off); };
@@ -2368,10 +2397,17 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
             return rc;
         if (int rc = ffk_eigensolver_status_dev(ws, wsb, G, d, reinterpret_cast<int32_t*>(dp + L.status), s))
             return rc;
+        if (spectrum)
+            if (int rc = ffk_infidelity_dev(dptr(L.F), A, W, reinterpret_cast<const double*>(hp + o_spec), s_ndim,
+                                            dptr(L.omega), reinterpret_cast<const int32_t*>(hp + o_idx), n_idx,
+                                            d_inf, reinterpret_cast<double*>(hp + o_out),
+                                            static_cast<unsigned char*>(ws) + wsb + hsb, iwsb, s))
+                return rc;
         FFK_HIP(hipMemcpyAsync(hp + L.D, dp + L.D, L.outputs_end - L.D, hipMemcpyDeviceToHost, s));
         return FFK_OK;
     };
-    const ResidentGraphKey key{dev, G, d, W, N, A, hamiltonian ? 0 : n_c, on_device ? 1 : 0, dp, hp, ws, s,
+    const ResidentGraphKey key{dev, G, d, W, N, A, hamiltonian ? 0 : n_c, on_device ? 1 : 0,
+                               spectrum ? s_ndim : 0, spectrum ? n_idx : 0, spectrum ? d_inf : 0, dp, hp, ws, s,
                                g_knob_epoch.load()};
     ResidentGraph* hit = nullptr;
     ResidentGraph* victim = &g_resident_graphs[0];
@@ -2436,6 +2472,7 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
     *eigvecs = reinterpret_cast<double*>(hp + L.V);
     *propagators = reinterpret_cast<double*>(hp + L.Q);
     *filter_function = reinterpret_cast<double*>(hp + L.F);
+    if (spectrum) std::memcpy(infid, hp + o_out, 8*n_out);
     r->valid = true;
     return FFK_OK;
 }
@@ -2443,6 +2480,20 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
 }  // namespace
 
 extern "C" {
+
+int ffk_resident_filter_function_infidelity(ffk_resident* r, const double* c_opers, int n_cops,
+                                            const double* c_coeffs, const double* dt, const double* t, int G,
+                                            int d, const double* omega, int W, const double* basis, int N,
+                                            const double* n_opers, int A, const double* n_coeffs,
+                                            const double* spectrum, int s_ndim, int spectrum_is_real,
+                                            const int32_t* idx, int n_idx, int d_infidelity, double** eigvals,
+                                            double** eigvecs, double** propagators, double** filter_function,
+                                            double* infidelity) {
+    FFK_REQUIRE(spectrum && idx && infidelity, "NULL argument");
+    return resident_pass(r, nullptr, c_opers, n_cops, c_coeffs, dt, t, G, d, omega, W, basis, N, n_opers, A,
+                         n_coeffs, eigvals, eigvecs, propagators, filter_function, spectrum, s_ndim,
+                         spectrum_is_real, idx, n_idx, d_infidelity, infidelity);
+}
 
 int ffk_resident_filter_function(ffk_resident* r, const double* hamiltonian, const double* dt,
                                  const double* t, int G, int d, const double* omega, int W,

@@ -288,10 +288,18 @@ def infidelity(pulse, spectrum, omega, n_oper_identifiers=None, which='total',
             check(_lib.load().ffk_filter_function_weighted(ptr(R), A, N, W, ptr(weights),
                                                            1.0/pulse.d, ptr(filter_function)))
         else:
-            filter_function = pulse.get_filter_function(omega, which='fidelity',
-                                                        show_progressbar=show_progressbar,
-                                                        cache_intermediates=cache_intermediates)
-        infid = _integrate_filter_function(filter_function, spectrum, omega, idx, pulse.d, pulse)
+            if pulse.nothing_cached_for(omega, cache_intermediates):
+                # filter function AND integral in one library call (the filter function ends up
+                # cached as after get_filter_function)
+                parsed = util.parse_spectrum(spectrum, as_f64(omega), np.asarray(idx))
+                infid = pulse._resident_pass(spectrum=parsed, idx=idx)
+                filter_function = None
+            else:
+                filter_function = pulse.get_filter_function(omega, which='fidelity',
+                                                            show_progressbar=show_progressbar,
+                                                            cache_intermediates=cache_intermediates)
+        if filter_function is not None:
+            infid = _integrate_filter_function(filter_function, spectrum, omega, idx, pulse.d, pulse)
     else:
         if pulse.is_cached('omega') and not np.array_equal(pulse.omega, omega):
             raise ValueError('Pulse correlation infidelities requested '

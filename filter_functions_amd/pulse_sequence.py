@@ -356,13 +356,17 @@ class PulseSequence:
                 and not any(key in self._frequency_data
                             for key in ('control_matrix', 'control_matrix_pc')))
 
-    def _resident_pass(self, keep_filter_function=True):
+    def _resident_pass(self, keep_filter_function=True, spectrum=None, idx=None):
         """diagonalize + control matrix + filter function in one library call; the control matrix
         stays on the device behind a :class:`Deferred` cache entry.  (``cache_control_matrix`` caches
-        no filter function in the reference: *keep_filter_function* False leaves it out.)"""
+        no filter function in the reference: *keep_filter_function* False leaves it out.)  With a
+        validated *spectrum* and *idx* the infidelity integral rides in the same call and is
+        returned."""
         result = ResidentResult()
-        D, V, Q, F = result.evaluate(self.c_opers, self.dt, self.t, self.omega, np.asarray(self.basis),
-                                     self.n_opers, self.n_coeffs, c_coeffs=self.c_coeffs)
+        integral = {} if spectrum is None else dict(spectrum=spectrum, idx=idx, d_infidelity=self.d)
+        out = result.evaluate(self.c_opers, self.dt, self.t, self.omega, np.asarray(self.basis),
+                              self.n_opers, self.n_coeffs, c_coeffs=self.c_coeffs, **integral)
+        D, V, Q, F = out[:4]
         self._data.update(eigvals=D, eigvecs=V, propagators=Q, total_propagator=Q[-1])
         self._frequency_data['control_matrix'] = Deferred(result.control_matrix,
                                                           result.control_matrix_nbytes())
@@ -370,6 +374,14 @@ class PulseSequence:
             self._frequency_data['filter_function'] = F
         self._defer_by_products()
         self._resident = result
+        return out[4] if spectrum is not None else None
+
+    def nothing_cached_for(self, omega, cache_intermediates=False):
+        """Sets *omega* and says whether ``ff.infidelity`` can run the whole path and the integral in
+        one library call (``_resident_pass(spectrum=..., idx=...)``): a pulse with nothing to reuse."""
+        self.omega = omega
+        return ('filter_function' not in self._frequency_data and len(self.omega) >= 2
+                and self._resident_pass_applies('fidelity', 1, cache_intermediates))
 
     def _defer_by_products(self):
         """What the reference's cache_control_matrix computes on the spot -- total phase factors and

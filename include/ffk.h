@@ -507,6 +507,19 @@ int ffk_resident_filter_function_from_controls(ffk_resident* handle, const doubl
                                                const double* n_opers, int A, const double* n_coeffs,
                                                double** eigvals, double** eigvecs,
                                                double** propagators, double** filter_function);
+/* The same pass with the infidelity integral of numeric.infidelity (numeric.py:2063-2334, `which='total'`,
+ * traceless basis) riding in it: `ff.infidelity(pulse, S, omega)` on a pulse with nothing cached is one
+ * round trip to the device instead of two.  spectrum: (W,), (n_idx, W) or (n_idx, n_idx, W), f64 if
+ * spectrum_is_real else c128, already validated (util.parse_spectrum, util.py:214-227); idx: the noise
+ * operators' indices; d_infidelity: the dimension in 1/(2 pi d); infidelity: (n_idx,) resp. (n_idx, n_idx). */
+int ffk_resident_filter_function_infidelity(ffk_resident* handle, const double* c_opers, int n_cops,
+                                            const double* c_coeffs, const double* dt, const double* t,
+                                            int G, int d, const double* omega, int W, const double* basis,
+                                            int N, const double* n_opers, int A, const double* n_coeffs,
+                                            const double* spectrum, int s_ndim, int spectrum_is_real,
+                                            const int32_t* idx, int n_idx, int d_infidelity,
+                                            double** eigvals, double** eigvecs, double** propagators,
+                                            double** filter_function, double* infidelity);
 /* host-clock seconds of the last pass: [0] packing the inputs into the pinned block, [1] enqueueing
  * the H2D copy, the kernels and the D2H copy, [2] waiting for the stream                         */
 int ffk_resident_timing(ffk_resident* handle, double* seconds);

@@ -2138,6 +2138,43 @@ def test_frequencies_on_and_around_the_resonances(d, G, A):
     assert (num <= 1e-11*den).all(), omega[np.argmax(num/den)]
 
 
+def test_infidelity_on_a_fresh_pulse_is_one_library_call():
+    """ff.infidelity(pulse, S, omega) on a pulse with nothing cached: path and integral in ONE pass
+    (ffk_resident_filter_function_infidelity) -- same integrals as the two-call route and as the
+    array route for spectra of one, two and three dimensions, identifier subsets and complex
+    spectra; the filter function is cached afterwards; a second call integrates the resident F."""
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs(G=30, W=500, seed=11)
+    basis = ff.Basis.pauli(2)
+    H_c, H_n = list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs))
+
+    def fresh():
+        return ff.PulseSequence(H_c, H_n, dt, basis)
+    rng = np.random.default_rng(3)
+    S1 = 1e-3/omega
+    S2 = np.outer([1.0, 2.0, 3.0], 1e-3/omega)
+    X = rng.standard_normal((3, 3, len(omega)))
+    S3 = (np.einsum('abo,cbo->aco', X, X) + 0j)*1e-3
+    S2c = S2*(1 + 0.3j)
+    lib = _lib.load()
+    for S, ids in ((S1, None), (S2, None), (S3, None), (S2c, None), (S2[[2, 0]], [2, 0]), (S1, [1])):
+        one = fresh()
+        kw = {} if ids is None else {'n_oper_identifiers': one.n_oper_identifiers[ids]}
+        got = ff.infidelity(one, S, omega, **kw)
+        assert one._resident is not None and one.is_cached('filter_function')
+        two = fresh()
+        two.get_filter_function(omega)
+        ref2 = ff.infidelity(two, S, omega, **kw)
+        arr = fresh()
+        arr.diagonalize()                                   # anything cached -> array route
+        ref = ff.infidelity(arr, S, omega, **kw)
+        assert got.shape == ref.shape == ref2.shape
+        assert rel_err(got, ref2) < 1e-14 and rel_err(got, ref) < 1e-13
+        assert rel_err(one.get_filter_function(omega), arr.get_filter_function(omega)) < 1e-13
+        assert rel_err(ff.infidelity(one, S, omega, **kw), got) < 1e-14      # resident F, second call
+    with pytest.raises(ValueError):
+        ff.infidelity(fresh(), np.ones((2, 5)), omega)
+
+
 def test_resident_pass_replayed_from_its_captured_graph():
     """The user-facing pass is captured as a hipGraph the first time a shape runs on a pair of pooled
     blocks and REPLAYED afterwards (ffk_api.hip::resident_pass): pulses of one shape evaluated one
