@@ -908,28 +908,31 @@ def main():
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved/FP64_PEAK_TFLOPS, 'frac_step': step_tflops/FP64_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_source': traffic_src,
-                'frac_contraction_only': (16.0*d**3 + 6.0*d*d)*A*G*args.omega_per_gpu/(acc_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
-                'frac_executed': ((16.0*d**3 + 6.0*d*d)*A + 18.0*(d*(d - 1) + 1) + 62.0)*G*args.omega_per_gpu/(acc_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+                'frac_r3_algorithm': ((16.0*d**3 + 6.0*d*d)*A + 18.0*(d*(d - 1) + 1) + 62.0)*G*args.omega_per_gpu/(acc_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+                'frac_of_power_capped_fma_stream': achieved/59.4,
                 'avg_launch_ms': acc_ms, 'launches_timed': n_ev + n_extra,
                 'launches_in_timed_region': n_ev,
                 'avg_launch_ms_in_timed_region': float(np.mean(in_region_ms)),
                 'launch_ms_min_max': [float(np.min(in_region_ms + extra_ms)),
                                       float(np.max(in_region_ms + extra_ms))],
                 'flops_per_launch': stats['accumulate_flops'],
-                'note': 'FP64 vector-FMA issue bound (the kernel issues v_fma_f64 only; vector = '
-                        'matrix FP64 peak 78.6 TFLOP/s on MI355X); flops = FMA-counted flops of the '
-                        'Hilbert-space algorithm actually run; frac = dominant kernel alone (HIP events, '
-                        'each instrumented launch gated on the previous accumulate kernel), frac_step = '
-                        'the same flops over the whole step time -- above frac when passes pipeline: '
-                        'consecutive accumulate kernels then overlap ramp and tail; frac_contraction_only = the '
-                        'contraction FMAs alone, (16 d^3 + 6 d^2) A per (segment, omega), without the modelled 55 flop '
-                        'per integral entry (a direct evaluation: sincos 26 + reciprocal 9 + 20; the model has been the '
-                        'same since round 1 so that rounds compare); frac_executed = what the kernel executes since the '
-                        'round-3 generator (ffk_math.h::phased_integral_aa): 18 flop per entry + 62 per (segment, omega) '
-                        'for the two sincos and the phase; SURVEY 8(d)\'s (8 d^2 + 8) flop per element is the Liouville-space form, '
-                        'which this kernel does not execute, and is not used here.  A pure v_fma_f64 stream on random '
-                        'operands sustains 59 TFLOP/s on this part at an in-kernel clock of 1.89 GHz (2.38 GHz on '
-                        'constants: tools/fp64_ceiling_probe.hip, profiles/r03_d_*)',
+                'note': 'FP64 vector-FMA issue bound, and on this part power bound (the kernel issues '
+                        'v_fma_f64 / v_mul_f64 only; vector = matrix FP64 peak 78.6 TFLOP/s on MI355X); '
+                        'flops = FMA-counted flops the kernel EXECUTES (ffk_api.hip::accumulate_flops): since '
+                        'round 4 (real integral tile, phases folded into the frequency-independent '
+                        'operands) 838 per operator + 198 per tile = 2712 per (segment, omega) at A = 3, '
+                        'where the round-3 kernel executed 3656 for the same elements; frac = dominant '
+                        'kernel alone (HIP events, each instrumented launch gated on the previous accumulate '
+                        'kernel), frac_step = the same flops over the whole step time -- above frac when '
+                        'passes pipeline; frac_r3_algorithm = the SAME elements priced at the round-3 '
+                        'kernel\'s executed flops (3656): a speed comparison with BENCH_r03\'s 0.605, not a '
+                        'utilisation -- an algorithm that needs fewer flops per element lowers frac and '
+                        'raises `value`; frac_of_power_capped_fma_stream = achieved / 59.4 TFLOP/s, what a '
+                        'pure v_fma_f64 stream on random operands sustains on this part at its 1400 W cap '
+                        '(in-kernel clock 1.89 GHz; 2.38 GHz on constants: tools/fp64_ceiling_probe.hip, '
+                        'profiles/r03_d_*; rocm-smi reads ~1000 W averaged over a pass of which this kernel '
+                        'is 60 %, profiles/r04_e_*); SURVEY 8(d)\'s (8 d^2 + 8) flop per element is the '
+                        'Liouville-space form, which this kernel does not execute, and is not used here',
             },
             'roofline_hbm': {
                 'bound': 'hbm', 'achieved': stats['accumulate_bytes']/(acc_ms*1e-3)/1e9,

@@ -1,4 +1,4 @@
-// ctrl_pc.hip -- K3p: the control-matrix accumulation for small d with SPECIALISED wavefronts.
+// ctrl_pc.hip -- K3p: the control-matrix accumulation for d = 4 with SPECIALISED wavefronts.
 // Same mathematics, inputs, output layout and per-lane arithmetic as ctrl.hip (one frequency per
 // lane, 64 per wave; Y_a(w) = sum_g T_g^dag [Bbar_a o E_g(w)] T_g), different division of labour:
 // every sub-chunk of a block consists of ONE producer wavefront, which generates the whole integral
@@ -10,35 +10,66 @@
 // (profiles/r01_c_*: generation alone 43 us, contraction alone 80 us, together 111 us).  Here they
 // run side by side on every SIMD.  Producers sit on different SIMDs (sub-chunk s -> wave s of its
 // group): with four sub-chunks of one producer and three consumers every SIMD hosts exactly one
-// producer and three consumers, and with 13 entries the producer's ~555 instructions per segment
-// match a consumer's 576.
+// producer and three consumers (checked with HW_ID stamps, profiles/r04_a_*).
 // The consumers take T_g through SCALAR loads (wave-uniform addresses, issued one segment ahead at
 // the end of the previous one): 32 doubles in SGPRs feed v_fma_f64 directly instead of occupying
-// 64 VGPRs, which brings the kernel to 104 VGPRs, i.e. four wavefronts per SIMD.  (The first
-// version of ctrl.hip fed ALL operands from scalar loads issued right before their use and spent
-// 60 % of its time waiting for them; here the loads have a whole barrier interval to land.)
-// Measured at config 2 on one box: symmetric kernel 108.4 us, 3 sub-chunks with T_g from LDS
-// 104.5 us (166 VGPRs), 3 sub-chunks scalar T_g 106.9 us, 4 sub-chunks scalar T_g 100.8 us.
+// 64 VGPRs, which brings the kernel to 104 VGPRs, i.e. four wavefronts per SIMD.
+//
+// Round 4 (profiles/r04_*): three changes, each from a measurement.
+//  * REAL tile.  E = psi e^{ib} q with q = 2 sin(a + b)/x real and psi = e^{i w t_g} e^{ia} per
+//    (segment, frequency) (ffk_math.h).  The producer publishes the 13 distinct q and psi only; the
+//    phase e^{ib}, Bbar and the first T are folded into W_a[m][n][j] = Bbar_a[m][n] e^{i b_mn} T[n][j]
+//    (frequency independent, one element per producer lane).  Consumers: Z[m][j] = sum_n q[m][n]
+//    W[m][n][j] (real x complex), z = psi Z, Y[i][j] += conj(T[m][i]) z: 448 instead of 576 vector
+//    instructions per consumer and segment, ~250 instead of ~440 for the producer.
+//  * Queue instead of barrier.  The per-wavefront timeline (tools/trace_pc.py) of the round-3
+//    kernel: wavefronts of a SIMD finish one after the other (the arbiter serves the oldest), the
+//    block waits ~400 cycles for the release of its 16-wavefront s_barrier and every consumer starts
+//    with the same burst of LDS reads: ~1000 of a step's ~9700 cycles without issue.  Now each
+//    sub-chunk is a single-producer / NC-consumer queue over its two tile buffers, with a `ready`
+//    count written by the producer and a `done` count per consumer in LDS: a consumer that finds its
+//    tile ready (the usual case) never waits, the producer sleeps until its buffer is free.  The
+//    sub-chunks drift apart, so a SIMD always has wavefronts in other phases to issue from; because
+//    the arbiter would let the oldest sub-chunk run away, a consumer that is k tiles behind the most
+//    advanced sub-chunk raises its priority to min(k, 2) (soft lockstep: 71.1 -> 67.8 us per step).
+//  * The consumer's segment is ONE generated asm block (ctrl_pc_consumer.inc): the folded operands
+//    have no reuse, so their LDS reads must fly ahead of their use inside a 112-VGPR budget; hipcc
+//    serialised them (read, s_waitcnt 0, two FMAs) or spilled the accumulators.
+// Same box, bench schedule: round-3 kernel 78.1 us per step, this one 67.4-70.7.
+// Dropped (lost their A/B, records in profiles/r03_c_*, r03_u_*, r04_*): matrix-core consumers (two
+// forms, also under sustained load), Bbar folded into T with a complex tile, T_g from LDS, four
+// wavefronts meeting at an LDS counter, one s_barrier per segment (70.1 vs 67.4 us with this tile).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
 #include "ffk_internal.h"
-#include "ffk_mfma_util.h"
+#ifndef FFK_PC_CONSUMER_INC   /* tuning builds: another ring depth */
+#define FFK_PC_CONSUMER_INC "ctrl_pc_consumer.inc"
+#endif
+#include FFK_PC_CONSUMER_INC   // generated: tools/gen_pc_consumer.py
 
 namespace ffk {
 namespace {
 
-#ifndef FFK_PC_WFOLD            /* 1: consumers contract with Bbar_mn T_nj from LDS (no Bbar o E pass) */
-#define FFK_PC_WFOLD 0
-#endif
-#ifndef FFK_PC_PRIO_PRODUCER   /* 0..3; tuning builds override */
-#define FFK_PC_PRIO_PRODUCER 1
-#endif
-#if defined(FFK_PC_SUB)       /* tuning builds */
-constexpr int kPcSub = FFK_PC_SUB;
+constexpr int kPcSub = 4;               // sub-chunks per block: 4 x (1 + 3) = 16 waves = 4 per SIMD
+constexpr int kPcSpinLimit = 1 << 21;   // bound of every flag wait: a stuck wait ends (results garbage)
+
+#ifdef FFK_PC_CLOCK   /* tuning build: per-wavefront timeline of the d = 4 kernel (tools/trace_pc.py) */
+// per wavefront kPcTraceLen words: [0] HW_ID | XCC_ID << 32, [1] role (0 producer, 1.. consumer),
+// [2] shader clock at kernel entry, [3] 100 MHz ticks at entry, [4] first loop top, then per step
+// (top = tile available / barrier passed, done = work finished), then loop end, kernel end (shader
+// clock), kernel end (100 MHz ticks)
+constexpr int kPcTraceSteps = 64, kPcTraceLen = 8 + 2*kPcTraceSteps;
+__device__ unsigned long long g_pc_trace[1024*16*kPcTraceLen];
+#define FFK_PC_STAMP(slot) \
+    do { if (pc_tr != nullptr && lane == 0) pc_tr[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FFK_PC_STEP_TOP(it) do { if ((it) < kPcTraceSteps) FFK_PC_STAMP(5 + 2*(it)); } while (0)
+#define FFK_PC_STEP_DONE(it) do { if ((it) < kPcTraceSteps) FFK_PC_STAMP(6 + 2*(it)); } while (0)
 #else
-constexpr int kPcSub = 4;   // sub-chunks per block: 4 x (1 + 3) = 16 waves = 4 per SIMD
+#define FFK_PC_STAMP(slot)
+#define FFK_PC_STEP_TOP(it)
+#define FFK_PC_STEP_DONE(it)
 #endif
 
 template <int D>
@@ -76,32 +107,50 @@ struct PcEntries {          // every entry once, the (coinciding) diagonal entri
     static constexpr Slots slot_table = make_table();
 };
 
-// MF != 0: the consumers contract on the FP64 matrix cores (v_mfma_f64_4x4x4_4b) instead of
-// v_fma_f64.  MF = 1: 16 frequencies on the instruction's columns, four groups per wavefront, a
-// 4 x 4 transpose across lanes between the two products (layout in ffk_mfma_util.h).  MF = 2: one
-// frequency per 4 x 4 x 4 block, the first product's result is the second's A operand as it stands.
-// The integral tile's slots are TS complex apart: 64 frequencies (+ 4 of padding for MF = 2, whose
-// lanes read 16 slots x 4 frequencies at once).
-constexpr int pc_tile_stride(int mf) { return mf == 2 ? 68 : 64; }
-template <int D, int NC, int MF = 0>
+// ---- LDS flags of the queue mode (every word is written by exactly one wavefront) ---------------
+// LDS operations of one wavefront execute in order, so "data, s_waitcnt lgkmcnt(0), flag" on the
+// writing side and "flag, then data" on the reading side is all the ordering there is to keep; the
+// asm memory clobbers keep the compiler from moving LDS accesses across the flag accesses.
+// Layout (ints): ready[sub] at [sub] (tiles of the sub-chunk that are complete), done of consumer c
+// of a sub-chunk at [4 + 4 sub + c] (tiles it has finished reading).
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double8_t __attribute__((ext_vector_type(8)));
+constexpr int kPcFlagWords = 4 + 4*kPcSub;
+typedef __attribute__((address_space(3))) int lds_int_t;    // (a generic volatile access would be a flat_ one)
+__device__ __forceinline__ void lds_publish(int* flag, int value, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) *(volatile lds_int_t*)(flag) = value;
+}
+__device__ __forceinline__ int lds_peek(const int* flag) {
+    return __builtin_amdgcn_readfirstlane(*(const volatile lds_int_t*)(flag));
+}
+// doubles of the LDS body: the four sub-chunks' double-buffered tiles, or (epilogue) the six
+// accumulator sets parked by the tree reduction, whichever is larger; the queue flags follow
+constexpr int kPcPlanes = 15;   // tile planes of 64 doubles: 13 distinct q | psi.re | psi.im
+__host__ __device__ constexpr int pc_lds_body_doubles(int d, int nc) {
+    const int buffers = kPcSub*2*(kPcPlanes*64 + 2*nc*d*d*d);
+    const int parked = 2*nc*d*d*64*2;
+    return buffers > parked ? buffers : parked;
+}
+
+template <int D, int NC>
 __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
     constexpr int GS = kPcSub, NWS = NC + 1;
-    constexpr int S = seg_stride(D), DD = D*D;
-    // cplx per integral tile: the D (D - 1) + 1 distinct entries only.  (With all D^2 slots the block
-    // held 140.5 KiB of LDS; a kernel of another pass needing more than ~8 KiB -- the scan: 9.5 KiB,
-    // the prologue: 17.5 KiB -- could then not be placed beside it and waited the whole 83 us for it
-    // to retire, tools/corun.hip and profiles/r02_q_*.)
-    constexpr int TS = pc_tile_stride(MF);
-    constexpr int TILE = PcEntries<D>::count*TS;
-#if FFK_PC_WFOLD
-    constexpr int OPS = DD + NC*D*DD;                 // T_g | W_a[m][n][j] = Bbar_a[m][n] T_g[n][j]
-#else
-    constexpr int OPS = (1 + NC)*DD;                  // T_g | Bbar_0 ..
-#endif
-    constexpr int BUF = TILE + OPS;                   // cplx per buffer: tile | operands
-    constexpr int SUB = 2*BUF + S;                    // cplx per sub-chunk: 2 buffers | 2 table rows
+    constexpr int S = seg_stride(D), DD = D*D, NE = PcEntries<D>::count;
+    static_assert(D == 4 && NE + 2 == kPcPlanes, "lane <-> (m, n, j) of the folded operand needs D^3 = 64");
+    // One buffer of a sub-chunk, in doubles: kPcPlanes planes of 64 (the REAL factors q of the NE
+    // distinct integral entries, psi.re, psi.im) | the folded operands W_a[m][n][j] (NC x 64 complex).
+    // (With complex entries and Bbar, T in LDS the block held 119 KiB; a kernel of another pass that
+    // needs more than what is left beside it waits for the whole accumulate kernel to retire,
+    // tools/corun.hip and profiles/r02_q_*.)
+    constexpr int QT = kPcPlanes*64, WS = 2*NC*D*DD;
+    constexpr int BUFD = QT + WS;                     // doubles per buffer
+    constexpr int SUBD = 2*BUFD;                      // per sub-chunk: 2 buffers
+    constexpr int YSZ = DD*64;                        // cplx of one consumer's accumulators
+    constexpr int BODY = pc_lds_body_doubles(D, NC);  // max(buffers, reduction slots), in doubles
+    static_assert(GS*SUBD <= BODY && 2*NC*YSZ*2 <= BODY, "flags live behind both uses of the body");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
     const int lane = threadIdx.x & 63;
@@ -114,449 +163,295 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
     const int alpha = alpha0 + cidx;
     const bool active = !producer && alpha < A;
     const int n_alpha = min(NC, A - alpha0);
-    cplx* lds = reinterpret_cast<cplx*>(lds_raw) + static_cast<size_t>(sub)*SUB;
-    double* rows = reinterpret_cast<double*>(lds + 2*BUF);
+    double* ldsd = reinterpret_cast<double*>(lds_raw) + static_cast<size_t>(sub)*SUBD;
+    // queue flags behind the body
+    int* flags = reinterpret_cast<int*>(reinterpret_cast<double*>(lds_raw) + BODY);
+    int* my_ready = flags + sub;
+    int* my_done = flags + 4 + 4*sub;
     const int iw = blockIdx.x*64 + lane;
-    const double om = omega[iw < W ? iw : W - 1];
     const int sub_len = (chunk_len + GS - 1)/GS;
     const int g0 = blockIdx.z*chunk_len + sub*sub_len;
     const int g1 = min(min(G, static_cast<int>(blockIdx.z + 1)*chunk_len), g0 + sub_len);
+    const int n_it = max(0, g1 - g0);                 // tiles of this sub-chunk
+#ifdef FFK_PC_CLOCK
+    unsigned long long* pc_tr = nullptr;
+    {
+        const unsigned bl = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);
+        if (bl < 1024 && wave_all < 16) {
+            pc_tr = g_pc_trace + (static_cast<size_t>(bl)*16 + wave_all)*kPcTraceLen;
+            if (lane == 0) {
+                pc_tr[0] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                           (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11))) << 32);
+                pc_tr[1] = producer ? 0 : 1 + cidx;
+                pc_tr[2] = __builtin_amdgcn_s_memtime();
+                pc_tr[3] = __builtin_amdgcn_s_memrealtime();
+            }
+        }
+    }
+#endif
 
-    // Tile of the FIRST segment: generated by all waves of the sub-chunk together (every NWS-th entry
-    // each, the per-frequency trigonometry recomputed by each wave), after the producer has staged
-    // the table rows.  Left to the producer alone, its dependent chains kept the twelve consumer
-    // waves of a block waiting ~2.5 us of the block's ~83 us.
-    auto generate_first_share = [&]() {
-        const double* st = rows;                          // slot 0 = row g0
-        cplx* tile = lds + lane;                          // buffer 0
+    // The q planes of one segment for the entries k0, k0 + kstep, ...: the table row is read through
+    // SCALAR loads (its address is wave-uniform: dE, sin b, cos b feed the arithmetic as SGPR
+    // operands, no LDS staging of rows), all entries on the straight-line path first -- thirteen
+    // independent chains the hardware can interleave -- and the rare near-resonance lanes patched
+    // afterwards under one branch.  (Round 3 walked the entries one by one with an LDS read and a
+    // divergent branch each: a chain of ~6 k cycles per segment, which became the critical path once
+    // the consumers' work shrank, profiles/r04_c_*.)
+    auto generate = [&](double* buf, int g, double om, int k0, int kstep, bool with_psi) __attribute__((always_inline)) {
+        const double* st = segtab + static_cast<size_t>(g)*S;
+        double* qt = buf + lane;
         const double dtg = st[0];
         cplx ph;
-        sincos_pi<true>(om*st[1], &ph.im, &ph.re);
+        sincos_pi<false>(om*st[1], &ph.im, &ph.re);
         double sa, ca;
-        sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
-        constexpr auto& sl = PcEntries<D>::slots;
+        sincos_pi<false>(0.5*(om*dtg), &sa, &ca);
         const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
-        for (int k = wl; k < PcEntries<D>::count; k += NWS) {
-            const int e = sl.v[k];
-            const double* r = st + seg_rec(e);
-            tile[k*TS] = phased_integral_aa(pf, r[0], r[1], r[2]);
+        if (with_psi) {
+            qt[NE*64] = pf.pr;
+            qt[(NE + 1)*64] = pf.pi;
+        }
+        constexpr auto& sl = PcEntries<D>::slots;
+        double qv[NE];
+        unsigned near = 0u;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            if (k % kstep != k0 % kstep && kstep != 1) continue;
+            const double* r = st + seg_rec(sl.v[k]);
+            const double x = om + r[0];
+            qv[k] = fma(pf.sa2, r[2], pf.ca2*r[1])*rcp_fast(x);
+            near |= (fabs(x) < pf.thr ? 1u : 0u) << k;
+        }
+        if (near != 0u) {
+#pragma unroll
+            for (int k = 0; k < NE; ++k) {
+                if (k % kstep != k0 % kstep && kstep != 1) continue;
+                const double* r = st + seg_rec(sl.v[k]);
+                if ((near >> k) & 1u) qv[k] = phased_q(pf, r[0], r[1], r[2]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            if (k % kstep != k0 % kstep && kstep != 1) continue;
+            qt[k*64] = qv[k];
         }
     };
 
     if (producer) {
-        // ---- producer: operands + table rows -> LDS, integral tile of the next segment ----------
-        // Static issue priority: the producer's work is a chain of dependent operations (argument
+        // ---- producer: tile and folded operands of the next segment ------------------------------
+        // Static issue priority: the producer's work is chains of dependent operations (argument
         // reduction -> polynomial -> reciprocal -> entries); at equal priority it competes with three
-        // consumers' independent FMAs for every issue slot, finishes last and all 16 waves wait for it
-        // at the barrier.  One s_setprio before the loop, no per-segment flips: accumulate 92.0 ->
-        // 86.2 us at config 2 (priority 3: the same; consumers at priority 1 instead: 94.6 us).
-        __builtin_amdgcn_s_setprio(FFK_PC_PRIO_PRODUCER);
+        // consumers' independent FMAs for every issue slot, finishes last and everybody waits for it.
+        // One s_setprio before the loop, no per-segment flips (priority 1: the same; 0: 74 instead of
+        // 67.8 us per step, profiles/r04_d_*).
+        __builtin_amdgcn_s_setprio(3);
+        const double om = omega[iw < W ? iw : W - 1];
         const int n_ops = (1 + n_alpha)*DD;           // <= 64: one element per lane
-        auto load_ops = [&](int g) -> cplx {
-            const cplx* src = ops + static_cast<size_t>(g)*(1 + A)*DD;
-            return lane < n_ops ? src[lane < DD ? lane : lane + alpha0*DD] : cplx{0.0, 0.0};
+        struct Staged {
+            cplx o;           // lane l: element l of [T | Bbar_0 | Bbar_1 ..] of the segment
+            double sb, cb;    // sin b, cos b of entry (m, n) = l >> 2
         };
-        // operands of one segment into LDS; lane l holds element l of [T | Bbar_0 | Bbar_1 ..]
-        auto store_ops = [&](cplx* dst, cplx o) {
-#if FFK_PC_WFOLD
-            // W_a[m][n][j] = Bbar_a[m][n] T[n][j], (m, n, j) = this lane's index: the factors come
-            // from the lanes that loaded them
-            if (lane < DD) dst[lane] = o;
-            const int src_t = lane % DD;                          // T[n][j]
-            const cplx tv = {__shfl(o.re, src_t, 64), __shfl(o.im, src_t, 64)};
+        auto load_ops = [&](int g) __attribute__((always_inline)) -> Staged {
+            const cplx* src = ops + static_cast<size_t>(g)*(1 + A)*DD;
+            const double* r = segtab + static_cast<size_t>(g)*S + seg_rec(lane >> 2);
+            Staged t;
+            t.o = lane < n_ops ? src[lane < DD ? lane : lane + alpha0*DD] : cplx{0.0, 0.0};
+            t.sb = r[1];
+            t.cb = r[2];
+            return t;
+        };
+        // W_a[m][n][j] = Bbar_a[m][n] e^{i b_mn} T[n][j], (m, n, j) = this lane's index: the factors
+        // come from the lanes that loaded them
+        auto fold_ops = [&](double* buf, const Staged& t) __attribute__((always_inline)) {
+            const int src_t = lane & (DD - 1);                        // T[n][j]
+            const cplx tv = {__shfl(t.o.re, src_t, 64), __shfl(t.o.im, src_t, 64)};
+            const cplx et = cmul(cplx{t.cb, t.sb}, tv);
+            cplx* wb = reinterpret_cast<cplx*>(buf + QT);
 #pragma unroll
             for (int a = 0; a < NC; ++a) {
-                const int src_b = DD + a*DD + lane / D;           // Bbar_a[m][n]
-                const cplx bv = {__shfl(o.re, src_b, 64), __shfl(o.im, src_b, 64)};
-                dst[DD + a*D*DD + lane] = cmul(bv, tv);
-            }
-#else
-            if (lane < n_ops) dst[lane] = o;
-#endif
-        };
-        auto load_row = [&](int g) -> cplx {
-            const cplx* src = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
-            return lane < S/2 ? src[lane] : cplx{0.0, 0.0};
-        };
-        auto generate = [&](int buf, int slot) {
-            const double* st = rows + slot*S;
-            cplx* tile = lds + static_cast<size_t>(buf)*BUF + lane;
-            const double dtg = st[0];
-            cplx ph;
-            sincos_pi<true>(om*st[1], &ph.im, &ph.re);
-            double sa, ca;
-            sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
-            const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
-#pragma unroll
-            for (int k = 0; k < PcEntries<D>::count; ++k) {
-                constexpr auto& sl = PcEntries<D>::slots;
-                const int e = sl.v[k];
-                const double* r = st + seg_rec(e);
-                tile[k*TS] = phased_integral_aa(pf, r[0], r[1], r[2]);
+                const int src_b = DD + a*DD + (lane >> 2);            // Bbar_a[m][n]
+                const cplx bv = {__shfl(t.o.re, src_b, 64), __shfl(t.o.im, src_b, 64)};
+                wb[a*D*DD + lane] = cmul(bv, et);
             }
         };
-        static_assert((1 + NC)*DD <= 64 && S/2 <= 64, "one staging element per lane");
-        static_assert(!FFK_PC_WFOLD || D*DD == 64, "W_a has one element per lane");
-        // prologue: rows g0, g0+1 and operands g0 straight in, tile g0
+        static_assert((1 + NC)*DD <= 64, "one staging element per lane");
+        if (lane < 4) {                  // tile 0 is complete after the barrier
+            if (lane == 0) *(volatile lds_int_t*)(my_ready) = 1;
+            else *(volatile lds_int_t*)(my_done + (lane - 1)) = 0;
+        }
+        // tile g0: the planes by all wavefronts of the sub-chunk together (every NWS-th each; left to
+        // the producer alone its chains kept the consumers waiting), the operands folded here
         if (g0 < g1) {
-            const cplx r0 = load_row(g0), o0 = load_ops(g0);
-            const cplx r1 = g0 + 1 < g1 ? load_row(g0 + 1) : cplx{0.0, 0.0};
-            if (lane < S/2) {
-                reinterpret_cast<cplx*>(rows)[lane] = r0;
-                reinterpret_cast<cplx*>(rows + S)[lane] = r1;
-            }
-            store_ops(lds + TILE, o0);
-        }
-        __syncthreads();                              // rows of g0 visible to the whole sub-chunk
-        if (g0 < g1) generate_first_share();
-        __syncthreads();
-        for (int it = 0; it < sub_len; ++it) {
-            const int g = g0 + it;
-            const int nb = (it + 1) & 1;
-            if (g + 1 < g1) {
-                // operands of g+1 and the table row of g+2: loads now, LDS stores after the tile
-                const cplx o = load_ops(g + 1);
-                const cplx r = g + 2 < g1 ? load_row(g + 2) : cplx{0.0, 0.0};
-#if !(defined(FFK_PC_ABLATE) && FFK_PC_ABLATE == 1)   /* diagnostic: no generation */
-                generate(nb, nb);                     // row g+1 lives in slot (it+1) & 1
-#endif
-                store_ops(lds + static_cast<size_t>(nb)*BUF + TILE, o);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();      // row g+1 fully read before it is replaced
-                if (lane < S/2) reinterpret_cast<cplx*>(rows + (it & 1)*S)[lane] = r;
-            }
-            __syncthreads();
-        }
-    } else if constexpr (MF == 1) {
-        // ---- matrix-core consumers ---------------------------------------------------------------
-        // lane (cl = lane & 15, q = lane >> 4); per group wg of 16 frequencies (column cl):
-        //   step 1:  Z_m[j = q]  = sum_n T[n, j] X_m[n],  X_m[n = q] = Bbar[m, q] E[m, q]     (m = 0..3)
-        //   4 x 4 transpose of (m, q) across the 16-lane rows
-        //   step 2:  Y[i = q, j] += sum_m conj(T[m, i]) Z_m[j]
-        // Both steps take the SAME A operand, T[q][cl & 3] (conjugation through the NEG bits): one
-        // complex per lane and segment.  32 matrix instructions per group replace 128 v_fma_f64.
-        static_assert(D == 4, "one 4 x 4 block per matrix");
-        const int cl = lane & 15, q = lane >> 4, c4 = cl & 3;
-        double Yr[4][D], Yi[4][D];                    // [frequency group][column j], row i = q
-#pragma unroll
-        for (int wg = 0; wg < 4; ++wg)
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                Yr[wg][j] = 0.0;
-                Yi[wg][j] = 0.0;
-            }
-        // tile slot of entry (m, n = q): the diagonal entries share slot 0
-        int slot[D];
-#pragma unroll
-        for (int m = 0; m < D; ++m) {
-            const int e = m*D + q;
-            slot[m] = (m == q) ? 0 : e - (e > 5) - (e > 10);
+            const Staged t0 = load_ops(g0);
+            generate(ldsd, g0, om, wl, NWS, true);
+            fold_ops(ldsd, t0);
         }
         __syncthreads();
-        if (g0 < g1) generate_first_share();
-        __syncthreads();
-        for (int it = 0; it < sub_len; ++it) {
-            const int g = g0 + it;
-            if (active && g < g1) {
-                const cplx* tile = lds + static_cast<size_t>(it & 1)*BUF;
-                const cplx* opT = tile + TILE;
-                const cplx* opB = opT + (1 + cidx)*DD;
-                const cplx t = opT[q*D + c4];
-                cplx b[D];
-#pragma unroll
-                for (int m = 0; m < D; ++m) b[m] = opB[m*D + q];
-#pragma unroll
-                for (int wg = 0; wg < 4; ++wg) {
-                    const cplx* ecol = tile + 16*wg + cl;
-                    double zr[4], zi[4];
-#pragma unroll
-                    for (int m = 0; m < D; ++m) {
-                        const cplx x = cmul(b[m], ecol[slot[m]*64]);
-                        zr[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.re, x.re, 0.0, 0, 0, 0);
-                        zi[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.re, x.im, 0.0, 0, 0, 0);
-                        zr[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.im, x.im, zr[m], 0, 0, 1);
-                        zi[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.im, x.re, zi[m], 0, 0, 0);
+        FFK_PC_STAMP(4);
+        {
+            // queue mode: tile it+1 goes into buffer (it+1) & 1, whose previous tenant was tile it-1
+            for (int it = 0; it + 1 < n_it; ++it) {
+                const int g = g0 + it;
+                const int nb = (it + 1) & 1;
+                const Staged t = load_ops(g + 1);
+                if (it > 0) {
+                    for (int spin = 0; spin < kPcSpinLimit; ++spin) {
+                        int dn = lds_peek(my_done);
+                        if (n_alpha > 1) dn = min(dn, lds_peek(my_done + 1));
+                        if (n_alpha > 2) dn = min(dn, lds_peek(my_done + 2));
+                        if (dn >= it) break;
+                        __builtin_amdgcn_s_sleep(2);
                     }
-                    transpose_rows(zr);
-                    transpose_rows(zi);
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        Yr[wg][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.re, zr[j], Yr[wg][j], 0, 0, 0);
-                        Yi[wg][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.re, zi[j], Yi[wg][j], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        Yr[wg][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.im, zi[j], Yr[wg][j], 0, 0, 0);
-                        Yi[wg][j] = __builtin_amdgcn_mfma_f64_4x4x4f64(t.im, zr[j], Yi[wg][j], 0, 0, 1);
-                    }
+                    asm volatile("" ::: "memory");
                 }
-            }
-            __syncthreads();
-        }
-        // sub-chunks > 0 hand their accumulators to sub-chunk 0 through LDS (tiles are dead now)
-        cplx* red = reinterpret_cast<cplx*>(lds_raw);
-        constexpr int YSZ = DD*64;
-#pragma unroll
-        for (int s = 1; s < GS; ++s) {
-            if (sub == s) {
-                cplx* dst = red + static_cast<size_t>(cidx)*YSZ + lane;
-#pragma unroll
-                for (int wg = 0; wg < 4; ++wg)
-#pragma unroll
-                    for (int j = 0; j < D; ++j) dst[(wg*D + j)*64] = {Yr[wg][j], Yi[wg][j]};
-            }
-            __syncthreads();
-            if (sub == 0) {
-                const cplx* srcy = red + static_cast<size_t>(cidx)*YSZ + lane;
-#pragma unroll
-                for (int wg = 0; wg < 4; ++wg)
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        const cplx v = srcy[(wg*D + j)*64];
-                        Yr[wg][j] += v.re;
-                        Yi[wg][j] += v.im;
-                    }
-            }
-            __syncthreads();
-        }
-        if (sub == 0 && active) {
-#pragma unroll
-            for (int wg = 0; wg < 4; ++wg) {
-                const int iwm = blockIdx.x*64 + 16*wg + cl;
-                if (iwm < W) {
-                    cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W + iwm;
-#pragma unroll
-                    for (int j = 0; j < D; ++j) out[static_cast<size_t>(q*D + j)*W] = {Yr[wg][j], Yi[wg][j]};
-                }
+                FFK_PC_STEP_TOP(it);
+                generate(ldsd + nb*BUFD, g + 1, om, 0, 1, true);
+                fold_ops(ldsd + nb*BUFD, t);
+                lds_publish(my_ready, it + 2, lane);
+                FFK_PC_STEP_DONE(it);
             }
         }
-        return;
-    } else if constexpr (MF == 2) {
-        // ---- matrix-core consumers, one frequency per 4 x 4 x 4 block ----------------------------
-        // lane (c = lane & 15, q = lane >> 4) supplies A_b[c & 3][q], B_b[q][c & 3] of block
-        // b = c >> 2 and receives D_b[q][c & 3]: a product's result is the transpose of an A operand.
-        //   step 1:  P[n, i] = sum_m X[m, n] conj(T[m, i])     A = X^T: lane holds X[q][c & 3]
-        //   step 2:  Y[i, j] += sum_n P[n, i] T[n, j]          A = P^T: step 1's registers
-        // B is T[q][c & 3] in both steps (conjugation through the NEG bit), Bbar[q][c & 3] is read
-        // once per segment: 16 + 2 LDS reads and 16 complex products per lane and segment, 8 matrix
-        // instructions per set of four frequencies, 16 sets per wavefront.
-        static_assert(D == 4, "one 4 x 4 block per matrix");
-        const int cl = lane & 15, q = lane >> 4, c4 = cl & 3, b = cl >> 2;
-        double Yr[16], Yi[16];                        // [set]: Y[q][c4] at frequency 4 set + b
-#pragma unroll
-        for (int set = 0; set < 16; ++set) {
-            Yr[set] = 0.0;
-            Yi[set] = 0.0;
-        }
-        const int e_mine = q*D + c4;
-        const int slot = (q == c4) ? 0 : e_mine - (e_mine > 5) - (e_mine > 10);
-        __syncthreads();
-        if (g0 < g1) generate_first_share();
-        __syncthreads();
-        for (int it = 0; it < sub_len; ++it) {
-            const int g = g0 + it;
-            if (active && g < g1) {
-                const cplx* tile = lds + static_cast<size_t>(it & 1)*BUF;
-                const cplx* opT = tile + TILE;
-                const cplx t = opT[e_mine];
-                const cplx bb = opT[(1 + cidx)*DD + e_mine];
-                const cplx* ecol = tile + slot*TS + b;
-#pragma unroll
-                for (int set = 0; set < 16; ++set) {
-                    const cplx x = cmul(bb, ecol[4*set]);
-                    double pr = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, t.re, 0.0, 0, 0, 0);
-                    double pi = __builtin_amdgcn_mfma_f64_4x4x4f64(x.im, t.re, 0.0, 0, 0, 0);
-                    pr = __builtin_amdgcn_mfma_f64_4x4x4f64(x.im, t.im, pr, 0, 0, 0);
-                    pi = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, t.im, pi, 0, 0, 1);
-                    Yr[set] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr, t.re, Yr[set], 0, 0, 0);
-                    Yi[set] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr, t.im, Yi[set], 0, 0, 0);
-                    Yr[set] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi, t.im, Yr[set], 0, 0, 1);
-                    Yi[set] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi, t.re, Yi[set], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-        }
-        // sub-chunks > 0 hand their accumulators to sub-chunk 0 through LDS (tiles are dead now)
-        cplx* red = reinterpret_cast<cplx*>(lds_raw);
-        constexpr int YSZ = DD*64;
-#pragma unroll
-        for (int s = 1; s < GS; ++s) {
-            if (sub == s) {
-                cplx* dst = red + static_cast<size_t>(cidx)*YSZ + lane;
-#pragma unroll
-                for (int set = 0; set < 16; ++set) dst[set*64] = {Yr[set], Yi[set]};
-            }
-            __syncthreads();
-            if (sub == 0) {
-                const cplx* srcy = red + static_cast<size_t>(cidx)*YSZ + lane;
-#pragma unroll
-                for (int set = 0; set < 16; ++set) {
-                    const cplx v = srcy[set*64];
-                    Yr[set] += v.re;
-                    Yi[set] += v.im;
-                }
-            }
-            __syncthreads();
-        }
-        if (sub == 0 && active) {
-            cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD + e_mine)*W;
-#pragma unroll
-            for (int set = 0; set < 16; ++set) {
-                const int iws = blockIdx.x*64 + 4*set + b;
-                if (iws < W) out[iws] = {Yr[set], Yi[set]};
-            }
-        }
-        return;
+        FFK_PC_STAMP(5 + 2*kPcTraceSteps);
     } else {
-        // ---- consumers: Y += T^dag [Bbar o E] T on the tile of the current segment -------------
-#if defined(FFK_PC_PRIO_CONSUMER)     /* tuning builds */
-        __builtin_amdgcn_s_setprio(FFK_PC_PRIO_CONSUMER);
-#endif
-        cplx Y[D][D];
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int j = 0; j < D; ++j) Y[i][j] = {0.0, 0.0};
-#if !defined(FFK_PC_T_FROM_LDS)
-        // T_g through scalar loads (wave-uniform addresses -> SGPRs feeding v_fma_f64 directly):
-        // 64 VGPRs less per consumer; the loads for segment g+1 are issued at the end of segment g
-        cplx Ts[D][D];
+        // ---- consumers: Y += psi T^dag Z,  Z[m][j] = sum_n q[m][n] W[m][n][j]  ------------------
+        // q is REAL (E = psi e^{ib} q, the phase e^{ib} folded into W by the producer): the first
+        // product costs 2 instead of 4 multiply-adds per term and Bbar o E is never formed:
+        // 448 instead of 576 vector instructions per consumer and segment.
+        // Accumulators and T_g live in FIXED registers, the segment's work is one generated asm
+        // block (ctrl_pc_consumer.inc, tools/gen_pc_consumer.py): Y[i][j] = v[Y0 + 4 (4 i + j) : +3],
+        // T_g[m][i] = s[36 + 16 m + 4 i : +3].  T_g comes through scalar loads (wave-uniform addresses
+        // -> SGPR operands of v_fma_f64), issued for segment g+1 at the end of segment g.
+        double4_t Y0 = 0.0, Y1 = 0.0, Y2 = 0.0, Y3 = 0.0, Y4 = 0.0, Y5 = 0.0, Y6 = 0.0, Y7 = 0.0;
+        double8_t T0 = 0.0, T1 = 0.0, T2 = 0.0, T3 = 0.0;
         auto load_T = [&](int g) {
-            const cplx* tg = ops + static_cast<size_t>(g)*(1 + A)*DD;
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = 0; j < D; ++j) Ts[i][j] = tg[i*D + j];
+            const double8_t* tg = reinterpret_cast<const double8_t*>(ops + static_cast<size_t>(g)*(1 + A)*DD);
+            T0 = tg[0];
+            T1 = tg[1];
+            T2 = tg[2];
+            T3 = tg[3];
         };
-        if (g0 < g1) load_T(g0);
-#endif
+        const unsigned lds_base = static_cast<unsigned>(reinterpret_cast<uintptr_t>(ldsd));
+        auto contract = [&](int it) __attribute__((always_inline)) {
+            const unsigned buf = lds_base + static_cast<unsigned>((it & 1)*BUFD*sizeof(double));
+            const unsigned vq = buf + lane*8;                                   // plane[k][lane]
+            const unsigned vw = buf + QT*8 + cidx*(D*DD*16);                    // W_cidx[m][n][j]
+            asm volatile(FFK_PC_CONSUMER_ASM
+                         : FFK_PC_CONSUMER_Y_OPERANDS(Y0, Y1, Y2, Y3, Y4, Y5, Y6, Y7)
+                         : [vq] "v"(vq), [vw] "v"(vw), "{s[36:51]}"(T0), "{s[52:67]}"(T1), "{s[68:83]}"(T2),
+                           "{s[84:99]}"(T3)
+                         : FFK_PC_CONSUMER_CLOBBERS);
+        };
+        if (g0 < g1) {
+            load_T(g0);
+            const double om = omega[iw < W ? iw : W - 1];
+            generate(ldsd, g0, om, wl, NWS, wl == 0);
+        }
         __syncthreads();
-        if (g0 < g1) generate_first_share();
-        __syncthreads();
-        for (int it = 0; it < sub_len; ++it) {
-            const int g = g0 + it;
-#if defined(FFK_PC_ABLATE) && FFK_PC_ABLATE == 2      /* diagnostic: no contraction */
-            if (false) {
-#else
-            if (active && g < g1) {
-#endif
-                const cplx* tile = lds + static_cast<size_t>(it & 1)*BUF;
-                const cplx* src = tile + lane;
-                const cplx* opT = tile + TILE;                       // T[n][j]
-#if FFK_PC_WFOLD
-                const cplx* opW = opT + DD + cidx*D*DD;              // Bbar_alpha[m][n] T[n][j]
-#else
-                const cplx* opB = opT + (1 + cidx)*DD;               // Bbar_alpha[m][n]
-#endif
-#pragma unroll
-                for (int m = 0; m < D; ++m) {
-                    cplx Z[D];
-#pragma unroll
-                    for (int j = 0; j < D; ++j) Z[j] = {0.0, 0.0};
-#if FFK_PC_WFOLD
-                    // Z_j = sum_n E_mn (Bbar_mn T_nj): no separate Bbar o E pass
-#pragma unroll
-                    for (int n = 0; n < D; ++n) {
-                        const int slot = PcEntries<D>::slot_table.v[m*D + n];
-                        const cplx e = src[slot*64];
-#pragma unroll
-                        for (int j = 0; j < D; ++j) cmac(Z[j], opW[(m*D + n)*D + j], e);
-                    }
-#else
-                    cplx X[D];
-#pragma unroll
-                    for (int n = 0; n < D; ++n) {
-                        const int slot = PcEntries<D>::slot_table.v[m*D + n];
-                        X[n] = cmul(opB[m*D + n], src[slot*64]);
-                    }
-#pragma unroll
-                    for (int n = 0; n < D; ++n)
-#pragma unroll
-                        for (int j = 0; j < D; ++j) {
-#if !defined(FFK_PC_T_FROM_LDS)
-                            cmac(Z[j], Ts[n][j], X[n]);
-#else
-                            cmac(Z[j], opT[n*D + j], X[n]);
-#endif
-                        }
-#endif
-#pragma unroll
-                    for (int i = 0; i < D; ++i) {
-#if !defined(FFK_PC_T_FROM_LDS)
-                        const cplx t = Ts[m][i];
-#else
-                        const cplx t = opT[m*D + i];
-#endif
-#pragma unroll
-                        for (int j = 0; j < D; ++j) cmac_conj(Y[i][j], t, Z[j]);
-                    }
+        FFK_PC_STAMP(4);
+        if (active) {
+            int prio = 0;
+            for (int it = 0; it < n_it; ++it) {
+                // tile `it` published?  (usually yes: the producer works one tile ahead)
+                int lead = 0;
+                for (int spin = 0; spin < kPcSpinLimit; ++spin) {
+                    const int r0 = lds_peek(flags), r1 = lds_peek(flags + 1), r2 = lds_peek(flags + 2),
+                              r3 = lds_peek(flags + 3);
+                    const int mine = sub == 0 ? r0 : sub == 1 ? r1 : sub == 2 ? r2 : r3;
+                    lead = max(max(r0, r1), max(r2, r3)) - (it + 1);
+                    if (mine >= it + 1) break;
+                    __builtin_amdgcn_s_sleep(1);
                 }
+                asm volatile("" ::: "memory");
+                // tiles the most advanced sub-chunk is ahead of this one -> issue priority
+                lead = min(2, max(0, lead));
+                if (lead != prio) {
+                    prio = lead;
+                    if (lead == 0) __builtin_amdgcn_s_setprio(0);
+                    else if (lead == 1) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(2);
+                }
+                FFK_PC_STEP_TOP(it);
+                contract(it);
+                lds_publish(my_done + cidx, it + 1, lane);
+                FFK_PC_STEP_DONE(it);
+                // the scalar loads of the next T_g behind the flag (an opaque index: read-only
+                // __restrict__ data could otherwise be fetched early)
+                int gn = g0 + it + 1;
+                asm volatile("" : "+s"(gn));
+                if (it + 1 < n_it) load_T(gn);
             }
-#if !defined(FFK_PC_T_FROM_LDS)
-            if (g + 1 < g1) load_T(g + 1);
-#endif
-            __syncthreads();
+            __builtin_amdgcn_s_setprio(0);
         }
-        // sub-chunks > 0 hand their accumulators to sub-chunk 0 through LDS (tiles are dead now)
+        FFK_PC_STAMP(5 + 2*kPcTraceSteps);
+        __syncthreads();                              // every tile consumed: the buffers are free
+        // The four sub-chunks' accumulators are summed through LDS (the tiles are dead now) as a
+        // tree: sub-chunks 2, 3 -> 0, 1, then 1 -> 0, which writes the chunk's partial sum.
         cplx* red = reinterpret_cast<cplx*>(lds_raw);
-        constexpr int YSZ = DD*64;
+        cplx Y[D][D];
+        {
+            const double4_t yv[8] = {Y0, Y1, Y2, Y3, Y4, Y5, Y6, Y7};
 #pragma unroll
-        for (int s = 1; s < GS; ++s) {
-            if (sub == s) {
-                cplx* dst = red + static_cast<size_t>(cidx)*YSZ + lane;
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-#pragma unroll
-                    for (int j = 0; j < D; ++j) dst[(i*D + j)*64] = Y[i][j];
-            }
-            __syncthreads();
-            if (sub == 0) {
-                const cplx* srcy = red + static_cast<size_t>(cidx)*YSZ + lane;
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        const cplx v = srcy[(i*D + j)*64];
-                        Y[i][j].re += v.re;
-                        Y[i][j].im += v.im;
-                    }
-            }
-            __syncthreads();
+            for (int e = 0; e < DD; ++e) Y[e / D][e % D] = {yv[e >> 1][2*(e & 1)], yv[e >> 1][2*(e & 1) + 1]};
         }
-        if (sub == 0 && active && iw < W) {
-            cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W + iw;
+        auto park = [&](int slot) {
+            cplx* dst = red + static_cast<size_t>(slot)*YSZ + lane;
 #pragma unroll
             for (int i = 0; i < D; ++i)
 #pragma unroll
-                for (int j = 0; j < D; ++j) out[static_cast<size_t>(i*D + j)*W] = Y[i][j];
+                for (int j = 0; j < D; ++j) dst[(i*D + j)*64] = Y[i][j];
+        };
+        auto fetch_add = [&](int slot) {
+            const cplx* srcy = red + static_cast<size_t>(slot)*YSZ + lane;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const cplx v = srcy[(i*D + j)*64];
+                    Y[i][j].re += v.re;
+                    Y[i][j].im += v.im;
+                }
+        };
+        if (sub >= 2) park((sub - 2)*NC + cidx);
+        __syncthreads();
+        if (sub < 2) fetch_add(sub*NC + cidx);
+        __syncthreads();
+        if (sub == 1) park(cidx);
+        __syncthreads();
+        if (sub == 0) {
+            fetch_add(cidx);
+            if (active && iw < W) {
+                cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W + iw;
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) out[static_cast<size_t>(i*D + j)*W] = Y[i][j];
+            }
         }
+#ifdef FFK_PC_CLOCK
+        if (pc_tr != nullptr && lane == 0) {
+            pc_tr[6 + 2*kPcTraceSteps] = __builtin_amdgcn_s_memtime();
+            pc_tr[7 + 2*kPcTraceSteps] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
         return;
     }
     // producers keep the consumers' epilogue barriers company
-#pragma unroll
-    for (int s = 1; s < GS; ++s) {
-        __syncthreads();
-        __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+#ifdef FFK_PC_CLOCK
+    if (pc_tr != nullptr && lane == 0) {
+        pc_tr[6 + 2*kPcTraceSteps] = __builtin_amdgcn_s_memtime();
+        pc_tr[7 + 2*kPcTraceSteps] = __builtin_amdgcn_s_memrealtime();
     }
-}
-
-// FFK_TUNE_PC_MFMA: 0 vector consumers (default), 1 / 2 the matrix-core forms (tuning / A-B)
-int pc_consumer_form() {
-    static const int form = [] {
-        const char* e = std::getenv("FFK_TUNE_PC_MFMA");
-        return (e != nullptr && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0;
-    }();
-    return form;
+#endif
 }
 
 template <int D, int NC>
 hipError_t launch_pc(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                      int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
     const int lds = pc_accumulate_lds_bytes(D, NC);
-    const int form = pc_consumer_form();
-    auto kern = form == 2   ? ctrl_accumulate_pc_kernel<D, NC, 2>
-                : form == 1 ? ctrl_accumulate_pc_kernel<D, NC, 1>
-                            : ctrl_accumulate_pc_kernel<D, NC, 0>;
+    auto kern = ctrl_accumulate_pc_kernel<D, NC>;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (err != hipSuccess) return err;
@@ -572,10 +467,7 @@ bool pc_accumulate_supported(int d, int A) { return d == 4 && A >= 1; }
 int pc_accumulate_ops_per_block(int A) { return A >= 3 ? 3 : A; }
 int pc_accumulate_subchunks() { return kPcSub; }
 int pc_accumulate_lds_bytes(int d, int nc) {
-    const int S = seg_stride(d), dd = d*d;
-    const int ops = FFK_PC_WFOLD ? dd + nc*d*dd : (1 + nc)*dd;
-    const int entries = d*(d - 1) + 1;                // distinct integral entries (PcEntries<D>::count)
-    return static_cast<int>(kPcSub*(2*(entries*pc_tile_stride(pc_consumer_form()) + ops) + S)*sizeof(cplx));
+    return pc_lds_body_doubles(d, nc)*static_cast<int>(sizeof(double)) + kPcFlagWords*static_cast<int>(sizeof(int));
 }
 
 hipError_t launch_accumulate_pc(const double* omega, int W, const double* segtab, const cplx* ops,
@@ -591,3 +483,12 @@ hipError_t launch_accumulate_pc(const double* omega, int W, const double* segtab
 }
 
 }  // namespace ffk
+
+#ifdef FFK_PC_CLOCK
+// (tuning build only, not in include/ffk.h) the last launch's per-wavefront timeline
+extern "C" int ffk_debug_pc_trace(unsigned long long* out, int n_waves) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ffk::g_pc_trace),
+                               sizeof(unsigned long long)*ffk::kPcTraceLen*static_cast<size_t>(n_waves)) != hipSuccess;
+}
+extern "C" int ffk_debug_pc_trace_len(void) { return ffk::kPcTraceLen; }
+#endif

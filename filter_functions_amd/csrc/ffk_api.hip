@@ -161,11 +161,20 @@ int max_chunks_for(int W, int A, int G, int d) {
 }
 
 double accumulate_flops(int W, int A, int G, int d) {
-    // FMA-counted real flops of the accumulate kernel's algorithm (DESIGN.md "Roofline"):
-    //   contraction: (2 d^3 MAC + d^2 mul) complex per (g, w, a) = 16 d^3 + 6 d^2 flops
-    //   integral:    (d(d-1)+1) entries per (g, w), each ~ sincos(26) + reciprocal(9) + 14 misc
-    //                + complex phase multiply (6), counted as 55 flops; phase sincos 26
-    const double per_gw = (16.0*d*d*d + 6.0*d*d)*A + 55.0*(d*(d - 1) + 1) + 26.0;
+    // FMA-counted real flops the accumulate kernels EXECUTE per (segment, frequency)
+    // (DESIGN.md section 3).
+    // d = 4 (ctrl_pc.hip, round 4: real tile, folded operands): per operator 16 x (zz: 2 mul + 6 fma,
+    // z = psi zz: 2 mul + 2 fma, Y: 16 fma) = 832; per group of <= 3 operators the tile: 13 entries x
+    // 10 (x, addition theorem 3, reciprocal 5, product 1) + 62 (two sincos and psi) + 6 (e^{ib} T of
+    // the fold, one element per lane = one per frequency) and 6 per operator (Bbar times that).
+    if (d == 4 && ffk::pc_accumulate_supported(d, A))
+        return (838.0*A + 198.0*((A + 2)/3))*double(G)*double(W);
+    // other d: contraction (2 d^3 MAC + d^2 mul) complex per (g, w, a) = 16 d^3 + 6 d^2 flops; tile:
+    // ffk_math.h::phased_integral_aa, 18 flops per distinct entry (rotation 6, addition theorem 3,
+    // x 1, reciprocal 4, products 3 + 1), d(d-1)+1 entries per (g, w); two sincos and the phase: 62.
+    // (Rounds 1-3 reported a direct-evaluation model, 55 flops per entry + 26, which the kernels
+    // have not executed since the round-3 generator.)
+    const double per_gw = (16.0*d*d*d + 6.0*d*d)*A + 18.0*(d*(d - 1) + 1) + 62.0;
     return per_gw*double(G)*double(W);
 }
 

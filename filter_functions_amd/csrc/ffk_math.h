@@ -230,6 +230,8 @@ FFK_HD cplx first_order_integral_aa(double omega, double dE, double dt, double s
 // formed, the phase costs nothing extra, the x == 0 limit lives in the rare branch).  Near a
 // resonance (|x dt| < 2^-4, which includes x == 0 and zero-length segments) the sine comes from the
 // short polynomial -- the sum would cancel -- as in first_order_integral_aa.
+// E = psi e^{ib} q with q = 2 sin(a + b)/x REAL: the d = 4 kernel (ctrl_pc.hip) never forms E; it
+// folds e^{ib} into the frequency-independent operands and contracts with q (phased_q) alone.
 struct PhasedFrequency {
     double om, dt, thr;        // frequency, segment length, 2^-4/dt
     double pr, pi;             // psi = e^{i omega t_g} e^{i a}
@@ -247,10 +249,9 @@ FFK_HD PhasedFrequency phased_frequency(double om, double dt, cplx ph, double sa
     f.ca2 = ca + ca;
     return f;
 }
-FFK_HD cplx phased_integral_aa(const PhasedFrequency& f, double dE, double sb, double cb) {
+// the real factor 2 sin(a + b)/x of an entry (x == 0: dt)
+FFK_HD double phased_q(const PhasedFrequency& f, double dE, double sb, double cb) {
     const double x = f.om + dE;
-    const double er = fma(f.pr, cb, -(f.pi*sb));
-    const double ei = fma(f.pr, sb, f.pi*cb);
     double q;
     if (fabs(x) < f.thr) {
         double s, c;
@@ -259,6 +260,12 @@ FFK_HD cplx phased_integral_aa(const PhasedFrequency& f, double dE, double sb, d
     } else {
         q = fma(f.sa2, cb, f.ca2*sb)*rcp_fast(x);
     }
+    return q;
+}
+FFK_HD cplx phased_integral_aa(const PhasedFrequency& f, double dE, double sb, double cb) {
+    const double er = fma(f.pr, cb, -(f.pi*sb));
+    const double ei = fma(f.pr, sb, f.pi*cb);
+    const double q = phased_q(f, dE, sb, cb);
     return {q*er, q*ei};
 }
 

@@ -599,7 +599,7 @@ int ffk_set_accumulate_variant(int variant);
 /* Per-call statistics of the last ffk_control_matrix*_dev launch on this thread:
  * algorithmic FP64 flops of the accumulate kernel, its grid/block geometry, chunks used.   */
 typedef struct ffk_stats {
-    double accumulate_flops;   /* FMA-counted real flops of ffk::ctrl_accumulate           */
+    double accumulate_flops;   /* FMA-counted real flops ffk::ctrl_accumulate executes      */
     double accumulate_bytes;   /* HBM bytes it must move (inputs + partial sums)            */
     int chunks;                /* segment chunks                                            */
     int grid_x, grid_y, grid_z, block;
