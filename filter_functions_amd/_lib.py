@@ -24,7 +24,8 @@ FFK_ENOCONV = -4
 WANT_NOISE_OPERATORS = 0x1
 FF_FIDELITY = 0
 FF_GENERALIZED = 1
-MAX_D = 16
+MAX_D = 64             # include/ffk.h FFK_MAX_D: diagonalize, control matrix, filter function, Liouville
+MAX_D_TEMPLATED = 16   # FFK_MAX_D_TEMPLATED: intermediates, second order, gradients, cumulant, resident passes
 
 _dp = POINTER(c_double)
 _ip = POINTER(c_int32)

@@ -769,6 +769,28 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     geo.gsplit = 1;
     geo.pc = false;
     geo.pcw = false;
+    geo.generic = false;
+    if (generic_dimension(d)) {
+        // generic.hip: one 256-thread block per (frequency, operator, segment chunk); chunks only
+        // where W A alone does not fill the chip (every chunk costs a partial sum of A d^2 W)
+        geo.generic = true;
+        geo.mfma = false;
+        geo.wave_kernel = false;
+        geo.nwaves = 4;
+        geo.task_groups = A;
+        geo.na_blk = 1;
+        geo.nbuf = 1;
+        geo.lds_bytes = static_cast<int>(2*sizeof(cplx)*d*d + 64*sizeof(double));
+        int chunks = forced_chunks;
+        if (chunks <= 0) {
+            const long blocks = static_cast<long>(W)*A;
+            chunks = static_cast<int>(std::max<long>(1, (2L*device_cu_count() + blocks - 1)/blocks));
+        }
+        chunks = std::max(1, std::min(chunks, G));
+        geo.chunk_len = (G + chunks - 1)/chunks;
+        geo.chunks = (G + geo.chunk_len - 1)/geo.chunk_len;
+        return geo;
+    }
     geo.mfma = mfma_accumulate_supported(d) && g_mfma_policy != 1 && (d >= 12 || g_mfma_policy == 2);
     // d = 4: the producer/consumer kernel (ctrl_pc.hip) is the default -- 3.4 % faster than the
     // symmetric kernel below at config 2 (101 vs 104.5 us on the same box) and free of register
@@ -982,6 +1004,9 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
                              hipStream_t stream) {
+    if (geo.generic)
+        return launch_accumulate_generic(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
+                                         stream);
     if (geo.pc)
         return launch_accumulate_pc(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
                                     geo.chunk_len, Ypart, stream);

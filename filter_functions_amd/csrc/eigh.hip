@@ -329,6 +329,8 @@ hipError_t launch_count_failures(const int* status, int G, int32_t* out, hipStre
 
 hipError_t launch_eigh_expm(const cplx* H, const double* dt, int G, int d, double* eigvals,
                             cplx* eigvecs, cplx* seg_prop, int* status, hipStream_t stream) {
+    if (generic_dimension(d))
+        return launch_eigh_expm_generic(H, dt, G, d, eigvals, eigvecs, seg_prop, status, stream);
     switch (d) {
 #define FFK_CASE(D) \
     case D:         \

@@ -80,6 +80,8 @@ int fail(int code, const char* fmt, ...) {
     } while (0)
 
 bool d_ok(int d) { return d >= 2 && d <= FFK_MAX_D; }
+// entry points whose kernels are compiled per dimension (see include/ffk.h)
+bool d_templated_ok(int d) { return d >= 2 && d <= FFK_MAX_D_TEMPLATED; }
 
 // internal flag of ffk_control_matrix_dev: the workspace already holds segtab/Tc/ops (written by
 // the fused front end of ffk_pipeline_dev)
@@ -593,7 +595,7 @@ static int intermediates_impl(const double* eigvals, const double* eigvecs,
                               double* basis_transformed, double* phase_factors,
                               double* first_order_integral, double* control_matrix_step,
                               double* noise_operators_step) {
-    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D_TEMPLATED);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
     FFK_REQUIRE(eigvals && eigvecs && propagators && omega && n_opers && n_coeffs && dt && t,
                 "NULL argument");
@@ -948,7 +950,7 @@ int ffk_concatenate_sequence(const double* total_propagators, const double* tota
                              int N, int W, int which, double* control_matrix,
                              double* total_propagator, double* propagators_liouville,
                              double* filter_function) {
-    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D_TEMPLATED);
     FFK_REQUIRE(T >= 1 && G >= 1 && A >= 1 && N >= 1 && W >= 1, "empty axis");
     FFK_REQUIRE(!filter_function || which == 0, "the filter function needs the summed control matrix");
     FFK_REQUIRE(total_propagators && total_phases && control_matrix_table && index && basis &&
@@ -1038,7 +1040,7 @@ int ffk_noise_operators_from_atomic(const double* phases, const double* noise_op
     FFK_REQUIRE(noise_operators_atomic && noise_operators, "NULL argument");
     FFK_REQUIRE(G == 1 || (phases && propagators), "NULL argument");
     FFK_REQUIRE(G >= 1 && W >= 1 && A >= 1, "empty axis: G=%d W=%d A=%d", G, W, A);
-    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D_TEMPLATED);
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t dd = size_t(d)*d;
     const size_t nph = 16*size_t(G > 1 ? G - 1 : 1)*W, nat = 16*size_t(G)*W*A*dd;
@@ -1270,7 +1272,7 @@ int ffk_decay_amplitudes(const double* control_matrix, int n_pulses, int A, int 
 }
 
 size_t ffk_cumulant_function_workspace_bytes(int batch, int N, int d) {
-    if (batch < 1 || N < 1 || !d_ok(d)) return 0;
+    if (batch < 1 || N < 1 || !d_templated_ok(d)) return 0;
     return ffk::cumulant_workspace_bytes(batch, N, d);
 }
 
@@ -1279,7 +1281,7 @@ int ffk_cumulant_function_dev(const double* decay_amplitudes, int batch, int N, 
                               void* workspace, size_t workspace_bytes, void* stream) {
     FFK_REQUIRE(decay_amplitudes && basis && cumulant_function, "NULL argument");
     FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis");
-    FFK_REQUIRE(d_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D_TEMPLATED);
     FFK_REQUIRE(!single_qubit || (d == 2 && N == 4), "single-qubit expression needs d = 2, N = 4");
     if (!single_qubit) {
         FFK_REQUIRE(batch <= 65535, "batch %d too large", batch);
@@ -1297,7 +1299,7 @@ int ffk_cumulant_function(const double* decay_amplitudes, int batch, int N, int 
                           const double* basis, int single_qubit, double* cumulant_function) {
     FFK_REQUIRE(decay_amplitudes && basis && cumulant_function, "NULL argument");
     FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis");
-    FFK_REQUIRE(d_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D_TEMPLATED);
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t nG = 8*size_t(batch)*N*N;
     const size_t nB = 16*size_t(N)*d*d;
@@ -1327,7 +1329,7 @@ static int second_order_impl(const double* eigvals, const double* eigvecs,
                              const double* n_coeffs, const double* dt, const double* t, int G, int d,
                              double* filter_function_2, const double* spectrum, int s_ndim,
                              const int32_t* idx, int n_idx, double* frequency_shifts) {
-    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D_TEMPLATED);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
     FFK_REQUIRE(eigvals && eigvecs && propagators && omega && basis && n_opers && n_coeffs && dt && t,
                 "NULL argument");
@@ -1507,7 +1509,7 @@ int ffk_cumulant_function_second_order(const double* frequency_shifts, int batch
                                        const double* basis, double* cumulant_function) {
     FFK_REQUIRE(frequency_shifts && basis && cumulant_function, "NULL argument");
     FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis");
-    FFK_REQUIRE(d_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D_TEMPLATED);
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t nG = 8*size_t(batch)*N*N;
     const size_t nB = 16*size_t(N)*d*d;
@@ -1531,7 +1533,7 @@ int ffk_cumulant_function_second_order(const double* frequency_shifts, int batch
 }
 
 size_t ffk_second_order_workspace_bytes(int W, int N, int A, int G, int d) {
-    if (W < 1 || N < 1 || A < 1 || G < 1 || !d_ok(d)) return 0;
+    if (W < 1 || N < 1 || A < 1 || G < 1 || !d_templated_ok(d)) return 0;
     const size_t dd = size_t(d)*d;
     size_t b = 0;
     b += align_up(8*size_t(G)*ffk::seg_stride(d)) + align_up(16*size_t(G)*dd);        // segtab, Tc
@@ -1548,7 +1550,7 @@ int ffk_second_order_filter_function_dev(const double* eigvals, const double* ei
                                          const double* n_coeffs, const double* dt, const double* t,
                                          int G, int d, double* filter_function_2, void* workspace,
                                          size_t workspace_bytes, void* stream) {
-    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D_TEMPLATED);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
     FFK_REQUIRE(eigvals && eigvecs && propagators && omega && basis && n_opers && n_coeffs && dt && t &&
                     filter_function_2 && workspace, "NULL argument");
@@ -1604,7 +1606,7 @@ int ffk_frequency_shifts_shard_dev(const double* filter_function_2, int A, int N
 }
 
 size_t ffk_cumulant_function_second_order_workspace_bytes(int batch, int N, int d) {
-    if (batch < 1 || N < 1 || !d_ok(d)) return 0;
+    if (batch < 1 || N < 1 || !d_templated_ok(d)) return 0;
     return align_up(ffk::cumulant_second_order_workspace_bytes(batch, N, d));
 }
 
@@ -1613,7 +1615,7 @@ int ffk_cumulant_function_second_order_dev(const double* frequency_shifts, int b
                                            void* workspace, size_t workspace_bytes, void* stream) {
     FFK_REQUIRE(frequency_shifts && basis && cumulant_function && workspace, "NULL argument");
     FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis");
-    FFK_REQUIRE(d_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D_TEMPLATED);
     FFK_REQUIRE(workspace_bytes >= ffk_cumulant_function_second_order_workspace_bytes(batch, N, d),
                 "workspace too small");
     FFK_HIP(ffk::launch_cumulant_second_order(frequency_shifts, batch, N, d,
@@ -1991,7 +1993,7 @@ int ffk_liouville(const double* U, int batch, int d, const double* basis, int N,
 // fused device-resident pipeline
 // ---------------------------------------------------------------------------------------------
 size_t ffk_pipeline_workspace_bytes(int W, int N, int A, int G, int d, int n_idx, int s_ndim) {
-    if (W < 1 || N < 1 || A < 1 || G < 1 || !d_ok(d)) return 0;
+    if (W < 1 || N < 1 || A < 1 || G < 1 || !d_templated_ok(d)) return 0;
     size_t b = ffk_diagonalize_workspace_bytes(G, d) + ffk_control_matrix_workspace_bytes(W, N, A, G, d);
     b += align_up(8*size_t(G)*d) + align_up(16*size_t(G)*d*d) + align_up(16*size_t(G + 1)*d*d);
     b += align_up(16*size_t(A)*N*W) + align_up(16*size_t(A)*A*W);
@@ -2005,7 +2007,7 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
                      const int32_t* idx, int n_idx, double* eigvals, double* eigvecs,
                      double* propagators, double* control_matrix, double* filter_function,
                      double* infid, void* workspace, size_t workspace_bytes, void* stream) {
-    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D_TEMPLATED);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
     FFK_REQUIRE(hamiltonian && dt && t && omega && basis && n_opers && n_coeffs && workspace, "NULL argument");
     const bool want_infid = spectrum != nullptr && infid != nullptr;
@@ -2296,7 +2298,7 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
                   int spectrum_is_real = 0, const int32_t* idx = nullptr, int n_idx = 0, int d_inf = 0,
                   double* infid = nullptr) {
     FFK_REQUIRE(r, "NULL handle");
-    FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
+    FFK_REQUIRE(d_templated_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D_TEMPLATED);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
     FFK_REQUIRE(hamiltonian || (c_opers && c_coeffs && n_c >= 1), "NULL argument");
     FFK_REQUIRE(dt && t && omega && basis && n_opers && n_coeffs, "NULL argument");
@@ -2782,7 +2784,7 @@ extern "C" int ffk_selftest_host(int rounds, unsigned seed, char* report, int re
         }
     };
     for (int r = 0; r < rounds; ++r) {
-        const int d = pick(2, FFK_MAX_D), G = pick(1, 300), A = pick(1, 9), W = pick(1, 700);
+        const int d = pick(2, FFK_MAX_D_TEMPLATED), G = pick(1, 300), A = pick(1, 9), W = pick(1, 700);
         const int N = pick(1, d*d);
         // (a) arena: reserve, write all of it, grow, shrink requests
         void* base = nullptr;

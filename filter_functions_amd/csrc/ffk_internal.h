@@ -12,14 +12,19 @@
 
 namespace ffk {
 
-constexpr int kMaxD = 16;
+constexpr int kMaxD = 16;          // compile-time-D kernels (registers / wave-private LDS)
+constexpr int kMaxDGeneric = 64;   // runtime-d kernels of generic.hip (FFK_MAX_D)
 constexpr int kWave = 64;
 
 // Per-segment uniform table row (doubles): [0] = dt_g, [1] = t_g, [2..3] pad, then one 4-double
 // record per matrix entry e = m*d + n:  (dE = D_m - D_n, sin b, cos b, 0) with b = fl(dE*dt)/2,
 // the frequency-independent half-angle of first_order_integral_aa.  A record is one 32-byte LDS
 // read.  Rows are padded to a multiple of 8 doubles (64-byte aligned).
-__host__ __device__ constexpr int seg_stride(int d) { return ((4 + 4*d*d + 7)/8)*8; }
+// d > kMaxD (generic.hip): [0] = dt_g, [1] = t_g, [2..3] pad, then the d eigenvalues (the generic
+// accumulate kernel evaluates the integral entries directly and needs no per-entry records).
+__host__ __device__ constexpr int seg_stride(int d) {
+    return d > kMaxD ? ((4 + d + 7)/8)*8 : ((4 + 4*d*d + 7)/8)*8;
+}
 __host__ __device__ constexpr int seg_rec(int e) { return 4 + 4*e; }
 
 // Columns of the Hilbert-space accumulator kept per thread in ctrl_accumulate.
@@ -61,7 +66,9 @@ hipError_t launch_count_failures(const int* status, int G, int32_t* out, hipStre
 // 16-wave FMA loop finished 3 us after the loop ended, 230 us later; with s_setprio 3 after 7 us).
 __host__ __device__ constexpr int front_chunk(int d) { return d <= 8 ? 16 : 8; }
 // The fused front end is used while the serial part of its second kernel stays short.
-inline bool use_fused_front(int G, int d) { return (G + front_chunk(d) - 1)/front_chunk(d) <= 64; }
+inline bool use_fused_front(int G, int d) {
+    return d <= kMaxD && (G + front_chunk(d) - 1)/front_chunk(d) <= 64;
+}
 
 // ---- scan.hip --------------------------------------------------------------------------------
 size_t scan_workspace_bytes(int G, int d);
@@ -120,6 +127,7 @@ struct AccumGeometry {
     bool mfma;        // large-d matrix-core kernel (ctrl_mfma.hip): 16 frequencies per block
     bool pc;          // producer/consumer kernel (ctrl_pc.hip), d = 4
     bool pcw;         // producer/consumer kernel with column-split consumers (ctrl_pcw.hip), d = 8
+    bool generic;     // runtime-d kernel (generic.hip), d > 16: one block per (frequency, operator, chunk)
 };
 void set_use_wave_kernel(bool on);
 void set_use_gsplit(bool on);
@@ -289,6 +297,24 @@ hipError_t launch_noise_ops_from_atomic(const cplx* phases, const cplx* atomic, 
 // exp of a real N x N matrix (device pointers; t0, t1: N*N scratch each); see decay.hip
 hipError_t launch_expm_real(const double* A, int N, int squarings, double* out, double* const w[5],
                             hipStream_t stream);
+
+// ---- generic.hip (17 <= d <= kMaxDGeneric) -----------------------------------------------------
+bool generic_dimension(int d);
+hipError_t launch_eigh_expm_generic(const cplx* H, const double* dt, int G, int d, double* eigvals,
+                                    cplx* eigvecs, cplx* seg_prop, int* status, hipStream_t stream);
+hipError_t launch_prefix_products_generic(const cplx* seg_prop, int G, int d, cplx* Q, hipStream_t stream);
+hipError_t launch_prologue_generic(const double* eigvals, const cplx* eigvecs, const cplx* propagators,
+                                   const cplx* n_opers, const double* n_coeffs, const double* dt,
+                                   const double* t, int G, int d, int A, double* segtab, cplx* Tc, cplx* ops,
+                                   cplx* n_opers_transformed, cplx* eigvecs_propagated,
+                                   hipStream_t stream);
+hipError_t launch_accumulate_generic(const double* omega, int W, const double* segtab, const cplx* ops,
+                                     int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
+                                     hipStream_t stream);
+// U^dag C_i U into the Liouville GEMM's K-major operands (liouville.hip)
+hipError_t launch_conjugate_basis_generic(const cplx* U, int batch, int d, const cplx* basis, int N,
+                                          int Npad, int K, int want_imag, double* AopRe, double* AopIm,
+                                          hipStream_t stream);
 
 // ---- liouville.hip ---------------------------------------------------------------------------
 size_t liouville_workspace_bytes(int batch, int d, int N);

@@ -411,6 +411,12 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
             return e == nullptr || e[0] != '0';
         }();
         bool done = false;
+        if (generic_dimension(d)) {
+            const hipError_t eg = launch_conjugate_basis_generic(Us, nb, d, basis, N, Npad, K, want_imag, are,
+                                                                 aim, stream);
+            if (eg != hipSuccess) return eg;
+            done = true;
+        }
         // FFK_TUNE_LIOUVILLE_MFMA=0: vector conjugation throughout; =8: the matrix-core kernel also at d = 8
         static const int mfma_env = [] {
             const char* e = std::getenv("FFK_TUNE_LIOUVILLE_MFMA");

@@ -667,7 +667,8 @@ bool expand_force_sparse() {          // FFK_TUNE_EXPAND_SPARSE=1: 64-frequency 
 hipError_t launch_expand_chunks(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d,
                                 int W, cplx* R, void* ws, hipStream_t stream) {
     if (A > 65535 || N > 65535) return hipErrorInvalidValue;
-    if (d >= 8 && !expand_force_sparse()) return launch_expand_lds(Ypart, chunks, slab, A, N, d, W, R, ws, stream);
+    if (d >= 8 && d <= kMaxD && !expand_force_sparse())      // (d > 16: the tile would not fit LDS)
+        return launch_expand_lds(Ypart, chunks, slab, A, N, d, W, R, ws, stream);
     const CompactWs cw = slice_compact_ws(ws, N, d);
     hipLaunchKernelGGL(expand_chunks_kernel, dim3((W + 63)/64, A, N), dim3(64), 0, stream, Ypart,
                        chunks, slab, cw.nnz, cw.rows, cw.vals, N, d*d, W, R);
@@ -684,7 +685,7 @@ hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d
     cplx* vals = cw.vals;
     if (!compacted)
         hipLaunchKernelGGL(basis_compact_kernel, dim3(N), dim3(64), 0, stream, basis, d, nnz, rows, vals);
-    if (d >= 8 && !expand_force_sparse()) {
+    if (d >= 8 && d <= kMaxD && !expand_force_sparse()) {
         // both forms, each deciding on the device whether the basis is its kind (see basis_is_sparse)
         hipError_t err = launch_expand_lds(Bt, 1, 0, A2, N, d, W, R, ws, stream, 0);
         if (err != hipSuccess) return err;

@@ -338,6 +338,9 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
                            const double* t, int G, int d, int A, double* segtab, cplx* Tc,
                            cplx* ops, cplx* n_opers_transformed, cplx* eigvecs_propagated,
                            hipStream_t stream) {
+    if (generic_dimension(d))
+        return launch_prologue_generic(eigvals, eigvecs, propagators, n_opers, n_coeffs, dt, t, G, d, A, segtab,
+                                       Tc, ops, n_opers_transformed, eigvecs_propagated, stream);
     switch (d) {
 #define FFK_CASE(D)                                                                             \
     case D:                                                                                     \

@@ -213,6 +213,7 @@ size_t scan_workspace_bytes(int G, int d) {
 
 hipError_t launch_prefix_products(const cplx* seg_prop, int G, int d, cplx* Q, void* ws,
                                   hipStream_t stream) {
+    if (generic_dimension(d)) return launch_prefix_products_generic(seg_prop, G, d, Q, stream);
     switch (d) {
 #define FFK_CASE(D) \
     case D:         \

@@ -40,9 +40,13 @@ __all__ = ['diagonalize', 'calculate_control_matrix_from_scratch',
            'calculate_second_order_filter_function_from_atomic', 'calculate_frequency_shifts']
 
 
-def _check_d(d):
-    if not 2 <= d <= _lib.MAX_D:
-        raise ValueError(f'Hilbert space dimension d={d} unsupported: need 2 <= d <= {_lib.MAX_D}.')
+def _check_d(d, templated=False, what=None):
+    """The main path (diagonalize, control matrix / noise operators, filter function, Liouville
+    representation) serves d <= 64; *templated* entry points (kernels compiled per dimension) d <= 16."""
+    limit = _lib.MAX_D_TEMPLATED if templated else _lib.MAX_D
+    if not 2 <= d <= limit:
+        raise ValueError(f'Hilbert space dimension d={d} unsupported' + (f' for {what}' if what else '')
+                         + f': need 2 <= d <= {limit}.')
 
 
 def diagonalize(hamiltonian, dt):
@@ -132,6 +136,8 @@ def calculate_control_matrix_from_scratch(eigvals, eigvecs, propagators, omega, 
     if W == 0:
         R[...] = 0
     else:
+        if cache_intermediates:
+            _check_d(d, templated=True, what='cache_intermediates=True')
         check(lib.ffk_control_matrix(ptr(eigvals), ptr(eigvecs), ptr(propagators), ptr(omega), W,
                                      ptr(basis_arr), N, ptr(n_opers), A, ptr(n_coeffs), ptr(dt),
                                      ptr(t), G, d, 0, ptr(R), None))
@@ -376,7 +382,7 @@ def calculate_noise_operators_from_atomic(phases, noise_operators_atomic, propag
         raise ValueError(f'Expected noise_operators_atomic of shape (G, n_omega, n_nops, d, d), '
                          f'not {Ba.shape}.')
     G, W, A, d = Ba.shape[:4]
-    _check_d(d)
+    _check_d(d, templated=True)
     ph = as_c128(np.asarray(phases)[:max(G - 1, 0)])
     props = as_c128(np.asarray(propagators)[:max(G - 1, 0)])
     if G > 1 and (ph.shape != (G - 1, W) or props.shape != (G - 1, d, d)):
@@ -663,7 +669,7 @@ def calculate_frequency_shifts(pulse, spectrum, omega, n_oper_identifiers=None,
     C, B = as_c128(np.asarray(pulse.basis)), as_c128(pulse.n_opers)
     s, dt = as_f64(pulse.n_coeffs), as_f64(pulse.dt)
     G, d = D.shape
-    _check_d(d)
+    _check_d(d, templated=True)
     A, N, W, n_idx = len(B), len(C), len(omega), len(idx)
     t = np.concatenate(([0.0], dt.cumsum()))
     F2 = np.empty((A, A, N, N, W), dtype=np.complex128)
@@ -713,7 +719,7 @@ def calculate_second_order_filter_function_from_scratch(eigvals, eigvecs, propag
     s = as_f64(n_coeffs)
     dt = as_f64(dt)
     G, d = D.shape
-    _check_d(d)
+    _check_d(d, templated=True)
     if cache_cumulative:
         raise NotImplementedError('cache_cumulative: the per-segment cumulative second-order filter '
                                   'function is not materialised by the device path.')
@@ -769,7 +775,7 @@ def calculate_second_order_filter_function_from_atomic(filter_function_atomic,
 
 def _cumulant_function(decay_amplitudes, basis, frequency_shifts=None):
     N, d = basis.shape[:2]
-    _check_d(d)
+    _check_d(d, templated=True)
     G = as_f64(decay_amplitudes)
     if G.ndim < 2 or G.shape[-2:] != (N, N):
         raise ValueError(f'Expected decay amplitudes of shape (..., {N}, {N}), not {G.shape}.')

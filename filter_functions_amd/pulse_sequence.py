@@ -350,7 +350,7 @@ class PulseSequence:
     def _resident_pass_applies(self, which, order, cache_intermediates):
         """The one-call evaluation serves the plain request on a pulse that has nothing to reuse."""
         return (order == 1 and which == 'fidelity' and not cache_intermediates
-                and len(self.omega) > 0 and 2 <= self.c_opers.shape[-1] <= numeric._lib.MAX_D
+                and len(self.omega) > 0 and 2 <= self.c_opers.shape[-1] <= numeric._lib.MAX_D_TEMPLATED
                 and self.d == self.c_opers.shape[-1]      # (a user-overridden d: the array route)
                 and not any(key in self._data for key in _DIAGONALIZATION)
                 and not any(key in self._frequency_data

@@ -24,7 +24,15 @@
  *                     caller (size from the matching *_workspace_bytes query).  No
  *                     allocation, no synchronisation: safe to capture in a hipGraph.  This
  *                     is what bench.py and the multi-GPU driver call with HBM-resident data.
- *   - d (Hilbert-space dimension) must satisfy 2 <= d <= FFK_MAX_D.
+ *   - d (Hilbert-space dimension) must satisfy 2 <= d <= FFK_MAX_D (64) for the path the reference's
+ *     get_filter_function / infidelity / liouville_representation walk: ffk_diagonalize*,
+ *     ffk_control_matrix* (control matrix and noise operators), ffk_filter_function*, ffk_infidelity*,
+ *     ffk_decay_amplitudes*, ffk_control_matrix_from_atomic*, ffk_liouville*.  Up to
+ *     FFK_MAX_D_TEMPLATED (16) the kernels are compiled per dimension (operands in registers or
+ *     wave-private LDS); above it one runtime-d kernel set serves (csrc/generic.hip, workgroup-wide
+ *     LDS tiles).  The remaining entry points (intermediates, second order, gradients, cumulant
+ *     function, fused pipeline and resident passes, sequence concatenation in one call) accept
+ *     d <= FFK_MAX_D_TEMPLATED only and return FFK_EINVAL above it.
  *   - Thread-safety: calls on one device are serialised by the caller; the library keeps one
  *     arena per process and device.
  */
@@ -39,7 +47,8 @@ extern "C" {
 #endif
 
 #define FFK_VERSION 100 /* 0.1.0 */
-#define FFK_MAX_D 16
+#define FFK_MAX_D 64
+#define FFK_MAX_D_TEMPLATED 16
 
 #define FFK_OK 0
 #define FFK_EINVAL -1   /* bad argument (shape, NULL, unsupported d) -> ValueError        */

@@ -647,7 +647,38 @@ def make_periodic_driving():
          written_out_total_propagator=written_out.total_propagator)
 
 
+def make_large_d():
+    """Dimensions above 16 (the runtime-d kernels of csrc/generic.hip): the full path of small random
+    pulses at d = 17, 20 (GGM) and 32 (Pauli, five qubits).  The bases are not stored (the package's
+    own Basis.ggm / Basis.pauli are pinned bit-exact by the basis fixtures); of the d^4 entries of the
+    Liouville representation every 37th row is kept."""
+    def two_sided(tau, dt, n):
+        w = np.geomspace(1e-2/tau, 1e2/dt.min(), n)
+        return np.concatenate([-w[::-1][:n//4], [0.0, 1e-10], w])
+
+    for name, (d, G, ncop, nnop, btype, seed, W) in {
+            'rand_d17_ggm': (17, 5, 3, 2, 'GGM', 21, 8),
+            'rand_d20_ggm': (20, 4, 3, 3, 'GGM', 22, 8),
+            'rand_d32_pauli': (32, 3, 3, 2, 'Pauli', 23, 8),
+    }.items():
+        rng = np.random.default_rng(seed)
+        pulse = rand_pulse(d, G, ncop, nnop, btype, rng)
+        omega = two_sided(pulse.tau, pulse.dt, W)
+        arrays = pulse_inputs(pulse)
+        arrays['basis_sha256'] = np.array(hashlib.sha256(
+            np.ascontiguousarray(arrays.pop('basis') + 0.0).tobytes()).hexdigest())
+        arrays['omega'] = omega
+        out = full_path_outputs(pulse, omega, intermediates=False)
+        out['total_propagator_liouville_rows'] = np.arange(0, d*d, 37)
+        out['total_propagator_liouville'] = out['total_propagator_liouville'][::37]
+        arrays.update(out)
+        save(name, **arrays)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'large_d':
+        make_large_d()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'periodic_driving':
         make_periodic_driving()
         return
@@ -912,6 +943,7 @@ def main():
     make_cnot()
     make_baseline_configs()
     make_periodic_driving()
+    make_large_d()
 
 
 if __name__ == '__main__':

@@ -19,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 RAND = ['rand_d2_ggm', 'rand_d3_ggm', 'rand_d4_pauli', 'rand_d4_ggm', 'rand_d5_ggm',
         'rand_d8_pauli', 'rand_d16_ggm', 'edge_degenerate_d4', 'edge_single_segment_d2',
-        'cfg2_small', 'hadamard']
+        'cfg2_small', 'hadamard',
+        'rand_d17_ggm', 'rand_d20_ggm', 'rand_d32_pauli']     # d > 16: csrc/generic.hip
 TOL = 1e-10          # acceptance bar (north_star)
 TIGHT = 2e-13        # what the kernels reach on O(1) data
 
@@ -111,7 +112,10 @@ def test_pulse_sequence_end_to_end(name):
     assert rel_err(pulse.get_control_matrix(omega), g['control_matrix']) < 1e-12
     assert np.abs(pulse.eigvals - g['eigvals']).max() < 1e-13*max(1, np.abs(g['H']).max())
     assert rel_err(pulse.propagators, g['propagators']) < 1e-12
-    assert rel_err(pulse.total_propagator_liouville, g['total_propagator_liouville']) < 1e-12
+    L = pulse.total_propagator_liouville
+    if 'total_propagator_liouville_rows' in g:                   # large d: every 37th row is stored
+        L = L[g['total_propagator_liouville_rows']]
+    assert rel_err(L, g['total_propagator_liouville']) < 1e-12
     # diagonal of F is real and non-negative (tests/test_core.py:750-760)
     for a in range(F.shape[0]):
         assert np.abs(F[a, a].imag).max() <= 1e-15*max(1, np.abs(F).max())
@@ -306,7 +310,7 @@ def test_error_behaviour():
     with pytest.raises(ValueError):
         numeric.calculate_filter_function(g['control_matrix'], which='bogus')
     with pytest.raises(ValueError):
-        numeric.diagonalize(np.zeros((3, 17, 17), complex), np.ones(3))         # d > 16
+        numeric.diagonalize(np.zeros((3, 65, 65), complex), np.ones(3))         # d > FFK_MAX_D
     with pytest.raises(ValueError):
         numeric.diagonalize(np.zeros((3, 2, 2), complex), np.ones(4))
     pulse = pulse_from(g)
@@ -2580,3 +2584,68 @@ def test_block_rule_kernel_with_a_non_hermitian_basis(n_nops):
     for got in (resident, via_host):
         assert rel_err(got.get_control_matrix(omega), R_ref) < 1e-11
         assert rel_err(got.get_filter_function(omega), F_ref) < 1e-11
+
+
+# ---- dimensions above 16: the runtime-d kernels (csrc/generic.hip) ---------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('d,G,A,W,btype', [(24, 3, 2, 9, 'GGM'), (33, 2, 2, 7, 'GGM'), (40, 2, 1, 5, 'GGM'),
+                                           (48, 2, 1, 5, 'GGM'), (64, 2, 1, 4, 'Pauli')])
+def test_large_d_against_the_oracle(d, G, A, W, btype):
+    """Every register-tile size of the generic kernels (d = 17..32, 33..48, 49..64) on seeded random
+    pulses, the whole path against the oracle: eigensystem, propagators, control matrix, noise
+    operators, filter function, infidelity, Liouville representation (1e-10 relative, north_star)."""
+    rng = np.random.default_rng(1000 + d)
+
+    def herm(n):
+        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+        M = (M + M.conj().transpose(0, 2, 1))/2
+        return M - np.trace(M, axis1=1, axis2=2)[:, None, None]*np.eye(d)/d
+    c_opers, n_opers = herm(2), herm(A)
+    c_coeffs, n_coeffs = rng.standard_normal((2, G)), rng.random((A, G))
+    dt = 1 - rng.random(G)
+    omega = np.concatenate([[-3.0, 0.0, 1e-10], np.geomspace(1e-2/dt.sum(), 1e2/dt.min(), W - 3)])
+    basis = ff.Basis.ggm(d) if btype == 'GGM' else ff.Basis.pauli(int(np.log2(d)))
+    H = orc.hamiltonian(c_opers, c_coeffs)
+    D, V, Q = numeric.diagonalize(H, dt)
+    Dr, Vr, Qr = orc.diagonalize(H, dt)
+    assert np.abs(D - Dr).max() < 1e-12*np.abs(H).max()*d
+    assert rel_err(Q, Qr) < 1e-11
+    for k in range(G):
+        assert np.abs(V[k].conj().T @ V[k] - np.eye(d)).max() < 1e-12
+        assert np.abs(V[k].conj().T @ H[k] @ V[k] - np.diag(D[k])).max() < 1e-11*np.abs(H).max()
+    R = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+    R_ref = orc.control_matrix_from_scratch(Dr, Vr, Qr, omega, np.asarray(basis), n_opers, n_coeffs, dt)
+    assert R.shape == (A, d*d, W)
+    assert rel_err(R, R_ref) < TOL
+    B = numeric.calculate_noise_operators_from_scratch(D, V, Q, omega, n_opers, n_coeffs, dt)
+    assert rel_err(orc.basis_expand(B, np.asarray(basis)).transpose(1, 2, 0), R_ref) < TOL
+    F = numeric.calculate_filter_function(R)
+    assert rel_err(F, orc.filter_function(R_ref)) < TOL
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
+    S = 1e-3/(np.abs(omega) + 1e-2)
+    got = ff.infidelity(pulse, S, omega)
+    ref = orc.infidelity_from_filter_function(orc.filter_function(R_ref), S, omega, np.arange(A), d)
+    assert rel_err(got, ref) < TOL
+    rows = np.arange(0, d*d, max(1, d*d//23))
+    L = ff.liouville_representation(Q[-1], basis)
+    assert L.shape == (d*d, d*d) and L.dtype == np.float64
+    Lr = orc.liouville_representation(Qr[-1], np.asarray(basis))
+    assert rel_err(L[rows], Lr[rows]) < TOL
+
+
+@pytest.mark.gpu
+def test_large_d_limits_are_reported():
+    """Above FFK_MAX_D everything raises; between 17 and 64 the entry points whose kernels are
+    compiled per dimension do (and say so), the main path does not."""
+    d = 17
+    with pytest.raises(ValueError, match='d=65'):
+        numeric.diagonalize(np.zeros((2, 65, 65), complex), np.ones(2))
+    g = load_golden('rand_d17_ggm')
+    with pytest.raises(ValueError, match='cache_intermediates'):
+        numeric.calculate_control_matrix_from_scratch(
+            g['eigvals'], g['eigvecs'], g['propagators'], g['omega'], g['basis'], g['n_opers'],
+            g['n_coeffs'], g['dt'], cache_intermediates=True)
+    pulse = pulse_from(g)
+    assert pulse.d == d
+    with pytest.raises(ValueError):
+        pulse.get_filter_function(g['omega'], order=2)

@@ -14,7 +14,8 @@ from conftest import load_golden, rel_err
 
 RAND = ['rand_d2_ggm', 'rand_d3_ggm', 'rand_d4_pauli', 'rand_d4_ggm', 'rand_d5_ggm',
         'rand_d8_pauli', 'rand_d16_ggm', 'edge_degenerate_d4', 'edge_single_segment_d2',
-        'cfg2_small', 'hadamard']
+        'cfg2_small', 'hadamard',
+        'rand_d17_ggm', 'rand_d20_ggm', 'rand_d32_pauli']     # d > 16: the runtime-d kernels' fixtures
 
 
 def test_basis_bit_exact():
