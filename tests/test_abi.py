@@ -37,7 +37,10 @@ def test_workspace_queries_need_no_gpu():
     lib = _lib.load()
     assert lib.ffk_diagonalize_workspace_bytes(256, 4) > 256*16*16
     assert lib.ffk_control_matrix_workspace_bytes(4096, 16, 3, 256, 4) > 3*16*4096*16
-    assert lib.ffk_control_matrix_workspace_bytes(4096, 16, 3, 256, 17) == 0     # unsupported d
+    assert lib.ffk_control_matrix_workspace_bytes(64, 289, 3, 8, 17) > 3*289*64*16   # runtime-d kernels
+    assert lib.ffk_control_matrix_workspace_bytes(4096, 16, 3, 256, 65) == 0     # above FFK_MAX_D
+    assert lib.ffk_diagonalize_workspace_bytes(8, 64) > 0 and lib.ffk_diagonalize_workspace_bytes(8, 65) == 0
+    assert lib.ffk_pipeline_workspace_bytes(64, 289, 3, 8, 17, 3, 1) == 0        # per-dimension kernels only
     assert lib.ffk_liouville_workspace_bytes(1, 4, 16) > 0
     assert lib.ffk_infidelity_workspace_bytes(4096, 3, 3) > 0
     assert lib.ffk_pipeline_workspace_bytes(4096, 16, 3, 256, 4, 3, 1) > 0
