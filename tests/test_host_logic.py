@@ -144,6 +144,27 @@ def test_cache_bookkeeping_without_kernels():
     assert p.nbytes == 0
 
 
+def test_remembered_grid_is_a_private_copy():
+    """The reference copies omega into the cache (pulse_sequence.py:1166).  Only grids this package
+    froze itself are shared between pulses; a caller's read-only VIEW of a writable array is copied, so
+    changing the base afterwards cannot change the remembered grid under the cached results."""
+    X, Z = util.paulis[1], util.paulis[3]
+    p = ff.PulseSequence([[X, [1]]], [[Z, [1]]], [1.0])
+    base = np.array([1.0, 2.0, 3.0])
+    view = base[:]
+    view.flags.writeable = False
+    p.omega = view
+    assert p.omega is not view and not p.omega.flags.writeable
+    base[1] = 7.0
+    assert np.array_equal(p.omega, [1.0, 2.0, 3.0])
+    q = ff.PulseSequence([[X, [1]]], [[Z, [1]]], [1.0])
+    q.omega = p.omega                       # the package's own frozen copy: shared as it is
+    assert q.omega is p.omega
+    r = ff.PulseSequence([[X, [1]]], [[Z, [1]]], [1.0])
+    r.omega = [1.0, 2.0, 3.0]               # same content from elsewhere: the one interned object
+    assert r.omega is p.omega
+
+
 def test_spectrum_validation():
     with pytest.raises(ValueError):
         util.parse_spectrum(np.ones((3, 5)), np.arange(5), [0, 1])           # wrong n_idx
