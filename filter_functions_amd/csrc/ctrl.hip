@@ -1010,9 +1010,18 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
     if (geo.pc)
         return launch_accumulate_pc(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
                                     geo.chunk_len, Ypart, stream);
-    if (geo.pcw)
+    if (geo.pcw) {
+        // FFK_TUNE_PCR=0: the round-3 kernel (complex tile, two complex products) for A/B
+        static const bool real_tile = [] {
+            const char* e = std::getenv("FFK_TUNE_PCR");
+            return e == nullptr || e[0] != '0';
+        }();
+        if (real_tile && pcr_accumulate_supported(d, A))
+            return launch_accumulate_pcr(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
+                                         stream);
         return launch_accumulate_pcw(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
                                      stream);
+    }
     if (geo.mfma)
         return launch_accumulate_mfma(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len,
                                       geo.nwaves, Ypart, stream);

@@ -166,6 +166,13 @@ hipError_t launch_accumulate_pcw(const double* omega, int W, const double* segta
                                  int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
                                  hipStream_t stream);
 
+// ---- ctrl_pcr.hip (d = 8, real integral tile) --------------------------------------------------
+bool pcr_accumulate_supported(int d, int A);
+int pcr_accumulate_lds_bytes();
+hipError_t launch_accumulate_pcr(const double* omega, int W, const double* segtab, const cplx* ops,
+                                 int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
+                                 hipStream_t stream);
+
 // ---- post.hip --------------------------------------------------------------------------------
 // Bt (A,d,d,W) = sum over chunks of Ypart
 hipError_t launch_reduce_chunks(const cplx* Ypart, int chunks, size_t slab, cplx* Bt,

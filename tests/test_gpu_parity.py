@@ -2677,5 +2677,5 @@ def test_resident_results_are_read_only_views():
     G2 *= 2
     S = 1e-3/omega
     ref = ff.infidelity(pulse, S, omega)
-    assert rel_err(np.trapz(np.einsum('aaw->aw', G2).real*S, omega)/(2*np.pi*4)/2, ref) < 1e-12
+    assert rel_err(util.integrate(np.einsum('aaw->aw', G2).real*S, omega)/(2*np.pi*4)/2, ref) < 1e-12
     assert not ff.Basis.ggm(3).flags.writeable or True      # (shared default bases: documented, not enforced here)
