@@ -519,11 +519,7 @@ hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int
         const int glen = (G + nslab - 1)/nslab;
         const int rows = A*N;
         const size_t lds = (static_cast<size_t>(std::max(T*rows, nslab*rows + rows)) + T + nslab)*64*sizeof(cplx);
-        static const bool enabled = [] {
-            const char* e = std::getenv("FFK_TUNE_ATOMIC_BLOCK");
-            return e == nullptr || e[0] != '0';
-        }();
-        if (enabled && lds <= 150*1024) {
+        if (lds <= 150*1024) {
             auto launch = [&](auto kern) -> hipError_t {
                 hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -69,7 +69,7 @@ int g_mfma_policy = 0;            // 0: matrix-core kernel for d >= 12, 1: never
 #endif
 #ifndef FFK_TCOL_SGPR           /* 1: the wave's columns of T_g through scalar loads (d >= 6):     */
 #define FFK_TCOL_SGPR 0         /* in this template the allocator answers with 752 spilled VGPRs;  */
-#endif                          /* the idea lives in ctrl_pcw.hip, written around it               */
+#endif                          /* the idea lives in ctrl_pcr.hip, written around it               */
 #ifndef FFK_SKEW_PRIO           /* issue priority of a wave while it generates (skewed build) */
 #define FFK_SKEW_PRIO 1
 #endif
@@ -794,12 +794,8 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     geo.mfma = mfma_accumulate_supported(d) && g_mfma_policy != 1 && (d >= 12 || g_mfma_policy == 2);
     // d = 4: the producer/consumer kernel (ctrl_pc.hip) is the default -- 3.4 % faster than the
     // symmetric kernel below at config 2 (101 vs 104.5 us on the same box) and free of register
-    // spills; FFK_TUNE_PC=0 or the tuning variants 1/2 select the symmetric kernel
-    static const bool use_pc = [] {
-        const char* e = std::getenv("FFK_TUNE_PC");
-        return e == nullptr || e[0] != '0';
-    }();
-    if (use_pc && g_use_gsplit && !g_use_wave_kernel && pc_accumulate_supported(d, A) && !geo.mfma) {
+    // spills; the tuning variants 1/2 (ffk_set_accumulate_variant) select the symmetric kernel
+    if (g_use_gsplit && !g_use_wave_kernel && pc_accumulate_supported(d, A) && !geo.mfma) {
         // producer/consumer kernel: 3 sub-chunks x (1 producer + nc consumers) per block
         const int nc = pc_accumulate_ops_per_block(A);
         geo.pc = true;
@@ -831,21 +827,17 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         geo.chunks = (G + geo.chunk_len - 1)/geo.chunk_len;
         return geo;
     }
-    // d = 8: producer/consumer kernel with column-split consumers (ctrl_pcw.hip); FFK_TUNE_PCW=0
-    // or the tuning variants 1/2 select the symmetric kernel below
-    static const bool use_pcw = [] {
-        const char* e = std::getenv("FFK_TUNE_PCW");
-        return e == nullptr || e[0] != '0';
-    }();
-    if (use_pcw && g_use_gsplit && !g_use_wave_kernel && pcw_accumulate_supported(d, A) && !geo.mfma) {
-        const int nc = pcw_accumulate_ops_per_block();
+    // d = 8: producer/consumer kernel on the matrix cores with a real integral tile (ctrl_pcr.hip);
+    // the tuning variants 1/2 (ffk_set_accumulate_variant) select the symmetric kernel below
+    if (g_use_gsplit && !g_use_wave_kernel && pcr_accumulate_supported(d, A) && !geo.mfma) {
+        const int nc = pcr_accumulate_ops_per_block();
         geo.pcw = true;
         geo.wave_kernel = false;
-        geo.nwaves = pcw_accumulate_waves();
+        geo.nwaves = pcr_accumulate_waves();
         geo.task_groups = (A + nc - 1)/nc;
         geo.na_blk = nc;
         geo.nbuf = 2;
-        geo.lds_bytes = pcw_accumulate_lds_bytes();
+        geo.lds_bytes = pcr_accumulate_lds_bytes();
         const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups;
         int chunks = forced_chunks;
         if (chunks <= 0) {
@@ -948,10 +940,6 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
             }
         }
     }
-    if (const char* env = std::getenv("FFK_TUNE_NWAVES")) {   // tuning only
-        const int v = std::atoi(env);
-        if (v >= 1 && v <= 8) nw = std::min(v, ntasks);
-    }
     geo.nwaves = nw;
     geo.task_groups = (ntasks + nw - 1)/nw;
     const int nj = d / jb;
@@ -1010,18 +998,9 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
     if (geo.pc)
         return launch_accumulate_pc(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
                                     geo.chunk_len, Ypart, stream);
-    if (geo.pcw) {
-        // FFK_TUNE_PCR=0: the round-3 kernel (complex tile, two complex products) for A/B
-        static const bool real_tile = [] {
-            const char* e = std::getenv("FFK_TUNE_PCR");
-            return e == nullptr || e[0] != '0';
-        }();
-        if (real_tile && pcr_accumulate_supported(d, A))
-            return launch_accumulate_pcr(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
-                                         stream);
-        return launch_accumulate_pcw(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
+    if (geo.pcw)
+        return launch_accumulate_pcr(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
                                      stream);
-    }
     if (geo.mfma)
         return launch_accumulate_mfma(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len,
                                       geo.nwaves, Ypart, stream);

@@ -17,10 +17,10 @@
 //     leaves Z_m[j = q + 4r, w_c] in lane (c, q) (c = lane & 15, q = lane >> 4), step 2 wants
 //     Z_{m = 4 mg + q}[j, w_c] there: a 4 x 4 transpose across the four 16-lane rows of the wavefront
 //     (v_permlane16_swap / v_permlane32_swap, ffk_mfma_util.h).  The columns of Y are split over JH
-//     wavefronts per operator.  5.18 ms / 2.41 ms on the same shapes (FFK_TUNE_MFMA_BF=0).
+//     wavefronts per operator.  5.18 ms / 2.41 ms on the same shapes (round-3 A/B build).
 //   * ctrl_accumulate_mfma_kernel<D> -- v_mfma_f64_16x16x4, one wavefront per noise operator with
 //     all d x d x 16 accumulators (one wavefront per SIMD): 6.7 ms at d = 16; a tuning reference
-//     (FFK_TUNE_MFMA_BF=0 FFK_TUNE_MFMA_JH=0).
+//     (round-3 A/B build).
 #include <algorithm>
 #include <cstdlib>
 
@@ -754,30 +754,15 @@ hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx
 // 4x4x4 kernel with the columns of Y split over JH wavefronts per operator.  Measured (MI355X):
 //   d = 16 (13 segments, 18 operators, 16384 omega): 16x16x4 6.7 ms, JH = 2 5.4 ms, JH = 4 6.5 ms
 //   d = 12 (64 segments, 6 operators, 8192 omega):   16x16x4 3.4 ms, JH = 1 2.4 ms, JH = 3 3.3 ms
-// -- two wavefronts per SIMD beat the wider tile.  FFK_TUNE_MFMA_JH overrides (tuning).
-// FFK_TUNE_MFMA_BF: 1 = the block-frequency form of the 4x4x4 kernel (d = 12, 16), 0 = frequency on
-// the columns.  With it JH counts the wavefronts that share an operator's 16 frequencies (1, 2, 4).
-static bool mfma_block_frequency(int d) {
-    static const int env = [] {
-        const char* e = std::getenv("FFK_TUNE_MFMA_BF");
-        return e ? std::atoi(e) : -1;
-    }();
-    if (d != 12 && d != 16) return false;
-    return env < 0 ? FFK_MFMA_BF_DEFAULT : env != 0;
-}
+// -- two wavefronts per SIMD beat the wider tile.
+// The block-frequency form of the 4x4x4 kernel serves d = 12, 16 (the frequency-on-the-columns form
+// lost its A/B there, profiles/r03_l_*); with it JH counts the wavefronts that share an operator's
+// 16 frequencies.
+static bool mfma_block_frequency(int d) { return (d == 12 || d == 16) && FFK_MFMA_BF_DEFAULT; }
 
 static int mfma_column_split(int d) {
-    static const int env = [] {
-        const char* e = std::getenv("FFK_TUNE_MFMA_JH");
-        return e ? std::atoi(e) : -1;
-    }();
-    if (mfma_block_frequency(d)) return (env == 1 || env == 2 || env == 4) ? env : 2;
-    const int def = d == 16 ? 2 : 1;
-    if (env < 0) return def;
-    const bool ok = (d == 16 && (env == 0 || env == 2 || env == 4)) ||
-                    (d == 12 && (env == 0 || env == 1 || env == 3)) ||
-                    (d == 8 && (env == 1 || env == 2)) || (d == 4 && env == 1);
-    return ok ? env : def;
+    if (mfma_block_frequency(d)) return 2;
+    return d == 16 ? 2 : 1;
 }
 
 // d = 4 and d = 8 are served on request only (ffk_set_accumulate_variant(4)): the A/B against the
@@ -846,20 +831,12 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
         // get a launch of their own with four wavefronts per operator (one set of four frequencies
         // each), i.e. blocks of two operators (a single one leaves four of the eight wavefronts without a
         // contraction; they still generate): 4.77 -> 4.66 ms at config 5.
-        static const bool split_rest = [] {
-            const char* e = std::getenv("FFK_TUNE_MFMA_REST");
-            return e == nullptr || e[0] != '0';
-        }();
+        constexpr bool split_rest = true;
         // Eight operators per tile first (two per wavefront, 8-frequency tiles), the block-of-four
         // form for what is left.  Measured (profiles/r03_s_*): d = 12, 8 operators 2.19 -> 2.09 ms;
         // d = 16, 18 operators 4.61 -> 5.04 ms (256 registers with 91 spilled, and nine 4-KiB operand
         // matrices staged per 8-frequency tile instead of five per 16) -- so the default is d = 12 only.
-        // FFK_TUNE_MFMA_X2=0 / 1: never / also at d = 16.
-        static const int x2_env = [] {
-            const char* e = std::getenv("FFK_TUNE_MFMA_X2");
-            return e ? std::atoi(e) : -1;
-        }();
-        const bool x2 = x2_env < 0 ? d == 12 : x2_env != 0;
+        const bool x2 = d == 12;
         int base = 0;
         if (x2 && jh == 2 && nw == 8 && A >= 8) {
             base = A/8*8;

@@ -223,230 +223,8 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
         }
 }
 
-// The same product for N >= 128 with operands staged through LDS: a 256-thread block (four
-// wavefronts, one per SIMD) owns a 128 x 128 tile of Gamma, each wavefront a 64 x 64 quarter (4 x 4
-// MFMA tiles, 16 independent accumulators).  Per step of 16 frequencies the block copies 128 rows
-// x 16 frequencies of each operand (2 x 32 KiB) global -> registers -> LDS, one step AHEAD of the
-// matrix instructions that consume them (double-buffered image, one barrier per step); the spectral
-// weight is multiplied in once on the way (the register-fed kernel does it per wavefront).  Against
-// decay_gemm_kernel<4,4>: every operand byte is fetched from L2 once per block instead of once per
-// wavefront (half the traffic), and the fetch of step s + 1 overlaps the 128 MFMAs of step s instead
-// of preceding them (profiles/r02_*: 1.59 ms, matrix pipe ~36 % busy at config 5).
-// LDS image: [row][16 frequencies + 1 pad] complex -- rows 272 B apart, so the sixteen rows a
-// ds_read_b128 lane group touches fall on different banks.
-#ifndef FFK_DG_WAVES             /* wavefronts per SIMD the LDS-staged kernel is compiled for (blocks per CU) */
-#define FFK_DG_WAVES 1
-#endif
-constexpr int kDgRows = 128, kDgStep = 16, kDgStride = kDgStep + 1;
-template <bool M4>
-__global__ __launch_bounds__(256, FFK_DG_WAVES) void decay_gemm_lds_kernel(
-    const cplx* __restrict__ R, int Gp, int A, int N, int W, const cplx* __restrict__ scale,
-    int s_ndim, const int32_t* __restrict__ idx, int n_idx, int kchunk, int tiles,
-    double* __restrict__ out, size_t split_stride, int mirror_in_store,
-    const int* __restrict__ complex_weights, int tri) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    cplx* As = reinterpret_cast<cplx*>(lds_raw);                       // [2][128][17]
-    cplx* Bs = As + 2*kDgRows*kDgStride;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l15 = lane & 15, lk = lane >> 4;
-    // (tri as in decay_gemm_kernel: 0 all block tiles, 1 on and above the diagonal, 2 below it)
-    const int ntile = tri == 0 ? tiles*tiles : (tri == 1 ? tiles*(tiles + 1)/2 : tiles*(tiles - 1)/2);
-    unsigned bx, by;
-    xcd_block(bx, by);
-    const int tile = bx % ntile;
-    int z = bx / ntile;
-    int ti, tj;
-    if (tri == 0) {
-        ti = tile / tiles;
-        tj = tile % tiles;
-    } else if (tri == 1) {
-        ti = 0;
-        int rem = tile;
-        while (rem >= tiles - ti) {
-            rem -= tiles - ti;
-            ++ti;
-        }
-        tj = ti + rem;
-    } else {
-        ti = 1;
-        int rem = tile;
-        while (rem >= ti) {
-            rem -= ti;
-            ++ti;
-        }
-        tj = rem;
-    }
-    const int nb = s_ndim == 3 ? n_idx : 1;
-    const int ib0 = z % nb;
-    z /= nb;
-    const int ia = z % n_idx;
-    z /= n_idx;
-    const int h = z % Gp, g = z / Gp;
-    const int ib = s_ndim == 3 ? ib0 : ia;
-    const bool symmetric = s_ndim != 3 && g == h && *complex_weights == 0;
-    if (symmetric && ti > tj) return;                 // (whole block: no barrier is left waiting)
-    // 64 x 64 quarters strictly below the diagonal are mirrored, not computed
-    const bool compute = !(symmetric && ti == tj && wm > wn);
-    const int srow = s_ndim == 1 ? 0 : (s_ndim == 2 ? ia : ia*n_idx + ib);
-    const cplx* sp = scale + static_cast<size_t>(srow)*W;
-    // staging: element e = j 256 + tid (j = 0..7) of the 128 x 16 step image, row e / 16, frequency
-    // e % 16: the sixteen lanes of a row read 256 contiguous bytes (four rows, eight full 128-byte
-    // lines per wave instruction); a thread keeps ONE frequency column, hence one spectral weight
-    const int scol = tid & 15, srow0 = tid >> 4;           // rows srow0 + 16 j
-    const cplx* La[8];
-    const cplx* Rb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        La[j] = R + ((static_cast<size_t>(g)*A + idx[ia])*N + min(N - 1, ti*kDgRows + srow0 + 16*j))*W;
-        Rb[j] = R + ((static_cast<size_t>(h)*A + idx[ib])*N + min(N - 1, tj*kDgRows + srow0 + 16*j))*W;
-    }
-    const int wbeg = by*kchunk;
-    const int wend = min(W, wbeg + kchunk);
-    // fetch only LOADS (nothing here may wait for the data: the MFMAs of the current step are issued
-    // between fetch and park); masking and the spectral weight are applied in park
-    cplx ra[8], rb[8], rs;
-    auto fetch = [&](int w0) {
-        const int wc = min(w0 + scol, wend - 1);
-        rs = sp[wc];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            ra[j] = La[j][wc];
-            rb[j] = Rb[j][wc];
-        }
-    };
-    auto park = [&](int buf, int w0) {
-        const bool ok = w0 + scol < wend;
-        cplx* da = As + (static_cast<size_t>(buf)*kDgRows + srow0)*kDgStride + scol;
-        cplx* db = Bs + (static_cast<size_t>(buf)*kDgRows + srow0)*kDgStride + scol;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            da[16*j*kDgStride] = ok ? ra[j] : cplx{0.0, 0.0};
-            db[16*j*kDgStride] = ok ? cmul(rs, rb[j]) : cplx{0.0, 0.0};
-        }
-    };
-    if constexpr (M4) {
-        // The same block tile on v_mfma_f64_4x4x4_4b (4 rows x 16 columns per instruction, the A operand
-        // replicated over the four 4-column blocks): ONE wavefront per SIMD saturates this instruction
-        // (tools/mfma4_occupancy_probe.hip), which it does not for the 64-cycle 16x16x4 form (34 TFLOP/s
-        // at one wavefront per SIMD), and it holds its clock on random data (72.7 against ~60 TFLOP/s).
-        // acc4[rg][cg] is element (row 4 rg + q, column 16 cg + cl) of the wavefront's 64 x 64 quarter.
-        const int cl = lane & 15, q = lane >> 4, c4 = cl & 3;
-        double acc4[16][4];
-#pragma unroll
-        for (int rg = 0; rg < 16; ++rg)
-#pragma unroll
-            for (int cg = 0; cg < 4; ++cg) acc4[rg][cg] = 0.0;
-        if (wbeg < wend) {
-            fetch(wbeg);
-            park(0, wbeg);
-        }
-        __syncthreads();
-        int buf4 = 0;
-        for (int w0 = wbeg; w0 < wend; w0 += kDgStep, buf4 ^= 1) {
-            const bool more = w0 + kDgStep < wend;
-            if (more) fetch(w0 + kDgStep);
-            if (compute) {
-                const cplx* ap = As + (static_cast<size_t>(buf4)*kDgRows + wm*64 + c4)*kDgStride + 4*q;
-                const cplx* bp = Bs + (static_cast<size_t>(buf4)*kDgRows + wn*64 + cl)*kDgStride + 4*q;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    cplx b[4];
-#pragma unroll
-                    for (int cg = 0; cg < 4; ++cg) b[cg] = bp[cg*16*kDgStride + cc];
-#pragma unroll
-                    for (int rg = 0; rg < 16; ++rg) {
-                        const cplx a = ap[rg*4*kDgStride + cc];
-#pragma unroll
-                        for (int cg = 0; cg < 4; ++cg)
-                            acc4[rg][cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.re, b[cg].re, acc4[rg][cg], 0, 0, 0);
-#pragma unroll
-                        for (int cg = 0; cg < 4; ++cg)
-                            acc4[rg][cg] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.im, b[cg].im, acc4[rg][cg], 0, 0, 0);
-                    }
-                }
-            }
-            if (more) park(buf4 ^ 1, w0 + kDgStep);
-            __syncthreads();
-        }
-        if (!compute) return;
-        double* o4 = out + static_cast<size_t>(by)*split_stride + static_cast<size_t>(bx / ntile)*N*N;
-        const bool mirror4 = mirror_in_store && symmetric && (ti < tj || wm < wn);
-#pragma unroll
-        for (int rg = 0; rg < 16; ++rg)
-#pragma unroll
-            for (int cg = 0; cg < 4; ++cg) {
-                const int row = ti*kDgRows + wm*64 + 4*rg + q;
-                const int col = tj*kDgRows + wn*64 + 16*cg + cl;
-                if (row < N && col < N) {
-                    o4[static_cast<size_t>(row)*N + col] = acc4[rg][cg];
-                    if (mirror4) o4[static_cast<size_t>(col)*N + row] = acc4[rg][cg];
-                }
-            }
-        return;
-    }
-    f64x4 acc[4][4];
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = {0.0, 0.0, 0.0, 0.0};
-
-    if (wbeg < wend) {
-        fetch(wbeg);
-        park(0, wbeg);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int w0 = wbeg; w0 < wend; w0 += kDgStep, buf ^= 1) {
-        const bool more = w0 + kDgStep < wend;
-        if (more) fetch(w0 + kDgStep);                // global loads in flight during the MFMAs
-        if (compute) {
-            const cplx* ap = As + (static_cast<size_t>(buf)*kDgRows + wm*64 + l15)*kDgStride + 4*lk;
-            const cplx* bp = Bs + (static_cast<size_t>(buf)*kDgRows + wn*64 + l15)*kDgStride + 4*lk;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                cplx a[4], b[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    a[t] = ap[t*16*kDgStride + c];
-                    b[t] = bp[t*16*kDgStride + c];
-                }
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].re, b[tn].re, acc[tm][tn], 0, 0, 0);
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].im, b[tn].im, acc[tm][tn], 0, 0, 0);
-            }
-        }
-        if (more) park(buf ^ 1, w0 + kDgStep);        // (last read in the previous step: barrier below)
-        __syncthreads();
-    }
-    if (!compute) return;
-    double* o = out + static_cast<size_t>(by)*split_stride + static_cast<size_t>(bx / ntile)*N*N;
-    const bool mirror = mirror_in_store && symmetric && (ti < tj || wm < wn);
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 4; ++tn) {
-            const int col = tj*kDgRows + wn*64 + tn*16 + l15;
-            if (col >= N) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = ti*kDgRows + wm*64 + tm*16 + lk + 4*r;
-                if (row < N) {
-                    o[static_cast<size_t>(row)*N + col] = acc[tm][tn][r];
-                    if (mirror) o[static_cast<size_t>(col)*N + row] = acc[tm][tn][r];
-                }
-            }
-        }
-}
-constexpr size_t kDgLdsBytes = 2*2*static_cast<size_t>(kDgRows)*kDgStride*sizeof(cplx);
+// (Round 3's LDS-staged 128 x 128 variant of this product -- half the operand traffic, but 1.20 ms
+// against 1.07 ms at config 5 -- was removed in round 4; the A/B is profiles/r03_e_*, r03_m_*.)
 
 // out[i] = sum_s part[s][i], fixed order.  tile > 0: batches of a pulse with itself (g == h in the
 // batch index (g*Gp + h)*n_idx + a) are symmetric matrices of which only the tiles (of `tile`
@@ -474,63 +252,17 @@ struct DecayPlan {
     int tm, tn, tiles_m, tiles_n, ksplit, kchunk;
     size_t batch;
     bool tri;       // register-fed kernel: one grid for the tiles on and above the diagonal, one for the rest
-    bool lds;       // decay_gemm_lds_kernel: 128 x 128 block tiles (tiles_m = tiles_n = ceil(N / 128))
 };
-
-// FFK_TUNE_DECAY_LDS=1 selects the LDS-staged kernel (tuning / A-B).  Measured at config 5 (d = 16,
-// 18 operators, 16384 omega; profiles/r03_m_*), both with the triangle grids: 1.20 ms against 1.07 ms
-// for the register-fed kernel -- half the operand traffic, but ten of its twelve wavefronts work on
-// the symmetric half and its own loop keeps the matrix pipe 74 % busy.  Not the default.
-bool decay_lds_enabled() {
-    static const bool on = [] {
-        const char* e = std::getenv("FFK_TUNE_DECAY_LDS");
-        return e != nullptr && e[0] == '1';
-    }();
-    return on;
-}
 
 DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
     DecayPlan p;
-    p.lds = false;
     p.tri = false;
-    if (N >= 128 && decay_lds_enabled()) {
-        p.lds = true;
-        p.tm = p.tn = 4;
-        p.tiles_m = p.tiles_n = (N + kDgRows - 1)/kDgRows;
-        p.batch = static_cast<size_t>(Gp)*Gp*n_idx*(s_ndim == 3 ? n_idx : 1);
-        // blocks that do work: the upper triangle of tiles for a pulse with itself (the common case)
-        const size_t per = s_ndim != 3 && Gp == 1 ? static_cast<size_t>(p.tiles_m)*(p.tiles_m + 1)/2
-                                                  : static_cast<size_t>(p.tiles_m)*p.tiles_n;
-        const size_t blocks = p.batch*per;
-        // split the frequency axis so that the grid is a whole number of rounds of one block per
-        // CU (256), at least 256 frequencies per split; fewest steps per CU wins
-        const int max_split = std::max(1, (W + 255)/256);
-        long best = -1;
-        int best_split = 1;
-        for (int split = 1; split <= max_split; ++split) {
-            const int chunk = ((W + split - 1)/split + kDgStep - 1)/kDgStep*kDgStep;
-            const long rounds = static_cast<long>((blocks*split + 255)/256);
-            const long cost = rounds*(chunk/kDgStep + 8);
-            if (best < 0 || cost < best) {
-                best = cost;
-                best_split = split;
-            }
-        }
-        p.kchunk = ((W + best_split - 1)/best_split + kDgStep - 1)/kDgStep*kDgStep;
-        p.ksplit = (W + p.kchunk - 1)/p.kchunk;
-        return p;
-    }
     const int t = N <= 16 ? 1 : (N < 128 ? 2 : 4);
     p.tm = p.tn = t;
     // N >= 128: 64 x 64 tiles per wavefront (one wavefront per SIMD: 128 accumulator + 128 operand
-    // registers).  FFK_TUNE_DECAY_TN=2 selects 64 x 32 tiles (two wavefronts per SIMD; no triangle grid
-    // for rectangular tiles): 9.0 instead of 6.0 GB of operand reads per call at config 5, where the
-    // square tiles already run at the rate the operands are delivered (profiles/r03_e_*, r03_m_*)
-    static const int tn_big = [] {
-        const char* e = std::getenv("FFK_TUNE_DECAY_TN");
-        return e && e[0] == '2' ? 2 : 4;
-    }();
-    if (t == 4) p.tn = tn_big;
+    // registers).  (64 x 32 tiles, two wavefronts per SIMD, read 9.0 instead of 6.0 GB of operands per
+    // call at config 5, where the square tiles already run at the rate the operands are delivered:
+    // profiles/r03_e_*, r03_m_*.)
     p.tiles_m = (N + 16*p.tm - 1)/(16*p.tm);
     p.tiles_n = (N + 16*p.tn - 1)/(16*p.tn);
     p.batch = static_cast<size_t>(Gp)*Gp*n_idx*(s_ndim == 3 ? n_idx : 1);
@@ -558,10 +290,6 @@ DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
         }
     }
     p.kchunk = static_cast<int>(((W + want - 1)/want + 15)/16*16);
-    if (const char* e = std::getenv("FFK_TUNE_DECAY_KCHUNK")) {      // tuning
-        const int v = std::atoi(e);
-        if (v >= 64) p.kchunk = std::min((v + 15)/16*16, (W + 15)/16*16);
-    }
     p.ksplit = (W + p.kchunk - 1)/p.kchunk;
     return p;
 }
@@ -820,26 +548,7 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
     double* dst = p.ksplit > 1 ? part : gamma;
     const int mirror = p.ksplit > 1 ? 0 : 1;    // with split-K the reduction fills the lower tiles
     const dim3 grid(static_cast<unsigned>(blocks), p.ksplit);
-    if (p.lds) {
-        static const bool m4 = [] {              // FFK_TUNE_DECAY_M4=0: the 16x16x4 instruction
-            const char* e = std::getenv("FFK_TUNE_DECAY_M4");
-            return e == nullptr || e[0] != '0';
-        }();
-        auto kern = m4 ? decay_gemm_lds_kernel<true> : decay_gemm_lds_kernel<false>;
-        hipError_t aerr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              static_cast<int>(kDgLdsBytes));
-        if (aerr != hipSuccess) return aerr;
-        const bool tri_ok = s_ndim != 3 && Gp == 1;
-        const int t_all = p.tiles_m*p.tiles_m, t_up = p.tiles_m*(p.tiles_m + 1)/2;
-        for (int pass = 0; pass < (tri_ok && p.tiles_m > 1 ? 2 : 1); ++pass) {
-            const int tri = tri_ok ? 1 + pass : 0;
-            const size_t nblk = p.batch*(tri == 0 ? t_all : (tri == 1 ? t_up : t_all - t_up));
-            hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(nblk), p.ksplit), dim3(256), kDgLdsBytes, stream,
-                               R, Gp, A, N, W, scale, s_ndim, idx, n_idx, p.kchunk, p.tiles_m, dst, n, mirror,
-                               complex_weights, tri);
-        }
-    } else {
+    {
         // p.tri: the tiles on and above the diagonal, then (if there are any) those below it, whose
         // blocks all return at once when the weights are real
         const int t_all = p.tiles_m*p.tiles_n, t_up = p.tiles_m*(p.tiles_m + 1)/2;
@@ -854,8 +563,6 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
                 FFK_DG_LAUNCH(1, 1);
             else if (p.tm == 2)
                 FFK_DG_LAUNCH(2, 2);
-            else if (p.tn == 2)
-                FFK_DG_LAUNCH(4, 2);
             else
                 FFK_DG_LAUNCH(4, 4);
 #undef FFK_DG_LAUNCH
@@ -1038,12 +745,8 @@ hipError_t launch_cumulant_function(const double* gamma, size_t batch, int N, in
     const long sD = static_cast<long>(align_up(N*d2*sizeof(cplx))/sizeof(cplx));
     const long sM = static_cast<long>(align_up(d2*d2*sizeof(cplx))/sizeof(cplx));
     hipError_t err;
-    // the basis' non-zeros by element and by entry, and whether they are few (FFK_TUNE_CUMULANT_SPARSE=0:
-    // dense products regardless)
-    static const bool sparse_ok = [] {
-        const char* e = std::getenv("FFK_TUNE_CUMULANT_SPARSE");
-        return e == nullptr || e[0] != '0';
-    }();
+    // the basis' non-zeros by element and by entry, and whether they are few
+    constexpr bool sparse_ok = true;
     const int idd = static_cast<int>(d2);
     const int* skip = nullptr;
     if (sparse_ok && N <= 65535 && d2 <= 65535) {

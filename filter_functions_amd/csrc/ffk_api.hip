@@ -171,6 +171,11 @@ double accumulate_flops(int W, int A, int G, int d) {
     // the fold, one element per lane = one per frequency) and 6 per operator (Bbar times that).
     if (d == 4 && ffk::pc_accumulate_supported(d, A))
         return (838.0*A + 198.0*((A + 2)/3))*double(G)*double(W);
+    // d = 8 (ctrl_pcr.hip, round 4): per operator the first product real x complex 4 d^3 = 2048, psi P
+    // 6 d^2 = 384, the second product complex 8 d^3 = 4096, the fold (one (m, n) per lane = per
+    // frequency) 9 complex products = 54; per group of <= 3 operators the tile: 57 entries x 10 + 62.
+    if (d == 8 && ffk::pcr_accumulate_supported(d, A))
+        return (6582.0*A + 632.0*((A + 2)/3))*double(G)*double(W);
     // other d: contraction (2 d^3 MAC + d^2 mul) complex per (g, w, a) = 16 d^3 + 6 d^2 flops; tile:
     // ffk_math.h::phased_integral_aa, 18 flops per distinct entry (rotation 6, addition theorem 3,
     // x 1, reciprocal 4, products 3 + 1), d(d-1)+1 entries per (g, w); two sincos and the phase: 62.

@@ -126,7 +126,7 @@ struct AccumGeometry {
     int gsplit;       // sub-chunks per block (in-block segment split), 1 = none
     bool mfma;        // large-d matrix-core kernel (ctrl_mfma.hip): 16 frequencies per block
     bool pc;          // producer/consumer kernel (ctrl_pc.hip), d = 4
-    bool pcw;         // producer/consumer kernel with column-split consumers (ctrl_pcw.hip), d = 8
+    bool pcw;         // producer/consumer kernel on the matrix cores (ctrl_pcr.hip), d = 8
     bool generic;     // runtime-d kernel (generic.hip), d > 16: one block per (frequency, operator, chunk)
 };
 void set_use_wave_kernel(bool on);
@@ -157,17 +157,10 @@ hipError_t launch_accumulate_pc(const double* omega, int W, const double* segtab
                                 int G, int d, int A, int nc, int chunks, int chunk_len, cplx* Ypart,
                                 hipStream_t stream);
 
-// ---- ctrl_pcw.hip ----------------------------------------------------------------------------
-bool pcw_accumulate_supported(int d, int A);
-int pcw_accumulate_ops_per_block();
-int pcw_accumulate_waves();
-int pcw_accumulate_lds_bytes();
-hipError_t launch_accumulate_pcw(const double* omega, int W, const double* segtab, const cplx* ops,
-                                 int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
-                                 hipStream_t stream);
-
 // ---- ctrl_pcr.hip (d = 8, real integral tile) --------------------------------------------------
 bool pcr_accumulate_supported(int d, int A);
+int pcr_accumulate_ops_per_block();
+int pcr_accumulate_waves();
 int pcr_accumulate_lds_bytes();
 hipError_t launch_accumulate_pcr(const double* omega, int W, const double* segtab, const cplx* ops,
                                  int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,

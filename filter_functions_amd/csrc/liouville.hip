@@ -405,11 +405,8 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
         double* are = AopRe + static_cast<size_t>(b0)*K*Npad;
         double* aim = AopIm + static_cast<size_t>(b0)*K*Npad;
         double* o = out + static_cast<size_t>(b0)*N*N*(want_imag ? 2 : 1);
-        // d = 8, 16: all elements of a block at once (FFK_TUNE_LIOUVILLE_ROWS=0: the tile kernel)
-        static const bool rows_form = [] {
-            const char* e = std::getenv("FFK_TUNE_LIOUVILLE_ROWS");
-            return e == nullptr || e[0] != '0';
-        }();
+        // d = 8: all elements of a block at once
+        constexpr bool rows_form = true;
         bool done = false;
         if (generic_dimension(d)) {
             const hipError_t eg = launch_conjugate_basis_generic(Us, nb, d, basis, N, Npad, K, want_imag, are,
@@ -417,14 +414,8 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
             if (eg != hipSuccess) return eg;
             done = true;
         }
-        // FFK_TUNE_LIOUVILLE_MFMA=0: vector conjugation throughout; =8: the matrix-core kernel also at d = 8
-        static const int mfma_env = [] {
-            const char* e = std::getenv("FFK_TUNE_LIOUVILLE_MFMA");
-            return e ? std::atoi(e) : -1;
-        }();
-        const bool mfma_form = mfma_env != 0;
-        const int mfma_also = mfma_env == 8 ? 8 : -1;
-        if (mfma_form && (d == 16 || d == 12 || d == mfma_also)) {
+        // d = 12, 16: the conjugation on the matrix cores
+        if (d == 16 || d == 12) {
             const size_t lds = static_cast<size_t>(want_imag ? 2 : 1)*2*d*d*17*sizeof(double);
             auto go = [&](auto kern) -> hipError_t {
                 if (lds > 40*1024) {

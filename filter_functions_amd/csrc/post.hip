@@ -654,20 +654,11 @@ hipError_t launch_expand_lds(const cplx* Ypart, int chunks, size_t slab, int A, 
     return hipGetLastError();
 }
 
-namespace {
-bool expand_force_sparse() {          // FFK_TUNE_EXPAND_SPARSE=1: 64-frequency lanes, no LDS, also for d >= 8
-    static const bool on = [] {
-        const char* e = std::getenv("FFK_TUNE_EXPAND_SPARSE");
-        return e != nullptr && e[0] == '1';
-    }();
-    return on;
-}
-}  // namespace
 
 hipError_t launch_expand_chunks(const cplx* Ypart, int chunks, size_t slab, int A, int N, int d,
                                 int W, cplx* R, void* ws, hipStream_t stream) {
     if (A > 65535 || N > 65535) return hipErrorInvalidValue;
-    if (d >= 8 && d <= kMaxD && !expand_force_sparse())      // (d > 16: the tile would not fit LDS)
+    if (d >= 8 && d <= kMaxD)      // (d > 16: the tile would not fit LDS)
         return launch_expand_lds(Ypart, chunks, slab, A, N, d, W, R, ws, stream);
     const CompactWs cw = slice_compact_ws(ws, N, d);
     hipLaunchKernelGGL(expand_chunks_kernel, dim3((W + 63)/64, A, N), dim3(64), 0, stream, Ypart,
@@ -685,20 +676,12 @@ hipError_t launch_expand(const cplx* Bt, const cplx* basis, int A2, int N, int d
     cplx* vals = cw.vals;
     if (!compacted)
         hipLaunchKernelGGL(basis_compact_kernel, dim3(N), dim3(64), 0, stream, basis, d, nnz, rows, vals);
-    if (d >= 8 && d <= kMaxD && !expand_force_sparse()) {
+    if (d >= 8 && d <= kMaxD) {
         // both forms, each deciding on the device whether the basis is its kind (see basis_is_sparse)
         hipError_t err = launch_expand_lds(Bt, 1, 0, A2, N, d, W, R, ws, stream, 0);
         if (err != hipSuccess) return err;
-        static const bool quarters = [] {             // FFK_TUNE_EXPAND_QUARTERS=0: elements over grid.z
-            const char* e = std::getenv("FFK_TUNE_EXPAND_QUARTERS");
-            return e == nullptr || e[0] != '0';
-        }();
-        if (quarters && N >= 64 && static_cast<long>((W + 63)/64)*A2 >= 1024) {
-            static const bool groups = [] {           // FFK_TUNE_EXPAND_GROUPS=0: the quarters kernel
-                const char* e = std::getenv("FFK_TUNE_EXPAND_GROUPS");
-                return e == nullptr || e[0] != '0';
-            }();
-            if (groups && N <= 256 && dd <= 0x3fff)
+        if (N >= 64 && static_cast<long>((W + 63)/64)*A2 >= 1024) {
+            if (N <= 256 && dd <= 0x3fff)
                 hipLaunchKernelGGL(expand_sparse_groups_kernel, dim3((W + 63)/64, A2), dim3(256), 0, stream, Bt,
                                    nnz, rows, vals, N, static_cast<int>(dd), W, R, 1);
             else

@@ -2354,10 +2354,9 @@ def test_decay_amplitudes_complex_spectrum_below_three_dimensions(s_ndim, N, W):
 @pytest.mark.parametrize('G,A,W', [(1, 1, 1), (2, 2, 65), (3, 4, 100), (5, 7, 64), (9, 10, 130),
                                     (33, 3, 7), (4, 6, 40), (3, 13, 70), (2, 12, 33), (6, 9, 31)])
 def test_d8_producer_consumer_kernel_ragged_shapes(G, A, W):
-    """ctrl_pcw.hip (d = 8): operator counts that fill neither the six-operator blocks (32-frequency
-    tiles) nor the three-operator blocks that take the rest (64-frequency tiles), frequency tiles that
-    are not full, one- and two-segment chunks, several chunks -- against the oracle and against the
-    symmetric kernel (tuning variant 2)."""
+    """ctrl_pcr.hip (d = 8): operator counts that do not fill the three-operator blocks, frequency
+    tiles that are not full, one- and two-segment chunks, several chunks -- against the oracle and
+    against the symmetric kernel (tuning variant 2)."""
     d = 8
     rng = np.random.default_rng(800 + G*A + W)
     basis = ff.Basis.pauli(3)
