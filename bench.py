@@ -1003,8 +1003,8 @@ def main():
         }
         if configs:
             out['configs'] = configs
-        out['scaling_model'] = scaling_model(elapsed/args.steps*1e3 if world == 1 else latency_ms,
-                                             A*A*args.omega_per_gpu*16, configs)
+        if world == 1:      # the model extrapolates from what ONE GPU measures
+            out['scaling_model'] = scaling_model(elapsed/args.steps*1e3, A*A*args.omega_per_gpu*16, configs)
         if world == 1 and not args.child:
             api, infid_api = bench_api_call(ff, c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega,
                                             spectrum_full)
