@@ -1,5 +1,5 @@
 // ffk_internal.h -- launcher declarations shared between the kernel translation units and the
-// C-ABI layer (ffk_api.hip).  Everything here is device-pointer based and asynchronous on the
+// C-ABI layer (ffk_api*.hip).  Everything here is device-pointer based and asynchronous on the
 // given stream; nothing allocates.
 #pragma once
 

@@ -2181,7 +2181,7 @@ def test_infidelity_on_a_fresh_pulse_is_one_library_call():
 
 def test_resident_pass_replayed_from_its_captured_graph():
     """The user-facing pass is captured as a hipGraph the first time a shape runs on a pair of pooled
-    blocks and REPLAYED afterwards (ffk_api.hip::resident_pass): pulses of one shape evaluated one
+    blocks and REPLAYED afterwards (ffk_api_resident.hip::resident_pass): pulses of one shape evaluated one
     after the other (each on a new handle that gets the previous one's blocks), another shape in
     between, a tuning knob changed in between -- every result against the array route."""
     import gc
