@@ -367,6 +367,113 @@ __global__ __launch_bounds__(64, (TM == 4 && !IMAG) ? 3 : 1) void liouville_gemm
         }
 }
 
+// ---- the same product with operands shared through LDS (Hermitian bases, Npad a multiple of 256) ----
+// The register-fed kernel above reads 64 columns of Aop and 64 of Bop per 64 x 64 tile straight from
+// L2: 8 flops per byte, 4 GB per call at d = 16 / batch 512, and it runs at the rate L2 delivers them
+// (5.5 TB/s, 0.58 of the matrix peak).  Here a workgroup of four wavefronts owns 128 rows (one batch
+// element's basis elements i) x 128 columns (j): all batch elements stacked, the product is
+// (batch N) x K by K x N with the SAME right operand for every row block.  K is walked 16 rows at a
+// time: every thread fetches its share of the next 16 rows of both operands into registers while the
+// matrix cores work on the current ones from LDS (two buffers, one barrier per 16 rows = per 64
+// matrix instructions of a wavefront); a wavefront's 64 x 64 tile is 16 accumulators of 16 x 16.
+// d = 16, batch 512: 750 -> 600 us, 57 TFLOP/s = 0.73 of the matrix peak (profiles/r04_l_*).
+// LDS rows are padded by 16 doubles: the four k rows of an operand fragment then start 32 banks
+// apart, so the two 16-lane groups of a half-wavefront never meet in a bank.
+constexpr int kLbMT = 128, kLbKS = 16, kLbPad = 16;
+constexpr int kLbSA = kLbMT + kLbPad;
+// NTW: 16-column tiles per wavefront; the workgroup (2 x 2 wavefronts) owns 128 x 32 NTW.  Built with
+// NTW = 4: 128 x 128 and TWO workgroups per CU, so that one's barrier, LDS waits, first fetch and
+// result stores are covered by the other's matrix instructions (16 flops per byte from L2).  The
+// 128 x 256 form (NTW = 8, 256 accumulator registers, one workgroup per CU, 22 flops per byte) was
+// 4 % slower at d = 16 / batch 512 (profiles/r04_l_*).
+template <int NTW>
+constexpr size_t lb_lds_bytes() { return sizeof(double)*2*kLbKS*(kLbSA + 32*NTW + kLbPad); }
+
+template <int NTW>
+__global__ __launch_bounds__(256, NTW >= 8 ? 1 : 2) void liouville_gemm_block_kernel(
+    const double* __restrict__ Aop, const double* __restrict__ Bop, int N, int Npad, int K,
+    double* __restrict__ out) {
+    using double2_t = __attribute__((ext_vector_type(2))) double;
+    constexpr int NT = 32*NTW, SB = NT + kLbPad;
+    constexpr int BT = NT/2;                      // threads per row of the right operand's 16-row slab
+    constexpr int BR = 256/BT, BP = kLbKS/BR;     // rows per pass, passes
+    extern __shared__ __attribute__((aligned(16))) double lb_lds[];
+    double* As = lb_lds;                               // [2][16][128 + 16]
+    double* Bs = lb_lds + 2*kLbKS*kLbSA;               // [2][16][NT + 16]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int mt_per = Npad/kLbMT;
+    const int bt = blockIdx.x/mt_per, i0 = (blockIdx.x % mt_per)*kLbMT, j0 = blockIdx.y*NT;
+    const double* Ag = Aop + static_cast<size_t>(bt)*K*Npad + i0 + 2*(t & 63) + static_cast<size_t>(t >> 6)*Npad;
+    const double* Bg = Bop + j0 + 2*(t % BT) + static_cast<size_t>(t / BT)*Npad;
+    double* Aw = As + (t >> 6)*kLbSA + 2*(t & 63);
+    double* Bw = Bs + (t / BT)*SB + 2*(t % BT);
+    double2_t ra[4], rb[BP];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2)
+            ra[p2] = *reinterpret_cast<const double2_t*>(Ag + static_cast<size_t>(k0 + 4*p2)*Npad);
+#pragma unroll
+        for (int p2 = 0; p2 < BP; ++p2)
+            rb[p2] = *reinterpret_cast<const double2_t*>(Bg + static_cast<size_t>(k0 + BR*p2)*Npad);
+    };
+    auto park = [&](int buf) {
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2)
+            *reinterpret_cast<double2_t*>(Aw + (buf*kLbKS + 4*p2)*kLbSA) = ra[p2];
+#pragma unroll
+        for (int p2 = 0; p2 < BP; ++p2)
+            *reinterpret_cast<double2_t*>(Bw + (buf*kLbKS + BR*p2)*SB) = rb[p2];
+    };
+    f64x4 acc[4][NTW];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) acc[m][n] = {0.0, 0.0, 0.0, 0.0};
+    const int wi = (wave & 1)*64, wj = (wave >> 1)*16*NTW;
+    fetch(0);
+    park(0);
+    __syncthreads();
+    for (int k0 = 0; k0 < K; k0 += kLbKS) {
+        const int buf = (k0/kLbKS) & 1;
+        const bool more = k0 + kLbKS < K;
+        if (more) fetch(k0 + kLbKS);
+        const double* Ab = As + (buf*kLbKS + lk)*kLbSA + wi + l15;
+        const double* Bb = Bs + (buf*kLbKS + lk)*SB + wj + l15;
+#pragma unroll
+        for (int kk = 0; kk < kLbKS/4; ++kk) {
+            double a[4], b[NTW];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = Ab[4*kk*kLbSA + 16*m];
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) b[n] = Bb[4*kk*SB + 16*n];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        if (more) park(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            const int col = j0 + wj + 16*n + l15;
+            if (col >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rowi = i0 + wi + 16*m + lk + 4*r;
+                if (rowi < N) out[(static_cast<size_t>(bt)*N + rowi)*N + col] = acc[m][n][r];
+            }
+        }
+}
+
+bool liouville_block_gemm_applies(int Npad, int K, int want_imag) {
+    return !want_imag && Npad % 128 == 0 && K % kLbKS == 0;
+}
+
 }  // namespace
 
 size_t liouville_workspace_bytes(int batch, int d, int N) {
@@ -484,7 +591,20 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
             hipLaunchKernelGGL(kern, dim3((tiles + t - 1)/t, (tiles + t - 1)/t, nb), dim3(64), 0, stream, are,
                                aim, Bop, N, Npad, K, o);
         };
-        if (tiles >= 4 && waves4 >= 2048) {
+        if (liouville_block_gemm_applies(Npad, K, want_imag) && static_cast<long>(nb)*(Npad/128)*(Npad/128) >= 512) {
+            auto go = [&](auto kern, size_t lds, int nt) -> hipError_t {
+                hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    static_cast<int>(lds));
+                if (e4 != hipSuccess) return e4;
+                // (grid.x <= 65535 batch elements x Npad/128 row blocks: 2^31 - 1 is the limit there)
+                hipLaunchKernelGGL(kern, dim3(nb*(Npad/kLbMT), Npad/nt), dim3(256), lds, stream, are, Bop, N,
+                                   Npad, K, o);
+                return hipGetLastError();
+            };
+            const hipError_t e5 = go(liouville_gemm_block_kernel<4>, lb_lds_bytes<4>(), 128);
+            if (e5 != hipSuccess) return e5;
+        } else if (tiles >= 4 && waves4 >= 2048) {
             if (want_imag) launch(liouville_gemm_kernel<4, 4, true>, 4);
             else launch(liouville_gemm_kernel<4, 4, false>, 4);
         } else if (tiles >= 2 && waves2 >= 2048) {
