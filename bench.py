@@ -722,8 +722,8 @@ def main():
         compute_stream = compute_streams[0]
         comm_stream = torch.cuda.Stream(device=device)
         torch.cuda.synchronize(device)
-        # FFK_GATHER: 'auto' (default: the one-sided all-gather of csrc/peer.hip if its set-up and a
-        # verified round trip succeed on every rank, else the RCCL collective), 'push', 'rccl'
+        # FFK_GATHER: 'rccl' (default: the RCCL all-gather), 'auto' (the one-sided all-gather of
+        # csrc/peer.hip if its set-up and a verified round trip succeed on every rank, else RCCL), 'push'
         # Steps are independent passes (one pulse each): with two passes in flight on two HIP
         # streams the latency-bound launches of one pass (eigensolver, scan, prologue, expansion,
         # integral: ~32 us on 256 wavefronts or fewer) run beside the accumulate kernel of the

@@ -70,6 +70,21 @@ inline bool use_fused_front(int G, int d) {
     return d <= kMaxD && (G + front_chunk(d) - 1)/front_chunk(d) <= 64;
 }
 
+// ---- liouville.hip / generic.hip: rows of the Liouville GEMM's operands for a Hermitian basis -----
+// tr(CB_i C_j) with CB_i = U^dag C_i U and C_j both Hermitian (CB_i is, whatever U):
+//   sum_a Re CB[a,a] Re C[a,a] + sum_{a<b} 2 (Re CB[a,b] Re C[b,a] - Im CB[a,b] Im C[b,a]),
+// i.e. K = d^2 real rows instead of 2 d^2: row a for the diagonal, rows d + 2 p(a,b) (real parts) and
+// d + 2 p(a,b) + 1 (imaginary parts) for the pair a < b, p(a,b) = a (2d - a - 1)/2 + b - a - 1.
+// Returns -1 for the entries that are not stored (a > b; the imaginary part of the diagonal).
+__host__ __device__ inline int hermitian_operand_row(int a, int b, int imag_part, int d) {
+    if (a == b) return imag_part ? -1 : a;
+    if (a > b) return -1;
+    return d + 2*(a*(2*d - a - 1)/2 + b - a - 1) + imag_part;
+}
+__host__ __device__ inline int liouville_operand_rows(int d, int want_imag) {
+    return ((want_imag ? 2*d*d : d*d) + 3)/4*4;       // padded to the MFMA k-step
+}
+
 // ---- scan.hip --------------------------------------------------------------------------------
 size_t scan_workspace_bytes(int G, int d);
 // chunk-local prefix products Qloc (G+1,d,d) (Qloc[0] = 1) and chunk totals (nchunks,d,d)

@@ -440,11 +440,16 @@ __global__ __launch_bounds__(kGenThreads) void conjugate_generic_kernel(
             const int ra = r + 16*a, cb = c + 16*b;
             if (ra < d && cb < d) {
                 const size_t e = static_cast<size_t>(ra)*d + cb;
-                are[e*Npad + i] = acc[a][b].re;
-                are[(dd + e)*Npad + i] = -acc[a][b].im;
                 if (want_imag) {
+                    are[e*Npad + i] = acc[a][b].re;
+                    are[(dd + e)*Npad + i] = -acc[a][b].im;
                     aim[e*Npad + i] = acc[a][b].im;
                     aim[(dd + e)*Npad + i] = acc[a][b].re;
+                } else {
+                    // Hermitian basis: K = d^2 rows (ffk_internal.h::hermitian_operand_row)
+                    const int r0 = hermitian_operand_row(ra, cb, 0, d), r1 = hermitian_operand_row(ra, cb, 1, d);
+                    if (r0 >= 0) are[static_cast<size_t>(r0)*Npad + i] = acc[a][b].re;
+                    if (r1 >= 0) are[static_cast<size_t>(r1)*Npad + i] = -acc[a][b].im;
                 }
             }
         }

@@ -23,7 +23,7 @@ namespace {
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 // Bop[kk][j]: kk = b*d + a (Re), d*d + b*d + a (Im) of C_j[b][a]
-__global__ void build_bop_kernel(const cplx* __restrict__ basis, int N, int d, int Npad,
+__global__ void build_bop_kernel(const cplx* __restrict__ basis, int N, int d, int Npad, int hermitian,
                                  double* __restrict__ Bop) {
     const int j = blockIdx.x*blockDim.x + threadIdx.x;
     const int ab = blockIdx.y;  // a*d + b
@@ -31,8 +31,43 @@ __global__ void build_bop_kernel(const cplx* __restrict__ basis, int N, int d, i
     const int a = ab / d, b = ab % d;
     cplx v = {0.0, 0.0};
     if (j < N) v = basis[(static_cast<size_t>(j)*d + b)*d + a];
+    if (hermitian) {
+        // (rows of hermitian_operand_row: the pair (a, b), (b, a) contributes twice the stored half)
+        const int r0 = hermitian_operand_row(a, b, 0, d), r1 = hermitian_operand_row(a, b, 1, d);
+        if (r0 >= 0) Bop[static_cast<size_t>(r0)*Npad + j] = a == b ? v.re : 2.0*v.re;
+        if (r1 >= 0) Bop[static_cast<size_t>(r1)*Npad + j] = 2.0*v.im;
+        return;
+    }
     Bop[static_cast<size_t>(ab)*Npad + j] = v.re;
     Bop[static_cast<size_t>(d*d + ab)*Npad + j] = v.im;
+}
+
+// The LDS tile [2 d^2][EPB + 1] of a block's EPB conjugated elements (row kk = a d + b: Re CB[a,b],
+// d^2 + a d + b: -Im CB[a,b]; `transposed_slots`: the rows kernel keeps entry (a, b) in slot b d + a)
+// to the K-major operand(s): EPB consecutive doubles per row.  Hermitian basis (no imaginary operand):
+// only the rows of hermitian_operand_row are written, K = d^2.
+template <int D, int EPB>
+__device__ __forceinline__ void copy_out_operand_tile(const double* tre, const double* tim, int want_imag,
+                                                      double* __restrict__ AopRe,
+                                                      double* __restrict__ AopIm, int bt, int Npad, int i0,
+                                                      int N, int tid, bool transposed_slots) {
+    constexpr int DD = D*D, ROW = EPB + 1;
+    const size_t K = liouville_operand_rows(D, want_imag);     // pad rows stay zero
+    double* are = AopRe + static_cast<size_t>(bt)*K*Npad;
+    double* aim = AopIm + static_cast<size_t>(bt)*K*Npad;
+    for (int idx = tid; idx < 2*DD*EPB; idx += 256) {
+        const int kk = idx / EPB, jj = idx % EPB;
+        if (i0 + jj >= N) continue;
+        const int half = kk / DD, e = kk % DD, a = e / D, b = e % D;
+        const int slot = transposed_slots ? half*DD + b*D + a : kk;
+        if (want_imag) {
+            are[static_cast<size_t>(kk)*Npad + i0 + jj] = tre[slot*ROW + jj];
+            aim[static_cast<size_t>(kk)*Npad + i0 + jj] = tim[slot*ROW + jj];
+        } else {
+            const int r = hermitian_operand_row(a, b, half, D);
+            if (r >= 0) are[static_cast<size_t>(r)*Npad + i0 + jj] = tre[slot*ROW + jj];
+        }
+    }
 }
 
 // Conjugation of the basis with COALESCED operand stores.  The GEMM wants its A operand K-major,
@@ -89,16 +124,7 @@ __global__ __launch_bounds__(256) void conjugate_basis_tile_kernel(const cplx* _
         }
     }
     __syncthreads();
-    const size_t K = (2*DD + 3)/4*4;     // padded to the MFMA k-step; pad rows stay zero
-    double* are = AopRe + static_cast<size_t>(bt)*K*Npad;
-    double* aim = AopIm + static_cast<size_t>(bt)*K*Npad;
-    for (int idx = tid; idx < 2*DD*EPB; idx += 256) {
-        const int kk = idx / EPB, j = idx % EPB;
-        if (i0 + j < N) {
-            are[static_cast<size_t>(kk)*Npad + i0 + j] = tre[kk*ROW + j];
-            if (want_imag) aim[static_cast<size_t>(kk)*Npad + i0 + j] = tim[kk*ROW + j];
-        }
-    }
+    copy_out_operand_tile<D, EPB>(tre, tim, want_imag, AopRe, AopIm, bt, Npad, i0, N, tid, false);
 }
 
 // The same conjugation with the block's EPB = 256/D basis elements worked on AT ONCE: thread (j, r)
@@ -163,18 +189,7 @@ __global__ __launch_bounds__(256) void conjugate_basis_rows_kernel(const cplx* _
         }
     }
     __syncthreads();
-    const size_t K = (2*DD + 3)/4*4;     // padded to the MFMA k-step; pad rows stay zero
-    double* are = AopRe + static_cast<size_t>(bt)*K*Npad;
-    double* aim = AopIm + static_cast<size_t>(bt)*K*Npad;
-    for (int idx = tid; idx < 2*DD*EPB; idx += 256) {
-        const int kk = idx / EPB, jj = idx % EPB;
-        if (i0 + jj < N) {
-            const int half = kk / DD, e = kk % DD;
-            const int slot = half*DD + (e % D)*D + e / D;
-            are[static_cast<size_t>(kk)*Npad + i0 + jj] = tre[slot*ROW + jj];
-            if (want_imag) aim[static_cast<size_t>(kk)*Npad + i0 + jj] = tim[slot*ROW + jj];
-        }
-    }
+    copy_out_operand_tile<D, EPB>(tre, tim, want_imag, AopRe, AopIm, bt, Npad, i0, N, tid, true);
 }
 
 // d = 12, 16 (8 on request): the conjugation U^dag C_i U on the FP64 matrix cores, in the block-frequency form of the
@@ -187,7 +202,9 @@ __global__ __launch_bounds__(256) void conjugate_basis_rows_kernel(const cplx* _
 // the tile kernel, whose LDS output tile and coalesced copy-out it shares.  The vector kernels read
 // an entry of U from LDS per complex multiply-add and are bound by that (rows kernel above: no
 // faster than the tile kernel at d = 16).
-template <int D>
+// HERM (Hermitian basis): only the blocks of Y on and above the diagonal are formed -- the operand
+// keeps the entries a <= b (hermitian_operand_row): 10 of 16 block pairs of the second product at d = 16.
+template <int D, bool HERM>
 __global__ __launch_bounds__(256) void conjugate_basis_mfma_kernel(const cplx* __restrict__ U,
                                                                      const cplx* __restrict__ basis, int N,
                                                                      int Npad, int want_imag,
@@ -245,18 +262,42 @@ __global__ __launch_bounds__(256) void conjugate_basis_mfma_kernel(const cplx* _
 #pragma unroll
         for (int ig = 0; ig < NS; ++ig) {
 #pragma unroll
-            for (int jg = 0; jg < NS; ++jg) {
+            for (int jg = HERM ? ig : 0; jg < NS; ++jg) {
                 Yr[ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr[ig], tq[ng][jg].re, Yr[ig][jg], 0, 0, 0);
                 Yi[ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pr[ig], tq[ng][jg].im, Yi[ig][jg], 0, 0, 0);
             }
 #pragma unroll
-            for (int jg = 0; jg < NS; ++jg) {
+            for (int jg = HERM ? ig : 0; jg < NS; ++jg) {
                 Yr[ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi[ig], tq[ng][jg].im, Yr[ig][jg], 0, 0, 1);
                 Yi[ig][jg] = __builtin_amdgcn_mfma_f64_4x4x4f64(pi[ig], tq[ng][jg].re, Yi[ig][jg], 0, 0, 0);
             }
         }
     }
     const bool valid = i < N;
+    if constexpr (HERM) {
+        // the tile holds the operand's rows directly (hermitian_operand_row: d^2 of them), and the
+        // copy-out writes 16 bytes per lane: eight lanes per 128-byte row
+#pragma unroll
+        for (int ig = 0; ig < NS; ++ig)
+#pragma unroll
+            for (int jg = ig; jg < NS; ++jg) {
+                const int a = 4*ig + q, b2 = 4*jg + c4;
+                const int r0 = hermitian_operand_row(a, b2, 0, D), r1 = hermitian_operand_row(a, b2, 1, D);
+                if (r0 >= 0) tre[r0*ROW + j] = valid ? Yr[ig][jg] : 0.0;
+                if (r1 >= 0) tre[r1*ROW + j] = valid ? -Yi[ig][jg] : 0.0;
+            }
+        __syncthreads();
+        using double2_t = __attribute__((ext_vector_type(2))) double;
+        double* are = AopRe + static_cast<size_t>(bt)*liouville_operand_rows(D, 0)*Npad + i0;
+        for (int idx = tid; idx < DD*(EPB/2); idx += 256) {
+            const int r = idx/(EPB/2), cp = 2*(idx % (EPB/2));
+            const double2_t v = {tre[r*ROW + cp], tre[r*ROW + cp + 1]};
+            double* dst = are + static_cast<size_t>(r)*Npad + cp;
+            if (i0 + cp + 1 < N) *reinterpret_cast<double2_t*>(dst) = v;
+            else if (i0 + cp < N) dst[0] = v.x;
+        }
+        return;
+    }
 #pragma unroll
     for (int ig = 0; ig < NS; ++ig)
 #pragma unroll
@@ -271,16 +312,7 @@ __global__ __launch_bounds__(256) void conjugate_basis_mfma_kernel(const cplx* _
             }
         }
     __syncthreads();
-    const size_t K = 2*DD;               // (a multiple of the MFMA k-step already)
-    double* are = AopRe + static_cast<size_t>(bt)*K*Npad;
-    double* aim = AopIm + static_cast<size_t>(bt)*K*Npad;
-    for (int idx = tid; idx < 2*DD*EPB; idx += 256) {
-        const int kk = idx / EPB, jj = idx % EPB;
-        if (i0 + jj < N) {
-            are[static_cast<size_t>(kk)*Npad + i0 + jj] = tre[kk*ROW + jj];
-            if (want_imag) aim[static_cast<size_t>(kk)*Npad + i0 + jj] = tim[kk*ROW + jj];
-        }
-    }
+    copy_out_operand_tile<D, EPB>(tre, tim, want_imag, AopRe, AopIm, bt, Npad, i0, N, tid, false);
 }
 
 // One wavefront per (16 TM) x (16 TN) tile of L = Aop^T Bop.  v_mfma_f64_16x16x4_f64 operand maps
@@ -485,8 +517,8 @@ size_t liouville_workspace_bytes(int batch, int d, int N) {
 hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, int N,
                             int hermitian, double* out, void* ws, hipStream_t stream) {
     const int Npad = (N + 15)/16*16;
-    const int K = (2*d*d + 3)/4*4;
     const int want_imag = hermitian ? 0 : 1;
+    const int K = liouville_operand_rows(d, want_imag);
     unsigned char* p = static_cast<unsigned char*>(ws);
     double* Bop = reinterpret_cast<double*>(p);
     p += align_up(static_cast<size_t>(K)*Npad*sizeof(double));
@@ -497,12 +529,12 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
 
     // padding rows (K) and columns (N -> Npad) must contribute nothing: zero the operands once --
     // unless there is no padding at all (d^2 a multiple of 16, e.g. d = 4, 8, 16)
-    if (Npad != N || K != 2*d*d) {
+    if (Npad != N || K != (want_imag ? 2 : 1)*d*d) {
         hipError_t err = hipMemsetAsync(ws, 0, liouville_workspace_bytes(batch, d, N), stream);
         if (err != hipSuccess) return err;
     }
     hipLaunchKernelGGL(build_bop_kernel, dim3((Npad + 63)/64, d*d), dim3(64), 0, stream, basis, N, d,
-                       Npad, Bop);
+                       Npad, hermitian ? 1 : 0, Bop);
     // the batch axis rides on grid.y / grid.z (at most 65535 blocks): longer batches (the
     // propagators of a 200 000-segment pulse) go in slabs
     const int tiles = Npad/16;
@@ -523,7 +555,8 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
         }
         // d = 12, 16: the conjugation on the matrix cores
         if (d == 16 || d == 12) {
-            const size_t lds = static_cast<size_t>(want_imag ? 2 : 1)*2*d*d*17*sizeof(double);
+            // (Hermitian basis: the tile holds the operand's d^2 rows only)
+            const size_t lds = static_cast<size_t>(want_imag ? 4 : 1)*d*d*17*sizeof(double);
             auto go = [&](auto kern) -> hipError_t {
                 if (lds > 40*1024) {
                     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -535,9 +568,10 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
                                    want_imag, are, aim);
                 return hipGetLastError();
             };
-            const hipError_t e3 = d == 16 ? go(conjugate_basis_mfma_kernel<16>)
-                                  : d == 12 ? go(conjugate_basis_mfma_kernel<12>)
-                                            : go(conjugate_basis_mfma_kernel<8>);
+            const hipError_t e3 = d == 16 ? (want_imag ? go(conjugate_basis_mfma_kernel<16, false>)
+                                                       : go(conjugate_basis_mfma_kernel<16, true>))
+                                            : (want_imag ? go(conjugate_basis_mfma_kernel<12, false>)
+                                                         : go(conjugate_basis_mfma_kernel<12, true>));
             if (e3 != hipSuccess) return e3;
             done = true;
         }

@@ -5,7 +5,7 @@ device resident and batched over the segments of a pulse as `concatenate` and th
 
 Prints, per dimension, the time of the whole launch sequence (memset, operand build, basis
 conjugation, GEMM) from HIP events, the real FP64 flops of the GEMM
-(batch * N * 2d^2 * N * 2, N = d^2, real part only for the Hermitian Pauli basis) and the rate.
+(batch * N * d^2 * N * 2, N = d^2: Hermitian Pauli basis, half of the plain trace's rows) and the rate.
 Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split and under
 `rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE` for the utilisation.
 """
@@ -63,14 +63,18 @@ def main():
             _lib.check(lib.ffk_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
             times.append(ms.value)
         t = float(np.median(times))
-        flops = B*N*(2*d*d)*N*2.0
+        # executed by the GEMM since round 4: K = d^2 rows for a Hermitian basis (the pair (a, b), (b, a)
+        # of a Hermitian operand contributes twice its stored half); 2 d^2 rows is the plain trace
+        flops = B*N*(d*d)*N*2.0
+        flops_plain = B*N*(2*d*d)*N*2.0
         # parity on the first elements against the defining trace
         L = out[:2].cpu().numpy()
         C = np.asarray(basis)
         ref = np.einsum('bka,ikl,blm,jma->bij', U[:2].conj(), C, U[:2], C).real
         err = np.abs(L - ref).max()
-        print(f'd={d:2d} N={N:3d} batch={B}: {t*1e3:9.1f} us per call, GEMM {flops/1e9:8.3f} GFLOP '
-              f'-> {flops/(t*1e-3)/1e12:6.2f} TFLOP/s over the whole call; max abs err {err:.1e}')
+        print(f'd={d:2d} N={N:3d} batch={B}: {t*1e3:9.1f} us per call, GEMM {flops/1e9:8.3f} GFLOP executed '
+              f'-> {flops/(t*1e-3)/1e12:6.2f} TFLOP/s over the whole call ({flops_plain/(t*1e-3)/1e12:6.2f} at the '
+              f'plain trace\'s 2 d^2 rows); max abs err {err:.1e}')
 
 
 if __name__ == '__main__':
