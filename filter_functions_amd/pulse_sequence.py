@@ -699,14 +699,14 @@ def _all_bases_equal(pulses):
     first = pulses[0].basis
     # the same Basis object (or one already compared) needs no element-wise comparison: a long
     # sequence is typically built from a handful of distinct pulse objects
-    seen = {id(first)}
-    for p in pulses[1:]:
-        if id(p.basis) in seen:
-            continue
-        if p.basis.shape != first.shape or not np.array_equal(np.asarray(p.basis), np.asarray(first)):
-            return False
-        seen.add(id(p.basis))
-    return True
+    others = {id(p.basis): p.basis for p in pulses[1:]}
+    others.pop(id(first), None)
+    if not others:
+        return True
+    if any(b.shape != first.shape for b in others.values()):
+        return False
+    # the remaining distinct objects in ONE comparison (24 small arrays: one call instead of 23)
+    return bool((np.array([np.asarray(b) for b in others.values()]) == np.asarray(first)).all())
 
 
 def _distinct_objects(objects):
@@ -732,7 +732,22 @@ def _ragged_columns(lengths, index):
     return np.repeat(offsets[index] - starts, lens) + np.arange(int(lens.sum()), dtype=np.intp)
 
 
-def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index=None):
+def _same_operator_tables(opers, identifiers):
+    """Do all entries hold identical operator arrays under identical identifiers, in the same order?"""
+    n = len(opers[0])
+    if any(len(o) != n for o in opers) or any(len(i) != n for i in identifiers):
+        return False
+    try:
+        ids = np.array([np.asarray(i) for i in identifiers])
+        ops = np.array([np.asarray(o) for o in opers])
+    except ValueError:                       # ragged: operators of different dimension
+        return False
+    if ids.ndim != 2 or ops.ndim != 4:
+        return False
+    return bool((ids == ids[0]).all()) and bool((ops == ops[0]).all())
+
+
+def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index=None, columns=None):
     """Merge the operator tables of several pulses (contract of reference
     pulse_sequence.py:1340-1483).
 
@@ -752,6 +767,24 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index
     """
     if index is None:
         first, index = np.arange(len(opers)), np.arange(len(opers))
+    n_entries = len(opers)
+    if n_entries > 1 and _same_operator_tables(opers, identifiers):
+        # Every pulse carries the same operators under the same names in the same order (a gate
+        # sequence over one register): the bookkeeping of ONE entry holds for all of them --
+        # names, order and error checks as below -- and the coefficient table is the entries'
+        # tables side by side, rows permuted, blocks gathered.
+        c_opers, c_ids, _, one_map = _concatenate_hamiltonian(opers[:1], identifiers[:1], coeffs[:1], kind,
+                                                              first[:1], np.zeros(1, dtype=np.intp))
+        names = [str(ident) for ident in identifiers[0]]
+        perm = [names.index(old) for new in c_ids for old, mapped in one_map[0].items() if mapped == new]
+        lengths = np.array([np.shape(c)[1] for c in coeffs], dtype=np.intp)
+        if (lengths == lengths[0]).all():
+            table = np.array(coeffs, dtype=float)[index][:, perm].transpose(1, 0, 2).reshape(len(perm), -1)
+        else:
+            if columns is None:
+                columns = _ragged_columns(lengths, index)
+            table = np.take(np.concatenate(coeffs, axis=1)[perm], columns, axis=1)
+        return c_opers, c_ids, table, _PositionMap([one_map[0]]*n_entries, index)
     # one record per (entry, operator): (entry, row in the pulse, matrix, name)
     records = [(k, i, np.ascontiguousarray(op).tobytes(), str(ident))
                for k in range(len(opers))
@@ -776,13 +809,23 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index
     # side by side in ONE array -- and its identifier map; per pulse position: a reference to those
     lengths = np.array([np.shape(c)[1] for c in coeffs], dtype=np.intp)
     offsets = np.concatenate(([0], np.cumsum(lengths)))
-    side_by_side = np.full((len(ordered), int(offsets[-1])), np.nan)
+    # (a control term a pulse lacks is zero; a noise sensitivity it lacks is to be inferred: NaN for now)
+    side_by_side = np.full((len(ordered), int(offsets[-1])), np.nan if kind == 'noise' else 0.0)
     maps = [{} for _ in coeffs]
     carried = np.zeros((len(ordered), len(coeffs)), dtype=bool)
     for k, i, key, ident in records:
-        side_by_side[row[key], offsets[k]:offsets[k + 1]] = np.asarray(coeffs[k])[i]
         maps[k][ident] = new_ident[key]
-        carried[row[key], k] = True
+    if records:
+        # all blocks in ONE scatter: the records are in (entry, row) order, i.e. the order of the
+        # entries' coefficient arrays read row by row
+        rec_k = np.array([rec[0] for rec in records], dtype=np.intp)
+        rec_row = np.array([row[rec[2]] for rec in records], dtype=np.intp)
+        rec_len = lengths[rec_k]
+        starts = np.cumsum(rec_len) - rec_len
+        values = np.concatenate([np.asarray(c, dtype=float).reshape(-1) for c in coeffs])
+        dest = np.repeat(rec_row*int(offsets[-1]) + offsets[rec_k] - starts, rec_len) + np.arange(len(values))
+        side_by_side.reshape(-1)[dest] = values
+        carried[rec_row, rec_k] = True
     complete = bool(carried.all())                     # every pulse carries every operator: no NaN
     if (lengths == lengths[0]).all():
         # equal segment counts: one gather (operators, entries, segments)[:, index] -> (operators, all segments)
@@ -793,19 +836,17 @@ def _concatenate_hamiltonian(opers, identifiers, coeffs, kind, first=None, index
     else:
         # many positions drawn from few pulses, ragged: one gather of columns (no Python-level loop
         # over the positions)
-        table = side_by_side[:, _ragged_columns(lengths, index)]
+        # (np.take along the axis: 5x faster than the equivalent fancy index on a few long rows)
+        table = np.take(side_by_side, _ragged_columns(lengths, index) if columns is None else columns, axis=1)
     mapping = _PositionMap(maps, index)
-    if not complete:
-        missing = np.isnan(table)
-        if kind == 'noise':
-            for r in np.nonzero(missing.any(axis=1))[0]:
-                known = table[r][~missing[r]]
-                if not (known == known[0]).all():
-                    raise ValueError('Not all pulses have the same noise operators and '
-                                     'non-trivial noise sensitivities so I cannot infer them.')
-                table[r, missing[r]] = known[0]
-        elif missing.any():
-            table[missing] = 0
+    if not complete and kind == 'noise':
+        for r in np.nonzero(~carried.all(axis=1))[0]:          # rows that some pulse does not carry
+            missing = np.isnan(table[r])
+            known = table[r][~missing]
+            if not (known == known[0]).all():
+                raise ValueError('Not all pulses have the same noise operators and '
+                                 'non-trivial noise sensitivities so I cannot infer them.')
+            table[r, missing] = known[0]
     return concat_opers, concat_identifiers, table, mapping
 
 
@@ -852,23 +893,27 @@ def _concatenate_distinct(pulses, distinct, first, index):
         raise ValueError('Trying to concatenate PulseSequence instances with different dimension!')
     if not _all_bases_equal(distinct):
         raise ValueError('Trying to concatenate PulseSequence instances with different bases!')
+    lengths = np.array([len(p.dt) for p in distinct])
+    # (ragged pulses, many positions: the three gathers below share their column numbers)
+    ragged = not (lengths == lengths[0]).all() and len(index) > 4*len(distinct)
+    columns = _ragged_columns(lengths, index) if ragged else None
     c_opers, c_ids, c_coeffs, c_map = _concatenate_hamiltonian(
         [p.c_opers for p in distinct], [p.c_oper_identifiers for p in distinct],
-        [p.c_coeffs for p in distinct], 'control', first, index)
+        [p.c_coeffs for p in distinct], 'control', first, index, columns)
     n_opers, n_ids, n_coeffs, n_map = _concatenate_hamiltonian(
         [p.n_opers for p in distinct], [p.n_oper_identifiers for p in distinct],
-        [p.n_coeffs for p in distinct], 'noise', first, index)
-    lengths = np.array([len(p.dt) for p in distinct])
+        [p.n_coeffs for p in distinct], 'noise', first, index, columns)
     if (lengths == lengths[0]).all():
         dt = np.stack([p.dt for p in distinct])[index].reshape(-1)
-    elif len(index) <= 4*len(distinct):
+    elif not ragged:
         dt = np.concatenate([distinct[k].dt for k in index])
     else:
-        dt = np.concatenate([p.dt for p in distinct])[_ragged_columns(lengths, index)]
+        dt = np.concatenate([p.dt for p in distinct]).take(columns)
     newpulse = PulseSequence.from_arrays(c_opers, c_ids, c_coeffs, n_opers, n_ids, n_coeffs, dt,
                                          distinct[0].basis)
-    # (summed position by position like the reference's sum over the pulses)
-    newpulse.tau = sum(np.array([p.tau for p in distinct])[index].tolist())
+    # (summed position by position like the reference's sum over the pulses: a running sum, not
+    # NumPy's pairwise reduction)
+    newpulse.tau = float(np.cumsum(np.array([p.tau for p in distinct], dtype=float)[index])[-1])
     return newpulse, c_map, n_map
 
 
