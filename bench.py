@@ -363,7 +363,7 @@ def bench_config3(ff):
     draw = wl.rb_draw(cfg['n_gates'], cfg['seed'])
     seq = [cliffords[k] for k in draw]
     times = []
-    for _ in range(4):
+    for _ in range(12):           # (the first calls pay the arena, the pools and the clocks' ramp: min of 12)
         t0 = time.perf_counter()
         total = ff.concatenate(seq)
         total.get_filter_function(omega)

@@ -236,6 +236,22 @@ def test_liouville_representation_against_the_oracle(d, batch, hermitian):
     assert rel_err(L, ref) < 1e-13
 
 
+@pytest.mark.parametrize('d,batch', [(2, 3), (3, 5), (5, 4), (7, 2), (8, 5), (12, 3), (16, 2), (20, 2), (32, 1)])
+def test_liouville_representation_of_any_operator_in_a_hermitian_basis(d, batch):
+    """For a Hermitian basis the library contracts d^2 operand rows instead of 2 d^2: U^dag C_i U is
+    Hermitian whenever C_i is -- WHATEVER U -- so the entries a <= b carry the whole trace
+    (csrc/ffk_internal.h::hermitian_operand_row).  Checked with operators that are NOT unitary, on
+    every conjugation kernel (tile: d = 2..7, rows: 8, matrix cores: 12 / 16, runtime-d: 20 / 32; the
+    GEMM through LDS at N = 256, 1024) against the oracle's plain trace (superoperator.py:51-84)."""
+    rng = np.random.default_rng(77*d + batch)
+    basis = ff.Basis.ggm(d)
+    U = rng.standard_normal((batch, d, d)) + 1j*rng.standard_normal((batch, d, d))
+    L = ff.liouville_representation(U, basis)
+    ref = orc.liouville_representation(U, np.asarray(basis))
+    assert not np.iscomplexobj(L) and L.shape == ref.shape
+    assert rel_err(L, ref) < 1e-13
+
+
 @pytest.mark.parametrize('name', ['rand_d2_ggm', 'rand_d3_ggm', 'rand_d4_pauli', 'rand_d4_ggm',
                                   'edge_degenerate_d4'])
 def test_intermediates(name):

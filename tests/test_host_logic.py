@@ -278,6 +278,50 @@ def test_concatenation_bookkeeping():
         ff.concatenate([a, b], calc_second_order_FF=True)
 
 
+def test_long_sequence_bookkeeping_equals_pairwise_concatenation():
+    """A long sequence drawn from a few pulses takes vectorised routes (one scatter for the
+    coefficient blocks, np.take gathers, shared ragged columns; the bookkeeping of ONE entry when all
+    pulses carry the same operator table): the result must be the pulse that concatenating the
+    positions one after the other gives -- ragged and equal segment counts, pulses with and without
+    all control operators, operators in different order, a noise operator one pulse lacks."""
+    X, Y, Z = util.paulis[1:]
+    rng = np.random.default_rng(11)
+
+    def chain(seq):
+        out = seq[0]
+        for p in seq[1:]:
+            out = ff.concatenate_without_filter_function([out, p])
+        return out
+
+    def same(a, b):
+        assert list(a.c_oper_identifiers) == list(b.c_oper_identifiers)
+        assert list(a.n_oper_identifiers) == list(b.n_oper_identifiers)
+        assert np.array_equal(a.c_opers, b.c_opers) and np.array_equal(a.n_opers, b.n_opers)
+        assert np.array_equal(a.c_coeffs, b.c_coeffs) and np.array_equal(a.n_coeffs, b.n_coeffs)
+        assert np.array_equal(a.dt, b.dt) and a.tau == b.tau
+
+    def pulse(n_dt, controls, noises):
+        return ff.PulseSequence([[op, rng.random(n_dt), name] for op, name in controls],
+                                [[op, [s]*n_dt, name] for op, name, s in noises], rng.random(n_dt) + 0.1)
+    families = {
+        # same operator table everywhere, ragged lengths (the fast path)
+        'same table, ragged': [pulse(n, [(X, 'X'), (Y, 'Y')], [(Z, 'Z', 1.0)]) for n in (1, 3, 2, 4)],
+        # same table, equal lengths
+        'same table, equal': [pulse(2, [(X, 'X'), (Y, 'Y')], [(Z, 'Z', 1.0), (X, 'nX', 0.5)]) for _ in range(3)],
+        # control operators missing from some pulses, other order in others (general path, zero fill)
+        'mixed controls': [pulse(2, [(X, 'X')], [(Z, 'Z', 1.0)]), pulse(3, [(Y, 'Y'), (X, 'X')], [(Z, 'Z', 1.0)]),
+                           pulse(1, [(Y, 'Y')], [(Z, 'Z', 1.0)])],
+        # a noise operator only some pulses know (constant sensitivity: inferred)
+        'missing noise': [pulse(2, [(X, 'X')], [(Z, 'Z', 1.0), (Y, 'nY', 0.25)]), pulse(3, [(X, 'X')], [(Z, 'Z', 1.0)])],
+    }
+    for name, distinct in families.items():
+        for n_positions in (2, 7, 40):              # 40 > 4 x len(distinct): the gather routes
+            draw = rng.integers(0, len(distinct), n_positions)
+            draw[:len(distinct)] = np.arange(len(distinct))[:n_positions]     # every pulse appears
+            seq = [distinct[k] for k in draw]
+            same(ff.concatenate_without_filter_function(seq), chain(seq))
+
+
 def test_pulse_sequence_equality():
     """__eq__ merges constant stretches before comparing (reference pulse_sequence.py:363-440)."""
     X, Y, Z = util.paulis[1:]
@@ -453,6 +497,40 @@ def test_basis_from_partial_and_analytic_formulas():
     assert np.allclose(ff.analytic.UDD(z, 1), ff.analytic.SE(z))
     assert np.allclose(ff.analytic.CDD(z, 1), ff.analytic.PDD(z, 1))
     assert np.isscalar(float(ff.analytic.UDD(1.3, 4)))
+
+
+def test_hermitian_operand_rows_carry_the_whole_trace():
+    """The identity behind the Liouville kernels' d^2 operand rows (csrc/ffk_internal.h::
+    hermitian_operand_row, restated here): for Hermitian C_i, C_j and ANY U,
+    tr(U^dag C_i U C_j) = sum_a Re CB[a,a] Re C[a,a] + sum_{a<b} 2 (Re CB[a,b] Re C[b,a] - Im CB[a,b] Im C[b,a]),
+    with the rows numbered a (diagonal), d + 2 p(a,b) (+1 for the imaginary parts)."""
+    def row(a, b, imag, d):
+        if a == b:
+            return -1 if imag else a
+        if a > b:
+            return -1
+        return d + 2*(a*(2*d - a - 1)//2 + b - a - 1) + imag
+    rng = np.random.default_rng(5)
+    for d in (2, 3, 5, 8):
+        basis = np.asarray(ff.Basis.ggm(d))
+        U = rng.standard_normal((d, d)) + 1j*rng.standard_normal((d, d))       # not unitary
+        CB = np.einsum('ba,ibc,cd->iad', U.conj(), basis, U)
+        rows = sorted(row(a, b, im, d) for a in range(d) for b in range(d) for im in (0, 1)
+                      if row(a, b, im, d) >= 0)
+        assert rows == list(range(d*d))                                        # a bijection onto 0 .. d^2 - 1
+        A = np.zeros((d*d, len(basis)))
+        B = np.zeros((d*d, len(basis)))
+        for a in range(d):
+            for b in range(a, d):
+                r0, r1 = row(a, b, 0, d), row(a, b, 1, d)
+                A[r0] = CB[:, a, b].real
+                B[r0] = basis[:, b, a].real*(1 if a == b else 2)
+                if r1 >= 0:
+                    A[r1] = -CB[:, a, b].imag
+                    B[r1] = 2*basis[:, b, a].imag
+        full = np.einsum('iab,jba->ij', CB, basis)
+        assert np.abs(full.imag).max() < 1e-12
+        assert np.abs(A.T @ B - full.real).max() < 1e-12
 
 
 def test_tensor_product_chains():
