@@ -353,6 +353,55 @@ def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
         geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')})
 
 
+def bench_liouville(ff, torch, lib, _lib, device):
+    """superoperator.liouville_representation (the one kernel BASELINE's north_star
+    names for the matrix cores): d = 16, Pauli basis, batch 512, device resident -- basis conjugation
+    + the GEMM (`tools/time_liouville.py` is the stand-alone version, with a parity check)."""
+    import ctypes
+    d, B = 16, 512
+    N = d*d
+    rng = np.random.default_rng(0)
+    basis = ff.Basis.pauli(4)
+    U = np.linalg.qr(rng.standard_normal((B, d, d)) + 1j*rng.standard_normal((B, d, d)))[0]
+    with torch.cuda.device(device):
+        Ud = torch.from_numpy(U).to(device)
+        Cd = torch.from_numpy(np.ascontiguousarray(np.asarray(basis))).to(device)
+        out = torch.empty((B, N, N), dtype=torch.float64, device=device)
+        need = lib.ffk_liouville_workspace_bytes(B, d, N)
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+        def run():
+            _lib.check(lib.ffk_liouville_dev(p(Ud), B, d, p(Cd), N, 1, p(out), p(ws), need,
+                                             ctypes.c_void_p(stream)))
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        times = []
+        for _ in range(20):
+            e0.record()
+            run()
+            e1.record()
+            torch.cuda.synchronize(device)
+            times.append(e0.elapsed_time(e1))
+    ms = float(np.median(times))
+    executed = B*N*float(d*d)*N*2.0            # Hermitian basis: d^2 operand rows (DESIGN 6.5)
+    plain = 2*executed                         # the plain trace's 2 d^2 rows
+    return dict(
+        config='K5', workload='superoperator.liouville_representation: d=16 (N=256), Pauli basis, batch 512, '
+                              'device resident (basis conjugation on v_mfma_f64_4x4x4 + GEMM on '
+                              'v_mfma_f64_16x16x4 through LDS)',
+        ms=ms, dominant_kernel='ffk::liouville_gemm_block_kernel<4>',
+        executed_gemm_flops=executed, tflops_whole_call=executed/(ms*1e-3)/1e12,
+        frac_whole_call=executed/(ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+        tflops_at_plain_trace_rows=plain/(ms*1e-3)/1e12,
+        note='whole launch sequence (operand build, conjugation, GEMM) over the GEMM flops the library '
+             'executes; per-kernel split and the GEMM alone (0.68 of the FP64 matrix peak): '
+             'profiles/r04_l_liouville_block_gemm.txt')
+
+
 def bench_config3(ff):
     """examples/randomized_benchmarking.py: 1000 Clifford gates drawn from 24, 8192 omega, filter
     function by the concatenation rule (whole Python call, host arrays in and out)."""
@@ -899,6 +948,7 @@ def main():
             configs.append(bench_config3(ff))
             configs.append(bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream)[1])
             configs.append(bench_config5(ff, torch, lib, _lib, DevicePipeline, device, compute_stream))
+            configs.append(bench_liouville(ff, torch, lib, _lib, device))
             if args.published_example:     # doc notebook (concatenate_periodic): outside SURVEY section 8
                 configs.append(bench_published_example(ff))
 
