@@ -36,6 +36,25 @@ namespace {
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 constexpr int kMW = 4;   // wavefronts (= noise operators) per block, one per SIMD
 
+#ifdef FFK_MFMA_CLOCK   /* tuning build: where a wavefront of the d = 12, 16 kernel spends its cycles */
+// sums over every wavefront of the last launches, shader-clock cycles: [0] wait at the barrier that
+// frees the tile, [1] issue of the staging loads + generation, [2] parking the staged operands,
+// [3] wait at the barrier that publishes the tile, [4] contraction, [5] segment-steps counted
+__device__ unsigned long long g_mfma_phase[8];
+#define FFK_MC_T() __builtin_amdgcn_s_memtime()
+// (summed per wavefront in scalar registers, one atomic per phase at the end of the kernel: six atomics
+// per step on six addresses stalled the staging loads behind them and tripled the kernel's time)
+#define FFK_MC_DECL() unsigned long long mc_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define FFK_MC_ADD(slot, t0, t1) mc_sum[slot] += static_cast<unsigned long long>((t1) - (t0))
+#define FFK_MC_FLUSH() \
+    do { if (lane == 0) for (int mc_i = 0; mc_i < 8; ++mc_i) atomicAdd(&g_mfma_phase[mc_i], mc_sum[mc_i]); } while (0)
+#else
+#define FFK_MC_T() 0ull
+#define FFK_MC_DECL()
+#define FFK_MC_ADD(slot, t0, t1)
+#define FFK_MC_FLUSH()
+#endif
+
 template <int D>
 struct MfmaLayout {
     static constexpr int S = seg_stride(D);
@@ -470,21 +489,36 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
         issue_stage(g0);
         park(0);
     }
+    FFK_MC_DECL();
     for (int g = g0; g < g1; ++g) {
         const int buf = (g - g0) & 1;
+        [[maybe_unused]] const unsigned long long mc0 = FFK_MC_T();
         __syncthreads();
         if constexpr (BF) {
+            [[maybe_unused]] const unsigned long long mc1 = FFK_MC_T();
             // the staging loads of segment g + 1 fly during the generation, not the contraction,
             // whose accumulators, T entries and products leave no registers for them (d = 16)
             if (g + 1 < g1) issue_stage(g + 1);
+            [[maybe_unused]] const unsigned long long mc1b = FFK_MC_T();
+            FFK_MC_ADD(6, mc1, mc1b);        // [6] of [1]: issue of the staging loads alone
 #if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 1)   /* diagnostic build 1: no generation */
             generate(buf);
 #endif
+            [[maybe_unused]] const unsigned long long mc2 = FFK_MC_T();
             if (g + 1 < g1) park(buf ^ 1);   // buffer buf ^ 1: last read before this barrier interval
+            [[maybe_unused]] const unsigned long long mc3 = FFK_MC_T();
             __syncthreads();
+            [[maybe_unused]] const unsigned long long mc4 = FFK_MC_T();
 #if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 2)   /* diagnostic build 2: no contraction */
             if (active) contract_bf(buf);
 #endif
+            [[maybe_unused]] const unsigned long long mc5 = FFK_MC_T();
+            FFK_MC_ADD(0, mc0, mc1);
+            FFK_MC_ADD(1, mc1, mc2);
+            FFK_MC_ADD(2, mc2, mc3);
+            FFK_MC_ADD(3, mc3, mc4);
+            FFK_MC_ADD(4, mc4, mc5);
+            FFK_MC_ADD(5, 0ull, 1ull);
         } else {
 #if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 1)
             generate(buf);
@@ -498,6 +532,7 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
         }
     }
 
+    FFK_MC_FLUSH();
     if constexpr (BF) {
         if (active) {
             cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W;
@@ -884,3 +919,15 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
 }
 
 }  // namespace ffk
+
+#ifdef FFK_MFMA_CLOCK
+// (tuning build only, not in include/ffk.h) phase sums since the last reset; reset != 0 clears them
+extern "C" int ffk_debug_mfma_phases(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ffk::g_mfma_phase), sizeof(unsigned long long)*8) != hipSuccess) return 1;
+    if (reset) {
+        const unsigned long long zero[8] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ffk::g_mfma_phase), zero, sizeof zero) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
