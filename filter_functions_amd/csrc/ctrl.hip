@@ -991,7 +991,8 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
 
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
-                             hipStream_t stream) {
+                             hipStream_t stream, const ExpandEpilogue* expand, bool* expanded) {
+    if (expanded) *expanded = false;
     if (geo.generic)
         return launch_accumulate_generic(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
                                          stream);
@@ -1003,7 +1004,7 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
                                      stream);
     if (geo.mfma)
         return launch_accumulate_mfma(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len,
-                                      geo.nwaves, Ypart, stream);
+                                      geo.nwaves, Ypart, stream, geo.chunks == 1 ? expand : nullptr, expanded);
     switch (d) {
 #define FFK_CASE(D) \
     case D:         \

@@ -275,7 +275,7 @@ template <int D, int JH, int MAXW = 8, bool BF = false>
 __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, int nw, cplx* __restrict__ Ypart,
-    int alpha_base, int alpha_end) {
+    int alpha_base, int alpha_end, ExpandEpilogue ep) {
     static_assert(D % 4 == 0 && D >= 4 && D <= 16, "d must be a multiple of 4");
     static_assert(BF ? 4 % JH == 0 : (D/4) % JH == 0, "row groups / frequency sets must split evenly");
     constexpr int S = seg_stride(D), DD = D*D, NS = D/4;
@@ -534,6 +534,48 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
 
     FFK_MC_FLUSH();
     if constexpr (BF) {
+        if (ep.R != nullptr) {
+            // One segment chunk: Y is complete here.  Operator by operator, the wavefronts that own it
+            // lay their Y out in the (now free) tile as [entry i d + j][16 frequencies], and all
+            // wavefronts expand it in the basis from there -- expand_lds_kernel's arithmetic (two
+            // accumulators, alternating, summed at the end), thread = (frequency, basis element mod
+            // nthreads/16) -- writing R[a, k, w] instead of Y.
+            cplx* yl = tile;
+            const int wl = tid & 15, kl = tid >> 4, nk = nthreads >> 4;
+            const int wo = blockIdx.x*16 + wl;
+            for (int op = 0; op < na; ++op) {
+                __syncthreads();         // the tile's last readers (contraction / previous operator) are done
+                if (active && alpha_l == op) {
+#pragma unroll
+                    for (int set = 0; set < NSET; ++set) {
+                        const int f = 4*(jh*NSET + set) + (c >> 2);
+#pragma unroll
+                        for (int ig = 0; ig < NS; ++ig)
+#pragma unroll
+                            for (int jg = 0; jg < NS; ++jg)
+                                yl[((4*ig + q)*D + 4*jg + c4)*16 + f] = {Yr[set*NS + ig][jg], Yi[set*NS + ig][jg]};
+                    }
+                }
+                __syncthreads();
+                const int a = alpha0 + op;
+                if (a < alpha_end && wo < W) {
+                    for (int k = kl; k < ep.N; k += nk) {
+                        const int n = ep.nnz[k];
+                        const int* rk = ep.rows + static_cast<size_t>(k)*DD;
+                        const cplx* vk = ep.vals + static_cast<size_t>(k)*DD;
+                        cplx acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+                        int qq = 0;
+                        for (; qq + 1 < n; qq += 2) {
+                            cmac(acc0, vk[qq], yl[rk[qq]*16 + wl]);
+                            cmac(acc1, vk[qq + 1], yl[rk[qq + 1]*16 + wl]);
+                        }
+                        if (qq < n) cmac(acc0, vk[qq], yl[rk[qq]*16 + wl]);
+                        ep.R[(static_cast<size_t>(a)*ep.N + k)*W + wo] = {acc0.re + acc1.re, acc0.im + acc1.im};
+                    }
+                }
+            }
+            return;
+        }
         if (active) {
             cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W;
 #pragma unroll
@@ -748,7 +790,7 @@ size_t mfma4_lds_bytes(int nw) {
 template <int D, int JH, int MAXW = 8, bool BF = false>
 hipError_t launch_d4(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                      int chunks, int chunk_len, int nw, cplx* Ypart, hipStream_t stream,
-                     int alpha_base = 0, int alpha_end = -1) {
+                     int alpha_base = 0, int alpha_end = -1, const ExpandEpilogue* expand = nullptr) {
     auto kern = ctrl_accumulate_mfma4_kernel<D, JH, MAXW, BF>;
     if (nw > MAXW) return hipErrorInvalidValue;
     const int lds = static_cast<int>(mfma4_lds_bytes<D, JH, BF>(nw));
@@ -764,8 +806,10 @@ hipError_t launch_d4(const double* omega, int W, const double* segtab, const cpl
     // operators [alpha_base, alpha_end) of the A the arrays are laid out for
     if (alpha_end < 0) alpha_end = A;
     const dim3 grid((W + 15)/16, (alpha_end - alpha_base + na - 1)/na, chunks);
+    ExpandEpilogue ep = {};
+    if (expand && BF) ep = *expand;
     hipLaunchKernelGGL(kern, grid, dim3(nw*64), lds, stream, omega, W, segtab, ops, G, A, chunk_len,
-                       nw, Ypart, alpha_base, alpha_end);
+                       nw, Ypart, alpha_base, alpha_end, ep);
     return hipGetLastError();
 }
 
@@ -858,8 +902,15 @@ int mfma_accumulate_lds_bytes(int d, int nw) {
 
 hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segtab, const cplx* ops,
                                   int G, int d, int A, int chunks, int chunk_len, int nw,
-                                  cplx* Ypart, hipStream_t stream) {
+                                  cplx* Ypart, hipStream_t stream, const ExpandEpilogue* expand,
+                                  bool* expanded) {
     const int jh = mfma_column_split(d);
+    // the expansion epilogue: block-frequency kernels only, and not where the eight-operator form
+    // (d = 12, A >= 8) takes part of the operators
+    const bool x2_applies = d == 12 && jh == 2 && nw == 8 && A >= 8;
+    const ExpandEpilogue* ep = (expand && expand->R && chunks == 1 && mfma_block_frequency(d) && !x2_applies &&
+                                (d == 16 ? jh == 2 || jh == 4 : true)) ? expand : nullptr;
+    if (expanded) *expanded = ep != nullptr;
     if (mfma_block_frequency(d)) {
         // Two wavefronts per operator make blocks of four operators: one or two left over would
         // leave a whole row of blocks half or three quarters idle (config 5: 18 = 4 x 4 + 2).  They
@@ -887,22 +938,22 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
     if (d == D) { \
         if (main_ops > base) { \
             const hipError_t err = launch_d4<D, 2, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, 8, \
-                                                            Ypart, stream, base, main_ops); \
+                                                            Ypart, stream, base, main_ops, ep); \
             if (err != hipSuccess || main_ops == A) return err; \
         } \
         return launch_d4<D, 4, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, 8, Ypart, stream, \
-                                        main_ops, A); \
+                                        main_ops, A, ep); \
     }
             FFK_BF_SPLIT(12) FFK_BF_SPLIT(16)
 #undef FFK_BF_SPLIT
         }
 #define FFK_BF(D, JH) \
     if (d == D && jh == JH) \
-        return launch_d4<D, JH, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);
+        return launch_d4<D, JH, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream, 0, -1, ep);
         FFK_BF(12, 1) FFK_BF(12, 2) FFK_BF(12, 4) FFK_BF(16, 2) FFK_BF(16, 4)
 #undef FFK_BF
         if (d == 16 && jh == 1)
-            return launch_d4<16, 1, 4, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream);
+            return launch_d4<16, 1, 4, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream, 0, -1, ep);
     }
 #define FFK_M4(D, JH) \
     if (d == D && jh == JH) \

@@ -381,13 +381,27 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
         if (g_ev_gate) FFK_HIP(hipStreamWaitEvent(s, g_ev_gate, 0));
         FFK_HIP(hipEventRecord(g_ev_start, s));
     }
-    FFK_HIP(ffk::launch_accumulate(omega, W, segtab, ops, G, d, A, geo, Ypart, s));
+    const bool want_B = (flags & FFK_WANT_NOISE_OPERATORS) != 0;
+    bool compacted = (flags & FFK_INTERNAL_COMPACT_DONE) != 0;
+    // one segment chunk, only R wanted, basis lists ready: the accumulate kernel may expand Y itself
+    // (ffk_internal.h::ExpandEpilogue) and write the control matrix instead of the partial sums
+    ffk::ExpandEpilogue epilogue = {};
+    if (compacted && control_matrix && !want_B && geo.chunks == 1) {
+        int* nnz;
+        int* rows;
+        cplx* vals;
+        ffk::expand_workspace_slices(ews, N, d, &nnz, &rows, &vals);
+        epilogue = {nnz, rows, vals, N, reinterpret_cast<cplx*>(control_matrix)};
+    }
+    bool expanded = false;
+    FFK_HIP(ffk::launch_accumulate(omega, W, segtab, ops, G, d, A, geo, Ypart, s,
+                                   epilogue.R ? &epilogue : nullptr, &expanded));
     if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_stop, s));
     const size_t slab = size_t(A)*d*d*W;
-    const bool want_B = (flags & FFK_WANT_NOISE_OPERATORS) != 0;
     const cplx* Bsum = Ypart;
-    bool compacted = (flags & FFK_INTERNAL_COMPACT_DONE) != 0;
-    if (compacted && control_matrix && !want_B && g_fuse_F && ffk::expand_ff_supported(A, N)) {
+    if (expanded) {
+        // R is written; F (if wanted through g_fuse_F) is left to the caller's filter-function launch
+    } else if (compacted && control_matrix && !want_B && g_fuse_F && ffk::expand_ff_supported(A, N)) {
         // only R and F are wanted and the basis lists are ready: chunk sum, expansion and F in one
         FFK_HIP(ffk::launch_expand_ff(Ypart, geo.chunks, slab, A, N, d, W,
                                       reinterpret_cast<cplx*>(control_matrix), g_fuse_F, ews, s));

@@ -149,9 +149,22 @@ void set_use_gsplit(bool on);
 void set_mfma_policy(int policy);   // 0 default (d >= 12), 1 never, 2 wherever supported (d = 8 too)
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks);
 // Ypart (chunks, A, d, d, W): partial Hilbert-space sums, omega fastest
+// `expand` (optional): with ONE segment chunk the block that owns an (operator, frequency tile) holds
+// the complete Y of it when its last segment is done; a kernel that supports it (the d = 12, 16
+// matrix-core kernel) then expands Y in the basis from LDS and writes the control matrix R (A, N, W)
+// INSTEAD of Ypart -- the expansion launch and the round trip of Y through HBM disappear (config 5:
+// 1.2 GB written and read back).  *expanded is set to whether that happened.
+struct ExpandEpilogue {
+    const int* nnz;        // compacted basis lists (post.hip: expand_workspace_slices)
+    const int* rows;
+    const cplx* vals;
+    int N;
+    cplx* R;               // NULL: no epilogue
+};
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
-                             hipStream_t stream);
+                             hipStream_t stream, const ExpandEpilogue* expand = nullptr,
+                             bool* expanded = nullptr);
 
 // ---- ctrl_mfma.hip ---------------------------------------------------------------------------
 int device_cu_count();   // compute units of the current device (ctrl.hip)
@@ -161,7 +174,8 @@ int mfma_accumulate_ops_per_block(int d, int A);
 int mfma_accumulate_lds_bytes(int d, int nw);
 hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segtab, const cplx* ops,
                                   int G, int d, int A, int chunks, int chunk_len, int nw,
-                                  cplx* Ypart, hipStream_t stream);
+                                  cplx* Ypart, hipStream_t stream,
+                                  const ExpandEpilogue* expand = nullptr, bool* expanded = nullptr);
 
 // ---- ctrl_pc.hip -----------------------------------------------------------------------------
 bool pc_accumulate_supported(int d, int A);

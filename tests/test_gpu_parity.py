@@ -1044,6 +1044,48 @@ def test_device_pipeline_random_shapes(seed):
         assert np.abs(pipe.infid.cpu().numpy() - ref).max() <= TOL*np.abs(ref).max(), tag
 
 
+@pytest.mark.parametrize('d,A,btype', [(16, 1, 'ggm'), (16, 2, 'pauli'), (16, 5, 'ggm'), (16, 6, 'pauli'), (16, 9, 'ggm'),
+                                       (12, 1, 'ggm'), (12, 3, 'ggm'), (12, 6, 'ggm')])
+def test_expansion_in_the_accumulate_kernels_epilogue(d, A, btype):
+    """With ONE segment chunk the d = 12 / 16 matrix-core kernel holds the complete Y of its tile and
+    expands it in the basis itself (ctrl_mfma.hip: ExpandEpilogue), writing R instead of Y: 1 / 2 / left-over
+    operator blocks, sparse (GGM) and dense (Pauli) bases, a frequency count that leaves the last tile
+    partly empty -- must equal the separate expansion of the same Y (array entry point on the
+    pipeline's own eigensystem, same single chunk) to the last bit, and the oracle within tolerance."""
+    import torch
+    from filter_functions_amd import _lib
+    from filter_functions_amd.device import DevicePipeline
+    rng = np.random.default_rng(100*d + A)
+    G, W = 7, 41
+
+    def herm(n):
+        M = rng.standard_normal((n, d, d)) + 1j*rng.standard_normal((n, d, d))
+        return M + M.conj().transpose(0, 2, 1)
+    c_opers, n_opers = herm(2), herm(A)
+    c_coeffs, n_coeffs = rng.standard_normal((2, G)), rng.random((A, G)) + 0.1
+    dt = rng.random(G) + 0.2
+    omega = np.sort(rng.random(W))*30 + 1e-3
+    basis = ff.Basis.ggm(d) if btype == 'ggm' else ff.Basis.pauli(int(np.log2(d)))
+    lib = _lib.load()
+    try:
+        _lib.check(lib.ffk_set_segment_chunks(1))
+        pipe = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega)
+        pipe.launch()
+        torch.cuda.synchronize()
+        R = pipe.control_matrix.cpu().numpy()
+        D, V, Q = (t.cpu().numpy() for t in (pipe.eigvals, pipe.eigvecs, pipe.propagators))
+        t = np.concatenate(([0.0], dt.cumsum()))
+        R_two_launches = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs,
+                                                                       dt, t)
+    finally:
+        _lib.check(lib.ffk_set_segment_chunks(0))
+    assert np.array_equal(R, R_two_launches)
+    R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), n_opers, n_coeffs, dt)
+    assert rel_err(R, R_ref) < TOL
+    F = pipe.filter_function.cpu().numpy()
+    assert rel_err(F, orc.filter_function(R_ref)) < TOL
+
+
 @pytest.mark.parametrize('N,scale', [(36, 1e-4), (64, 0.3), (100, 5.0), (256, 1e-3), (256, 40.0), (33, 0.0)])
 def test_matrix_exponential_against_scipy(N, scale):
     """ffk_expm_real (scaling and squaring, Taylor degree 18, MFMA products) against
