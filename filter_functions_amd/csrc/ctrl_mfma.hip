@@ -553,24 +553,49 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
                         for (int ig = 0; ig < NS; ++ig)
 #pragma unroll
                             for (int jg = 0; jg < NS; ++jg)
-                                yl[((4*ig + q)*D + 4*jg + c4)*16 + f] = {Yr[set*NS + ig][jg], Yi[set*NS + ig][jg]};
+                                yl[((4*ig + q)*D + 4*jg + c4)*16 + (f ^ (4*c4))] =
+                                    {Yr[set*NS + ig][jg], Yi[set*NS + ig][jg]};
                     }
                 }
                 __syncthreads();
                 const int a = alpha0 + op;
                 if (a < alpha_end && wo < W) {
-                    for (int k = kl; k < ep.N; k += nk) {
-                        const int n = ep.nnz[k];
-                        const int* rk = ep.rows + static_cast<size_t>(k)*DD;
-                        const cplx* vk = ep.vals + static_cast<size_t>(k)*DD;
-                        cplx acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
-                        int qq = 0;
-                        for (; qq + 1 < n; qq += 2) {
-                            cmac(acc0, vk[qq], yl[rk[qq]*16 + wl]);
-                            cmac(acc1, vk[qq + 1], yl[rk[qq + 1]*16 + wl]);
+                    // frequency f of entry e sits in slot f ^ 4 (e & 3) (e & 3 = the column's low bits:
+                    // a 16-lane row of the stores above then hits 16 distinct bank groups)
+                    auto ysw = [&](int e) { return yl[e*16 + (wl ^ (4*(e & 3)))]; };
+                    // four elements per trip, their list heads requested together (the lists sit in L2:
+                    // one element at a time the loop was a chain of dependent trips, count -> row -> LDS)
+                    constexpr int KU = 4;
+                    for (int k0 = kl; k0 < ep.N; k0 += KU*nk) {
+                        int nn[KU], r0[KU], r1[KU];
+                        cplx v0[KU], v1[KU];
+#pragma unroll
+                        for (int u = 0; u < KU; ++u) {
+                            const size_t k = min(k0 + u*nk, ep.N - 1);
+                            nn[u] = ep.nnz[k];
+                            r0[u] = ep.rows[k*DD];
+                            r1[u] = ep.rows[k*DD + 1];
+                            v0[u] = ep.vals[k*DD];
+                            v1[u] = ep.vals[k*DD + 1];
                         }
-                        if (qq < n) cmac(acc0, vk[qq], yl[rk[qq]*16 + wl]);
-                        ep.R[(static_cast<size_t>(a)*ep.N + k)*W + wo] = {acc0.re + acc1.re, acc0.im + acc1.im};
+#pragma unroll
+                        for (int u = 0; u < KU; ++u) {
+                            const int k = k0 + u*nk;
+                            if (k >= ep.N) break;
+                            const int n = nn[u];
+                            const int* rk = ep.rows + static_cast<size_t>(k)*DD;
+                            const cplx* vk = ep.vals + static_cast<size_t>(k)*DD;
+                            cplx acc0 = {0.0, 0.0}, acc1 = {0.0, 0.0};
+                            if (n > 0) cmac(acc0, v0[u], ysw(r0[u]));
+                            if (n > 1) cmac(acc1, v1[u], ysw(r1[u]));
+                            int qq = 2;
+                            for (; qq + 1 < n; qq += 2) {
+                                cmac(acc0, vk[qq], ysw(rk[qq]));
+                                cmac(acc1, vk[qq + 1], ysw(rk[qq + 1]));
+                            }
+                            if (qq < n) cmac(acc0, vk[qq], ysw(rk[qq]));
+                            ep.R[(static_cast<size_t>(a)*ep.N + k)*W + wo] = {acc0.re + acc1.re, acc0.im + acc1.im};
+                        }
                     }
                 }
             }
