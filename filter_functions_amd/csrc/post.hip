@@ -304,6 +304,96 @@ __global__ __launch_bounds__(128) void ff_fidelity_blocked_kernel(const cplx* __
     }
 }
 
+// The same again with R read ONCE.  In ff_fidelity_blocked_kernel every TB x TB tile of operator
+// pairs re-reads its rows of R: 54 row sets for 18 operators instead of 18, 3.6 GB through L2 /
+// Infinity Cache at config 5 (0.39 ms).  Here a block owns 64 frequencies and ALL operators: the rows
+// of R for a few k at a time are staged in LDS by everybody (1 KiB runs; the next chunk's loads fly
+// while this one is worked on, two LDS buffers), and wavefront t forms the pairs of tile t (of the
+// tiles on and above the diagonal) from LDS.  Same summation order per pair: bit-identical F.
+template <int TB, int NT>
+__global__ __launch_bounds__(NT*64) void ff_fidelity_lds_kernel(const cplx* __restrict__ R, int A, int N, int W,
+                                                             int kc, cplx* __restrict__ F) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ffl_raw[];
+    cplx* buf = reinterpret_cast<cplx*>(ffl_raw);                  // [2][kc][A][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int nb = (A + TB - 1)/TB;
+    int ba = 0, rem = wave;                                       // wave -> tile (ba, bb), ba <= bb
+    while (rem >= nb - ba) {
+        rem -= nb - ba;
+        ++ba;
+    }
+    const int bb = ba + rem;
+    const int a0 = ba*TB, b0 = bb*TB;
+    const int w0 = blockIdx.x*64;
+    const int w = w0 + lane;
+    const int wc = min(w, W - 1);
+    const int rows = kc*A;                        // rows of 64 frequencies per chunk
+    constexpr int kMaxRows = 12;                  // per wavefront and chunk (host: rows <= kMaxRows*nwaves)
+    // row r of this wavefront's share of a chunk: operator and k offset (the same for every chunk)
+    const cplx* src[kMaxRows];
+    int dst[kMaxRows];
+#pragma unroll
+    for (int r = 0; r < kMaxRows; ++r) {
+        // (rows past the end repeat the last one: the same values fetched and parked again)
+        const int row = min(wave + r*nwaves, rows - 1);
+        src[r] = R + (static_cast<size_t>(row % A)*N + row / A)*W + wc;
+        dst[r] = row*64 + lane;
+    }
+    cplx acc[TB][TB];
+#pragma unroll
+    for (int i = 0; i < TB; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = {0.0, 0.0};
+    // chunk 0 straight into buffer 0
+#pragma unroll
+    for (int r = 0; r < kMaxRows; ++r) buf[dst[r]] = src[r][0];
+    __syncthreads();
+    int b = 0;
+    for (int k0 = 0; k0 < N; k0 += kc) {
+        // The next chunk's rows are requested before this chunk is worked on and parked after it --
+        // unconditionally, as plain locals: under `if (more chunks)` / in a lambda the staged rows
+        // lived in scratch memory and every load was waited for where it was requested (0.93 ms
+        // instead of 0.39).  The trip after the last chunk re-reads clamped rows and parks them
+        // where nobody looks.
+        cplx staged[kMaxRows];
+        const size_t knext = static_cast<size_t>(min(k0 + kc, N - kc < 0 ? 0 : N - kc))*W;
+#pragma unroll
+        for (int r = 0; r < kMaxRows; ++r) staged[r] = src[r][knext];
+        const int kn = min(kc, N - k0);
+        for (int kk = 0; kk < kn; ++kk) {
+            const cplx* rowp = buf + (static_cast<size_t>(b)*rows + kk*A)*64 + lane;
+            cplx ra[TB], rb[TB];
+#pragma unroll
+            for (int i = 0; i < TB; ++i) {
+                ra[i] = rowp[min(a0 + i, A - 1)*64];
+                rb[i] = rowp[min(b0 + i, A - 1)*64];
+            }
+#pragma unroll
+            for (int i = 0; i < TB; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j) cmac_conj(acc[i][j], ra[i], rb[j]);
+        }
+#pragma unroll
+        for (int r = 0; r < kMaxRows; ++r) buf[static_cast<size_t>(b ^ 1)*rows*64 + dst[r]] = staged[r];
+        __syncthreads();
+        b ^= 1;
+    }
+    if (w >= W) return;
+#pragma unroll
+    for (int i = 0; i < TB; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int a = a0 + i, bq = b0 + j;
+            if (a >= A || bq >= A || a > bq) continue;
+            cplx v = acc[i][j];
+            if (a == bq) v.im = 0.0;
+            F[(static_cast<size_t>(a)*A + bq)*W + w] = v;
+            if (a != bq) F[(static_cast<size_t>(bq)*A + a)*W + w] = {v.re, -v.im};
+        }
+}
+
 // F[a,b,w] = scale * sum_kl conj(R[a,k,w]) M[k,l] R[b,l,w]   ('ako,blo,kl->abo', the filter
 // function of a basis that is not traceless, numeric.py:2295-2305; M from the four-element traces)
 __global__ __launch_bounds__(128) void ff_weighted_kernel(const cplx* __restrict__ R, int A, int N,
@@ -724,6 +814,23 @@ hipError_t launch_filter_function(const cplx* R, int A, int N, int W, int which,
     if (which == 0 && A > 4) {
         constexpr int TB = 6;
         const int nb = (A + TB - 1)/TB;
+        // many frequencies, up to 24 operators: R read once through LDS (one wavefront per pair tile)
+        const int ntiles = nb*(nb + 1)/2;
+        int kc = std::min(8, (72*1024)/(A*1024));
+        while (kc > 1 && kc*A > 12*ntiles) --kc;            // at most 12 staged rows per wavefront and chunk
+        if (ntiles <= 6 && kc >= 1 && kc*A <= 12*ntiles && (W + 63)/64 >= 128) {
+            const size_t lds = sizeof(cplx)*2*static_cast<size_t>(kc)*A*64;
+            auto go = [&](auto kern) -> hipError_t {
+                hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     static_cast<int>(lds));
+                if (err != hipSuccess) return err;
+                hipLaunchKernelGGL(kern, dim3((W + 63)/64), dim3(64*ntiles), lds, stream, R, A, N, W, kc, F);
+                return hipGetLastError();
+            };
+            // (A <= 6: one tile; <= 12: three; <= 18: six wavefronts = pair tiles per block)
+            return ntiles <= 3 ? go(ff_fidelity_lds_kernel<TB, 3>) : go(ff_fidelity_lds_kernel<TB, 6>);
+        }
         hipLaunchKernelGGL(ff_fidelity_blocked_kernel<TB>,
                            dim3((W + block - 1)/block, grid_axis(static_cast<long long>(nb)*nb)),
                            dim3(block), 0, stream, R, A, N, W, F);
