@@ -350,7 +350,11 @@ def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
         tflops=st['accumulate_flops']/(kernel_ms*1e-3)/1e12,
         frac=st['accumulate_flops']/(kernel_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
         entanglement_infidelity=float(1 - np.trace(U)/qft.d**2),
-        geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')})
+        geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')},
+        note='one segment chunk: since round 4 the accumulate kernel expands its complete Y in the basis in '
+             'its epilogue and writes the control matrix itself (no expansion launch); kernel_ms spans its two '
+             'launches (16 + 2 operators) including that epilogue, tflops / frac count the accumulation flops '
+             'alone over it')
 
 
 def bench_liouville(ff, torch, lib, _lib, device):
