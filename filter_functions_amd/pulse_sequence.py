@@ -974,10 +974,23 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     new_ids = list(newpulse.n_oper_identifiers)
     column = {ident: c for c, ident in enumerate(new_ids)}
     carried = np.zeros((len(distinct), len(new_ids)), dtype=bool)
+    # (one scatter; pulses that share their identifier map -- all of them when the sequence carries
+    # one operator table -- share their columns)
+    columns_of, rows_k, cols_k = {}, [], []
     for k, p in enumerate(first_position):
-        carried[k, [column[ident] for ident in n_map[p].values()]] = True
-    present = carried[index]
-    shared_n_opers = bool((present.sum(axis=0) > 1).any())
+        this_map = n_map[p]
+        cols = columns_of.get(id(this_map))
+        if cols is None:
+            cols = columns_of[id(this_map)] = [column[ident] for ident in this_map.values()]
+        rows_k += [k]*len(cols)
+        cols_k += cols
+    carried[rows_k, cols_k] = True
+    if carried.all():
+        present = np.broadcast_to(True, (len(index), len(new_ids)))
+        shared_n_opers = len(index) > 1
+    else:
+        present = carried[index]
+        shared_n_opers = bool((present.sum(axis=0) > 1).any())
     if calc_second_order_FF and not present.all():
         warn('Second order FF requested but not all pulses have the same n_opers. '
              'Not implemented.', UserWarning)
@@ -1012,12 +1025,19 @@ def concatenate(pulses, calc_pulse_correlation_FF=False, calc_filter_function=No
     # every distinct control matrix is evaluated / fetched once
     seg = np.concatenate(([0], np.cumsum(np.array([len(pls.dt) for pls in distinct])[index])))
 
+    own_rows_of = {}
+
     def own_rows(i):
         """Rows of pulse i's control matrix in the order of the new pulse's noise operators."""
         pls = pulses[i]
-        return [list(pls.n_oper_identifiers).index(old)
-                for new in np.asarray(new_ids)[present[i]]
-                for old, mapped in n_map[i].items() if mapped == new]
+        # (pulses that share identifier map, identifiers and presence give the same answer)
+        key = (id(n_map[i]), tuple(pls.n_oper_identifiers), present[i].tobytes())
+        rows = own_rows_of.get(key)
+        if rows is None:
+            rows = own_rows_of[key] = [list(pls.n_oper_identifiers).index(old)
+                                       for new in np.asarray(new_ids)[present[i]]
+                                       for old, mapped in n_map[i].items() if mapped == new]
+        return rows
 
     def atomic_control_matrix(i):
         """Control matrix of the pulse at position i in the new pulse's operator order."""
