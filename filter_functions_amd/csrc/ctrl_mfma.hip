@@ -540,12 +540,16 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
             // wavefronts expand it in the basis from there -- expand_lds_kernel's arithmetic (two
             // accumulators, alternating, summed at the end), thread = (frequency, basis element mod
             // nthreads/16) -- writing R[a, k, w] instead of Y.
-            cplx* yl = tile;
-            const int wl = tid & 15, kl = tid >> 4, nk = nthreads >> 4;
+            // Two operators per round (the launch reserves 2 x d^2 x 16 complex numbers of LDS for it:
+            // everything in LDS is free by now), half the threads expand each.
+            const int half = nthreads >> 1;
+            const int hsel = tid >= half ? 1 : 0, th = tid - hsel*half;
+            const int wl = th & 15, kl = th >> 4, nk = half >> 4;
             const int wo = blockIdx.x*16 + wl;
-            for (int op = 0; op < na; ++op) {
-                __syncthreads();         // the tile's last readers (contraction / previous operator) are done
-                if (active && alpha_l == op) {
+            for (int op0 = 0; op0 < na; op0 += 2) {
+                __syncthreads();         // the tile's last readers (contraction / previous round) are done
+                if (active && (alpha_l == op0 || alpha_l == op0 + 1)) {
+                    cplx* yw = tile + (alpha_l - op0)*DD*16;
 #pragma unroll
                     for (int set = 0; set < NSET; ++set) {
                         const int f = 4*(jh*NSET + set) + (c >> 2);
@@ -553,13 +557,14 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
                         for (int ig = 0; ig < NS; ++ig)
 #pragma unroll
                             for (int jg = 0; jg < NS; ++jg)
-                                yl[((4*ig + q)*D + 4*jg + c4)*16 + (f ^ (4*c4))] =
+                                yw[((4*ig + q)*D + 4*jg + c4)*16 + (f ^ (4*c4))] =
                                     {Yr[set*NS + ig][jg], Yi[set*NS + ig][jg]};
                     }
                 }
                 __syncthreads();
-                const int a = alpha0 + op;
-                if (a < alpha_end && wo < W) {
+                const int a = alpha0 + op0 + hsel;
+                if (op0 + hsel < na && a < alpha_end && wo < W) {
+                    const cplx* yl = tile + hsel*DD*16;
                     // frequency f of entry e sits in slot f ^ 4 (e & 3) (e & 3 = the column's low bits:
                     // a 16-lane row of the stores above then hits 16 distinct bank groups)
                     auto ysw = [&](int e) { return yl[e*16 + (wl ^ (4*(e & 3)))]; };
@@ -832,8 +837,19 @@ hipError_t launch_d4(const double* omega, int W, const double* segtab, const cpl
     if (alpha_end < 0) alpha_end = A;
     const dim3 grid((W + 15)/16, (alpha_end - alpha_base + na - 1)/na, chunks);
     ExpandEpilogue ep = {};
-    if (expand && BF) ep = *expand;
-    hipLaunchKernelGGL(kern, grid, dim3(nw*64), lds, stream, omega, W, segtab, ops, G, A, chunk_len,
+    int lds_launch = lds;
+    if (expand && BF) {
+        ep = *expand;
+        // the epilogue lays two operators' Y side by side: 2 d^2 x 16 complex numbers
+        const int need = static_cast<int>(2*static_cast<size_t>(D)*D*16*sizeof(cplx));
+        if (need > lds_launch) {
+            lds_launch = need;
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds_launch);
+            if (err != hipSuccess) return err;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(nw*64), lds_launch, stream, omega, W, segtab, ops, G, A, chunk_len,
                        nw, Ypart, alpha_base, alpha_end, ep);
     return hipGetLastError();
 }
