@@ -322,9 +322,16 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     auto issue_stage = [&](int g) {
         const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*DD;
         const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
+        // The element numbers through an OPAQUE copy of the thread index: as loop invariants the source
+        // offsets and range conditions of the staged elements were hoisted out of the segment loop,
+        // kept alive across the contraction -- i.e. spilled -- and reloaded here: scratch load, wait,
+        // global load, four times in a row, each wait draining the load before it (2.5-3 k cycles of
+        // a 40.7 k-cycle step, profiles/r04_o_*).  Recomputing them costs a dozen instructions.
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
 #pragma unroll
         for (int k = 0; k < kMaxStage; ++k) {
-            const int e = tid + k*nthreads;
+            const int e = tid_o + k*nthreads;
             // (one unconditional assignment per element: with the two guarded ones the array stayed in
             // scratch memory)
             const cplx* src = e < n_ops ? src_ops + (e < DD ? e : e + alpha0*DD) : src_tab + (e - n_ops);
@@ -334,9 +341,11 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     auto park = [&](int buf) {
         cplx* dst_ops = opsb + buf*kops;
         cplx* dst_tab = reinterpret_cast<cplx*>(rows + buf*S);
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
 #pragma unroll
         for (int k = 0; k < kMaxStage; ++k) {
-            const int e = tid + k*nthreads;
+            const int e = tid_o + k*nthreads;
             if (e < n_ops)
                 dst_ops[e] = staged[k];
             else if (e < n_ops + S/2)
@@ -679,9 +688,11 @@ __global__ __launch_bounds__(512) void ctrl_accumulate_mfma4x2_kernel(
     auto issue_stage = [&](int g) {
         const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*DD;
         const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
+        int tid_o = tid;                 // (opaque: see ctrl_accumulate_mfma4_kernel::issue_stage)
+        asm volatile("" : "+v"(tid_o));
 #pragma unroll
         for (int k = 0; k < kStage; ++k) {
-            const int e = tid + k*NT;
+            const int e = tid_o + k*NT;
             const cplx* src = e < n_ops ? src_ops + (e < DD ? e : e + alpha0*DD) : src_tab + (e - n_ops);
             staged[k] = e < n_ops + S/2 ? *src : cplx{0.0, 0.0};
         }
@@ -689,9 +700,11 @@ __global__ __launch_bounds__(512) void ctrl_accumulate_mfma4x2_kernel(
     auto park = [&](int buf) {
         cplx* dst_ops = opsb + buf*kops;
         cplx* dst_tab = reinterpret_cast<cplx*>(rows + buf*S);
+        int tid_o = tid;
+        asm volatile("" : "+v"(tid_o));
 #pragma unroll
         for (int k = 0; k < kStage; ++k) {
-            const int e = tid + k*NT;
+            const int e = tid_o + k*NT;
             if (e < n_ops)
                 dst_ops[e] = staged[k];
             else if (e < n_ops + S/2)
