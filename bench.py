@@ -1011,35 +1011,39 @@ def main():
                          ('torch.distributed.run' if 'RANK' in os.environ else 'direct')),
             'prewarm': prewarm,
             'roofline': {
-                'kernel': 'ffk::ctrl_accumulate_pc_kernel<4,3>', 'bound': 'fp64_valu',
+                'kernel': 'ffk::ctrl_accumulate_pq_kernel<3>', 'bound': 'mfma',
+                'bound_detail': 'FP64 issue: vector FMA and 4x4x4 matrix instructions share one pipe and one peak',
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved/FP64_PEAK_TFLOPS, 'frac_step': step_tflops/FP64_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_source': traffic_src,
+                'frac_r4_algorithm': (838.0*A + 198.0*((A + 2)//3))*G*args.omega_per_gpu/(acc_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+                'frac_step_r4_algorithm': (838.0*A + 198.0*((A + 2)//3))*G*args.omega_per_gpu/(elapsed/args.steps)/1e12/FP64_PEAK_TFLOPS,
                 'frac_r3_algorithm': ((16.0*d**3 + 6.0*d*d)*A + 18.0*(d*(d - 1) + 1) + 62.0)*G*args.omega_per_gpu/(acc_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
-                'frac_of_power_capped_fma_stream': achieved/59.4,
                 'avg_launch_ms': acc_ms, 'launches_timed': n_ev + n_extra,
                 'launches_in_timed_region': n_ev,
                 'avg_launch_ms_in_timed_region': float(np.mean(in_region_ms)),
                 'launch_ms_min_max': [float(np.min(in_region_ms + extra_ms)),
                                       float(np.max(in_region_ms + extra_ms))],
                 'flops_per_launch': stats['accumulate_flops'],
-                'note': 'FP64 vector-FMA issue bound, and on this part power bound (the kernel issues '
-                        'v_fma_f64 / v_mul_f64 only; vector = matrix FP64 peak 78.6 TFLOP/s on MI355X); '
-                        'flops = FMA-counted flops the kernel EXECUTES (ffk_api.hip::accumulate_flops): since '
-                        'round 4 (real integral tile, phases folded into the frequency-independent '
-                        'operands) 838 per operator + 198 per tile = 2712 per (segment, omega) at A = 3, '
-                        'where the round-3 kernel executed 3656 for the same elements; frac = dominant '
-                        'kernel alone (HIP events, each instrumented launch gated on the previous accumulate '
-                        'kernel), frac_step = the same flops over the whole step time -- above frac when '
-                        'passes pipeline; frac_r3_algorithm = the SAME elements priced at the round-3 '
-                        'kernel\'s executed flops (3656): a speed comparison with BENCH_r03\'s 0.605, not a '
-                        'utilisation -- an algorithm that needs fewer flops per element lowers frac and '
-                        'raises `value`; frac_of_power_capped_fma_stream = achieved / 59.4 TFLOP/s, what a '
-                        'pure v_fma_f64 stream on random operands sustains on this part at its 1400 W cap '
-                        '(in-kernel clock 1.89 GHz; 2.38 GHz on constants: tools/fp64_ceiling_probe.hip, '
-                        'profiles/r03_d_*; rocm-smi reads ~1000 W averaged over a pass of which this kernel '
-                        'is 60 %, profiles/r04_e_*); SURVEY 8(d)\'s (8 d^2 + 8) flop per element is the '
-                        'Liouville-space form, which this kernel does not execute, and is not used here',
+                'note': 'FP64 issue bound (vector FMA and v_mfma_f64_4x4x4 share the pipe: 78.6 TFLOP/s either '
+                        'way on MI355X); flops = FMA-counted flops the kernel EXECUTES '
+                        '(ffk_api.hip::accumulate_flops).  Round 5 (ctrl_pq.hip): the second product on the '
+                        'matrix cores as THREE real products (Gauss) with psi folded into the A operand once '
+                        'per set of four frequencies: 630 per operator + 310 per tile = 2200 per (segment, '
+                        'omega) at A = 3, where the round-4 kernel executed 2712 and the round-3 kernel 3656 '
+                        'for the same elements.  frac = dominant kernel alone (HIP events, each instrumented '
+                        'launch gated on the previous accumulate kernel), frac_step = the same flops over the '
+                        'whole step time -- above frac when passes pipeline.  frac_r4_algorithm / '
+                        'frac_step_r4_algorithm = the SAME elements priced at the round-4 kernel\'s executed '
+                        'flops (2712): a speed comparison with BENCH_r04\'s 0.50, not a utilisation -- an '
+                        'algorithm that needs fewer flops per element lowers frac and raises `value`; '
+                        'frac_r3_algorithm likewise against BENCH_r03 (3656).  What bounds the kernel: '
+                        'tools/fp64_mix_probe.hip (profiles/r05_a_*): the consumers\' instruction mix (13 vector '
+                        '+ 3 matrix instructions per operator and four frequencies) alone, operands from LDS, '
+                        'sustains 18 900 sets/us on this part = 41.6 us for this launch\'s 786 432 sets before '
+                        'the tile generation (23 % of the issue slots) is added; DESIGN.md section 6.1.  '
+                        'SURVEY 8(d)\'s (8 d^2 + 8) flop per element is the Liouville-space form, which this '
+                        'kernel does not execute, and is not used here',
             },
             'roofline_hbm': {
                 'bound': 'hbm', 'achieved': stats['accumulate_bytes']/(acc_ms*1e-3)/1e9,

@@ -20,6 +20,7 @@ FFK_EINVAL = -1
 FFK_EHIP = -2
 FFK_ENOMEM = -3
 FFK_ENOCONV = -4
+FFK_EKERNEL = -5
 
 WANT_NOISE_OPERATORS = 0x1
 FF_FIDELITY = 0
@@ -33,6 +34,11 @@ _ip = POINTER(c_int32)
 
 class FFKError(RuntimeError):
     """A HIP runtime failure inside libffk."""
+
+
+class FFKKernelFault(FFKError):
+    """A kernel reported an internal fault (``FFK_EKERNEL``): a bounded wait between the wavefronts
+    of the d = 4 accumulate kernel ran out and the launch's results are invalid."""
 
 
 class ffk_stats(ctypes.Structure):
@@ -192,6 +198,7 @@ SIGNATURES = {
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
     'ffk_eigensolver_status_dev': (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p, c_void_p]),
+    'ffk_kernel_fault_status': (c_int, [POINTER(c_int32), c_int]),
     'ffk_resident_create': (c_int, [POINTER(c_void_p)]),
     'ffk_resident_destroy': (c_int, [c_void_p]),
     'ffk_resident_release_pools': (c_int, []),
@@ -295,7 +302,20 @@ def check(status):
         raise MemoryError(msg)
     if status == FFK_ENOCONV:
         raise np.linalg.LinAlgError(msg)
+    if status == FFK_EKERNEL:
+        raise FFKKernelFault(msg)
     raise FFKError(msg)
+
+
+def check_kernel_fault(clear=True):
+    """For callers of the ``_dev`` flavour, AFTER they synchronised their stream: raise
+    :class:`FFKKernelFault` if a kernel stored a code in the library's sticky fault word since it was
+    last cleared (include/ffk.h: ``ffk_kernel_fault_status``)."""
+    word = c_int32(0)
+    check(load().ffk_kernel_fault_status(ctypes.byref(word), 1 if clear else 0))
+    if word.value:
+        raise FFKKernelFault(f'a flag wait inside the d = 4 accumulate kernel ran out (code {word.value}): '
+                             'the results of the launches since the last check are invalid')
 
 
 def ptr(arr):

@@ -44,6 +44,9 @@ constexpr int kGsplitMaxNW = 4;
 bool g_use_gsplit = true;
 bool g_use_wave_kernel = false;   // tuning/testing: one-wave-per-block variant for d <= 4
 int g_mfma_policy = 0;            // 0: matrix-core kernel for d >= 12, 1: never, 2: also d = 8
+// d = 4: 0 = ctrl_pc.hip (vector ALU only, round 4), 1 = ctrl_pq.hip (second product on the matrix cores,
+// round 5: the default; FFK_D4_KERNEL=0 / ffk_set_accumulate_variant(5) select the round-4 kernel for A/B runs)
+int g_d4_kernel = std::getenv("FFK_D4_KERNEL") ? std::atoi(std::getenv("FFK_D4_KERNEL")) : 1;
 
 // MR = integral rows generated per LDS stage.  MR == D (one stage per segment, diagonal computed
 // once, optionally double-buffered) whenever the D*D*64 tile fits the 160 KiB LDS; MR < D splits
@@ -763,11 +766,13 @@ namespace {
 void set_use_wave_kernel(bool on) { g_use_wave_kernel = on; }
 void set_use_gsplit(bool on) { g_use_gsplit = on; }
 void set_mfma_policy(int policy) { g_mfma_policy = policy; }
+void set_d4_kernel(int which) { g_d4_kernel = which; }
 
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks) {
     AccumGeometry geo;
     geo.gsplit = 1;
     geo.pc = false;
+    geo.pq = false;
     geo.pcw = false;
     geo.generic = false;
     if (generic_dimension(d)) {
@@ -800,11 +805,12 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         const int nc = pc_accumulate_ops_per_block(A);
         geo.pc = true;
         geo.wave_kernel = false;
-        geo.nwaves = (nc + 1)*pc_accumulate_subchunks();
+        geo.pq = g_d4_kernel == 1;
+        geo.nwaves = geo.pq ? pq_accumulate_waves(nc) : (nc + 1)*pc_accumulate_subchunks();
         geo.task_groups = (A + nc - 1)/nc;
         geo.na_blk = nc;
         geo.nbuf = 2;
-        geo.lds_bytes = pc_accumulate_lds_bytes(d, nc);
+        geo.lds_bytes = geo.pq ? pq_accumulate_lds_bytes(nc) : pc_accumulate_lds_bytes(d, nc);
         const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups;
         int chunks = forced_chunks;
         if (chunks <= 0) {
@@ -996,6 +1002,9 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
     if (geo.generic)
         return launch_accumulate_generic(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
                                          stream);
+    if (geo.pc && geo.pq)
+        return launch_accumulate_pq(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
+                                    geo.chunk_len, Ypart, stream);
     if (geo.pc)
         return launch_accumulate_pc(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
                                     geo.chunk_len, Ypart, stream);

@@ -53,7 +53,25 @@ namespace ffk {
 namespace {
 
 constexpr int kPcSub = 4;               // sub-chunks per block: 4 x (1 + 3) = 16 waves = 4 per SIMD
-constexpr int kPcSpinLimit = 1 << 21;   // bound of every flag wait: a stuck wait ends (results garbage)
+// Bound of every flag wait.  A wait that runs out is a FAULT, not a result: the wavefront stores a code
+// in the library's sticky fault word (mapped host memory, ffk_internal.h::kernel_fault_word; every host
+// entry point reads it after its synchronisation and returns FFK_EKERNEL, `_dev` callers ask
+// ffk_kernel_fault_status), stops waiting for the rest of the launch and runs to the end so that the
+// grid drains.  -DFFK_PC_SPIN_LIMIT=n -DFFK_PC_FAULT_INJECT: the test build whose producers stop
+// publishing after their second tile (tests/test_gpu_parity.py::test_flag_wait_timeout_is_an_error).
+#ifndef FFK_PC_SPIN_LIMIT
+#define FFK_PC_SPIN_LIMIT (1 << 21)
+#endif
+constexpr int kPcSpinLimit = FFK_PC_SPIN_LIMIT;
+// (the word's address sits in a device global, read on the fault path only: as a kernel argument it cost
+// two scalar registers that the consumers' loop spills -- 111 -> 114 VGPRs, past the 112 at which a
+// second pass's small kernels still fit beside this one)
+__device__ int* g_pc_fault_word = nullptr;
+__device__ __noinline__ void pc_report_fault(int code) {
+    int* fault = g_pc_fault_word;
+    if (fault != nullptr && (threadIdx.x & 63) == 0)
+        __hip_atomic_store(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 #ifdef FFK_PC_CLOCK   /* tuning build: per-wavefront timeline of the d = 4 kernel (tools/trace_pc.py) */
 // per wavefront kPcTraceLen words: [0] HW_ID | XCC_ID << 32, [1] role (0 producer, 1.. consumer),
@@ -173,6 +191,7 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
     const int g0 = blockIdx.z*chunk_len + sub*sub_len;
     const int g1 = min(min(G, static_cast<int>(blockIdx.z + 1)*chunk_len), g0 + sub_len);
     const int n_it = max(0, g1 - g0);                 // tiles of this sub-chunk
+    int spin_limit = kPcSpinLimit;                    // 0 after a wait of this wavefront has run out
 #ifdef FFK_PC_CLOCK
     unsigned long long* pc_tr = nullptr;
     {
@@ -294,18 +313,26 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
                 const int nb = (it + 1) & 1;
                 const Staged t = load_ops(g + 1);
                 if (it > 0) {
-                    for (int spin = 0; spin < kPcSpinLimit; ++spin) {
+                    int spin = 0;
+                    for (; spin < spin_limit; ++spin) {
                         int dn = lds_peek(my_done);
                         if (n_alpha > 1) dn = min(dn, lds_peek(my_done + 1));
                         if (n_alpha > 2) dn = min(dn, lds_peek(my_done + 2));
                         if (dn >= it) break;
                         __builtin_amdgcn_s_sleep(2);
                     }
+                    if (spin == spin_limit && spin_limit != 0) {
+                        pc_report_fault(kFaultPcProducerWait);
+                        spin_limit = 0;
+                    }
                     asm volatile("" ::: "memory");
                 }
                 FFK_PC_STEP_TOP(it);
                 generate(ldsd + nb*BUFD, g + 1, om, 0, 1, true);
                 fold_ops(ldsd + nb*BUFD, t);
+#ifdef FFK_PC_FAULT_INJECT
+                if (it < 1)
+#endif
                 lds_publish(my_ready, it + 2, lane);
                 FFK_PC_STEP_DONE(it);
             }
@@ -352,13 +379,18 @@ __global__ __launch_bounds__((NC + 1)*kPcSub*64, kPcSub) void ctrl_accumulate_pc
             for (int it = 0; it < n_it; ++it) {
                 // tile `it` published?  (usually yes: the producer works one tile ahead)
                 int lead = 0;
-                for (int spin = 0; spin < kPcSpinLimit; ++spin) {
+                int spin = 0;
+                for (; spin < spin_limit; ++spin) {
                     const int r0 = lds_peek(flags), r1 = lds_peek(flags + 1), r2 = lds_peek(flags + 2),
                               r3 = lds_peek(flags + 3);
                     const int mine = sub == 0 ? r0 : sub == 1 ? r1 : sub == 2 ? r2 : r3;
                     lead = max(max(r0, r1), max(r2, r3)) - (it + 1);
                     if (mine >= it + 1) break;
                     __builtin_amdgcn_s_sleep(1);
+                }
+                if (spin == spin_limit && spin_limit != 0) {
+                    pc_report_fault(kFaultPcConsumerWait);
+                    spin_limit = 0;
                 }
                 asm volatile("" ::: "memory");
                 // tiles the most advanced sub-chunk is ahead of this one -> issue priority
@@ -451,6 +483,7 @@ template <int D, int NC>
 hipError_t launch_pc(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                      int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
     const int lds = pc_accumulate_lds_bytes(D, NC);
+    (void)kernel_fault_word();
     auto kern = ctrl_accumulate_pc_kernel<D, NC>;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -462,6 +495,11 @@ hipError_t launch_pc(const double* omega, int W, const double* segtab, const cpl
 }
 
 }  // namespace
+
+// called once, from kernel_fault_word(): the d = 4 kernel finds the word through a device global
+hipError_t pc_bind_fault_word(int* device_pointer) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pc_fault_word), &device_pointer, sizeof device_pointer);
+}
 
 bool pc_accumulate_supported(int d, int A) { return d == 4 && A >= 1; }
 int pc_accumulate_ops_per_block(int A) { return A >= 3 ? 3 : A; }

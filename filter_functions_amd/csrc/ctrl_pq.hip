@@ -1,0 +1,486 @@
+// ctrl_pq.hip -- K3q: the control-matrix accumulation for d = 4 with the second product on the matrix
+// cores (round 5).  Same mathematics, inputs and output layout as ctrl_pc.hip:
+//     Y_a(w) = sum_g T_g^dag [ Bbar_a o E_g(w) ] T_g,   E = psi e^{ib} q,  q = 2 sin(a + b)/x REAL,
+//     Z[m][j] = sum_n q[m][n] W_a[m][n][j]  (W_a = Bbar_a e^{ib} T folded by the producers),
+//     y = psi Z,   Y[i][j] += sum_m conj(T[m][i]) y[m][j].
+// What changes is who owns what.  In ctrl_pc.hip a lane is a frequency and a consumer wavefront owns
+// (operator, 64 frequencies, a QUARTER of the block's segments): 64 accumulator registers per lane, the
+// block's segments split four ways only to have sixteen wavefronts, a tree reduction at the end, and every
+// multiply-add a v_fma_f64 -- on random operands that stream is power capped at 1.9-2.07 GHz
+// (profiles/r03_d_*, r05_a_*).  Here a consumer owns (operator, SIXTEEN frequencies, ALL segments of the
+// block) and a lane is (row m, frequency f of a set of four, column j) -- the B-operand layout of
+// v_mfma_f64_4x4x4_4b with one frequency per 4x4x4 block:
+//   * the first product and psi Z stay on the vector ALU in that layout (12 instructions per set of four
+//     frequencies, all 64 lanes busy, W_a[m][.][j] in 16 registers for the whole segment): y lands where
+//     the matrix instruction wants its B operand, nothing moves between the two products;
+//   * the second product is THREE matrix instructions per set (Gauss' three real products for a complex
+//     one, on c = psi conj(T) and Z: P1 = cr^T zr, P2 = ci^T zi, P3 = (cr + ci)^T (zr + zi); Re Y = P1 - P2,
+//     Im Y = P3 - P1 - P2; P1..P3 are linear, so they are summed over the segments and combined once):
+//     16 instead of 28 instruction slots of 4 cycles per frequency set... 13 vector + 3 matrix
+//     instructions = 100 cycles against 112, on an instruction mix that holds 2.33 GHz
+//     (tools/fp64_mix_probe.hip, profiles/r05_a_*: +19 % sets per microsecond than the vector-only mix);
+//   * twelve accumulator registers per lane instead of 64: no segment split inside the block, no tree
+//     reduction, ~80 VGPRs.
+// Four producer wavefronts (one per SIMD) generate the tiles of segments p, p + 4, ... into a ring of
+// eight slots; eight consumers (all operators, eight frequencies = two sets of four each) walk every tile.
+// Flags in LDS as in ctrl_pc.hip: ready[slot] written by the slot's producer, done[slot] counted up by
+// the consumers with ds_add; every wait is bounded and a wait that runs out is a reported fault
+// (ffk_internal.h::kernel_fault_word).
+// Replaces, for this kernel: reference hot loop numeric.py:846-869 / :596-609.
+#include <algorithm>
+#include <cstdlib>
+
+#include "ffk_internal.h"
+#include "ctrl_pq_consumer.inc"   // generated: tools/gen_pq_consumer.py
+
+namespace ffk {
+namespace {
+
+constexpr int kPqProducers = 4;   // wavefronts 0..3, one per SIMD
+constexpr int kPqSets = 2;        // a consumer owns two sets of four of the block's 64 frequencies, all operators
+constexpr int kPqConsumers = 16/kPqSets;   // wavefronts 4..11: two per SIMD
+constexpr int kPqRing = 8;        // tile slots: two per producer
+#ifndef FFK_PC_SPIN_LIMIT
+#define FFK_PC_SPIN_LIMIT (1 << 21)
+#endif
+constexpr int kPqSpinLimit = FFK_PC_SPIN_LIMIT;
+
+__device__ int* g_pq_fault_word = nullptr;
+__device__ __forceinline__ void pq_report_fault(int code) {
+    int* fault = g_pq_fault_word;
+    if (fault != nullptr && (threadIdx.x & 63) == 0)
+        __hip_atomic_store(fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+#ifdef FFK_PQ_CLOCK   /* tuning build: s_memtime stamps of block (0, 0, 0), tools/trace_pq.py */
+constexpr int kPqTraceTiles = 64, kPqTraceStamps = 4, kPqTraceWaves = 16;
+__device__ unsigned long long g_pq_trace[kPqTraceWaves*(2 + kPqTraceTiles*kPqTraceStamps)];
+#define FFK_PQ_STAMP(it, k)                                                                          \
+    do {                                                                                              \
+        if (pq_tr != nullptr && (it) < kPqTraceTiles) pq_tr[2 + (it)*kPqTraceStamps + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define FFK_PQ_STAMP(it, k)
+#endif
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) int lds_int_t;
+
+// ---- one tile slot, in doubles ----------------------------------------------------------------------
+//   [0, 1024)      q: two planes h (columns n = 2h, 2h + 1), per plane [frequency 0..63][4 slots of
+//                  (q[m][2h], q[m][2h+1])], row m of frequency w in slot (m ^ (w >> 2)) & 3: the
+//                  producer's lanes (= frequencies, 64 bytes apart) store to all bank groups, a
+//                  consumer's set of four frequencies reads 256 contiguous bytes
+//   [1024, 1152)   psi[frequency] (re, im)
+//   [1152, ..)     W_a[n][m][j] complex, NC x 64: the consumer lane (m, ., j) reads column n with its
+//                  n-th 16-byte read, every read 256 contiguous bytes
+//   then           (Tr, Ti)[16], index m*4 + i, 16 bytes each: the A operands before psi (same lane offset as W)
+// behind the ring: one private copy of the current segment's table row per producer, the flags
+constexpr int kPqQ = 0, kPqPsi = 1024, kPqW = 1152;
+constexpr int kPqRow = seg_stride(4);             // 72 doubles
+__host__ __device__ constexpr int pq_tile_doubles(int nc) { return kPqW + nc*128 + 32; }
+__host__ __device__ constexpr int pq_lds_bytes_for(int nc) {
+    return (kPqRing*pq_tile_doubles(nc) + kPqProducers*kPqRow)*8 + 3*kPqRing*4;
+}
+
+__device__ __forceinline__ int lds_peek(const int* flag) {
+    return __builtin_amdgcn_readfirstlane(*(const volatile lds_int_t*)(flag));
+}
+
+template <int NC>
+__global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accumulate_pq_kernel(
+    const double* __restrict__ omega, int W, const double* __restrict__ segtab,
+    const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
+    constexpr int D = 4, DD = 16, S = kPqRow, TILE = pq_tile_doubles(NC);
+    constexpr int TOP = kPqW + NC*128;                  // the A operands of a slot
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double* ring = reinterpret_cast<double*>(lds_raw);
+    double* rows = ring + kPqRing*TILE;
+    int* ready = reinterpret_cast<int*>(rows + kPqProducers*S);
+    int* done = ready + kPqRing;
+    int* progress = done + kPqRing;                    // per consumer: the tile it will take next
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int alpha0 = blockIdx.y*NC;
+    const int n_alpha = min(NC, A - alpha0);
+    const int g0 = blockIdx.z*chunk_len;
+    const int g1 = min(G, g0 + chunk_len);
+    const int n_it = max(0, g1 - g0);                  // tiles of this block
+    int spin_limit = kPqSpinLimit;                     // 0 after a wait of this wavefront has run out
+
+    if (threadIdx.x < 3*kPqRing) *(volatile lds_int_t*)(ready + threadIdx.x) = 0;
+    __syncthreads();
+#ifdef FFK_PQ_CLOCK
+    unsigned long long* pq_tr = nullptr;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && wave < kPqTraceWaves) {
+        pq_tr = g_pq_trace + wave*(2 + kPqTraceTiles*kPqTraceStamps);
+        pq_tr[0] = __builtin_amdgcn_s_memtime();
+        pq_tr[1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+
+    if (wave < kPqProducers) {
+        // ---- producer p: tiles p, p + 4, ... -------------------------------------------------------
+        // The operands of tile it + 4 (one element of [T | Bbar_a] and two doubles of the table row per
+        // lane) are requested before tile it is worked on and parked in this producer's LDS row at the top
+        // of their own iteration: every record of the row is then one broadcast ds_read away.  (Through
+        // scalar loads the 41 doubles of a row do not fit the SGPR file at once; the compiler fetched them
+        // in ten batches with a full wait after each -- 3.1 us per tile, profiles/r05_b_*.)
+        __builtin_amdgcn_s_setprio(3);
+        const int iw = blockIdx.x*64 + lane;
+        const double om = omega[iw < W ? iw : W - 1];
+        const int n_ops = (1 + n_alpha)*DD;            // <= 64: one staged element per lane
+        double* row = rows + wave*S;
+        struct Staged {
+            cplx o;            // lane l: element l of [T | Bbar_0 | Bbar_1 ..] of the segment
+            double r0, r1;     // doubles l and (l < 8) 64 + l of the table row
+        };
+        auto request = [&](int it) __attribute__((always_inline)) -> Staged {
+            const int g = g0 + it;
+            const cplx* src = ops + static_cast<size_t>(g)*(1 + A)*DD;
+            const double* st = segtab + static_cast<size_t>(g)*S;
+            Staged t;
+            t.o = lane < n_ops ? src[lane < DD ? lane : lane + alpha0*DD] : cplx{0.0, 0.0};
+            t.r0 = st[lane];
+            t.r1 = lane < S - 64 ? st[64 + lane] : 0.0;
+            return t;
+        };
+        Staged cur = {};
+        if (wave < n_it) cur = request(wave);
+        for (int it = wave; it < n_it; it += kPqProducers) {
+#if defined(FFK_PQ_ABLATE) && (FFK_PQ_ABLATE == 1 || FFK_PQ_ABLATE >= 3)   /* tuning: only the first round of tiles is generated */
+            if (it >= kPqRing) {
+                if (lane == 0) *(volatile lds_int_t*)(ready + (it & (kPqRing - 1))) = it + 1;
+                continue;
+            }
+#endif
+            const int slot = it & (kPqRing - 1);
+            const int gen = it/kPqRing;
+            double* buf = ring + slot*TILE;
+            FFK_PQ_STAMP(it, 0);
+            row[lane] = cur.r0;
+            if (lane < S - 64) row[64 + lane] = cur.r1;
+            const cplx o = cur.o;
+            if (it + kPqProducers < n_it) cur = request(it + kPqProducers);
+            // The records of the row are requested in two batches, each all at once (the compiler otherwise
+            // fetches them in pairs with a full LDS round trip between the pairs; all 13 at once take 104 registers).
+            const double* st = row;
+            const double2_t sbcb = *reinterpret_cast<const double2_t*>(st + seg_rec(lane >> 2) + 1);
+            const double2_t head = *reinterpret_cast<const double2_t*>(st);          // dt_g, t_g
+            const double sb = sbcb.x, cb = sbcb.y;
+            // the tile: q of the 13 distinct entries (all diagonal entries coincide), psi
+            const double dtg = head.x;
+            cplx ph;
+            sincos_pi<false>(om*head.y, &ph.im, &ph.re);
+            double sa, ca;
+            sincos_pi<false>(0.5*(om*dtg), &sa, &ca);
+            const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
+            double q[DD];
+            auto batch = [&](int e0, int e1) __attribute__((always_inline)) {
+                double4_t rec[DD];
+#pragma unroll
+                for (int e = 0; e < DD; ++e) {
+                    if (e < e0 || e >= e1 || (e != 0 && e/D == e%D)) continue;
+                    rec[e] = *reinterpret_cast<const double4_t*>(st + seg_rec(e));
+                }
+                asm volatile("" ::: "memory");
+                unsigned near = 0u;
+#pragma unroll
+                for (int e = 0; e < DD; ++e) {
+                    if (e < e0 || e >= e1 || (e != 0 && e/D == e%D)) continue;
+                    const double x = om + rec[e].x;
+                    q[e] = fma(pf.sa2, rec[e].z, pf.ca2*rec[e].y)*rcp_fast(x);
+                    near |= (fabs(x) < pf.thr ? 1u : 0u) << e;
+                }
+                if (near != 0u) {
+#pragma unroll
+                    for (int e = 0; e < DD; ++e) {
+                        if (e < e0 || e >= e1 || (e != 0 && e/D == e%D)) continue;
+                        if ((near >> e) & 1u) q[e] = phased_q(pf, rec[e].x, rec[e].y, rec[e].z);
+                    }
+                }
+            };
+            batch(0, 8);
+            batch(8, 16);
+            q[5] = q[0];
+            q[10] = q[0];
+            q[15] = q[0];
+            FFK_PQ_STAMP(it, 1);
+            // the slot's previous tenant (tile it - 8) has been read by every consumer?
+            if (gen > 0) {
+                int spin = 0;
+                for (; spin < spin_limit; ++spin) {
+                    if (lds_peek(done + slot) >= gen*kPqConsumers) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (spin == spin_limit && spin_limit != 0) {
+                    pq_report_fault(kFaultPcProducerWait);
+                    spin_limit = 0;
+                }
+                asm volatile("" ::: "memory");
+            }
+            FFK_PQ_STAMP(it, 2);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int m = 0; m < D; ++m) {
+                    const double2_t v = {q[m*D + 2*h], q[m*D + 2*h + 1]};
+                    *reinterpret_cast<double2_t*>(buf + kPqQ + h*512 + lane*8 + (((m ^ (lane >> 2)) & 3) << 1)) = v;
+                }
+            {
+                const double2_t v = {pf.pr, pf.pi};
+                *reinterpret_cast<double2_t*>(buf + kPqPsi + lane*2) = v;
+            }
+            // W_a[m][n][j] = Bbar_a[m][n] e^{i b_mn} T[n][j], (m, n, j) = this lane's index
+            {
+                const int src_t = lane & (DD - 1);                          // T[n][j]
+                const cplx tv = {__shfl(o.re, src_t, 64), __shfl(o.im, src_t, 64)};
+                const cplx et = cmul(cplx{cb, sb}, tv);
+                const int wslot = ((lane >> 2) & 3)*16 + (lane >> 4)*4 + (lane & 3);   // [n][m][j]
+#pragma unroll
+                for (int a = 0; a < NC; ++a) {
+                    const int src_b = DD + a*DD + (lane >> 2);              // Bbar_a[m][n]
+                    const cplx bv = {__shfl(o.re, src_b, 64), __shfl(o.im, src_b, 64)};
+                    const cplx w = cmul(bv, et);
+                    const double2_t v = {w.re, w.im};
+                    *reinterpret_cast<double2_t*>(buf + kPqW + a*128 + wslot*2) = v;
+                }
+            }
+            if (lane < DD) {
+                const double2_t v = {o.re, o.im};
+                *reinterpret_cast<double2_t*>(buf + TOP + lane*2) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef FFK_PC_FAULT_INJECT
+            if (it < 2*kPqProducers)
+#endif
+            if (lane == 0) *(volatile lds_int_t*)(ready + slot) = it + 1;
+            FFK_PQ_STAMP(it, 3);
+        }
+        return;
+    }
+
+    // ---- consumer: eight frequencies (two sets of four), all operators, every tile of the block ----------
+    // The flag of a later tile and the progress of the SIMD partner (the other consumer of this SIMD) are
+    // read a tile ahead, beside the tile's operands: in the usual case -- the producers are ahead -- the loop
+    // finds the flag in a register instead of paying an LDS round trip (~600 cycles under load,
+    // profiles/r05_b_*).  The SIMD's arbiter serves the older wavefront first, which lets one consumer run
+    // ahead until the ring stops it and leaves the other to finish alone: whoever is behind its partner
+    // raises its priority (soft lockstep, as in ctrl_pc.hip).
+    const int octant = wave - kPqProducers;            // frequencies 8 octant .. 8 octant + 7 of the block
+    const int m = lane >> 4, f = (lane >> 2) & 3, j = lane & 3;
+    const int me = octant, partner = me ^ 4;
+    int flag_v = 0, partner_v = 0;
+    int prio = 0;
+    auto await = [&](int it) __attribute__((always_inline)) {     // tile `it` published?
+        if (__builtin_amdgcn_readfirstlane(flag_v) < it + 1) {
+            int spin = 0;
+            for (; spin < spin_limit; ++spin) {
+                if (lds_peek(ready + (it & (kPqRing - 1))) >= it + 1) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (spin == spin_limit && spin_limit != 0) {
+                pq_report_fault(kFaultPcConsumerWait);
+                spin_limit = 0;
+            }
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto set_priority = [&](int it) __attribute__((always_inline)) {
+        const int want = __builtin_amdgcn_readfirstlane(partner_v) > it + 1 ? 1 : 0;
+        if (want != prio) {
+            prio = want;
+            if (want) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+    };
+    // this lane's offsets inside a slot, in doubles
+    const int mj = m*4 + j;                                            // W, T: (m, j) = (m, i)
+    const int wf = octant*8 + f;                                       // the lane's frequency of set 0; set 1: + 4
+    const int o_w = kPqW + mj*2;                                       // + a*128 + n*32; T at + NC*128
+    const int o_p = kPqPsi + wf*2;                                     // set 1: + 8
+    const int o_q0 = kPqQ + wf*8 + ((m ^ ((2*octant) & 3)) << 1);      // row m in 16-byte slot m ^ ((w >> 2) & 3)
+    const int o_q1 = (o_q0 ^ 2) + 32;                                  // set 1; plane h = 1: + 512
+    cplx y[NC][kPqSets];                                               // the block's sums, combined
+
+    if constexpr (NC == 3) {
+        // ---- the tile loop as generated assembly (tools/gen_pq_consumer.py has the register map) ---------
+        typedef double double8_t __attribute__((ext_vector_type(8)));
+        double8_t W0v, W1v, W2v;        // v[24:39], v[40:55], v[56:71]: W_a[n] = (re, im), n = 0..3
+        double8_t Qv;                   // v[72:87]: q01, q23, psi, (tr, ti)
+        double8_t A0 = 0.0, A1 = 0.0;   // v[88:103], v[104:119]: P_k of (a, s), index 3 (2 a + s) + k
+        double2_t A2 = 0.0;             // v[120:123]
+        const unsigned ring_b = static_cast<unsigned>(reinterpret_cast<uintptr_t>(ring));
+        const unsigned flags_b = static_cast<unsigned>(reinterpret_cast<uintptr_t>(ready));
+        const unsigned b_w = ring_b + o_w*8, b_p = ring_b + o_p*8, b_q0 = ring_b + o_q0*8, b_q1 = ring_b + o_q1*8;
+        const unsigned a_partner = flags_b + (2*kPqRing + partner)*4, a_prog = flags_b + (2*kPqRing + me)*4;
+        if (n_it > 0) {
+            await(0);
+            asm volatile(FFK_PQ_CONSUMER_PROLOGUE_ASM
+                         : "=&{v[24:39]}"(W0v), "=&{v[40:55]}"(W1v), "=&{v[56:71]}"(W2v), "=&{v[72:87]}"(Qv)
+                         : [a_w] "v"(b_w), [a_p] "v"(b_p), [a_q0] "v"(b_q0)
+                         : "memory");
+        }
+        for (int it = 0; it < n_it; ++it) {
+            FFK_PQ_STAMP(it, 0);
+            const bool last = it + 1 == n_it;
+            // the block requests tile it + 1's operands: its flag (read by the block of tile it - 1) must be up.
+            // (Waiting here holds back nothing the producers need: they wait for tile it - 7 at most.)
+            if (!last) await(it + 1);
+            set_priority(it);
+            const unsigned cur = static_cast<unsigned>((it & (kPqRing - 1))*TILE*8);
+            // (the last tile requests its own slot once more: one asm statement in the loop -- with a second
+            // variant behind a branch the compiler parks the loop-carried operands elsewhere and copies all 100
+            // registers in front of every block)
+            const unsigned nxt = last ? cur : static_cast<unsigned>(((it + 1) & (kPqRing - 1))*TILE*8);
+            const unsigned a_w = b_w + nxt, a_p = b_p + nxt, a_q0 = b_q0 + nxt;
+            const unsigned a_q1 = b_q1 + cur, a_p1 = b_p + cur + 64;
+            const unsigned a_flag = flags_b + ((it + 2) & (kPqRing - 1))*4;
+            const unsigned a_done = flags_b + (kPqRing + (it & (kPqRing - 1)))*4;
+            const int progress_v = it + 1, one = 1;
+            FFK_PQ_STAMP(it, 1);
+#define FFK_PQ_ASM_OPERANDS                                                                                    \
+    : "+{v[24:39]}"(W0v), "+{v[40:55]}"(W1v), "+{v[56:71]}"(W2v), "+{v[72:87]}"(Qv), "+{v[88:103]}"(A0),       \
+      "+{v[104:119]}"(A1), "+{v[120:123]}"(A2), [flag] "=&v"(flag_v), [partner] "=&v"(partner_v)               \
+    : [a_w] "v"(a_w), [a_p] "v"(a_p), [a_q0] "v"(a_q0), [a_q1] "v"(a_q1), [a_p1] "v"(a_p1), [a_flag] "v"(a_flag), \
+      [a_partner] "v"(a_partner), [a_done] "v"(a_done), [a_prog] "v"(a_prog), [progress] "v"(progress_v),     \
+      [one] "v"(one)                                                                                           \
+    : FFK_PQ_CONSUMER_CLOBBERS
+            asm volatile(FFK_PQ_CONSUMER_ASM FFK_PQ_ASM_OPERANDS);
+#undef FFK_PQ_ASM_OPERANDS
+            FFK_PQ_STAMP(it, 2);
+            FFK_PQ_STAMP(it, 3);
+        }
+        // (the compiler does not know that matrix instructions wrote the accumulators: keep the vector
+        // instructions that read them next out of their shadow)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15"
+                     : "+{v[24:39]}"(W0v), "+{v[40:55]}"(W1v), "+{v[56:71]}"(W2v), "+{v[72:87]}"(Qv)
+                     :
+                     : "memory");
+        const double P[18] = {A0[0], A0[1], A0[2], A0[3], A0[4], A0[5], A0[6], A0[7], A1[0], A1[1], A1[2], A1[3],
+                              A1[4], A1[5], A1[6], A1[7], A2[0], A2[1]};
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+#pragma unroll
+            for (int s = 0; s < kPqSets; ++s) {
+                const double p1 = P[3*(2*a + s)], p2 = P[3*(2*a + s) + 1], p3 = P[3*(2*a + s) + 2];
+                y[a][s] = cplx{p1 - p2, p3 - (p1 + p2)};
+            }
+    } else {
+        // ---- one or two operators per block: the same arithmetic in C++ (not the headline's path) --------
+        double acc[NC][kPqSets][3];
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+#pragma unroll
+            for (int s = 0; s < kPqSets; ++s) acc[a][s][0] = acc[a][s][1] = acc[a][s][2] = 0.0;
+        for (int it = 0; it < n_it; ++it) {
+            const int slot = it & (kPqRing - 1);
+            await(it);
+            set_priority(it);
+            const double* buf = ring + slot*TILE;
+            const double2_t t = *reinterpret_cast<const double2_t*>(buf + o_w + NC*128);
+            double2_t w[NC][4];
+#pragma unroll
+            for (int a = 0; a < NC; ++a)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) w[a][n] = *reinterpret_cast<const double2_t*>(buf + o_w + a*128 + n*32);
+            flag_v = *(const volatile lds_int_t*)(ready + ((it + 1) & (kPqRing - 1)));
+            partner_v = *(const volatile lds_int_t*)(progress + partner);
+#pragma unroll
+            for (int s = 0; s < kPqSets; ++s) {
+                const int oq = s == 0 ? o_q0 : o_q1;
+                const double2_t q01 = *reinterpret_cast<const double2_t*>(buf + oq);
+                const double2_t q23 = *reinterpret_cast<const double2_t*>(buf + oq + 512);
+                const double2_t psi = *reinterpret_cast<const double2_t*>(buf + o_p + s*8);
+                // c = psi conj(T[m][i]) = (pr tr + pi ti) + i (pi tr - pr ti)
+                const double cr = fma(psi.x, t.x, psi.y*t.y), ci = fma(-psi.x, t.y, psi.y*t.x);
+                const double cs = cr + ci;
+#pragma unroll
+                for (int a = 0; a < NC; ++a) {
+                    double zr = q01.x*w[a][0].x, zi = q01.x*w[a][0].y;
+                    zr = fma(q01.y, w[a][1].x, zr);
+                    zi = fma(q01.y, w[a][1].y, zi);
+                    zr = fma(q23.x, w[a][2].x, zr);
+                    zi = fma(q23.x, w[a][2].y, zi);
+                    zr = fma(q23.y, w[a][3].x, zr);
+                    zi = fma(q23.y, w[a][3].y, zi);
+                    const double zs = zr + zi;
+                    acc[a][s][0] = __builtin_amdgcn_mfma_f64_4x4x4f64(cr, zr, acc[a][s][0], 0, 0, 0);
+                    acc[a][s][1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ci, zi, acc[a][s][1], 0, 0, 0);
+                    acc[a][s][2] = __builtin_amdgcn_mfma_f64_4x4x4f64(cs, zs, acc[a][s][2], 0, 0, 0);
+                }
+            }
+            // done with the slot (LDS operations of a wavefront execute in order: no wait needed)
+            asm volatile("" ::: "memory");
+            if (lane == 0) {
+                *(volatile lds_int_t*)(progress + me) = it + 1;
+                __hip_atomic_fetch_add(done + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+#pragma unroll
+            for (int s = 0; s < kPqSets; ++s)
+                y[a][s] = cplx{acc[a][s][0] - acc[a][s][1], acc[a][s][2] - (acc[a][s][0] + acc[a][s][1])};
+    }
+    // D[i = lane >> 4][column lane & 15]: Y_f[i][j] of frequency f = (lane >> 2) & 3 of the set
+#pragma unroll
+    for (int a = 0; a < NC; ++a) {
+        const int alpha = alpha0 + a;
+        if (alpha >= A) break;
+        cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD + mj)*W;
+#pragma unroll
+        for (int s = 0; s < kPqSets; ++s) {
+            const int iw = blockIdx.x*64 + wf + s*4;
+            if (iw < W) out[iw] = y[a][s];
+        }
+    }
+}
+
+template <int NC>
+hipError_t launch_pq(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
+                     int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
+    const int lds = pq_lds_bytes_for(NC);
+    (void)kernel_fault_word();
+    auto kern = ctrl_accumulate_pq_kernel<NC>;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err != hipSuccess) return err;
+    const dim3 grid((W + 63)/64, (A + NC - 1)/NC, chunks);
+    hipLaunchKernelGGL(kern, grid, dim3((kPqProducers + kPqConsumers)*64), lds, stream, omega, W, segtab,
+                       ops, G, A, chunk_len, Ypart);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t pq_bind_fault_word(int* device_pointer) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_pq_fault_word), &device_pointer, sizeof device_pointer);
+}
+int pq_accumulate_lds_bytes(int nc) { return pq_lds_bytes_for(nc); }
+int pq_accumulate_waves(int) { return kPqProducers + kPqConsumers; }
+int pq_accumulate_slabs_per_block() { return 1; }
+
+hipError_t launch_accumulate_pq(const double* omega, int W, const double* segtab, const cplx* ops,
+                                int G, int d, int A, int nc, int chunks, int chunk_len, cplx* Ypart,
+                                hipStream_t stream) {
+    if (d != 4) return hipErrorInvalidValue;
+    switch (nc) {
+        case 1: return launch_pq<1>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
+        case 2: return launch_pq<2>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
+        case 3: return launch_pq<3>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ffk
+
+#ifdef FFK_PQ_CLOCK
+// (tuning build only, not in include/ffk.h) the last launch's stamps of block (0, 0, 0)
+extern "C" int ffk_debug_pq_trace(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ffk::g_pq_trace), sizeof(ffk::g_pq_trace)) != hipSuccess;
+}
+extern "C" int ffk_debug_pq_trace_words(void) { return static_cast<int>(sizeof(ffk::g_pq_trace)/8); }
+#endif

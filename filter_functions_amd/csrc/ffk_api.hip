@@ -26,6 +26,58 @@ int fail(int code, const char* fmt, ...) {
     g_error = buf;
     return code;
 }
+
+// ---- sticky fault word of the kernels that wait on flags (ctrl_pc.hip, ctrl_pq.hip) ------------
+// One int in mapped pinned host memory per process: a kernel whose bounded flag wait runs out stores
+// a code there (its results are garbage from then on), the host reads it with a plain load after the
+// synchronisation it does anyway -- no copy, no extra launch; nothing is written on the good path.
+namespace {
+std::once_flag g_fault_once;
+int* g_fault_host = nullptr;
+int* g_fault_dev = nullptr;
+}  // namespace
+}  // namespace ffk_api
+namespace ffk {
+int* kernel_fault_word() {
+    std::call_once(ffk_api::g_fault_once, [] {
+        void* h = nullptr;
+#if defined(FFK_HOST_SANITIZE)
+        if (hipHostMalloc(&h, 64, 0) != hipSuccess) return;
+        ffk_api::g_fault_dev = static_cast<int*>(h);
+#else
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return;
+        void* dptr = nullptr;
+        if (hipHostGetDevicePointer(&dptr, h, 0) != hipSuccess) {
+            (void)hipHostFree(h);
+            return;
+        }
+        ffk_api::g_fault_dev = static_cast<int*>(dptr);
+#endif
+        *static_cast<volatile int*>(h) = 0;
+        ffk_api::g_fault_host = static_cast<int*>(h);
+#if !defined(FFK_HOST_SANITIZE)
+        (void)pc_bind_fault_word(ffk_api::g_fault_dev);
+        (void)pq_bind_fault_word(ffk_api::g_fault_dev);
+#endif
+    });
+    return ffk_api::g_fault_dev;
+}
+}  // namespace ffk
+namespace ffk_api {
+int kernel_fault_peek(bool clear) {
+    if (!g_fault_host) return 0;
+    const int w = *static_cast<volatile int*>(g_fault_host);
+    if (w != 0 && clear) *static_cast<volatile int*>(g_fault_host) = 0;
+    return w;
+}
+int kernel_fault_status() {
+    const int w = kernel_fault_peek(true);
+    if (w == 0) return FFK_OK;
+    return fail(FFK_EKERNEL,
+                "a flag wait inside the d = 4 accumulate kernel ran out (code %d): the launch's results are "
+                "invalid", w);
+}
+
 int arena_reserve(size_t bytes, void** out) {
     int dev = 0;
     FFK_HIP(hipGetDevice(&dev));
@@ -70,8 +122,18 @@ double accumulate_flops(int W, int A, int G, int d) {
     // z = psi zz: 2 mul + 2 fma, Y: 16 fma) = 832; per group of <= 3 operators the tile: 13 entries x
     // 10 (x, addition theorem 3, reciprocal 5, product 1) + 62 (two sincos and psi) + 6 (e^{ib} T of
     // the fold, one element per lane = one per frequency) and 6 per operator (Bbar times that).
-    if (d == 4 && ffk::pc_accumulate_supported(d, A))
+    if (d == 4 && ffk::pc_accumulate_supported(d, A)) {
+        // ctrl_pq.hip (round 5; the default): per operator the first product 16 x (2 mul + 6 fma) = 224,
+        // zr + zi 16, the second product as THREE real 4 x 4 x 4 matrix products (Gauss) 3 x 128 = 384, the fold
+        // 6 = 630 -- and blocks of nc = min(3, A) operators execute nc of them whether or not the last block is
+        // full; per block the tile 13 x 10 + 62 + 6 = 198 and c = psi conj(T), cr + ci: 16 x 7 = 112.
+        const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);
+        if (geo.pq) {
+            const int nc = A >= 3 ? 3 : A;
+            return (630.0*nc + 310.0)*double((A + nc - 1)/nc)*double(G)*double(W);
+        }
         return (838.0*A + 198.0*((A + 2)/3))*double(G)*double(W);
+    }
     // d = 8 (ctrl_pcr.hip, round 4): per operator the first product real x complex 4 d^3 = 2048, psi P
     // 6 d^2 = 384, the second product complex 8 d^3 = 4096, the fold (one (m, n) per lane = per
     // frequency) 9 complex products = 54; per group of <= 3 operators the tile: 57 entries x 10 + 62.
@@ -238,11 +300,12 @@ int ffk_set_segment_chunks(int chunks) {
     return FFK_OK;
 }
 int ffk_set_accumulate_variant(int variant) {
-    FFK_REQUIRE(variant >= 0 && variant <= 4, "variant must be 0..4");
+    FFK_REQUIRE(variant >= 0 && variant <= 6, "variant must be 0..6");
     ++g_knob_epoch;
     ffk::set_use_wave_kernel(variant == 1);
     ffk::set_use_gsplit(variant != 2);
     ffk::set_mfma_policy(variant == 3 ? 1 : (variant == 4 ? 2 : 0));
+    if (variant == 5 || variant == 6) ffk::set_d4_kernel(variant == 6 ? 1 : 0);
     return FFK_OK;
 }
 int ffk_set_accumulate_events(void* start, void* stop) {
@@ -496,7 +559,7 @@ int ffk_control_matrix(const double* eigvals, const double* eigvecs, const doubl
     if (want_B)
         FFK_HIP(hipMemcpyAsync(noise_operators, dB, 16*size_t(A)*dd*W, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipStreamSynchronize(nullptr));
-    return FFK_OK;
+    return kernel_fault_status();
 }
 
 static int intermediates_impl(const double* eigvals, const double* eigvecs,
@@ -592,7 +655,7 @@ static int intermediates_impl(const double* eigvals, const double* eigvecs,
     if (control_matrix_step) FFK_HIP(d2h(control_matrix_step, dstep, 16*size_t(G)*A*N*W));
     if (noise_operators_step) FFK_HIP(d2h(noise_operators_step, dnstep, 16*size_t(G)*W*A*dd));
     FFK_HIP(hipStreamSynchronize(nullptr));
-    return FFK_OK;
+    return kernel_fault_status();
 }
 
 int ffk_control_matrix_intermediates(const double* eigvals, const double* eigvecs,
@@ -881,6 +944,13 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// fault word of the flag-passing kernels, for callers of the device-pointer flavour
+int ffk_kernel_fault_status(int32_t* word, int clear) {
+    FFK_REQUIRE(word, "word is NULL");
+    *word = kernel_fault_peek(clear != 0);
+    return FFK_OK;
+}
+
 // eigensolver status of a device-resident run
 // ---------------------------------------------------------------------------------------------
 int ffk_eigensolver_status_dev(const void* workspace, size_t workspace_bytes, int G, int d,

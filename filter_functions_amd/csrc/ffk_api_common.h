@@ -63,6 +63,10 @@ extern int g_forced_chunks;
 extern thread_local hipEvent_t g_ev_start, g_ev_stop, g_ev_gate;
 
 int fail(int code, const char* fmt, ...);
+// the kernels' sticky fault word (ffk::kernel_fault_word, ffk_internal.h), read AFTER a synchronisation:
+// FFK_OK, or FFK_EKERNEL with the message set and the word cleared; peek: the raw word
+int kernel_fault_status();
+int kernel_fault_peek(bool clear);
 
 
 #define FFK_HIP(expr)                                                                      \

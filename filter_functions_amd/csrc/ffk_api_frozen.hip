@@ -408,7 +408,7 @@ int ffk_filter_function_derivative(const double* eigvals, const double* eigvecs,
     if (filter_function_derivative)
         FFK_HIP(hipMemcpyAsync(filter_function_derivative, dF, 8*nF, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipStreamSynchronize(nullptr));
-    return FFK_OK;
+    return kernel_fault_status();
 }
 
 int ffk_control_matrix_derivative(const double* eigvals, const double* eigvecs, const double* propagators,
@@ -491,7 +491,7 @@ int ffk_control_matrix_derivative(const double* eigvals, const double* eigvecs, 
                                                   dE, dR, nullptr));
     FFK_HIP(hipMemcpyAsync(control_matrix_derivative, dR, 16*nR, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipStreamSynchronize(nullptr));
-    return FFK_OK;
+    return kernel_fault_status();
 }
 
 int ffk_filter_function_derivative_from_control_matrix(const double* control_matrix,

@@ -411,6 +411,7 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
     const int32_t failed = *reinterpret_cast<const int32_t*>(hp + L.status);
     if (failed != 0)
         return fail(FFK_ENOCONV, "Jacobi eigensolver did not converge for %d segment(s)", int(failed));
+    if (int rc = kernel_fault_status()) return rc;
     *eigvals = reinterpret_cast<double*>(hp + L.D);
     *eigvecs = reinterpret_cast<double*>(hp + L.V);
     *propagators = reinterpret_cast<double*>(hp + L.Q);

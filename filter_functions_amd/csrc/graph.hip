@@ -38,6 +38,7 @@ int ffk_graph_capture_begin(void* stream) {
     }
     // relaxed: calls that other threads (or this one) make outside the captured stream -- PyTorch's
     // allocator, another rank's set-up -- are none of the capture's business
+    (void)ffk::kernel_fault_word();   // the kernels' fault word exists before anything is captured
     hipError_t e = hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeRelaxed);
     return e == hipSuccess ? FFK_OK : graph_fail("hipStreamBeginCapture", e);
 }

@@ -157,7 +157,9 @@ class DevicePipeline:
     def check_status(self, stream=None):
         """Raise ``numpy.linalg.LinAlgError`` if the eigensolver of the last :meth:`launch` flagged
         a segment (no convergence, NaN/Inf in the Hamiltonian): the device-resident counterpart of
-        the exception ``numeric.diagonalize`` raises.  Copies 4 bytes and synchronises the stream."""
+        the exception ``numeric.diagonalize`` raises.  Copies 4 bytes and synchronises the stream.
+        Raises ``_lib.FFKKernelFault`` if a flag wait inside the accumulate kernel ran out in any
+        launch (direct or through a captured graph) since the last check."""
         torch = self.torch
         s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
         if getattr(self, '_n_failed', None) is None:
@@ -167,6 +169,7 @@ class DevicePipeline:
                                                      ctypes.c_void_p(s)))
         check(_lib.load().ffk_stream_synchronize(ctypes.c_void_p(s)))
         failed = int(self._n_failed.cpu().item())
+        _lib.check_kernel_fault()
         if failed:
             raise np.linalg.LinAlgError(
                 f'Jacobi eigensolver did not converge for {failed} segment(s)')

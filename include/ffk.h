@@ -55,6 +55,8 @@ extern "C" {
 #define FFK_EHIP -2     /* a HIP runtime call failed -> RuntimeError                       */
 #define FFK_ENOMEM -3   /* device allocation failed / workspace too small -> MemoryError   */
 #define FFK_ENOCONV -4  /* Jacobi eigensolver did not converge -> numpy.linalg.LinAlgError */
+#define FFK_EKERNEL -5  /* a kernel reported an internal fault (a bounded wait between its       */
+                        /* wavefronts ran out): the launch's results are invalid -> RuntimeError */
 
 /* flags for ffk_control_matrix* */
 #define FFK_WANT_NOISE_OPERATORS 0x1 /* also return B~(w) laid out (W, A, d, d)           */
@@ -480,6 +482,15 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
 int ffk_eigensolver_status_dev(const void* workspace, size_t workspace_bytes, int G, int d,
                                int32_t* n_failed, void* stream);
 
+/* Fault word of the kernels whose wavefronts hand tiles to one another through flags in LDS (the d = 4
+ * accumulation behind ffk_control_matrix*, ffk_pipeline_dev and the resident passes; reference loop
+ * numeric.py:846-869).  Their waits are bounded; a wait that runs out stores a non-zero code in one
+ * process-wide word of mapped host memory and the launch's results are invalid.  The host-pointer
+ * entry points read the word after their own synchronisation and return FFK_EKERNEL; callers of the
+ * `_dev` flavour (also through a captured graph) call this AFTER synchronising the stream: *word = 0
+ * means every launch since the last clearing was sound.  Sticky until read with clear != 0.        */
+int ffk_kernel_fault_status(int32_t* word, int clear);
+
 /* ---- resident evaluation: the user-facing call PulseSequence.get_filter_function(omega)
  *      followed by ff.infidelity(pulse, S, omega) (pulse_sequence.py:691-805, 577-677;
  *      numeric.py:2062-2334) on host arrays with the minimum of PCIe traffic ------------------
@@ -603,7 +614,9 @@ int ffk_set_segment_chunks(int chunks);
  * generated integral through LDS), 1 = one-wave-per-block variant for d <= 4 (kept for tuning;
  * measured slower on MI355X because its 48 accumulators per lane spill into AGPRs),
  * 2 = default kernel without the in-block segment split (tuning), 3 = never use the matrix-core
- * kernel (d >= 12 use it by default), 4 = use the matrix-core kernel wherever it exists (d = 8 too). */
+ * kernel (d >= 12 use it by default), 4 = use the matrix-core kernel wherever it exists (d = 8 too);
+ * 5 / 6 (sticky, A/B runs): d = 4 on the round-4 vector-ALU kernel / on the round-5 kernel with the second
+ * product on the matrix cores (the default).                                                        */
 int ffk_set_accumulate_variant(int variant);
 /* Per-call statistics of the last ffk_control_matrix*_dev launch on this thread:
  * algorithmic FP64 flops of the accumulate kernel, its grid/block geometry, chunks used.   */

@@ -2746,3 +2746,88 @@ def test_resident_results_are_read_only_views():
     ref = ff.infidelity(pulse, S, omega)
     assert rel_err(util.integrate(np.einsum('aaw->aw', G2).real*S, omega)/(2*np.pi*4)/2, ref) < 1e-12
     assert not ff.Basis.ggm(3).flags.writeable or True      # (shared default bases: documented, not enforced here)
+
+
+_FAULT_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, {root!r})
+import workloads as wl
+import filter_functions_amd as ff
+from filter_functions_amd import _lib, numeric
+from filter_functions_amd.device import DevicePipeline
+
+c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**wl.CONFIG2)
+omega = wl.random_pulse_omega(dt, 512)
+basis = ff.Basis.pauli(2)
+seen = []
+
+
+def expect_fault(name, fn):
+    try:
+        fn()
+    except _lib.FFKKernelFault as exc:
+        assert isinstance(exc, RuntimeError) and 'flag wait' in str(exc), exc
+        seen.append(name)
+    else:
+        raise SystemExit(f'{{name}}: no error from a launch whose flag wait ran out')
+    word = _lib.ctypes.c_int32(7)
+    _lib.check(_lib.load().ffk_kernel_fault_status(_lib.ctypes.byref(word), 0))
+    assert word.value == 0, f'{{name}}: the fault word was not cleared by the report'
+
+
+def pulse():
+    return ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
+
+
+# 1. the array call (ffk_control_matrix on host arrays)
+p1 = pulse()
+p1.diagonalize()
+expect_fault('array', lambda: numeric.calculate_control_matrix_from_scratch(
+    p1.eigvals, p1.eigvecs, p1.propagators, omega, basis, p1.n_opers, p1.n_coeffs, p1.dt))
+# 2. the resident pass behind PulseSequence.get_filter_function (twice: the second one is the replayed graph)
+expect_fault('resident', lambda: pulse().get_filter_function(omega))
+expect_fault('resident, second sighting', lambda: pulse().get_filter_function(omega))
+expect_fault('resident, replayed', lambda: pulse().get_filter_function(omega))
+# 3. the device-pointer pass, call by call and 4. through a captured graph
+pipe = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum=1e-3/omega)
+pipe.launch()
+expect_fault('_dev', pipe.check_status)
+graph = pipe.graph()
+_lib.check_kernel_fault()   # (the capture launches nothing: still clean)
+graph.launch(None)
+expect_fault('captured graph', pipe.check_status)
+print('FAULTS SEEN:', ', '.join(seen))
+"""
+
+
+@pytest.mark.gpu
+def test_flag_wait_timeout_is_an_error():
+    """A flag wait of the d = 4 accumulate kernel that runs out is reported, not returned as numbers
+    (VERDICT r4 item 2): a test build of the library whose producers stop publishing tiles
+    (-DFFK_PC_FAULT_INJECT, spin limit 64; built by __graft_entry__.build) must raise FFKKernelFault
+    (a RuntimeError, C status FFK_EKERNEL) from the array call, the resident pass (enqueued and replayed),
+    the device-pointer pass and a captured graph -- and the product build must not.  Reference loop:
+    numeric.py:846-869."""
+    import os
+    import subprocess
+    import sys
+    root = ROOT
+    lib = os.path.join(root, 'build', 'libffk_pcfault.so')
+    assert os.path.exists(lib), 'build/libffk_pcfault.so missing: run __graft_entry__.build()'
+    env = dict(os.environ, FFK_LIBRARY=lib)
+    out = subprocess.run([sys.executable, '-c', _FAULT_SCRIPT.format(root=root)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert 'FAULTS SEEN: array, resident, resident, second sighting, resident, replayed, _dev, captured graph' \
+        in out.stdout, out.stdout
+    # the product build: same calls, no fault, word stays 0
+    from filter_functions_amd import _lib
+    import workloads as wl
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**wl.CONFIG2)
+    omega = wl.random_pulse_omega(dt, 512)
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt,
+                             ff.Basis.pauli(2))
+    pulse.get_filter_function(omega)
+    _lib.check_kernel_fault()

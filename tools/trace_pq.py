@@ -1,0 +1,69 @@
+"""Timeline of one block of the d = 4 matrix-core accumulate kernel (tuning build -DFFK_PQ_CLOCK).
+
+    make -C filter_functions_amd/csrc VARIANT=pqclock VSRCS=ctrl_pq.hip VFLAGS=-DFFK_PQ_CLOCK
+    FFK_D4_KERNEL=1 FFK_LIBRARY=build/libffk_pqclock.so python tools/trace_pq.py
+
+Lane 0 of every wavefront of block (0, 0, 0) stamps s_memtime four times per tile: producers at the top
+of the iteration, when the tile's numbers are computed, when the slot is free, when the tile is published;
+consumers at the loop top, when the tile's flag is seen, when its arithmetic is done, when the slot is
+handed back.  Printed per wavefront: median cycles of each phase and of a whole tile.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+import filter_functions_amd as ff  # noqa: E402
+import workloads as wl  # noqa: E402
+from filter_functions_amd import _lib  # noqa: E402
+from filter_functions_amd.device import DevicePipeline  # noqa: E402
+
+
+def main():
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**wl.CONFIG2)
+    omega = wl.random_pulse_omega(dt, 4096)
+    _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    stream = torch.cuda.current_stream().cuda_stream
+    pipe = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, ff.Basis.pauli(2), omega, spectrum=1e-3/omega)
+    for _ in range(2000):
+        pipe.launch(stream=stream)
+    torch.cuda.synchronize()
+    n = raw.ffk_debug_pq_trace_words()
+    buf = (ctypes.c_ulonglong*n)()
+    assert raw.ffk_debug_pq_trace(buf) == 0
+    tr = np.array(buf, dtype=np.uint64).reshape(16, -1)
+    st = _lib.stats()
+    nw = st['block']//64
+    t0 = int(tr[:nw, 0].min())
+    print(f'block of {nw} wavefronts, grid ({st["grid_x"]}, {st["grid_y"]}, {st["grid_z"]})')
+    for w in range(nw):
+        stamps = tr[w, 2:].reshape(-1, 4).astype(np.int64)
+        used = np.nonzero(stamps[:, 3])[0]
+        if used.size == 0:
+            continue
+        s = stamps[used] - t0
+        role = 'producer' if w < 4 else 'consumer'
+        ph = np.diff(s, axis=1)
+        gap = s[1:, 0] - s[:-1, 3]
+        per = np.diff(s[:, 0])
+        print(f'wave {w:2d} {role}: tiles {used.size:3d}  first top {s[0, 0]:7d}  last end {s[-1, 3]:7d}  '
+              f'phases median {np.median(ph, axis=0).astype(int)}  between tiles {int(np.median(gap)) if gap.size else 0}  '
+              f'tile period median {int(np.median(per)) if per.size else 0}')
+    print('per-tile stamps of wave 4 (consumer), first 12 tiles:')
+    s = tr[4, 2:].reshape(-1, 4).astype(np.int64)
+    for it in np.nonzero(s[:, 3])[0][:12]:
+        print(f'  tile {it:3d}:', (s[it] - t0).tolist())
+    print('per-tile stamps of wave 0 (producer), first 8 tiles:')
+    s = tr[0, 2:].reshape(-1, 4).astype(np.int64)
+    for it in np.nonzero(s[:, 3])[0][:8]:
+        print(f'  tile {it:3d}:', (s[it] - t0).tolist())
+
+
+if __name__ == '__main__':
+    main()
