@@ -316,6 +316,31 @@ def bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream, ra
                       'shape, which fixes the segment chunks' if cfg['A'] >= 6 else None)
 
 
+def bench_config4_full(ff, torch, lib, _lib, DevicePipeline, device, stream):
+    """BASELINE config 4 WHOLE on one GPU: d = 8, 512 segments, 9 noise operators, all 65536 omega
+    (the strong-scaling baseline of `scaling_model`: a measurement, not 8 x one block)."""
+    cfg = wl.CONFIG4
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**cfg)
+    omega = wl.random_pulse_omega(dt, cfg['W'])
+    basis = ff.Basis.pauli(3)
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, basis)
+    pipe = DevicePipeline(pulse.c_opers, pulse.c_coeffs, pulse.n_opers, pulse.n_coeffs, dt, basis,
+                          omega, spectrum=1e-3/omega, device=device)
+    ms, kernel_ms = time_pipeline(pipe, torch, lib, _lib, stream, reps=3, warm_s=0.2)
+    st = _lib.stats()
+    E = cfg['G']*len(omega)*cfg['A']*cfg['d']**2
+    del pipe
+    torch.cuda.empty_cache()
+    return dict(
+        config='4 (whole grid, one GPU)',
+        workload='d=8, 512 segments, 9 noise ops, Pauli basis, seed 43: ALL 65536 omega on one GPU, '
+                 'diagonalize -> infidelity, HBM-resident',
+        ms=ms, elements_per_s=E/(ms*1e-3), dominant_kernel='ffk::ctrl_accumulate (d = 8)',
+        kernel_ms_last_launch=kernel_ms, executed_flops=st['accumulate_flops'],
+        note='kernel_ms_last_launch: the d = 8 path issues two accumulate launches (six operators, then three); '
+             'the events bracket the last one')
+
+
 def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
     """examples/qft.py: d = 16, 13 segments, 18 noise operators, 16384 omega: control matrix ->
     decay amplitudes -> cumulant function -> error transfer matrix."""
@@ -450,16 +475,31 @@ def bench_config3(ff):
     G, W, T = cfg['n_gates'], cfg['W'], len(distinct)
     rule_flops = 102.0*G*W
     rule_bytes = 16.0*W*(T*5 + 4 + 1)
-    kernel_ms, kernel_src = None, None
+    # the rule kernel timed IN THIS RUN: HIP events recorded by the library around its launch, on the stream
+    # it runs on (ffk_set_accumulate_events), over eight more device calls
+    import ctypes
+    from filter_functions_amd import _lib
+    lib = _lib.load()
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    for e in (e0, e1):
+        _lib.check(lib.ffk_event_create(ctypes.byref(e)))
+    rule_kernel = []
+    ms_ev = ctypes.c_float()
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_f_config3_kernel_stats.txt')) as fh:
-            for line in fh:
-                if line.startswith('from_atomic_block_kernel'):
-                    kernel_ms = float(line.split('avg_us=')[1].split()[0])*1e-3
-                    kernel_src = ('committed rocprofv3 --kernel-trace --stats summary of tools/time_config3.py '
-                                  '(profiles/r03_f_config3_kernel_stats.txt); not measured in this run')
-    except (OSError, ValueError, IndexError):
-        pass
+        for _ in range(8):
+            keep = ResidentResult()
+            _lib.check(lib.ffk_set_accumulate_events(e0, e1))
+            numeric.concatenate_sequence_resident(residents, taus, index, distinct[0].basis, which='total',
+                                                  return_filter_function=True, keep=keep)
+            _lib.check(lib.ffk_event_elapsed_ms(e0, e1, ctypes.byref(ms_ev)))
+            rule_kernel.append(ms_ev.value)
+    finally:
+        _lib.check(lib.ffk_set_accumulate_events(None, None))
+        for e in (e0, e1):
+            _lib.check(lib.ffk_event_destroy(e))
+    kernel_ms = float(np.mean(rule_kernel))
+    kernel_src = ('live: HIP events around the rule launch on its stream, mean of 8 calls of this run '
+                  f'(min {min(rule_kernel)*1e3:.1f}, max {max(rule_kernel)*1e3:.1f} us)')
     roof = None
     if kernel_ms:
         t_fp64 = rule_flops/(FP64_PEAK_TFLOPS*1e12)*1e3
@@ -652,11 +692,11 @@ def scaling_model(step_ms_one_gpu, f_block_bytes, configs):
         'headline_weak': rows(lambda n: step_ms_one_gpu, lambda n: f_block_bytes, strong=False),
     }
     for c in configs or []:
-        if c.get('config') == 4 and 'ms' in c:
-            # measured: one of 8 omega blocks of 8192; the accumulate time is linear in the block
-            full = c['ms']*8
+        if c.get('config') == '4 (whole grid, one GPU)' and 'ms' in c:
+            # measured in this run: the whole 65536-omega grid on one GPU
+            full = c['ms']
             model['config4_strong'] = rows(lambda n: full/n, lambda n: 9*9*65536//n*16, strong=True)
-            model['config4_strong']['one_gpu_ms_extrapolated_from_one_block_of_8'] = full
+            model['config4_strong']['one_gpu_ms_measured_whole_grid'] = full
         if c.get('config') == 5 and 'ms' in c:
             # measured whole on one GPU; control matrix + F + decay-amplitude partial integrals shard
             # along omega (all-gather of F: 18 x 18 x 16384/N; all-reduce of 256 x 256 x 18 partial
@@ -951,6 +991,7 @@ def main():
         elif rank == 0:
             configs.append(bench_config3(ff))
             configs.append(bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream)[1])
+            configs.append(bench_config4_full(ff, torch, lib, _lib, DevicePipeline, device, stream))
             configs.append(bench_config5(ff, torch, lib, _lib, DevicePipeline, device, compute_stream))
             configs.append(bench_liouville(ff, torch, lib, _lib, device))
             if args.published_example:     # doc notebook (concatenate_periodic): outside SURVEY section 8

@@ -44,9 +44,6 @@ constexpr int kGsplitMaxNW = 4;
 bool g_use_gsplit = true;
 bool g_use_wave_kernel = false;   // tuning/testing: one-wave-per-block variant for d <= 4
 int g_mfma_policy = 0;            // 0: matrix-core kernel for d >= 12, 1: never, 2: also d = 8
-// d = 4: 0 = ctrl_pc.hip (vector ALU only, round 4), 1 = ctrl_pq.hip (second product on the matrix cores,
-// round 5: the default; FFK_D4_KERNEL=0 / ffk_set_accumulate_variant(5) select the round-4 kernel for A/B runs)
-int g_d4_kernel = std::getenv("FFK_D4_KERNEL") ? std::atoi(std::getenv("FFK_D4_KERNEL")) : 1;
 
 // MR = integral rows generated per LDS stage.  MR == D (one stage per segment, diagonal computed
 // once, optionally double-buffered) whenever the D*D*64 tile fits the 160 KiB LDS; MR < D splits
@@ -297,7 +294,7 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
     // instead of D*JB broadcast ds_read_b128 per row.  At d = 8 (JB = 2) the LDS array is otherwise
     // as busy as the FP64 pipe: 40 ds_read_b128 (4 LDS cycles each, 8 waves per CU) against 160
     // v_fma_f64 (4 cycles each, 2 waves per SIMD) per row -- 1280 cycles both; with the columns in
-    // SGPRs 24 reads remain.  Loaded for segment g + 1 at the end of segment g (ctrl_pc.hip scheme).
+    // SGPRs 24 reads remain.  Loaded for segment g + 1 at the end of segment g (the scheme of the producer/consumer kernels).
     constexpr bool TCOL = FFK_TCOL_SGPR && SHARE && D >= 6 && D*JB <= 16;
     cplx Tcol[TCOL ? D : 1][TCOL ? JB : 1];
     auto load_tcol = [&](int g) {
@@ -396,7 +393,7 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
                 // One copy of each phase in the instruction stream; the two half-steps run them in
                 // the order of this wave's parity.  The generating wave runs at raised issue priority:
                 // its dependent chains (argument reduction -> polynomial -> reciprocal) otherwise lose
-                // every arbitration against the neighbour's independent FMAs (cf. ctrl_pc.hip).
+                // every arbitration against the neighbour's independent FMAs (cf. ctrl_pq.hip).
                 if (g + 1 < g1) phase_a(g + 1, 0, buf ^ 1, r1, buf ^ 1, true, false);
 #pragma nounroll
                 for (int half = 0; half < 2; ++half) {
@@ -766,13 +763,11 @@ namespace {
 void set_use_wave_kernel(bool on) { g_use_wave_kernel = on; }
 void set_use_gsplit(bool on) { g_use_gsplit = on; }
 void set_mfma_policy(int policy) { g_mfma_policy = policy; }
-void set_d4_kernel(int which) { g_d4_kernel = which; }
 
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks) {
     AccumGeometry geo;
     geo.gsplit = 1;
     geo.pc = false;
-    geo.pq = false;
     geo.pcw = false;
     geo.generic = false;
     if (generic_dimension(d)) {
@@ -797,31 +792,28 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         return geo;
     }
     geo.mfma = mfma_accumulate_supported(d) && g_mfma_policy != 1 && (d >= 12 || g_mfma_policy == 2);
-    // d = 4: the producer/consumer kernel (ctrl_pc.hip) is the default -- 3.4 % faster than the
-    // symmetric kernel below at config 2 (101 vs 104.5 us on the same box) and free of register
-    // spills; the tuning variants 1/2 (ffk_set_accumulate_variant) select the symmetric kernel
-    if (g_use_gsplit && !g_use_wave_kernel && pc_accumulate_supported(d, A) && !geo.mfma) {
-        // producer/consumer kernel: 3 sub-chunks x (1 producer + nc consumers) per block
-        const int nc = pc_accumulate_ops_per_block(A);
+    // d = 4: the producer/consumer kernel with the second product on the matrix cores (ctrl_pq.hip); the tuning
+    // variants 1/2 (ffk_set_accumulate_variant) select the symmetric kernel below
+    if (g_use_gsplit && !g_use_wave_kernel && pq_accumulate_supported(d, A) && !geo.mfma) {
+        const int nc = pq_accumulate_ops_per_block(A);
         geo.pc = true;
         geo.wave_kernel = false;
-        geo.pq = g_d4_kernel == 1;
-        geo.nwaves = geo.pq ? pq_accumulate_waves(nc) : (nc + 1)*pc_accumulate_subchunks();
+        geo.nwaves = pq_accumulate_waves(nc);
         geo.task_groups = (A + nc - 1)/nc;
         geo.na_blk = nc;
         geo.nbuf = 2;
-        geo.lds_bytes = geo.pq ? pq_accumulate_lds_bytes(nc) : pc_accumulate_lds_bytes(d, nc);
+        geo.lds_bytes = pq_accumulate_lds_bytes(nc);
         const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups;
         int chunks = forced_chunks;
         if (chunks <= 0) {
+            // one block per CU and round; a block's fixed cost (first tile, last hand-over) is about three tiles
             const long capacity = device_cu_count();
-            const int ns = pc_accumulate_subchunks();
-            const int max_chunks = std::max(1, std::min((G + 4*ns - 1)/(4*ns), 256));
+            const int max_chunks = std::max(1, std::min((G + 15)/16, 256));
             double best = 0.0;
             chunks = 1;
             for (int c = 1; c <= max_chunks; ++c) {
                 const long rounds = (tiles*c + capacity - 1)/capacity;
-                const double cost = static_cast<double>(rounds)*((G + ns*c - 1)/(ns*c) + 2);
+                const double cost = static_cast<double>(rounds)*((G + c - 1)/c + 3);
                 if (c == 1 || cost < best*0.999) {
                     best = cost;
                     chunks = c;
@@ -1002,11 +994,8 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
     if (geo.generic)
         return launch_accumulate_generic(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
                                          stream);
-    if (geo.pc && geo.pq)
-        return launch_accumulate_pq(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
-                                    geo.chunk_len, Ypart, stream);
     if (geo.pc)
-        return launch_accumulate_pc(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
+        return launch_accumulate_pq(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
                                     geo.chunk_len, Ypart, stream);
     if (geo.pcw)
         return launch_accumulate_pcr(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,

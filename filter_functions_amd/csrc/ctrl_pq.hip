@@ -1,32 +1,46 @@
-// ctrl_pq.hip -- K3q: the control-matrix accumulation for d = 4 with the second product on the matrix
-// cores (round 5).  Same mathematics, inputs and output layout as ctrl_pc.hip:
-//     Y_a(w) = sum_g T_g^dag [ Bbar_a o E_g(w) ] T_g,   E = psi e^{ib} q,  q = 2 sin(a + b)/x REAL,
-//     Z[m][j] = sum_n q[m][n] W_a[m][n][j]  (W_a = Bbar_a e^{ib} T folded by the producers),
-//     y = psi Z,   Y[i][j] += sum_m conj(T[m][i]) y[m][j].
-// What changes is who owns what.  In ctrl_pc.hip a lane is a frequency and a consumer wavefront owns
-// (operator, 64 frequencies, a QUARTER of the block's segments): 64 accumulator registers per lane, the
-// block's segments split four ways only to have sixteen wavefronts, a tree reduction at the end, and every
-// multiply-add a v_fma_f64 -- on random operands that stream is power capped at 1.9-2.07 GHz
-// (profiles/r03_d_*, r05_a_*).  Here a consumer owns (operator, SIXTEEN frequencies, ALL segments of the
-// block) and a lane is (row m, frequency f of a set of four, column j) -- the B-operand layout of
-// v_mfma_f64_4x4x4_4b with one frequency per 4x4x4 block:
-//   * the first product and psi Z stay on the vector ALU in that layout (12 instructions per set of four
-//     frequencies, all 64 lanes busy, W_a[m][.][j] in 16 registers for the whole segment): y lands where
-//     the matrix instruction wants its B operand, nothing moves between the two products;
-//   * the second product is THREE matrix instructions per set (Gauss' three real products for a complex
-//     one, on c = psi conj(T) and Z: P1 = cr^T zr, P2 = ci^T zi, P3 = (cr + ci)^T (zr + zi); Re Y = P1 - P2,
-//     Im Y = P3 - P1 - P2; P1..P3 are linear, so they are summed over the segments and combined once):
-//     16 instead of 28 instruction slots of 4 cycles per frequency set... 13 vector + 3 matrix
-//     instructions = 100 cycles against 112, on an instruction mix that holds 2.33 GHz
-//     (tools/fp64_mix_probe.hip, profiles/r05_a_*: +19 % sets per microsecond than the vector-only mix);
-//   * twelve accumulator registers per lane instead of 64: no segment split inside the block, no tree
-//     reduction, ~80 VGPRs.
-// Four producer wavefronts (one per SIMD) generate the tiles of segments p, p + 4, ... into a ring of
-// eight slots; eight consumers (all operators, eight frequencies = two sets of four each) walk every tile.
-// Flags in LDS as in ctrl_pc.hip: ready[slot] written by the slot's producer, done[slot] counted up by
-// the consumers with ds_add; every wait is bounded and a wait that runs out is a reported fault
-// (ffk_internal.h::kernel_fault_word).
-// Replaces, for this kernel: reference hot loop numeric.py:846-869 / :596-609.
+// ctrl_pq.hip -- K3q: the control-matrix accumulation for d = 4 (BASELINE config 2, the headline) with
+// SPECIALISED wavefronts and the second product on the matrix cores (round 5; replaces ctrl_pc.hip).
+//     Y_a(w) = sum_g T_g^dag [ Bbar_a o E_g(w) ] T_g,   E = psi e^{ib} q,  q = 2 sin(a + b)/x REAL   (ffk_math.h)
+//     Z_a[m][j] = sum_n q[m][n] W_a[m][n][j]     W_a = Bbar_a e^{ib} T, frequency independent, folded by the producers
+//     Y_a[i][j] += sum_m c[m][i] Z_a[m][j]       c = psi conj(T): psi is per frequency, T per segment
+// Replaces the reference's hot loop numeric.py:846-869 / :596-609.
+//
+// A block owns 64 frequencies, a chunk of the segments and up to three operators: 12 wavefronts.
+//   * FOUR PRODUCERS (one per SIMD, lane = frequency) generate the tile of segment p, p + 4, ...: the 13 distinct
+//     q, psi, the folded operands W_a and (Tr, Ti) -- into a ring of eight LDS slots.  The table row of the NEXT
+//     tile and its operands are requested a tile ahead and parked in a private LDS row, whose records are then
+//     read in two batches (through scalar loads the row's 41 doubles do not fit the SGPR file: ten batches with
+//     a full wait each, 3.1 us per tile; profiles/r05_b_*).
+//   * EIGHT CONSUMERS (two per SIMD) own eight frequencies each -- two sets of four -- and ALL operators, and
+//     walk every tile.  A lane is (row m, frequency f of the set, column j): the B-operand layout of
+//     v_mfma_f64_4x4x4_4b with ONE FREQUENCY PER 4x4x4 BLOCK.  The first product stays on the vector ALU in that
+//     layout (8 instructions per operator and set, all 64 lanes busy, W_a[m][.][j] in registers for the whole
+//     tile), so Z lands where the matrix instruction wants its B operand: nothing moves between the products.
+//     The second product is THREE matrix instructions (Gauss: P1 = cr^T zr, P2 = ci^T zi, P3 = (cr + ci)^T
+//     (zr + zi); Re Y = P1 - P2, Im Y = P3 - P1 - P2; each linear in the segment's data, so P1..P3 are summed
+//     over the segments and combined once at the end).  psi multiplies the A operand -- one complex product per
+//     lane and set, shared by the operators -- instead of every Z.  Per operator and four frequencies: 9 vector +
+//     3 matrix instructions + 5/3 shared = 90.7 issue cycles against the 112 of the round-4 kernel's 28 v_fma_f64,
+//     on a mix that holds 2.33 GHz where the pure v_fma_f64 stream is power capped at 2.03
+//     (tools/fp64_mix_probe.hip, profiles/r05_a_*).  18 accumulator registers per lane instead of 64: no
+//     segment split inside the block, no tree reduction at the end.
+//   * The consumer's tile is ONE generated asm block (ctrl_pq_consumer.inc, tools/gen_pq_consumer.py): the next
+//     tile's operands are requested from inside the last set, when their registers are dead, and fly during its
+//     matrix instructions and the hand-over; the flag of the tile after that and the SIMD partner's progress
+//     are read a tile ahead; every s_waitcnt carries the exact count of younger LDS operations.  hipcc moved the
+//     last set's vector work behind the requests (168 VGPRs, accumulators spilled in the loop) or serialised
+//     the reads.  At 148 VGPRs three of these wavefronts per SIMD leave room for a wavefront of another pass's
+//     small kernels (56): the two-pass schedule of the bench keeps overlapping.
+//   * Flags in LDS: ready[slot] written by the slot's producer, done[slot] counted up by the consumers with
+//     ds_add, progress[consumer]; the lagging consumer of a SIMD raises its priority (the arbiter serves the
+//     oldest wavefront first and would let one run ahead until the ring stops it: soft lockstep).  Every wait is
+//     bounded; a wait that runs out is a reported FAULT (ffk_internal.h::kernel_fault_word -> FFK_EKERNEL),
+//     the wavefront stops waiting for the rest of the launch and runs to the end so that the grid drains.
+//     -DFFK_PC_SPIN_LIMIT=n -DFFK_PC_FAULT_INJECT: the test build whose producers stop publishing after eight
+//     tiles (tests/test_gpu_parity.py::test_flag_wait_timeout_is_an_error).
+// Same box, bench schedule: round-4 kernel 67.6-68.7 us per step, this one 59.6-59.8 (kernel alone 72.6-73.5 ->
+// 63.2-63.7); the steps in between with their measurements: profiles/r05_b_d4_matrix_core_kernel_steps.txt.
+// One or two operators per block (A < 3) run the same arithmetic through a C++ consumer.
 #include <algorithm>
 #include <cstdlib>
 
@@ -150,7 +164,7 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accu
         Staged cur = {};
         if (wave < n_it) cur = request(wave);
         for (int it = wave; it < n_it; it += kPqProducers) {
-#if defined(FFK_PQ_ABLATE) && (FFK_PQ_ABLATE == 1 || FFK_PQ_ABLATE >= 3)   /* tuning: only the first round of tiles is generated */
+#if defined(FFK_PQ_ABLATE) && FFK_PQ_ABLATE == 1   /* tuning: only the first round of tiles is generated */
             if (it >= kPqRing) {
                 if (lane == 0) *(volatile lds_int_t*)(ready + (it & (kPqRing - 1))) = it + 1;
                 continue;
@@ -268,7 +282,7 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accu
     // finds the flag in a register instead of paying an LDS round trip (~600 cycles under load,
     // profiles/r05_b_*).  The SIMD's arbiter serves the older wavefront first, which lets one consumer run
     // ahead until the ring stops it and leaves the other to finish alone: whoever is behind its partner
-    // raises its priority (soft lockstep, as in ctrl_pc.hip).
+    // raises its priority (soft lockstep).
     const int octant = wave - kPqProducers;            // frequencies 8 octant .. 8 octant + 7 of the block
     const int m = lane >> 4, f = (lane >> 2) & 3, j = lane & 3;
     const int me = octant, partner = me ^ 4;
@@ -461,7 +475,8 @@ hipError_t pq_bind_fault_word(int* device_pointer) {
 }
 int pq_accumulate_lds_bytes(int nc) { return pq_lds_bytes_for(nc); }
 int pq_accumulate_waves(int) { return kPqProducers + kPqConsumers; }
-int pq_accumulate_slabs_per_block() { return 1; }
+bool pq_accumulate_supported(int d, int A) { return d == 4 && A >= 1; }
+int pq_accumulate_ops_per_block(int A) { return A >= 3 ? 3 : A; }
 
 hipError_t launch_accumulate_pq(const double* omega, int W, const double* segtab, const cplx* ops,
                                 int G, int d, int A, int nc, int chunks, int chunk_len, cplx* Ypart,

@@ -27,7 +27,7 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-// ---- sticky fault word of the kernels that wait on flags (ctrl_pc.hip, ctrl_pq.hip) ------------
+// ---- sticky fault word of the kernels that wait on flags (ctrl_pq.hip) -------------------------
 // One int in mapped pinned host memory per process: a kernel whose bounded flag wait runs out stores
 // a code there (its results are garbage from then on), the host reads it with a plain load after the
 // synchronisation it does anyway -- no copy, no extra launch; nothing is written on the good path.
@@ -56,7 +56,6 @@ int* kernel_fault_word() {
         *static_cast<volatile int*>(h) = 0;
         ffk_api::g_fault_host = static_cast<int*>(h);
 #if !defined(FFK_HOST_SANITIZE)
-        (void)pc_bind_fault_word(ffk_api::g_fault_dev);
         (void)pq_bind_fault_word(ffk_api::g_fault_dev);
 #endif
     });
@@ -118,21 +117,19 @@ int max_chunks_for(int W, int A, int G, int d) {
 double accumulate_flops(int W, int A, int G, int d) {
     // FMA-counted real flops the accumulate kernels EXECUTE per (segment, frequency)
     // (DESIGN.md section 3).
-    // d = 4 (ctrl_pc.hip, round 4: real tile, folded operands): per operator 16 x (zz: 2 mul + 6 fma,
-    // z = psi zz: 2 mul + 2 fma, Y: 16 fma) = 832; per group of <= 3 operators the tile: 13 entries x
-    // 10 (x, addition theorem 3, reciprocal 5, product 1) + 62 (two sincos and psi) + 6 (e^{ib} T of
-    // the fold, one element per lane = one per frequency) and 6 per operator (Bbar times that).
-    if (d == 4 && ffk::pc_accumulate_supported(d, A)) {
+    // d = 4: the tile per group of <= 3 operators: 13 entries x 10 (x, addition theorem 3, reciprocal 5, product
+    // 1) + 62 (two sincos and psi) + 6 (e^{ib} T of the fold, one element per lane = one per frequency) and 6 per
+    // operator (Bbar times that).
+    if (d == 4 && ffk::pq_accumulate_supported(d, A)) {
         // ctrl_pq.hip (round 5; the default): per operator the first product 16 x (2 mul + 6 fma) = 224,
         // zr + zi 16, the second product as THREE real 4 x 4 x 4 matrix products (Gauss) 3 x 128 = 384, the fold
         // 6 = 630 -- and blocks of nc = min(3, A) operators execute nc of them whether or not the last block is
         // full; per block the tile 13 x 10 + 62 + 6 = 198 and c = psi conj(T), cr + ci: 16 x 7 = 112.
         const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);
-        if (geo.pq) {
+        if (geo.pc) {
             const int nc = A >= 3 ? 3 : A;
             return (630.0*nc + 310.0)*double((A + nc - 1)/nc)*double(G)*double(W);
         }
-        return (838.0*A + 198.0*((A + 2)/3))*double(G)*double(W);
     }
     // d = 8 (ctrl_pcr.hip, round 4): per operator the first product real x complex 4 d^3 = 2048, psi P
     // 6 d^2 = 384, the second product complex 8 d^3 = 4096, the fold (one (m, n) per lane = per
@@ -300,12 +297,11 @@ int ffk_set_segment_chunks(int chunks) {
     return FFK_OK;
 }
 int ffk_set_accumulate_variant(int variant) {
-    FFK_REQUIRE(variant >= 0 && variant <= 6, "variant must be 0..6");
+    FFK_REQUIRE(variant >= 0 && variant <= 4, "variant must be 0..4");
     ++g_knob_epoch;
     ffk::set_use_wave_kernel(variant == 1);
     ffk::set_use_gsplit(variant != 2);
     ffk::set_mfma_policy(variant == 3 ? 1 : (variant == 4 ? 2 : 0));
-    if (variant == 5 || variant == 6) ffk::set_d4_kernel(variant == 6 ? 1 : 0);
     return FFK_OK;
 }
 int ffk_set_accumulate_events(void* start, void* stop) {

@@ -226,9 +226,12 @@ int sequence_on_device(const double* dU, const double* dP, const double* dR, con
                                           hermitian_basis, dL, wliou, s));
     }
     // the table rule, the slab reduction and (which = 0) the filter function of the sum
+    // (ffk_set_accumulate_events: the caller times this launch on the stream it runs on)
+    if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_start, s));
     FFK_HIP(ffk::launch_from_atomic(reinterpret_cast<const cplx*>(dP), reinterpret_cast<const cplx*>(dR), dI,
                                     dL, l_is_complex, G, A, N, W, which, reinterpret_cast<cplx*>(dO), watom,
                                     s, dRtab, reinterpret_cast<cplx*>(dF), T));
+    if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_stop, s));
     if (dF) FFK_HIP(hipMemcpyAsync(filter_function, dF, nF, hipMemcpyDeviceToHost, s));
     if (control_matrix) FFK_HIP(hipMemcpyAsync(control_matrix, dO, nO, hipMemcpyDeviceToHost, s));
     FFK_HIP(hipMemcpyAsync(total_propagator, dQ + size_t(G)*dd, 16*dd, hipMemcpyDeviceToHost, s));
@@ -436,7 +439,7 @@ int ffk_decay_amplitudes(const double* control_matrix, int n_pulses, int A, int 
 }
 
 size_t ffk_cumulant_function_workspace_bytes(int batch, int N, int d) {
-    if (batch < 1 || N < 1 || !d_templated_ok(d)) return 0;
+    if (batch < 1 || N < 1 || !d_ok(d)) return 0;
     return ffk::cumulant_workspace_bytes(batch, N, d);
 }
 
@@ -445,7 +448,7 @@ int ffk_cumulant_function_dev(const double* decay_amplitudes, int batch, int N, 
                               void* workspace, size_t workspace_bytes, void* stream) {
     FFK_REQUIRE(decay_amplitudes && basis && cumulant_function, "NULL argument");
     FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis");
-    FFK_REQUIRE(d_templated_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D_TEMPLATED);
+    FFK_REQUIRE(d_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D);
     FFK_REQUIRE(!single_qubit || (d == 2 && N == 4), "single-qubit expression needs d = 2, N = 4");
     if (!single_qubit) {
         FFK_REQUIRE(batch <= 65535, "batch %d too large", batch);
@@ -463,7 +466,7 @@ int ffk_cumulant_function(const double* decay_amplitudes, int batch, int N, int 
                           const double* basis, int single_qubit, double* cumulant_function) {
     FFK_REQUIRE(decay_amplitudes && basis && cumulant_function, "NULL argument");
     FFK_REQUIRE(batch >= 1 && N >= 1, "empty axis");
-    FFK_REQUIRE(d_templated_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D_TEMPLATED);
+    FFK_REQUIRE(d_ok(d), "dimension %d outside [2, %d]", d, FFK_MAX_D);
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t nG = 8*size_t(batch)*N*N;
     const size_t nB = 16*size_t(N)*d*d;

@@ -140,15 +140,13 @@ struct AccumGeometry {
     bool wave_kernel; // small-d one-wave-per-block variant
     int gsplit;       // sub-chunks per block (in-block segment split), 1 = none
     bool mfma;        // large-d matrix-core kernel (ctrl_mfma.hip): 16 frequencies per block
-    bool pc;          // producer/consumer kernel (ctrl_pc.hip), d = 4
-    bool pq;          // ... its successor with the second product on the matrix cores (ctrl_pq.hip)
+    bool pc;          // producer/consumer kernel with the second product on the matrix cores (ctrl_pq.hip), d = 4
     bool pcw;         // producer/consumer kernel on the matrix cores (ctrl_pcr.hip), d = 8
     bool generic;     // runtime-d kernel (generic.hip), d > 16: one block per (frequency, operator, chunk)
 };
 void set_use_wave_kernel(bool on);
 void set_use_gsplit(bool on);
 void set_mfma_policy(int policy);   // 0 default (d >= 12), 1 never, 2 wherever supported (d = 8 too)
-void set_d4_kernel(int which);      // 0 ctrl_pc.hip, 1 ctrl_pq.hip
 AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks);
 // Ypart (chunks, A, d, d, W): partial Hilbert-space sums, omega fastest
 // `expand` (optional): with ONE segment chunk the block that owns an (operator, frequency tile) holds
@@ -184,22 +182,13 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
 // capture: ffk_graph_capture_begin and the resident pass touch it first).  A kernel whose bounded flag
 // wait runs out stores a non-zero code there; NULL only if the runtime refused the allocation.
 int* kernel_fault_word();
-hipError_t pc_bind_fault_word(int* device_pointer);   // ctrl_pc.hip
 constexpr int kFaultPcProducerWait = 1, kFaultPcConsumerWait = 2;
-
-// ---- ctrl_pc.hip -----------------------------------------------------------------------------
-bool pc_accumulate_supported(int d, int A);
-int pc_accumulate_ops_per_block(int A);
-int pc_accumulate_subchunks();
-int pc_accumulate_lds_bytes(int d, int nc);
-hipError_t launch_accumulate_pc(const double* omega, int W, const double* segtab, const cplx* ops,
-                                int G, int d, int A, int nc, int chunks, int chunk_len, cplx* Ypart,
-                                hipStream_t stream);
 
 // ---- ctrl_pq.hip (d = 4, second product on the matrix cores) -------------------------------------
 int pq_accumulate_lds_bytes(int nc);
 int pq_accumulate_waves(int nc);
-int pq_accumulate_slabs_per_block();   // partial sums a block writes (its even and its odd tiles)
+bool pq_accumulate_supported(int d, int A);
+int pq_accumulate_ops_per_block(int A);
 hipError_t pq_bind_fault_word(int* device_pointer);
 hipError_t launch_accumulate_pq(const double* omega, int W, const double* segtab, const cplx* ops,
                                 int G, int d, int A, int nc, int chunks, int chunk_len, cplx* Ypart,

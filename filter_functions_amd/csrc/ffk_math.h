@@ -230,7 +230,7 @@ FFK_HD cplx first_order_integral_aa(double omega, double dE, double dt, double s
 // formed, the phase costs nothing extra, the x == 0 limit lives in the rare branch).  Near a
 // resonance (|x dt| < 2^-4, which includes x == 0 and zero-length segments) the sine comes from the
 // short polynomial -- the sum would cancel -- as in first_order_integral_aa.
-// E = psi e^{ib} q with q = 2 sin(a + b)/x REAL: the d = 4 kernel (ctrl_pc.hip) never forms E; it
+// E = psi e^{ib} q with q = 2 sin(a + b)/x REAL: the d = 4 kernel (ctrl_pq.hip) never forms E; it
 // folds e^{ib} into the frequency-independent operands and contracts with q (phased_q) alone.
 struct PhasedFrequency {
     double om, dt, thr;        // frequency, segment length, 2^-4/dt

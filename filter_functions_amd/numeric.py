@@ -45,8 +45,13 @@ def _check_d(d, templated=False, what=None):
     representation) serves d <= 64; *templated* entry points (kernels compiled per dimension) d <= 16."""
     limit = _lib.MAX_D_TEMPLATED if templated else _lib.MAX_D
     if not 2 <= d <= limit:
+        hint = ''
+        if templated and 2 <= d <= _lib.MAX_D:
+            hint = (f'  (The kernels behind it are compiled per dimension up to {limit}; the control matrix, noise '
+                    f'operators, filter function, infidelity, decay amplitudes, cumulant function and error transfer '
+                    f'matrix themselves are served up to d = {_lib.MAX_D}: call them without it.)')
         raise ValueError(f'Hilbert space dimension d={d} unsupported' + (f' for {what}' if what else '')
-                         + f': need 2 <= d <= {limit}.')
+                         + f': need 2 <= d <= {limit}.' + hint)
 
 
 def diagonalize(hamiltonian, dt):
@@ -775,7 +780,7 @@ def calculate_second_order_filter_function_from_atomic(filter_function_atomic,
 
 def _cumulant_function(decay_amplitudes, basis, frequency_shifts=None):
     N, d = basis.shape[:2]
-    _check_d(d, templated=True)
+    _check_d(d)
     G = as_f64(decay_amplitudes)
     if G.ndim < 2 or G.shape[-2:] != (N, N):
         raise ValueError(f'Expected decay amplitudes of shape (..., {N}, {N}), not {G.shape}.')

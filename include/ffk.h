@@ -27,11 +27,12 @@
  *   - d (Hilbert-space dimension) must satisfy 2 <= d <= FFK_MAX_D (64) for the path the reference's
  *     get_filter_function / infidelity / liouville_representation walk: ffk_diagonalize*,
  *     ffk_control_matrix* (control matrix and noise operators), ffk_filter_function*, ffk_infidelity*,
- *     ffk_decay_amplitudes*, ffk_control_matrix_from_atomic*, ffk_liouville*.  Up to
+ *     ffk_decay_amplitudes*, ffk_cumulant_function*, ffk_expm_real, ffk_control_matrix_from_atomic*,
+ *     ffk_liouville*.  Up to
  *     FFK_MAX_D_TEMPLATED (16) the kernels are compiled per dimension (operands in registers or
  *     wave-private LDS); above it one runtime-d kernel set serves (csrc/generic.hip, workgroup-wide
- *     LDS tiles).  The remaining entry points (intermediates, second order, gradients, cumulant
- *     function, fused pipeline and resident passes, sequence concatenation in one call) accept
+ *     LDS tiles).  The remaining entry points (intermediates, second order, gradients, fused
+ *     pipeline and resident passes, sequence concatenation in one call) accept
  *     d <= FFK_MAX_D_TEMPLATED only and return FFK_EINVAL above it.
  *   - Thread-safety: calls on one device are serialised by the caller; the library keeps one
  *     arena per process and device.
@@ -614,9 +615,7 @@ int ffk_set_segment_chunks(int chunks);
  * generated integral through LDS), 1 = one-wave-per-block variant for d <= 4 (kept for tuning;
  * measured slower on MI355X because its 48 accumulators per lane spill into AGPRs),
  * 2 = default kernel without the in-block segment split (tuning), 3 = never use the matrix-core
- * kernel (d >= 12 use it by default), 4 = use the matrix-core kernel wherever it exists (d = 8 too);
- * 5 / 6 (sticky, A/B runs): d = 4 on the round-4 vector-ALU kernel / on the round-5 kernel with the second
- * product on the matrix cores (the default).                                                        */
+ * kernel (d >= 12 use it by default), 4 = use the matrix-core kernel wherever it exists (d = 8 too). */
 int ffk_set_accumulate_variant(int variant);
 /* Per-call statistics of the last ffk_control_matrix*_dev launch on this thread:
  * algorithmic FP64 flops of the accumulate kernel, its grid/block geometry, chunks used.   */
@@ -631,7 +630,8 @@ int ffk_get_stats(ffk_stats* out);
 /* Profiling hook: when both are non-NULL hipEvent_t handles, the next ffk_control_matrix_dev /
  * ffk_pipeline_dev calls on this thread record `start` immediately before and `stop`
  * immediately after the accumulate kernel, on the stream it is launched on (so that a caller
- * can time the dominant kernel inside its own timed region).  Pass NULLs to switch off.     */
+ * can time the dominant kernel inside its own timed region); the concatenation entry points
+ * (ffk_concatenate_sequence*) do the same around their rule kernel.  Pass NULLs to switch off. */
 int ffk_set_accumulate_events(void* start, void* stop);
 /* With several passes in flight on several streams, the accumulate kernel of one pass waits for the
  * blocks of the other pass's to retire, and a start event recorded on its own stream would include

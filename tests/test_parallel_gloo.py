@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the omega-sharding and all-gather logic of
+"""CPU, world_size 2 and 8, gloo: the omega-sharding and all-gather logic of
 filter_functions_amd.parallel (partition, uneven blocks, complex payloads, layout), with the
 oracle standing in for the per-shard compute (the product's compute is the HIP pipeline; these
 tests only exercise the distribution logic, which is backend independent)."""
@@ -263,3 +263,44 @@ def test_sharded_step_ring_with_several_compute_streams(tmp_path):
         got = np.load(os.path.join(str(tmp_path), f'ring{rank}.npz'))
         assert np.abs(got['results'] - ref).max() <= 1e-14*np.abs(ref).max()
         assert int(got['waits']) == n_steps - depth
+
+
+@pytest.mark.parametrize('n_compute', [1, 2])
+def test_sharded_step_ring_world_size_8(tmp_path, n_compute):
+    """The shape `bench.py --gpus 8` runs: eight ranks, eight buffer sets, one or two
+    compute streams, an omega grid that does not divide by eight (blocks of 9 and 8 frequencies): every
+    step's infidelities equal the unsharded integral on every rank, buffer sets are not reused early."""
+    world, depth, n_steps, n_omega = 8, 8, 19, 67
+    mp.spawn(_ring_worker, args=(world, _free_port(), n_omega, depth, n_steps, str(tmp_path), n_compute),
+             nprocs=world, join=True)
+    omega = torch.from_numpy(np.geomspace(0.1, 50.0, n_omega))
+    S = 1e-3/omega
+    ref = np.array([_FakePipe.integrate(_FakePipe.model(omega, 3, step), omega, S, 4).numpy()
+                    for step in range(n_steps)])
+    for rank in range(world):
+        got = np.load(os.path.join(str(tmp_path), f'ring{rank}.npz'))
+        assert got['results'].shape == ref.shape
+        assert np.abs(got['results'] - ref).max() <= 1e-14*np.abs(ref).max()
+        assert int(got['waits']) == ((n_steps - 1)//(depth//2) if n_compute == 1 else n_steps - depth)
+
+
+def test_sharded_filter_function_world_size_8(tmp_path):
+    """Eight ranks, 67 frequencies: partition, all-gather of F, rank-ordered sums of the partial decay
+    amplitudes, frequency shifts and gradients -- identical on every rank, equal to the unsharded values."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import ff_oracle as orc
+    world, n_omega = 8, 67
+    mp.spawn(_worker, args=(world, _free_port(), n_omega, str(tmp_path)), nprocs=world, join=True)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'rand_d3_ggm.npz'))
+    omega = np.linspace(-2.0, 9.0, n_omega)
+    R = orc.control_matrix_from_scratch(g['eigvals'], g['eigvecs'], g['propagators'], omega,
+                                        g['basis'], g['n_opers'], g['n_coeffs'], g['dt'], g['t'])
+    F_ref = orc.filter_function(R)
+    got = [np.load(os.path.join(str(tmp_path), f'rank{r}.npz')) for r in range(world)]
+    for r in range(world):
+        assert np.abs(got[r]['F'] - F_ref).max() <= 1e-13*np.abs(F_ref).max()
+        assert np.array_equal(got[r]['idx'], np.tile(np.arange(n_omega, dtype=float), (2, 1)))
+        for key in ('gamma', 'delta', 'grad'):
+            assert np.array_equal(got[r][key], got[0][key]), key
+    ref = np.load(os.path.join(ROOT, 'tests', 'golden', 'etm.npz'))['g3_decay_amplitudes_S2']
+    assert np.abs(got[0]['gamma'] - ref).max() <= 1e-13*np.abs(ref).max()

@@ -2,7 +2,7 @@
 // Sixteen wavefronts per CU (one 1024-thread block per CU, like the accumulate kernel), every wavefront
 // loops over "segments"; per segment it handles NSETS sets of four frequencies.  Three mixes per set, all
 // on pseudo-random operands read from LDS (the operands of the real kernel have no reuse either):
-//   mix 0  the vector-only consumer of ctrl_pc.hip:    28 v_fma_f64 per set, 69/16 ds_read_b128
+//   mix 0  the vector-only consumer of the round-4 kernel:    28 v_fma_f64 per set, 69/16 ds_read_b128
 //   mix 1  first product + psi on the vector ALU (12 instructions), second product as FOUR
 //          v_mfma_f64_4x4x4_4b (one frequency per block), 3 ds_read_b128
 //   mix 2  the same with the three-product complex multiplication: 13 vector + THREE matrix instructions

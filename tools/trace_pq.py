@@ -1,7 +1,7 @@
 """Timeline of one block of the d = 4 matrix-core accumulate kernel (tuning build -DFFK_PQ_CLOCK).
 
     make -C filter_functions_amd/csrc VARIANT=pqclock VSRCS=ctrl_pq.hip VFLAGS=-DFFK_PQ_CLOCK
-    FFK_D4_KERNEL=1 FFK_LIBRARY=build/libffk_pqclock.so python tools/trace_pq.py
+    FFK_LIBRARY=build/libffk_pqclock.so python tools/trace_pq.py
 
 Lane 0 of every wavefront of block (0, 0, 0) stamps s_memtime four times per tile: producers at the top
 of the iteration, when the tile's numbers are computed, when the slot is free, when the tile is published;
