@@ -200,19 +200,22 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accu
                     rec[e] = *reinterpret_cast<const double4_t*>(st + seg_rec(e));
                 }
                 asm volatile("" ::: "memory");
-                unsigned near = 0u;
+                // near a resonance (|x| < thr, rare) the entry is redone under one branch; whether any of the
+                // batch's entries is, is ONE running minimum of |x| (a compare, a select and an or per entry
+                // were a twelfth of the producer's instructions)
+                double xmin = pf.thr;
 #pragma unroll
                 for (int e = 0; e < DD; ++e) {
                     if (e < e0 || e >= e1 || (e != 0 && e/D == e%D)) continue;
                     const double x = om + rec[e].x;
                     q[e] = fma(pf.sa2, rec[e].z, pf.ca2*rec[e].y)*rcp_fast(x);
-                    near |= (fabs(x) < pf.thr ? 1u : 0u) << e;
+                    asm("v_min_f64 %0, |%1|, %0" : "+v"(xmin) : "v"(x));
                 }
-                if (near != 0u) {
+                if (xmin < pf.thr) {
 #pragma unroll
                     for (int e = 0; e < DD; ++e) {
                         if (e < e0 || e >= e1 || (e != 0 && e/D == e%D)) continue;
-                        if ((near >> e) & 1u) q[e] = phased_q(pf, rec[e].x, rec[e].y, rec[e].z);
+                        if (fabs(om + rec[e].x) < pf.thr) q[e] = phased_q(pf, rec[e].x, rec[e].y, rec[e].z);
                     }
                 }
             };

@@ -842,3 +842,55 @@ def test_shallow_copy_outlives_the_original_with_by_products_still_due(monkeypat
                         lambda self: self._data.update(total_propagator=2*U))
     assert np.array_equal(twin.total_propagator_liouville, np.eye(4))
     assert np.array_equal(seen[-1][0], 2*U)
+
+
+def test_merged_tables_of_a_pulse_set_are_remembered_and_safe():
+    """`concatenate_without_filter_function` remembers, per set of distinct pulse OBJECTS, the merged operator
+    tables (reference pulse_sequence.py:1340-1483 recomputes them per call): sequences drawn from one gate set
+    -- randomized benchmarking -- pay them once.  The results must not alias the remembered tables, a pulse
+    whose arrays are replaced must be re-merged, different orders of the same set must agree with a fresh
+    evaluation."""
+    from filter_functions_amd import pulse_sequence as ps
+    X, Y, Z = util.paulis[1:]
+    rng = np.random.default_rng(3)
+    gates = [ff.PulseSequence([[X/2, rng.standard_normal(2), 'X']], [[Z/2, [1, 1], 'Z']], [1.0, 0.5]),
+             ff.PulseSequence([[Y/2, rng.standard_normal(3), 'Y']], [[Z/2, [1, 1, 1], 'Z']], [0.3, 0.2, 0.1]),
+             ff.PulseSequence([[X/2, rng.standard_normal(1), 'X'], [Y/2, rng.standard_normal(1), 'Y']],
+                              [[Z/2, [1], 'Z'], [X/2, [0.5], 'Xn']], [0.7])]
+
+    def fresh(seq):
+        ps._MERGED.clear()
+        return ps.concatenate_without_filter_function(seq, return_identifier_mappings=True)
+
+    def same(a, b):
+        (pa, ca, na), (pb, cb, nb) = a, b
+        assert pa == pb and dict(ca.items()) == dict(cb.items()) and dict(na.items()) == dict(nb.items())
+        for key in ('c_opers', 'n_opers', 'c_coeffs', 'n_coeffs', 'dt'):
+            assert np.array_equal(getattr(pa, key), getattr(pb, key), equal_nan=True), key
+        assert list(pa.c_oper_identifiers) == list(pb.c_oper_identifiers) and pa.tau == pb.tau
+
+    for order in ([0, 1, 2, 1, 0, 0, 2], [2, 2, 1, 0], list(rng.integers(0, 3, 40))):
+        seq = [gates[k] for k in order]
+        want = fresh(seq)
+        ps._MERGED.clear()
+        first = ps.concatenate_without_filter_function(seq, return_identifier_mappings=True)
+        assert len(ps._MERGED) == 1
+        again = ps.concatenate_without_filter_function(seq, return_identifier_mappings=True)   # served from memory
+        same(first, want)
+        same(again, want)
+        # no aliasing: scribbling over a result leaves the next one intact
+        again[0].c_opers[...] = 0
+        again[0].n_coeffs[...] = -1
+        same(ps.concatenate_without_filter_function(seq, return_identifier_mappings=True), want)
+    # a pulse whose coefficients are REPLACED is merged anew (in-place edits need cleanup, as for every cache)
+    seq = [gates[0], gates[1], gates[0]]
+    before = ps.concatenate_without_filter_function(seq)
+    gates[1].c_coeffs = gates[1].c_coeffs*2.0
+    after = ps.concatenate_without_filter_function(seq)
+    assert not np.array_equal(before.c_coeffs, after.c_coeffs)
+    same((after, {}, {}), (fresh(seq)[0], {}, {}))
+    # identifiers that must be disambiguated by the position are never remembered
+    clash = ff.PulseSequence([[Z/2, [1.0], 'X']], [[Z/2, [1], 'Z']], [1.0])      # 'X' names another matrix here
+    ps._MERGED.clear()
+    out = ps.concatenate_without_filter_function([gates[0], clash])
+    assert len(ps._MERGED) == 0 and sorted(out.c_oper_identifiers) == ['X_0', 'X_1']
