@@ -45,7 +45,10 @@
 #include <cstdlib>
 
 #include "ffk_internal.h"
-#include "ctrl_pq_consumer.inc"   // generated: tools/gen_pq_consumer.py
+#ifndef FFK_PQ_CONSUMER_INC   /* tuning builds: a block with parts left out (GEN_PQ_DROP) */
+#define FFK_PQ_CONSUMER_INC "ctrl_pq_consumer.inc"
+#endif
+#include FFK_PQ_CONSUMER_INC   // generated: tools/gen_pq_consumer.py
 
 namespace ffk {
 namespace {

@@ -28,7 +28,11 @@ Registers (fixed; `{v[a:b]}` constraints on the C++ side):
 LDS operations, in queue order: flag of tile it + 2, partner's progress | set 1's q01, q23, psi |
 next tile's T, psi, q01, W[.][0], W[.][1], q23, W[.][2], W[.][3] | done counter, own progress.
 """
+import os
+
 NC = 3
+# tuning builds (never shipped): GEN_PQ_DROP=mfma|valu|next|set1 leaves that part of the block out
+DROP = os.environ.get("GEN_PQ_DROP", "")
 ZR = [4*a for a in range(NC)]
 ZI = [4*a + 2 for a in range(NC)]
 ZS = [12 + 2*a for a in range(NC)]
@@ -68,6 +72,10 @@ class Stream:
         self.fifo = list(fifo)      # tags of LDS operations in flight, oldest first
 
     def emit(self, text):
+        if DROP == 'mfma' and 'mfma' in text:
+            return
+        if DROP == 'valu' and text.startswith('v_') and 'mfma' not in text:
+            return
         self.lines.append(text)
 
     def lds(self, text, tag):
@@ -157,8 +165,10 @@ def build(last):
     vector_part(st, 1)
     # every operand register is dead: the next tile's operands fly during the matrix instructions and the hand-over
     assert not st.fifo, st.fifo
-    if not last:
+    if not last and DROP != 'next':
         next_tile_requests(st)
+    elif DROP == 'next':
+        st.fifo = list(ENTRY[:-2])
     matrix_part(st, 1)
     # hand the slot back: lane 0 counts this consumer in and publishes its progress (LDS operations of a
     # wavefront execute in order: both are behind the tile's reads without a wait)
