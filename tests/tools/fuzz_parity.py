@@ -1,5 +1,6 @@
 """Randomised parity sweep against the oracle (not part of the test suite: run on the GPU box when
-kernels change).  Usage: python tests/tools/fuzz_parity.py [n_cases] [seed] [long]
+kernels change).  Usage: python tests/tools/fuzz_parity.py [n_cases] [seed] [long | d=<n>]
+("d=4": every case at that dimension -- the sweep of one accumulate kernel)
 ("long": segment counts up to a few thousand -- the unfused front end, the chunked scans, the
 long-sequence kernel choice at d = 2 -- on small frequency grids and d <= 8, so that the oracle keeps up)"""
 import os
@@ -18,6 +19,7 @@ from filter_functions_amd import numeric  # noqa: E402
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 long_sequences = len(sys.argv) > 3 and sys.argv[3] == 'long'
+fixed_d = int(sys.argv[3][2:]) if len(sys.argv) > 3 and sys.argv[3].startswith('d=') else None
 rng = np.random.default_rng(seed)
 
 
@@ -37,6 +39,9 @@ for case in range(n_cases):
         d = int(rng.choice([2, 2, 2, 3, 4, 4, 5, 8]))
         G = int(rng.choice([63, 64, 65, 257, 1023, 1024, 1025, 2500, 4097]))
         W = int(rng.choice([1, 3, 64, 65]))
+    if fixed_d is not None:
+        d = fixed_d
+        G = int(rng.choice([1, 2, 7, 8, 9, 16, 17, 33, 64, 100, 257]))
     n_cops = int(rng.integers(1, 4))
     btype = 'Pauli' if d in (2, 4, 8, 16) and rng.random() < 0.5 else 'GGM'
 
