@@ -45,8 +45,15 @@
 #include <cstdlib>
 
 #include "ffk_internal.h"
+#ifndef FFK_PQ_SETS            /* sets of four frequencies per consumer: 2 (shipped) or 4 (tuning: profiles/r05_b_*, ab_pq18; needs GEN_PQ_SETS=4 python tools/gen_pq_consumer.py > ctrl_pq_consumer4.inc) */
+#define FFK_PQ_SETS 2
+#endif
 #ifndef FFK_PQ_CONSUMER_INC   /* tuning builds: a block with parts left out (GEN_PQ_DROP) */
+#if FFK_PQ_SETS == 4
+#define FFK_PQ_CONSUMER_INC "ctrl_pq_consumer4.inc"
+#else
 #define FFK_PQ_CONSUMER_INC "ctrl_pq_consumer.inc"
+#endif
 #endif
 #include FFK_PQ_CONSUMER_INC   // generated: tools/gen_pq_consumer.py
 
@@ -54,8 +61,8 @@ namespace ffk {
 namespace {
 
 constexpr int kPqProducers = 4;   // wavefronts 0..3, one per SIMD
-constexpr int kPqSets = 2;        // a consumer owns two sets of four of the block's 64 frequencies, all operators
-constexpr int kPqConsumers = 16/kPqSets;   // wavefronts 4..11: two per SIMD
+constexpr int kPqSets = FFK_PQ_SETS;   // a consumer owns this many sets of four of the block's 64 frequencies, all operators
+constexpr int kPqConsumers = 16/kPqSets;   // wavefronts 4..11: two per SIMD (four sets: 4..7, one per SIMD)
 constexpr int kPqRing = 8;        // tile slots: two per producer
 #ifndef FFK_PC_SPIN_LIMIT
 #define FFK_PC_SPIN_LIMIT (1 << 21)
@@ -106,7 +113,7 @@ __device__ __forceinline__ int lds_peek(const int* flag) {
 }
 
 template <int NC>
-__global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accumulate_pq_kernel(
+__global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 : 2) void ctrl_accumulate_pq_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
     constexpr int D = 4, DD = 16, S = kPqRow, TILE = pq_tile_doubles(NC);
@@ -291,7 +298,7 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accu
     // raises its priority (soft lockstep).
     const int octant = wave - kPqProducers;            // frequencies 8 octant .. 8 octant + 7 of the block
     const int m = lane >> 4, f = (lane >> 2) & 3, j = lane & 3;
-    const int me = octant, partner = me ^ 4;
+    const int me = octant, partner = kPqSets == 2 ? me ^ 4 : me;      // (four sets: one consumer per SIMD, no partner)
     int flag_v = 0, partner_v = 0;
     int prio = 0;
     auto await = [&](int it) __attribute__((always_inline)) {     // tile `it` published?
@@ -318,11 +325,11 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accu
     };
     // this lane's offsets inside a slot, in doubles
     const int mj = m*4 + j;                                            // W, T: (m, j) = (m, i)
-    const int wf = octant*8 + f;                                       // the lane's frequency of set 0; set 1: + 4
+    const int wf = octant*4*kPqSets + f;                               // the lane's frequency of set 0; set s: + 4 s
     const int o_w = kPqW + mj*2;                                       // + a*128 + n*32; T at + NC*128
     const int o_p = kPqPsi + wf*2;                                     // set 1: + 8
-    const int o_q0 = kPqQ + wf*8 + ((m ^ ((2*octant) & 3)) << 1);      // row m in 16-byte slot m ^ ((w >> 2) & 3)
-    const int o_q1 = (o_q0 ^ 2) + 32;                                  // set 1; plane h = 1: + 512
+    const int o_q0 = kPqQ + wf*8 + ((m ^ ((kPqSets*octant) & 3)) << 1);   // row m in 16-byte slot m ^ ((w >> 2) & 3)
+    auto o_q = [&](int s) { return (o_q0 ^ (s << 1)) + s*32; };        // set s; plane h = 1: + 512
     cplx y[NC][kPqSets];                                               // the block's sums, combined
 
     if constexpr (NC == 3) {
@@ -330,11 +337,20 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accu
         typedef double double8_t __attribute__((ext_vector_type(8)));
         double8_t W0v, W1v, W2v;        // v[24:39], v[40:55], v[56:71]: W_a[n] = (re, im), n = 0..3
         double8_t Qv;                   // v[72:87]: q01, q23, psi, (tr, ti)
-        double8_t A0 = 0.0, A1 = 0.0;   // v[88:103], v[104:119]: P_k of (a, s), index 3 (2 a + s) + k
+        // accumulators P_k of (a, s), index 3 (kPqSets a + s) + k: two sets v[88:123], four sets v[88:159]
+        double8_t A0 = 0.0, A1 = 0.0;   // v[88:103], v[104:119]
+#if FFK_PQ_SETS == 4
+        double8_t A2 = 0.0, A3 = 0.0;   // v[120:135], v[136:151]
+        double4_t A4 = 0.0;             // v[152:159]
+#else
         double2_t A2 = 0.0;             // v[120:123]
+#endif
         const unsigned ring_b = static_cast<unsigned>(reinterpret_cast<uintptr_t>(ring));
         const unsigned flags_b = static_cast<unsigned>(reinterpret_cast<uintptr_t>(ready));
-        const unsigned b_w = ring_b + o_w*8, b_p = ring_b + o_p*8, b_q0 = ring_b + o_q0*8, b_q1 = ring_b + o_q1*8;
+        const unsigned b_w = ring_b + o_w*8, b_p = ring_b + o_p*8, b_q0 = ring_b + o_q0*8, b_q1 = ring_b + o_q(1)*8;
+#if FFK_PQ_SETS == 4
+        const unsigned b_q2 = ring_b + o_q(2)*8, b_q3 = ring_b + o_q(3)*8;
+#endif
         const unsigned a_partner = flags_b + (2*kPqRing + partner)*4, a_prog = flags_b + (2*kPqRing + me)*4;
         if (n_it > 0) {
             await(0);
@@ -357,19 +373,31 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accu
             const unsigned nxt = last ? cur : static_cast<unsigned>(((it + 1) & (kPqRing - 1))*TILE*8);
             const unsigned a_w = b_w + nxt, a_p = b_p + nxt, a_q0 = b_q0 + nxt;
             const unsigned a_q1 = b_q1 + cur, a_p1 = b_p + cur + 64;
+#if FFK_PQ_SETS == 4
+            const unsigned a_q2 = b_q2 + cur, a_q3 = b_q3 + cur;
+#endif
             const unsigned a_flag = flags_b + ((it + 2) & (kPqRing - 1))*4;
             const unsigned a_done = flags_b + (kPqRing + (it & (kPqRing - 1)))*4;
             const int progress_v = it + 1, one = 1;
             FFK_PQ_STAMP(it, 1);
+#if FFK_PQ_SETS == 4
+#define FFK_PQ_ASM_ACC "+{v[120:135]}"(A2), "+{v[136:151]}"(A3), "+{v[152:159]}"(A4)
+#define FFK_PQ_ASM_SETS , [a_q2] "v"(a_q2), [a_q3] "v"(a_q3)
+#else
+#define FFK_PQ_ASM_ACC "+{v[120:123]}"(A2)
+#define FFK_PQ_ASM_SETS
+#endif
 #define FFK_PQ_ASM_OPERANDS                                                                                    \
     : "+{v[24:39]}"(W0v), "+{v[40:55]}"(W1v), "+{v[56:71]}"(W2v), "+{v[72:87]}"(Qv), "+{v[88:103]}"(A0),       \
-      "+{v[104:119]}"(A1), "+{v[120:123]}"(A2), [flag] "=&v"(flag_v), [partner] "=&v"(partner_v)               \
+      "+{v[104:119]}"(A1), FFK_PQ_ASM_ACC, [flag] "=&v"(flag_v), [partner] "=&v"(partner_v)                    \
     : [a_w] "v"(a_w), [a_p] "v"(a_p), [a_q0] "v"(a_q0), [a_q1] "v"(a_q1), [a_p1] "v"(a_p1), [a_flag] "v"(a_flag), \
       [a_partner] "v"(a_partner), [a_done] "v"(a_done), [a_prog] "v"(a_prog), [progress] "v"(progress_v),     \
-      [one] "v"(one)                                                                                           \
+      [one] "v"(one) FFK_PQ_ASM_SETS                                                                           \
     : FFK_PQ_CONSUMER_CLOBBERS
             asm volatile(FFK_PQ_CONSUMER_ASM FFK_PQ_ASM_OPERANDS);
 #undef FFK_PQ_ASM_OPERANDS
+#undef FFK_PQ_ASM_ACC
+#undef FFK_PQ_ASM_SETS
             FFK_PQ_STAMP(it, 2);
             FFK_PQ_STAMP(it, 3);
         }
@@ -379,13 +407,19 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accu
                      : "+{v[24:39]}"(W0v), "+{v[40:55]}"(W1v), "+{v[56:71]}"(W2v), "+{v[72:87]}"(Qv)
                      :
                      : "memory");
+#if FFK_PQ_SETS == 4
+        const double P[36] = {A0[0], A0[1], A0[2], A0[3], A0[4], A0[5], A0[6], A0[7], A1[0], A1[1], A1[2], A1[3],
+                              A1[4], A1[5], A1[6], A1[7], A2[0], A2[1], A2[2], A2[3], A2[4], A2[5], A2[6], A2[7],
+                              A3[0], A3[1], A3[2], A3[3], A3[4], A3[5], A3[6], A3[7], A4[0], A4[1], A4[2], A4[3]};
+#else
         const double P[18] = {A0[0], A0[1], A0[2], A0[3], A0[4], A0[5], A0[6], A0[7], A1[0], A1[1], A1[2], A1[3],
                               A1[4], A1[5], A1[6], A1[7], A2[0], A2[1]};
+#endif
 #pragma unroll
         for (int a = 0; a < NC; ++a)
 #pragma unroll
             for (int s = 0; s < kPqSets; ++s) {
-                const double p1 = P[3*(2*a + s)], p2 = P[3*(2*a + s) + 1], p3 = P[3*(2*a + s) + 2];
+                const double p1 = P[3*(kPqSets*a + s)], p2 = P[3*(kPqSets*a + s) + 1], p3 = P[3*(kPqSets*a + s) + 2];
                 y[a][s] = cplx{p1 - p2, p3 - (p1 + p2)};
             }
     } else {
@@ -410,7 +444,7 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, 3) void ctrl_accu
             partner_v = *(const volatile lds_int_t*)(progress + partner);
 #pragma unroll
             for (int s = 0; s < kPqSets; ++s) {
-                const int oq = s == 0 ? o_q0 : o_q1;
+                const int oq = o_q(s);
                 const double2_t q01 = *reinterpret_cast<const double2_t*>(buf + oq);
                 const double2_t q23 = *reinterpret_cast<const double2_t*>(buf + oq + 512);
                 const double2_t psi = *reinterpret_cast<const double2_t*>(buf + o_p + s*8);

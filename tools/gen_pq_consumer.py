@@ -33,6 +33,9 @@ import os
 NC = 3
 # tuning builds (never shipped): GEN_PQ_DROP=mfma|valu|next|set1 leaves that part of the block out
 DROP = os.environ.get("GEN_PQ_DROP", "")
+# sets of four frequencies a consumer owns (2: eight consumers per block, two per SIMD -- the shipped kernel;
+# 4: four consumers, one per SIMD, 72 accumulator registers -- ctrl_pq.hip -DFFK_PQ_SETS=4)
+NSETS = int(os.environ.get("GEN_PQ_SETS", "2"))
 ZR = [4*a for a in range(NC)]
 ZI = [4*a + 2 for a in range(NC)]
 ZS = [12 + 2*a for a in range(NC)]
@@ -58,7 +61,7 @@ def wre(a, n):
 
 
 def acc(a, s, k):
-    return ACC0 + 2*(3*(2*a + s) + k)
+    return ACC0 + 2*(3*(NSETS*a + s) + k)
 
 
 # the LDS queue at block entry: what the previous block left in flight (after the C++ prologue or a spin on
@@ -154,22 +157,24 @@ def build(last):
     st = Stream(ENTRY)
     st.lds('ds_read_b32 %[flag], %[a_flag]', 'flag')
     st.lds('ds_read_b32 %[partner], %[a_partner]', 'partner')
-    vector_part(st, 0)
-    # set 1's q, psi into the registers set 0 is done with; they arrive during the nine matrix instructions
-    st.lds(f'ds_read_b128 {v4(PSI)}, %[a_p1]', 'psi')
-    st.lds(f'ds_read_b128 {v4(Q01)}, %[a_q1]', 'q01')
-    st.lds(f'ds_read_b128 {v4(Q23)}, %[a_q1] offset:4096', 'q23')
-    matrix_part(st, 0)
-    # T and W are still this tile's: only q01, q23, psi have to arrive
-    st.fifo = [t if t in ('q01', 'q23', 'psi', 'flag', 'partner') else 'old' for t in st.fifo]
-    vector_part(st, 1)
+    for s_ in range(NSETS - 1):
+        vector_part(st, s_)
+        # the next set's q, psi into the registers this set is done with; they arrive during its nine matrix
+        # instructions
+        st.lds(f'ds_read_b128 {v4(PSI)}, %[a_p1] offset:{64*s_}', 'psi')
+        st.lds(f'ds_read_b128 {v4(Q01)}, %[a_q{s_ + 1}]', 'q01')
+        st.lds(f'ds_read_b128 {v4(Q23)}, %[a_q{s_ + 1}] offset:4096', 'q23')
+        matrix_part(st, s_)
+        # T and W are still this tile's: only q01, q23, psi have to arrive
+        st.fifo = [t if t in ('q01', 'q23', 'psi', 'flag', 'partner') else 'old' for t in st.fifo]
+    vector_part(st, NSETS - 1)
     # every operand register is dead: the next tile's operands fly during the matrix instructions and the hand-over
     assert not st.fifo, st.fifo
     if not last and DROP != 'next':
         next_tile_requests(st)
     elif DROP == 'next':
         st.fifo = list(ENTRY[:-2])
-    matrix_part(st, 1)
+    matrix_part(st, NSETS - 1)
     # hand the slot back: lane 0 counts this consumer in and publishes its progress (LDS operations of a
     # wavefront execute in order: both are behind the tile's reads without a wait)
     st.emit('s_mov_b64 exec, 1')
