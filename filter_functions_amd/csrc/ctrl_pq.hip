@@ -77,7 +77,7 @@ __device__ __forceinline__ void pq_report_fault(int code) {
 }
 
 #ifdef FFK_PQ_CLOCK   /* tuning build: s_memtime stamps of block (0, 0, 0), tools/trace_pq.py */
-constexpr int kPqTraceTiles = 64, kPqTraceStamps = 4, kPqTraceWaves = 16;
+constexpr int kPqTraceTiles = 64, kPqTraceStamps = 12, kPqTraceWaves = 16;   // 4 C++ stamps + 8 inside the asm block
 __device__ unsigned long long g_pq_trace[kPqTraceWaves*(2 + kPqTraceTiles*kPqTraceStamps)];
 #define FFK_PQ_STAMP(it, k)                                                                          \
     do {                                                                                              \
@@ -359,6 +359,25 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
                          : [a_w] "v"(b_w), [a_p] "v"(b_p), [a_q0] "v"(b_q0)
                          : "memory");
         }
+#if defined(FFK_PQ_CONSUMER_LOOP_ASM) && !defined(FFK_PQ_CLOCK) && !defined(FFK_PQ_TILE_BLOCKS) && FFK_PQ_SETS == 2
+        // ---- the whole tile loop as ONE block (FFK_PQ_TILE_BLOCKS: the per-tile form below, for A/B runs) ----
+        static_assert(FFK_PQ_TILE_BYTES == TILE*8, "tools/gen_pq_consumer.py and pq_tile_doubles() disagree");
+        if (n_it > 0) {
+            typedef int int4_t __attribute__((ext_vector_type(4)));
+            int4_t sarg = {n_it, spin_limit, static_cast<int>(flags_b), me};
+            const int4_t varg = {static_cast<int>(b_w), static_cast<int>(b_q0), static_cast<int>(b_q1),
+                                 static_cast<int>(b_p)};
+            int fault_code;
+            asm volatile(FFK_PQ_CONSUMER_LOOP_ASM
+                         : "+{v[24:39]}"(W0v), "+{v[40:55]}"(W1v), "+{v[56:71]}"(W2v), "+{v[72:87]}"(Qv),
+                           "+{v[88:103]}"(A0), "+{v[104:119]}"(A1), "+{v[120:123]}"(A2), "+{s[36:39]}"(sarg),
+                           "={s48}"(fault_code)
+                         : "{v[138:141]}"(varg)
+                         : FFK_PQ_LOOP_CLOBBERS);
+            if (fault_code != 0) pq_report_fault(fault_code);
+            (void)a_partner; (void)a_prog; (void)flag_v; (void)partner_v; (void)prio;
+        }
+#else
         for (int it = 0; it < n_it; ++it) {
             FFK_PQ_STAMP(it, 0);
             const bool last = it + 1 == n_it;
@@ -387,9 +406,16 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
 #define FFK_PQ_ASM_ACC "+{v[120:123]}"(A2)
 #define FFK_PQ_ASM_SETS
 #endif
+#ifdef FFK_PQ_CLOCK   /* build with -DFFK_PQ_CONSUMER_INC pointing at a GEN_PQ_STAMPS=1 block */
+            unsigned long long ts[8];
+#define FFK_PQ_ASM_STAMPS , [t0] "=s"(ts[0]), [t1] "=s"(ts[1]), [t2] "=s"(ts[2]), [t3] "=s"(ts[3]), [t4] "=s"(ts[4]), \
+                            [t5] "=s"(ts[5]), [t6] "=s"(ts[6]), [t7] "=s"(ts[7])
+#else
+#define FFK_PQ_ASM_STAMPS
+#endif
 #define FFK_PQ_ASM_OPERANDS                                                                                    \
     : "+{v[24:39]}"(W0v), "+{v[40:55]}"(W1v), "+{v[56:71]}"(W2v), "+{v[72:87]}"(Qv), "+{v[88:103]}"(A0),       \
-      "+{v[104:119]}"(A1), FFK_PQ_ASM_ACC, [flag] "=&v"(flag_v), [partner] "=&v"(partner_v)                    \
+      "+{v[104:119]}"(A1), FFK_PQ_ASM_ACC, [flag] "=&v"(flag_v), [partner] "=&v"(partner_v) FFK_PQ_ASM_STAMPS    \
     : [a_w] "v"(a_w), [a_p] "v"(a_p), [a_q0] "v"(a_q0), [a_q1] "v"(a_q1), [a_p1] "v"(a_p1), [a_flag] "v"(a_flag), \
       [a_partner] "v"(a_partner), [a_done] "v"(a_done), [a_prog] "v"(a_prog), [progress] "v"(progress_v),     \
       [one] "v"(one) FFK_PQ_ASM_SETS                                                                           \
@@ -398,9 +424,15 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
 #undef FFK_PQ_ASM_OPERANDS
 #undef FFK_PQ_ASM_ACC
 #undef FFK_PQ_ASM_SETS
+#undef FFK_PQ_ASM_STAMPS
+#ifdef FFK_PQ_CLOCK
+            if (pq_tr != nullptr && it < kPqTraceTiles)
+                for (int k = 0; k < 8; ++k) pq_tr[2 + it*kPqTraceStamps + 4 + k] = ts[k];
+#endif
             FFK_PQ_STAMP(it, 2);
             FFK_PQ_STAMP(it, 3);
         }
+#endif
         // (the compiler does not know that matrix instructions wrote the accumulators: keep the vector
         // instructions that read them next out of their shadow)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15"

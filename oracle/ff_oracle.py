@@ -517,6 +517,33 @@ def cumulant_function(Gamma, basis):
     return np.einsum('iba,...abpq,jpq->...ij', C, S4, C).real
 
 
+def cumulant_function_matrix_form(Gamma, basis):
+    """The cumulant superoperator applied to every basis element with plain matrix products -- for dimensions
+    where `cumulant_function`'s (d, d, d, d) intermediates and `cumulant_function_dense`'s N^4 trace tensor are
+    out of reach (d > 16: N = d^2 > 256).  Same definition (filter_functions/numeric.py:1119-1165, 1190 with the
+    four-element traces written out): with D_k = sum_l Gamma_kl C_l,
+        K(X) = -1/2 (G1 X + X G2 - sum_k C_k X D_k - sum_k D_k X C_k),  G1 = sum_k C_k D_k,  G2 = sum_k D_k C_k,
+        K_ij = Re tr(C_i K(C_j)).
+    Pinned to `cumulant_function` and to the reference's fixtures at small d in tests/test_oracle_golden.py."""
+    C = np.asarray(basis)
+    N, d = C.shape[:2]
+    Gamma = np.asarray(Gamma)
+    lead = Gamma.shape[:-2]
+    out = np.empty(lead + (N, N))
+    for index in np.ndindex(*lead):
+        D = np.tensordot(Gamma[index], C, axes=(1, 0))                 # (N, d, d): D_k
+        G1 = np.einsum('kab,kbc->ac', C, D)
+        G2 = np.einsum('kab,kbc->ac', D, C)
+        KX = np.matmul(G1, C) + np.matmul(C, G2)                       # (N, d, d): G1 C_j + C_j G2
+        # sum_k C_k X D_k for every X = C_j: (k a b)(j b c)(k c e) -> (j a e), as two batched products
+        left = np.tensordot(C, C, axes=(2, 1))                         # [k, a, j, c] = (C_k C_j)[a, c]
+        KX -= np.einsum('kajc,kce->jae', left, D, optimize=True)
+        left = np.tensordot(D, C, axes=(2, 1))                         # [k, a, j, c] = (D_k C_j)[a, c]
+        KX -= np.einsum('kajc,kce->jae', left, C, optimize=True)
+        out[index] = -0.5*np.einsum('iab,jba->ij', C, KX, optimize=True).real
+    return out
+
+
 def error_transfer_matrix(K):
     """exp(sum over all but the last two axes of K), filter_functions/numeric.py:2049-2053."""
     from scipy.linalg import expm

@@ -220,6 +220,8 @@ def test_decay_amplitudes_cumulant_and_error_transfer_matrix(name, single_qubit)
             # the reference's single-qubit shortcut differs from it for cross-correlated spectra
             # before the sum over operator pairs
             assert rel_err(orc.cumulant_function(gamma, basis), K_ref) < 1e-14
+            # (the form the GPU tests use above d = 16, where the other two are out of reach)
+            assert rel_err(orc.cumulant_function_matrix_form(gamma, basis), K_ref) < 1e-14
         K_sum = orc.cumulant_function(gamma, basis).sum(axis=tuple(range(gamma.ndim - 2)))
         assert np.abs(K_sum - K_ref.sum(axis=tuple(range(gamma.ndim - 2)))).max() < 1e-20
         U = orc.error_transfer_matrix(orc.cumulant_function_dense(gamma, basis, single_qubit))

@@ -36,6 +36,9 @@ DROP = os.environ.get("GEN_PQ_DROP", "")
 # sets of four frequencies a consumer owns (2: eight consumers per block, two per SIMD -- the shipped kernel;
 # 4: four consumers, one per SIMD, 72 accumulator registers -- ctrl_pq.hip -DFFK_PQ_SETS=4)
 NSETS = int(os.environ.get("GEN_PQ_SETS", "2"))
+# trace build (ctrl_pq.hip -DFFK_PQ_CLOCK, tools/trace_pq.py): s_memtime into the SGPR pairs %[t0] .. %[t7] at eight
+# points of the block; the stamps ride in the same in-order count as the LDS operations
+STAMPS = os.environ.get("GEN_PQ_STAMPS", "") == "1"
 ZR = [4*a for a in range(NC)]
 ZI = [4*a + 2 for a in range(NC)]
 ZS = [12 + 2*a for a in range(NC)]
@@ -66,7 +69,24 @@ def acc(a, s, k):
 
 # the LDS queue at block entry: what the previous block left in flight (after the C++ prologue or a spin on
 # a flag everything is complete and the waits are satisfied at once)
-ENTRY = ['T', 'psi', 'q01'] + ['w0']*NC + ['w1']*NC + ['q23'] + ['w2']*NC + ['w3']*NC + ['done', 'prog']
+ENTRY = ['w0']*NC + ['T', 'psi', 'q01'] + ['w1']*NC + ['w2']*NC + ['q23'] + ['w3']*NC + ['done', 'prog']
+
+
+# logical operands of the block: asm operands in the per-tile form, fixed registers in the whole-loop form
+TILE_OPERANDS = {k: f'%[{k}]' for k in ('a_w', 'a_p', 'a_q0', 'a_q1', 'a_q2', 'a_q3', 'a_p1', 'a_flag', 'a_partner', 'a_done', 'a_prog',
+                                        'progress', 'one', 'flag', 'partner')}
+LOOP_V = dict(a_w='v124', a_q0='v125', a_p='v126', a_q1='v127', a_p1='v128', a_flag='v129', a_done='v130',
+              progress='v131', a_partner='v132', a_prog='v133', one='v134', flag='v135', partner='v136',
+              b_w='v138', b_q0='v139', b_q1='v140', b_p='v141', spin='v137')
+LOOP_S = dict(nit='s36', limit='s37', flags='s38', me='s39', it='s40', cur='s41', nxt='s42', t='s43', fnext='s44',
+              p='s45', prio='s46', want='s47', fault='s48', spin='s49', t2='s50', has='s51')
+LOCKSTEP = int(os.environ.get('GEN_PQ_LOCKSTEP', '2'))
+TILE_BYTES = (1152 + NC*128 + 32)*8          # ctrl_pq.hip: pq_tile_doubles(NC) * 8 (checked there)
+OPS = dict(TILE_OPERANDS)
+
+
+def O(name):
+    return OPS[name]
 
 
 class Stream:
@@ -85,6 +105,10 @@ class Stream:
         self.lines.append(text)
         self.fifo.append(tag)
 
+    def stamp(self, k):
+        if STAMPS:
+            self.lds(f's_memtime %[t{k}]', 'stamp')
+
     def need(self, *tags):
         """wait until the operations tagged `tags` are done (the LDS queue is in order)"""
         last = max((i for i, t in enumerate(self.fifo) if t in tags), default=None)
@@ -98,30 +122,44 @@ class Stream:
             self.fifo = self.fifo[len(self.fifo) - 15:]
 
 
-def next_tile_requests(st):
-    st.lds(f'ds_read_b128 {v4(T)}, %[a_w] offset:{T_OFF}', 'T')
-    st.lds(f'ds_read_b128 {v4(PSI)}, %[a_p]', 'psi')
-    st.lds(f'ds_read_b128 {v4(Q01)}, %[a_q0]', 'q01')
-    for n in (0, 1):
+def next_tile_requests(st, stage):
+    """The next tile's operands, each requested right behind the LAST use of the registers it lands in (the last
+    set's vector stages): W[.][n] is dead after stage n + 1, T, psi and q01 after stage 2, q23 after stage 4.
+    (All 16 in one burst behind stage 4 cost 3.7 us of the consumers' 54.7: profiles/r05_b_*.)"""
+    if DROP == 'next':
+        return
+    def w(n):
         for a in range(NC):
-            st.lds(f'ds_read_b128 {v4(wre(a, n))}, %[a_w] offset:{a*W_BYTES + n*256}', f'w{n}')
-    st.lds(f'ds_read_b128 {v4(Q23)}, %[a_q0] offset:4096', 'q23')
-    for n in (2, 3):
-        for a in range(NC):
-            st.lds(f'ds_read_b128 {v4(wre(a, n))}, %[a_w] offset:{a*W_BYTES + n*256}', f'w{n}')
+            st.lds(f'ds_read_b128 {v4(wre(a, n))}, {O("a_w")} offset:{a*W_BYTES + n*256}', f'w{n}')
+    if stage == 1:
+        w(0)
+    elif stage == 2:
+        st.lds(f'ds_read_b128 {v4(T)}, {O("a_w")} offset:{T_OFF}', 'T')
+        st.lds(f'ds_read_b128 {v4(PSI)}, {O("a_p")}', 'psi')
+        st.lds(f'ds_read_b128 {v4(Q01)}, {O("a_q0")}', 'q01')
+        w(1)
+    elif stage == 3:
+        w(2)
+    elif stage == 4:
+        st.lds(f'ds_read_b128 {v4(Q23)}, {O("a_q0")} offset:4096', 'q23')
+        w(3)
 
 
-def vector_part(st, s):
+def vector_part(st, s, after_stage=None):
     q = [Q01, Q01 + 2, Q23, Q23 + 2]
     pr, pi = PSI, PSI + 2
     tr, ti = T, T + 2
     # stage 1
     st.need('T', 'psi', 'q01', 'w0')
+    if NSETS == 2:
+        st.stamp(1 if s == 0 else 4)
     st.emit(f'v_mul_f64 {v(CR)}, {v(pi)}, {v(ti)}')
     st.emit(f'v_mul_f64 {v(CI)}, {v(pi)}, {v(tr)}')
     for a in range(NC):
         st.emit(f'v_mul_f64 {v(ZR[a])}, {v(q[0])}, {v(wre(a, 0))}')
         st.emit(f'v_mul_f64 {v(ZI[a])}, {v(q[0])}, {v(wre(a, 0) + 2)}')
+    if after_stage:
+        after_stage(1)
     # stage 2
     st.need('w1')
     st.emit(f'v_fma_f64 {v(CR)}, {v(pr)}, {v(tr)}, {v(CR)}')
@@ -129,62 +167,231 @@ def vector_part(st, s):
     for a in range(NC):
         st.emit(f'v_fma_f64 {v(ZR[a])}, {v(q[1])}, {v(wre(a, 1))}, {v(ZR[a])}')
         st.emit(f'v_fma_f64 {v(ZI[a])}, {v(q[1])}, {v(wre(a, 1) + 2)}, {v(ZI[a])}')
+    if after_stage:
+        after_stage(2)
     # stage 3
     st.need('q23', 'w2')
     st.emit(f'v_add_f64 {v(CS)}, {v(CR)}, {v(CI)}')
     for a in range(NC):
         st.emit(f'v_fma_f64 {v(ZR[a])}, {v(q[2])}, {v(wre(a, 2))}, {v(ZR[a])}')
         st.emit(f'v_fma_f64 {v(ZI[a])}, {v(q[2])}, {v(wre(a, 2) + 2)}, {v(ZI[a])}')
+    if after_stage:
+        after_stage(3)
     # stage 4
     st.need('w3')
     for a in range(NC):
         st.emit(f'v_fma_f64 {v(ZR[a])}, {v(q[3])}, {v(wre(a, 3))}, {v(ZR[a])}')
         st.emit(f'v_fma_f64 {v(ZI[a])}, {v(q[3])}, {v(wre(a, 3) + 2)}, {v(ZI[a])}')
+    if after_stage:
+        after_stage(4)
 
 
-def matrix_part(st, s):
+def matrix_part(st, s, glue=()):
+    """the nine matrix instructions of a set; `glue`: scalar / address instructions of the loop form, dealt out
+    behind the matrix instructions (they issue while the matrix pipe works)"""
+    if NSETS == 2:
+        st.stamp(2 if s == 0 else 5)
     for a in range(NC):
         st.emit(f'v_add_f64 {v(ZS[a])}, {v(ZR[a])}, {v(ZI[a])}')
+    glue = list(glue)
+    per = -(-len(glue)//(3*NC)) if glue else 0
     for a in range(NC):
-        st.emit(f'v_mfma_f64_4x4x4_4b_f64 {v(acc(a, s, 0))}, {v(CR)}, {v(ZR[a])}, {v(acc(a, s, 0))}')
-        st.emit(f'v_mfma_f64_4x4x4_4b_f64 {v(acc(a, s, 1))}, {v(CI)}, {v(ZI[a])}, {v(acc(a, s, 1))}')
-        st.emit(f'v_mfma_f64_4x4x4_4b_f64 {v(acc(a, s, 2))}, {v(CS)}, {v(ZS[a])}, {v(acc(a, s, 2))}')
+        for k, (src_a, src_b) in enumerate(((CR, ZR[a]), (CI, ZI[a]), (CS, ZS[a]))):
+            st.emit(f'v_mfma_f64_4x4x4_4b_f64 {v(acc(a, s, k))}, {v(src_a)}, {v(src_b)}, {v(acc(a, s, k))}')
+            for _ in range(per):
+                if glue:
+                    item = glue.pop(0)          # a tuple: instructions with branches among them, kept together
+                    for line in ((item,) if isinstance(item, str) else item):
+                        st.emit(line)
+    assert not glue
+    if NSETS == 2:
+        st.stamp(3 if s == 0 else 6)
 
 
 def build(last):
     """one tile; `last`: no next tile to request (the last tile of the block)"""
     # what the previous block (or the C++ prologue, all of it complete) left in the queue
     st = Stream(ENTRY)
-    st.lds('ds_read_b32 %[flag], %[a_flag]', 'flag')
-    st.lds('ds_read_b32 %[partner], %[a_partner]', 'partner')
+    st.stamp(0)
+    st.lds(f'ds_read_b32 {O("flag")}, {O("a_flag")}', 'flag')
+    st.lds(f'ds_read_b32 {O("partner")}, {O("a_partner")}', 'partner')
     for s_ in range(NSETS - 1):
-        vector_part(st, s_)
-        # the next set's q, psi into the registers this set is done with; they arrive during its nine matrix
-        # instructions
-        st.lds(f'ds_read_b128 {v4(PSI)}, %[a_p1] offset:{64*s_}', 'psi')
-        st.lds(f'ds_read_b128 {v4(Q01)}, %[a_q{s_ + 1}]', 'q01')
-        st.lds(f'ds_read_b128 {v4(Q23)}, %[a_q{s_ + 1}] offset:4096', 'q23')
+        # the next set's psi, q01 behind stage 2 (their registers' last use), q23 behind stage 4: they arrive during
+        # the rest of the set and its nine matrix instructions
+        def inner(stage, s_=s_):
+            if stage == 2:
+                st.lds(f'ds_read_b128 {v4(PSI)}, {O("a_p1")} offset:{64*s_}', 'psi')
+                st.lds(f'ds_read_b128 {v4(Q01)}, {O("a_q" + str(s_ + 1))}', 'q01')
+            elif stage == 4:
+                st.lds(f'ds_read_b128 {v4(Q23)}, {O("a_q" + str(s_ + 1))} offset:4096', 'q23')
+        vector_part(st, s_, inner)
         matrix_part(st, s_)
         # T and W are still this tile's: only q01, q23, psi have to arrive
-        st.fifo = [t if t in ('q01', 'q23', 'psi', 'flag', 'partner') else 'old' for t in st.fifo]
-    vector_part(st, NSETS - 1)
-    # every operand register is dead: the next tile's operands fly during the matrix instructions and the hand-over
-    assert not st.fifo, st.fifo
-    if not last and DROP != 'next':
-        next_tile_requests(st)
-    elif DROP == 'next':
+        st.fifo = [t if t in ('q01', 'q23', 'psi', 'flag', 'partner', 'stamp') else 'old' for t in st.fifo]
+    vector_part(st, NSETS - 1, None if last else (lambda stage: next_tile_requests(st, stage)))
+    if DROP == 'next':
         st.fifo = list(ENTRY[:-2])
     matrix_part(st, NSETS - 1)
     # hand the slot back: lane 0 counts this consumer in and publishes its progress (LDS operations of a
     # wavefront execute in order: both are behind the tile's reads without a wait)
     st.emit('s_mov_b64 exec, 1')
-    st.lds('ds_add_u32 %[a_done], %[one]', 'done')
-    st.lds('ds_write_b32 %[a_prog], %[progress]', 'prog')
+    st.lds(f'ds_add_u32 {O("a_done")}, {O("one")}', 'done')
+    st.lds(f'ds_write_b32 {O("a_prog")}, {O("progress")}', 'prog')
     st.emit('s_mov_b64 exec, -1')
+    st.stamp(7)
     if last:
         st.emit('s_waitcnt lgkmcnt(0)')
+    elif STAMPS:
+        st.emit('s_waitcnt lgkmcnt(0)')     # (trace build: the stamps must have landed; the next block finds nothing in flight)
     else:
         assert st.fifo == ENTRY, st.fifo
+    return st
+
+
+def build_loop():
+    """The whole tile loop of a consumer as one block: no compiler-generated code between the tiles.  (With the tile
+    as the unit, ~35 scalar / address instructions sat between two blocks; beside a partner issuing 16-cycle matrix
+    instructions each of them waits its turn: ~580 of a tile's ~2000 cycles, profiles/r05_b_trace_6_*.)  The address
+    arithmetic of the next tile rides behind the matrix instructions; what is left between two tiles is the loop
+    branch.  Inputs s[36:39] = (tiles, spin limit, LDS address of the flags, consumer number), v[138:141] = LDS
+    addresses of this lane's W/T, q (set 0), q (set 1), psi in slot 0; the first tile's operands are in their
+    registers (prologue block).  Output s48: 0, or the fault code of a flag wait that ran out."""
+    assert NSETS == 2 and not STAMPS
+    global OPS
+    OPS = dict(LOOP_V)
+    V, S = LOOP_V, LOOP_S
+    st = Stream([])
+    e = st.emit
+    # ---- preamble ----
+    for r in ('it', 'cur', 'prio', 'fault', 'fnext'):
+        e(f's_mov_b32 {S[r]}, 0')
+    e(f'v_mov_b32 {V["flag"]}, 0')
+    e(f'v_mov_b32 {V["partner"]}, 0')
+    e(f'v_mov_b32 {V["one"]}, 1')
+    e(f's_xor_b32 {S["t"]}, {S["me"]}, 4')
+    e(f's_lshl_b32 {S["t"]}, {S["t"]}, 2')
+    e(f's_add_i32 {S["t"]}, {S["t"]}, {S["flags"]}')
+    e(f's_add_i32 {S["t"]}, {S["t"]}, 64')
+    e(f'v_mov_b32 {V["a_partner"]}, {S["t"]}')
+    e(f's_lshl_b32 {S["t"]}, {S["me"]}, 2')
+    e(f's_add_i32 {S["t"]}, {S["t"]}, {S["flags"]}')
+    e(f's_add_i32 {S["t"]}, {S["t"]}, 64')
+    e(f'v_mov_b32 {V["a_prog"]}, {S["t"]}')
+    e(f'v_mov_b32 {V["a_q1"]}, {V["b_q1"]}')
+    e(f'v_mov_b32 {V["a_p1"]}, {V["b_p"]}')
+    e(f's_add_i32 {S["t"]}, {S["flags"]}, 8')
+    e(f'v_mov_b32 {V["a_flag"]}, {S["t"]}')
+    e('L_tile%=:')
+    st.fifo = list(ENTRY)
+    st.lds(f'ds_read_b32 {V["flag"]}, {V["a_flag"]}', 'flag')
+    st.lds(f'ds_read_b32 {V["partner"]}, {V["a_partner"]}', 'partner')
+
+    def inner(stage):
+        if stage == 2:
+            st.lds(f'ds_read_b128 {v4(PSI)}, {V["a_p1"]} offset:64', 'psi')
+            st.lds(f'ds_read_b128 {v4(Q01)}, {V["a_q1"]}', 'q01')
+        elif stage == 4:
+            st.lds(f'ds_read_b128 {v4(Q23)}, {V["a_q1"]} offset:4096', 'q23')
+    vector_part(st, 0, inner)
+    glue0 = [
+        f's_add_i32 {S["t2"]}, {S["it"]}, 1',
+        f's_cmp_lt_i32 {S["t2"]}, {S["nit"]}',
+        f's_cselect_b32 {S["has"]}, 1, 0',
+        f's_and_b32 {S["t"]}, {S["t2"]}, 7',
+        f's_mul_i32 {S["t"]}, {S["t"]}, {TILE_BYTES}',
+        f's_cmp_eq_u32 {S["has"]}, 1',
+        f's_cselect_b32 {S["nxt"]}, {S["t"]}, {S["cur"]}',       # the last tile requests its own slot once more
+        f'v_add_u32_e32 {V["a_w"]}, {S["nxt"]}, {V["b_w"]}',
+        f'v_add_u32_e32 {V["a_q0"]}, {S["nxt"]}, {V["b_q0"]}',
+        f'v_add_u32_e32 {V["a_p"]}, {S["nxt"]}, {V["b_p"]}',
+        # tile it + 1 published?  (its flag was read a tile ago; the slow path spins, bounded)
+        f's_add_i32 {S["t"]}, {S["it"]}, 2',
+        (f's_cmp_ge_i32 {S["fnext"]}, {S["t"]}',
+         's_cbranch_scc1 L_ready%=',
+         f's_cmp_eq_u32 {S["has"]}, 0',
+         's_cbranch_scc1 L_ready%=',
+         's_branch L_spin%=',
+         'L_ready%=:'),
+    ]
+    matrix_part(st, 0, glue0)
+    st.fifo = [t if t in ('q01', 'q23', 'psi', 'flag', 'partner') else 'old' for t in st.fifo]
+    vector_part(st, 1, lambda stage: next_tile_requests(st, stage))
+    glue1 = [
+        f'v_readfirstlane_b32 {S["fnext"]}, {V["flag"]}',        # flag of tile it + 2: the next tile's "next"
+        f'v_readfirstlane_b32 {S["p"]}, {V["partner"]}',
+        # whoever is behind its SIMD partner raises its priority (the partner's count was read at the top of this
+        # tile: the same distance as the per-tile form's, which compared a tile-old sample with it + 1)
+        f's_add_i32 {S["t"]}, {S["it"]}, {LOCKSTEP}',
+        f's_cmp_gt_i32 {S["p"]}, {S["t"]}',
+        f's_cselect_b32 {S["want"]}, 1, 0',
+        (f's_cmp_eq_u32 {S["want"]}, {S["prio"]}',
+         's_cbranch_scc1 L_prio_done%=',
+         f's_mov_b32 {S["prio"]}, {S["want"]}',
+         f's_cmp_eq_u32 {S["want"]}, 1',
+         's_cbranch_scc1 L_prio_hi%=',
+         's_setprio 0',
+         's_branch L_prio_done%=',
+         'L_prio_hi%=:',
+         's_setprio 1',
+         'L_prio_done%=:'),
+        # the hand-over's operands
+        f's_and_b32 {S["t"]}, {S["it"]}, 7',
+        f's_lshl_b32 {S["t"]}, {S["t"]}, 2',
+        f's_add_i32 {S["t"]}, {S["t"]}, {S["flags"]}',
+        f's_add_i32 {S["t"]}, {S["t"]}, 32',
+        f'v_mov_b32 {V["a_done"]}, {S["t"]}',
+        f's_add_i32 {S["t"]}, {S["it"]}, 1',
+        f'v_mov_b32 {V["progress"]}, {S["t"]}',
+        # the next iteration: flag of tile it + 3, this iteration's "next" becomes "current"
+        f's_add_i32 {S["t"]}, {S["it"]}, 3',
+        f's_and_b32 {S["t"]}, {S["t"]}, 7',
+        f's_lshl_b32 {S["t"]}, {S["t"]}, 2',
+        f's_add_i32 {S["t"]}, {S["t"]}, {S["flags"]}',
+        f'v_mov_b32 {V["a_flag"]}, {S["t"]}',
+        f'v_add_u32_e32 {V["a_q1"]}, {S["nxt"]}, {V["b_q1"]}',
+        f'v_mov_b32 {V["a_p1"]}, {V["a_p"]}',
+        f's_mov_b32 {S["cur"]}, {S["nxt"]}',
+    ]
+    matrix_part(st, 1, glue1)
+    e('s_mov_b64 exec, 1')
+    st.lds(f'ds_add_u32 {V["a_done"]}, {V["one"]}', 'done')
+    st.lds(f'ds_write_b32 {V["a_prog"]}, {V["progress"]}', 'prog')
+    e('s_mov_b64 exec, -1')
+    assert st.fifo == ENTRY, st.fifo
+    e(f's_add_i32 {S["it"]}, {S["it"]}, 1')
+    e(f's_cmp_lt_i32 {S["it"]}, {S["nit"]}')
+    e('s_cbranch_scc1 L_tile%=')
+    e('s_waitcnt lgkmcnt(0)')
+    e('s_setprio 0')
+    e('s_nop 15')
+    e('s_nop 15')
+    e('s_branch L_end%=')
+    # ---- slow path: tile it + 1 is not published yet ----
+    e('L_spin%=:')
+    e(f's_cmp_eq_u32 {S["limit"]}, 0')
+    e('s_cbranch_scc1 L_ready%=')                                # a wait ran out earlier: no more waiting
+    e(f's_and_b32 {S["t"]}, {S["t2"]}, 7')
+    e(f's_lshl_b32 {S["t"]}, {S["t"]}, 2')
+    e(f's_add_i32 {S["t"]}, {S["t"]}, {S["flags"]}')
+    e(f'v_mov_b32 {V["spin"]}, {S["t"]}')
+    e(f's_mov_b32 {S["spin"]}, 0')
+    e('L_spin_loop%=:')
+    e(f'ds_read_b32 {V["spin"]}, {V["spin"]}')                    # (address register reused for the value: reloaded below)
+    e('s_waitcnt lgkmcnt(0)')
+    e(f'v_readfirstlane_b32 {S["p"]}, {V["spin"]}')
+    e(f'v_mov_b32 {V["spin"]}, {S["t"]}')
+    e(f's_add_i32 {S["want"]}, {S["it"]}, 2')
+    e(f's_cmp_ge_i32 {S["p"]}, {S["want"]}')
+    e('s_cbranch_scc1 L_ready%=')
+    e('s_sleep 1')
+    e(f's_add_i32 {S["spin"]}, {S["spin"]}, 1')
+    e(f's_cmp_lt_u32 {S["spin"]}, {S["limit"]}')
+    e('s_cbranch_scc1 L_spin_loop%=')
+    e(f's_mov_b32 {S["fault"]}, 2')                               # kFaultPcConsumerWait
+    e(f's_mov_b32 {S["limit"]}, 0')
+    e('s_branch L_ready%=')
+    e('L_end%=:')
+    OPS = dict(TILE_OPERANDS)
     return st
 
 
@@ -203,7 +410,8 @@ def prologue():
     """the first tile's operands (the compiler then has no LDS read of its own pending on the fixed registers,
     and does not put a full wait in front of the loop's block)"""
     st = Stream([])
-    next_tile_requests(st)
+    for stage in (1, 2, 3, 4):
+        next_tile_requests(st, stage)
     st.emit('s_waitcnt lgkmcnt(0)')
     return st
 
@@ -212,6 +420,13 @@ def main():
     print('// GENERATED by tools/gen_pq_consumer.py -- do not edit; see that file for the register map.')
     dump('FFK_PQ_CONSUMER_ASM', build(False))
     dump('FFK_PQ_CONSUMER_PROLOGUE_ASM', prologue())
+    if NSETS == 2 and not STAMPS and not DROP:
+        dump('FFK_PQ_CONSUMER_LOOP_ASM', build_loop())
+        print(f'#define FFK_PQ_TILE_BYTES {TILE_BYTES}')
+        print('#define FFK_PQ_LOOP_CLOBBERS \\')
+        regs = [f'"v{r}"' for r in range(NTMP)] + [f'"v{r}"' for r in range(124, 138)]
+        regs += [f'"s{r}"' for r in list(range(40, 48)) + [49, 50, 51]] + ['"scc"', '"memory"']
+        print('    ' + ', '.join(regs))
     print('#define FFK_PQ_CONSUMER_CLOBBERS \\')
     print('    ' + ', '.join(f'"v{r}"' for r in range(NTMP)) + ', "memory"')
 

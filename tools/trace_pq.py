@@ -43,7 +43,7 @@ def main():
     t0 = int(tr[:nw, 0].min())
     print(f'block of {nw} wavefronts, grid ({st["grid_x"]}, {st["grid_y"]}, {st["grid_z"]})')
     for w in range(nw):
-        stamps = tr[w, 2:].reshape(-1, 4).astype(np.int64)
+        stamps = tr[w, 2:].reshape(-1, 12).astype(np.int64)[:, :4]
         used = np.nonzero(stamps[:, 3])[0]
         if used.size == 0:
             continue
@@ -55,12 +55,26 @@ def main():
         print(f'wave {w:2d} {role}: tiles {used.size:3d}  first top {s[0, 0]:7d}  last end {s[-1, 3]:7d}  '
               f'phases median {np.median(ph, axis=0).astype(int)}  between tiles {int(np.median(gap)) if gap.size else 0}  '
               f'tile period median {int(np.median(per)) if per.size else 0}')
+    # inside the generated block (GEN_PQ_STAMPS=1 build): top, operands in, set 0 vector done, set 0 matrix done,
+    # set 1 operands in, set 1 vector done, set 1 matrix done, hand-over issued
+    names = ['entry wait', 'set 0 vector', 'set 0 matrix', 'wait set 1', 'set 1 vector (+ requests)', 'set 1 matrix',
+             'hand-over']
+    for w in range(4, nw):
+        inner = tr[w, 2:].reshape(-1, 12).astype(np.int64)[:, 4:]
+        used = np.nonzero(inner[:, 7])[0]
+        if used.size < 4:
+            continue
+        ph = np.diff(inner[used], axis=1)
+        nxt = inner[used[1:], 0] - inner[used[:-1], 7]
+        print(f'wave {w:2d} inside the block, median cycles: ' +
+              ', '.join(f'{n} {int(v)}' for n, v in zip(names, np.median(ph, axis=0))) +
+              f'; end of block -> next block top {int(np.median(nxt))}')
     print('per-tile stamps of wave 4 (consumer), first 12 tiles:')
-    s = tr[4, 2:].reshape(-1, 4).astype(np.int64)
+    s = tr[4, 2:].reshape(-1, 12).astype(np.int64)[:, :4]
     for it in np.nonzero(s[:, 3])[0][:12]:
         print(f'  tile {it:3d}:', (s[it] - t0).tolist())
     print('per-tile stamps of wave 0 (producer), first 8 tiles:')
-    s = tr[0, 2:].reshape(-1, 4).astype(np.int64)
+    s = tr[0, 2:].reshape(-1, 12).astype(np.int64)[:, :4]
     for it in np.nonzero(s[:, 3])[0][:8]:
         print(f'  tile {it:3d}:', (s[it] - t0).tolist())
 
