@@ -79,6 +79,7 @@ __device__ __forceinline__ void pq_report_fault(int code) {
 #ifdef FFK_PQ_CLOCK   /* tuning build: s_memtime stamps of block (0, 0, 0), tools/trace_pq.py */
 constexpr int kPqTraceTiles = 64, kPqTraceStamps = 12, kPqTraceWaves = 16;   // 4 C++ stamps + 8 inside the asm block
 __device__ unsigned long long g_pq_trace[kPqTraceWaves*(2 + kPqTraceTiles*kPqTraceStamps)];
+__device__ unsigned long long g_pq_blocks[3*1024];   // per block: start, end of its last wavefront (100 MHz ticks), HW_ID | XCC_ID << 32
 #define FFK_PQ_STAMP(it, k)                                                                          \
     do {                                                                                              \
         if (pq_tr != nullptr && (it) < kPqTraceTiles) pq_tr[2 + (it)*kPqTraceStamps + (k)] = __builtin_amdgcn_s_memtime(); \
@@ -136,12 +137,22 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
 
     if (threadIdx.x < 3*kPqRing) *(volatile lds_int_t*)(ready + threadIdx.x) = 0;
     __syncthreads();
+#if defined(FFK_PQ_ABLATE) && FFK_PQ_ABLATE == 4   /* tuning: what does the launch cost with no work in it? */
+    if (n_it >= 0) return;
+#endif
 #ifdef FFK_PQ_CLOCK
     unsigned long long* pq_tr = nullptr;
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && wave < kPqTraceWaves) {
         pq_tr = g_pq_trace + wave*(2 + kPqTraceTiles*kPqTraceStamps);
         pq_tr[0] = __builtin_amdgcn_s_memtime();
         pq_tr[1] = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned pq_block = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);
+    if (threadIdx.x == 0 && pq_block < 1024) {
+        g_pq_blocks[3*pq_block] = __builtin_amdgcn_s_memrealtime();
+        g_pq_blocks[3*pq_block + 1] = 0;
+        g_pq_blocks[3*pq_block + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                                      (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11))) << 32);
     }
 #endif
 
@@ -359,7 +370,7 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
                          : [a_w] "v"(b_w), [a_p] "v"(b_p), [a_q0] "v"(b_q0)
                          : "memory");
         }
-#if defined(FFK_PQ_CONSUMER_LOOP_ASM) && !defined(FFK_PQ_CLOCK) && !defined(FFK_PQ_TILE_BLOCKS) && FFK_PQ_SETS == 2
+#if defined(FFK_PQ_CONSUMER_LOOP_ASM) && (!defined(FFK_PQ_CLOCK) || defined(FFK_PQ_LOOP_CLOCK)) && !defined(FFK_PQ_TILE_BLOCKS) && FFK_PQ_SETS == 2
         // ---- the whole tile loop as ONE block (FFK_PQ_TILE_BLOCKS: the per-tile form below, for A/B runs) ----
         static_assert(FFK_PQ_TILE_BYTES == TILE*8, "tools/gen_pq_consumer.py and pq_tile_doubles() disagree");
         if (n_it > 0) {
@@ -368,12 +379,28 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
             const int4_t varg = {static_cast<int>(b_w), static_cast<int>(b_q0), static_cast<int>(b_q1),
                                  static_cast<int>(b_p)};
             int fault_code;
+#ifdef FFK_PQ_LOOP_CLOCK   /* tuning (GEN_PQ_LOOP_CLOCK=1 block via -DFFK_PQ_CONSUMER_INC): s_memtime around the loop */
+            unsigned long long loop_t0, loop_t1;
+#define FFK_PQ_LOOP_STAMPS , "={s[52:53]}"(loop_t0), "={s[54:55]}"(loop_t1)
+#else
+#define FFK_PQ_LOOP_STAMPS
+#endif
             asm volatile(FFK_PQ_CONSUMER_LOOP_ASM
                          : "+{v[24:39]}"(W0v), "+{v[40:55]}"(W1v), "+{v[56:71]}"(W2v), "+{v[72:87]}"(Qv),
                            "+{v[88:103]}"(A0), "+{v[104:119]}"(A1), "+{v[120:123]}"(A2), "+{s[36:39]}"(sarg),
-                           "={s48}"(fault_code)
+                           "={s48}"(fault_code) FFK_PQ_LOOP_STAMPS
                          : "{v[138:141]}"(varg)
                          : FFK_PQ_LOOP_CLOBBERS);
+#undef FFK_PQ_LOOP_STAMPS
+#ifdef FFK_PQ_LOOP_CLOCK
+            if (pq_tr != nullptr) {
+                pq_tr[2] = loop_t0;
+                pq_tr[3] = loop_t1;
+                pq_tr[4] = static_cast<unsigned long long>(n_it);
+                pq_tr[5] = __builtin_amdgcn_s_memtime();
+                pq_tr[6] = __builtin_amdgcn_s_memrealtime();
+            }
+#endif
             if (fault_code != 0) pq_report_fault(fault_code);
             (void)a_partner; (void)a_prog; (void)flag_v; (void)partner_v; (void)prio;
         }
@@ -520,9 +547,16 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
 #pragma unroll
         for (int s = 0; s < kPqSets; ++s) {
             const int iw = blockIdx.x*64 + wf + s*4;
+#if defined(FFK_PQ_ABLATE) && FFK_PQ_ABLATE == 3   /* tuning: the block's results are not stored (a never-true condition keeps them alive) */
+            if (iw < W && y[a][s].re == 1.2345e300) out[iw] = y[a][s];
+#else
             if (iw < W) out[iw] = y[a][s];
+#endif
         }
     }
+#ifdef FFK_PQ_CLOCK
+    if (lane == 0 && pq_block < 1024) atomicMax(&g_pq_blocks[3*pq_block + 1], __builtin_amdgcn_s_memrealtime());
+#endif
 }
 
 template <int NC>
@@ -568,6 +602,9 @@ hipError_t launch_accumulate_pq(const double* omega, int W, const double* segtab
 // (tuning build only, not in include/ffk.h) the last launch's stamps of block (0, 0, 0)
 extern "C" int ffk_debug_pq_trace(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ffk::g_pq_trace), sizeof(ffk::g_pq_trace)) != hipSuccess;
+}
+extern "C" int ffk_debug_pq_blocks(unsigned long long* out, int n_blocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ffk::g_pq_blocks), sizeof(unsigned long long)*3*n_blocks) != hipSuccess;
 }
 extern "C" int ffk_debug_pq_trace_words(void) { return static_cast<int>(sizeof(ffk::g_pq_trace)/8); }
 #endif

@@ -81,12 +81,24 @@ LOOP_V = dict(a_w='v124', a_q0='v125', a_p='v126', a_q1='v127', a_p1='v128', a_f
 LOOP_S = dict(nit='s36', limit='s37', flags='s38', me='s39', it='s40', cur='s41', nxt='s42', t='s43', fnext='s44',
               p='s45', prio='s46', want='s47', fault='s48', spin='s49', t2='s50', has='s51')
 LOCKSTEP = int(os.environ.get('GEN_PQ_LOCKSTEP', '2'))
+ROLLED = os.environ.get('GEN_PQ_ROLLED', '') == '1'                # the whole-loop block with run-time slot arithmetic (A/B)
+LOOP_CLOCK = os.environ.get('GEN_PQ_LOOP_CLOCK', '') == '1'     # s_memtime in s[52:53] / s[54:55] around the whole-loop block
 TILE_BYTES = (1152 + NC*128 + 32)*8          # ctrl_pq.hip: pq_tile_doubles(NC) * 8 (checked there)
 OPS = dict(TILE_OPERANDS)
 
 
+OFFS = {}                                     # unrolled loop form: the slot's byte offset rides in the instruction
+
+
 def O(name):
     return OPS[name]
+
+
+def A(name, offset=0):
+    """address operand of an LDS instruction: register and immediate offset"""
+    off = offset + OFFS.get(name, 0)
+    assert 0 <= off < 65536
+    return f'{OPS[name]} offset:{off}' if off else OPS[name]
 
 
 class Stream:
@@ -130,18 +142,18 @@ def next_tile_requests(st, stage):
         return
     def w(n):
         for a in range(NC):
-            st.lds(f'ds_read_b128 {v4(wre(a, n))}, {O("a_w")} offset:{a*W_BYTES + n*256}', f'w{n}')
+            st.lds(f'ds_read_b128 {v4(wre(a, n))}, {A("a_w", a*W_BYTES + n*256)}', f'w{n}')
     if stage == 1:
         w(0)
     elif stage == 2:
-        st.lds(f'ds_read_b128 {v4(T)}, {O("a_w")} offset:{T_OFF}', 'T')
-        st.lds(f'ds_read_b128 {v4(PSI)}, {O("a_p")}', 'psi')
-        st.lds(f'ds_read_b128 {v4(Q01)}, {O("a_q0")}', 'q01')
+        st.lds(f'ds_read_b128 {v4(T)}, {A("a_w", T_OFF)}', 'T')
+        st.lds(f'ds_read_b128 {v4(PSI)}, {A("a_p")}', 'psi')
+        st.lds(f'ds_read_b128 {v4(Q01)}, {A("a_q0")}', 'q01')
         w(1)
     elif stage == 3:
         w(2)
     elif stage == 4:
-        st.lds(f'ds_read_b128 {v4(Q23)}, {O("a_q0")} offset:4096', 'q23')
+        st.lds(f'ds_read_b128 {v4(Q23)}, {A("a_q0", 4096)}', 'q23')
         w(3)
 
 
@@ -281,6 +293,9 @@ def build_loop():
     e(f'v_mov_b32 {V["a_p1"]}, {V["b_p"]}')
     e(f's_add_i32 {S["t"]}, {S["flags"]}, 8')
     e(f'v_mov_b32 {V["a_flag"]}, {S["t"]}')
+    if LOOP_CLOCK:
+        e('s_memtime s[52:53]')
+        e('s_waitcnt lgkmcnt(0)')
     e('L_tile%=:')
     st.fifo = list(ENTRY)
     st.lds(f'ds_read_b32 {V["flag"]}, {V["a_flag"]}', 'flag')
@@ -363,6 +378,9 @@ def build_loop():
     e('s_cbranch_scc1 L_tile%=')
     e('s_waitcnt lgkmcnt(0)')
     e('s_setprio 0')
+    if LOOP_CLOCK:
+        e('s_memtime s[54:55]')
+        e('s_waitcnt lgkmcnt(0)')
     e('s_nop 15')
     e('s_nop 15')
     e('s_branch L_end%=')
@@ -395,6 +413,128 @@ def build_loop():
     return st
 
 
+def build_loop_unrolled():
+    """The whole-loop block unrolled over the ring's eight slots: every LDS address of a tile is a per-lane base
+    register (slots 0-3: the inputs v[138:141]; slots 4-7: the same plus four tiles) and an immediate offset, flags
+    and counters are immediates too.  What is left of the loop's bookkeeping per tile: the test of the next tile's
+    flag, the partner priority, the progress counter and the loop count -- ~16 instructions instead of 48 (a
+    wavefront does not issue in the shadow of its own matrix instructions, tools/fp64_issue_probe.py: every one of
+    them lengthens the consumer's chain).  Same inputs and outputs as build_loop()."""
+    assert NSETS == 2 and not STAMPS
+    global OPS, OFFS
+    V, S = LOOP_V, LOOP_S
+    v_flags = V['a_flag']
+    half = [dict(a_w=V['b_w'], a_q0=V['b_q0'], a_q1=V['b_q1'], a_p=V['b_p']),
+            dict(a_w=V['a_w'], a_q0=V['a_q0'], a_q1=V['a_q1'], a_p=V['a_p'])]
+    st = Stream([])
+    e = st.emit
+    for r in ('it', 'prio', 'fault', 'fnext'):
+        e(f's_mov_b32 {S[r]}, 0')
+    for r in ('flag', 'partner', 'progress'):
+        e(f'v_mov_b32 {V[r]}, 0')
+    e(f'v_mov_b32 {V["one"]}, 1')
+    e(f'v_mov_b32 {v_flags}, {S["flags"]}')
+    e(f's_xor_b32 {S["t"]}, {S["me"]}, 4')
+    e(f'v_lshl_add_u32 {V["a_partner"]}, {S["t"]}, 2, {v_flags}')
+    e(f'v_lshl_add_u32 {V["a_prog"]}, {S["me"]}, 2, {v_flags}')
+    for name in ('a_w', 'a_q0', 'a_q1', 'a_p'):
+        e(f'v_add_u32_e32 {half[1][name]}, {4*TILE_BYTES}, {half[0][name]}')
+    if LOOP_CLOCK:
+        e('s_memtime s[52:53]')
+        e('s_waitcnt lgkmcnt(0)')
+    for k in range(8):
+        cur, nxt = k, (k + 1) & 7
+        e(f'L_slot{k}_%=:')
+        st.fifo = list(ENTRY)
+        OPS = dict(LOOP_V)
+        OPS.update(a_q1=half[cur >> 2]['a_q1'], a_p1=half[cur >> 2]['a_p'],
+                   a_w=half[nxt >> 2]['a_w'], a_q0=half[nxt >> 2]['a_q0'], a_p=half[nxt >> 2]['a_p'])
+        OFFS = dict(a_q1=(cur & 3)*TILE_BYTES, a_p1=(cur & 3)*TILE_BYTES,
+                    a_w=(nxt & 3)*TILE_BYTES, a_q0=(nxt & 3)*TILE_BYTES, a_p=(nxt & 3)*TILE_BYTES)
+        st.lds(f'ds_read_b32 {V["flag"]}, {v_flags} offset:{4*((k + 2) & 7)}', 'flag')
+        st.lds(f'ds_read_b32 {V["partner"]}, {V["a_partner"]} offset:64', 'partner')
+
+        def inner(stage):
+            if stage == 2:
+                st.lds(f'ds_read_b128 {v4(PSI)}, {A("a_p1", 64)}', 'psi')
+                st.lds(f'ds_read_b128 {v4(Q01)}, {A("a_q1")}', 'q01')
+            elif stage == 4:
+                st.lds(f'ds_read_b128 {v4(Q23)}, {A("a_q1", 4096)}', 'q23')
+        vector_part(st, 0, inner)
+        # tile it + 1 published?  (its flag was read a tile ago; the slow path spins, bounded; no wait behind the last tile)
+        glue0 = [f's_add_i32 {S["t"]}, {S["it"]}, 2',
+                 (f's_cmp_ge_i32 {S["fnext"]}, {S["t"]}',
+                  f's_cbranch_scc1 L_ready{k}_%=',
+                  f's_add_i32 {S["t2"]}, {S["it"]}, 1',
+                  f's_cmp_ge_i32 {S["t2"]}, {S["nit"]}',
+                  f's_cbranch_scc1 L_ready{k}_%=',
+                  f's_branch L_spin{k}_%=',
+                  f'L_ready{k}_%=:')]
+        matrix_part(st, 0, glue0)
+        st.fifo = [t if t in ('q01', 'q23', 'psi', 'flag', 'partner') else 'old' for t in st.fifo]
+        vector_part(st, 1, lambda stage: next_tile_requests(st, stage))
+        glue1 = [f'v_readfirstlane_b32 {S["fnext"]}, {V["flag"]}',
+                 f'v_readfirstlane_b32 {S["p"]}, {V["partner"]}',
+                 f's_add_i32 {S["t"]}, {S["it"]}, {LOCKSTEP}',
+                 (f's_cmp_gt_i32 {S["p"]}, {S["t"]}',
+                  f's_cselect_b32 {S["want"]}, 1, 0',
+                  f's_cmp_eq_u32 {S["want"]}, {S["prio"]}',
+                  f's_cbranch_scc1 L_prio_done{k}_%=',
+                  f's_mov_b32 {S["prio"]}, {S["want"]}',
+                  f's_cmp_eq_u32 {S["want"]}, 1',
+                  f's_cbranch_scc1 L_prio_hi{k}_%=',
+                  's_setprio 0',
+                  f's_branch L_prio_done{k}_%=',
+                  f'L_prio_hi{k}_%=:',
+                  's_setprio 1',
+                  f'L_prio_done{k}_%=:'),
+                 f'v_add_u32_e32 {V["progress"]}, 1, {V["progress"]}']
+        matrix_part(st, 1, glue1)
+        e('s_mov_b64 exec, 1')
+        st.lds(f'ds_add_u32 {v_flags}, {V["one"]} offset:{32 + 4*k}', 'done')
+        st.lds(f'ds_write_b32 {V["a_prog"]}, {V["progress"]} offset:64', 'prog')
+        e('s_mov_b64 exec, -1')
+        assert st.fifo == ENTRY, st.fifo
+        e(f's_add_i32 {S["it"]}, {S["it"]}, 1')
+        e(f's_cmp_ge_i32 {S["it"]}, {S["nit"]}')
+        e('s_cbranch_scc1 L_exit%=')
+        if k == 7:
+            e('s_branch L_slot0_%=')
+    e('L_exit%=:')
+    e('s_waitcnt lgkmcnt(0)')
+    e('s_setprio 0')
+    if LOOP_CLOCK:
+        e('s_memtime s[54:55]')
+        e('s_waitcnt lgkmcnt(0)')
+    e('s_nop 15')
+    e('s_nop 15')
+    e('s_branch L_end%=')
+    for k in range(8):
+        # ---- slow path of slot k: tile it + 1 (slot k + 1) is not published yet ----
+        e(f'L_spin{k}_%=:')
+        e(f's_cmp_eq_u32 {S["limit"]}, 0')
+        e(f's_cbranch_scc1 L_ready{k}_%=')                        # a wait ran out earlier: no more waiting
+        e(f's_mov_b32 {S["spin"]}, 0')
+        e(f's_add_i32 {S["want"]}, {S["it"]}, 2')
+        e(f'L_spin_loop{k}_%=:')
+        e(f'ds_read_b32 {V["spin"]}, {v_flags} offset:{4*((k + 1) & 7)}')
+        e('s_waitcnt lgkmcnt(0)')
+        e(f'v_readfirstlane_b32 {S["p"]}, {V["spin"]}')
+        e(f's_cmp_ge_i32 {S["p"]}, {S["want"]}')
+        e(f's_cbranch_scc1 L_ready{k}_%=')
+        e('s_sleep 1')
+        e(f's_add_i32 {S["spin"]}, {S["spin"]}, 1')
+        e(f's_cmp_lt_u32 {S["spin"]}, {S["limit"]}')
+        e(f's_cbranch_scc1 L_spin_loop{k}_%=')
+        e(f's_mov_b32 {S["fault"]}, 2')                           # kFaultPcConsumerWait
+        e(f's_mov_b32 {S["limit"]}, 0')
+        e(f's_branch L_ready{k}_%=')
+    e('L_end%=:')
+    OPS = dict(TILE_OPERANDS)
+    OFFS = {}
+    return st
+
+
 def dump(name, st):
     n_valu = sum(1 for ln in st.lines if ln.startswith('v_') and 'mfma' not in ln)
     n_mfma = sum(1 for ln in st.lines if 'mfma' in ln)
@@ -421,7 +561,9 @@ def main():
     dump('FFK_PQ_CONSUMER_ASM', build(False))
     dump('FFK_PQ_CONSUMER_PROLOGUE_ASM', prologue())
     if NSETS == 2 and not STAMPS and not DROP:
-        dump('FFK_PQ_CONSUMER_LOOP_ASM', build_loop())
+        dump('FFK_PQ_CONSUMER_LOOP_ASM', build_loop() if ROLLED else build_loop_unrolled())
+        if LOOP_CLOCK:
+            print('#define FFK_PQ_LOOP_CLOCK 1')
         print(f'#define FFK_PQ_TILE_BYTES {TILE_BYTES}')
         print('#define FFK_PQ_LOOP_CLOBBERS \\')
         regs = [f'"v{r}"' for r in range(NTMP)] + [f'"v{r}"' for r in range(124, 138)]

@@ -42,6 +42,43 @@ def main():
     nw = st['block']//64
     t0 = int(tr[:nw, 0].min())
     print(f'block of {nw} wavefronts, grid ({st["grid_x"]}, {st["grid_y"]}, {st["grid_z"]})')
+    if 'blocks' in sys.argv[1:]:
+        # when does each block of the LAST launch start and end (100 MHz ticks), and where does it run?
+        nb = st['grid_x']*st['grid_y']*st['grid_z']
+        bb = (ctypes.c_ulonglong*(3*nb))()
+        assert raw.ffk_debug_pq_blocks(bb, nb) == 0
+        b = np.array(bb, dtype=np.uint64).reshape(nb, 3)
+        start, end = b[:, 0].astype(np.int64), b[:, 1].astype(np.int64)
+        first = start.min()
+        xcc, hw = (b[:, 2] >> np.uint64(32)).astype(np.int64), (b[:, 2] & np.uint64(0xffffffff)).astype(np.int64)
+        cu, se = (hw >> 8) & 15, (hw >> 13) & 7
+        places = {(int(x), int(s_), int(c)) for x, s_, c in zip(xcc, se, cu)}
+        q = lambda a: f'min {a.min()/100:.2f} median {np.median(a)/100:.2f} max {a.max()/100:.2f} us'
+        print(f'{nb} blocks on {len(places)} distinct (XCD, SE, CU) places')
+        print(f'start after the first block\'s start: {q(start - first)}')
+        print(f'duration of a block:                  {q(end - start)}')
+        print(f'end after the first block\'s start:   {q(end - first)}')
+        late = np.argsort(start)[-8:]
+        print('latest starters (block, start us, duration us, XCD/SE/CU):',
+              [(int(i), round((start[i] - first)/100, 2), round((end[i] - start[i])/100, 2), (int(xcc[i]), int(se[i]), int(cu[i]))) for i in late])
+        return
+    if 'loop' in sys.argv[1:]:
+        # whole-loop build (GEN_PQ_LOOP_CLOCK=1 block, -DFFK_PQ_CLOCK): the consumers stamp loop entry and exit only
+        for w in range(nw):
+            if w < 4:
+                stamps = tr[w, 2:].reshape(-1, 12).astype(np.int64)[:, :4]
+                used = np.nonzero(stamps[:, 3])[0]
+                s = stamps[used] - t0
+                print(f'wave {w:2d} producer: tiles {used.size:3d}  first top {s[0, 0]:7d}  first tile published {s[0, 3]:7d}  '
+                      f'last published {s[-1, 3]:7d}  waiting for a free slot, median {int(np.median(s[:, 2] - s[:, 1]))}')
+            else:
+                a, b, n_it = int(tr[w, 2]) - t0, int(tr[w, 3]) - t0, int(tr[w, 4])
+                print(f'wave {w:2d} consumer: loop entered at {a:7d}, left at {b:7d}: {n_it} tiles, {(b - a)/max(n_it, 1):7.1f} cycles per tile')
+        clock = (int(tr[:nw, 3].max()) - t0)
+        print(f'block: last consumer leaves its loop {clock} cycles after the first wavefront started')
+        ghz = [(int(tr[w, 5]) - int(tr[w, 0]))/((int(tr[w, 6]) - int(tr[w, 1]))*10.0) for w in range(4, nw)]
+        print(f'clock over the consumers\' lifetime (s_memtime / s_memrealtime): {min(ghz):.3f} .. {max(ghz):.3f} GHz')
+        return
     for w in range(nw):
         stamps = tr[w, 2:].reshape(-1, 12).astype(np.int64)[:, :4]
         used = np.nonzero(stamps[:, 3])[0]
