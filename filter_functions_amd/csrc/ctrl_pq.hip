@@ -163,7 +163,17 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
         // of their own iteration: every record of the row is then one broadcast ds_read away.  (Through
         // scalar loads the 41 doubles of a row do not fit the SGPR file at once; the compiler fetched them
         // in ten batches with a full wait after each -- 3.1 us per tile, profiles/r05_b_*.)
-        __builtin_amdgcn_s_setprio(3);
+        // Priority 0: the producers are the oldest wavefronts of their SIMDs and win the arbiter anyway, except against
+        // a consumer that is behind its partner.  (Priority 3, as the small kernels have it: kernel the same, step
+        // +1.3 %; consumers always above the producers: 71 us -- the producers alone make a tile per 1600 cycles, the
+        // consumers want one per 1430, and a starved ring costs more than it saves.  profiles/r05_l_*.)
+#ifndef FFK_PQ_PRODUCER_PRIO          /* tuning; FFK_PQ_PRODUCER_PRIO_LATER: from a producer's second tile on */
+#define FFK_PQ_PRODUCER_PRIO 0
+#endif
+#ifndef FFK_PQ_PRODUCER_PRIO_LATER
+#define FFK_PQ_PRODUCER_PRIO_LATER FFK_PQ_PRODUCER_PRIO
+#endif
+        __builtin_amdgcn_s_setprio(FFK_PQ_PRODUCER_PRIO);
         const int iw = blockIdx.x*64 + lane;
         const double om = omega[iw < W ? iw : W - 1];
         const int n_ops = (1 + n_alpha)*DD;            // <= 64: one staged element per lane
@@ -295,6 +305,8 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
             if (it < 2*kPqProducers)
 #endif
             if (lane == 0) *(volatile lds_int_t*)(ready + slot) = it + 1;
+            if (FFK_PQ_PRODUCER_PRIO_LATER != FFK_PQ_PRODUCER_PRIO && it == wave)
+                __builtin_amdgcn_s_setprio(FFK_PQ_PRODUCER_PRIO_LATER);
             FFK_PQ_STAMP(it, 3);
         }
         return;

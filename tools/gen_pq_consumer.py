@@ -81,6 +81,9 @@ LOOP_V = dict(a_w='v124', a_q0='v125', a_p='v126', a_q1='v127', a_p1='v128', a_f
 LOOP_S = dict(nit='s36', limit='s37', flags='s38', me='s39', it='s40', cur='s41', nxt='s42', t='s43', fnext='s44',
               p='s45', prio='s46', want='s47', fault='s48', spin='s49', t2='s50', has='s51')
 LOCKSTEP = int(os.environ.get('GEN_PQ_LOCKSTEP', '2'))
+MERGE_WAITS = os.environ.get('GEN_PQ_MERGE_WAITS', '') == '1'      # one wait per set instead of one per stage
+PRIO_EVERY = int(os.environ.get('GEN_PQ_PRIO_EVERY', '1'))          # partner priority every n-th tile (unrolled form)
+PRIO_LOW, PRIO_HIGH = (int(x) for x in os.environ.get('GEN_PQ_PRIOS', '0,1').split(','))   # consumer priorities: normal, behind its partner
 ROLLED = os.environ.get('GEN_PQ_ROLLED', '') == '1'                # the whole-loop block with run-time slot arithmetic (A/B)
 LOOP_CLOCK = os.environ.get('GEN_PQ_LOOP_CLOCK', '') == '1'     # s_memtime in s[52:53] / s[54:55] around the whole-loop block
 TILE_BYTES = (1152 + NC*128 + 32)*8          # ctrl_pq.hip: pq_tile_doubles(NC) * 8 (checked there)
@@ -162,7 +165,11 @@ def vector_part(st, s, after_stage=None):
     pr, pi = PSI, PSI + 2
     tr, ti = T, T + 2
     # stage 1
-    st.need('T', 'psi', 'q01', 'w0')
+    if MERGE_WAITS:
+        # everything the set reads (requested most of a tile ago): the later waits then find nothing to wait for
+        st.need('T', 'psi', 'q01', 'q23', 'w0', 'w1', 'w2', 'w3')
+    else:
+        st.need('T', 'psi', 'q01', 'w0')
     if NSETS == 2:
         st.stamp(1 if s == 0 else 4)
     st.emit(f'v_mul_f64 {v(CR)}, {v(pi)}, {v(ti)}')
@@ -442,17 +449,21 @@ def build_loop_unrolled():
     if LOOP_CLOCK:
         e('s_memtime s[52:53]')
         e('s_waitcnt lgkmcnt(0)')
+    if PRIO_LOW:
+        e(f's_setprio {PRIO_LOW}')
     for k in range(8):
         cur, nxt = k, (k + 1) & 7
         e(f'L_slot{k}_%=:')
-        st.fifo = list(ENTRY)
+        prio_here, prio_before = k % PRIO_EVERY == 0, ((k - 1) & 7) % PRIO_EVERY == 0
+        st.fifo = list(ENTRY if prio_before else ENTRY[:-1])
         OPS = dict(LOOP_V)
         OPS.update(a_q1=half[cur >> 2]['a_q1'], a_p1=half[cur >> 2]['a_p'],
                    a_w=half[nxt >> 2]['a_w'], a_q0=half[nxt >> 2]['a_q0'], a_p=half[nxt >> 2]['a_p'])
         OFFS = dict(a_q1=(cur & 3)*TILE_BYTES, a_p1=(cur & 3)*TILE_BYTES,
                     a_w=(nxt & 3)*TILE_BYTES, a_q0=(nxt & 3)*TILE_BYTES, a_p=(nxt & 3)*TILE_BYTES)
         st.lds(f'ds_read_b32 {V["flag"]}, {v_flags} offset:{4*((k + 2) & 7)}', 'flag')
-        st.lds(f'ds_read_b32 {V["partner"]}, {V["a_partner"]} offset:64', 'partner')
+        if prio_here:
+            st.lds(f'ds_read_b32 {V["partner"]}, {V["a_partner"]} offset:64', 'partner')
 
         def inner(stage):
             if stage == 2:
@@ -474,6 +485,9 @@ def build_loop_unrolled():
         st.fifo = [t if t in ('q01', 'q23', 'psi', 'flag', 'partner') else 'old' for t in st.fifo]
         vector_part(st, 1, lambda stage: next_tile_requests(st, stage))
         glue1 = [f'v_readfirstlane_b32 {S["fnext"]}, {V["flag"]}',
+                 f'v_add_u32_e32 {V["progress"]}, 1, {V["progress"]}']
+        if prio_here:
+            glue1 += [
                  f'v_readfirstlane_b32 {S["p"]}, {V["partner"]}',
                  f's_add_i32 {S["t"]}, {S["it"]}, {LOCKSTEP}',
                  (f's_cmp_gt_i32 {S["p"]}, {S["t"]}',
@@ -483,18 +497,18 @@ def build_loop_unrolled():
                   f's_mov_b32 {S["prio"]}, {S["want"]}',
                   f's_cmp_eq_u32 {S["want"]}, 1',
                   f's_cbranch_scc1 L_prio_hi{k}_%=',
-                  's_setprio 0',
+                  f's_setprio {PRIO_LOW}',
                   f's_branch L_prio_done{k}_%=',
                   f'L_prio_hi{k}_%=:',
-                  's_setprio 1',
-                  f'L_prio_done{k}_%=:'),
-                 f'v_add_u32_e32 {V["progress"]}, 1, {V["progress"]}']
+                  f's_setprio {PRIO_HIGH}',
+                  f'L_prio_done{k}_%=:')]
         matrix_part(st, 1, glue1)
         e('s_mov_b64 exec, 1')
         st.lds(f'ds_add_u32 {v_flags}, {V["one"]} offset:{32 + 4*k}', 'done')
-        st.lds(f'ds_write_b32 {V["a_prog"]}, {V["progress"]} offset:64', 'prog')
+        if prio_here:
+            st.lds(f'ds_write_b32 {V["a_prog"]}, {V["progress"]} offset:64', 'prog')
         e('s_mov_b64 exec, -1')
-        assert st.fifo == ENTRY, st.fifo
+        assert st.fifo == (ENTRY if prio_here else ENTRY[:-1]), st.fifo
         e(f's_add_i32 {S["it"]}, {S["it"]}, 1')
         e(f's_cmp_ge_i32 {S["it"]}, {S["nit"]}')
         e('s_cbranch_scc1 L_exit%=')
