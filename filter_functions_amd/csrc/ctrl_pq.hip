@@ -80,6 +80,11 @@ __device__ __forceinline__ void pq_report_fault(int code) {
 constexpr int kPqTraceTiles = 64, kPqTraceStamps = 12, kPqTraceWaves = 16;   // 4 C++ stamps + 8 inside the asm block
 __device__ unsigned long long g_pq_trace[kPqTraceWaves*(2 + kPqTraceTiles*kPqTraceStamps)];
 __device__ unsigned long long g_pq_blocks[3*1024];   // per block: start, end of its last wavefront (100 MHz ticks), HW_ID | XCC_ID << 32
+// every wavefront of every launch: start, end (100 MHz ticks), HW_ID | XCC_ID << 32, block | wave << 32 -- a ring over
+// the last ~21 launches, for the turn-around of a CU between the blocks of consecutive launches (tools/trace_pq.py cu)
+constexpr unsigned kPqWaveRing = 1u << 16;
+__device__ unsigned long long g_pq_waves[4*kPqWaveRing];
+__device__ unsigned g_pq_waves_head = 0;
 #define FFK_PQ_STAMP(it, k)                                                                          \
     do {                                                                                              \
         if (pq_tr != nullptr && (it) < kPqTraceTiles) pq_tr[2 + (it)*kPqTraceStamps + (k)] = __builtin_amdgcn_s_memtime(); \
@@ -148,6 +153,21 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
         pq_tr[1] = __builtin_amdgcn_s_memrealtime();
     }
     const unsigned pq_block = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z);
+    const unsigned long long pq_wave_start = __builtin_amdgcn_s_memrealtime();
+    auto pq_wave_record = [&]() {
+        if (lane != 0) return;
+        // (one atomic per wavefront on one address serialises the 3072 wavefronts of a launch: +27 us.)  Slot by launch
+        // number -- block 0 counts the launches -- block and wavefront; a wavefront that ends after the next launch's
+        // first block has started lands in that launch's slot and is overwritten there: one record lost
+        const unsigned seq = __hip_atomic_load(&g_pq_waves_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned at = ((seq & 15u)*4096u + (pq_block*12u + static_cast<unsigned>(wave))) & (kPqWaveRing - 1);
+        g_pq_waves[4*at] = pq_wave_start;
+        g_pq_waves[4*at + 1] = __builtin_amdgcn_s_memrealtime();
+        g_pq_waves[4*at + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                               (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11))) << 32);
+        g_pq_waves[4*at + 3] = pq_block | (static_cast<unsigned long long>(wave) << 32);
+    };
+    if (threadIdx.x == 0 && pq_block == 0) atomicAdd(&g_pq_waves_head, 1u);
     if (threadIdx.x == 0 && pq_block < 1024) {
         g_pq_blocks[3*pq_block] = __builtin_amdgcn_s_memrealtime();
         g_pq_blocks[3*pq_block + 1] = 0;
@@ -309,6 +329,9 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
                 __builtin_amdgcn_s_setprio(FFK_PQ_PRODUCER_PRIO_LATER);
             FFK_PQ_STAMP(it, 3);
         }
+#ifdef FFK_PQ_CLOCK
+        pq_wave_record();
+#endif
         return;
     }
 
@@ -568,6 +591,7 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
     }
 #ifdef FFK_PQ_CLOCK
     if (lane == 0 && pq_block < 1024) atomicMax(&g_pq_blocks[3*pq_block + 1], __builtin_amdgcn_s_memrealtime());
+    pq_wave_record();
 #endif
 }
 
@@ -617,6 +641,10 @@ extern "C" int ffk_debug_pq_trace(unsigned long long* out) {
 }
 extern "C" int ffk_debug_pq_blocks(unsigned long long* out, int n_blocks) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(ffk::g_pq_blocks), sizeof(unsigned long long)*3*n_blocks) != hipSuccess;
+}
+extern "C" int ffk_debug_pq_waves(unsigned long long* out, unsigned* head) {
+    if (hipMemcpyFromSymbol(head, HIP_SYMBOL(ffk::g_pq_waves_head), sizeof(unsigned)) != hipSuccess) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ffk::g_pq_waves), sizeof(ffk::g_pq_waves)) != hipSuccess;
 }
 extern "C" int ffk_debug_pq_trace_words(void) { return static_cast<int>(sizeof(ffk::g_pq_trace)/8); }
 #endif

@@ -24,13 +24,81 @@ from filter_functions_amd import _lib  # noqa: E402
 from filter_functions_amd.device import DevicePipeline  # noqa: E402
 
 
+def analyse_waves(w):
+    """per CU: life of a block (first wavefront in .. last wavefront out) and the idle time between consecutive blocks"""
+    # per launch (a slot of 4096 records): first wavefront in, last wavefront out
+    spans = []
+    for k in range(w.shape[0]//4096):
+        x = w[4096*k:4096*(k + 1)]
+        x = x[x[:, 1] > 0]
+        if x.shape[0] >= 3000:
+            spans.append((int(x[:, 0].min()), int(x[:, 1].max()), x.shape[0]))
+    spans.sort()
+    if len(spans) > 2:
+        st0 = np.array([a for a, _, _ in spans]); en0 = np.array([b for _, b, _ in spans])
+        print(f'{len(spans)} launches: first wavefront in -> last out median {np.median(en0 - st0)/100:.2f} us; '
+              f'launch to launch {np.median(np.diff(st0))/100:.2f} us (min {np.diff(st0).min()/100:.2f}, max {np.diff(st0).max()/100:.2f})')
+    w = w[w[:, 1] > 0]
+    start, end = w[:, 0].astype(np.int64), w[:, 1].astype(np.int64)
+    hw, xcc = (w[:, 2] & np.uint64(0xffffffff)).astype(np.int64), (w[:, 2] >> np.uint64(32)).astype(np.int64)
+    cu = xcc*1024 + ((hw >> 13) & 7)*16 + ((hw >> 8) & 15)
+    gaps, lives, first_to_first = [], [], []
+    for c in np.unique(cu):
+        m = cu == c
+        order = np.argsort(start[m])
+        st_, en_ = start[m][order], end[m][order]
+        # clusters of wavefronts that arrived within 2 us of each other = one block
+        cuts = np.nonzero(np.diff(st_) > 200)[0] + 1
+        b_start = np.array([x.min() for x in np.split(st_, cuts)])
+        b_end = np.array([x.max() for x in np.split(en_, cuts)])
+        n_w = np.array([x.size for x in np.split(st_, cuts)])
+        ok = n_w == 12
+        for i in range(len(b_start) - 1):
+            if ok[i] and ok[i + 1]:
+                gaps.append(b_start[i + 1] - b_end[i])
+                first_to_first.append(b_start[i + 1] - b_start[i])
+        lives.extend((b_end - b_start)[ok])
+    if 'detail' in sys.argv:
+        c = np.unique(cu)[5]
+        m = cu == c
+        order = np.argsort(start[m])
+        t0 = start[m].min()
+        blk = (w[m][:, 3] & np.uint64(0xffffffff)).astype(np.int64)[order]
+        wv = (w[m][:, 3] >> np.uint64(32)).astype(np.int64)[order]
+        for a, b, bl, ww in list(zip(start[m][order] - t0, end[m][order] - t0, blk, wv))[:60]:
+            print(f'   start {a/100:8.2f}  end {b/100:8.2f}  block {bl:4d} wave {ww:2d}')
+    q = lambda a: f'median {np.median(a)/100:.2f}  p10 {np.percentile(a, 10)/100:.2f}  p90 {np.percentile(a, 90)/100:.2f} us  (n = {len(a)})'
+    print(f'{len(np.unique(cu))} CUs, {w.shape[0]} wavefront records')
+    print('life of a block on its CU            ', q(np.array(lives)))
+    print('CU idle between consecutive blocks   ', q(np.array(gaps)))
+    print('block start to next block start      ', q(np.array(first_to_first)))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == 'waves':
+        analyse_waves(np.load(sys.argv[2]))       # FFK_BENCH_DUMP_PQ_WAVES=<file> python bench.py ... on a -DFFK_PQ_CLOCK build
+        return
     c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(**wl.CONFIG2)
     omega = wl.random_pulse_omega(dt, 4096)
     _lib.load()
     raw = ctypes.CDLL(_lib.LIB_PATH)
     stream = torch.cuda.current_stream().cuda_stream
     pipe = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, ff.Basis.pauli(2), omega, spectrum=1e-3/omega)
+    if 'cu' in sys.argv[1:]:
+        # the bench's schedule in small: two passes in flight on two streams, graph replay; then, per CU, the time
+        # between the last wavefront of one launch's block leaving and the first wavefront of the next launch's arriving
+        pipe2 = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, ff.Basis.pauli(2), omega, spectrum=1e-3/omega)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        g1, g2 = pipe.graph(), pipe2.graph()
+        for _ in range(300):
+            g1.launch(s1.cuda_stream)
+            g2.launch(s2.cuda_stream)
+        torch.cuda.synchronize()
+        ring = (ctypes.c_ulonglong*(4*65536))()
+        head = ctypes.c_uint(0)
+        assert raw.ffk_debug_pq_waves(ring, ctypes.byref(head)) == 0
+        analyse_waves(np.array(ring, dtype=np.uint64).reshape(-1, 4))
+        return
     for _ in range(2000):
         pipe.launch(stream=stream)
     torch.cuda.synchronize()
