@@ -63,7 +63,7 @@ __device__ __forceinline__ bool jacobi_rotation(cplx apq, double alpha, double* 
 // memory in ascending order, segment propagator P = V exp(-i D dt) V^dag to `P` (LDS or global).
 // Returns false if the Jacobi iteration clearly failed to converge.
 template <int D>
-__device__ bool eigh_expm_wave(EighState<D>& st, const cplx* __restrict__ Hg, double dtg, int lane,
+__device__ __forceinline__ bool eigh_expm_wave(EighState<D>& st, const cplx* __restrict__ Hg, double dtg, int lane,
                                double* __restrict__ eigvals_g, cplx* __restrict__ eigvecs_g,
                                cplx* P) {
     constexpr int DP = EighState<D>::DP;
@@ -282,7 +282,8 @@ __global__ __launch_bounds__(64) void eigh_expm_kernel(const cplx* __restrict__ 
                                                        double* __restrict__ eigvals,
                                                        cplx* __restrict__ eigvecs,
                                                        cplx* __restrict__ seg_prop,
-                                                       int* __restrict__ status) {
+                                                       int* __restrict__ status,
+                                                       int* __restrict__ fail_count) {
     __shared__ EighState<D> st;
     __builtin_amdgcn_s_setprio(3);     // see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
     const int g = blockIdx.x;
@@ -291,14 +292,59 @@ __global__ __launch_bounds__(64) void eigh_expm_kernel(const cplx* __restrict__ 
                                       eigvals + static_cast<size_t>(g)*D,
                                       eigvecs + static_cast<size_t>(g)*D*D,
                                       seg_prop + static_cast<size_t>(g)*D*D);
-    if (lane == 0) status[g] = ok ? 0 : 1;
+    if (lane == 0) {
+        status[g] = ok ? 0 : 1;
+        // (resident API path: a word in mapped host memory that the host zeroed before the launch -- the count of
+        // flagged segments without a memset, a counting kernel and their two launch floors; never taken when all is well)
+        if (!ok && fail_count != nullptr)
+            __hip_atomic_fetch_add(fail_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The same with the Hamiltonian summed in the kernel: H[g] = sum_i coeffs[i, g] opers[i] (pulse_sequence.py:1300-1302,
+// 'ijk,il->ljk', in operator order -- the order and the FMAs of the resident path's assemble_hamiltonian_kernel,
+// whose launch and whose separate copy of the controls this saves there).  A kernel of its own: the plain one's
+// registers and LDS are budgeted for running beside another pass's accumulate blocks.
+template <int D>
+__global__ __launch_bounds__(64) void eigh_expm_controls_kernel(const cplx* __restrict__ opers,
+                                                                const double* __restrict__ coeffs, int n_c,
+                                                                const double* __restrict__ dt, int G,
+                                                                double* __restrict__ eigvals,
+                                                                cplx* __restrict__ eigvecs,
+                                                                cplx* __restrict__ seg_prop,
+                                                                int* __restrict__ status,
+                                                                int* __restrict__ fail_count) {
+    __shared__ EighState<D> st;
+    __shared__ cplx Hs[D*D];
+    __builtin_amdgcn_s_setprio(3);     // see ffk_internal.h FFK_SMALL_KERNEL_PRIORITY
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int e = lane; e < D*D; e += 64) {
+        cplx acc = {0.0, 0.0};
+        for (int i = 0; i < n_c; ++i) {
+            const double c = coeffs[static_cast<size_t>(i)*G + g];
+            const cplx o = opers[i*D*D + e];
+            acc.re = fma(c, o.re, acc.re);
+            acc.im = fma(c, o.im, acc.im);
+        }
+        Hs[e] = acc;
+    }
+    wave_sync();
+    const bool ok = eigh_expm_wave<D>(st, Hs, dt[g], lane, eigvals + static_cast<size_t>(g)*D,
+                                      eigvecs + static_cast<size_t>(g)*D*D,
+                                      seg_prop + static_cast<size_t>(g)*D*D);
+    if (lane == 0) {
+        status[g] = ok ? 0 : 1;
+        if (!ok && fail_count != nullptr)
+            __hip_atomic_fetch_add(fail_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 template <int D>
 hipError_t launch_d(const cplx* H, const double* dt, int G, double* eigvals, cplx* eigvecs,
-                    cplx* seg_prop, int* status, hipStream_t stream) {
+                    cplx* seg_prop, int* status, int* fail_count, hipStream_t stream) {
     hipLaunchKernelGGL(eigh_expm_kernel<D>, dim3(G), dim3(64), 0, stream, H, dt, G, eigvals,
-                       eigvecs, seg_prop, status);
+                       eigvecs, seg_prop, status, fail_count);
     return hipGetLastError();
 }
 
@@ -327,14 +373,34 @@ hipError_t launch_count_failures(const int* status, int G, int32_t* out, hipStre
     return hipGetLastError();
 }
 
+bool eigh_fail_count_supported(int d) { return !generic_dimension(d); }
+
+hipError_t launch_eigh_expm_controls(const cplx* opers, const double* coeffs, int n_c, const double* dt, int G,
+                                     int d, double* eigvals, cplx* eigvecs, cplx* seg_prop, int* status,
+                                     hipStream_t stream, int* fail_count) {
+    switch (d) {
+#define FFK_CASE(D)                                                                                          \
+    case D:                                                                                                  \
+        hipLaunchKernelGGL(eigh_expm_controls_kernel<D>, dim3(G), dim3(64), 0, stream, opers, coeffs, n_c,   \
+                           dt, G, eigvals, eigvecs, seg_prop, status, fail_count);                           \
+        return hipGetLastError();
+        FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
+        FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
+        FFK_CASE(15) FFK_CASE(16)
+#undef FFK_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_eigh_expm(const cplx* H, const double* dt, int G, int d, double* eigvals,
-                            cplx* eigvecs, cplx* seg_prop, int* status, hipStream_t stream) {
+                            cplx* eigvecs, cplx* seg_prop, int* status, hipStream_t stream, int* fail_count) {
     if (generic_dimension(d))
         return launch_eigh_expm_generic(H, dt, G, d, eigvals, eigvecs, seg_prop, status, stream);
     switch (d) {
 #define FFK_CASE(D) \
     case D:         \
-        return launch_d<D>(H, dt, G, eigvals, eigvecs, seg_prop, status, stream);
+        return launch_d<D>(H, dt, G, eigvals, eigvecs, seg_prop, status, fail_count, stream);
         FFK_CASE(2) FFK_CASE(3) FFK_CASE(4) FFK_CASE(5) FFK_CASE(6) FFK_CASE(7) FFK_CASE(8)
         FFK_CASE(9) FFK_CASE(10) FFK_CASE(11) FFK_CASE(12) FFK_CASE(13) FFK_CASE(14)
         FFK_CASE(15) FFK_CASE(16)

@@ -15,6 +15,10 @@ int g_forced_chunks = 0;
 thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr, g_ev_gate = nullptr;
 thread_local cplx* g_fuse_F = nullptr;
 thread_local bool g_fuse_F_done = false;
+// hints of the resident API path (ffk_api_resident.hip) to the device-pointer calls it is built from:
+thread_local int* g_eigh_fail_count = nullptr;       // the eigensolver counts flagged segments into this mapped host word
+thread_local bool g_infid_spectrum_on_host = false;  // spectrum and idx of ffk_infidelity_dev are in mapped host memory
+thread_local EighControls g_eigh_controls = {nullptr, nullptr, 0};   // ffk_pipeline_dev's Hamiltonian, as its summands
 Arena g_arena;
 
 int fail(int code, const char* fmt, ...) {
@@ -345,7 +349,7 @@ int ffk_diagonalize_dev(const double* hamiltonian, const double* dt, int G, int 
     const DiagWs w = slice_diag_ws(workspace, workspace_bytes, G, d);
     const cplx* H = reinterpret_cast<const cplx*>(hamiltonian);
     FFK_HIP(ffk::launch_eigh_expm(H, dt, G, d, eigvals, reinterpret_cast<cplx*>(eigvecs), w.seg_prop,
-                                  w.status, s));
+                                  w.status, s, g_eigh_fail_count));
     if (ffk::use_fused_front(G, d)) {
         cplx* totals = static_cast<cplx*>(w.small);
         FFK_HIP(ffk::launch_scan_local(w.seg_prop, G, d, ffk::front_chunk(d), w.qloc, totals, s));
@@ -761,7 +765,8 @@ int ffk_infidelity_dev(const double* filter_function, int A, int W, const double
     FFK_REQUIRE(workspace_bytes >= ffk_infidelity_workspace_bytes(W, n_idx, s_ndim), "workspace too small");
     FFK_HIP(ffk::launch_infidelity(reinterpret_cast<const cplx*>(filter_function), A, W,
                                    reinterpret_cast<const cplx*>(spectrum), s_ndim, omega, idx, n_idx,
-                                   d, 0, infid, workspace, static_cast<hipStream_t>(stream)));
+                                   d, 0, infid, workspace, static_cast<hipStream_t>(stream),
+                                   g_infid_spectrum_on_host));
     return FFK_OK;
 }
 
@@ -900,8 +905,13 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
         hipStream_t s = static_cast<hipStream_t>(stream);
         const DiagWs w = slice_diag_ws(dws, dwsb, G, d);
         cplx* totals = static_cast<cplx*>(w.small);
+        if (g_eigh_controls.opers != nullptr && ffk::eigh_fail_count_supported(d))
+            FFK_HIP(ffk::launch_eigh_expm_controls(g_eigh_controls.opers, g_eigh_controls.coeffs, g_eigh_controls.n_c,
+                                                   dt, G, d, D, reinterpret_cast<cplx*>(V), w.seg_prop, w.status, s,
+                                                   g_eigh_fail_count));
+        else
         FFK_HIP(ffk::launch_eigh_expm(reinterpret_cast<const cplx*>(hamiltonian), dt, G, d, D,
-                                      reinterpret_cast<cplx*>(V), w.seg_prop, w.status, s));
+                                      reinterpret_cast<cplx*>(V), w.seg_prop, w.status, s, g_eigh_fail_count));
         FFK_HIP(ffk::launch_scan_local(w.seg_prop, G, d, ffk::front_chunk(d), w.qloc, totals, s));
         // same slicing as ffk_control_matrix_dev; the launch also compacts the basis (extra blocks)
         const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);

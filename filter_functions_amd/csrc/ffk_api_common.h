@@ -95,6 +95,14 @@ constexpr unsigned FFK_INTERNAL_COMPACT_DONE = 0x40000000u;
 // function should go if the expansion launch can produce it too, and whether it did
 extern thread_local cplx* g_fuse_F;
 extern thread_local bool g_fuse_F_done;
+extern thread_local int* g_eigh_fail_count;
+extern thread_local bool g_infid_spectrum_on_host;
+struct EighControls {
+    const ffk::cplx* opers;      // (n_c, d, d), device
+    const double* coeffs;        // (n_c, G), device
+    int n_c;
+};
+extern thread_local EighControls g_eigh_controls;
 
 // Scratch from the shared arena is handed to kernels on a non-blocking stream while g_arena.mu is
 // held; the lock may only be dropped once that stream has drained -- on EVERY exit path, also the

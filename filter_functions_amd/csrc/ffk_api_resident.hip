@@ -316,10 +316,12 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
     StreamDrain drain{s};      // (the successful path has synchronised already: a no-op then)
     const auto clock1 = std::chrono::steady_clock::now();
     auto dptr = [dp](size_t off) { return reinterpret_cast<double*>(dp + off); };
+    const bool count_on_host = ffk::eigh_fail_count_supported(d) && ffk::use_fused_front(G, d);
     // copies in, kernels, copies out: on `s`, no synchronisation
     auto enqueue = [&]() -> int {
         const double* Hdev = dptr(L.H);
-        if (on_device) {
+        const bool sum_in_eigensolver = on_device && count_on_host;     // (compiled d, fused front)
+        if (on_device && !sum_in_eigensolver) {
             // the controls first, so that the sum runs while the rest of the inputs is still in flight
             FFK_HIP(hipMemcpyAsync(dp + L.H, hp + L.H, ctrl_bytes, hipMemcpyHostToDevice, s));
             cplx* Hsum = reinterpret_cast<cplx*>(static_cast<unsigned char*>(ws) + wsb);
@@ -331,24 +333,39 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
             FFK_HIP(hipMemcpyAsync(dp + L.dt, hp + L.dt, L.inputs_end - L.dt, hipMemcpyHostToDevice, s));
             Hdev = reinterpret_cast<const double*>(Hsum);
         } else {
+            // one copy; with the controls in the Hamiltonian's slot the eigensolver sums them itself
             FFK_HIP(hipMemcpyAsync(dp, hp, L.inputs_end, hipMemcpyHostToDevice, s));
         }
-        if (int rc = ffk_pipeline_dev(Hdev, dptr(L.dt), dptr(L.t), G, d, dptr(L.omega), W,
-                                      dptr(L.basis), N, dptr(L.n_opers), A, dptr(L.n_coeffs), nullptr, 0,
-                                      nullptr, 0, dptr(L.D), dptr(L.V), dptr(L.Q), dptr(L.R), dptr(L.F),
-                                      nullptr, ws, wsb, s))
-            return rc;
-        if (int rc = ffk_eigensolver_status_dev(ws, wsb, G, d, reinterpret_cast<int32_t*>(dp + L.status), s))
-            return rc;
-        if (spectrum)
-            if (int rc = ffk_infidelity_dev(dptr(L.F), A, W, reinterpret_cast<const double*>(hp + o_spec), s_ndim,
-                                            dptr(L.omega), reinterpret_cast<const int32_t*>(hp + o_idx), n_idx,
-                                            d_inf, reinterpret_cast<double*>(hp + o_out),
-                                            static_cast<unsigned char*>(ws) + wsb + hsb, iwsb, s))
+        if (sum_in_eigensolver)
+            g_eigh_controls = {reinterpret_cast<const cplx*>(dp + L.H),
+                               reinterpret_cast<const double*>(dp + L.H + ctrl_opers), n_c};
+        // the eigensolver counts its flagged segments straight into the pinned block's status word (zeroed below,
+        // before the launch): no memset, no counting kernel, and the word stays out of the copy back
+        g_eigh_fail_count = count_on_host ? reinterpret_cast<int*>(hp + L.status) : nullptr;
+        const int rc_pass = ffk_pipeline_dev(Hdev, dptr(L.dt), dptr(L.t), G, d, dptr(L.omega), W,
+                                             dptr(L.basis), N, dptr(L.n_opers), A, dptr(L.n_coeffs), nullptr, 0,
+                                             nullptr, 0, dptr(L.D), dptr(L.V), dptr(L.Q), dptr(L.R), dptr(L.F),
+                                             nullptr, ws, wsb, s);
+        g_eigh_fail_count = nullptr;
+        g_eigh_controls = {nullptr, nullptr, 0};
+        if (rc_pass) return rc_pass;
+        if (!count_on_host)
+            if (int rc = ffk_eigensolver_status_dev(ws, wsb, G, d, reinterpret_cast<int32_t*>(dp + L.status), s))
                 return rc;
-        FFK_HIP(hipMemcpyAsync(hp + L.D, dp + L.D, L.outputs_end - L.D, hipMemcpyDeviceToHost, s));
+        if (spectrum) {
+            g_infid_spectrum_on_host = true;       // spectrum and idx are read from the pinned block
+            const int rc = ffk_infidelity_dev(dptr(L.F), A, W, reinterpret_cast<const double*>(hp + o_spec), s_ndim,
+                                              dptr(L.omega), reinterpret_cast<const int32_t*>(hp + o_idx), n_idx,
+                                              d_inf, reinterpret_cast<double*>(hp + o_out),
+                                              static_cast<unsigned char*>(ws) + wsb + hsb, iwsb, s);
+            g_infid_spectrum_on_host = false;
+            if (rc) return rc;
+        }
+        FFK_HIP(hipMemcpyAsync(hp + L.D, dp + L.D, (count_on_host ? L.status : L.outputs_end) - L.D,
+                               hipMemcpyDeviceToHost, s));
         return FFK_OK;
     };
+    if (count_on_host) *reinterpret_cast<volatile int32_t*>(hp + L.status) = 0;
     const ResidentGraphKey key{dev, G, d, W, N, A, hamiltonian ? 0 : n_c, on_device ? 1 : 0,
                                spectrum ? s_ndim : 0, spectrum ? n_idx : 0, spectrum ? d_inf : 0, dp, hp, ws, s,
                                g_knob_epoch.load()};
@@ -673,12 +690,15 @@ int ffk_resident_infidelity(ffk_resident* r, const double* spectrum, int s_ndim,
         const size_t iwsb = ffk_infidelity_workspace_bytes(W, n_idx, s_ndim);
         void* iws;
         rc = arena_reserve(iwsb, &iws);
-        if (!rc)
+        if (!rc) {
+            g_infid_spectrum_on_host = true;
             rc = ffk_infidelity_dev(reinterpret_cast<const double*>(dp + L.F), A, W,
                                     reinterpret_cast<const double*>(stage_ptr), s_ndim,
                                     reinterpret_cast<const double*>(dp + L.omega),
                                     reinterpret_cast<const int32_t*>(stage_ptr + o_idx), n_idx, d,
                                     reinterpret_cast<double*>(stage_ptr + o_out), iws, iwsb, s);
+            g_infid_spectrum_on_host = false;
+        }
         if (!rc) {
             const hipError_t e = hipStreamSynchronize(s);
             if (e != hipSuccess) rc = fail(FFK_EHIP, "infidelity failed: %s", hipGetErrorString(e));

@@ -51,8 +51,17 @@ void set_last_error(const char* message);
 // ---- eigh.hip --------------------------------------------------------------------------------
 // eigvals (G,d), eigvecs (G,d,d), seg_prop (G,d,d) = V exp(-i D dt) V^dag; status (G) ints:
 // 1 for every segment whose Jacobi iteration failed to converge, else 0.
+// fail_count (optional, compiled dimensions only: eigh_fail_count_supported): a counter in memory the kernel can
+// reach with a system-scope atomic, incremented per flagged segment (the caller zeroes it).
 hipError_t launch_eigh_expm(const cplx* H, const double* dt, int G, int d, double* eigvals,
-                            cplx* eigvecs, cplx* seg_prop, int* status, hipStream_t stream);
+                            cplx* eigvecs, cplx* seg_prop, int* status, hipStream_t stream,
+                            int* fail_count = nullptr);
+bool eigh_fail_count_supported(int d);
+// the same from control operators (n_c, d, d) and amplitudes (n_c, G): H[g] = sum_i coeffs[i, g] opers[i] is formed
+// in the kernel (compiled dimensions only)
+hipError_t launch_eigh_expm_controls(const cplx* opers, const double* coeffs, int n_c, const double* dt, int G,
+                                     int d, double* eigvals, cplx* eigvecs, cplx* seg_prop, int* status,
+                                     hipStream_t stream, int* fail_count = nullptr);
 // out[0] = number of non-zero entries of status (G): the device-resident paths' convergence check
 hipError_t launch_count_failures(const int* status, int G, int32_t* out, hipStream_t stream);
 // Chunk length of the two-kernel scan used by the fused front end (scan_local + fix-up fused
@@ -231,9 +240,12 @@ hipError_t launch_filter_function(const cplx* R, int A, int N, int W, int which,
 hipError_t launch_filter_function_weighted(const cplx* R, int A, int N, int W, const cplx* M,
                                            double scale, cplx* F, hipStream_t stream);
 size_t infidelity_workspace_bytes(int W, int n_idx, int s_ndim);
+// spectrum_on_host: S (and idx) live in mapped pinned HOST memory: the spectrum is staged through LDS with all of
+// a thread's reads in flight at once (every read is a trip over PCIe); same sums in the same order.
 hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_ndim,
                              const double* omega, const int32_t* idx, int n_idx, int d,
-                             int shard_width, double* infid, void* ws, hipStream_t stream);
+                             int shard_width, double* infid, void* ws, hipStream_t stream,
+                             bool spectrum_on_host = false);
 
 // ---- atomic.hip -----------------------------------------------------------------------------
 size_t from_atomic_workspace_bytes(int G, int A, int N, int W);

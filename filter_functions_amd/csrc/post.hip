@@ -498,6 +498,72 @@ __global__ __launch_bounds__(kInfidThreads) void infid_kernel(const cplx* __rest
     if (threadIdx.x == 0) infid[p] = (red[0]/2.0)/(2.0*3.141592653589793*d);
 }
 
+// The same integral with the spectrum in mapped pinned HOST memory (the resident API path hands it over
+// without a copy): infid_kernel's loop reads S[w], S[w + 1] per trip, sixteen dependent trips over PCIe per
+// thread -- 27 us where the device-resident spectrum takes 8 (profiles/r05_r_*).  Here a batch of 4096 spectrum
+// values goes through LDS first, every thread's 17 reads in flight together; then the same slots sum the same
+// terms in the same order (the batch is a multiple of the 1024 slots): bit-identical results.
+constexpr int kInfidStage = 4096;
+__global__ __launch_bounds__(kInfidThreads) void infid_host_spectrum_kernel(
+    const cplx* __restrict__ F, int A, int W, const cplx* __restrict__ S, int s_ndim,
+    const double* __restrict__ omega, const int32_t* __restrict__ idx, int n_idx, int d,
+    double* __restrict__ infid) {
+    __shared__ double red[kInfidSlots];
+    extern __shared__ __attribute__((aligned(16))) unsigned char stage_raw[];
+    cplx* sl = reinterpret_cast<cplx*>(stage_raw);       // [kInfidStage + 1]
+    const int p = blockIdx.x;
+    int ia, ib;
+    const cplx* Sp;
+    if (s_ndim == 3) {
+        ia = idx[p / n_idx];
+        ib = idx[p % n_idx];
+        Sp = S + static_cast<size_t>(p)*W;
+    } else {
+        ia = ib = idx[p];
+        Sp = S + (s_ndim == 2 ? static_cast<size_t>(p)*W : 0);
+    }
+    const cplx* Fp = F + (static_cast<size_t>(ia)*A + ib)*W;
+    constexpr int kPer = kInfidSlots/kInfidThreads;      // slots per thread
+    constexpr int kLoads = kInfidStage/kInfidThreads + 1;
+    double acc[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) acc[j] = 0.0;
+    for (int base = 0; base < W - 1; base += kInfidStage) {
+        const int n = min(kInfidStage + 1, W - base);
+        cplx v[kLoads];
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            const int i = threadIdx.x + kInfidThreads*k;
+            v[k] = i < n ? Sp[base + i] : cplx{0.0, 0.0};
+        }
+#pragma unroll
+        for (int k = 0; k < kLoads; ++k) {
+            const int i = threadIdx.x + kInfidThreads*k;
+            if (i < n) sl[i] = v[k];
+        }
+        __syncthreads();
+        const int wend = min(W - 1, base + kInfidStage);
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            for (int w = base + threadIdx.x + kInfidThreads*j; w < wend; w += kInfidSlots) {
+                const cplx f0 = Fp[w], f1 = Fp[w + 1], s0 = sl[w - base], s1 = sl[w + 1 - base];
+                const double i0 = f0.re*s0.re - f0.im*s0.im;
+                const double i1 = f1.re*s1.re - f1.im*s1.im;
+                acc[j] += (i1 + i0)*(omega[w + 1] - omega[w]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) red[threadIdx.x + kInfidThreads*j] = acc[j];
+    __syncthreads();
+    for (int s2 = kInfidSlots/2; s2 > 0; s2 >>= 1) {
+        for (int vv = threadIdx.x; vv < s2; vv += kInfidThreads) red[vv] += red[vv + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) infid[p] = (red[0]/2.0)/(2.0*3.141592653589793*d);
+}
+
 }  // namespace
 
 hipError_t launch_reduce_chunks(const cplx* Ypart, int chunks, size_t slab, cplx* Bt,
@@ -865,9 +931,19 @@ size_t infidelity_workspace_bytes(int W, int n_idx, int s_ndim) {
 
 hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_ndim,
                              const double* omega, const int32_t* idx, int n_idx, int d,
-                             int shard_width, double* infid, void* ws, hipStream_t stream) {
+                             int shard_width, double* infid, void* ws, hipStream_t stream,
+                             bool spectrum_on_host) {
     (void)ws;
     const int nout = s_ndim == 3 ? n_idx*n_idx : n_idx;
+    if (spectrum_on_host && shard_width <= 0) {
+        const int lds = static_cast<int>(sizeof(cplx))*(kInfidStage + 1);
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(infid_host_spectrum_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(infid_host_spectrum_kernel, dim3(nout), dim3(kInfidThreads), lds, stream, F, A, W, S,
+                           s_ndim, omega, idx, n_idx, d, infid);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(infid_kernel, dim3(nout), dim3(kInfidThreads), 0, stream, F, A, W, S, s_ndim, omega,
                        idx, n_idx, d, shard_width, infid);
     return hipGetLastError();

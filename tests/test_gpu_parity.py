@@ -2368,6 +2368,29 @@ def test_eigensolver_failure_is_reported_on_every_path():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize('W', [2, 1025, 4096, 4097, 9000])
+def test_resident_integral_with_the_spectrum_in_host_memory_is_bit_identical(W):
+    """The resident route hands the spectrum over in mapped pinned host memory and stages it through LDS in
+    batches of 4096 (infid_host_spectrum_kernel); the array route copies it to the device (infid_kernel).
+    Same slots, same order: the same bits -- across batch boundaries, for every spectrum rank."""
+    from filter_functions_amd import numeric
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, _ = config2_inputs(G=7, W=64)
+    omega = np.sort(np.random.default_rng(W).uniform(0.1, 30.0, W))
+    pulse = ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, ff.Basis.pauli(2))
+    F = pulse.get_filter_function(omega)
+    A = F.shape[0]
+    idx = np.arange(A)
+    rng = np.random.default_rng(5)
+    for shape in [(W,), (A, W), (A, A, W)]:
+        S = rng.uniform(0.5, 1.5, shape)
+        if len(shape) == 3:
+            S = S + S.transpose(1, 0, 2)
+        resident = numeric._integrate_filter_function(F, S, omega, idx, pulse.d, pulse)
+        arrays = numeric._integrate_filter_function(np.array(F), S, omega, idx, pulse.d)
+        assert resident.shape == arrays.shape
+        assert np.array_equal(resident, arrays), (shape, np.abs(resident - arrays).max())
+
+
 def test_filter_function_pair_grids_beyond_65535():
     """'generalized' at d = 16 has N*N = 65536 basis pairs, a pulse-correlation filter function of
     a long sequence (G*A)^2 operator pairs: both exceed one grid axis."""
