@@ -454,6 +454,72 @@ __global__ void ff_generalized_kernel(const cplx* __restrict__ R, int A, int N, 
 // shard_width > 0: F is the raw all-gather buffer (n_shards, A, A, shard_width) of omega blocks
 // (one block per rank) instead of (A, A, W): global frequency w lives in shard w / shard_width.
 constexpr int kInfidSlots = 1024, kInfidThreads = 256;
+constexpr int kInfidPer = kInfidSlots/kInfidThreads;       // slots per thread: v = thread + 256 j
+
+// One batch of 1024 intervals [base, base + 1024): thread t owns the frequencies w = base + t + 256 j, forms the
+// integrand there ONCE and takes integrand and frequency at w + 1 from its neighbour lane (the last lane of a
+// wavefront fetches them itself).  All of a thread's loads of a batch are in flight together: the loop this
+// replaces made one trip to memory per interval -- sixteen dependent round trips per thread at config 2, most of
+// the kernel's 5 us above its launch floor (profiles/r05_s_*).  Same terms, same order per slot: same bits.
+// (J0, JN: the slots taken in one go -- all four where registers are free, two and two in the kernel that has to fit
+// beside another pass's accumulate blocks: 56 registers)
+// acc: the slots' running sums -- registers, or (red != nullptr) the slots of the LDS array the final tree reduces,
+// where the registers are needed for the loads in flight.
+template <int J0, int JN, typename LoadF, typename LoadS>
+__device__ __forceinline__ void infid_batch(int base, int W, const double* __restrict__ omega, LoadF Fat, LoadS Sat,
+                                            double (&acc)[kInfidPer], double* red = nullptr) {
+    const int lane = threadIdx.x & 63;
+    cplx f[kInfidPer], sp[kInfidPer];
+    double om[kInfidPer];
+#pragma unroll
+    for (int j = J0; j < J0 + JN; ++j) {
+        const int w = base + static_cast<int>(threadIdx.x) + kInfidThreads*j;
+        const int wc = w < W ? w : W - 1;
+        f[j] = Fat(wc);
+        sp[j] = Sat(wc);
+        om[j] = omega[wc];
+    }
+#pragma unroll
+    for (int j = J0; j < J0 + JN; ++j) {
+        const int w = base + static_cast<int>(threadIdx.x) + kInfidThreads*j;
+        const double i0 = f[j].re*sp[j].re - f[j].im*sp[j].im;
+        double i1 = __shfl_down(i0, 1, 64), o1 = __shfl_down(om[j], 1, 64);
+        if (lane == 63 && w + 1 < W) {
+            const cplx f1 = Fat(w + 1), s1 = Sat(w + 1);
+            i1 = f1.re*s1.re - f1.im*s1.im;
+            o1 = omega[w + 1];
+        }
+        if (w < W - 1) {
+            if (red != nullptr) red[threadIdx.x + kInfidThreads*j] += (i1 + i0)*(o1 - om[j]);
+            else acc[j] += (i1 + i0)*(o1 - om[j]);
+        }
+    }
+}
+
+// The tree over the 1024 slots, pairing (v, v + s) for s = 512, 256, .., 1 as a loop over LDS with a barrier per level
+// would: the levels 512 and 256 pair slots of ONE thread (registers), 128 and 64 cross wavefronts (two barriers), the
+// last six stay inside wavefront 0 (lane shifts).  Same association, same bits, eight barriers fewer.
+template <bool FROM_REGISTERS = true>
+__device__ __forceinline__ void infid_finish(double* red, const double (&acc)[kInfidPer], int d, double* out) {
+    static_assert(kInfidPer == 4 && kInfidThreads == 256, "the tree below is written for 4 slots per thread, 4 wavefronts");
+    double sl[kInfidPer];
+#pragma unroll
+    for (int j = 0; j < kInfidPer; ++j) sl[j] = FROM_REGISTERS ? acc[j] : red[threadIdx.x + kInfidThreads*j];
+    double x = (sl[0] + sl[2]) + (sl[1] + sl[3]);
+    __syncthreads();                                   // (every thread has read its own slots)
+    red[threadIdx.x] = x;
+    __syncthreads();
+    if (threadIdx.x < 128) red[threadIdx.x] = x = x + red[threadIdx.x + 128];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        x = x + red[threadIdx.x + 64];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x = x + __shfl_down(x, off, 64);
+        if (threadIdx.x == 0) *out = (x/2.0)/(2.0*3.141592653589793*d);
+    }
+}
+
+template <bool SHARDED>
 __global__ __launch_bounds__(kInfidThreads) void infid_kernel(const cplx* __restrict__ F, int A, int W,
                                                               const cplx* __restrict__ S, int s_ndim,
                                                               const double* __restrict__ omega,
@@ -473,36 +539,31 @@ __global__ __launch_bounds__(kInfidThreads) void infid_kernel(const cplx* __rest
         ia = ib = idx[p];
         Sp = S + (s_ndim == 2 ? static_cast<size_t>(p)*W : 0);
     }
+    const cplx* Fp = F + (static_cast<size_t>(ia)*A + ib)*(SHARDED ? shard_width : W);
     auto Fat = [&](int w) -> cplx {
-        if (shard_width > 0) {
+        if (SHARDED) {
             const int r = w / shard_width, wl = w - r*shard_width;
-            return F[((static_cast<size_t>(r)*A + ia)*A + ib)*shard_width + wl];
+            return Fp[static_cast<size_t>(r)*A*A*shard_width + wl];
         }
-        return F[(static_cast<size_t>(ia)*A + ib)*W + w];
+        return Fp[w];
     };
-    for (int v = threadIdx.x; v < kInfidSlots; v += kInfidThreads) {
-        double acc = 0.0;
-        for (int w = v; w < W - 1; w += kInfidSlots) {
-            const cplx f0 = Fat(w), f1 = Fat(w + 1), s0 = Sp[w], s1 = Sp[w + 1];
-            const double i0 = f0.re*s0.re - f0.im*s0.im;
-            const double i1 = f1.re*s1.re - f1.im*s1.im;
-            acc += (i1 + i0)*(omega[w + 1] - omega[w]);
-        }
-        red[v] = acc;
+    auto Sat = [&](int w) -> cplx { return Sp[w]; };
+    // this kernel runs beside another pass's accumulate blocks: 56 registers (tests/test_kernel_resources.py) -- the
+    // running sums live in the LDS slots themselves (each thread its own four), the registers hold the loads in flight
+    double acc[kInfidPer];
+#pragma unroll
+    for (int j = 0; j < kInfidPer; ++j) red[threadIdx.x + kInfidThreads*j] = 0.0;
+    for (int base = 0; base < W - 1; base += kInfidSlots) {
+        infid_batch<0, kInfidPer>(base, W, omega, Fat, Sat, acc, red);
+        asm volatile("" ::: "memory");      // (keeps the next batch's loads behind this batch's sums)
     }
-    __syncthreads();
-    for (int s2 = kInfidSlots/2; s2 > 0; s2 >>= 1) {
-        for (int v = threadIdx.x; v < s2; v += kInfidThreads) red[v] += red[v + s2];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) infid[p] = (red[0]/2.0)/(2.0*3.141592653589793*d);
+    infid_finish<false>(red, acc, d, infid + p);
 }
 
 // The same integral with the spectrum in mapped pinned HOST memory (the resident API path hands it over
-// without a copy): infid_kernel's loop reads S[w], S[w + 1] per trip, sixteen dependent trips over PCIe per
-// thread -- 27 us where the device-resident spectrum takes 8 (profiles/r05_r_*).  Here a batch of 4096 spectrum
-// values goes through LDS first, every thread's 17 reads in flight together; then the same slots sum the same
-// terms in the same order (the batch is a multiple of the 1024 slots): bit-identical results.
+// without a copy): every read of it is a trip over PCIe, so a stage of 4096 spectrum values goes through LDS
+// first, every thread's 17 reads in flight together (27 us -> 14 us with the interval-by-interval loop,
+// profiles/r05_r_*); then the same batches as above: bit-identical results.
 constexpr int kInfidStage = 4096;
 __global__ __launch_bounds__(kInfidThreads) void infid_host_spectrum_kernel(
     const cplx* __restrict__ F, int A, int W, const cplx* __restrict__ S, int s_ndim,
@@ -523,18 +584,17 @@ __global__ __launch_bounds__(kInfidThreads) void infid_host_spectrum_kernel(
         Sp = S + (s_ndim == 2 ? static_cast<size_t>(p)*W : 0);
     }
     const cplx* Fp = F + (static_cast<size_t>(ia)*A + ib)*W;
-    constexpr int kPer = kInfidSlots/kInfidThreads;      // slots per thread
     constexpr int kLoads = kInfidStage/kInfidThreads + 1;
-    double acc[kPer];
+    double acc[kInfidPer];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) acc[j] = 0.0;
-    for (int base = 0; base < W - 1; base += kInfidStage) {
-        const int n = min(kInfidStage + 1, W - base);
+    for (int j = 0; j < kInfidPer; ++j) acc[j] = 0.0;
+    for (int s0 = 0; s0 < W - 1; s0 += kInfidStage) {
+        const int n = min(kInfidStage + 1, W - s0);
         cplx v[kLoads];
 #pragma unroll
         for (int k = 0; k < kLoads; ++k) {
             const int i = threadIdx.x + kInfidThreads*k;
-            v[k] = i < n ? Sp[base + i] : cplx{0.0, 0.0};
+            v[k] = i < n ? Sp[s0 + i] : cplx{0.0, 0.0};
         }
 #pragma unroll
         for (int k = 0; k < kLoads; ++k) {
@@ -542,26 +602,13 @@ __global__ __launch_bounds__(kInfidThreads) void infid_host_spectrum_kernel(
             if (i < n) sl[i] = v[k];
         }
         __syncthreads();
-        const int wend = min(W - 1, base + kInfidStage);
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            for (int w = base + threadIdx.x + kInfidThreads*j; w < wend; w += kInfidSlots) {
-                const cplx f0 = Fp[w], f1 = Fp[w + 1], s0 = sl[w - base], s1 = sl[w + 1 - base];
-                const double i0 = f0.re*s0.re - f0.im*s0.im;
-                const double i1 = f1.re*s1.re - f1.im*s1.im;
-                acc[j] += (i1 + i0)*(omega[w + 1] - omega[w]);
-            }
-        }
+        auto Fat = [&](int w) -> cplx { return Fp[w]; };
+        auto Sat = [&](int w) -> cplx { return sl[w - s0]; };
+        const int bend = min(W - 1, s0 + kInfidStage);
+        for (int base = s0; base < bend; base += kInfidSlots) infid_batch<0, kInfidPer>(base, W, omega, Fat, Sat, acc);
         __syncthreads();
     }
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) red[threadIdx.x + kInfidThreads*j] = acc[j];
-    __syncthreads();
-    for (int s2 = kInfidSlots/2; s2 > 0; s2 >>= 1) {
-        for (int vv = threadIdx.x; vv < s2; vv += kInfidThreads) red[vv] += red[vv + s2];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) infid[p] = (red[0]/2.0)/(2.0*3.141592653589793*d);
+    infid_finish(red, acc, d, infid + p);
 }
 
 }  // namespace
@@ -944,8 +991,12 @@ hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_n
                            s_ndim, omega, idx, n_idx, d, infid);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(infid_kernel, dim3(nout), dim3(kInfidThreads), 0, stream, F, A, W, S, s_ndim, omega,
-                       idx, n_idx, d, shard_width, infid);
+    if (shard_width > 0)
+        hipLaunchKernelGGL(infid_kernel<true>, dim3(nout), dim3(kInfidThreads), 0, stream, F, A, W, S, s_ndim, omega,
+                           idx, n_idx, d, shard_width, infid);
+    else
+        hipLaunchKernelGGL(infid_kernel<false>, dim3(nout), dim3(kInfidThreads), 0, stream, F, A, W, S, s_ndim, omega,
+                           idx, n_idx, d, shard_width, infid);
     return hipGetLastError();
 }
 

@@ -92,7 +92,7 @@ def _one(kernels, *fragments):
 def test_small_kernels_of_the_headline_pass_fit_beside_the_accumulate_kernel(kernels):
     small = [_one(kernels, 'eigh_expm_kernelILi4E'), _one(kernels, 'scan_local_kernelILi4E'),
              _one(kernels, 'apply_prologue_kernelILi4E'), _one(kernels, 'expand_ff_kernel'),
-             _one(kernels, 'infid_kernel')]
+             _one(kernels, 'infid_kernelILb0E')]
     for k in small:
         assert k['.vgpr_count'] <= 56, (k['.name'], k['.vgpr_count'])
         assert k['.vgpr_spill_count'] == 0 and k['.sgpr_spill_count'] == 0, k['.name']
