@@ -982,7 +982,7 @@ hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_n
                              bool spectrum_on_host) {
     (void)ws;
     const int nout = s_ndim == 3 ? n_idx*n_idx : n_idx;
-    if (spectrum_on_host && shard_width <= 0) {
+    if (spectrum_on_host && (shard_width <= 0 || shard_width >= W)) {
         const int lds = static_cast<int>(sizeof(cplx))*(kInfidStage + 1);
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(infid_host_spectrum_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -991,7 +991,8 @@ hipError_t launch_infidelity(const cplx* F, int A, int W, const cplx* S, int s_n
                            s_ndim, omega, idx, n_idx, d, infid);
         return hipGetLastError();
     }
-    if (shard_width > 0)
+    // (one shard as wide as the grid -- the single-GPU bench -- IS the plain layout: no index division per load)
+    if (shard_width > 0 && shard_width < W)
         hipLaunchKernelGGL(infid_kernel<true>, dim3(nout), dim3(kInfidThreads), 0, stream, F, A, W, S, s_ndim, omega,
                            idx, n_idx, d, shard_width, infid);
     else
