@@ -1097,7 +1097,7 @@ def main():
                         'way on MI355X); flops = FMA-counted flops the kernel EXECUTES '
                         '(ffk_api.hip::accumulate_flops).  Round 5 (ctrl_pq.hip): the second product on the '
                         'matrix cores as THREE real products (Gauss) with psi folded into the A operand once '
-                        'per set of four frequencies: 630 per operator + 310 per tile = 2200 per (segment, '
+                        'per set of four frequencies: 624 per operator + 304 per tile = 2176 per (segment, '
                         'omega) at A = 3, where the round-4 kernel executed 2712 and the round-3 kernel 3656 '
                         'for the same elements.  frac = dominant kernel alone (HIP events, each instrumented '
                         'launch gated on the previous accumulate kernel), frac_step = the same flops over the '

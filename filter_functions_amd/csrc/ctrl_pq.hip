@@ -58,6 +58,9 @@
 #include FFK_PQ_CONSUMER_INC   // generated: tools/gen_pq_consumer.py
 
 namespace ffk {
+
+thread_local cplx* g_d4_wfold = nullptr;     // ffk_internal.h
+
 namespace {
 
 constexpr int kPqProducers = 4;   // wavefronts 0..3, one per SIMD
@@ -118,10 +121,12 @@ __device__ __forceinline__ int lds_peek(const int* flag) {
     return __builtin_amdgcn_readfirstlane(*(const volatile lds_int_t*)(flag));
 }
 
-template <int NC>
+// PRE: W_a comes folded from the prologue kernel (wfold, ffk_internal.h g_d4_wfold) instead of being folded here
+template <int NC, bool PRE>
 __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 : 2) void ctrl_accumulate_pq_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
-    const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
+    const cplx* __restrict__ ops, int G, int A, int chunk_len, cplx* __restrict__ Ypart,
+    const cplx* __restrict__ wfold) {
     constexpr int D = 4, DD = 16, S = kPqRow, TILE = pq_tile_doubles(NC);
     constexpr int TOP = kPqW + NC*128;                  // the A operands of a slot
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -276,6 +281,15 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
             q[10] = q[0];
             q[15] = q[0];
             FFK_PQ_STAMP(it, 1);
+            // the pre-folded W_a of the segment (element `lane` of each operator's 64): requested HERE, with the tile's
+            // records dead, and used behind the wait for the slot -- staged a tile ahead like the row it cost 12
+            // registers across the whole tile: 168 with spills where the consumers' loop needs 146
+            cplx wpre[NC];
+            if constexpr (PRE) {
+#pragma unroll
+                for (int a = 0; a < NC; ++a)
+                    wpre[a] = a < n_alpha ? wfold[(static_cast<size_t>(g0 + it)*A + alpha0 + a)*64 + lane] : cplx{0.0, 0.0};
+            }
             // the slot's previous tenant (tile it - 8) has been read by every consumer?
             if (gen > 0) {
                 int spin = 0;
@@ -301,8 +315,15 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
                 const double2_t v = {pf.pr, pf.pi};
                 *reinterpret_cast<double2_t*>(buf + kPqPsi + lane*2) = v;
             }
-            // W_a[m][n][j] = Bbar_a[m][n] e^{i b_mn} T[n][j], (m, n, j) = this lane's index
-            {
+            // W_a[m][n][j] = Bbar_a[m][n] e^{i b_mn} T[n][j], (m, n, j) = this lane's index: folded once per segment
+            // by the prologue kernel where the caller gave it a buffer (ffk_internal.h g_d4_wfold), else here
+            if constexpr (PRE) {
+#pragma unroll
+                for (int a = 0; a < NC; ++a) {
+                    const double2_t v = {wpre[a].re, wpre[a].im};
+                    *reinterpret_cast<double2_t*>(buf + kPqW + a*128 + lane*2) = v;
+                }
+            } else {
                 const int src_t = lane & (DD - 1);                          // T[n][j]
                 const cplx tv = {__shfl(o.re, src_t, 64), __shfl(o.im, src_t, 64)};
                 const cplx et = cmul(cplx{cb, sb}, tv);
@@ -595,19 +616,28 @@ __global__ __launch_bounds__((kPqProducers + kPqConsumers)*64, kPqSets == 2 ? 3 
 #endif
 }
 
-template <int NC>
-hipError_t launch_pq(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
-                     int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
+template <int NC, bool PRE>
+hipError_t launch_pq_as(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
+                        int chunks, int chunk_len, cplx* Ypart, const cplx* wfold, hipStream_t stream) {
     const int lds = pq_lds_bytes_for(NC);
     (void)kernel_fault_word();
-    auto kern = ctrl_accumulate_pq_kernel<NC>;
+    auto kern = ctrl_accumulate_pq_kernel<NC, PRE>;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (err != hipSuccess) return err;
     const dim3 grid((W + 63)/64, (A + NC - 1)/NC, chunks);
     hipLaunchKernelGGL(kern, grid, dim3((kPqProducers + kPqConsumers)*64), lds, stream, omega, W, segtab,
-                       ops, G, A, chunk_len, Ypart);
+                       ops, G, A, chunk_len, Ypart, wfold);
     return hipGetLastError();
+}
+
+template <int NC>
+hipError_t launch_pq(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
+                     int chunks, int chunk_len, cplx* Ypart, hipStream_t stream) {
+    const cplx* wfold = g_d4_wfold;
+    return wfold != nullptr
+               ? launch_pq_as<NC, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, wfold, stream)
+               : launch_pq_as<NC, false>(omega, W, segtab, ops, G, A, chunks, chunk_len, Ypart, nullptr, stream);
 }
 
 }  // namespace

@@ -109,6 +109,7 @@ size_t ctrl_ws_bytes(int W, int N, int A, int G, int d, int chunks) {
     b += align_up(sizeof(cplx)*size_t(chunks)*A*d*d*W);                   // Ypart
     b += align_up(sizeof(cplx)*size_t(A)*d*d*W);                          // Bt
     b += ffk::expand_workspace_bytes(N, d);                               // compacted basis
+    if (d == 4) b += align_up(sizeof(cplx)*ffk::d4_wfold_elems(G, A));    // folded W_a (ffk_internal.h g_d4_wfold), LAST
     return b;
 }
 
@@ -122,17 +123,19 @@ double accumulate_flops(int W, int A, int G, int d) {
     // FMA-counted real flops the accumulate kernels EXECUTE per (segment, frequency)
     // (DESIGN.md section 3).
     // d = 4: the tile per group of <= 3 operators: 13 entries x 10 (x, addition theorem 3, reciprocal 5, product
-    // 1) + 62 (two sincos and psi) + 6 (e^{ib} T of the fold, one element per lane = one per frequency) and 6 per
-    // operator (Bbar times that).
+    // 1) + 62 (two sincos and psi).
     if (d == 4 && ffk::pq_accumulate_supported(d, A)) {
         // ctrl_pq.hip (round 5; the default): per operator the first product 16 x (2 mul + 6 fma) = 224,
-        // zr + zi 16, the second product as THREE real 4 x 4 x 4 matrix products (Gauss) 3 x 128 = 384, the fold
-        // 6 = 630 -- and blocks of nc = min(3, A) operators execute nc of them whether or not the last block is
-        // full; per block the tile 13 x 10 + 62 + 6 = 198 and c = psi conj(T), cr + ci: 16 x 7 = 112.
+        // zr + zi 16, the second product as THREE real 4 x 4 x 4 matrix products (Gauss) 3 x 128 = 384 = 624 --
+        // and blocks of nc = min(3, A) operators execute nc of them whether or not the last block is
+        // full; per block the tile 13 x 10 + 62 = 192 and c = psi conj(T), cr + ci: 16 x 7 = 112.
+        // The fold of W_a (6 per operator for Bbar times e^{ib} T, 6 per block for that product) is NOT counted:
+        // this entry point has the prologue kernel do it once per segment (ffk_internal.h g_d4_wfold), the kernel
+        // copies it.  (Until the last change of round 5 the kernel folded it per frequency block: 630 nc + 310.)
         const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);
         if (geo.pc) {
             const int nc = A >= 3 ? 3 : A;
-            return (630.0*nc + 310.0)*double((A + nc - 1)/nc)*double(G)*double(W);
+            return (624.0*nc + 304.0)*double((A + nc - 1)/nc)*double(G)*double(W);
         }
     }
     // d = 8 (ctrl_pcr.hip, round 4): per operator the first product real x complex 4 d^3 = 2048, psi P
@@ -431,12 +434,19 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     cplx* Bt = ws.take<cplx>(size_t(A)*d*d*W);
     void* ews = ws.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
     FFK_REQUIRE(Bt && ews, "workspace too small");
+    // d = 4: the prologue folds W_a once per segment for the accumulate kernel (a hint to both launches, reset below)
+    cplx* wfold = d == 4 ? ws.take<cplx>(ffk::d4_wfold_elems(G, A)) : nullptr;
+    FFK_REQUIRE(d != 4 || wfold, "workspace too small");
 
-    if (!(flags & FFK_INTERNAL_PROLOGUE_DONE))
-        FFK_HIP(ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
-                                     reinterpret_cast<const cplx*>(propagators),
-                                     reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G, d, A,
-                                     segtab, Tc, ops, nullptr, nullptr, s));
+    if (!(flags & FFK_INTERNAL_PROLOGUE_DONE)) {
+        ffk::g_d4_wfold = wfold;
+        const hipError_t pe = ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
+                                                   reinterpret_cast<const cplx*>(propagators),
+                                                   reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G, d, A,
+                                                   segtab, Tc, ops, nullptr, nullptr, s);
+        ffk::g_d4_wfold = nullptr;
+        FFK_HIP(pe);
+    }
     if (g_ev_start && g_ev_stop) {
         // `gate`: an event of ANOTHER stream (the previous pass's accumulate kernel) that this
         // stream waits for first, so that start..stop spans this kernel's execution and not its
@@ -457,8 +467,11 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
         epilogue = {nnz, rows, vals, N, reinterpret_cast<cplx*>(control_matrix)};
     }
     bool expanded = false;
-    FFK_HIP(ffk::launch_accumulate(omega, W, segtab, ops, G, d, A, geo, Ypart, s,
-                                   epilogue.R ? &epilogue : nullptr, &expanded));
+    ffk::g_d4_wfold = wfold;            // (written by the prologue above, or by the fused front's with the same slicing)
+    const hipError_t ae = ffk::launch_accumulate(omega, W, segtab, ops, G, d, A, geo, Ypart, s,
+                                                 epilogue.R ? &epilogue : nullptr, &expanded);
+    ffk::g_d4_wfold = nullptr;
+    FFK_HIP(ae);
     if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_stop, s));
     const size_t slab = size_t(A)*d*d*W;
     const cplx* Bsum = Ypart;
@@ -923,10 +936,13 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
         cw.take<cplx>(size_t(A)*d*d*W);                // Bt
         void* ews = cw.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
         FFK_REQUIRE(ews, "workspace too small");
-        FFK_HIP(ffk::launch_apply_prologue_compact(
+        ffk::g_d4_wfold = d == 4 ? cw.take<cplx>(ffk::d4_wfold_elems(G, A)) : nullptr;
+        const hipError_t fe = ffk::launch_apply_prologue_compact(
             w.qloc, totals, G, d, reinterpret_cast<cplx*>(Q), D, reinterpret_cast<const cplx*>(V),
             reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, A, segtab, Tc, ops,
-            reinterpret_cast<const cplx*>(basis), N, ews, s));
+            reinterpret_cast<const cplx*>(basis), N, ews, s);
+        ffk::g_d4_wfold = nullptr;
+        FFK_HIP(fe);
         cm_flags = FFK_INTERNAL_PROLOGUE_DONE | FFK_INTERNAL_COMPACT_DONE;
     } else {
         if (int rc = ffk_diagonalize_dev(hamiltonian, dt, G, d, D, V, Q, dws, dwsb, stream)) return rc;

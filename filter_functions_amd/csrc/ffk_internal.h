@@ -199,6 +199,15 @@ int pq_accumulate_waves(int nc);
 bool pq_accumulate_supported(int d, int A);
 int pq_accumulate_ops_per_block(int A);
 hipError_t pq_bind_fault_word(int* device_pointer);
+// d = 4: W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j] per (segment, operator), 64 complex numbers in the order the
+// accumulate kernel's tile holds them.  It does not depend on the frequency: when this pointer is set (by
+// ffk_control_matrix_dev / ffk_pipeline_dev around their prologue and accumulate launches, which own the buffer) the
+// prologue kernels write it once per segment and the accumulate kernel's producers copy it into their tiles instead
+// of each of the W/64 frequency blocks folding it again (same products in the same order: same bits).  NULL: the
+// accumulate kernel folds it itself (callers that bring their own `ops`).
+extern thread_local cplx* g_d4_wfold;
+constexpr size_t d4_wfold_elems(int G, int A) { return static_cast<size_t>(G)*A*64; }
+
 hipError_t launch_accumulate_pq(const double* omega, int W, const double* segtab, const cplx* ops,
                                 int G, int d, int A, int nc, int chunks, int chunk_len, cplx* Ypart,
                                 hipStream_t stream);

@@ -15,20 +15,22 @@ namespace {
 // Prologue arithmetic for one segment by one wavefront; V (eigenvectors) and Q (propagator
 // before the segment) already sit in LDS.
 template <int D>
-__device__ void prologue_segment(const cplx (*V)[D], const cplx (*Q)[D], cplx (*T)[D], cplx (*BV)[D],
+__device__ void prologue_segment(const cplx (*V)[D], cplx (*Q)[D], cplx (*T)[D], cplx (*BV)[D],
                                  int g, int lane, const double* __restrict__ eigvals,
                                  const cplx* __restrict__ n_opers,
                                  const double* __restrict__ n_coeffs,
                                  const double* __restrict__ dt, const double* __restrict__ t, int G,
                                  int A, double* __restrict__ segtab, cplx* __restrict__ Tc,
                                  cplx* __restrict__ ops, cplx* __restrict__ n_opers_transformed,
-                                 cplx* __restrict__ eigvecs_propagated, bool with_noise_ops = true) {
+                                 cplx* __restrict__ eigvecs_propagated, bool with_noise_ops = true,
+                                 cplx* __restrict__ wfold = nullptr) {
     constexpr int S = seg_stride(D);
     double* st = segtab + static_cast<size_t>(g)*S;
     if (lane == 0) {
         st[0] = dt[g];
         st[1] = t[g];
     }
+    cplx eb = {1.0, 0.0};                              // e^{i b_mn} of this lane's entry (d = 4: one entry per lane < 16)
     for (int e = lane; e < D*D; e += 64) {
         const double dE = eigvals[static_cast<size_t>(g)*D + e / D] - eigvals[static_cast<size_t>(g)*D + e % D];
         double sb, cb;
@@ -37,6 +39,7 @@ __device__ void prologue_segment(const cplx (*V)[D], const cplx (*Q)[D], cplx (*
         st[seg_rec(e) + 1] = sb;
         st[seg_rec(e) + 2] = cb;
         st[seg_rec(e) + 3] = 0.0;
+        eb = {cb, sb};
     }
     if (lane < 2) st[2 + lane] = 0.0;
     for (int e = 4 + 4*D*D + lane; e < S; e += 64) st[e] = 0.0;
@@ -57,6 +60,13 @@ __device__ void prologue_segment(const cplx (*V)[D], const cplx (*Q)[D], cplx (*
     __syncthreads();
 
     if (!with_noise_ops) return;        // (large d: noise_ops_kernel, one block per operator)
+    // d = 4 with a buffer for it (ffk_internal.h g_d4_wfold): W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j], the
+    // operand the accumulate kernel's tiles hold, folded here once per segment.  Q is free by now: it keeps e^{ib}.
+    const bool fold = D == 4 && wfold != nullptr;
+    if (fold) {
+        if (lane < D*D) Q[lane / D][lane % D] = eb;
+        __syncthreads();
+    }
     for (int a = 0; a < A; ++a) {
         const cplx* B = n_opers + static_cast<size_t>(a)*D*D;
         const double s = n_coeffs ? n_coeffs[static_cast<size_t>(a)*G + g] : 1.0;   // NULL: unit
@@ -70,6 +80,7 @@ __device__ void prologue_segment(const cplx (*V)[D], const cplx (*Q)[D], cplx (*
         }
         __syncthreads();
         // Bbar = s V^dag BV
+        cplx bbar = {0.0, 0.0};
         for (int e = lane; e < D*D; e += 64) {
             const int m = e / D, n = e % D;
             cplx acc = {0.0, 0.0};
@@ -80,8 +91,21 @@ __device__ void prologue_segment(const cplx (*V)[D], const cplx (*Q)[D], cplx (*
             ops[(static_cast<size_t>(g)*(1 + A) + 1 + a)*D*D + e] = acc;
             if (n_opers_transformed)
                 n_opers_transformed[(static_cast<size_t>(a)*G + g)*D*D + e] = acc;
+            if (fold) bbar = acc;
         }
         __syncthreads();
+        if (fold) {
+            if (lane < D*D) BV[lane / D][lane % D] = bbar;      // (every lane has its products out of BV: the barrier above)
+            __syncthreads();
+            if constexpr (D == 4) {
+                // lane = (m, n, j), the accumulate kernel's order of products: (e^{ib} T) first, then Bbar times that
+                const int m = lane >> 4, n = (lane >> 2) & 3, j = lane & 3;
+                const cplx et = cmul(Q[m][n], T[n][j]);
+                const cplx w = cmul(BV[m][n], et);
+                wfold[(static_cast<size_t>(g)*A + a)*64 + n*16 + m*4 + j] = w;
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -92,7 +116,7 @@ __global__ __launch_bounds__(64) void prologue_kernel(
     const double* __restrict__ n_coeffs, const double* __restrict__ dt,
     const double* __restrict__ t, int G, int A, double* __restrict__ segtab,
     cplx* __restrict__ Tc, cplx* __restrict__ ops, cplx* __restrict__ n_opers_transformed,
-    cplx* __restrict__ eigvecs_propagated, bool with_noise_ops) {
+    cplx* __restrict__ eigvecs_propagated, bool with_noise_ops, cplx* __restrict__ wfold) {
     __shared__ cplx V[D][D];
     __shared__ cplx Q[D][D];
     __shared__ cplx T[D][D];
@@ -105,7 +129,7 @@ __global__ __launch_bounds__(64) void prologue_kernel(
     }
     __syncthreads();
     prologue_segment<D>(V, Q, T, BV, g, lane, eigvals, n_opers, n_coeffs, dt, t, G, A, segtab, Tc,
-                        ops, n_opers_transformed, eigvecs_propagated, with_noise_ops);
+                        ops, n_opers_transformed, eigvecs_propagated, with_noise_ops, wfold);
 }
 
 // Bbar_a^(g) = s_a(t_g) V_g^dag B_a V_g for one (segment, noise operator) per block.  For large d the
@@ -162,7 +186,7 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
     const double* __restrict__ dt, const double* __restrict__ t, int A,
     double* __restrict__ segtab, cplx* __restrict__ Tc, cplx* __restrict__ ops,
     const cplx* __restrict__ basis, int* __restrict__ nnz, int* __restrict__ rows,
-    cplx* __restrict__ vals, bool with_noise_ops) {
+    cplx* __restrict__ vals, bool with_noise_ops, cplx* __restrict__ wfold) {
     // extra blocks (launch_apply_prologue_compact): basis compaction
     if (static_cast<int>(blockIdx.x) >= G) {
         basis_compact_one(basis, D, static_cast<int>(blockIdx.x) - G, threadIdx.x, nnz, rows, vals);
@@ -276,7 +300,7 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
     for (int e = lane; e < D*D; e += 64) V[e / D][e % D] = eigvecs[static_cast<size_t>(g)*D*D + e];
     __syncthreads();
     prologue_segment<D>(V, Q, T, BV, g, lane, eigvals, n_opers, n_coeffs, dt, t, G, A, segtab, Tc,
-                        ops, nullptr, nullptr, with_noise_ops);
+                        ops, nullptr, nullptr, with_noise_ops, wfold);
 }
 
 // out[g,k] = T_g C_k T_g^dag with T_g = conj(Tc[g])   (= (Q^dag V)^dag C_k (Q^dag V))
@@ -346,7 +370,8 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
     case D:                                                                                     \
         hipLaunchKernelGGL(prologue_kernel<D>, dim3(G), dim3(64), 0, stream, eigvals, eigvecs,  \
                            propagators, n_opers, n_coeffs, dt, t, G, A, segtab, Tc, ops,        \
-                           n_opers_transformed, eigvecs_propagated, !split_noise_ops(D, A));    \
+                           n_opers_transformed, eigvecs_propagated, !split_noise_ops(D, A),     \
+                           D == 4 ? g_d4_wfold : nullptr);                                      \
         if (split_noise_ops(D, A))                                                              \
             hipLaunchKernelGGL(noise_ops_kernel<D>, dim3(G, A), dim3(64), 0, stream, eigvecs,   \
                                n_opers, n_coeffs, G, A, ops, n_opers_transformed);              \
@@ -388,7 +413,8 @@ hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, i
         hipLaunchKernelGGL(apply_prologue_kernel<D>, dim3(G + extra), dim3(64),                  \
                            sizeof(cplx)*D*D*(D <= 8 ? (G + L - 1)/L : 16), stream, Qloc,         \
                            totals, G, L, Q, eigvals, eigvecs, n_opers, n_coeffs, dt, t, A,       \
-                           segtab, Tc, ops, basis, nnz, rows, vals, !split_noise_ops(D, A));     \
+                           segtab, Tc, ops, basis, nnz, rows, vals, !split_noise_ops(D, A),      \
+                           D == 4 ? g_d4_wfold : nullptr);                                       \
         if (split_noise_ops(D, A))                                                               \
             hipLaunchKernelGGL(noise_ops_kernel<D>, dim3(G, A), dim3(64), 0, stream, eigvecs,    \
                                n_opers, n_coeffs, G, A, ops, nullptr);                           \

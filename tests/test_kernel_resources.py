@@ -102,11 +102,12 @@ def test_small_kernels_of_the_headline_pass_fit_beside_the_accumulate_kernel(ker
 
 def test_d4_accumulate_kernel_leaves_room_for_a_second_pass(kernels):
     for nc in (1, 2, 3):
-        k = _one(kernels, 'ctrl_accumulate_pq_kernelILi%dE' % nc)
-        # three wavefronts per SIMD at <= 152 registers (allocation granule 8) + one small-kernel wavefront at 56
-        assert k['.vgpr_count'] <= 152, (nc, k['.vgpr_count'])
-        assert k['.vgpr_spill_count'] == 0 and k['.sgpr_spill_count'] == 0, nc
-        assert k['.max_flat_workgroup_size'] == 768
+        for pre in (0, 1):          # W_a folded in the kernel / by the prologue kernel
+            k = _one(kernels, 'ctrl_accumulate_pq_kernelILi%dELb%dE' % (nc, pre))
+            # three wavefronts per SIMD at <= 152 registers (allocation granule 8) + one small-kernel wavefront at 56
+            assert k['.vgpr_count'] <= 152, (nc, pre, k['.vgpr_count'])
+            assert k['.vgpr_spill_count'] == 0 and k['.sgpr_spill_count'] == 0, (nc, pre)
+            assert k['.max_flat_workgroup_size'] == 768
 
 
 def test_matrix_core_accumulate_kernels_keep_their_occupancy(kernels):
