@@ -24,13 +24,19 @@
 //     on a mix that holds 2.33 GHz where the pure v_fma_f64 stream is power capped at 2.03
 //     (tools/fp64_mix_probe.hip, profiles/r05_a_*).  18 accumulator registers per lane instead of 64: no
 //     segment split inside the block, no tree reduction at the end.
-//   * The consumer's tile is ONE generated asm block (ctrl_pq_consumer.inc, tools/gen_pq_consumer.py): the next
-//     tile's operands are requested from inside the last set, when their registers are dead, and fly during its
-//     matrix instructions and the hand-over; the flag of the tile after that and the SIMD partner's progress
-//     are read a tile ahead; every s_waitcnt carries the exact count of younger LDS operations.  hipcc moved the
-//     last set's vector work behind the requests (168 VGPRs, accumulators spilled in the loop) or serialised
-//     the reads.  At 148 VGPRs three of these wavefronts per SIMD leave room for a wavefront of another pass's
-//     small kernels (56): the two-pass schedule of the bench keeps overlapping.
+//   * The consumer's WHOLE TILE LOOP is one generated asm block (ctrl_pq_consumer.inc, tools/gen_pq_consumer.py),
+//     unrolled over the ring's eight slots so that every LDS address is a per-lane base register plus an
+//     immediate: the next tile's operands are requested from inside the last set, when their registers are dead,
+//     and fly during its matrix instructions and the hand-over; the flag of the tile after that and the SIMD
+//     partner's progress are read a tile ahead; every s_waitcnt carries the exact count of younger LDS
+//     operations; 16 bookkeeping instructions per tile (a wavefront does not issue in the shadow of its own
+//     matrix instructions: each of the 48 of a rolled loop lengthened the consumer's chain,
+//     tools/fp64_issue_probe.py, profiles/r05_l_*, r05_m_*).  hipcc moved the last set's vector work behind the
+//     requests (168 VGPRs, accumulators spilled in the loop) or serialised the reads.  At 146 VGPRs three of these
+//     wavefronts per SIMD leave room for a wavefront of another pass's small kernels (56): the two-pass schedule
+//     of the bench keeps overlapping (tests/test_kernel_resources.py).
+//   * W_a comes folded from the prologue kernel where the caller owns a buffer for it (PRE, ffk_internal.h
+//     g_d4_wfold: ffk_control_matrix_dev / ffk_pipeline_dev), else the producers fold it per tile.
 //   * Flags in LDS: ready[slot] written by the slot's producer, done[slot] counted up by the consumers with
 //     ds_add, progress[consumer]; the lagging consumer of a SIMD raises its priority (the arbiter serves the
 //     oldest wavefront first and would let one run ahead until the ring stops it: soft lockstep).  Every wait is
@@ -38,8 +44,9 @@
 //     the wavefront stops waiting for the rest of the launch and runs to the end so that the grid drains.
 //     -DFFK_PC_SPIN_LIMIT=n -DFFK_PC_FAULT_INJECT: the test build whose producers stop publishing after eight
 //     tiles (tests/test_gpu_parity.py::test_flag_wait_timeout_is_an_error).
-// Same box, bench schedule: round-4 kernel 67.6-68.7 us per step, this one 59.6-59.8 (kernel alone 72.6-73.5 ->
-// 63.2-63.7); the steps in between with their measurements: profiles/r05_b_d4_matrix_core_kernel_steps.txt.
+// Same box, bench schedule: round-4 kernel 67.6-68.7 us per step, the per-tile asm block 59.6-59.8, this one 58.0
+// (kernel alone 72.6-73.5 -> 63.2-63.7 -> 60.9); the steps in between with their measurements:
+// profiles/r05_b_d4_matrix_core_kernel_steps.txt, r05_l_*; where the time is: DESIGN.md section 6.1.
 // One or two operators per block (A < 3) run the same arithmetic through a C++ consumer.
 #include <algorithm>
 #include <cstdlib>
