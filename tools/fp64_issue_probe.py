@@ -82,13 +82,13 @@ def consumer_tile(drop=()):
     return out
 
 
-def consumer_loop(lockstep=2):
+def consumer_loop(lockstep=0):
     """the shipped whole-loop block (flags all up: no tile is ever waited for)"""
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import gen_pq_consumer as g
     g.LOCKSTEP = lockstep
     lines = g.build_loop().lines
-    g.LOCKSTEP = 2
+    g.LOCKSTEP = 0
     return lines
 
 
@@ -234,7 +234,7 @@ def main():
     tiles = tile_patterns()
     for k, (name, body) in enumerate(tiles):
         src.append(TILE_KERNEL % dict(k=k, init=c_string(init), body=c_string(body)))
-    loops = [('loop: the shipped whole-loop block', consumer_loop(2)), ('loop: priority never raised', consumer_loop(1 << 28))]
+    loops = [('loop: the shipped whole-loop block', consumer_loop(0)), ('loop: priority never raised', consumer_loop(1 << 28))]
     for k, (name, body) in enumerate(loops):
         src.append(LOOP_KERNEL % dict(k=k, init=c_string(init), body=c_string(body)))
     src.append('struct Pattern { const char* name; void (*kernel)(Stamp*, int, double); int n; };\n')

@@ -80,7 +80,10 @@ LOOP_V = dict(a_w='v124', a_q0='v125', a_p='v126', a_q1='v127', a_p1='v128', a_f
               b_w='v138', b_q0='v139', b_q1='v140', b_p='v141', spin='v137')
 LOOP_S = dict(nit='s36', limit='s37', flags='s38', me='s39', it='s40', cur='s41', nxt='s42', t='s43', fnext='s44',
               p='s45', prio='s46', want='s47', fault='s48', spin='s49', t2='s50', has='s51')
-LOCKSTEP = int(os.environ.get('GEN_PQ_LOCKSTEP', '2'))
+# a consumer raises its priority while its SIMD partner has finished more than `it + LOCKSTEP` tiles (it = the tile this
+# consumer works on; the partner's count is read at the top of the tile).  0: the one behind by a tile or more --
+# 2 (the first shipped value): step +1.2 %, 5: +4 % (profiles/r05_v_*)
+LOCKSTEP = int(os.environ.get('GEN_PQ_LOCKSTEP', '0'))
 MERGE_WAITS = os.environ.get('GEN_PQ_MERGE_WAITS', '') == '1'      # one wait per set instead of one per stage
 PRIO_EVERY = int(os.environ.get('GEN_PQ_PRIO_EVERY', '1'))          # partner priority every n-th tile (unrolled form)
 PRIO_LOW, PRIO_HIGH = (int(x) for x in os.environ.get('GEN_PQ_PRIOS', '0,1').split(','))   # consumer priorities: normal, behind its partner
