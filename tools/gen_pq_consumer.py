@@ -87,6 +87,7 @@ LOCKSTEP = int(os.environ.get('GEN_PQ_LOCKSTEP', '0'))
 MERGE_WAITS = os.environ.get('GEN_PQ_MERGE_WAITS', '') == '1'      # one wait per set instead of one per stage
 PRIO_EVERY = int(os.environ.get('GEN_PQ_PRIO_EVERY', '1'))          # partner priority every n-th tile (unrolled form)
 PRIO_LOW, PRIO_HIGH = (int(x) for x in os.environ.get('GEN_PQ_PRIOS', '0,1').split(','))   # consumer priorities: normal, behind its partner
+PHASE_PRIO = os.environ.get('GEN_PQ_PHASE_PRIO', '')    # tuning: 'v,m' = static priorities of the vector / matrix part of a set instead of the partner rule
 ROLLED = os.environ.get('GEN_PQ_ROLLED', '') == '1'                # the whole-loop block with run-time slot arithmetic (A/B)
 LOOP_CLOCK = os.environ.get('GEN_PQ_LOOP_CLOCK', '') == '1'     # s_memtime in s[52:53] / s[54:55] around the whole-loop block
 TILE_BYTES = (1152 + NC*128 + 32)*8          # ctrl_pq.hip: pq_tile_doubles(NC) * 8 (checked there)
@@ -474,7 +475,11 @@ def build_loop_unrolled():
                 st.lds(f'ds_read_b128 {v4(Q01)}, {A("a_q1")}', 'q01')
             elif stage == 4:
                 st.lds(f'ds_read_b128 {v4(Q23)}, {A("a_q1", 4096)}', 'q23')
+        if PHASE_PRIO:
+            e(f's_setprio {PHASE_PRIO.split(",")[0]}')
         vector_part(st, 0, inner)
+        if PHASE_PRIO:
+            e(f's_setprio {PHASE_PRIO.split(",")[1]}')
         # tile it + 1 published?  (its flag was read a tile ago; the slow path spins, bounded; no wait behind the last tile)
         glue0 = [f's_add_i32 {S["t"]}, {S["it"]}, 2',
                  (f's_cmp_ge_i32 {S["fnext"]}, {S["t"]}',
@@ -486,10 +491,14 @@ def build_loop_unrolled():
                   f'L_ready{k}_%=:')]
         matrix_part(st, 0, glue0)
         st.fifo = [t if t in ('q01', 'q23', 'psi', 'flag', 'partner') else 'old' for t in st.fifo]
+        if PHASE_PRIO:
+            e(f's_setprio {PHASE_PRIO.split(",")[0]}')
         vector_part(st, 1, lambda stage: next_tile_requests(st, stage))
+        if PHASE_PRIO:
+            e(f's_setprio {PHASE_PRIO.split(",")[1]}')
         glue1 = [f'v_readfirstlane_b32 {S["fnext"]}, {V["flag"]}',
                  f'v_add_u32_e32 {V["progress"]}, 1, {V["progress"]}']
-        if prio_here:
+        if prio_here and not PHASE_PRIO:
             glue1 += [
                  f'v_readfirstlane_b32 {S["p"]}, {V["partner"]}',
                  f's_add_i32 {S["t"]}, {S["it"]}, {LOCKSTEP}',
