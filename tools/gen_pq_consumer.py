@@ -87,6 +87,7 @@ LOCKSTEP = int(os.environ.get('GEN_PQ_LOCKSTEP', '0'))
 MERGE_WAITS = os.environ.get('GEN_PQ_MERGE_WAITS', '') == '1'      # one wait per set instead of one per stage
 PRIO_EVERY = int(os.environ.get('GEN_PQ_PRIO_EVERY', '1'))          # partner priority every n-th tile (unrolled form)
 PRIO_LOW, PRIO_HIGH = (int(x) for x in os.environ.get('GEN_PQ_PRIOS', '0,1').split(','))   # consumer priorities: normal, behind its partner
+PRIO_EARLY = os.environ.get('GEN_PQ_PRIO_EARLY', '') == '1'        # tuning: the partner rule decided behind set 0's matrix instructions (half a tile fresher)
 PHASE_PRIO = os.environ.get('GEN_PQ_PHASE_PRIO', '')    # tuning: 'v,m' = static priorities of the vector / matrix part of a set instead of the partner rule
 ROLLED = os.environ.get('GEN_PQ_ROLLED', '') == '1'                # the whole-loop block with run-time slot arithmetic (A/B)
 LOOP_CLOCK = os.environ.get('GEN_PQ_LOOP_CLOCK', '') == '1'     # s_memtime in s[52:53] / s[54:55] around the whole-loop block
@@ -489,6 +490,23 @@ def build_loop_unrolled():
                   f's_cbranch_scc1 L_ready{k}_%=',
                   f's_branch L_spin{k}_%=',
                   f'L_ready{k}_%=:')]
+        if PRIO_EARLY and prio_here and not PHASE_PRIO:
+            st.need('partner')
+            glue0 = glue0 + [
+                 f'v_readfirstlane_b32 {S["p"]}, {V["partner"]}',
+                 f's_add_i32 {S["t"]}, {S["it"]}, {LOCKSTEP}',
+                 (f's_cmp_gt_i32 {S["p"]}, {S["t"]}',
+                  f's_cselect_b32 {S["want"]}, 1, 0',
+                  f's_cmp_eq_u32 {S["want"]}, {S["prio"]}',
+                  f's_cbranch_scc1 L_prio_done{k}_%=',
+                  f's_mov_b32 {S["prio"]}, {S["want"]}',
+                  f's_cmp_eq_u32 {S["want"]}, 1',
+                  f's_cbranch_scc1 L_prio_hi{k}_%=',
+                  f's_setprio {PRIO_LOW}',
+                  f's_branch L_prio_done{k}_%=',
+                  f'L_prio_hi{k}_%=:',
+                  f's_setprio {PRIO_HIGH}',
+                  f'L_prio_done{k}_%=:')]
         matrix_part(st, 0, glue0)
         st.fifo = [t if t in ('q01', 'q23', 'psi', 'flag', 'partner') else 'old' for t in st.fifo]
         if PHASE_PRIO:
@@ -498,7 +516,7 @@ def build_loop_unrolled():
             e(f's_setprio {PHASE_PRIO.split(",")[1]}')
         glue1 = [f'v_readfirstlane_b32 {S["fnext"]}, {V["flag"]}',
                  f'v_add_u32_e32 {V["progress"]}, 1, {V["progress"]}']
-        if prio_here and not PHASE_PRIO:
+        if prio_here and not PHASE_PRIO and not PRIO_EARLY:
             glue1 += [
                  f'v_readfirstlane_b32 {S["p"]}, {V["partner"]}',
                  f's_add_i32 {S["t"]}, {S["it"]}, {LOCKSTEP}',
