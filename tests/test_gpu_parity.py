@@ -2135,9 +2135,9 @@ def test_libffk_before_torch_shares_one_hip_runtime():
         res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True,
                              timeout=240)
     except subprocess.TimeoutExpired:
-        # seen once in about ten runs of the suite on the pool's boxes (round 5): the second process never got
-        # through the start-up of the GPU runtime -- nothing of this library had run in it yet.  What the test pins
-        # is the ORDER of initialisation when the child does start.
+        # seen once in about ten runs of the suite on the pool's boxes (round 5): the second process printed nothing
+        # in 300 s -- it hung somewhere in its own GPU start-up, with the same library that passes before and after.
+        # What the test pins is the ORDER of initialisation in a child that does start.
         pytest.skip('the child interpreter did not get through GPU start-up in 240 s (environment)')
     assert res.returncode == 0 and 'shared' in res.stdout, res.stderr[-2000:]
 
