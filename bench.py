@@ -309,11 +309,7 @@ def bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream, ra
         kernel_ms=kernel_ms, executed_flops=st['accumulate_flops'],
         tflops=st['accumulate_flops']/(kernel_ms*1e-3)/1e12,
         frac=st['accumulate_flops']/(kernel_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
-        geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')},
-        geometry_note='two launches since round 3 (six operators per 32-omega tile: grid '
-                      f"({(len(omega) + 31)//32}, {cfg['A']//6}, {st['chunks']}), then the remaining "
-                      f"{cfg['A'] % 6} on 64-omega tiles); `geometry` is the planner's three-operator "
-                      'shape, which fixes the segment chunks' if cfg['A'] >= 6 else None)
+        geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')})
 
 
 def bench_config4_full(ff, torch, lib, _lib, DevicePipeline, device, stream):
@@ -336,9 +332,70 @@ def bench_config4_full(ff, torch, lib, _lib, DevicePipeline, device, stream):
         workload='d=8, 512 segments, 9 noise ops, Pauli basis, seed 43: ALL 65536 omega on one GPU, '
                  'diagonalize -> infidelity, HBM-resident',
         ms=ms, elements_per_s=E/(ms*1e-3), dominant_kernel='ffk::ctrl_accumulate (d = 8)',
-        kernel_ms_last_launch=kernel_ms, executed_flops=st['accumulate_flops'],
-        note='kernel_ms_last_launch: the d = 8 path issues two accumulate launches (six operators, then three); '
-             'the events bracket the last one')
+        kernel_ms=kernel_ms, executed_flops=st['accumulate_flops'],
+        tflops=st['accumulate_flops']/(kernel_ms*1e-3)/1e12,
+        frac=st['accumulate_flops']/(kernel_ms*1e-3)/1e12/FP64_PEAK_TFLOPS)
+
+
+def bench_other_dimensions(ff, torch, lib, _lib, DevicePipeline, device, stream):
+    """The accumulate kernels no bench entry covered until round 6: ctrl.hip's symmetric
+    generate / contract kernel at d = 2 and d = 3 (the reference's most common case: one qubit, one qutrit) and at
+    d = 6 (the shape of doc/source/examples/calculating_quantum_processes.ipynb's CNOT: 6 noise operators, 250
+    segments, 400 omega), and generic.hip's runtime-d kernel at d = 32 (five qubits).  Each entry: ms per pass
+    (diagonalize -> infidelity, HBM-resident; d = 32: the control-matrix call on host arrays, transfers included),
+    the accumulate kernel by HIP events, its executed flops (ffk_api.hip::accumulate_flops) and the FP64 fraction.
+    Reference loop numeric.py:707-881."""
+    entries = []
+    shapes = [dict(d=2, G=256, A=3, W=4096, basis='GGM(2)', seed=52, kernel='ffk::ctrl_accumulate_kernel<2> (ctrl.hip)'),
+              dict(d=3, G=256, A=3, W=4096, basis='GGM(3)', seed=53, kernel='ffk::ctrl_accumulate_kernel<3> (ctrl.hip)'),
+              dict(d=6, G=250, A=6, W=400, basis='GGM(6)', seed=56, kernel='ffk::ctrl_accumulate_kernel<6> (ctrl.hip)'),
+              dict(d=2, G=4096, A=2, W=500, basis='GGM(2)', seed=57,
+                   kernel='ffk::ctrl_accumulate_wave_kernel<2> (ctrl.hip, >= 1024 segments)')]
+    for sh in shapes:
+        d, G, A, W = sh['d'], sh['G'], sh['A'], sh['W']
+        c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(sh['seed'], d, G, A)
+        omega = wl.random_pulse_omega(dt, W)
+        basis = ff.Basis.ggm(d)
+        pipe = DevicePipeline(c_opers, c_coeffs, n_opers, n_coeffs, dt, basis, omega, spectrum=1e-3/omega,
+                              device=device)
+        ms, kernel_ms = time_pipeline(pipe, torch, lib, _lib, stream, reps=20, warm_s=0.1)
+        st = _lib.stats()
+        entries.append(dict(
+            config=f"d={d}", workload=f"d={d}, {G} segments, {A} noise ops, {sh['basis']}, {W} omega, seed {sh['seed']}: "
+                                      'diagonalize -> infidelity, HBM-resident',
+            ms=ms, elements_per_s=G*W*A*d*d/(ms*1e-3), dominant_kernel=sh['kernel'], kernel_ms=kernel_ms,
+            executed_flops=st['accumulate_flops'], tflops=st['accumulate_flops']/(kernel_ms*1e-3)/1e12,
+            frac=st['accumulate_flops']/(kernel_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+            geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')}))
+        del pipe
+    # d = 32: the runtime-d kernels serve the array calls (DevicePipeline is compiled per dimension, d <= 16)
+    d, G, A, W = 32, 100, 10, 1000
+    c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(59, d, G, A)
+    omega = wl.random_pulse_omega(dt, W)
+    basis = ff.Basis.pauli(5)
+    H = np.einsum('ijk,il->ljk', c_opers, c_coeffs)
+    D, V, Q = ff.numeric.diagonalize(H, dt)
+    timer = AccumulateTimer(lib, _lib, 1)
+    best, kernel_ms = float('inf'), float('nan')
+    for rep in range(3):
+        timer.arm(0)
+        t0 = time.perf_counter()
+        ff.numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+        best = min(best, time.perf_counter() - t0)
+        timer.disarm()
+        kernel_ms = timer.read_ms()[0]
+    st = _lib.stats()
+    timer.close()
+    entries.append(dict(
+        config='d=32', workload='d=32 (five qubits), 100 segments, 10 noise ops, Pauli(5) (1024 elements), 1000 omega, '
+                                'seed 59: calculate_control_matrix_from_scratch on host arrays (R is 164 MB: the '
+                                'call is mostly its copy back)',
+        ms=best*1e3, elements_per_s=G*W*A*d*d/best, dominant_kernel='ffk::accumulate_generic_kernel (generic.hip)',
+        kernel_ms=kernel_ms, executed_flops=st['accumulate_flops'],
+        tflops=st['accumulate_flops']/(kernel_ms*1e-3)/1e12,
+        frac=st['accumulate_flops']/(kernel_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+        geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')}))
+    return entries
 
 
 def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
@@ -440,12 +497,19 @@ def bench_config3(ff):
     _, cliffords = wl.rb_cliffords(ff, omega, cfg['T'])
     draw = wl.rb_draw(cfg['n_gates'], cfg['seed'])
     seq = [cliffords[k] for k in draw]
-    times = []
-    for _ in range(12):           # (the first calls pay the arena, the pools and the clocks' ramp: min of 12)
+    from filter_functions_amd import pulse_sequence as ps_mod
+    times, cold = [], []
+    for rep in range(12):
         t0 = time.perf_counter()
         total = ff.concatenate(seq)
         total.get_filter_function(omega)
         times.append(time.perf_counter() - t0)
+    for rep in range(5):          # every call with the remembered merged tables of the gate set forgotten first
+        ps_mod.clear_merged_tables()
+        t0 = time.perf_counter()
+        total = ff.concatenate(seq)
+        total.get_filter_function(omega)
+        cold.append(time.perf_counter() - t0)
     table = np.array([c.get_control_matrix(omega) for c in cliffords])
     phases = np.array([c.get_total_phases(omega) for c in cliffords])
     L = util.adot(np.array([p.total_propagator_liouville for p in seq[:-1]]))
@@ -513,7 +577,14 @@ def bench_config3(ff):
         config=3, workload='1000-gate randomized-benchmarking sequence (24 Cliffords from X/2, Y/2), '
                            'd=2, 1 noise op, 8192 omega, ff.concatenate + get_filter_function on host '
                            'arrays',
-        ms=min(times)*1e3, elements_per_s=E/min(times),
+        ms=float(np.median(times))*1e3, elements_per_s=E/float(np.median(times)),
+        ms_first=times[0]*1e3, ms_median=float(np.median(times))*1e3, ms_min=min(times)*1e3,
+        ms_median_tables_forgotten=float(np.median(cold))*1e3,
+        ms_note='12 identical calls: ms_first pays the arena, the block pools, the merge of the gate set\'s operator '
+                'tables and the clocks\' ramp; from the second call on the merged tables of the 24 pulse objects are '
+                'remembered (pulse_sequence._merged_tables: randomized benchmarking draws many sequences from one gate '
+                'set); ms_median_tables_forgotten: five more calls, each after clear_merged_tables(); `ms` and '
+                '`elements_per_s` are the MEDIAN of the 12 (rounds 3-5 reported the minimum)',
         dominant_kernel='ffk::from_atomic_block_kernel<1,4> (table rule + reduction + F, LDS-staged tables)',
         rule_call_ms=min(rule)*1e3,
         note='ms = whole Python call incl. host bookkeeping over 1000 pulse objects; the 24 Cliffords '
@@ -521,6 +592,50 @@ def bench_config3(ff):
              'ffk_concatenate_sequence_resident alone (two launches: front = gather + running products + '
              'Liouville representations + total phases, rule = table rule + slab reduction + F); '
              'rule_call_ms = the indexed concatenation rule alone on host arrays (tables H2D + kernel + R D2H)')
+
+
+def bench_config3_optimized(ff):
+    """Config 3 with the example's OPTIMISED gate set (examples/randomized_benchmarking.py:112-151): X/2, Y/2 as
+    100-segment pulses (data: tests/golden/rb_optimized_gates.npz), so the atoms come from the d = 2 from-scratch
+    kernel, the 24 Cliffords (100-700 segments) from the concatenation rule, the 1000-gate sequence from the rule
+    kernel with 332 200 segments of host bookkeeping."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tests', 'golden', 'rb_optimized_gates.npz'))
+    cfg = wl.CONFIG3
+    omega = wl.rb_omega(cfg['W'], cfg['T'])
+    gates = {name: (g[f'{name}_eps'], g[f'{name}_t'], g[f'{name}_B']) for name in ('X2', 'Y2')}
+    t0 = time.perf_counter()
+    atoms, cliffords = wl.rb_cliffords_optimized(ff, omega, gates)
+    t_gate_set = time.perf_counter() - t0
+    t_atoms = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for name in ('x', 'y'):
+            fresh = ff.PulseSequence(list(zip(atoms[name].c_opers, atoms[name].c_coeffs)),
+                                     list(zip(atoms[name].n_opers, atoms[name].n_coeffs)), atoms[name].dt)
+            fresh.cache_control_matrix(omega)
+        t_atoms.append(time.perf_counter() - t0)
+    draw = wl.rb_draw(cfg['n_gates'], cfg['seed'])
+    seq = [cliffords[k] for k in draw]
+    times = []
+    for _ in range(8):
+        t0 = time.perf_counter()
+        total = ff.concatenate(seq)
+        total.get_filter_function(omega)
+        times.append(time.perf_counter() - t0)
+    infid = float(ff.infidelity(total, wl.rb_spectrum(omega), omega)[0])
+    return dict(
+        config='3 (optimised gates)',
+        workload='the same 1000-gate sequence from the example\'s optimised X/2, Y/2 pulses (100 segments each, '
+                 'examples/data/X2ID.mat, Y2ID.mat): 24 Cliffords of 100-700 segments, 332 200 segments in all, d=2, '
+                 '1 noise op, 8192 omega',
+        ms_first=times[0]*1e3, ms_median=float(np.median(times))*1e3, ms_min=min(times)*1e3,
+        ms=float(np.median(times))*1e3, n_segments=int(len(total)),
+        elements_per_s=cfg['n_gates']*cfg['W']*4/float(np.median(times)),
+        gate_set_ms=t_gate_set*1e3, atoms_from_scratch_ms=float(np.median(t_atoms))*1e3, infidelity=infid,
+        note='gate_set_ms: both atoms from scratch (ffk::ctrl_accumulate_kernel<2>, 100 segments, 8192 omega) + 41 '
+             'concatenations building the 24 Cliffords, once; atoms_from_scratch_ms: the two atoms alone (PulseSequence + '
+             'cache_control_matrix); ms: ff.concatenate + get_filter_function of the 1000-gate sequence, median of 8 '
+             '(the coefficient tables of 332 200 segments are host bookkeeping)')
 
 
 def bench_published_example(ff):
@@ -660,6 +775,45 @@ def self_launch(n_gpus, argv, run=None):
 # ---- scaling model ("the measured single-GPU throughput plus the modelled comm cost") ----
 XGMI_LINK_GBS_PER_DIRECTION = 76.5     # 7 links x ~153 GB/s per GPU, bidirectional: half per direction
 RCCL_SMALL_MESSAGE_LATENCY_MS = 0.025  # launch + rendezvous of one all-gather (assumed; not measured)
+
+
+def measure_all_gather(torch, dist, device, world, rank, block_bytes_list, reps=100):
+    """N > 1: the RCCL all-gather ALONE, per rank and at several block sizes (the headline's F block, config 4's),
+    HIP events on the current stream, next to the two constants `scaling_model` assumes -- so that the first run on
+    real xGMI validates or replaces them without a code change.  Returns a dict for rank 0: per
+    size the per-rank mean / min in ms and, from the smallest and the largest size, the latency and the per-link rate
+    the model's formula t = latency + bytes / rate implies."""
+    rows = []
+    for nbytes in block_bytes_list:
+        n = max(2, int(nbytes)//16*2)
+        mine = torch.full((n,), float(rank), dtype=torch.float64, device=device)
+        full = torch.empty((world*n,), dtype=torch.float64, device=device)
+        for _ in range(10):
+            dist.all_gather_into_tensor(full, mine)
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record()
+            dist.all_gather_into_tensor(full, mine)
+            b.record()
+        torch.cuda.synchronize(device)
+        ms = [a.elapsed_time(b) for a, b in ev]
+        stat = torch.tensor([sum(ms)/len(ms), min(ms)], dtype=torch.float64, device=device)
+        every = [torch.zeros(2, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(every, stat)
+        rows.append({'block_bytes': n*8, 'mean_ms_per_rank': [float(e[0]) for e in every],
+                     'min_ms_per_rank': [float(e[1]) for e in every]})
+    out = {'sizes': rows, 'model_assumes': {'link_GBps_per_direction': XGMI_LINK_GBS_PER_DIRECTION,
+                                            'rccl_all_gather_latency_ms': RCCL_SMALL_MESSAGE_LATENCY_MS}}
+    if len(rows) >= 2:
+        (b0, t0), (b1, t1) = [(r['block_bytes'], max(r['mean_ms_per_rank'])) for r in (rows[0], rows[-1])]
+        if b1 > b0 and t1 > t0:
+            rate = (b1 - b0)/((t1 - t0)*1e-3)/1e9
+            out['measured_fit'] = {'link_GBps_per_direction': rate, 'latency_ms': t0 - b0/(rate*1e9)*1e3,
+                                   'note': 'slowest rank\'s mean at the smallest and the largest size, t = latency + '
+                                           'block_bytes / rate (a rank receives its N - 1 blocks on N - 1 links at once)'}
+    return out
 
 
 def scaling_model(step_ms_one_gpu, f_block_bytes, configs):
@@ -929,6 +1083,12 @@ def main():
             dist.all_reduce(word, op=dist.ReduceOp.MAX)
             push_error_word = int(word.item())
     pipe.check_status()                          # eigensolver flags of the device-resident run
+    all_gather_measured = None
+    if use_dist:
+        # the collective alone at the headline's block size and at config 4's per-rank size: what `scaling_model`
+        # assumes (76.5 GB/s per link and direction, 25 us) against what this node does
+        all_gather_measured = measure_all_gather(torch, dist, device, world, rank,
+                                                 [A*A*args.omega_per_gpu*16, 9*9*(65536//world)*16])
     gather_ab = {'fallback': gather_fallback} if gather_fallback else None
     if gather_fallback:
         os.environ['FFK_GATHER'] = 'rccl'        # the strong-scaled configs below follow suit
@@ -1017,10 +1177,12 @@ def main():
             configs.append(bench_config5_strong(ff, torch, dist, DevicePipeline, device, world, rank))
         elif rank == 0:
             configs.append(bench_config3(ff))
+            configs.append(bench_config3_optimized(ff))
             configs.append(bench_config4_shard(ff, torch, lib, _lib, DevicePipeline, device, stream)[1])
             configs.append(bench_config4_full(ff, torch, lib, _lib, DevicePipeline, device, stream))
             configs.append(bench_config5(ff, torch, lib, _lib, DevicePipeline, device, compute_stream))
             configs.append(bench_liouville(ff, torch, lib, _lib, device))
+            configs.extend(bench_other_dimensions(ff, torch, lib, _lib, DevicePipeline, device, stream))
             if args.published_example:     # doc notebook (concatenate_periodic): outside SURVEY section 8
                 configs.append(bench_published_example(ff))
 
@@ -1129,6 +1291,8 @@ def main():
         }
         if configs:
             out['configs'] = configs
+        if all_gather_measured is not None:
+            out['all_gather_measured'] = all_gather_measured
         if world == 1:      # the model extrapolates from what ONE GPU measures
             out['scaling_model'] = scaling_model(elapsed/args.steps*1e3, A*A*args.omega_per_gpu*16, configs)
         if world == 1 and not args.child:

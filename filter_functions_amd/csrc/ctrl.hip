@@ -795,25 +795,31 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     // d = 4: the producer/consumer kernel with the second product on the matrix cores (ctrl_pq.hip); the tuning
     // variants 1/2 (ffk_set_accumulate_variant) select the symmetric kernel below
     if (g_use_gsplit && !g_use_wave_kernel && pq_accumulate_supported(d, A) && !geo.mfma) {
-        const int nc = pq_accumulate_ops_per_block(A);
+        // groups of three operators, the remainder as groups of two (or a single operator): one launch per group
+        // size, each with the same segment chunks (ctrl_pq.hip: pq_accumulate_groups)
+        const PqGroups grp = pq_accumulate_groups(A);
+        const int nc = grp.n3 > 0 ? 3 : (grp.n2 > 0 ? 2 : 1);
         geo.pc = true;
         geo.wave_kernel = false;
         geo.nwaves = pq_accumulate_waves(nc);
-        geo.task_groups = (A + nc - 1)/nc;
+        geo.task_groups = grp.n3 + grp.n2 + grp.n1;
         geo.na_blk = nc;
         geo.nbuf = 2;
         geo.lds_bytes = pq_accumulate_lds_bytes(nc);
-        const long tiles = static_cast<long>((W + 63)/64)*geo.task_groups;
+        const long wt = (W + 63)/64;
+        const long launch_tiles[3] = {wt*grp.n3, wt*grp.n2, wt*grp.n1};
         int chunks = forced_chunks;
         if (chunks <= 0) {
-            // one block per CU and round; a block's fixed cost (first tile, last hand-over) is about three tiles
+            // one block per CU and round, per launch; a block's fixed cost (first tile, last hand-over) is about
+            // three tiles
             const long capacity = device_cu_count();
             const int max_chunks = std::max(1, std::min((G + 15)/16, 256));
             double best = 0.0;
             chunks = 1;
             for (int c = 1; c <= max_chunks; ++c) {
-                const long rounds = (tiles*c + capacity - 1)/capacity;
-                const double cost = static_cast<double>(rounds)*((G + c - 1)/c + 3);
+                double cost = 0.0;
+                for (long tiles : launch_tiles)
+                    if (tiles > 0) cost += static_cast<double>((tiles*c + capacity - 1)/capacity)*((G + c - 1)/c + 3);
                 if (c == 1 || cost < best*0.999) {
                     best = cost;
                     chunks = c;
@@ -989,14 +995,15 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
 
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
-                             hipStream_t stream, const ExpandEpilogue* expand, bool* expanded) {
+                             hipStream_t stream, const ExpandEpilogue* expand, bool* expanded,
+                             const cplx* d4_wfold) {
     if (expanded) *expanded = false;
     if (geo.generic)
         return launch_accumulate_generic(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
                                          stream);
     if (geo.pc)
-        return launch_accumulate_pq(omega, W, segtab, ops, G, d, A, geo.na_blk, geo.chunks,
-                                    geo.chunk_len, Ypart, stream);
+        return launch_accumulate_pq(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart, d4_wfold,
+                                    stream);
     if (geo.pcw)
         return launch_accumulate_pcr(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
                                      stream);

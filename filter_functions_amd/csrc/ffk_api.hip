@@ -13,12 +13,6 @@ thread_local ffk_stats g_stats = {};
 std::atomic<unsigned long long> g_knob_epoch{0};
 int g_forced_chunks = 0;
 thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr, g_ev_gate = nullptr;
-thread_local cplx* g_fuse_F = nullptr;
-thread_local bool g_fuse_F_done = false;
-// hints of the resident API path (ffk_api_resident.hip) to the device-pointer calls it is built from:
-thread_local int* g_eigh_fail_count = nullptr;       // the eigensolver counts flagged segments into this mapped host word
-thread_local bool g_infid_spectrum_on_host = false;  // spectrum and idx of ffk_infidelity_dev are in mapped host memory
-thread_local EighControls g_eigh_controls = {nullptr, nullptr, 0};   // ffk_pipeline_dev's Hamiltonian, as its summands
 Arena g_arena;
 
 int fail(int code, const char* fmt, ...) {
@@ -31,25 +25,35 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-// ---- sticky fault word of the kernels that wait on flags (ctrl_pq.hip) -------------------------
-// One int in mapped pinned host memory per process: a kernel whose bounded flag wait runs out stores
-// a code there (its results are garbage from then on), the host reads it with a plain load after the
-// synchronisation it does anyway -- no copy, no extra launch; nothing is written on the good path.
+// ---- sticky fault words of the kernels that wait on flags (ctrl_pq.hip) ------------------------
+// One block of ints in mapped, portable pinned host memory per process, one word per host thread (slots are handed
+// out round robin on a thread's first use): a kernel whose bounded flag wait runs out stores a code in the word its
+// launcher passed it as an ARGUMENT (so the word is right on whichever device the launch goes to; its results are
+// garbage from then on), the host reads it with a plain load after the synchronisation it does anyway -- no copy, no
+// extra launch; nothing is written on the good path.  A thread sees only the faults of launches it enqueued itself.
 namespace {
+constexpr int kFaultWords = 256;
 std::once_flag g_fault_once;
-int* g_fault_host = nullptr;
-int* g_fault_dev = nullptr;
+int* g_fault_host = nullptr;      // kFaultWords ints
+int* g_fault_dev = nullptr;       // the same block as the devices see it
+std::atomic<unsigned> g_fault_next{0};
+thread_local int g_fault_slot = -1;
+int fault_slot() {
+    if (g_fault_slot < 0) g_fault_slot = static_cast<int>(g_fault_next.fetch_add(1) % kFaultWords);
+    return g_fault_slot;
+}
 }  // namespace
 }  // namespace ffk_api
 namespace ffk {
 int* kernel_fault_word() {
     std::call_once(ffk_api::g_fault_once, [] {
         void* h = nullptr;
+        const size_t bytes = sizeof(int)*ffk_api::kFaultWords;
 #if defined(FFK_HOST_SANITIZE)
-        if (hipHostMalloc(&h, 64, 0) != hipSuccess) return;
+        if (hipHostMalloc(&h, bytes, 0) != hipSuccess) return;
         ffk_api::g_fault_dev = static_cast<int*>(h);
 #else
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return;
+        if (hipHostMalloc(&h, bytes, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return;
         void* dptr = nullptr;
         if (hipHostGetDevicePointer(&dptr, h, 0) != hipSuccess) {
             (void)hipHostFree(h);
@@ -57,20 +61,18 @@ int* kernel_fault_word() {
         }
         ffk_api::g_fault_dev = static_cast<int*>(dptr);
 #endif
-        *static_cast<volatile int*>(h) = 0;
+        for (int i = 0; i < ffk_api::kFaultWords; ++i) static_cast<volatile int*>(h)[i] = 0;
         ffk_api::g_fault_host = static_cast<int*>(h);
-#if !defined(FFK_HOST_SANITIZE)
-        (void)pq_bind_fault_word(ffk_api::g_fault_dev);
-#endif
     });
-    return ffk_api::g_fault_dev;
+    return ffk_api::g_fault_dev ? ffk_api::g_fault_dev + ffk_api::fault_slot() : nullptr;
 }
 }  // namespace ffk
 namespace ffk_api {
 int kernel_fault_peek(bool clear) {
     if (!g_fault_host) return 0;
-    const int w = *static_cast<volatile int*>(g_fault_host);
-    if (w != 0 && clear) *static_cast<volatile int*>(g_fault_host) = 0;
+    volatile int* word = g_fault_host + fault_slot();
+    const int w = *word;
+    if (w != 0 && clear) *word = 0;
     return w;
 }
 int kernel_fault_status() {
@@ -80,6 +82,14 @@ int kernel_fault_status() {
                 "a flag wait inside the d = 4 accumulate kernel ran out (code %d): the launch's results are "
                 "invalid", w);
 }
+int kernel_fault_stale() {
+    const int w = kernel_fault_peek(true);
+    if (w == 0) return FFK_OK;
+    return fail(FFK_EKERNEL,
+                "an EARLIER asynchronous launch of this thread reported a kernel fault (code %d) that was never "
+                "collected with ffk_kernel_fault_status: its results are invalid; this call has not run", w);
+}
+int kernel_fault_slot_for_selftest() { return fault_slot(); }
 
 int arena_reserve(size_t bytes, void** out) {
     int dev = 0;
@@ -109,7 +119,7 @@ size_t ctrl_ws_bytes(int W, int N, int A, int G, int d, int chunks) {
     b += align_up(sizeof(cplx)*size_t(chunks)*A*d*d*W);                   // Ypart
     b += align_up(sizeof(cplx)*size_t(A)*d*d*W);                          // Bt
     b += ffk::expand_workspace_bytes(N, d);                               // compacted basis
-    if (d == 4) b += align_up(sizeof(cplx)*ffk::d4_wfold_elems(G, A));    // folded W_a (ffk_internal.h g_d4_wfold), LAST
+    if (d == 4) b += align_up(sizeof(cplx)*ffk::d4_wfold_elems(G, A));    // folded W_a (ffk_internal.h d4_wfold), LAST
     return b;
 }
 
@@ -130,7 +140,7 @@ double accumulate_flops(int W, int A, int G, int d) {
         // and blocks of nc = min(3, A) operators execute nc of them whether or not the last block is
         // full; per block the tile 13 x 10 + 62 = 192 and c = psi conj(T), cr + ci: 16 x 7 = 112.
         // The fold of W_a (6 per operator for Bbar times e^{ib} T, 6 per block for that product) is NOT counted:
-        // this entry point has the prologue kernel do it once per segment (ffk_internal.h g_d4_wfold), the kernel
+        // this entry point has the prologue kernel do it once per segment (ffk_internal.h d4_wfold), the kernel
         // copies it.  (Until the last change of round 5 the kernel folded it per frequency block: 630 nc + 310.)
         const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);
         if (geo.pc) {
@@ -344,6 +354,14 @@ size_t ffk_diagonalize_workspace_bytes(int G, int d) {
 int ffk_diagonalize_dev(const double* hamiltonian, const double* dt, int G, int d, double* eigvals,
                         double* eigvecs, double* propagators, void* workspace,
                         size_t workspace_bytes, void* stream) {
+    return diagonalize_dev_impl(hamiltonian, dt, G, d, eigvals, eigvecs, propagators, workspace, workspace_bytes,
+                                stream, PassOptions{});
+}
+}  // extern "C"
+namespace ffk_api {
+int diagonalize_dev_impl(const double* hamiltonian, const double* dt, int G, int d, double* eigvals, double* eigvecs,
+                         double* propagators, void* workspace, size_t workspace_bytes, void* stream,
+                         const PassOptions& opt) {
     FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
     FFK_REQUIRE(G >= 1, "need at least one segment, got G=%d", G);
     FFK_REQUIRE(hamiltonian && dt && eigvals && eigvecs && propagators && workspace, "NULL argument");
@@ -352,7 +370,7 @@ int ffk_diagonalize_dev(const double* hamiltonian, const double* dt, int G, int 
     const DiagWs w = slice_diag_ws(workspace, workspace_bytes, G, d);
     const cplx* H = reinterpret_cast<const cplx*>(hamiltonian);
     FFK_HIP(ffk::launch_eigh_expm(H, dt, G, d, eigvals, reinterpret_cast<cplx*>(eigvecs), w.seg_prop,
-                                  w.status, s, g_eigh_fail_count));
+                                  w.status, s, opt.eigh_fail_count));
     if (ffk::use_fused_front(G, d)) {
         cplx* totals = static_cast<cplx*>(w.small);
         FFK_HIP(ffk::launch_scan_local(w.seg_prop, G, d, ffk::front_chunk(d), w.qloc, totals, s));
@@ -365,6 +383,8 @@ int ffk_diagonalize_dev(const double* hamiltonian, const double* dt, int G, int 
     }
     return FFK_OK;
 }
+}  // namespace ffk_api
+extern "C" {
 
 int ffk_diagonalize(const double* hamiltonian, const double* dt, int G, int d, double* eigvals,
                     double* eigvecs, double* propagators) {
@@ -416,6 +436,18 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
                            const double* t, int G, int d, unsigned flags, double* control_matrix,
                            double* noise_operators, void* workspace, size_t workspace_bytes,
                            void* stream) {
+    PassOptions opt;
+    return control_matrix_dev_impl(eigvals, eigvecs, propagators, omega, W, basis, N, n_opers, A, n_coeffs, dt, t, G,
+                                   d, flags, control_matrix, noise_operators, workspace, workspace_bytes, stream,
+                                   opt);
+}
+}  // extern "C"
+namespace ffk_api {
+int control_matrix_dev_impl(const double* eigvals, const double* eigvecs, const double* propagators,
+                            const double* omega, int W, const double* basis, int N, const double* n_opers, int A,
+                            const double* n_coeffs, const double* dt, const double* t, int G, int d, unsigned flags,
+                            double* control_matrix, double* noise_operators, void* workspace,
+                            size_t workspace_bytes, void* stream, PassOptions& opt) {
     FFK_REQUIRE(d_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
     FFK_REQUIRE(eigvals && eigvecs && propagators && omega && n_opers && n_coeffs && dt && t && workspace,
@@ -434,18 +466,15 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     cplx* Bt = ws.take<cplx>(size_t(A)*d*d*W);
     void* ews = ws.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
     FFK_REQUIRE(Bt && ews, "workspace too small");
-    // d = 4: the prologue folds W_a once per segment for the accumulate kernel (a hint to both launches, reset below)
+    // d = 4: the prologue folds W_a once per segment for the accumulate kernel (handed to both launches)
     cplx* wfold = d == 4 ? ws.take<cplx>(ffk::d4_wfold_elems(G, A)) : nullptr;
     FFK_REQUIRE(d != 4 || wfold, "workspace too small");
 
     if (!(flags & FFK_INTERNAL_PROLOGUE_DONE)) {
-        ffk::g_d4_wfold = wfold;
-        const hipError_t pe = ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
-                                                   reinterpret_cast<const cplx*>(propagators),
-                                                   reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G, d, A,
-                                                   segtab, Tc, ops, nullptr, nullptr, s);
-        ffk::g_d4_wfold = nullptr;
-        FFK_HIP(pe);
+        FFK_HIP(ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
+                                     reinterpret_cast<const cplx*>(propagators),
+                                     reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, G, d, A, segtab, Tc, ops,
+                                     nullptr, nullptr, s, wfold));
     }
     if (g_ev_start && g_ev_stop) {
         // `gate`: an event of ANOTHER stream (the previous pass's accumulate kernel) that this
@@ -467,21 +496,19 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
         epilogue = {nnz, rows, vals, N, reinterpret_cast<cplx*>(control_matrix)};
     }
     bool expanded = false;
-    ffk::g_d4_wfold = wfold;            // (written by the prologue above, or by the fused front's with the same slicing)
-    const hipError_t ae = ffk::launch_accumulate(omega, W, segtab, ops, G, d, A, geo, Ypart, s,
-                                                 epilogue.R ? &epilogue : nullptr, &expanded);
-    ffk::g_d4_wfold = nullptr;
-    FFK_HIP(ae);
+    // (wfold: written by the prologue above, or by the fused front's with the same slicing)
+    FFK_HIP(ffk::launch_accumulate(omega, W, segtab, ops, G, d, A, geo, Ypart, s, epilogue.R ? &epilogue : nullptr,
+                                   &expanded, wfold));
     if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_stop, s));
     const size_t slab = size_t(A)*d*d*W;
     const cplx* Bsum = Ypart;
     if (expanded) {
-        // R is written; F (if wanted through g_fuse_F) is left to the caller's filter-function launch
-    } else if (compacted && control_matrix && !want_B && g_fuse_F && ffk::expand_ff_supported(A, N)) {
+        // R is written; F (if wanted through opt.fuse_F) is left to the caller's filter-function launch
+    } else if (compacted && control_matrix && !want_B && opt.fuse_F && ffk::expand_ff_supported(A, N)) {
         // only R and F are wanted and the basis lists are ready: chunk sum, expansion and F in one
         FFK_HIP(ffk::launch_expand_ff(Ypart, geo.chunks, slab, A, N, d, W,
-                                      reinterpret_cast<cplx*>(control_matrix), g_fuse_F, ews, s));
-        g_fuse_F_done = true;
+                                      reinterpret_cast<cplx*>(control_matrix), opt.fuse_F, ews, s));
+        opt.fuse_F_done = true;
     } else if (compacted && control_matrix && !want_B && geo.chunks > 1) {
         // only R is wanted and the basis lists are ready: expand straight from the chunk partials
         FFK_HIP(ffk::launch_expand_chunks(Ypart, geo.chunks, slab, A, N, d, W,
@@ -515,6 +542,8 @@ int ffk_control_matrix_dev(const double* eigvals, const double* eigvecs, const d
     g_stats.lds_bytes = geo.lds_bytes;
     return FFK_OK;
 }
+}  // namespace ffk_api
+extern "C" {
 
 int ffk_control_matrix(const double* eigvals, const double* eigvecs, const double* propagators,
                        const double* omega, int W, const double* basis, int N,
@@ -525,6 +554,7 @@ int ffk_control_matrix(const double* eigvals, const double* eigvecs, const doubl
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
     FFK_REQUIRE(eigvals && eigvecs && propagators && omega && n_opers && n_coeffs && dt && t,
                 "NULL argument");
+    if (int rc = kernel_fault_stale()) return rc;
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t dd = size_t(d)*d;
     const size_t wsb = ffk_control_matrix_workspace_bytes(W, N, A, G, d);
@@ -589,6 +619,7 @@ static int intermediates_impl(const double* eigvals, const double* eigvecs,
                 "NULL argument");
     FFK_REQUIRE(basis || !(basis_transformed || control_matrix_step), "basis is NULL");
     FFK_REQUIRE(size_t(G)*A <= 65535, "G*A = %zu too large for the materialising variant", size_t(G)*A);
+    if (int rc = kernel_fault_stale()) return rc;
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t dd = size_t(d)*d;
     // inputs + operands + every requested product, all resident at once (HBM is 288 GB)
@@ -772,6 +803,14 @@ size_t ffk_infidelity_workspace_bytes(int W, int n_idx, int s_ndim) {
 int ffk_infidelity_dev(const double* filter_function, int A, int W, const double* spectrum,
                        int s_ndim, const double* omega, const int32_t* idx, int n_idx, int d,
                        double* infid, void* workspace, size_t workspace_bytes, void* stream) {
+    return infidelity_dev_impl(filter_function, A, W, spectrum, s_ndim, omega, idx, n_idx, d, infid, workspace,
+                               workspace_bytes, stream, PassOptions{});
+}
+}  // extern "C"
+namespace ffk_api {
+int infidelity_dev_impl(const double* filter_function, int A, int W, const double* spectrum, int s_ndim,
+                        const double* omega, const int32_t* idx, int n_idx, int d, double* infid, void* workspace,
+                        size_t workspace_bytes, void* stream, const PassOptions& opt) {
     FFK_REQUIRE(filter_function && spectrum && omega && idx && infid && workspace, "NULL argument");
     FFK_REQUIRE(s_ndim >= 1 && s_ndim <= 3, "Expected spectrum to have < 4 dimensions, not %d", s_ndim);
     FFK_REQUIRE(A >= 1 && W >= 1 && n_idx >= 1 && d >= 1, "empty axis");
@@ -779,9 +818,11 @@ int ffk_infidelity_dev(const double* filter_function, int A, int W, const double
     FFK_HIP(ffk::launch_infidelity(reinterpret_cast<const cplx*>(filter_function), A, W,
                                    reinterpret_cast<const cplx*>(spectrum), s_ndim, omega, idx, n_idx,
                                    d, 0, infid, workspace, static_cast<hipStream_t>(stream),
-                                   g_infid_spectrum_on_host));
+                                   opt.infid_spectrum_on_host));
     return FFK_OK;
 }
+}  // namespace ffk_api
+extern "C" {
 
 int ffk_infidelity_sharded_dev(const double* filter_function_shards, int n_shards, int shard_width,
                                int A, const double* spectrum, int s_ndim, const double* omega,
@@ -894,6 +935,19 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
                      const int32_t* idx, int n_idx, double* eigvals, double* eigvecs,
                      double* propagators, double* control_matrix, double* filter_function,
                      double* infid, void* workspace, size_t workspace_bytes, void* stream) {
+    PassOptions opt;
+    return pipeline_dev_impl(hamiltonian, dt, t, G, d, omega, W, basis, N, n_opers, A, n_coeffs, spectrum, s_ndim, idx,
+                             n_idx, eigvals, eigvecs, propagators, control_matrix, filter_function, infid, workspace,
+                             workspace_bytes, stream, opt);
+}
+}  // extern "C"
+namespace ffk_api {
+int pipeline_dev_impl(const double* hamiltonian, const double* dt, const double* t, int G, int d,
+                      const double* omega, int W, const double* basis, int N, const double* n_opers, int A,
+                      const double* n_coeffs, const double* spectrum, int s_ndim, const int32_t* idx, int n_idx,
+                      double* eigvals, double* eigvecs, double* propagators, double* control_matrix,
+                      double* filter_function, double* infid, void* workspace, size_t workspace_bytes,
+                      void* stream, PassOptions& opt) {
     FFK_REQUIRE(d_templated_ok(d), "unsupported dimension d=%d (need 2 <= d <= %d)", d, FFK_MAX_D_TEMPLATED);
     FFK_REQUIRE(W >= 1 && N >= 1 && A >= 1 && G >= 1, "empty axis: W=%d N=%d A=%d G=%d", W, N, A, G);
     FFK_REQUIRE(hamiltonian && dt && t && omega && basis && n_opers && n_coeffs && workspace, "NULL argument");
@@ -918,13 +972,13 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
         hipStream_t s = static_cast<hipStream_t>(stream);
         const DiagWs w = slice_diag_ws(dws, dwsb, G, d);
         cplx* totals = static_cast<cplx*>(w.small);
-        if (g_eigh_controls.opers != nullptr && ffk::eigh_fail_count_supported(d))
-            FFK_HIP(ffk::launch_eigh_expm_controls(g_eigh_controls.opers, g_eigh_controls.coeffs, g_eigh_controls.n_c,
-                                                   dt, G, d, D, reinterpret_cast<cplx*>(V), w.seg_prop, w.status, s,
-                                                   g_eigh_fail_count));
+        if (opt.eigh_controls.opers != nullptr && ffk::eigh_fail_count_supported(d))
+            FFK_HIP(ffk::launch_eigh_expm_controls(opt.eigh_controls.opers, opt.eigh_controls.coeffs,
+                                                   opt.eigh_controls.n_c, dt, G, d, D, reinterpret_cast<cplx*>(V),
+                                                   w.seg_prop, w.status, s, opt.eigh_fail_count));
         else
-        FFK_HIP(ffk::launch_eigh_expm(reinterpret_cast<const cplx*>(hamiltonian), dt, G, d, D,
-                                      reinterpret_cast<cplx*>(V), w.seg_prop, w.status, s, g_eigh_fail_count));
+            FFK_HIP(ffk::launch_eigh_expm(reinterpret_cast<const cplx*>(hamiltonian), dt, G, d, D,
+                                          reinterpret_cast<cplx*>(V), w.seg_prop, w.status, s, opt.eigh_fail_count));
         FFK_HIP(ffk::launch_scan_local(w.seg_prop, G, d, ffk::front_chunk(d), w.qloc, totals, s));
         // same slicing as ffk_control_matrix_dev; the launch also compacts the basis (extra blocks)
         const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);
@@ -936,34 +990,34 @@ int ffk_pipeline_dev(const double* hamiltonian, const double* dt, const double* 
         cw.take<cplx>(size_t(A)*d*d*W);                // Bt
         void* ews = cw.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
         FFK_REQUIRE(ews, "workspace too small");
-        ffk::g_d4_wfold = d == 4 ? cw.take<cplx>(ffk::d4_wfold_elems(G, A)) : nullptr;
-        const hipError_t fe = ffk::launch_apply_prologue_compact(
+        cplx* wfold = d == 4 ? cw.take<cplx>(ffk::d4_wfold_elems(G, A)) : nullptr;
+        FFK_HIP(ffk::launch_apply_prologue_compact(
             w.qloc, totals, G, d, reinterpret_cast<cplx*>(Q), D, reinterpret_cast<const cplx*>(V),
             reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, A, segtab, Tc, ops,
-            reinterpret_cast<const cplx*>(basis), N, ews, s);
-        ffk::g_d4_wfold = nullptr;
-        FFK_HIP(fe);
+            reinterpret_cast<const cplx*>(basis), N, ews, s, wfold));
         cm_flags = FFK_INTERNAL_PROLOGUE_DONE | FFK_INTERNAL_COMPACT_DONE;
     } else {
-        if (int rc = ffk_diagonalize_dev(hamiltonian, dt, G, d, D, V, Q, dws, dwsb, stream)) return rc;
+        if (int rc = diagonalize_dev_impl(hamiltonian, dt, G, d, D, V, Q, dws, dwsb, stream, opt)) return rc;
     }
-    g_fuse_F = reinterpret_cast<cplx*>(F);
-    g_fuse_F_done = false;
-    const int rc_cm = ffk_control_matrix_dev(D, V, Q, omega, W, basis, N, n_opers, A, n_coeffs, dt, t,
-                                             G, d, cm_flags, R, nullptr, cws, cwsb, stream);
-    g_fuse_F = nullptr;
+    opt.fuse_F = reinterpret_cast<cplx*>(F);
+    opt.fuse_F_done = false;
+    const int rc_cm = control_matrix_dev_impl(D, V, Q, omega, W, basis, N, n_opers, A, n_coeffs, dt, t, G, d,
+                                              cm_flags, R, nullptr, cws, cwsb, stream, opt);
+    opt.fuse_F = nullptr;
     if (rc_cm) return rc_cm;
-    if (!g_fuse_F_done)
+    if (!opt.fuse_F_done)
         if (int rc = ffk_filter_function_dev(R, A, N, W, FFK_FF_FIDELITY, F, stream)) return rc;
     if (want_infid) {
         const size_t iwsb = ffk_infidelity_workspace_bytes(W, n_idx, s_ndim);
         void* iws = ws.take<unsigned char>(iwsb);
         FFK_REQUIRE(iws, "workspace too small");
-        if (int rc = ffk_infidelity_dev(F, A, W, spectrum, s_ndim, omega, idx, n_idx, d, infid, iws, iwsb, stream))
+        if (int rc = infidelity_dev_impl(F, A, W, spectrum, s_ndim, omega, idx, n_idx, d, infid, iws, iwsb, stream, opt))
             return rc;
     }
     return FFK_OK;
 }
+}  // namespace ffk_api
+extern "C" {
 
 // ---------------------------------------------------------------------------------------------
 // fault word of the flag-passing kernels, for callers of the device-pointer flavour

@@ -67,6 +67,10 @@ int fail(int code, const char* fmt, ...);
 // FFK_OK, or FFK_EKERNEL with the message set and the word cleared; peek: the raw word
 int kernel_fault_status();
 int kernel_fault_peek(bool clear);
+// at the top of a host-pointer entry point: a fault left by an earlier, never checked asynchronous launch of this
+// thread is reported as such (and cleared) instead of being attributed to the call that is about to run
+int kernel_fault_stale();
+int kernel_fault_slot_for_selftest();
 
 
 #define FFK_HIP(expr)                                                                      \
@@ -91,18 +95,43 @@ inline bool d_templated_ok(int d) { return d >= 2 && d <= FFK_MAX_D_TEMPLATED; }
 constexpr unsigned FFK_INTERNAL_PROLOGUE_DONE = 0x80000000u;
 // ... and the compacted basis lists in the expansion workspace (same launch)
 constexpr unsigned FFK_INTERNAL_COMPACT_DONE = 0x40000000u;
-// set by ffk_pipeline_dev around its call of ffk_control_matrix_dev: where the fidelity filter
-// function should go if the expansion launch can produce it too, and whether it did
-extern thread_local cplx* g_fuse_F;
-extern thread_local bool g_fuse_F_done;
-extern thread_local int* g_eigh_fail_count;
-extern thread_local bool g_infid_spectrum_on_host;
+// What a caller INSIDE the library asks of the device-pointer entry points it is built from (the resident pass of
+// ffk_api_resident.hip, ffk_pipeline_dev around its own stages).  Passed down explicitly to the *_impl functions
+// below; the extern "C" entry points call them with the defaults.  (Rounds 3-5: seven thread_local variables.)
 struct EighControls {
     const ffk::cplx* opers;      // (n_c, d, d), device
     const double* coeffs;        // (n_c, G), device
     int n_c;
 };
-extern thread_local EighControls g_eigh_controls;
+struct PassOptions {
+    // where the fidelity filter function should go if the control matrix's expansion launch can produce it too,
+    // and (out) whether it did
+    ffk::cplx* fuse_F = nullptr;
+    bool fuse_F_done = false;
+    // the eigensolver counts flagged segments into this mapped host word (no memset, no counting kernel)
+    int* eigh_fail_count = nullptr;
+    // the pipeline's Hamiltonian as its summands: the eigensolver kernel sums the control operators itself
+    EighControls eigh_controls = {nullptr, nullptr, 0};
+    // spectrum and idx of the infidelity integral are in mapped host memory (staged through LDS by the kernel)
+    bool infid_spectrum_on_host = false;
+};
+int diagonalize_dev_impl(const double* hamiltonian, const double* dt, int G, int d, double* eigvals, double* eigvecs,
+                         double* propagators, void* workspace, size_t workspace_bytes, void* stream,
+                         const PassOptions& opt);
+int control_matrix_dev_impl(const double* eigvals, const double* eigvecs, const double* propagators,
+                            const double* omega, int W, const double* basis, int N, const double* n_opers, int A,
+                            const double* n_coeffs, const double* dt, const double* t, int G, int d, unsigned flags,
+                            double* control_matrix, double* noise_operators, void* workspace,
+                            size_t workspace_bytes, void* stream, PassOptions& opt);
+int infidelity_dev_impl(const double* filter_function, int A, int W, const double* spectrum, int s_ndim,
+                        const double* omega, const int32_t* idx, int n_idx, int d, double* infid, void* workspace,
+                        size_t workspace_bytes, void* stream, const PassOptions& opt);
+int pipeline_dev_impl(const double* hamiltonian, const double* dt, const double* t, int G, int d,
+                      const double* omega, int W, const double* basis, int N, const double* n_opers, int A,
+                      const double* n_coeffs, const double* spectrum, int s_ndim, const int32_t* idx, int n_idx,
+                      double* eigvals, double* eigvecs, double* propagators, double* control_matrix,
+                      double* filter_function, double* infid, void* workspace, size_t workspace_bytes,
+                      void* stream, PassOptions& opt);
 
 // Scratch from the shared arena is handed to kernels on a non-blocking stream while g_arena.mu is
 // held; the lock may only be dropped once that stream has drained -- on EVERY exit path, also the

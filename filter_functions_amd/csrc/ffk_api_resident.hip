@@ -174,12 +174,13 @@ __global__ void assemble_hamiltonian_kernel(const cplx* __restrict__ opers, cons
 struct ResidentGraphKey {
     int dev, G, d, W, N, A, n_c, on_device;
     int s_ndim, n_idx, d_inf;                        // the integral riding in the pass (0: none)
+    int fault_slot;                                  // the capturing thread's fault word is baked into the kernel arguments
     const void *dp, *hp, *ws;
     hipStream_t stream;
     unsigned long long epoch;
     bool operator==(const ResidentGraphKey& o) const {
         return dev == o.dev && G == o.G && d == o.d && W == o.W && N == o.N && A == o.A && n_c == o.n_c &&
-               s_ndim == o.s_ndim && n_idx == o.n_idx && d_inf == o.d_inf &&
+               s_ndim == o.s_ndim && n_idx == o.n_idx && d_inf == o.d_inf && fault_slot == o.fault_slot &&
                on_device == o.on_device && dp == o.dp && hp == o.hp && ws == o.ws && stream == o.stream &&
                epoch == o.epoch;
     }
@@ -336,30 +337,27 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
             // one copy; with the controls in the Hamiltonian's slot the eigensolver sums them itself
             FFK_HIP(hipMemcpyAsync(dp, hp, L.inputs_end, hipMemcpyHostToDevice, s));
         }
+        PassOptions opt;
         if (sum_in_eigensolver)
-            g_eigh_controls = {reinterpret_cast<const cplx*>(dp + L.H),
-                               reinterpret_cast<const double*>(dp + L.H + ctrl_opers), n_c};
+            opt.eigh_controls = {reinterpret_cast<const cplx*>(dp + L.H),
+                                 reinterpret_cast<const double*>(dp + L.H + ctrl_opers), n_c};
         // the eigensolver counts its flagged segments straight into the pinned block's status word (zeroed below,
         // before the launch): no memset, no counting kernel, and the word stays out of the copy back
-        g_eigh_fail_count = count_on_host ? reinterpret_cast<int*>(hp + L.status) : nullptr;
-        const int rc_pass = ffk_pipeline_dev(Hdev, dptr(L.dt), dptr(L.t), G, d, dptr(L.omega), W,
-                                             dptr(L.basis), N, dptr(L.n_opers), A, dptr(L.n_coeffs), nullptr, 0,
-                                             nullptr, 0, dptr(L.D), dptr(L.V), dptr(L.Q), dptr(L.R), dptr(L.F),
-                                             nullptr, ws, wsb, s);
-        g_eigh_fail_count = nullptr;
-        g_eigh_controls = {nullptr, nullptr, 0};
-        if (rc_pass) return rc_pass;
+        opt.eigh_fail_count = count_on_host ? reinterpret_cast<int*>(hp + L.status) : nullptr;
+        if (int rc = pipeline_dev_impl(Hdev, dptr(L.dt), dptr(L.t), G, d, dptr(L.omega), W, dptr(L.basis), N,
+                                       dptr(L.n_opers), A, dptr(L.n_coeffs), nullptr, 0, nullptr, 0, dptr(L.D),
+                                       dptr(L.V), dptr(L.Q), dptr(L.R), dptr(L.F), nullptr, ws, wsb, s, opt))
+            return rc;
         if (!count_on_host)
             if (int rc = ffk_eigensolver_status_dev(ws, wsb, G, d, reinterpret_cast<int32_t*>(dp + L.status), s))
                 return rc;
         if (spectrum) {
-            g_infid_spectrum_on_host = true;       // spectrum and idx are read from the pinned block
-            const int rc = ffk_infidelity_dev(dptr(L.F), A, W, reinterpret_cast<const double*>(hp + o_spec), s_ndim,
-                                              dptr(L.omega), reinterpret_cast<const int32_t*>(hp + o_idx), n_idx,
-                                              d_inf, reinterpret_cast<double*>(hp + o_out),
-                                              static_cast<unsigned char*>(ws) + wsb + hsb, iwsb, s);
-            g_infid_spectrum_on_host = false;
-            if (rc) return rc;
+            opt.infid_spectrum_on_host = true;     // spectrum and idx are read from the pinned block
+            if (int rc = infidelity_dev_impl(dptr(L.F), A, W, reinterpret_cast<const double*>(hp + o_spec), s_ndim,
+                                             dptr(L.omega), reinterpret_cast<const int32_t*>(hp + o_idx), n_idx,
+                                             d_inf, reinterpret_cast<double*>(hp + o_out),
+                                             static_cast<unsigned char*>(ws) + wsb + hsb, iwsb, s, opt))
+                return rc;
         }
         FFK_HIP(hipMemcpyAsync(hp + L.D, dp + L.D, (count_on_host ? L.status : L.outputs_end) - L.D,
                                hipMemcpyDeviceToHost, s));
@@ -367,8 +365,8 @@ int resident_pass(ffk_resident* r, const double* hamiltonian, const double* c_op
     };
     if (count_on_host) *reinterpret_cast<volatile int32_t*>(hp + L.status) = 0;
     const ResidentGraphKey key{dev, G, d, W, N, A, hamiltonian ? 0 : n_c, on_device ? 1 : 0,
-                               spectrum ? s_ndim : 0, spectrum ? n_idx : 0, spectrum ? d_inf : 0, dp, hp, ws, s,
-                               g_knob_epoch.load()};
+                               spectrum ? s_ndim : 0, spectrum ? n_idx : 0, spectrum ? d_inf : 0,
+                               kernel_fault_slot_for_selftest(), dp, hp, ws, s, g_knob_epoch.load()};
     ResidentGraph* hit = nullptr;
     ResidentGraph* victim = &g_resident_graphs[0];
     if (resident_graphs_enabled()) {
@@ -691,13 +689,13 @@ int ffk_resident_infidelity(ffk_resident* r, const double* spectrum, int s_ndim,
         void* iws;
         rc = arena_reserve(iwsb, &iws);
         if (!rc) {
-            g_infid_spectrum_on_host = true;
-            rc = ffk_infidelity_dev(reinterpret_cast<const double*>(dp + L.F), A, W,
-                                    reinterpret_cast<const double*>(stage_ptr), s_ndim,
-                                    reinterpret_cast<const double*>(dp + L.omega),
-                                    reinterpret_cast<const int32_t*>(stage_ptr + o_idx), n_idx, d,
-                                    reinterpret_cast<double*>(stage_ptr + o_out), iws, iwsb, s);
-            g_infid_spectrum_on_host = false;
+            PassOptions opt;
+            opt.infid_spectrum_on_host = true;
+            rc = infidelity_dev_impl(reinterpret_cast<const double*>(dp + L.F), A, W,
+                                     reinterpret_cast<const double*>(stage_ptr), s_ndim,
+                                     reinterpret_cast<const double*>(dp + L.omega),
+                                     reinterpret_cast<const int32_t*>(stage_ptr + o_idx), n_idx, d,
+                                     reinterpret_cast<double*>(stage_ptr + o_out), iws, iwsb, s, opt);
         }
         if (!rc) {
             const hipError_t e = hipStreamSynchronize(s);

@@ -113,7 +113,13 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
                            const cplx* n_opers, const double* n_coeffs, const double* dt,
                            const double* t, int G, int d, int A, double* segtab, cplx* Tc,
                            cplx* ops, cplx* n_opers_transformed, cplx* eigvecs_propagated,
-                           hipStream_t stream);
+                           hipStream_t stream, cplx* d4_wfold = nullptr);
+// d4_wfold (d = 4 only, may be NULL): W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j] per (segment, operator), 64
+// complex numbers in the order the d = 4 accumulate kernel's tile holds them (d4_wfold_elems(G, A) in all).  It
+// does not depend on the frequency: a caller that owns a buffer for it (ffk_control_matrix_dev, ffk_pipeline_dev)
+// has the prologue kernels write it once per segment and hands it to launch_accumulate, whose producers then copy
+// it into their tiles instead of each of the W/64 frequency blocks folding it again (same products in the same
+// order: same bits).  NULL: the accumulate kernel folds it itself.
 // Fused scan fix-up (+ prologue): every block rebuilds the exclusive chunk prefix E_c from
 // `totals`, writes Q[g+1] = Qloc[g+1] E_c (Q[0] = 1 by block 0) and, if segtab != NULL, runs the
 // prologue for its segment with Q[g] without a round trip through memory.
@@ -128,7 +134,7 @@ hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, i
                                          const cplx* n_opers, const double* n_coeffs,
                                          const double* dt, const double* t, int A, double* segtab,
                                          cplx* Tc, cplx* ops, const cplx* basis, int N, void* ews,
-                                         hipStream_t stream);
+                                         hipStream_t stream, cplx* d4_wfold = nullptr);
 // basis_transformed (G,N,d,d) = (Q^dag V)^dag C_k (Q^dag V)   (numeric.py:863-864)
 hipError_t launch_basis_transformed(const cplx* Tc, const cplx* basis, int G, int N, int d,
                                     cplx* out, hipStream_t stream);
@@ -173,7 +179,7 @@ struct ExpandEpilogue {
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
                              hipStream_t stream, const ExpandEpilogue* expand = nullptr,
-                             bool* expanded = nullptr);
+                             bool* expanded = nullptr, const cplx* d4_wfold = nullptr);
 
 // ---- ctrl_mfma.hip ---------------------------------------------------------------------------
 int device_cu_count();   // compute units of the current device (ctrl.hip)
@@ -186,10 +192,12 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
                                   cplx* Ypart, hipStream_t stream,
                                   const ExpandEpilogue* expand = nullptr, bool* expanded = nullptr);
 
-// ---- sticky fault word (ffk_api.hip) -----------------------------------------------------------
-// Device pointer of ONE int in mapped pinned host memory (created on first use, never inside a stream
-// capture: ffk_graph_capture_begin and the resident pass touch it first).  A kernel whose bounded flag
-// wait runs out stores a non-zero code there; NULL only if the runtime refused the allocation.
+// ---- sticky fault words (ffk_api.hip) ----------------------------------------------------------
+// Device pointer of the CALLING THREAD's int in mapped pinned host memory (one block of words per process,
+// created on first use -- never inside a stream capture: ffk_graph_capture_begin and the resident pass touch it
+// first; portable memory, so the pointer is valid on every device).  Launchers pass it to their kernels as an
+// ARGUMENT; a kernel whose bounded flag wait runs out stores a non-zero code there.  One word per host thread: a
+// thread reads only the faults of launches it enqueued itself.  NULL only if the runtime refused the allocation.
 int* kernel_fault_word();
 constexpr int kFaultPcProducerWait = 1, kFaultPcConsumerWait = 2;
 
@@ -197,20 +205,14 @@ constexpr int kFaultPcProducerWait = 1, kFaultPcConsumerWait = 2;
 int pq_accumulate_lds_bytes(int nc);
 int pq_accumulate_waves(int nc);
 bool pq_accumulate_supported(int d, int A);
-int pq_accumulate_ops_per_block(int A);
-hipError_t pq_bind_fault_word(int* device_pointer);
-// d = 4: W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j] per (segment, operator), 64 complex numbers in the order the
-// accumulate kernel's tile holds them.  It does not depend on the frequency: when this pointer is set (by
-// ffk_control_matrix_dev / ffk_pipeline_dev around their prologue and accumulate launches, which own the buffer) the
-// prologue kernels write it once per segment and the accumulate kernel's producers copy it into their tiles instead
-// of each of the W/64 frequency blocks folding it again (same products in the same order: same bits).  NULL: the
-// accumulate kernel folds it itself (callers that bring their own `ops`).
-extern thread_local cplx* g_d4_wfold;
+struct PqGroups {
+    int n3, n2, n1;     // blocks of three, two, one operator(s): 3 n3 + 2 n2 + n1 = A, one launch per size
+};
+PqGroups pq_accumulate_groups(int A);
 constexpr size_t d4_wfold_elems(int G, int A) { return static_cast<size_t>(G)*A*64; }
-
 hipError_t launch_accumulate_pq(const double* omega, int W, const double* segtab, const cplx* ops,
-                                int G, int d, int A, int nc, int chunks, int chunk_len, cplx* Ypart,
-                                hipStream_t stream);
+                                int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
+                                const cplx* wfold, hipStream_t stream);
 
 // ---- ctrl_pcr.hip (d = 8, real integral tile) --------------------------------------------------
 bool pcr_accumulate_supported(int d, int A);

@@ -60,7 +60,7 @@ __device__ void prologue_segment(const cplx (*V)[D], cplx (*Q)[D], cplx (*T)[D],
     __syncthreads();
 
     if (!with_noise_ops) return;        // (large d: noise_ops_kernel, one block per operator)
-    // d = 4 with a buffer for it (ffk_internal.h g_d4_wfold): W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j], the
+    // d = 4 with a buffer for it (ffk_internal.h d4_wfold): W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j], the
     // operand the accumulate kernel's tiles hold, folded here once per segment.  Q is free by now: it keeps e^{ib}.
     const bool fold = D == 4 && wfold != nullptr;
     if (fold) {
@@ -361,7 +361,7 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
                            const cplx* n_opers, const double* n_coeffs, const double* dt,
                            const double* t, int G, int d, int A, double* segtab, cplx* Tc,
                            cplx* ops, cplx* n_opers_transformed, cplx* eigvecs_propagated,
-                           hipStream_t stream) {
+                           hipStream_t stream, cplx* d4_wfold) {
     if (generic_dimension(d))
         return launch_prologue_generic(eigvals, eigvecs, propagators, n_opers, n_coeffs, dt, t, G, d, A, segtab,
                                        Tc, ops, n_opers_transformed, eigvecs_propagated, stream);
@@ -371,7 +371,7 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
         hipLaunchKernelGGL(prologue_kernel<D>, dim3(G), dim3(64), 0, stream, eigvals, eigvecs,  \
                            propagators, n_opers, n_coeffs, dt, t, G, A, segtab, Tc, ops,        \
                            n_opers_transformed, eigvecs_propagated, !split_noise_ops(D, A),     \
-                           D == 4 ? g_d4_wfold : nullptr);                                      \
+                           D == 4 ? d4_wfold : nullptr);                                        \
         if (split_noise_ops(D, A))                                                              \
             hipLaunchKernelGGL(noise_ops_kernel<D>, dim3(G, A), dim3(64), 0, stream, eigvecs,   \
                                n_opers, n_coeffs, G, A, ops, n_opers_transformed);              \
@@ -391,7 +391,7 @@ hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, i
                                          const cplx* n_opers, const double* n_coeffs,
                                          const double* dt, const double* t, int A, double* segtab,
                                          cplx* Tc, cplx* ops, const cplx* basis, int N, void* ews,
-                                         hipStream_t stream) {
+                                         hipStream_t stream, cplx* d4_wfold) {
     const int L = front_chunk(d);
     int* nnz = nullptr;
     int* rows = nullptr;
@@ -414,7 +414,7 @@ hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, i
                            sizeof(cplx)*D*D*(D <= 8 ? (G + L - 1)/L : 16), stream, Qloc,         \
                            totals, G, L, Q, eigvals, eigvecs, n_opers, n_coeffs, dt, t, A,       \
                            segtab, Tc, ops, basis, nnz, rows, vals, !split_noise_ops(D, A),      \
-                           D == 4 ? g_d4_wfold : nullptr);                                       \
+                           D == 4 ? d4_wfold : nullptr);                                         \
         if (split_noise_ops(D, A))                                                               \
             hipLaunchKernelGGL(noise_ops_kernel<D>, dim3(G, A), dim3(64), 0, stream, eigvecs,    \
                                n_opers, n_coeffs, G, A, ops, nullptr);                           \

@@ -18,7 +18,9 @@ reference.
 """
 import copy
 import functools
+import os
 import weakref
+import zlib
 from collections import OrderedDict
 from collections.abc import Mapping
 from types import MappingProxyType
@@ -125,6 +127,11 @@ def _checked_basis(basis, d):
         raise ValueError(f"Expected basis elements to be of shape ({d}, {d}), "
                          f"not {basis.shape[1:]}!")
     return basis
+
+
+#: Default of ``PulseSequence.get_filter_function(..., writable=)``: hand out owned, writable arrays (the reference's
+#: convention) instead of read-only views of the resident results.  From the environment variable FFK_WRITABLE_RESULTS.
+WRITABLE_RESULTS = os.environ.get('FFK_WRITABLE_RESULTS', '') not in ('', '0')
 
 
 class PulseSequence:
@@ -454,11 +461,19 @@ class PulseSequence:
 
     @util.parse_optional_parameters(which=('fidelity', 'generalized'), order=(1, 2))
     def get_filter_function(self, omega, which='fidelity', order=1, show_progressbar=False,
-                            cache_intermediates=False, cache_second_order_cumulative=False):
+                            cache_intermediates=False, cache_second_order_cumulative=False, writable=None):
         """Filter function, memoised (reference pulse_sequence.py:691-805).  order=1: 'fidelity' ->
         (n_nops, n_nops, n_omega), 'generalized' -> (n_nops, n_nops, d², d², n_omega); order=2: the
-        second-order filter function (n_nops, n_nops, d², d², n_omega), *which* ignored."""
+        second-order filter function (n_nops, n_nops, d², d², n_omega), *which* ignored.
+
+        ``writable`` (not in the reference; default :data:`WRITABLE_RESULTS`, i.e. the environment variable
+        ``FFK_WRITABLE_RESULTS``, else False): the resident pass hands out a READ-ONLY view of pinned memory whose
+        device copy ``ff.infidelity`` integrates in place.  With ``writable=True`` the cached entry becomes an
+        ordinary owned array, as the reference returns it (pulse_sequence.py:772-783): edits are allowed and
+        ``ff.infidelity`` integrates the array as the caller left it (one upload of F)."""
         self.omega = omega
+        if writable is None:
+            writable = WRITABLE_RESULTS
         wanted = ('filter_function_2' if order == 2 else
                   'filter_function' if which == 'fidelity' else 'filter_function_gen')
         if wanted not in self._frequency_data:
@@ -469,7 +484,12 @@ class PulseSequence:
                     self.omega, which=which, order=order, show_progressbar=show_progressbar,
                     cache_intermediates=cache_intermediates,
                     cache_second_order_cumulative=cache_second_order_cumulative)
-        return self._frequency_data[wanted]
+        result = self._frequency_data[wanted]
+        if writable and not result.flags.writeable:
+            # an owned copy takes the view's place in the cache (memoised by reference from now on); the resident F is
+            # no longer "this array", so infidelity() takes the array route
+            result = self._frequency_data[wanted] = np.array(result)
+        return result
 
     @util.parse_optional_parameters(which=('fidelity', 'generalized'), order=(1, 2))
     def cache_filter_function(self, omega, control_matrix=None, filter_function=None,
@@ -624,7 +644,9 @@ class PulseSequence:
         """Drop cached by-products (reference pulse_sequence.py:1188-1245): 'conservative' the
         diagonalisation; 'greedy' also the total propagators, the control matrices, the total
         phases and the intermediates (the filter functions stay); 'frequency dependent' all that
-        belongs to a frequency grid; 'all' everything."""
+        belongs to a frequency grid; 'all' everything.  Every method also drops what concatenations remember
+        about this pulse (:func:`clear_merged_tables`)."""
+        clear_merged_tables(self)
         if method in ('all', 'frequency dependent'):
             if method == 'all':
                 self._data.clear()
@@ -910,22 +932,49 @@ def _validated_sequence(pulses):
     return pulses, distinct, first, index
 
 
-#: merged tables of sets of distinct pulses (see :func:`_merged_tables`): few entries, oldest dropped first
+#: Merged tables of sets of distinct pulses (see :func:`_merged_tables`): few entries, oldest dropped first.  A
+#: process-wide cache of COPIES keyed on the pulse objects; an entry is dropped when one of its pulses dies, is
+#: ``cleanup()``-ed (any method), or no longer holds the arrays -- object AND content -- it was built from.
+#: :func:`clear_merged_tables` empties it.
 _MERGED = OrderedDict()
 _MERGED_MAX = 8
+
+
+def clear_merged_tables(pulse=None):
+    """Forget the remembered merged tables of concatenations: all of them, or those that involve ``pulse``
+    (``PulseSequence.cleanup`` calls this with itself)."""
+    if pulse is None:
+        _MERGED.clear()
+        return
+    for key in [k for k, hit in _MERGED.items() if any(r() is pulse for r in hit['refs'])]:
+        del _MERGED[key]
+
+
+def _content_stamp(pulse):
+    """A checksum of the arrays a concatenation reads from ``pulse``: a pulse whose coefficients, time steps or
+    operators were modified IN PLACE no longer matches its remembered tables (the reference rebuilds from the live
+    arrays on every call, pulse_sequence.py:1599-1665).  ~0.3 us per small array."""
+    crc = 0
+    for a in (pulse.c_coeffs, pulse.n_coeffs, pulse.dt, pulse.c_opers, pulse.n_opers):
+        a = np.asarray(a)
+        crc = zlib.crc32(a if a.flags.c_contiguous else np.ascontiguousarray(a), crc)
+    return crc
 
 
 def _merged_tables(distinct, first):
     """What a concatenation needs of its DISTINCT pulses and not of their order: dimension and basis checks,
     the merged control and noise tables, segment counts, durations.  Randomized benchmarking evaluates many
-    sequences drawn from one gate set: the result is remembered per set of pulse OBJECTS and reused while
-    they are alive and still hold the same arrays (like every cache on a pulse it does not notice arrays
-    modified in place: ``cleanup`` is the contract, as in the reference); 0.22 -> 0.09 ms of the 0.49 ms a
-    1000-gate sequence takes (profiles/r05_h_*)."""
+    sequences drawn from one gate set: the result is remembered per set of pulse OBJECTS and reused while they
+    are alive and still hold the same arrays with the same content (identity of every attribute the tables are
+    built from -- the entry keeps those objects alive, so an ``id`` cannot be recycled -- plus a checksum of the
+    numeric ones); 0.22 -> 0.09 ms of the 0.49 ms a 1000-gate sequence takes (profiles/r05_h_*)."""
+    for key in [k for k, hit in _MERGED.items() if any(r() is None for r in hit['refs'])]:
+        del _MERGED[key]                  # a pulse of the set has died
     key = tuple(map(id, distinct))
-    stamp = tuple(id(a) for p in distinct
-                  for a in (p.c_opers, p.c_coeffs, p.n_opers, p.n_coeffs, p.dt, p.basis, p.c_oper_identifiers,
-                            p.n_oper_identifiers))
+    held = tuple(a for p in distinct
+                 for a in (p.c_opers, p.c_coeffs, p.n_opers, p.n_coeffs, p.dt, p.basis, p.c_oper_identifiers,
+                           p.n_oper_identifiers))
+    stamp = tuple(map(id, held)) + tuple(_content_stamp(p) for p in distinct)
     hit = _MERGED.get(key)
     if hit is not None and hit['stamp'] == stamp and all(r() is p for r, p in zip(hit['refs'], distinct)):
         _MERGED.move_to_end(key)
@@ -937,7 +986,7 @@ def _merged_tables(distinct, first):
     lengths = np.array([len(p.dt) for p in distinct])
     equal = bool((lengths == lengths[0]).all())
     merged = dict(
-        stamp=stamp, refs=[weakref.ref(p) for p in distinct], lengths=lengths, equal_lengths=equal,
+        stamp=stamp, held=held, refs=[weakref.ref(p) for p in distinct], lengths=lengths, equal_lengths=equal,
         control=_merge_hamiltonian([p.c_opers for p in distinct], [p.c_oper_identifiers for p in distinct],
                                    [p.c_coeffs for p in distinct], 'control', first),
         noise=_merge_hamiltonian([p.n_opers for p in distinct], [p.n_oper_identifiers for p in distinct],

@@ -623,6 +623,40 @@ def make_baseline_configs():
          clifford_control_matrices=np.array([c.get_control_matrix(omega) for c in cliffords]))
 
 
+def make_rb_optimized():
+    """Config 3 with the example's OPTIMISED gates (examples/randomized_benchmarking.py:112-128): the pulse data of
+    examples/data/X2ID.mat / Y2ID.mat (arrays eps, t, B: DATA the reference ships) and the reference's outputs for them
+    on 16 of the 8192 frequencies: the two atoms' control matrices (from scratch, 100 segments), the 24 Cliffords'
+    (concatenation rule, up to 700 segments), and the 1000-gate sequence's filter function and infidelity."""
+    from scipy import io
+    sys.path.insert(0, os.path.dirname(HERE))
+    import workloads as wl
+    data = os.path.join(os.path.dirname(os.path.dirname(ff.__file__)), 'examples', 'data')
+    gates, arrays = {}, {}
+    for name in ('X2', 'Y2'):
+        mat = io.loadmat(os.path.join(data, name + 'ID.mat'))
+        gates[name] = (np.asarray(mat['eps'], dtype=float), np.asarray(mat['t'], dtype=float).ravel(),
+                       np.asarray(mat['B'], dtype=float).ravel())
+        for key, value in zip(('eps', 't', 'B'), gates[name]):
+            arrays[f'{name}_{key}'] = value
+    cfg = wl.CONFIG3
+    omega_full = wl.rb_omega(cfg['W'], cfg['T'])
+    sub = np.linspace(0, cfg['W'] - 1, 16).astype(int)
+    omega = omega_full[sub]
+    atoms, cliffords = wl.rb_cliffords_optimized(ff, omega, gates)
+    draw = wl.rb_draw(cfg['n_gates'], cfg['seed'])
+    total = ff.concatenate([cliffords[k] for k in draw])
+    assert total.is_cached('control_matrix')
+    S = wl.rb_spectrum(omega)
+    save('rb_optimized_gates', omega_index=sub, omega=omega, draw=draw,
+         atom_control_matrices=np.array([atoms[k].get_control_matrix(omega) for k in 'xy']),
+         atom_total_propagators=np.array([atoms[k].total_propagator for k in 'xy']),
+         clifford_control_matrices=np.array([c.get_control_matrix(omega) for c in cliffords]),
+         clifford_segments=np.array([len(c.dt) for c in cliffords]),
+         filter_function=total.get_filter_function(omega), infidelity=ff.infidelity(total, S, omega),
+         total_propagator=total.total_propagator, n_segments=len(total.dt), tau=total.tau, **arrays)
+
+
 def make_periodic_driving():
     """The reference's timed example doc/source/examples/periodic_driving.ipynb at full size (inputs
     from workloads.periodic_driving): its own concatenate_periodic / concatenate outputs on all 500
@@ -681,6 +715,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'periodic_driving':
         make_periodic_driving()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'rb_optimized':
+        make_rb_optimized()
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'configs':
         make_baseline_configs()

@@ -229,6 +229,52 @@ def test_config3_thousand_gate_sequence_by_concatenation():
     assert rel_err(R_plain, R) < 1e-11
 
 
+def test_config3_optimized_gates_full_size():
+    """Config 3 as the example runs it with its OPTIMISED gate set (examples/randomized_benchmarking.py:112-151;
+    VERDICT r5 "what's missing" 2): the X/2 and Y/2 atoms are 100-segment pulses (data of examples/data/X2ID.mat,
+    Y2ID.mat, held in tests/golden/rb_optimized_gates.npz), so their control matrices come from the d = 2
+    from-scratch kernel, the 24 Cliffords (100 to 700 segments) from the concatenation rule, and the 1000-gate
+    sequence (332 200 segments of bookkeeping) from the rule kernel -- all 8192 frequencies, against the reference's
+    outputs at 16 of them, the oracle's rule on the materialised arrays, and the oracle from scratch on a Clifford."""
+    g = load_golden('rb_optimized_gates')
+    cfg = wl.CONFIG3
+    omega = wl.rb_omega(cfg['W'], cfg['T'])
+    gates = {name: (g[f'{name}_eps'], g[f'{name}_t'], g[f'{name}_B']) for name in ('X2', 'Y2')}
+    atoms, cliffords = wl.rb_cliffords_optimized(ff, omega, gates)
+    at = g['omega_index']
+    for k, letter in enumerate('xy'):
+        assert len(atoms[letter]) == 100
+        assert rel_err(atoms[letter].get_control_matrix(omega)[..., at], g['atom_control_matrices'][k]) < TOL
+    assert all(c.is_cached('control_matrix') for c in cliffords)
+    assert np.array_equal([len(c) for c in cliffords], g['clifford_segments'])
+    table = np.array([c.get_control_matrix(omega) for c in cliffords])
+    assert rel_err(table[..., at], g['clifford_control_matrices']) < TOL
+    # one Clifford (700 segments) from scratch on the device and by the oracle
+    long = cliffords[16]
+    fresh = ff.concatenate_without_filter_function([atoms[c] for c in wl.CLIFFORD_WORDS[16]])
+    assert len(fresh) == 700
+    assert rel_err(fresh.get_control_matrix(omega), table[16]) < TOL
+    sub = np.linspace(0, cfg['W'] - 1, 40).astype(int)
+    D, V, Q = orc.diagonalize(orc.hamiltonian(long.c_opers, long.c_coeffs), long.dt)
+    R_orc = orc.control_matrix_from_scratch(D, V, Q, omega[sub], np.asarray(long.basis), long.n_opers, long.n_coeffs,
+                                            long.dt)
+    assert rel_err(table[16][..., sub], R_orc) < TOL
+    draw = wl.rb_draw(cfg['n_gates'], cfg['seed'])
+    seq = [cliffords[k] for k in draw]
+    total = ff.concatenate(seq)
+    assert len(total) == g['n_segments'] and abs(total.tau - g['tau']) < 1e-9*g['tau']
+    F = total.get_filter_function(omega)
+    assert rel_err(total.total_propagator, g['total_propagator']) < 1e-10
+    assert rel_err(F[..., at], g['filter_function']) < 1e-9
+    S = wl.rb_spectrum(omega)
+    assert rel_err(ff.infidelity(total, S[at], omega[at]), g['infidelity']) < 1e-9
+    # the oracle's rule on the materialised arrays, full size
+    phases = np.array([p.get_total_phases(omega) for p in seq[:-1]]).cumprod(axis=0)
+    L = util.adot(np.array([p.total_propagator_liouville for p in seq[:-1]]))
+    R_ref = orc.control_matrix_from_atomic(phases, table[draw], L)
+    assert rel_err(total.get_control_matrix(omega), R_ref) < 1e-10
+
+
 @pytest.mark.slow
 def test_published_example_periodic_driving():
     """The reference's timed example (doc/source/examples/periodic_driving.ipynb) at full size:

@@ -2478,6 +2478,57 @@ def test_d8_producer_consumer_kernel_ragged_shapes(G, A, W):
         lib.ffk_set_accumulate_variant(0)
 
 
+@pytest.mark.parametrize('G,A,W', [(1, 1, 1), (40, 1, 130), (3, 2, 65), (70, 2, 200), (5, 4, 100), (64, 4, 257),
+                                    (9, 5, 64), (33, 5, 300), (7, 7, 70), (50, 7, 129), (4, 8, 40), (6, 10, 31),
+                                    (2, 13, 33), (300, 4, 64)])
+def test_d4_operator_groups_ragged_shapes(G, A, W):
+    """ctrl_pq.hip (d = 4): the launch serves A operators as blocks of three plus blocks of two (A = 4: 2 + 2,
+    5: 3 + 2, 7: 3 + 2 + 2, 10: 3 + 3 + 2 + 2; A = 1: a single one) -- every block size runs the generated
+    consumer loop.  Operator counts of every residue, frequency tiles that are not full,
+    chunks shorter and longer than the ring of eight tiles, several chunks -- against the oracle and against the
+    symmetric kernel (tuning variant 2); with W_a folded by the prologue kernel (this call) and by the producers
+    (the intermediates call brings its own operands).  Reference loop numeric.py:846-869."""
+    d = 4
+    rng = np.random.default_rng(400 + G*A + W)
+    basis = ff.Basis.pauli(2)
+    c_opers = rng.standard_normal((3, d, d)) + 1j*rng.standard_normal((3, d, d))
+    c_opers = c_opers + c_opers.conj().transpose(0, 2, 1)
+    n_opers = rng.standard_normal((A, d, d)) + 1j*rng.standard_normal((A, d, d))
+    n_opers = n_opers + n_opers.conj().transpose(0, 2, 1)
+    H = np.einsum('ijk,il->ljk', c_opers, rng.standard_normal((3, G)))
+    dt = 0.5 + rng.random(G)
+    n_coeffs = rng.random((A, G)) + 0.5
+    omega = np.concatenate(([0.0], np.geomspace(1e-3, 50, W - 1))) if W > 1 else np.array([0.3])
+    D, V, Q = numeric.diagonalize(H, dt)
+    lib = _lib.load()
+    R = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+    st = _lib.stats()
+    assert st['block'] == 768                                     # the producer / consumer kernel ran
+    assert st['grid_y'] == {0: A//3, 1: (A - 4)//3 + 2 if A > 1 else 1, 2: (A - 2)//3 + 1}[A % 3], st
+    R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), n_opers, n_coeffs, dt)
+    assert rel_err(R, R_ref) < 1e-12
+    _lib.check_kernel_fault()
+    try:
+        for chunks in (1, 2, 3):
+            _lib.check(lib.ffk_set_segment_chunks(chunks))
+            R_c = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+            assert rel_err(R_c, R_ref) < 1e-12
+        _lib.check(lib.ffk_set_segment_chunks(0))
+        _lib.check(lib.ffk_set_accumulate_variant(2))
+        R_sym = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+        assert _lib.stats()['block'] != 768
+        assert rel_err(R_sym, R) < 1e-12
+    finally:
+        lib.ffk_set_segment_chunks(0)
+        lib.ffk_set_accumulate_variant(0)
+    if G*A <= 200 and W <= 130:
+        # the call that materialises the per-segment steps brings its own operands: the producers fold W_a
+        R_i, inter = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt,
+                                                                   cache_intermediates=True)
+        assert rel_err(R_i, R_ref) < 1e-12
+        assert rel_err(inter['control_matrix_step'].sum(axis=0), R_ref) < 1e-12
+
+
 @pytest.mark.parametrize('d,G,n_c', [(2, 1, 5), (2, 700, 2), (4, 33, 3), (3, 2, 20), (8, 16, 6)])
 def test_resident_pass_from_controls(d, G, n_c):
     """ffk_resident_filter_function_from_controls (control operators and amplitudes in, the
@@ -2777,6 +2828,37 @@ def test_resident_results_are_read_only_views():
     assert not ff.Basis.ggm(3).flags.writeable or True      # (shared default bases: documented, not enforced here)
 
 
+def test_writable_results_option():
+    """``get_filter_function(..., writable=True)``: an owned, writable array as the reference
+    returns it (pulse_sequence.py:772-783), memoised by reference, and ``ff.infidelity`` integrates it as the caller
+    left it."""
+    c_opers, c_coeffs, n_opers, n_coeffs, dt, omega = config2_inputs(G=12, W=200, seed=18)
+
+    def pulse():
+        return ff.PulseSequence(list(zip(c_opers, c_coeffs)), list(zip(n_opers, n_coeffs)), dt, ff.Basis.pauli(2))
+    S = 1e-3/omega
+    p_ro, p_rw = pulse(), pulse()
+    F_ro = p_ro.get_filter_function(omega)
+    F_rw = p_rw.get_filter_function(omega, writable=True)
+    assert F_rw.flags.writeable and F_rw.flags.owndata and F_rw.flags.c_contiguous
+    assert np.array_equal(F_ro, F_rw)
+    assert p_rw.get_filter_function(omega) is F_rw                      # memoised by reference
+    ref = ff.infidelity(p_ro, S, omega)
+    assert rel_err(ff.infidelity(p_rw, S, omega), ref) < 1e-13
+    F_rw *= 2                                                            # the caller's edit is what gets integrated
+    assert rel_err(ff.infidelity(p_rw, S, omega), 2*ref) < 1e-13
+    # upgrading an entry that was handed out read-only before
+    F2 = p_ro.get_filter_function(omega, writable=True)
+    assert F2 is not F_ro and F2.flags.writeable and p_ro.get_filter_function(omega) is F2
+    # the module-wide default
+    from filter_functions_amd import pulse_sequence as ps
+    ps.WRITABLE_RESULTS = True
+    try:
+        assert pulse().get_filter_function(omega).flags.writeable
+    finally:
+        ps.WRITABLE_RESULTS = False
+
+
 _FAULT_SCRIPT = r"""
 import sys
 import numpy as np
@@ -2815,6 +2897,12 @@ p1 = pulse()
 p1.diagonalize()
 expect_fault('array', lambda: numeric.calculate_control_matrix_from_scratch(
     p1.eigvals, p1.eigvecs, p1.propagators, omega, basis, p1.n_opers, p1.n_coeffs, p1.dt))
+# 1b. one, two and five operators: the NC = 1 and NC = 2 blocks' waits (alone, and behind a block of three)
+for n_a in (1, 2, 5):
+    ops_a = np.concatenate([p1.n_opers, p1.n_opers[::-1]])[:n_a]
+    cfs_a = np.concatenate([p1.n_coeffs, p1.n_coeffs[::-1]])[:n_a]
+    expect_fault(f'array A={{n_a}}', lambda: numeric.calculate_control_matrix_from_scratch(
+        p1.eigvals, p1.eigvecs, p1.propagators, omega, basis, ops_a, cfs_a, p1.dt))
 # 2. the resident pass behind PulseSequence.get_filter_function (twice: the second one is the replayed graph)
 expect_fault('resident', lambda: pulse().get_filter_function(omega))
 expect_fault('resident, second sighting', lambda: pulse().get_filter_function(omega))
@@ -2849,7 +2937,8 @@ def test_flag_wait_timeout_is_an_error():
     out = subprocess.run([sys.executable, '-c', _FAULT_SCRIPT.format(root=root)], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    assert 'FAULTS SEEN: array, resident, resident, second sighting, resident, replayed, _dev, captured graph' \
+    assert ('FAULTS SEEN: array, array A=1, array A=2, array A=5, resident, resident, second sighting, resident, replayed, '
+            '_dev, captured graph') \
         in out.stdout, out.stdout
     # the product build: same calls, no fault, word stays 0
     from filter_functions_amd import _lib

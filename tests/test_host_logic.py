@@ -889,6 +889,30 @@ def test_merged_tables_of_a_pulse_set_are_remembered_and_safe():
     after = ps.concatenate_without_filter_function(seq)
     assert not np.array_equal(before.c_coeffs, after.c_coeffs)
     same((after, {}, {}), (fresh(seq)[0], {}, {}))
+    # ... and so is one whose arrays are modified IN PLACE (the reference rebuilds from the live arrays on every
+    # call, pulse_sequence.py:1599-1665): with or without a cleanup in between
+    want_tail = gates[0].c_coeffs.copy()
+    gates[0].c_coeffs[0, :] = [10.0, 20.0]
+    edited = ps.concatenate_without_filter_function(seq)
+    assert np.array_equal(edited.c_coeffs[0, :2], [10.0, 20.0]) and np.array_equal(edited.c_coeffs[0, -2:], [10.0, 20.0])
+    gates[0].dt[0] = 0.25
+    gates[0].cleanup('all')
+    assert not any(any(r() is gates[0] for r in hit['refs']) for hit in ps._MERGED.values())   # cleanup forgets
+    assert ps.concatenate_without_filter_function(seq).dt[0] == 0.25
+    gates[0].c_coeffs[...] = want_tail
+    gates[0].dt[0] = 1.0
+    same((ps.concatenate_without_filter_function(seq), {}, {}), (fresh(seq)[0], {}, {}))
+    # an entry dies with its pulses: the remembered copies do not outlive the gate set
+    import gc
+    tmp = [ff.PulseSequence([[X/2, [0.1, 0.2], 'X']], [[Z/2, [1, 1], 'Z']], [1.0, 0.5]) for _ in range(2)]
+    ps.concatenate_without_filter_function(tmp + tmp)
+    n_before = len(ps._MERGED)
+    del tmp
+    gc.collect()
+    ps.concatenate_without_filter_function(seq)
+    assert len(ps._MERGED) < n_before + 1 and all(all(r() is not None for r in hit['refs']) for hit in ps._MERGED.values())
+    ps.clear_merged_tables()
+    assert len(ps._MERGED) == 0
     # identifiers that must be disambiguated by the position are never remembered
     clash = ff.PulseSequence([[Z/2, [1.0], 'X']], [[Z/2, [1], 'Z']], [1.0])      # 'X' names another matrix here
     ps._MERGED.clear()

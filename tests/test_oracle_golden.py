@@ -450,6 +450,63 @@ def test_config3_subgrid_fixture_against_oracle():
     assert rel_err(infid, g['infidelity']) < 1e-11
 
 
+def _rb_optimized_gate_data(g):
+    return {name: (g[f'{name}_eps'], g[f'{name}_t'], g[f'{name}_B']) for name in ('X2', 'Y2')}
+
+
+def test_oracle_config3_optimized_gates():
+    """Config 3 with the example's optimised 100-segment X/2, Y/2 pulses (examples/randomized_benchmarking.py:
+    112-128, data of examples/data/X2ID.mat / Y2ID.mat held in the fixture): the atoms' control matrices from scratch
+    (numeric.py:707-881), the 24 Cliffords and the 1000-gate sequence by the concatenation rule (numeric.py:621-704),
+    against the reference's outputs on 16 of the 8192 frequencies."""
+    import workloads as wl
+    g = load_golden('rb_optimized_gates')
+    cfg = wl.CONFIG3
+    omega = g['omega']
+    assert np.array_equal(wl.rb_omega(cfg['W'], cfg['T'])[g['omega_index']], omega)
+    assert np.array_equal(g['draw'], wl.rb_draw(cfg['n_gates'], cfg['seed']))
+    X, Z = np.array([[0, 1], [1, 0]], complex), np.array([[1, 0], [0, -1]], complex)
+    basis = orc.basis_pauli(1)
+    atoms = {}
+    for k, (letter, name) in enumerate((('x', 'X2'), ('y', 'Y2'))):
+        eps, t, B = _rb_optimized_gate_data(g)[name]
+        c_coeffs = np.array([np.exp(eps)[0], B[0]*np.ones(len(t))])
+        D, V, Q = orc.diagonalize(orc.hamiltonian(np.array([X/2, Z/2]), c_coeffs), t)
+        R = orc.control_matrix_from_scratch(D, V, Q, omega, basis, np.array([X/2]), np.ones((1, len(t))), t)
+        assert rel_err(R, g['atom_control_matrices'][k]) < 1e-11
+        assert rel_err(Q[-1], g['atom_total_propagators'][k]) < 1e-12
+        atoms[letter] = (R, Q[-1], t.sum())
+    # the Cliffords by the concatenation rule on the atoms
+    table, U, tau = [], [], []
+    for word in wl.CLIFFORD_WORDS:
+        Rs = np.array([atoms[c][0] for c in word])
+        props, durs = [atoms[c][1] for c in word], [atoms[c][2] for c in word]
+        Qc, ph = [np.eye(4)], [np.ones(len(omega), complex)]
+        M = np.eye(2, dtype=complex)
+        for u, d_ in zip(props[:-1], durs[:-1]):
+            M = u @ M
+            Qc.append(orc.liouville_representation(M, basis))
+            ph.append(ph[-1]*orc.cexp(omega*d_))
+        table.append(orc.control_matrix_from_atomic(np.array(ph[1:]), Rs, np.array(Qc[1:])))
+        U.append(props[-1] @ M)
+        tau.append(sum(durs))
+    table = np.array(table)
+    assert rel_err(table, g['clifford_control_matrices']) < 1e-10
+    assert np.array_equal(g['clifford_segments'], [100*len(w) for w in wl.CLIFFORD_WORDS])
+    draw = g['draw']
+    L = np.array([orc.liouville_representation(u, basis) for u in U])
+    phase_step = np.array([orc.cexp(omega*t) for t in tau])
+    Qs, ph = [np.eye(4)], [np.ones(len(omega), complex)]
+    for k in draw[:-1]:
+        Qs.append(L[k] @ Qs[-1])
+        ph.append(ph[-1]*phase_step[k])
+    R = orc.control_matrix_from_atomic(np.array(ph[1:]), g['clifford_control_matrices'][draw], np.array(Qs[1:]))
+    F = orc.filter_function(R)
+    assert rel_err(F, g['filter_function']) < 1e-9
+    infid = orc.infidelity_from_filter_function(F, wl.rb_spectrum(omega), omega, np.arange(1), 2)
+    assert rel_err(infid, g['infidelity']) < 1e-9
+
+
 @pytest.mark.parametrize('name', ['q1', 'g3', 'p4'])
 def test_oracle_periodic_closed_form(name):
     """orc.control_matrix_periodic against the reference's concatenate_periodic outputs."""

@@ -7,7 +7,7 @@ apart: straight-line blocks of one instruction kind with FIXED physical register
 traffic inside the timed loop, s_memtime around it, 1 / 2 / 3 / 4 wavefronts per SIMD.  Register patterns:
 the accumulator, the two sources on the same or on different register pairs modulo 4 (the vector register
 file of earlier GCN parts has four banks by register number), and the exact operand patterns of the shipped
-consumer block (tools/gen_pq_consumer.py).
+consumer block (the round-5 generator, tools/tuning/gen_pq_consumer_r5.py).
 
     python3 tools/fp64_issue_probe.py            # writes build/probe/fp64_issue.hip, compiles, runs, prints a table
 """
@@ -39,16 +39,16 @@ def block_mfma(acc_base, acc_stride, a, b, n=18, nacc=9):
 
 def consumer_vector():
     """the 32 vector instructions of one set of the shipped block, its registers (operands preloaded)"""
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
-    import gen_pq_consumer as g
+    sys.path.insert(0, os.path.join(ROOT, 'tools', 'tuning'))
+    import gen_pq_consumer_r5 as g
     st = g.Stream([])
     g.vector_part(st, 0, None)
     return [l for l in st.lines if l.startswith('v_')]
 
 
 def consumer_set():
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
-    import gen_pq_consumer as g
+    sys.path.insert(0, os.path.join(ROOT, 'tools', 'tuning'))
+    import gen_pq_consumer_r5 as g
     st = g.Stream([])
     g.vector_part(st, 0, None)
     g.matrix_part(st, 0)
@@ -60,8 +60,8 @@ def consumer_tile(drop=()):
     address points into a 32 KB window of the block's LDS, every flag is up -- the block as the kernel runs it, minus
     the producers and minus any waiting for a tile.  `drop`: 'reads' (no ds_read_b128 and no waits), 'handover'
     (no flag reads, no ds_add / ds_write), 'mfma', 'vector'."""
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
-    import gen_pq_consumer as g
+    sys.path.insert(0, os.path.join(ROOT, 'tools', 'tuning'))
+    import gen_pq_consumer_r5 as g
     g.OPS = dict(g.LOOP_V)
     lines = g.build(False).lines
     g.OPS = dict(g.TILE_OPERANDS)
@@ -84,8 +84,8 @@ def consumer_tile(drop=()):
 
 def consumer_loop(lockstep=0):
     """the shipped whole-loop block (flags all up: no tile is ever waited for)"""
-    sys.path.insert(0, os.path.join(ROOT, 'tools'))
-    import gen_pq_consumer as g
+    sys.path.insert(0, os.path.join(ROOT, 'tools', 'tuning'))
+    import gen_pq_consumer_r5 as g
     g.LOCKSTEP = lockstep
     lines = g.build_loop().lines
     g.LOCKSTEP = 0

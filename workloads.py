@@ -8,7 +8,8 @@ and ``bench.py`` with the HIP implementation.
 
 cfg 1  README Hadamard                      -> :func:`hadamard_pulse`
 cfg 2  random 2-qubit pulse, seed 42        -> :func:`random_pulse_inputs` (d=4, G=256, A=3)
-cfg 3  1000-gate RB sequence (naive gates)  -> :func:`rb_cliffords`, :func:`rb_sequence`
+cfg 3  1000-gate RB sequence                -> :func:`rb_cliffords` (naive gates), :func:`rb_cliffords_optimized`
+                                               (the example's 100-segment pulses), :func:`rb_draw`
 cfg 4  random 3-qubit pulse, seed 43        -> :func:`random_pulse_inputs` (d=8, G=512, A=9)
 cfg 5  4-qubit QFT                          -> :func:`qft_pulse`
 
@@ -74,6 +75,31 @@ def rb_cliffords(ff, omega, T=20.0):
              'y': ff.PulseSequence([[Y/2, [np.pi/2/T], 'Y']], [[X/2, [1], 'X']], [T])}
     for atom in atoms.values():
         atom.cache_control_matrix(omega)
+    cliffords = []
+    for word in CLIFFORD_WORDS:
+        gate = atoms[word[0]]
+        for letter in word[1:]:
+            gate = gate @ atoms[letter]
+        cliffords.append(gate)
+    return atoms, cliffords
+
+
+def rb_cliffords_optimized(ff, omega, gates):
+    """The example's OPTIMISED gate set (examples/randomized_benchmarking.py:112-128): X/2 and Y/2 as 100-segment
+    exchange-coupled pulses, control on X with J = exp(eps[0]) and on Z with the constant B[0], noise on X.
+    ``gates``: {'X2': (eps (3, 100), t (100,), B (3,)), 'Y2': ...} -- the arrays of the example's
+    ``examples/data/X2ID.mat`` / ``Y2ID.mat`` (data; tests/golden/rb_optimized_gates.npz holds them).  Returns the
+    atoms (control matrices cached at *omega*, computed from scratch on their 100 segments) and the 24 Cliffords built
+    from them with ``@`` (100 to 700 segments each)."""
+    X, Z = ff.util.paulis[1], ff.util.paulis[3]
+    atoms = {}
+    for letter, name in (('x', 'X2'), ('y', 'Y2')):
+        eps, t, B = (np.asarray(a, dtype=float) for a in gates[name])
+        t = np.ascontiguousarray(t.ravel())
+        n_dt = len(t)
+        c_coeffs = [np.exp(eps)[0], B.ravel()[0]*np.ones(n_dt)]
+        atoms[letter] = ff.PulseSequence(list(zip((X/2, Z/2), c_coeffs, ('X', 'Z'))), [[X/2, np.ones(n_dt), 'X']], t)
+        atoms[letter].cache_control_matrix(omega)
     cliffords = []
     for word in CLIFFORD_WORDS:
         gate = atoms[word[0]]
