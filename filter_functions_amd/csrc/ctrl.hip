@@ -996,16 +996,16 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
                              hipStream_t stream, const ExpandEpilogue* expand, bool* expanded,
-                             const cplx* d4_wfold) {
+                             const cplx* wfold) {
     if (expanded) *expanded = false;
     if (geo.generic)
         return launch_accumulate_generic(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
                                          stream);
     if (geo.pc)
-        return launch_accumulate_pq(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart, d4_wfold,
+        return launch_accumulate_pq(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart, wfold,
                                     stream);
     if (geo.pcw)
-        return launch_accumulate_pcr(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
+        return launch_accumulate_pcr(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart, wfold,
                                      stream);
     if (geo.mfma)
         return launch_accumulate_mfma(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len,

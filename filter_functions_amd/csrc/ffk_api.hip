@@ -119,7 +119,7 @@ size_t ctrl_ws_bytes(int W, int N, int A, int G, int d, int chunks) {
     b += align_up(sizeof(cplx)*size_t(chunks)*A*d*d*W);                   // Ypart
     b += align_up(sizeof(cplx)*size_t(A)*d*d*W);                          // Bt
     b += ffk::expand_workspace_bytes(N, d);                               // compacted basis
-    if (d == 4) b += align_up(sizeof(cplx)*ffk::d4_wfold_elems(G, A));    // folded W_a (ffk_internal.h d4_wfold), LAST
+    b += align_up(sizeof(cplx)*ffk::wfold_elems(d, G, A));                // folded W_a (d = 4, 8: ffk_internal.h wfold), LAST
     return b;
 }
 
@@ -140,7 +140,7 @@ double accumulate_flops(int W, int A, int G, int d) {
         // and blocks of nc = min(3, A) operators execute nc of them whether or not the last block is
         // full; per block the tile 13 x 10 + 62 = 192 and c = psi conj(T), cr + ci: 16 x 7 = 112.
         // The fold of W_a (6 per operator for Bbar times e^{ib} T, 6 per block for that product) is NOT counted:
-        // this entry point has the prologue kernel do it once per segment (ffk_internal.h d4_wfold), the kernel
+        // this entry point has the prologue kernel do it once per segment (ffk_internal.h wfold), the kernel
         // copies it.  (Until the last change of round 5 the kernel folded it per frequency block: 630 nc + 310.)
         const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);
         if (geo.pc) {
@@ -149,10 +149,12 @@ double accumulate_flops(int W, int A, int G, int d) {
         }
     }
     // d = 8 (ctrl_pcr.hip, round 4): per operator the first product real x complex 4 d^3 = 2048, psi P
-    // 6 d^2 = 384, the second product complex 8 d^3 = 4096, the fold (one (m, n) per lane = per
-    // frequency) 9 complex products = 54; per group of <= 3 operators the tile: 57 entries x 10 + 62.
+    // 6 d^2 = 384, the second product complex 8 d^3 = 4096; per group of <= 3 operators the tile: 57 entries x 10 +
+    // 62.  The fold of W' (one (m, n) per lane = per frequency: 9 complex products = 54 per operator) is NOT counted
+    // since round 6: the prologue does it once per segment (ffk_internal.h wfold) and the kernel copies it by LDS-DMA
+    // (until then 6582 A + 632 per group).
     if (d == 8 && ffk::pcr_accumulate_supported(d, A))
-        return (6582.0*A + 632.0*((A + 2)/3))*double(G)*double(W);
+        return (6528.0*A + 632.0*((A + 2)/3))*double(G)*double(W);
     // other d: contraction (2 d^3 MAC + d^2 mul) complex per (g, w, a) = 16 d^3 + 6 d^2 flops; tile:
     // ffk_math.h::phased_integral_aa, 18 flops per distinct entry (rotation 6, addition theorem 3,
     // x 1, reciprocal 4, products 3 + 1), d(d-1)+1 entries per (g, w); two sincos and the phase: 62.
@@ -466,9 +468,9 @@ int control_matrix_dev_impl(const double* eigvals, const double* eigvecs, const 
     cplx* Bt = ws.take<cplx>(size_t(A)*d*d*W);
     void* ews = ws.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
     FFK_REQUIRE(Bt && ews, "workspace too small");
-    // d = 4: the prologue folds W_a once per segment for the accumulate kernel (handed to both launches)
-    cplx* wfold = d == 4 ? ws.take<cplx>(ffk::d4_wfold_elems(G, A)) : nullptr;
-    FFK_REQUIRE(d != 4 || wfold, "workspace too small");
+    // d = 4, 8: the prologue folds W_a once per segment for the accumulate kernel (handed to both launches)
+    cplx* wfold = ffk::wfold_elems(d, G, A) ? ws.take<cplx>(ffk::wfold_elems(d, G, A)) : nullptr;
+    FFK_REQUIRE(!ffk::wfold_elems(d, G, A) || wfold, "workspace too small");
 
     if (!(flags & FFK_INTERNAL_PROLOGUE_DONE)) {
         FFK_HIP(ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
@@ -990,7 +992,7 @@ int pipeline_dev_impl(const double* hamiltonian, const double* dt, const double*
         cw.take<cplx>(size_t(A)*d*d*W);                // Bt
         void* ews = cw.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
         FFK_REQUIRE(ews, "workspace too small");
-        cplx* wfold = d == 4 ? cw.take<cplx>(ffk::d4_wfold_elems(G, A)) : nullptr;
+        cplx* wfold = ffk::wfold_elems(d, G, A) ? cw.take<cplx>(ffk::wfold_elems(d, G, A)) : nullptr;
         FFK_HIP(ffk::launch_apply_prologue_compact(
             w.qloc, totals, G, d, reinterpret_cast<cplx*>(Q), D, reinterpret_cast<const cplx*>(V),
             reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, A, segtab, Tc, ops,

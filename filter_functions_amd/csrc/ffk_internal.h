@@ -113,9 +113,11 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
                            const cplx* n_opers, const double* n_coeffs, const double* dt,
                            const double* t, int G, int d, int A, double* segtab, cplx* Tc,
                            cplx* ops, cplx* n_opers_transformed, cplx* eigvecs_propagated,
-                           hipStream_t stream, cplx* d4_wfold = nullptr);
-// d4_wfold (d = 4 only, may be NULL): W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j] per (segment, operator), 64
-// complex numbers in the order the d = 4 accumulate kernel's tile holds them (d4_wfold_elems(G, A) in all).  It
+                           hipStream_t stream, cplx* wfold = nullptr);
+// wfold (d = 4 and d = 8, may be NULL): the frequency-independent operand of the accumulate kernel's first product per
+// (segment, operator), in the order the kernel's tile holds it, wfold_elems(d, G, A) complex numbers in all -- d = 4:
+// W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j] (64 per segment and operator); d = 8: W'_a[m][n][i] = Bbar_a[m][n]
+// e^{i b_mn} conj(T[m][i]) (512, ctrl_pcr.hip).  It
 // does not depend on the frequency: a caller that owns a buffer for it (ffk_control_matrix_dev, ffk_pipeline_dev)
 // has the prologue kernels write it once per segment and hands it to launch_accumulate, whose producers then copy
 // it into their tiles instead of each of the W/64 frequency blocks folding it again (same products in the same
@@ -134,7 +136,7 @@ hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, i
                                          const cplx* n_opers, const double* n_coeffs,
                                          const double* dt, const double* t, int A, double* segtab,
                                          cplx* Tc, cplx* ops, const cplx* basis, int N, void* ews,
-                                         hipStream_t stream, cplx* d4_wfold = nullptr);
+                                         hipStream_t stream, cplx* wfold = nullptr);
 // basis_transformed (G,N,d,d) = (Q^dag V)^dag C_k (Q^dag V)   (numeric.py:863-864)
 hipError_t launch_basis_transformed(const cplx* Tc, const cplx* basis, int G, int N, int d,
                                     cplx* out, hipStream_t stream);
@@ -179,7 +181,7 @@ struct ExpandEpilogue {
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
                              hipStream_t stream, const ExpandEpilogue* expand = nullptr,
-                             bool* expanded = nullptr, const cplx* d4_wfold = nullptr);
+                             bool* expanded = nullptr, const cplx* wfold = nullptr);
 
 // ---- ctrl_mfma.hip ---------------------------------------------------------------------------
 int device_cu_count();   // compute units of the current device (ctrl.hip)
@@ -209,7 +211,9 @@ struct PqGroups {
     int n3, n2, n1;     // blocks of three, two, one operator(s): 3 n3 + 2 n2 + n1 = A, one launch per size
 };
 PqGroups pq_accumulate_groups(int A);
-constexpr size_t d4_wfold_elems(int G, int A) { return static_cast<size_t>(G)*A*64; }
+constexpr size_t wfold_elems(int d, int G, int A) {
+    return d == 4 ? static_cast<size_t>(G)*A*64 : (d == 8 ? static_cast<size_t>(G)*A*512 : 0);
+}
 hipError_t launch_accumulate_pq(const double* omega, int W, const double* segtab, const cplx* ops,
                                 int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
                                 const cplx* wfold, hipStream_t stream);
@@ -219,9 +223,11 @@ bool pcr_accumulate_supported(int d, int A);
 int pcr_accumulate_ops_per_block();
 int pcr_accumulate_waves();
 int pcr_accumulate_lds_bytes();
+// d = 8: fills wfold from the prologue's outputs (segtab, ops): one 64-thread block per (segment, operator)
+hipError_t launch_fold_w8(const double* segtab, const cplx* ops, int G, int A, cplx* wfold, hipStream_t stream);
 hipError_t launch_accumulate_pcr(const double* omega, int W, const double* segtab, const cplx* ops,
                                  int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
-                                 hipStream_t stream);
+                                 const cplx* wfold, hipStream_t stream);
 
 // ---- post.hip --------------------------------------------------------------------------------
 // Bt (A,d,d,W) = sum over chunks of Ypart

@@ -60,7 +60,7 @@ __device__ void prologue_segment(const cplx (*V)[D], cplx (*Q)[D], cplx (*T)[D],
     __syncthreads();
 
     if (!with_noise_ops) return;        // (large d: noise_ops_kernel, one block per operator)
-    // d = 4 with a buffer for it (ffk_internal.h d4_wfold): W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j], the
+    // d = 4 with a buffer for it (ffk_internal.h wfold): W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j], the
     // operand the accumulate kernel's tiles hold, folded here once per segment.  Q is free by now: it keeps e^{ib}.
     const bool fold = D == 4 && wfold != nullptr;
     if (fold) {
@@ -357,11 +357,39 @@ __global__ void phase_integral_kernel(const double* __restrict__ omega, int W,
 
 }  // namespace
 
+// d = 8: W'_a[m][n][i] = Bbar_a[m][n] e^{i b_mn} conj(T[m][i]), the frequency-independent A operand of the accumulate
+// kernel's first product (ctrl_pcr.hip), once per (segment, operator) instead of once per 64-frequency block: the
+// kernel's producers then copy it into their tiles by LDS-DMA.  Thread l <-> (m, n) = (l >> 3, l & 7); the products,
+// their order and the layout [(s, ng, ig)][consumer lane] are those of the producers' own fold (same bits).
+__global__ __launch_bounds__(64) void fold_w8_kernel(const double* __restrict__ segtab, const cplx* __restrict__ ops,
+                                                     int A, cplx* __restrict__ wfold) {
+    constexpr int D = 8, DD = 64, S = seg_stride(8);
+    const int g = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+    const cplx* src = ops + static_cast<size_t>(g)*(1 + A)*DD;
+    const double* r = segtab + static_cast<size_t>(g)*S + seg_rec(lane);
+    const cplx x = src[static_cast<size_t>(1 + a)*DD + lane];
+    const double sb = r[1], cb = r[2];
+    const int m = lane >> 3, n = lane & 7;
+    const int base = ((m >> 2)*2 + (n >> 2))*2*64 + 4*(n & 3) + 16*(m & 3);
+    const cplx bt = cmul(x, cplx{cb, sb});
+    cplx* out = wfold + (static_cast<size_t>(g)*A + a)*512;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const cplx t = src[m*D + i];
+        out[base + (i >> 2)*64 + (i & 3)] = cmul(bt, cplx{t.re, -t.im});
+    }
+}
+
+hipError_t launch_fold_w8(const double* segtab, const cplx* ops, int G, int A, cplx* wfold, hipStream_t stream) {
+    hipLaunchKernelGGL(fold_w8_kernel, dim3(G, A), dim3(64), 0, stream, segtab, ops, A, wfold);
+    return hipGetLastError();
+}
+
 hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cplx* propagators,
                            const cplx* n_opers, const double* n_coeffs, const double* dt,
                            const double* t, int G, int d, int A, double* segtab, cplx* Tc,
                            cplx* ops, cplx* n_opers_transformed, cplx* eigvecs_propagated,
-                           hipStream_t stream, cplx* d4_wfold) {
+                           hipStream_t stream, cplx* wfold) {
     if (generic_dimension(d))
         return launch_prologue_generic(eigvals, eigvecs, propagators, n_opers, n_coeffs, dt, t, G, d, A, segtab,
                                        Tc, ops, n_opers_transformed, eigvecs_propagated, stream);
@@ -371,7 +399,7 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
         hipLaunchKernelGGL(prologue_kernel<D>, dim3(G), dim3(64), 0, stream, eigvals, eigvecs,  \
                            propagators, n_opers, n_coeffs, dt, t, G, A, segtab, Tc, ops,        \
                            n_opers_transformed, eigvecs_propagated, !split_noise_ops(D, A),     \
-                           D == 4 ? d4_wfold : nullptr);                                        \
+                           D == 4 ? wfold : nullptr);                                           \
         if (split_noise_ops(D, A))                                                              \
             hipLaunchKernelGGL(noise_ops_kernel<D>, dim3(G, A), dim3(64), 0, stream, eigvecs,   \
                                n_opers, n_coeffs, G, A, ops, n_opers_transformed);              \
@@ -383,6 +411,7 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
         default:
             return hipErrorInvalidValue;
     }
+    if (d == 8 && wfold != nullptr) return launch_fold_w8(segtab, ops, G, A, wfold, stream);
     return hipGetLastError();
 }
 
@@ -391,7 +420,7 @@ hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, i
                                          const cplx* n_opers, const double* n_coeffs,
                                          const double* dt, const double* t, int A, double* segtab,
                                          cplx* Tc, cplx* ops, const cplx* basis, int N, void* ews,
-                                         hipStream_t stream, cplx* d4_wfold) {
+                                         hipStream_t stream, cplx* wfold) {
     const int L = front_chunk(d);
     int* nnz = nullptr;
     int* rows = nullptr;
@@ -414,7 +443,7 @@ hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, i
                            sizeof(cplx)*D*D*(D <= 8 ? (G + L - 1)/L : 16), stream, Qloc,         \
                            totals, G, L, Q, eigvals, eigvecs, n_opers, n_coeffs, dt, t, A,       \
                            segtab, Tc, ops, basis, nnz, rows, vals, !split_noise_ops(D, A),      \
-                           D == 4 ? d4_wfold : nullptr);                                         \
+                           D == 4 ? wfold : nullptr);                                            \
         if (split_noise_ops(D, A))                                                               \
             hipLaunchKernelGGL(noise_ops_kernel<D>, dim3(G, A), dim3(64), 0, stream, eigvecs,    \
                                n_opers, n_coeffs, G, A, ops, nullptr);                           \
@@ -426,6 +455,7 @@ hipError_t launch_apply_prologue_compact(const cplx* Qloc, const cplx* totals, i
         default:
             return hipErrorInvalidValue;
     }
+    if (d == 8 && wfold != nullptr) return launch_fold_w8(segtab, ops, G, A, wfold, stream);
     return hipGetLastError();
 }
 

@@ -113,7 +113,8 @@ def test_d4_accumulate_kernel_leaves_room_for_a_second_pass(kernels):
 def test_matrix_core_accumulate_kernels_keep_their_occupancy(kernels):
     """d = 8 (config 4): 16 wavefronts per block = four per SIMD -> at most 128 registers; d = 16 (config 5): eight
     wavefronts = two per SIMD -> at most 256."""
-    k8 = _one(kernels, 'ctrl_accumulate_pcr_kernelILi3E')
-    assert k8['.vgpr_count'] <= 128 and k8['.max_flat_workgroup_size'] == 1024, k8['.vgpr_count']
+    for pre in (0, 1):              # W' folded by the kernel's producers / copied from the prologue's fold by LDS-DMA
+        k8 = _one(kernels, 'ctrl_accumulate_pcr_kernelILi3ELb%dE' % pre)
+        assert k8['.vgpr_count'] <= 128 and k8['.max_flat_workgroup_size'] == 1024, k8['.vgpr_count']
     k16 = _one(kernels, 'ctrl_accumulate_mfma4_kernelILi16ELi2ELi8ELb1E')      # the instantiation config 5 launches
     assert k16['.vgpr_count'] <= 256 and k16['.max_flat_workgroup_size'] == 512, k16['.vgpr_count']

@@ -62,15 +62,24 @@ def prod(u, ng, ig, reim):
     return P0 + 2*(((u*2 + ng)*2 + ig)*2 + reim)
 
 
+import os
+# tuning builds (wrong results, never shipped): GEN_PCR_DROP=rot|valu|reads|waits leaves that part of the block out
+DROP = os.environ.get('GEN_PCR_DROP', '').split(',')
+
+
 class Stream:
     def __init__(self):
         self.lines = []
         self.fifo = []              # tags of LDS operations in flight, oldest first
 
     def emit(self, text):
+        if 'valu' in DROP and text.startswith('v_') and 'mfma' not in text and not text.startswith('v_add_u32'):
+            return
         self.lines.append(text)
 
     def lds(self, text, tag):
+        if ('rot' in DROP and 'bpermute' in text) or ('reads' in DROP and text.startswith('ds_read')):
+            return
         self.lines.append(text)
         self.fifo.append(tag)
 
@@ -80,7 +89,8 @@ class Stream:
         if last is None:
             return
         younger = len(self.fifo) - 1 - last
-        self.lines.append(f's_waitcnt lgkmcnt({min(younger, 15)})')
+        if 'waits' not in DROP:
+            self.lines.append(f's_waitcnt lgkmcnt({min(younger, 15)})')
         if younger <= 15:
             self.fifo = self.fifo[last + 1:]
         else:
