@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "ffk_internal.h"
+#include "ffk_mfma_util.h"
 
 namespace ffk {
 namespace {
@@ -180,7 +181,7 @@ template <int A, int N, bool LCPLX>
 __global__ __launch_bounds__(1024) void from_atomic_block_kernel(
     const cplx* __restrict__ phases, const cplx* __restrict__ Ratomic, const cplx* const* __restrict__ Rtab,
     const int32_t* __restrict__ index, const double* __restrict__ L, int G, int T, int W, int glen,
-    cplx* __restrict__ out, cplx* __restrict__ F) {
+    cplx* __restrict__ out, cplx* __restrict__ F, const double* __restrict__ Lpulse) {
     constexpr int ROWS = A*N;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     __builtin_amdgcn_s_setprio(3);
@@ -209,8 +210,15 @@ __global__ __launch_bounds__(1024) void from_atomic_block_kernel(
     };
     // product of the total phases of this slab's positions, then of all earlier slabs
     // (index[] is wave uniform: scalar loads, a trip to the scalar cache per position)
+    // (the slab's pulse numbers in ONE coalesced load -- lane l holds position g0 + l -- and a v_readlane per position
+    // where the slab has at most 64 positions; round 5: a scalar load and a full wait per position, twice)
+    const bool slab_in_lanes = glen <= 64;
+    const int my_index = slab_in_lanes && g0 + lane < g1 ? index[g0 + lane] : 0;
+    auto pulse_at = [&](int g) -> int {
+        return slab_in_lanes ? __builtin_amdgcn_readlane(my_index, g - g0) : index[g];
+    };
     cplx loc = {1.0, 0.0};
-    for (int g = g0; g < g1; ++g) times(loc, Ps[index[g]*64 + lane]);
+    for (int g = g0; g < g1; ++g) times(loc, Ps[pulse_at(g)*64 + lane]);
     Pslab[wave*64 + lane] = loc;
     __syncthreads();
     cplx run = {1.0, 0.0};
@@ -218,12 +226,111 @@ __global__ __launch_bounds__(1024) void from_atomic_block_kernel(
     cplx acc[ROWS];
 #pragma unroll
     for (int e = 0; e < ROWS; ++e) acc[e] = {0.0, 0.0};
-    // the position's pulse number and propagator are wave uniform (scalar loads); those of position
-    // g + 1 are requested before position g is worked on, so that a trip to L2 overlaps the
-    // arithmetic instead of preceding it
     constexpr int LN = N*N*(LCPLX ? 2 : 1);
+    if (Lpulse != nullptr) {
+        // Round 6: the slab by a BACKWARD recurrence on the DISTINCT pulses' own propagators.  With v_g the control
+        // matrix of the pulse at position g, p_g its total phase, L_g the Liouville representation of its propagator
+        // and P_g, M_g the products of the phases / representations of the positions before g,
+        //     sum_{g in slab} P_g v_g M_g = P_{g0} S_{g0} M_{g0},     S_g = v_g + p_g (S_{g+1} L_g),   S_{g1} = 0:
+        // every operand of a position comes from a table of the T distinct pulses -- the representations, T x 128
+        // bytes, through scalar loads that stay in the scalar cache -- and only the slab's first position needs a
+        // cumulative propagator.  Rounds 2-5 read ONE CUMULATIVE propagator per position (two s_load_dwordx16 from
+        // 128 KB that 16 wavefronts x 128 blocks stream through a 16-KB scalar cache, every wait lgkmcnt(0)): ~0.5 us
+        // of stall per position on 0.43 us of arithmetic, 57 us for 27 us of issue (profiles/r04_m_*, r06_e_*).
+        // 48 instead of 60 vector instructions per position.  The sum is re-associated (62 more orthogonal 4 x 4
+        // products in a row than the reference's form): ~1e-15 relative.
+        // (Measured and not kept in round 6, same arithmetic as before: the cumulative propagators through vector
+        // loads, every lane the same address, 57.6 -> 80.6 us; through a per-wavefront LDS ring filled by LDS-DMA and
+        // broadcast reads, 75.9 us -- 8 KB into the vector registers per position and wavefront either way.)
+        cplx S[ROWS];
+#pragma unroll
+        for (int e = 0; e < ROWS; ++e) S[e] = {0.0, 0.0};
+        int k_next = g0 < g1 ? pulse_at(g1 - 1) : 0;
+        double Lnext[LN];
+        auto request = [&](int k) {
+            const double* Lk = Lpulse + static_cast<size_t>(k)*LN;
+#pragma unroll
+            for (int e = 0; e < LN; ++e) Lnext[e] = Lk[e];
+        };
+        if (g0 < g1) request(k_next);
+#if defined(FFK_RULE_ABLATE)     /* tuning: the launch without its recurrence (what do staging, products and reduction cost?) */
+        for (int g = g1 - 1; g >= g0 + (g1 - g0) - FFK_RULE_ABLATE; --g) {
+#else
+        for (int g = g1 - 1; g >= g0; --g) {
+#endif
+            const int k = k_next;
+            double Lk[LN];
+#pragma unroll
+            for (int e = 0; e < LN; ++e) Lk[e] = Lnext[e];
+            if (g > g0) {
+                k_next = pulse_at(g - 1);
+                request(k_next);
+            }
+            const cplx* Rg = Rs + static_cast<size_t>(k)*ROWS*64 + lane;
+            const cplx p = Ps[k*64 + lane];
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                cplx t[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) t[j] = {0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < N; ++kk)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        if (LCPLX) {
+                            const cplx q = {Lk[2*(kk*N + j)], Lk[2*(kk*N + j) + 1]};
+                            cmac(t[j], q, S[a*N + kk]);
+                        } else {
+                            const double q = Lk[kk*N + j];
+                            t[j].re = fma(q, S[a*N + kk].re, t[j].re);
+                            t[j].im = fma(q, S[a*N + kk].im, t[j].im);
+                        }
+                    }
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const cplx v = Rg[(a*N + j)*64];
+                    S[a*N + j] = {fma(p.re, t[j].re, fma(-p.im, t[j].im, v.re)),
+                                  fma(p.re, t[j].im, fma(p.im, t[j].re, v.im))};
+                }
+            }
+        }
+        // the slab's sum: P_{g0} S M_{g0} (M_0 = 1)
+        if (g0 < g1) {
+            if (g0 == 0) {
+#pragma unroll
+                for (int e = 0; e < ROWS; ++e) acc[e] = S[e];
+            } else {
+                const double* Lg = L + static_cast<size_t>(g0 - 1)*LN;
+#pragma unroll
+                for (int a = 0; a < A; ++a) {
+                    cplx step[N];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) step[j] = {0.0, 0.0};
+#pragma unroll
+                    for (int kk = 0; kk < N; ++kk) {
+                        const cplx v = cmul(run, S[a*N + kk]);
+#pragma unroll
+                        for (int j = 0; j < N; ++j) {
+                            if (LCPLX) {
+                                const cplx q = {Lg[2*(kk*N + j)], Lg[2*(kk*N + j) + 1]};
+                                cmac(step[j], q, v);
+                            } else {
+                                const double q = Lg[kk*N + j];
+                                step[j].re = fma(q, v.re, step[j].re);
+                                step[j].im = fma(q, v.im, step[j].im);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < N; ++j) acc[a*N + j] = step[j];
+                }
+            }
+        }
+    } else {
+    // The position's propagator is wave uniform (scalar loads); that of position g + 1 is requested before position g
+    // is worked on, so that a trip to L2 overlaps the arithmetic instead of preceding it.
     double Lnext[LN];
-    int k_next = g0 < g1 ? index[g0] : 0;
+    int k_next = g0 < g1 ? pulse_at(g0) : 0;
     auto request = [&](int g) {
         const double* Lg = L + static_cast<size_t>(g > 0 ? g - 1 : 0)*LN;
 #pragma unroll
@@ -236,7 +343,7 @@ __global__ __launch_bounds__(1024) void from_atomic_block_kernel(
 #pragma unroll
         for (int e = 0; e < LN; ++e) Lg[e] = Lnext[e];
         if (g + 1 < g1) {
-            k_next = index[g + 1];
+            k_next = pulse_at(g + 1);
             request(g + 1);
         }
         const cplx* Rg = Rs + static_cast<size_t>(k)*ROWS*64 + lane;
@@ -276,6 +383,7 @@ __global__ __launch_bounds__(1024) void from_atomic_block_kernel(
             }
         }
         times(run, Ps[k*64 + lane]);                // run <- run * total_phase[pulse at position g]
+    }
     }
     __syncthreads();                                // tables dead: the slab sums take their place
     cplx* red = Rs;
@@ -321,7 +429,7 @@ __global__ __launch_bounds__(1024) void sequence_front_kernel(
     const cplx* __restrict__ U, const int32_t* __restrict__ index, int G, const cplx* __restrict__ basis,
     int N, int l_is_complex, cplx* __restrict__ Q, double* __restrict__ L,
     const double* __restrict__ tau, const double* __restrict__ omega, int T, int W,
-    cplx* __restrict__ phases, double* __restrict__ omega_copy) {
+    cplx* __restrict__ phases, double* __restrict__ omega_copy, double* __restrict__ Lpulse) {
     constexpr int DD = D*D;
     __builtin_amdgcn_s_setprio(3);
     if (blockIdx.x > 0) {
@@ -389,8 +497,8 @@ __global__ __launch_bounds__(1024) void sequence_front_kernel(
 #pragma unroll
         for (int e = 0; e < DD; ++e) Q[static_cast<size_t>(g + 1)*DD + e] = M[e];
     }
-    if (g + 1 < G) {
-        // L_g = representation of Q_{g+1} = M:  CB_i = M^dag C_i M,  L[i,j] = tr(CB_i C_j)
+    // representation of a matrix M:  CB_i = M^dag C_i M,  L[i,j] = tr(CB_i C_j)  -> dst (N, N), f64 or c128
+    auto represent = [&](const cplx (&Mx)[DD], double* dst) {
         for (int i = 0; i < N; ++i) {
             const cplx* Ci = Cs + i*DD;
             cplx CM[DD], CB[DD];
@@ -400,7 +508,7 @@ __global__ __launch_bounds__(1024) void sequence_front_kernel(
                 for (int c = 0; c < D; ++c) {
                     cplx acc = {0.0, 0.0};
 #pragma unroll
-                    for (int k = 0; k < D; ++k) cmac(acc, Ci[r*D + k], M[k*D + c]);
+                    for (int k = 0; k < D; ++k) cmac(acc, Ci[r*D + k], Mx[k*D + c]);
                     CM[r*D + c] = acc;
                 }
 #pragma unroll
@@ -409,7 +517,7 @@ __global__ __launch_bounds__(1024) void sequence_front_kernel(
                 for (int b = 0; b < D; ++b) {
                     cplx acc = {0.0, 0.0};
 #pragma unroll
-                    for (int k = 0; k < D; ++k) cmac_conj(acc, M[k*D + a], CM[k*D + b]);
+                    for (int k = 0; k < D; ++k) cmac_conj(acc, Mx[k*D + a], CM[k*D + b]);
                     CB[a*D + b] = acc;
                 }
             for (int j = 0; j < N; ++j) {
@@ -419,16 +527,28 @@ __global__ __launch_bounds__(1024) void sequence_front_kernel(
                 for (int a = 0; a < D; ++a)
 #pragma unroll
                     for (int b = 0; b < D; ++b) cmac(acc, CB[a*D + b], Cj[b*D + a]);
-                const size_t o = (static_cast<size_t>(g)*N + i)*N + j;
+                const size_t o = static_cast<size_t>(i)*N + j;
                 if (l_is_complex) {
-                    L[2*o] = acc.re;
-                    L[2*o + 1] = acc.im;
+                    dst[2*o] = acc.re;
+                    dst[2*o + 1] = acc.im;
                 } else {
-                    L[o] = acc.re;
+                    dst[o] = acc.re;
                 }
             }
         }
-    }
+    };
+    // L_g = representation of Q_{g+1} = M
+    if (g + 1 < G) represent(M, L + static_cast<size_t>(g)*N*N*(l_is_complex ? 2 : 1));
+    // round 6: the representations of the T distinct pulses' own propagators as well (the rule kernel's backward
+    // recurrence reads these -- a table of a few KB that stays in the scalar cache -- instead of one cumulative
+    // propagator per position)
+    if (Lpulse != nullptr)
+        for (int k = g; k < T; k += blockDim.x) {
+            cplx Uk[DD];
+#pragma unroll
+            for (int e = 0; e < DD; ++e) Uk[e] = U[static_cast<size_t>(k)*DD + e];
+            represent(Uk, Lpulse + static_cast<size_t>(k)*N*N*(l_is_complex ? 2 : 1));
+        }
 }
 
 template <bool LCPLX, bool INDEXED>
@@ -473,7 +593,7 @@ bool sequence_front_supported(int d, int G, int N) {
 hipError_t launch_sequence_front(const cplx* U, const int32_t* index, int G, int d, const cplx* basis,
                                  int N, int l_is_complex, cplx* Q, double* L, const double* tau,
                                  const double* omega, int T, int W, cplx* phases, double* omega_copy,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, double* Lpulse) {
     if (!sequence_front_supported(d, G, N)) return hipErrorInvalidValue;
     const int threads = front_threads(G);
     const size_t lds = front_lds_bytes(G, d, N);
@@ -488,7 +608,7 @@ hipError_t launch_sequence_front(const cplx* U, const int32_t* index, int G, int
             if (err != hipSuccess) return err;                                                         \
         }                                                                                              \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, stream, U, index, G, basis, N,      \
-                           l_is_complex, Q, L, tau, omega, T, W, phases, omega_copy);                  \
+                           l_is_complex, Q, L, tau, omega, T, W, phases, omega_copy, Lpulse);          \
         break;                                                                                         \
     }
     switch (d) {
@@ -518,7 +638,7 @@ size_t from_atomic_workspace_bytes(int G, int A, int N, int W) {
 hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int32_t* index,
                               const double* L, int l_is_complex, int G, int A, int N, int W,
                               int correlations, cplx* out, void* ws, hipStream_t stream,
-                              const cplx* const* Rtab, cplx* F, int T) {
+                              const cplx* const* Rtab, cplx* F, int T, const double* Lpulse) {
     if (A > 65535) return hipErrorInvalidValue;
     if (index && !correlations && T > 0 && N == 4 && A <= 4 && G >= 64) {
         // single-qubit rows, tables that fit LDS: one block per 64 frequencies does rule, reduction and F
@@ -533,7 +653,7 @@ hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int
                                                     static_cast<int>(lds));
                 if (e2 != hipSuccess) return e2;
                 hipLaunchKernelGGL(kern, dim3((W + 63)/64), dim3(nslab*64), lds, stream, phases, Ratomic, Rtab,
-                                   index, L, G, T, W, glen, out, F);
+                                   index, L, G, T, W, glen, out, F, Lpulse);
                 return hipGetLastError();
             };
 #define FFK_BLK(AA)                                                                             \

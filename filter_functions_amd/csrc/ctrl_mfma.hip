@@ -352,6 +352,24 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
                 dst_tab[e - n_ops] = staged[k];
         }
     };
+    // BF, round 6: the staging copy by LDS-DMA (ffk_mfma_util.h lds_dma16): pieces of 64 complex numbers dealt over the
+    // wavefronts, requested at the top of a step into the buffer the step before has finished with, in flight during
+    // the generation AND the contraction, waited for before the barrier at the top of the next step.  No staging
+    // registers (16 of 256, next to 5 spilled), no ds_write_b128 (35-45 cycles of issue each, tools/lds_issue_probe.py).
+    auto dma_stage = [&](int g, int buf) {
+        const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*DD;
+        const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
+        const int n_och = (n_ops + 63) >> 6, n_rch = (S/2 + 63) >> 6;
+        for (int ch = wave; ch < n_och + n_rch; ch += nw) {
+            if (ch < n_och) {
+                const int e = 64*ch + lane;
+                if (e < n_ops) lds_dma16(src_ops + (e < DD ? e : e + alpha0*DD), opsb + buf*kops + 64*ch);
+            } else {
+                const int e = 64*(ch - n_och) + lane;
+                if (e < S/2) lds_dma16(src_tab + e, reinterpret_cast<cplx*>(rows + buf*S) + 64*(ch - n_och));
+            }
+        }
+    };
     auto generate = [&](int slot) {
         const double* st = rows + slot*S;
         const double dtg = st[0];
@@ -494,27 +512,41 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
         }
     };
 
+#if defined(FFK_M_REGISTER_STAGING)   /* A/B builds: rounds 1-5's staging through registers */
+    constexpr bool kDmaStage = false;
+#else
+    constexpr bool kDmaStage = BF;
+#endif
     if (g0 < g1) {
-        issue_stage(g0);
-        park(0);
+        if constexpr (kDmaStage) {
+            dma_stage(g0, 0);
+        } else {
+            issue_stage(g0);
+            park(0);
+        }
     }
     FFK_MC_DECL();
     for (int g = g0; g < g1; ++g) {
         const int buf = (g - g0) & 1;
         [[maybe_unused]] const unsigned long long mc0 = FFK_MC_T();
+        if constexpr (kDmaStage) lds_dma_wait();     // the copies of this segment's operands and table row
         __syncthreads();
         if constexpr (BF) {
             [[maybe_unused]] const unsigned long long mc1 = FFK_MC_T();
             // the staging loads of segment g + 1 fly during the generation, not the contraction,
             // whose accumulators, T entries and products leave no registers for them (d = 16)
-            if (g + 1 < g1) issue_stage(g + 1);
+            if (g + 1 < g1) {
+                if constexpr (kDmaStage) dma_stage(g + 1, buf ^ 1);     // buffer buf ^ 1: last read before this barrier
+                else issue_stage(g + 1);
+            }
             [[maybe_unused]] const unsigned long long mc1b = FFK_MC_T();
             FFK_MC_ADD(6, mc1, mc1b);        // [6] of [1]: issue of the staging loads alone
 #if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 1)   /* diagnostic build 1: no generation */
             generate(buf);
 #endif
             [[maybe_unused]] const unsigned long long mc2 = FFK_MC_T();
-            if (g + 1 < g1) park(buf ^ 1);   // buffer buf ^ 1: last read before this barrier interval
+            if constexpr (!kDmaStage)
+                if (g + 1 < g1) park(buf ^ 1);   // buffer buf ^ 1: last read before this barrier interval
             [[maybe_unused]] const unsigned long long mc3 = FFK_MC_T();
             __syncthreads();
             [[maybe_unused]] const unsigned long long mc4 = FFK_MC_T();

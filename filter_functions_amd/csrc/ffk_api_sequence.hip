@@ -171,7 +171,7 @@ size_t sequence_scratch_bytes(int G, int d, int A, int N, int W, int which, bool
            align_up(which ? 16*size_t(G)*A*N*W : 16*size_t(A)*N*W) +
            align_up(ffk::scan_workspace_bytes(G, d)) + align_up(ffk::liouville_workspace_bytes(nl, d, N)) +
            align_up(ffk_control_matrix_from_atomic_workspace_bytes(G, A, N, W)) +
-           (want_F ? align_up(16*size_t(A)*A*W) : 0);
+           (want_F ? align_up(16*size_t(A)*A*W) : 0) + align_up(16*size_t(G)*N*N);      // (last: the distinct pulses' representations, T <= G)
 }
 
 // gather -> prefix products -> Liouville representation -> table rule (-> F) on `s`, all operands
@@ -202,6 +202,10 @@ int sequence_on_device(const double* dU, const double* dP, const double* dR, con
     void* watom = a.take<unsigned char>(aws);
     double* dF = nF ? a.take<double>(nF/8) : nullptr;
     FFK_REQUIRE(watom && (!nF || dF), "workspace too small");
+    // the T distinct pulses' own Liouville representations, for the rule kernel's backward recurrence (the fused front
+    // launch writes them; T <= G)
+    double* dLp = (dTau && T <= G && ffk::sequence_front_supported(d, G, N))
+                      ? a.take<double>((l_is_complex ? 2 : 1)*size_t(T)*N*N) : nullptr;
     if (resident_R) dO = resident_R;          // results that stay in a handle's device block
     if (resident_F) dF = resident_F;
     if (dTau && ffk::sequence_front_supported(d, G, N)) {
@@ -209,7 +213,7 @@ int sequence_on_device(const double* dU, const double* dP, const double* dR, con
         FFK_HIP(ffk::launch_sequence_front(reinterpret_cast<const cplx*>(dU), dI, G, d,
                                            reinterpret_cast<const cplx*>(dB), N, l_is_complex, dQ, dL, dTau,
                                            dOmega, T, W, reinterpret_cast<cplx*>(const_cast<double*>(dP)),
-                                           omega_copy, s));
+                                           omega_copy, s, dLp));
     } else {
         if (dTau) {
             hipLaunchKernelGGL(total_phases_kernel, dim3((W + 255)/256, T), dim3(256), 0, s, dOmega, dTau, T,
@@ -230,7 +234,7 @@ int sequence_on_device(const double* dU, const double* dP, const double* dR, con
     if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_start, s));
     FFK_HIP(ffk::launch_from_atomic(reinterpret_cast<const cplx*>(dP), reinterpret_cast<const cplx*>(dR), dI,
                                     dL, l_is_complex, G, A, N, W, which, reinterpret_cast<cplx*>(dO), watom,
-                                    s, dRtab, reinterpret_cast<cplx*>(dF), T));
+                                    s, dRtab, reinterpret_cast<cplx*>(dF), T, dLp));
     if (g_ev_start && g_ev_stop) FFK_HIP(hipEventRecord(g_ev_stop, s));
     if (dF) FFK_HIP(hipMemcpyAsync(filter_function, dF, nF, hipMemcpyDeviceToHost, s));
     if (control_matrix) FFK_HIP(hipMemcpyAsync(control_matrix, dO, nO, hipMemcpyDeviceToHost, s));

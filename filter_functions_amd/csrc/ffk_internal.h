@@ -275,7 +275,11 @@ size_t from_atomic_workspace_bytes(int G, int A, int N, int W);
 hipError_t launch_from_atomic(const cplx* phases, const cplx* Ratomic, const int32_t* index,
                               const double* L, int l_is_complex, int G, int A, int N, int W,
                               int correlations, cplx* out, void* ws, hipStream_t stream,
-                              const cplx* const* Rtab = nullptr, cplx* F = nullptr, int T = 0);
+                              const cplx* const* Rtab = nullptr, cplx* F = nullptr, int T = 0,
+                              const double* Lpulse = nullptr);
+// Lpulse (optional, with index and T): the Liouville representations (T, N, N) of the T distinct pulses' own total
+// propagators (f64, or c128 with l_is_complex): the single-qubit block kernel then walks a slab by a backward
+// recurrence on these instead of reading one cumulative propagator per position (atomic.hip)
 // (T: number of distinct pulses of the indexed form; with it, few rows and tables that fit LDS the
 // rule, its slab reduction and F are ONE launch, from_atomic_block_kernel)
 // The front of a sequence concatenation in one launch (d <= 4, G <= 1024, N <= 16): Q (G+1,d,d)
@@ -285,7 +289,7 @@ bool sequence_front_supported(int d, int G, int N);
 hipError_t launch_sequence_front(const cplx* U, const int32_t* index, int G, int d, const cplx* basis,
                                  int N, int l_is_complex, cplx* Q, double* L, const double* tau,
                                  const double* omega, int T, int W, cplx* phases, double* omega_copy,
-                                 hipStream_t stream);
+                                 hipStream_t stream, double* Lpulse = nullptr);
 
 // ---- decay.hip -------------------------------------------------------------------------------
 // Gamma (Gp,Gp,n_idx[,n_idx],N,N) f64 from R (Gp,A,N,W) c128 (Gp = 1: the total control matrix),
