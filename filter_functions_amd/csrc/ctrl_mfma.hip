@@ -24,6 +24,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <cstdio>
+
 #include "ffk_internal.h"
 #include "ffk_mfma_util.h"
 
@@ -270,32 +272,41 @@ __global__ __launch_bounds__(kMW*64, 1) void ctrl_accumulate_mfma_kernel(
 // frequencies come as 4 / JH sets of four: the JH wavefronts of an operator split the tile's 16
 // frequencies, not the columns of Y.  The tile's slots are 20 complex apart (16 frequencies + 4 of
 // padding: a 16-lane row reads 4 slots x 4 frequencies, banks (4 (c & 3) + (c >> 2)) mod 16).
-constexpr int mfma4_tile_stride(bool bf) { return bf ? 20 : 16; }
-template <int D, int JH, int MAXW = 8, bool BF = false>
-__global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
+constexpr int mfma4_tile_stride(bool bf, int tw = 16) { return bf ? tw + 4 : 16; }
+// TW (block-frequency form only): frequencies per tile.  16: a block = eight wavefronts, two per SIMD, all in the same
+// phase -- generate, barrier, contract, barrier -- so the matrix pipe is idle while the tile is generated (7.1 k of a
+// 40.7 k-cycle step, profiles/r04_o_*) and the wavefront of a SIMD that finishes its contraction first waits for its
+// sibling.  8 (round 6): a block = FOUR wavefronts, one per SIMD, one operator each (JH = 1), 76 KB of LDS (operands
+// single-buffered: copied by LDS-DMA behind the barrier that ends the contraction, in flight during the generation)
+// -- TWO INDEPENDENT BLOCKS per CU, each with its own barriers: the SIMD's older wavefront wins the arbiter, runs
+// ahead, and from then on one block generates its tile while the other's matrix instructions have the pipe.
+template <int D, int JH, int MAXW = 8, bool BF = false, int TW = 16>
+__global__ __launch_bounds__(MAXW*64, TW == 8 ? 2 : 1) void ctrl_accumulate_mfma4_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab,
     const cplx* __restrict__ ops, int G, int A, int chunk_len, int nw, cplx* __restrict__ Ypart,
     int alpha_base, int alpha_end, ExpandEpilogue ep) {
     static_assert(D % 4 == 0 && D >= 4 && D <= 16, "d must be a multiple of 4");
-    static_assert(BF ? 4 % JH == 0 : (D/4) % JH == 0, "row groups / frequency sets must split evenly");
+    static_assert(BF ? (TW/4) % JH == 0 : (D/4) % JH == 0, "row groups / frequency sets must split evenly");
+    static_assert(TW == 16 || (TW == 8 && BF), "8-frequency tiles: block-frequency form only");
     constexpr int S = seg_stride(D), DD = D*D, NS = D/4;
     constexpr int NJG = BF ? NS : NS/JH;   // row groups (of 4 columns of Y) owned by this wave
-    constexpr int NSET = BF ? 4/JH : 1;    // BF: sets of four frequencies owned by this wave
-    constexpr int TS = mfma4_tile_stride(BF);
+    constexpr int NSET = BF ? (TW/4)/JH : 1;    // BF: sets of four frequencies owned by this wave
+    constexpr int TS = mfma4_tile_stride(BF, TW);
+    constexpr bool kSingleOps = TW == 8;         // one operand buffer (see above)
     constexpr int kMaxStage = D == 16 ? (MAXW < 8 ? 8 : 4) : 8;   // staged elements per thread (see launch_d4)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int na = nw/JH;             // noise operators per block
     const int kops = (1 + na)*DD;
     cplx* tile = reinterpret_cast<cplx*>(lds_raw);
     cplx* opsb = tile + DD*TS;
-    double* rows = reinterpret_cast<double*>(opsb + 2*kops);
+    double* rows = reinterpret_cast<double*>(opsb + (kSingleOps ? 1 : 2)*kops);
 
     const int tid = threadIdx.x;
     const int nthreads = nw*64;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4, c4 = c & 3;
-    const int iw = blockIdx.x*16 + c;
+    const int iw = blockIdx.x*TW + (c & (TW - 1));      // the frequency this lane GENERATES entries for
     const double om = omega[iw < W ? iw : W - 1];
     const int alpha0 = alpha_base + blockIdx.y*na;   // the launch serves operators [alpha_base, alpha_end)
     const int alpha_l = wave / JH, jh = wave % JH;
@@ -356,20 +367,22 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     // wavefronts, requested at the top of a step into the buffer the step before has finished with, in flight during
     // the generation AND the contraction, waited for before the barrier at the top of the next step.  No staging
     // registers (16 of 256, next to 5 spilled), no ds_write_b128 (35-45 cycles of issue each, tools/lds_issue_probe.py).
-    auto dma_stage = [&](int g, int buf) {
-        const cplx* src_ops = ops + static_cast<size_t>(g)*(1 + A)*DD;
-        const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S);
-        const int n_och = (n_ops + 63) >> 6, n_rch = (S/2 + 63) >> 6;
+    // (g_ops / g_row: the segments whose operands / table row are copied, -1 = none; obuf / rbuf: their buffers)
+    auto dma_stage2 = [&](int g_ops, int obuf, int g_row, int rbuf) {
+        const int n_och = g_ops >= 0 ? (n_ops + 63) >> 6 : 0, n_rch = g_row >= 0 ? (S/2 + 63) >> 6 : 0;
         for (int ch = wave; ch < n_och + n_rch; ch += nw) {
             if (ch < n_och) {
+                const cplx* src_ops = ops + static_cast<size_t>(g_ops)*(1 + A)*DD;
                 const int e = 64*ch + lane;
-                if (e < n_ops) lds_dma16(src_ops + (e < DD ? e : e + alpha0*DD), opsb + buf*kops + 64*ch);
+                if (e < n_ops) lds_dma16(src_ops + (e < DD ? e : e + alpha0*DD), opsb + obuf*kops + 64*ch);
             } else {
+                const cplx* src_tab = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g_row)*S);
                 const int e = 64*(ch - n_och) + lane;
-                if (e < S/2) lds_dma16(src_tab + e, reinterpret_cast<cplx*>(rows + buf*S) + 64*(ch - n_och));
+                if (e < S/2) lds_dma16(src_tab + e, reinterpret_cast<cplx*>(rows + rbuf*S) + 64*(ch - n_och));
             }
         }
     };
+    auto dma_stage = [&](int g, int buf) { dma_stage2(g, buf, g, buf); };
     auto generate = [&](int slot) {
         const double* st = rows + slot*S;
         const double dtg = st[0];
@@ -378,9 +391,11 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
         double sa, ca;
         sincos_pi<true>(0.5*(om*dtg), &sa, &ca);
         const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
-        for (int e = wave*4 + q; e < DD; e += 4*nw) {
+        // thread (wave, q, c): frequency c mod TW, entries (wave 4 + q) 16/TW + c/TW + 64 nw/TW k
+        constexpr int EPL = 16/TW;                  // entries per 16-lane row
+        for (int e = (wave*4 + q)*EPL + c/TW; e < DD; e += 4*nw*EPL) {
             const double* r = st + seg_rec(e);
-            tile[e*TS + c] = phased_integral_aa(pf, r[0], r[1], r[2]);
+            tile[e*TS + (c & (TW - 1))] = phased_integral_aa(pf, r[0], r[1], r[2]);
         }
     };
     // v_mfma_f64: the last builtin argument carries the NEG bits of the operands (bit 0 = A)
@@ -456,7 +471,7 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
     };
 
     auto contract_bf = [&](int buf) {
-        const cplx* opT = opsb + buf*kops;
+        const cplx* opT = opsb + (kSingleOps ? 0 : buf)*kops;
         const cplx* opB = opT + (1 + alpha_l)*DD;
         cplx tq[NS][NS];                              // T[4 s + q][4 g + c4]
 #pragma unroll
@@ -480,6 +495,8 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
                     pr[ig] = 0.0;
                     pi[ig] = 0.0;
                 }
+                // (round 6, measured and not kept: the column group's d/4 entries of X first, as one group of vector
+                // instructions, then its matrix instructions -- at two wavefronts per SIMD no difference, 5.27 ms either way)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const int e = (4*s + q)*D + 4*ng + c4;
@@ -517,14 +534,19 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
 #else
     constexpr bool kDmaStage = BF;
 #endif
+    static_assert(!kSingleOps || kDmaStage, "8-frequency tiles stage by LDS-DMA");
     if (g0 < g1) {
-        if constexpr (kDmaStage) {
+        if constexpr (kSingleOps) {
+            dma_stage2(-1, 0, g0, 0);                 // the first table row; the operands follow behind the barrier
+        } else if constexpr (kDmaStage) {
             dma_stage(g0, 0);
         } else {
             issue_stage(g0);
             park(0);
         }
     }
+    // (round 6, measured and not kept: the two blocks of a CU at different priorities -- by bit 8 of the block number
+    // 4.92 -> 5.08 ms, by bit 0 no difference)
     FFK_MC_DECL();
     for (int g = g0; g < g1; ++g) {
         const int buf = (g - g0) & 1;
@@ -535,20 +557,29 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
             [[maybe_unused]] const unsigned long long mc1 = FFK_MC_T();
             // the staging loads of segment g + 1 fly during the generation, not the contraction,
             // whose accumulators, T entries and products leave no registers for them (d = 16)
-            if (g + 1 < g1) {
+            if constexpr (kSingleOps) {
+                // this segment's operands into the ONE operand buffer (the contraction that read it ended before the
+                // barrier above): in flight during the generation
+                dma_stage2(g, 0, -1, 0);
+            } else if (g + 1 < g1) {
                 if constexpr (kDmaStage) dma_stage(g + 1, buf ^ 1);     // buffer buf ^ 1: last read before this barrier
                 else issue_stage(g + 1);
             }
             [[maybe_unused]] const unsigned long long mc1b = FFK_MC_T();
             FFK_MC_ADD(6, mc1, mc1b);        // [6] of [1]: issue of the staging loads alone
 #if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 1)   /* diagnostic build 1: no generation */
-            generate(buf);
+            generate(kSingleOps ? 0 : buf);
 #endif
             [[maybe_unused]] const unsigned long long mc2 = FFK_MC_T();
             if constexpr (!kDmaStage)
                 if (g + 1 < g1) park(buf ^ 1);   // buffer buf ^ 1: last read before this barrier interval
             [[maybe_unused]] const unsigned long long mc3 = FFK_MC_T();
+            if constexpr (kSingleOps) lds_dma_wait();
             __syncthreads();
+            // (8-frequency tiles: ONE table row too -- the next segment's, behind the barrier that ends the generation,
+            // in flight during the contraction: 76 KB of LDS per block, two blocks per CU)
+            if constexpr (kSingleOps)
+                if (g + 1 < g1) dma_stage2(-1, 0, g + 1, 0);
             [[maybe_unused]] const unsigned long long mc4 = FFK_MC_T();
 #if !(defined(FFK_M_ABLATE) && FFK_M_ABLATE == 2)   /* diagnostic build 2: no contraction */
             if (active) contract_bf(buf);
@@ -585,12 +616,12 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
             // everything in LDS is free by now), half the threads expand each.
             const int half = nthreads >> 1;
             const int hsel = tid >= half ? 1 : 0, th = tid - hsel*half;
-            const int wl = th & 15, kl = th >> 4, nk = half >> 4;
-            const int wo = blockIdx.x*16 + wl;
+            const int wl = th & (TW - 1), kl = th/TW, nk = half/TW;
+            const int wo = blockIdx.x*TW + wl;
             for (int op0 = 0; op0 < na; op0 += 2) {
                 __syncthreads();         // the tile's last readers (contraction / previous round) are done
                 if (active && (alpha_l == op0 || alpha_l == op0 + 1)) {
-                    cplx* yw = tile + (alpha_l - op0)*DD*16;
+                    cplx* yw = tile + (alpha_l - op0)*DD*TW;
 #pragma unroll
                     for (int set = 0; set < NSET; ++set) {
                         const int f = 4*(jh*NSET + set) + (c >> 2);
@@ -598,17 +629,17 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
                         for (int ig = 0; ig < NS; ++ig)
 #pragma unroll
                             for (int jg = 0; jg < NS; ++jg)
-                                yw[((4*ig + q)*D + 4*jg + c4)*16 + (f ^ (4*c4))] =
+                                yw[((4*ig + q)*D + 4*jg + c4)*TW + (f ^ ((4*c4) & (TW - 1)))] =
                                     {Yr[set*NS + ig][jg], Yi[set*NS + ig][jg]};
                     }
                 }
                 __syncthreads();
                 const int a = alpha0 + op0 + hsel;
                 if (op0 + hsel < na && a < alpha_end && wo < W) {
-                    const cplx* yl = tile + hsel*DD*16;
+                    const cplx* yl = tile + hsel*DD*TW;
                     // frequency f of entry e sits in slot f ^ 4 (e & 3) (e & 3 = the column's low bits:
                     // a 16-lane row of the stores above then hits 16 distinct bank groups)
-                    auto ysw = [&](int e) { return yl[e*16 + (wl ^ (4*(e & 3)))]; };
+                    auto ysw = [&](int e) { return yl[e*TW + (wl ^ ((4*(e & 3)) & (TW - 1)))]; };
                     // four elements per trip, their list heads requested together (the lists sit in L2:
                     // one element at a time the loop was a chain of dependent trips, count -> row -> LDS)
                     constexpr int KU = 4;
@@ -651,7 +682,7 @@ __global__ __launch_bounds__(MAXW*64) void ctrl_accumulate_mfma4_kernel(
             cplx* out = Ypart + ((static_cast<size_t>(blockIdx.z)*A + alpha)*DD)*W;
 #pragma unroll
             for (int set = 0; set < NSET; ++set) {
-                const int iws = blockIdx.x*16 + 4*(jh*NSET + set) + (c >> 2);
+                const int iws = blockIdx.x*TW + 4*(jh*NSET + set) + (c >> 2);
                 if (iws < W) {
 #pragma unroll
                     for (int ig = 0; ig < NS; ++ig)
@@ -856,22 +887,22 @@ hipError_t launch_x2(const double* omega, int W, const double* segtab, const cpl
     return hipGetLastError();
 }
 
-template <int D, int JH, bool BF = false>
+template <int D, int JH, bool BF = false, int TW = 16>
 size_t mfma4_lds_bytes(int nw) {
-    return (static_cast<size_t>(D*D)*mfma4_tile_stride(BF) + 2*static_cast<size_t>(1 + nw/JH)*D*D)*sizeof(cplx) +
-           2*static_cast<size_t>(seg_stride(D))*sizeof(double);
+    return (static_cast<size_t>(D*D)*mfma4_tile_stride(BF, TW) + (TW == 8 ? 1 : 2)*static_cast<size_t>(1 + nw/JH)*D*D)*sizeof(cplx) +
+           (TW == 8 ? 1 : 2)*static_cast<size_t>(seg_stride(D))*sizeof(double);
 }
 
-template <int D, int JH, int MAXW = 8, bool BF = false>
+template <int D, int JH, int MAXW = 8, bool BF = false, int TW = 16>
 hipError_t launch_d4(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
                      int chunks, int chunk_len, int nw, cplx* Ypart, hipStream_t stream,
                      int alpha_base = 0, int alpha_end = -1, const ExpandEpilogue* expand = nullptr) {
-    auto kern = ctrl_accumulate_mfma4_kernel<D, JH, MAXW, BF>;
+    auto kern = ctrl_accumulate_mfma4_kernel<D, JH, MAXW, BF, TW>;
     if (nw > MAXW) return hipErrorInvalidValue;
-    const int lds = static_cast<int>(mfma4_lds_bytes<D, JH, BF>(nw));
+    const int lds = static_cast<int>(mfma4_lds_bytes<D, JH, BF, TW>(nw));
     // staging: (1 + na) d^2 + row/2 elements over nw*64 threads must fit kMaxStage per thread
     constexpr int kMaxStage = D == 16 ? (MAXW < 8 ? 8 : 4) : 8;
-    if (nw % JH != 0 || (1 + nw/JH)*D*D + seg_stride(D)/2 > kMaxStage*nw*64) return hipErrorInvalidValue;
+    if (nw % JH != 0 || (TW == 16 && (1 + nw/JH)*D*D + seg_stride(D)/2 > kMaxStage*nw*64)) return hipErrorInvalidValue;
     if (lds > 48*1024) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -880,19 +911,25 @@ hipError_t launch_d4(const double* omega, int W, const double* segtab, const cpl
     const int na = nw/JH;
     // operators [alpha_base, alpha_end) of the A the arrays are laid out for
     if (alpha_end < 0) alpha_end = A;
-    const dim3 grid((W + 15)/16, (alpha_end - alpha_base + na - 1)/na, chunks);
+    const dim3 grid((W + TW - 1)/TW, (alpha_end - alpha_base + na - 1)/na, chunks);
     ExpandEpilogue ep = {};
     int lds_launch = lds;
     if (expand && BF) {
         ep = *expand;
         // the epilogue lays two operators' Y side by side: 2 d^2 x 16 complex numbers
-        const int need = static_cast<int>(2*static_cast<size_t>(D)*D*16*sizeof(cplx));
+        const int need = static_cast<int>(2*static_cast<size_t>(D)*D*TW*sizeof(cplx));
         if (need > lds_launch) {
             lds_launch = need;
             hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_launch);
             if (err != hipSuccess) return err;
         }
+    }
+    if (std::getenv("FFK_DEBUG_OCCUPANCY")) {      // (the 8-frequency form is built on TWO blocks per CU: a table row more did not fit)
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), nw*64, lds_launch);
+        fprintf(stderr, "mfma4<D=%d, JH=%d, TW=%d>: %d threads, %d bytes of LDS -> %d blocks per CU\n", D, JH, TW, nw*64,
+                lds_launch, nb);
     }
     hipLaunchKernelGGL(kern, grid, dim3(nw*64), lds_launch, stream, omega, W, segtab, ops, G, A, chunk_len,
                        nw, Ypart, alpha_base, alpha_end, ep);
@@ -924,6 +961,17 @@ hipError_t launch_d(const double* omega, int W, const double* segtab, const cplx
 // lost its A/B there, profiles/r03_l_*); with it JH counts the wavefronts that share an operator's
 // 16 frequencies.
 static bool mfma_block_frequency(int d) { return (d == 12 || d == 16) && FFK_MFMA_BF_DEFAULT; }
+// round 6: the main launch of d = 12, 16 on 8-frequency tiles, four wavefronts per block, two blocks per CU
+// (FFK_MFMA_TILE16: rounds 3-5's 16-frequency tiles, eight wavefronts per block, for A/B builds)
+// Measured (profiles/r06_f_*): d = 16, 16 operators, 13 segments, 16384 omega 4.69 -> 4.39 ms without and 3.92 -> 3.83 ms
+// with the expansion epilogue; d = 12 (64 segments, 6 operators, 8192 omega) 1.72 -> 1.74 ms: d = 16 only.
+static bool mfma_tile8(int d) {
+#if defined(FFK_MFMA_TILE16)
+    return false;
+#else
+    return d == 16;
+#endif
+}
 
 static int mfma_column_split(int d) {
     if (mfma_block_frequency(d)) return 2;
@@ -1023,8 +1071,9 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
 #define FFK_BF_SPLIT(D) \
     if (d == D) { \
         if (main_ops > base) { \
-            const hipError_t err = launch_d4<D, 2, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, 8, \
-                                                            Ypart, stream, base, main_ops, ep); \
+            const hipError_t err = mfma_tile8(D) \
+                ? launch_d4<D, 1, 4, true, 8>(omega, W, segtab, ops, G, A, chunks, chunk_len, 4, Ypart, stream, base, main_ops, ep) \
+                : launch_d4<D, 2, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, 8, Ypart, stream, base, main_ops, ep); \
             if (err != hipSuccess || main_ops == A) return err; \
         } \
         return launch_d4<D, 4, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, 8, Ypart, stream, \
@@ -1033,6 +1082,10 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
             FFK_BF_SPLIT(12) FFK_BF_SPLIT(16)
 #undef FFK_BF_SPLIT
         }
+    if (jh == 2 && nw == 8 && mfma_tile8(d)) {
+        if (d == 12) return launch_d4<12, 1, 4, true, 8>(omega, W, segtab, ops, G, A, chunks, chunk_len, 4, Ypart, stream, 0, -1, ep);
+        if (d == 16) return launch_d4<16, 1, 4, true, 8>(omega, W, segtab, ops, G, A, chunks, chunk_len, 4, Ypart, stream, 0, -1, ep);
+    }
 #define FFK_BF(D, JH) \
     if (d == D && jh == JH) \
         return launch_d4<D, JH, 8, true>(omega, W, segtab, ops, G, A, chunks, chunk_len, nw, Ypart, stream, 0, -1, ep);
