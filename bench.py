@@ -1117,33 +1117,6 @@ def main():
                     gather_ab['push_error_word'] = int(ring_b.peer.error.cpu().item())
         except RuntimeError as err:
             gather_ab = {'headline': ring.gather, other: f'failed: {err}'}
-    # (tuning builds of the d = 4 kernel only: the per-wavefront records of the timed region's last launches,
-    # tools/trace_pq.py waves <file>)
-    if os.environ.get('FFK_BENCH_DUMP_PQ_WAVES') and rank == 0:
-        import ctypes
-        from filter_functions_amd import _lib as _ffk_lib
-        raw = ctypes.CDLL(_ffk_lib.LIB_PATH)
-        if hasattr(raw, 'ffk_debug_pq_waves'):
-            torch.cuda.synchronize(device)
-            t_dbg = time.perf_counter()
-            for _ in range(400):                 # (the region's last launches were the instrumented, gated ones)
-                step()
-            torch.cuda.synchronize(device)
-            print(f'debug: 400 more steps at {(time.perf_counter() - t_dbg)/400*1e6:.2f} us each', file=sys.stderr)
-            words = (ctypes.c_ulonglong*(4*65536))()
-            head = ctypes.c_uint(0)
-            if raw.ffk_debug_pq_waves(words, ctypes.byref(head)) == 0:
-                np.save(os.environ['FFK_BENCH_DUMP_PQ_WAVES'], np.array(words, dtype=np.uint64).reshape(-1, 4))
-            if hasattr(raw, 'ffk_debug_pq_trace'):
-                n_tr = raw.ffk_debug_pq_trace_words()
-                tr = (ctypes.c_ulonglong*n_tr)()
-                if raw.ffk_debug_pq_trace(tr) == 0:
-                    tr = np.array(tr, dtype=np.uint64).reshape(16, -1).astype(np.int64)
-                    ghz = [(tr[w, 5] - tr[w, 0])/((tr[w, 6] - tr[w, 1])*10.0) for w in range(4, 12) if tr[w, 6] > tr[w, 1]]
-                    if ghz:
-                        print(f'debug: clock over the consumers\' lifetime in block 0 of the last launch: '
-                              f'{min(ghz):.3f} .. {max(ghz):.3f} GHz, loop {(tr[4, 3] - tr[4, 2])/max(1, tr[4, 4]):.0f} cycles per tile',
-                              file=sys.stderr)
     # latency of one pass on its own (one stream, nothing else in flight), for reference
     latency_ms = None
     if not use_dist:
@@ -1241,7 +1214,7 @@ def main():
                          ('torch.distributed.run' if 'RANK' in os.environ else 'direct')),
             'prewarm': prewarm,
             'roofline': {
-                'kernel': 'ffk::ctrl_accumulate_pq_kernel<3>', 'bound': 'mfma',
+                'kernel': 'ffk::ctrl_accumulate_pq_kernel<3, true>', 'bound': 'mfma',
                 'bound_detail': 'FP64 issue: vector FMA and 4x4x4 matrix instructions share one pipe and one peak',
                 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved/FP64_PEAK_TFLOPS, 'frac_step': step_tflops/FP64_PEAK_TFLOPS,

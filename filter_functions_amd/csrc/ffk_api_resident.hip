@@ -2,6 +2,8 @@
 // ff.infidelity call with one H2D, one pass of ffk_pipeline_dev and one D2H of the small results
 // (R stays in HBM), concatenations that read resident control matrices in place, hipGraph replay
 // of repeated passes; and the host-logic self test of the sanitizer build.
+#include <thread>
+
 #include "ffk_api_common.h"
 
 
@@ -744,6 +746,27 @@ extern "C" int ffk_selftest_host(int rounds, unsigned seed, char* report, int re
             std::lock_guard<std::mutex> lock(g_arena.mu);
             if (arena_reserve(want, &base) != FFK_OK) return -1;
             touch(base, g_arena.size);
+        }
+        // (a') the kernels' fault words: one per host thread -- a word set for this thread is seen (and cleared) by this
+        // thread's check and by no other thread's; the word the launchers would hand their kernels is this thread's
+        if (r == 0) {
+            int* mine = ffk::kernel_fault_word();
+            if (mine == nullptr) return -20;
+            if (kernel_fault_peek(false) != 0) return -21;
+            *static_cast<volatile int*>(mine) = ffk::kernel_fault_code_for_selftest();
+            int other_saw = -1, other_slot = -1;
+            int* others = nullptr;
+            std::thread peer([&] {
+                others = ffk::kernel_fault_word();
+                other_slot = kernel_fault_slot_for_selftest();
+                other_saw = kernel_fault_peek(true);          // must not see (or clear) this thread's fault
+            });
+            peer.join();
+            if (others == nullptr || others == mine || other_slot == kernel_fault_slot_for_selftest()) return -22;
+            if (other_saw != 0) return -23;
+            if (kernel_fault_stale() != FFK_EKERNEL) return -24;      // reported to the thread that owns it, once
+            if (kernel_fault_peek(false) != 0 || kernel_fault_status() != FFK_OK) return -25;
+            if (ffk::kernel_fault_word() != mine) return -26;          // a thread keeps its word
         }
         // (b) control-matrix workspace: the slices of ffk_control_matrix_dev
         {

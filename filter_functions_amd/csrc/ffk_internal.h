@@ -202,6 +202,7 @@ hipError_t launch_accumulate_mfma(const double* omega, int W, const double* segt
 // thread reads only the faults of launches it enqueued itself.  NULL only if the runtime refused the allocation.
 int* kernel_fault_word();
 constexpr int kFaultPcProducerWait = 1, kFaultPcConsumerWait = 2;
+inline int kernel_fault_code_for_selftest() { return kFaultPcConsumerWait; }
 
 // ---- ctrl_pq.hip (d = 4, second product on the matrix cores) -------------------------------------
 int pq_accumulate_lds_bytes(int nc);
