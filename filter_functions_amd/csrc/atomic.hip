@@ -227,8 +227,8 @@ __global__ __launch_bounds__(1024) void from_atomic_block_kernel(
 #pragma unroll
     for (int e = 0; e < ROWS; ++e) acc[e] = {0.0, 0.0};
     constexpr int LN = N*N*(LCPLX ? 2 : 1);
-    if (Lpulse != nullptr) {
-        // Round 6: the slab by a BACKWARD recurrence on the DISTINCT pulses' own propagators.  With v_g the control
+    if (!LCPLX && Lpulse != nullptr) {
+        // Round 6 (Hermitian bases): the slab by a BACKWARD recurrence on the DISTINCT pulses' own propagators.  With v_g the control
         // matrix of the pulse at position g, p_g its total phase, L_g the Liouville representation of its propagator
         // and P_g, M_g the products of the phases / representations of the positions before g,
         //     sum_{g in slab} P_g v_g M_g = P_{g0} S_{g0} M_{g0},     S_g = v_g + p_g (S_{g+1} L_g),   S_{g1} = 0:

@@ -978,7 +978,12 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         }
         // fold a factor kGsplit of the split into the block (same number of waves in flight,
         // kGsplit x fewer partial sums) when the block stays within 16 waves and the LDS
-        if (g_use_gsplit && d <= kGsplitMaxD && nw <= kGsplitMaxNW && geo.nbuf == 2 &&
+        // (round 6, measured with the first bench entries of d = 2, 3 -- profiles/r06_g_*: at d = 3 with 64 or more
+        // frequency tiles the unfolded grid is faster, 256 segments x 3 operators x 4096 omega 92.7 -> 68.0 us, the
+        // pass 132 -> 119 us; at 16 tiles the extra partial sums cost the pass 11 %; at d = 2 the kernel gains 9 % and
+        // the pass loses 4 %: folded as before)
+        const bool unfolded_is_faster = d == 3 && tiles >= 64;
+        if (g_use_gsplit && d <= kGsplitMaxD && nw <= kGsplitMaxNW && geo.nbuf == 2 && !unfolded_is_faster &&
             chunks >= kGsplit && chunks % kGsplit == 0 &&
             static_cast<size_t>(kGsplit)*geo.lds_bytes <= 160*1024) {
             geo.gsplit = kGsplit;

@@ -204,8 +204,11 @@ int sequence_on_device(const double* dU, const double* dP, const double* dR, con
     FFK_REQUIRE(watom && (!nF || dF), "workspace too small");
     // the T distinct pulses' own Liouville representations, for the rule kernel's backward recurrence (the fused front
     // launch writes them; T <= G)
-    double* dLp = (dTau && T <= G && ffk::sequence_front_supported(d, G, N))
-                      ? a.take<double>((l_is_complex ? 2 : 1)*size_t(T)*N*N) : nullptr;
+    // (Hermitian bases only: the recurrence composes representations, L(U Q) = L(U) L(Q), which holds where
+    // tr(X C_k) are X's expansion coefficients -- an orthonormal HERMITIAN basis; a non-Hermitian one keeps the walk
+    // along the cumulative propagators: tests/test_gpu_parity.py::test_block_rule_kernel_with_a_non_hermitian_basis)
+    double* dLp = (dTau && T <= G && !l_is_complex && ffk::sequence_front_supported(d, G, N))
+                      ? a.take<double>(size_t(T)*N*N) : nullptr;
     if (resident_R) dO = resident_R;          // results that stay in a handle's device block
     if (resident_F) dF = resident_F;
     if (dTau && ffk::sequence_front_supported(d, G, N)) {

@@ -485,11 +485,15 @@ int ffk_eigensolver_status_dev(const void* workspace, size_t workspace_bytes, in
 
 /* Fault word of the kernels whose wavefronts hand tiles to one another through flags in LDS (the d = 4
  * accumulation behind ffk_control_matrix*, ffk_pipeline_dev and the resident passes; reference loop
- * numeric.py:846-869).  Their waits are bounded; a wait that runs out stores a non-zero code in one
- * process-wide word of mapped host memory and the launch's results are invalid.  The host-pointer
- * entry points read the word after their own synchronisation and return FFK_EKERNEL; callers of the
- * `_dev` flavour (also through a captured graph) call this AFTER synchronising the stream: *word = 0
- * means every launch since the last clearing was sound.  Sticky until read with clear != 0.        */
+ * numeric.py:846-869).  Their waits are bounded; a wait that runs out stores a non-zero code in a word of mapped
+ * host memory that the launcher hands the kernel as an ARGUMENT (so it is right on whichever device the launch goes
+ * to), and the launch's results are invalid.  ONE WORD PER HOST THREAD: a thread sees the faults of the launches it
+ * enqueued itself, and only those (a captured graph reports to the thread that captured it).  The host-pointer
+ * entry points read the calling thread's word after their own synchronisation and return FFK_EKERNEL; a fault that
+ * an EARLIER, never checked asynchronous launch of the thread left behind is reported by them on entry, as such,
+ * before anything runs.  Callers of the `_dev` flavour call this AFTER synchronising the stream, on the thread that
+ * enqueued: *word = 0 means every launch of this thread since the last clearing was sound.  Sticky until read with
+ * clear != 0.                                                                                                    */
 int ffk_kernel_fault_status(int32_t* word, int clear);
 
 /* ---- resident evaluation: the user-facing call PulseSequence.get_filter_function(omega)
