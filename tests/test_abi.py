@@ -70,14 +70,16 @@ def test_product_never_imports_the_oracle():
                 assert 'ff_oracle' not in src and 'oracle/' not in src, f
 
 
-def test_generated_consumer_is_current():
-    """The d = 4 accumulate kernel's consumer loop (filter_functions_amd/csrc/ctrl_pq_consumer.inc, inline assembly
-    per operator count) is generated: the committed file must be what tools/gen_pq_consumer.py prints (VERDICT r5
-    item 7)."""
+@pytest.mark.parametrize('generator, committed', [('gen_pq_consumer.py', 'ctrl_pq_consumer.inc'),
+                                                  ('gen_pcr_consumer.py', 'ctrl_pcr_consumer.inc')])
+def test_generated_consumers_are_current(generator, committed):
+    """The d = 4 and d = 8 accumulate kernels' consumer loops (filter_functions_amd/csrc/ctrl_p*_consumer.inc, inline
+    assembly) are generated: each committed file must be what its generator under tools/ prints."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'gen_pq_consumer.py')], capture_output=True,
-                         text=True, check=True).stdout
-    with open(os.path.join(root, 'filter_functions_amd', 'csrc', 'ctrl_pq_consumer.inc')) as fh:
+    env = {k: v for k, v in os.environ.items() if not k.startswith('GEN_PCR_')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', generator)], capture_output=True,
+                         text=True, check=True, env=env).stdout
+    with open(os.path.join(root, 'filter_functions_amd', 'csrc', committed)) as fh:
         assert fh.read() == out

@@ -4,7 +4,7 @@ NC = 1, 2, 3, with an explicit instruction order and exact s_waitcnt counts.
 
     python tools/gen_pq_consumer.py > filter_functions_amd/csrc/ctrl_pq_consumer.inc
 
-(tests/test_host_logic.py::test_generated_consumer_is_current asserts that the committed file is what this
+(tests/test_abi.py::test_generated_consumers_are_current asserts that the committed file is what this
 script prints.)
 
 Why generated assembly (profiles/r05_b_*, r05_l_*, r05_m_*): a tile is 8 NC + 13 (+ 3 NC adds) vector and 6 NC
