@@ -417,8 +417,7 @@ def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
         with torch.cuda.stream(torch_stream):
             gamma = pipe.decay_amplitudes(stream=stream)
             K = pipe.cumulant_function(gamma, stream=stream)
-            K_total = K.sum(dim=0).cpu().numpy()
-        result['U'] = ff.error_transfer_matrix(cumulant_function=K_total[None])
+            result['U'] = pipe.error_transfer_matrix(K, stream=stream).cpu().numpy()
     ms, kernel_ms = time_pipeline(pipe, torch, lib, _lib, stream, reps=10, extra=etm)
     st = _lib.stats()
     E = len(qft.dt)*W*A*qft.d**2

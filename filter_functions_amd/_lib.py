@@ -188,6 +188,8 @@ SIGNATURES = {
                                                          c_void_p, c_void_p, c_void_p, c_size_t,
                                                          c_void_p]),
     'ffk_expm_real': (c_int, [c_void_p, c_int, c_void_p]),
+    'ffk_error_transfer_matrix_workspace_bytes': (c_size_t, [c_int]),
+    'ffk_error_transfer_matrix_dev': (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     'ffk_liouville': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     'ffk_liouville_workspace_bytes': (c_size_t, [c_int, c_int, c_int]),
     'ffk_liouville_dev': (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p,

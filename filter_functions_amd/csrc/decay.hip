@@ -23,6 +23,7 @@
 #include <utility>
 
 #include "ffk_internal.h"
+#include "ffk_mfma_util.h"
 
 namespace ffk {
 namespace {
@@ -31,14 +32,19 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 // scale[row][w] = trapezoid weight(w_offset + w) * S_row(w) / (2 pi); the weights are those of the
 // GLOBAL grid omega (Wg,), of which this call integrates the block [w_offset, w_offset + W)
+// (rows of `scale` are `stride` >= W apart; the entries from W up to the stride are zero)
 __global__ __launch_bounds__(256) void spectral_weights_kernel(const cplx* __restrict__ S, int rows,
                                                                int W,
                                                                const double* __restrict__ omega,
                                                                int Wg, int w_offset,
-                                                               cplx* __restrict__ scale,
+                                                               cplx* __restrict__ scale, int stride,
                                                                int* __restrict__ complex_weights) {
     const int w = blockIdx.x*256 + threadIdx.x;
-    if (w >= W) return;
+    if (w >= W) {
+        if (w < stride)
+            for (int r = blockIdx.y; r < rows; r += gridDim.y) scale[static_cast<size_t>(r)*stride + w] = {0.0, 0.0};
+        return;
+    }
     const int gw = w_offset + w;
     const double lo = gw > 0 ? omega[gw] - omega[gw - 1] : 0.0;
     const double hi = gw < Wg - 1 ? omega[gw + 1] - omega[gw] : 0.0;
@@ -46,7 +52,7 @@ __global__ __launch_bounds__(256) void spectral_weights_kernel(const cplx* __res
     bool any_imag = false;
     for (int r = blockIdx.y; r < rows; r += gridDim.y) {
         const cplx s = S[static_cast<size_t>(r)*W + w];
-        scale[static_cast<size_t>(r)*W + w] = {s.re*wgt, s.im*wgt};
+        scale[static_cast<size_t>(r)*stride + w] = {s.re*wgt, s.im*wgt};
         any_imag |= s.im != 0.0;
     }
     if (complex_weights && any_imag) atomicOr(complex_weights, 1);
@@ -97,7 +103,10 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
     const cplx* __restrict__ R, int Gp, int A, int N, int W, const cplx* __restrict__ scale,
     int s_ndim, const int32_t* __restrict__ idx, int n_idx, int kchunk, int tiles_m, int tiles_n,
     double* __restrict__ out, size_t split_stride, int mirror_in_store,
-    const int* __restrict__ complex_weights, int tri) {
+    const int* __restrict__ complex_weights, int tri, int scale_stride, int only_complex_weights) {
+    // only_complex_weights: the symmetric case is served by decay_gemm_sym256_kernel; this launch works only when the
+    // weights turned out complex (every block of the launch alike)
+    if (only_complex_weights && *complex_weights == 0) return;
     const int lane = threadIdx.x;
     const int l15 = lane & 15, lk = lane >> 4;
     // tri: which tiles of a Gamma block the grid enumerates -- 0 all tiles_m x tiles_n, 1 those on
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
     const int tjg = (tj*TN)/TM;              // row-granule index of this tile's columns
     if (symmetric && ti > tjg) return;
     const int srow = s_ndim == 1 ? 0 : (s_ndim == 2 ? ia : ia*n_idx + ib);
-    const cplx* sp = scale + static_cast<size_t>(srow)*W;
+    const cplx* sp = scale + static_cast<size_t>(srow)*scale_stride;
     const cplx* Lp[TM];
     const cplx* Rp[TN];
 #pragma unroll
@@ -226,6 +235,130 @@ __global__ __launch_bounds__(64) void decay_gemm_kernel(
 // (Round 3's LDS-staged 128 x 128 variant of this product -- half the operand traffic, but 1.20 ms
 // against 1.07 ms at config 5 -- was removed in round 4; the A/B is profiles/r03_e_*, r03_m_*.)
 
+// ---- Round 6: one pulse with itself, N = 256 (d = 16, full basis), real weights: a workgroup per (operator,
+// frequency chunk) computes the whole symmetric 256 x 256 block from ONE copy of the operator's rows in LDS.
+//   * Both operands of Gamma_aa = R_a diag(s) R_a^T are the same 256 rows: per step of 16 frequencies the block
+//     brings 256 x 16 complex (64 KB) + the 16 weights into LDS by global_load_lds_dwordx4 (no register, no ds_write:
+//     the ds_write_b128 of round 3's LDS-staged variant cost a wavefront 35-45 issue cycles each, tools/
+//     lds_issue_probe.py) -- 1.2 GB per call at config 5 instead of the 6.0 GB the register-fed kernel pulls through
+//     L2 -- double-buffered, one barrier per step.
+//   * Ten 64 x 64 tiles lie on or above the diagonal; eight wavefronts (two per SIMD, 256 registers) own one each
+//     and split the other two into 16 x 64 strips, one per wavefront: 20 products per wavefront and frequency quad,
+//     the same on every SIMD (ten wavefronts of one tile each would load the SIMDs 3, 3, 2, 2).
+//   * LDS image: row r holds its 16 frequencies as 16-byte slots, frequency j in slot j ^ (r & 15) -- the copy
+//     chooses which frequency a lane fetches, the destination of a lane is fixed --, so that the 16 lanes of a
+//     matrix-instruction operand (16 consecutive rows, one frequency) read 16 different slots.
+// The partial sums go to the split-K planes the reduction kernel (with its mirror of the lower tiles) already reads.
+constexpr int kSymN = 256;
+constexpr int kSymStep = 16;
+constexpr int kSymTile = (kSymN + 1)*kSymStep;                      // complex entries: 256 rows + the weights
+constexpr size_t kSymLdsBytes = 2*sizeof(cplx)*kSymTile;           // 131,584 B
+
+__global__ __launch_bounds__(512) void decay_gemm_sym256_kernel(
+    const cplx* __restrict__ R, int W, const cplx* __restrict__ scale, int scale_stride, int s_ndim,
+    const int32_t* __restrict__ idx, double* __restrict__ out, size_t split_stride,
+    const int* __restrict__ complex_weights) {
+    if (*complex_weights != 0) return;                 // (every block alike: the general kernel serves this call)
+    extern __shared__ __attribute__((aligned(16))) unsigned char sym_lds[];
+    cplx* const tiles = reinterpret_cast<cplx*>(sym_lds);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lk = lane >> 4;
+    const int ia = blockIdx.x, split = blockIdx.y;
+    const cplx* sp = scale + static_cast<size_t>(s_ndim == 1 ? 0 : ia)*scale_stride;
+    const cplx* Ra = R + static_cast<size_t>(idx[ia])*kSymN*W;
+    // this workgroup's share of the ceil(W / 16) steps: as even as whole steps allow (the chunk length the general
+    // kernel is given would leave the last workgroup of an operator 992 of 1184 frequencies at config 5 -- the planes
+    // are summed, their boundaries need not agree between the two kernels)
+    const int all_steps = (W + kSymStep - 1)/kSymStep, nsplit = gridDim.y;
+    const int first_step = static_cast<int>(static_cast<long>(all_steps)*split/nsplit);
+    const int steps = static_cast<int>(static_cast<long>(all_steps)*(split + 1)/nsplit) - first_step;
+    const int wbeg = first_step*kSymStep;
+
+    // the copy: wavefront `wave` brings rows 32 wave .. + 31, four rows per instruction (lane -> row 4 q + lk, slot
+    // l15, i.e. frequency l15 ^ (row & 15)); wavefront 0 also the weights (16 lanes)
+    const int row0 = 32*wave + lk;
+    const cplx* src_row = Ra + static_cast<size_t>(row0)*W;
+    auto copy_step = [&](int step, int buf) {
+        cplx* T = tiles + buf*kSymTile;
+        const int w0 = wbeg + step*kSymStep;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int w = min(w0 + (l15 ^ ((4*q + lk) & 15)), W - 1);       // (beyond W: the weight is zero)
+            lds_dma16(src_row + static_cast<size_t>(4*q)*W + w, T + (32*wave + 4*q)*kSymStep);
+        }
+        if (wave == 0 && lane < 16) lds_dma16(sp + w0 + lane, T + kSymN*kSymStep);
+    };
+
+    // tiles on and above the diagonal, row-major: wavefront j owns the j-th of the first eight; (2,3) goes in strips
+    // to wavefronts 0..3, (3,3) to wavefronts 4..7
+    const int ti = wave < 4 ? 0 : (wave < 7 ? 1 : 2);
+    const int tj = wave < 4 ? wave : (wave < 7 ? wave - 3 : 2);
+    const int strip_row = (wave < 4 ? 2 : 3)*64 + (wave & 3)*16;
+    f64x4 acc[4][4], strip[4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) strip[tn] = {0.0, 0.0, 0.0, 0.0};
+
+    FFK_DG_CLOCK_BEGIN
+    copy_step(0, 0);
+    for (int step = 0; step < steps; ++step) {
+        lds_dma_wait();
+        __syncthreads();                 // this step's tile has landed; everybody is done with the other buffer
+        if (step + 1 < steps) copy_step(step + 1, (step + 1) & 1);
+        const cplx* T = tiles + (step & 1)*kSymTile;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int slot = (4*lk + c) ^ l15;
+            const double s = T[kSymN*kSymStep + 4*lk + c].re;
+            cplx a[4], b[4], x[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[t] = T[(ti*64 + t*16 + l15)*kSymStep + slot];
+                const cplx y = T[(tj*64 + t*16 + l15)*kSymStep + slot];
+                b[t] = {s*y.re, s*y.im};
+            }
+            const cplx as = T[(strip_row + l15)*kSymStep + slot];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const cplx y = T[(3*64 + t*16 + l15)*kSymStep + slot];
+                x[t] = {s*y.re, s*y.im};
+            }
+            // real parts of all tiles, then imaginary parts: consecutive instructions never share an accumulator
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].re, b[tn].re, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) strip[tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(as.re, x[tn].re, strip[tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tm].im, b[tn].im, acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) strip[tn] = __builtin_amdgcn_mfma_f64_16x16x4f64(as.im, x[tn].im, strip[tn], 0, 0, 0);
+        }
+    }
+    FFK_DG_CLOCK_END
+    double* o = out + static_cast<size_t>(split)*split_stride + static_cast<size_t>(ia)*kSymN*kSymN;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[static_cast<size_t>(ti*64 + tm*16 + lk + 4*r)*kSymN + tj*64 + tn*16 + l15] = acc[tm][tn][r];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            o[static_cast<size_t>(strip_row + lk + 4*r)*kSymN + 3*64 + tn*16 + l15] = strip[tn][r];
+}
+
 // out[i] = sum_s part[s][i], fixed order.  tile > 0: batches of a pulse with itself (g == h in the
 // batch index (g*Gp + h)*n_idx + a) are symmetric matrices of which only the tiles (of `tile`
 // rows/columns) on or above the diagonal were computed; the rest is read transposed.
@@ -236,22 +369,29 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const double* __rest
                                                             double* __restrict__ out) {
     const size_t i = static_cast<size_t>(blockIdx.x)*256 + threadIdx.x;
     if (i >= n) return;
-    size_t src = i;
+    // (round 6: the entry above the diagonal is summed once, read along rows, and stored twice; before, the thread of
+    // the entry below summed the planes again, reading them down a column -- 8 bytes per 2-KiB line, nsplit times)
+    size_t twin = i;
     if (tile > 0 && *complex_weights == 0) {
         const size_t b = i / (static_cast<size_t>(N)*N);
         const int row = static_cast<int>((i / N) % N), col = static_cast<int>(i % N);
         const size_t gh = b / n_idx;
-        if (gh / Gp == gh % Gp && row / tile > col / tile) src = (b*N + col)*N + row;
+        if (gh / Gp == gh % Gp) {
+            if (row / tile > col / tile) return;
+            if (row / tile < col / tile) twin = (b*N + col)*N + row;
+        }
     }
-    double acc = part[src];
-    for (int s = 1; s < nsplit; ++s) acc += part[static_cast<size_t>(s)*n + src];
+    double acc = part[i];
+    for (int s = 1; s < nsplit; ++s) acc += part[static_cast<size_t>(s)*n + i];
     out[i] = acc;
+    if (twin != i) out[twin] = acc;
 }
 
 struct DecayPlan {
     int tm, tn, tiles_m, tiles_n, ksplit, kchunk;
     size_t batch;
     bool tri;       // register-fed kernel: one grid for the tiles on and above the diagonal, one for the rest
+    bool sym256;    // decay_gemm_sym256_kernel serves the call when the weights are real
 };
 
 DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
@@ -291,6 +431,21 @@ DecayPlan decay_plan(int Gp, int N, int W, int n_idx, int s_ndim) {
     }
     p.kchunk = static_cast<int>(((W + want - 1)/want + 15)/16*16);
     p.ksplit = (W + p.kchunk - 1)/p.kchunk;
+    // One pulse with itself at N = 256: a workgroup per (operator, chunk), one workgroup per CU -- as many chunks as
+    // fill the chip once (config 5: 18 operators x 14 = 252 workgroups), at least 128 frequencies each, at least two
+    // (the lower tiles are mirrored by the reduction over the chunks).  Below a chip's worth of such chunks the
+    // register-fed kernel, whose unit is a wavefront and 64 frequencies, spreads the work better (3 operators x 1030
+    // frequencies: 0.19 ms here).
+    const long cus = device_cu_count();
+    p.sym256 = p.tri && N == kSymN && p.batch <= 65535 && static_cast<long>(p.batch)*(W/128) >= cus &&
+               std::getenv("FFK_DECAY_REGISTER_FED") == nullptr;
+    if (p.sym256) {
+        long want_split = std::max<long>(2, cus/static_cast<long>(p.batch));
+        want_split = std::min<long>(want_split, std::max(2, W/128));
+        p.kchunk = static_cast<int>(((W + want_split - 1)/want_split + 15)/16*16);
+        p.ksplit = (W + p.kchunk - 1)/p.kchunk;
+        p.sym256 = p.ksplit >= 2;
+    }
     return p;
 }
 
@@ -513,14 +668,17 @@ __global__ __launch_bounds__(64) void cumulant_single_qubit_kernel(const double*
 hipError_t launch_spectral_weights(const cplx* S, int rows, int W, const double* omega, int Wg,
                                    int w_offset, cplx* scale, hipStream_t stream) {
     hipLaunchKernelGGL(spectral_weights_kernel, dim3((W + 255)/256, min(rows, 1024)), dim3(256), 0,
-                       stream, S, rows, W, omega, Wg, w_offset, scale, nullptr);
+                       stream, S, rows, W, omega, Wg, w_offset, scale, W, nullptr);
     return hipGetLastError();
 }
+
+// rows of the weights are padded with zeros to whole steps of 16 frequencies
+static size_t scale_row_stride(int W) { return (static_cast<size_t>(W) + 15)/16*16; }
 
 size_t decay_amplitudes_workspace_bytes(int Gp, int N, int W, int n_idx, int s_ndim) {
     const DecayPlan p = decay_plan(Gp, N, W, n_idx, s_ndim);
     const size_t rows = s_ndim == 1 ? 1 : (s_ndim == 2 ? n_idx : static_cast<size_t>(n_idx)*n_idx);
-    size_t bytes = align_up(sizeof(int)) + align_up(rows*W*sizeof(cplx));   // flag, scale
+    size_t bytes = align_up(sizeof(int)) + align_up(rows*scale_row_stride(W)*sizeof(cplx));   // flag, scale
     if (p.ksplit > 1) bytes += align_up(static_cast<size_t>(p.ksplit)*p.batch*N*N*sizeof(double));
     return bytes;
 }
@@ -537,17 +695,26 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
     int* complex_weights = reinterpret_cast<int*>(base);
     base += align_up(sizeof(int));
     cplx* scale = reinterpret_cast<cplx*>(base);
-    double* part = reinterpret_cast<double*>(base + align_up(static_cast<size_t>(rows)*W*sizeof(cplx)));
+    const int stride = static_cast<int>(scale_row_stride(W));
+    double* part = reinterpret_cast<double*>(base + align_up(static_cast<size_t>(rows)*stride*sizeof(cplx)));
     hipError_t merr = hipMemsetAsync(complex_weights, 0, sizeof(int), stream);
     if (merr != hipSuccess) return merr;
-    hipLaunchKernelGGL(spectral_weights_kernel, dim3((W + 255)/256, min(rows, 1024)), dim3(256), 0,
-                       stream, S, rows, W, omega, Wg, w_offset, scale, s_ndim != 3 ? complex_weights : nullptr);
+    hipLaunchKernelGGL(spectral_weights_kernel, dim3((stride + 255)/256, min(rows, 1024)), dim3(256), 0,
+                       stream, S, rows, W, omega, Wg, w_offset, scale, stride,
+                       s_ndim != 3 ? complex_weights : nullptr);
     const size_t n = p.batch*N*N;
     const size_t blocks = p.batch*p.tiles_m*p.tiles_n;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     double* dst = p.ksplit > 1 ? part : gamma;
     const int mirror = p.ksplit > 1 ? 0 : 1;    // with split-K the reduction fills the lower tiles
-    const dim3 grid(static_cast<unsigned>(blocks), p.ksplit);
+    if (p.sym256) {
+        hipError_t aerr = hipFuncSetAttribute(reinterpret_cast<const void*>(decay_gemm_sym256_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              static_cast<int>(kSymLdsBytes));
+        if (aerr != hipSuccess) return aerr;
+        hipLaunchKernelGGL(decay_gemm_sym256_kernel, dim3(static_cast<unsigned>(p.batch), p.ksplit), dim3(512),
+                           kSymLdsBytes, stream, R, W, scale, stride, s_ndim, idx, dst, n, complex_weights);
+    }
     {
         // p.tri: the tiles on and above the diagonal, then (if there are any) those below it, whose
         // blocks all return at once when the weights are real
@@ -558,7 +725,8 @@ hipError_t launch_decay_amplitudes(const cplx* R, int Gp, int A, int N, int W, c
             const dim3 g(static_cast<unsigned>(nblk), p.ksplit);
 #define FFK_DG_LAUNCH(TM, TN) \
     hipLaunchKernelGGL((decay_gemm_kernel<TM, TN>), g, dim3(64), 0, stream, R, Gp, A, N, W, scale, s_ndim, \
-                       idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror, complex_weights, tri)
+                       idx, n_idx, p.kchunk, p.tiles_m, p.tiles_n, dst, n, mirror, complex_weights, tri, stride, \
+                       p.sym256 ? 1 : 0)
             if (p.tm == 1)
                 FFK_DG_LAUNCH(1, 1);
             else if (p.tm == 2)
@@ -788,7 +956,7 @@ hipError_t launch_cumulant_function(const double* gamma, size_t batch, int N, in
 
 
 // ---- matrix exponential of a real N x N matrix (error_transfer_matrix, numeric.py:2049-2053) ----
-// C = alpha A B + c0 I + c1 X1 + c2 X2 + c3 X3, real FP64, row-major, one 16x16 tile per wavefront
+// C = alpha A B + c0 I + c1 X1 + c2 X2 + c3 X3, real FP64, row-major, one 16x16 tile per block of four wavefronts
 // on v_mfma_f64_16x16x4 (operand maps as in decay_gemm_kernel); edges are zero-padded by the loads.
 // (X pointers with a zero coefficient are not read.)
 namespace {
@@ -797,24 +965,63 @@ struct PolyTerms {
     const double *X1, *X2, *X3;
 };
 
-__global__ __launch_bounds__(64) void dgemm_poly_kernel(const double* __restrict__ A,
-                                                        const double* __restrict__ B, int N,
-                                                        double alpha, PolyTerms p,
-                                                        double* __restrict__ C) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void dgemm_poly_kernel(const double* __restrict__ A,
+                                                         const double* __restrict__ B, int N,
+                                                         double alpha, PolyTerms p,
+                                                         double* __restrict__ C) {
+    __shared__ double partial[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lk = lane >> 4;
     const int ti = blockIdx.y, tj = blockIdx.x;
     const int row = ti*16 + l15, col = tj*16 + l15;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    if (alpha != 0.0) {
-        for (int k0 = 0; k0 < N; k0 += 4) {
-            const int k = k0 + lk;
-            const double a = (row < N && k < N) ? A[static_cast<size_t>(row)*N + k] : 0.0;
-            const double b = (k < N && col < N) ? B[static_cast<size_t>(k)*N + col] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    // the linear combination's terms are requested before the product, not after it
+    double x1[4] = {0.0, 0.0, 0.0, 0.0}, x2[4] = {0.0, 0.0, 0.0, 0.0}, x3[4] = {0.0, 0.0, 0.0, 0.0};
+    if (wave == 0 && col < N)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = ti*16 + lk + 4*r;
+            if (i >= N) continue;
+            const size_t o = static_cast<size_t>(i)*N + col;
+            if (p.c1 != 0.0) x1[r] = p.X1[o];
+            if (p.c2 != 0.0) x2[r] = p.X2[o];
+            if (p.c3 != 0.0) x3[r] = p.X3[o];
         }
+    if (alpha != 0.0) {
+        // The sum over k does not care which lane group carries which k as long as both operands agree: lane group lk
+        // owns k0 + 4 lk + j, j = 0..3, of a 16-wide step, so that its A operands are 32 contiguous bytes of its row,
+        // and a step of 64 has all its operands requested before the first is consumed; the block's four wavefronts
+        // take every fourth step and add their tiles through LDS (round 6; before, one wavefront walked all of k and
+        // every matrix instruction waited for its own two 8-byte loads: 16 us per product at N = 256, all of it load
+        // latency, eleven products in a row).
+        const double* a_row = A + static_cast<size_t>(row < N ? row : 0)*N;
+        const double* b_col = B + (col < N ? col : 0);
+        const bool row_ok = row < N, col_ok = col < N;
+        for (int k0 = 64*wave; k0 < N; k0 += 256) {
+            double a[4][4], b[4][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + 16*s + 4*lk + j;
+                    const bool k_ok = k < N;
+                    a[s][j] = (row_ok && k_ok) ? a_row[k] : 0.0;
+                    b[s][j] = (col_ok && k_ok) ? b_col[static_cast<size_t>(k)*N] : 0.0;
+                }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][j], b[s][j], acc, 0, 0, 0);
+        }
+        if (wave > 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) partial[wave - 1][r][lane] = acc[r];
+        __syncthreads();
+        if (wave == 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = ((acc[r] + partial[0][r][lane]) + partial[1][r][lane]) + partial[2][r][lane];
     }
-    if (col >= N) return;
+    if (wave > 0 || col >= N) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = ti*16 + lk + 4*r;
@@ -822,13 +1029,68 @@ __global__ __launch_bounds__(64) void dgemm_poly_kernel(const double* __restrict
         const size_t o = static_cast<size_t>(i)*N + col;
         double v = alpha*acc[r];
         if (i == col) v += p.c0;
-        if (p.c1 != 0.0) v = fma(p.c1, p.X1[o], v);
-        if (p.c2 != 0.0) v = fma(p.c2, p.X2[o], v);
-        if (p.c3 != 0.0) v = fma(p.c3, p.X3[o], v);
+        if (p.c1 != 0.0) v = fma(p.c1, x1[r], v);
+        if (p.c2 != 0.0) v = fma(p.c2, x2[r], v);
+        if (p.c3 != 0.0) v = fma(p.c3, x3[r], v);
         C[o] = v;
     }
 }
+
+// sum over the leading axis of (batch, N, N): one thread per entry, the batch in order (the order NumPy's sum over
+// axis 0 takes); also clears the two words one_norm_kernel accumulates into
+__global__ __launch_bounds__(256) void sum_leading_axis_kernel(const double* __restrict__ K, int batch, size_t nn,
+                                                               double* __restrict__ out,
+                                                               unsigned long long* __restrict__ norm_and_bad) {
+    const size_t i = static_cast<size_t>(blockIdx.x)*256 + threadIdx.x;
+    if (i < 2) norm_and_bad[i] = 0ull;
+    if (i >= nn) return;
+    double v = K[i];
+    for (int b = 1; b < batch; ++b) v += K[static_cast<size_t>(b)*nn + i];
+    out[i] = v;
+}
+
+// result[0] = 1-norm (largest column sum of absolute values; the bits of a non-negative double order like an
+// unsigned integer), result[1] = number of entries that are NaN or Inf (as an integer).  64 columns per block, 16
+// threads per column, each adding every 16th row; the column's sum is then taken in row-group order.
+__global__ __launch_bounds__(1024) void one_norm_kernel(const double* __restrict__ A, int N,
+                                                        unsigned long long* __restrict__ result) {
+    __shared__ double part[16][64];
+    __shared__ unsigned bad[16][64];
+    const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int j = blockIdx.x*64 + c;
+    double column = 0.0;
+    unsigned non_finite = 0;
+    if (j < N) {
+#pragma unroll 4
+        for (int i = r; i < N; i += 16) {
+            const double v = A[static_cast<size_t>(i)*N + j];
+            non_finite += !(v - v == 0.0);
+            column += fabs(v);
+        }
+    }
+    part[r][c] = column;
+    bad[r][c] = non_finite;
+    __syncthreads();
+    if (r == 0 && j < N) {
+        for (int q = 1; q < 16; ++q) {
+            column += part[q][c];
+            non_finite += bad[q][c];
+        }
+        if (non_finite) atomicAdd(result + 1, static_cast<unsigned long long>(non_finite));
+        else atomicMax(result, static_cast<unsigned long long>(__double_as_longlong(column)));
+    }
+}
 }  // namespace
+
+hipError_t launch_sum_and_one_norm(const double* K, int batch, int N, double* sum, double* norm_and_bad,
+                                   hipStream_t stream) {
+    const size_t nn = static_cast<size_t>(N)*N;
+    unsigned long long* words = reinterpret_cast<unsigned long long*>(norm_and_bad);
+    hipLaunchKernelGGL(sum_leading_axis_kernel, dim3(static_cast<unsigned>((nn + 255)/256)), dim3(256), 0, stream, K,
+                       batch, nn, sum, words);
+    hipLaunchKernelGGL(one_norm_kernel, dim3((N + 63)/64), dim3(1024), 0, stream, sum, N, words);
+    return hipGetLastError();
+}
 
 // out = exp(A) by scaling and squaring: B = A / 2^s with |B|_1 <= 1/2, Taylor polynomial of degree
 // 18 (remainder < 2^-19/19! ~ 1e-23) evaluated the Paterson-Stockmeyer way -- B^2, B^3, B^4 once,
@@ -846,7 +1108,7 @@ hipError_t launch_expm_real(const double* A, int N, int squarings, double* out, 
     double *X1 = w[0], *X2 = w[1], *X3 = w[2], *X4 = w[3], *S = w[4];
     const PolyTerms none = {0.0, 0.0, 0.0, 0.0, nullptr, nullptr, nullptr};
     auto launch = [&](const double* a, const double* b, double alpha, const PolyTerms& p, double* c) {
-        hipLaunchKernelGGL(dgemm_poly_kernel, grid, dim3(64), 0, stream, a, b, N, alpha, p, c);
+        hipLaunchKernelGGL(dgemm_poly_kernel, grid, dim3(256), 0, stream, a, b, N, alpha, p, c);
     };
     // X1 = B = scale A (as a linear combination: no product), X2 = B B, X3 = X2 B, X4 = X2 X2
     launch(A, A, 0.0, PolyTerms{0.0, scale, 0.0, 0.0, A, nullptr, nullptr}, X1);

@@ -495,6 +495,18 @@ int ffk_cumulant_function(const double* decay_amplitudes, int batch, int N, int 
 }
 
 // ---------------------------------------------------------------------------------------------
+namespace {
+// |B|_1 <= 1/2 after s halvings (launch_expm_real's Taylor polynomial is sized for that)
+int squarings_for(double norm) {
+    int squarings = 0;
+    while (norm > 0.5 && squarings < 64) {
+        norm *= 0.5;
+        ++squarings;
+    }
+    return squarings;
+}
+}  // namespace
+
 int ffk_expm_real(const double* matrix, int N, double* result) {
     FFK_REQUIRE(matrix && result, "NULL argument");
     FFK_REQUIRE(N >= 1 && N <= 4096, "matrix dimension %d outside [1, 4096]", N);
@@ -509,11 +521,7 @@ int ffk_expm_real(const double* matrix, int N, double* result) {
         }
         norm = col > norm ? col : norm;
     }
-    int squarings = 0;
-    while (norm > 0.5 && squarings < 64) {
-        norm *= 0.5;
-        ++squarings;
-    }
+    const int squarings = squarings_for(norm);
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t nb = 8*size_t(N)*N;
     void* base;
@@ -527,6 +535,36 @@ int ffk_expm_real(const double* matrix, int N, double* result) {
     FFK_HIP(ffk::launch_expm_real(dA, N, squarings, dO, w, nullptr));
     FFK_HIP(hipMemcpyAsync(result, dO, nb, hipMemcpyDeviceToHost, nullptr));
     FFK_HIP(hipStreamSynchronize(nullptr));
+    return FFK_OK;
+}
+
+size_t ffk_error_transfer_matrix_workspace_bytes(int N) {
+    if (N < 1) return 0;
+    return 6*align_up(8*size_t(N)*N) + align_up(16);
+}
+
+int ffk_error_transfer_matrix_dev(const double* cumulant_function, int batch, int N, double* result,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+    FFK_REQUIRE(cumulant_function && result, "NULL argument");
+    FFK_REQUIRE(batch >= 1, "empty axis");
+    FFK_REQUIRE(N >= 1 && N <= 4096, "matrix dimension %d outside [1, 4096]", N);
+    FFK_REQUIRE(workspace && workspace_bytes >= ffk_error_transfer_matrix_workspace_bytes(N), "workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Bump a(workspace, workspace_bytes);
+    const size_t nn = size_t(N)*N;
+    double* dA = a.take<double>(nn);
+    double* w[5];
+    for (double*& m : w) m = a.take<double>(nn);
+    double* d_norm = a.take<double>(2);
+    FFK_HIP(ffk::launch_sum_and_one_norm(cumulant_function, batch, N, dA, d_norm, st));
+    // the number of squarings decides how many products are enqueued: 16 bytes come back first
+    unsigned long long words[2];
+    FFK_HIP(hipMemcpyAsync(words, d_norm, sizeof(words), hipMemcpyDeviceToHost, st));
+    FFK_HIP(hipStreamSynchronize(st));
+    FFK_REQUIRE(words[1] == 0, "matrix contains NaN or Inf");
+    double norm;
+    std::memcpy(&norm, &words[0], sizeof(norm));
+    FFK_HIP(ffk::launch_expm_real(dA, N, squarings_for(norm), result, w, st));
     return FFK_OK;
 }
 

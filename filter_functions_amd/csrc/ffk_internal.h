@@ -365,7 +365,11 @@ hipError_t launch_infidelity_derivative(const double* dF, int A, int G, int H, i
 hipError_t launch_noise_ops_from_atomic(const cplx* phases, const cplx* atomic, const cplx* props,
                                         int G, int W, int A, int d, cplx* out, hipStream_t stream);
 
-// exp of a real N x N matrix (device pointers; t0, t1: N*N scratch each); see decay.hip
+// sum = K summed over its leading axis (batch, N, N) -> (N, N); norm_and_bad[0] = |sum|_1 (a double), [1] = count
+// of NaN / Inf entries (a 64-bit integer; columns holding one do not enter the norm)
+hipError_t launch_sum_and_one_norm(const double* K, int batch, int N, double* sum, double* norm_and_bad,
+                                   hipStream_t stream);
+// exp of a real N x N matrix (device pointers; w: five N*N scratch matrices); see decay.hip
 hipError_t launch_expm_real(const double* A, int N, int squarings, double* out, double* const w[5],
                             hipStream_t stream);
 

@@ -244,6 +244,27 @@ class DevicePipeline:
                                             ctypes.c_void_p(s)))
         return out
 
+    def error_transfer_matrix(self, cumulant_function, stream=None):
+        """``exp`` of the device cumulant function ``(..., N, N)`` summed over its leading axes (reference
+        numeric.py:2049-2053), computed and left in HBM (``ffk_error_transfer_matrix_dev``: sum, 1-norm and every
+        product of the scaling-and-squaring on the device; 16 bytes cross to the host to choose the number of
+        squarings)."""
+        torch = self.torch
+        s = torch.cuda.current_stream(self.device).cuda_stream if stream is None else stream
+        K = cumulant_function.contiguous()
+        n = K.shape[-1]
+        if K.dim() < 2 or K.shape[-2] != n:
+            raise ValueError(f'cumulant_function invalid shape: {tuple(K.shape)}')
+        batch = K.numel()//(n*n)
+        out = torch.empty((n, n), dtype=torch.float64, device=self.device)
+        lib = _lib.load()
+        need = lib.ffk_error_transfer_matrix_workspace_bytes(n)
+        if getattr(self, '_ews', None) is None or self._ews.numel() < need:
+            self._ews = torch.empty(need, dtype=torch.uint8, device=self.device)
+        p = self._p
+        check(lib.ffk_error_transfer_matrix_dev(p(K), batch, n, p(out), p(self._ews), need, ctypes.c_void_p(s)))
+        return out
+
     def second_order_filter_function(self, stream=None):
         """Second-order filter function ``(A, A, N, N, W)`` of the pulse on this omega block, from
         the eigensystem of the last ``launch`` (``ffk_second_order_filter_function_dev``); stays in

@@ -128,7 +128,6 @@ def sharded_error_transfer_matrix(pipe, omega_global, w_offset, single_qubit=Fal
     commutator terms are added to the cumulant function.  Returns ``(decay_amplitudes,
     cumulant_function, U)``; the first two are device tensors, ``U`` a NumPy array.
     """
-    from . import numeric
     gamma = sum_omega_shards(pipe.decay_amplitudes(omega_global=omega_global, w_offset=w_offset),
                              group=group)
     K = pipe.cumulant_function(gamma, single_qubit=single_qubit)
@@ -136,8 +135,7 @@ def sharded_error_transfer_matrix(pipe, omega_global, w_offset, single_qubit=Fal
         delta = sum_omega_shards(pipe.frequency_shifts(omega_global=omega_global, w_offset=w_offset),
                                  group=group)
         K = pipe.add_second_order_cumulant(K, delta)
-    U = numeric.error_transfer_matrix(
-        cumulant_function=K.sum(dim=tuple(range(K.dim() - 2))).cpu().numpy()[None])
+    U = pipe.error_transfer_matrix(K).cpu().numpy()
     return gamma, K, U
 
 

@@ -27,8 +27,8 @@
  *   - d (Hilbert-space dimension) must satisfy 2 <= d <= FFK_MAX_D (64) for the path the reference's
  *     get_filter_function / infidelity / liouville_representation walk: ffk_diagonalize*,
  *     ffk_control_matrix* (control matrix and noise operators), ffk_filter_function*, ffk_infidelity*,
- *     ffk_decay_amplitudes*, ffk_cumulant_function*, ffk_expm_real, ffk_control_matrix_from_atomic*,
- *     ffk_liouville*.  Up to
+ *     ffk_decay_amplitudes*, ffk_cumulant_function*, ffk_expm_real, ffk_error_transfer_matrix_dev (the one
+ *     `_dev` call that synchronises its stream, see there), ffk_control_matrix_from_atomic*, ffk_liouville*.  Up to
  *     FFK_MAX_D_TEMPLATED (16) the kernels are compiled per dimension (operands in registers or
  *     wave-private LDS); above it one runtime-d kernel set serves (csrc/generic.hip, workgroup-wide
  *     LDS tiles).  The remaining entry points (intermediates, second order, gradients, fused
@@ -446,6 +446,14 @@ int ffk_filter_function_derivative_shard_dev(const double* eigvals, const double
  * matrix (N, N) f64 row-major -> result (N, N) = exp(matrix): scaling and squaring with a Taylor
  * polynomial of degree 18, every product on v_mfma_f64_16x16x4.                                */
 int ffk_expm_real(const double* matrix, int N, double* result);
+
+/* The same for a cumulant function that is already in HBM (round 6): cumulant_function (batch, N, N) f64 is summed
+ * over its leading axis in order (numeric.py:2049: `cumulant_function.sum(axis=...)`), the 1-norm that sizes the
+ * scaling is taken on the device (16 bytes cross to the host, one stream synchronisation: the number of squarings
+ * decides how many products are enqueued), result (N, N) f64 stays in HBM.  NaN / Inf in the sum: FFK_EINVAL.  */
+size_t ffk_error_transfer_matrix_workspace_bytes(int N);
+int ffk_error_transfer_matrix_dev(const double* cumulant_function, int batch, int N, double* result,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- superoperator.liouville_representation (superoperator.py:51-84 + Basis.expand
  *      basis.py:350-371, 650-698) --------------------------------------------------------

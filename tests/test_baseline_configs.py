@@ -103,6 +103,9 @@ def test_config5_full_size_error_transfer_matrix():
     U = ff.error_transfer_matrix(cumulant_function=K_total[None])
     U_ref = orc.error_transfer_matrix(K_ref)
     assert np.abs(U - U_ref).max() < TOL*np.abs(U_ref - np.eye(N)).max()
+    # the same without leaving HBM (what bench.py's config-5 entry times)
+    # (sums the 18 operators in order; torch's reduction above pairs them: equal to rounding, not to the bit)
+    assert np.abs(pipe.error_transfer_matrix(K).cpu().numpy() - U).max() < 1e-15
     # trace preservation: first row of the transfer matrix is e_0 (identity element first)
     assert np.abs(U[0] - np.eye(N)[0]).max() < 1e-14
     # entanglement infidelity to first order = sum of the operators' infidelities

@@ -1105,6 +1105,99 @@ def test_matrix_exponential_against_scipy(N, scale):
     assert np.array_equal(U, out)
 
 
+@pytest.mark.parametrize('case', ['real 2-D', 'real 1-D', 'complex 2-D', 'shard of a larger grid'])
+def test_decay_amplitudes_symmetric_block_kernel(case):
+    """N = 256 (d = 16, full basis), one pulse with itself, enough (operator, 128-frequency chunk) pairs to fill the
+    chip: decay_gemm_sym256_kernel (the operator's rows through LDS once, ten tiles on eight wavefronts) computes the
+    integral of numeric.py:1194-1337; a ragged frequency count, an operator subset out of order; complex weights make
+    it stand down for the general kernel inside the same call."""
+    import ctypes
+    import torch
+    lib = _lib.load()
+    A, N, n_idx = 6, 256, 4
+    W = 8192 + 5
+    rng = np.random.default_rng(7)
+    R = rng.standard_normal((A, N, W)) + 1j*rng.standard_normal((A, N, W))
+    omega_all = np.sort(rng.uniform(0.0, 50.0, W + 300))
+    idx = np.array([5, 0, 3, 1], dtype=np.int32)
+    w_offset = 0
+    omega = omega_all[:W]
+    if case == 'real 1-D':
+        S = rng.uniform(-0.5, 1.0, W)
+    else:
+        S = rng.uniform(-0.5, 1.0, (n_idx, W))
+    if case == 'complex 2-D':
+        S = S + 1j*rng.standard_normal((n_idx, W))
+    if case == 'shard of a larger grid':
+        omega, w_offset = omega_all, 120
+    ref = orc.decay_amplitudes_shard(R, S, omega, w_offset, idx)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    Rd, Sd, od, idxd = dev(R), dev(S.astype(complex)), dev(omega), dev(idx)
+    out = torch.full((n_idx, N, N), float('nan'), dtype=torch.float64, device='cuda')
+    need = lib.ffk_decay_amplitudes_workspace_bytes(1, N, W, n_idx, S.ndim)
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    if case == 'shard of a larger grid':
+        _lib.check(lib.ffk_decay_amplitudes_shard_dev(p(Rd), 1, A, N, W, p(Sd), S.ndim, p(od), len(omega), w_offset,
+                                                      p(idxd), n_idx, p(out), p(ws), need, None))
+    else:
+        _lib.check(lib.ffk_decay_amplitudes_dev(p(Rd), 1, A, N, W, p(Sd), S.ndim, p(od), p(idxd), n_idx, p(out),
+                                                p(ws), need, None))
+    gamma = out.cpu().numpy()
+    assert rel_err(gamma, ref) < 1e-12
+    if case != 'complex 2-D':
+        # the 64 x 64 tiles below the diagonal are mirrored, not recomputed
+        assert np.array_equal(gamma[:, 64:, :64], gamma[:, :64, 64:].swapaxes(-1, -2))
+        assert np.array_equal(gamma[:, 192:, 128:192], gamma[:, 128:192, 192:].swapaxes(-1, -2))
+
+
+@pytest.mark.parametrize('N,batch,scale', [(36, 1, 1e-4), (64, 3, 0.3), (100, 2, 5.0), (256, 18, 1e-3),
+                                           (256, 2, 40.0), (33, 1, 0.0), (16, 4, 0.2)])
+def test_device_error_transfer_matrix_against_scipy(N, batch, scale):
+    """ffk_error_transfer_matrix_dev (sum over the leading axis, 1-norm, scaling and squaring, all in HBM) against
+    scipy.linalg.expm of the NumPy sum (numeric.py:2049-2053), and bit-identical to the host-boundary call."""
+    import ctypes
+    import torch
+    from scipy.linalg import expm
+    from filter_functions_amd.device import DevicePipeline
+    rng = np.random.default_rng(N + batch)
+    K = rng.standard_normal((batch, N, N))*scale/np.sqrt(N)/batch
+    K = K - 0.5*np.abs(K.sum(0)).sum(axis=0).max()*np.eye(N)*(scale > 1)/batch
+    lib = _lib.load()
+    Kd = torch.from_numpy(K).cuda()
+    out = torch.empty((N, N), dtype=torch.float64, device='cuda')
+    need = lib.ffk_error_transfer_matrix_workspace_bytes(N)
+    ws = torch.empty(need, dtype=torch.uint8, device='cuda')
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ffk_error_transfer_matrix_dev(p(Kd), batch, N, p(out), p(ws), need, ctypes.c_void_p(stream)))
+    ref = expm(K.sum(axis=0))
+    U = out.cpu().numpy()
+    assert np.abs(U - ref).max() <= 1e-12*max(np.abs(ref).max(), 1.0)
+    host = np.empty((N, N))
+    total = np.ascontiguousarray(K.sum(axis=0))
+    _lib.check(lib.ffk_expm_real(total.ctypes.data_as(ctypes.c_void_p), N, host.ctypes.data_as(ctypes.c_void_p)))
+    assert np.array_equal(U, host)
+    # the wrapper on the pipeline object (any leading axes) is the same call
+    assert np.array_equal(DevicePipeline.error_transfer_matrix(_EtmOnly(torch), Kd[None]).cpu().numpy(), U)
+    # errors: a workspace that is too small, NaN in the input
+    assert lib.ffk_error_transfer_matrix_dev(p(Kd), batch, N, p(out), p(ws), need - 1, ctypes.c_void_p(stream)) \
+        == _lib.FFK_EINVAL
+    Kd[0, 0, 0] = float('nan')
+    assert lib.ffk_error_transfer_matrix_dev(p(Kd), batch, N, p(out), p(ws), need, ctypes.c_void_p(stream)) \
+        == _lib.FFK_EINVAL
+
+
+class _EtmOnly:
+    """the attributes DevicePipeline.error_transfer_matrix uses"""
+
+    def __init__(self, torch):
+        import ctypes
+        self.torch = torch
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self._p = lambda t: ctypes.c_void_p(t.data_ptr())
+
+
 def test_sharded_error_transfer_matrix_single_rank():
     """parallel.sharded_error_transfer_matrix on a one-rank gloo group (the collective path with
     world size 1 is the identity): same result as the host API."""

@@ -106,9 +106,10 @@ def main():
     wgt = torch.zeros(W, dtype=torch.float64, device=dev)
     wgt[:-1] += 0.5*(omega[1:] - omega[:-1])
     wgt[1:] += 0.5*(omega[1:] - omega[:-1])
-    Rc = torch.view_as_complex(R[0])
-    ref = torch.real((Rc.conj()*(S[0, :, 0]*wgt/(2*np.pi))) @ Rc.T)
-    print('max rel err vs torch:', float((gamma[0] - ref).abs().max()/ref.abs().max()))
+    for a in sorted({0, A//2, A - 1}):
+        Rc = torch.view_as_complex(R[a])
+        ref = torch.real((Rc.conj()*(S[a, :, 0]*wgt/(2*np.pi))) @ Rc.T)
+        print(f'operator {a}: max rel err vs torch:', float((gamma[a] - ref).abs().max()/ref.abs().max()))
 
 
 if __name__ == '__main__':

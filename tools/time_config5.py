@@ -54,6 +54,29 @@ def main():
     print(f'config 5 pass (no exp, no copy to the host): median {np.median(times):.3f} ms, '
           f'min {np.min(times):.3f} ms over {args.reps} passes')
 
+    # the tail: sum over the operators -> exp -> host, the round-6 way (all in HBM) and the earlier one (sum to the
+    # host, ffk_expm_real from and to host memory)
+    def tail_device(K):
+        return pipe.error_transfer_matrix(K, stream=stream).cpu().numpy()
+
+    def tail_host(K):
+        return ff.error_transfer_matrix(cumulant_function=K.sum(dim=0).cpu().numpy()[None])
+
+    with torch.cuda.stream(ts):
+        pipe.launch(stream=stream)
+        K = pipe.cumulant_function(pipe.decay_amplitudes(stream=stream), stream=stream)
+        for name, tail in (('in HBM', tail_device), ('through the host', tail_host)):
+            for _ in range(3):
+                U = tail(K)
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(args.reps):
+                t0 = time.perf_counter()
+                U = tail(K)
+                times.append((time.perf_counter() - t0)*1e3)
+            print(f'sum over operators + exp + copy to the host, {name}: median {np.median(times):.3f} ms, '
+                  f'min {np.min(times):.3f} ms; trace {np.trace(U):.12f}')
+
 
 if __name__ == '__main__':
     main()
