@@ -16,8 +16,19 @@ from conftest import ROOT
 LIB = os.path.join(ROOT, 'build', 'libffk_asan.so')
 RUNTIME = sorted(glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so'))
 
-pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and RUNTIME),
-                                reason='sanitizer variant not built (tools/build_asan.sh)')
+
+
+def _stale():
+    """the sanitizer build is older than a source it was made from (a new entry point would be missing from it)"""
+    built = os.path.getmtime(LIB)
+    sources = glob.glob(os.path.join(ROOT, 'filter_functions_amd', 'csrc', '*.h*')) + \
+        glob.glob(os.path.join(ROOT, 'filter_functions_amd', 'csrc', '*.inc')) + \
+        glob.glob(os.path.join(ROOT, 'include', '*.h'))
+    return any(os.path.getmtime(f) > built for f in sources)
+
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(LIB) and RUNTIME) or _stale(),
+                                reason='sanitizer variant not built or older than the sources (tools/build_asan.sh)')
 
 CHILD = r'''
 import ctypes, itertools, os, random, sys
