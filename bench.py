@@ -422,6 +422,19 @@ def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
     st = _lib.stats()
     E = len(qft.dt)*W*A*qft.d**2
     U = result['U']
+    # the decay amplitudes alone (weights, the symmetric-block GEMM, the reduction over the frequency chunks)
+    with torch.cuda.stream(torch_stream):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gamma_ms = []
+        for _ in range(12):
+            e0.record()
+            pipe.decay_amplitudes(stream=stream)
+            e1.record()
+            e1.synchronize()
+            gamma_ms.append(e0.elapsed_time(e1))
+    gamma_ms = float(np.median(gamma_ms[2:]))
+    N = qft.d**2
+    gamma_flops = A*10*64*64*2.0*(2*W)          # ten of the sixteen 64 x 64 tiles of each symmetric 256 x 256 block
     return dict(
         config=5, workload='examples/qft.py 4-qubit QFT: d=16, 13 segments, 18 noise ops, GGM basis, '
                            '16384 omega; control matrix + F + infidelity -> decay amplitudes -> '
@@ -431,6 +444,11 @@ def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
         tflops=st['accumulate_flops']/(kernel_ms*1e-3)/1e12,
         frac=st['accumulate_flops']/(kernel_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
         entanglement_infidelity=float(1 - np.trace(U)/qft.d**2),
+        decay_amplitudes=dict(ms=gamma_ms, executed_flops=gamma_flops, tflops=gamma_flops/(gamma_ms*1e-3)/1e12,
+                              frac_whole_call=gamma_flops/(gamma_ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+                              kernel='ffk::decay_gemm_sym256_kernel',
+                              note='whole call (weights, GEMM, reduction of 14 frequency chunks) over the flops of '
+                                   'the symmetric half; the GEMM kernel alone: profiles/r06_m_*'),
         geometry={k: st[k] for k in ('chunks', 'grid_x', 'grid_y', 'grid_z', 'block', 'lds_bytes')},
         note='one segment chunk: since round 4 the accumulate kernel expands its complete Y in the basis in '
              'its epilogue and writes the control matrix itself (no expansion launch); kernel_ms spans its two '
@@ -438,19 +456,24 @@ def bench_config5(ff, torch, lib, _lib, DevicePipeline, device, torch_stream):
              'alone over it')
 
 
-def bench_liouville(ff, torch, lib, _lib, device):
+def bench_liouville(ff, torch, lib, _lib, device, dense_basis=False):
     """superoperator.liouville_representation (the one kernel BASELINE's north_star
-    names for the matrix cores): d = 16, Pauli basis, batch 512, device resident -- basis conjugation
-    + the GEMM (`tools/time_liouville.py` is the stand-alone version, with a parity check)."""
+    names for the matrix cores): d = 16, batch 512, device resident (`tools/time_liouville.py` is the
+    stand-alone version, with a parity check).  Pauli basis: since round 6 the conjugation kernel (matrix cores)
+    contracts its tile with the operand's non-zeros itself and no GEMM runs; *dense_basis* (the Pauli basis rotated
+    by a random unitary: Hermitian, orthonormal, no zeros) keeps the conjugation + GEMM form measured."""
     import ctypes
     d, B = 16, 512
     N = d*d
     rng = np.random.default_rng(0)
-    basis = ff.Basis.pauli(4)
+    basis = np.asarray(ff.Basis.pauli(4))
+    if dense_basis:
+        V = np.linalg.qr(rng.standard_normal((d, d)) + 1j*rng.standard_normal((d, d)))[0]
+        basis = V @ basis @ V.conj().T
     U = np.linalg.qr(rng.standard_normal((B, d, d)) + 1j*rng.standard_normal((B, d, d)))[0]
     with torch.cuda.device(device):
         Ud = torch.from_numpy(U).to(device)
-        Cd = torch.from_numpy(np.ascontiguousarray(np.asarray(basis))).to(device)
+        Cd = torch.from_numpy(np.ascontiguousarray(basis)).to(device)
         out = torch.empty((B, N, N), dtype=torch.float64, device=device)
         need = lib.ffk_liouville_workspace_bytes(B, d, N)
         ws = torch.empty(need, dtype=torch.uint8, device=device)
@@ -472,19 +495,32 @@ def bench_liouville(ff, torch, lib, _lib, device):
             torch.cuda.synchronize(device)
             times.append(e0.elapsed_time(e1))
     ms = float(np.median(times))
-    executed = B*N*float(d*d)*N*2.0            # Hermitian basis: d^2 operand rows
-    plain = 2*executed                         # the plain trace's 2 d^2 rows
+    gemm = B*N*float(d*d)*N*2.0                # Hermitian basis: d^2 operand rows
+    conj = B*N*(256 + 160)/4*512.0             # matrix instructions of the conjugation: 416 per four elements
+    if dense_basis:
+        return dict(
+            config='K5-dense', workload='superoperator.liouville_representation: d=16 (N=256), a basis without zero '
+                                        'entries (Pauli rotated by a random unitary), batch 512, device resident '
+                                        '(basis conjugation on v_mfma_f64_4x4x4 + GEMM on v_mfma_f64_16x16x4 through LDS)',
+            ms=ms, dominant_kernel='ffk::liouville_gemm_block_kernel<4>',
+            executed_gemm_flops=gemm, tflops_whole_call=gemm/(ms*1e-3)/1e12,
+            frac_whole_call=gemm/(ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+            note='whole launch sequence (operand build, conjugation, GEMM) over the GEMM flops the library '
+                 'executes; per-kernel split and the GEMM alone (0.68 of the FP64 matrix peak): '
+                 'profiles/r04_l_liouville_block_gemm.txt')
     return dict(
-        config='K5', workload='superoperator.liouville_representation: d=16 (N=256), Pauli basis, batch 512, '
-                              'device resident (basis conjugation on v_mfma_f64_4x4x4 + GEMM on '
-                              'v_mfma_f64_16x16x4 through LDS)',
-        ms=ms, dominant_kernel='ffk::liouville_gemm_block_kernel<4>',
-        executed_gemm_flops=executed, tflops_whole_call=executed/(ms*1e-3)/1e12,
-        frac_whole_call=executed/(ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
-        tflops_at_plain_trace_rows=plain/(ms*1e-3)/1e12,
-        note='whole launch sequence (operand build, conjugation, GEMM) over the GEMM flops the library '
-             'executes; per-kernel split and the GEMM alone (0.68 of the FP64 matrix peak): '
-             'profiles/r04_l_liouville_block_gemm.txt')
+        config='K5', workload='superoperator.liouville_representation: d=16 (N=256), Pauli basis, batch 512, device '
+                              'resident (round 6: basis conjugation on v_mfma_f64_4x4x4, contracted in the same '
+                              'kernel with the 8-16 non-zero operand rows of each basis element; no GEMM, no operand '
+                              'round trip through HBM)',
+        ms=ms, dominant_kernel='ffk::conjugate_basis_mfma_kernel<16, true, true>',
+        executed_matrix_flops=conj, tflops_whole_call=conj/(ms*1e-3)/1e12,
+        frac_whole_call=conj/(ms*1e-3)/1e12/FP64_PEAK_TFLOPS,
+        hbm_bytes=float(B*N*N*8), hbm_gbs_whole_call=B*N*N*8/(ms*1e-3)/1e9,
+        tflops_a_gemm_would_need=gemm/(ms*1e-3)/1e12,
+        note='frac_whole_call counts the conjugation\'s matrix instructions only (the sparse contraction is LDS reads '
+             'and vector FMAs); tflops_a_gemm_would_need = the rate the round-5 GEMM form (0.48 ms, entry K5-dense keeps '
+             'it measured) would have to sustain to match this time; profiles/r06_l_liouville_fused.txt')
 
 
 def bench_config3(ff):
@@ -1154,6 +1190,7 @@ def main():
             configs.append(bench_config4_full(ff, torch, lib, _lib, DevicePipeline, device, stream))
             configs.append(bench_config5(ff, torch, lib, _lib, DevicePipeline, device, compute_stream))
             configs.append(bench_liouville(ff, torch, lib, _lib, device))
+            configs.append(bench_liouville(ff, torch, lib, _lib, device, dense_basis=True))
             configs.extend(bench_other_dimensions(ff, torch, lib, _lib, DevicePipeline, device, stream))
             if args.published_example:     # doc notebook (concatenate_periodic): outside SURVEY section 8
                 configs.append(bench_published_example(ff))

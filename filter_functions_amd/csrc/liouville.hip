@@ -42,6 +42,59 @@ __global__ void build_bop_kernel(const cplx* __restrict__ basis, int N, int d, i
     Bop[static_cast<size_t>(d*d + ab)*Npad + j] = v.im;
 }
 
+// ---- the right operand's non-zeros (round 6) ------------------------------------------------------
+// For the two bases the package builds (Pauli: d non-zero entries per element, GGM: one or two, d on the diagonal
+// elements) a column of Bop has 8-16 resp. 1-16 non-zeros of its d^2 rows: the contraction with it is a gather of a
+// handful of terms, not a GEMM.  One wavefront per column lists them in ascending row order (64 rows per step,
+// positions from the ballot); a column with more than kLvNzMax raises `dense`, and the call runs as the GEMM.
+constexpr int kLvNzMax = 32;
+struct OperandLists {
+    int* dense;        // != 0: some column has more than kLvNzMax non-zeros
+    int* count;        // [Npad]
+    int* row;          // [Npad][kLvNzMax]  a column's entries side by side (a thread fetches 16 of them with four
+    double* value;     // [Npad][kLvNzMax]  resp. eight 16-byte loads); entries past the count: row 0, value 0
+};
+size_t operand_lists_bytes(int Npad) {
+    return align_up(sizeof(int)) + align_up(sizeof(int)*Npad) + align_up(sizeof(int)*kLvNzMax*Npad) +
+           align_up(sizeof(double)*kLvNzMax*Npad);
+}
+OperandLists slice_operand_lists(void* ws, int Npad) {
+    unsigned char* p = static_cast<unsigned char*>(ws);
+    OperandLists L;
+    L.dense = reinterpret_cast<int*>(p);   p += align_up(sizeof(int));
+    L.count = reinterpret_cast<int*>(p);   p += align_up(sizeof(int)*Npad);
+    L.row = reinterpret_cast<int*>(p);     p += align_up(sizeof(int)*kLvNzMax*Npad);
+    L.value = reinterpret_cast<double*>(p);
+    return L;
+}
+__global__ __launch_bounds__(64) void operand_lists_kernel(const double* __restrict__ Bop, int K, int Npad,
+                                                           OperandLists L) {
+    const int j = blockIdx.x, lane = threadIdx.x;
+    int* rows = L.row + static_cast<size_t>(j)*kLvNzMax;
+    double* values = L.value + static_cast<size_t>(j)*kLvNzMax;
+    int n = 0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const int k = k0 + lane;
+        const double v = k < K ? Bop[static_cast<size_t>(k)*Npad + j] : 0.0;
+        const bool nz = v != 0.0;
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(nz);
+        const int pos = n + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        if (nz && pos < kLvNzMax) {
+            rows[pos] = k;
+            values[pos] = v;
+        }
+        n += __builtin_popcountll(mask);
+    }
+    if (lane >= n && lane < kLvNzMax) {
+        rows[lane] = 0;
+        values[lane] = 0.0;
+    }
+    if (lane == 0) {
+        L.count[j] = min(n, kLvNzMax);
+        if (n > kLvNzMax) atomicOr(L.dense, 1);
+    }
+}
+
 // The LDS tile [2 d^2][EPB + 1] of a block's EPB conjugated elements (row kk = a d + b: Re CB[a,b],
 // d^2 + a d + b: -Im CB[a,b]; `transposed_slots`: the rows kernel keeps entry (a, b) in slot b d + a)
 // to the K-major operand(s): EPB consecutive doubles per row.  Hermitian basis (no imaginary operand):
@@ -204,14 +257,22 @@ __global__ __launch_bounds__(256) void conjugate_basis_rows_kernel(const cplx* _
 // faster than the tile kernel at d = 16).
 // HERM (Hermitian basis): only the blocks of Y on and above the diagonal are formed -- the operand
 // keeps the entries a <= b (hermitian_operand_row): 10 of 16 block pairs of the second product at d = 16.
-template <int D, bool HERM>
-__global__ __launch_bounds__(256) void conjugate_basis_mfma_kernel(const cplx* __restrict__ U,
+// FUSED (round 6, Hermitian basis whose operand columns are short lists, OperandLists): the block contracts its 16
+// conjugated elements with the right operand's non-zeros straight from the LDS tile -- thread = column j, 16 sums
+// each -- and writes 16 rows of L; the 0.25 GB operand (d = 16, batch 512) is neither written nor read back, the GEMM
+// does not run.  `dense` decides on the device which of the two forms works; the other one's blocks all return.
+template <int D, bool HERM, bool FUSED = false>
+__global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kernel(const cplx* __restrict__ U,
                                                                      const cplx* __restrict__ basis, int N,
                                                                      int Npad, int want_imag,
                                                                      double* __restrict__ AopRe,
-                                                                     double* __restrict__ AopIm) {
+                                                                     double* __restrict__ AopIm,
+                                                                     OperandLists lists,
+                                                                     double* __restrict__ out) {
     static_assert(D % 4 == 0 && D <= 16, "d = 4, 8, 12, 16");
+    static_assert(HERM || !FUSED, "the fused form keeps the Hermitian operand's rows");
     constexpr int DD = D*D, NS = D/4, EPB = 16, ROW = EPB + 1;
+    if (lists.dense != nullptr && (*lists.dense != 0) == FUSED) return;     // (every block of the launch alike)
     __shared__ cplx Us[DD];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double* tre = reinterpret_cast<double*>(lds_raw);                  // [2 DD][ROW]
@@ -221,6 +282,12 @@ __global__ __launch_bounds__(256) void conjugate_basis_mfma_kernel(const cplx* _
     const int c = lane & 15, q = lane >> 4, c4 = c & 3, b = c >> 2;
     const int i0 = blockIdx.x*EPB;
     const int j = 4*wave + b, i = i0 + j;             // this lane's basis element
+    const cplx* Ci = basis + static_cast<size_t>(min(i, N - 1))*DD;
+    // the element's first column block is requested before U is staged: it does not depend on U, and behind the
+    // barrier its trip to L2 would be the second of two in a row at the head of every block (round 6)
+    cplx x0[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) x0[s] = Ci[(4*s + q)*D + c4];
     if (tid < DD) Us[tid] = U[static_cast<size_t>(bt)*DD + tid];
     __syncthreads();
     cplx tq[NS][NS];                                  // U[4 s + q][4 g + c4]
@@ -228,7 +295,6 @@ __global__ __launch_bounds__(256) void conjugate_basis_mfma_kernel(const cplx* _
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int g = 0; g < NS; ++g) tq[s][g] = Us[(4*s + q)*D + 4*g + c4];
-    const cplx* Ci = basis + static_cast<size_t>(min(i, N - 1))*DD;
     double Yr[NS][NS], Yi[NS][NS];                    // Y[4 ig + q][4 jg + c4]
 #pragma unroll
     for (int ig = 0; ig < NS; ++ig)
@@ -247,7 +313,7 @@ __global__ __launch_bounds__(256) void conjugate_basis_mfma_kernel(const cplx* _
         }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const cplx x = Ci[(4*s + q)*D + 4*ng + c4];           // C_i[4 s + q][4 ng + c4]
+            const cplx x = ng == 0 ? x0[s] : Ci[(4*s + q)*D + 4*ng + c4];           // C_i[4 s + q][4 ng + c4]
 #pragma unroll
             for (int ig = 0; ig < NS; ++ig) {
                 pr[ig] = __builtin_amdgcn_mfma_f64_4x4x4f64(x.re, tq[s][ig].re, pr[ig], 0, 0, 0);
@@ -286,6 +352,71 @@ __global__ __launch_bounds__(256) void conjugate_basis_mfma_kernel(const cplx* _
                 if (r0 >= 0) tre[r0*ROW + j] = valid ? Yr[ig][jg] : 0.0;
                 if (r1 >= 0) tre[r1*ROW + j] = valid ? -Yi[ig][jg] : 0.0;
             }
+        if constexpr (FUSED) {
+            // L[bt][i0 + jj][col] = sum over the non-zero rows k of column col: tile[k][jj] Bop[k][col], k ascending.
+            // Sixteen list entries are requested at once -- the first batch before the barrier that completes the
+            // tile, so that the trip to L2 runs beside the other wavefronts' last matrix instructions -- (a padding
+            // entry reads row 0 with weight 0: a broadcast).
+            constexpr int NB = 16;
+            using int4_t = __attribute__((ext_vector_type(4))) int;
+            using double2_t = __attribute__((ext_vector_type(2))) double;
+            int4_t kk[NB/4];
+            double2_t vv[NB/2];
+            auto request = [&](int col, int base) __attribute__((always_inline)) {
+                const int4_t* rp = reinterpret_cast<const int4_t*>(lists.row + static_cast<size_t>(col)*kLvNzMax + base);
+                const double2_t* vp =
+                    reinterpret_cast<const double2_t*>(lists.value + static_cast<size_t>(col)*kLvNzMax + base);
+#pragma unroll
+                for (int t = 0; t < NB/4; ++t) kk[t] = rp[t];
+#pragma unroll
+                for (int t = 0; t < NB/2; ++t) vv[t] = vp[t];
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the requests stay behind the tile's stores)
+            // (the fused form is launched for complete bases only, N = d^2: a column per thread, no edge)
+            const int col = tid < DD ? tid : 0;
+            const int n = lists.count[col];
+            request(col, 0);
+            __syncthreads();
+            if (tid >= DD) return;
+            double acc[EPB];
+#pragma unroll
+            for (int jj = 0; jj < EPB; ++jj) acc[jj] = 0.0;
+            for (int base = 0;;) {
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    // the row's 16 entries as one asm statement with its own wait, which names the running sums as
+                    // inputs it does not use -- so that it stays behind the previous row's multiply-adds: left to
+                    // the scheduler all 256 reads of the batch are requested first and ~500 registers spill
+                    const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>(tre + kk[t/4][t%4]*ROW));
+                    const double v = vv[t/2][t%2];
+                    double2_t r[EPB/2];
+                    asm volatile("ds_read2_b64 %0, %8 offset1:1\n\t"
+                                 "ds_read2_b64 %1, %8 offset0:2 offset1:3\n\t"
+                                 "ds_read2_b64 %2, %8 offset0:4 offset1:5\n\t"
+                                 "ds_read2_b64 %3, %8 offset0:6 offset1:7\n\t"
+                                 "ds_read2_b64 %4, %8 offset0:8 offset1:9\n\t"
+                                 "ds_read2_b64 %5, %8 offset0:10 offset1:11\n\t"
+                                 "ds_read2_b64 %6, %8 offset0:12 offset1:13\n\t"
+                                 "ds_read2_b64 %7, %8 offset0:14 offset1:15\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]),
+                                   "=&v"(r[6]), "=&v"(r[7])
+                                 : "v"(addr), "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]),
+                                   "v"(acc[6]), "v"(acc[7]), "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]),
+                                   "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15])
+                                 : "memory");
+#pragma unroll
+                    for (int jj = 0; jj < EPB; ++jj) acc[jj] = fma(r[jj/2][jj%2], v, acc[jj]);
+                }
+                base += NB;
+                if (base >= n) break;
+                request(col, base);
+            }
+            double* o = out + (static_cast<size_t>(bt)*DD + i0)*DD + col;
+#pragma unroll
+            for (int jj = 0; jj < EPB; ++jj) o[jj*DD] = acc[jj];
+            return;
+        }
         __syncthreads();
         using double2_t = __attribute__((ext_vector_type(2))) double;
         double* are = AopRe + static_cast<size_t>(bt)*liouville_operand_rows(D, 0)*Npad + i0;
@@ -331,7 +462,9 @@ __global__ __launch_bounds__(64, (TM == 4 && !IMAG) ? 3 : 1) void liouville_gemm
                                                             const double* __restrict__ AopIm,
                                                             const double* __restrict__ Bop, int N,
                                                             int Npad, int K,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out,
+                                                            const int* __restrict__ only_if_dense) {
+    if (only_if_dense != nullptr && *only_if_dense == 0) return;       // (served by the fused conjugation)
     const int lane = threadIdx.x;
     const int ti = blockIdx.x, tj = blockIdx.y, bt = blockIdx.z;
     const int l15 = lane & 15, lk = lane >> 4;
@@ -424,7 +557,8 @@ constexpr size_t lb_lds_bytes() { return sizeof(double)*2*kLbKS*(kLbSA + 32*NTW 
 template <int NTW>
 __global__ __launch_bounds__(256, NTW >= 8 ? 1 : 2) void liouville_gemm_block_kernel(
     const double* __restrict__ Aop, const double* __restrict__ Bop, int N, int Npad, int K,
-    double* __restrict__ out) {
+    double* __restrict__ out, const int* __restrict__ only_if_dense) {
+    if (only_if_dense != nullptr && *only_if_dense == 0) return;       // (served by the fused conjugation)
     using double2_t = __attribute__((ext_vector_type(2))) double;
     constexpr int NT = 32*NTW, SB = NT + kLbPad;
     constexpr int BT = NT/2;                      // threads per row of the right operand's 16-row slab
@@ -535,6 +669,17 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
     }
     hipLaunchKernelGGL(build_bop_kernel, dim3((Npad + 63)/64, d*d), dim3(64), 0, stream, basis, N, d,
                        Npad, hermitian ? 1 : 0, Bop);
+    // d = 12, 16 with a Hermitian basis: the fused form for operands of short columns (the lists live in the unused
+    // imaginary operand's space); both forms are enqueued, `dense` picks one on the device
+    OperandLists lists = {nullptr, nullptr, nullptr, nullptr};
+    const bool may_fuse = hermitian && (d == 16 || d == 12) && N == d*d && std::getenv("FFK_LIOUVILLE_GEMM") == nullptr &&
+                          operand_lists_bytes(Npad) <= align_up(static_cast<size_t>(batch)*K*Npad*sizeof(double));
+    if (may_fuse) {
+        lists = slice_operand_lists(AopIm, Npad);
+        hipError_t err = hipMemsetAsync(lists.dense, 0, sizeof(int), stream);
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(operand_lists_kernel, dim3(Npad), dim3(64), 0, stream, Bop, K, Npad, lists);
+    }
     // the batch axis rides on grid.y / grid.z (at most 65535 blocks): longer batches (the
     // propagators of a 200 000-segment pulse) go in slabs
     const int tiles = Npad/16;
@@ -565,7 +710,7 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
                     if (e2 != hipSuccess) return e2;
                 }
                 hipLaunchKernelGGL(kern, dim3((N + 15)/16, nb), dim3(256), lds, stream, Us, basis, N, Npad,
-                                   want_imag, are, aim);
+                                   want_imag, are, aim, lists, o);
                 return hipGetLastError();
             };
             const hipError_t e3 = d == 16 ? (want_imag ? go(conjugate_basis_mfma_kernel<16, false>)
@@ -573,6 +718,11 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
                                             : (want_imag ? go(conjugate_basis_mfma_kernel<12, false>)
                                                          : go(conjugate_basis_mfma_kernel<12, true>));
             if (e3 != hipSuccess) return e3;
+            if (may_fuse) {
+                const hipError_t e6 = d == 16 ? go(conjugate_basis_mfma_kernel<16, true, true>)
+                                              : go(conjugate_basis_mfma_kernel<12, true, true>);
+                if (e6 != hipSuccess) return e6;
+            }
             done = true;
         }
         if (!done && rows_form && d == 8) {
@@ -623,7 +773,7 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
         const long waves2 = static_cast<long>((tiles + 1)/2)*((tiles + 1)/2)*nb;
         auto launch = [&](auto kern, int t) {
             hipLaunchKernelGGL(kern, dim3((tiles + t - 1)/t, (tiles + t - 1)/t, nb), dim3(64), 0, stream, are,
-                               aim, Bop, N, Npad, K, o);
+                               aim, Bop, N, Npad, K, o, lists.dense);
         };
         if (liouville_block_gemm_applies(Npad, K, want_imag) && static_cast<long>(nb)*(Npad/128)*(Npad/128) >= 512) {
             auto go = [&](auto kern, size_t lds, int nt) -> hipError_t {
@@ -633,7 +783,7 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
                 if (e4 != hipSuccess) return e4;
                 // (grid.x <= 65535 batch elements x Npad/128 row blocks: 2^31 - 1 is the limit there)
                 hipLaunchKernelGGL(kern, dim3(nb*(Npad/kLbMT), Npad/nt), dim3(256), lds, stream, are, Bop, N,
-                                   Npad, K, o);
+                                   Npad, K, o, lists.dense);
                 return hipGetLastError();
             };
             const hipError_t e5 = go(liouville_gemm_block_kernel<4>, lb_lds_bytes<4>(), 128);

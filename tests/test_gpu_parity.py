@@ -236,6 +236,36 @@ def test_liouville_representation_against_the_oracle(d, batch, hermitian):
     assert rel_err(L, ref) < 1e-13
 
 
+@pytest.mark.parametrize('d,kind,batch', [(16, 'pauli', 3), (16, 'ggm', 2), (12, 'ggm', 5), (16, 'rotated pairs', 2),
+                                          (12, 'rotated pairs', 3), (16, 'dense', 2), (12, 'dense', 2),
+                                          (16, 'pauli, one element dense', 2)])
+def test_liouville_representation_fused_with_a_sparse_operand(d, kind, batch):
+    """d = 12, 16 with a Hermitian basis: when every element has at most 32 non-zero operand rows the conjugation
+    kernel contracts its tile with them itself (conjugate_basis_mfma_kernel<D, true, true>, liouville.hip) and no
+    GEMM runs; otherwise the two-kernel form does.  Pauli (8 or 16 rows per element), GGM (1, 2 or d), a basis
+    rotated by 2 x 2 blocks (lists of more than one batch of eight), dense Hermitian bases and a sparse basis with ONE
+    dense element (the device-side switch) -- against the oracle's plain trace (superoperator.py:51-84)."""
+    rng = np.random.default_rng(31*d + batch)
+    base = np.array(ff.Basis.pauli(4) if kind.startswith('pauli') else ff.Basis.ggm(d))
+    if kind == 'rotated pairs':
+        V = np.zeros((d, d), dtype=complex)
+        for a in range(0, d, 2):
+            V[a:a + 2, a:a + 2] = np.linalg.qr(rng.standard_normal((2, 2)) + 1j*rng.standard_normal((2, 2)))[0]
+        base = V @ base @ V.conj().T
+    elif kind == 'dense':
+        V = np.linalg.qr(rng.standard_normal((d, d)) + 1j*rng.standard_normal((d, d)))[0]
+        base = V @ base @ V.conj().T
+    elif kind == 'pauli, one element dense':
+        M = rng.standard_normal((d, d)) + 1j*rng.standard_normal((d, d))
+        base[77] = (M + M.conj().T)/np.linalg.norm(M + M.conj().T)
+    U = np.linalg.qr(rng.standard_normal((batch, d, d)) + 1j*rng.standard_normal((batch, d, d)))[0]
+    U[-1] = rng.standard_normal((d, d)) + 1j*rng.standard_normal((d, d))        # (and one that is not unitary)
+    L = ff.liouville_representation(U, ff.Basis(base))
+    ref = orc.liouville_representation(U, base)
+    assert not np.iscomplexobj(L) and L.shape == ref.shape
+    assert rel_err(L, ref) < 1e-13
+
+
 @pytest.mark.parametrize('d,batch', [(2, 3), (3, 5), (5, 4), (7, 2), (8, 5), (12, 3), (16, 2), (20, 2), (32, 1)])
 def test_liouville_representation_of_any_operator_in_a_hermitian_basis(d, batch):
     """For a Hermitian basis the library contracts d^2 operand rows instead of 2 d^2: U^dag C_i U is

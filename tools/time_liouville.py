@@ -29,6 +29,8 @@ def main():
     ap.add_argument('--batch', type=int, default=512)
     ap.add_argument('--d', type=int, nargs='*', default=[4, 8, 16])
     ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--dense-basis', action='store_true',
+                    help='rotate the basis by a random unitary: Hermitian, orthonormal, no zero entries (the GEMM form)')
     args = ap.parse_args()
     lib = _lib.load()
     rng = np.random.default_rng(0)
@@ -40,7 +42,10 @@ def main():
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     for d in args.d:
         N, B = d*d, args.batch
-        basis = ff.Basis.pauli(int(np.log2(d)))
+        basis = np.asarray(ff.Basis.pauli(int(np.log2(d))))
+        if args.dense_basis:
+            V = np.linalg.qr(rng.standard_normal((d, d)) + 1j*rng.standard_normal((d, d)))[0]
+            basis = V @ basis @ V.conj().T
         U = np.linalg.qr(rng.standard_normal((B, d, d)) + 1j*rng.standard_normal((B, d, d)))[0]
         Ud = torch.from_numpy(U).cuda()
         Cd = torch.from_numpy(np.ascontiguousarray(np.asarray(basis))).cuda()
@@ -72,9 +77,13 @@ def main():
         C = np.asarray(basis)
         ref = np.einsum('bka,ikl,blm,jma->bij', U[:2].conj(), C, U[:2], C).real
         err = np.abs(L - ref).max()
-        print(f'd={d:2d} N={N:3d} batch={B}: {t*1e3:9.1f} us per call, GEMM {flops/1e9:8.3f} GFLOP executed '
-              f'-> {flops/(t*1e-3)/1e12:6.2f} TFLOP/s over the whole call ({flops_plain/(t*1e-3)/1e12:6.2f} at the '
-              f'plain trace\'s 2 d^2 rows); max abs err {err:.1e}')
+        # d = 12, 16 with a basis of short operand columns (Pauli, GGM): since round 6 no GEMM runs -- the conjugation
+        # kernel contracts with the non-zeros itself; the rate below is then what a GEMM would have had to sustain
+        fused = d in (12, 16) and not args.dense_basis and not os.environ.get('FFK_LIOUVILLE_GEMM')
+        what = 'fused sparse contraction; a GEMM of' if fused else 'GEMM'
+        print(f'd={d:2d} N={N:3d} batch={B}: {t*1e3:9.1f} us per call, {what} {flops/1e9:8.3f} GFLOP '
+              f'{"would need" if fused else "executed ->"} {flops/(t*1e-3)/1e12:6.2f} TFLOP/s over the whole call '
+              f'({flops_plain/(t*1e-3)/1e12:6.2f} at the plain trace\'s 2 d^2 rows); max abs err {err:.1e}')
 
 
 if __name__ == '__main__':
