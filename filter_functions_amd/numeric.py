@@ -807,8 +807,8 @@ def error_transfer_matrix(pulse=None, spectrum=None, omega=None, n_oper_identifi
                           memory_parsimonious=False, cache_intermediates=False):
     r"""Error transfer matrix :math:`\langle\tilde{\mathcal{U}}\rangle = \exp\mathcal{K}`
     (reference numeric.py:1938-2059): the cumulant function summed over the noise operators,
-    exponentiated (one ``d**2 x d**2`` real matrix; ``scipy.linalg.expm`` on the host like the
-    reference)."""
+    exponentiated (one ``d**2 x d**2`` real matrix: scaling and squaring on the GPU, ``ffk_expm_real``; the
+    reference calls ``scipy.linalg.expm``)."""
     from scipy import linalg as sla
 
     if cumulant_function is None:
@@ -827,8 +827,9 @@ def error_transfer_matrix(pulse=None, spectrum=None, omega=None, n_oper_identifi
     K = cumulant_function.sum(axis=tuple(range(cumulant_function.ndim - 2)))
     if K.shape[0] != K.shape[1]:
         raise ValueError(f'cumulant_function invalid shape: {cumulant_function.shape}')
-    if np.iscomplexobj(K) or K.shape[0] < 32 or not np.isfinite(K).all():
-        return sla.expm(K)       # tiny or unusual input: SciPy, exactly like the reference
+    if np.iscomplexobj(K) or not np.isfinite(K).all():
+        # not a cumulant function (those are real and finite): what the reference's call does with it
+        return sla.expm(K)
     K = as_f64(K)
     out = np.empty_like(K)
     check(_lib.load().ffk_expm_real(ptr(K), K.shape[0], ptr(out)))

@@ -1116,7 +1116,8 @@ def test_expansion_in_the_accumulate_kernels_epilogue(d, A, btype):
     assert rel_err(F, orc.filter_function(R_ref)) < TOL
 
 
-@pytest.mark.parametrize('N,scale', [(36, 1e-4), (64, 0.3), (100, 5.0), (256, 1e-3), (256, 40.0), (33, 0.0)])
+@pytest.mark.parametrize('N,scale', [(36, 1e-4), (64, 0.3), (100, 5.0), (256, 1e-3), (256, 40.0), (33, 0.0), (4, 0.5),
+                                     (9, 3.0), (16, 1e-3), (1, 2.0)])
 def test_matrix_exponential_against_scipy(N, scale):
     """ffk_expm_real (scaling and squaring, Taylor degree 18, MFMA products) against
     scipy.linalg.expm, which the reference's error_transfer_matrix calls (numeric.py:2051)."""
@@ -1130,7 +1131,7 @@ def test_matrix_exponential_against_scipy(N, scale):
                                          out.ctypes.data_as(ctypes.c_void_p)))
     ref = expm(K)
     assert np.abs(out - ref).max() <= 1e-12*max(np.abs(ref).max(), 1.0)
-    # the public function takes the same route for N >= 32
+    # the public function takes the same route
     U = ff.error_transfer_matrix(cumulant_function=K[None])
     assert np.array_equal(U, out)
 
