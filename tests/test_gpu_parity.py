@@ -2255,14 +2255,19 @@ def test_libffk_before_torch_shares_one_hip_runtime():
             'x = torch.ones(4, device="cuda")\n'
             'assert float(x.sum()) == 4.0\n'
             'print("shared", D.ravel())\n')
-    try:
-        res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True,
-                             timeout=240)
-    except subprocess.TimeoutExpired:
-        # seen once in about ten runs of the suite on the pool's boxes (round 5): the second process printed nothing
-        # in 300 s -- it hung somewhere in its own GPU start-up, with the same library that passes before and after.
-        # What the test pins is the ORDER of initialisation in a child that does start.
-        pytest.skip('the child interpreter did not get through GPU start-up in 240 s (environment)')
+    # Seen once in about ten runs of the suite on the pool's boxes (round 5): the child printed nothing in 300 s -- it
+    # hung somewhere in its own GPU start-up, with the same library that passes before and after.  One hang is retried
+    # in a fresh child; two in a row are reported as a failure (a real initialisation-order deadlock between libffk
+    # and torch is exactly what this test exists to catch -- ADVICE r5).
+    res, hung = None, []
+    for attempt in range(2):
+        try:
+            res = subprocess.run([sys.executable, '-c', code], cwd=ROOT, capture_output=True, text=True,
+                                 timeout=200)
+            break
+        except subprocess.TimeoutExpired as exc:
+            hung.append((exc.stderr or b'')[-1000:])
+    assert res is not None, f'the child interpreter hung twice in GPU start-up: {hung}'
     assert res.returncode == 0 and 'shared' in res.stdout, res.stderr[-2000:]
 
 
