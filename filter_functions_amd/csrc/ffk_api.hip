@@ -136,16 +136,18 @@ double accumulate_flops(int W, int A, int G, int d) {
     // 1) + 62 (two sincos and psi).
     if (d == 4 && ffk::pq_accumulate_supported(d, A)) {
         // ctrl_pq.hip (round 5; the default): per operator the first product 16 x (2 mul + 6 fma) = 224,
-        // zr + zi 16, the second product as THREE real 4 x 4 x 4 matrix products (Gauss) 3 x 128 = 384 = 624 --
-        // and blocks of nc = min(3, A) operators execute nc of them whether or not the last block is
-        // full; per block the tile 13 x 10 + 62 = 192 and c = psi conj(T), cr + ci: 16 x 7 = 112.
+        // zr + zi 16, the second product as THREE real 4 x 4 x 4 matrix products (Gauss) 3 x 128 = 384 = 624;
+        // per group of operators (ctrl_pq.hip::pq_accumulate_groups) the tile 13 x 10 + 62 = 192 and c = psi conj(T),
+        // cr + ci: 16 x 7 = 112.
         // The fold of W_a (6 per operator for Bbar times e^{ib} T, 6 per block for that product) is NOT counted:
         // this entry point has the prologue kernel do it once per segment (ffk_internal.h wfold), the kernel
         // copies it.  (Until the last change of round 5 the kernel folded it per frequency block: 630 nc + 310.)
         const ffk::AccumGeometry geo = ffk::accumulate_geometry(W, A, G, d, g_forced_chunks);
         if (geo.pc) {
-            const int nc = A >= 3 ? 3 : A;
-            return (624.0*nc + 304.0)*double((A + nc - 1)/nc)*double(G)*double(W);
+            // round 6: groups of three, of two and (A = 1) of one operator, each executing exactly its own
+            const ffk::PqGroups gr = ffk::pq_accumulate_groups(A);
+            const double per_gw = 624.0*A + 304.0*(gr.n3 + gr.n2 + gr.n1);
+            return per_gw*double(G)*double(W);
         }
     }
     // d = 8 (ctrl_pcr.hip, round 4): per operator the first product real x complex 4 d^3 = 2048, psi P

@@ -13,6 +13,7 @@
 // The imaginary GEMM is skipped for Hermitian bases, where the reference returns the real part
 // only (basis.py:692 `cast`).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "ffk_internal.h"
@@ -47,6 +48,23 @@ __global__ void build_bop_kernel(const cplx* __restrict__ basis, int N, int d, i
 // elements) a column of Bop has 8-16 resp. 1-16 non-zeros of its d^2 rows: the contraction with it is a gather of a
 // handful of terms, not a GEMM.  One wavefront per column lists them in ascending row order (64 rows per step,
 // positions from the ballot); a column with more than kLvNzMax raises `dense`, and the call runs as the GEMM.
+#ifdef FFK_LV_TRACE   /* tuning build: when is a block of the fused conjugation in which phase? (100 MHz ticks) */
+__device__ unsigned long long g_lv_trace[6*8192];
+#define FFK_LV_STAMP(k) \
+    if (threadIdx.x == 0) { \
+        const unsigned lv_l = blockIdx.x + gridDim.x*blockIdx.y; \
+        if (lv_l < 8192) g_lv_trace[6*lv_l + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    }
+#define FFK_LV_HWID \
+    if (threadIdx.x == 0) { \
+        const unsigned lv_l = blockIdx.x + gridDim.x*blockIdx.y; \
+        if (lv_l < 8192) g_lv_trace[6*lv_l + 5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | \
+            (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11))) << 32); \
+    }
+#else
+#define FFK_LV_STAMP(k)
+#define FFK_LV_HWID
+#endif
 constexpr int kLvNzMax = 32;
 struct OperandLists {
     int* dense;        // != 0: some column has more than kLvNzMax non-zeros
@@ -262,7 +280,8 @@ __global__ __launch_bounds__(256) void conjugate_basis_rows_kernel(const cplx* _
 // each -- and writes 16 rows of L; the 0.25 GB operand (d = 16, batch 512) is neither written nor read back, the GEMM
 // does not run.  `dense` decides on the device which of the two forms works; the other one's blocks all return.
 template <int D, bool HERM, bool FUSED = false>
-__global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kernel(const cplx* __restrict__ U,
+__global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kernel(
+    const cplx* __restrict__ U,
                                                                      const cplx* __restrict__ basis, int N,
                                                                      int Npad, int want_imag,
                                                                      double* __restrict__ AopRe,
@@ -272,7 +291,18 @@ __global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kerne
     static_assert(D % 4 == 0 && D <= 16, "d = 4, 8, 12, 16");
     static_assert(HERM || !FUSED, "the fused form keeps the Hermitian operand's rows");
     constexpr int DD = D*D, NS = D/4, EPB = 16, ROW = EPB + 1;
-    if (lists.dense != nullptr && (*lists.dense != 0) == FUSED) return;     // (every block of the launch alike)
+    // which form works is decided on the device (every block of a launch alike).  The fused form reads the flag
+    // BESIDE its first operands and looks at it behind the first barrier: as the kernel's first statement it was a
+    // round trip to memory of its own at the head of every block (2-3 us under this kernel's load, of 20 per block:
+    // tools/tuning/trace_liouville_blocks.py)
+    int dense_now = 0;
+    if constexpr (FUSED) {
+        FFK_LV_STAMP(0)
+        FFK_LV_HWID
+        dense_now = *lists.dense;
+    } else if (lists.dense != nullptr && *lists.dense == 0) {
+        return;
+    }
     __shared__ cplx Us[DD];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double* tre = reinterpret_cast<double*>(lds_raw);                  // [2 DD][ROW]
@@ -290,11 +320,13 @@ __global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kerne
     for (int s = 0; s < NS; ++s) x0[s] = Ci[(4*s + q)*D + c4];
     if (tid < DD) Us[tid] = U[static_cast<size_t>(bt)*DD + tid];
     __syncthreads();
+    if (FUSED && dense_now != 0) return;
     cplx tq[NS][NS];                                  // U[4 s + q][4 g + c4]
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int g = 0; g < NS; ++g) tq[s][g] = Us[(4*s + q)*D + 4*g + c4];
+    if constexpr (FUSED) { FFK_LV_STAMP(1) }
     double Yr[NS][NS], Yi[NS][NS];                    // Y[4 ig + q][4 jg + c4]
 #pragma unroll
     for (int ig = 0; ig < NS; ++ig)
@@ -340,6 +372,7 @@ __global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kerne
         }
     }
     const bool valid = i < N;
+    if constexpr (FUSED) { FFK_LV_STAMP(2) }
     if constexpr (HERM) {
         // the tile holds the operand's rows directly (hermitian_operand_row: d^2 of them), and the
         // copy-out writes 16 bytes per lane: eight lanes per 128-byte row
@@ -377,44 +410,73 @@ __global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kerne
             const int n = lists.count[col];
             request(col, 0);
             __syncthreads();
+            FFK_LV_STAMP(3)
             if (tid >= DD) return;
             double acc[EPB];
 #pragma unroll
             for (int jj = 0; jj < EPB; ++jj) acc[jj] = 0.0;
+            // A row of the tile = eight ds_read2_b64 as ONE asm statement; the next row is requested before the current
+            // one is waited for (s_waitcnt lgkmcnt(8): the eight younger reads may still fly).  The statements name
+            // the running sums as inputs they do not use, so that a request stays behind the multiply-adds of the row
+            // before last -- whose registers it reuses --: left to the scheduler all 256 reads of a batch are
+            // requested first and ~500 registers spill.
+#define FFK_LV_READ_ROW(r, k)                                                                                        \
+    {                                                                                                                \
+        const unsigned addr_ = static_cast<unsigned>(reinterpret_cast<uintptr_t>(tre + (k)*ROW));                   \
+        asm volatile("ds_read2_b64 %0, %8 offset1:1\n\t"                                                            \
+                     "ds_read2_b64 %1, %8 offset0:2 offset1:3\n\t"                                                  \
+                     "ds_read2_b64 %2, %8 offset0:4 offset1:5\n\t"                                                  \
+                     "ds_read2_b64 %3, %8 offset0:6 offset1:7\n\t"                                                  \
+                     "ds_read2_b64 %4, %8 offset0:8 offset1:9\n\t"                                                  \
+                     "ds_read2_b64 %5, %8 offset0:10 offset1:11\n\t"                                                \
+                     "ds_read2_b64 %6, %8 offset0:12 offset1:13\n\t"                                                \
+                     "ds_read2_b64 %7, %8 offset0:14 offset1:15"                                                     \
+                     : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]),    \
+                       "=&v"(r[7])                                                                                   \
+                     : "v"(addr_), "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]),     \
+                       "v"(acc[6]), "v"(acc[7]), "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]), "v"(acc[12]), \
+                       "v"(acc[13]), "v"(acc[14]), "v"(acc[15])                                                      \
+                     : "memory");                                                                                    \
+    }
+#define FFK_LV_WAIT_ROW(r, younger)                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(" #younger ")"                                                                   \
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])    \
+                 :                                                                                                   \
+                 : "memory");
             for (int base = 0;;) {
+                double2_t ra[EPB/2], rb[EPB/2];
+                FFK_LV_READ_ROW(ra, kk[0][0])
 #pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    // the row's 16 entries as one asm statement with its own wait, which names the running sums as
-                    // inputs it does not use -- so that it stays behind the previous row's multiply-adds: left to
-                    // the scheduler all 256 reads of the batch are requested first and ~500 registers spill
-                    const unsigned addr = static_cast<unsigned>(reinterpret_cast<uintptr_t>(tre + kk[t/4][t%4]*ROW));
-                    const double v = vv[t/2][t%2];
-                    double2_t r[EPB/2];
-                    asm volatile("ds_read2_b64 %0, %8 offset1:1\n\t"
-                                 "ds_read2_b64 %1, %8 offset0:2 offset1:3\n\t"
-                                 "ds_read2_b64 %2, %8 offset0:4 offset1:5\n\t"
-                                 "ds_read2_b64 %3, %8 offset0:6 offset1:7\n\t"
-                                 "ds_read2_b64 %4, %8 offset0:8 offset1:9\n\t"
-                                 "ds_read2_b64 %5, %8 offset0:10 offset1:11\n\t"
-                                 "ds_read2_b64 %6, %8 offset0:12 offset1:13\n\t"
-                                 "ds_read2_b64 %7, %8 offset0:14 offset1:15\n\t"
-                                 "s_waitcnt lgkmcnt(0)"
-                                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]),
-                                   "=&v"(r[6]), "=&v"(r[7])
-                                 : "v"(addr), "v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]), "v"(acc[4]), "v"(acc[5]),
-                                   "v"(acc[6]), "v"(acc[7]), "v"(acc[8]), "v"(acc[9]), "v"(acc[10]), "v"(acc[11]),
-                                   "v"(acc[12]), "v"(acc[13]), "v"(acc[14]), "v"(acc[15])
-                                 : "memory");
+                for (int t = 0; t < NB; t += 2) {
+                    FFK_LV_READ_ROW(rb, kk[(t + 1)/4][(t + 1)%4])
+                    FFK_LV_WAIT_ROW(ra, 8)
+                    {
+                        const double v = vv[t/2][t%2];
 #pragma unroll
-                    for (int jj = 0; jj < EPB; ++jj) acc[jj] = fma(r[jj/2][jj%2], v, acc[jj]);
+                        for (int jj = 0; jj < EPB; ++jj) acc[jj] = fma(ra[jj/2][jj%2], v, acc[jj]);
+                    }
+                    if (t + 2 < NB) {
+                        FFK_LV_READ_ROW(ra, kk[(t + 2)/4][(t + 2)%4])
+                        FFK_LV_WAIT_ROW(rb, 8)
+                    } else {
+                        FFK_LV_WAIT_ROW(rb, 0)
+                    }
+                    {
+                        const double v = vv[(t + 1)/2][(t + 1)%2];
+#pragma unroll
+                        for (int jj = 0; jj < EPB; ++jj) acc[jj] = fma(rb[jj/2][jj%2], v, acc[jj]);
+                    }
                 }
                 base += NB;
                 if (base >= n) break;
                 request(col, base);
             }
+#undef FFK_LV_READ_ROW
+#undef FFK_LV_WAIT_ROW
             double* o = out + (static_cast<size_t>(bt)*DD + i0)*DD + col;
 #pragma unroll
             for (int jj = 0; jj < EPB; ++jj) o[jj*DD] = acc[jj];
+            FFK_LV_STAMP(4)
             return;
         }
         __syncthreads();
@@ -709,6 +771,12 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
                                                         static_cast<int>(lds));
                     if (e2 != hipSuccess) return e2;
                 }
+                if (std::getenv("FFK_DEBUG_OCCUPANCY")) {
+                    int per_cu = -1;
+                    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256,
+                                                                       lds);
+                    fprintf(stderr, "conjugate_basis_mfma: %zu bytes of LDS -> %d blocks per CU\n", lds, per_cu);
+                }
                 hipLaunchKernelGGL(kern, dim3((N + 15)/16, nb), dim3(256), lds, stream, Us, basis, N, Npad,
                                    want_imag, are, aim, lists, o);
                 return hipGetLastError();
@@ -803,3 +871,10 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
 }
 
 }  // namespace ffk
+
+#ifdef FFK_LV_TRACE
+// (tuning build only, not in include/ffk.h) per block of the last fused launch: five stamps and the hardware id
+extern "C" int ffk_debug_lv_trace(unsigned long long* out, int n_blocks) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ffk::g_lv_trace), sizeof(unsigned long long)*6*n_blocks) != hipSuccess;
+}
+#endif
