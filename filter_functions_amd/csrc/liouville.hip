@@ -50,6 +50,11 @@ __global__ void build_bop_kernel(const cplx* __restrict__ basis, int N, int d, i
 // positions from the ballot); a column with more than kLvNzMax raises `dense`, and the call runs as the GEMM.
 #ifdef FFK_LV_TRACE   /* tuning build: when is a block of the fused conjugation in which phase? (100 MHz ticks) */
 __device__ unsigned long long g_lv_trace[6*8192];
+#define FFK_LV_STAMP_AT(k, T) \
+    if (threadIdx.x == (T)) { \
+        const unsigned lv_l = blockIdx.x + gridDim.x*blockIdx.y; \
+        if (lv_l < 8192) g_lv_trace[6*lv_l + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    }
 #define FFK_LV_STAMP(k) \
     if (threadIdx.x == 0) { \
         const unsigned lv_l = blockIdx.x + gridDim.x*blockIdx.y; \
@@ -63,13 +68,15 @@ __device__ unsigned long long g_lv_trace[6*8192];
     }
 #else
 #define FFK_LV_STAMP(k)
+#define FFK_LV_STAMP_AT(k, T)
 #define FFK_LV_HWID
 #endif
 constexpr int kLvNzMax = 32;
 struct OperandLists {
     int* dense;        // != 0: some column has more than kLvNzMax non-zeros
     int* count;        // [Npad]
-    int* row;          // [Npad][kLvNzMax]  a column's entries side by side (a thread fetches 16 of them with four
+    int* row;          // [Npad][kLvNzMax]  (as offsets into the fused kernel's tile, fused_tile_offset) a column's
+                       //                   entries side by side (a thread fetches 16 of them with four
     double* value;     // [Npad][kLvNzMax]  resp. eight 16-byte loads); entries past the count: row 0, value 0
 };
 size_t operand_lists_bytes(int Npad) {
@@ -85,8 +92,28 @@ OperandLists slice_operand_lists(void* ws, int Npad) {
     L.value = reinterpret_cast<double*>(p);
     return L;
 }
+// Row k of the Hermitian operand (hermitian_operand_row) -> slot of the persistent fused kernel's tile: entry (a, b),
+// a <= b, keeps its real part at a d + b and (a < b) minus its imaginary part at b d + a -- slots a lane of the
+// conjugation reaches with one per-lane base and an immediate.
+__device__ inline int hermitian_row_to_slot(int k, int d) {
+    if (k < d) return k*d + k;
+    const int p = (k - d) >> 1, imag_part = (k - d) & 1;
+    int a = 0;
+    while ((a + 1)*(2*d - a - 2)/2 <= p) ++a;
+    const int b = p - a*(2*d - a - 1)/2 + a + 1;
+    return imag_part ? b*d + a : a*d + b;
+}
+
+// ... and the slot's place in the tile, in doubles: 17 per slot (16 elements + 1) and one more per d slots, so that
+// BOTH neighbours of an entry -- (a, b + 1) and (a + 1, b), 1 resp. d slots away -- start 34 banks further on: a
+// wavefront's 64 columns ask for rows that differ in a or in b (Pauli: eight distinct b for the real parts, eight
+// distinct a for the imaginary parts); with 17 d doubles between (a, b) and (a + 1, b) every second of those met in one
+// bank (SQ_LDS_BANK_CONFLICT: 55 % of the LDS cycles of the first build)
+__host__ __device__ constexpr int fused_tile_offset(int slot, int d) { return slot*17 + slot/d; }
+__host__ __device__ constexpr int fused_tile_doubles(int d) { return d*d*17 + d; }
+
 __global__ __launch_bounds__(64) void operand_lists_kernel(const double* __restrict__ Bop, int K, int Npad,
-                                                           OperandLists L) {
+                                                           OperandLists L, int slots_of_d) {
     const int j = blockIdx.x, lane = threadIdx.x;
     int* rows = L.row + static_cast<size_t>(j)*kLvNzMax;
     double* values = L.value + static_cast<size_t>(j)*kLvNzMax;
@@ -98,7 +125,7 @@ __global__ __launch_bounds__(64) void operand_lists_kernel(const double* __restr
         const unsigned long long mask = __builtin_amdgcn_ballot_w64(nz);
         const int pos = n + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
         if (nz && pos < kLvNzMax) {
-            rows[pos] = k;
+            rows[pos] = slots_of_d > 0 ? fused_tile_offset(hermitian_row_to_slot(k, slots_of_d), slots_of_d) : k;
             values[pos] = v;
         }
         n += __builtin_popcountll(mask);
@@ -374,17 +401,31 @@ __global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kerne
     const bool valid = i < N;
     if constexpr (FUSED) { FFK_LV_STAMP(2) }
     if constexpr (HERM) {
-        // the tile holds the operand's rows directly (hermitian_operand_row: d^2 of them), and the
-        // copy-out writes 16 bytes per lane: eight lanes per 128-byte row
+        if constexpr (FUSED) {
+            // entry (a, b) = (4 ig + q, 4 jg + c4), a <= b: Re at slot a D + b, -Im (a < b) at slot b D + a, slots
+            // placed by fused_tile_offset: one per-lane base each and an immediate (the operand's own row numbers cost
+            // ~200 integer instructions per block here)
+            const int base_re = fused_tile_offset(q*D + c4, D) + j, base_im = fused_tile_offset(c4*D + q, D) + j;
 #pragma unroll
-        for (int ig = 0; ig < NS; ++ig)
+            for (int ig = 0; ig < NS; ++ig)
 #pragma unroll
-            for (int jg = ig; jg < NS; ++jg) {
-                const int a = 4*ig + q, b2 = 4*jg + c4;
-                const int r0 = hermitian_operand_row(a, b2, 0, D), r1 = hermitian_operand_row(a, b2, 1, D);
-                if (r0 >= 0) tre[r0*ROW + j] = valid ? Yr[ig][jg] : 0.0;
-                if (r1 >= 0) tre[r1*ROW + j] = valid ? -Yi[ig][jg] : 0.0;
-            }
+                for (int jg = ig; jg < NS; ++jg) {
+                    if (ig < jg || q <= c4) tre[base_re + (4*ig*D + 4*jg)*ROW + 4*ig] = Yr[ig][jg];
+                    if (ig < jg || q < c4) tre[base_im + (4*jg*D + 4*ig)*ROW + 4*jg] = -Yi[ig][jg];
+                }
+        } else {
+            // the tile holds the operand's rows directly (hermitian_operand_row: d^2 of them), and the
+            // copy-out writes 16 bytes per lane: eight lanes per 128-byte row
+#pragma unroll
+            for (int ig = 0; ig < NS; ++ig)
+#pragma unroll
+                for (int jg = ig; jg < NS; ++jg) {
+                    const int a = 4*ig + q, b2 = 4*jg + c4;
+                    const int r0 = hermitian_operand_row(a, b2, 0, D), r1 = hermitian_operand_row(a, b2, 1, D);
+                    if (r0 >= 0) tre[r0*ROW + j] = valid ? Yr[ig][jg] : 0.0;
+                    if (r1 >= 0) tre[r1*ROW + j] = valid ? -Yi[ig][jg] : 0.0;
+                }
+        }
         if constexpr (FUSED) {
             // L[bt][i0 + jj][col] = sum over the non-zero rows k of column col: tile[k][jj] Bop[k][col], k ascending.
             // Sixteen list entries are requested at once -- the first batch before the barrier that completes the
@@ -407,7 +448,12 @@ __global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kerne
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the requests stay behind the tile's stores)
             // (the fused form is launched for complete bases only, N = d^2: a column per thread, no edge)
             const int col = tid < DD ? tid : 0;
-            const int n = lists.count[col];
+            // the longest list among the wavefront's columns: the gather's trip count (wave-uniform; a Pauli element
+            // has 8 or 16 non-zero rows, a GGM element mostly 1 or 2)
+            int n_wave = lists.count[col];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) n_wave = max(n_wave, __shfl_xor(n_wave, off, 64));
+            n_wave = __builtin_amdgcn_readfirstlane(n_wave);
             request(col, 0);
             __syncthreads();
             FFK_LV_STAMP(3)
@@ -415,14 +461,15 @@ __global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kerne
             double acc[EPB];
 #pragma unroll
             for (int jj = 0; jj < EPB; ++jj) acc[jj] = 0.0;
-            // A row of the tile = eight ds_read2_b64 as ONE asm statement; the next row is requested before the current
-            // one is waited for (s_waitcnt lgkmcnt(8): the eight younger reads may still fly).  The statements name
-            // the running sums as inputs they do not use, so that a request stays behind the multiply-adds of the row
-            // before last -- whose registers it reuses --: left to the scheduler all 256 reads of a batch are
-            // requested first and ~500 registers spill.
+            // A row of the tile = eight ds_read2_b64 as ONE asm statement (the list entry IS the row's offset in the
+            // tile, fused_tile_offset); rows go in pairs, the second requested before the first is waited for
+            // (s_waitcnt lgkmcnt(8): the eight younger reads may still fly).  The statements name the running sums as
+            // inputs they do not use, so that a request stays behind the multiply-adds of the pair before -- whose
+            // registers it reuses --: left to the scheduler all 256 reads of a batch are requested first and ~500
+            // registers spill.
 #define FFK_LV_READ_ROW(r, k)                                                                                        \
     {                                                                                                                \
-        const unsigned addr_ = static_cast<unsigned>(reinterpret_cast<uintptr_t>(tre + (k)*ROW));                   \
+        const unsigned addr_ = static_cast<unsigned>(reinterpret_cast<uintptr_t>(tre + (k)));                       \
         asm volatile("ds_read2_b64 %0, %8 offset1:1\n\t"                                                            \
                      "ds_read2_b64 %1, %8 offset0:2 offset1:3\n\t"                                                  \
                      "ds_read2_b64 %2, %8 offset0:4 offset1:5\n\t"                                                  \
@@ -445,9 +492,10 @@ __global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kerne
                  : "memory");
             for (int base = 0;;) {
                 double2_t ra[EPB/2], rb[EPB/2];
-                FFK_LV_READ_ROW(ra, kk[0][0])
 #pragma unroll
                 for (int t = 0; t < NB; t += 2) {
+                    if (base + t >= n_wave) break;
+                    FFK_LV_READ_ROW(ra, kk[t/4][t%4])
                     FFK_LV_READ_ROW(rb, kk[(t + 1)/4][(t + 1)%4])
                     FFK_LV_WAIT_ROW(ra, 8)
                     {
@@ -455,12 +503,7 @@ __global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kerne
 #pragma unroll
                         for (int jj = 0; jj < EPB; ++jj) acc[jj] = fma(ra[jj/2][jj%2], v, acc[jj]);
                     }
-                    if (t + 2 < NB) {
-                        FFK_LV_READ_ROW(ra, kk[(t + 2)/4][(t + 2)%4])
-                        FFK_LV_WAIT_ROW(rb, 8)
-                    } else {
-                        FFK_LV_WAIT_ROW(rb, 0)
-                    }
+                    FFK_LV_WAIT_ROW(rb, 0)
                     {
                         const double v = vv[(t + 1)/2][(t + 1)%2];
 #pragma unroll
@@ -468,7 +511,7 @@ __global__ __launch_bounds__(256, FUSED ? 3 : 1) void conjugate_basis_mfma_kerne
                     }
                 }
                 base += NB;
-                if (base >= n) break;
+                if (base >= n_wave) break;
                 request(col, base);
             }
 #undef FFK_LV_READ_ROW
@@ -740,7 +783,7 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
         lists = slice_operand_lists(AopIm, Npad);
         hipError_t err = hipMemsetAsync(lists.dense, 0, sizeof(int), stream);
         if (err != hipSuccess) return err;
-        hipLaunchKernelGGL(operand_lists_kernel, dim3(Npad), dim3(64), 0, stream, Bop, K, Npad, lists);
+        hipLaunchKernelGGL(operand_lists_kernel, dim3(Npad), dim3(64), 0, stream, Bop, K, Npad, lists, d);
     }
     // the batch axis rides on grid.y / grid.z (at most 65535 blocks): longer batches (the
     // propagators of a 200 000-segment pulse) go in slabs
@@ -763,7 +806,7 @@ hipError_t launch_liouville(const cplx* U, int batch, int d, const cplx* basis, 
         // d = 12, 16: the conjugation on the matrix cores
         if (d == 16 || d == 12) {
             // (Hermitian basis: the tile holds the operand's d^2 rows only)
-            const size_t lds = static_cast<size_t>(want_imag ? 4 : 1)*d*d*17*sizeof(double);
+            const size_t lds = static_cast<size_t>(want_imag ? 4 : 1)*fused_tile_doubles(d)*sizeof(double);   // (d more than d^2 x 17: the fused form's padding)
             auto go = [&](auto kern) -> hipError_t {
                 if (lds > 40*1024) {
                     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -29,6 +29,25 @@ nblk = 8192
 tr = (ctypes.c_ulonglong*(6*nblk))()
 lib.ffk_debug_lv_trace(tr, nblk)
 tr = np.array(tr, dtype=np.uint64).reshape(nblk, 6)
+if not os.environ.get('FFK_LIOUVILLE_FUSED', '').startswith('b'):
+    # the persistent form: a block per batch element (or share): start, U staged, first group's matrix instructions done,
+    # first barrier, conjugating wavefronts done, (the gather's end in place of the hardware id)
+    tr = tr[tr[:, 4] > 0]
+    t0 = tr[:, 0].min()
+    st = (tr[:, :5].astype(np.int64) - int(t0))/100.0
+    gend = (tr[:, 5].astype(np.int64) - int(t0))/100.0
+    print('blocks', len(tr), 'span %.1f us' % max(st[:, 4].max(), gend.max()))
+    for name, col in (('head (U, first operands, barrier)', st[:, 1] - st[:, 0]),
+                      ('first group: matrix instructions', st[:, 2] - st[:, 1]),
+                      ('first group: tile + barrier', st[:, 3] - st[:, 2]),
+                      ('all groups, conjugating wavefronts', st[:, 4] - st[:, 1]),
+                      ('gather behind the conjugation', gend - st[:, 4])):
+        print(f'  {name:36s}: median {np.median(col):7.2f} us, 10 % {np.percentile(col, 10):7.2f}, 90 % {np.percentile(col, 90):7.2f}')
+    order = np.argsort(st[:, 0])
+    print('first and last blocks to start (start, head done, mfma 1 done, barrier 1, conj done, gather done):')
+    for b in list(order[:4]) + list(order[-4:]):
+        print('   ', ' '.join('%8.2f' % v for v in st[b]), '%8.2f' % gend[b])
+    sys.exit(0)
 t0 = tr[:, 0].min()
 st = (tr[:, :5] - t0)/100.0          # us
 hw = tr[:, 5] & 0xffffffff
