@@ -346,11 +346,11 @@ def bench_other_dimensions(ff, torch, lib, _lib, DevicePipeline, device, stream)
     the accumulate kernel by HIP events, its executed flops (ffk_api.hip::accumulate_flops) and the FP64 fraction.
     Reference loop numeric.py:707-881."""
     entries = []
-    shapes = [dict(d=2, G=256, A=3, W=4096, basis='GGM(2)', seed=52, kernel='ffk::ctrl_accumulate_kernel<2> (ctrl.hip)'),
+    shapes = [dict(d=2, G=256, A=3, W=4096, basis='GGM(2)', seed=52, kernel='ffk::ctrl_accumulate_d2_kernel<3> (ctrl_d2.hip)'),
               dict(d=3, G=256, A=3, W=4096, basis='GGM(3)', seed=53, kernel='ffk::ctrl_accumulate_kernel<3> (ctrl.hip)'),
               dict(d=6, G=250, A=6, W=400, basis='GGM(6)', seed=56, kernel='ffk::ctrl_accumulate_kernel<6> (ctrl.hip)'),
               dict(d=2, G=4096, A=2, W=500, basis='GGM(2)', seed=57,
-                   kernel='ffk::ctrl_accumulate_wave_kernel<2> (ctrl.hip, >= 1024 segments)')]
+                   kernel='ffk::ctrl_accumulate_d2_kernel<2> (ctrl_d2.hip; until late round 6 the one-wave kernel of ctrl.hip)')]
     for sh in shapes:
         d, G, A, W = sh['d'], sh['G'], sh['A'], sh['W']
         c_opers, c_coeffs, n_opers, n_coeffs, dt = wl.random_pulse_inputs(sh['seed'], d, G, A)
@@ -667,7 +667,7 @@ def bench_config3_optimized(ff):
         ms=float(np.median(times))*1e3, n_segments=int(len(total)),
         elements_per_s=cfg['n_gates']*cfg['W']*4/float(np.median(times)),
         gate_set_ms=t_gate_set*1e3, atoms_from_scratch_ms=float(np.median(t_atoms))*1e3, infidelity=infid,
-        note='gate_set_ms: both atoms from scratch (ffk::ctrl_accumulate_kernel<2>, 100 segments, 8192 omega) + 41 '
+        note='gate_set_ms: both atoms from scratch (ffk::ctrl_accumulate_d2_kernel, 100 segments, 8192 omega) + 41 '
              'concatenations building the 24 Cliffords, once; atoms_from_scratch_ms: the two atoms alone (PulseSequence + '
              'cache_control_matrix); ms: ff.concatenate + get_filter_function of the 1000-gate sequence, median of 8 '
              '(the coefficient tables of 332 200 segments are host bookkeeping)')

@@ -831,6 +831,30 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
         geo.chunks = (G + geo.chunk_len - 1)/geo.chunk_len;
         return geo;
     }
+    // d = 2: the folded-operand kernel (ctrl_d2.hip): blocks of independent wavefronts that split the block's segment
+    // chunk and add up through LDS; enough chunks for one block per CU, at least two segments per wavefront.  The tuning variants 1/2 select the kernels below.
+    if (g_use_gsplit && !g_use_wave_kernel && d2_accumulate_supported(d)) {
+        geo.d2 = true;
+        geo.mfma = false;
+        geo.wave_kernel = false;
+        geo.nwaves = d2_accumulate_waves();
+        geo.na_blk = d2_accumulate_ops_per_block(A);
+        geo.task_groups = (A + geo.na_blk - 1)/geo.na_blk;
+        geo.nbuf = 2;
+        geo.lds_bytes = d2_accumulate_lds_bytes(geo.na_blk);
+        int chunks = forced_chunks;
+        if (chunks <= 0) {
+            const int fpb = d2_accumulate_freqs_per_block();
+            const long tiles = static_cast<long>((W + fpb - 1)/fpb)*geo.task_groups;
+            const long want_waves = 8L*device_cu_count();      // one block of eight wavefronts per CU
+            chunks = static_cast<int>(std::max<long>(1, (want_waves + tiles*geo.nwaves - 1)/(tiles*geo.nwaves)));
+            chunks = std::min(chunks, std::max(1, G/(2*geo.nwaves)));
+        }
+        chunks = std::max(1, std::min(chunks, G));
+        geo.chunk_len = (G + chunks - 1)/chunks;
+        geo.chunks = (G + geo.chunk_len - 1)/geo.chunk_len;
+        return geo;
+    }
     // d = 8: producer/consumer kernel on the matrix cores with a real integral tile (ctrl_pcr.hip);
     // the tuning variants 1/2 (ffk_set_accumulate_variant) select the symmetric kernel below
     if (g_use_gsplit && !g_use_wave_kernel && pcr_accumulate_supported(d, A) && !geo.mfma) {
@@ -1006,6 +1030,7 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
     if (geo.generic)
         return launch_accumulate_generic(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
                                          stream);
+    if (geo.d2) return launch_accumulate_d2(omega, W, segtab, ops, G, A, geo.chunks, geo.chunk_len, Ypart, stream);
     if (geo.pc)
         return launch_accumulate_pq(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart, wfold,
                                     stream);

@@ -1,9 +1,3 @@
-// NOT BUILT.  A dedicated d = 2 accumulate kernel tried late in round 6 and dropped: folded operands (twelve complex
-// multiply-adds per operator, segment and frequency), eight independent wavefronts per block, partial sums added
-// through LDS.  Bit-for-bit correct against the whole GPU suite, but 43-45 us where the symmetric kernel of ctrl.hip
-// takes 36-39 (256 segments, 3 operators, 4096 omega): ablation builds put 8.6 us on launch + reduction + output
-// and ~17 us on a segment loop with its tile and all but one multiply-add removed -- four iterations per wavefront --,
-// which was not understood in the time left (profiles/r06_g_small_d_segment_split.txt, last section).
 // ctrl_d2.hip -- K3s: the control-matrix accumulation for d = 2 (one qubit; round 6).
 //     Y_a(w) = sum_g T_g^dag [ Bbar_a o E_g(w) ] T_g                    (reference numeric.py:846-869 / :596-609)
 // At d = 2 the integral tile has THREE distinct entries -- the diagonal (both entries coincide), (0, 1), (1, 0) -- and
@@ -22,7 +16,10 @@
 // ahead, beside the current segment's arithmetic), twelve more lanes bring the table row; the record is read back as
 // broadcasts.  At the end the eight partial sums are added through LDS in a fixed tree and ONE partial sum per block
 // is written (the chunks of a launch are the blocks along grid.z: 8 instead of 32 partial sums of A d^2 W at the
-// documentation's shapes).  Four wavefronts per SIMD cover one another's chains.
+// documentation's shapes).  164 registers: one block per CU, two wavefronts per SIMD; measured alternatives (128
+// registers with spills and two blocks per CU; blocks of four wavefronts, three per CU; two frequencies per lane) were
+// level or slower -- at ~350 instructions per segment of which half are not multiply-adds the kernel issues one
+// instruction per ~6.7 cycles and SIMD whatever the arrangement (profiles/r06_g_*, last section).
 #include <algorithm>
 
 #include "ffk_internal.h"
@@ -35,7 +32,7 @@ constexpr int kD2Waves = 8;
 using double4_t = __attribute__((ext_vector_type(4))) double;
 
 template <int AT>
-__global__ __launch_bounds__(kD2Waves*64, 4) void ctrl_accumulate_d2_kernel(
+__global__ __launch_bounds__(kD2Waves*64) void ctrl_accumulate_d2_kernel(
     const double* __restrict__ omega, int W, const double* __restrict__ segtab, const cplx* __restrict__ ops,
     int G, int A, int chunk_len, cplx* __restrict__ Ypart) {
     constexpr int D = 2, DD = 4, S = seg_stride(2);
@@ -59,41 +56,31 @@ __global__ __launch_bounds__(kD2Waves*64, 4) void ctrl_accumulate_d2_kernel(
     const int a = lane/12, which = (lane % 12)/4, e = lane % 4, i = e >> 1, j = e & 1;
     const bool is_m = lane < 12*na, is_row = lane >= NM && lane < NREC;
     const int m1 = which == 2 ? 1 : 0, n1 = which == 1 ? 1 : 0;      // M^d: (0,0) then (1,1); M^01: (0,1); M^10: (1,0)
-    struct Pending {
-        cplx b1, ti1, tj1, b2, ti2, tj2, row;
-    };
-    auto request = [&](int g) -> Pending {
-        Pending p = {};
+    // Seven loads per lane and segment from fixed per-lane offsets, NO branch around them and plain variables: with the
+    // loads under `if (is_m) .. else if (is_row)` (or in a struct returned from a lambda) the compiler kept the values
+    // in scratch memory and waited for every load on the spot -- 4 us per segment (profiles/r06_g_*, last section).
+    const int ob = is_m ? (1 + alpha0 + a)*DD : 0;
+    const int o_b1 = ob + (is_m ? m1*D + n1 : 0), o_ti1 = is_m ? m1*D + i : 0, o_tj1 = is_m ? n1*D + j : 0;
+    const int o_b2 = ob + (is_m ? 3 : 0), o_ti2 = is_m ? D + i : 0, o_tj2 = is_m ? D + j : 0;
+    const int o_row = is_row ? lane - NM : 0;
+    const double w2 = is_m && which == 0 ? 1.0 : 0.0;     // M^d has a second term
+    cplx p_b1, p_ti1, p_tj1, p_b2, p_ti2, p_tj2, p_row;
+    auto request = [&](int g) __attribute__((always_inline)) {
         const cplx* src = ops + static_cast<size_t>(g)*(1 + A)*DD;
-        if (is_m) {
-            const cplx* Bm = src + static_cast<size_t>(1 + alpha0 + a)*DD;
-            p.b1 = Bm[m1*D + n1];
-            p.ti1 = src[m1*D + i];
-            p.tj1 = src[n1*D + j];
-            if (which == 0) {
-                p.b2 = Bm[3];
-                p.ti2 = src[D + i];
-                p.tj2 = src[D + j];
-            }
-        } else if (is_row) {
-            p.row = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S)[lane - NM];
-        }
-        return p;
+        p_b1 = src[o_b1];
+        p_ti1 = src[o_ti1];
+        p_tj1 = src[o_tj1];
+        p_b2 = src[o_b2];
+        p_ti2 = src[o_ti2];
+        p_tj2 = src[o_tj2];
+        p_row = reinterpret_cast<const cplx*>(segtab + static_cast<size_t>(g)*S)[o_row];
     };
-    auto park = [&](const Pending& p, int buf) {
-        if (is_m) {
-            cplx v = cmul(cmul(p.b1, cplx{p.ti1.re, -p.ti1.im}), p.tj1);
-            if (which == 0) {
-                const cplx u = cmul(cmul(p.b2, cplx{p.ti2.re, -p.ti2.im}), p.tj2);
-                v.re += u.re;
-                v.im += u.im;
-            }
-            record[wave][buf][lane] = v;
-        } else if (lane < NM) {
-            record[wave][buf][lane] = {0.0, 0.0};        // operators beyond the launch's last one
-        } else if (is_row) {
-            record[wave][buf][lane] = p.row;
-        }
+    auto park = [&](int buf) __attribute__((always_inline)) {
+        const cplx v1 = cmul(cmul(p_b1, cplx{p_ti1.re, -p_ti1.im}), p_tj1);
+        const cplx v2 = cmul(cmul(p_b2, cplx{p_ti2.re, -p_ti2.im}), p_tj2);
+        cplx v = {fma(w2, v2.re, v1.re), fma(w2, v2.im, v1.im)};
+        if (!is_m) v = is_row ? p_row : cplx{0.0, 0.0};          // (operators beyond the launch's last one: zeros)
+        if (lane < NREC) record[wave][buf][lane] = v;
     };
 
     cplx Y[AT][DD];
@@ -102,21 +89,14 @@ __global__ __launch_bounds__(kD2Waves*64, 4) void ctrl_accumulate_d2_kernel(
 #pragma unroll
         for (int k = 0; k < DD; ++k) Y[q][k] = {0.0, 0.0};
 
-#if defined(FFK_D2_ABLATE) && (FFK_D2_ABLATE & 8)
-    const int g1_run = g0;
-#else
-    const int g1_run = g1;
-    if (g0 < g1) park(request(g0), 0);
-#endif
-    for (int g = g0; g < g1_run; ++g) {
+    if (g0 < g1) {
+        request(g0);
+        park(0);
+    }
+    for (int g = g0; g < g1; ++g) {
         const int buf = (g - g0) & 1;
         const bool more = g + 1 < g1;
-        Pending next = {};
-#if defined(FFK_D2_ABLATE) && (FFK_D2_ABLATE & 4)
-        if (more && g == g0) next = request(g + 1);
-#else
-        if (more) next = request(g + 1);
-#endif
+        if (more) request(g + 1);
         const cplx* rec = record[wave][buf];
         const double* st = reinterpret_cast<const double*>(rec + NM);
         // the tile: e^{i w t_g} I^(g), the diagonal entry and the two off-diagonal ones by angle addition from the
@@ -127,20 +107,12 @@ __global__ __launch_bounds__(kD2Waves*64, 4) void ctrl_accumulate_d2_kernel(
         const double dtg = st[0];
         cplx ph;
         double sa, ca;
-#if defined(FFK_D2_ABLATE) && (FFK_D2_ABLATE & 1)
-        ph = {om, 1.0}; sa = om; ca = 1.0;
-#else
         sincos_pi(om*st[1], &ph.im, &ph.re);
         sincos_pi(0.5*(om*dtg), &sa, &ca);
-#endif
         const PhasedFrequency pf = phased_frequency(om, dtg, ph, sa, ca);
         const double4_t r1 = *reinterpret_cast<const double4_t*>(st + seg_rec(1));
         const double4_t r2 = *reinterpret_cast<const double4_t*>(st + seg_rec(2));
         cplx Ed, Eo[2];
-#if defined(FFK_D2_ABLATE) && (FFK_D2_ABLATE & 1)
-        Ed = {om, dtg}; Eo[0] = {r1.x, om}; Eo[1] = {r2.x, dtg};
-        if (false)
-#endif
         {
             const double x0 = om, x1 = om + r1.x, x2 = om + r2.x;
             const double q0 = pf.sa2*rcp_fast(x0);
@@ -160,25 +132,18 @@ __global__ __launch_bounds__(kD2Waves*64, 4) void ctrl_accumulate_d2_kernel(
             if (q < na) {
 #pragma unroll
                 for (int k = 0; k < DD; ++k) {
-#if defined(FFK_D2_ABLATE) && (FFK_D2_ABLATE & 2)
-                    if (k > 0 || q > 0) continue;
-#endif
                     cmac(Y[q][k], Ed, rec[q*12 + k]);
                     cmac(Y[q][k], Eo[0], rec[q*12 + 4 + k]);
                     cmac(Y[q][k], Eo[1], rec[q*12 + 8 + k]);
                 }
             }
         }
-        if (more) park(next, buf ^ 1);
+        if (more) park(buf ^ 1);
     }
 
     // the eight partial sums in a fixed tree: (w, w + 4), (w, w + 2), (w, w + 1)
 #pragma unroll
-#if defined(FFK_D2_ABLATE) && (FFK_D2_ABLATE & 16)
-    for (int half = 0; half >= 1; half >>= 1) {
-#else
     for (int half = kD2Waves/2; half >= 1; half >>= 1) {
-#endif
         if (wave >= half && wave < 2*half) {
 #pragma unroll
             for (int q = 0; q < AT; ++q)
@@ -214,6 +179,7 @@ __global__ __launch_bounds__(kD2Waves*64, 4) void ctrl_accumulate_d2_kernel(
 
 bool d2_accumulate_supported(int d) { return d == 2; }
 int d2_accumulate_waves() { return kD2Waves; }
+int d2_accumulate_freqs_per_block() { return 64; }
 // operators per block: at most three (the reduction tree's LDS: 16 KB per operator), the groups of a launch as equal
 // as they come (4 -> 2 + 2, 5 -> 3 + 2)
 int d2_accumulate_ops_per_block(int A) {

@@ -150,6 +150,11 @@ double accumulate_flops(int W, int A, int G, int d) {
             return per_gw*double(G)*double(W);
         }
     }
+    // d = 2 (ctrl_d2.hip, round 6): the tile's three distinct entries as below (18 x 3 + 62 = 116), twelve complex
+    // multiply-adds per operator with the folded operands (96), the fold itself -- a lane's share of a segment's
+    // record: two triple products and an add -- 26.
+    if (d == 2 && ffk::accumulate_geometry(W, A, G, d, g_forced_chunks).d2)
+        return (96.0*A + 116.0 + 26.0)*double(G)*double(W);
     // d = 8 (ctrl_pcr.hip, round 4): per operator the first product real x complex 4 d^3 = 2048, psi P
     // 6 d^2 = 384, the second product complex 8 d^3 = 4096; per group of <= 3 operators the tile: 57 entries x 10 +
     // 62.  The fold of W' (one (m, n) per lane = per frequency: 9 complex products = 54 per operator) is NOT counted
@@ -539,7 +544,7 @@ int control_matrix_dev_impl(const double* eigvals, const double* eigvecs, const 
     g_stats.accumulate_bytes = double(sizeof(cplx))*(double(geo.chunks)*slab) + 8.0*W +
                                double(sizeof(cplx))*G*(double(1 + A)*d*d);
     g_stats.chunks = geo.chunks;
-    g_stats.grid_x = geo.mfma ? (W + 15)/16 : (W + 63)/64;
+    g_stats.grid_x = geo.mfma ? (W + 15)/16 : (geo.d2 ? (W + ffk::d2_accumulate_freqs_per_block() - 1)/ffk::d2_accumulate_freqs_per_block() : (W + 63)/64);
     g_stats.grid_y = geo.task_groups;
     g_stats.grid_z = geo.chunks;
     g_stats.block = geo.nwaves*geo.gsplit*64;

@@ -160,6 +160,7 @@ struct AccumGeometry {
     bool pc;          // producer/consumer kernel with the second product on the matrix cores (ctrl_pq.hip), d = 4
     bool pcw;         // producer/consumer kernel on the matrix cores (ctrl_pcr.hip), d = 8
     bool generic;     // runtime-d kernel (generic.hip), d > 16: one block per (frequency, operator, chunk)
+    bool d2 = false;  // folded-operand kernel for d = 2 (ctrl_d2.hip): independent wavefronts, one partial sum per block
 };
 void set_use_wave_kernel(bool on);
 void set_use_gsplit(bool on);
@@ -218,6 +219,15 @@ constexpr size_t wfold_elems(int d, int G, int A) {
 hipError_t launch_accumulate_pq(const double* omega, int W, const double* segtab, const cplx* ops,
                                 int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,
                                 const cplx* wfold, hipStream_t stream);
+
+// ---- ctrl_d2.hip (d = 2, folded operands) ------------------------------------------------------
+bool d2_accumulate_supported(int d);
+int d2_accumulate_waves();
+int d2_accumulate_freqs_per_block();
+int d2_accumulate_ops_per_block(int A);
+int d2_accumulate_lds_bytes(int ops_per_block);
+hipError_t launch_accumulate_d2(const double* omega, int W, const double* segtab, const cplx* ops, int G, int A,
+                                int chunks, int chunk_len, cplx* Ypart, hipStream_t stream);
 
 // ---- ctrl_pcr.hip (d = 8, real integral tile) --------------------------------------------------
 bool pcr_accumulate_supported(int d, int A);
