@@ -2607,6 +2607,53 @@ def test_d8_producer_consumer_kernel_ragged_shapes(G, A, W):
         lib.ffk_set_accumulate_variant(0)
 
 
+@pytest.mark.parametrize('G,A,W', [(1, 1, 1), (2, 3, 64), (7, 1, 70), (8, 2, 65), (9, 4, 130), (17, 7, 64), (100, 5, 300),
+                                    (33, 3, 129), (260, 3, 64), (64, 6, 31), (1100, 2, 200)])
+def test_d2_kernel_ragged_shapes(G, A, W):
+    """ctrl_d2.hip (one qubit): operands folded into three 2 x 2 matrices per segment and operator, eight wavefronts
+    per block that split the block's segment chunk and add up through LDS.  Fewer segments than wavefronts (some own
+    none), chunk counts that leave ragged sub-chunks, operator groups of 3 + 1 / 3 + 2 / 2 + 2, frequency tiles that
+    are not full, omega = 0 and a frequency on a resonance -- against the oracle and against the symmetric kernel
+    (tuning variant 2) it replaces.  Reference loop numeric.py:846-869."""
+    d = 2
+    rng = np.random.default_rng(200 + G*A + W)
+    basis = ff.Basis.pauli(1)
+    c_opers = rng.standard_normal((3, d, d)) + 1j*rng.standard_normal((3, d, d))
+    c_opers = c_opers + c_opers.conj().transpose(0, 2, 1)
+    n_opers = rng.standard_normal((A, d, d)) + 1j*rng.standard_normal((A, d, d))
+    n_opers = n_opers + n_opers.conj().transpose(0, 2, 1)
+    H = np.einsum('ijk,il->ljk', c_opers, rng.standard_normal((3, G)))
+    dt = 0.5 + rng.random(G)
+    n_coeffs = rng.random((A, G)) + 0.5
+    omega = np.concatenate(([0.0], np.geomspace(1e-3, 50, W - 1))) if W > 1 else np.array([0.3])
+    D, V, Q = numeric.diagonalize(H, dt)
+    if W > 4:
+        omega[3] = D[0, 1] - D[0, 0]                  # x = omega + dE = 0 exactly for one entry of segment 0
+    lib = _lib.load()
+    R = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+    st = _lib.stats()
+    assert st['block'] == 512 and st['grid_y'] == (A + 2)//3, st          # the d = 2 kernel ran, groups of <= 3
+    R_ref = orc.control_matrix_from_scratch(D, V, Q, omega, np.asarray(basis), n_opers, n_coeffs, dt)
+    assert rel_err(R, R_ref) < 1e-12
+    try:
+        for chunks in (1, 2, 3, 5):
+            _lib.check(lib.ffk_set_segment_chunks(chunks))
+            R_c = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+            assert rel_err(R_c, R_ref) < 1e-12, chunks
+        _lib.check(lib.ffk_set_segment_chunks(0))
+        _lib.check(lib.ffk_set_accumulate_variant(2))
+        R_sym = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+        assert _lib.stats()['block'] != 512 or _lib.stats()['grid_y'] != (A + 2)//3 or A > 3
+        assert rel_err(R_sym, R) < 1e-12
+    finally:
+        lib.ffk_set_segment_chunks(0)
+        lib.ffk_set_accumulate_variant(0)
+    # and the noise operators (the Hilbert-space twin reads the same accumulation)
+    B = numeric.calculate_noise_operators_from_scratch(D, V, Q, omega, n_opers, n_coeffs, dt)
+    B_ref = orc.noise_operators_from_scratch(D, V, Q, omega, n_opers, n_coeffs, dt)
+    assert rel_err(B, B_ref) < 1e-12
+
+
 @pytest.mark.parametrize('G,A,W', [(1, 1, 1), (40, 1, 130), (3, 2, 65), (70, 2, 200), (5, 4, 100), (64, 4, 257),
                                     (9, 5, 64), (33, 5, 300), (7, 7, 70), (50, 7, 129), (4, 8, 40), (6, 10, 31),
                                     (2, 13, 33), (300, 4, 64)])
