@@ -236,10 +236,12 @@ __global__ __launch_bounds__(64) void apply_prologue_kernel(
                 __syncthreads();
             }
             if (n & 1) {                            // the newest factor moves up unpaired
-                cplx carry = {0.0, 0.0};
-                if (lane < DD) carry = (&tot[n - 1][0][0])[lane];
+                // (two doubles read by every lane from a clamped index: as a struct copy the value was kept in SCRATCH
+                // memory across the barrier -- a trip to memory per odd level of the tree, in every pass; round 6)
+                const cplx* from = &tot[n - 1][0][0] + (lane < DD ? lane : 0);
+                const double carry_re = from->re, carry_im = from->im;      // (two doubles, not a struct copy)
                 __syncthreads();
-                if (lane < DD) (&tot[pairs][0][0])[lane] = carry;
+                if (lane < DD) (&tot[pairs][0][0])[lane] = {carry_re, carry_im};
                 __syncthreads();
             }
             n = pairs + (n & 1);
