@@ -195,7 +195,11 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
 
     // Phase A: this wave's share of e^{i w t_g} I^(g)[rows of stage][:] -> LDS, plus (stage 0)
     // the segment's operands T_g, Bbar_{alpha0..}^(g) and the table row of segment g + AHEAD -> LDS.
-    cplx staged = {0.0, 0.0};   // this thread's share of the staging copy, in flight across phase B
+    // this thread's share of the staging copy, in flight across phase B.  Two doubles and an UNCONDITIONAL load (round 6):
+    // as a `cplx` assigned under `if (e0 < n_ops) .. else if ..` the value lived in scratch memory, and every segment's
+    // staging load was waited for on the spot -- global_load; s_waitcnt vmcnt(0); scratch_store -- in every
+    // instantiation of this kernel (found through the same fault in ctrl_d2.hip's first build, profiles/r06_g_*)
+    double staged_re = 0.0, staged_im = 0.0;
     // fetch: issue the staging loads; generate: compute this wave's integral entries (the two
     // halves can be called apart, so that the loads are in flight across whatever runs between)
     auto phase_a = [&](int g, int stage, int buf, int row_slot, int trig_slot, bool fetch = true,
@@ -210,10 +214,11 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
         const int n_tab = (g + AHEAD < g1) ? S/2 : 0;
         const int e0 = tid;
         if (stage == 0 && fetch) {
-            if (e0 < n_ops)
-                staged = src_ops[e0 < D*D ? e0 : e0 + alpha0*D*D];
-            else if (e0 < n_ops + n_tab)
-                staged = src_tab[e0 - n_ops];
+            // (a thread without a share reads the first operand: a valid address, the value is not parked)
+            const cplx* src = e0 < n_ops ? src_ops + (e0 < D*D ? e0 : e0 + alpha0*D*D)
+                                         : (e0 < n_ops + n_tab ? src_tab + (e0 - n_ops) : src_ops);
+            staged_re = src->re;
+            staged_im = src->im;
         }
         if (!generate) return;
         const double dtg = st[0];
@@ -278,9 +283,9 @@ __global__ __launch_bounds__(NW*GS*64, FFK_ACCUM_WPE(D)) void ctrl_accumulate_ke
         cplx* dst_ops = tile + TILE;
         cplx* dst_tab = reinterpret_cast<cplx*>(tabs + next_slot*S);
         if (e0 < n_ops)
-            dst_ops[e0] = staged;
+            dst_ops[e0] = {staged_re, staged_im};
         else if (e0 < n_ops + n_tab)
-            dst_tab[e0 - n_ops] = staged;
+            dst_tab[e0 - n_ops] = {staged_re, staged_im};
         for (int e = e0 + nthreads; e < n_ops + n_tab; e += nthreads) {
             if (e < n_ops)
                 dst_ops[e] = src_ops[e < D*D ? e : e + alpha0*D*D];
