@@ -1027,11 +1027,90 @@ AccumGeometry accumulate_geometry(int W, int A, int G, int d, int forced_chunks)
     return geo;
 }
 
+namespace {
+// ---- padded dimensions (ffk_internal.h: padded_dimension) -------------------------------------------------------
+// One thread per complex number of the padded operands and table rows of a segment: T (+) 1, Bbar_a (+) 0; a table
+// record (dE, sin b, cos b) of an entry that involves an added level is that of a degenerate pair (0, 0, 1) -- Bbar is
+// zero there, the entry multiplies nothing.
+__global__ __launch_bounds__(256) void pad_operands_kernel(const double* __restrict__ segtab, const cplx* __restrict__ ops,
+                                                           int d, int p, int A, cplx* __restrict__ ops_p,
+                                                           double* __restrict__ segtab_p) {
+    const int g = blockIdx.x;
+    const int n_ops = (1 + A)*p*p, S = seg_stride(d), Sp = seg_stride(p);
+    const cplx* src = ops + static_cast<size_t>(g)*(1 + A)*d*d;
+    cplx* dst = ops_p + static_cast<size_t>(g)*n_ops;
+    for (int e = threadIdx.x; e < n_ops; e += 256) {
+        const int o = e/(p*p), i = (e/p) % p, j = e % p;
+        cplx v = {0.0, 0.0};
+        if (i < d && j < d) v = src[(o*d + i)*d + j];
+        else if (o == 0 && i == j) v = {1.0, 0.0};
+        dst[e] = v;
+    }
+    const double* row = segtab + static_cast<size_t>(g)*S;
+    double* row_p = segtab_p + static_cast<size_t>(g)*Sp;
+    for (int e = threadIdx.x; e < Sp; e += 256) {
+        double v = 0.0;
+        if (e < 4) {
+            v = row[e];
+        } else if (e < 4 + 4*p*p) {
+            const int rec = (e - 4)/4, k = (e - 4) % 4, m = rec/p, n = rec % p;
+            if (m < d && n < d) v = row[seg_rec(m*d + n) + k];
+            else v = k == 2 ? 1.0 : 0.0;
+        }
+        row_p[e] = v;
+    }
+}
+// Y (chunks, A, d, d, W) <- the d x d blocks of Y' (chunks', A, p, p, W); the planes of chunks the padded launch did
+// not use (it chooses its own, at most the caller's) are zeros
+__global__ __launch_bounds__(256) void unpad_partial_sums_kernel(const cplx* __restrict__ Yp, int d, int p, int W,
+                                                                 int planes_used, cplx* __restrict__ Y) {
+    const int w = blockIdx.x*256 + threadIdx.x;
+    if (w >= W) return;
+    const int e = blockIdx.y, ca = blockIdx.z, i = e/d, j = e % d;
+    cplx v = {0.0, 0.0};
+    if (ca < planes_used) v = Yp[(static_cast<size_t>(ca)*p*p + i*p + j)*W + w];
+    Y[(static_cast<size_t>(ca)*d*d + e)*W + w] = v;
+}
+}  // namespace
+
 hipError_t launch_accumulate(const double* omega, int W, const double* segtab, const cplx* ops,
                              int G, int d, int A, const AccumGeometry& geo, cplx* Ypart,
                              hipStream_t stream, const ExpandEpilogue* expand, bool* expanded,
                              const cplx* wfold) {
     if (expanded) *expanded = false;
+    // A dimension between the specialised kernels, with scratch for it (the callers that size their workspace by
+    // wfold_elems): padded to the next one.  The chunks are those of this dimension's own geometry -- the partial
+    // sums the caller reads keep their shape.
+    const int p = padded_dimension(d);
+    // (small problems lose to the dimension's own kernel -- d = 7: 100 segments x 2 operators x 1000 frequencies 115
+    // against 95 us, d = 11: 20 x 2 x 200 61 against 54 us; d = 13-15 gain at every size tried: profiles/r06_p_*)
+    const double work = static_cast<double>(G)*W*A;
+    const bool worth_it = d == 7 ? work >= 1.0e6 : (d == 11 ? work >= 5.0e4 : true);
+    if (p != 0 && worth_it && wfold != nullptr && !geo.generic && g_use_gsplit && !g_use_wave_kernel &&
+        static_cast<long>(geo.chunks)*A <= 65535 && std::getenv("FFK_NO_PADDED_DIMENSIONS") == nullptr) {
+        // (the padded kernel runs the caller's segment chunks: its own choice, where smaller, measured level or worse)
+        const int chunk_len = geo.chunk_len, used = geo.chunks;
+        cplx* scratch = const_cast<cplx*>(wfold);
+        cplx* ops_p = scratch;
+        double* segtab_p = reinterpret_cast<double*>(ops_p + static_cast<size_t>(G)*(1 + A)*p*p);
+        cplx* Yp = reinterpret_cast<cplx*>(segtab_p + static_cast<size_t>(G)*seg_stride(p));
+        cplx* fold8 = Yp + static_cast<size_t>(geo.chunks)*A*p*p*W;
+        hipLaunchKernelGGL(pad_operands_kernel, dim3(G), dim3(256), 0, stream, segtab, ops, d, p, A, ops_p, segtab_p);
+        hipError_t err = hipGetLastError();
+        if (err != hipSuccess) return err;
+        if (p == 8) {
+            err = launch_fold_w8(segtab_p, ops_p, G, A, fold8, stream);
+            if (err == hipSuccess)
+                err = launch_accumulate_pcr(omega, W, segtab_p, ops_p, G, p, A, used, chunk_len, Yp, fold8, stream);
+        } else {
+            err = launch_accumulate_mfma(omega, W, segtab_p, ops_p, G, p, A, used, chunk_len,
+                                         mfma_accumulate_waves(p, A), Yp, stream, nullptr, nullptr);
+        }
+        if (err != hipSuccess) return err;
+        hipLaunchKernelGGL(unpad_partial_sums_kernel, dim3((W + 255)/256, d*d, geo.chunks*A), dim3(256), 0, stream, Yp,
+                           d, p, W, used*A, Ypart);
+        return hipGetLastError();
+    }
     if (geo.generic)
         return launch_accumulate_generic(omega, W, segtab, ops, G, d, A, geo.chunks, geo.chunk_len, Ypart,
                                          stream);

@@ -119,7 +119,7 @@ size_t ctrl_ws_bytes(int W, int N, int A, int G, int d, int chunks) {
     b += align_up(sizeof(cplx)*size_t(chunks)*A*d*d*W);                   // Ypart
     b += align_up(sizeof(cplx)*size_t(A)*d*d*W);                          // Bt
     b += ffk::expand_workspace_bytes(N, d);                               // compacted basis
-    b += align_up(sizeof(cplx)*ffk::wfold_elems(d, G, A));                // folded W_a (d = 4, 8: ffk_internal.h wfold), LAST
+    b += align_up(sizeof(cplx)*ffk::wfold_elems(d, G, A, W, chunks));     // folded W_a / padded operands (ffk_internal.h wfold), LAST
     return b;
 }
 
@@ -476,8 +476,9 @@ int control_matrix_dev_impl(const double* eigvals, const double* eigvecs, const 
     void* ews = ws.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
     FFK_REQUIRE(Bt && ews, "workspace too small");
     // d = 4, 8: the prologue folds W_a once per segment for the accumulate kernel (handed to both launches)
-    cplx* wfold = ffk::wfold_elems(d, G, A) ? ws.take<cplx>(ffk::wfold_elems(d, G, A)) : nullptr;
-    FFK_REQUIRE(!ffk::wfold_elems(d, G, A) || wfold, "workspace too small");
+    const size_t n_fold = ffk::wfold_elems(d, G, A, W, geo.chunks);
+    cplx* wfold = n_fold ? ws.take<cplx>(n_fold) : nullptr;
+    FFK_REQUIRE(!n_fold || wfold, "workspace too small");
 
     if (!(flags & FFK_INTERNAL_PROLOGUE_DONE)) {
         FFK_HIP(ffk::launch_prologue(eigvals, reinterpret_cast<const cplx*>(eigvecs),
@@ -999,7 +1000,8 @@ int pipeline_dev_impl(const double* hamiltonian, const double* dt, const double*
         cw.take<cplx>(size_t(A)*d*d*W);                // Bt
         void* ews = cw.take<unsigned char>(ffk::expand_workspace_bytes(N, d));
         FFK_REQUIRE(ews, "workspace too small");
-        cplx* wfold = ffk::wfold_elems(d, G, A) ? cw.take<cplx>(ffk::wfold_elems(d, G, A)) : nullptr;
+        const size_t n_fold = ffk::wfold_elems(d, G, A, W, geo.chunks);
+        cplx* wfold = n_fold ? cw.take<cplx>(n_fold) : nullptr;
         FFK_HIP(ffk::launch_apply_prologue_compact(
             w.qloc, totals, G, d, reinterpret_cast<cplx*>(Q), D, reinterpret_cast<const cplx*>(V),
             reinterpret_cast<const cplx*>(n_opers), n_coeffs, dt, t, A, segtab, Tc, ops,

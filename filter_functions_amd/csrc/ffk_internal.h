@@ -115,7 +115,7 @@ hipError_t launch_prologue(const double* eigvals, const cplx* eigvecs, const cpl
                            cplx* ops, cplx* n_opers_transformed, cplx* eigvecs_propagated,
                            hipStream_t stream, cplx* wfold = nullptr);
 // wfold (d = 4 and d = 8, may be NULL): the frequency-independent operand of the accumulate kernel's first product per
-// (segment, operator), in the order the kernel's tile holds it, wfold_elems(d, G, A) complex numbers in all -- d = 4:
+// (segment, operator), in the order the kernel's tile holds it, wfold_elems(d, G, A, W, chunks) complex numbers in all -- d = 4:
 // W_a[n][m][j] = Bbar_a[m][n] e^{i b_mn} T[n][j] (64 per segment and operator); d = 8: W'_a[m][n][i] = Bbar_a[m][n]
 // e^{i b_mn} conj(T[m][i]) (512, ctrl_pcr.hip).  It
 // does not depend on the frequency: a caller that owns a buffer for it (ffk_control_matrix_dev, ffk_pipeline_dev)
@@ -213,8 +213,23 @@ struct PqGroups {
     int n3, n2, n1;     // blocks of three, two, one operator(s): 3 n3 + 2 n2 + n1 = A, one launch per size
 };
 PqGroups pq_accumulate_groups(int A);
-constexpr size_t wfold_elems(int d, int G, int A) {
-    return d == 4 ? static_cast<size_t>(G)*A*64 : (d == 8 ? static_cast<size_t>(G)*A*512 : 0);
+// Dimensions between the specialised kernels run PADDED with decoupled levels on the next specialised kernel
+// (7 -> 8: ctrl_pcr.hip; 11 -> 12 and 13, 14, 15 -> 16: ctrl_mfma.hip): operands T (+) 1 and Bbar (+) 0, the
+// d x d block of Y copied out (ctrl.hip: launch_accumulate).  0: d is not padded (d = 5, 6, 9, 10 do not gain: d = 10 on the d = 12
+// kernel measured 577 against 517 us; profiles/r06_p_*).
+constexpr int padded_dimension(int d) {
+    return d == 7 ? 8 : (d == 11 ? 12 : ((d >= 13 && d <= 15) ? 16 : 0));
+}
+// Complex numbers of scratch the accumulate launch wants beside its operands (`wfold`): the folded operand of the
+// d = 4 / d = 8 kernels; for a padded dimension the padded operands, table rows and partial sums (and the d = 8
+// kernel's folded operand).
+constexpr size_t wfold_elems(int d, int G, int A, int W, int chunks) {
+    if (d == 4) return static_cast<size_t>(G)*A*64;
+    if (d == 8) return static_cast<size_t>(G)*A*512;
+    const int p = padded_dimension(d);
+    if (p == 0) return 0;
+    return static_cast<size_t>(G)*(1 + A)*p*p + static_cast<size_t>(G)*seg_stride(p)/2 +
+           static_cast<size_t>(chunks)*A*p*p*W + (p == 8 ? static_cast<size_t>(G)*A*512 : 0);
 }
 hipError_t launch_accumulate_pq(const double* omega, int W, const double* segtab, const cplx* ops,
                                 int G, int d, int A, int chunks, int chunk_len, cplx* Ypart,

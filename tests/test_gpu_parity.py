@@ -7,6 +7,7 @@ Tolerance contract (DESIGN.md "Numerics"): for a complex tensor T, max|T - T_ref
 tol * max|T_ref| with tol = 1e-10 as the acceptance bar of BASELINE.json; the assertions below
 use the much tighter values the implementation actually reaches so that regressions show.
 """
+import os
 import numpy as np
 import pytest
 
@@ -2605,6 +2606,54 @@ def test_d8_producer_consumer_kernel_ragged_shapes(G, A, W):
     finally:
         lib.ffk_set_segment_chunks(0)
         lib.ffk_set_accumulate_variant(0)
+
+
+@pytest.mark.parametrize('d,G,A,W', [(7, 64, 3, 5300), (7, 40, 1, 25001), (11, 24, 3, 700), (11, 9, 7, 1000),
+                                      (13, 5, 2, 33), (13, 20, 4, 300), (14, 12, 3, 129), (15, 1, 1, 17),
+                                      (15, 30, 5, 260)])
+def test_padded_dimensions(d, G, A, W):
+    """d = 7, 11, 13, 14, 15 on large enough problems run on the next specialised kernel (8: ctrl_pcr.hip, 12 / 16:
+    ctrl_mfma.hip) with decoupled levels added -- operands T (+) 1, Bbar (+) 0, the d x d block of Y copied out
+    (ctrl.hip: launch_accumulate, ffk_internal.h: padded_dimension).  Against the oracle, against the dimension's own
+    kernel (FFK_NO_PADDED_DIMENSIONS=1, read per call), with forced segment chunks, frequency counts that leave tiles
+    partly empty, omega = 0 and a frequency on a resonance.  Reference loop numeric.py:846-869."""
+    rng = np.random.default_rng(1000*d + G + A + W)
+    basis = ff.Basis.ggm(d)
+    c_opers = rng.standard_normal((3, d, d)) + 1j*rng.standard_normal((3, d, d))
+    c_opers = c_opers + c_opers.conj().transpose(0, 2, 1)
+    n_opers = rng.standard_normal((A, d, d)) + 1j*rng.standard_normal((A, d, d))
+    n_opers = n_opers + n_opers.conj().transpose(0, 2, 1)
+    H = np.einsum('ijk,il->ljk', c_opers, rng.standard_normal((3, G)))
+    dt = 0.5 + rng.random(G)
+    n_coeffs = rng.random((A, G)) + 0.5
+    omega = np.concatenate(([0.0], np.geomspace(1e-3, 50, W - 1)))
+    D, V, Q = numeric.diagonalize(H, dt)
+    omega[3] = D[0, 2] - D[0, 1]
+    lib = _lib.load()
+    R = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+    sub = slice(None) if W*G <= 40000 else np.r_[0:8, W//2:W//2 + 8, W - 8:W]
+    R_ref = orc.control_matrix_from_scratch(D, V, Q, omega[sub], np.asarray(basis), n_opers, n_coeffs, dt)
+    assert rel_err(R[..., sub], R_ref) < 1e-12
+    os.environ['FFK_NO_PADDED_DIMENSIONS'] = '1'
+    try:
+        R_own = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+    finally:
+        del os.environ['FFK_NO_PADDED_DIMENSIONS']
+    assert rel_err(R_own, R) < 1e-12
+    big = d != 7 or G*W*A >= 1e6
+    assert (not np.array_equal(R_own, R)) == big or G == 1       # the padded form ran exactly where it should
+    try:
+        for chunks in (1, 2, 3):
+            _lib.check(lib.ffk_set_segment_chunks(chunks))
+            R_c = numeric.calculate_control_matrix_from_scratch(D, V, Q, omega, basis, n_opers, n_coeffs, dt)
+            assert rel_err(R_c, R) < 1e-12, chunks
+    finally:
+        lib.ffk_set_segment_chunks(0)
+    # the Hilbert-space twin reads the same partial sums
+    if W <= 1000:
+        B = numeric.calculate_noise_operators_from_scratch(D, V, Q, omega, n_opers, n_coeffs, dt)
+        B_ref = orc.noise_operators_from_scratch(D, V, Q, omega, n_opers, n_coeffs, dt)
+        assert rel_err(B, B_ref) < 1e-12
 
 
 @pytest.mark.parametrize('G,A,W', [(1, 1, 1), (2, 3, 64), (7, 1, 70), (8, 2, 65), (9, 4, 130), (17, 7, 64), (100, 5, 300),
