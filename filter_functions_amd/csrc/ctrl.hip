@@ -1082,11 +1082,7 @@ hipError_t launch_accumulate(const double* omega, int W, const double* segtab, c
     // wfold_elems): padded to the next one.  The chunks are those of this dimension's own geometry -- the partial
     // sums the caller reads keep their shape.
     const int p = padded_dimension(d);
-    // (small problems lose to the dimension's own kernel -- d = 7: 100 segments x 2 operators x 1000 frequencies 115
-    // against 95 us, d = 11: 20 x 2 x 200 61 against 54 us; d = 13-15 gain at every size tried: profiles/r06_p_*)
-    const double work = static_cast<double>(G)*W*A;
-    const bool worth_it = d == 7 ? work >= 1.0e6 : (d == 11 ? work >= 5.0e4 : true);
-    if (p != 0 && worth_it && wfold != nullptr && !geo.generic && g_use_gsplit && !g_use_wave_kernel &&
+    if (p != 0 && padded_launch_pays(d, G, W, A) && wfold != nullptr && !geo.generic && g_use_gsplit && !g_use_wave_kernel &&
         static_cast<long>(geo.chunks)*A <= 65535 && std::getenv("FFK_NO_PADDED_DIMENSIONS") == nullptr) {
         // (the padded kernel runs the caller's segment chunks: its own choice, where smaller, measured level or worse)
         const int chunk_len = geo.chunk_len, used = geo.chunks;

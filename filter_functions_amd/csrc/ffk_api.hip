@@ -130,6 +130,10 @@ int max_chunks_for(int W, int A, int G, int d) {
 }
 
 double accumulate_flops(int W, int A, int G, int d) {
+    // a dimension that runs padded on the next specialised kernel executes that kernel's flops (ffk_internal.h:
+    // padded_dimension; the callers of this function are the ones that hand the launch its scratch)
+    if (ffk::padded_launch_pays(d, G, W, A) && std::getenv("FFK_NO_PADDED_DIMENSIONS") == nullptr)
+        return accumulate_flops(W, A, G, ffk::padded_dimension(d));
     // FMA-counted real flops the accumulate kernels EXECUTE per (segment, frequency)
     // (DESIGN.md section 3).
     // d = 4: the tile per group of <= 3 operators: 13 entries x 10 (x, addition theorem 3, reciprocal 5, product

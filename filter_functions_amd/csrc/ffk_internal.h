@@ -220,6 +220,12 @@ PqGroups pq_accumulate_groups(int A);
 constexpr int padded_dimension(int d) {
     return d == 7 ? 8 : (d == 11 ? 12 : ((d >= 13 && d <= 15) ? 16 : 0));
 }
+// (small problems lose to the dimension's own kernel -- d = 7: 100 segments x 2 operators x 1000 frequencies 115
+// against 95 us, d = 11: 20 x 2 x 200 61 against 54 us; d = 13-15 gain at every size tried: profiles/r06_p_*)
+inline bool padded_launch_pays(int d, int G, int W, int A) {
+    const double work = static_cast<double>(G)*W*A;
+    return padded_dimension(d) != 0 && (d == 7 ? work >= 1.0e6 : (d == 11 ? work >= 5.0e4 : true));
+}
 // Complex numbers of scratch the accumulate launch wants beside its operands (`wfold`): the folded operand of the
 // d = 4 / d = 8 kernels; for a padded dimension the padded operands, table rows and partial sums (and the d = 8
 // kernel's folded operand).
