@@ -349,6 +349,9 @@ def bench_other_dimensions(ff, torch, lib, _lib, DevicePipeline, device, stream)
     shapes = [dict(d=2, G=256, A=3, W=4096, basis='GGM(2)', seed=52, kernel='ffk::ctrl_accumulate_d2_kernel<3> (ctrl_d2.hip)'),
               dict(d=3, G=256, A=3, W=4096, basis='GGM(3)', seed=53, kernel='ffk::ctrl_accumulate_kernel<3> (ctrl.hip)'),
               dict(d=6, G=250, A=6, W=400, basis='GGM(6)', seed=56, kernel='ffk::ctrl_accumulate_kernel<6> (ctrl.hip)'),
+              dict(d=7, G=256, A=3, W=4096, basis='GGM(7)', seed=58,
+                   kernel='pad -> ffk::ctrl_accumulate_pcr_kernel<3, true> (d = 8) -> unpad (ctrl.hip: launch_accumulate; '
+                          'kernel_ms spans the four launches, the flops are the d = 8 kernel\'s)'),
               dict(d=2, G=4096, A=2, W=500, basis='GGM(2)', seed=57,
                    kernel='ffk::ctrl_accumulate_d2_kernel<2> (ctrl_d2.hip; until late round 6 the one-wave kernel of ctrl.hip)')]
     for sh in shapes:

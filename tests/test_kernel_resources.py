@@ -118,3 +118,25 @@ def test_matrix_core_accumulate_kernels_keep_their_occupancy(kernels):
         assert k8['.vgpr_count'] <= 128 and k8['.max_flat_workgroup_size'] == 1024, k8['.vgpr_count']
     k16 = _one(kernels, 'ctrl_accumulate_mfma4_kernelILi16ELi2ELi8ELb1E')      # the instantiation config 5 launches
     assert k16['.vgpr_count'] <= 256 and k16['.max_flat_workgroup_size'] == 512, k16['.vgpr_count']
+
+
+def test_hot_kernels_keep_nothing_in_private_memory(kernels):
+    """A value that the compiler keeps in scratch memory although nothing is spilled -- a struct assigned under a
+    lane-type branch, a struct copy held across a barrier -- turns every load that feeds it into `global_load;
+    s_waitcnt vmcnt(0); scratch_store`: the first build of the d = 2 kernel spent 4 us per segment that way, and the
+    general accumulate kernel and the prologue had the same pattern (profiles/r06_g_*, last sections).  The kernels of
+    the measured paths use no private memory at all (the d = 8 kernel: one spilled register pair outside its loops)."""
+    clean = [name for name in kernels
+             if any(f in name for f in ('ctrl_accumulate_d2_kernel', 'ctrl_accumulate_pq_kernelILi3ELb1E',
+                                        'decay_gemm_sym256_kernel', 'conjugate_basis_mfma_kernelILi16ELb1ELb1E',
+                                        'ctrl_accumulate_mfma4_kernelILi16ELi1ELi4ELb1ELi8E', 'expand_ff_kernel',
+                                        'eigh_expm_kernelILi4E', 'scan_local_kernelILi4E', 'infid_kernelILb0E'))]
+    clean += [name for name in kernels if 'apply_prologue_kernelILi' in name and 'ILi16E' not in name]
+    clean += [name for name in kernels if 'ctrl_accumulate_kernelILi' in name and
+              any('kernelILi%dE' % d in name for d in (2, 3, 6, 7, 9, 10, 11))]
+    assert len(clean) > 100, len(clean)
+    for name in clean:
+        assert kernels[name]['.private_segment_fixed_size'] == 0, (name, kernels[name]['.private_segment_fixed_size'])
+    k8 = _one(kernels, 'ctrl_accumulate_pcr_kernelILi3ELb1E')
+    assert k8['.private_segment_fixed_size'] <= 16 and k8['.vgpr_spill_count'] <= 2
+
